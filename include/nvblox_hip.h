@@ -1,0 +1,196 @@
+/*
+ * nvblox_hip.h -- C-ABI of libnvblox_hip.so, the MI355X (gfx950) implementation of the nvblox_core hot path
+ * that isaac_ros_nvblox reaches through nvblox::MultiMapper / nvblox::Mapper / nvblox::EsdfSlicer.
+ *
+ * Every entry point names the reference call site it serves (paths relative to the reference root).  The C++ classes
+ * in include/nvblox/ are inline wrappers over these functions, so nvblox_ros links against this library unchanged at
+ * the call-expression level (INTEGRATION.md shows the CMake swap).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.  `*_dev` pointers are device (HBM) addresses on the mapper's
+ *     GPU, everything else is host memory.
+ *   - all work is enqueued on the mapper's stream (the reference is single-caller, stream-ordered:
+ *     nvblox_ros/src/lib/nvblox_node.cpp:99,456-459).  Functions that return host-visible results synchronise that
+ *     stream; the integrate / update calls do not.
+ *   - return value: 0 = ok, negative = error (NVBX_E_*).  Nothing throws across the boundary; device faults are
+ *     reported through nvbx_last_error().  (Reference convention: bool for I/O, CHECK/abort for programmer errors,
+ *     checkCudaErrors -> exit(99): nvblox_ros_common/src/check_cuda_errors.cpp:24-32.)
+ *   - transforms are row-major 4x4 float (T_L_C: camera -> layer/world), cameras are (fu,fv,cu,cv,width,height) as in
+ *     conversions/image_conversions.cpp:27-32.
+ *   - voxel blocks are 8x8x8, block copies use the reference's voxel structs and its linear order z + 8*y + 64*x
+ *     (nvblox_ros/src/lib/layer_publishing.cpp:335,501).
+ */
+#ifndef NVBLOX_HIP_H_
+#define NVBLOX_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVBX_OK 0
+#define NVBX_E_INVALID (-1)   /* bad argument */
+#define NVBX_E_DEVICE (-2)    /* HIP runtime error, see nvbx_last_error() */
+#define NVBX_E_CAPACITY (-3)  /* block pool / arena / window capacity exceeded */
+#define NVBX_E_NOTFOUND (-4)
+
+/* layer selectors (bit mask), mirrors the reference's LayerType usage in layer_publishing.cpp:675-826 */
+#define NVBX_LAYER_TSDF 1u
+#define NVBX_LAYER_COLOR 2u
+#define NVBX_LAYER_ESDF 4u
+#define NVBX_LAYER_MESH 8u
+
+typedef struct nvbx_mapper nvbx_mapper; /* replaces nvblox::Mapper (one per GPU / stream) */
+
+typedef struct { int32_t x, y, z; } nvbx_index3d;                      /* nvblox::Index3D */
+typedef struct { float fu, fv, cu, cv; int32_t width, height; } nvbx_camera; /* nvblox::Camera */
+
+/* Voxel structs as the reference's consumers read them. */
+typedef struct { float distance, weight; } nvbx_tsdf_voxel;            /* layer_publishing.cpp:111,179 */
+typedef struct { uint8_t r, g, b, pad; float weight; } nvbx_color_voxel; /* layer_publishing.cpp:62-76; Color = 3 x u8 */
+typedef struct {                                                        /* esdf_and_gradients_conversions.cu:33-44 */
+  float squared_distance_vox; int32_t parent_direction[3]; uint8_t is_inside, observed, is_site, pad;
+} nvbx_esdf_voxel;
+
+/* WeightingFunctionType, nvblox_ros/src/lib/mapper_initialization.cpp:31-42 */
+enum {
+  NVBX_WEIGHT_CONSTANT = 0, NVBX_WEIGHT_CONSTANT_DROPOFF = 1, NVBX_WEIGHT_INVERSE_SQUARE = 2,
+  NVBX_WEIGHT_INVERSE_SQUARE_DROPOFF = 3, NVBX_WEIGHT_INVERSE_SQUARE_TSDF_DISTANCE_PENALTY = 4,
+  NVBX_WEIGHT_LINEAR_WITH_MAX = 5
+};
+
+/* The MapperParams fields that reach this path (mapper_initialization.cpp:231-466, values fuser.yaml:24-42). */
+typedef struct {
+  float voxel_size;                       /* node param voxel_size, node_params.hpp:84 */
+  float max_integration_distance_m;       /* projective_integrator_max_integration_distance_m */
+  float truncation_distance_vox;          /* projective_integrator_truncation_distance_vox */
+  float max_weight;                       /* projective_integrator_max_weight */
+  int32_t weighting_mode;                 /* projective_integrator_weighting_mode */
+  int32_t raycast_subsampling_factor;     /* raycast_subsampling_factor */
+  float esdf_min_weight;                  /* esdf_integrator_min_weight */
+  float esdf_max_site_distance_vox;       /* esdf_integrator_max_site_distance_vox */
+  float esdf_max_distance_m;              /* esdf_integrator_max_distance_m */
+  float esdf_slice_height;                /* esdf_slice_height */
+  float esdf_slice_min_height;            /* esdf_slice_min_height */
+  float esdf_slice_max_height;            /* esdf_slice_max_height */
+  float mesh_min_weight;                  /* mesh_integrator_min_weight */
+  int32_t mesh_weld_vertices;             /* mesh_integrator_weld_vertices */
+  int32_t sphere_tracing_subsampling;     /* colour integrator synthetic-depth subsampling (4) */
+  int32_t sphere_tracing_max_steps;       /* 100 */
+  float sphere_tracing_max_ray_length_m;  /* 15 */
+  float sphere_tracing_surface_eps_vox;   /* 0.1 */
+  float tsdf_decay_factor;                /* tsdf_decay_factor */
+  float tsdf_decayed_weight_threshold;    /* tsdf_decayed_weight_threshold */
+  int32_t esdf_site_rule;                 /* 0: inside && |d| <= max_site_distance (default); 1: |d| <= max_site_distance */
+  int32_t depth_interp_nearest;           /* 0: bilinear with validity (default); 1: nearest */
+} nvbx_mapper_params;
+
+/* Per-frame work counters (bench.py turns them into algorithmic bytes). */
+typedef struct {
+  int64_t blocks_allocated;     /* live hash entries */
+  int64_t tsdf_blocks_in_view;  /* N_v of the last integrateDepth */
+  int64_t color_blocks_updated; /* N_c of the last integrateColor */
+  int64_t esdf_columns_marked;  /* N_u columns re-marked by the last updateEsdf */
+  int64_t esdf_blocks_swept;    /* N_e ESDF blocks rewritten by the last updateEsdf */
+  int64_t esdf_window_voxels;   /* voxels of the EDT working window (incl. halo) */
+  int64_t mesh_blocks_updated;  /* N_m of the last updateColorMesh */
+  int64_t mesh_vertices;        /* V written by the last updateColorMesh */
+  int64_t mesh_triangles;       /* T (triangles) written by the last updateColorMesh */
+  int64_t capacity_overflow;    /* != 0 if any pool / arena / window overflowed since creation */
+} nvbx_counters;
+
+/* ---- lifetime --------------------------------------------------------------------------------------------------
+ * nvblox::MultiMapper(voxel_size, MappingType, EsdfMode, MemoryType::kDevice, shared_ptr<CudaStream>)
+ *   nvblox_ros/src/lib/nvblox_node.cpp:187-190, fuser_node.cpp:85-89.  `hip_stream` may be NULL (library-owned stream).
+ * block_capacity = number of 8^3 blocks the HBM pools are sized for (3 x 4 KiB per block). */
+int nvbx_mapper_create(int device, void* hip_stream, const nvbx_mapper_params* params, int64_t block_capacity,
+                       nvbx_mapper** out);
+int nvbx_mapper_destroy(nvbx_mapper* m);
+/* MultiMapper::setMapperParams  -- nvblox_node.cpp:203, fuser_node.cpp:94 */
+int nvbx_mapper_set_params(nvbx_mapper* m, const nvbx_mapper_params* params);
+int nvbx_mapper_get_params(const nvbx_mapper* m, nvbx_mapper_params* out);
+/* CudaStream::synchronize -- conversions/esdf_slice_conversions.cu:107-108 */
+int nvbx_synchronize(nvbx_mapper* m);
+const char* nvbx_last_error(void);
+/* Mapper::clear / fresh map (load_map path re-creates the mapper: nvblox_node.cpp:1698-1703) */
+int nvbx_mapper_clear(nvbx_mapper* m);
+
+/* ---- integration (asynchronous on the mapper stream) --------------------------------------------------------------
+ * MultiMapper::integrateDepth(const DepthImage&, const Transform& T_L_C, const Camera&, Time) -- nvblox_node.cpp:1062 */
+int nvbx_integrate_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16],
+                         const nvbx_camera* camera);
+/* Same, depth given as uint16 millimetres: fuses conversions::depthImageFromNitrosViewAsync's DivideBy1000
+ * (conversions/image_conversions_thrust.cu:39-45,140-142) into the integrator's depth read. */
+int nvbx_integrate_depth_u16mm(nvbx_mapper* m, const uint16_t* depth_mm_dev, int32_t rows, int32_t cols,
+                               const float T_L_C[16], const nvbx_camera* camera);
+/* MultiMapper::integrateColor(const ColorImage&, const Transform&, const Camera&) -- nvblox_node.cpp:1264.
+ * rgb_dev: rows*cols*3 bytes, nvblox::Color order r,g,b (image_conversions.cpp:100-101). */
+int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16],
+                         const nvbx_camera* camera);
+/* MultiMapper::updateEsdf() (EsdfMode::k2D) -- nvblox_node.cpp:781 */
+int nvbx_update_esdf(nvbx_mapper* m);
+/* Mapper::updateColorMesh(UpdateFullLayer) -- layer_publishing.cpp:686-689, nvblox_node.cpp:1611 */
+int nvbx_update_color_mesh(nvbx_mapper* m, int32_t update_full_layer);
+/* Mapper::decayTsdfExcludeLastView<Camera>() / decayTsdf -- nvblox_node.cpp:931-936 */
+int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view);
+/* Mapper::clearOutsideRadius(center, radius) -- nvblox_node.cpp:1566-1583 */
+int nvbx_clear_outside_radius(nvbx_mapper* m, const float center[3], float radius);
+
+/* ---- ESDF slice (EsdfSlicer) ------------------------------------------------------------------------------------
+ * EsdfSlicer::sliceLayerToDistanceImage(esdf_layer, slice_height, unknown_value, &aabb, &Image<float>) --
+ * nvblox_node.cpp:836-844.  Two-step like Image<float> allocation: query the size, then fill a device image
+ * (row = y, col = x, row-major; origin aabb[0..2]; conversions/esdf_slice_conversions.cu:60-64). */
+int nvbx_esdf_slice_size(nvbx_mapper* m, int32_t* rows, int32_t* cols, float aabb_min_max[6]);
+int nvbx_esdf_slice_to_image(nvbx_mapper* m, float unknown_value, float* image_dev, int64_t capacity_elems,
+                             int32_t* rows, int32_t* cols, float aabb_min_max[6]);
+/* EsdfSliceConverter::distanceMapSliceMsgFromSliceImage's D2H (esdf_slice_conversions.cu:81-109) in one call. */
+int nvbx_esdf_slice_to_host(nvbx_mapper* m, float unknown_value, float* image_host, int64_t capacity_elems,
+                            int32_t* rows, int32_t* cols, float aabb_min_max[6]);
+/* EsdfSlicer::occupancyGridFromSliceImage(img, int8_t*, unknown) -- nvblox_node.cpp:917-919:
+ * 100 where distance <= 0 (inside), 0 where observed free, -1 where unknown. */
+int nvbx_occupancy_grid_from_slice(nvbx_mapper* m, const float* image_dev, int32_t rows, int32_t cols,
+                                   float unknown_value, int8_t* grid_dev);
+/* conversions::EsdfSliceConverter::pointcloudFromSliceImage kernel (esdf_slice_conversions.cu:33-73,138-159):
+ * compacts observed pixels to {x,y,z,intensity} float4; returns the count through *n_points (synchronises). */
+int nvbx_pointcloud_from_slice(nvbx_mapper* m, const float* image_dev, int32_t rows, int32_t cols,
+                               const float aabb_min_max[6], float slice_height, float unknown_value,
+                               float* points_xyzi_dev, int32_t* n_points);
+/* voxelLayerToDenseVoxelGridInAABBAsync<SignedDistanceFunctor> (esdf_and_gradients_conversions.cu:88-125):
+ * out[x*(Ny*Nz) + y*Nz + z] = signed metres or default_value; AABB given in global voxel indices. */
+int nvbx_esdf_dense_grid(nvbx_mapper* m, const int32_t min_vox[3], const int32_t size_vox[3], float default_value,
+                         float* grid_dev);
+
+/* ---- layer access (Layer<VoxelBlock> accessors; synchronise) ----------------------------------------------------
+ * layer.numAllocatedBlocks(), getAllBlockIndices(), getBlockAtIndex(), allocateBlockAtIndex(),
+ * callFunctionOnAllVoxels -- test_esdf_and_gradient_conversions.cpp:85-92,114,118 */
+int64_t nvbx_num_blocks(nvbx_mapper* m, uint32_t layer);
+int64_t nvbx_block_indices(nvbx_mapper* m, uint32_t layer, nvbx_index3d* out, int64_t capacity);
+int nvbx_get_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, void* voxels_out /* 512 reference structs */);
+int nvbx_set_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, const void* voxels_in);
+/* batched getBlockAtIndex: n blocks into voxels_out[n][512]; found_out[i] = 1 if block i exists (may be NULL) */
+int nvbx_get_blocks(nvbx_mapper* m, uint32_t layer, const nvbx_index3d* idx, int64_t n, void* voxels_out, int32_t* found_out);
+/* blocks touched by the last integrateDepth / integrateColor (what Mapper records as "blocks to update") */
+int64_t nvbx_last_depth_view(nvbx_mapper* m, nvbx_index3d* out, int64_t capacity);
+int64_t nvbx_last_color_view(nvbx_mapper* m, nvbx_index3d* out, int64_t capacity);
+int nvbx_get_synthetic_depth(nvbx_mapper* m, float* out_host, int64_t capacity, int32_t* rows, int32_t* cols);
+int nvbx_get_counters(nvbx_mapper* m, nvbx_counters* out);
+
+/* ---- mesh output (SerializedColorMeshLayer accessors, conversions/mesh_conversions.cpp:62-104) -------------------
+ * Flat arrays + per-block offsets for the blocks meshed by the last nvbx_update_color_mesh: vertices (x,y,z f32),
+ * normals (f32 x3), colours (rgba u8), triangle indices (int32, local to the block). */
+int nvbx_mesh_sizes(nvbx_mapper* m, int64_t* n_blocks, int64_t* n_vertices, int64_t* n_triangles);
+int nvbx_mesh_copy(nvbx_mapper* m, nvbx_index3d* block_indices, int32_t* vertex_offsets /* n_blocks+1 */,
+                   int32_t* triangle_offsets /* n_blocks+1 */, float* vertices, float* normals, uint8_t* colors,
+                   int32_t* triangles);
+
+/* ---- multi-GPU (one camera per GPU, all-gather of updated block indices before the ESDF sweep) -----
+ * Device-resident list of the TSDF blocks dirtied since the last updateEsdf: `indices_dev` -> int32[capacity][3],
+ * `count_dev` -> int32.  The caller all-gathers both over RCCL and feeds the union back with nvbx_mark_esdf_dirty. */
+int nvbx_esdf_dirty_list(nvbx_mapper* m, int32_t** indices_dev, int32_t** count_dev, int64_t* capacity);
+int nvbx_mark_esdf_dirty(nvbx_mapper* m, const int32_t* indices_dev, const int32_t* count_dev, int64_t max_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVBLOX_HIP_H_ */

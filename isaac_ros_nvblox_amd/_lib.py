@@ -1,0 +1,114 @@
+"""Loader of libnvblox_hip.so (the C-ABI in include/nvblox_hip.h).  Fails loudly: there is no CPU fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnvblox_hip.so")
+
+
+class Params(C.Structure):
+    """nvbx_mapper_params (include/nvblox_hip.h); field names = the reference's ROS parameter names
+    (nvblox_ros/src/lib/mapper_initialization.cpp:231-466) without the integrator prefixes."""
+    _fields_ = [
+        ("voxel_size", C.c_float),
+        ("max_integration_distance_m", C.c_float),
+        ("truncation_distance_vox", C.c_float),
+        ("max_weight", C.c_float),
+        ("weighting_mode", C.c_int32),
+        ("raycast_subsampling_factor", C.c_int32),
+        ("esdf_min_weight", C.c_float),
+        ("esdf_max_site_distance_vox", C.c_float),
+        ("esdf_max_distance_m", C.c_float),
+        ("esdf_slice_height", C.c_float),
+        ("esdf_slice_min_height", C.c_float),
+        ("esdf_slice_max_height", C.c_float),
+        ("mesh_min_weight", C.c_float),
+        ("mesh_weld_vertices", C.c_int32),
+        ("sphere_tracing_subsampling", C.c_int32),
+        ("sphere_tracing_max_steps", C.c_int32),
+        ("sphere_tracing_max_ray_length_m", C.c_float),
+        ("sphere_tracing_surface_eps_vox", C.c_float),
+        ("tsdf_decay_factor", C.c_float),
+        ("tsdf_decayed_weight_threshold", C.c_float),
+        ("esdf_site_rule", C.c_int32),
+        ("depth_interp_nearest", C.c_int32),
+    ]
+
+
+class Camera(C.Structure):
+    _fields_ = [("fu", C.c_float), ("fv", C.c_float), ("cu", C.c_float), ("cv", C.c_float),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class Index3D(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("z", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "blocks_allocated", "tsdf_blocks_in_view", "color_blocks_updated", "esdf_columns_marked", "esdf_blocks_swept",
+        "esdf_window_voxels", "mesh_blocks_updated", "mesh_vertices", "mesh_triangles", "capacity_overflow")]
+
+
+# every symbol include/nvblox_hip.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_pi32 = C.POINTER(C.c_int32)
+SIGNATURES = {
+    "nvbx_mapper_create": (C.c_int, [C.c_int, _vp, C.POINTER(Params), _i64, C.POINTER(_vp)]),
+    "nvbx_mapper_destroy": (C.c_int, [_vp]),
+    "nvbx_mapper_set_params": (C.c_int, [_vp, C.POINTER(Params)]),
+    "nvbx_mapper_get_params": (C.c_int, [_vp, C.POINTER(Params)]),
+    "nvbx_synchronize": (C.c_int, [_vp]),
+    "nvbx_last_error": (C.c_char_p, []),
+    "nvbx_mapper_clear": (C.c_int, [_vp]),
+    "nvbx_integrate_depth": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera)]),
+    "nvbx_integrate_depth_u16mm": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera)]),
+    "nvbx_integrate_color": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera)]),
+    "nvbx_update_esdf": (C.c_int, [_vp]),
+    "nvbx_update_color_mesh": (C.c_int, [_vp, _i32]),
+    "nvbx_decay_tsdf": (C.c_int, [_vp, _i32]),
+    "nvbx_clear_outside_radius": (C.c_int, [_vp, _vp, _f]),
+    "nvbx_esdf_slice_size": (C.c_int, [_vp, _pi32, _pi32, _vp]),
+    "nvbx_esdf_slice_to_image": (C.c_int, [_vp, _f, _vp, _i64, _pi32, _pi32, _vp]),
+    "nvbx_esdf_slice_to_host": (C.c_int, [_vp, _f, _vp, _i64, _pi32, _pi32, _vp]),
+    "nvbx_occupancy_grid_from_slice": (C.c_int, [_vp, _vp, _i32, _i32, _f, _vp]),
+    "nvbx_pointcloud_from_slice": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _f, _f, _vp, _pi32]),
+    "nvbx_esdf_dense_grid": (C.c_int, [_vp, _vp, _vp, _f, _vp]),
+    "nvbx_num_blocks": (_i64, [_vp, C.c_uint32]),
+    "nvbx_block_indices": (_i64, [_vp, C.c_uint32, _vp, _i64]),
+    "nvbx_get_block": (C.c_int, [_vp, C.c_uint32, Index3D, _vp]),
+    "nvbx_set_block": (C.c_int, [_vp, C.c_uint32, Index3D, _vp]),
+    "nvbx_get_blocks": (C.c_int, [_vp, C.c_uint32, _vp, _i64, _vp, _vp]),
+    "nvbx_last_depth_view": (_i64, [_vp, _vp, _i64]),
+    "nvbx_last_color_view": (_i64, [_vp, _vp, _i64]),
+    "nvbx_get_synthetic_depth": (C.c_int, [_vp, _vp, _i64, _pi32, _pi32]),
+    "nvbx_get_counters": (C.c_int, [_vp, C.POINTER(Counters)]),
+    "nvbx_mesh_sizes": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "nvbx_mesh_copy": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "nvbx_esdf_dirty_list": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i64)]),
+    "nvbx_mark_esdf_dirty": (C.c_int, [_vp, _vp, _vp, _i64]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library.  torch is imported first so that both share ONE libamdhip64.so.7 (same SONAME)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libnvblox_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C isaac_ros_nvblox_amd/csrc`. There is no CPU fallback for the product path." % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (loads torch's bundled HIP runtime first)
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here == header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,378 @@
+// esdf.hip -- MultiMapper::updateEsdf (EsdfMode::k2D) + EsdfSlicer on MI355X.
+//
+// The 2-D ESDF slice is an exact Euclidean distance transform with a cut-off radius R = esdf_max_distance_m / voxel
+// (the reference's sweep/propagate loop iterates towards the same field; DESIGN.md "ESDF semantics").  The plane of one
+// 8x8x8 ESDF block is exactly one wavefront (64 lanes, lane = x + 8y), stored as one contiguous 512-B line.
+// Per update, four launches, all sizes decided on the device (no host read-back):
+//   k_esdf_mark    one wave per dirty TSDF block: insert the ESDF block (x, y, z_slice), de-duplicate columns with an
+//                  epoch stamp, scan the TSDF z-band (each lane owns one (x,y) column = 64 contiguous bytes per TSDF
+//                  block) -> observed / inside / site flags; grows the dirty window with atomicMin/Max.
+//   k_esdf_bitmap  one wave per block cell of the window (+2R halo): __ballot of the site flags = 8 bytes of a
+//                  row-major 1-bit-per-voxel site bitmap.
+//   k_esdf_rows    per voxel: nearest site along x within R by clz/ctz on 64-bit words of the bitmap -> int8 dx.
+//   k_esdf_cols    one wave per ESDF block of the window (+R): stage the 8 x (8+2R) dx strip in LDS, minimise
+//                  dy^2 + dx^2 over dy, write {sq, parent, flags} back as one 8-byte store per lane.
+// Call sites served: nvblox_ros/src/lib/nvblox_node.cpp:781 (updateEsdf), :836-844 (sliceLayerToDistanceImage),
+// :917-919 (occupancyGridFromSliceImage); conversions/esdf_slice_conversions.cu:33-73; esdf_and_gradients_conversions.cu:88-125.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "nvbx_mapper.h"
+
+using namespace nvbx;
+
+constexpr int8_t DX_NONE = 127;
+
+__global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a, const int32_t* dirty) {
+  const int32_t n = m.counters[C_ESDF_DIRTY];
+  const int lane = threadIdx.x;
+  const int vx = lane & 7, vy = lane >> 3;
+  for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const uint32_t tslot = (uint32_t)dirty[i];
+    const uint32_t tflags = m.slot_flags[tslot];
+    if (lane == 0) atomicAnd(&m.slot_flags[tslot], ~F_DIRTY_ESDF);
+    const int32_t bx = m.slot_index[3 * tslot], by = m.slot_index[3 * tslot + 1], bz = m.slot_index[3 * tslot + 2];
+    // a dirty TSDF block of the z band dirties its column; a block that lost its TSDF (decay) only re-marks an
+    // existing column
+    if (bz < a.bz_lo || bz > a.bz_hi) continue;
+    if (!(tflags & F_TSDF) && !slot_ok(find_slot(m, bx, by, a.bz_out, F_ESDF))) continue;
+    uint32_t eslot = SLOT_NONE; int first = 0;
+    if (lane == 0) {
+      bool is_new;
+      const int32_t h = hash_insert(m, bx, by, a.bz_out, F_ESDF, &is_new);
+      if (h >= 0) {
+        do { eslot = ld_slot_acquire(&m.table[h]); } while (eslot == SLOT_INVALID);
+        if (slot_ok(eslot)) {
+          atomicOr(&m.slot_flags[eslot], F_ESDF);
+          first = atomicExch(&m.slot_stamp[eslot], a.epoch) != a.epoch;
+          if (first) {
+            atomicMin(&m.counters[a.rec + 0], bx); atomicMin(&m.counters[a.rec + 1], by);
+            atomicMax(&m.counters[a.rec + 2], bx); atomicMax(&m.counters[a.rec + 3], by);
+            atomicMin(&m.counters[C_ESDF_AABB + 0], bx); atomicMin(&m.counters[C_ESDF_AABB + 1], by);
+            atomicMax(&m.counters[C_ESDF_AABB + 2], bx); atomicMax(&m.counters[C_ESDF_AABB + 3], by);
+            atomicAdd(&m.counters[a.rec + 4], 1);
+          }
+        }
+      }
+    }
+    eslot = __shfl(eslot, 0); first = __shfl(first, 0);
+    if (!first || !slot_ok(eslot)) continue;
+    int observed = 0, inside = 0, site = 0;
+    for (int32_t bzz = a.bz_lo; bzz <= a.bz_hi; ++bzz) {
+      const uint32_t ts = find_slot(m, bx, by, bzz, F_TSDF);
+      if (!slot_ok(ts)) continue;
+      // this lane's column: voxels z = 0..7 at linear index 64*vx + 8*vy + z  -> 64 contiguous bytes
+      const float4* col = reinterpret_cast<const float4*>(&m.tsdf[(size_t)ts * 512 + 64 * vx + 8 * vy]);
+      float dz[8], wz[8];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const float4 v = col[q]; dz[2 * q] = v.x; wz[2 * q] = v.y; dz[2 * q + 1] = v.z; wz[2 * q + 1] = v.w; }
+#pragma unroll
+      for (int z = 0; z < 8; z++) {
+        const int32_t kz = bzz * 8 + z;
+        if (kz < a.kz_min || kz > a.kz_max) continue;
+        if (wz[z] >= a.min_weight) {
+          observed = 1;
+          const int in = dz[z] <= 0.0f;
+          if (in) inside = 1;
+          if ((a.site_rule == 1 || in) && fabsf(dz[z]) <= a.site_dist_m) site = 1;
+        }
+      }
+    }
+    m.esdf[(size_t)eslot * 512 + a.vz_out * 64 + lane] = make_uint2(__float_as_uint(a.max_sq), esdf_meta(0, 0, 0, observed, inside, site));
+  }
+}
+
+// window geometry shared by the three EDT kernels, derived on device from the update record
+struct Win { int32_t gx0, gy0, gw, gh; int32_t wx0, wy0, ww, wh; int32_t stride; bool ok; };
+__device__ inline Win esdf_window(const DMap& m, const EsdfArgs& a) {
+  Win w;
+  const int32_t x0 = m.counters[a.rec + 0], y0 = m.counters[a.rec + 1], x1 = m.counters[a.rec + 2], y1 = m.counters[a.rec + 3];
+  w.ok = x0 <= x1 && y0 <= y1;
+  w.wx0 = x0 - a.rb; w.wy0 = y0 - a.rb; w.ww = x1 - x0 + 1 + 2 * a.rb; w.wh = y1 - y0 + 1 + 2 * a.rb;
+  w.gx0 = x0 - 2 * a.rb; w.gy0 = y0 - 2 * a.rb; w.gw = x1 - x0 + 1 + 4 * a.rb; w.gh = y1 - y0 + 1 + 4 * a.rb;
+  w.stride = 8 * (((w.gw + 7) >> 3) + 2);   // bytes per bitmap row: one zero u64 of padding on each side
+  if (w.ok) {
+    const int64_t need_bm = (int64_t)w.stride * w.gh * 8, need_rd = (int64_t)w.gw * 8 * w.gh * 8;
+    if (need_bm > a.bitmap_bytes || need_rd > a.rowdx_bytes) w.ok = false;
+  }
+  return w;
+}
+
+__global__ __launch_bounds__(64) void k_esdf_bitmap(DMap m, EsdfArgs a, uint8_t* bitmap) {
+  const Win w = esdf_window(m, a);
+  const int lane = threadIdx.x;
+  if (blockIdx.x == 0 && lane == 0) {
+    m.counters[C_ESDF_DIRTY] = 0;                                 // dirty list consumed by k_esdf_mark
+    m.counters[a.rec_next + 0] = INT32_MAX; m.counters[a.rec_next + 1] = INT32_MAX;
+    m.counters[a.rec_next + 2] = INT32_MIN; m.counters[a.rec_next + 3] = INT32_MIN;
+    m.counters[a.rec_next + 4] = 0; m.counters[a.rec_next + 5] = 0; m.counters[a.rec_next + 6] = 0;
+    if (w.ok) m.counters[a.rec + 6] = w.gw * 8 * w.gh * 8;
+    else if (m.counters[a.rec + 0] <= m.counters[a.rec + 2]) atomicExch(&m.counters[C_OVERFLOW], 1);
+  }
+  if (!w.ok) return;
+  const int32_t ncell = w.stride * w.gh;     // one cell per bitmap byte column per block row (padding cells included)
+  for (int32_t c = blockIdx.x; c < ncell; c += gridDim.x) {
+    const int32_t cy = c / w.stride, cb = c - cy * w.stride;      // block row, byte column
+    const int32_t cx = cb - 8;                                    // block column relative to gx0
+    uint32_t site = 0;
+    if (cx >= 0 && cx < w.gw) {
+      const uint32_t es = find_slot(m, w.gx0 + cx, w.gy0 + cy, a.bz_out, F_ESDF);
+      if (slot_ok(es)) site = m.esdf[(size_t)es * 512 + a.vz_out * 64 + lane].y & ESDF_SITE;
+    }
+    const u64 mask = __ballot(site != 0);
+    if (lane < 8) bitmap[(size_t)(cy * 8 + lane) * w.stride + cb] = (uint8_t)((mask >> (8 * lane)) & 0xFF);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_esdf_rows(DMap m, EsdfArgs a, const uint8_t* bitmap, int8_t* rowdx) {
+  const Win w = esdf_window(m, a);
+  if (!w.ok) return;
+  const int32_t W = w.gw * 8, H = w.gh * 8;
+  const int64_t n = (int64_t)W * H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t Y = (int32_t)(i / W), X = (int32_t)(i - (int64_t)Y * W);
+    const u64* row = reinterpret_cast<const u64*>(bitmap + (size_t)Y * w.stride);
+    const int wi = 1 + (X >> 6), b = X & 63;
+    const u64 cur = row[wi], prev = row[wi - 1], next = row[wi + 1];
+    const u64 left = (b == 63) ? cur : ((cur << (63 - b)) | (prev >> (b + 1)));   // bit 63 <-> x, bit 62 <-> x-1, ...
+    const u64 right = (b == 0) ? cur : ((cur >> b) | (next << (64 - b)));         // bit 0 <-> x, bit 1 <-> x+1, ...
+    const int dl = left ? __clzll((long long)left) : 64;
+    const int dr = right ? (__ffsll((long long)right) - 1) : 64;
+    int8_t v = DX_NONE;
+    if (dl <= dr) { if (dl <= a.ri) v = (int8_t)(-dl); }
+    else { if (dr <= a.ri) v = (int8_t)dr; }
+    rowdx[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_esdf_cols(DMap m, EsdfArgs a, const int8_t* rowdx) {
+  __shared__ int8_t strip[(8 + 2 * 63) * 8];
+  const Win w = esdf_window(m, a);
+  if (!w.ok) return;
+  const int lane = threadIdx.x;
+  const int vx = lane & 7, vy = lane >> 3;
+  const int32_t W = w.gw * 8;
+  const int32_t ncell = w.ww * w.wh;
+  const int rows = 8 + 2 * a.ri;
+  for (int32_t c = blockIdx.x; c < ncell; c += gridDim.x) {
+    const int32_t cy = c / w.ww, cx = c - cy * w.ww;
+    const int32_t bx = w.wx0 + cx, by = w.wy0 + cy;
+    const uint32_t es = find_slot(m, bx, by, a.bz_out, F_ESDF);
+    if (!slot_ok(es)) continue;          // wave-uniform
+    const int32_t X0 = (bx - w.gx0) * 8, Y0 = (by - w.gy0) * 8 - a.ri;   // strip origin in window voxels (always inside G)
+    __syncthreads();
+    for (int q = lane; q < rows * 8; q += 64) strip[q] = rowdx[(int64_t)(Y0 + (q >> 3)) * W + X0 + (q & 7)];
+    __syncthreads();
+    int32_t best = INT32_MAX, bdx = 0, bdy = 0;
+    for (int dy = -a.ri; dy <= a.ri; dy++) {
+      const int8_t dx = strip[(vy + a.ri + dy) * 8 + vx];
+      if (dx == DX_NONE) continue;
+      const int32_t sq = dy * dy + (int32_t)dx * dx;
+      if (sq < best) { best = sq; bdx = dx; bdy = dy; }
+    }
+    uint2* vp = &m.esdf[(size_t)es * 512 + a.vz_out * 64 + lane];
+    const uint32_t flags = vp->y & ESDF_FLAG_MASK;
+    if (best != INT32_MAX && (float)best <= a.max_sq)
+      *vp = make_uint2(__float_as_uint((float)best), (flags) | ((uint32_t)(uint8_t)(int8_t)bdx) | (((uint32_t)(uint8_t)(int8_t)bdy) << 8));
+    else
+      *vp = make_uint2(__float_as_uint(a.max_sq), flags);
+    if (lane == 0) atomicAdd(&m.counters[a.rec + 5], 1);
+  }
+}
+
+extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
+  if (!m) return NVBX_E_INVALID;
+  NVBX_HIP(hipSetDevice(m->device));
+  const EsdfArgs a = m->make_esdf_args();
+  if (m->p.esdf_max_distance_m / m->p.voxel_size >= 64.0f) { set_error("esdf_max_distance_m / voxel_size must be < 64 voxels"); return NVBX_E_INVALID; }
+  hipLaunchKernelGGL(k_esdf_mark, dim3(1024), dim3(64), 0, m->stream, m->d, a, m->esdf_dirty);
+  hipLaunchKernelGGL(k_esdf_bitmap, dim3(1024), dim3(64), 0, m->stream, m->d, a, m->bitmap);
+  hipLaunchKernelGGL(k_esdf_rows, dim3(1024), dim3(256), 0, m->stream, m->d, a, m->bitmap, m->rowdx);
+  hipLaunchKernelGGL(k_esdf_cols, dim3(2048), dim3(64), 0, m->stream, m->d, a, m->rowdx);
+  NVBX_HIP(hipGetLastError());
+  m->esdf_epoch++;
+  return NVBX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ slicer
+__global__ __launch_bounds__(64) void k_esdf_slice(DMap m, int32_t bz_out, int32_t vz_out, float voxel_size, float unknown, float* img,
+                                                   int32_t bx0, int32_t by0, int32_t nbx, int32_t nby) {
+  const int lane = threadIdx.x;
+  const int vx = lane & 7, vy = lane >> 3;
+  const int32_t cols = nbx * 8;
+  for (int32_t c = blockIdx.x; c < nbx * nby; c += gridDim.x) {
+    const int32_t cy = c / nbx, cx = c - cy * nbx;
+    const uint32_t es = find_slot(m, bx0 + cx, by0 + cy, bz_out, F_ESDF);
+    float v = unknown;
+    if (slot_ok(es)) {
+      const uint2 e = m.esdf[(size_t)es * 512 + vz_out * 64 + lane];
+      if (e.y & ESDF_OBSERVED) { v = sqrtf(__uint_as_float(e.x)) * voxel_size; if (e.y & ESDF_INSIDE) v = -v; }
+    }
+    img[(int64_t)(cy * 8 + vy) * cols + cx * 8 + vx] = v;
+  }
+}
+
+extern "C" int nvbx_esdf_slice_size(nvbx_mapper* m, int32_t* rows, int32_t* cols, float aabb[6]) {
+  if (!m || !rows || !cols) return NVBX_E_INVALID;
+  if (m->fetch_counters()) return NVBX_E_DEVICE;
+  const int32_t* c = m->h_counters + C_ESDF_AABB;
+  if (c[0] > c[2]) { *rows = 0; *cols = 0; return NVBX_OK; }
+  const EsdfArgs a = m->make_esdf_args();
+  const float bs = m->p.voxel_size * 8.0f;
+  *cols = (c[2] - c[0] + 1) * 8; *rows = (c[3] - c[1] + 1) * 8;
+  if (aabb) {
+    aabb[0] = (float)c[0] * bs; aabb[1] = (float)c[1] * bs; aabb[2] = (float)a.bz_out * bs;
+    aabb[3] = (float)(c[2] + 1) * bs; aabb[4] = (float)(c[3] + 1) * bs; aabb[5] = (float)(a.bz_out + 1) * bs;
+  }
+  return NVBX_OK;
+}
+
+extern "C" int nvbx_esdf_slice_to_image(nvbx_mapper* m, float unknown_value, float* image_dev, int64_t capacity_elems, int32_t* rows,
+                                        int32_t* cols, float aabb[6]) {
+  if (!m || !rows || !cols) return NVBX_E_INVALID;
+  int rc = nvbx_esdf_slice_size(m, rows, cols, aabb); if (rc) return rc;
+  if (*rows == 0) return NVBX_OK;
+  if (!image_dev || (int64_t)*rows * *cols > capacity_elems) { set_error("slice image capacity too small"); return NVBX_E_CAPACITY; }
+  const EsdfArgs a = m->make_esdf_args();
+  const int32_t* c = m->h_counters + C_ESDF_AABB;
+  const int32_t nbx = c[2] - c[0] + 1, nby = c[3] - c[1] + 1;
+  hipLaunchKernelGGL(k_esdf_slice, dim3(std::min(nbx * nby, 4096)), dim3(64), 0, m->stream, m->d, a.bz_out, a.vz_out, m->p.voxel_size,
+                     unknown_value, image_dev, c[0], c[1], nbx, nby);
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;
+}
+
+static int ensure_staging(nvbx_mapper* m, int64_t bytes) {
+  if (bytes <= m->staging_bytes) return NVBX_OK;
+  NVBX_HIP(hipStreamSynchronize(m->stream));
+  if (m->staging) NVBX_HIP(hipFree(m->staging));
+  m->staging = nullptr; m->staging_bytes = 0;
+  NVBX_HIP(hipMalloc(&m->staging, bytes));
+  m->staging_bytes = bytes;
+  return NVBX_OK;
+}
+
+extern "C" int nvbx_esdf_slice_to_host(nvbx_mapper* m, float unknown_value, float* image_host, int64_t capacity_elems, int32_t* rows,
+                                       int32_t* cols, float aabb[6]) {
+  if (!m || !rows || !cols) return NVBX_E_INVALID;
+  int rc = nvbx_esdf_slice_size(m, rows, cols, aabb); if (rc) return rc;
+  const int64_t n = (int64_t)*rows * *cols;
+  if (n == 0) return NVBX_OK;
+  if (!image_host || n > capacity_elems) { set_error("slice image capacity too small"); return NVBX_E_CAPACITY; }
+  rc = ensure_staging(m, n * 4); if (rc) return rc;
+  rc = nvbx_esdf_slice_to_image(m, unknown_value, (float*)m->staging, n, rows, cols, aabb); if (rc) return rc;
+  NVBX_HIP(hipMemcpyAsync(image_host, m->staging, n * 4, hipMemcpyDeviceToHost, m->stream));
+  NVBX_HIP(hipStreamSynchronize(m->stream));
+  return NVBX_OK;
+}
+
+__global__ void k_occupancy(const float* img, int64_t n, float unknown, int8_t* grid) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = img[i];
+    int8_t o = 0;
+    if (fabsf(v - unknown) < 1e-2f) o = -1; else if (v <= 0.0f) o = 100;
+    grid[i] = o;
+  }
+}
+extern "C" int nvbx_occupancy_grid_from_slice(nvbx_mapper* m, const float* image_dev, int32_t rows, int32_t cols, float unknown_value,
+                                              int8_t* grid_dev) {
+  if (!m || !image_dev || !grid_dev || rows <= 0 || cols <= 0) return NVBX_E_INVALID;
+  const int64_t n = (int64_t)rows * cols;
+  hipLaunchKernelGGL(k_occupancy, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, m->stream, image_dev, n, unknown_value, grid_dev);
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;
+}
+
+// conversions/esdf_slice_conversions.cu:33-73 restated for wave64: one wave per 8x8 pixel tile, one atomicAdd per
+// wave (ballot + popcount prefix) instead of one per pixel.
+__global__ __launch_bounds__(64) void k_slice_pointcloud(DMap m, const float* img, int32_t rows, int32_t cols, float ax, float ay,
+                                                         float slice_height, float voxel_size, float unknown, float4* out) {
+  const int lane = threadIdx.x;
+  const int tiles_x = (cols + 7) >> 3, tiles_y = (rows + 7) >> 3;
+  for (int32_t t = blockIdx.x; t < tiles_x * tiles_y; t += gridDim.x) {
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int r = ty * 8 + (lane >> 3), c = tx * 8 + (lane & 7);
+    bool keep = false; float v = 0.0f;
+    if (r < rows && c < cols) { v = img[(int64_t)r * cols + c]; keep = !(fabsf(v - unknown) < 1e-2f); }
+    const u64 mask = __ballot(keep);
+    int base = 0;
+    if (lane == 0 && mask) base = atomicAdd(&m.counters[C_TMP], (int)__popcll(mask));
+    base = __shfl(base, 0);
+    if (keep) {
+      const int off = (int)__popcll(mask & ((1ull << lane) - 1ull));
+      out[base + off] = make_float4(ax + voxel_size * (float)c, ay + voxel_size * (float)r, slice_height, v);
+    }
+  }
+}
+__global__ void k_zero_tmp2(DMap m) { m.counters[C_TMP] = 0; }
+
+extern "C" int nvbx_pointcloud_from_slice(nvbx_mapper* m, const float* image_dev, int32_t rows, int32_t cols, const float aabb[6],
+                                          float slice_height, float unknown_value, float* points_xyzi_dev, int32_t* n_points) {
+  if (!m || !image_dev || !aabb || !points_xyzi_dev || !n_points || rows <= 0 || cols <= 0) return NVBX_E_INVALID;
+  hipLaunchKernelGGL(k_zero_tmp2, dim3(1), dim3(1), 0, m->stream, m->d);
+  const int tiles = ((rows + 7) / 8) * ((cols + 7) / 8);
+  hipLaunchKernelGGL(k_slice_pointcloud, dim3(std::min(tiles, 4096)), dim3(64), 0, m->stream, m->d, image_dev, rows, cols, aabb[0], aabb[1],
+                     slice_height, m->p.voxel_size, unknown_value, (float4*)points_xyzi_dev);
+  if (m->fetch_counters()) return NVBX_E_DEVICE;
+  *n_points = m->h_counters[C_TMP];
+  return NVBX_OK;
+}
+
+// voxelLayerToDenseVoxelGridInAABBAsync<SignedDistanceFunctor> (esdf_and_gradients_conversions.cu:28-48,88-125)
+__global__ void k_esdf_dense(DMap m, int32_t mx, int32_t my, int32_t mz, int32_t sx, int32_t sy, int32_t sz, float voxel_size, float def, float* out) {
+  const int64_t n = (int64_t)sx * sy * sz;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t z = (int32_t)(i % sz), y = (int32_t)((i / sz) % sy), x = (int32_t)(i / ((int64_t)sz * sy));
+    const int32_t gx = mx + x, gy = my + y, gz = mz + z;
+    const uint32_t es = find_slot(m, gx >> 3, gy >> 3, gz >> 3, F_ESDF);
+    float v = def;
+    if (slot_ok(es)) {
+      const uint2 e = m.esdf[(size_t)es * 512 + (gx & 7) + 8 * (gy & 7) + 64 * (gz & 7)];
+      if (e.y & ESDF_OBSERVED) { v = sqrtf(__uint_as_float(e.x)) * voxel_size; if (e.y & ESDF_INSIDE) v = v * -1.0f; }
+    }
+    out[i] = v;
+  }
+}
+extern "C" int nvbx_esdf_dense_grid(nvbx_mapper* m, const int32_t min_vox[3], const int32_t size_vox[3], float default_value, float* grid_dev) {
+  if (!m || !min_vox || !size_vox || !grid_dev || size_vox[0] <= 0 || size_vox[1] <= 0 || size_vox[2] <= 0) return NVBX_E_INVALID;
+  const int64_t n = (int64_t)size_vox[0] * size_vox[1] * size_vox[2];
+  hipLaunchKernelGGL(k_esdf_dense, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, m->stream, m->d, min_vox[0], min_vox[1],
+                     min_vox[2], size_vox[0], size_vox[1], size_vox[2], m->p.voxel_size, default_value, grid_dev);
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ multi-GPU hooks
+__global__ void k_export_dirty(DMap m, const int32_t* dirty, int32_t* out_idx, int32_t* out_count) {
+  const int32_t n = m.counters[C_ESDF_DIRTY];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = n;
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int32_t s = dirty[i];
+    out_idx[3 * i] = m.slot_index[3 * s]; out_idx[3 * i + 1] = m.slot_index[3 * s + 1]; out_idx[3 * i + 2] = m.slot_index[3 * s + 2];
+  }
+}
+extern "C" int nvbx_esdf_dirty_list(nvbx_mapper* m, int32_t** indices_dev, int32_t** count_dev, int64_t* capacity) {
+  if (!m || !indices_dev || !count_dev) return NVBX_E_INVALID;
+  hipLaunchKernelGGL(k_export_dirty, dim3(64), dim3(256), 0, m->stream, m->d, m->esdf_dirty, m->export_idx, m->export_count);
+  NVBX_HIP(hipGetLastError());
+  *indices_dev = m->export_idx; *count_dev = m->export_count;
+  if (capacity) *capacity = m->capacity;
+  return NVBX_OK;
+}
+// Union step after the all-gather: blocks another GPU updated that exist locally as TSDF blocks become ESDF-dirty here.
+__global__ void k_import_dirty(DMap m, const int32_t* idx, const int32_t* count, int64_t max_count, int32_t* dirty) {
+  int64_t n = *count; if (n > max_count) n = max_count;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t s = find_slot(m, idx[3 * i], idx[3 * i + 1], idx[3 * i + 2], F_TSDF);
+    if (!slot_ok(s)) continue;
+    const uint32_t old = atomicOr(&m.slot_flags[s], F_DIRTY_ESDF);
+    if (!(old & F_DIRTY_ESDF)) dirty[atomicAdd(&m.counters[C_ESDF_DIRTY], 1)] = (int32_t)s;
+  }
+}
+extern "C" int nvbx_mark_esdf_dirty(nvbx_mapper* m, const int32_t* indices_dev, const int32_t* count_dev, int64_t max_count) {
+  if (!m || !indices_dev || !count_dev || max_count < 0) return NVBX_E_INVALID;
+  hipLaunchKernelGGL(k_import_dirty, dim3(64), dim3(256), 0, m->stream, m->d, indices_dev, count_dev, max_count, m->esdf_dirty);
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;
+}

@@ -1,0 +1,128 @@
+// maintenance.hip -- Mapper::decayTsdf / clearOutsideRadius on MI355X (device-side deallocation + hash rebuild).
+//
+// Deallocation never leaves tombstones: freed slots go back on the free stack (their 4 KiB blocks are zeroed by the
+// freeing workgroup, so a popped slot is always clean) and the hash table is rebuilt on the device from the live slots
+// (memset + one insert per live slot).  Call sites served: nvblox_ros/src/lib/nvblox_node.cpp:931-936 (decayTsdf...),
+// :1566-1583 (clearOutsideRadius); parameters nvblox_base.yaml:103-107.
+#include <algorithm>
+#include "nvbx_mapper.h"
+
+using namespace nvbx;
+
+constexpr uint32_t LAYER_MASK = F_TSDF | F_COLOR | F_ESDF | F_MESH;
+
+__device__ inline void free_slot(DMap& m, uint32_t slot) {   // one thread
+  const int32_t pos = atomicAdd(&m.counters[C_FREE_TOP], 1);
+  m.free_stack[pos] = slot;
+  atomicSub(&m.counters[C_LIVE], 1);
+}
+
+__global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, int32_t* esdf_dirty,
+                                               int32_t* mesh_dirty, int32_t mesh_cnt) {
+  __shared__ int s_alive;
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  const int tid = threadIdx.x;
+  for (int32_t slot = blockIdx.x; slot < hw; slot += gridDim.x) {
+    const uint32_t flags = m.slot_flags[slot];
+    if (!(flags & F_TSDF)) continue;
+    if (exclude_stamp && m.table[m.slot_entry[slot]].stamp == exclude_stamp) continue;
+    __syncthreads();
+    if (tid == 0) s_alive = 0;
+    __syncthreads();
+    float2 tv = m.tsdf[(size_t)slot * 512 + tid];
+    tv.y = tv.y * factor;
+    if (!(tv.y < thresh)) s_alive = 1;
+    __syncthreads();
+    const bool alive = s_alive != 0;
+    if (alive) {
+      m.tsdf[(size_t)slot * 512 + tid] = tv;
+    } else {
+      m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f);
+      m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
+    }
+    if (tid == 0) {
+      uint32_t old;
+      if (alive) old = atomicOr(&m.slot_flags[slot], F_DIRTY_ESDF | F_DIRTY_MESH);
+      else {
+        old = atomicOr(&m.slot_flags[slot], F_DIRTY_ESDF | F_DIRTY_MESH);
+        atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH));
+        if (!(flags & F_ESDF)) free_slot(m, (uint32_t)slot);
+      }
+      if (!(old & F_DIRTY_ESDF)) esdf_dirty[atomicAdd(&m.counters[C_ESDF_DIRTY], 1)] = slot;
+      if (!(old & F_DIRTY_MESH)) mesh_dirty[atomicAdd(&m.counters[mesh_cnt], 1)] = slot;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float cy, float cz, float r2, float bs) {
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  const int tid = threadIdx.x;
+  for (int32_t slot = blockIdx.x; slot < hw; slot += gridDim.x) {
+    const uint32_t flags = m.slot_flags[slot];
+    if (!(flags & LAYER_MASK)) continue;
+    const float dx = ((float)m.slot_index[3 * slot] * bs + bs * 0.5f) - cx;
+    const float dy = ((float)m.slot_index[3 * slot + 1] * bs + bs * 0.5f) - cy;
+    const float dz = ((float)m.slot_index[3 * slot + 2] * bs + bs * 0.5f) - cz;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    if (!(d2 > r2)) continue;
+    if (flags & F_TSDF) m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f);
+    if (flags & F_COLOR) m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
+    if (flags & F_ESDF) m.esdf[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
+    if (tid == 0) { atomicAnd(&m.slot_flags[slot], ~LAYER_MASK); free_slot(m, (uint32_t)slot); }
+  }
+}
+
+// rebuild: (1) remember each live slot's view stamp, (2) memset table, (3) re-insert live slots, recompute ESDF AABB
+__global__ void k_save_stamps(DMap m, uint32_t* tmp) {
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  for (int32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < hw; s += gridDim.x * blockDim.x)
+    tmp[s] = (m.slot_flags[s] & LAYER_MASK) ? m.table[m.slot_entry[s]].stamp : 0xFFFFFFFFu;
+  if (blockIdx.x == 0 && threadIdx.x < 4) m.counters[C_ESDF_AABB + threadIdx.x] = threadIdx.x < 2 ? INT32_MAX : INT32_MIN;
+}
+__global__ void k_reinsert(DMap m, const uint32_t* tmp) {
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  for (int32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < hw; s += gridDim.x * blockDim.x) {
+    const uint32_t flags = m.slot_flags[s];
+    if (!(flags & LAYER_MASK)) continue;
+    const int32_t x = m.slot_index[3 * s], y = m.slot_index[3 * s + 1], z = m.slot_index[3 * s + 2];
+    const u64 key = pack_key(x, y, z);
+    uint32_t h = index_hash(x, y, z) & m.mask;
+    for (;;) {
+      const u64 k = atomicCAS(&m.table[h].key, KEY_EMPTY, key);
+      if (k == KEY_EMPTY) break;
+      h = (h + 1) & m.mask;
+    }
+    m.table[h].slot = (uint32_t)s; m.table[h].stamp = tmp[s];
+    m.slot_entry[s] = h;
+    if (flags & F_ESDF) {
+      atomicMin(&m.counters[C_ESDF_AABB + 0], x); atomicMin(&m.counters[C_ESDF_AABB + 1], y);
+      atomicMax(&m.counters[C_ESDF_AABB + 2], x); atomicMax(&m.counters[C_ESDF_AABB + 3], y);
+    }
+  }
+}
+
+static int rebuild_table(nvbx_mapper* m) {
+  uint32_t* tmp = (uint32_t*)m->export_idx;   // capacity * 12 bytes scratch >= capacity * 4
+  hipLaunchKernelGGL(k_save_stamps, dim3(256), dim3(256), 0, m->stream, m->d, tmp);
+  NVBX_HIP(hipMemsetAsync(m->d.table, 0xFF, ((size_t)m->d.mask + 1) * sizeof(Entry), m->stream));
+  hipLaunchKernelGGL(k_reinsert, dim3(256), dim3(256), 0, m->stream, m->d, tmp);
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;
+}
+
+extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
+  if (!m) return NVBX_E_INVALID;
+  NVBX_HIP(hipSetDevice(m->device));
+  const int grid = (int)std::min<int64_t>(m->capacity, 2048);
+  hipLaunchKernelGGL(k_decay, dim3(grid), dim3(512), 0, m->stream, m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
+                     exclude_last_view ? m->last_view_frame : 0u, m->esdf_dirty, m->mesh_dirty_live(), m->mesh_dirty_counter());
+  return rebuild_table(m);
+}
+
+extern "C" int nvbx_clear_outside_radius(nvbx_mapper* m, const float center[3], float radius) {
+  if (!m || !center) return NVBX_E_INVALID;
+  NVBX_HIP(hipSetDevice(m->device));
+  const int grid = (int)std::min<int64_t>(m->capacity, 2048);
+  hipLaunchKernelGGL(k_clear_outside, dim3(grid), dim3(512), 0, m->stream, m->d, center[0], center[1], center[2], radius * radius, m->p.voxel_size * 8.0f);
+  return rebuild_table(m);
+}

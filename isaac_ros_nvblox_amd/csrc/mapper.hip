@@ -1,0 +1,375 @@
+// mapper.hip -- lifetime, parameters, layer accessors of libnvblox_hip.so (host code + small utility kernels).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include "nvbx_mapper.h"
+
+using namespace nvbx;
+
+namespace nvbx {
+static thread_local std::string g_err;
+void set_error(const char* what, hipError_t e) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+}
+void set_error(const char* what) { g_err = what; }
+}  // namespace nvbx
+
+extern "C" const char* nvbx_last_error(void) { return nvbx::g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------------ utility kernels
+__global__ void k_init_map(DMap m) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m.capacity) { m.free_stack[i] = m.capacity - 1 - i; m.slot_flags[i] = 0; m.slot_stamp[i] = 0xFFFFFFFFu; }
+  if (i < C_NUM) {
+    int32_t v = 0;
+    if (i == C_FREE_TOP) v = (int32_t)m.capacity;
+    const int r = (int)i - C_ESDF_UPD;
+    if (r >= 0 && r < 16) { const int k = r & 7; if (k < 2) v = INT32_MAX; else if (k < 4) v = INT32_MIN; }
+    const int a = (int)i - C_ESDF_AABB;
+    if (a >= 0 && a < 4) v = a < 2 ? INT32_MAX : INT32_MIN;
+    m.counters[i] = v;
+  }
+}
+
+// collect Index3D of every live slot carrying `layer` (order arbitrary; host sorts)
+__global__ void k_collect_indices(DMap m, uint32_t layer, int32_t* out, int32_t cap) {
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  for (int32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < hw; s += gridDim.x * blockDim.x) {
+    if (m.slot_flags[s] & layer) {
+      const int32_t p = atomicAdd(&m.counters[C_TMP], 1);
+      if (p < cap) { out[3 * p] = m.slot_index[3 * s]; out[3 * p + 1] = m.slot_index[3 * s + 1]; out[3 * p + 2] = m.slot_index[3 * s + 2]; }
+    }
+  }
+}
+__global__ void k_zero_tmp(DMap m) { m.counters[C_TMP] = 0; }
+
+// list (hash-entry ids or slots) -> Index3D
+__global__ void k_list_to_indices(DMap m, const int32_t* list, int32_t count_idx, int32_t is_entry, int32_t* out, int32_t cap) {
+  int32_t n = m.counters[count_idx]; if (n > cap) n = cap;
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    uint32_t s = (uint32_t)list[i];
+    if (is_entry) s = m.table[s].slot;
+    if (slot_ok(s) && m.slot_flags[s]) { out[3 * i] = m.slot_index[3 * s]; out[3 * i + 1] = m.slot_index[3 * s + 1]; out[3 * i + 2] = m.slot_index[3 * s + 2]; }
+    else { out[3 * i] = INT32_MIN; out[3 * i + 1] = INT32_MIN; out[3 * i + 2] = INT32_MIN; }
+  }
+}
+
+// gather n blocks of `layer` into a dense buffer in the REFERENCE voxel struct layout (z + 8y + 64x order).
+// found[i] = 1 if the block exists.  One 512-thread workgroup per block.
+__global__ __launch_bounds__(512) void k_gather_blocks(DMap m, uint32_t layer, const int32_t* idx, int32_t n, uint8_t* out, int32_t* found) {
+  const int i = blockIdx.x; if (i >= n) return;
+  const uint32_t s = find_slot(m, idx[3 * i], idx[3 * i + 1], idx[3 * i + 2], layer);
+  const int t = threadIdx.x;
+  if (t == 0) found[i] = slot_ok(s) ? 1 : 0;
+  if (!slot_ok(s)) return;
+  if (layer == F_TSDF) { reinterpret_cast<float2*>(out)[(size_t)i * 512 + t] = m.tsdf[(size_t)s * 512 + t]; }
+  else if (layer == F_COLOR) { reinterpret_cast<uint2*>(out)[(size_t)i * 512 + t] = m.color[(size_t)s * 512 + t]; }
+  else if (layer == F_ESDF) {
+    const int x = t >> 6, y = (t >> 3) & 7, z = t & 7;             // reference order
+    const uint2 v = m.esdf[(size_t)s * 512 + x + 8 * y + 64 * z];  // device order
+    nvbx_esdf_voxel o;
+    o.squared_distance_vox = __uint_as_float(v.x);
+    o.parent_direction[0] = (int8_t)(v.y & 0xFF); o.parent_direction[1] = (int8_t)((v.y >> 8) & 0xFF); o.parent_direction[2] = (int8_t)((v.y >> 16) & 0xFF);
+    o.observed = (v.y & ESDF_OBSERVED) ? 1 : 0; o.is_inside = (v.y & ESDF_INSIDE) ? 1 : 0; o.is_site = (v.y & ESDF_SITE) ? 1 : 0; o.pad = 0;
+    reinterpret_cast<nvbx_esdf_voxel*>(out)[(size_t)i * 512 + t] = o;
+  }
+}
+
+// allocateBlockAtIndex + whole-block write from reference structs
+__global__ __launch_bounds__(512) void k_scatter_block(DMap m, uint32_t layer, int32_t x, int32_t y, int32_t z, const uint8_t* in,
+                                                       int32_t* esdf_dirty, int32_t* mesh_dirty, int32_t mesh_cnt) {
+  __shared__ uint32_t s_slot;
+  const int t = threadIdx.x;
+  if (t == 0) {
+    bool is_new; const int32_t h = hash_insert(m, x, y, z, layer, &is_new);
+    uint32_t s = SLOT_NONE;
+    if (h >= 0) s = m.table[h].slot;
+    if (slot_ok(s)) {
+      uint32_t add = layer;
+      if (layer == F_TSDF) add |= F_DIRTY_ESDF | F_DIRTY_MESH;
+      const uint32_t old = atomicOr(&m.slot_flags[s], add);
+      if (layer == F_TSDF) {
+        if (!(old & F_DIRTY_ESDF)) esdf_dirty[atomicAdd(&m.counters[C_ESDF_DIRTY], 1)] = (int32_t)s;
+        if (!(old & F_DIRTY_MESH)) mesh_dirty[atomicAdd(&m.counters[mesh_cnt], 1)] = (int32_t)s;
+      }
+      if (layer == F_ESDF) {
+        atomicMin(&m.counters[C_ESDF_AABB + 0], x); atomicMin(&m.counters[C_ESDF_AABB + 1], y);
+        atomicMax(&m.counters[C_ESDF_AABB + 2], x); atomicMax(&m.counters[C_ESDF_AABB + 3], y);
+      }
+    }
+    s_slot = s;
+  }
+  __syncthreads();
+  const uint32_t s = s_slot;
+  if (!slot_ok(s)) return;
+  if (layer == F_TSDF) m.tsdf[(size_t)s * 512 + t] = reinterpret_cast<const float2*>(in)[t];
+  else if (layer == F_COLOR) m.color[(size_t)s * 512 + t] = reinterpret_cast<const uint2*>(in)[t];
+  else if (layer == F_ESDF) {
+    const int vx = t >> 6, vy = (t >> 3) & 7, vz = t & 7;
+    const nvbx_esdf_voxel v = reinterpret_cast<const nvbx_esdf_voxel*>(in)[t];
+    m.esdf[(size_t)s * 512 + vx + 8 * vy + 64 * vz] =
+        make_uint2(__float_as_uint(v.squared_distance_vox),
+                   esdf_meta(v.parent_direction[0], v.parent_direction[1], v.parent_direction[2], v.observed, v.is_inside, v.is_site));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host helpers
+static int alloc_all(nvbx_mapper* m) {
+  const int64_t cap = m->capacity;
+  uint64_t tsz = 1; while (tsz < (uint64_t)cap * 2) tsz <<= 1;
+  DMap& d = m->d;
+  d.capacity = (uint32_t)cap; d.mask = (uint32_t)(tsz - 1);
+  NVBX_HIP(hipMalloc(&d.table, tsz * sizeof(Entry)));
+  NVBX_HIP(hipMalloc(&d.free_stack, cap * 4));
+  NVBX_HIP(hipMalloc(&d.counters, C_NUM * 4));
+  NVBX_HIP(hipMalloc(&d.slot_flags, cap * 4));
+  NVBX_HIP(hipMalloc(&d.slot_index, cap * 12));
+  NVBX_HIP(hipMalloc(&d.slot_entry, cap * 4));
+  NVBX_HIP(hipMalloc(&d.slot_stamp, cap * 4));
+  NVBX_HIP(hipMalloc(&d.tsdf, cap * 4096));
+  NVBX_HIP(hipMalloc(&d.color, cap * 4096));
+  NVBX_HIP(hipMalloc(&d.esdf, cap * 4096));
+  NVBX_HIP(hipMalloc(&m->view_list, cap * 4));
+  NVBX_HIP(hipMalloc(&m->esdf_dirty, cap * 4));
+  NVBX_HIP(hipMalloc(&m->mesh_dirty, cap * 8));
+  NVBX_HIP(hipMalloc(&m->color_list, cap * 4));
+  NVBX_HIP(hipMalloc(&m->export_idx, cap * 12));
+  NVBX_HIP(hipMalloc(&m->export_count, 64));
+  // ESDF EDT window scratch: up to 4096 x 4096 voxels (+ halo) by default, grows with capacity
+  int64_t side = 4096; while (side * side < cap * 64 * 4 && side < 32768) side *= 2;
+  m->bitmap_bytes = (side / 8 + 16) * side; m->rowdx_bytes = side * side;
+  NVBX_HIP(hipMalloc(&m->bitmap, m->bitmap_bytes));
+  NVBX_HIP(hipMalloc(&m->rowdx, m->rowdx_bytes));
+  // mesh arena
+  m->mesh_vert_cap = std::min<int64_t>(cap * 192, 48ll << 20); m->mesh_tri_cap = m->mesh_vert_cap * 2;
+  NVBX_HIP(hipMalloc(&m->mesh_vert, m->mesh_vert_cap * 12));
+  NVBX_HIP(hipMalloc(&m->mesh_nrm, m->mesh_vert_cap * 12));
+  NVBX_HIP(hipMalloc(&m->mesh_col, m->mesh_vert_cap * 4));
+  NVBX_HIP(hipMalloc(&m->mesh_tri, m->mesh_tri_cap * 12));
+  NVBX_HIP(hipMalloc(&m->mesh_rec, cap * sizeof(MeshRecord)));
+  m->staging_bytes = 8 << 20;
+  NVBX_HIP(hipMalloc(&m->staging, m->staging_bytes));
+  NVBX_HIP(hipHostMalloc(&m->h_counters, C_NUM * 4));
+  return NVBX_OK;
+}
+
+static int reset_map(nvbx_mapper* m) {
+  DMap& d = m->d;
+  const int64_t cap = m->capacity;
+  NVBX_HIP(hipMemsetAsync(d.table, 0xFF, ((size_t)d.mask + 1) * sizeof(Entry), m->stream));
+  NVBX_HIP(hipMemsetAsync(d.tsdf, 0, cap * 4096, m->stream));
+  NVBX_HIP(hipMemsetAsync(d.color, 0, cap * 4096, m->stream));
+  NVBX_HIP(hipMemsetAsync(d.esdf, 0, cap * 4096, m->stream));
+  NVBX_HIP(hipMemsetAsync(m->export_count, 0, 64, m->stream));
+  const int64_t n = std::max<int64_t>(cap, C_NUM);
+  hipLaunchKernelGGL(k_init_map, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, d);
+  NVBX_HIP(hipGetLastError());
+  m->frame_id = 0; m->esdf_epoch = 0; m->mesh_epoch = 0; m->last_view_frame = 0; m->synth_rows = m->synth_cols = 0;
+  return NVBX_OK;
+}
+
+int nvbx_mapper::fetch_counters() {
+  NVBX_HIP(hipMemcpyAsync(h_counters, d.counters, C_NUM * 4, hipMemcpyDeviceToHost, stream));
+  NVBX_HIP(hipStreamSynchronize(stream));
+  return NVBX_OK;
+}
+
+// T_L_C row-major 4x4 -> forward and inverse rigid transforms, fixed evaluation order (matches oracle rt_from_T)
+Frame nvbx_mapper::make_frame(const float T[16], const nvbx_camera* cam, int32_t rows, int32_t cols, int32_t subsample) const {
+  Frame f{};
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) f.R_LC[3 * i + j] = T[4 * i + j]; f.t_LC[i] = T[4 * i + 3]; }
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) f.R_CL[3 * i + j] = f.R_LC[3 * j + i];
+  for (int i = 0; i < 3; i++) {
+    float s = f.R_CL[3 * i + 0] * f.t_LC[0];
+    s = s + f.R_CL[3 * i + 1] * f.t_LC[1];
+    s = s + f.R_CL[3 * i + 2] * f.t_LC[2];
+    f.t_CL[i] = -s;
+  }
+  f.fu = cam->fu; f.fv = cam->fv; f.cu = cam->cu; f.cv = cam->cv; f.w = cam->width; f.h = cam->height;
+  f.rows = rows; f.cols = cols;
+  f.voxel_size = p.voxel_size; f.block_size = p.voxel_size * 8.0f;
+  f.trunc = p.truncation_distance_vox * p.voxel_size;
+  f.max_dist = p.max_integration_distance_m; f.max_weight = p.max_weight;
+  f.weighting_mode = p.weighting_mode; f.interp_nearest = p.depth_interp_nearest;
+  f.subsample = subsample < 1 ? 1 : subsample;
+  f.n_ray_rows = 0; f.n_ray_cols = 0;
+  f.frame_id = frame_id;
+  return f;
+}
+
+EsdfArgs nvbx_mapper::make_esdf_args() const {
+  EsdfArgs c{};
+  const float vs = p.voxel_size;
+  c.kz_min = (int32_t)floorf(p.esdf_slice_min_height / vs);
+  c.kz_max = (int32_t)floorf(p.esdf_slice_max_height / vs);
+  c.kz_out = (int32_t)floorf(p.esdf_slice_height / vs);
+  c.bz_lo = c.kz_min >> 3; c.bz_hi = c.kz_max >> 3; c.bz_out = c.kz_out >> 3; c.vz_out = c.kz_out & 7;
+  const float r = p.esdf_max_distance_m / vs;
+  c.max_sq = r * r;
+  c.ri = (int32_t)floorf(r); if (c.ri > 63) c.ri = 63; if (c.ri < 1) c.ri = 1;
+  c.rb = (c.ri + 7) / 8;
+  c.site_dist_m = p.esdf_max_site_distance_vox * vs;
+  c.min_weight = p.esdf_min_weight; c.voxel_size = vs; c.site_rule = p.esdf_site_rule;
+  c.epoch = esdf_epoch;
+  c.rec = C_ESDF_UPD + 8 * (int)(esdf_epoch & 1); c.rec_next = C_ESDF_UPD + 8 * (int)((esdf_epoch + 1) & 1);
+  c.bitmap_bytes = bitmap_bytes; c.rowdx_bytes = rowdx_bytes;
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------------ C-ABI: lifetime
+extern "C" int nvbx_mapper_create(int device, void* hip_stream, const nvbx_mapper_params* params, int64_t block_capacity, nvbx_mapper** out) {
+  if (!params || !out || block_capacity < 64 || block_capacity > (1ll << 24) || !(params->voxel_size > 0.0f)) {
+    set_error("nvbx_mapper_create: invalid argument"); return NVBX_E_INVALID;
+  }
+  NVBX_HIP(hipSetDevice(device));
+  nvbx_mapper* m = new nvbx_mapper();
+  m->device = device; m->p = *params; m->capacity = block_capacity;
+  if (hip_stream) { m->stream = (hipStream_t)hip_stream; m->own_stream = false; }
+  else { hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking); if (e != hipSuccess) { set_error("hipStreamCreate", e); delete m; return NVBX_E_DEVICE; } m->own_stream = true; }
+  int rc = alloc_all(m); if (rc) { nvbx_mapper_destroy(m); return rc; }
+  rc = reset_map(m); if (rc) { nvbx_mapper_destroy(m); return rc; }
+  hipError_t e = hipStreamSynchronize(m->stream);
+  if (e != hipSuccess) { set_error("create sync", e); nvbx_mapper_destroy(m); return NVBX_E_DEVICE; }
+  *out = m;
+  return NVBX_OK;
+}
+
+extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
+  if (!m) return NVBX_OK;
+  hipSetDevice(m->device);
+  if (m->stream) hipStreamSynchronize(m->stream);
+  DMap& d = m->d;
+  void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.tsdf, d.color, d.esdf,
+                  m->view_list, m->esdf_dirty, m->mesh_dirty, m->color_list, m->export_idx, m->export_count, m->bitmap, m->rowdx,
+                  m->synth, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (m->h_counters) hipHostFree(m->h_counters);
+  if (m->own_stream && m->stream) hipStreamDestroy(m->stream);
+  delete m;
+  return NVBX_OK;
+}
+
+extern "C" int nvbx_mapper_set_params(nvbx_mapper* m, const nvbx_mapper_params* params) {
+  if (!m || !params) return NVBX_E_INVALID;
+  if (params->voxel_size != m->p.voxel_size) { set_error("voxel_size cannot change after creation"); return NVBX_E_INVALID; }
+  m->p = *params; return NVBX_OK;
+}
+extern "C" int nvbx_mapper_get_params(const nvbx_mapper* m, nvbx_mapper_params* out) {
+  if (!m || !out) return NVBX_E_INVALID;
+  *out = m->p; return NVBX_OK;
+}
+extern "C" int nvbx_synchronize(nvbx_mapper* m) {
+  if (!m) return NVBX_E_INVALID;
+  NVBX_HIP(hipStreamSynchronize(m->stream));
+  return NVBX_OK;
+}
+extern "C" int nvbx_mapper_clear(nvbx_mapper* m) {
+  if (!m) return NVBX_E_INVALID;
+  NVBX_HIP(hipSetDevice(m->device));
+  return reset_map(m);
+}
+
+// ------------------------------------------------------------------------------------------------ C-ABI: layer access
+static bool single_layer(uint32_t layer) { return layer == F_TSDF || layer == F_COLOR || layer == F_ESDF || layer == F_MESH; }
+
+static void sort_indices(nvbx_index3d* v, int64_t n) {
+  std::sort(v, v + n, [](const nvbx_index3d& a, const nvbx_index3d& b) {
+    if (a.x != b.x) return a.x < b.x; if (a.y != b.y) return a.y < b.y; return a.z < b.z; });
+}
+
+extern "C" int64_t nvbx_block_indices(nvbx_mapper* m, uint32_t layer, nvbx_index3d* out, int64_t capacity) {
+  if (!m || !single_layer(layer)) return NVBX_E_INVALID;
+  hipLaunchKernelGGL(k_zero_tmp, dim3(1), dim3(1), 0, m->stream, m->d);
+  hipLaunchKernelGGL(k_collect_indices, dim3(256), dim3(256), 0, m->stream, m->d, layer, m->export_idx, (int32_t)m->capacity);
+  if (m->fetch_counters()) return NVBX_E_DEVICE;
+  int64_t n = m->h_counters[C_TMP];
+  if (n > m->capacity) n = m->capacity;
+  const int64_t k = std::min<int64_t>(n, capacity);
+  if (out && k > 0) {
+    std::vector<nvbx_index3d> tmp((size_t)n);
+    NVBX_HIP(hipMemcpy(tmp.data(), m->export_idx, (size_t)n * 12, hipMemcpyDeviceToHost));
+    sort_indices(tmp.data(), n);
+    memcpy(out, tmp.data(), (size_t)k * 12);
+  }
+  return n;
+}
+extern "C" int64_t nvbx_num_blocks(nvbx_mapper* m, uint32_t layer) { return nvbx_block_indices(m, layer, nullptr, 0); }
+
+static int64_t list_indices(nvbx_mapper* m, const int32_t* list, int count_idx, int is_entry, nvbx_index3d* out, int64_t capacity) {
+  hipLaunchKernelGGL(k_list_to_indices, dim3(64), dim3(256), 0, m->stream, m->d, list, count_idx, is_entry, m->export_idx, (int32_t)m->capacity);
+  if (m->fetch_counters()) return NVBX_E_DEVICE;
+  int64_t n = m->h_counters[count_idx]; if (n > m->capacity) n = m->capacity;
+  const int64_t k = std::min<int64_t>(n, capacity);
+  if (out && k > 0) {
+    std::vector<nvbx_index3d> tmp((size_t)n);
+    NVBX_HIP(hipMemcpy(tmp.data(), m->export_idx, (size_t)n * 12, hipMemcpyDeviceToHost));
+    sort_indices(tmp.data(), n);
+    memcpy(out, tmp.data(), (size_t)k * 12);
+  }
+  return n;
+}
+extern "C" int64_t nvbx_last_depth_view(nvbx_mapper* m, nvbx_index3d* out, int64_t capacity) {
+  if (!m) return NVBX_E_INVALID;
+  if (m->last_view_frame == 0) return 0;
+  return list_indices(m, m->view_list, C_VIEW_COUNT + (int)(m->last_view_frame & 3), 0, out, capacity);
+}
+extern "C" int64_t nvbx_last_color_view(nvbx_mapper* m, nvbx_index3d* out, int64_t capacity) {
+  if (!m) return NVBX_E_INVALID;
+  return list_indices(m, m->color_list, C_COLOR_COUNT, 0, out, capacity);
+}
+
+static size_t ref_voxel_bytes(uint32_t layer) { return layer == F_ESDF ? sizeof(nvbx_esdf_voxel) : 8; }
+
+extern "C" int nvbx_get_blocks(nvbx_mapper* m, uint32_t layer, const nvbx_index3d* idx, int64_t n, void* voxels_out, int32_t* found_out) {
+  if (!m || !idx || !voxels_out || n < 0 || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF)) return NVBX_E_INVALID;
+  const size_t bb = 512 * ref_voxel_bytes(layer);
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)((m->staging_bytes - 65536) / (bb + 16)));
+  for (int64_t o = 0; o < n; o += chunk) {
+    const int64_t c = std::min(chunk, n - o);
+    int32_t* d_idx = (int32_t*)m->staging; int32_t* d_found = d_idx + 3 * c;
+    uint8_t* d_out = (uint8_t*)m->staging + (((size_t)c * 16 + 255) & ~(size_t)255);
+    NVBX_HIP(hipMemcpyAsync(d_idx, idx + o, (size_t)c * 12, hipMemcpyHostToDevice, m->stream));
+    hipLaunchKernelGGL(k_gather_blocks, dim3((unsigned)c), dim3(512), 0, m->stream, m->d, layer, d_idx, (int32_t)c, d_out, d_found);
+    NVBX_HIP(hipMemcpyAsync((uint8_t*)voxels_out + (size_t)o * bb, d_out, (size_t)c * bb, hipMemcpyDeviceToHost, m->stream));
+    if (found_out) NVBX_HIP(hipMemcpyAsync(found_out + o, d_found, (size_t)c * 4, hipMemcpyDeviceToHost, m->stream));
+    NVBX_HIP(hipStreamSynchronize(m->stream));
+  }
+  return NVBX_OK;
+}
+extern "C" int nvbx_get_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, void* voxels_out) {
+  int32_t found = 0;
+  const int rc = nvbx_get_blocks(m, layer, &idx, 1, voxels_out, &found);
+  if (rc) return rc;
+  return found ? NVBX_OK : NVBX_E_NOTFOUND;
+}
+extern "C" int nvbx_set_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, const void* voxels_in) {
+  if (!m || !voxels_in || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF)) return NVBX_E_INVALID;
+  const size_t bb = 512 * ref_voxel_bytes(layer);
+  NVBX_HIP(hipMemcpyAsync(m->staging, voxels_in, bb, hipMemcpyHostToDevice, m->stream));
+  hipLaunchKernelGGL(k_scatter_block, dim3(1), dim3(512), 0, m->stream, m->d, layer, idx.x, idx.y, idx.z, (const uint8_t*)m->staging,
+                     m->esdf_dirty, m->mesh_dirty_live(), m->mesh_dirty_counter());
+  NVBX_HIP(hipStreamSynchronize(m->stream));
+  return NVBX_OK;
+}
+
+extern "C" int nvbx_get_counters(nvbx_mapper* m, nvbx_counters* out) {
+  if (!m || !out) return NVBX_E_INVALID;
+  if (m->fetch_counters()) return NVBX_E_DEVICE;
+  const int32_t* c = m->h_counters;
+  memset(out, 0, sizeof(*out));
+  out->blocks_allocated = c[C_LIVE];
+  out->tsdf_blocks_in_view = m->last_view_frame ? c[C_VIEW_COUNT + (m->last_view_frame & 3)] : 0;
+  out->color_blocks_updated = c[C_COLOR_COUNT];
+  const int rec = C_ESDF_UPD + 8 * (int)((m->esdf_epoch + 1) & 1);   // record of the last finished update (epoch - 1)
+  out->esdf_columns_marked = m->esdf_epoch ? c[rec + 4] : 0;
+  out->esdf_blocks_swept = m->esdf_epoch ? c[rec + 5] : 0;
+  out->esdf_window_voxels = m->esdf_epoch ? c[rec + 6] : 0;
+  const int mrec = C_MESH_OUT + 4 * (int)((m->mesh_epoch + 1) & 1);   // record of the last finished mesh update
+  out->mesh_blocks_updated = m->mesh_epoch ? c[mrec + 0] : 0;
+  out->mesh_vertices = m->mesh_epoch ? c[mrec + 1] : 0;
+  out->mesh_triangles = m->mesh_epoch ? c[mrec + 2] : 0;
+  out->capacity_overflow = c[C_OVERFLOW];
+  return NVBX_OK;
+}

@@ -1,0 +1,284 @@
+// mesh.hip -- Mapper::updateColorMesh on MI355X: marching cubes, count + weld + emit fused in ONE launch.
+//
+// One 512-thread workgroup (8 wave64) per TSDF block.  The 9^3 corner lattice (own block + the +x/+y/+z neighbour
+// blocks, found by 8 hash probes) is staged in LDS once; thread = cube in z + 8y + 64x order.  Triangle offsets come
+// from a block-wide exclusive scan (wave shuffles + 8 partials), vertices are welded by construction: every vertex
+// lives on one lattice edge (corner, axis), `atomicMin` in LDS records the first triangle of each crossed edge, a
+// second scan over the 2187 possible edges numbers the vertices in ascending edge id.  A single returning atomicAdd per
+// block reserves space in the pre-allocated vertex / triangle arenas, so there is no count -> host -> alloc -> emit
+// round trip ([U] MeshIntegrator is two-pass with a host sync in between).
+// Ordering contract (shared with the oracle): vertices ascending edge id ((lx*9+ly)*9+lz)*3+axis; triangles in cube
+// order then table order; vertex normal = normal of the first triangle referencing it; colour = nearest colour voxel.
+// Call sites served: nvblox_ros/src/lib/layer_publishing.cpp:686-689, nvblox_node.cpp:1611; output contract
+// conversions/mesh_conversions.cpp:62-104.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+#include "nvbx_mapper.h"
+
+using namespace nvbx;
+
+__constant__ int8_t MC_TRI_C[256][16] = {
+#include "mc_table.inc"
+};
+__constant__ int8_t MC_EDGE_BASE_C[12][3] = {{0,0,0},{1,0,0},{0,1,0},{0,0,0},{0,0,1},{1,0,1},{0,1,1},{0,0,1},{0,0,0},{1,0,0},{1,1,0},{0,1,0}};
+__constant__ int8_t MC_EDGE_AXIS_C[12] = {0,1,0,1,0,1,0,1,2,2,2,2};
+
+constexpr int NLAT = 729, NEDGE = 2187, MAXTRI = 2560;
+
+struct MeshArgs {
+  float voxel_size, block_size, min_weight;
+  int32_t full;          // 1: every TSDF block, 0: dirty list
+  int32_t dirty_cnt;     // counter index of the live dirty list
+  int32_t next_cnt;      // counter index of the other parity's list (reset here)
+  int32_t rec, rec_next; // C_MESH_OUT records
+  int64_t vert_cap, tri_cap;
+};
+
+// exclusive scan over the 512 threads of the workgroup; returns this thread's offset, *total = sum
+__device__ inline int block_scan_512(int v, int* s_part, int tid, int* total) {
+  const int lane = tid & 63, wave = tid >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  __syncthreads();
+  if (lane == 63) s_part[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 8; w++) { const int p = s_part[w]; if (w < wave) base += p; tot += p; }
+  *total = tot;
+  return base + inc - v;
+}
+
+__device__ inline void edge_decode(int eid, int* li, int* lj, int* axis, int* lx, int* ly, int* lz) {
+  *axis = eid % 3; *li = eid / 3;
+  *lz = *li % 9; *ly = (*li / 9) % 9; *lx = *li / 81;
+  *lj = *li + (*axis == 0 ? 81 : (*axis == 1 ? 9 : 1));
+}
+
+__global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, const int32_t* dirty, float* o_vert, float* o_nrm, uint32_t* o_col,
+                                              int32_t* o_tri, MeshRecord* o_rec) {
+  __shared__ float s_d[NLAT];
+  __shared__ uint8_t s_valid[NLAT];
+  __shared__ int32_t s_first[NEDGE];
+  __shared__ int32_t s_vid[NEDGE];
+  __shared__ uint16_t s_tri_edges[MAXTRI * 3];
+  __shared__ uint32_t s_nslot[8];
+  __shared__ uint32_t s_nflags[8];
+  __shared__ int s_part[8];
+  __shared__ int s_base[3];
+  const int tid = threadIdx.x;
+  const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
+  if (blockIdx.x == 0 && tid == 0) {
+    m.counters[a.next_cnt] = 0;
+    m.counters[a.rec_next + 0] = 0; m.counters[a.rec_next + 1] = 0; m.counters[a.rec_next + 2] = 0;
+  }
+  const int32_t n = a.full ? m.counters[C_HIGH_WATER] : m.counters[a.dirty_cnt];
+  for (int32_t it = blockIdx.x; it < n; it += gridDim.x) {
+    const uint32_t slot = a.full ? (uint32_t)it : (uint32_t)dirty[it];
+    const uint32_t flags = m.slot_flags[slot];
+    if (!(flags & F_TSDF)) {                                             // uniform: block was deallocated meanwhile
+      if (tid == 0 && (flags & F_DIRTY_MESH)) atomicAnd(&m.slot_flags[slot], ~F_DIRTY_MESH);
+      continue;
+    }
+    const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
+    __syncthreads();                                                     // previous iteration done with LDS
+    if (tid < 8) {
+      const uint32_t ns = tid == 0 ? slot : find_slot(m, bx + (tid & 1), by + ((tid >> 1) & 1), bz + ((tid >> 2) & 1), F_TSDF);
+      s_nslot[tid] = ns;
+      s_nflags[tid] = slot_ok(ns) ? m.slot_flags[ns] : 0u;
+    }
+    if (tid == 0) { atomicAnd(&m.slot_flags[slot], ~F_DIRTY_MESH); atomicOr(&m.slot_flags[slot], F_MESH); }
+    for (int e = tid; e < NEDGE; e += 512) s_first[e] = INT32_MAX;
+    __syncthreads();
+    for (int li = tid; li < NLAT; li += 512) {
+      const int lz = li % 9, ly = (li / 9) % 9, lx = li / 81;
+      const uint32_t ns = s_nslot[(lx >> 3) | ((ly >> 3) << 1) | ((lz >> 3) << 2)];
+      float d = 0.0f; uint8_t ok = 0;
+      if (slot_ok(ns)) { const float2 tv = m.tsdf[(size_t)ns * 512 + (lz & 7) + 8 * (ly & 7) + 64 * (lx & 7)]; d = tv.x; ok = tv.y >= a.min_weight ? 1 : 0; }
+      s_d[li] = d; s_valid[li] = ok;
+    }
+    __syncthreads();
+    // cube classification
+    int cube = 0; bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const int cx = (c == 1 || c == 2 || c == 5 || c == 6) ? 1 : 0, cy = (c == 2 || c == 3 || c == 6 || c == 7) ? 1 : 0, cz = c >> 2;
+      const int li = ((vx + cx) * 9 + (vy + cy)) * 9 + (vz + cz);
+      ok = ok && s_valid[li];
+      if (s_d[li] < 0.0f) cube |= 1 << c;
+    }
+    int ntri = 0;
+    if (ok && cube != 0 && cube != 255) { while (ntri < 5 && MC_TRI_C[cube][3 * ntri] >= 0) ntri++; }
+    int T;
+    const int toff = block_scan_512(ntri, s_part, tid, &T);
+    for (int j = 0; j < ntri; j++) {
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int e = MC_TRI_C[cube][3 * j + q];
+        const int eid = (((vx + MC_EDGE_BASE_C[e][0]) * 9 + (vy + MC_EDGE_BASE_C[e][1])) * 9 + (vz + MC_EDGE_BASE_C[e][2])) * 3 + MC_EDGE_AXIS_C[e];
+        s_tri_edges[3 * (toff + j) + q] = (uint16_t)eid;
+        atomicMin(&s_first[eid], toff + j);
+      }
+    }
+    __syncthreads();
+    // vertex numbering: 5 consecutive edge ids per thread (512 * 5 >= 2187), ascending
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) { const int e = tid * 5 + k; if (e < NEDGE && s_first[e] != INT32_MAX) cnt++; }
+    int V;
+    int voff = block_scan_512(cnt, s_part, tid, &V);
+#pragma unroll
+    for (int k = 0; k < 5; k++) { const int e = tid * 5 + k; if (e < NEDGE) s_vid[e] = (s_first[e] != INT32_MAX) ? voff++ : -1; }
+    if (tid == 0) {
+      int vb = atomicAdd(&m.counters[a.rec + 1], V);
+      int tb = atomicAdd(&m.counters[a.rec + 2], T);
+      const int bi = atomicAdd(&m.counters[a.rec + 0], 1);
+      int nv = V, nt = T;
+      if ((int64_t)vb + V > a.vert_cap || (int64_t)tb + T > a.tri_cap) { atomicExch(&m.counters[C_OVERFLOW], 1); nv = 0; nt = 0; vb = -1; }
+      MeshRecord r; r.x = bx; r.y = by; r.z = bz; r.vbase = vb; r.nvert = nv; r.tbase = tb; r.ntri = nt; r.pad = 0;
+      o_rec[bi] = r;
+      s_base[0] = vb; s_base[1] = tb;
+    }
+    __syncthreads();
+    const int vbase = s_base[0], tbase = s_base[1];
+    if (vbase < 0) continue;                                             // uniform (arena overflow)
+    // emit vertices
+    const int32_t b3[3] = {bx, by, bz};
+#pragma unroll 1
+    for (int k = 0; k < 5; k++) {
+      const int e = tid * 5 + k;
+      if (e >= NEDGE) break;
+      const int vid = s_vid[e];
+      if (vid < 0) continue;
+      int li, lj, axis, lx, ly, lz;
+      edge_decode(e, &li, &lj, &axis, &lx, &ly, &lz);
+      const float da = s_d[li], db = s_d[lj];
+      const float t = da / (da - db);
+      const int32_t l3[3] = {lx, ly, lz};
+      float p[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        float pos = ((float)b3[q] * a.block_size + (float)l3[q] * a.voxel_size) + a.voxel_size * 0.5f;
+        if (q == axis) pos = pos + t * a.voxel_size;
+        p[q] = pos;
+      }
+      // colour: nearest lattice end point
+      const int lc = (t < 0.5f) ? li : lj;
+      const int cz = lc % 9, cy = (lc / 9) % 9, cx = lc / 81;
+      const int nb = (cx >> 3) | ((cy >> 3) << 1) | ((cz >> 3) << 2);
+      uint32_t rgba = 127u | (127u << 8) | (127u << 16);
+      if (s_nflags[nb] & F_COLOR) {
+        const uint2 cv = m.color[(size_t)s_nslot[nb] * 512 + (cz & 7) + 8 * (cy & 7) + 64 * (cx & 7)];
+        if (__uint_as_float(cv.y) > 0.0f) rgba = cv.x & 0x00FFFFFFu;
+      }
+      rgba |= 255u << 24;
+      // normal: first triangle referencing this vertex
+      const int tf = s_first[e];
+      float tp[3][3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int eq = s_tri_edges[3 * tf + q];
+        int qi, qj, qa, qx, qy, qz;
+        edge_decode(eq, &qi, &qj, &qa, &qx, &qy, &qz);
+        const float ea = s_d[qi], eb = s_d[qj];
+        const float tt = ea / (ea - eb);
+        const int32_t q3[3] = {qx, qy, qz};
+#pragma unroll
+        for (int w = 0; w < 3; w++) {
+          float pos = ((float)b3[w] * a.block_size + (float)q3[w] * a.voxel_size) + a.voxel_size * 0.5f;
+          if (w == qa) pos = pos + tt * a.voxel_size;
+          tp[q][w] = pos;
+        }
+      }
+      const float e1[3] = {tp[1][0] - tp[0][0], tp[1][1] - tp[0][1], tp[1][2] - tp[0][2]};
+      const float e2[3] = {tp[2][0] - tp[0][0], tp[2][1] - tp[0][1], tp[2][2] - tp[0][2]};
+      float nn[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+      const float len = sqrtf((nn[0] * nn[0] + nn[1] * nn[1]) + nn[2] * nn[2]);
+      if (len > 0.0f) { nn[0] = nn[0] / len; nn[1] = nn[1] / len; nn[2] = nn[2] / len; }
+      const size_t o = (size_t)(vbase + vid);
+      o_vert[3 * o] = p[0]; o_vert[3 * o + 1] = p[1]; o_vert[3 * o + 2] = p[2];
+      o_nrm[3 * o] = nn[0]; o_nrm[3 * o + 1] = nn[1]; o_nrm[3 * o + 2] = nn[2];
+      o_col[o] = rgba;
+    }
+    // emit triangles (indices local to the block)
+    for (int j = 0; j < ntri; j++) {
+      const size_t o = (size_t)(tbase + toff + j);
+      o_tri[3 * o] = s_vid[s_tri_edges[3 * (toff + j)]];
+      o_tri[3 * o + 1] = s_vid[s_tri_edges[3 * (toff + j) + 1]];
+      o_tri[3 * o + 2] = s_vid[s_tri_edges[3 * (toff + j) + 2]];
+    }
+  }
+}
+
+extern "C" int nvbx_update_color_mesh(nvbx_mapper* m, int32_t update_full_layer) {
+  if (!m) return NVBX_E_INVALID;
+  NVBX_HIP(hipSetDevice(m->device));
+  MeshArgs a{};
+  a.voxel_size = m->p.voxel_size; a.block_size = m->p.voxel_size * 8.0f; a.min_weight = m->p.mesh_min_weight;
+  a.full = update_full_layer ? 1 : 0;
+  const int par = (int)(m->mesh_epoch & 1);
+  a.dirty_cnt = C_MESH_DIRTY + par; a.next_cnt = C_MESH_DIRTY + (par ^ 1);
+  a.rec = C_MESH_OUT + 4 * par; a.rec_next = C_MESH_OUT + 4 * (par ^ 1);
+  a.vert_cap = m->mesh_vert_cap; a.tri_cap = m->mesh_tri_cap;
+  const int grid = (int)std::min<int64_t>(m->capacity, 2048);
+  hipLaunchKernelGGL(k_mesh, dim3(grid), dim3(512), 0, m->stream, m->d, a, m->mesh_dirty_live(), m->mesh_vert, m->mesh_nrm, (uint32_t*)m->mesh_col,
+                     m->mesh_tri, m->mesh_rec);
+  NVBX_HIP(hipGetLastError());
+  m->mesh_epoch++;
+  return NVBX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ output
+extern "C" int nvbx_mesh_sizes(nvbx_mapper* m, int64_t* n_blocks, int64_t* n_vertices, int64_t* n_triangles) {
+  if (!m || !n_blocks || !n_vertices || !n_triangles) return NVBX_E_INVALID;
+  if (m->mesh_epoch == 0) { *n_blocks = *n_vertices = *n_triangles = 0; return NVBX_OK; }
+  if (m->fetch_counters()) return NVBX_E_DEVICE;
+  const int rec = C_MESH_OUT + 4 * (int)((m->mesh_epoch + 1) & 1);
+  *n_blocks = m->h_counters[rec + 0];
+  *n_vertices = std::min<int64_t>(m->h_counters[rec + 1], m->mesh_vert_cap);
+  *n_triangles = std::min<int64_t>(m->h_counters[rec + 2], m->mesh_tri_cap);
+  return NVBX_OK;
+}
+
+// Copies the last update's mesh to host memory, re-packed in ascending (x,y,z) block order so the output is
+// deterministic although arena placement is not.
+extern "C" int nvbx_mesh_copy(nvbx_mapper* m, nvbx_index3d* block_indices, int32_t* vertex_offsets, int32_t* triangle_offsets, float* vertices,
+                              float* normals, uint8_t* colors, int32_t* triangles) {
+  if (!m) return NVBX_E_INVALID;
+  int64_t nb, nv, nt;
+  int rc = nvbx_mesh_sizes(m, &nb, &nv, &nt); if (rc) return rc;
+  if (nb == 0) { if (vertex_offsets) vertex_offsets[0] = 0; if (triangle_offsets) triangle_offsets[0] = 0; return NVBX_OK; }
+  std::vector<MeshRecord> rec((size_t)nb);
+  NVBX_HIP(hipMemcpy(rec.data(), m->mesh_rec, (size_t)nb * sizeof(MeshRecord), hipMemcpyDeviceToHost));
+  std::vector<float> v((size_t)nv * 3), n((size_t)nv * 3); std::vector<uint8_t> c((size_t)nv * 4); std::vector<int32_t> t((size_t)nt * 3);
+  if (nv) {
+    NVBX_HIP(hipMemcpy(v.data(), m->mesh_vert, (size_t)nv * 12, hipMemcpyDeviceToHost));
+    NVBX_HIP(hipMemcpy(n.data(), m->mesh_nrm, (size_t)nv * 12, hipMemcpyDeviceToHost));
+    NVBX_HIP(hipMemcpy(c.data(), m->mesh_col, (size_t)nv * 4, hipMemcpyDeviceToHost));
+  }
+  if (nt) NVBX_HIP(hipMemcpy(t.data(), m->mesh_tri, (size_t)nt * 12, hipMemcpyDeviceToHost));
+  std::vector<int> order((size_t)nb);
+  for (int64_t i = 0; i < nb; i++) order[(size_t)i] = (int)i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    const MeshRecord &p = rec[(size_t)a], &q = rec[(size_t)b];
+    if (p.x != q.x) return p.x < q.x; if (p.y != q.y) return p.y < q.y; return p.z < q.z; });
+  int64_t vo = 0, to = 0;
+  for (int64_t i = 0; i < nb; i++) {
+    const MeshRecord& r = rec[(size_t)order[(size_t)i]];
+    if (block_indices) { block_indices[i].x = r.x; block_indices[i].y = r.y; block_indices[i].z = r.z; }
+    if (vertex_offsets) vertex_offsets[i] = (int32_t)vo;
+    if (triangle_offsets) triangle_offsets[i] = (int32_t)to;
+    if (r.nvert > 0) {
+      if (vertices) memcpy(vertices + vo * 3, v.data() + (size_t)r.vbase * 3, (size_t)r.nvert * 12);
+      if (normals) memcpy(normals + vo * 3, n.data() + (size_t)r.vbase * 3, (size_t)r.nvert * 12);
+      if (colors) memcpy(colors + vo * 4, c.data() + (size_t)r.vbase * 4, (size_t)r.nvert * 4);
+    }
+    if (r.ntri > 0 && triangles) memcpy(triangles + to * 3, t.data() + (size_t)r.tbase * 3, (size_t)r.ntri * 12);
+    vo += r.nvert; to += r.ntri;
+  }
+  if (vertex_offsets) vertex_offsets[nb] = (int32_t)vo;
+  if (triangle_offsets) triangle_offsets[nb] = (int32_t)to;
+  return NVBX_OK;
+}

@@ -1,0 +1,237 @@
+// nvbx_internal.h -- device data layout + device helpers shared by the HIP kernels of libnvblox_hip.so.
+//
+// HBM layout (one per mapper == one per GPU), sized once for `capacity` blocks, never reallocated:
+//   table      : open-addressing hash, 2^k >= 2*capacity entries of 16 B {key64, slot32, view_stamp32}.  The probe
+//                start is the reference's Index3DHash x + 17191 y + 17191^2 z (nvblox_hash_utils.h:40-50) masked to
+//                the table size; linear probing; no tombstones (deallocation rebuilds the table on device).
+//   slot_*     : per-slot metadata (layer/dirty flags, Index3D, back-pointer to the hash entry, ESDF epoch stamp)
+//   tsdf/color : capacity x 512 x 8 B voxel pools, voxel order z + 8y + 64x (the reference's order, so block copies
+//                are memcpy); one slot id addresses the TSDF, colour and ESDF block of the same Index3D.
+//   esdf       : capacity x 512 x 8 B, voxel order x + 8y + 64z so that the 2-D slice plane of a block is one
+//                contiguous 512-B line = one 8-byte access per lane of one wavefront; packed {f32 sq, u32 meta}.
+// All voxel types are 8 bytes -> every block of every layer is 4 KiB and a 512-thread workgroup (8 wave64) moves one
+// block with one coalesced 8-B access per lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nvbx {
+
+typedef unsigned long long u64;
+
+constexpr u64 KEY_EMPTY = ~0ull;
+constexpr uint32_t SLOT_INVALID = 0xFFFFFFFFu;   // entry inserted, slot not published yet
+constexpr uint32_t SLOT_NONE = 0xFFFFFFFEu;      // entry exists but the pool was exhausted
+__host__ __device__ inline bool slot_ok(uint32_t s) { return s < SLOT_NONE; }
+
+// slot_flags bits
+constexpr uint32_t F_TSDF = 1u, F_COLOR = 2u, F_ESDF = 4u, F_MESH = 8u;
+constexpr uint32_t F_DIRTY_ESDF = 1u << 8, F_DIRTY_MESH = 1u << 9;
+
+struct Entry { u64 key; uint32_t slot; uint32_t stamp; };
+
+// counters[] indices (device int32 array, mirrored to pinned host memory on demand)
+enum {
+  C_FREE_TOP = 0,      // number of free slots on the stack
+  C_HIGH_WATER = 1,    // 1 + highest slot ever handed out
+  C_OVERFLOW = 2,      // sticky capacity-overflow flag
+  C_VIEW_COUNT = 4,    // [4..7]  ring of per-frame view-list counts (frame & 3)
+  C_ESDF_DIRTY = 8,    // number of entries in esdf_dirty list
+  C_MESH_DIRTY = 9,    // [9..10] entries in the mesh_dirty list of mesh-update parity 0 / 1
+  C_COLOR_COUNT = 11,  // blocks updated by the last colour frame
+  C_ESDF_UPD = 16,     // [16..31] two parity-indexed records of 8 ints for ESDF update e (record e & 1):
+                       //   +0..3 dirty window min_x, min_y, max_x, max_y (block coords), +4 columns re-marked,
+                       //   +5 ESDF blocks swept, +6 window voxels, +7 unused
+  C_ESDF_AABB = 32,    // [32..35] AABB of all ESDF blocks: min_x, min_y, max_x, max_y
+  C_MESH_OUT = 36,     // [36..43] two parity-indexed records {blocks, vertices, triangles, pad} of mesh update e
+  C_LIVE = 44,         // live hash entries
+  C_TMP = 45,          // scratch counter (point cloud compaction etc.)
+  C_NUM = 48
+};
+
+struct DMap {
+  Entry* table; uint32_t mask;
+  uint32_t capacity;
+  uint32_t* free_stack;
+  int32_t* counters;
+  uint32_t* slot_flags;
+  int32_t* slot_index;      // 3 ints per slot
+  uint32_t* slot_entry;     // slot -> hash entry
+  uint32_t* slot_stamp;     // ESDF epoch stamp per slot (column de-duplication)
+  float2* tsdf;
+  uint2* color;
+  uint2* esdf;
+};
+
+// Per-call camera / pose / parameter bundle (kernel argument, lives in SGPRs).
+struct Frame {
+  float R_CL[9], t_CL[3];   // p_C = R_CL p_L + t_CL
+  float R_LC[9], t_LC[3];   // p_L = R_LC p_C + t_LC
+  float fu, fv, cu, cv; int32_t w, h;
+  int32_t rows, cols;
+  float voxel_size, block_size, trunc, max_dist, max_weight;
+  int32_t weighting_mode, interp_nearest;
+  int32_t subsample;        // raycast / sphere-tracing subsampling
+  int32_t n_ray_rows, n_ray_cols;
+  uint32_t frame_id;
+};
+
+__host__ __device__ inline u64 pack_key(int32_t x, int32_t y, int32_t z) {
+  const u64 B = 1ull << 20;
+  return (((u64)(int64_t)x + B) & 0x1FFFFFull) | ((((u64)(int64_t)y + B) & 0x1FFFFFull) << 21) |
+         ((((u64)(int64_t)z + B) & 0x1FFFFFull) << 42);
+}
+__host__ __device__ inline uint32_t index_hash(int32_t x, int32_t y, int32_t z) {
+  // nvblox_hash_utils.h:43-48 -- uint32 wrap-around is identical to truncating the size_t sum
+  return (uint32_t)x + (uint32_t)y * 17191u + (uint32_t)z * (17191u * 17191u);
+}
+
+#ifdef __HIPCC__
+__device__ inline int32_t floor_div8(int32_t v) { return v >> 3; }
+__device__ inline int32_t mod8(int32_t v) { return v & 7; }
+
+__device__ inline uint32_t ld_slot_acquire(const Entry* e) {
+  return __hip_atomic_load(&e->slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Lookup of a key inserted by an EARLIER kernel (or earlier in this kernel by this thread). Returns entry or -1.
+__device__ inline int32_t hash_find(const DMap& m, int32_t x, int32_t y, int32_t z) {
+  const u64 key = pack_key(x, y, z);
+  uint32_t h = index_hash(x, y, z) & m.mask;
+  for (uint32_t probe = 0; probe <= m.mask; ++probe) {
+    const u64 k = m.table[h].key;
+    if (k == key) return (int32_t)h;
+    if (k == KEY_EMPTY) return -1;
+    h = (h + 1) & m.mask;
+  }
+  return -1;
+}
+// slot of an existing block carrying `layer`, or SLOT_NONE
+__device__ inline uint32_t find_slot(const DMap& m, int32_t x, int32_t y, int32_t z, uint32_t layer) {
+  const int32_t h = hash_find(m, x, y, z);
+  if (h < 0) return SLOT_NONE;
+  const uint32_t s = m.table[h].slot;
+  if (!slot_ok(s)) return SLOT_NONE;
+  return (m.slot_flags[s] & layer) ? s : SLOT_NONE;
+}
+
+// Insert-if-absent. Device-scope CAS on the key decides the winner; the winner pops a pool slot and publishes it with
+// an agent-scope store.  `is_new` tells the caller it won.  Returns the entry index or -1 (table full).
+__device__ inline int32_t hash_insert(const DMap& m, int32_t x, int32_t y, int32_t z, uint32_t layer_flags, bool* is_new) {
+  const u64 key = pack_key(x, y, z);
+  uint32_t h = index_hash(x, y, z) & m.mask;
+  *is_new = false;
+  for (uint32_t probe = 0; probe <= m.mask; ++probe) {
+    u64 k = m.table[h].key;              // may be a stale EMPTY: the CAS below is the truth
+    if (k == KEY_EMPTY) {
+      k = atomicCAS(&m.table[h].key, KEY_EMPTY, key);
+      if (k == KEY_EMPTY) {
+        *is_new = true;
+        const int32_t top = atomicSub(&m.counters[C_FREE_TOP], 1);
+        uint32_t slot = SLOT_NONE;
+        if (top > 0) {
+          slot = m.free_stack[top - 1];
+          m.slot_index[3 * slot] = x; m.slot_index[3 * slot + 1] = y; m.slot_index[3 * slot + 2] = z;
+          m.slot_entry[slot] = h;
+          atomicOr(&m.slot_flags[slot], layer_flags);
+          atomicMax(&m.counters[C_HIGH_WATER], (int32_t)slot + 1);
+          atomicAdd(&m.counters[C_LIVE], 1);
+        } else {
+          atomicAdd(&m.counters[C_FREE_TOP], 1);
+          atomicExch(&m.counters[C_OVERFLOW], 1);
+        }
+        __hip_atomic_store(&m.table[h].slot, slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (int32_t)h;
+      }
+    }
+    if (k == key) return (int32_t)h;
+    h = (h + 1) & m.mask;
+  }
+  atomicExch(&m.counters[C_OVERFLOW], 1);
+  return -1;
+}
+
+// ---------------------------------------------------------------- numerical contract: fixed evaluation order,
+// no contraction (-ffp-contract=off), IEEE division and sqrt.
+__device__ inline void apply_rt(const float* R, const float* t, float x, float y, float z, float* o) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    float s = R[3 * i + 0] * x;
+    s = s + R[3 * i + 1] * y;
+    s = s + R[3 * i + 2] * z;
+    o[i] = s + t[i];
+  }
+}
+__device__ inline void rotate(const float* R, float x, float y, float z, float* o) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    float s = R[3 * i + 0] * x;
+    s = s + R[3 * i + 1] * y;
+    s = s + R[3 * i + 2] * z;
+    o[i] = s;
+  }
+}
+__device__ inline float voxel_center(int32_t bi, int32_t vi, float bs, float vs) {
+  return ((float)bi * bs + (float)vi * vs) + vs * 0.5f;   // layer_publishing.cpp:527
+}
+__device__ inline bool cam_project(const Frame& f, const float* p, float* u, float* v) {
+  if (p[2] <= 0.0f) return false;
+  *u = f.fu * (p[0] / p[2]) + f.cu;
+  *v = f.fv * (p[1] / p[2]) + f.cv;
+  if (*u < 0.0f || *v < 0.0f || *u > (float)f.w || *v > (float)f.h) return false;
+  return true;
+}
+
+struct DepthF32 { const float* p; __device__ float operator()(int64_t i) const { return p[i]; } };
+struct DepthU16mm {   // conversions/image_conversions_thrust.cu:39-45 fused into the read
+  const uint16_t* p; __device__ float operator()(int64_t i) const { return (float)p[i] * (1.0f / 1000.0f); } };
+
+template <typename Img>
+__device__ inline bool interp_depth(const Img& img, int rows, int cols, float u, float v, int nearest, float* out) {
+  if (nearest) {
+    const int c = (int)floorf(u), r = (int)floorf(v);
+    if (c < 0 || r < 0 || c >= cols || r >= rows) return false;
+    const float d = img((int64_t)r * cols + c);
+    if (!(d > 0.0f)) return false;
+    *out = d; return true;
+  }
+  const float uc = u - 0.5f, vc = v - 0.5f;
+  const float fx = floorf(uc), fy = floorf(vc);
+  const int x0 = (int)fx, y0 = (int)fy;
+  if (x0 < 0 || y0 < 0 || x0 + 1 > cols - 1 || y0 + 1 > rows - 1) return false;
+  const float ax = uc - fx, ay = vc - fy;
+  const float f00 = img((int64_t)y0 * cols + x0), f10 = img((int64_t)y0 * cols + x0 + 1);
+  const float f01 = img((int64_t)(y0 + 1) * cols + x0), f11 = img((int64_t)(y0 + 1) * cols + x0 + 1);
+  if (!(f00 > 0.0f) || !(f10 > 0.0f) || !(f01 > 0.0f) || !(f11 > 0.0f)) return false;
+  const float top = (1.0f - ax) * f00 + ax * f10;
+  const float bot = (1.0f - ax) * f01 + ax * f11;
+  *out = (1.0f - ay) * top + ay * bot;
+  return true;
+}
+
+__device__ inline float weight_fn(int mode, float d_meas, float d_vox, float trunc) {
+  float w = 1.0f;
+  if (mode == 2 || mode == 3 || mode == 4) {
+    w = 1.0f / (d_meas * d_meas);
+  } else if (mode == 5) {
+    w = 1.0f / d_meas;
+    if (w > 1.0f) w = 1.0f;
+  }
+  const float sdf = d_meas - d_vox;
+  if (mode == 1 || mode == 3) {
+    if (sdf < 0.0f) { float g = (trunc + sdf) / trunc; if (g < 0.0f) g = 0.0f; w = w * g; }
+  } else if (mode == 4) {
+    if (sdf > trunc) w = w * (trunc / sdf);
+  }
+  return w;
+}
+
+// ESDF packed voxel: {f32 squared_distance_vox, u32 meta}; meta = dx | dy<<8 | dz<<16 (int8 each) | observed<<24 | inside<<25 | site<<26
+__device__ __host__ inline uint32_t esdf_meta(int dx, int dy, int dz, int observed, int inside, int site) {
+  return ((uint32_t)(uint8_t)(int8_t)dx) | (((uint32_t)(uint8_t)(int8_t)dy) << 8) | (((uint32_t)(uint8_t)(int8_t)dz) << 16) |
+         ((uint32_t)(observed != 0) << 24) | ((uint32_t)(inside != 0) << 25) | ((uint32_t)(site != 0) << 26);
+}
+constexpr uint32_t ESDF_OBSERVED = 1u << 24, ESDF_INSIDE = 1u << 25, ESDF_SITE = 1u << 26, ESDF_FLAG_MASK = 7u << 24;
+#endif  // __HIPCC__
+
+}  // namespace nvbx

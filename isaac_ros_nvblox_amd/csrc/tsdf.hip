@@ -1,0 +1,165 @@
+// tsdf.hip -- MultiMapper::integrateDepth on MI355X: block marking (view calculation) + projective TSDF update.
+//
+// Two launches per depth frame, no host round trip in between:
+//   k_mark_view      one wavefront per 8x8 tile of the sub-sampled ray grid.  Each lane walks its ray through the
+//                    block grid (Amanatides-Woo); block keys are first filtered through a 4 KiB LDS set (rays of one
+//                    tile share almost all their blocks) and only the first lane to see a block touches HBM: CAS
+//                    insert-if-absent into the hash (device-side allocation from the slot stack) and append to the
+//                    frame's view list exactly once (per-entry frame stamp).
+//   k_integrate_tsdf one 512-thread workgroup (8 wave64) per 8^3 block, grid-striding over the device-resident view
+//                    list; lane = voxel in z + 8y + 64x order, so every wave reads/writes 512 contiguous bytes.
+// Reference semantics restated: [U] ViewCalculator::getBlocksInImageViewRaycast and ProjectiveTsdfIntegrator
+// (call site nvblox_ros/src/lib/nvblox_node.cpp:1062; knobs mapper_initialization.cpp:264-358).
+#include <algorithm>
+#include "nvbx_mapper.h"
+
+using namespace nvbx;
+
+constexpr int LSET = 512;   // LDS dedup set entries per wave-tile (8 B each)
+
+template <typename Img>
+__global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, int32_t* view_list, int32_t list_cap) {
+  __shared__ u64 lset[LSET];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < LSET; i += 64) lset[i] = KEY_EMPTY;
+  if (blockIdx.x == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
+  __syncthreads();
+
+  const int tiles_x = (f.n_ray_cols + 7) >> 3;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int ri = ty * 8 + (lane >> 3), ci = tx * 8 + (lane & 7);
+  bool active = ri < f.n_ray_rows && ci < f.n_ray_cols;
+
+  int32_t cur[3] = {0, 0, 0}, step[3] = {0, 0, 0}, nsteps = -1;
+  float tmax[3] = {0, 0, 0}, tdelta[3] = {0, 0, 0};
+  if (active) {
+    int prow = ri * f.subsample; if (prow >= f.rows) prow = f.rows - 1;
+    int pcol = ci * f.subsample; if (pcol >= f.cols) pcol = f.cols - 1;
+    const float d = depth((int64_t)prow * f.cols + pcol);
+    if (!(d > 0.0f)) active = false;
+    else {
+      float de = d + f.trunc;
+      if (f.max_dist > 0.0f && de > f.max_dist) de = f.max_dist;
+      const float rx = (((float)pcol + 0.5f) - f.cu) / f.fu;
+      const float ry = (((float)prow + 0.5f) - f.cv) / f.fv;
+      float pl[3];
+      apply_rt(f.R_LC, f.t_LC, de * rx, de * ry, de, pl);
+      nsteps = 0;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const float s = f.t_LC[a] / f.block_size, t = pl[a] / f.block_size;
+        cur[a] = (int32_t)floorf(s);
+        const int32_t end = (int32_t)floorf(t);
+        const int32_t dd = end - cur[a]; nsteps += dd < 0 ? -dd : dd;
+        const float ray = t - s;
+        step[a] = ray > 0.0f ? 1 : (ray < 0.0f ? -1 : 0);
+        const float corrected = step[a] > 0 ? 1.0f : 0.0f;
+        const float dist_to_boundary = corrected - (s - (float)cur[a]);
+        if (fabsf(ray) < 1e-9f) { tmax[a] = 2.0f; tdelta[a] = 2.0f; }
+        else { tmax[a] = dist_to_boundary / ray; tdelta[a] = (float)step[a] / ray; }
+      }
+    }
+  }
+  int32_t* cnt = &m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
+  for (int32_t k = 0; k <= nsteps; k++) {
+    const u64 key = pack_key(cur[0], cur[1], cur[2]);
+    // stage 1: LDS filter
+    bool need = true;
+    uint32_t lh = (index_hash(cur[0], cur[1], cur[2]) * 2654435761u) >> 23;   // 9 bits
+#pragma unroll 1
+    for (int p = 0; p < 8; p++) {
+      const u64 old = atomicCAS(&lset[(lh + p) & (LSET - 1)], KEY_EMPTY, key);
+      if (old == KEY_EMPTY) break;
+      if (old == key) { need = false; break; }
+    }
+    // stage 2: HBM hash
+    if (need) {
+      bool is_new;
+      const int32_t h = hash_insert(m, cur[0], cur[1], cur[2], F_TSDF, &is_new);
+      if (h >= 0) {
+        const uint32_t old = atomicExch(&m.table[h].stamp, f.frame_id);
+        if (old != f.frame_id) {
+          const int32_t pos = atomicAdd(cnt, 1);
+          if (pos < list_cap) view_list[pos] = h;
+        }
+      }
+    }
+    int a = 0;
+    if (tmax[1] < tmax[a]) a = 1;
+    if (tmax[2] < tmax[a]) a = 2;
+    // (select without dynamic register indexing)
+    if (a == 0) { cur[0] += step[0]; tmax[0] = tmax[0] + tdelta[0]; }
+    else if (a == 1) { cur[1] += step[1]; tmax[1] = tmax[1] + tdelta[1]; }
+    else { cur[2] += step[2]; tmax[2] = tmax[2] + tdelta[2]; }
+  }
+}
+
+template <typename Img>
+__global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img depth, int32_t* view_list, int32_t list_cap,
+                                                        int32_t* esdf_dirty, int32_t* mesh_dirty, int32_t mesh_cnt) {
+  int32_t n = m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
+  if (n > list_cap) n = list_cap;
+  const int tid = threadIdx.x;
+  const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
+  for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const uint32_t h = (uint32_t)view_list[i];
+    const uint32_t slot = m.table[h].slot;
+    __syncthreads();                       // every thread has read the entry id before it is replaced
+    if (tid == 0) view_list[i] = (int32_t)slot;   // the list now names pool slots (stable across hash rebuilds)
+    if (!slot_ok(slot)) continue;
+    const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
+    if (tid == 0) {
+      const uint32_t old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH);
+      if (!(old & F_DIRTY_ESDF)) esdf_dirty[atomicAdd(&m.counters[C_ESDF_DIRTY], 1)] = (int32_t)slot;
+      if (!(old & F_DIRTY_MESH)) mesh_dirty[atomicAdd(&m.counters[mesh_cnt], 1)] = (int32_t)slot;
+    }
+    float pc[3];
+    apply_rt(f.R_CL, f.t_CL, voxel_center(bx, vx, f.block_size, f.voxel_size), voxel_center(by, vy, f.block_size, f.voxel_size),
+             voxel_center(bz, vz, f.block_size, f.voxel_size), pc);
+    float u, v;
+    if (!cam_project(f, pc, &u, &v)) continue;
+    const float vd = pc[2];
+    if (f.max_dist > 0.0f && vd > f.max_dist) continue;
+    float ds;
+    if (!interp_depth(depth, f.rows, f.cols, u, v, f.interp_nearest, &ds)) continue;
+    const float sdf = ds - vd;
+    if (sdf < -f.trunc) continue;
+    float2* vp = &m.tsdf[(size_t)slot * 512 + tid];
+    const float2 cur = *vp;
+    const float wm = weight_fn(f.weighting_mode, ds, vd, f.trunc);
+    const float wsum = wm + cur.y;
+    if (!(wsum > 0.0f)) continue;
+    float fused = (sdf * wm + cur.x * cur.y) / wsum;
+    if (fused > 0.0f) fused = fminf(f.trunc, fused); else fused = fmaxf(-f.trunc, fused);
+    *vp = make_float2(fused, fminf(wsum, f.max_weight));
+  }
+}
+
+template <typename Img>
+static int integrate_depth_impl(nvbx_mapper* m, Img img, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera) {
+  NVBX_HIP(hipSetDevice(m->device));
+  m->frame_id++;
+  Frame f = m->make_frame(T_L_C, camera, rows, cols, m->p.raycast_subsampling_factor);
+  const int s = f.subsample;
+  f.n_ray_rows = (rows + s - 1 + s - 1) / s;   // indices i with i*s < rows + s - 1
+  f.n_ray_cols = (cols + s - 1 + s - 1) / s;
+  const int tiles = ((f.n_ray_rows + 7) / 8) * ((f.n_ray_cols + 7) / 8);
+  hipLaunchKernelGGL((k_mark_view<Img>), dim3(tiles), dim3(64), 0, m->stream, m->d, f, img, m->view_list, (int32_t)m->capacity);
+  const int grid = (int)std::min<int64_t>(m->capacity, 2048);
+  hipLaunchKernelGGL((k_integrate_tsdf<Img>), dim3(grid), dim3(512), 0, m->stream, m->d, f, img, m->view_list, (int32_t)m->capacity,
+                     m->esdf_dirty, m->mesh_dirty_live(), m->mesh_dirty_counter());
+  NVBX_HIP(hipGetLastError());
+  m->last_view_frame = m->frame_id;
+  return NVBX_OK;
+}
+
+extern "C" int nvbx_integrate_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16],
+                                    const nvbx_camera* camera) {
+  if (!m || !depth_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_depth: invalid argument"); return NVBX_E_INVALID; }
+  return integrate_depth_impl(m, DepthF32{depth_dev}, rows, cols, T_L_C, camera);
+}
+extern "C" int nvbx_integrate_depth_u16mm(nvbx_mapper* m, const uint16_t* depth_mm_dev, int32_t rows, int32_t cols, const float T_L_C[16],
+                                          const nvbx_camera* camera) {
+  if (!m || !depth_mm_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_depth_u16mm: invalid argument"); return NVBX_E_INVALID; }
+  return integrate_depth_impl(m, DepthU16mm{depth_mm_dev}, rows, cols, T_L_C, camera);
+}

@@ -1,0 +1,264 @@
+"""Host-side mirror of nvblox::Mapper / MultiMapper / EsdfSlicer for tests and bench.py (thin ctypes over the C-ABI).
+
+Method names follow the reference call sites (nvblox_ros/src/lib/nvblox_node.cpp:781,1062,1264;
+layer_publishing.cpp:686-689).  Images are torch CUDA tensors (device memory, like the reference's
+MemoryType::kDevice images) or numpy arrays (uploaded first).
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import Camera, Counters, Index3D, Params
+
+LAYER_TSDF, LAYER_COLOR, LAYER_ESDF, LAYER_MESH = 1, 2, 4, 8
+
+TSDF_DT = np.dtype([("distance", "<f4"), ("weight", "<f4")])
+COLOR_DT = np.dtype([("r", "u1"), ("g", "u1"), ("b", "u1"), ("pad", "u1"), ("weight", "<f4")])
+ESDF_DT = np.dtype([("squared_distance_vox", "<f4"), ("parent_direction", "<i4", (3,)),
+                    ("is_inside", "u1"), ("observed", "u1"), ("is_site", "u1"), ("pad", "u1")])
+_DT = {LAYER_TSDF: TSDF_DT, LAYER_COLOR: COLOR_DT, LAYER_ESDF: ESDF_DT}
+
+
+def default_params(**kw):
+    """fuser.yaml values (nvblox_examples_bringup/config/nvblox/fuser.yaml:24-42) + nvblox_base.yaml:87,103-107."""
+    p = Params(
+        voxel_size=0.05, max_integration_distance_m=8.0, truncation_distance_vox=4.0, max_weight=5.0,
+        weighting_mode=0, raycast_subsampling_factor=4,
+        esdf_min_weight=0.1, esdf_max_site_distance_vox=2.0, esdf_max_distance_m=2.0,
+        esdf_slice_height=0.09, esdf_slice_min_height=0.09, esdf_slice_max_height=0.65,
+        mesh_min_weight=0.1, mesh_weld_vertices=1,
+        sphere_tracing_subsampling=4, sphere_tracing_max_steps=100,
+        sphere_tracing_max_ray_length_m=15.0, sphere_tracing_surface_eps_vox=0.1,
+        tsdf_decay_factor=0.95, tsdf_decayed_weight_threshold=0.001,
+        esdf_site_rule=0, depth_interp_nearest=0)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class NvbxError(RuntimeError):
+    pass
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Mapper:
+    def __init__(self, params=None, device=0, block_capacity=1 << 15, stream=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise NvbxError("no HIP device visible: the product path has no CPU fallback")
+        self._torch = torch
+        self.lib = _lib.load()
+        self.params = params or default_params()
+        self.device = device
+        self._h = C.c_void_p()
+        torch.cuda.set_device(device)
+        s = C.c_void_p(stream) if stream else None
+        self._check(self.lib.nvbx_mapper_create(device, s, C.byref(self.params), block_capacity, C.byref(self._h)))
+        self.capacity = block_capacity
+        self._keep = []
+
+    def _check(self, rc):
+        if rc < 0:
+            raise NvbxError("nvbx error %d: %s" % (rc, self.lib.nvbx_last_error().decode()))
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.nvbx_mapper_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers
+    def _dev(self, a, dtype):
+        torch = self._torch
+        if isinstance(a, torch.Tensor):
+            t = a
+            if not t.is_cuda:
+                t = t.cuda(self.device)
+            t = t.contiguous()
+            assert t.dtype == dtype, (t.dtype, dtype)
+            return t
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda(self.device)
+
+    @staticmethod
+    def _T(T):
+        return np.ascontiguousarray(np.asarray(T, np.float32).reshape(4, 4))
+
+    @staticmethod
+    def _cam(cam):
+        if isinstance(cam, Camera):
+            return cam
+        return Camera(float(cam[0]), float(cam[1]), float(cam[2]), float(cam[3]), int(cam[4]), int(cam[5]))
+
+    def set_params(self, params):
+        self._check(self.lib.nvbx_mapper_set_params(self._h, C.byref(params)))
+        self.params = params
+
+    def synchronize(self):
+        self._check(self.lib.nvbx_synchronize(self._h))
+
+    def clear(self):
+        self._check(self.lib.nvbx_mapper_clear(self._h))
+
+    # -- integration (async)
+    def integrate_depth(self, depth, T_L_C, cam):
+        torch = self._torch
+        if isinstance(depth, torch.Tensor) and depth.dtype == torch.int16 or (
+                not isinstance(depth, torch.Tensor) and np.asarray(depth).dtype == np.uint16):
+            if not isinstance(depth, torch.Tensor):
+                depth = torch.from_numpy(np.ascontiguousarray(depth).view(np.int16))
+            d = self._dev(depth, torch.int16)
+            fn = self.lib.nvbx_integrate_depth_u16mm
+        else:
+            d = self._dev(depth, torch.float32)
+            fn = self.lib.nvbx_integrate_depth
+        T = self._T(T_L_C); k = self._cam(cam)
+        self._check(fn(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k)))
+        self._keep = [d]   # keep the device image alive until the next call (stream-ordered use)
+
+    def integrate_color(self, rgb, T_L_C, cam):
+        d = self._dev(rgb, self._torch.uint8)
+        assert d.dim() == 3 and d.shape[2] == 3
+        T = self._T(T_L_C); k = self._cam(cam)
+        self._check(self.lib.nvbx_integrate_color(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k)))
+        self._keep_c = [d]
+
+    def update_esdf(self):
+        self._check(self.lib.nvbx_update_esdf(self._h))
+
+    def update_color_mesh(self, full=False):
+        self._check(self.lib.nvbx_update_color_mesh(self._h, int(full)))
+
+    update_mesh = update_color_mesh
+
+    def decay_tsdf(self, exclude_last_view=True):
+        self._check(self.lib.nvbx_decay_tsdf(self._h, int(exclude_last_view)))
+
+    def clear_outside_radius(self, center, radius):
+        c = np.asarray(center, np.float32)
+        self._check(self.lib.nvbx_clear_outside_radius(self._h, _np_ptr(c), float(radius)))
+
+    # -- queries (synchronise)
+    def counters(self):
+        c = Counters()
+        self._check(self.lib.nvbx_get_counters(self._h, C.byref(c)))
+        return {n: getattr(c, n) for n, _ in Counters._fields_}
+
+    def num_blocks(self, layer=LAYER_TSDF):
+        return self._check(self.lib.nvbx_num_blocks(self._h, layer))
+
+    def block_indices(self, layer=LAYER_TSDF):
+        n = self.num_blocks(layer)
+        out = np.zeros((max(n, 1), 3), np.int32)
+        n2 = self._check(self.lib.nvbx_block_indices(self._h, layer, _np_ptr(out), out.shape[0]))
+        return out[:min(n, n2)]
+
+    def last_view(self):
+        out = np.zeros((self.capacity, 3), np.int32)
+        n = self._check(self.lib.nvbx_last_depth_view(self._h, _np_ptr(out), out.shape[0]))
+        return out[:n].copy()
+
+    def last_color_view(self):
+        out = np.zeros((self.capacity, 3), np.int32)
+        n = self._check(self.lib.nvbx_last_color_view(self._h, _np_ptr(out), out.shape[0]))
+        return out[:n].copy()
+
+    def get_blocks(self, layer, indices):
+        idx = np.ascontiguousarray(np.asarray(indices, np.int32).reshape(-1, 3))
+        out = np.zeros((idx.shape[0], 512), _DT[layer])
+        found = np.zeros(idx.shape[0], np.int32)
+        self._check(self.lib.nvbx_get_blocks(self._h, layer, _np_ptr(idx), idx.shape[0], _np_ptr(out), _np_ptr(found)))
+        return out, found.astype(bool)
+
+    def get_block(self, layer, idx):
+        out, found = self.get_blocks(layer, [idx])
+        return out[0] if found[0] else None
+
+    def set_block(self, layer, idx, data):
+        data = np.ascontiguousarray(data, _DT[layer]); assert data.size == 512
+        self._check(self.lib.nvbx_set_block(self._h, layer, Index3D(int(idx[0]), int(idx[1]), int(idx[2])), _np_ptr(data)))
+
+    def synthetic_depth(self):
+        r, c = C.c_int32(), C.c_int32()
+        self._check(self.lib.nvbx_get_synthetic_depth(self._h, None, 0, C.byref(r), C.byref(c)))
+        if r.value == 0:
+            return None
+        out = np.zeros((r.value, c.value), np.float32)
+        self._check(self.lib.nvbx_get_synthetic_depth(self._h, _np_ptr(out), out.size, C.byref(r), C.byref(c)))
+        return out
+
+    def esdf_slice_image(self, unknown_value=1000.0):
+        r, c = C.c_int32(), C.c_int32()
+        aabb = np.zeros(6, np.float32)
+        self._check(self.lib.nvbx_esdf_slice_size(self._h, C.byref(r), C.byref(c), _np_ptr(aabb)))
+        img = np.zeros((r.value, c.value), np.float32)
+        if img.size:
+            self._check(self.lib.nvbx_esdf_slice_to_host(self._h, unknown_value, _np_ptr(img), img.size, C.byref(r), C.byref(c), _np_ptr(aabb)))
+        return img, aabb
+
+    def esdf_slice_image_device(self, unknown_value=1000.0):
+        torch = self._torch
+        r, c = C.c_int32(), C.c_int32()
+        aabb = np.zeros(6, np.float32)
+        self._check(self.lib.nvbx_esdf_slice_size(self._h, C.byref(r), C.byref(c), _np_ptr(aabb)))
+        img = torch.empty((r.value, c.value), dtype=torch.float32, device="cuda:%d" % self.device)
+        if img.numel():
+            self._check(self.lib.nvbx_esdf_slice_to_image(self._h, unknown_value, C.c_void_p(img.data_ptr()), img.numel(), C.byref(r), C.byref(c), _np_ptr(aabb)))
+        return img, aabb
+
+    def occupancy_grid_from_slice(self, img_dev, unknown_value=1000.0):
+        torch = self._torch
+        grid = torch.empty(img_dev.shape, dtype=torch.int8, device=img_dev.device)
+        self._check(self.lib.nvbx_occupancy_grid_from_slice(self._h, C.c_void_p(img_dev.data_ptr()), img_dev.shape[0], img_dev.shape[1], unknown_value, C.c_void_p(grid.data_ptr())))
+        self.synchronize()
+        return grid
+
+    def pointcloud_from_slice(self, img_dev, aabb, slice_height, unknown_value=1000.0):
+        torch = self._torch
+        pts = torch.empty((img_dev.numel(), 4), dtype=torch.float32, device=img_dev.device)
+        n = C.c_int32()
+        a = np.ascontiguousarray(aabb, np.float32)
+        self._check(self.lib.nvbx_pointcloud_from_slice(self._h, C.c_void_p(img_dev.data_ptr()), img_dev.shape[0], img_dev.shape[1], _np_ptr(a), float(slice_height), unknown_value, C.c_void_p(pts.data_ptr()), C.byref(n)))
+        return pts[:n.value]
+
+    def esdf_dense_grid(self, min_vox, size_vox, default_value):
+        torch = self._torch
+        mn = np.asarray(min_vox, np.int32); sz = np.asarray(size_vox, np.int32)
+        out = torch.empty(tuple(int(s) for s in sz), dtype=torch.float32, device="cuda:%d" % self.device)
+        self._check(self.lib.nvbx_esdf_dense_grid(self._h, _np_ptr(mn), _np_ptr(sz), default_value, C.c_void_p(out.data_ptr())))
+        self.synchronize()
+        return out.cpu().numpy()
+
+    def mesh(self):
+        """Mesh of the last update_color_mesh: dict block index tuple -> dict(vertices, normals, colors, triangles)."""
+        nb, nv, nt = C.c_int64(), C.c_int64(), C.c_int64()
+        self._check(self.lib.nvbx_mesh_sizes(self._h, C.byref(nb), C.byref(nv), C.byref(nt)))
+        nb, nv, nt = nb.value, nv.value, nt.value
+        idx = np.zeros((max(nb, 1), 3), np.int32); vo = np.zeros(nb + 1, np.int32); to = np.zeros(nb + 1, np.int32)
+        v = np.zeros((max(nv, 1), 3), np.float32); n = np.zeros((max(nv, 1), 3), np.float32)
+        c = np.zeros((max(nv, 1), 4), np.uint8); t = np.zeros((max(nt, 1), 3), np.int32)
+        self._check(self.lib.nvbx_mesh_copy(self._h, _np_ptr(idx), _np_ptr(vo), _np_ptr(to), _np_ptr(v), _np_ptr(n), _np_ptr(c), _np_ptr(t)))
+        out = {}
+        for i in range(nb):
+            out[tuple(int(q) for q in idx[i])] = dict(vertices=v[vo[i]:vo[i + 1]], normals=n[vo[i]:vo[i + 1]],
+                                                      colors=c[vo[i]:vo[i + 1]], triangles=t[to[i]:to[i + 1]])
+        return out
+
+    # -- multi-GPU hooks
+    def esdf_dirty_list(self):
+        """Device views (torch tensors) of the indices [capacity,3] int32 and count [1] int32 of TSDF blocks dirtied since the last updateEsdf."""
+        torch = self._torch
+        pi, pc, cap = C.c_void_p(), C.c_void_p(), C.c_int64()
+        self._check(self.lib.nvbx_esdf_dirty_list(self._h, C.byref(pi), C.byref(pc), C.byref(cap)))
+        return pi.value, pc.value, cap.value
+
+    def mark_esdf_dirty(self, idx_tensor, count_tensor, max_count):
+        self._check(self.lib.nvbx_mark_esdf_dirty(self._h, C.c_void_p(idx_tensor.data_ptr()), C.c_void_p(count_tensor.data_ptr()), int(max_count)))

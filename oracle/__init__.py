@@ -1,0 +1,225 @@
+"""ctypes binding of the CPU oracle (oracle/nvblox_oracle.c).
+
+TEST INFRASTRUCTURE: importable only from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libnvblox_oracle.so")
+
+L_TSDF, L_COLOR, L_ESDF, L_MESH = 1, 2, 4, 8
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("voxel_size", C.c_float),
+        ("max_integration_distance_m", C.c_float),
+        ("truncation_distance_vox", C.c_float),
+        ("max_weight", C.c_float),
+        ("weighting_mode", C.c_int32),
+        ("raycast_subsampling_factor", C.c_int32),
+        ("esdf_min_weight", C.c_float),
+        ("esdf_max_site_distance_vox", C.c_float),
+        ("esdf_max_distance_m", C.c_float),
+        ("esdf_slice_height", C.c_float),
+        ("esdf_slice_min_height", C.c_float),
+        ("esdf_slice_max_height", C.c_float),
+        ("mesh_min_weight", C.c_float),
+        ("mesh_weld_vertices", C.c_int32),
+        ("sphere_tracing_subsampling", C.c_int32),
+        ("sphere_tracing_max_steps", C.c_int32),
+        ("sphere_tracing_max_ray_length_m", C.c_float),
+        ("sphere_tracing_surface_eps_vox", C.c_float),
+        ("tsdf_decay_factor", C.c_float),
+        ("tsdf_decayed_weight_threshold", C.c_float),
+        ("esdf_site_rule", C.c_int32),
+        ("depth_interp_nearest", C.c_int32),
+    ]
+
+
+def default_params(**kw):
+    """fuser.yaml values (nvblox_examples_bringup/config/nvblox/fuser.yaml:24-42) + nvblox_base.yaml:87,103-107."""
+    p = OrcParams(
+        voxel_size=0.05, max_integration_distance_m=8.0, truncation_distance_vox=4.0, max_weight=5.0,
+        weighting_mode=0, raycast_subsampling_factor=4,
+        esdf_min_weight=0.1, esdf_max_site_distance_vox=2.0, esdf_max_distance_m=2.0,
+        esdf_slice_height=0.09, esdf_slice_min_height=0.09, esdf_slice_max_height=0.65,
+        mesh_min_weight=0.1, mesh_weld_vertices=1,
+        sphere_tracing_subsampling=4, sphere_tracing_max_steps=100,
+        sphere_tracing_max_ray_length_m=15.0, sphere_tracing_surface_eps_vox=0.1,
+        tsdf_decay_factor=0.95, tsdf_decayed_weight_threshold=0.001,
+        esdf_site_rule=0, depth_interp_nearest=0)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "nvblox_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        vp, i32, i64, f32p = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_float)
+        L.orc_create.restype = vp; L.orc_create.argtypes = [C.POINTER(OrcParams)]
+        L.orc_set_params.argtypes = [vp, C.POINTER(OrcParams)]
+        L.orc_destroy.argtypes = [vp]
+        L.orc_num_threads.restype = C.c_int
+        L.orc_index_hash.restype = C.c_uint32; L.orc_index_hash.argtypes = [i32, i32, i32]
+        L.orc_integrate_depth.restype = i64; L.orc_integrate_depth.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+        L.orc_integrate_color.restype = i64; L.orc_integrate_color.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+        L.orc_num_blocks.restype = i64; L.orc_num_blocks.argtypes = [vp, C.c_uint32]
+        L.orc_block_indices.restype = i64; L.orc_block_indices.argtypes = [vp, C.c_uint32, vp, i64]
+        L.orc_last_view.restype = i64; L.orc_last_view.argtypes = [vp, vp, i64]
+        L.orc_last_color_view.restype = i64; L.orc_last_color_view.argtypes = [vp, vp, i64]
+        L.orc_get_block.restype = C.c_int; L.orc_get_block.argtypes = [vp, C.c_uint32, i32, i32, i32, vp]
+        L.orc_set_block.restype = C.c_int; L.orc_set_block.argtypes = [vp, C.c_uint32, i32, i32, i32, vp]
+        L.orc_get_synthetic_depth.restype = C.c_int; L.orc_get_synthetic_depth.argtypes = [vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_update_esdf.restype = i64; L.orc_update_esdf.argtypes = [vp]
+        L.orc_esdf_slice_image.restype = i64
+        L.orc_esdf_slice_image.argtypes = [vp, C.c_float, vp, i64, C.POINTER(i32), C.POINTER(i32), vp]
+        L.orc_esdf_dense_grid.argtypes = [vp, vp, vp, C.c_float, vp]
+        L.orc_update_mesh.restype = i64; L.orc_update_mesh.argtypes = [vp, C.c_int]
+        L.orc_mesh_counts.restype = C.c_int; L.orc_mesh_counts.argtypes = [vp, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+        L.orc_mesh_get.restype = C.c_int; L.orc_mesh_get.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
+        L.orc_decay_tsdf.restype = i64; L.orc_decay_tsdf.argtypes = [vp, C.c_int]
+        L.orc_clear_outside_radius.restype = i64; L.orc_clear_outside_radius.argtypes = [vp, vp, C.c_float]
+        _lib = L
+    return _lib
+
+
+TSDF_DT = np.dtype([("distance", "<f4"), ("weight", "<f4")])
+COLOR_DT = np.dtype([("r", "u1"), ("g", "u1"), ("b", "u1"), ("pad", "u1"), ("weight", "<f4")])
+ESDF_DT = np.dtype([("squared_distance_vox", "<f4"), ("parent_direction", "<i4", (3,)),
+                    ("is_inside", "u1"), ("observed", "u1"), ("is_site", "u1"), ("pad", "u1")])
+_DT = {L_TSDF: TSDF_DT, L_COLOR: COLOR_DT, L_ESDF: ESDF_DT}
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleMap:
+    """CPU oracle of nvblox::Mapper for the hot path (same method names as the C-ABI host mirror)."""
+
+    def __init__(self, params=None):
+        self.params = params or default_params()
+        self._h = lib().orc_create(C.byref(self.params))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_destroy(self._h); self._h = None
+
+    def set_params(self, params):
+        self.params = params
+        lib().orc_set_params(self._h, C.byref(params))
+
+    @staticmethod
+    def _T(T):
+        return np.ascontiguousarray(np.asarray(T, np.float32).reshape(4, 4))
+
+    @staticmethod
+    def _cam(cam):
+        return np.ascontiguousarray(np.asarray(cam, np.float32).reshape(6))
+
+    def integrate_depth(self, depth, T_L_C, cam):
+        depth = np.ascontiguousarray(depth, np.float32)
+        T = self._T(T_L_C); k = self._cam(cam)
+        return lib().orc_integrate_depth(self._h, _p(depth), depth.shape[0], depth.shape[1], _p(T), _p(k))
+
+    def integrate_color(self, rgb, T_L_C, cam):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        assert rgb.ndim == 3 and rgb.shape[2] == 3
+        T = self._T(T_L_C); k = self._cam(cam)
+        return lib().orc_integrate_color(self._h, _p(rgb), rgb.shape[0], rgb.shape[1], _p(T), _p(k))
+
+    def num_blocks(self, layer=L_TSDF):
+        return lib().orc_num_blocks(self._h, layer)
+
+    def block_indices(self, layer=L_TSDF):
+        n = self.num_blocks(layer)
+        out = np.zeros((max(n, 1), 3), np.int32)
+        lib().orc_block_indices(self._h, layer, _p(out), n)
+        return out[:n]
+
+    def last_view(self):
+        out = np.zeros((1 << 20, 3), np.int32)
+        n = lib().orc_last_view(self._h, _p(out), out.shape[0])
+        return out[:n].copy()
+
+    def last_color_view(self):
+        out = np.zeros((1 << 20, 3), np.int32)
+        n = lib().orc_last_color_view(self._h, _p(out), out.shape[0])
+        return out[:n].copy()
+
+    def get_block(self, layer, idx):
+        out = np.zeros(512, _DT[layer])
+        ok = lib().orc_get_block(self._h, layer, int(idx[0]), int(idx[1]), int(idx[2]), _p(out))
+        return out if ok else None
+
+    def set_block(self, layer, idx, data):
+        data = np.ascontiguousarray(data, _DT[layer]); assert data.size == 512
+        return lib().orc_set_block(self._h, layer, int(idx[0]), int(idx[1]), int(idx[2]), _p(data))
+
+    def synthetic_depth(self):
+        r, c = C.c_int(), C.c_int()
+        if not lib().orc_get_synthetic_depth(self._h, None, C.byref(r), C.byref(c)):
+            return None
+        out = np.zeros((r.value, c.value), np.float32)
+        lib().orc_get_synthetic_depth(self._h, _p(out), C.byref(r), C.byref(c))
+        return out
+
+    def update_esdf(self):
+        return lib().orc_update_esdf(self._h)
+
+    def esdf_slice_image(self, unknown_value=1000.0):
+        r, c = C.c_int32(), C.c_int32()
+        aabb = np.zeros(6, np.float32)
+        n = lib().orc_esdf_slice_image(self._h, unknown_value, None, 0, C.byref(r), C.byref(c), _p(aabb))
+        img = np.zeros((r.value, c.value), np.float32)
+        if n:
+            lib().orc_esdf_slice_image(self._h, unknown_value, _p(img), n, C.byref(r), C.byref(c), _p(aabb))
+        return img, aabb
+
+    def esdf_dense_grid(self, min_vox, size_vox, default_value):
+        mn = np.asarray(min_vox, np.int32); sz = np.asarray(size_vox, np.int32)
+        out = np.zeros(tuple(int(s) for s in sz), np.float32)
+        lib().orc_esdf_dense_grid(self._h, _p(mn), _p(sz), default_value, _p(out))
+        return out
+
+    def update_mesh(self, full=False):
+        return lib().orc_update_mesh(self._h, int(full))
+
+    def mesh_block(self, idx):
+        nv, nt = C.c_int32(), C.c_int32()
+        if not lib().orc_mesh_counts(self._h, int(idx[0]), int(idx[1]), int(idx[2]), C.byref(nv), C.byref(nt)):
+            return None
+        v = np.zeros((nv.value, 3), np.float32); n = np.zeros((nv.value, 3), np.float32)
+        c = np.zeros((nv.value, 4), np.uint8); t = np.zeros((nt.value, 3), np.int32)
+        lib().orc_mesh_get(self._h, int(idx[0]), int(idx[1]), int(idx[2]), _p(v), _p(n), _p(c), _p(t))
+        return dict(vertices=v, normals=n, colors=c, triangles=t)
+
+    def decay_tsdf(self, exclude_last_view=True):
+        return lib().orc_decay_tsdf(self._h, int(exclude_last_view))
+
+    def clear_outside_radius(self, center, radius):
+        c = np.asarray(center, np.float32)
+        return lib().orc_clear_outside_radius(self._h, _p(c), float(radius))
+
+
+def num_threads():
+    return lib().orc_num_threads()

@@ -1,0 +1,951 @@
+/*
+ * nvblox_oracle.c -- CPU restatement of the nvblox_core TSDF / Color / ESDF-2D /
+ * Mesh hot path.  TEST INFRASTRUCTURE ONLY: nothing under oracle/ is linked,
+ * imported or executed by the product library (libnvblox_hip.so) or its host
+ * code.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may use it, and only as the checker.
+ *
+ * PARITY STATUS: *unpinned* for TSDF / colour / ESDF propagation / mesh.  The
+ * arithmetic of this path lives in the un-vendored submodule
+ * nvidia-isaac/nvblox (branch `public`, commit not recoverable; contemporaneous
+ * with isaac_ros_nvblox 4.3.0 -- /root/reference/.gitmodules:1-4,
+ * nvblox_ros/package.xml:24).  This file restates the published algorithms of
+ * that module and anchors every data-layout / parameter decision on the
+ * reference's own call sites.  The single golden test the reference holds for
+ * this path (nvblox_ros/test/unit_tests/test_esdf_and_gradient_conversions.cpp:
+ * 36-157) is reproduced in tests/test_kat_esdf_grid.py against orc_esdf_dense_grid().
+ *
+ * Anchors inside /root/reference (file:line):
+ *   block = 8x8x8 voxels, linear index z + 8*y + 64*x ... nvblox_ros/src/lib/layer_publishing.cpp:335,501
+ *   voxel centre = bi*block_size + i*voxel_size + voxel_size/2 ... layer_publishing.cpp:527-529
+ *   block hash x + 17191*y + 17191^2*z (uint32) ... nvblox_rviz_plugin/include/nvblox_rviz_plugin/nvblox_hash_utils.h:40-50
+ *   TsdfVoxel{distance,weight}, ColorVoxel{color,weight}, EsdfVoxel{squared_distance_vox,observed,is_inside,...}
+ *        ... layer_publishing.cpp:62-76,111,179,192; conversions/esdf_and_gradients_conversions.cu:28-48
+ *   Camera(fu,fv,cu,cv,w,h) from K[0],K[4],K[2],K[5] ... conversions/image_conversions.cpp:27-32
+ *   integrator knobs ... mapper_initialization.cpp:231-466; values nvblox_examples_bringup/config/nvblox/fuser.yaml:24-42
+ *   ESDF signed metres = +-sqrt(sq)*voxel_size, default when !observed ... esdf_and_gradients_conversions.cu:33-44
+ *   slice image row=y, col=x, origin aabb.min ... conversions/esdf_slice_conversions.cu:60-64; nvblox_msgs/msg/DistanceMapSlice.msg:9-30
+ *   dense grid linearisation x*(Ny*Nz)+y*Nz+z ... esdf_and_gradients_conversions.cu:110-119
+ *
+ * Floating point: compiled with -ffp-contract=off; every expression below is
+ * written in the evaluation order that DESIGN.md ("numerical contract") fixes
+ * so that the HIP kernels (also contraction-off, IEEE div/sqrt) can be
+ * compared bit-for-bit on indices and to 1e-4 on values.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define VPS 8
+#define NVOX 512
+
+typedef struct { int32_t x, y, z; } Idx3;
+typedef struct { float distance, weight; } TsdfVoxel;
+typedef struct { uint8_t r, g, b, pad; float weight; } ColorVoxel;
+typedef struct { float sq; int32_t parent[3]; uint8_t is_inside, observed, is_site, pad; } EsdfVoxel;
+
+/* Parameter block: mirrors the reference's MapperParams fields that touch this path
+ * (mapper_initialization.cpp:246-380).  Layout shared with tests via ctypes. */
+typedef struct {
+  float voxel_size;
+  float max_integration_distance_m;     /* projective_integrator_max_integration_distance_m */
+  float truncation_distance_vox;        /* projective_integrator_truncation_distance_vox */
+  float max_weight;                     /* projective_integrator_max_weight */
+  int32_t weighting_mode;               /* WeightingFunctionType, mapper_initialization.cpp:31-42 */
+  int32_t raycast_subsampling_factor;   /* view calculator */
+  float esdf_min_weight;                /* esdf_integrator_min_weight */
+  float esdf_max_site_distance_vox;     /* esdf_integrator_max_site_distance_vox */
+  float esdf_max_distance_m;            /* esdf_integrator_max_distance_m */
+  float esdf_slice_height;              /* esdf_slice_height */
+  float esdf_slice_min_height;          /* esdf_slice_min_height */
+  float esdf_slice_max_height;          /* esdf_slice_max_height */
+  float mesh_min_weight;                /* mesh_integrator_min_weight */
+  int32_t mesh_weld_vertices;           /* mesh_integrator_weld_vertices */
+  int32_t sphere_tracing_subsampling;   /* projective_color_integrator sphere-tracing ray subsampling (4) */
+  int32_t sphere_tracing_max_steps;     /* 100 */
+  float sphere_tracing_max_ray_length_m;/* 15 */
+  float sphere_tracing_surface_eps_vox; /* 0.1 */
+  float tsdf_decay_factor;              /* tsdf_decay_factor */
+  float tsdf_decayed_weight_threshold;  /* tsdf_decayed_weight_threshold */
+  int32_t esdf_site_rule;               /* 0: inside && |d|<=max_site (default, [U] recall); 1: |d|<=max_site */
+  int32_t depth_interp_nearest;         /* 0: bilinear-with-validity (default); 1: nearest */
+} OrcParams;
+
+enum { W_CONSTANT = 0, W_CONSTANT_DROPOFF = 1, W_INVERSE_SQUARE = 2, W_INVERSE_SQUARE_DROPOFF = 3,
+       W_INVERSE_SQUARE_TSDF_DISTANCE_PENALTY = 4, W_LINEAR_WITH_MAX = 5 };
+
+typedef struct MeshBlock {
+  int32_t n_vert, n_tri;
+  float* vert;    /* n_vert*3 */
+  float* nrm;     /* n_vert*3 */
+  uint8_t* col;   /* n_vert*4 rgba */
+  int32_t* tri;   /* n_tri*3 */
+} MeshBlock;
+
+typedef struct Block {
+  Idx3 idx;
+  uint32_t flags;         /* bit0 tsdf, bit1 color, bit2 esdf, bit3 mesh */
+  TsdfVoxel* tsdf;        /* [512] */
+  ColorVoxel* color;      /* [512] */
+  EsdfVoxel* esdf;        /* [512] */
+  MeshBlock mesh;
+  int32_t stamp_view, stamp_esdf, dirty_esdf, dirty_mesh, remark_esdf;
+} Block;
+
+enum { L_TSDF = 1, L_COLOR = 2, L_ESDF = 4, L_MESH = 8 };
+
+typedef struct {
+  OrcParams p;
+  Block** table; int64_t cap; int64_t count;   /* open addressing, hash = x + 17191 y + 17191^2 z */
+  Block** order; int64_t order_cap;            /* insertion order */
+  int32_t frame, esdf_epoch;
+  Idx3* view; int64_t n_view, view_cap;        /* blocks in view of last depth frame */
+  Idx3* cview; int64_t n_cview, cview_cap;     /* blocks updated by last colour frame */
+  float* synth; int synth_rows, synth_cols;    /* last synthetic depth image (sphere tracing) */
+} OrcMap;
+
+static const int8_t MC_TRI[256][16] = {
+#include "mc_table.inc"
+};
+
+/* ------------------------------------------------------------------ hashing */
+static inline uint32_t idx_hash(Idx3 i) {
+  /* nvblox_hash_utils.h:43-48: static_cast<unsigned int>(x + y*sl + z*sl2) with size_t arithmetic */
+  const uint64_t sl = 17191ull, sl2 = sl * sl;
+  return (uint32_t)((uint64_t)(int64_t)i.x + (uint64_t)(int64_t)i.y * sl + (uint64_t)(int64_t)i.z * sl2);
+}
+uint32_t orc_index_hash(int32_t x, int32_t y, int32_t z) { Idx3 i = {x, y, z}; return idx_hash(i); }
+
+static Block* map_find(const OrcMap* m, Idx3 i) {
+  if (!m->cap) return NULL;
+  uint64_t h = idx_hash(i) & (uint64_t)(m->cap - 1);
+  for (;;) {
+    Block* b = m->table[h];
+    if (!b) return NULL;
+    if (b->idx.x == i.x && b->idx.y == i.y && b->idx.z == i.z) return b;
+    h = (h + 1) & (uint64_t)(m->cap - 1);
+  }
+}
+static void map_put_raw(OrcMap* m, Block* b) {
+  uint64_t h = idx_hash(b->idx) & (uint64_t)(m->cap - 1);
+  while (m->table[h]) h = (h + 1) & (uint64_t)(m->cap - 1);
+  m->table[h] = b;
+}
+static Block* map_get_or_create(OrcMap* m, Idx3 i) {
+  Block* b = map_find(m, i);
+  if (b) return b;
+  if ((m->count + 1) * 2 > m->cap) {
+    int64_t ncap = m->cap ? m->cap * 2 : 1024;
+    Block** old = m->table; int64_t ocap = m->cap;
+    m->table = (Block**)calloc((size_t)ncap, sizeof(Block*)); m->cap = ncap;
+    for (int64_t k = 0; k < ocap; k++) if (old[k]) map_put_raw(m, old[k]);
+    free(old);
+  }
+  b = (Block*)calloc(1, sizeof(Block));
+  b->idx = i; b->stamp_view = -1; b->stamp_esdf = -1;
+  map_put_raw(m, b);
+  if (m->count + 1 > m->order_cap) {
+    m->order_cap = m->order_cap ? m->order_cap * 2 : 1024;
+    m->order = (Block**)realloc(m->order, (size_t)m->order_cap * sizeof(Block*));
+  }
+  m->order[m->count++] = b;
+  return b;
+}
+static void block_free(Block* b) {
+  free(b->tsdf); free(b->color); free(b->esdf);
+  free(b->mesh.vert); free(b->mesh.nrm); free(b->mesh.col); free(b->mesh.tri);
+  free(b);
+}
+static void map_rebuild(OrcMap* m) { /* after removals: rebuild table from order[] */
+  memset(m->table, 0, (size_t)m->cap * sizeof(Block*));
+  for (int64_t k = 0; k < m->count; k++) map_put_raw(m, m->order[k]);
+}
+static void ensure_layer(Block* b, uint32_t layer) {
+  if (b->flags & layer) return;
+  if (layer == L_TSDF) b->tsdf = (TsdfVoxel*)calloc(NVOX, sizeof(TsdfVoxel));
+  if (layer == L_COLOR) b->color = (ColorVoxel*)calloc(NVOX, sizeof(ColorVoxel));
+  if (layer == L_ESDF) b->esdf = (EsdfVoxel*)calloc(NVOX, sizeof(EsdfVoxel));
+  b->flags |= layer;
+}
+
+OrcMap* orc_create(const OrcParams* p) {
+  OrcMap* m = (OrcMap*)calloc(1, sizeof(OrcMap));
+  m->p = *p;
+  return m;
+}
+void orc_set_params(OrcMap* m, const OrcParams* p) { m->p = *p; }
+void orc_destroy(OrcMap* m) {
+  if (!m) return;
+  for (int64_t k = 0; k < m->count; k++) block_free(m->order[k]);
+  free(m->table); free(m->order); free(m->view); free(m->cview); free(m->synth); free(m);
+}
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------ geometry */
+typedef struct { float r[9]; float t[3]; } Rt;   /* p' = R p + t, R row-major */
+
+/* T is a row-major 4x4 rigid transform T_L_C.  Inverse = (R^T, -(R^T t)). */
+static void rt_from_T(const float* T, Rt* fwd, Rt* inv) {
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) fwd->r[3 * i + j] = T[4 * i + j]; fwd->t[i] = T[4 * i + 3]; }
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) inv->r[3 * i + j] = fwd->r[3 * j + i];
+  for (int i = 0; i < 3; i++) {
+    float s = inv->r[3 * i + 0] * fwd->t[0];
+    s = s + inv->r[3 * i + 1] * fwd->t[1];
+    s = s + inv->r[3 * i + 2] * fwd->t[2];
+    inv->t[i] = -s;
+  }
+}
+static inline void rt_apply(const Rt* a, float x, float y, float z, float* o) {
+  for (int i = 0; i < 3; i++) {
+    float s = a->r[3 * i + 0] * x;
+    s = s + a->r[3 * i + 1] * y;
+    s = s + a->r[3 * i + 2] * z;
+    o[i] = s + a->t[i];
+  }
+}
+static inline void rt_rotate(const Rt* a, float x, float y, float z, float* o) {
+  for (int i = 0; i < 3; i++) {
+    float s = a->r[3 * i + 0] * x;
+    s = s + a->r[3 * i + 1] * y;
+    s = s + a->r[3 * i + 2] * z;
+    o[i] = s;
+  }
+}
+static inline int32_t floor_div8(int32_t v) { return v >> 3; }          /* arithmetic shift = floor division */
+static inline int32_t mod8(int32_t v) { return v & 7; }
+static inline float voxel_center(int32_t bi, int32_t vi, float bs, float vs) {
+  /* layer_publishing.cpp:527: block_index * block_size + x * voxel_size + voxel_size / 2.f */
+  return ((float)bi * bs + (float)vi * vs) + vs * 0.5f;
+}
+
+typedef struct { float fu, fv, cu, cv; int32_t w, h; } Cam;
+static Cam cam_from(const float* c) { Cam k = {c[0], c[1], c[2], c[3], (int32_t)c[4], (int32_t)c[5]}; return k; }
+
+/* Camera::project ([U] nvblox sensors/camera: z<=0 fails, image-plane coords corner-referenced,
+ * in view iff 0<=u<=w, 0<=v<=h) */
+static inline int cam_project(const Cam* k, const float* p, float* u, float* v) {
+  if (p[2] <= 0.0f) return 0;
+  *u = k->fu * (p[0] / p[2]) + k->cu;
+  *v = k->fv * (p[1] / p[2]) + k->cv;
+  if (*u < 0.0f || *v < 0.0f || *u > (float)k->w || *v > (float)k->h) return 0;
+  return 1;
+}
+
+/* interpolate2DLinear with FloatPixelGreaterThanZero ([U] nvblox interpolation_2d): u,v corner-referenced;
+ * subtract 0.5 to get centre-referenced; low pixel = floor; needs low+1 in bounds; all four > 0. */
+static inline int interp_depth(const float* img, int rows, int cols, float u, float v, int nearest, float* out) {
+  if (nearest) {
+    int c = (int)floorf(u), r = (int)floorf(v);
+    if (c < 0 || r < 0 || c >= cols || r >= rows) return 0;
+    float d = img[(int64_t)r * cols + c];
+    if (!(d > 0.0f)) return 0;
+    *out = d; return 1;
+  }
+  float uc = u - 0.5f, vc = v - 0.5f;
+  float fx = floorf(uc), fy = floorf(vc);
+  int x0 = (int)fx, y0 = (int)fy;
+  if (x0 < 0 || y0 < 0 || x0 + 1 > cols - 1 || y0 + 1 > rows - 1) return 0;
+  float ax = uc - fx, ay = vc - fy;
+  float f00 = img[(int64_t)y0 * cols + x0], f10 = img[(int64_t)y0 * cols + x0 + 1];
+  float f01 = img[(int64_t)(y0 + 1) * cols + x0], f11 = img[(int64_t)(y0 + 1) * cols + x0 + 1];
+  if (!(f00 > 0.0f) || !(f10 > 0.0f) || !(f01 > 0.0f) || !(f11 > 0.0f)) return 0;
+  float top = (1.0f - ax) * f00 + ax * f10;
+  float bot = (1.0f - ax) * f01 + ax * f11;
+  *out = (1.0f - ay) * top + ay * bot;
+  return 1;
+}
+
+/* WeightingFunction (mapper_initialization.cpp:31-42 names the six modes; formulas [U]/[D]) */
+static inline float weight_fn(int mode, float d_meas, float d_vox, float trunc) {
+  float w = 1.0f;
+  if (mode == W_INVERSE_SQUARE || mode == W_INVERSE_SQUARE_DROPOFF || mode == W_INVERSE_SQUARE_TSDF_DISTANCE_PENALTY) {
+    w = 1.0f / (d_meas * d_meas);
+  } else if (mode == W_LINEAR_WITH_MAX) {
+    w = 1.0f / d_meas;                       /* [D] linear-in-inverse-depth, capped at 1 (i.e. full weight inside 1 m) */
+    if (w > 1.0f) w = 1.0f;
+  }
+  const float sdf = d_meas - d_vox;
+  if (mode == W_CONSTANT_DROPOFF || mode == W_INVERSE_SQUARE_DROPOFF) {
+    /* 1 in front of the surface, linear ramp to 0 at -trunc behind it */
+    if (sdf < 0.0f) { float f = (trunc + sdf) / trunc; if (f < 0.0f) f = 0.0f; w = w * f; }
+  } else if (mode == W_INVERSE_SQUARE_TSDF_DISTANCE_PENALTY) {
+    /* [D] voxels further than trunc in front of the surface are down-weighted by trunc/sdf */
+    if (sdf > trunc) w = w * (trunc / sdf);
+  }
+  return w;
+}
+
+/* ------------------------------------------------------------------ view calculation */
+/* [U] ViewCalculator::getBlocksInImageViewRaycast restated: one ray per subsampled pixel (overhang clamped to the
+ * border), end point at depth+trunc (clipped to max integration distance), Amanatides-Woo walk through the block grid. */
+static void view_push(OrcMap* m, Idx3 i) {
+  Block* b = map_get_or_create(m, i);
+  if (b->stamp_view == m->frame) return;
+  b->stamp_view = m->frame;
+  ensure_layer(b, L_TSDF);
+  b->dirty_esdf = 1; b->dirty_mesh = 1;
+  if (m->n_view + 1 > m->view_cap) { m->view_cap = m->view_cap ? m->view_cap * 2 : 1024; m->view = (Idx3*)realloc(m->view, (size_t)m->view_cap * sizeof(Idx3)); }
+  m->view[m->n_view++] = i;
+}
+
+static void raycast_blocks(OrcMap* m, const float* o, const float* e, float bs) {
+  float s[3], t[3];
+  int32_t cur[3], end[3], step[3];
+  float tmax[3], tdelta[3];
+  int32_t nsteps = 0;
+  for (int a = 0; a < 3; a++) {
+    s[a] = o[a] / bs; t[a] = e[a] / bs;
+    cur[a] = (int32_t)floorf(s[a]); end[a] = (int32_t)floorf(t[a]);
+    int32_t d = end[a] - cur[a]; nsteps += d < 0 ? -d : d;
+    float ray = t[a] - s[a];
+    step[a] = ray > 0.0f ? 1 : (ray < 0.0f ? -1 : 0);
+    float corrected = step[a] > 0 ? 1.0f : 0.0f;
+    float dist_to_boundary = corrected - (s[a] - (float)cur[a]);
+    if (fabsf(ray) < 1e-9f) { tmax[a] = 2.0f; tdelta[a] = 2.0f; }
+    else { tmax[a] = dist_to_boundary / ray; tdelta[a] = (float)step[a] / ray; }
+  }
+  for (int32_t k = 0; k <= nsteps; k++) {
+    Idx3 i = {cur[0], cur[1], cur[2]};
+    view_push(m, i);
+    int a = 0;
+    if (tmax[1] < tmax[a]) a = 1;
+    if (tmax[2] < tmax[a]) a = 2;
+    cur[a] += step[a];
+    tmax[a] = tmax[a] + tdelta[a];
+  }
+}
+
+static void view_calc(OrcMap* m, const float* depth, int rows, int cols, const Rt* T_L_C, const Cam* k) {
+  const OrcParams* p = &m->p;
+  const float vs = p->voxel_size, bs = vs * 8.0f;
+  const float trunc = p->truncation_distance_vox * vs;
+  const int f = p->raycast_subsampling_factor < 1 ? 1 : p->raycast_subsampling_factor;
+  m->n_view = 0;
+  const float* o = T_L_C->t;
+  /* ray grid: indices i with i*f < rows + f - 1 ; pixel = min(i*f, rows-1) */
+  for (int ri = 0; ri * f < rows + f - 1; ri++) {
+    int prow = ri * f; if (prow >= rows) prow = rows - 1;
+    for (int ci = 0; ci * f < cols + f - 1; ci++) {
+      int pcol = ci * f; if (pcol >= cols) pcol = cols - 1;
+      float d = depth[(int64_t)prow * cols + pcol];
+      if (!(d > 0.0f)) continue;
+      float de = d + trunc;
+      if (p->max_integration_distance_m > 0.0f && de > p->max_integration_distance_m) de = p->max_integration_distance_m;
+      /* vectorFromPixelIndices: pixel centre at +0.5 */
+      float rx = (((float)pcol + 0.5f) - k->cu) / k->fu;
+      float ry = (((float)prow + 0.5f) - k->cv) / k->fv;
+      float pc[3] = {de * rx, de * ry, de};
+      float pl[3];
+      rt_apply(T_L_C, pc[0], pc[1], pc[2], pl);
+      raycast_blocks(m, o, pl, bs);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ TSDF */
+/* [U] ProjectiveTsdfIntegrator::integrateFrame -> integrateBlocksKernel + UpdateTsdfVoxelFunctor restated. */
+static void tsdf_integrate_block(const OrcParams* p, Block* b, const float* depth, int rows, int cols, const Rt* T_C_L, const Cam* k) {
+  const float vs = p->voxel_size, bs = vs * 8.0f;
+  const float trunc = p->truncation_distance_vox * vs;
+  for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) for (int z = 0; z < 8; z++) {
+    float pl[3] = {voxel_center(b->idx.x, x, bs, vs), voxel_center(b->idx.y, y, bs, vs), voxel_center(b->idx.z, z, bs, vs)};
+    float pc[3]; rt_apply(T_C_L, pl[0], pl[1], pl[2], pc);
+    float u, v;
+    if (!cam_project(k, pc, &u, &v)) continue;
+    const float vd = pc[2];
+    if (p->max_integration_distance_m > 0.0f && vd > p->max_integration_distance_m) continue;
+    float ds;
+    if (!interp_depth(depth, rows, cols, u, v, p->depth_interp_nearest, &ds)) continue;
+    const float sdf = ds - vd;
+    if (sdf < -trunc) continue;
+    TsdfVoxel* vx = &b->tsdf[z + 8 * y + 64 * x];
+    const float wm = weight_fn(p->weighting_mode, ds, vd, trunc);
+    const float wsum = wm + vx->weight;
+    if (!(wsum > 0.0f)) continue;
+    float fused = (sdf * wm + vx->distance * vx->weight) / wsum;
+    if (fused > 0.0f) fused = fminf(trunc, fused); else fused = fmaxf(-trunc, fused);
+    vx->distance = fused;
+    vx->weight = fminf(wsum, p->max_weight);
+  }
+}
+
+int64_t orc_integrate_depth(OrcMap* m, const float* depth, int rows, int cols, const float* T_L_C16, const float* cam6) {
+  Rt T_L_C, T_C_L; rt_from_T(T_L_C16, &T_L_C, &T_C_L);
+  Cam k = cam_from(cam6);
+  m->frame++;
+  view_calc(m, depth, rows, cols, &T_L_C, &k);
+  const int64_t n = m->n_view;
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int64_t i = 0; i < n; i++) {
+    Block* b = map_find(m, m->view[i]);
+    tsdf_integrate_block(&m->p, b, depth, rows, cols, &T_C_L, &k);
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------ accessors */
+static int idx_cmp(const void* a, const void* b) {
+  const Idx3* p = (const Idx3*)a; const Idx3* q = (const Idx3*)b;
+  if (p->x != q->x) return p->x < q->x ? -1 : 1;
+  if (p->y != q->y) return p->y < q->y ? -1 : 1;
+  if (p->z != q->z) return p->z < q->z ? -1 : 1;
+  return 0;
+}
+int64_t orc_num_blocks(const OrcMap* m, uint32_t layer) {
+  int64_t n = 0;
+  for (int64_t k = 0; k < m->count; k++) if (m->order[k]->flags & layer) n++;
+  return n;
+}
+/* sorted (x,y,z) lexicographic */
+int64_t orc_block_indices(const OrcMap* m, uint32_t layer, int32_t* out, int64_t cap) {
+  int64_t n = 0;
+  for (int64_t k = 0; k < m->count; k++) if (m->order[k]->flags & layer) {
+    if (n < cap) { out[3 * n] = m->order[k]->idx.x; out[3 * n + 1] = m->order[k]->idx.y; out[3 * n + 2] = m->order[k]->idx.z; }
+    n++;
+  }
+  qsort(out, (size_t)(n < cap ? n : cap), sizeof(Idx3), idx_cmp);
+  return n;
+}
+int64_t orc_last_view(const OrcMap* m, int32_t* out, int64_t cap) {
+  int64_t n = m->n_view < cap ? m->n_view : cap;
+  memcpy(out, m->view, (size_t)n * sizeof(Idx3));
+  qsort(out, (size_t)n, sizeof(Idx3), idx_cmp);
+  return m->n_view;
+}
+int64_t orc_last_color_view(const OrcMap* m, int32_t* out, int64_t cap) {
+  int64_t n = m->n_cview < cap ? m->n_cview : cap;
+  memcpy(out, m->cview, (size_t)n * sizeof(Idx3));
+  qsort(out, (size_t)n, sizeof(Idx3), idx_cmp);
+  return m->n_cview;
+}
+/* copy a block out in the reference's voxel struct layout, index z + 8y + 64x */
+int orc_get_block(const OrcMap* m, uint32_t layer, int32_t x, int32_t y, int32_t z, void* out) {
+  Idx3 i = {x, y, z};
+  Block* b = map_find(m, i);
+  if (!b || !(b->flags & layer)) return 0;
+  if (layer == L_TSDF) memcpy(out, b->tsdf, NVOX * sizeof(TsdfVoxel));
+  else if (layer == L_COLOR) memcpy(out, b->color, NVOX * sizeof(ColorVoxel));
+  else if (layer == L_ESDF) memcpy(out, b->esdf, NVOX * sizeof(EsdfVoxel));
+  else return 0;
+  return 1;
+}
+/* allocateBlockAtIndex + voxel write (used by the known-answer test, test_esdf_and_gradient_conversions.cpp:85-92,114) */
+int orc_set_block(OrcMap* m, uint32_t layer, int32_t x, int32_t y, int32_t z, const void* in) {
+  Idx3 i = {x, y, z};
+  Block* b = map_get_or_create(m, i);
+  ensure_layer(b, layer);
+  if (layer == L_TSDF) { memcpy(b->tsdf, in, NVOX * sizeof(TsdfVoxel)); b->dirty_esdf = 1; b->dirty_mesh = 1; }
+  else if (layer == L_COLOR) memcpy(b->color, in, NVOX * sizeof(ColorVoxel));
+  else if (layer == L_ESDF) memcpy(b->esdf, in, NVOX * sizeof(EsdfVoxel));
+  else return 0;
+  return 1;
+}
+
+/* ------------------------------------------------------------------ colour */
+static inline const TsdfVoxel* tsdf_at_position(const OrcMap* m, const float* pl, float vs) {
+  int32_t gx = (int32_t)floorf(pl[0] / vs), gy = (int32_t)floorf(pl[1] / vs), gz = (int32_t)floorf(pl[2] / vs);
+  Idx3 bi = {floor_div8(gx), floor_div8(gy), floor_div8(gz)};
+  Block* b = map_find(m, bi);
+  if (!b || !(b->flags & L_TSDF)) return NULL;
+  return &b->tsdf[mod8(gz) + 8 * mod8(gy) + 64 * mod8(gx)];
+}
+
+/* [U] SphereTracer::cast restated.  Returns 1 and *t_out on success. */
+static int sphere_cast(const OrcMap* m, const float* o, const float* dir, float trunc, float eps_m, int max_steps, float max_len, float* t_out) {
+  const float vs = m->p.voxel_size;
+  int last_positive = 0;
+  float t = 0.0f;
+  for (int i = 0; i < max_steps && t < max_len; i++) {
+    float pl[3] = {o[0] + t * dir[0], o[1] + t * dir[1], o[2] + t * dir[2]};
+    const TsdfVoxel* v = tsdf_at_position(m, pl, vs);
+    float step;
+    if (!v || !(v->weight > 1e-4f)) {
+      if (!last_positive) step = trunc;
+      else return 0;
+    } else {
+      if (v->distance < eps_m) {
+        if (last_positive) { *t_out = t + v->distance; return 1; }
+        return 0;
+      }
+      step = v->distance; last_positive = 1;
+    }
+    t = t + step;
+  }
+  return 0;
+}
+
+static void render_synthetic_depth(OrcMap* m, const Rt* T_L_C, const Cam* k, int rows, int cols) {
+  const OrcParams* p = &m->p;
+  const int f = p->sphere_tracing_subsampling < 1 ? 1 : p->sphere_tracing_subsampling;
+  const int srows = rows / f, scols = cols / f;
+  const float trunc = p->truncation_distance_vox * p->voxel_size;
+  const float eps_m = p->sphere_tracing_surface_eps_vox * p->voxel_size;
+  free(m->synth);
+  m->synth = (float*)calloc((size_t)srows * scols, sizeof(float));
+  m->synth_rows = srows; m->synth_cols = scols;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int r = 0; r < srows; r++) for (int c = 0; c < scols; c++) {
+    /* ray through the centre of full-res pixel (c*f, r*f) */
+    float rx = (((float)(c * f) + 0.5f) - k->cu) / k->fu;
+    float ry = (((float)(r * f) + 0.5f) - k->cv) / k->fv;
+    float n = sqrtf((rx * rx + ry * ry) + 1.0f);
+    float dc[3] = {rx / n, ry / n, 1.0f / n};
+    float dl[3]; rt_rotate(T_L_C, dc[0], dc[1], dc[2], dl);
+    float t;
+    if (sphere_cast(m, T_L_C->t, dl, trunc, eps_m, p->sphere_tracing_max_steps, p->sphere_tracing_max_ray_length_m, &t))
+      m->synth[(int64_t)r * scols + c] = t * dc[2];     /* depth = z component of the hit in C */
+  }
+}
+
+/* conservative frustum test: reject iff all 8 block corners are outside one of the 6 planes (in camera frame) */
+static int block_in_frustum(Idx3 bi, float bs, const Rt* T_C_L, const Cam* k, float max_d) {
+  int out[6] = {0, 0, 0, 0, 0, 0};
+  for (int c = 0; c < 8; c++) {
+    float pl[3] = {(float)(bi.x + (c & 1)) * bs, (float)(bi.y + ((c >> 1) & 1)) * bs, (float)(bi.z + ((c >> 2) & 1)) * bs};
+    float pc[3]; rt_apply(T_C_L, pl[0], pl[1], pl[2], pc);
+    if (k->fu * pc[0] + k->cu * pc[2] < 0.0f) out[0]++;
+    if (k->fu * pc[0] + (k->cu - (float)k->w) * pc[2] > 0.0f) out[1]++;
+    if (k->fv * pc[1] + k->cv * pc[2] < 0.0f) out[2]++;
+    if (k->fv * pc[1] + (k->cv - (float)k->h) * pc[2] > 0.0f) out[3]++;
+    if (pc[2] < 0.0f) out[4]++;
+    if (max_d > 0.0f && pc[2] > max_d) out[5]++;
+  }
+  for (int q = 0; q < 6; q++) if (out[q] == 8) return 0;
+  return 1;
+}
+static int block_in_band(const Block* b, float trunc) {
+  for (int i = 0; i < NVOX; i++) if (b->tsdf[i].weight > 1e-4f && fabsf(b->tsdf[i].distance) < trunc) return 1;
+  return 0;
+}
+static inline uint8_t blend_u8(float c0, float w0, float c1, float w1) {
+  /* Color::blendTwoColors [U]: normalise weights, blend, round-half-away */
+  float tw = w0 + w1;
+  float a = w0 / tw, b = w1 / tw;
+  float v = c0 * a + c1 * b;
+  v = floorf(v + 0.5f);
+  if (v < 0.0f) v = 0.0f; if (v > 255.0f) v = 255.0f;
+  return (uint8_t)v;
+}
+static int interp_color(const uint8_t* img, int rows, int cols, float u, float v, float* rgb) {
+  float uc = u - 0.5f, vc = v - 0.5f;
+  float fx = floorf(uc), fy = floorf(vc);
+  int x0 = (int)fx, y0 = (int)fy;
+  if (x0 < 0 || y0 < 0 || x0 + 1 > cols - 1 || y0 + 1 > rows - 1) return 0;
+  float ax = uc - fx, ay = vc - fy;
+  for (int ch = 0; ch < 3; ch++) {
+    float f00 = img[((int64_t)y0 * cols + x0) * 3 + ch], f10 = img[((int64_t)y0 * cols + x0 + 1) * 3 + ch];
+    float f01 = img[((int64_t)(y0 + 1) * cols + x0) * 3 + ch], f11 = img[((int64_t)(y0 + 1) * cols + x0 + 1) * 3 + ch];
+    float top = (1.0f - ax) * f00 + ax * f10;
+    float bot = (1.0f - ax) * f01 + ax * f11;
+    rgb[ch] = (1.0f - ay) * top + ay * bot;
+  }
+  return 1;
+}
+
+/* [U] ProjectiveColorIntegrator::integrateFrame restated: blocks = allocated TSDF blocks in frustum and in the
+ * truncation band; synthetic depth by sphere tracing at 1/f resolution; per voxel occlusion test
+ * |synthetic - voxel_depth| <= trunc; bilinear colour; weight 1 blend; weight clamp at max_weight. */
+int64_t orc_integrate_color(OrcMap* m, const uint8_t* rgb, int rows, int cols, const float* T_L_C16, const float* cam6) {
+  Rt T_L_C, T_C_L; rt_from_T(T_L_C16, &T_L_C, &T_C_L);
+  Cam k = cam_from(cam6);
+  const OrcParams* p = &m->p;
+  const float vs = p->voxel_size, bs = vs * 8.0f;
+  const float trunc = p->truncation_distance_vox * vs;
+  const int f = p->sphere_tracing_subsampling < 1 ? 1 : p->sphere_tracing_subsampling;
+  render_synthetic_depth(m, &T_L_C, &k, rows, cols);
+  m->n_cview = 0;
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    if (!(b->flags & L_TSDF)) continue;
+    if (!block_in_frustum(b->idx, bs, &T_C_L, &k, p->max_integration_distance_m)) continue;
+    if (!block_in_band(b, trunc)) continue;
+    ensure_layer(b, L_COLOR);
+    b->dirty_mesh = 1;
+    if (m->n_cview + 1 > m->cview_cap) { m->cview_cap = m->cview_cap ? m->cview_cap * 2 : 1024; m->cview = (Idx3*)realloc(m->cview, (size_t)m->cview_cap * sizeof(Idx3)); }
+    m->cview[m->n_cview++] = b->idx;
+  }
+  const int64_t n = m->n_cview;
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int64_t i = 0; i < n; i++) {
+    Block* b = map_find(m, m->cview[i]);
+    for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) for (int z = 0; z < 8; z++) {
+      float pl[3] = {voxel_center(b->idx.x, x, bs, vs), voxel_center(b->idx.y, y, bs, vs), voxel_center(b->idx.z, z, bs, vs)};
+      float pc[3]; rt_apply(&T_C_L, pl[0], pl[1], pl[2], pc);
+      float u, v;
+      if (!cam_project(&k, pc, &u, &v)) continue;
+      const float vd = pc[2];
+      if (p->max_integration_distance_m > 0.0f && vd > p->max_integration_distance_m) continue;
+      float sd;
+      if (!interp_depth(m->synth, m->synth_rows, m->synth_cols, u / (float)f, v / (float)f, 0, &sd)) continue;
+      if (fabsf(sd - vd) > trunc) continue;
+      float c[3];
+      if (!interp_color(rgb, rows, cols, u, v, c)) continue;
+      ColorVoxel* cv = &b->color[z + 8 * y + 64 * x];
+      const float w0 = cv->weight;
+      cv->r = blend_u8((float)cv->r, w0, c[0], 1.0f);
+      cv->g = blend_u8((float)cv->g, w0, c[1], 1.0f);
+      cv->b = blend_u8((float)cv->b, w0, c[2], 1.0f);
+      cv->weight = fminf(w0 + 1.0f, p->max_weight);
+    }
+  }
+  return n;
+}
+int orc_get_synthetic_depth(const OrcMap* m, float* out, int* rows, int* cols) {
+  *rows = m->synth_rows; *cols = m->synth_cols;
+  if (out && m->synth) memcpy(out, m->synth, (size_t)m->synth_rows * m->synth_cols * sizeof(float));
+  return m->synth != NULL;
+}
+
+/* ------------------------------------------------------------------ ESDF (2-D slice) */
+typedef struct { int32_t kz_min, kz_max, kz_out, ri; float max_sq, site_dist_m; } EsdfCfg;
+static EsdfCfg esdf_cfg(const OrcParams* p) {
+  EsdfCfg c;
+  const float vs = p->voxel_size;
+  c.kz_min = (int32_t)floorf(p->esdf_slice_min_height / vs);
+  c.kz_max = (int32_t)floorf(p->esdf_slice_max_height / vs);
+  c.kz_out = (int32_t)floorf(p->esdf_slice_height / vs);
+  float r = p->esdf_max_distance_m / vs;
+  c.max_sq = r * r;
+  c.ri = (int32_t)floorf(r);
+  c.site_dist_m = p->esdf_max_site_distance_vox * vs;
+  return c;
+}
+
+/* Exact 2-D Euclidean distance transform of the slice with cut-off: row pass (nearest site along x, ties -> -x),
+ * column pass (dy ascending, strict improvement).  Restates what [U] EsdfIntegrator's sweep/propagate loop
+ * converges to on a convex allocated region; DESIGN.md "ESDF semantics" states the difference elsewhere. */
+int64_t orc_update_esdf(OrcMap* m) {
+  const OrcParams* p = &m->p;
+  const EsdfCfg c = esdf_cfg(p);
+  const int32_t bz_out = floor_div8(c.kz_out), vz_out = mod8(c.kz_out);
+  const int32_t bz_lo = floor_div8(c.kz_min), bz_hi = floor_div8(c.kz_max);
+  /* 1. allocate + mark sites for dirty TSDF columns intersecting the z band; columns whose TSDF block was
+   *    deallocated (decay) are re-marked if their ESDF block exists */
+  int64_t n_dirty = 0;
+  const int64_t count0 = m->count;
+  for (int64_t q = 0; q < count0; q++) {
+    Block* tb = m->order[q];
+    int want = 0;
+    if ((tb->flags & L_TSDF) && tb->dirty_esdf) { tb->dirty_esdf = 0; if (tb->idx.z >= bz_lo && tb->idx.z <= bz_hi) want = 1; }
+    if (tb->remark_esdf) { tb->remark_esdf = 0; want = 2; }
+    if (!want) continue;
+    Idx3 ei = {tb->idx.x, tb->idx.y, bz_out};
+    Block* eb = want == 1 ? map_get_or_create(m, ei) : map_find(m, ei);
+    if (!eb) continue;
+    if (want == 2 && !(eb->flags & L_ESDF)) continue;
+    ensure_layer(eb, L_ESDF);
+    if (eb->stamp_esdf == m->esdf_epoch) continue;   /* column already re-marked in this update */
+    eb->stamp_esdf = m->esdf_epoch;
+    n_dirty++;
+    for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) {
+      int observed = 0, inside = 0, site = 0;
+      for (int32_t kz = c.kz_min; kz <= c.kz_max; kz++) {
+        Idx3 ti = {ei.x, ei.y, floor_div8(kz)};
+        Block* b = map_find(m, ti);
+        if (!b || !(b->flags & L_TSDF)) continue;
+        const TsdfVoxel* tv = &b->tsdf[mod8(kz) + 8 * y + 64 * x];
+        if (tv->weight >= p->esdf_min_weight) {
+          observed = 1;
+          const int in = tv->distance <= 0.0f;
+          if (in) inside = 1;
+          if ((p->esdf_site_rule == 1 || in) && fabsf(tv->distance) <= c.site_dist_m) site = 1;
+        }
+      }
+      EsdfVoxel* ev = &eb->esdf[vz_out + 8 * y + 64 * x];
+      ev->observed = (uint8_t)observed; ev->is_inside = (uint8_t)inside; ev->is_site = (uint8_t)site;
+    }
+  }
+  m->esdf_epoch++;
+  /* 2. exact EDT over all ESDF blocks of the slice (the HIP path windows this; result identical) */
+  int32_t bx0 = INT32_MAX, bx1 = INT32_MIN, by0 = INT32_MAX, by1 = INT32_MIN;
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    if (!(b->flags & L_ESDF) || b->idx.z != bz_out) continue;
+    if (b->idx.x < bx0) bx0 = b->idx.x; if (b->idx.x > bx1) bx1 = b->idx.x;
+    if (b->idx.y < by0) by0 = b->idx.y; if (b->idx.y > by1) by1 = b->idx.y;
+  }
+  if (bx0 > bx1) return 0;
+  const int64_t W = (int64_t)(bx1 - bx0 + 1) * 8, H = (int64_t)(by1 - by0 + 1) * 8;
+  uint8_t* site = (uint8_t*)calloc((size_t)(W * H), 1);
+  int16_t* rowdx = (int16_t*)malloc((size_t)(W * H) * sizeof(int16_t));
+  const int16_t NONE = 32767;
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    if (!(b->flags & L_ESDF) || b->idx.z != bz_out) continue;
+    for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++)
+      site[((int64_t)(b->idx.y - by0) * 8 + y) * W + (int64_t)(b->idx.x - bx0) * 8 + x] = b->esdf[vz_out + 8 * y + 64 * x].is_site;
+  }
+#pragma omp parallel for
+  for (int64_t y = 0; y < H; y++) for (int64_t x = 0; x < W; x++) {
+    int16_t best = NONE;
+    for (int32_t d = 0; d <= c.ri; d++) {
+      if (x - d >= 0 && site[y * W + x - d]) { best = (int16_t)(-d); break; }
+      if (x + d < W && site[y * W + x + d]) { best = (int16_t)d; break; }
+    }
+    rowdx[y * W + x] = best;
+  }
+#pragma omp parallel for
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    if (!(b->flags & L_ESDF) || b->idx.z != bz_out) continue;
+    for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) {
+      const int64_t gx = (int64_t)(b->idx.x - bx0) * 8 + x, gy = (int64_t)(b->idx.y - by0) * 8 + y;
+      int32_t best_sq = INT32_MAX, bdx = 0, bdy = 0;
+      for (int32_t dy = -c.ri; dy <= c.ri; dy++) {
+        const int64_t yy = gy + dy;
+        if (yy < 0 || yy >= H) continue;
+        const int16_t dx = rowdx[yy * W + gx];
+        if (dx == NONE) continue;
+        const int32_t sq = dy * dy + (int32_t)dx * dx;
+        if (sq < best_sq) { best_sq = sq; bdx = dx; bdy = dy; }
+      }
+      EsdfVoxel* ev = &b->esdf[vz_out + 8 * y + 64 * x];
+      if (best_sq != INT32_MAX && (float)best_sq <= c.max_sq) {
+        ev->sq = (float)best_sq; ev->parent[0] = bdx; ev->parent[1] = bdy; ev->parent[2] = 0;
+      } else {
+        ev->sq = c.max_sq; ev->parent[0] = 0; ev->parent[1] = 0; ev->parent[2] = 0;
+      }
+    }
+  }
+  free(site); free(rowdx);
+  return n_dirty;
+}
+
+/* [U] EsdfSlicer::sliceLayerToDistanceImage: AABB of allocated ESDF blocks -> rows x cols image, row=y col=x,
+ * value = signed metres (esdf_and_gradients_conversions.cu:33-44 functor) or unknown_value.
+ * aabb6 = min xyz, max xyz in metres.  Returns rows*cols (0 if no blocks); writes image if cap suffices. */
+int64_t orc_esdf_slice_image(const OrcMap* m, float unknown_value, float* img, int64_t cap, int32_t* rows, int32_t* cols, float* aabb6) {
+  const OrcParams* p = &m->p;
+  const EsdfCfg c = esdf_cfg(p);
+  const float vs = p->voxel_size, bs = vs * 8.0f;
+  const int32_t bz_out = floor_div8(c.kz_out), vz_out = mod8(c.kz_out);
+  int32_t bx0 = INT32_MAX, bx1 = INT32_MIN, by0 = INT32_MAX, by1 = INT32_MIN;
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    if (!(b->flags & L_ESDF) || b->idx.z != bz_out) continue;
+    if (b->idx.x < bx0) bx0 = b->idx.x; if (b->idx.x > bx1) bx1 = b->idx.x;
+    if (b->idx.y < by0) by0 = b->idx.y; if (b->idx.y > by1) by1 = b->idx.y;
+  }
+  if (bx0 > bx1) { *rows = 0; *cols = 0; return 0; }
+  const int64_t W = (int64_t)(bx1 - bx0 + 1) * 8, H = (int64_t)(by1 - by0 + 1) * 8;
+  *rows = (int32_t)H; *cols = (int32_t)W;
+  aabb6[0] = (float)bx0 * bs; aabb6[1] = (float)by0 * bs; aabb6[2] = (float)bz_out * bs;
+  aabb6[3] = (float)(bx1 + 1) * bs; aabb6[4] = (float)(by1 + 1) * bs; aabb6[5] = (float)(bz_out + 1) * bs;
+  if (W * H > cap) return W * H;
+  for (int64_t i = 0; i < W * H; i++) img[i] = unknown_value;
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    if (!(b->flags & L_ESDF) || b->idx.z != bz_out) continue;
+    for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) {
+      const EsdfVoxel* ev = &b->esdf[vz_out + 8 * y + 64 * x];
+      if (!ev->observed) continue;
+      float d = sqrtf(ev->sq) * vs;
+      if (ev->is_inside) d = -d;
+      img[((int64_t)(b->idx.y - by0) * 8 + y) * W + (int64_t)(b->idx.x - bx0) * 8 + x] = d;
+    }
+  }
+  return W * H;
+}
+
+/* voxelLayerToDenseVoxelGridInAABB<SignedDistanceFunctor> restated (esdf_and_gradients_conversions.cu:28-48,88-125):
+ * min_vox / size_vox give the AABB in global voxel indices; out[x*(Ny*Nz) + y*Nz + z]. */
+void orc_esdf_dense_grid(const OrcMap* m, const int32_t* min_vox, const int32_t* size_vox, float default_value, float* out) {
+  const float vs = m->p.voxel_size;
+  for (int32_t x = 0; x < size_vox[0]; x++) for (int32_t y = 0; y < size_vox[1]; y++) for (int32_t z = 0; z < size_vox[2]; z++) {
+    const int32_t gx = min_vox[0] + x, gy = min_vox[1] + y, gz = min_vox[2] + z;
+    Idx3 bi = {floor_div8(gx), floor_div8(gy), floor_div8(gz)};
+    const Block* b = map_find(m, bi);
+    float v = default_value;
+    if (b && (b->flags & L_ESDF)) {
+      const EsdfVoxel* ev = &b->esdf[mod8(gz) + 8 * mod8(gy) + 64 * mod8(gx)];
+      if (ev->observed) { v = sqrtf(ev->sq) * vs; if (ev->is_inside) v = v * -1.0f; }
+    }
+    out[((int64_t)x * size_vox[1] + y) * size_vox[2] + z] = v;
+  }
+}
+
+/* ------------------------------------------------------------------ mesh (marching cubes) */
+static const int8_t MC_CORNER[8][3] = {{0,0,0},{1,0,0},{1,1,0},{0,1,0},{0,0,1},{1,0,1},{1,1,1},{0,1,1}};
+/* edge -> (lower lattice corner offset, axis) */
+static const int8_t MC_EDGE_BASE[12][3] = {{0,0,0},{1,0,0},{0,1,0},{0,0,0},{0,0,1},{1,0,1},{0,1,1},{0,0,1},{0,0,0},{1,0,0},{1,1,0},{0,1,0}};
+static const int8_t MC_EDGE_AXIS[12] = {0,1,0,1,0,1,0,1,2,2,2,2};
+
+/* [U] MeshIntegrator restated: per block, 8^3 cubes whose 8 corners are the voxel centres (own + +x/+y/+z neighbour
+ * blocks); cube skipped if any corner weight < min_weight or neighbour missing; vertices live on lattice edges
+ * (lattice corner, axis) so welding = one vertex per crossed edge.  Ordering contract: vertices ascending edge id
+ * ((lx*9+ly)*9+lz)*3+axis; triangles in voxel order x-major (x,y,z loops) then table order.  Normal of a welded
+ * vertex = normal of the first triangle that references it; colour = colour voxel nearest the vertex (gray 127 if none). */
+static int mesh_block(OrcMap* m, Block* b) {
+  const OrcParams* p = &m->p;
+  const float vs = p->voxel_size, bs = vs * 8.0f;
+  static const int L = 9;
+  float d[9 * 9 * 9], w[9 * 9 * 9];
+  uint8_t has[9 * 9 * 9];
+  const ColorVoxel* cptr[9 * 9 * 9];
+  Block* nb[8];
+  for (int n = 0; n < 8; n++) {
+    Idx3 ni = {b->idx.x + (n & 1), b->idx.y + ((n >> 1) & 1), b->idx.z + ((n >> 2) & 1)};
+    nb[n] = map_find(m, ni);
+    if (nb[n] && !(nb[n]->flags & L_TSDF)) nb[n] = NULL;
+  }
+  for (int x = 0; x < L; x++) for (int y = 0; y < L; y++) for (int z = 0; z < L; z++) {
+    const int n = (x >> 3) | ((y >> 3) << 1) | ((z >> 3) << 2);
+    const int li = (x * L + y) * L + z;
+    if (!nb[n]) { has[li] = 0; d[li] = 0; w[li] = 0; cptr[li] = NULL; continue; }
+    const int vi = (z & 7) + 8 * (y & 7) + 64 * (x & 7);
+    has[li] = 1; d[li] = nb[n]->tsdf[vi].distance; w[li] = nb[n]->tsdf[vi].weight;
+    cptr[li] = (nb[n]->flags & L_COLOR) ? &nb[n]->color[vi] : NULL;
+  }
+  int32_t* edge_vid = (int32_t*)malloc(sizeof(int32_t) * 9 * 9 * 9 * 3);
+  int32_t* edge_first_tri = (int32_t*)malloc(sizeof(int32_t) * 9 * 9 * 9 * 3);
+  for (int i = 0; i < 9 * 9 * 9 * 3; i++) { edge_vid[i] = -1; edge_first_tri[i] = -1; }
+  int32_t* tri_edges = (int32_t*)malloc(sizeof(int32_t) * 512 * 5 * 3);
+  int32_t ntri = 0;
+  for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) for (int z = 0; z < 8; z++) {
+    int cube = 0, ok = 1;
+    for (int c = 0; c < 8; c++) {
+      const int li = ((x + MC_CORNER[c][0]) * L + (y + MC_CORNER[c][1])) * L + (z + MC_CORNER[c][2]);
+      if (!has[li] || !(w[li] >= p->mesh_min_weight)) { ok = 0; break; }
+      if (d[li] < 0.0f) cube |= 1 << c;
+    }
+    if (!ok || cube == 0 || cube == 255) continue;
+    for (int t = 0; MC_TRI[cube][t] >= 0; t += 3) {
+      for (int q = 0; q < 3; q++) {
+        const int e = MC_TRI[cube][t + q];
+        const int eid = (((x + MC_EDGE_BASE[e][0]) * L + (y + MC_EDGE_BASE[e][1])) * L + (z + MC_EDGE_BASE[e][2])) * 3 + MC_EDGE_AXIS[e];
+        tri_edges[3 * ntri + q] = eid;
+        if (edge_first_tri[eid] < 0) edge_first_tri[eid] = ntri;
+      }
+      ntri++;
+    }
+  }
+  /* vertices in ascending edge id */
+  int32_t nvert = 0;
+  for (int eid = 0; eid < 9 * 9 * 9 * 3; eid++) if (edge_first_tri[eid] >= 0) edge_vid[eid] = nvert++;
+  MeshBlock* mb = &b->mesh;
+  free(mb->vert); free(mb->nrm); free(mb->col); free(mb->tri);
+  mb->n_vert = nvert; mb->n_tri = ntri;
+  mb->vert = (float*)calloc((size_t)(nvert ? nvert : 1) * 3, sizeof(float));
+  mb->nrm = (float*)calloc((size_t)(nvert ? nvert : 1) * 3, sizeof(float));
+  mb->col = (uint8_t*)calloc((size_t)(nvert ? nvert : 1) * 4, 1);
+  mb->tri = (int32_t*)calloc((size_t)(ntri ? ntri : 1) * 3, sizeof(int32_t));
+  for (int eid = 0; eid < 9 * 9 * 9 * 3; eid++) {
+    const int32_t v = edge_vid[eid];
+    if (v < 0) continue;
+    const int axis = eid % 3; const int li = eid / 3;
+    const int lz = li % 9, ly = (li / 9) % 9, lx = li / 81;
+    const int lj = li + (axis == 0 ? 81 : (axis == 1 ? 9 : 1));
+    const float da = d[li], db = d[lj];
+    const float t = da / (da - db);
+    const int32_t l3[3] = {lx, ly, lz};
+    const int32_t b3[3] = {b->idx.x, b->idx.y, b->idx.z};
+    for (int a = 0; a < 3; a++) {
+      float pos = ((float)b3[a] * bs + (float)l3[a] * vs) + vs * 0.5f;
+      if (a == axis) pos = pos + t * vs;
+      mb->vert[3 * v + a] = pos;
+    }
+    const ColorVoxel* cv = (t < 0.5f) ? cptr[li] : cptr[lj];
+    if (cv && cv->weight > 0.0f) { mb->col[4 * v] = cv->r; mb->col[4 * v + 1] = cv->g; mb->col[4 * v + 2] = cv->b; }
+    else { mb->col[4 * v] = 127; mb->col[4 * v + 1] = 127; mb->col[4 * v + 2] = 127; }
+    mb->col[4 * v + 3] = 255;
+  }
+  for (int32_t t = 0; t < ntri; t++) for (int q = 0; q < 3; q++) mb->tri[3 * t + q] = edge_vid[tri_edges[3 * t + q]];
+  for (int eid = 0; eid < 9 * 9 * 9 * 3; eid++) {
+    const int32_t v = edge_vid[eid];
+    if (v < 0) continue;
+    const int32_t t = edge_first_tri[eid];
+    const float* p0 = &mb->vert[3 * mb->tri[3 * t]]; const float* p1 = &mb->vert[3 * mb->tri[3 * t + 1]]; const float* p2 = &mb->vert[3 * mb->tri[3 * t + 2]];
+    const float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const float len = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+    if (len > 0.0f) { n[0] = n[0] / len; n[1] = n[1] / len; n[2] = n[2] / len; }
+    mb->nrm[3 * v] = n[0]; mb->nrm[3 * v + 1] = n[1]; mb->nrm[3 * v + 2] = n[2];
+  }
+  free(edge_vid); free(edge_first_tri); free(tri_edges);
+  b->flags |= L_MESH;
+  return ntri;
+}
+
+/* Mapper::updateColorMesh(UpdateFullLayer) restated at call-site level (layer_publishing.cpp:686-689). Returns #blocks meshed. */
+int64_t orc_update_mesh(OrcMap* m, int full) {
+  int64_t n = 0;
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    if (!(b->flags & L_TSDF)) continue;
+    if (!full && !b->dirty_mesh) continue;
+    b->dirty_mesh = 0;
+    mesh_block(m, b);
+    n++;
+  }
+  return n;
+}
+int orc_mesh_counts(const OrcMap* m, int32_t x, int32_t y, int32_t z, int32_t* n_vert, int32_t* n_tri) {
+  Idx3 i = {x, y, z}; Block* b = map_find(m, i);
+  if (!b || !(b->flags & L_MESH)) return 0;
+  *n_vert = b->mesh.n_vert; *n_tri = b->mesh.n_tri; return 1;
+}
+int orc_mesh_get(const OrcMap* m, int32_t x, int32_t y, int32_t z, float* vert, float* nrm, uint8_t* col, int32_t* tri) {
+  Idx3 i = {x, y, z}; Block* b = map_find(m, i);
+  if (!b || !(b->flags & L_MESH)) return 0;
+  memcpy(vert, b->mesh.vert, (size_t)b->mesh.n_vert * 12); memcpy(nrm, b->mesh.nrm, (size_t)b->mesh.n_vert * 12);
+  memcpy(col, b->mesh.col, (size_t)b->mesh.n_vert * 4); memcpy(tri, b->mesh.tri, (size_t)b->mesh.n_tri * 12);
+  return 1;
+}
+
+/* ------------------------------------------------------------------ decay / clearing */
+/* Mapper::decayTsdf restated (nvblox_node.cpp:931-936; params nvblox_base.yaml:103-107): weight *= factor for every
+ * TSDF voxel of every block NOT in the last depth view; block deallocated when all weights < threshold. */
+int64_t orc_decay_tsdf(OrcMap* m, int exclude_last_view) {
+  const OrcParams* p = &m->p;
+  int64_t removed = 0, keep = 0;
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    int drop = 0;
+    if ((b->flags & L_TSDF) && !(exclude_last_view && b->stamp_view == m->frame)) {
+      int alive = 0;
+      for (int i = 0; i < NVOX; i++) { b->tsdf[i].weight = b->tsdf[i].weight * p->tsdf_decay_factor; if (!(b->tsdf[i].weight < p->tsdf_decayed_weight_threshold)) alive = 1; }
+      b->dirty_esdf = 1; b->dirty_mesh = 1;
+      if (!alive) {
+        drop = 1;
+        const EsdfCfg ec = esdf_cfg(p);
+        if (b->idx.z >= floor_div8(ec.kz_min) && b->idx.z <= floor_div8(ec.kz_max)) {
+          Idx3 ei = {b->idx.x, b->idx.y, floor_div8(ec.kz_out)};
+          Block* eb = map_find(m, ei);
+          if (eb && (eb->flags & L_ESDF)) eb->remark_esdf = 1;
+        }
+      }
+    }
+    if (drop && !(b->flags & L_ESDF)) { block_free(b); removed++; }
+    else {
+      if (drop) { free(b->tsdf); b->tsdf = NULL; free(b->color); b->color = NULL; b->flags &= ~(uint32_t)(L_TSDF | L_COLOR | L_MESH); removed++; }
+      m->order[keep++] = b;
+    }
+  }
+  m->count = keep;
+  if (removed) map_rebuild(m);
+  return removed;
+}
+/* Mapper::clearOutsideRadius restated (nvblox_node.cpp:1566-1583): drop blocks whose centre is farther than r from c. */
+int64_t orc_clear_outside_radius(OrcMap* m, const float* c, float r) {
+  const float bs = m->p.voxel_size * 8.0f;
+  int64_t removed = 0, keep = 0;
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    float dx = ((float)b->idx.x * bs + bs * 0.5f) - c[0], dy = ((float)b->idx.y * bs + bs * 0.5f) - c[1], dz = ((float)b->idx.z * bs + bs * 0.5f) - c[2];
+    float d2 = (dx * dx + dy * dy) + dz * dz;
+    if (d2 > r * r) { block_free(b); removed++; } else m->order[keep++] = b;
+  }
+  m->count = keep;
+  if (removed) map_rebuild(m);
+  return removed;
+}
