@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- ms/frame and frames/s of the TSDF + Color + ESDF hot path (mesh timed beside it) on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d [D]): synthetic Replica-like room, 640x480 depth + colour, 0.05 m voxels,
+fuser.yaml integrator parameters, camera on the circle trajectory; ESDF updated every frame (worst case).  A "step" is
+one frame: integrateDepth + integrateColor + updateEsdf, inputs already resident in HBM.  N > 1: one camera per GPU
+(45 degree yaw offsets on the same rig, config 4), block-index all-gather over RCCL before every ESDF sweep, weak scaling.
+
+Prints ONE JSON line (rank 0).  `value` = frames/s of the whole job (all ranks' frames / max-over-ranks time).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+README_RTX5090_MS = {"tsdf": 0.1, "color": 0.3, "esdf": 0.3, "mesh": 0.3}   # /root/reference README.md:69-97 (Replica)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(kernel, c, rows, cols):
+    """SURVEY.md 8(d) per-frame algorithmic bytes of one launch of `kernel`, from the measured per-frame counts."""
+    B = 4096
+    Nv, Nc, Na = c["tsdf_blocks_in_view"], c["color_blocks_updated"], c["blocks_allocated"]
+    Nu, Ne, Wv = c["esdf_columns_marked"], c["esdf_blocks_swept"], c["esdf_window_voxels"]
+    if kernel.startswith("k_integrate_tsdf"):
+        return rows * cols * 4 + Nv * (12 + 8) + Nv * B * 2
+    if kernel.startswith("k_mark_view"):
+        return (rows // 4) * (cols // 4) * 4 + Nv * 16 * 2          # sub-sampled depth read + one hash entry RMW per block in view
+    if kernel.startswith("k_integrate_color"):
+        return rows * cols * 3 + (rows // 4) * (cols // 4) * 4 + Na * B + Nc * B * 2   # colour + synthetic depth + TSDF band scan + colour RMW
+    if kernel.startswith("k_sphere_trace"):
+        return (rows // 4) * (cols // 4) * 4 + Nc * B                # synthetic depth write + TSDF blocks read once
+    if kernel.startswith("k_esdf_mark"):
+        return Nu * 2 * B + Nu * 512
+    if kernel.startswith("k_esdf_bitmap"):
+        return Ne * 512 + Wv // 8
+    if kernel.startswith("k_esdf_rows"):
+        return Wv // 8 + Wv
+    if kernel.startswith("k_esdf_cols"):
+        return Ne * (512 * 2 + 88 * 8)
+    if kernel.startswith("k_mesh"):
+        return int(c["mesh_blocks_updated"] * B * (1.42 + 1.0) + c["mesh_vertices"] * 28 + c["mesh_triangles"] * 12)
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--unique-frames", type=int, default=50, help="distinct rendered frames cycled through (HBM-resident)")
+    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the same workload timed on the CPU oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from isaac_ros_nvblox_amd import mapper as M, synthetic as S
+    from isaac_ros_nvblox_amd.dist import DirtyBlockExchange, camera_yaw_offset_deg
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    cam = S.REPLICA_LIKE_CAM
+    rows, cols = cam[5], cam[4]
+    scene = S.Scene()
+    nu = max(2, min(args.unique_frames, args.steps + args.warmup))
+    stride = max(1, 200 // nu)
+    yaw = camera_yaw_offset_deg(rank, world)
+    host_frames = []
+    for i in range(nu):
+        T = S.trajectory_pose(i * stride, 200, yaw_offset_deg=yaw)
+        d, rgb = S.render(scene, T, cam)
+        host_frames.append((d, rgb, T))
+    depth_dev = [torch.from_numpy(d).to(dev) for d, _, _ in host_frames]
+    rgb_dev = [torch.from_numpy(c).to(dev) for _, c, _ in host_frames]
+    poses = [T for _, _, T in host_frames]
+
+    stream = torch.cuda.Stream(dev)      # one explicit stream for torch ops, RCCL hand-off and every mapper kernel
+    torch.cuda.set_stream(stream)
+    g = M.Mapper(M.default_params(), device=local_rank, block_capacity=1 << 15, stream=stream.cuda_stream)
+    ex = DirtyBlockExchange(4096, dev) if world > 1 else None
+
+    def step(i, mesh=False):
+        k = i % nu
+        g.integrate_depth(depth_dev[k], poses[k], cam)
+        g.integrate_color(rgb_dev[k], poses[k], cam)
+        if ex is not None:
+            ex.exchange(g)
+        g.update_esdf()
+        if mesh:
+            g.update_color_mesh()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    fps = world * args.steps / dt
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier(); dist.destroy_process_group()
+        return
+
+    # ---- rank 0 extras (outside the timed region): per-component times, per-kernel roofline, CPU baseline
+    def timed(fn, n):
+        torch.cuda.synchronize(dev); t = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t) / n * 1e3
+
+    base = args.warmup + args.steps
+    n2 = min(args.steps, 100)
+    comp = {}
+    comp["tsdf"] = timed(lambda i: g.integrate_depth(depth_dev[(base + i) % nu], poses[(base + i) % nu], cam), n2)
+    comp["color"] = timed(lambda i: g.integrate_color(rgb_dev[(base + i) % nu], poses[(base + i) % nu], cam), n2)
+
+    def esdf_only(i):
+        g.integrate_depth(depth_dev[(base + i) % nu], poses[(base + i) % nu], cam); g.update_esdf()
+    comp["esdf"] = max(0.0, timed(esdf_only, n2) - comp["tsdf"])
+
+    def mesh_only(i):
+        g.integrate_depth(depth_dev[(base + i) % nu], poses[(base + i) % nu], cam); g.update_color_mesh()
+    comp["mesh"] = max(0.0, timed(mesh_only, n2) - comp["tsdf"])
+
+    # per-kernel durations with hipEvent pairs on the mapper stream, same frames, mesh included
+    g.set_profiling(True)
+    counts_acc = {}
+    for i in range(n2):
+        step(base + i, mesh=True)
+        if i % 10 == 0:
+            c = g.counters()
+            for k_, v_ in c.items():
+                counts_acc.setdefault(k_, []).append(v_)
+    prof = g.profile()
+    g.set_profiling(False)
+    counts = {k_: float(np.mean(v_)) for k_, v_ in counts_acc.items()}
+    kern = {k_: {"avg_us": v_["total_ms"] / v_["count"] * 1e3, "launches_per_frame": v_["count"] / n2} for k_, v_ in prof.items()}
+    hot = [k_ for k_ in kern if not k_.startswith("k_mesh")]
+    dom = max(hot, key=lambda k_: kern[k_]["avg_us"] * kern[k_]["launches_per_frame"])
+    dom_bytes = algorithmic_bytes(dom.strip(), counts, rows, cols)
+    dom_us = kern[dom]["avg_us"]
+    achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+            traffic = pmc.get(dom.strip(), {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom.strip(), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 3),
+                "note": "640x480 @ 0.05 m moves ~6 MB/frame: latency/launch-bound, not HBM-bound (SURVEY.md 0.7)"}
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        import oracle
+        po = oracle.OrcParams()
+        for name, _ in oracle.OrcParams._fields_:
+            setattr(po, name, getattr(g.params, name))
+        o = oracle.OracleMap(po)
+        nf = max(2, args.cpu_frames)
+        for k in range(2):    # warm the map like the GPU warm-up does
+            d, c_, T = host_frames[k]
+            o.integrate_depth(d, T, cam); o.integrate_color(c_, T, cam); o.update_esdf()
+        t = time.perf_counter()
+        for k in range(nf):
+            d, c_, T = host_frames[(2 + k) % nu]
+            o.integrate_depth(d, T, cam); o.integrate_color(c_, T, cam); o.update_esdf()
+        cdt = time.perf_counter() - t
+        cpu = {"value": round(nf / cdt, 3), "unit": "frames/s", "cores": int(oracle.num_threads()), "kind": "port",
+               "ms_per_frame": round(cdt / nf * 1e3, 2),
+               "sample": "%d frames of the same 640x480 sequence, TSDF+Color+ESDF, oracle/nvblox_oracle.c with OpenMP" % nf}
+
+    out = {
+        "metric": "frames/s, TSDF+Color+ESDF integrate per frame, synthetic Replica-like 640x480 @0.05m",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: synthetic Replica-like room (SURVEY 8d), 640x480 depth+colour, 0.05 m voxels, "
+                               "fuser.yaml params, TSDF+Color+ESDF every frame (mesh timed separately)",
+                   "cameras_per_gpu": 1, "parallelism": "one camera per GPU, RCCL all-gather of dirty block indices" if world > 1 else "single GPU",
+                   "unique_frames": nu},
+        "ms_per_frame": round(ms_per_step, 4),
+        "ms_components": {k_: round(v_, 4) for k_, v_ in comp.items()},
+        "readme_rtx5090_ms": README_RTX5090_MS,
+        "speedup_vs_readme_rtx5090_tsdf_color_esdf": round(0.7 / ms_per_step, 2),
+        "per_frame_counts": {k_: round(v_, 1) for k_, v_ in counts.items()},
+        "kernels": {k_.strip(): {"avg_us": round(v_["avg_us"], 3), "launches_per_frame": round(v_["launches_per_frame"], 2)} for k_, v_ in kern.items()},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

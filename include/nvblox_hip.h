@@ -185,10 +185,18 @@ int nvbx_mesh_copy(nvbx_mapper* m, nvbx_index3d* block_indices, int32_t* vertex_
                    int32_t* triangles);
 
 /* ---- multi-GPU (one camera per GPU, all-gather of updated block indices before the ESDF sweep) -----
- * Device-resident list of the TSDF blocks dirtied since the last updateEsdf: `indices_dev` -> int32[capacity][3],
- * `count_dev` -> int32.  The caller all-gathers both over RCCL and feeds the union back with nvbx_mark_esdf_dirty. */
-int nvbx_esdf_dirty_list(nvbx_mapper* m, int32_t** indices_dev, int32_t** count_dev, int64_t* capacity);
+ * nvbx_esdf_dirty_list writes the Index3D of the TSDF blocks dirtied since the last updateEsdf into caller-owned
+ * device buffers (indices int32[capacity][3], count int32[1], clamped to capacity) -- asynchronous, no host copy.
+ * The caller all-gathers both over RCCL and feeds every peer's list back with nvbx_mark_esdf_dirty (count is read
+ * on the device; max_count bounds it). */
+int nvbx_esdf_dirty_list(nvbx_mapper* m, int32_t* indices_dev_out, int32_t* count_dev_out, int64_t capacity);
 int nvbx_mark_esdf_dirty(nvbx_mapper* m, const int32_t* indices_dev, const int32_t* count_dev, int64_t max_count);
+
+/* ---- instrumentation (timing::Timer analogue for the per-kernel roofline line of bench.py) -----------------------
+ * While enabled every kernel launch is bracketed by a hipEvent pair on the mapper stream. nvbx_get_profile returns a
+ * JSON object {"kernel": {"count": n, "total_ms": t}}. */
+int nvbx_set_profiling(nvbx_mapper* m, int32_t enable);
+int nvbx_get_profile(nvbx_mapper* m, char* json_out, int64_t capacity);
 
 #ifdef __cplusplus
 }

@@ -85,8 +85,10 @@ SIGNATURES = {
     "nvbx_get_counters": (C.c_int, [_vp, C.POINTER(Counters)]),
     "nvbx_mesh_sizes": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "nvbx_mesh_copy": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "nvbx_esdf_dirty_list": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i64)]),
+    "nvbx_esdf_dirty_list": (C.c_int, [_vp, _vp, _vp, _i64]),
     "nvbx_mark_esdf_dirty": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "nvbx_set_profiling": (C.c_int, [_vp, _i32]),
+    "nvbx_get_profile": (C.c_int, [_vp, C.c_char_p, _i64]),
 }
 
 _lib = None

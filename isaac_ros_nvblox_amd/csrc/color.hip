@@ -154,10 +154,10 @@ extern "C" int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int3
   }
   m->synth_rows = srows; m->synth_cols = scols;
   const int tiles = ((srows + 7) / 8) * ((scols + 7) / 8);
-  hipLaunchKernelGGL(k_sphere_trace, dim3(tiles), dim3(64), 0, m->stream, m->d, f, m->synth, srows, scols, m->p.sphere_tracing_max_steps,
+  NVBX_LAUNCH(m, k_sphere_trace, dim3(tiles), dim3(64), m->d, f, m->synth, srows, scols, m->p.sphere_tracing_max_steps,
                      m->p.sphere_tracing_max_ray_length_m, m->p.sphere_tracing_surface_eps_vox * m->p.voxel_size);
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
-  hipLaunchKernelGGL(k_integrate_color, dim3(grid), dim3(512), 0, m->stream, m->d, f, rgb_dev, m->synth, srows, scols, m->color_list, m->mesh_dirty_live(), m->mesh_dirty_counter());
+  NVBX_LAUNCH(m, k_integrate_color, dim3(grid), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->color_list, m->mesh_dirty_live(), m->mesh_dirty_counter());
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }

@@ -186,10 +186,10 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
   NVBX_HIP(hipSetDevice(m->device));
   const EsdfArgs a = m->make_esdf_args();
   if (m->p.esdf_max_distance_m / m->p.voxel_size >= 64.0f) { set_error("esdf_max_distance_m / voxel_size must be < 64 voxels"); return NVBX_E_INVALID; }
-  hipLaunchKernelGGL(k_esdf_mark, dim3(1024), dim3(64), 0, m->stream, m->d, a, m->esdf_dirty);
-  hipLaunchKernelGGL(k_esdf_bitmap, dim3(1024), dim3(64), 0, m->stream, m->d, a, m->bitmap);
-  hipLaunchKernelGGL(k_esdf_rows, dim3(1024), dim3(256), 0, m->stream, m->d, a, m->bitmap, m->rowdx);
-  hipLaunchKernelGGL(k_esdf_cols, dim3(2048), dim3(64), 0, m->stream, m->d, a, m->rowdx);
+  NVBX_LAUNCH(m, k_esdf_mark, dim3(1024), dim3(64), m->d, a, m->esdf_dirty);
+  NVBX_LAUNCH(m, k_esdf_bitmap, dim3(1024), dim3(64), m->d, a, m->bitmap);
+  NVBX_LAUNCH(m, k_esdf_rows, dim3(1024), dim3(256), m->d, a, m->bitmap, m->rowdx);
+  NVBX_LAUNCH(m, k_esdf_cols, dim3(2048), dim3(64), m->d, a, m->rowdx);
   NVBX_HIP(hipGetLastError());
   m->esdf_epoch++;
   return NVBX_OK;
@@ -237,7 +237,7 @@ extern "C" int nvbx_esdf_slice_to_image(nvbx_mapper* m, float unknown_value, flo
   const EsdfArgs a = m->make_esdf_args();
   const int32_t* c = m->h_counters + C_ESDF_AABB;
   const int32_t nbx = c[2] - c[0] + 1, nby = c[3] - c[1] + 1;
-  hipLaunchKernelGGL(k_esdf_slice, dim3(std::min(nbx * nby, 4096)), dim3(64), 0, m->stream, m->d, a.bz_out, a.vz_out, m->p.voxel_size,
+  NVBX_LAUNCH(m, k_esdf_slice, dim3(std::min(nbx * nby, 4096)), dim3(64), m->d, a.bz_out, a.vz_out, m->p.voxel_size,
                      unknown_value, image_dev, c[0], c[1], nbx, nby);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
@@ -279,7 +279,7 @@ extern "C" int nvbx_occupancy_grid_from_slice(nvbx_mapper* m, const float* image
                                               int8_t* grid_dev) {
   if (!m || !image_dev || !grid_dev || rows <= 0 || cols <= 0) return NVBX_E_INVALID;
   const int64_t n = (int64_t)rows * cols;
-  hipLaunchKernelGGL(k_occupancy, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, m->stream, image_dev, n, unknown_value, grid_dev);
+  NVBX_LAUNCH(m, k_occupancy, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), image_dev, n, unknown_value, grid_dev);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }
@@ -310,9 +310,9 @@ __global__ void k_zero_tmp2(DMap m) { m.counters[C_TMP] = 0; }
 extern "C" int nvbx_pointcloud_from_slice(nvbx_mapper* m, const float* image_dev, int32_t rows, int32_t cols, const float aabb[6],
                                           float slice_height, float unknown_value, float* points_xyzi_dev, int32_t* n_points) {
   if (!m || !image_dev || !aabb || !points_xyzi_dev || !n_points || rows <= 0 || cols <= 0) return NVBX_E_INVALID;
-  hipLaunchKernelGGL(k_zero_tmp2, dim3(1), dim3(1), 0, m->stream, m->d);
+  NVBX_LAUNCH(m, k_zero_tmp2, dim3(1), dim3(1), m->d);
   const int tiles = ((rows + 7) / 8) * ((cols + 7) / 8);
-  hipLaunchKernelGGL(k_slice_pointcloud, dim3(std::min(tiles, 4096)), dim3(64), 0, m->stream, m->d, image_dev, rows, cols, aabb[0], aabb[1],
+  NVBX_LAUNCH(m, k_slice_pointcloud, dim3(std::min(tiles, 4096)), dim3(64), m->d, image_dev, rows, cols, aabb[0], aabb[1],
                      slice_height, m->p.voxel_size, unknown_value, (float4*)points_xyzi_dev);
   if (m->fetch_counters()) return NVBX_E_DEVICE;
   *n_points = m->h_counters[C_TMP];
@@ -337,27 +337,25 @@ __global__ void k_esdf_dense(DMap m, int32_t mx, int32_t my, int32_t mz, int32_t
 extern "C" int nvbx_esdf_dense_grid(nvbx_mapper* m, const int32_t min_vox[3], const int32_t size_vox[3], float default_value, float* grid_dev) {
   if (!m || !min_vox || !size_vox || !grid_dev || size_vox[0] <= 0 || size_vox[1] <= 0 || size_vox[2] <= 0) return NVBX_E_INVALID;
   const int64_t n = (int64_t)size_vox[0] * size_vox[1] * size_vox[2];
-  hipLaunchKernelGGL(k_esdf_dense, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, m->stream, m->d, min_vox[0], min_vox[1],
+  NVBX_LAUNCH(m, k_esdf_dense, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), m->d, min_vox[0], min_vox[1],
                      min_vox[2], size_vox[0], size_vox[1], size_vox[2], m->p.voxel_size, default_value, grid_dev);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ multi-GPU hooks
-__global__ void k_export_dirty(DMap m, const int32_t* dirty, int32_t* out_idx, int32_t* out_count) {
-  const int32_t n = m.counters[C_ESDF_DIRTY];
+__global__ void k_export_dirty(DMap m, const int32_t* dirty, int32_t* out_idx, int32_t* out_count, int32_t cap) {
+  int32_t n = m.counters[C_ESDF_DIRTY]; if (n > cap) n = cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = n;
   for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int32_t s = dirty[i];
     out_idx[3 * i] = m.slot_index[3 * s]; out_idx[3 * i + 1] = m.slot_index[3 * s + 1]; out_idx[3 * i + 2] = m.slot_index[3 * s + 2];
   }
 }
-extern "C" int nvbx_esdf_dirty_list(nvbx_mapper* m, int32_t** indices_dev, int32_t** count_dev, int64_t* capacity) {
-  if (!m || !indices_dev || !count_dev) return NVBX_E_INVALID;
-  hipLaunchKernelGGL(k_export_dirty, dim3(64), dim3(256), 0, m->stream, m->d, m->esdf_dirty, m->export_idx, m->export_count);
+extern "C" int nvbx_esdf_dirty_list(nvbx_mapper* m, int32_t* indices_dev_out, int32_t* count_dev_out, int64_t capacity) {
+  if (!m || !indices_dev_out || !count_dev_out || capacity <= 0) return NVBX_E_INVALID;
+  NVBX_LAUNCH(m, k_export_dirty, dim3(64), dim3(256), m->d, m->esdf_dirty, indices_dev_out, count_dev_out, (int32_t)std::min<int64_t>(capacity, m->capacity));
   NVBX_HIP(hipGetLastError());
-  *indices_dev = m->export_idx; *count_dev = m->export_count;
-  if (capacity) *capacity = m->capacity;
   return NVBX_OK;
 }
 // Union step after the all-gather: blocks another GPU updated that exist locally as TSDF blocks become ESDF-dirty here.
@@ -372,7 +370,7 @@ __global__ void k_import_dirty(DMap m, const int32_t* idx, const int32_t* count,
 }
 extern "C" int nvbx_mark_esdf_dirty(nvbx_mapper* m, const int32_t* indices_dev, const int32_t* count_dev, int64_t max_count) {
   if (!m || !indices_dev || !count_dev || max_count < 0) return NVBX_E_INVALID;
-  hipLaunchKernelGGL(k_import_dirty, dim3(64), dim3(256), 0, m->stream, m->d, indices_dev, count_dev, max_count, m->esdf_dirty);
+  NVBX_LAUNCH(m, k_import_dirty, dim3(64), dim3(256), m->d, indices_dev, count_dev, max_count, m->esdf_dirty);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }

@@ -103,9 +103,9 @@ __global__ void k_reinsert(DMap m, const uint32_t* tmp) {
 
 static int rebuild_table(nvbx_mapper* m) {
   uint32_t* tmp = (uint32_t*)m->export_idx;   // capacity * 12 bytes scratch >= capacity * 4
-  hipLaunchKernelGGL(k_save_stamps, dim3(256), dim3(256), 0, m->stream, m->d, tmp);
+  NVBX_LAUNCH(m, k_save_stamps, dim3(256), dim3(256), m->d, tmp);
   NVBX_HIP(hipMemsetAsync(m->d.table, 0xFF, ((size_t)m->d.mask + 1) * sizeof(Entry), m->stream));
-  hipLaunchKernelGGL(k_reinsert, dim3(256), dim3(256), 0, m->stream, m->d, tmp);
+  NVBX_LAUNCH(m, k_reinsert, dim3(256), dim3(256), m->d, tmp);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }
@@ -114,7 +114,7 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   if (!m) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
-  hipLaunchKernelGGL(k_decay, dim3(grid), dim3(512), 0, m->stream, m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
+  NVBX_LAUNCH(m, k_decay, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
                      exclude_last_view ? m->last_view_frame : 0u, m->esdf_dirty, m->mesh_dirty_live(), m->mesh_dirty_counter());
   return rebuild_table(m);
 }
@@ -123,6 +123,6 @@ extern "C" int nvbx_clear_outside_radius(nvbx_mapper* m, const float center[3], 
   if (!m || !center) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
-  hipLaunchKernelGGL(k_clear_outside, dim3(grid), dim3(512), 0, m->stream, m->d, center[0], center[1], center[2], radius * radius, m->p.voxel_size * 8.0f);
+  NVBX_LAUNCH(m, k_clear_outside, dim3(grid), dim3(512), m->d, center[0], center[1], center[2], radius * radius, m->p.voxel_size * 8.0f);
   return rebuild_table(m);
 }

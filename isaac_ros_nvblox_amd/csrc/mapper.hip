@@ -164,7 +164,7 @@ static int reset_map(nvbx_mapper* m) {
   NVBX_HIP(hipMemsetAsync(d.esdf, 0, cap * 4096, m->stream));
   NVBX_HIP(hipMemsetAsync(m->export_count, 0, 64, m->stream));
   const int64_t n = std::max<int64_t>(cap, C_NUM);
-  hipLaunchKernelGGL(k_init_map, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->stream, d);
+  NVBX_LAUNCH(m, k_init_map, dim3((unsigned)((n + 255) / 256)), dim3(256), d);
   NVBX_HIP(hipGetLastError());
   m->frame_id = 0; m->esdf_epoch = 0; m->mesh_epoch = 0; m->last_view_frame = 0; m->synth_rows = m->synth_cols = 0;
   return NVBX_OK;
@@ -281,8 +281,8 @@ static void sort_indices(nvbx_index3d* v, int64_t n) {
 
 extern "C" int64_t nvbx_block_indices(nvbx_mapper* m, uint32_t layer, nvbx_index3d* out, int64_t capacity) {
   if (!m || !single_layer(layer)) return NVBX_E_INVALID;
-  hipLaunchKernelGGL(k_zero_tmp, dim3(1), dim3(1), 0, m->stream, m->d);
-  hipLaunchKernelGGL(k_collect_indices, dim3(256), dim3(256), 0, m->stream, m->d, layer, m->export_idx, (int32_t)m->capacity);
+  NVBX_LAUNCH(m, k_zero_tmp, dim3(1), dim3(1), m->d);
+  NVBX_LAUNCH(m, k_collect_indices, dim3(256), dim3(256), m->d, layer, m->export_idx, (int32_t)m->capacity);
   if (m->fetch_counters()) return NVBX_E_DEVICE;
   int64_t n = m->h_counters[C_TMP];
   if (n > m->capacity) n = m->capacity;
@@ -298,7 +298,7 @@ extern "C" int64_t nvbx_block_indices(nvbx_mapper* m, uint32_t layer, nvbx_index
 extern "C" int64_t nvbx_num_blocks(nvbx_mapper* m, uint32_t layer) { return nvbx_block_indices(m, layer, nullptr, 0); }
 
 static int64_t list_indices(nvbx_mapper* m, const int32_t* list, int count_idx, int is_entry, nvbx_index3d* out, int64_t capacity) {
-  hipLaunchKernelGGL(k_list_to_indices, dim3(64), dim3(256), 0, m->stream, m->d, list, count_idx, is_entry, m->export_idx, (int32_t)m->capacity);
+  NVBX_LAUNCH(m, k_list_to_indices, dim3(64), dim3(256), m->d, list, count_idx, is_entry, m->export_idx, (int32_t)m->capacity);
   if (m->fetch_counters()) return NVBX_E_DEVICE;
   int64_t n = m->h_counters[count_idx]; if (n > m->capacity) n = m->capacity;
   const int64_t k = std::min<int64_t>(n, capacity);
@@ -331,7 +331,7 @@ extern "C" int nvbx_get_blocks(nvbx_mapper* m, uint32_t layer, const nvbx_index3
     int32_t* d_idx = (int32_t*)m->staging; int32_t* d_found = d_idx + 3 * c;
     uint8_t* d_out = (uint8_t*)m->staging + (((size_t)c * 16 + 255) & ~(size_t)255);
     NVBX_HIP(hipMemcpyAsync(d_idx, idx + o, (size_t)c * 12, hipMemcpyHostToDevice, m->stream));
-    hipLaunchKernelGGL(k_gather_blocks, dim3((unsigned)c), dim3(512), 0, m->stream, m->d, layer, d_idx, (int32_t)c, d_out, d_found);
+    NVBX_LAUNCH(m, k_gather_blocks, dim3((unsigned)c), dim3(512), m->d, layer, d_idx, (int32_t)c, d_out, d_found);
     NVBX_HIP(hipMemcpyAsync((uint8_t*)voxels_out + (size_t)o * bb, d_out, (size_t)c * bb, hipMemcpyDeviceToHost, m->stream));
     if (found_out) NVBX_HIP(hipMemcpyAsync(found_out + o, d_found, (size_t)c * 4, hipMemcpyDeviceToHost, m->stream));
     NVBX_HIP(hipStreamSynchronize(m->stream));
@@ -348,7 +348,7 @@ extern "C" int nvbx_set_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, 
   if (!m || !voxels_in || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF)) return NVBX_E_INVALID;
   const size_t bb = 512 * ref_voxel_bytes(layer);
   NVBX_HIP(hipMemcpyAsync(m->staging, voxels_in, bb, hipMemcpyHostToDevice, m->stream));
-  hipLaunchKernelGGL(k_scatter_block, dim3(1), dim3(512), 0, m->stream, m->d, layer, idx.x, idx.y, idx.z, (const uint8_t*)m->staging,
+  NVBX_LAUNCH(m, k_scatter_block, dim3(1), dim3(512), m->d, layer, idx.x, idx.y, idx.z, (const uint8_t*)m->staging,
                      m->esdf_dirty, m->mesh_dirty_live(), m->mesh_dirty_counter());
   NVBX_HIP(hipStreamSynchronize(m->stream));
   return NVBX_OK;
@@ -371,5 +371,53 @@ extern "C" int nvbx_get_counters(nvbx_mapper* m, nvbx_counters* out) {
   out->mesh_vertices = m->mesh_epoch ? c[mrec + 1] : 0;
   out->mesh_triangles = m->mesh_epoch ? c[mrec + 2] : 0;
   out->capacity_overflow = c[C_OVERFLOW];
+  return NVBX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ per-kernel timing
+hipEvent_t nvbx_mapper::get_event() {
+  if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+}
+void nvbx_mapper::span_begin(const char* name) {
+  Span s{name, get_event(), get_event()};
+  (void)hipEventRecord(s.a, stream);
+  spans.push_back(s);
+}
+void nvbx_mapper::span_end() { (void)hipEventRecord(spans.back().b, stream); }
+
+extern "C" int nvbx_set_profiling(nvbx_mapper* m, int32_t enable) {
+  if (!m) return NVBX_E_INVALID;
+  NVBX_HIP(hipStreamSynchronize(m->stream));
+  for (auto& s : m->spans) { m->event_pool.push_back(s.a); m->event_pool.push_back(s.b); }
+  m->spans.clear();
+  m->profiling = enable != 0;
+  return NVBX_OK;
+}
+
+// JSON object {"kernel": {"count": n, "total_ms": t}, ...} of every launch since nvbx_set_profiling(m, 1).
+extern "C" int nvbx_get_profile(nvbx_mapper* m, char* json_out, int64_t capacity) {
+  if (!m || !json_out || capacity < 4) return NVBX_E_INVALID;
+  NVBX_HIP(hipStreamSynchronize(m->stream));
+  struct Acc { const char* name; int64_t n; double ms; };
+  std::vector<Acc> acc;
+  for (auto& s : m->spans) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) continue;
+    bool hit = false;
+    for (auto& a : acc) if (!strcmp(a.name, s.name)) { a.n++; a.ms += ms; hit = true; break; }
+    if (!hit) acc.push_back({s.name, 1, ms});
+  }
+  std::string out = "{";
+  for (size_t i = 0; i < acc.size(); i++) {
+    char buf[256];
+    std::string nm = acc[i].name;
+    for (char& c : nm) if (c == '(' || c == ')' ) c = ' ';
+    snprintf(buf, sizeof(buf), "%s\"%s\": {\"count\": %lld, \"total_ms\": %.6f}", i ? ", " : "", nm.c_str(), (long long)acc[i].n, acc[i].ms);
+    out += buf;
+  }
+  out += "}";
+  if ((int64_t)out.size() + 1 > capacity) return NVBX_E_CAPACITY;
+  memcpy(json_out, out.c_str(), out.size() + 1);
   return NVBX_OK;
 }

@@ -223,7 +223,7 @@ extern "C" int nvbx_update_color_mesh(nvbx_mapper* m, int32_t update_full_layer)
   a.rec = C_MESH_OUT + 4 * par; a.rec_next = C_MESH_OUT + 4 * (par ^ 1);
   a.vert_cap = m->mesh_vert_cap; a.tri_cap = m->mesh_tri_cap;
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
-  hipLaunchKernelGGL(k_mesh, dim3(grid), dim3(512), 0, m->stream, m->d, a, m->mesh_dirty_live(), m->mesh_vert, m->mesh_nrm, (uint32_t*)m->mesh_col,
+  NVBX_LAUNCH(m, k_mesh, dim3(grid), dim3(512), m->d, a, m->mesh_dirty_live(), m->mesh_vert, m->mesh_nrm, (uint32_t*)m->mesh_col,
                      m->mesh_tri, m->mesh_rec);
   NVBX_HIP(hipGetLastError());
   m->mesh_epoch++;

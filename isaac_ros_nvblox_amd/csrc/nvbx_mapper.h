@@ -65,7 +65,23 @@ struct nvbx_mapper {
   nvbx::Frame make_frame(const float T_L_C[16], const nvbx_camera* cam, int32_t rows, int32_t cols, int32_t subsample) const;
   nvbx::EsdfArgs make_esdf_args() const;
   int fetch_counters();              // D2H of all counters + stream sync
+  // optional per-kernel timing (hipEvent pairs on the mapper stream), used by bench.py for the roofline line
+  bool profiling = false;
+  struct Span { const char* name; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> event_pool;
+  hipEvent_t get_event();
+  void span_begin(const char* name);
+  void span_end();
 };
+
+// every kernel launch of the library goes through this macro (name = the kernel's name in rocprof output)
+#define NVBX_LAUNCH(m, kernel, grid, block, ...)                                     \
+  do {                                                                               \
+    if ((m)->profiling) (m)->span_begin(#kernel);                                    \
+    hipLaunchKernelGGL(kernel, grid, block, 0, (m)->stream, __VA_ARGS__);            \
+    if ((m)->profiling) (m)->span_end();                                             \
+  } while (0)
 
 #define NVBX_HIP(call)                                                 \
   do {                                                                 \

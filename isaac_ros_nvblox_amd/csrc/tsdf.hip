@@ -144,9 +144,9 @@ static int integrate_depth_impl(nvbx_mapper* m, Img img, int32_t rows, int32_t c
   f.n_ray_rows = (rows + s - 1 + s - 1) / s;   // indices i with i*s < rows + s - 1
   f.n_ray_cols = (cols + s - 1 + s - 1) / s;
   const int tiles = ((f.n_ray_rows + 7) / 8) * ((f.n_ray_cols + 7) / 8);
-  hipLaunchKernelGGL((k_mark_view<Img>), dim3(tiles), dim3(64), 0, m->stream, m->d, f, img, m->view_list, (int32_t)m->capacity);
+  NVBX_LAUNCH(m, (k_mark_view<Img>), dim3(tiles), dim3(64), m->d, f, img, m->view_list, (int32_t)m->capacity);
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
-  hipLaunchKernelGGL((k_integrate_tsdf<Img>), dim3(grid), dim3(512), 0, m->stream, m->d, f, img, m->view_list, (int32_t)m->capacity,
+  NVBX_LAUNCH(m, (k_integrate_tsdf<Img>), dim3(grid), dim3(512), m->d, f, img, m->view_list, (int32_t)m->capacity,
                      m->esdf_dirty, m->mesh_dirty_live(), m->mesh_dirty_counter());
   NVBX_HIP(hipGetLastError());
   m->last_view_frame = m->frame_id;

@@ -253,12 +253,20 @@ class Mapper:
         return out
 
     # -- multi-GPU hooks
-    def esdf_dirty_list(self):
-        """Device views (torch tensors) of the indices [capacity,3] int32 and count [1] int32 of TSDF blocks dirtied since the last updateEsdf."""
-        torch = self._torch
-        pi, pc, cap = C.c_void_p(), C.c_void_p(), C.c_int64()
-        self._check(self.lib.nvbx_esdf_dirty_list(self._h, C.byref(pi), C.byref(pc), C.byref(cap)))
-        return pi.value, pc.value, cap.value
+    def esdf_dirty_list(self, idx_out, count_out):
+        """Write the Index3D list [cap,3] int32 + count [1] int32 of TSDF blocks dirtied since the last updateEsdf
+        into caller-owned device tensors (async)."""
+        self._check(self.lib.nvbx_esdf_dirty_list(self._h, C.c_void_p(idx_out.data_ptr()), C.c_void_p(count_out.data_ptr()), int(idx_out.shape[0])))
 
     def mark_esdf_dirty(self, idx_tensor, count_tensor, max_count):
         self._check(self.lib.nvbx_mark_esdf_dirty(self._h, C.c_void_p(idx_tensor.data_ptr()), C.c_void_p(count_tensor.data_ptr()), int(max_count)))
+
+    # -- instrumentation
+    def set_profiling(self, enable):
+        self._check(self.lib.nvbx_set_profiling(self._h, int(enable)))
+
+    def profile(self):
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        self._check(self.lib.nvbx_get_profile(self._h, buf, len(buf)))
+        return json.loads(buf.value.decode())
