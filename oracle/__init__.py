@@ -98,6 +98,8 @@ def lib():
         L.orc_mesh_get.restype = C.c_int; L.orc_mesh_get.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
         L.orc_decay_tsdf.restype = i64; L.orc_decay_tsdf.argtypes = [vp, C.c_int]
         L.orc_clear_outside_radius.restype = i64; L.orc_clear_outside_radius.argtypes = [vp, vp, C.c_float]
+        L.orc_mark_esdf_dirty.restype = i64; L.orc_mark_esdf_dirty.argtypes = [vp, vp, i64]
+        L.orc_esdf_dirty_list.restype = i64; L.orc_esdf_dirty_list.argtypes = [vp, vp, i64]
         _lib = L
     return _lib
 
@@ -212,6 +214,15 @@ class OracleMap:
         c = np.zeros((nv.value, 4), np.uint8); t = np.zeros((nt.value, 3), np.int32)
         lib().orc_mesh_get(self._h, int(idx[0]), int(idx[1]), int(idx[2]), _p(v), _p(n), _p(c), _p(t))
         return dict(vertices=v, normals=n, colors=c, triangles=t)
+
+    def mark_esdf_dirty(self, indices):
+        idx = np.ascontiguousarray(np.asarray(indices, np.int32).reshape(-1, 3))
+        return lib().orc_mark_esdf_dirty(self._h, _p(idx), idx.shape[0])
+
+    def esdf_dirty_list(self):
+        out = np.zeros((1 << 18, 3), np.int32)
+        n = lib().orc_esdf_dirty_list(self._h, _p(out), out.shape[0])
+        return out[:n].copy()
 
     def decay_tsdf(self, exclude_last_view=True):
         return lib().orc_decay_tsdf(self._h, int(exclude_last_view))

@@ -949,3 +949,24 @@ int64_t orc_clear_outside_radius(OrcMap* m, const float* c, float r) {
   if (removed) map_rebuild(m);
   return removed;
 }
+
+/* multi-GPU union step: TSDF blocks another mapper updated become ESDF-dirty here if they exist locally */
+int64_t orc_mark_esdf_dirty(OrcMap* m, const int32_t* idx, int64_t n) {
+  int64_t hit = 0;
+  for (int64_t i = 0; i < n; i++) {
+    Idx3 k = {idx[3 * i], idx[3 * i + 1], idx[3 * i + 2]};
+    Block* b = map_find(m, k);
+    if (b && (b->flags & L_TSDF)) { b->dirty_esdf = 1; hit++; }
+  }
+  return hit;
+}
+/* Index3D of the TSDF blocks currently ESDF-dirty (sorted) */
+int64_t orc_esdf_dirty_list(const OrcMap* m, int32_t* out, int64_t cap) {
+  int64_t n = 0;
+  for (int64_t k = 0; k < m->count; k++) if ((m->order[k]->flags & L_TSDF) && m->order[k]->dirty_esdf) {
+    if (n < cap) { out[3 * n] = m->order[k]->idx.x; out[3 * n + 1] = m->order[k]->idx.y; out[3 * n + 2] = m->order[k]->idx.z; }
+    n++;
+  }
+  qsort(out, (size_t)(n < cap ? n : cap), sizeof(Idx3), idx_cmp);
+  return n;
+}

@@ -1,0 +1,88 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/nvblox_hip.h declares;
+struct layouts agree between the header (compiled with gcc) and the ctypes mirror.  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "nvblox_hip.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nvbx_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_the_expected_surface():
+    syms = declared_symbols()
+    for must in ["nvbx_mapper_create", "nvbx_integrate_depth", "nvbx_integrate_color", "nvbx_update_esdf",
+                 "nvbx_update_color_mesh", "nvbx_esdf_slice_to_image", "nvbx_esdf_dirty_list", "nvbx_mark_esdf_dirty"]:
+        assert must in syms
+    assert len(syms) >= 30
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    from isaac_ros_nvblox_amd import _lib
+    for s in declared_symbols():
+        assert hasattr(hip_lib, s), "libnvblox_hip.so does not export %s" % s
+        assert s in _lib.SIGNATURES, "ctypes mirror lacks %s" % s
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_header_is_plain_c_and_struct_layouts_match():
+    from isaac_ros_nvblox_amd import _lib
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "nvblox_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(nvbx_mapper_params), sizeof(nvbx_camera), sizeof(nvbx_index3d),
+         sizeof(nvbx_counters), sizeof(nvbx_esdf_voxel), sizeof(nvbx_tsdf_voxel), sizeof(nvbx_color_voxel));
+  printf("%zu %zu\n", offsetof(nvbx_mapper_params, esdf_slice_height), offsetof(nvbx_mapper_params, depth_interp_nearest));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "t.c"); exe = os.path.join(td, "t")
+        open(c, "w").write(src)
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = subprocess.check_output([exe]).decode().split()
+    sizes = list(map(int, out))
+    assert sizes[0] == C.sizeof(_lib.Params)
+    assert sizes[1] == C.sizeof(_lib.Camera)
+    assert sizes[2] == C.sizeof(_lib.Index3D) == 12
+    assert sizes[3] == C.sizeof(_lib.Counters)
+    assert sizes[4] == 20 and sizes[5] == 8 and sizes[6] == 8
+    assert sizes[7] == _lib.Params.esdf_slice_height.offset and sizes[8] == _lib.Params.depth_interp_nearest.offset
+
+
+def test_oracle_params_layout_equals_product_params(oracle_mod):
+    from isaac_ros_nvblox_amd import _lib
+    assert [n for n, _ in oracle_mod.OrcParams._fields_] == [n for n, _ in _lib.Params._fields_]
+    assert C.sizeof(oracle_mod.OrcParams) == C.sizeof(_lib.Params)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under isaac_ros_nvblox_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("isaac_ros_nvblox_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                    t = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"^\s*(import|from)\s+oracle\b", t, flags=re.M) or "libnvblox_oracle" in t or "orc_" in t:
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_mapper_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from isaac_ros_nvblox_amd import mapper as M
+    with pytest.raises(M.NvbxError):
+        M.Mapper(M.default_params())

@@ -1,0 +1,63 @@
+"""World-size-2 CPU (gloo) coverage of the N>1 path: the dirty-block all-gather of isaac_ros_nvblox_amd/dist.py and the
+camera sharding used by bench.py.  The GPU side of the exchange (nvbx_esdf_dirty_list / nvbx_mark_esdf_dirty) is covered
+by tests/test_gpu_multi.py on one GPU with two mappers."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isaac_ros_nvblox_amd.dist import DirtyBlockExchange, camera_yaw_offset_deg
+    ex = DirtyBlockExchange(64, torch.device("cpu"))
+    rng = np.random.default_rng(rank)
+    n = 10 + 7 * rank
+    mine = rng.integers(-20, 20, size=(n, 3)).astype(np.int32)
+    ex.idx[:n] = torch.from_numpy(mine); ex.cnt[0] = n
+    ex.all_gather()
+    got = ex.union_host()
+    # expected union computed independently from the known seeds
+    want = set()
+    for r in range(world):
+        rr = np.random.default_rng(r)
+        want |= set(map(tuple, rr.integers(-20, 20, size=(10 + 7 * r, 3)).astype(np.int32).tolist()))
+    ok = got == want and ex.all_cnt.tolist() == [10 + 7 * r for r in range(world)]
+    ok = ok and camera_yaw_offset_deg(rank, world) == 45.0 * rank
+    # max-over-ranks timing reduction used by bench.py
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = ok and float(t.item()) == float(world)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dirty_block_allgather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_single_process_exchange_is_identity():
+    from isaac_ros_nvblox_amd.dist import DirtyBlockExchange
+    ex = DirtyBlockExchange(8, torch.device("cpu"))
+    ex.idx[:3] = torch.tensor([[1, 2, 3], [4, 5, 6], [1, 2, 3]], dtype=torch.int32); ex.cnt[0] = 3
+    ex.all_gather()
+    assert ex.union_host() == {(1, 2, 3), (4, 5, 6)}
