@@ -38,13 +38,9 @@ def algorithmic_bytes(kernel, c, rows, cols):
     if kernel.startswith("k_sphere_trace"):
         return (rows // 4) * (cols // 4) * 4 + Nc * B                # synthetic depth write + TSDF blocks read once
     if kernel.startswith("k_esdf_mark"):
-        return Nu * 2 * B + Nu * 512
-    if kernel.startswith("k_esdf_bitmap"):
-        return Ne * 512 + Wv // 8
-    if kernel.startswith("k_esdf_rows"):
-        return Wv // 8 + Wv
-    if kernel.startswith("k_esdf_cols"):
-        return Ne * (512 * 2 + 88 * 8)
+        return Nu * 2 * B + Nu * 512 + Nu * 8                       # TSDF z-band (k_z = 2 blocks) read + slice plane + site mask written
+    if kernel.startswith("k_esdf_edt"):
+        return Ne * (512 * 2 + 121 * (16 + 8))                      # plane RMW + 11x11 neighbour hash entries and site masks per swept block
     if kernel.startswith("k_mesh"):
         return int(c["mesh_blocks_updated"] * B * (1.42 + 1.0) + c["mesh_vertices"] * 28 + c["mesh_triangles"] * 12)
     return 0

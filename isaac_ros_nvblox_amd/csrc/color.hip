@@ -3,7 +3,7 @@
 // Two launches per colour frame:
 //   k_sphere_trace    one wavefront per 8x8 tile of the 1/f-resolution synthetic depth image; each lane sphere-traces
 //                     its ray through the TSDF, caching the last block's slot so consecutive samples of a ray skip the
-//                     hash probe ([U] SphereTracer::cast restated).
+//                     hash probe and the last voxel's value so repeated samples of one voxel skip memory ([U] SphereTracer::cast restated).
 //   k_integrate_color one 512-thread workgroup per allocated block slot (grid-stride over the slot range): frustum test
 //                     (8 lanes = 8 corners), truncation-band test (block-wide vote), then the per-voxel projective
 //                     colour blend -- selection and integration fused, no block list round trip
@@ -14,6 +14,26 @@
 
 using namespace nvbx;
 
+// Slot of the block at (x,y,z) for a TSDF read, or SLOT_NONE.  No layer-flag check: the TSDF pool of a slot that does
+// not carry F_TSDF is all-zero (freed / ESDF-only slots are zeroed, maintenance.hip), and weight 0 reads as "unobserved"
+// exactly like a missing block.  One 16-B entry load per probe.
+__device__ inline uint32_t tsdf_slot_any(const DMap& m, int32_t x, int32_t y, int32_t z) {
+  const u64 key = pack_key(x, y, z);
+  uint32_t h = table_pos(m, x, y, z);
+  for (uint32_t probe = 0; probe <= m.mask; ++probe) {
+    const uint4 e = *reinterpret_cast<const uint4*>(&m.table[h]);
+    const u64 k = ((u64)e.y << 32) | (u64)e.x;
+    if (k == key) return slot_ok(e.z) ? e.z : SLOT_NONE;
+    if (k == KEY_EMPTY) return SLOT_NONE;
+    h = (h + 1) & m.mask;
+  }
+  return SLOT_NONE;
+}
+
+// [U] SphereTracer::cast restated.  The march t <- t + tsdf(t) reads the TSDF by nearest voxel, so close to the surface
+// it takes several steps inside ONE voxel (step = that voxel's small distance): a one-voxel register cache serves those
+// without touching memory, and a one-block cache skips the hash probe while the ray stays inside a block.  The sequence
+// of t values is bit-identical to the uncached march (same float operations in the same order).
 __global__ __launch_bounds__(64) void k_sphere_trace(DMap m, Frame f, float* synth, int32_t srows, int32_t scols, int32_t max_steps,
                                                      float max_len, float eps_m) {
   const int lane = threadIdx.x;
@@ -30,23 +50,26 @@ __global__ __launch_bounds__(64) void k_sphere_trace(DMap m, Frame f, float* syn
   rotate(f.R_LC, dcx, dcy, dcz, dl);
   bool last_positive = false, hit = false;
   float t = 0.0f;
-  int32_t cbx = INT32_MIN, cby = 0, cbz = 0; uint32_t cslot = SLOT_NONE;
+  int32_t cbx = INT32_MIN, cby = 0, cbz = 0; uint32_t cslot = SLOT_NONE;      // block cache
+  int32_t cgx = INT32_MIN, cgy = 0, cgz = 0; float2 cv = make_float2(0.0f, 0.0f);   // voxel cache
   for (int i = 0; i < max_steps && t < max_len; i++) {
     const float px = f.t_LC[0] + t * dl[0], py = f.t_LC[1] + t * dl[1], pz = f.t_LC[2] + t * dl[2];
     const int32_t gx = (int32_t)floorf(px / f.voxel_size), gy = (int32_t)floorf(py / f.voxel_size), gz = (int32_t)floorf(pz / f.voxel_size);
-    const int32_t bx = gx >> 3, by = gy >> 3, bz = gz >> 3;
-    if (bx != cbx || by != cby || bz != cbz) { cslot = find_slot(m, bx, by, bz, F_TSDF); cbx = bx; cby = by; cbz = bz; }
-    float2 v = make_float2(0.0f, 0.0f);
-    if (slot_ok(cslot)) v = m.tsdf[(size_t)cslot * 512 + (gz & 7) + 8 * (gy & 7) + 64 * (gx & 7)];
+    if (gx != cgx || gy != cgy || gz != cgz) {
+      const int32_t bx = gx >> 3, by = gy >> 3, bz = gz >> 3;
+      if (bx != cbx || by != cby || bz != cbz) { cslot = tsdf_slot_any(m, bx, by, bz); cbx = bx; cby = by; cbz = bz; }
+      cv = slot_ok(cslot) ? m.tsdf[(size_t)cslot * 512 + (gz & 7) + 8 * (gy & 7) + 64 * (gx & 7)] : make_float2(0.0f, 0.0f);
+      cgx = gx; cgy = gy; cgz = gz;
+    }
     float step;
-    if (!slot_ok(cslot) || !(v.y > 1e-4f)) {
+    if (!(cv.y > 1e-4f)) {                       // missing block or unobserved voxel
       if (!last_positive) step = f.trunc; else break;
     } else {
-      if (v.x < eps_m) {
-        if (last_positive) { t = t + v.x; hit = true; }
+      if (cv.x < eps_m) {
+        if (last_positive) { t = t + cv.x; hit = true; }
         break;
       }
-      step = v.x; last_positive = true;
+      step = cv.x; last_positive = true;
     }
     t = t + step;
   }

@@ -2,16 +2,17 @@
 //
 // The 2-D ESDF slice is an exact Euclidean distance transform with a cut-off radius R = esdf_max_distance_m / voxel
 // (the reference's sweep/propagate loop iterates towards the same field; DESIGN.md "ESDF semantics").  The plane of one
-// 8x8x8 ESDF block is exactly one wavefront (64 lanes, lane = x + 8y), stored as one contiguous 512-B line.
-// Per update, four launches, all sizes decided on the device (no host read-back):
+// 8x8x8 ESDF block is exactly one wavefront (64 lanes, lane = x + 8y), stored as one contiguous 512-B line, and its
+// site mask is exactly one 64-bit word (__ballot) kept per block in `site_bits`.
+// Per update, TWO launches, all sizes decided on the device (no host read-back, no scratch image):
 //   k_esdf_mark    one wave per dirty TSDF block: insert the ESDF block (x, y, z_slice), de-duplicate columns with an
 //                  epoch stamp, scan the TSDF z-band (each lane owns one (x,y) column = 64 contiguous bytes per TSDF
-//                  block) -> observed / inside / site flags; grows the dirty window with atomicMin/Max.
-//   k_esdf_bitmap  one wave per block cell of the window (+2R halo): __ballot of the site flags = 8 bytes of a
-//                  row-major 1-bit-per-voxel site bitmap.
-//   k_esdf_rows    per voxel: nearest site along x within R by clz/ctz on 64-bit words of the bitmap -> int8 dx.
-//   k_esdf_cols    one wave per ESDF block of the window (+R): stage the 8 x (8+2R) dx strip in LDS, minimise
-//                  dy^2 + dx^2 over dy, write {sq, parent, flags} back as one 8-byte store per lane.
+//                  block) -> observed / inside / site flags, site mask = __ballot; grows the dirty window (atomicMin/Max).
+//   k_esdf_edt     one wave per ESDF block of the window (dirty AABB + R): gathers the site masks of the (2R/8+1)^2
+//                  surrounding blocks through the hash into LDS, expands them to a local row bitmap, finds the nearest
+//                  site along x by clz/ctz on 64-bit words (row pass, int8 dx in LDS), then minimises dy^2 + dx^2 over dy
+//                  in order of increasing |dy| with early exit (column pass) and writes {sq, parent, flags} back as one
+//                  8-byte store per lane.
 // Call sites served: nvblox_ros/src/lib/nvblox_node.cpp:781 (updateEsdf), :836-844 (sliceLayerToDistanceImage),
 // :917-919 (occupancyGridFromSliceImage); conversions/esdf_slice_conversions.cu:33-73; esdf_and_gradients_conversions.cu:88-125.
 #include <algorithm>
@@ -23,6 +24,10 @@
 using namespace nvbx;
 
 constexpr int8_t DX_NONE = 127;
+constexpr int EDT_MAX_RB = 8;                       // ri <= 63 voxels -> <= 8 blocks each side
+constexpr int EDT_MAX_NN = 2 * EDT_MAX_RB + 1;      // 17 x 17 neighbourhood
+constexpr int EDT_MAX_ROWS = 8 + 2 * 63;            // 134 rows of the local strip
+constexpr int EDT_ROW_WORDS = 5;                    // zero pad word + 3 data words (<= 136 bits) + zero pad word
 
 __global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a, const int32_t* dirty) {
   const int32_t n = m.counters[C_ESDF_DIRTY];
@@ -80,96 +85,105 @@ __global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a, const int3
       }
     }
     m.esdf[(size_t)eslot * 512 + a.vz_out * 64 + lane] = make_uint2(__float_as_uint(a.max_sq), esdf_meta(0, 0, 0, observed, inside, site));
+    const u64 bits = __ballot(site != 0);          // bit (x + 8y) of the block's slice plane
+    if (lane == 0) m.site_bits[eslot] = bits;
   }
 }
 
-// window geometry shared by the three EDT kernels, derived on device from the update record
-struct Win { int32_t gx0, gy0, gw, gh; int32_t wx0, wy0, ww, wh; int32_t stride; bool ok; };
-__device__ inline Win esdf_window(const DMap& m, const EsdfArgs& a) {
-  Win w;
-  const int32_t x0 = m.counters[a.rec + 0], y0 = m.counters[a.rec + 1], x1 = m.counters[a.rec + 2], y1 = m.counters[a.rec + 3];
-  w.ok = x0 <= x1 && y0 <= y1;
-  w.wx0 = x0 - a.rb; w.wy0 = y0 - a.rb; w.ww = x1 - x0 + 1 + 2 * a.rb; w.wh = y1 - y0 + 1 + 2 * a.rb;
-  w.gx0 = x0 - 2 * a.rb; w.gy0 = y0 - 2 * a.rb; w.gw = x1 - x0 + 1 + 4 * a.rb; w.gh = y1 - y0 + 1 + 4 * a.rb;
-  w.stride = 8 * (((w.gw + 7) >> 3) + 2);   // bytes per bitmap row: one zero u64 of padding on each side
-  if (w.ok) {
-    const int64_t need_bm = (int64_t)w.stride * w.gh * 8, need_rd = (int64_t)w.gw * 8 * w.gh * 8;
-    if (need_bm > a.bitmap_bytes || need_rd > a.rowdx_bytes) w.ok = false;
+// slot of any block at (x, y, z) (no layer check), one 16-B entry load per probe
+__device__ inline uint32_t any_slot(const DMap& m, int32_t x, int32_t y, int32_t z) {
+  const u64 key = pack_key(x, y, z);
+  uint32_t h = table_pos(m, x, y, z);
+  for (uint32_t probe = 0; probe <= m.mask; ++probe) {
+    const uint4 e = *reinterpret_cast<const uint4*>(&m.table[h]);
+    const u64 k = ((u64)e.y << 32) | (u64)e.x;
+    if (k == key) return slot_ok(e.z) ? e.z : SLOT_NONE;
+    if (k == KEY_EMPTY) return SLOT_NONE;
+    h = (h + 1) & m.mask;
   }
-  return w;
+  return SLOT_NONE;
 }
 
-__global__ __launch_bounds__(64) void k_esdf_bitmap(DMap m, EsdfArgs a, uint8_t* bitmap) {
-  const Win w = esdf_window(m, a);
+__global__ __launch_bounds__(64) void k_esdf_edt(DMap m, EsdfArgs a) {
+  __shared__ u64 s_bits[EDT_MAX_NN * EDT_MAX_NN];
+  __shared__ u64 s_rows[EDT_MAX_ROWS * EDT_ROW_WORDS];
+  __shared__ int8_t s_dx[EDT_MAX_ROWS * 8];
   const int lane = threadIdx.x;
+  const int vx = lane & 7, vy = lane >> 3;
+  // sweep window = dirty AABB of this update + R (in blocks), decided on the device
+  const int32_t x0 = m.counters[a.rec + 0], y0 = m.counters[a.rec + 1], x1 = m.counters[a.rec + 2], y1 = m.counters[a.rec + 3];
+  const bool ok = x0 <= x1 && y0 <= y1;
+  const int32_t wx0 = x0 - a.rb, wy0 = y0 - a.rb, ww = x1 - x0 + 1 + 2 * a.rb, wh = y1 - y0 + 1 + 2 * a.rb;
   if (blockIdx.x == 0 && lane == 0) {
     m.counters[C_ESDF_DIRTY] = 0;                                 // dirty list consumed by k_esdf_mark
     m.counters[a.rec_next + 0] = INT32_MAX; m.counters[a.rec_next + 1] = INT32_MAX;
     m.counters[a.rec_next + 2] = INT32_MIN; m.counters[a.rec_next + 3] = INT32_MIN;
     m.counters[a.rec_next + 4] = 0; m.counters[a.rec_next + 5] = 0; m.counters[a.rec_next + 6] = 0;
-    if (w.ok) m.counters[a.rec + 6] = w.gw * 8 * w.gh * 8;
-    else if (m.counters[a.rec + 0] <= m.counters[a.rec + 2]) atomicExch(&m.counters[C_OVERFLOW], 1);
+    if (ok) m.counters[a.rec + 6] = ww * 8 * wh * 8;
   }
-  if (!w.ok) return;
-  const int32_t ncell = w.stride * w.gh;     // one cell per bitmap byte column per block row (padding cells included)
+  if (!ok) return;
+  const int nn = 2 * a.rb + 1;                // neighbourhood side in blocks
+  const int rows = 8 + 2 * a.ri;              // local strip: rows Y0 - ri .. Y0 + 7 + ri
+  const int yoff = 8 * a.rb - a.ri;           // strip row 0 in neighbourhood voxel rows
+  const int32_t ncell = ww * wh;
   for (int32_t c = blockIdx.x; c < ncell; c += gridDim.x) {
-    const int32_t cy = c / w.stride, cb = c - cy * w.stride;      // block row, byte column
-    const int32_t cx = cb - 8;                                    // block column relative to gx0
-    uint32_t site = 0;
-    if (cx >= 0 && cx < w.gw) {
-      const uint32_t es = find_slot(m, w.gx0 + cx, w.gy0 + cy, a.bz_out, F_ESDF);
-      if (slot_ok(es)) site = m.esdf[(size_t)es * 512 + a.vz_out * 64 + lane].y & ESDF_SITE;
-    }
-    const u64 mask = __ballot(site != 0);
-    if (lane < 8) bitmap[(size_t)(cy * 8 + lane) * w.stride + cb] = (uint8_t)((mask >> (8 * lane)) & 0xFF);
-  }
-}
-
-__global__ __launch_bounds__(256) void k_esdf_rows(DMap m, EsdfArgs a, const uint8_t* bitmap, int8_t* rowdx) {
-  const Win w = esdf_window(m, a);
-  if (!w.ok) return;
-  const int32_t W = w.gw * 8, H = w.gh * 8;
-  const int64_t n = (int64_t)W * H;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int32_t Y = (int32_t)(i / W), X = (int32_t)(i - (int64_t)Y * W);
-    const u64* row = reinterpret_cast<const u64*>(bitmap + (size_t)Y * w.stride);
-    const int wi = 1 + (X >> 6), b = X & 63;
-    const u64 cur = row[wi], prev = row[wi - 1], next = row[wi + 1];
-    const u64 left = (b == 63) ? cur : ((cur << (63 - b)) | (prev >> (b + 1)));   // bit 63 <-> x, bit 62 <-> x-1, ...
-    const u64 right = (b == 0) ? cur : ((cur >> b) | (next << (64 - b)));         // bit 0 <-> x, bit 1 <-> x+1, ...
-    const int dl = left ? __clzll((long long)left) : 64;
-    const int dr = right ? (__ffsll((long long)right) - 1) : 64;
-    int8_t v = DX_NONE;
-    if (dl <= dr) { if (dl <= a.ri) v = (int8_t)(-dl); }
-    else { if (dr <= a.ri) v = (int8_t)dr; }
-    rowdx[i] = v;
-  }
-}
-
-__global__ __launch_bounds__(64) void k_esdf_cols(DMap m, EsdfArgs a, const int8_t* rowdx) {
-  __shared__ int8_t strip[(8 + 2 * 63) * 8];
-  const Win w = esdf_window(m, a);
-  if (!w.ok) return;
-  const int lane = threadIdx.x;
-  const int vx = lane & 7, vy = lane >> 3;
-  const int32_t W = w.gw * 8;
-  const int32_t ncell = w.ww * w.wh;
-  const int rows = 8 + 2 * a.ri;
-  for (int32_t c = blockIdx.x; c < ncell; c += gridDim.x) {
-    const int32_t cy = c / w.ww, cx = c - cy * w.ww;
-    const int32_t bx = w.wx0 + cx, by = w.wy0 + cy;
+    const int32_t cy = c / ww, cx = c - cy * ww;
+    const int32_t bx = wx0 + cx, by = wy0 + cy;
     const uint32_t es = find_slot(m, bx, by, a.bz_out, F_ESDF);
     if (!slot_ok(es)) continue;          // wave-uniform
-    const int32_t X0 = (bx - w.gx0) * 8, Y0 = (by - w.gy0) * 8 - a.ri;   // strip origin in window voxels (always inside G)
+    __syncthreads();                     // previous block's LDS reads are done
+    // 1. site masks of the nn x nn surrounding blocks (zero where there is no block: site_bits of non-ESDF slots is 0)
+    for (int q = lane; q < nn * nn; q += 64) {
+      const int qy = q / nn, qx = q - qy * nn;
+      const uint32_t s = any_slot(m, bx + qx - a.rb, by + qy - a.rb, a.bz_out);
+      s_bits[q] = slot_ok(s) ? m.site_bits[s] : 0ull;
+    }
     __syncthreads();
-    for (int q = lane; q < rows * 8; q += 64) strip[q] = rowdx[(int64_t)(Y0 + (q >> 3)) * W + X0 + (q & 7)];
+    // 2. row bitmap: word w of row r holds neighbourhood voxel columns 64(w-1) .. 64(w-1)+63 (bit = column & 63)
+    for (int q = lane; q < rows * EDT_ROW_WORDS; q += 64) {
+      const int r = q / EDT_ROW_WORDS, w = q - r * EDT_ROW_WORDS;
+      u64 word = 0ull;
+      if (w >= 1 && w <= 3) {
+        const int yy = r + yoff, qy = yy >> 3, sh = 8 * (yy & 7);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+          const int qx = (w - 1) * 8 + b;
+          if (qx < nn) word |= ((s_bits[qy * nn + qx] >> sh) & 0xFFull) << (8 * b);
+        }
+      }
+      s_rows[q] = word;
+    }
     __syncthreads();
+    // 3. row pass: nearest site along x within ri (ties -> -x), for the block's own 8 columns on every strip row
+    for (int q = lane; q < rows * 8; q += 64) {
+      const int r = q >> 3, X = 8 * a.rb + (q & 7);
+      const u64* row = &s_rows[r * EDT_ROW_WORDS];
+      const int wi = 1 + (X >> 6), b = X & 63;
+      const u64 cur = row[wi], prev = row[wi - 1], next = row[wi + 1];
+      const u64 left = (b == 63) ? cur : ((cur << (63 - b)) | (prev >> (b + 1)));   // bit 63 <-> x, bit 62 <-> x-1, ...
+      const u64 right = (b == 0) ? cur : ((cur >> b) | (next << (64 - b)));         // bit 0 <-> x, bit 1 <-> x+1, ...
+      const int dl = left ? __clzll((long long)left) : 64;
+      const int dr = right ? (__ffsll((long long)right) - 1) : 64;
+      int8_t v = DX_NONE;
+      if (dl <= dr) { if (dl <= a.ri) v = (int8_t)(-dl); }
+      else { if (dr <= a.ri) v = (int8_t)dr; }
+      s_dx[q] = v;
+    }
+    __syncthreads();
+    // 4. column pass: argmin over dy of (dy^2 + dx^2, dy) -- the oracle scans dy ascending with strict improvement,
+    //    i.e. the smallest dy among equal distances; scanning by increasing |dy| lets every lane stop at dy^2 > best.
     int32_t best = INT32_MAX, bdx = 0, bdy = 0;
-    for (int dy = -a.ri; dy <= a.ri; dy++) {
-      const int8_t dx = strip[(vy + a.ri + dy) * 8 + vx];
-      if (dx == DX_NONE) continue;
-      const int32_t sq = dy * dy + (int32_t)dx * dx;
-      if (sq < best) { best = sq; bdx = dx; bdy = dy; }
+    for (int ady = 0; ady <= a.ri; ady++) {
+      if (ady * ady > best) break;
+#pragma unroll
+      for (int sgn = 0; sgn < 2; sgn++) {
+        if (sgn == 1 && ady == 0) continue;
+        const int dy = sgn == 0 ? -ady : ady;
+        const int8_t dx = s_dx[(vy + a.ri + dy) * 8 + vx];
+        if (dx == DX_NONE) continue;
+        const int32_t sq = dy * dy + (int32_t)dx * dx;
+        if (sq < best || (sq == best && dy < bdy)) { best = sq; bdx = dx; bdy = dy; }
+      }
     }
     uint2* vp = &m.esdf[(size_t)es * 512 + a.vz_out * 64 + lane];
     const uint32_t flags = vp->y & ESDF_FLAG_MASK;
@@ -187,9 +201,7 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
   const EsdfArgs a = m->make_esdf_args();
   if (m->p.esdf_max_distance_m / m->p.voxel_size >= 64.0f) { set_error("esdf_max_distance_m / voxel_size must be < 64 voxels"); return NVBX_E_INVALID; }
   NVBX_LAUNCH(m, k_esdf_mark, dim3(1024), dim3(64), m->d, a, m->esdf_dirty);
-  NVBX_LAUNCH(m, k_esdf_bitmap, dim3(1024), dim3(64), m->d, a, m->bitmap);
-  NVBX_LAUNCH(m, k_esdf_rows, dim3(1024), dim3(256), m->d, a, m->bitmap, m->rowdx);
-  NVBX_LAUNCH(m, k_esdf_cols, dim3(2048), dim3(64), m->d, a, m->rowdx);
+  NVBX_LAUNCH(m, k_esdf_edt, dim3(2048), dim3(64), m->d, a);
   NVBX_HIP(hipGetLastError());
   m->esdf_epoch++;
   return NVBX_OK;

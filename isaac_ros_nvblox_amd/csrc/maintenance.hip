@@ -68,7 +68,7 @@ __global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float c
     if (flags & F_TSDF) m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f);
     if (flags & F_COLOR) m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
     if (flags & F_ESDF) m.esdf[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
-    if (tid == 0) { atomicAnd(&m.slot_flags[slot], ~LAYER_MASK); free_slot(m, (uint32_t)slot); }
+    if (tid == 0) { atomicAnd(&m.slot_flags[slot], ~LAYER_MASK); m.site_bits[slot] = 0ull; free_slot(m, (uint32_t)slot); }
   }
 }
 
@@ -86,7 +86,7 @@ __global__ void k_reinsert(DMap m, const uint32_t* tmp) {
     if (!(flags & LAYER_MASK)) continue;
     const int32_t x = m.slot_index[3 * s], y = m.slot_index[3 * s + 1], z = m.slot_index[3 * s + 2];
     const u64 key = pack_key(x, y, z);
-    uint32_t h = index_hash(x, y, z) & m.mask;
+    uint32_t h = table_pos(m, x, y, z);
     for (;;) {
       const u64 k = atomicCAS(&m.table[h].key, KEY_EMPTY, key);
       if (k == KEY_EMPTY) break;

@@ -79,8 +79,9 @@ __global__ __launch_bounds__(512) void k_gather_blocks(DMap m, uint32_t layer, c
 
 // allocateBlockAtIndex + whole-block write from reference structs
 __global__ __launch_bounds__(512) void k_scatter_block(DMap m, uint32_t layer, int32_t x, int32_t y, int32_t z, const uint8_t* in,
-                                                       int32_t* esdf_dirty, int32_t* mesh_dirty, int32_t mesh_cnt) {
+                                                       int32_t* esdf_dirty, int32_t* mesh_dirty, int32_t mesh_cnt, int32_t bz_out, int32_t vz_out) {
   __shared__ uint32_t s_slot;
+  __shared__ u64 s_sites;
   const int t = threadIdx.x;
   if (t == 0) {
     bool is_new; const int32_t h = hash_insert(m, x, y, z, layer, &is_new);
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(512) void k_scatter_block(DMap m, uint32_t layer, i
         atomicMax(&m.counters[C_ESDF_AABB + 2], x); atomicMax(&m.counters[C_ESDF_AABB + 3], y);
       }
     }
-    s_slot = s;
+    s_slot = s; s_sites = 0ull;
   }
   __syncthreads();
   const uint32_t s = s_slot;
@@ -112,6 +113,10 @@ __global__ __launch_bounds__(512) void k_scatter_block(DMap m, uint32_t layer, i
     m.esdf[(size_t)s * 512 + vx + 8 * vy + 64 * vz] =
         make_uint2(__float_as_uint(v.squared_distance_vox),
                    esdf_meta(v.parent_direction[0], v.parent_direction[1], v.parent_direction[2], v.observed, v.is_inside, v.is_site));
+    // keep the slice plane's site mask (what k_esdf_edt reads) consistent with the written voxels
+    if (z == bz_out && vz == vz_out && v.is_site) atomicOr(&s_sites, 1ull << (vx + 8 * vy));
+    __syncthreads();
+    if (t == 0) m.site_bits[s] = (z == bz_out) ? s_sites : 0ull;
   }
 }
 
@@ -121,6 +126,7 @@ static int alloc_all(nvbx_mapper* m) {
   uint64_t tsz = 1; while (tsz < (uint64_t)cap * 2) tsz <<= 1;
   DMap& d = m->d;
   d.capacity = (uint32_t)cap; d.mask = (uint32_t)(tsz - 1);
+  { uint32_t lg = 0; while ((1ull << lg) < tsz) lg++; d.shift = 32u - lg; }
   NVBX_HIP(hipMalloc(&d.table, tsz * sizeof(Entry)));
   NVBX_HIP(hipMalloc(&d.free_stack, cap * 4));
   NVBX_HIP(hipMalloc(&d.counters, C_NUM * 4));
@@ -137,11 +143,7 @@ static int alloc_all(nvbx_mapper* m) {
   NVBX_HIP(hipMalloc(&m->color_list, cap * 4));
   NVBX_HIP(hipMalloc(&m->export_idx, cap * 12));
   NVBX_HIP(hipMalloc(&m->export_count, 64));
-  // ESDF EDT window scratch: up to 4096 x 4096 voxels (+ halo) by default, grows with capacity
-  int64_t side = 4096; while (side * side < cap * 64 * 4 && side < 32768) side *= 2;
-  m->bitmap_bytes = (side / 8 + 16) * side; m->rowdx_bytes = side * side;
-  NVBX_HIP(hipMalloc(&m->bitmap, m->bitmap_bytes));
-  NVBX_HIP(hipMalloc(&m->rowdx, m->rowdx_bytes));
+  NVBX_HIP(hipMalloc(&d.site_bits, cap * 8));
   // mesh arena
   m->mesh_vert_cap = std::min<int64_t>(cap * 192, 48ll << 20); m->mesh_tri_cap = m->mesh_vert_cap * 2;
   NVBX_HIP(hipMalloc(&m->mesh_vert, m->mesh_vert_cap * 12));
@@ -162,6 +164,7 @@ static int reset_map(nvbx_mapper* m) {
   NVBX_HIP(hipMemsetAsync(d.tsdf, 0, cap * 4096, m->stream));
   NVBX_HIP(hipMemsetAsync(d.color, 0, cap * 4096, m->stream));
   NVBX_HIP(hipMemsetAsync(d.esdf, 0, cap * 4096, m->stream));
+  NVBX_HIP(hipMemsetAsync(d.site_bits, 0, cap * 8, m->stream));
   NVBX_HIP(hipMemsetAsync(m->export_count, 0, 64, m->stream));
   const int64_t n = std::max<int64_t>(cap, C_NUM);
   NVBX_LAUNCH(m, k_init_map, dim3((unsigned)((n + 255) / 256)), dim3(256), d);
@@ -214,7 +217,6 @@ EsdfArgs nvbx_mapper::make_esdf_args() const {
   c.min_weight = p.esdf_min_weight; c.voxel_size = vs; c.site_rule = p.esdf_site_rule;
   c.epoch = esdf_epoch;
   c.rec = C_ESDF_UPD + 8 * (int)(esdf_epoch & 1); c.rec_next = C_ESDF_UPD + 8 * (int)((esdf_epoch + 1) & 1);
-  c.bitmap_bytes = bitmap_bytes; c.rowdx_bytes = rowdx_bytes;
   return c;
 }
 
@@ -238,15 +240,15 @@ extern "C" int nvbx_mapper_create(int device, void* hip_stream, const nvbx_mappe
 
 extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   if (!m) return NVBX_OK;
-  hipSetDevice(m->device);
-  if (m->stream) hipStreamSynchronize(m->stream);
+  (void)hipSetDevice(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
   DMap& d = m->d;
   void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.tsdf, d.color, d.esdf,
-                  m->view_list, m->esdf_dirty, m->mesh_dirty, m->color_list, m->export_idx, m->export_count, m->bitmap, m->rowdx,
+                  m->view_list, m->esdf_dirty, m->mesh_dirty, m->color_list, m->export_idx, m->export_count, d.site_bits,
                   m->synth, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
-  for (void* p : ptrs) if (p) hipFree(p);
-  if (m->h_counters) hipHostFree(m->h_counters);
-  if (m->own_stream && m->stream) hipStreamDestroy(m->stream);
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (m->h_counters) (void)hipHostFree(m->h_counters);
+  if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
   return NVBX_OK;
 }
@@ -348,8 +350,9 @@ extern "C" int nvbx_set_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, 
   if (!m || !voxels_in || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF)) return NVBX_E_INVALID;
   const size_t bb = 512 * ref_voxel_bytes(layer);
   NVBX_HIP(hipMemcpyAsync(m->staging, voxels_in, bb, hipMemcpyHostToDevice, m->stream));
+  const EsdfArgs ea = m->make_esdf_args();
   NVBX_LAUNCH(m, k_scatter_block, dim3(1), dim3(512), m->d, layer, idx.x, idx.y, idx.z, (const uint8_t*)m->staging,
-                     m->esdf_dirty, m->mesh_dirty_live(), m->mesh_dirty_counter());
+                     m->esdf_dirty, m->mesh_dirty_live(), m->mesh_dirty_counter(), ea.bz_out, ea.vz_out);
   NVBX_HIP(hipStreamSynchronize(m->stream));
   return NVBX_OK;
 }

@@ -2,13 +2,14 @@
 //
 // HBM layout (one per mapper == one per GPU), sized once for `capacity` blocks, never reallocated:
 //   table      : open-addressing hash, 2^k >= 2*capacity entries of 16 B {key64, slot32, view_stamp32}.  The probe
-//                start is the reference's Index3DHash x + 17191 y + 17191^2 z (nvblox_hash_utils.h:40-50) masked to
-//                the table size; linear probing; no tombstones (deallocation rebuilds the table on device).
+//                start is the reference's Index3DHash x + 17191 y + 17191^2 z (nvblox_hash_utils.h:40-50) scattered by
+//                a Fibonacci multiply (table_pos); linear probing; no tombstones (deallocation rebuilds the table on device).
 //   slot_*     : per-slot metadata (layer/dirty flags, Index3D, back-pointer to the hash entry, ESDF epoch stamp)
 //   tsdf/color : capacity x 512 x 8 B voxel pools, voxel order z + 8y + 64x (the reference's order, so block copies
 //                are memcpy); one slot id addresses the TSDF, colour and ESDF block of the same Index3D.
 //   esdf       : capacity x 512 x 8 B, voxel order x + 8y + 64z so that the 2-D slice plane of a block is one
 //                contiguous 512-B line = one 8-byte access per lane of one wavefront; packed {f32 sq, u32 meta}.
+//   site_bits  : capacity x 8 B, the slice plane's site mask of each ESDF block (one __ballot word)
 // All voxel types are 8 bytes -> every block of every layer is 4 KiB and a 512-thread workgroup (8 wave64) moves one
 // block with one coalesced 8-B access per lane.
 #pragma once
@@ -50,7 +51,7 @@ enum {
 };
 
 struct DMap {
-  Entry* table; uint32_t mask;
+  Entry* table; uint32_t mask; uint32_t shift;   // table size = mask + 1 = 2^(32 - shift)
   uint32_t capacity;
   uint32_t* free_stack;
   int32_t* counters;
@@ -61,6 +62,7 @@ struct DMap {
   float2* tsdf;
   uint2* color;
   uint2* esdf;
+  u64* site_bits;           // per slot: site mask of the block's ESDF slice plane (bit x + 8y); 0 for non-ESDF slots
 };
 
 // Per-call camera / pose / parameter bundle (kernel argument, lives in SGPRs).
@@ -86,6 +88,13 @@ __host__ __device__ inline uint32_t index_hash(int32_t x, int32_t y, int32_t z) 
   return (uint32_t)x + (uint32_t)y * 17191u + (uint32_t)z * (17191u * 17191u);
 }
 
+// Probe start: the reference's Index3DHash scattered by a Fibonacci multiply.  The raw hash maps x-neighbours to
+// adjacent table entries (and y/z strides alias: 17191*5 = 17191^2*3 - 16 mod 2^16), which turns linear probing into
+// 20-40 dependent loads per lookup on a room-sized map; the multiply restores ~1 probe at our <= 0.5 load factor.
+__host__ __device__ inline uint32_t table_pos(const DMap& m, int32_t x, int32_t y, int32_t z) {
+  return (index_hash(x, y, z) * 2654435761u) >> m.shift;
+}
+
 #ifdef __HIPCC__
 __device__ inline int32_t floor_div8(int32_t v) { return v >> 3; }
 __device__ inline int32_t mod8(int32_t v) { return v & 7; }
@@ -97,7 +106,7 @@ __device__ inline uint32_t ld_slot_acquire(const Entry* e) {
 // Lookup of a key inserted by an EARLIER kernel (or earlier in this kernel by this thread). Returns entry or -1.
 __device__ inline int32_t hash_find(const DMap& m, int32_t x, int32_t y, int32_t z) {
   const u64 key = pack_key(x, y, z);
-  uint32_t h = index_hash(x, y, z) & m.mask;
+  uint32_t h = table_pos(m, x, y, z);
   for (uint32_t probe = 0; probe <= m.mask; ++probe) {
     const u64 k = m.table[h].key;
     if (k == key) return (int32_t)h;
@@ -119,7 +128,7 @@ __device__ inline uint32_t find_slot(const DMap& m, int32_t x, int32_t y, int32_
 // an agent-scope store.  `is_new` tells the caller it won.  Returns the entry index or -1 (table full).
 __device__ inline int32_t hash_insert(const DMap& m, int32_t x, int32_t y, int32_t z, uint32_t layer_flags, bool* is_new) {
   const u64 key = pack_key(x, y, z);
-  uint32_t h = index_hash(x, y, z) & m.mask;
+  uint32_t h = table_pos(m, x, y, z);
   *is_new = false;
   for (uint32_t probe = 0; probe <= m.mask; ++probe) {
     u64 k = m.table[h].key;              // may be a stale EMPTY: the CAS below is the truth

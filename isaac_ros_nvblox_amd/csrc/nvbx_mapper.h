@@ -19,7 +19,6 @@ struct EsdfArgs {
   uint32_t epoch;
   int32_t rec;                      // C_ESDF_UPD + 8 * (epoch & 1)
   int32_t rec_next;                 // record of the next epoch (reset by this update)
-  int64_t bitmap_bytes, rowdx_bytes;
 };
 
 struct MeshRecord { int32_t x, y, z, vbase, nvert, tbase, ntri, pad; };
@@ -43,9 +42,6 @@ struct nvbx_mapper {
   int32_t* color_list = nullptr;     // slots updated by the last colour frame
   int32_t* export_idx = nullptr;     // int32[capacity][3] scratch for multi-GPU export of the dirty list
   int32_t* export_count = nullptr;
-  // ESDF scratch
-  uint8_t* bitmap = nullptr; int64_t bitmap_bytes = 0;
-  int8_t* rowdx = nullptr; int64_t rowdx_bytes = 0;
   // colour scratch
   float* synth = nullptr; int64_t synth_cap = 0; int32_t synth_rows = 0, synth_cols = 0;
   // mesh arena

@@ -1,11 +1,12 @@
 // tsdf.hip -- MultiMapper::integrateDepth on MI355X: block marking (view calculation) + projective TSDF update.
 //
 // Two launches per depth frame, no host round trip in between:
-//   k_mark_view      one wavefront per 8x8 tile of the sub-sampled ray grid.  Each lane walks its ray through the
-//                    block grid (Amanatides-Woo); block keys are first filtered through a 4 KiB LDS set (rays of one
-//                    tile share almost all their blocks) and only the first lane to see a block touches HBM: CAS
-//                    insert-if-absent into the hash (device-side allocation from the slot stack) and append to the
-//                    frame's view list exactly once (per-entry frame stamp).
+//   k_mark_view      one wavefront per 8x8 tile of the sub-sampled ray grid.  Phase 1: each lane walks its ray through
+//                    the block grid (Amanatides-Woo) and drops the block keys into a 4 KiB LDS set (rays of one tile
+//                    share almost all their blocks) -- no HBM access inside the walk.  Phase 2: the set is compacted
+//                    (ballot + popcount) and ONE key per lane goes to HBM: CAS insert-if-absent into the hash
+//                    (device-side allocation from the slot stack), per-entry frame stamp, and a wave-aggregated append
+//                    of the pool slot to the frame's view list (exactly once per block and frame).
 //   k_integrate_tsdf one 512-thread workgroup (8 wave64) per 8^3 block, grid-striding over the device-resident view
 //                    list; lane = voxel in z + 8y + 64x order, so every wave reads/writes 512 contiguous bytes.
 // Reference semantics restated: [U] ViewCalculator::getBlocksInImageViewRaycast and ProjectiveTsdfIntegrator
@@ -17,9 +18,46 @@ using namespace nvbx;
 
 constexpr int LSET = 512;   // LDS dedup set entries per wave-tile (8 B each)
 
+__device__ inline void unpack_key(u64 key, int32_t* x, int32_t* y, int32_t* z) {
+  *x = (int32_t)(key & 0x1FFFFFull) - (1 << 20);
+  *y = (int32_t)((key >> 21) & 0x1FFFFFull) - (1 << 20);
+  *z = (int32_t)((key >> 42) & 0x1FFFFFull) - (1 << 20);
+}
+
+// One block key -> HBM: insert-if-absent, stamp the entry with this frame, and report whether THIS call was the first
+// of the frame to do so (the caller then appends the block's pool slot to the view list exactly once).
+__device__ inline bool mark_block(const DMap& m, u64 key, uint32_t frame_id, uint32_t* slot_out) {
+  int32_t x, y, z; unpack_key(key, &x, &y, &z);
+  bool is_new;
+  const int32_t h = hash_insert(m, x, y, z, F_TSDF, &is_new);
+  if (h < 0) return false;
+  // cheap L2-served read first: most tiles find the entry already stamped by a neighbouring tile
+  if (__hip_atomic_load(&m.table[h].stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == frame_id) return false;
+  if (atomicExch(&m.table[h].stamp, frame_id) == frame_id) return false;
+  uint32_t s;
+  do { s = ld_slot_acquire(&m.table[h]); } while (s == SLOT_INVALID);   // the winner publishes right after its CAS
+  *slot_out = s;
+  return true;
+}
+
+// wave-aggregated append of this lane's `slot` (if `first`) to the frame's view list: one returning atomic per wave
+__device__ inline void view_append(int32_t* cnt, int32_t* view_list, int32_t list_cap, bool first, uint32_t slot, int lane) {
+  const u64 mask = __ballot(first);
+  if (!mask) return;
+  int32_t base = 0;
+  const int leader = __ffsll((long long)mask) - 1;
+  if (lane == leader) base = atomicAdd(cnt, (int32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  if (first) {
+    const int32_t pos = base + (int32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (pos < list_cap) view_list[pos] = (int32_t)slot;
+  }
+}
+
 template <typename Img>
 __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, int32_t* view_list, int32_t list_cap) {
   __shared__ u64 lset[LSET];
+  __shared__ u64 lkeys[LSET];
   const int lane = threadIdx.x;
   for (int i = lane; i < LSET; i += 64) lset[i] = KEY_EMPTY;
   if (blockIdx.x == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
@@ -61,28 +99,21 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, in
     }
   }
   int32_t* cnt = &m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
+  // ---- phase 1: walk.  Keys go to the LDS set only; HBM is touched here only if the set overflows (never at
+  //      640x480 / 8 m: a tile's ray bundle crosses < 100 blocks).
   for (int32_t k = 0; k <= nsteps; k++) {
     const u64 key = pack_key(cur[0], cur[1], cur[2]);
-    // stage 1: LDS filter
-    bool need = true;
-    uint32_t lh = (index_hash(cur[0], cur[1], cur[2]) * 2654435761u) >> 23;   // 9 bits
+    bool spill = true;
+    const uint32_t lh = (index_hash(cur[0], cur[1], cur[2]) * 2654435761u) >> 23;   // 9 bits
 #pragma unroll 1
-    for (int p = 0; p < 8; p++) {
+    for (int p = 0; p < 16; p++) {
       const u64 old = atomicCAS(&lset[(lh + p) & (LSET - 1)], KEY_EMPTY, key);
-      if (old == KEY_EMPTY) break;
-      if (old == key) { need = false; break; }
+      if (old == KEY_EMPTY || old == key) { spill = false; break; }
     }
-    // stage 2: HBM hash
-    if (need) {
-      bool is_new;
-      const int32_t h = hash_insert(m, cur[0], cur[1], cur[2], F_TSDF, &is_new);
-      if (h >= 0) {
-        const uint32_t old = atomicExch(&m.table[h].stamp, f.frame_id);
-        if (old != f.frame_id) {
-          const int32_t pos = atomicAdd(cnt, 1);
-          if (pos < list_cap) view_list[pos] = h;
-        }
-      }
+    if (__ballot(spill)) {                       // rare overflow path, wave-uniform branch
+      uint32_t slot = SLOT_NONE;
+      const bool first = spill && mark_block(m, key, f.frame_id, &slot);
+      view_append(cnt, view_list, list_cap, first, slot, lane);
     }
     int a = 0;
     if (tmax[1] < tmax[a]) a = 1;
@@ -92,20 +123,34 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, in
     else if (a == 1) { cur[1] += step[1]; tmax[1] = tmax[1] + tdelta[1]; }
     else { cur[2] += step[2]; tmax[2] = tmax[2] + tdelta[2]; }
   }
+  __syncthreads();
+  // ---- phase 2: compact the set (ballot + popcount), then one key per lane goes to HBM: the hash probe, the stamp
+  //      exchange and the slot read of all the tile's blocks are in flight together instead of one per ray step.
+  int32_t nk = 0;
+#pragma unroll
+  for (int i = 0; i < LSET / 64; i++) {
+    const u64 key = lset[i * 64 + lane];
+    const u64 mask = __ballot(key != KEY_EMPTY);
+    if (key != KEY_EMPTY) lkeys[nk + (int32_t)__popcll(mask & ((1ull << lane) - 1ull))] = key;
+    nk += (int32_t)__popcll(mask);
+  }
+  __syncthreads();
+  for (int32_t i = 0; i < nk; i += 64) {
+    uint32_t slot = SLOT_NONE;
+    const bool first = (i + lane < nk) && mark_block(m, lkeys[i + lane], f.frame_id, &slot);
+    view_append(cnt, view_list, list_cap, first, slot, lane);
+  }
 }
 
 template <typename Img>
-__global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img depth, int32_t* view_list, int32_t list_cap,
+__global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img depth, const int32_t* view_list, int32_t list_cap,
                                                         int32_t* esdf_dirty, int32_t* mesh_dirty, int32_t mesh_cnt) {
   int32_t n = m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
   if (n > list_cap) n = list_cap;
   const int tid = threadIdx.x;
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
   for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const uint32_t h = (uint32_t)view_list[i];
-    const uint32_t slot = m.table[h].slot;
-    __syncthreads();                       // every thread has read the entry id before it is replaced
-    if (tid == 0) view_list[i] = (int32_t)slot;   // the list now names pool slots (stable across hash rebuilds)
+    const uint32_t slot = (uint32_t)view_list[i];      // pool slots (stable across hash rebuilds)
     if (!slot_ok(slot)) continue;
     const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
     if (tid == 0) {
