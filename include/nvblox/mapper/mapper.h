@@ -1,0 +1,170 @@
+// nvblox/mapper/mapper.h -- nvblox::Mapper as nvblox_ros uses it (signatures collected in SURVEY.md 8b from
+// nvblox_node.cpp / layer_publishing.cpp / fuser_node.cpp), implemented as inline wrappers over the C-ABI of
+// libnvblox_hip.so (include/nvblox_hip.h).  Single-caller, stream-ordered like the reference (nvblox_node.cpp:99,456-459).
+#pragma once
+#include <memory>
+#include <optional>
+#include <string>
+#include <vector>
+#include "nvblox/core/cuda_stream.h"
+#include "nvblox/core/types.h"
+#include "nvblox/map/layer.h"
+#include "nvblox/mapper/mapper_params.h"
+#include "nvblox/mesh/mesh.h"
+#include "nvblox/sensors/camera.h"
+#include "nvblox/sensors/image.h"
+#include "nvblox/utils/timing.h"
+#include "nvblox_hip.h"
+
+namespace nvblox {
+
+// LayerType bit mask used by serializeSelectedLayers (layer_publishing.cpp:675-711)
+using LayerTypeBitMask = uint32_t;
+namespace LayerType {
+constexpr LayerTypeBitMask kTsdf = NVBX_LAYER_TSDF, kColor = NVBX_LAYER_COLOR, kEsdf = NVBX_LAYER_ESDF, kColorMesh = NVBX_LAYER_MESH,
+                           kFreespace = 16u, kOccupancy = 32u;
+}
+struct BlockExclusionParams {   // layer_publishing.cpp:702-707
+  Vector3f exclusion_center_m; float exclusion_height_m = -1.f; float exclusion_radius_m = -1.f; float block_size_m = 0.f;
+};
+
+class Mapper {
+ public:
+  static constexpr int64_t kDefaultBlockCapacity = 1 << 16;   // 64 k blocks = 768 MiB of voxel pools in HBM
+
+  Mapper(float voxel_size_m, MemoryType memory_type = MemoryType::kDevice, ProjectiveLayerType projective_layer_type = ProjectiveLayerType::kTsdf,
+         std::shared_ptr<CudaStream> cuda_stream = std::make_shared<CudaStreamOwning>(), int64_t block_capacity = kDefaultBlockCapacity)
+      : voxel_size_m_(voxel_size_m), projective_layer_type_(projective_layer_type), cuda_stream_(std::move(cuda_stream)) {
+    (void)memory_type;   // blocks always live in HBM (MemoryType::kDevice, nvblox_node.cpp:190)
+    int dev = 0; (void)hipGetDevice(&dev);
+    const nvbx_mapper_params p = params_.toCAbi(voxel_size_m);
+    checkNvbx(nvbx_mapper_create(dev, (void*)(hipStream_t)(*cuda_stream_), &p, block_capacity, &m_), "nvbx_mapper_create");
+    rebuildViews();
+  }
+  ~Mapper() { if (m_) nvbx_mapper_destroy(m_); }
+  Mapper(const Mapper&) = delete;
+  Mapper& operator=(const Mapper&) = delete;
+
+  void setMapperParams(const MapperParams& params) {
+    params_ = params;
+    const nvbx_mapper_params p = params_.toCAbi(voxel_size_m_);
+    checkNvbx(nvbx_mapper_set_params(m_, &p), "nvbx_mapper_set_params");
+  }
+  const MapperParams& params() const { return params_; }
+
+  // -- integration (asynchronous on the mapper's stream); README timer tags tsdf/integrate, color/integrate, ...
+  void integrateDepth(const DepthImage& depth_frame, const Transform& T_L_C, const Camera& camera) {
+    timing::Timer t("tsdf/integrate");
+    float T[16]; T_L_C.toRowMajor(T);
+    checkNvbx(nvbx_integrate_depth(m_, depth_frame.dataConstPtr(), depth_frame.rows(), depth_frame.cols(), T, &camera.c_abi()), "nvbx_integrate_depth");
+  }
+  // 16-bit millimetre depth: fuses conversions::depthImageFromNitrosViewAsync (image_conversions_thrust.cu:39-45)
+  void integrateDepth(const Image<uint16_t>& depth_mm, const Transform& T_L_C, const Camera& camera) {
+    timing::Timer t("tsdf/integrate");
+    float T[16]; T_L_C.toRowMajor(T);
+    checkNvbx(nvbx_integrate_depth_u16mm(m_, depth_mm.dataConstPtr(), depth_mm.rows(), depth_mm.cols(), T, &camera.c_abi()), "nvbx_integrate_depth_u16mm");
+  }
+  void integrateColor(const ColorImage& color_frame, const Transform& T_L_C, const Camera& camera) {
+    timing::Timer t("color/integrate");
+    float T[16]; T_L_C.toRowMajor(T);
+    checkNvbx(nvbx_integrate_color(m_, reinterpret_cast<const uint8_t*>(color_frame.dataConstPtr()), color_frame.rows(), color_frame.cols(), T, &camera.c_abi()),
+              "nvbx_integrate_color");
+  }
+  void updateEsdf() { timing::Timer t("esdf/integrate"); checkNvbx(nvbx_update_esdf(m_), "nvbx_update_esdf"); }
+  void updateColorMesh(UpdateFullLayer update_full_layer = UpdateFullLayer::kNo) {
+    timing::Timer t("mesh/integrate");
+    checkNvbx(nvbx_update_color_mesh(m_, update_full_layer == UpdateFullLayer::kYes ? 1 : 0), "nvbx_update_color_mesh");
+  }
+  void updateMesh(UpdateFullLayer f = UpdateFullLayer::kNo) { updateColorMesh(f); }
+  void decayTsdf() { checkNvbx(nvbx_decay_tsdf(m_, 0), "nvbx_decay_tsdf"); }
+  template <typename SensorType>
+  void decayTsdfExcludeLastView() { checkNvbx(nvbx_decay_tsdf(m_, 1), "nvbx_decay_tsdf"); }   // nvblox_node.cpp:935
+  void clearOutsideRadius(const Vector3f& center, float radius) {   // nvblox_node.cpp:1575
+    const std::vector<Index3D> before = tsdf_layer_.getAllBlockIndices();
+    checkNvbx(nvbx_clear_outside_radius(m_, center.data(), radius), "nvbx_clear_outside_radius");
+    const std::vector<Index3D> after = tsdf_layer_.getAllBlockIndices();   // both sorted
+    size_t j = 0;
+    for (const auto& b : before) { while (j < after.size() && after[j] < b) j++; if (j >= after.size() || !(after[j] == b)) cleared_blocks_.push_back(b); }
+  }
+  // layer_publishing.cpp:716: blocks removed since the last call
+  std::vector<Index3D> getClearedBlocks(const std::vector<uint32_t>& = {}) { std::vector<Index3D> out; out.swap(cleared_blocks_); return out; }
+  void clear() { checkNvbx(nvbx_mapper_clear(m_), "nvbx_mapper_clear"); }
+
+  // -- layers
+  const TsdfLayer& tsdf_layer() const { return tsdf_layer_; }
+  const ColorLayer& color_layer() const { return color_layer_; }
+  const EsdfLayer& esdf_layer() const { return esdf_layer_; }
+  TsdfLayer& tsdf_layer() { return tsdf_layer_; }
+  ColorLayer& color_layer() { return color_layer_; }
+  EsdfLayer& esdf_layer() { return esdf_layer_; }
+  float voxel_size_m() const { return voxel_size_m_; }
+  ProjectiveLayerType projective_layer_type() const { return projective_layer_type_; }
+
+  // -- integrator parameter accessors used by the node (nvblox_node.cpp:136,1509,1513,1529-1533)
+  struct EsdfIntegratorView {
+    const Mapper* m;
+    float esdf_slice_height() const { return m->params_.esdf_integrator_params.esdf_slice_height; }
+    float esdf_slice_min_height() const { return m->params_.esdf_integrator_params.esdf_slice_min_height; }
+    float esdf_slice_max_height() const { return m->params_.esdf_integrator_params.esdf_slice_max_height; }
+    float max_esdf_distance_m() const { return m->params_.esdf_integrator_params.esdf_integrator_max_distance_m; }
+  };
+  struct ViewCalculatorView {
+    const Mapper* m;
+    WorkspaceBoundsType workspace_bounds_type() const { return m->params_.view_calculator_params.workspace_bounds_type; }
+    Vector3f workspace_bounds_min_corner_m() const { const auto& v = m->params_.view_calculator_params; return {v.workspace_bounds_min_corner_x_m, v.workspace_bounds_min_corner_y_m, v.workspace_bounds_min_height_m}; }
+    Vector3f workspace_bounds_max_corner_m() const { const auto& v = m->params_.view_calculator_params; return {v.workspace_bounds_max_corner_x_m, v.workspace_bounds_max_corner_y_m, v.workspace_bounds_max_height_m}; }
+    int raycast_subsampling_factor() const { return m->params_.view_calculator_params.raycast_subsampling_factor; }
+  };
+  struct TsdfIntegratorView {
+    const Mapper* m;
+    ViewCalculatorView view_calculator() const { return ViewCalculatorView{m}; }
+    float max_integration_distance_m() const { return m->params_.projective_integrator_params.projective_integrator_max_integration_distance_m; }
+    float truncation_distance_vox() const { return m->params_.projective_integrator_params.projective_integrator_truncation_distance_vox; }
+  };
+  EsdfIntegratorView esdf_integrator() const { return EsdfIntegratorView{this}; }
+  TsdfIntegratorView tsdf_integrator() const { return TsdfIntegratorView{this}; }
+
+  // -- serialization of the mesh for publishing (layer_publishing.cpp:702-711,770-776; mesh_conversions.cpp:62-104)
+  void serializeSelectedLayers(LayerTypeBitMask layers, float /*bandwidth_limit_mbps*/ = -1.f, const BlockExclusionParams& = BlockExclusionParams()) {
+    if (layers & LayerType::kColorMesh) serializeColorMesh();
+  }
+  std::shared_ptr<SerializedColorMeshLayer> serializedColorMeshLayer() const { return serialized_mesh_; }
+
+  // .nvblx save/load is outside the hot path and not provided by libnvblox_hip: report failure
+  // through the reference's bool convention (nvblox_node.cpp:1668,1703).
+  bool saveLayerCake(const std::string&) const { return false; }
+  bool loadMap(const std::string&) { return false; }
+
+  void synchronize() const { checkNvbx(nvbx_synchronize(m_), "nvbx_synchronize"); }
+  nvbx_mapper* c_handle() const { return m_; }
+  const std::shared_ptr<CudaStream>& cuda_stream() const { return cuda_stream_; }
+
+ private:
+  void rebuildViews() { tsdf_layer_ = TsdfLayer(m_, voxel_size_m_); color_layer_ = ColorLayer(m_, voxel_size_m_); esdf_layer_ = EsdfLayer(m_, voxel_size_m_); }
+  void serializeColorMesh() {
+    int64_t nb = 0, nv = 0, nt = 0;
+    checkNvbx(nvbx_mesh_sizes(m_, &nb, &nv, &nt), "nvbx_mesh_sizes");
+    auto s = std::make_shared<SerializedColorMeshLayer>();
+    s->block_indices.resize((size_t)nb); s->vertices.resize((size_t)nv); s->vertex_normals.resize((size_t)nv);
+    s->vertex_appearances.resize((size_t)nv); s->triangle_indices.resize((size_t)nt * 3);
+    s->vertex_block_offsets.assign((size_t)nb + 1, 0); s->triangle_index_block_offsets.assign((size_t)nb + 1, 0);
+    std::vector<uint8_t> rgba((size_t)nv * 4);
+    checkNvbx(nvbx_mesh_copy(m_, reinterpret_cast<nvbx_index3d*>(s->block_indices.data()), s->vertex_block_offsets.data(),
+                             s->triangle_index_block_offsets.data(), reinterpret_cast<float*>(s->vertices.data()),
+                             reinterpret_cast<float*>(s->vertex_normals.data()), rgba.data(), s->triangle_indices.data()), "nvbx_mesh_copy");
+    for (size_t i = 0; i < (size_t)nv; i++) s->vertex_appearances[i] = Color(rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2]);
+    for (auto& o : s->triangle_index_block_offsets) o *= 3;   // triangles -> indices
+    serialized_mesh_ = s;
+  }
+
+  float voxel_size_m_;
+  ProjectiveLayerType projective_layer_type_;
+  std::shared_ptr<CudaStream> cuda_stream_;
+  MapperParams params_;
+  nvbx_mapper* m_ = nullptr;
+  TsdfLayer tsdf_layer_; ColorLayer color_layer_; EsdfLayer esdf_layer_;
+  std::vector<Index3D> cleared_blocks_;
+  std::shared_ptr<SerializedColorMeshLayer> serialized_mesh_ = std::make_shared<SerializedColorMeshLayer>();
+};
+
+}  // namespace nvblox

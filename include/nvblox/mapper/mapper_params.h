@@ -1,0 +1,100 @@
+// nvblox/mapper/mapper_params.h -- MapperParams with the member names nvblox_ros writes
+// (nvblox_ros/src/lib/mapper_initialization.cpp:231-466).  Members outside the static TSDF / colour / ESDF-2D / mesh
+// path are carried (so getMapperParamsFromROS compiles) but ignored by libnvblox_hip; toCAbi() lists what is consumed.
+#pragma once
+#include "nvblox/core/types.h"
+#include "nvblox/integrators/weighting_function.h"
+#include "nvblox_hip.h"
+
+namespace nvblox {
+
+enum class WorkspaceBoundsType { kUnbounded, kHeightBounds, kBoundingBox };   // mapper_initialization.cpp:44-60
+enum class EsdfMode { k3D, k2D };                                             // node_params.hpp:86-91
+enum class MappingType { kStaticTsdf, kStaticOccupancy, kDynamic, kHumanWithStaticTsdf, kHumanWithStaticOccupancy };
+enum class ProjectiveLayerType { kTsdf, kOccupancy, kNone };
+enum class UpdateFullLayer { kNo, kYes };
+
+struct ProjectiveIntegratorParams {
+  float projective_integrator_max_integration_distance_m = 7.0f;
+  float lidar_projective_integrator_max_integration_distance_m = 10.0f;
+  float projective_integrator_truncation_distance_vox = 4.0f;
+  WeightingFunctionType projective_integrator_weighting_mode = WeightingFunctionType::kInverseSquareWeight;
+  float projective_integrator_max_weight = 5.0f;
+  float projective_tsdf_integrator_invalid_depth_decay_factor = -1.0f;
+};
+struct ViewCalculatorParams {
+  int raycast_subsampling_factor = 4;
+  WorkspaceBoundsType workspace_bounds_type = WorkspaceBoundsType::kUnbounded;
+  float workspace_bounds_min_height_m = 0.f, workspace_bounds_max_height_m = 0.f;
+  float workspace_bounds_min_corner_x_m = 0.f, workspace_bounds_max_corner_x_m = 0.f;
+  float workspace_bounds_min_corner_y_m = 0.f, workspace_bounds_max_corner_y_m = 0.f;
+};
+struct EsdfIntegratorParams {
+  float esdf_integrator_min_weight = 0.1f;
+  float esdf_integrator_max_site_distance_vox = 2.0f;
+  float esdf_integrator_max_distance_m = 2.0f;
+  float esdf_slice_min_height = 0.0f, esdf_slice_max_height = 1.0f, esdf_slice_height = 1.0f;
+  float slice_height_above_plane_m = 0.0f, slice_height_thickness_m = 0.0f;
+};
+struct MeshIntegratorParams { float mesh_integrator_min_weight = 0.1f; bool mesh_integrator_weld_vertices = true; };
+struct DecayIntegratorBaseParams { bool decay_integrator_deallocate_decayed_blocks = true; };
+struct TsdfDecayIntegratorParams {
+  float tsdf_decay_factor = 0.95f, tsdf_decayed_weight_threshold = 0.001f;
+  bool tsdf_set_free_distance_on_decayed = false; float tsdf_decayed_free_distance_vox = 4.0f;
+};
+struct OccupancyIntegratorParams {
+  float free_region_occupancy_probability = 0.3f, occupied_region_occupancy_probability = 0.7f,
+        unobserved_region_occupancy_probability = 0.5f, occupied_region_half_width_m = 0.1f;
+};
+struct OccupancyDecayIntegratorParams { float free_region_decay_probability = 0.55f, occupied_region_decay_probability = 0.4f; bool occupancy_decay_to_free = false; };
+struct FreespaceIntegratorParams {
+  float max_tsdf_distance_for_occupancy_m = 0.15f; Time max_unobserved_to_keep_consecutive_occupancy_ms{200};
+  Time min_duration_since_occupied_for_freespace_ms{1000}; Time min_consecutive_occupancy_duration_for_reset_ms{2000};
+  bool check_neighborhood = true, initialize_to_high_confidence_freespace = false;
+};
+
+struct MapperParams {
+  bool do_depth_preprocessing = false;
+  int depth_preprocessing_num_dilations = 4;
+  ProjectiveIntegratorParams projective_integrator_params;
+  ViewCalculatorParams view_calculator_params;
+  EsdfIntegratorParams esdf_integrator_params;
+  MeshIntegratorParams mesh_integrator_params;
+  DecayIntegratorBaseParams decay_integrator_base_params;
+  TsdfDecayIntegratorParams tsdf_decay_integrator_params;
+  OccupancyIntegratorParams occupancy_integrator_params;
+  OccupancyDecayIntegratorParams occupancy_decay_integrator_params;
+  FreespaceIntegratorParams freespace_integrator_params;
+
+  // what libnvblox_hip consumes
+  nvbx_mapper_params toCAbi(float voxel_size) const {
+    nvbx_mapper_params p{};
+    p.voxel_size = voxel_size;
+    p.max_integration_distance_m = projective_integrator_params.projective_integrator_max_integration_distance_m;
+    p.truncation_distance_vox = projective_integrator_params.projective_integrator_truncation_distance_vox;
+    p.max_weight = projective_integrator_params.projective_integrator_max_weight;
+    p.weighting_mode = (int32_t)projective_integrator_params.projective_integrator_weighting_mode;
+    p.raycast_subsampling_factor = view_calculator_params.raycast_subsampling_factor;
+    p.esdf_min_weight = esdf_integrator_params.esdf_integrator_min_weight;
+    p.esdf_max_site_distance_vox = esdf_integrator_params.esdf_integrator_max_site_distance_vox;
+    p.esdf_max_distance_m = esdf_integrator_params.esdf_integrator_max_distance_m;
+    p.esdf_slice_height = esdf_integrator_params.esdf_slice_height;
+    p.esdf_slice_min_height = esdf_integrator_params.esdf_slice_min_height;
+    p.esdf_slice_max_height = esdf_integrator_params.esdf_slice_max_height;
+    p.mesh_min_weight = mesh_integrator_params.mesh_integrator_min_weight;
+    p.mesh_weld_vertices = mesh_integrator_params.mesh_integrator_weld_vertices ? 1 : 0;
+    p.sphere_tracing_subsampling = 4; p.sphere_tracing_max_steps = 100;
+    p.sphere_tracing_max_ray_length_m = 15.0f; p.sphere_tracing_surface_eps_vox = 0.1f;
+    p.tsdf_decay_factor = tsdf_decay_integrator_params.tsdf_decay_factor;
+    p.tsdf_decayed_weight_threshold = tsdf_decay_integrator_params.tsdf_decayed_weight_threshold;
+    p.esdf_site_rule = 0; p.depth_interp_nearest = 0;
+    return p;
+  }
+};
+
+struct MultiMapperParams {   // multi_mapper.* parameters (mapper_initialization.cpp: getMultiMapperParamsFromROS)
+  int connected_mask_component_size_threshold = 2000;
+  int remove_small_connected_components = 1;
+};
+
+}  // namespace nvblox

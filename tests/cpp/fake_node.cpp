@@ -1,0 +1,163 @@
+// fake_node.cpp -- a ROS-free translation unit that drives libnvblox_hip through the nvblox:: C++ facade with the SAME call
+// expressions nvblox_ros uses (reference lines quoted at each call).  It proves the drop-in boundary compiles and links
+// (CPU test) and, on a GPU box, that the facade produces the same map as the ctypes path the parity tests use.
+//
+// usage: fake_node <frames.bin> [mesh]      prints one JSON line.
+// frames.bin: int32 n, rows, cols; float fu, fv, cu, cv; then n x { float T_L_C[16] row-major, float depth[rows*cols], uint8 rgb[rows*cols*3] }
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <string>
+#include <vector>
+#include <nvblox/nvblox.h>
+
+using namespace nvblox;
+
+struct FakeNode {
+  // nvblox_node.hpp:470-488,539,548: members of NvbloxNode
+  std::shared_ptr<CudaStream> cuda_stream_;
+  std::shared_ptr<MultiMapper> multi_mapper_;
+  std::shared_ptr<Mapper> static_mapper_, dynamic_mapper_;
+  DepthImage depth_image_{MemoryType::kDevice};
+  ColorImage color_image_{MemoryType::kDevice};
+  EsdfSlicer esdf_slicer_;
+  Transform T_L_C_depth_;
+  struct { float voxel_size = 0.05f; MappingType mapping_type = MappingType::kStaticTsdf; EsdfMode esdf_mode = EsdfMode::k2D;
+           float distance_map_unknown_value_optimistic = 1000.0f; } params_;
+
+  FakeNode() {
+    // nvblox_node.cpp:91
+    cuda_stream_ = CudaStream::createCudaStream(static_cast<CudaStreamType>(2));
+    // nvblox_node.cpp:186-190
+    multi_mapper_ =
+      std::make_shared<MultiMapper>(
+      params_.voxel_size, params_.mapping_type, params_.esdf_mode,
+      MemoryType::kDevice, cuda_stream_);
+    // what getMapperParamsFromROS("static_mapper") yields for fuser.yaml (mapper_initialization.cpp:231-466)
+    MapperParams static_mapper_params, dynamic_mapper_params;
+    auto& pi = static_mapper_params.projective_integrator_params;
+    pi.projective_integrator_max_integration_distance_m = 8.0f;
+    pi.projective_integrator_truncation_distance_vox = 4.0f;
+    pi.projective_integrator_weighting_mode = WeightingFunctionType::kConstantWeight;
+    pi.projective_integrator_max_weight = 5.0f;
+    static_mapper_params.view_calculator_params.raycast_subsampling_factor = 4;
+    static_mapper_params.esdf_integrator_params.esdf_integrator_min_weight = 0.1f;
+    static_mapper_params.esdf_integrator_params.esdf_integrator_max_site_distance_vox = 2.0f;
+    static_mapper_params.esdf_integrator_params.esdf_integrator_max_distance_m = 2.0f;
+    static_mapper_params.esdf_integrator_params.esdf_slice_height = 0.09f;
+    static_mapper_params.esdf_integrator_params.esdf_slice_min_height = 0.09f;
+    static_mapper_params.esdf_integrator_params.esdf_slice_max_height = 0.65f;
+    static_mapper_params.mesh_integrator_params.mesh_integrator_min_weight = 0.1f;
+    MultiMapperParams multi_mapper_params;
+    // nvblox_node.cpp:203-204
+    multi_mapper_->setMapperParams(static_mapper_params, dynamic_mapper_params);
+    multi_mapper_->setMultiMapperParams(multi_mapper_params);
+    // nvblox_node.cpp:209-210
+    static_mapper_ = multi_mapper_.get()->background_mapper();
+    dynamic_mapper_ = multi_mapper_.get()->foreground_mapper();
+  }
+
+  // nvblox_node.cpp:974-1091 processDepthImage, minus ROS
+  bool processDepthImage(const float* depth_host, int rows, int cols, const Transform& T_L_C, const Camera& depth_camera_) {
+    T_L_C_depth_ = T_L_C;
+    depth_image_.copyFromAsync(rows, cols, depth_host, *cuda_stream_);      // image_conversions.cpp:147-155
+    const Time update_time_ms(0);
+    multi_mapper_->integrateDepth(depth_image_, T_L_C_depth_, depth_camera_, update_time_ms);   // :1062
+    return true;
+  }
+  // nvblox_node.cpp:1186-1275 processColorImage
+  bool processColorImage(const Color* color_host, int rows, int cols, const Transform& T_L_C, const Camera& color_camera) {
+    color_image_.copyFromAsync(rows, cols, color_host, *cuda_stream_);
+    multi_mapper_->integrateColor(color_image_, T_L_C, color_camera);       // :1264
+    return true;
+  }
+  // nvblox_node.cpp:774-817 processEsdf + :819-889 sliceAndPublishEsdf
+  void processEsdf(std::vector<float>* slice_host, int* width, int* height, AxisAlignedBoundingBox* aabb_out, std::vector<int8_t>* occupancy) {
+    multi_mapper_->updateEsdf();                                            // :781
+    const std::shared_ptr<Mapper>& mapper = static_mapper_;
+    const float unknown_value = params_.distance_map_unknown_value_optimistic;
+    AxisAlignedBoundingBox aabb;
+    Image<float> map_slice_image(MemoryType::kDevice);
+    esdf_slicer_.sliceLayerToDistanceImage(
+      mapper->esdf_layer(),
+      mapper->esdf_integrator().esdf_slice_height(), unknown_value,
+      &aabb, &map_slice_image);                                             // :841-844
+    // esdf_slice_conversions.cu:86-108 distanceMapSliceMsgFromSliceImage
+    *width = map_slice_image.cols();
+    *height = map_slice_image.rows();
+    slice_host->assign((size_t)(*width) * (*height), unknown_value);
+    (void)hipMemcpyAsync(slice_host->data(), map_slice_image.dataConstPtr(), map_slice_image.numel() * sizeof(float), hipMemcpyDefault, *cuda_stream_);
+    cuda_stream_->synchronize();
+    *aabb_out = aabb;
+    // nvblox_node.cpp:914-919 publishOccupancyGridMsg
+    occupancy->assign((size_t)(*width) * (*height), (int8_t)-1);
+    esdf_slicer_.occupancyGridFromSliceImage(map_slice_image, occupancy->data(), unknown_value);
+  }
+  // layer_publishing.cpp:686-711 + mesh_conversions.cpp:62-104
+  void publishMesh(size_t* n_blocks, size_t* n_vertices, size_t* n_triangle_indices, double* vertex_sum) {
+    std::shared_ptr<Mapper> static_mapper = static_mapper_;
+    static_mapper->updateColorMesh();                                       // :688
+    BlockExclusionParams block_exclusion_params{
+      .exclusion_center_m = T_L_C_depth_.translation(),
+      .exclusion_height_m = -1.f,
+      .exclusion_radius_m = -1.f,
+      .block_size_m = static_mapper->tsdf_layer().block_size(),
+    };
+    static_mapper->serializeSelectedLayers(LayerType::kColorMesh, -1.f, block_exclusion_params);   // :709-711
+    const std::vector<Index3D> blocks_to_remove_static_mapper = static_mapper->getClearedBlocks({});   // :715-716
+    (void)blocks_to_remove_static_mapper;
+    const std::shared_ptr<SerializedColorMeshLayer> serialized_mesh = static_mapper->serializedColorMeshLayer();
+    const size_t num_blocks = serialized_mesh->block_indices.size();
+    *n_blocks = num_blocks; *n_vertices = 0; *n_triangle_indices = 0; *vertex_sum = 0.0;
+    for (size_t i_block = 0; i_block < num_blocks; ++i_block) {
+      const int num_vertices = serialized_mesh->getNumVerticesInBlock(i_block);
+      const int num_triangle_indices = serialized_mesh->getNumTriangleIndicesInBlock(i_block);
+      for (size_t i_vert = 0; i_vert < static_cast<size_t>(num_vertices); ++i_vert) {
+        const Vector3f v = serialized_mesh->getVertex(i_block, i_vert);
+        const Color c = serialized_mesh->getAppearance(i_block, i_vert);
+        *vertex_sum += (double)v.x() + (double)v.y() + (double)v.z() + (double)c.r;
+      }
+      for (size_t i_tri = 0; i_tri < static_cast<size_t>(num_triangle_indices); ++i_tri) {
+        if (serialized_mesh->getTriangleIndex(i_block, i_tri) >= num_vertices) { std::fprintf(stderr, "bad triangle index\n"); std::exit(1); }
+      }
+      *n_vertices += (size_t)num_vertices; *n_triangle_indices += (size_t)num_triangle_indices;
+    }
+  }
+};
+
+int main(int argc, char** argv) {
+  if (argc < 2) { std::fprintf(stderr, "usage: %s frames.bin\n", argv[0]); return 2; }
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f) { std::perror("open"); return 2; }
+  int32_t hdr[3]; float k[4];
+  if (std::fread(hdr, 4, 3, f) != 3 || std::fread(k, 4, 4, f) != 4) return 2;
+  const int n = hdr[0], rows = hdr[1], cols = hdr[2];
+  warmupCuda();                                                             // fuser_node_main.cpp:38
+  FakeNode node;
+  const Camera camera(k[0], k[1], k[2], k[3], cols, rows);                  // image_conversions.cpp:27-32
+  std::vector<float> depth((size_t)rows * cols); std::vector<Color> rgb((size_t)rows * cols); float T[16];
+  for (int i = 0; i < n; i++) {
+    if (std::fread(T, 4, 16, f) != 16 || std::fread(depth.data(), 4, depth.size(), f) != depth.size() || std::fread(rgb.data(), 3, rgb.size(), f) != rgb.size()) return 2;
+    const Transform T_L_C = Transform::fromRowMajor(T);
+    node.processDepthImage(depth.data(), rows, cols, T_L_C, camera);
+    node.processColorImage(rgb.data(), rows, cols, T_L_C, camera);
+    node.cuda_stream_->synchronize();      // host staging buffers are reused next iteration
+  }
+  std::fclose(f);
+  std::vector<float> slice; std::vector<int8_t> occ; int width = 0, height = 0; AxisAlignedBoundingBox aabb;
+  node.processEsdf(&slice, &width, &height, &aabb, &occ);
+  size_t mb = 0, mv = 0, mt = 0; double vsum = 0.0;
+  node.publishMesh(&mb, &mv, &mt, &vsum);
+  // summary the Python test compares with the ctypes path
+  const TsdfLayer& tsdf = node.static_mapper_->tsdf_layer();
+  double tsdf_sum = 0.0; size_t observed = 0;
+  callFunctionOnAllVoxels<TsdfVoxel>(tsdf, [&](const Index3D&, const Index3D&, const TsdfVoxel* v) { if (v->weight > 0.f) { tsdf_sum += (double)v->distance * (double)v->weight; observed++; } });
+  double slice_sum = 0.0; size_t known = 0, occupied = 0;
+  for (size_t i = 0; i < slice.size(); i++) { if (slice[i] < 999.0f) { slice_sum += slice[i]; known++; } if (occ[i] == 100) occupied++; }
+  std::printf("{\"tsdf_blocks\": %d, \"color_blocks\": %d, \"esdf_blocks\": %d, \"tsdf_observed\": %zu, \"tsdf_sum\": %.9g, "
+              "\"slice_width\": %d, \"slice_height\": %d, \"slice_known\": %zu, \"slice_sum\": %.9g, \"occupied\": %zu, "
+              "\"aabb_min\": [%.6f, %.6f, %.6f], \"mesh_blocks\": %zu, \"mesh_vertices\": %zu, \"mesh_triangle_indices\": %zu, \"mesh_vertex_sum\": %.9g}\n",
+              tsdf.numAllocatedBlocks(), node.static_mapper_->color_layer().numAllocatedBlocks(), node.static_mapper_->esdf_layer().numAllocatedBlocks(),
+              observed, tsdf_sum, width, height, known, slice_sum, occupied, aabb.min().x(), aabb.min().y(), aabb.min().z(), mb, mv, mt, vsum);
+  return 0;
+}
