@@ -91,13 +91,16 @@ def main():
     g = M.Mapper(M.default_params(), device=local_rank, block_capacity=1 << 15, stream=stream.cuda_stream)
     ex = DirtyBlockExchange(4096, dev) if world > 1 else None
 
+    dargs = [g.prepare_depth(depth_dev[k], poses[k], cam) for k in range(nu)]
+    cargs = [g.prepare_color(rgb_dev[k], poses[k], cam) for k in range(nu)]
+
     def step(i, mesh=False):
         k = i % nu
-        g.integrate_depth(depth_dev[k], poses[k], cam)
-        g.integrate_color(rgb_dev[k], poses[k], cam)
+        g.integrate_prepared(dargs[k])          # MultiMapper::integrateDepth
         if ex is not None:
-            ex.exchange(g)
-        g.update_esdf()
+            ex.exchange(g)                       # dirty block indices: export -> RCCL all-gather -> mark (needs only the depth pass)
+        g.integrate_prepared(cargs[k])          # MultiMapper::integrateColor
+        g.update_esdf()                          # MultiMapper::updateEsdf (side stream: overlaps the colour pass)
         if mesh:
             g.update_color_mesh()
 

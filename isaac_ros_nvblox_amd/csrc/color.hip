@@ -14,66 +14,100 @@
 
 using namespace nvbx;
 
-// Slot of the block at (x,y,z) for a TSDF read, or SLOT_NONE.  No layer-flag check: the TSDF pool of a slot that does
-// not carry F_TSDF is all-zero (freed / ESDF-only slots are zeroed, maintenance.hip), and weight 0 reads as "unobserved"
-// exactly like a missing block.  One 16-B entry load per probe.
-__device__ inline uint32_t tsdf_slot_any(const DMap& m, int32_t x, int32_t y, int32_t z) {
-  const u64 key = pack_key(x, y, z);
-  uint32_t h = table_pos(m, x, y, z);
+// TSDF reads below skip the layer-flag load: the TSDF pool of a slot that does not carry F_TSDF is all-zero (freed /
+// ESDF-only slots are zeroed, maintenance.hip), and weight 0 reads as "unobserved" exactly like a missing block.
+constexpr int RAY_LANES = 16;   // lanes cooperating on one ray = samples fetched per round trip
+
+// finish a lookup whose first probe `e` at `h` is already loaded (16 B): slot of any block with `key`, or SLOT_NONE
+__device__ inline uint32_t resolve_tsdf_slot(const DMap& m, u64 key, uint32_t h, uint4 e) {
   for (uint32_t probe = 0; probe <= m.mask; ++probe) {
-    const uint4 e = *reinterpret_cast<const uint4*>(&m.table[h]);
     const u64 k = ((u64)e.y << 32) | (u64)e.x;
     if (k == key) return slot_ok(e.z) ? e.z : SLOT_NONE;
     if (k == KEY_EMPTY) return SLOT_NONE;
     h = (h + 1) & m.mask;
+    e = *reinterpret_cast<const uint4*>(&m.table[h]);
   }
   return SLOT_NONE;
 }
 
-// [U] SphereTracer::cast restated.  The march t <- t + tsdf(t) reads the TSDF by nearest voxel, so close to the surface
-// it takes several steps inside ONE voxel (step = that voxel's small distance): a one-voxel register cache serves those
-// without touching memory, and a one-block cache skips the hash probe while the ray stays inside a block.  The sequence
-// of t values is bit-identical to the uncached march (same float operations in the same order).
-__global__ __launch_bounds__(64) void k_sphere_trace(DMap m, Frame f, float* synth, int32_t srows, int32_t scols, int32_t max_steps,
-                                                     float max_len, float eps_m) {
-  const int lane = threadIdx.x;
-  if (blockIdx.x == 0 && lane == 0) m.counters[C_COLOR_COUNT] = 0;
-  const int tiles_x = (scols + 7) >> 3;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int r = ty * 8 + (lane >> 3), c = tx * 8 + (lane & 7);
-  if (r >= srows || c >= scols) return;
+// [U] SphereTracer::cast restated, sample-parallel.  The serial march t <- t + tsdf(t) (nearest voxel) is a chain of
+// dependent HBM round trips (hash entry, then voxel) plus ~150 ALU ops per step, and a ray takes 10-20 steps.  But the
+// step is PREDICTABLE: exactly `trunc` through free (clamped) or unobserved space, and the same small value while the
+// ray stays inside one voxel near the surface.  So 16 lanes serve one ray: lane j fetches the sample at
+// t + j*ps (ps = predicted step, accumulated with the same float additions the serial march performs), all 16 hash
+// probes and voxel loads are in flight together, and the group consumes the samples in order with ballots while each
+// sample's step equals the prediction.  The first sample that breaks it supplies the next t and the next prediction.
+// The sequence of t values -- and so the result -- is bit-identical to the one-sample-at-a-time march.
+__global__ __launch_bounds__(256) void k_sphere_trace(DMap m, Frame f, float* synth, int32_t srows, int32_t scols, int32_t max_steps,
+                                                      float max_len, float eps_m) {
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid == 0) m.counters[C_COLOR_COUNT] = 0;
+  const int lane = tid & 63;
+  const int sub = lane & (RAY_LANES - 1);              // sample index within the ray's group
+  const int gsh = lane & ~(RAY_LANES - 1);             // first lane of the group (= shift of its bits in a ballot)
+  const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + tid) / RAY_LANES;
+  const bool valid = ray < (int64_t)srows * scols;
+  const int r = valid ? (int)(ray / scols) : 0, c = valid ? (int)(ray - (int64_t)r * scols) : 0;
   const float rx = (((float)(c * f.subsample) + 0.5f) - f.cu) / f.fu;
   const float ry = (((float)(r * f.subsample) + 0.5f) - f.cv) / f.fv;
   const float n = sqrtf((rx * rx + ry * ry) + 1.0f);
   const float dcx = rx / n, dcy = ry / n, dcz = 1.0f / n;
   float dl[3];
   rotate(f.R_LC, dcx, dcy, dcz, dl);
-  bool last_positive = false, hit = false;
-  float t = 0.0f;
-  int32_t cbx = INT32_MIN, cby = 0, cbz = 0; uint32_t cslot = SLOT_NONE;      // block cache
-  int32_t cgx = INT32_MIN, cgy = 0, cgz = 0; float2 cv = make_float2(0.0f, 0.0f);   // voxel cache
-  for (int i = 0; i < max_steps && t < max_len; i++) {
-    const float px = f.t_LC[0] + t * dl[0], py = f.t_LC[1] + t * dl[1], pz = f.t_LC[2] + t * dl[2];
+  // group-uniform march state (replicated in the group's lanes)
+  bool last_positive = false, hit = false, done = !valid;
+  float t = 0.0f, ps = f.trunc;
+  int i = 0;
+  while (__ballot(!done)) {                              // wave-uniform loop: ballots / shuffles below need all lanes
+    // this lane's sample: t advanced `sub` times by the predicted step (the serial march's additions, replayed)
+    float tc = t;
+    for (int j = 0; j < RAY_LANES - 1; j++) if (j < sub) tc = tc + ps;
+    const float px = f.t_LC[0] + tc * dl[0], py = f.t_LC[1] + tc * dl[1], pz = f.t_LC[2] + tc * dl[2];
     const int32_t gx = (int32_t)floorf(px / f.voxel_size), gy = (int32_t)floorf(py / f.voxel_size), gz = (int32_t)floorf(pz / f.voxel_size);
-    if (gx != cgx || gy != cgy || gz != cgz) {
-      const int32_t bx = gx >> 3, by = gy >> 3, bz = gz >> 3;
-      if (bx != cbx || by != cby || bz != cbz) { cslot = tsdf_slot_any(m, bx, by, bz); cbx = bx; cby = by; cbz = bz; }
-      cv = slot_ok(cslot) ? m.tsdf[(size_t)cslot * 512 + (gz & 7) + 8 * (gy & 7) + 64 * (gx & 7)] : make_float2(0.0f, 0.0f);
-      cgx = gx; cgy = gy; cgz = gz;
-    }
-    float step;
-    if (!(cv.y > 1e-4f)) {                       // missing block or unobserved voxel
-      if (!last_positive) step = f.trunc; else break;
-    } else {
-      if (cv.x < eps_m) {
-        if (last_positive) { t = t + cv.x; hit = true; }
-        break;
+    const int32_t bx = gx >> 3, by = gy >> 3, bz = gz >> 3;
+    const uint32_t h = done ? 0u : table_pos(m, bx, by, bz);
+    const uint4 e = *reinterpret_cast<const uint4*>(&m.table[h]);
+    const uint32_t slot = done ? SLOT_NONE : resolve_tsdf_slot(m, pack_key(bx, by, bz), h, e);
+    const float2 v = m.tsdf[slot_ok(slot) ? (size_t)slot * 512 + (gz & 7) + 8 * (gy & 7) + 64 * (gx & 7) : 0];
+    // classify the sample as the serial loop body would, assuming every earlier sample of the round kept the prediction
+    const bool in_bounds = (i + sub < max_steps) && (tc < max_len);
+    const bool observed = slot_ok(slot) && (v.y > 1e-4f);
+    const bool surf = observed && (v.x < eps_m);                     // hit test
+    const bool keep = observed && !surf && (v.x == ps);              // observed, step == prediction
+    const u64 obs_mask = __ballot(observed && !surf);                 // samples that set last_positive
+    const uint32_t before = (uint32_t)((obs_mask >> gsh) & ((1u << sub) - 1u));
+    const bool pos_before = last_positive || before != 0;            // last_positive when the serial loop reaches this sample
+    const bool unobs_keep = !observed && !pos_before && (ps == f.trunc);   // unobserved: step = trunc, if that is the prediction
+    const bool event = !done && !(in_bounds && (keep || unobs_keep));
+    const uint32_t ev = (uint32_t)((__ballot(event) >> gsh) & 0xFFFFu);
+    const int e_sub = ev ? (__ffs((int)ev) - 1) : RAY_LANES;         // first sample that breaks the prediction
+    const int src = gsh + (e_sub < RAY_LANES ? e_sub : RAY_LANES - 1);
+    // values at the event sample (or at the last sample if the whole round kept the prediction)
+    const float e_tc = __shfl(tc, src);
+    const float e_vx = __shfl(v.x, src);
+    const int e_inb = __shfl((int)in_bounds, src), e_obs = __shfl((int)observed, src), e_surf = __shfl((int)surf, src);
+    const int e_posb = __shfl((int)pos_before, src);
+    const int pos_last = __shfl((int)(pos_before || (observed && !surf)), gsh + RAY_LANES - 1);   // last_positive after 16 kept samples
+    if (!done) {
+      if (e_sub == RAY_LANES) {                      // all 16 samples consumed with the predicted step
+        t = e_tc + ps; i += RAY_LANES; last_positive = pos_last != 0;
+      } else {
+        i += e_sub;                                  // samples before the event were regular steps
+        last_positive = e_posb != 0;
+        if (!e_inb) { done = true; }
+        else if (!e_obs) {                           // unobserved / missing
+          if (!last_positive) { t = e_tc + f.trunc; i += 1; ps = f.trunc; }   // (prediction was not trunc)
+          else done = true;
+        } else if (e_surf) {
+          if (last_positive) { t = e_tc + e_vx; hit = true; }
+          done = true;
+        } else {                                     // observed, step differs from the prediction
+          t = e_tc + e_vx; i += 1; last_positive = true; ps = e_vx;
+        }
       }
-      step = cv.x; last_positive = true;
     }
-    t = t + step;
   }
-  synth[(int64_t)r * scols + c] = hit ? t * dcz : 0.0f;
+  if (valid && sub == 0) synth[(int64_t)r * scols + c] = hit ? t * dcz : 0.0f;
 }
 
 __device__ inline uint32_t blend_u8(float c0, float w0, float c1, float w1) {
@@ -86,8 +120,9 @@ __device__ inline uint32_t blend_u8(float c0, float w0, float c1, float w1) {
   return (uint32_t)v;
 }
 
-struct SynthImg { const float* p; __device__ float operator()(int64_t i) const { return p[i]; } };
-
+// Dependent-access chain: {slot flags, Index3D, TSDF voxel, colour voxel} (all addressed by the slot id alone, fetched
+// together) -> block vote -> {synthetic depth gather, colour gather} (both addressed by the projection, fetched
+// together) -> store.
 __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, const uint8_t* rgb, const float* synth, int32_t srows, int32_t scols,
                                                          int32_t* color_list, int32_t* mesh_dirty, int32_t mesh_cnt) {
   __shared__ int s_out[6];
@@ -96,8 +131,12 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, const 
   const int tid = threadIdx.x;
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
   for (int32_t slot = blockIdx.x; slot < hw; slot += gridDim.x) {
-    if (!(m.slot_flags[slot] & F_TSDF)) continue;     // uniform
+    const uint32_t flags = m.slot_flags[slot];
     const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
+    const float2 tv = m.tsdf[(size_t)slot * 512 + tid];          // zero for slots without a TSDF block
+    uint2* cp = &m.color[(size_t)slot * 512 + tid];
+    const uint2 cur = *cp;
+    if (!(flags & F_TSDF)) continue;     // uniform
     __syncthreads();
     if (tid < 6) s_out[tid] = 0;
     if (tid == 6) s_band = 0;
@@ -113,7 +152,6 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, const 
       if (pc[2] < 0.0f) atomicAdd(&s_out[4], 1);
       if (f.max_dist > 0.0f && pc[2] > f.max_dist) atomicAdd(&s_out[5], 1);
     }
-    const float2 tv = m.tsdf[(size_t)slot * 512 + tid];
     if (tv.y > 1e-4f && fabsf(tv.x) < f.trunc) s_band = 1;   // benign race: all writers store 1
     __syncthreads();
     bool in_view = true;
@@ -132,27 +170,39 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, const 
     if (!cam_project(f, pc, &u, &v)) continue;
     const float vd = pc[2];
     if (f.max_dist > 0.0f && vd > f.max_dist) continue;
-    float sd;
-    if (!interp_depth(SynthImg{synth}, srows, scols, u / (float)f.subsample, v / (float)f.subsample, 0, &sd)) continue;
-    if (fabsf(sd - vd) > f.trunc) continue;
-    // bilinear colour (interpolate2DLinear<Color>)
+    // bilinear taps of the colour image (interpolate2DLinear<Color>) and of the synthetic depth: addresses first, then
+    // all 4 + 12 loads in flight together
     const float uc = u - 0.5f, vc = v - 0.5f;
     const float fx = floorf(uc), fy = floorf(vc);
     const int x0 = (int)fx, y0 = (int)fy;
-    if (x0 < 0 || y0 < 0 || x0 + 1 > f.cols - 1 || y0 + 1 > f.rows - 1) continue;
-    const float ax = uc - fx, ay = vc - fy;
+    const bool c_ok = !(x0 < 0 || y0 < 0 || x0 + 1 > f.cols - 1 || y0 + 1 > f.rows - 1);
+    const float us = u / (float)f.subsample, vs_ = v / (float)f.subsample;
+    const float usc = us - 0.5f, vsc = vs_ - 0.5f;
+    const float sfx = floorf(usc), sfy = floorf(vsc);
+    const int sx0 = (int)sfx, sy0 = (int)sfy;
+    const bool s_ok = !(sx0 < 0 || sy0 < 0 || sx0 + 1 > scols - 1 || sy0 + 1 > srows - 1);
+    if (!c_ok || !s_ok) continue;
+    const float* sp = synth + (int64_t)sy0 * scols + sx0;
     const uint8_t* p00 = rgb + ((int64_t)y0 * f.cols + x0) * 3;
     const uint8_t* p01 = p00 + (int64_t)f.cols * 3;
+    const float s00 = sp[0], s10 = sp[1], s01 = sp[scols], s11 = sp[scols + 1];
+    float t00[3], t10[3], t01[3], t11[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) { t00[ch] = (float)p00[ch]; t10[ch] = (float)p00[3 + ch]; t01[ch] = (float)p01[ch]; t11[ch] = (float)p01[3 + ch]; }
+    if (!(s00 > 0.0f) || !(s10 > 0.0f) || !(s01 > 0.0f) || !(s11 > 0.0f)) continue;
+    const float sax = usc - sfx, say = vsc - sfy;
+    const float stop = (1.0f - sax) * s00 + sax * s10;
+    const float sbot = (1.0f - sax) * s01 + sax * s11;
+    const float sd = (1.0f - say) * stop + say * sbot;
+    if (fabsf(sd - vd) > f.trunc) continue;
+    const float ax = uc - fx, ay = vc - fy;
     float c[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
-      const float f00 = (float)p00[ch], f10 = (float)p00[3 + ch], f01 = (float)p01[ch], f11 = (float)p01[3 + ch];
-      const float top = (1.0f - ax) * f00 + ax * f10;
-      const float bot = (1.0f - ax) * f01 + ax * f11;
+      const float top = (1.0f - ax) * t00[ch] + ax * t10[ch];
+      const float bot = (1.0f - ax) * t01[ch] + ax * t11[ch];
       c[ch] = (1.0f - ay) * top + ay * bot;
     }
-    uint2* cp = &m.color[(size_t)slot * 512 + tid];
-    const uint2 cur = *cp;
     const float w0 = __uint_as_float(cur.y);
     const uint32_t r8 = blend_u8((float)(cur.x & 0xFF), w0, c[0], 1.0f);
     const uint32_t g8 = blend_u8((float)((cur.x >> 8) & 0xFF), w0, c[1], 1.0f);
@@ -176,8 +226,8 @@ extern "C" int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int3
     m->synth_cap = (int64_t)srows * scols;
   }
   m->synth_rows = srows; m->synth_cols = scols;
-  const int tiles = ((srows + 7) / 8) * ((scols + 7) / 8);
-  NVBX_LAUNCH(m, k_sphere_trace, dim3(tiles), dim3(64), m->d, f, m->synth, srows, scols, m->p.sphere_tracing_max_steps,
+  const int64_t nthreads = (int64_t)srows * scols * RAY_LANES;
+  NVBX_LAUNCH(m, k_sphere_trace, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), m->d, f, m->synth, srows, scols, m->p.sphere_tracing_max_steps,
                      m->p.sphere_tracing_max_ray_length_m, m->p.sphere_tracing_surface_eps_vox * m->p.voxel_size);
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
   NVBX_LAUNCH(m, k_integrate_color, dim3(grid), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->color_list, m->mesh_dirty_live(), m->mesh_dirty_counter());

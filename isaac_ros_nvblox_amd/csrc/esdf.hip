@@ -29,49 +29,74 @@ constexpr int EDT_MAX_NN = 2 * EDT_MAX_RB + 1;      // 17 x 17 neighbourhood
 constexpr int EDT_MAX_ROWS = 8 + 2 * 63;            // 134 rows of the local strip
 constexpr int EDT_ROW_WORDS = 5;                    // zero pad word + 3 data words (<= 136 bits) + zero pad word
 
+// 16-B entry at a probe position
+__device__ inline uint4 ld_entry(const DMap& m, uint32_t h) { return *reinterpret_cast<const uint4*>(&m.table[h]); }
+
+// finish a lookup whose first probe `e` at `h` is already loaded: slot of any block with `key` (no layer check) or SLOT_NONE
+__device__ inline uint32_t resolve_any(const DMap& m, u64 key, uint32_t h, uint4 e) {
+  for (uint32_t probe = 0; probe <= m.mask; ++probe) {
+    const u64 k = ((u64)e.y << 32) | (u64)e.x;
+    if (k == key) return slot_ok(e.z) ? e.z : SLOT_NONE;
+    if (k == KEY_EMPTY) return SLOT_NONE;
+    h = (h + 1) & m.mask;
+    e = ld_entry(m, h);
+  }
+  return SLOT_NONE;
+}
+__device__ inline uint32_t any_slot(const DMap& m, int32_t x, int32_t y, int32_t z) {
+  const uint32_t h = table_pos(m, x, y, z);
+  return resolve_any(m, pack_key(x, y, z), h, ld_entry(m, h));
+}
+
+// Dependent-access chain: {dirty count, dirty slot} -> {flags, Index3D} -> {hash entries of the ESDF block and of the
+// TSDF z-band blocks, one per lane, in flight together} -> {column stamp exchange || TSDF column loads} -> store.
 __global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a, const int32_t* dirty) {
-  const int32_t n = m.counters[C_ESDF_DIRTY];
   const int lane = threadIdx.x;
   const int vx = lane & 7, vy = lane >> 3;
+  int32_t ts0 = dirty[blockIdx.x];                         // speculative: valid iff blockIdx.x < n (gridDim.x <= capacity)
+  const int32_t n = m.counters[C_ESDF_DIRTY];
+  const int nz = a.bz_hi - a.bz_lo + 1;                    // TSDF blocks spanned by the slice z band (<= 62)
   for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const uint32_t tslot = (uint32_t)dirty[i];
+    const uint32_t tslot = (uint32_t)(i == (int32_t)blockIdx.x ? ts0 : dirty[i]);
     const uint32_t tflags = m.slot_flags[tslot];
-    if (lane == 0) atomicAnd(&m.slot_flags[tslot], ~F_DIRTY_ESDF);
     const int32_t bx = m.slot_index[3 * tslot], by = m.slot_index[3 * tslot + 1], bz = m.slot_index[3 * tslot + 2];
+    if (lane == 0) atomicAnd(&m.slot_flags[tslot], ~F_DIRTY_ESDF);
     // a dirty TSDF block of the z band dirties its column; a block that lost its TSDF (decay) only re-marks an
     // existing column
     if (bz < a.bz_lo || bz > a.bz_hi) continue;
-    if (!(tflags & F_TSDF) && !slot_ok(find_slot(m, bx, by, a.bz_out, F_ESDF))) continue;
-    uint32_t eslot = SLOT_NONE; int first = 0;
+    // lane 0: the ESDF block (x, y, z_slice); lanes 1..nz: the TSDF blocks of the band -- one probe each, together
+    const int32_t qz = lane == 0 ? a.bz_out : a.bz_lo + lane - 1;
+    const bool probing = lane <= nz;
+    const u64 qkey = pack_key(bx, by, qz);
+    const uint32_t qh = probing ? table_pos(m, bx, by, qz) : 0u;
+    const uint4 qe = ld_entry(m, qh);
+    uint32_t qslot = probing ? resolve_any(m, qkey, qh, qe) : SLOT_NONE;
+    uint32_t eslot = __shfl(qslot, 0);
+    const bool e_exists = slot_ok(eslot) && (m.slot_flags[slot_ok(eslot) ? eslot : 0] & F_ESDF);
+    if (!(tflags & F_TSDF) && !e_exists) continue;          // uniform
+    int first = 0;
     if (lane == 0) {
-      bool is_new;
-      const int32_t h = hash_insert(m, bx, by, a.bz_out, F_ESDF, &is_new);
-      if (h >= 0) {
-        do { eslot = ld_slot_acquire(&m.table[h]); } while (eslot == SLOT_INVALID);
-        if (slot_ok(eslot)) {
-          atomicOr(&m.slot_flags[eslot], F_ESDF);
-          first = atomicExch(&m.slot_stamp[eslot], a.epoch) != a.epoch;
-          if (first) {
-            atomicMin(&m.counters[a.rec + 0], bx); atomicMin(&m.counters[a.rec + 1], by);
-            atomicMax(&m.counters[a.rec + 2], bx); atomicMax(&m.counters[a.rec + 3], by);
-            atomicMin(&m.counters[C_ESDF_AABB + 0], bx); atomicMin(&m.counters[C_ESDF_AABB + 1], by);
-            atomicMax(&m.counters[C_ESDF_AABB + 2], bx); atomicMax(&m.counters[C_ESDF_AABB + 3], by);
-            atomicAdd(&m.counters[a.rec + 4], 1);
-          }
-        }
+      if (!slot_ok(eslot)) {                                // new column: insert (device-side allocation)
+        bool is_new;
+        const int32_t h = hash_insert(m, bx, by, a.bz_out, F_ESDF, &is_new);
+        if (h >= 0) { do { eslot = ld_slot_acquire(&m.table[h]); } while (eslot == SLOT_INVALID); }
+      }
+      if (slot_ok(eslot)) {
+        atomicOr(&m.slot_flags[eslot], F_ESDF);
+        first = atomicExch(&m.slot_stamp[eslot], a.epoch) != a.epoch;
       }
     }
-    eslot = __shfl(eslot, 0); first = __shfl(first, 0);
-    if (!first || !slot_ok(eslot)) continue;
+    // TSDF columns of the band: this lane's (x, y) column of block bzz is voxels 64*vx + 8*vy + 0..7 = 64 contiguous bytes
+    // (weight 0 -- also what a slot without a TSDF block reads -- contributes nothing)
     int observed = 0, inside = 0, site = 0;
-    for (int32_t bzz = a.bz_lo; bzz <= a.bz_hi; ++bzz) {
-      const uint32_t ts = find_slot(m, bx, by, bzz, F_TSDF);
-      if (!slot_ok(ts)) continue;
-      // this lane's column: voxels z = 0..7 at linear index 64*vx + 8*vy + z  -> 64 contiguous bytes
+    for (int32_t q = 0; q < nz; ++q) {
+      const uint32_t ts = __shfl(qslot, q + 1);
+      if (!slot_ok(ts)) continue;                           // uniform
+      const int32_t bzz = a.bz_lo + q;
       const float4* col = reinterpret_cast<const float4*>(&m.tsdf[(size_t)ts * 512 + 64 * vx + 8 * vy]);
       float dz[8], wz[8];
 #pragma unroll
-      for (int q = 0; q < 4; q++) { const float4 v = col[q]; dz[2 * q] = v.x; wz[2 * q] = v.y; dz[2 * q + 1] = v.z; wz[2 * q + 1] = v.w; }
+      for (int w = 0; w < 4; w++) { const float4 v = col[w]; dz[2 * w] = v.x; wz[2 * w] = v.y; dz[2 * w + 1] = v.z; wz[2 * w + 1] = v.w; }
 #pragma unroll
       for (int z = 0; z < 8; z++) {
         const int32_t kz = bzz * 8 + z;
@@ -84,37 +109,37 @@ __global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a, const int3
         }
       }
     }
+    eslot = __shfl(eslot, 0); first = __shfl(first, 0);
+    if (!first || !slot_ok(eslot)) continue;                // column already re-marked in this update
+    if (lane == 0) {
+      atomicMin(&m.counters[a.rec + 0], bx); atomicMin(&m.counters[a.rec + 1], by);
+      atomicMax(&m.counters[a.rec + 2], bx); atomicMax(&m.counters[a.rec + 3], by);
+      atomicMin(&m.counters[C_ESDF_AABB + 0], bx); atomicMin(&m.counters[C_ESDF_AABB + 1], by);
+      atomicMax(&m.counters[C_ESDF_AABB + 2], bx); atomicMax(&m.counters[C_ESDF_AABB + 3], by);
+      atomicAdd(&m.counters[a.rec + 4], 1);
+    }
     m.esdf[(size_t)eslot * 512 + a.vz_out * 64 + lane] = make_uint2(__float_as_uint(a.max_sq), esdf_meta(0, 0, 0, observed, inside, site));
     const u64 bits = __ballot(site != 0);          // bit (x + 8y) of the block's slice plane
     if (lane == 0) m.site_bits[eslot] = bits;
   }
 }
 
-// slot of any block at (x, y, z) (no layer check), one 16-B entry load per probe
-__device__ inline uint32_t any_slot(const DMap& m, int32_t x, int32_t y, int32_t z) {
-  const u64 key = pack_key(x, y, z);
-  uint32_t h = table_pos(m, x, y, z);
-  for (uint32_t probe = 0; probe <= m.mask; ++probe) {
-    const uint4 e = *reinterpret_cast<const uint4*>(&m.table[h]);
-    const u64 k = ((u64)e.y << 32) | (u64)e.x;
-    if (k == key) return slot_ok(e.z) ? e.z : SLOT_NONE;
-    if (k == KEY_EMPTY) return SLOT_NONE;
-    h = (h + 1) & m.mask;
-  }
-  return SLOT_NONE;
-}
-
-__global__ __launch_bounds__(64) void k_esdf_edt(DMap m, EsdfArgs a) {
+// Four wavefronts per ESDF block.  Dependent-access chain: {window record} -> {hash entries of the (2rb+1)^2
+// neighbourhood, own block included} -> {site masks, own layer flag, own voxel flags} -> LDS phases -> store.
+__global__ __launch_bounds__(256) void k_esdf_edt(DMap m, EsdfArgs a) {
   __shared__ u64 s_bits[EDT_MAX_NN * EDT_MAX_NN];
   __shared__ u64 s_rows[EDT_MAX_ROWS * EDT_ROW_WORDS];
   __shared__ int8_t s_dx[EDT_MAX_ROWS * 8];
-  const int lane = threadIdx.x;
+  __shared__ int32_t s_part[4 * 64];
+  __shared__ uint32_t s_own[2];               // own slot, own layer flags
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int vx = lane & 7, vy = lane >> 3;
   // sweep window = dirty AABB of this update + R (in blocks), decided on the device
   const int32_t x0 = m.counters[a.rec + 0], y0 = m.counters[a.rec + 1], x1 = m.counters[a.rec + 2], y1 = m.counters[a.rec + 3];
   const bool ok = x0 <= x1 && y0 <= y1;
   const int32_t wx0 = x0 - a.rb, wy0 = y0 - a.rb, ww = x1 - x0 + 1 + 2 * a.rb, wh = y1 - y0 + 1 + 2 * a.rb;
-  if (blockIdx.x == 0 && lane == 0) {
+  if (blockIdx.x == 0 && tid == 0) {
     m.counters[C_ESDF_DIRTY] = 0;                                 // dirty list consumed by k_esdf_mark
     m.counters[a.rec_next + 0] = INT32_MAX; m.counters[a.rec_next + 1] = INT32_MAX;
     m.counters[a.rec_next + 2] = INT32_MIN; m.counters[a.rec_next + 3] = INT32_MIN;
@@ -123,24 +148,29 @@ __global__ __launch_bounds__(64) void k_esdf_edt(DMap m, EsdfArgs a) {
   }
   if (!ok) return;
   const int nn = 2 * a.rb + 1;                // neighbourhood side in blocks
+  const int ctr = a.rb * nn + a.rb;           // own block's position in the neighbourhood
   const int rows = 8 + 2 * a.ri;              // local strip: rows Y0 - ri .. Y0 + 7 + ri
   const int yoff = 8 * a.rb - a.ri;           // strip row 0 in neighbourhood voxel rows
   const int32_t ncell = ww * wh;
   for (int32_t c = blockIdx.x; c < ncell; c += gridDim.x) {
     const int32_t cy = c / ww, cx = c - cy * ww;
     const int32_t bx = wx0 + cx, by = wy0 + cy;
-    const uint32_t es = find_slot(m, bx, by, a.bz_out, F_ESDF);
-    if (!slot_ok(es)) continue;          // wave-uniform
     __syncthreads();                     // previous block's LDS reads are done
     // 1. site masks of the nn x nn surrounding blocks (zero where there is no block: site_bits of non-ESDF slots is 0)
-    for (int q = lane; q < nn * nn; q += 64) {
+    for (int q = tid; q < nn * nn; q += 256) {
       const int qy = q / nn, qx = q - qy * nn;
       const uint32_t s = any_slot(m, bx + qx - a.rb, by + qy - a.rb, a.bz_out);
       s_bits[q] = slot_ok(s) ? m.site_bits[s] : 0ull;
+      if (q == ctr) { s_own[0] = s; s_own[1] = slot_ok(s) ? m.slot_flags[s] : 0u; }
     }
     __syncthreads();
+    const uint32_t es = s_own[0];
+    if (!slot_ok(es) || !(s_own[1] & F_ESDF)) continue;          // uniform: no ESDF block in this window cell
+    uint2* vp = &m.esdf[(size_t)es * 512 + a.vz_out * 64 + lane];
+    uint32_t vflags = 0;
+    if (wave == 0) vflags = vp->y & ESDF_FLAG_MASK;               // issued early, consumed at the store
     // 2. row bitmap: word w of row r holds neighbourhood voxel columns 64(w-1) .. 64(w-1)+63 (bit = column & 63)
-    for (int q = lane; q < rows * EDT_ROW_WORDS; q += 64) {
+    for (int q = tid; q < rows * EDT_ROW_WORDS; q += 256) {
       const int r = q / EDT_ROW_WORDS, w = q - r * EDT_ROW_WORDS;
       u64 word = 0ull;
       if (w >= 1 && w <= 3) {
@@ -155,7 +185,7 @@ __global__ __launch_bounds__(64) void k_esdf_edt(DMap m, EsdfArgs a) {
     }
     __syncthreads();
     // 3. row pass: nearest site along x within ri (ties -> -x), for the block's own 8 columns on every strip row
-    for (int q = lane; q < rows * 8; q += 64) {
+    for (int q = tid; q < rows * 8; q += 256) {
       const int r = q >> 3, X = 8 * a.rb + (q & 7);
       const u64* row = &s_rows[r * EDT_ROW_WORDS];
       const int wi = 1 + (X >> 6), b = X & 63;
@@ -171,9 +201,10 @@ __global__ __launch_bounds__(64) void k_esdf_edt(DMap m, EsdfArgs a) {
     }
     __syncthreads();
     // 4. column pass: argmin over dy of (dy^2 + dx^2, dy) -- the oracle scans dy ascending with strict improvement,
-    //    i.e. the smallest dy among equal distances; scanning by increasing |dy| lets every lane stop at dy^2 > best.
+    //    i.e. the smallest dy among equal distances.  Wave w takes |dy| = w, w+4, ... (increasing, stop at dy^2 > best);
+    //    the four partial minima are merged with the same lexicographic rule.
     int32_t best = INT32_MAX, bdx = 0, bdy = 0;
-    for (int ady = 0; ady <= a.ri; ady++) {
+    for (int ady = wave; ady <= a.ri; ady += 4) {
       if (ady * ady > best) break;
 #pragma unroll
       for (int sgn = 0; sgn < 2; sgn++) {
@@ -185,13 +216,21 @@ __global__ __launch_bounds__(64) void k_esdf_edt(DMap m, EsdfArgs a) {
         if (sq < best || (sq == best && dy < bdy)) { best = sq; bdx = dx; bdy = dy; }
       }
     }
-    uint2* vp = &m.esdf[(size_t)es * 512 + a.vz_out * 64 + lane];
-    const uint32_t flags = vp->y & ESDF_FLAG_MASK;
-    if (best != INT32_MAX && (float)best <= a.max_sq)
-      *vp = make_uint2(__float_as_uint((float)best), (flags) | ((uint32_t)(uint8_t)(int8_t)bdx) | (((uint32_t)(uint8_t)(int8_t)bdy) << 8));
-    else
-      *vp = make_uint2(__float_as_uint(a.max_sq), flags);
-    if (lane == 0) atomicAdd(&m.counters[a.rec + 5], 1);
+    // pack (sq, dy, dx) so that integer min == lexicographic (sq, dy) min: sq < 2^13, dy + 64 < 2^7, dx + 64 < 2^7
+    s_part[wave * 64 + lane] = best == INT32_MAX ? INT32_MAX : ((best << 14) | ((bdy + 64) << 7) | (bdx + 64));
+    __syncthreads();
+    if (wave == 0) {
+      int32_t p = s_part[lane];
+#pragma unroll
+      for (int w = 1; w < 4; w++) { const int32_t o = s_part[w * 64 + lane]; if (o < p) p = o; }
+      if (p != INT32_MAX && (float)(p >> 14) <= a.max_sq) {
+        const int32_t fdx = (p & 127) - 64, fdy = ((p >> 7) & 127) - 64;
+        *vp = make_uint2(__float_as_uint((float)(p >> 14)), vflags | ((uint32_t)(uint8_t)(int8_t)fdx) | (((uint32_t)(uint8_t)(int8_t)fdy) << 8));
+      } else {
+        *vp = make_uint2(__float_as_uint(a.max_sq), vflags);
+      }
+      if (lane == 0) atomicAdd(&m.counters[a.rec + 5], 1);
+    }
   }
 }
 
@@ -200,9 +239,18 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
   NVBX_HIP(hipSetDevice(m->device));
   const EsdfArgs a = m->make_esdf_args();
   if (m->p.esdf_max_distance_m / m->p.voxel_size >= 64.0f) { set_error("esdf_max_distance_m / voxel_size must be < 64 voxels"); return NVBX_E_INVALID; }
-  NVBX_LAUNCH(m, k_esdf_mark, dim3(1024), dim3(64), m->d, a, m->esdf_dirty);
-  NVBX_LAUNCH(m, k_esdf_edt, dim3(2048), dim3(64), m->d, a);
+  if (a.bz_hi - a.bz_lo + 1 > 63 || a.bz_hi < a.bz_lo) { set_error("esdf slice z band must span 1..63 blocks"); return NVBX_E_INVALID; }
+  hipStream_t s = m->stream;
+  if (m->use_side) {
+    // run behind the last non-colour operation, beside any colour integration enqueued after it
+    if (m->main_dirty) { if (m->mark_main()) return NVBX_E_DEVICE; }
+    NVBX_HIP(hipStreamWaitEvent(m->side, m->ev_main, 0));
+    s = m->side;
+  }
+  NVBX_LAUNCH_ON(m, s, k_esdf_mark, dim3((unsigned)std::min<int64_t>(m->capacity, 1024)), dim3(64), m->d, a, m->esdf_dirty);
+  NVBX_LAUNCH_ON(m, s, k_esdf_edt, dim3(1024), dim3(256), m->d, a);
   NVBX_HIP(hipGetLastError());
+  if (m->use_side) { NVBX_HIP(hipEventRecord(m->ev_side, m->side)); m->side_pending = true; }
   m->esdf_epoch++;
   return NVBX_OK;
 }
@@ -290,6 +338,7 @@ __global__ void k_occupancy(const float* img, int64_t n, float unknown, int8_t* 
 extern "C" int nvbx_occupancy_grid_from_slice(nvbx_mapper* m, const float* image_dev, int32_t rows, int32_t cols, float unknown_value,
                                               int8_t* grid_dev) {
   if (!m || !image_dev || !grid_dev || rows <= 0 || cols <= 0) return NVBX_E_INVALID;
+  if (m->join_side()) return NVBX_E_DEVICE;
   const int64_t n = (int64_t)rows * cols;
   NVBX_LAUNCH(m, k_occupancy, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), image_dev, n, unknown_value, grid_dev);
   NVBX_HIP(hipGetLastError());
@@ -322,6 +371,7 @@ __global__ void k_zero_tmp2(DMap m) { m.counters[C_TMP] = 0; }
 extern "C" int nvbx_pointcloud_from_slice(nvbx_mapper* m, const float* image_dev, int32_t rows, int32_t cols, const float aabb[6],
                                           float slice_height, float unknown_value, float* points_xyzi_dev, int32_t* n_points) {
   if (!m || !image_dev || !aabb || !points_xyzi_dev || !n_points || rows <= 0 || cols <= 0) return NVBX_E_INVALID;
+  if (m->join_side()) return NVBX_E_DEVICE;
   NVBX_LAUNCH(m, k_zero_tmp2, dim3(1), dim3(1), m->d);
   const int tiles = ((rows + 7) / 8) * ((cols + 7) / 8);
   NVBX_LAUNCH(m, k_slice_pointcloud, dim3(std::min(tiles, 4096)), dim3(64), m->d, image_dev, rows, cols, aabb[0], aabb[1],
@@ -348,6 +398,7 @@ __global__ void k_esdf_dense(DMap m, int32_t mx, int32_t my, int32_t mz, int32_t
 }
 extern "C" int nvbx_esdf_dense_grid(nvbx_mapper* m, const int32_t min_vox[3], const int32_t size_vox[3], float default_value, float* grid_dev) {
   if (!m || !min_vox || !size_vox || !grid_dev || size_vox[0] <= 0 || size_vox[1] <= 0 || size_vox[2] <= 0) return NVBX_E_INVALID;
+  if (m->join_side()) return NVBX_E_DEVICE;
   const int64_t n = (int64_t)size_vox[0] * size_vox[1] * size_vox[2];
   NVBX_LAUNCH(m, k_esdf_dense, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), m->d, min_vox[0], min_vox[1],
                      min_vox[2], size_vox[0], size_vox[1], size_vox[2], m->p.voxel_size, default_value, grid_dev);
@@ -366,6 +417,7 @@ __global__ void k_export_dirty(DMap m, const int32_t* dirty, int32_t* out_idx, i
 }
 extern "C" int nvbx_esdf_dirty_list(nvbx_mapper* m, int32_t* indices_dev_out, int32_t* count_dev_out, int64_t capacity) {
   if (!m || !indices_dev_out || !count_dev_out || capacity <= 0) return NVBX_E_INVALID;
+  if (m->join_side()) return NVBX_E_DEVICE;
   NVBX_LAUNCH(m, k_export_dirty, dim3(64), dim3(256), m->d, m->esdf_dirty, indices_dev_out, count_dev_out, (int32_t)std::min<int64_t>(capacity, m->capacity));
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
@@ -382,7 +434,8 @@ __global__ void k_import_dirty(DMap m, const int32_t* idx, const int32_t* count,
 }
 extern "C" int nvbx_mark_esdf_dirty(nvbx_mapper* m, const int32_t* indices_dev, const int32_t* count_dev, int64_t max_count) {
   if (!m || !indices_dev || !count_dev || max_count < 0) return NVBX_E_INVALID;
+  if (m->join_side()) return NVBX_E_DEVICE;
   NVBX_LAUNCH(m, k_import_dirty, dim3(64), dim3(256), m->d, indices_dev, count_dev, max_count, m->esdf_dirty);
   NVBX_HIP(hipGetLastError());
-  return NVBX_OK;
+  return m->mark_main();
 }

@@ -113,6 +113,7 @@ static int rebuild_table(nvbx_mapper* m) {
 extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   if (!m) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));
+  if (m->join_side()) return NVBX_E_DEVICE;
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
   NVBX_LAUNCH(m, k_decay, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
                      exclude_last_view ? m->last_view_frame : 0u, m->esdf_dirty, m->mesh_dirty_live(), m->mesh_dirty_counter());
@@ -122,6 +123,7 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
 extern "C" int nvbx_clear_outside_radius(nvbx_mapper* m, const float center[3], float radius) {
   if (!m || !center) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));
+  if (m->join_side()) return NVBX_E_DEVICE;
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
   NVBX_LAUNCH(m, k_clear_outside, dim3(grid), dim3(512), m->d, center[0], center[1], center[2], radius * radius, m->p.voxel_size * 8.0f);
   return rebuild_table(m);

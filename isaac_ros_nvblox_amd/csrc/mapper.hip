@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include "nvbx_mapper.h"
@@ -46,10 +47,10 @@ __global__ void k_collect_indices(DMap m, uint32_t layer, int32_t* out, int32_t 
 __global__ void k_zero_tmp(DMap m) { m.counters[C_TMP] = 0; }
 
 // list (hash-entry ids or slots) -> Index3D
-__global__ void k_list_to_indices(DMap m, const int32_t* list, int32_t count_idx, int32_t is_entry, int32_t* out, int32_t cap) {
+__global__ void k_list_to_indices(DMap m, const int32_t* list, int32_t stride, int32_t count_idx, int32_t is_entry, int32_t* out, int32_t cap) {
   int32_t n = m.counters[count_idx]; if (n > cap) n = cap;
   for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    uint32_t s = (uint32_t)list[i];
+    uint32_t s = (uint32_t)list[(int64_t)i * stride];
     if (is_entry) s = m.table[s].slot;
     if (slot_ok(s) && m.slot_flags[s]) { out[3 * i] = m.slot_index[3 * s]; out[3 * i + 1] = m.slot_index[3 * s + 1]; out[3 * i + 2] = m.slot_index[3 * s + 2]; }
     else { out[3 * i] = INT32_MIN; out[3 * i + 1] = INT32_MIN; out[3 * i + 2] = INT32_MIN; }
@@ -137,7 +138,7 @@ static int alloc_all(nvbx_mapper* m) {
   NVBX_HIP(hipMalloc(&d.tsdf, cap * 4096));
   NVBX_HIP(hipMalloc(&d.color, cap * 4096));
   NVBX_HIP(hipMalloc(&d.esdf, cap * 4096));
-  NVBX_HIP(hipMalloc(&m->view_list, cap * 4));
+  NVBX_HIP(hipMalloc(&m->view_list, cap * 16));    // int4 {slot, x, y, z} per block in view
   NVBX_HIP(hipMalloc(&m->esdf_dirty, cap * 4));
   NVBX_HIP(hipMalloc(&m->mesh_dirty, cap * 8));
   NVBX_HIP(hipMalloc(&m->color_list, cap * 4));
@@ -174,6 +175,7 @@ static int reset_map(nvbx_mapper* m) {
 }
 
 int nvbx_mapper::fetch_counters() {
+  if (join_side()) return NVBX_E_DEVICE;
   NVBX_HIP(hipMemcpyAsync(h_counters, d.counters, C_NUM * 4, hipMemcpyDeviceToHost, stream));
   NVBX_HIP(hipStreamSynchronize(stream));
   return NVBX_OK;
@@ -230,6 +232,14 @@ extern "C" int nvbx_mapper_create(int device, void* hip_stream, const nvbx_mappe
   m->device = device; m->p = *params; m->capacity = block_capacity;
   if (hip_stream) { m->stream = (hipStream_t)hip_stream; m->own_stream = false; }
   else { hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking); if (e != hipSuccess) { set_error("hipStreamCreate", e); delete m; return NVBX_E_DEVICE; } m->own_stream = true; }
+  // ESDF on a side stream beside colour integration: off by default, NVBX_SIDE_STREAM=1 enables (the
+  // cross-stream hand-off costs ~10 us each way on this runtime, which eats most of the overlap)
+  { const char* e = getenv("NVBX_SIDE_STREAM"); m->use_side = (e && e[0] == '1'); }
+  if (m->use_side) {
+    if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_side, hipEventDisableTiming) != hipSuccess) { set_error("side stream / events"); nvbx_mapper_destroy(m); return NVBX_E_DEVICE; }
+  }
   int rc = alloc_all(m); if (rc) { nvbx_mapper_destroy(m); return rc; }
   rc = reset_map(m); if (rc) { nvbx_mapper_destroy(m); return rc; }
   hipError_t e = hipStreamSynchronize(m->stream);
@@ -241,7 +251,11 @@ extern "C" int nvbx_mapper_create(int device, void* hip_stream, const nvbx_mappe
 extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   if (!m) return NVBX_OK;
   (void)hipSetDevice(m->device);
+  if (m->side) (void)hipStreamSynchronize(m->side);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
+  if (m->ev_main) (void)hipEventDestroy(m->ev_main);
+  if (m->ev_side) (void)hipEventDestroy(m->ev_side);
+  if (m->side) (void)hipStreamDestroy(m->side);
   DMap& d = m->d;
   void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.tsdf, d.color, d.esdf,
                   m->view_list, m->esdf_dirty, m->mesh_dirty, m->color_list, m->export_idx, m->export_count, d.site_bits,
@@ -264,12 +278,14 @@ extern "C" int nvbx_mapper_get_params(const nvbx_mapper* m, nvbx_mapper_params* 
 }
 extern "C" int nvbx_synchronize(nvbx_mapper* m) {
   if (!m) return NVBX_E_INVALID;
+  if (m->join_side()) return NVBX_E_DEVICE;
   NVBX_HIP(hipStreamSynchronize(m->stream));
   return NVBX_OK;
 }
 extern "C" int nvbx_mapper_clear(nvbx_mapper* m) {
   if (!m) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));
+  if (m->join_side()) return NVBX_E_DEVICE;
   return reset_map(m);
 }
 
@@ -283,6 +299,7 @@ static void sort_indices(nvbx_index3d* v, int64_t n) {
 
 extern "C" int64_t nvbx_block_indices(nvbx_mapper* m, uint32_t layer, nvbx_index3d* out, int64_t capacity) {
   if (!m || !single_layer(layer)) return NVBX_E_INVALID;
+  if (m->join_side()) return NVBX_E_DEVICE;
   NVBX_LAUNCH(m, k_zero_tmp, dim3(1), dim3(1), m->d);
   NVBX_LAUNCH(m, k_collect_indices, dim3(256), dim3(256), m->d, layer, m->export_idx, (int32_t)m->capacity);
   if (m->fetch_counters()) return NVBX_E_DEVICE;
@@ -299,8 +316,9 @@ extern "C" int64_t nvbx_block_indices(nvbx_mapper* m, uint32_t layer, nvbx_index
 }
 extern "C" int64_t nvbx_num_blocks(nvbx_mapper* m, uint32_t layer) { return nvbx_block_indices(m, layer, nullptr, 0); }
 
-static int64_t list_indices(nvbx_mapper* m, const int32_t* list, int count_idx, int is_entry, nvbx_index3d* out, int64_t capacity) {
-  NVBX_LAUNCH(m, k_list_to_indices, dim3(64), dim3(256), m->d, list, count_idx, is_entry, m->export_idx, (int32_t)m->capacity);
+static int64_t list_indices(nvbx_mapper* m, const int32_t* list, int stride, int count_idx, int is_entry, nvbx_index3d* out, int64_t capacity) {
+  if (m->join_side()) return NVBX_E_DEVICE;
+  NVBX_LAUNCH(m, k_list_to_indices, dim3(64), dim3(256), m->d, list, stride, count_idx, is_entry, m->export_idx, (int32_t)m->capacity);
   if (m->fetch_counters()) return NVBX_E_DEVICE;
   int64_t n = m->h_counters[count_idx]; if (n > m->capacity) n = m->capacity;
   const int64_t k = std::min<int64_t>(n, capacity);
@@ -315,17 +333,18 @@ static int64_t list_indices(nvbx_mapper* m, const int32_t* list, int count_idx, 
 extern "C" int64_t nvbx_last_depth_view(nvbx_mapper* m, nvbx_index3d* out, int64_t capacity) {
   if (!m) return NVBX_E_INVALID;
   if (m->last_view_frame == 0) return 0;
-  return list_indices(m, m->view_list, C_VIEW_COUNT + (int)(m->last_view_frame & 3), 0, out, capacity);
+  return list_indices(m, m->view_list, 4, C_VIEW_COUNT + (int)(m->last_view_frame & 3), 0, out, capacity);
 }
 extern "C" int64_t nvbx_last_color_view(nvbx_mapper* m, nvbx_index3d* out, int64_t capacity) {
   if (!m) return NVBX_E_INVALID;
-  return list_indices(m, m->color_list, C_COLOR_COUNT, 0, out, capacity);
+  return list_indices(m, m->color_list, 1, C_COLOR_COUNT, 0, out, capacity);
 }
 
 static size_t ref_voxel_bytes(uint32_t layer) { return layer == F_ESDF ? sizeof(nvbx_esdf_voxel) : 8; }
 
 extern "C" int nvbx_get_blocks(nvbx_mapper* m, uint32_t layer, const nvbx_index3d* idx, int64_t n, void* voxels_out, int32_t* found_out) {
   if (!m || !idx || !voxels_out || n < 0 || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF)) return NVBX_E_INVALID;
+  if (m->join_side()) return NVBX_E_DEVICE;
   const size_t bb = 512 * ref_voxel_bytes(layer);
   const int64_t chunk = std::max<int64_t>(1, (int64_t)((m->staging_bytes - 65536) / (bb + 16)));
   for (int64_t o = 0; o < n; o += chunk) {
@@ -348,6 +367,7 @@ extern "C" int nvbx_get_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, 
 }
 extern "C" int nvbx_set_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, const void* voxels_in) {
   if (!m || !voxels_in || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF)) return NVBX_E_INVALID;
+  if (m->join_side()) return NVBX_E_DEVICE;
   const size_t bb = 512 * ref_voxel_bytes(layer);
   NVBX_HIP(hipMemcpyAsync(m->staging, voxels_in, bb, hipMemcpyHostToDevice, m->stream));
   const EsdfArgs ea = m->make_esdf_args();
@@ -382,15 +402,26 @@ hipEvent_t nvbx_mapper::get_event() {
   if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
   hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
 }
-void nvbx_mapper::span_begin(const char* name) {
+void nvbx_mapper::span_begin(const char* name, hipStream_t st) {
   Span s{name, get_event(), get_event()};
-  (void)hipEventRecord(s.a, stream);
+  (void)hipEventRecord(s.a, st);
   spans.push_back(s);
 }
-void nvbx_mapper::span_end() { (void)hipEventRecord(spans.back().b, stream); }
+void nvbx_mapper::span_end(hipStream_t st) { (void)hipEventRecord(spans.back().b, st); }
+
+int nvbx_mapper::join_side() {
+  main_dirty = true;
+  if (side_pending) { NVBX_HIP(hipStreamWaitEvent(stream, ev_side, 0)); side_pending = false; }
+  return NVBX_OK;
+}
+int nvbx_mapper::mark_main() {
+  if (use_side) { NVBX_HIP(hipEventRecord(ev_main, stream)); main_dirty = false; }
+  return NVBX_OK;
+}
 
 extern "C" int nvbx_set_profiling(nvbx_mapper* m, int32_t enable) {
   if (!m) return NVBX_E_INVALID;
+  if (m->join_side()) return NVBX_E_DEVICE;
   NVBX_HIP(hipStreamSynchronize(m->stream));
   for (auto& s : m->spans) { m->event_pool.push_back(s.a); m->event_pool.push_back(s.b); }
   m->spans.clear();
@@ -401,6 +432,7 @@ extern "C" int nvbx_set_profiling(nvbx_mapper* m, int32_t enable) {
 // JSON object {"kernel": {"count": n, "total_ms": t}, ...} of every launch since nvbx_set_profiling(m, 1).
 extern "C" int nvbx_get_profile(nvbx_mapper* m, char* json_out, int64_t capacity) {
   if (!m || !json_out || capacity < 4) return NVBX_E_INVALID;
+  if (m->join_side()) return NVBX_E_DEVICE;
   NVBX_HIP(hipStreamSynchronize(m->stream));
   struct Acc { const char* name; int64_t n; double ms; };
   std::vector<Acc> acc;

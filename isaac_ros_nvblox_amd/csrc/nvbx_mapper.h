@@ -32,11 +32,21 @@ struct nvbx_mapper {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // Side stream: the ESDF update (k_esdf_mark + k_esdf_edt) is independent of colour integration, so it
+  // runs on its own stream behind an event recorded after the last non-colour operation and overlaps integrateColor.
+  // Every other entry point joins the side stream first, so the caller still sees single-stream ordering.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_main = nullptr, ev_side = nullptr;
+  bool use_side = false;        // NVBX_SIDE_STREAM=0 disables
+  bool side_pending = false;    // ESDF work enqueued on `side` that `stream` has not waited for yet
+  bool main_dirty = true;       // non-colour work enqueued on `stream` since ev_main was recorded
+  int join_side();              // make `stream` wait for the side stream (no host sync)
+  int mark_main();              // record ev_main on `stream` (call right after a non-colour operation)
   nvbx_mapper_params p{};
   int64_t capacity = 0;
   nvbx::DMap d{};
   // lists (device)
-  int32_t* view_list = nullptr;      // hash-entry ids of the blocks in view of the last depth frame
+  int32_t* view_list = nullptr;      // int4 {slot, x, y, z} of the blocks in view of the last depth frame
   int32_t* esdf_dirty = nullptr;     // slots dirtied since the last ESDF update
   int32_t* mesh_dirty = nullptr;     // 2 x capacity: slots dirtied since the last mesh update (list of parity mesh_epoch & 1 is live)
   int32_t* color_list = nullptr;     // slots updated by the last colour frame
@@ -67,17 +77,18 @@ struct nvbx_mapper {
   std::vector<Span> spans;
   std::vector<hipEvent_t> event_pool;
   hipEvent_t get_event();
-  void span_begin(const char* name);
-  void span_end();
+  void span_begin(const char* name, hipStream_t s);
+  void span_end(hipStream_t s);
 };
 
 // every kernel launch of the library goes through this macro (name = the kernel's name in rocprof output)
-#define NVBX_LAUNCH(m, kernel, grid, block, ...)                                     \
+#define NVBX_LAUNCH_ON(m, s, kernel, grid, block, ...)                               \
   do {                                                                               \
-    if ((m)->profiling) (m)->span_begin(#kernel);                                    \
-    hipLaunchKernelGGL(kernel, grid, block, 0, (m)->stream, __VA_ARGS__);            \
-    if ((m)->profiling) (m)->span_end();                                             \
+    if ((m)->profiling) (m)->span_begin(#kernel, (s));                               \
+    hipLaunchKernelGGL(kernel, grid, block, 0, (s), __VA_ARGS__);                    \
+    if ((m)->profiling) (m)->span_end((s));                                          \
   } while (0)
+#define NVBX_LAUNCH(m, kernel, grid, block, ...) NVBX_LAUNCH_ON(m, (m)->stream, kernel, grid, block, __VA_ARGS__)
 
 #define NVBX_HIP(call)                                                 \
   do {                                                                 \

@@ -8,7 +8,8 @@
 //                    (device-side allocation from the slot stack), per-entry frame stamp, and a wave-aggregated append
 //                    of the pool slot to the frame's view list (exactly once per block and frame).
 //   k_integrate_tsdf one 512-thread workgroup (8 wave64) per 8^3 block, grid-striding over the device-resident view
-//                    list; lane = voxel in z + 8y + 64x order, so every wave reads/writes 512 contiguous bytes.
+//                    list of {slot, Index3D} records; lane = voxel in z + 8y + 64x order, so every wave reads/writes
+//                    512 contiguous bytes.
 // Reference semantics restated: [U] ViewCalculator::getBlocksInImageViewRaycast and ProjectiveTsdfIntegrator
 // (call site nvblox_ros/src/lib/nvblox_node.cpp:1062; knobs mapper_initialization.cpp:264-358).
 #include <algorithm>
@@ -25,23 +26,34 @@ __device__ inline void unpack_key(u64 key, int32_t* x, int32_t* y, int32_t* z) {
 }
 
 // One block key -> HBM: insert-if-absent, stamp the entry with this frame, and report whether THIS call was the first
-// of the frame to do so (the caller then appends the block's pool slot to the view list exactly once).
-__device__ inline bool mark_block(const DMap& m, u64 key, uint32_t frame_id, uint32_t* slot_out) {
+// of the frame to do so (the caller then appends {slot, x, y, z} to the view list exactly once).  The common case -- the
+// block exists and a neighbouring tile has stamped it already -- is ONE 16-B load: key, slot and stamp arrive together.
+__device__ inline bool mark_block(const DMap& m, u64 key, uint32_t frame_id, int4* rec_out) {
   int32_t x, y, z; unpack_key(key, &x, &y, &z);
-  bool is_new;
-  const int32_t h = hash_insert(m, x, y, z, F_TSDF, &is_new);
-  if (h < 0) return false;
-  // cheap L2-served read first: most tiles find the entry already stamped by a neighbouring tile
-  if (__hip_atomic_load(&m.table[h].stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == frame_id) return false;
+  uint32_t h = table_pos(m, x, y, z);
+  uint32_t slot = SLOT_INVALID;
+  bool found = false;
+  for (uint32_t probe = 0; probe <= m.mask; ++probe) {
+    const uint4 e = *reinterpret_cast<const uint4*>(&m.table[h]);
+    const u64 k = ((u64)e.y << 32) | (u64)e.x;
+    if (k == key) { if (e.w == frame_id) return false; slot = e.z; found = true; break; }
+    if (k == KEY_EMPTY) break;           // (may be a stale EMPTY: hash_insert's CAS is the truth)
+    h = (h + 1) & m.mask;
+  }
+  if (!found) {
+    bool is_new;
+    const int32_t hi = hash_insert(m, x, y, z, F_TSDF, &is_new);
+    if (hi < 0) return false;
+    h = (uint32_t)hi;
+  }
   if (atomicExch(&m.table[h].stamp, frame_id) == frame_id) return false;
-  uint32_t s;
-  do { s = ld_slot_acquire(&m.table[h]); } while (s == SLOT_INVALID);   // the winner publishes right after its CAS
-  *slot_out = s;
+  while (slot == SLOT_INVALID) slot = ld_slot_acquire(&m.table[h]);     // the inserting lane publishes right after its CAS
+  *rec_out = make_int4((int32_t)slot, x, y, z);
   return true;
 }
 
-// wave-aggregated append of this lane's `slot` (if `first`) to the frame's view list: one returning atomic per wave
-__device__ inline void view_append(int32_t* cnt, int32_t* view_list, int32_t list_cap, bool first, uint32_t slot, int lane) {
+// wave-aggregated append of this lane's record (if `first`) to the frame's view list: one returning atomic per wave
+__device__ inline void view_append(int32_t* cnt, int4* view_list, int32_t list_cap, bool first, int4 rec, int lane) {
   const u64 mask = __ballot(first);
   if (!mask) return;
   int32_t base = 0;
@@ -50,12 +62,12 @@ __device__ inline void view_append(int32_t* cnt, int32_t* view_list, int32_t lis
   base = __shfl(base, leader);
   if (first) {
     const int32_t pos = base + (int32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    if (pos < list_cap) view_list[pos] = (int32_t)slot;
+    if (pos < list_cap) view_list[pos] = rec;
   }
 }
 
 template <typename Img>
-__global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, int32_t* view_list, int32_t list_cap) {
+__global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, int4* view_list, int32_t list_cap) {
   __shared__ u64 lset[LSET];
   __shared__ u64 lkeys[LSET];
   const int lane = threadIdx.x;
@@ -111,9 +123,9 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, in
       if (old == KEY_EMPTY || old == key) { spill = false; break; }
     }
     if (__ballot(spill)) {                       // rare overflow path, wave-uniform branch
-      uint32_t slot = SLOT_NONE;
-      const bool first = spill && mark_block(m, key, f.frame_id, &slot);
-      view_append(cnt, view_list, list_cap, first, slot, lane);
+      int4 rec = make_int4(0, 0, 0, 0);
+      const bool first = spill && mark_block(m, key, f.frame_id, &rec);
+      view_append(cnt, view_list, list_cap, first, rec, lane);
     }
     int a = 0;
     if (tmax[1] < tmax[a]) a = 1;
@@ -136,66 +148,75 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, in
   }
   __syncthreads();
   for (int32_t i = 0; i < nk; i += 64) {
-    uint32_t slot = SLOT_NONE;
-    const bool first = (i + lane < nk) && mark_block(m, lkeys[i + lane], f.frame_id, &slot);
-    view_append(cnt, view_list, list_cap, first, slot, lane);
+    int4 rec = make_int4(0, 0, 0, 0);
+    const bool first = (i + lane < nk) && mark_block(m, lkeys[i + lane], f.frame_id, &rec);
+    view_append(cnt, view_list, list_cap, first, rec, lane);
   }
 }
 
+// Dependent-access chain: {view count, view record} -> {depth gather, voxel} -> store.  The record of the first block
+// is fetched speculatively beside the count, the voxel is fetched before the projection decides whether it is needed,
+// and the flag / dirty-list atomics of lane 0 are issued first and consumed last.
 template <typename Img>
-__global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img depth, const int32_t* view_list, int32_t list_cap,
+__global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img depth, const int4* view_list, int32_t list_cap,
                                                         int32_t* esdf_dirty, int32_t* mesh_dirty, int32_t mesh_cnt) {
+  int4 rec = view_list[blockIdx.x];                       // speculative: valid iff blockIdx.x < n (gridDim.x <= list_cap)
   int32_t n = m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
   if (n > list_cap) n = list_cap;
   const int tid = threadIdx.x;
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
   for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const uint32_t slot = (uint32_t)view_list[i];      // pool slots (stable across hash rebuilds)
+    if (i != (int32_t)blockIdx.x) rec = view_list[i];
+    const uint32_t slot = (uint32_t)rec.x;               // pool slot (stable across hash rebuilds)
     if (!slot_ok(slot)) continue;
-    const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
+    float2* vp = &m.tsdf[(size_t)slot * 512 + tid];
+    const float2 cur = *vp;
+    uint32_t old = 0;
+    if (tid == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH);
+    float pc[3];
+    apply_rt(f.R_CL, f.t_CL, voxel_center(rec.y, vx, f.block_size, f.voxel_size), voxel_center(rec.z, vy, f.block_size, f.voxel_size),
+             voxel_center(rec.w, vz, f.block_size, f.voxel_size), pc);
+    float u, v, ds;
+    bool upd = cam_project(f, pc, &u, &v);
+    const float vd = pc[2];
+    if (upd && f.max_dist > 0.0f && vd > f.max_dist) upd = false;
+    if (upd) upd = interp_depth(depth, f.rows, f.cols, u, v, f.interp_nearest, &ds);
+    if (upd) {
+      const float sdf = ds - vd;
+      if (!(sdf < -f.trunc)) {
+        const float wm = weight_fn(f.weighting_mode, ds, vd, f.trunc);
+        const float wsum = wm + cur.y;
+        if (wsum > 0.0f) {
+          float fused = (sdf * wm + cur.x * cur.y) / wsum;
+          if (fused > 0.0f) fused = fminf(f.trunc, fused); else fused = fmaxf(-f.trunc, fused);
+          *vp = make_float2(fused, fminf(wsum, f.max_weight));
+        }
+      }
+    }
     if (tid == 0) {
-      const uint32_t old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH);
       if (!(old & F_DIRTY_ESDF)) esdf_dirty[atomicAdd(&m.counters[C_ESDF_DIRTY], 1)] = (int32_t)slot;
       if (!(old & F_DIRTY_MESH)) mesh_dirty[atomicAdd(&m.counters[mesh_cnt], 1)] = (int32_t)slot;
     }
-    float pc[3];
-    apply_rt(f.R_CL, f.t_CL, voxel_center(bx, vx, f.block_size, f.voxel_size), voxel_center(by, vy, f.block_size, f.voxel_size),
-             voxel_center(bz, vz, f.block_size, f.voxel_size), pc);
-    float u, v;
-    if (!cam_project(f, pc, &u, &v)) continue;
-    const float vd = pc[2];
-    if (f.max_dist > 0.0f && vd > f.max_dist) continue;
-    float ds;
-    if (!interp_depth(depth, f.rows, f.cols, u, v, f.interp_nearest, &ds)) continue;
-    const float sdf = ds - vd;
-    if (sdf < -f.trunc) continue;
-    float2* vp = &m.tsdf[(size_t)slot * 512 + tid];
-    const float2 cur = *vp;
-    const float wm = weight_fn(f.weighting_mode, ds, vd, f.trunc);
-    const float wsum = wm + cur.y;
-    if (!(wsum > 0.0f)) continue;
-    float fused = (sdf * wm + cur.x * cur.y) / wsum;
-    if (fused > 0.0f) fused = fminf(f.trunc, fused); else fused = fmaxf(-f.trunc, fused);
-    *vp = make_float2(fused, fminf(wsum, f.max_weight));
   }
 }
 
 template <typename Img>
 static int integrate_depth_impl(nvbx_mapper* m, Img img, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera) {
   NVBX_HIP(hipSetDevice(m->device));
+  if (m->join_side()) return NVBX_E_DEVICE;     // k_integrate_tsdf writes what k_esdf_mark reads
   m->frame_id++;
   Frame f = m->make_frame(T_L_C, camera, rows, cols, m->p.raycast_subsampling_factor);
   const int s = f.subsample;
   f.n_ray_rows = (rows + s - 1 + s - 1) / s;   // indices i with i*s < rows + s - 1
   f.n_ray_cols = (cols + s - 1 + s - 1) / s;
   const int tiles = ((f.n_ray_rows + 7) / 8) * ((f.n_ray_cols + 7) / 8);
-  NVBX_LAUNCH(m, (k_mark_view<Img>), dim3(tiles), dim3(64), m->d, f, img, m->view_list, (int32_t)m->capacity);
-  const int grid = (int)std::min<int64_t>(m->capacity, 2048);
-  NVBX_LAUNCH(m, (k_integrate_tsdf<Img>), dim3(grid), dim3(512), m->d, f, img, m->view_list, (int32_t)m->capacity,
+  NVBX_LAUNCH(m, (k_mark_view<Img>), dim3(tiles), dim3(64), m->d, f, img, (int4*)m->view_list, (int32_t)m->capacity);
+  const int grid = (int)std::min<int64_t>(m->capacity, 1024);
+  NVBX_LAUNCH(m, (k_integrate_tsdf<Img>), dim3(grid), dim3(512), m->d, f, img, (const int4*)m->view_list, (int32_t)m->capacity,
                      m->esdf_dirty, m->mesh_dirty_live(), m->mesh_dirty_counter());
   NVBX_HIP(hipGetLastError());
   m->last_view_frame = m->frame_id;
-  return NVBX_OK;
+  return m->mark_main();
 }
 
 extern "C" int nvbx_integrate_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16],

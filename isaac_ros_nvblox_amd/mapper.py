@@ -131,6 +131,25 @@ class Mapper:
         self._check(self.lib.nvbx_integrate_color(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k)))
         self._keep_c = [d]
 
+    # -- pre-marshalled calls: the reference hands ready C++ objects to integrateDepth/Color; this keeps Python's per-call
+    #    argument marshalling (tensor checks, numpy pose copy, struct construction) out of a measured loop
+    def prepare_depth(self, depth, T_L_C, cam):
+        torch = self._torch
+        d = self._dev(depth, torch.float32)
+        T = self._T(T_L_C); k = self._cam(cam)
+        return (self.lib.nvbx_integrate_depth, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k), (d, T, k))
+
+    def prepare_color(self, rgb, T_L_C, cam):
+        d = self._dev(rgb, self._torch.uint8)
+        assert d.dim() == 3 and d.shape[2] == 3
+        T = self._T(T_L_C); k = self._cam(cam)
+        return (self.lib.nvbx_integrate_color, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k), (d, T, k))
+
+    def integrate_prepared(self, a):
+        rc = a[0](self._h, a[1], a[2], a[3], a[4], a[5])
+        if rc < 0:
+            self._check(rc)
+
     def update_esdf(self):
         self._check(self.lib.nvbx_update_esdf(self._h))
 
