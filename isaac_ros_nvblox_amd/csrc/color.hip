@@ -16,7 +16,7 @@ using namespace nvbx;
 
 // TSDF reads below skip the layer-flag load: the TSDF pool of a slot that does not carry F_TSDF is all-zero (freed /
 // ESDF-only slots are zeroed, maintenance.hip), and weight 0 reads as "unobserved" exactly like a missing block.
-constexpr int RAY_LANES = 16;   // lanes cooperating on one ray = samples fetched per round trip
+constexpr int RAY_LANES = 8;    // lanes cooperating on one ray = samples fetched per round trip (4: 13.7, 8: 13.4, 16: 14.5, 32: 21.4 us)
 
 // finish a lookup whose first probe `e` at `h` is already loaded (16 B): slot of any block with `key`, or SLOT_NONE
 __device__ inline uint32_t resolve_tsdf_slot(const DMap& m, u64 key, uint32_t h, uint4 e) {
@@ -33,8 +33,8 @@ __device__ inline uint32_t resolve_tsdf_slot(const DMap& m, u64 key, uint32_t h,
 // [U] SphereTracer::cast restated, sample-parallel.  The serial march t <- t + tsdf(t) (nearest voxel) is a chain of
 // dependent HBM round trips (hash entry, then voxel) plus ~150 ALU ops per step, and a ray takes 10-20 steps.  But the
 // step is PREDICTABLE: exactly `trunc` through free (clamped) or unobserved space, and the same small value while the
-// ray stays inside one voxel near the surface.  So 16 lanes serve one ray: lane j fetches the sample at
-// t + j*ps (ps = predicted step, accumulated with the same float additions the serial march performs), all 16 hash
+// ray stays inside one voxel near the surface.  So RAY_LANES lanes serve one ray: lane j fetches the sample at
+// t + j*ps (ps = predicted step, accumulated with the same float additions the serial march performs), all their hash
 // probes and voxel loads are in flight together, and the group consumes the samples in order with ballots while each
 // sample's step equals the prediction.  The first sample that breaks it supplies the next t and the next prediction.
 // The sequence of t values -- and so the result -- is bit-identical to the one-sample-at-a-time march.
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_sphere_trace(DMap m, Frame f, float* sy
     const bool pos_before = last_positive || before != 0;            // last_positive when the serial loop reaches this sample
     const bool unobs_keep = !observed && !pos_before && (ps == f.trunc);   // unobserved: step = trunc, if that is the prediction
     const bool event = !done && !(in_bounds && (keep || unobs_keep));
-    const uint32_t ev = (uint32_t)((__ballot(event) >> gsh) & 0xFFFFu);
+    const uint32_t ev = (uint32_t)((__ballot(event) >> gsh) & (uint32_t)((1ull << RAY_LANES) - 1ull));
     const int e_sub = ev ? (__ffs((int)ev) - 1) : RAY_LANES;         // first sample that breaks the prediction
     const int src = gsh + (e_sub < RAY_LANES ? e_sub : RAY_LANES - 1);
     // values at the event sample (or at the last sample if the whole round kept the prediction)
@@ -87,9 +87,9 @@ __global__ __launch_bounds__(256) void k_sphere_trace(DMap m, Frame f, float* sy
     const float e_vx = __shfl(v.x, src);
     const int e_inb = __shfl((int)in_bounds, src), e_obs = __shfl((int)observed, src), e_surf = __shfl((int)surf, src);
     const int e_posb = __shfl((int)pos_before, src);
-    const int pos_last = __shfl((int)(pos_before || (observed && !surf)), gsh + RAY_LANES - 1);   // last_positive after 16 kept samples
+    const int pos_last = __shfl((int)(pos_before || (observed && !surf)), gsh + RAY_LANES - 1);   // last_positive after a fully kept round
     if (!done) {
-      if (e_sub == RAY_LANES) {                      // all 16 samples consumed with the predicted step
+      if (e_sub == RAY_LANES) {                      // all samples consumed with the predicted step
         t = e_tc + ps; i += RAY_LANES; last_positive = pos_last != 0;
       } else {
         i += e_sub;                                  // samples before the event were regular steps
