@@ -84,7 +84,18 @@ typedef struct {
   float tsdf_decayed_weight_threshold;    /* tsdf_decayed_weight_threshold */
   int32_t esdf_site_rule;                 /* 0: inside && |d| <= max_site_distance (default); 1: |d| <= max_site_distance */
   int32_t depth_interp_nearest;           /* 0: bilinear with validity (default); 1: nearest */
+  float lidar_max_integration_distance_m; /* lidar_projective_integrator_max_integration_distance_m (mapper_initialization.cpp:271-276) */
+  float lidar_linear_interpolation_max_allowable_difference_vox;    /* [U] 2.0: bilinear taps must agree within this */
+  float lidar_nearest_interpolation_max_allowable_dist_to_ray_vox;  /* [U] 0.5: nearest-beam fallback acceptance */
 } nvbx_mapper_params;
+
+/* nvblox::Lidar(num_azimuth_divisions, num_elevation_divisions, min_valid_range_m, vertical_fov_rad) or
+ * (…, min_angle_below_zero_elevation_rad, max_angle_above_zero_elevation_rad) -- nvblox_node.cpp:1315-1323.
+ * Elevations are signed here: min_elevation_rad < 0 below the horizon (vfov form: -vfov/2, +vfov/2). */
+typedef struct {
+  int32_t num_azimuth_divisions, num_elevation_divisions;
+  float min_valid_range_m, min_elevation_rad, max_elevation_rad;
+} nvbx_lidar;
 
 /* Per-frame work counters (bench.py turns them into algorithmic bytes). */
 typedef struct {
@@ -124,6 +135,16 @@ int nvbx_integrate_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, i
  * (conversions/image_conversions_thrust.cu:39-45,140-142) into the integrator's depth read. */
 int nvbx_integrate_depth_u16mm(nvbx_mapper* m, const uint16_t* depth_mm_dev, int32_t rows, int32_t cols,
                                const float T_L_C[16], const nvbx_camera* camera);
+/* MultiMapper::integrateDepth(const Pointcloud&, const Transform&, const Lidar&, ...) -- nvblox_node.cpp:1382-1384, after
+ * the point cloud has been rendered to a range image (nvbx_depth_image_from_pointcloud; the reference exposes that image
+ * as getLastDepthFrameFromPointcloud(), nvblox_node.cpp:1397).  range_dev: rows = elevation divisions, cols = azimuth
+ * divisions, metres along the beam, <= 0 invalid.  Uses lidar_max_integration_distance_m. */
+int nvbx_integrate_lidar_depth(nvbx_mapper* m, const float* range_dev, int32_t rows, int32_t cols, const float T_L_C[16],
+                               const nvbx_lidar* lidar);
+/* depthImageFromPointcloudKernel (conversions/pointcloud_conversions.cu:118-150): points (x,y,z f32, sensor frame) ->
+ * range image; NaN points and points outside the model are skipped; several points in one pixel: one of them wins. */
+int nvbx_depth_image_from_pointcloud(nvbx_mapper* m, const float* points_xyz_dev, int64_t n_points, const nvbx_lidar* lidar,
+                                     float* range_dev);
 /* MultiMapper::integrateColor(const ColorImage&, const Transform&, const Camera&) -- nvblox_node.cpp:1264.
  * rgb_dev: rows*cols*3 bytes, nvblox::Color order r,g,b (image_conversions.cpp:100-101). */
 int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16],

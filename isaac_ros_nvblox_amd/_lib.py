@@ -32,12 +32,20 @@ class Params(C.Structure):
         ("tsdf_decayed_weight_threshold", C.c_float),
         ("esdf_site_rule", C.c_int32),
         ("depth_interp_nearest", C.c_int32),
+        ("lidar_max_integration_distance_m", C.c_float),
+        ("lidar_linear_interpolation_max_allowable_difference_vox", C.c_float),
+        ("lidar_nearest_interpolation_max_allowable_dist_to_ray_vox", C.c_float),
     ]
 
 
 class Camera(C.Structure):
     _fields_ = [("fu", C.c_float), ("fv", C.c_float), ("cu", C.c_float), ("cv", C.c_float),
                 ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class Lidar(C.Structure):
+    _fields_ = [("num_azimuth_divisions", C.c_int32), ("num_elevation_divisions", C.c_int32),
+                ("min_valid_range_m", C.c_float), ("min_elevation_rad", C.c_float), ("max_elevation_rad", C.c_float)]
 
 
 class Index3D(C.Structure):
@@ -64,6 +72,8 @@ SIGNATURES = {
     "nvbx_integrate_depth": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera)]),
     "nvbx_integrate_depth_u16mm": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera)]),
     "nvbx_integrate_color": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera)]),
+    "nvbx_integrate_lidar_depth": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Lidar)]),
+    "nvbx_depth_image_from_pointcloud": (C.c_int, [_vp, _vp, _i64, C.POINTER(Lidar), _vp]),
     "nvbx_update_esdf": (C.c_int, [_vp]),
     "nvbx_update_color_mesh": (C.c_int, [_vp, _i32]),
     "nvbx_decay_tsdf": (C.c_int, [_vp, _i32]),

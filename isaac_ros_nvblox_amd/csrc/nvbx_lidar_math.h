@@ -1,0 +1,81 @@
+/* nvbx_lidar_math.h -- spinning-LiDAR sensor model shared by the HIP kernels and (for bit-parity of the projection) by
+ * the CPU oracle.  Plain C; every operation is an IEEE add / mul / div / sqrt in a fixed order (both sides build with
+ * -ffp-contract=off), so host and device produce identical bits -- libm's atan2f/acosf and the device's ocml versions
+ * differ in the last ulp, which would flip pixel taps and block boundaries between the two.
+ *
+ * Model ([U] nvblox sensors/lidar restated; anchors in the reference: Lidar(w, h, min_range, vfov) and
+ * Lidar(w, h, min_range, min_below, max_above) nvblox_ros/src/lib/nvblox_node.cpp:1315-1323; "each point projects to a
+ * pixel center" conversions/pointcloud_conversions.cu:78-92; elevation = asin(z/r), azimuth = atan2(y, x), equal angular
+ * bins nvblox_ros/scripts/calculate_lidar_params.py:50-58):
+ *   rows = elevation divisions (row 0 = highest beam), cols = azimuth divisions over 360 deg;
+ *   beam (k, j) passes through pixel CENTRE (j + 0.5, k + 0.5): elevation = max_el - k * rpp_el, azimuth = -pi + j * rpp_az,
+ *   rpp_el = (max_el - min_el) / (rows - 1), rpp_az = 2 pi / cols;   depth of a point = its range |p|.
+ */
+#ifndef NVBX_LIDAR_MATH_H_
+#define NVBX_LIDAR_MATH_H_
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define NVBX_HD __host__ __device__ inline
+#else
+#define NVBX_HD static inline
+#endif
+
+#define NVBX_PI_F 3.14159274101257324f      /* float(pi) */
+#define NVBX_HALF_PI_F 1.57079637050628662f
+#define NVBX_QUARTER_PI_F 0.785398185253143311f
+
+/* atan(x) for x in [0, 1]: Cephes atanf scheme (reduction at tan(pi/8), degree-4 polynomial in x^2), |err| < 2e-7 */
+NVBX_HD float nvbx_atan01f(float x) {
+  float y0 = 0.0f;
+  if (x > 0.414213568f) { y0 = NVBX_QUARTER_PI_F; x = (x - 1.0f) / (x + 1.0f); }
+  const float z = x * x;
+  float p = 8.05374449538e-2f * z;
+  p = p - 1.38776856032e-1f;
+  p = p * z;
+  p = p + 1.99777106478e-1f;
+  p = p * z;
+  p = p - 3.33329491539e-1f;
+  p = p * z;
+  p = p * x;
+  p = p + x;
+  return y0 + p;
+}
+NVBX_HD float nvbx_atan2f(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  if (ax == 0.0f && ay == 0.0f) return 0.0f;
+  float a = (ax >= ay) ? nvbx_atan01f(ay / ax) : (NVBX_HALF_PI_F - nvbx_atan01f(ax / ay));
+  if (x < 0.0f) a = NVBX_PI_F - a;
+  return y < 0.0f ? -a : a;
+}
+
+typedef struct {
+  int32_t cols, rows;             /* azimuth divisions, elevation divisions */
+  float min_valid_range_m;
+  float max_el, rpp_el, rpp_az;   /* derived: highest beam elevation, radians per pixel */
+} nvbx_lidar_model;
+
+NVBX_HD nvbx_lidar_model nvbx_lidar_make(int32_t cols, int32_t rows, float min_range, float min_el, float max_el) {
+  nvbx_lidar_model l;
+  l.cols = cols; l.rows = rows; l.min_valid_range_m = min_range; l.max_el = max_el;
+  l.rpp_el = (max_el - min_el) / (float)(rows - 1);
+  l.rpp_az = (2.0f * NVBX_PI_F) / (float)cols;
+  return l;
+}
+NVBX_HD float nvbx_lidar_range(const float* p) { return sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]); }
+
+/* Lidar::project: p (sensor frame) -> corner-referenced image coordinates (u along azimuth, v along elevation) */
+NVBX_HD int nvbx_lidar_project(const nvbx_lidar_model* l, const float* p, float r, float* u, float* v) {
+  if (r < l->min_valid_range_m || !(r > 0.0f)) return 0;
+  const float rho = sqrtf(p[0] * p[0] + p[1] * p[1]);
+  const float el = nvbx_atan2f(p[2], rho);
+  const float az = nvbx_atan2f(p[1], p[0]);
+  float uu = (az + NVBX_PI_F) / l->rpp_az + 0.5f;
+  const float vv = (l->max_el - el) / l->rpp_el + 0.5f;
+  if (uu >= (float)l->cols) uu = uu - (float)l->cols;           /* azimuth wrap-around */
+  if (vv < 0.0f || vv >= (float)l->rows || uu < 0.0f) return 0; /* outside the vertical field of view */
+  *u = uu; *v = vv;
+  return 1;
+}
+#endif

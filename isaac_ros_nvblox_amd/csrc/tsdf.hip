@@ -1,21 +1,103 @@
-// tsdf.hip -- MultiMapper::integrateDepth on MI355X: block marking (view calculation) + projective TSDF update.
+// tsdf.hip -- MultiMapper::integrateDepth on MI355X: block marking (view calculation) + projective TSDF update, for
+// the pinhole camera and for the spinning LiDAR (range image).
 //
 // Two launches per depth frame, no host round trip in between:
 //   k_mark_view      one wavefront per 8x8 tile of the sub-sampled ray grid.  Phase 1: each lane walks its ray through
 //                    the block grid (Amanatides-Woo) and drops the block keys into a 4 KiB LDS set (rays of one tile
-//                    share almost all their blocks) -- no HBM access inside the walk.  Phase 2: the set is compacted
-//                    (ballot + popcount) and ONE key per lane goes to HBM: CAS insert-if-absent into the hash
+//                    share almost all their blocks) -- no HBM access inside the walk.  Phase 2 (flush): the set is
+//                    compacted (ballot + popcount) and ONE key per lane goes to HBM: CAS insert-if-absent into the hash
 //                    (device-side allocation from the slot stack), per-entry frame stamp, and a wave-aggregated append
-//                    of the pool slot to the frame's view list (exactly once per block and frame).
+//                    of {slot, Index3D} to the frame's view list (exactly once per block and frame).  A camera tile
+//                    (< 100 blocks) flushes once; long LiDAR rays flush whenever the set is half full.
 //   k_integrate_tsdf one 512-thread workgroup (8 wave64) per 8^3 block, grid-striding over the device-resident view
 //                    list of {slot, Index3D} records; lane = voxel in z + 8y + 64x order, so every wave reads/writes
 //                    512 contiguous bytes.
+// Both kernels are templated on the depth source (f32 metres / u16 millimetres) and on the sensor model.
 // Reference semantics restated: [U] ViewCalculator::getBlocksInImageViewRaycast and ProjectiveTsdfIntegrator
-// (call site nvblox_ros/src/lib/nvblox_node.cpp:1062; knobs mapper_initialization.cpp:264-358).
+// (call sites nvblox_ros/src/lib/nvblox_node.cpp:1062 camera, :1382-1384 LiDAR; knobs mapper_initialization.cpp:264-358).
 #include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
 #include "nvbx_mapper.h"
+#include "nvbx_lidar_math.h"
 
 using namespace nvbx;
+
+// ------------------------------------------------------------------------------------------------ sensor models
+// Camera(fu, fv, cu, cv, w, h): conversions/image_conversions.cpp:27-32.  Everything it needs is in Frame.
+struct CameraSensor {
+  static constexpr bool kLongRays = false;
+  // end point (camera frame) of the ray through the centre of pixel (prow, pcol) at depth `de` along the optical axis
+  __device__ void ray_end(const Frame& f, int prow, int pcol, float de, float* pc) const {
+    const float rx = (((float)pcol + 0.5f) - f.cu) / f.fu;
+    const float ry = (((float)prow + 0.5f) - f.cv) / f.fv;
+    pc[0] = de * rx; pc[1] = de * ry; pc[2] = de;
+  }
+  // measured depth at the voxel centre `pc` and the voxel's own depth; false = voxel not updated
+  template <typename Img>
+  __device__ bool sample(const Frame& f, const Img& depth, const float* pc, float* ds, float* vd) const {
+    float u, v;
+    if (!cam_project(f, pc, &u, &v)) return false;
+    *vd = pc[2];
+    if (f.max_dist > 0.0f && *vd > f.max_dist) return false;
+    return interp_depth(depth, f.rows, f.cols, u, v, f.interp_nearest, ds);
+  }
+};
+
+// Lidar: nvbx_lidar_math.h.  el_tab[k] = {sin, cos} of beam row k's elevation, az_tab[j] = {sin, cos} of column j's azimuth.
+struct LidarSensor {
+  static constexpr bool kLongRays = true;
+  nvbx_lidar_model l;
+  const float2* el_tab; const float2* az_tab;
+  float max_diff_m, max_ray_dist_m;
+  __device__ void beam_dir(int row, int col, float* d) const {
+    const float2 e = el_tab[row], a = az_tab[col];
+    d[0] = e.y * a.y; d[1] = e.y * a.x; d[2] = e.x;
+  }
+  __device__ void ray_end(const Frame&, int prow, int pcol, float de, float* pc) const {
+    float d[3]; beam_dir(prow, pcol, d);
+    pc[0] = de * d[0]; pc[1] = de * d[1]; pc[2] = de * d[2];
+  }
+  // [U] interpolateLidarImage restated: bilinear if the four beams are valid and agree within max_diff_m, else the
+  // nearest beam if the voxel centre lies within max_ray_dist_m of that beam's ray.  Depth = range along the beam.
+  template <typename Img>
+  __device__ bool sample(const Frame& f, const Img& img, const float* pc, float* ds, float* vd) const {
+    const float r = nvbx_lidar_range(pc);
+    float u, v;
+    if (!nvbx_lidar_project(&l, pc, r, &u, &v)) return false;
+    *vd = r;
+    if (f.max_dist > 0.0f && r > f.max_dist) return false;
+    const float uc = u - 0.5f, vc = v - 0.5f;
+    const float fx = floorf(uc), fy = floorf(vc);
+    const int x0 = (int)fx, y0 = (int)fy;
+    if (!(x0 < 0 || y0 < 0 || x0 + 1 > f.cols - 1 || y0 + 1 > f.rows - 1)) {
+      const float f00 = img((int64_t)y0 * f.cols + x0), f10 = img((int64_t)y0 * f.cols + x0 + 1);
+      const float f01 = img((int64_t)(y0 + 1) * f.cols + x0), f11 = img((int64_t)(y0 + 1) * f.cols + x0 + 1);
+      if (f00 > 0.0f && f10 > 0.0f && f01 > 0.0f && f11 > 0.0f) {
+        const float mx = fmaxf(fmaxf(f00, f10), fmaxf(f01, f11)), mn = fminf(fminf(f00, f10), fminf(f01, f11));
+        if (mx - mn <= max_diff_m) {
+          const float ax = uc - fx, ay = vc - fy;
+          const float top = (1.0f - ax) * f00 + ax * f10;
+          const float bot = (1.0f - ax) * f01 + ax * f11;
+          *ds = (1.0f - ay) * top + ay * bot;
+          return true;
+        }
+      }
+    }
+    const int c = (int)floorf(u), rr = (int)floorf(v);
+    if (c < 0 || rr < 0 || c >= f.cols || rr >= f.rows) return false;
+    const float d = img((int64_t)rr * f.cols + c);
+    if (!(d > 0.0f)) return false;
+    float dir[3]; beam_dir(rr, c, dir);
+    float dot = pc[0] * dir[0]; dot = dot + pc[1] * dir[1]; dot = dot + pc[2] * dir[2];
+    const float ex = pc[0] - dot * dir[0], ey = pc[1] - dot * dir[1], ez = pc[2] - dot * dir[2];
+    const float dist = sqrtf((ex * ex + ey * ey) + ez * ez);
+    if (dist > max_ray_dist_m) return false;
+    *ds = d;
+    return true;
+  }
+};
 
 constexpr int LSET = 512;   // LDS dedup set entries per wave-tile (8 B each)
 
@@ -66,8 +148,52 @@ __device__ inline void view_append(int32_t* cnt, int4* view_list, int32_t list_c
   }
 }
 
-template <typename Img>
-__global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, int4* view_list, int32_t list_cap) {
+// insert `key` into the tile's LDS set; false = probe window exhausted (caller sends the key to HBM itself)
+__device__ inline bool lset_insert(u64* lset, const int32_t* cur, u64 key, bool* added) {
+  const uint32_t lh = (index_hash(cur[0], cur[1], cur[2]) * 2654435761u) >> 23;   // 9 bits
+  *added = false;
+#pragma unroll 1
+  for (int p = 0; p < 16; p++) {
+    const u64 old = atomicCAS(&lset[(lh + p) & (LSET - 1)], KEY_EMPTY, key);
+    if (old == KEY_EMPTY) { *added = true; return true; }
+    if (old == key) return true;
+  }
+  return false;
+}
+// Amanatides-Woo: advance to the next block along the ray (select without dynamic register indexing)
+__device__ inline void dda_step(int32_t* cur, const int32_t* step, float* tmax, const float* tdelta) {
+  int a = 0;
+  if (tmax[1] < tmax[a]) a = 1;
+  if (tmax[2] < tmax[a]) a = 2;
+  if (a == 0) { cur[0] += step[0]; tmax[0] = tmax[0] + tdelta[0]; }
+  else if (a == 1) { cur[1] += step[1]; tmax[1] = tmax[1] + tdelta[1]; }
+  else { cur[2] += step[2]; tmax[2] = tmax[2] + tdelta[2]; }
+}
+// Flush: compact the set (ballot + popcount), then ONE key per lane goes to HBM -- the hash probes, stamp exchanges and
+// slot reads of all the tile's blocks are in flight together instead of one per ray step.  Whole wave must call.
+__device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* lkeys, int32_t* cnt, int4* view_list, int32_t list_cap,
+                                 int lane, bool clear) {
+  __syncthreads();
+  int32_t nk = 0;
+#pragma unroll
+  for (int i = 0; i < LSET / 64; i++) {
+    const u64 kk = lset[i * 64 + lane];
+    const u64 mask = __ballot(kk != KEY_EMPTY);
+    if (kk != KEY_EMPTY) lkeys[nk + (int32_t)__popcll(mask & ((1ull << lane) - 1ull))] = kk;
+    nk += (int32_t)__popcll(mask);
+    if (clear) lset[i * 64 + lane] = KEY_EMPTY;
+  }
+  __syncthreads();
+  for (int32_t i = 0; i < nk; i += 64) {
+    int4 rec = make_int4(0, 0, 0, 0);
+    const bool first = (i + lane < nk) && mark_block(m, lkeys[i + lane], f.frame_id, &rec);
+    view_append(cnt, view_list, list_cap, first, rec, lane);
+  }
+  __syncthreads();
+}
+
+template <typename Img, typename Sensor>
+__global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Sensor sensor, int4* view_list, int32_t list_cap) {
   __shared__ u64 lset[LSET];
   __shared__ u64 lkeys[LSET];
   const int lane = threadIdx.x;
@@ -90,10 +216,9 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, in
     else {
       float de = d + f.trunc;
       if (f.max_dist > 0.0f && de > f.max_dist) de = f.max_dist;
-      const float rx = (((float)pcol + 0.5f) - f.cu) / f.fu;
-      const float ry = (((float)prow + 0.5f) - f.cv) / f.fv;
-      float pl[3];
-      apply_rt(f.R_LC, f.t_LC, de * rx, de * ry, de, pl);
+      float pc[3], pl[3];
+      sensor.ray_end(f, prow, pcol, de, pc);
+      apply_rt(f.R_LC, f.t_LC, pc[0], pc[1], pc[2], pl);
       nsteps = 0;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
@@ -111,54 +236,49 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, in
     }
   }
   int32_t* cnt = &m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
-  // ---- phase 1: walk.  Keys go to the LDS set only; HBM is touched here only if the set overflows (never at
-  //      640x480 / 8 m: a tile's ray bundle crosses < 100 blocks).
-  for (int32_t k = 0; k <= nsteps; k++) {
-    const u64 key = pack_key(cur[0], cur[1], cur[2]);
-    bool spill = true;
-    const uint32_t lh = (index_hash(cur[0], cur[1], cur[2]) * 2654435761u) >> 23;   // 9 bits
-#pragma unroll 1
-    for (int p = 0; p < 16; p++) {
-      const u64 old = atomicCAS(&lset[(lh + p) & (LSET - 1)], KEY_EMPTY, key);
-      if (old == KEY_EMPTY || old == key) { spill = false; break; }
+  if (!Sensor::kLongRays) {
+    // camera: a tile's rays cross < 100 blocks in ~20 steps -- walk every ray to its end, then flush once
+    for (int32_t k = 0; k <= nsteps; k++) {
+      bool added;
+      const u64 key = pack_key(cur[0], cur[1], cur[2]);
+      const bool spill = !lset_insert(lset, cur, key, &added);
+      if (__ballot(spill)) {                     // probe window exhausted (rare): this key goes to HBM directly
+        int4 rec = make_int4(0, 0, 0, 0);
+        const bool first = spill && mark_block(m, key, f.frame_id, &rec);
+        view_append(cnt, view_list, list_cap, first, rec, lane);
+      }
+      dda_step(cur, step, tmax, tdelta);
     }
-    if (__ballot(spill)) {                       // rare overflow path, wave-uniform branch
+    flush_set(m, f, lset, lkeys, cnt, view_list, list_cap, lane, false);
+    return;
+  }
+  // LiDAR: hundreds of steps per ray and little sharing at long range -- wave-uniform loop, flush whenever the set is
+  // half full
+  int32_t nset = 0;                                   // keys in the LDS set (wave-uniform)
+  for (int32_t k = 0; __ballot(k <= nsteps) != 0ull; k++) {
+    bool spill = false, added = false;
+    u64 key = KEY_EMPTY;
+    if (k <= nsteps) {
+      key = pack_key(cur[0], cur[1], cur[2]);
+      spill = !lset_insert(lset, cur, key, &added);
+      dda_step(cur, step, tmax, tdelta);
+    }
+    nset += (int32_t)__popcll(__ballot(added));
+    if (__ballot(spill)) {
       int4 rec = make_int4(0, 0, 0, 0);
       const bool first = spill && mark_block(m, key, f.frame_id, &rec);
       view_append(cnt, view_list, list_cap, first, rec, lane);
     }
-    int a = 0;
-    if (tmax[1] < tmax[a]) a = 1;
-    if (tmax[2] < tmax[a]) a = 2;
-    // (select without dynamic register indexing)
-    if (a == 0) { cur[0] += step[0]; tmax[0] = tmax[0] + tdelta[0]; }
-    else if (a == 1) { cur[1] += step[1]; tmax[1] = tmax[1] + tdelta[1]; }
-    else { cur[2] += step[2]; tmax[2] = tmax[2] + tdelta[2]; }
-  }
-  __syncthreads();
-  // ---- phase 2: compact the set (ballot + popcount), then one key per lane goes to HBM: the hash probe, the stamp
-  //      exchange and the slot read of all the tile's blocks are in flight together instead of one per ray step.
-  int32_t nk = 0;
-#pragma unroll
-  for (int i = 0; i < LSET / 64; i++) {
-    const u64 key = lset[i * 64 + lane];
-    const u64 mask = __ballot(key != KEY_EMPTY);
-    if (key != KEY_EMPTY) lkeys[nk + (int32_t)__popcll(mask & ((1ull << lane) - 1ull))] = key;
-    nk += (int32_t)__popcll(mask);
-  }
-  __syncthreads();
-  for (int32_t i = 0; i < nk; i += 64) {
-    int4 rec = make_int4(0, 0, 0, 0);
-    const bool first = (i + lane < nk) && mark_block(m, lkeys[i + lane], f.frame_id, &rec);
-    view_append(cnt, view_list, list_cap, first, rec, lane);
+    const bool last = __ballot(k + 1 <= nsteps) == 0ull;
+    if (last || nset > LSET / 2) { flush_set(m, f, lset, lkeys, cnt, view_list, list_cap, lane, !last); nset = 0; }
   }
 }
 
 // Dependent-access chain: {view count, view record} -> {depth gather, voxel} -> store.  The record of the first block
 // is fetched speculatively beside the count, the voxel is fetched before the projection decides whether it is needed,
 // and the flag / dirty-list atomics of lane 0 are issued first and consumed last.
-template <typename Img>
-__global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img depth, const int4* view_list, int32_t list_cap,
+template <typename Img, typename Sensor>
+__global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img depth, Sensor sensor, const int4* view_list, int32_t list_cap,
                                                         int32_t* esdf_dirty, int32_t* mesh_dirty, int32_t mesh_cnt) {
   int4 rec = view_list[blockIdx.x];                       // speculative: valid iff blockIdx.x < n (gridDim.x <= list_cap)
   int32_t n = m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
@@ -176,11 +296,8 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img dep
     float pc[3];
     apply_rt(f.R_CL, f.t_CL, voxel_center(rec.y, vx, f.block_size, f.voxel_size), voxel_center(rec.z, vy, f.block_size, f.voxel_size),
              voxel_center(rec.w, vz, f.block_size, f.voxel_size), pc);
-    float u, v, ds;
-    bool upd = cam_project(f, pc, &u, &v);
-    const float vd = pc[2];
-    if (upd && f.max_dist > 0.0f && vd > f.max_dist) upd = false;
-    if (upd) upd = interp_depth(depth, f.rows, f.cols, u, v, f.interp_nearest, &ds);
+    float ds = 0.0f, vd = 0.0f;
+    const bool upd = sensor.sample(f, depth, pc, &ds, &vd);
     if (upd) {
       const float sdf = ds - vd;
       if (!(sdf < -f.trunc)) {
@@ -200,32 +317,118 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img dep
   }
 }
 
-template <typename Img>
-static int integrate_depth_impl(nvbx_mapper* m, Img img, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera) {
-  NVBX_HIP(hipSetDevice(m->device));
-  if (m->join_side()) return NVBX_E_DEVICE;     // k_integrate_tsdf writes what k_esdf_mark reads
-  m->frame_id++;
-  Frame f = m->make_frame(T_L_C, camera, rows, cols, m->p.raycast_subsampling_factor);
+template <typename Img, typename Sensor>
+static int integrate_depth_impl(nvbx_mapper* m, Img img, const Sensor& sensor, const Frame& f0) {
+  Frame f = f0;
   const int s = f.subsample;
-  f.n_ray_rows = (rows + s - 1 + s - 1) / s;   // indices i with i*s < rows + s - 1
-  f.n_ray_cols = (cols + s - 1 + s - 1) / s;
+  f.n_ray_rows = (f.rows + s - 1 + s - 1) / s;   // indices i with i*s < rows + s - 1
+  f.n_ray_cols = (f.cols + s - 1 + s - 1) / s;
   const int tiles = ((f.n_ray_rows + 7) / 8) * ((f.n_ray_cols + 7) / 8);
-  NVBX_LAUNCH(m, (k_mark_view<Img>), dim3(tiles), dim3(64), m->d, f, img, (int4*)m->view_list, (int32_t)m->capacity);
+  NVBX_LAUNCH(m, (k_mark_view<Img, Sensor>), dim3(tiles), dim3(64), m->d, f, img, sensor, (int4*)m->view_list, (int32_t)m->capacity);
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);
-  NVBX_LAUNCH(m, (k_integrate_tsdf<Img>), dim3(grid), dim3(512), m->d, f, img, (const int4*)m->view_list, (int32_t)m->capacity,
+  NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor>), dim3(grid), dim3(512), m->d, f, img, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
                      m->esdf_dirty, m->mesh_dirty_live(), m->mesh_dirty_counter());
   NVBX_HIP(hipGetLastError());
   m->last_view_frame = m->frame_id;
   return m->mark_main();
 }
 
+template <typename Img>
+static int integrate_camera(nvbx_mapper* m, Img img, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera) {
+  NVBX_HIP(hipSetDevice(m->device));
+  if (m->join_side()) return NVBX_E_DEVICE;     // k_integrate_tsdf writes what k_esdf_mark reads
+  m->frame_id++;
+  const Frame f = m->make_frame(T_L_C, camera, rows, cols, m->p.raycast_subsampling_factor);
+  return integrate_depth_impl(m, img, CameraSensor{}, f);
+}
+
 extern "C" int nvbx_integrate_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                     const nvbx_camera* camera) {
   if (!m || !depth_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_depth: invalid argument"); return NVBX_E_INVALID; }
-  return integrate_depth_impl(m, DepthF32{depth_dev}, rows, cols, T_L_C, camera);
+  return integrate_camera(m, DepthF32{depth_dev}, rows, cols, T_L_C, camera);
 }
 extern "C" int nvbx_integrate_depth_u16mm(nvbx_mapper* m, const uint16_t* depth_mm_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                           const nvbx_camera* camera) {
   if (!m || !depth_mm_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_depth_u16mm: invalid argument"); return NVBX_E_INVALID; }
-  return integrate_depth_impl(m, DepthU16mm{depth_mm_dev}, rows, cols, T_L_C, camera);
+  return integrate_camera(m, DepthU16mm{depth_mm_dev}, rows, cols, T_L_C, camera);
+}
+
+// ------------------------------------------------------------------------------------------------ LiDAR
+static bool same_lidar(const nvbx_lidar& a, const nvbx_lidar& b) { return memcmp(&a, &b, sizeof(a)) == 0; }
+
+// beam direction tables: sin / cos evaluated in double on the host from the float model parameters, rounded to float
+// (the oracle builds the same tables the same way, so view rays are bit-identical)
+static int ensure_lidar_tables(nvbx_mapper* m, const nvbx_lidar* ld, const nvbx_lidar_model& l) {
+  if (m->lidar_tab && same_lidar(m->lidar_cached, *ld)) return NVBX_OK;
+  const size_t n = (size_t)l.rows + (size_t)l.cols;
+  if (n > m->lidar_tab_cap) {
+    NVBX_HIP(hipStreamSynchronize(m->stream));
+    if (m->lidar_tab) NVBX_HIP(hipFree(m->lidar_tab));
+    m->lidar_tab = nullptr; m->lidar_tab_cap = 0;
+    NVBX_HIP(hipMalloc(&m->lidar_tab, n * sizeof(float2)));
+    m->lidar_tab_cap = n;
+  }
+  m->lidar_host.resize(n * 2);
+  for (int k = 0; k < l.rows; k++) {
+    const double el = (double)l.max_el - (double)k * (double)l.rpp_el;
+    m->lidar_host[2 * (size_t)k] = (float)sin(el); m->lidar_host[2 * (size_t)k + 1] = (float)cos(el);
+  }
+  for (int j = 0; j < l.cols; j++) {
+    const double az = -(double)NVBX_PI_F + (double)j * (double)l.rpp_az;
+    m->lidar_host[2 * ((size_t)l.rows + j)] = (float)sin(az); m->lidar_host[2 * ((size_t)l.rows + j) + 1] = (float)cos(az);
+  }
+  NVBX_HIP(hipMemcpyAsync(m->lidar_tab, m->lidar_host.data(), n * sizeof(float2), hipMemcpyHostToDevice, m->stream));
+  NVBX_HIP(hipStreamSynchronize(m->stream));    // once per sensor model
+  m->lidar_cached = *ld;
+  return NVBX_OK;
+}
+
+static bool lidar_ok(const nvbx_lidar* ld) {
+  return ld && ld->num_azimuth_divisions >= 2 && ld->num_elevation_divisions >= 2 && ld->max_elevation_rad > ld->min_elevation_rad;
+}
+
+extern "C" int nvbx_integrate_lidar_depth(nvbx_mapper* m, const float* range_dev, int32_t rows, int32_t cols, const float T_L_C[16],
+                                          const nvbx_lidar* lidar) {
+  if (!m || !range_dev || !T_L_C || !lidar_ok(lidar) || rows != lidar->num_elevation_divisions || cols != lidar->num_azimuth_divisions) {
+    set_error("nvbx_integrate_lidar_depth: invalid argument (range image must be elevation x azimuth divisions)"); return NVBX_E_INVALID;
+  }
+  NVBX_HIP(hipSetDevice(m->device));
+  if (m->join_side()) return NVBX_E_DEVICE;
+  const nvbx_lidar_model l = nvbx_lidar_make(cols, rows, lidar->min_valid_range_m, lidar->min_elevation_rad, lidar->max_elevation_rad);
+  const int rc = ensure_lidar_tables(m, lidar, l); if (rc) return rc;
+  m->frame_id++;
+  nvbx_camera none{1.f, 1.f, 0.f, 0.f, cols, rows};
+  Frame f = m->make_frame(T_L_C, &none, rows, cols, m->p.raycast_subsampling_factor);
+  f.max_dist = m->p.lidar_max_integration_distance_m;
+  LidarSensor s{l, (const float2*)m->lidar_tab, (const float2*)m->lidar_tab + rows,
+                m->p.lidar_linear_interpolation_max_allowable_difference_vox * m->p.voxel_size,
+                m->p.lidar_nearest_interpolation_max_allowable_dist_to_ray_vox * m->p.voxel_size};
+  return integrate_depth_impl(m, DepthF32{range_dev}, s, f);
+}
+
+// depthImageFromPointcloudKernel (conversions/pointcloud_conversions.cu:118-150): last writer wins
+__global__ void k_depth_from_points(const float* pts, int64_t n, nvbx_lidar_model l, float* img) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    if (isnan(p[0]) || isnan(p[1]) || isnan(p[2])) continue;
+    const float r = nvbx_lidar_range(p);
+    float u, v;
+    if (!nvbx_lidar_project(&l, p, r, &u, &v)) continue;
+    const int c = (int)floorf(u), rr = (int)floorf(v);
+    if (c < 0 || rr < 0 || c >= l.cols || rr >= l.rows) continue;
+    img[(int64_t)rr * l.cols + c] = r;
+  }
+}
+extern "C" int nvbx_depth_image_from_pointcloud(nvbx_mapper* m, const float* points_xyz_dev, int64_t n_points, const nvbx_lidar* lidar,
+                                                float* range_dev) {
+  if (!m || !points_xyz_dev || n_points < 0 || !lidar_ok(lidar) || !range_dev) { set_error("nvbx_depth_image_from_pointcloud: invalid argument"); return NVBX_E_INVALID; }
+  NVBX_HIP(hipSetDevice(m->device));
+  if (m->join_side()) return NVBX_E_DEVICE;
+  const nvbx_lidar_model l = nvbx_lidar_make(lidar->num_azimuth_divisions, lidar->num_elevation_divisions, lidar->min_valid_range_m,
+                                             lidar->min_elevation_rad, lidar->max_elevation_rad);
+  NVBX_HIP(hipMemsetAsync(range_dev, 0, (size_t)l.rows * l.cols * sizeof(float), m->stream));
+  if (n_points > 0)
+    NVBX_LAUNCH(m, k_depth_from_points, dim3((unsigned)std::min<int64_t>((n_points + 255) / 256, 4096)), dim3(256), points_xyz_dev, n_points, l, range_dev);
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;
 }

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Camera, Counters, Index3D, Params
+from ._lib import Camera, Counters, Index3D, Lidar, Params
 
 LAYER_TSDF, LAYER_COLOR, LAYER_ESDF, LAYER_MESH = 1, 2, 4, 8
 
@@ -30,7 +30,10 @@ def default_params(**kw):
         sphere_tracing_subsampling=4, sphere_tracing_max_steps=100,
         sphere_tracing_max_ray_length_m=15.0, sphere_tracing_surface_eps_vox=0.1,
         tsdf_decay_factor=0.95, tsdf_decayed_weight_threshold=0.001,
-        esdf_site_rule=0, depth_interp_nearest=0)
+        esdf_site_rule=0, depth_interp_nearest=0,
+        lidar_max_integration_distance_m=10.0,
+        lidar_linear_interpolation_max_allowable_difference_vox=2.0,
+        lidar_nearest_interpolation_max_allowable_dist_to_ray_vox=0.5)
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -123,6 +126,34 @@ class Mapper:
         T = self._T(T_L_C); k = self._cam(cam)
         self._check(fn(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k)))
         self._keep = [d]   # keep the device image alive until the next call (stream-ordered use)
+
+    @staticmethod
+    def _lidar(lidar):
+        if isinstance(lidar, Lidar):
+            return lidar
+        return Lidar(int(lidar[0]), int(lidar[1]), float(lidar[2]), float(lidar[3]), float(lidar[4]))
+
+    def integrate_lidar_depth(self, range_image, T_L_C, lidar):
+        """range image [elevation divisions, azimuth divisions] f32 metres; lidar = (cols, rows, min_range, min_el, max_el)."""
+        d = self._dev(range_image, self._torch.float32)
+        T = self._T(T_L_C); k = self._lidar(lidar)
+        self._check(self.lib.nvbx_integrate_lidar_depth(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k)))
+        self._keep = [d]
+
+    def prepare_lidar(self, range_image, T_L_C, lidar):
+        d = self._dev(range_image, self._torch.float32)
+        T = self._T(T_L_C); k = self._lidar(lidar)
+        return (self.lib.nvbx_integrate_lidar_depth, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k), (d, T, k))
+
+    def depth_image_from_pointcloud(self, points, lidar):
+        torch = self._torch
+        p = self._dev(points, torch.float32)
+        assert p.dim() == 2 and p.shape[1] == 3
+        k = self._lidar(lidar)
+        img = torch.zeros((k.num_elevation_divisions, k.num_azimuth_divisions), dtype=torch.float32, device=p.device)
+        self._check(self.lib.nvbx_depth_image_from_pointcloud(self._h, C.c_void_p(p.data_ptr()), p.shape[0], C.byref(k), C.c_void_p(img.data_ptr())))
+        self.synchronize()
+        return img
 
     def integrate_color(self, rgb, T_L_C, cam):
         d = self._dev(rgb, self._torch.uint8)

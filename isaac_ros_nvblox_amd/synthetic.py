@@ -97,3 +97,64 @@ def sequence(n, scene=None, cam=REPLICA_LIKE_CAM, n_frames_in_loop=200, yaw_offs
         T = trajectory_pose(i, n_frames_in_loop, yaw_offset_deg=yaw_offset_deg, **kw)
         depth, rgb = render(scene, T, cam, color=color)
         yield depth, rgb, T
+
+
+# ------------------------------------------------------------------------------------------------ spinning LiDAR
+# BASELINE.json configs[4] / SURVEY.md 8(d) [D]: Lidar(1024, 64, min_range 0.1, vfov 45 deg), ground plane + 40 boxes
+# in a 300 x 300 m area (default_rng(1)), ranges beyond 200 m invalid.  Lidar tuple = (azimuth divisions, elevation
+# divisions, min_valid_range_m, min_elevation_rad, max_elevation_rad) -- the C-ABI's nvbx_lidar.
+SPINNING_LIDAR = (1024, 64, 0.1, -np.deg2rad(22.5), np.deg2rad(22.5))
+
+
+class LidarScene:
+    def __init__(self, n_boxes=40, extent=150.0, seed=1):
+        rng = np.random.default_rng(seed)
+        c = rng.uniform(-extent, extent, (n_boxes, 2))
+        sz = rng.uniform(2.0, 12.0, (n_boxes, 2)); h = rng.uniform(2.0, 15.0, n_boxes)
+        keep = np.hypot(c[:, 0], c[:, 1]) > 12.0          # keep the sensor's start area free
+        c, sz, h = c[keep], sz[keep], h[keep]
+        self.bmin = np.concatenate([c - sz / 2, np.zeros((len(c), 1))], 1)
+        self.bmax = np.concatenate([c + sz / 2, h[:, None]], 1)
+
+    def raycast(self, o, d):
+        """o (3,), d (N,3) unit directions -> range (inf where nothing is hit)."""
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = np.where(d[:, 2] < 0, -o[2] / d[:, 2], np.inf)         # ground plane z = 0
+            for bmin, bmax in zip(self.bmin, self.bmax):
+                t1 = (bmin - o) / d; t2 = (bmax - o) / d
+                tn = np.where(d == 0, -np.inf, np.minimum(t1, t2)).max(axis=1)
+                tf = np.where(d == 0, np.inf, np.maximum(t1, t2)).min(axis=1)
+                t = np.minimum(t, np.where((tn <= tf) & (tn > 0), tn, np.inf))
+        return t
+
+
+def lidar_beam_dirs(lidar=SPINNING_LIDAR):
+    """Unit beam directions [rows, cols, 3] in the sensor frame (x forward, z up); beam (k, j) = pixel centre (j+.5, k+.5)."""
+    cols, rows, _, min_el, max_el = lidar
+    el = max_el - np.arange(rows) * ((max_el - min_el) / (rows - 1))
+    az = -np.pi + np.arange(cols) * (2.0 * np.pi / cols)
+    d = np.empty((rows, cols, 3))
+    d[..., 0] = np.cos(el)[:, None] * np.cos(az)[None, :]
+    d[..., 1] = np.cos(el)[:, None] * np.sin(az)[None, :]
+    d[..., 2] = np.sin(el)[:, None]
+    return d
+
+
+def lidar_pose(i, n_frames=200, radius=8.0, height=2.0):
+    """Sensor frame = z up, x forward along the tangent of a slow circle (a vehicle driving a loop)."""
+    th = 2.0 * np.pi * (i / float(n_frames))
+    T = np.eye(4)
+    c, s = np.cos(th + np.pi / 2), np.sin(th + np.pi / 2)
+    T[:3, :3] = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+    T[:3, 3] = [radius * np.cos(th), radius * np.sin(th), height]
+    return T.astype(np.float32)
+
+
+def render_lidar(scene, T_L_C, lidar=SPINNING_LIDAR, max_range=200.0):
+    """Range image float32 [rows, cols] (0 = no return within max_range)."""
+    T = np.asarray(T_L_C, np.float64).reshape(4, 4)
+    dirs = lidar_beam_dirs(lidar)
+    d = (dirs.reshape(-1, 3) @ T[:3, :3].T)
+    t = scene.raycast(T[:3, 3], d).reshape(dirs.shape[:2])
+    rng_img = np.where(np.isfinite(t) & (t <= max_range) & (t >= lidar[2]), t, 0.0)
+    return rng_img.astype(np.float32)

@@ -38,6 +38,9 @@ class OrcParams(C.Structure):
         ("tsdf_decayed_weight_threshold", C.c_float),
         ("esdf_site_rule", C.c_int32),
         ("depth_interp_nearest", C.c_int32),
+        ("lidar_max_integration_distance_m", C.c_float),
+        ("lidar_linear_interpolation_max_allowable_difference_vox", C.c_float),
+        ("lidar_nearest_interpolation_max_allowable_dist_to_ray_vox", C.c_float),
     ]
 
 
@@ -52,7 +55,9 @@ def default_params(**kw):
         sphere_tracing_subsampling=4, sphere_tracing_max_steps=100,
         sphere_tracing_max_ray_length_m=15.0, sphere_tracing_surface_eps_vox=0.1,
         tsdf_decay_factor=0.95, tsdf_decayed_weight_threshold=0.001,
-        esdf_site_rule=0, depth_interp_nearest=0)
+        esdf_site_rule=0, depth_interp_nearest=0, lidar_max_integration_distance_m=10.0,
+        lidar_linear_interpolation_max_allowable_difference_vox=2.0,
+        lidar_nearest_interpolation_max_allowable_dist_to_ray_vox=0.5)
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -81,6 +86,10 @@ def lib():
         L.orc_num_threads.restype = C.c_int
         L.orc_index_hash.restype = C.c_uint32; L.orc_index_hash.argtypes = [i32, i32, i32]
         L.orc_integrate_depth.restype = i64; L.orc_integrate_depth.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+        L.orc_integrate_lidar_depth.restype = i64; L.orc_integrate_lidar_depth.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+        L.orc_depth_image_from_pointcloud.argtypes = [vp, i64, vp, vp]
+        L.orc_lidar_project.restype = C.c_int; L.orc_lidar_project.argtypes = [vp, vp, f32p, f32p]
+        L.orc_atan2f.restype = C.c_float; L.orc_atan2f.argtypes = [C.c_float, C.c_float]
         L.orc_integrate_color.restype = i64; L.orc_integrate_color.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
         L.orc_num_blocks.restype = i64; L.orc_num_blocks.argtypes = [vp, C.c_uint32]
         L.orc_block_indices.restype = i64; L.orc_block_indices.argtypes = [vp, C.c_uint32, vp, i64]
@@ -142,6 +151,11 @@ class OracleMap:
         depth = np.ascontiguousarray(depth, np.float32)
         T = self._T(T_L_C); k = self._cam(cam)
         return lib().orc_integrate_depth(self._h, _p(depth), depth.shape[0], depth.shape[1], _p(T), _p(k))
+
+    def integrate_lidar_depth(self, range_image, T_L_C, lidar):
+        d = np.ascontiguousarray(range_image, np.float32); T = self._T(T_L_C)
+        l5 = np.asarray(lidar, np.float32)
+        return lib().orc_integrate_lidar_depth(self._h, _p(d), d.shape[0], d.shape[1], _p(T), _p(l5))
 
     def integrate_color(self, rgb, T_L_C, cam):
         rgb = np.ascontiguousarray(rgb, np.uint8)
@@ -234,3 +248,17 @@ class OracleMap:
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def depth_image_from_pointcloud(points, lidar):
+    pts = np.ascontiguousarray(points, np.float32); l5 = np.asarray(lidar, np.float32)
+    img = np.zeros((int(lidar[1]), int(lidar[0])), np.float32)
+    lib().orc_depth_image_from_pointcloud(_p(pts), pts.shape[0], _p(l5), _p(img))
+    return img
+
+
+def lidar_project(lidar, p):
+    l5 = np.asarray(lidar, np.float32); q = np.asarray(p, np.float32)
+    u, v = C.c_float(), C.c_float()
+    ok = lib().orc_lidar_project(_p(l5), _p(q), C.byref(u), C.byref(v))
+    return (u.value, v.value) if ok else None

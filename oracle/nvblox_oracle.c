@@ -39,6 +39,9 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+/* The LiDAR sensor model (projection, atan2 polynomial) is shared with the product so both sides produce identical
+ * bits for the projection; a product header included by test infrastructure, not the other way round. */
+#include "../isaac_ros_nvblox_amd/csrc/nvbx_lidar_math.h"
 
 #define VPS 8
 #define NVOX 512
@@ -73,6 +76,9 @@ typedef struct {
   float tsdf_decayed_weight_threshold;  /* tsdf_decayed_weight_threshold */
   int32_t esdf_site_rule;               /* 0: inside && |d|<=max_site (default, [U] recall); 1: |d|<=max_site */
   int32_t depth_interp_nearest;         /* 0: bilinear-with-validity (default); 1: nearest */
+  float lidar_max_integration_distance_m;  /* lidar_projective_integrator_max_integration_distance_m, mapper_initialization.cpp:271-276 */
+  float lidar_linear_interpolation_max_allowable_difference_vox;   /* [U] 2.0 */
+  float lidar_nearest_interpolation_max_allowable_dist_to_ray_vox; /* [U] 0.5 */
 } OrcParams;
 
 enum { W_CONSTANT = 0, W_CONSTANT_DROPOFF = 1, W_INVERSE_SQUARE = 2, W_INVERSE_SQUARE_DROPOFF = 3,
@@ -392,6 +398,134 @@ int64_t orc_integrate_depth(OrcMap* m, const float* depth, int rows, int cols, c
   }
   return n;
 }
+
+
+/* ------------------------------------------------------------------ LiDAR (range image) */
+/* [U] ProjectiveTsdfIntegrator::integrateFrame(DepthImage, T_L_C, Lidar) restated (call site nvblox_node.cpp:1382-1384;
+ * model anchors in nvbx_lidar_math.h).  Same view calculation and voxel update as the camera path with the sensor
+ * model swapped: ray through the pixel centre = beam direction; voxel depth = range; measured depth by
+ * interpolateLidarImage ([U]: bilinear if the 4 beams are valid and agree within max_allowable_difference, else the
+ * nearest beam if the voxel centre is within max_allowable_dist_to_ray of it). */
+typedef struct { nvbx_lidar_model l; float* el; float* az; } LidarTab;   /* {sin, cos} pairs */
+static LidarTab lidar_tab_make(const float* lidar5) {
+  LidarTab t;
+  t.l = nvbx_lidar_make((int32_t)lidar5[0], (int32_t)lidar5[1], lidar5[2], lidar5[3], lidar5[4]);
+  t.el = (float*)malloc(sizeof(float) * 2 * (size_t)t.l.rows); t.az = (float*)malloc(sizeof(float) * 2 * (size_t)t.l.cols);
+  for (int k = 0; k < t.l.rows; k++) { const double el = (double)t.l.max_el - (double)k * (double)t.l.rpp_el; t.el[2 * k] = (float)sin(el); t.el[2 * k + 1] = (float)cos(el); }
+  for (int j = 0; j < t.l.cols; j++) { const double az = -(double)NVBX_PI_F + (double)j * (double)t.l.rpp_az; t.az[2 * j] = (float)sin(az); t.az[2 * j + 1] = (float)cos(az); }
+  return t;
+}
+static inline void lidar_dir(const LidarTab* t, int row, int col, float* d) {
+  const float se = t->el[2 * row], ce = t->el[2 * row + 1], sa = t->az[2 * col], ca = t->az[2 * col + 1];
+  d[0] = ce * ca; d[1] = ce * sa; d[2] = se;
+}
+static int lidar_sample(const OrcParams* p, const LidarTab* t, const float* img, int rows, int cols, const float* pc, float max_dist, float* ds, float* vd) {
+  const float r = nvbx_lidar_range(pc);
+  float u, v;
+  if (!nvbx_lidar_project(&t->l, pc, r, &u, &v)) return 0;
+  *vd = r;
+  if (max_dist > 0.0f && r > max_dist) return 0;
+  const float max_diff = p->lidar_linear_interpolation_max_allowable_difference_vox * p->voxel_size;
+  const float max_ray = p->lidar_nearest_interpolation_max_allowable_dist_to_ray_vox * p->voxel_size;
+  const float uc = u - 0.5f, vc = v - 0.5f;
+  const float fx = floorf(uc), fy = floorf(vc);
+  const int x0 = (int)fx, y0 = (int)fy;
+  if (!(x0 < 0 || y0 < 0 || x0 + 1 > cols - 1 || y0 + 1 > rows - 1)) {
+    const float f00 = img[(int64_t)y0 * cols + x0], f10 = img[(int64_t)y0 * cols + x0 + 1];
+    const float f01 = img[(int64_t)(y0 + 1) * cols + x0], f11 = img[(int64_t)(y0 + 1) * cols + x0 + 1];
+    if (f00 > 0.0f && f10 > 0.0f && f01 > 0.0f && f11 > 0.0f) {
+      const float mx = fmaxf(fmaxf(f00, f10), fmaxf(f01, f11)), mn = fminf(fminf(f00, f10), fminf(f01, f11));
+      if (mx - mn <= max_diff) {
+        const float ax = uc - fx, ay = vc - fy;
+        const float top = (1.0f - ax) * f00 + ax * f10;
+        const float bot = (1.0f - ax) * f01 + ax * f11;
+        *ds = (1.0f - ay) * top + ay * bot;
+        return 1;
+      }
+    }
+  }
+  const int c = (int)floorf(u), rr = (int)floorf(v);
+  if (c < 0 || rr < 0 || c >= cols || rr >= rows) return 0;
+  const float d = img[(int64_t)rr * cols + c];
+  if (!(d > 0.0f)) return 0;
+  float dir[3]; lidar_dir(t, rr, c, dir);
+  float dot = pc[0] * dir[0]; dot = dot + pc[1] * dir[1]; dot = dot + pc[2] * dir[2];
+  const float ex = pc[0] - dot * dir[0], ey = pc[1] - dot * dir[1], ez = pc[2] - dot * dir[2];
+  const float dist = sqrtf((ex * ex + ey * ey) + ez * ez);
+  if (dist > max_ray) return 0;
+  *ds = d;
+  return 1;
+}
+
+int64_t orc_integrate_lidar_depth(OrcMap* m, const float* range, int rows, int cols, const float* T_L_C16, const float* lidar5) {
+  Rt T_L_C, T_C_L; rt_from_T(T_L_C16, &T_L_C, &T_C_L);
+  const OrcParams* p = &m->p;
+  LidarTab tab = lidar_tab_make(lidar5);
+  const float vs = p->voxel_size, bs = vs * 8.0f;
+  const float trunc = p->truncation_distance_vox * vs;
+  const float max_dist = p->lidar_max_integration_distance_m;
+  const int f = p->raycast_subsampling_factor < 1 ? 1 : p->raycast_subsampling_factor;
+  m->frame++;
+  m->n_view = 0;
+  for (int ri = 0; ri * f < rows + f - 1; ri++) {
+    int prow = ri * f; if (prow >= rows) prow = rows - 1;
+    for (int ci = 0; ci * f < cols + f - 1; ci++) {
+      int pcol = ci * f; if (pcol >= cols) pcol = cols - 1;
+      const float d = range[(int64_t)prow * cols + pcol];
+      if (!(d > 0.0f)) continue;
+      float de = d + trunc;
+      if (max_dist > 0.0f && de > max_dist) de = max_dist;
+      float dir[3]; lidar_dir(&tab, prow, pcol, dir);
+      float pl[3];
+      rt_apply(&T_L_C, de * dir[0], de * dir[1], de * dir[2], pl);
+      raycast_blocks(m, T_L_C.t, pl, bs);
+    }
+  }
+  const int64_t n = m->n_view;
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int64_t i = 0; i < n; i++) {
+    Block* b = map_find(m, m->view[i]);
+    for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) for (int z = 0; z < 8; z++) {
+      float pc[3]; rt_apply(&T_C_L, voxel_center(b->idx.x, x, bs, vs), voxel_center(b->idx.y, y, bs, vs), voxel_center(b->idx.z, z, bs, vs), pc);
+      float ds, vd;
+      if (!lidar_sample(p, &tab, range, rows, cols, pc, max_dist, &ds, &vd)) continue;
+      const float sdf = ds - vd;
+      if (sdf < -trunc) continue;
+      TsdfVoxel* vx = &b->tsdf[z + 8 * y + 64 * x];
+      const float wm = weight_fn(p->weighting_mode, ds, vd, trunc);
+      const float wsum = wm + vx->weight;
+      if (!(wsum > 0.0f)) continue;
+      float fused = (sdf * wm + vx->distance * vx->weight) / wsum;
+      if (fused > 0.0f) fused = fminf(trunc, fused); else fused = fmaxf(-trunc, fused);
+      vx->distance = fused;
+      vx->weight = fminf(wsum, p->max_weight);
+    }
+  }
+  free(tab.el); free(tab.az);
+  return n;
+}
+
+/* depthImageFromPointcloudKernel restated (conversions/pointcloud_conversions.cu:118-150); points in order, last writer wins */
+void orc_depth_image_from_pointcloud(const float* pts, int64_t n, const float* lidar5, float* img) {
+  const nvbx_lidar_model l = nvbx_lidar_make((int32_t)lidar5[0], (int32_t)lidar5[1], lidar5[2], lidar5[3], lidar5[4]);
+  memset(img, 0, sizeof(float) * (size_t)l.rows * (size_t)l.cols);
+  for (int64_t i = 0; i < n; i++) {
+    const float* q = pts + 3 * i;
+    if (isnan(q[0]) || isnan(q[1]) || isnan(q[2])) continue;
+    const float r = nvbx_lidar_range(q);
+    float u, v;
+    if (!nvbx_lidar_project(&l, q, r, &u, &v)) continue;
+    const int c = (int)floorf(u), rr = (int)floorf(v);
+    if (c < 0 || rr < 0 || c >= l.cols || rr >= l.rows) continue;
+    img[(int64_t)rr * l.cols + c] = r;
+  }
+}
+/* exported for the model tests: project one point; returns 1 and (u, v) if inside the model */
+int orc_lidar_project(const float* lidar5, const float* p, float* u, float* v) {
+  const nvbx_lidar_model l = nvbx_lidar_make((int32_t)lidar5[0], (int32_t)lidar5[1], lidar5[2], lidar5[3], lidar5[4]);
+  return nvbx_lidar_project(&l, p, nvbx_lidar_range(p), u, v);
+}
+float orc_atan2f(float y, float x) { return nvbx_atan2f(y, x); }
 
 /* ------------------------------------------------------------------ accessors */
 static int idx_cmp(const void* a, const void* b) {

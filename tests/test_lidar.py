@@ -1,0 +1,143 @@
+"""Spinning-LiDAR projective integration (BASELINE.json configs[4]): sensor-model known answers on CPU, HIP vs oracle on GPU."""
+import math
+
+import numpy as np
+import pytest
+
+import helpers as H
+from isaac_ros_nvblox_amd import synthetic as S
+
+SMALL_LIDAR = (256, 16, 0.1, -math.radians(15.0), math.radians(15.0))
+
+
+def test_lidar_model_known_answers(oracle_mod):
+    """Beam (k, j) projects to the pixel centre (j + 0.5, k + 0.5) -- what checkLidarPointcloud asserts of a consistent
+    model (conversions/pointcloud_conversions.cu:73-97) -- with elevation = asin(z / r), azimuth = atan2(y, x)
+    (scripts/calculate_lidar_params.py:50-58)."""
+    for lidar in (S.SPINNING_LIDAR, SMALL_LIDAR, (2048, 64, 0.01, -0.285, 0.298)):      # last: nvblox_os1.yaml:7-12
+        dirs = S.lidar_beam_dirs(lidar)
+        rows, cols = dirs.shape[:2]
+        for k, j in [(0, 0), (rows - 1, cols - 1), (rows // 2, cols // 2), (3, 7), (rows - 2, 1)]:
+            uv = oracle_mod.lidar_project(lidar, 17.0 * dirs[k, j])
+            assert uv is not None
+            assert abs(uv[0] - (j + 0.5)) < 2e-3 and abs(uv[1] - (k + 0.5)) < 2e-3
+        # outside the vertical field of view / below the minimum range
+        up = np.array([0.1, 0.0, 1.0]); assert oracle_mod.lidar_project(lidar, up) is None
+        assert oracle_mod.lidar_project(lidar, 0.5 * lidar[2] * dirs[1, 1]) is None
+
+
+def test_shared_atan2_accuracy(oracle_mod):
+    L = oracle_mod.lib()
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for y, x in rng.normal(size=(5000, 2)).astype(np.float32):
+        worst = max(worst, abs(L.orc_atan2f(float(y), float(x)) - math.atan2(float(y), float(x))))
+    for y, x in [(0.0, 1.0), (0.0, -1.0), (1.0, 0.0), (-1.0, 0.0), (1.0, 1.0), (-1.0, -1.0), (0.0, 0.0)]:
+        worst = max(worst, abs(L.orc_atan2f(y, x) - math.atan2(y, x)))
+    assert worst < 5e-7
+
+
+def test_depth_image_from_pointcloud_oracle(oracle_mod):
+    """Point cloud -> range image (depthImageFromPointcloudKernel, pointcloud_conversions.cu:118-150): one point per beam
+    reproduces the range image; NaN points are skipped."""
+    sc = S.LidarScene(n_boxes=10, extent=40.0)
+    T = S.lidar_pose(0)
+    img = S.render_lidar(sc, T, SMALL_LIDAR, max_range=60.0)
+    dirs = S.lidar_beam_dirs(SMALL_LIDAR)
+    pts = (dirs * img[..., None]).reshape(-1, 3).astype(np.float32)
+    pts = pts[img.reshape(-1) > 0]
+    pts = np.concatenate([pts, np.full((3, 3), np.nan, np.float32)])
+    back = oracle_mod.depth_image_from_pointcloud(pts, SMALL_LIDAR)
+    assert back.shape == img.shape
+    assert np.abs(back - img).max() < 1e-4 and ((back > 0) == (img > 0)).all()
+
+
+def test_lidar_tsdf_against_analytic_ground(oracle_mod):
+    """Independent check of the oracle's LiDAR TSDF: near the ground plane z = 0, at steep incidence (where the nearest-beam
+    acceptance radius of half a voxel bounds the range error by ~0.09 m), the projective distance must agree with the
+    true distance to the plane along the voxel's own beam."""
+    po = oracle_mod.default_params(voxel_size=0.1, lidar_max_integration_distance_m=30.0, raycast_subsampling_factor=2)
+    o = oracle_mod.OracleMap(po)
+    sc = S.LidarScene(n_boxes=0)
+    T = S.lidar_pose(0, height=2.0)
+    wide = (256, 32, 0.1, -math.radians(60.0), math.radians(10.0))
+    img = S.render_lidar(sc, T, wide, max_range=30.0)
+    n = o.integrate_lidar_depth(img, T, wide)
+    assert n > 50
+    checked = 0
+    for idx in o.block_indices(oracle_mod.L_TSDF):
+        if idx[2] != 0:
+            continue
+        b = o.get_block(oracle_mod.L_TSDF, idx).reshape(8, 8, 8)      # [x][y][z]
+        w = b["weight"]; d = b["distance"]
+        for x, y, z in zip(*np.nonzero(w > 0)):
+            pz = (idx[2] * 8 + z + 0.5) * 0.1
+            px = (idx[0] * 8 + x + 0.5) * 0.1 - float(T[0, 3]); py = (idx[1] * 8 + y + 0.5) * 0.1 - float(T[1, 3])
+            dz = pz - float(T[2, 3])
+            r = math.sqrt(px * px + py * py + dz * dz)
+            if abs(d[x, y, z]) < 0.35 and -dz / r > 0.5:
+                true_along_beam = pz * r / (-dz)          # distance from the voxel to the plane along its own beam
+                assert abs(d[x, y, z] - true_along_beam) < 0.12, (idx, x, y, z, d[x, y, z], true_along_beam)
+                checked += 1
+    assert checked > 100
+
+
+@pytest.mark.gpu
+def test_lidar_parity_small(oracle_mod, hip_lib):
+    from isaac_ros_nvblox_amd import mapper as M
+    kw = dict(voxel_size=0.1, lidar_max_integration_distance_m=40.0, raycast_subsampling_factor=2)
+    pg = M.default_params(**kw); po = H.copy_params(pg, oracle_mod.OrcParams)
+    g = M.Mapper(pg, block_capacity=1 << 16); o = oracle_mod.OracleMap(po)
+    sc = S.LidarScene(n_boxes=12, extent=40.0)
+    for i in range(3):
+        T = S.lidar_pose(i * 7)
+        img = S.render_lidar(sc, T, SMALL_LIDAR, max_range=60.0)
+        g.integrate_lidar_depth(img, T, SMALL_LIDAR); o.integrate_lidar_depth(img, T, SMALL_LIDAR)
+        assert H.idx_set(g.last_view()) == H.idx_set(o.last_view())
+    ig = g.block_indices(M.LAYER_TSDF); io = o.block_indices(oracle_mod.L_TSDF)
+    assert np.array_equal(ig, io) and len(io) > 1000
+    bg, found = g.get_blocks(M.LAYER_TSDF, ig)
+    assert found.all()
+    for k, idx in enumerate(io):
+        bo = o.get_block(oracle_mod.L_TSDF, idx)
+        assert np.abs(bg[k]["distance"] - bo["distance"]).max() <= 1e-4, idx
+        assert np.abs(bg[k]["weight"] - bo["weight"]).max() <= 1e-4, idx
+    assert g.counters()["capacity_overflow"] == 0
+    # ESDF + mesh run on a LiDAR-built map like on a camera-built one
+    g.update_esdf(); o.update_esdf()
+    sg, ag = g.esdf_slice_image(); so, ao = o.esdf_slice_image()
+    assert sg.shape == so.shape and np.abs(sg - so).max() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_lidar_full_config_properties(hip_lib):
+    """BASELINE.json configs[4] shape: 1024 x 64 beams, 0.10 m voxels, 200 m range (too slow for the scalar oracle at full
+    size, so size-independent properties): integrating the same scan twice leaves the block set unchanged and doubles
+    the weights up to the clamp; the block set of a scan is a superset of the blocks containing its surface points."""
+    from isaac_ros_nvblox_amd import mapper as M
+    pg = M.default_params(voxel_size=0.1, lidar_max_integration_distance_m=200.0, raycast_subsampling_factor=2, weighting_mode=0)
+    g = M.Mapper(pg, block_capacity=1 << 19)
+    sc = S.LidarScene()
+    T = S.lidar_pose(0)
+    img = S.render_lidar(sc, T, S.SPINNING_LIDAR, max_range=200.0)
+    g.integrate_lidar_depth(img, T, S.SPINNING_LIDAR)
+    c1 = g.counters(); idx1 = g.block_indices(M.LAYER_TSDF)
+    assert c1["capacity_overflow"] == 0 and c1["tsdf_blocks_in_view"] == len(idx1) and len(idx1) > 20000
+    g.integrate_lidar_depth(img, T, S.SPINNING_LIDAR)
+    idx2 = g.block_indices(M.LAYER_TSDF)
+    assert np.array_equal(idx1, idx2)                                  # idempotent block set
+    sample = idx1[:: max(1, len(idx1) // 300)]
+    b, found = g.get_blocks(M.LAYER_TSDF, sample)
+    assert found.all()
+    w = b["weight"]
+    assert set(np.unique(w).tolist()) <= {0.0, 2.0}                     # constant weight 1, two identical scans
+    # surface points of the sub-sampled rays lie in allocated blocks
+    dirs = S.lidar_beam_dirs(S.SPINNING_LIDAR)
+    Td = np.asarray(T, np.float64)
+    pts = (dirs * img[..., None])[::2, ::2].reshape(-1, 3)
+    pts = pts[(img[::2, ::2].reshape(-1) > 0)]
+    pw = pts @ Td[:3, :3].T + Td[:3, 3]
+    bi = np.floor(pw / 0.8).astype(np.int64)
+    have = H.idx_set(idx1)
+    miss = [tuple(q) for q in bi[::17].tolist() if tuple(q) not in have]
+    assert len(miss) == 0, miss[:5]
