@@ -46,6 +46,56 @@ def algorithmic_bytes(kernel, c, rows, cols):
     return 0
 
 
+def main_lidar(args):
+    """configs[4]: one step = integrateDepth of one 1024x64 LiDAR scan (range image resident in HBM), 0.10 m voxels, 200 m."""
+    import torch
+    from isaac_ros_nvblox_amd import mapper as M, synthetic as S
+    assert args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1, "the LiDAR workload line is single-GPU"
+    dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+    lidar = S.SPINNING_LIDAR
+    sc = S.LidarScene()
+    nu = max(2, min(args.unique_frames, 16))
+    scans = []
+    for i in range(nu):
+        T = S.lidar_pose(i, 400)
+        scans.append((torch.from_numpy(S.render_lidar(sc, T, lidar, max_range=200.0)).to(dev), T))
+    stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream)
+    p = M.default_params(voxel_size=0.1, lidar_max_integration_distance_m=200.0, raycast_subsampling_factor=2)
+    g = M.Mapper(p, device=0, block_capacity=1 << 19, stream=stream.cuda_stream)
+    largs = [g.prepare_lidar(r, T, lidar) for r, T in scans]
+    for i in range(args.warmup):
+        g.integrate_prepared(largs[i % nu])
+    torch.cuda.synchronize(dev); t0 = time.perf_counter()
+    for i in range(args.steps):
+        g.integrate_prepared(largs[(args.warmup + i) % nu])
+    torch.cuda.synchronize(dev); dt = time.perf_counter() - t0
+    ms = dt / args.steps * 1e3
+    g.set_profiling(True)
+    nv = []
+    for i in range(min(args.steps, 40)):
+        g.integrate_prepared(largs[i % nu]); nv.append(g.counters()["tsdf_blocks_in_view"])
+    prof = g.profile(); g.set_profiling(False)
+    c = g.counters(); Nv = float(np.mean(nv))
+    kern = {}
+    for k_, v_ in prof.items():
+        us = v_["total_ms"] / v_["count"] * 1e3
+        name = "k_integrate_tsdf" if "integrate" in k_ else "k_mark_view"
+        ab = (64 * 1024 * 4 + Nv * (16 + 4096 * 2)) if name == "k_integrate_tsdf" else (32 * 512 * 4 + Nv * 16 * 2)
+        kern[name] = {"avg_us": round(us, 2), "algorithmic_bytes": int(ab), "achieved_GBps": round(ab / (us * 1e-6) / 1e9, 1)}
+    dom = max(kern, key=lambda k_: kern[k_]["avg_us"])
+    out = {"metric": "scans/s, LiDAR projective TSDF integrate, synthetic 1024x64 @0.10m, 200 m", "value": round(args.steps / dt, 2),
+           "unit": "scans/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[4]: synthetic 1024x64 spinning LiDAR (SURVEY 8d), 0.10 m voxels, 200 m range, ray subsampling 2"},
+           "per_scan_counts": {"tsdf_blocks_in_view": round(Nv, 1), "blocks_allocated": c["blocks_allocated"], "capacity_overflow": c["capacity_overflow"]},
+           "kernels": kern,
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(kern[dom]["achieved_GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes"], "avg_launch_us": kern[dom]["avg_us"]},
+           "cpu_baseline": None}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,7 +104,12 @@ def main():
     ap.add_argument("--unique-frames", type=int, default=50, help="distinct rendered frames cycled through (HBM-resident)")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="camera", choices=["camera", "lidar"],
+                    help="camera = BASELINE.json configs[1] (the metric's configuration, default); lidar = configs[4] "
+                         "(1024x64 spinning LiDAR, 0.10 m voxels, 200 m), the configuration where HBM bytes dominate")
     args = ap.parse_args()
+    if args.workload == "lidar":
+        return main_lidar(args)
 
     import torch
     import torch.distributed as dist

@@ -54,6 +54,7 @@ typedef struct {
   int32_t cols, rows;             /* azimuth divisions, elevation divisions */
   float min_valid_range_m;
   float max_el, rpp_el, rpp_az;   /* derived: highest beam elevation, radians per pixel */
+  float ppr_el, ppr_az;           /* derived: pixels per radian (1 / rpp, rounded once) */
 } nvbx_lidar_model;
 
 NVBX_HD nvbx_lidar_model nvbx_lidar_make(int32_t cols, int32_t rows, float min_range, float min_el, float max_el) {
@@ -61,6 +62,7 @@ NVBX_HD nvbx_lidar_model nvbx_lidar_make(int32_t cols, int32_t rows, float min_r
   l.cols = cols; l.rows = rows; l.min_valid_range_m = min_range; l.max_el = max_el;
   l.rpp_el = (max_el - min_el) / (float)(rows - 1);
   l.rpp_az = (2.0f * NVBX_PI_F) / (float)cols;
+  l.ppr_el = 1.0f / l.rpp_el; l.ppr_az = 1.0f / l.rpp_az;
   return l;
 }
 NVBX_HD float nvbx_lidar_range(const float* p) { return sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]); }
@@ -71,8 +73,8 @@ NVBX_HD int nvbx_lidar_project(const nvbx_lidar_model* l, const float* p, float 
   const float rho = sqrtf(p[0] * p[0] + p[1] * p[1]);
   const float el = nvbx_atan2f(p[2], rho);
   const float az = nvbx_atan2f(p[1], p[0]);
-  float uu = (az + NVBX_PI_F) / l->rpp_az + 0.5f;
-  const float vv = (l->max_el - el) / l->rpp_el + 0.5f;
+  float uu = (az + NVBX_PI_F) * l->ppr_az + 0.5f;
+  const float vv = (l->max_el - el) * l->ppr_el + 0.5f;
   if (uu >= (float)l->cols) uu = uu - (float)l->cols;           /* azimuth wrap-around */
   if (vv < 0.0f || vv >= (float)l->rows || uu < 0.0f) return 0; /* outside the vertical field of view */
   *u = uu; *v = vv;

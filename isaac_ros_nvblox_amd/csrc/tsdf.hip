@@ -28,6 +28,7 @@ using namespace nvbx;
 // Camera(fu, fv, cu, cv, w, h): conversions/image_conversions.cpp:27-32.  Everything it needs is in Frame.
 struct CameraSensor {
   static constexpr bool kLongRays = false;
+  static constexpr int kTileRows = 8, kTileCols = 8;     // rays per wavefront: one 8x8 tile of the ray grid
   // end point (camera frame) of the ray through the centre of pixel (prow, pcol) at depth `de` along the optical axis
   __device__ void ray_end(const Frame& f, int prow, int pcol, float de, float* pc) const {
     const float rx = (((float)pcol + 0.5f) - f.cu) / f.fu;
@@ -48,6 +49,9 @@ struct CameraSensor {
 // Lidar: nvbx_lidar_math.h.  el_tab[k] = {sin, cos} of beam row k's elevation, az_tab[j] = {sin, cos} of column j's azimuth.
 struct LidarSensor {
   static constexpr bool kLongRays = true;
+  // long rays: the walk is a serial chain per ray and the flushes dominate, so fewer rays per wavefront = more
+  // wavefronts in flight (16384 rays -> 1024 waves); all 64 lanes still work in the flushes
+  static constexpr int kTileRows = 4, kTileCols = 4;
   nvbx_lidar_model l;
   const float2* el_tab; const float2* az_tab;
   float max_diff_m, max_ray_dist_m;
@@ -64,10 +68,10 @@ struct LidarSensor {
   template <typename Img>
   __device__ bool sample(const Frame& f, const Img& img, const float* pc, float* ds, float* vd) const {
     const float r = nvbx_lidar_range(pc);
+    *vd = r;
+    if (f.max_dist > 0.0f && r > f.max_dist) return false;      // (before the projection: it costs two atan2)
     float u, v;
     if (!nvbx_lidar_project(&l, pc, r, &u, &v)) return false;
-    *vd = r;
-    if (f.max_dist > 0.0f && r > f.max_dist) return false;
     const float uc = u - 0.5f, vc = v - 0.5f;
     const float fx = floorf(uc), fy = floorf(vc);
     const int x0 = (int)fx, y0 = (int)fy;
@@ -99,7 +103,9 @@ struct LidarSensor {
   }
 };
 
-constexpr int LSET = 512;   // LDS dedup set entries per wave-tile (8 B each)
+constexpr int LSET = 1024;          // LDS dedup set entries per wave-tile (8 B each)
+constexpr int LSET_FLUSH = 256;     // early-flush threshold (long rays): keeps the set <= ~30 % full, probes short
+constexpr int FLUSH_ROUNDS = 6;     // keys per lane handled by one phase-wise flush pass (6 x 64 >= LSET_FLUSH + 64)
 
 __device__ inline void unpack_key(u64 key, int32_t* x, int32_t* y, int32_t* z) {
   *x = (int32_t)(key & 0x1FFFFFull) - (1 << 20);
@@ -150,7 +156,7 @@ __device__ inline void view_append(int32_t* cnt, int4* view_list, int32_t list_c
 
 // insert `key` into the tile's LDS set; false = probe window exhausted (caller sends the key to HBM itself)
 __device__ inline bool lset_insert(u64* lset, const int32_t* cur, u64 key, bool* added) {
-  const uint32_t lh = (index_hash(cur[0], cur[1], cur[2]) * 2654435761u) >> 23;   // 9 bits
+  const uint32_t lh = (index_hash(cur[0], cur[1], cur[2]) * 2654435761u) >> 22;   // 10 bits
   *added = false;
 #pragma unroll 1
   for (int p = 0; p < 16; p++) {
@@ -169,10 +175,16 @@ __device__ inline void dda_step(int32_t* cur, const int32_t* step, float* tmax, 
   else if (a == 1) { cur[1] += step[1]; tmax[1] = tmax[1] + tdelta[1]; }
   else { cur[2] += step[2]; tmax[2] = tmax[2] + tdelta[2]; }
 }
-// Flush: compact the set (ballot + popcount), then ONE key per lane goes to HBM -- the hash probes, stamp exchanges and
-// slot reads of all the tile's blocks are in flight together instead of one per ray step.  Whole wave must call.
+// Flush: compact the set (ballot + popcount), then every key goes to HBM with the dependent round trips taken
+// PHASE-WISE over up to 6 keys per lane at once: (A) the first TWO probe positions of every key are loaded together
+// (covers ~98 % of lookups at our load factor), (B) resolved -- a key further down its probe chain, a new block, or a
+// slot not published yet takes the general mark_block path, (C) the frame-stamp exchanges of all keys not yet stamped
+// are issued together, (D) ONE wave-aggregated returning atomicAdd reserves view-list space for all first-stampers,
+// (E) records are stored.  A camera tile flushes ~60 keys in one such pass; a long LiDAR bundle 256+ keys per pass
+// instead of 64 per dependent round.  Whole wave must call.
 __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* lkeys, int32_t* cnt, int4* view_list, int32_t list_cap,
                                  int lane, bool clear) {
+  constexpr int R = FLUSH_ROUNDS;
   __syncthreads();
   int32_t nk = 0;
 #pragma unroll
@@ -184,10 +196,63 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
     if (clear) lset[i * 64 + lane] = KEY_EMPTY;
   }
   __syncthreads();
-  for (int32_t i = 0; i < nk; i += 64) {
-    int4 rec = make_int4(0, 0, 0, 0);
-    const bool first = (i + lane < nk) && mark_block(m, lkeys[i + lane], f.frame_id, &rec);
-    view_append(cnt, view_list, list_cap, first, rec, lane);
+  for (int32_t kb = 0; kb < nk; kb += R * 64) {              // one pass per 384 keys (wave-uniform)
+    const int rounds = min(R, (nk - kb + 63) >> 6);
+    u64 key[R]; uint32_t h[R]; uint4 e0[R], e1[R]; bool have[R];
+    // (A) first two probe positions, all in flight
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      have[r] = r < rounds && (kb + r * 64 + lane) < nk;
+      key[r] = have[r] ? lkeys[kb + r * 64 + lane] : KEY_EMPTY;
+      int32_t x, y, z; unpack_key(key[r], &x, &y, &z);
+      h[r] = have[r] ? table_pos(m, x, y, z) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) if (r < rounds) {
+      e0[r] = *reinterpret_cast<const uint4*>(&m.table[h[r]]);
+      e1[r] = *reinterpret_cast<const uint4*>(&m.table[(h[r] + 1) & m.mask]);
+    }
+    // (B) resolve + (C) stamp exchanges in flight
+    bool fast[R], first[R]; uint32_t old[R], slot[R]; int4 rec[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      fast[r] = false; first[r] = false; old[r] = f.frame_id; slot[r] = SLOT_INVALID; rec[r] = make_int4(0, 0, 0, 0);
+      if (r < rounds && have[r]) {
+        const u64 k0 = ((u64)e0[r].y << 32) | (u64)e0[r].x, k1 = ((u64)e1[r].y << 32) | (u64)e1[r].x;
+        uint32_t hh = h[r], st = 0;
+        if (k0 == key[r]) { slot[r] = e0[r].z; st = e0[r].w; fast[r] = true; }
+        else if (k0 != KEY_EMPTY && k1 == key[r]) { slot[r] = e1[r].z; st = e1[r].w; hh = (h[r] + 1) & m.mask; fast[r] = true; }
+        if (slot[r] == SLOT_INVALID) fast[r] = false;              // being inserted right now: general path waits for the slot
+        if (fast[r] && st != f.frame_id) old[r] = atomicExch(&m.table[hh].stamp, f.frame_id);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      if (r < rounds && have[r]) {
+        if (fast[r]) {
+          first[r] = old[r] != f.frame_id;
+          if (first[r]) { int32_t x, y, z; unpack_key(key[r], &x, &y, &z); rec[r] = make_int4((int32_t)slot[r], x, y, z); }
+        } else {
+          first[r] = mark_block(m, key[r], f.frame_id, &rec[r]);     // longer probe chain, new block, or slot not published yet
+        }
+      }
+    }
+    // (D) one reservation for the whole pass
+    int32_t total = 0; int32_t pre[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const u64 mask = (r < rounds) ? __ballot(first[r]) : 0ull;
+      pre[r] = total + (int32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      total += (int32_t)__popcll(mask);
+    }
+    if (total) {
+      int32_t base = 0;
+      if (lane == 0) base = atomicAdd(cnt, total);
+      base = __shfl(base, 0);
+      // (E)
+#pragma unroll
+      for (int r = 0; r < R; r++) if (r < rounds && first[r]) { const int32_t pos = base + pre[r]; if (pos < list_cap) view_list[pos] = rec[r]; }
+    }
   }
   __syncthreads();
 }
@@ -201,10 +266,11 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
   if (blockIdx.x == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
   __syncthreads();
 
-  const int tiles_x = (f.n_ray_cols + 7) >> 3;
+  constexpr int TR = Sensor::kTileRows, TC = Sensor::kTileCols;
+  const int tiles_x = (f.n_ray_cols + TC - 1) / TC;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int ri = ty * 8 + (lane >> 3), ci = tx * 8 + (lane & 7);
-  bool active = ri < f.n_ray_rows && ci < f.n_ray_cols;
+  const int ri = ty * TR + lane / TC, ci = tx * TC + lane % TC;
+  bool active = lane < TR * TC && ri < f.n_ray_rows && ci < f.n_ray_cols;
 
   int32_t cur[3] = {0, 0, 0}, step[3] = {0, 0, 0}, nsteps = -1;
   float tmax[3] = {0, 0, 0}, tdelta[3] = {0, 0, 0};
@@ -270,7 +336,7 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
       view_append(cnt, view_list, list_cap, first, rec, lane);
     }
     const bool last = __ballot(k + 1 <= nsteps) == 0ull;
-    if (last || nset > LSET / 2) { flush_set(m, f, lset, lkeys, cnt, view_list, list_cap, lane, !last); nset = 0; }
+    if (last || nset > LSET_FLUSH) { flush_set(m, f, lset, lkeys, cnt, view_list, list_cap, lane, !last); nset = 0; }
   }
 }
 
@@ -287,24 +353,25 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img dep
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
   for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
     if (i != (int32_t)blockIdx.x) rec = view_list[i];
-    const uint32_t slot = (uint32_t)rec.x;               // pool slot (stable across hash rebuilds)
+    const int4 rec_c = rec;
+    const uint32_t slot = (uint32_t)rec_c.x;               // pool slot (stable across hash rebuilds)
     if (!slot_ok(slot)) continue;
     float2* vp = &m.tsdf[(size_t)slot * 512 + tid];
-    const float2 cur = *vp;
+    const float2 cur_c = *vp;
     uint32_t old = 0;
     if (tid == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH);
     float pc[3];
-    apply_rt(f.R_CL, f.t_CL, voxel_center(rec.y, vx, f.block_size, f.voxel_size), voxel_center(rec.z, vy, f.block_size, f.voxel_size),
-             voxel_center(rec.w, vz, f.block_size, f.voxel_size), pc);
+    apply_rt(f.R_CL, f.t_CL, voxel_center(rec_c.y, vx, f.block_size, f.voxel_size), voxel_center(rec_c.z, vy, f.block_size, f.voxel_size),
+             voxel_center(rec_c.w, vz, f.block_size, f.voxel_size), pc);
     float ds = 0.0f, vd = 0.0f;
     const bool upd = sensor.sample(f, depth, pc, &ds, &vd);
     if (upd) {
       const float sdf = ds - vd;
       if (!(sdf < -f.trunc)) {
         const float wm = weight_fn(f.weighting_mode, ds, vd, f.trunc);
-        const float wsum = wm + cur.y;
+        const float wsum = wm + cur_c.y;
         if (wsum > 0.0f) {
-          float fused = (sdf * wm + cur.x * cur.y) / wsum;
+          float fused = (sdf * wm + cur_c.x * cur_c.y) / wsum;
           if (fused > 0.0f) fused = fminf(f.trunc, fused); else fused = fmaxf(-f.trunc, fused);
           *vp = make_float2(fused, fminf(wsum, f.max_weight));
         }
@@ -323,7 +390,7 @@ static int integrate_depth_impl(nvbx_mapper* m, Img img, const Sensor& sensor, c
   const int s = f.subsample;
   f.n_ray_rows = (f.rows + s - 1 + s - 1) / s;   // indices i with i*s < rows + s - 1
   f.n_ray_cols = (f.cols + s - 1 + s - 1) / s;
-  const int tiles = ((f.n_ray_rows + 7) / 8) * ((f.n_ray_cols + 7) / 8);
+  const int tiles = ((f.n_ray_rows + Sensor::kTileRows - 1) / Sensor::kTileRows) * ((f.n_ray_cols + Sensor::kTileCols - 1) / Sensor::kTileCols);
   NVBX_LAUNCH(m, (k_mark_view<Img, Sensor>), dim3(tiles), dim3(64), m->d, f, img, sensor, (int4*)m->view_list, (int32_t)m->capacity);
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);
   NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor>), dim3(grid), dim3(512), m->d, f, img, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
