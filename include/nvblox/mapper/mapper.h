@@ -13,6 +13,8 @@
 #include "nvblox/mesh/mesh.h"
 #include "nvblox/sensors/camera.h"
 #include "nvblox/sensors/image.h"
+#include "nvblox/sensors/lidar.h"
+#include "nvblox/sensors/pointcloud.h"
 #include "nvblox/utils/timing.h"
 #include "nvblox_hip.h"
 
@@ -64,6 +66,21 @@ class Mapper {
     float T[16]; T_L_C.toRowMajor(T);
     checkNvbx(nvbx_integrate_depth_u16mm(m_, depth_mm.dataConstPtr(), depth_mm.rows(), depth_mm.cols(), T, &camera.c_abi()), "nvbx_integrate_depth_u16mm");
   }
+  // range image of a spinning LiDAR (rows = elevation divisions, cols = azimuth divisions, metres along the beam)
+  void integrateLidarDepth(const DepthImage& range_frame, const Transform& T_L_C, const Lidar& lidar) {
+    timing::Timer t("tsdf/integrate");
+    float T[16]; T_L_C.toRowMajor(T);
+    checkNvbx(nvbx_integrate_lidar_depth(m_, range_frame.dataConstPtr(), range_frame.rows(), range_frame.cols(), T, &lidar.c_abi()), "nvbx_integrate_lidar_depth");
+  }
+  // point cloud (sensor frame) -> range image -> integration; the image stays available like the reference's
+  // getLastDepthFrameFromPointcloud() (nvblox_node.cpp:1397)
+  void integrateLidarPointcloud(const Pointcloud& pointcloud, const Transform& T_L_C, const Lidar& lidar) {
+    last_depth_frame_from_pointcloud_.resize(lidar.rows(), lidar.cols());
+    checkNvbx(nvbx_depth_image_from_pointcloud(m_, reinterpret_cast<const float*>(pointcloud.dataConstPtr()), pointcloud.size(), &lidar.c_abi(),
+                                               last_depth_frame_from_pointcloud_.dataPtr()), "nvbx_depth_image_from_pointcloud");
+    integrateLidarDepth(last_depth_frame_from_pointcloud_, T_L_C, lidar);
+  }
+  const DepthImage& getLastDepthFrameFromPointcloud() const { return last_depth_frame_from_pointcloud_; }
   void integrateColor(const ColorImage& color_frame, const Transform& T_L_C, const Camera& camera) {
     timing::Timer t("color/integrate");
     float T[16]; T_L_C.toRowMajor(T);
@@ -164,6 +181,7 @@ class Mapper {
   nvbx_mapper* m_ = nullptr;
   TsdfLayer tsdf_layer_; ColorLayer color_layer_; EsdfLayer esdf_layer_;
   std::vector<Index3D> cleared_blocks_;
+  DepthImage last_depth_frame_from_pointcloud_{MemoryType::kDevice};
   std::shared_ptr<SerializedColorMeshLayer> serialized_mesh_ = std::make_shared<SerializedColorMeshLayer>();
 };
 

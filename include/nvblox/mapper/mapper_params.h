@@ -88,6 +88,10 @@ struct MapperParams {
     p.tsdf_decay_factor = tsdf_decay_integrator_params.tsdf_decay_factor;
     p.tsdf_decayed_weight_threshold = tsdf_decay_integrator_params.tsdf_decayed_weight_threshold;
     p.esdf_site_rule = 0; p.depth_interp_nearest = 0;
+    p.lidar_max_integration_distance_m = projective_integrator_params.lidar_projective_integrator_max_integration_distance_m;
+    p.lidar_linear_interpolation_max_allowable_difference_vox = 2.0f;
+    p.lidar_nearest_interpolation_max_allowable_dist_to_ray_vox = 0.5f;
+    p.invalid_depth_decay_factor = projective_integrator_params.projective_tsdf_integrator_invalid_depth_decay_factor;
     return p;
   }
 };

@@ -33,6 +33,16 @@ class MultiMapper {
     background_mapper_->integrateDepth(depth, T_L_C, camera);
   }
   void integrateDepth(const DepthImage&, const MonoImage&, const Transform&, const Transform&, const Camera&, const Camera&) { unsupported("masked depth integration (human mapping)"); }
+  // nvblox_node.cpp:1382-1384.  Per-point motion compensation (use_lidar_motion_compensation, node_params.hpp:152) needs
+  // per-point timestamps that this Pointcloud does not carry: run the node with use_lidar_motion_compensation:=false.
+  void integrateDepth(const Pointcloud& pointcloud, const Transform& T_L_C, const Lidar& lidar, bool use_lidar_motion_compensation = false,
+                      std::optional<Transform> T_L_S_scan_end = std::nullopt, std::optional<Time> scan_duration_ms = std::nullopt,
+                      std::optional<Time> update_time_ms = std::nullopt) {
+    (void)T_L_S_scan_end; (void)scan_duration_ms; (void)update_time_ms;
+    if (use_lidar_motion_compensation) unsupported("LiDAR motion compensation (set use_lidar_motion_compensation:=false)");
+    background_mapper_->integrateLidarPointcloud(pointcloud, T_L_C, lidar);
+  }
+  const DepthImage& getLastDepthFrameFromPointcloud() const { return background_mapper_->getLastDepthFrameFromPointcloud(); }
   void integrateColor(const ColorImage& color, const Transform& T_L_C, const Camera& camera) { background_mapper_->integrateColor(color, T_L_C, camera); }
   void integrateColor(const ColorImage&, const MonoImage&, const Transform&, const Camera&) { unsupported("masked colour integration (human mapping)"); }
   void updateEsdf() { background_mapper_->updateEsdf(); }

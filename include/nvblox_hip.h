@@ -87,6 +87,8 @@ typedef struct {
   float lidar_max_integration_distance_m; /* lidar_projective_integrator_max_integration_distance_m (mapper_initialization.cpp:271-276) */
   float lidar_linear_interpolation_max_allowable_difference_vox;    /* [U] 2.0: bilinear taps must agree within this */
   float lidar_nearest_interpolation_max_allowable_dist_to_ray_vox;  /* [U] 0.5: nearest-beam fallback acceptance */
+  float invalid_depth_decay_factor;       /* projective_tsdf_integrator_invalid_depth_decay_factor (mapper_initialization.cpp:294-300;
+                                             -1 = off, nvblox_base.yaml:80; 0.8 in nvblox_dynamics.yaml:11) */
 } nvbx_mapper_params;
 
 /* nvblox::Lidar(num_azimuth_divisions, num_elevation_divisions, min_valid_range_m, vertical_fov_rad) or

@@ -35,6 +35,7 @@ class Params(C.Structure):
         ("lidar_max_integration_distance_m", C.c_float),
         ("lidar_linear_interpolation_max_allowable_difference_vox", C.c_float),
         ("lidar_nearest_interpolation_max_allowable_dist_to_ray_vox", C.c_float),
+        ("invalid_depth_decay_factor", C.c_float),
     ]
 
 

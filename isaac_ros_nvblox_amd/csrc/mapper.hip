@@ -198,6 +198,7 @@ Frame nvbx_mapper::make_frame(const float T[16], const nvbx_camera* cam, int32_t
   f.trunc = p.truncation_distance_vox * p.voxel_size;
   f.max_dist = p.max_integration_distance_m; f.max_weight = p.max_weight;
   f.weighting_mode = p.weighting_mode; f.interp_nearest = p.depth_interp_nearest;
+  f.invalid_decay = p.invalid_depth_decay_factor;
   f.subsample = subsample < 1 ? 1 : subsample;
   f.n_ray_rows = 0; f.n_ray_cols = 0;
   f.frame_id = frame_id;

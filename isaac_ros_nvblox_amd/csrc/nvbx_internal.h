@@ -73,6 +73,7 @@ struct Frame {
   int32_t rows, cols;
   float voxel_size, block_size, trunc, max_dist, max_weight;
   int32_t weighting_mode, interp_nearest;
+  float invalid_decay;      // invalid_depth_decay_factor (< 0 = off)
   int32_t subsample;        // raycast / sphere-tracing subsampling
   int32_t n_ray_rows, n_ray_cols;
   uint32_t frame_id;
@@ -195,27 +196,28 @@ struct DepthF32 { const float* p; __device__ float operator()(int64_t i) const {
 struct DepthU16mm {   // conversions/image_conversions_thrust.cu:39-45 fused into the read
   const uint16_t* p; __device__ float operator()(int64_t i) const { return (float)p[i] * (1.0f / 1000.0f); } };
 
+// returns 1 = value, 0 = no sample (outside the image), -1 = a depth tap is invalid (<= 0)
 template <typename Img>
-__device__ inline bool interp_depth(const Img& img, int rows, int cols, float u, float v, int nearest, float* out) {
+__device__ inline int interp_depth(const Img& img, int rows, int cols, float u, float v, int nearest, float* out) {
   if (nearest) {
     const int c = (int)floorf(u), r = (int)floorf(v);
-    if (c < 0 || r < 0 || c >= cols || r >= rows) return false;
+    if (c < 0 || r < 0 || c >= cols || r >= rows) return 0;
     const float d = img((int64_t)r * cols + c);
-    if (!(d > 0.0f)) return false;
-    *out = d; return true;
+    if (!(d > 0.0f)) return -1;
+    *out = d; return 1;
   }
   const float uc = u - 0.5f, vc = v - 0.5f;
   const float fx = floorf(uc), fy = floorf(vc);
   const int x0 = (int)fx, y0 = (int)fy;
-  if (x0 < 0 || y0 < 0 || x0 + 1 > cols - 1 || y0 + 1 > rows - 1) return false;
+  if (x0 < 0 || y0 < 0 || x0 + 1 > cols - 1 || y0 + 1 > rows - 1) return 0;
   const float ax = uc - fx, ay = vc - fy;
   const float f00 = img((int64_t)y0 * cols + x0), f10 = img((int64_t)y0 * cols + x0 + 1);
   const float f01 = img((int64_t)(y0 + 1) * cols + x0), f11 = img((int64_t)(y0 + 1) * cols + x0 + 1);
-  if (!(f00 > 0.0f) || !(f10 > 0.0f) || !(f01 > 0.0f) || !(f11 > 0.0f)) return false;
+  if (!(f00 > 0.0f) || !(f10 > 0.0f) || !(f01 > 0.0f) || !(f11 > 0.0f)) return -1;
   const float top = (1.0f - ax) * f00 + ax * f10;
   const float bot = (1.0f - ax) * f01 + ax * f11;
   *out = (1.0f - ay) * top + ay * bot;
-  return true;
+  return 1;
 }
 
 __device__ inline float weight_fn(int mode, float d_meas, float d_vox, float trunc) {

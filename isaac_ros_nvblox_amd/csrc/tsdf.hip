@@ -35,13 +35,14 @@ struct CameraSensor {
     const float ry = (((float)prow + 0.5f) - f.cv) / f.fv;
     pc[0] = de * rx; pc[1] = de * ry; pc[2] = de;
   }
-  // measured depth at the voxel centre `pc` and the voxel's own depth; false = voxel not updated
+  // measured depth at the voxel centre `pc` and the voxel's own depth; 1 = update, 0 = voxel not touched,
+  // -1 = the voxel projects onto invalid depth (weight decays if invalid_depth_decay_factor >= 0)
   template <typename Img>
-  __device__ bool sample(const Frame& f, const Img& depth, const float* pc, float* ds, float* vd) const {
+  __device__ int sample(const Frame& f, const Img& depth, const float* pc, float* ds, float* vd) const {
     float u, v;
-    if (!cam_project(f, pc, &u, &v)) return false;
+    if (!cam_project(f, pc, &u, &v)) return 0;
     *vd = pc[2];
-    if (f.max_dist > 0.0f && *vd > f.max_dist) return false;
+    if (f.max_dist > 0.0f && *vd > f.max_dist) return 0;
     return interp_depth(depth, f.rows, f.cols, u, v, f.interp_nearest, ds);
   }
 };
@@ -66,12 +67,12 @@ struct LidarSensor {
   // [U] interpolateLidarImage restated: bilinear if the four beams are valid and agree within max_diff_m, else the
   // nearest beam if the voxel centre lies within max_ray_dist_m of that beam's ray.  Depth = range along the beam.
   template <typename Img>
-  __device__ bool sample(const Frame& f, const Img& img, const float* pc, float* ds, float* vd) const {
+  __device__ int sample(const Frame& f, const Img& img, const float* pc, float* ds, float* vd) const {
     const float r = nvbx_lidar_range(pc);
     *vd = r;
-    if (f.max_dist > 0.0f && r > f.max_dist) return false;      // (before the projection: it costs two atan2)
+    if (f.max_dist > 0.0f && r > f.max_dist) return 0;      // (before the projection: it costs two atan2)
     float u, v;
-    if (!nvbx_lidar_project(&l, pc, r, &u, &v)) return false;
+    if (!nvbx_lidar_project(&l, pc, r, &u, &v)) return 0;
     const float uc = u - 0.5f, vc = v - 0.5f;
     const float fx = floorf(uc), fy = floorf(vc);
     const int x0 = (int)fx, y0 = (int)fy;
@@ -85,21 +86,21 @@ struct LidarSensor {
           const float top = (1.0f - ax) * f00 + ax * f10;
           const float bot = (1.0f - ax) * f01 + ax * f11;
           *ds = (1.0f - ay) * top + ay * bot;
-          return true;
+          return 1;
         }
       }
     }
     const int c = (int)floorf(u), rr = (int)floorf(v);
-    if (c < 0 || rr < 0 || c >= f.cols || rr >= f.rows) return false;
+    if (c < 0 || rr < 0 || c >= f.cols || rr >= f.rows) return 0;
     const float d = img((int64_t)rr * f.cols + c);
-    if (!(d > 0.0f)) return false;
+    if (!(d > 0.0f)) return 0;
     float dir[3]; beam_dir(rr, c, dir);
     float dot = pc[0] * dir[0]; dot = dot + pc[1] * dir[1]; dot = dot + pc[2] * dir[2];
     const float ex = pc[0] - dot * dir[0], ey = pc[1] - dot * dir[1], ez = pc[2] - dot * dir[2];
     const float dist = sqrtf((ex * ex + ey * ey) + ez * ez);
-    if (dist > max_ray_dist_m) return false;
+    if (dist > max_ray_dist_m) return 0;
     *ds = d;
-    return true;
+    return 1;
   }
 };
 
@@ -364,8 +365,9 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img dep
     apply_rt(f.R_CL, f.t_CL, voxel_center(rec_c.y, vx, f.block_size, f.voxel_size), voxel_center(rec_c.z, vy, f.block_size, f.voxel_size),
              voxel_center(rec_c.w, vz, f.block_size, f.voxel_size), pc);
     float ds = 0.0f, vd = 0.0f;
-    const bool upd = sensor.sample(f, depth, pc, &ds, &vd);
-    if (upd) {
+    const int got = sensor.sample(f, depth, pc, &ds, &vd);
+    if (got < 0 && f.invalid_decay >= 0.0f) *vp = make_float2(cur_c.x, cur_c.y * f.invalid_decay);
+    if (got > 0) {
       const float sdf = ds - vd;
       if (!(sdf < -f.trunc)) {
         const float wm = weight_fn(f.weighting_mode, ds, vd, f.trunc);

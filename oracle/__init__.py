@@ -41,6 +41,7 @@ class OrcParams(C.Structure):
         ("lidar_max_integration_distance_m", C.c_float),
         ("lidar_linear_interpolation_max_allowable_difference_vox", C.c_float),
         ("lidar_nearest_interpolation_max_allowable_dist_to_ray_vox", C.c_float),
+        ("invalid_depth_decay_factor", C.c_float),
     ]
 
 
@@ -57,7 +58,7 @@ def default_params(**kw):
         tsdf_decay_factor=0.95, tsdf_decayed_weight_threshold=0.001,
         esdf_site_rule=0, depth_interp_nearest=0, lidar_max_integration_distance_m=10.0,
         lidar_linear_interpolation_max_allowable_difference_vox=2.0,
-        lidar_nearest_interpolation_max_allowable_dist_to_ray_vox=0.5)
+        lidar_nearest_interpolation_max_allowable_dist_to_ray_vox=0.5, invalid_depth_decay_factor=-1.0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p

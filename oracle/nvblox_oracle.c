@@ -79,6 +79,7 @@ typedef struct {
   float lidar_max_integration_distance_m;  /* lidar_projective_integrator_max_integration_distance_m, mapper_initialization.cpp:271-276 */
   float lidar_linear_interpolation_max_allowable_difference_vox;   /* [U] 2.0 */
   float lidar_nearest_interpolation_max_allowable_dist_to_ray_vox; /* [U] 0.5 */
+  float invalid_depth_decay_factor;     /* projective_tsdf_integrator_invalid_depth_decay_factor; < 0 = off */
 } OrcParams;
 
 enum { W_CONSTANT = 0, W_CONSTANT_DROPOFF = 1, W_INVERSE_SQUARE = 2, W_INVERSE_SQUARE_DROPOFF = 3,
@@ -249,12 +250,13 @@ static inline int cam_project(const Cam* k, const float* p, float* u, float* v) 
 
 /* interpolate2DLinear with FloatPixelGreaterThanZero ([U] nvblox interpolation_2d): u,v corner-referenced;
  * subtract 0.5 to get centre-referenced; low pixel = floor; needs low+1 in bounds; all four > 0. */
+/* returns 1 = value, 0 = no sample (outside the image), -1 = a depth tap is invalid (<= 0) */
 static inline int interp_depth(const float* img, int rows, int cols, float u, float v, int nearest, float* out) {
   if (nearest) {
     int c = (int)floorf(u), r = (int)floorf(v);
     if (c < 0 || r < 0 || c >= cols || r >= rows) return 0;
     float d = img[(int64_t)r * cols + c];
-    if (!(d > 0.0f)) return 0;
+    if (!(d > 0.0f)) return -1;
     *out = d; return 1;
   }
   float uc = u - 0.5f, vc = v - 0.5f;
@@ -264,7 +266,7 @@ static inline int interp_depth(const float* img, int rows, int cols, float u, fl
   float ax = uc - fx, ay = vc - fy;
   float f00 = img[(int64_t)y0 * cols + x0], f10 = img[(int64_t)y0 * cols + x0 + 1];
   float f01 = img[(int64_t)(y0 + 1) * cols + x0], f11 = img[(int64_t)(y0 + 1) * cols + x0 + 1];
-  if (!(f00 > 0.0f) || !(f10 > 0.0f) || !(f01 > 0.0f) || !(f11 > 0.0f)) return 0;
+  if (!(f00 > 0.0f) || !(f10 > 0.0f) || !(f01 > 0.0f) || !(f11 > 0.0f)) return -1;
   float top = (1.0f - ax) * f00 + ax * f10;
   float bot = (1.0f - ax) * f01 + ax * f11;
   *out = (1.0f - ay) * top + ay * bot;
@@ -371,10 +373,16 @@ static void tsdf_integrate_block(const OrcParams* p, Block* b, const float* dept
     const float vd = pc[2];
     if (p->max_integration_distance_m > 0.0f && vd > p->max_integration_distance_m) continue;
     float ds;
-    if (!interp_depth(depth, rows, cols, u, v, p->depth_interp_nearest, &ds)) continue;
+    TsdfVoxel* vx = &b->tsdf[z + 8 * y + 64 * x];
+    const int got = interp_depth(depth, rows, cols, u, v, p->depth_interp_nearest, &ds);
+    if (got < 0 && p->invalid_depth_decay_factor >= 0.0f) {
+      /* [U] invalid depth where the voxel projects: the surface estimate there loses confidence */
+      vx->weight = vx->weight * p->invalid_depth_decay_factor;
+      continue;
+    }
+    if (got <= 0) continue;
     const float sdf = ds - vd;
     if (sdf < -trunc) continue;
-    TsdfVoxel* vx = &b->tsdf[z + 8 * y + 64 * x];
     const float wm = weight_fn(p->weighting_mode, ds, vd, trunc);
     const float wsum = wm + vx->weight;
     if (!(wsum > 0.0f)) continue;
@@ -720,7 +728,7 @@ int64_t orc_integrate_color(OrcMap* m, const uint8_t* rgb, int rows, int cols, c
       const float vd = pc[2];
       if (p->max_integration_distance_m > 0.0f && vd > p->max_integration_distance_m) continue;
       float sd;
-      if (!interp_depth(m->synth, m->synth_rows, m->synth_cols, u / (float)f, v / (float)f, 0, &sd)) continue;
+      if (interp_depth(m->synth, m->synth_rows, m->synth_cols, u / (float)f, v / (float)f, 0, &sd) <= 0) continue;
       if (fabsf(sd - vd) > trunc) continue;
       float c[3];
       if (!interp_color(rgb, rows, cols, u, v, c)) continue;

@@ -4,9 +4,11 @@
 //
 // usage: fake_node <frames.bin> [mesh]      prints one JSON line.
 // frames.bin: int32 n, rows, cols; float fu, fv, cu, cv; then n x { float T_L_C[16] row-major, float depth[rows*cols], uint8 rgb[rows*cols*3] }
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <optional>
 #include <string>
 #include <vector>
 #include <nvblox/nvblox.h>
@@ -125,8 +127,44 @@ struct FakeNode {
   }
 };
 
+// nvblox_node.cpp:1277-1420 processLidarPointcloud, minus ROS: model, point cloud on the device, integrate, range image out
+static int lidarMain() {
+  const int lidar_width = 256, lidar_height = 16; const float lidar_min_valid_range_m = 0.1f, lidar_vertical_fov_rad = 0.5236f;
+  std::shared_ptr<CudaStream> cuda_stream_ = CudaStream::createCudaStream(static_cast<CudaStreamType>(2));
+  auto multi_mapper_ = std::make_shared<MultiMapper>(0.1f, MappingType::kStaticTsdf, EsdfMode::k2D, MemoryType::kDevice, cuda_stream_);
+  MapperParams p; p.projective_integrator_params.lidar_projective_integrator_max_integration_distance_m = 15.0f;   // nvblox_os1.yaml:31
+  p.projective_integrator_params.projective_integrator_weighting_mode = WeightingFunctionType::kConstantWeight;
+  p.view_calculator_params.raycast_subsampling_factor = 2;                                                         // nvblox_os1.yaml:33
+  multi_mapper_->setMapperParams(p);
+  Lidar lidar = Lidar(lidar_width, lidar_height, lidar_min_valid_range_m, lidar_vertical_fov_rad);                  // :1315-1323
+  // one return per beam from the inside of a sphere of radius 6 m
+  std::vector<Vector3f> pts;
+  for (int k = 0; k < lidar_height; k++) for (int j = 0; j < lidar_width; j++) {
+    const float el = 0.5f * lidar_vertical_fov_rad - k * (lidar_vertical_fov_rad / (lidar_height - 1)), az = -3.14159265f + j * (6.2831853f / lidar_width);
+    pts.emplace_back(6.f * std::cos(el) * std::cos(az), 6.f * std::cos(el) * std::sin(az), 6.f * std::sin(el));
+  }
+  Pointcloud nvblox_pointcloud(MemoryType::kDevice);
+  nvblox_pointcloud.copyFromAsync(pts, *cuda_stream_);
+  const Transform T_L_C = Transform::Identity();
+  const bool use_lidar_motion_compensation = false;
+  std::optional<Transform> maybe_T_L_S_scanEnd; std::optional<Time> maybe_scan_duration_ms; const Time update_time_ms(0);
+  multi_mapper_->integrateDepth(nvblox_pointcloud, T_L_C, lidar,
+                                use_lidar_motion_compensation, maybe_T_L_S_scanEnd,
+                                maybe_scan_duration_ms, update_time_ms);                                             // :1382-1384
+  const DepthImage& range = multi_mapper_->getLastDepthFrameFromPointcloud();                                     // :1397
+  std::vector<float> host((size_t)range.numel());
+  (void)hipMemcpyAsync(host.data(), range.dataConstPtr(), host.size() * sizeof(float), hipMemcpyDefault, *cuda_stream_);
+  cuda_stream_->synchronize();
+  size_t valid = 0; double sum = 0.0;
+  for (float v : host) if (v > 0.f) { valid++; sum += v; }
+  std::printf("{\"lidar_blocks\": %d, \"range_valid\": %zu, \"range_mean\": %.6f}\n",
+              multi_mapper_->background_mapper()->tsdf_layer().numAllocatedBlocks(), valid, valid ? sum / valid : 0.0);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2) { std::fprintf(stderr, "usage: %s frames.bin\n", argv[0]); return 2; }
+  if (argc >= 2 && std::string(argv[1]) == "lidar") return lidarMain();
+  if (argc < 2) { std::fprintf(stderr, "usage: %s frames.bin | lidar\n", argv[0]); return 2; }
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) { std::perror("open"); return 2; }
   int32_t hdr[3]; float k[4];

@@ -86,3 +86,14 @@ def test_facade_matches_ctypes_path(hip_lib, tmp_path):
     assert got["mesh_triangle_indices"] == 3 * sum(len(v["triangles"]) for v in mesh.values())
     vs = sum(float(v["vertices"].astype(np.float64).sum()) + float(v["colors"][:, 0].astype(np.float64).sum()) for v in mesh.values())
     assert abs(got["mesh_vertex_sum"] - vs) <= 1e-6 * max(1.0, abs(vs))
+
+
+@pytest.mark.gpu
+def test_facade_lidar_pointcloud(hip_lib):
+    """MultiMapper::integrateDepth(Pointcloud, T, Lidar, ...) through the facade (nvblox_node.cpp:1382-1384,1397)."""
+    exe = build_fake_node()
+    r = subprocess.run([exe, "lidar"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["range_valid"] == 256 * 16 and abs(got["range_mean"] - 6.0) < 1e-3
+    assert got["lidar_blocks"] > 500

@@ -75,6 +75,22 @@ def test_depth_u16mm_fused_conversion(oracle_mod, hip_lib):
     compare_layer(M, g, o, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
 
 
+def test_invalid_depth_decay_parity(oracle_mod, hip_lib):
+    """projective_tsdf_integrator_invalid_depth_decay_factor (mapper_initialization.cpp:294-300; 0.8 in nvblox_dynamics.yaml:11):
+    voxels that project onto invalid depth lose weight."""
+    M, g, o = make_pair(oracle_mod, invalid_depth_decay_factor=0.8)
+    fr = H.frames(4, H.SMALL_CAM, color=False, stride=5)
+    for k, (d, rgb, T) in enumerate(fr):
+        d = d.copy()
+        if k >= 2:
+            d[30:80, 40:110] = 0.0          # a hole of invalid depth over previously observed space
+        g.integrate_depth(d, T, H.SMALL_CAM); o.integrate_depth(d, T, H.SMALL_CAM)
+    n, worst = compare_layer(M, g, o, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
+    # the decay actually happened: some weights are 2 * 0.8^2 = 1.28 (two clean frames, two decays)
+    bg, _ = g.get_blocks(M.LAYER_TSDF, g.block_indices(M.LAYER_TSDF))
+    assert (np.abs(bg["weight"] - np.float32(2.0 * 0.8 * 0.8)) < 1e-5).sum() > 100
+
+
 def test_esdf_parity(oracle_mod, hip_lib):
     M, g, o = make_pair(oracle_mod)
     fr = H.frames(8, H.SMALL_CAM, color=False, stride=11)
