@@ -1,0 +1,113 @@
+"""Edge cases of the hot path on the GPU (empty / ragged inputs, capacity limits, idle updates), each against the oracle
+or against an invariant -- the inputs the reference's callers can legally hand over (nvblox_node.cpp drops frames but
+never validates image content)."""
+import numpy as np
+import pytest
+
+import helpers as H
+from isaac_ros_nvblox_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(oracle_mod, cap=1 << 13, **kw):
+    from isaac_ros_nvblox_amd import mapper as M
+    pg = M.default_params(**kw); po = H.copy_params(pg, oracle_mod.OrcParams)
+    return M, M.Mapper(pg, block_capacity=cap), oracle_mod.OracleMap(po)
+
+
+def test_all_invalid_depth_allocates_nothing(oracle_mod, hip_lib):
+    M, g, o = pair(oracle_mod)
+    d = np.zeros((120, 160), np.float32); T = S.trajectory_pose(0)
+    g.integrate_depth(d, T, H.SMALL_CAM); o.integrate_depth(d, T, H.SMALL_CAM)
+    assert g.num_blocks(M.LAYER_TSDF) == 0 == o.num_blocks(oracle_mod.L_TSDF)
+    assert len(g.last_view()) == 0
+    g.update_esdf(); g.update_color_mesh()                       # idle updates on an empty map
+    img, aabb = g.esdf_slice_image()
+    assert img.size == 0
+    assert g.mesh() == {}
+    c = g.counters()
+    assert c["blocks_allocated"] == 0 and c["capacity_overflow"] == 0
+    rgb = np.zeros((120, 160, 3), np.uint8)
+    g.integrate_color(rgb, T, H.SMALL_CAM)                        # colour on an empty map
+    assert g.num_blocks(M.LAYER_COLOR) == 0
+
+
+@pytest.mark.parametrize("shape", [(113, 157), (9, 11), (64, 64)])
+def test_ragged_image_sizes(oracle_mod, hip_lib, shape):
+    """Image sizes that are not multiples of the 8x8 tile / the sub-sampling factor."""
+    rows, cols = shape
+    cam = (cols / 2.0, cols / 2.0, cols / 2.0 - 0.5, rows / 2.0 - 0.5, cols, rows)
+    M, g, o = pair(oracle_mod)
+    sc = S.Scene()
+    for i in range(2):
+        T = S.trajectory_pose(i * 11)
+        d, rgb = S.render(sc, T, cam)
+        g.integrate_depth(d, T, cam); o.integrate_depth(d, T, cam)
+        assert H.idx_set(g.last_view()) == H.idx_set(o.last_view())
+        if rows >= 8:
+            g.integrate_color(rgb, T, cam); o.integrate_color(rgb, T, cam)
+            assert np.abs(g.synthetic_depth() - o.synthetic_depth()).max() <= 1e-4
+    ig = g.block_indices(M.LAYER_TSDF); io = o.block_indices(oracle_mod.L_TSDF)
+    assert np.array_equal(ig, io) and len(io) > 0
+    bg, _ = g.get_blocks(M.LAYER_TSDF, ig)
+    for k, idx in enumerate(io):
+        bo = o.get_block(oracle_mod.L_TSDF, idx)
+        assert np.abs(bg[k]["distance"] - bo["distance"]).max() <= 1e-4 and np.abs(bg[k]["weight"] - bo["weight"]).max() <= 1e-4
+
+
+def test_block_pool_exhaustion_is_reported_not_fatal(oracle_mod, hip_lib):
+    """More blocks in view than the pool holds: the sticky overflow flag is raised, allocated blocks stay consistent, and
+    the mapper keeps working after clear()."""
+    M, g, o = pair(oracle_mod, cap=128)
+    d, rgb, T = H.frames(1, H.SMALL_CAM, color=False)[0]
+    g.integrate_depth(d, T, H.SMALL_CAM)
+    c = g.counters()
+    assert c["capacity_overflow"] != 0
+    assert g.num_blocks(M.LAYER_TSDF) <= 128
+    g.update_esdf(); g.update_color_mesh(); g.synchronize()      # must not hang or fault
+    g.clear()
+    assert g.num_blocks(M.LAYER_TSDF) == 0
+
+
+def test_clear_then_reuse_matches_fresh_mapper(oracle_mod, hip_lib):
+    M, g, o = pair(oracle_mod)
+    fr = H.frames(2, H.SMALL_CAM, color=False, stride=9)
+    for d, rgb, T in fr:
+        g.integrate_depth(d, T, H.SMALL_CAM)
+    g.update_esdf()
+    g.clear()
+    for d, rgb, T in fr:
+        g.integrate_depth(d, T, H.SMALL_CAM); o.integrate_depth(d, T, H.SMALL_CAM)
+    g.update_esdf(); o.update_esdf()
+    assert np.array_equal(g.block_indices(M.LAYER_TSDF), o.block_indices(oracle_mod.L_TSDF))
+    sg, _ = g.esdf_slice_image(); so, _ = o.esdf_slice_image()
+    assert sg.shape == so.shape and np.abs(sg - so).max() <= 1e-4
+
+
+def test_esdf_update_without_new_data_is_idempotent(oracle_mod, hip_lib):
+    M, g, o = pair(oracle_mod)
+    for d, rgb, T in H.frames(2, H.SMALL_CAM, color=False, stride=9):
+        g.integrate_depth(d, T, H.SMALL_CAM)
+    g.update_esdf()
+    a, _ = g.esdf_slice_image()
+    g.update_esdf()                                              # nothing dirty: empty window
+    b, _ = g.esdf_slice_image()
+    assert np.array_equal(a, b)
+    assert g.counters()["esdf_columns_marked"] == 0
+
+
+def test_camera_facing_unmapped_space_then_back(oracle_mod, hip_lib):
+    """Depth beyond max_integration_distance almost everywhere: rays are clipped at 1 m, mostly free space is carved."""
+    M, g, o = pair(oracle_mod, max_integration_distance_m=1.0)
+    d, rgb, T = H.frames(1, H.SMALL_CAM, color=False)[0]
+    g.integrate_depth(d, T, H.SMALL_CAM); o.integrate_depth(d, T, H.SMALL_CAM)
+    ig = g.block_indices(M.LAYER_TSDF); io = o.block_indices(oracle_mod.L_TSDF)
+    assert np.array_equal(ig, io) and len(io) > 0
+    bg, _ = g.get_blocks(M.LAYER_TSDF, ig)
+    for k, idx in enumerate(io):
+        bo = o.get_block(oracle_mod.L_TSDF, idx)
+        assert np.abs(bg[k]["distance"] - bo["distance"]).max() <= 1e-4 and np.abs(bg[k]["weight"] - bo["weight"]).max() <= 1e-4
+    assert (bg["distance"][bg["weight"] > 0] > 0).mean() > 0.9     # nearly everything within 1 m is free space
+    g.update_color_mesh(); o.update_mesh()
+    assert sum(len(v["triangles"]) for v in g.mesh().values()) == sum(len(o.mesh_block(i)["triangles"]) for i in io)
