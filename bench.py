@@ -152,10 +152,11 @@ def main():
     def step(i, mesh=False):
         k = i % nu
         g.integrate_prepared(dargs[k])          # MultiMapper::integrateDepth
+        work = ex.start(g) if ex is not None else None   # dirty block indices: export + async RCCL all-gather (needs only the depth pass)
+        g.integrate_prepared(cargs[k])          # MultiMapper::integrateColor (runs while the all-gather is in flight)
         if ex is not None:
-            ex.exchange(g)                       # dirty block indices: export -> RCCL all-gather -> mark (needs only the depth pass)
-        g.integrate_prepared(cargs[k])          # MultiMapper::integrateColor
-        g.update_esdf()                          # MultiMapper::updateEsdf (side stream: overlaps the colour pass)
+            ex.finish(g, work)                   # join, mark the peers' blocks ESDF-dirty
+        g.update_esdf()                          # MultiMapper::updateEsdf
         if mesh:
             g.update_color_mesh()
 

@@ -1,8 +1,11 @@
 """One-camera-per-GPU sharding: all-gather of updated block indices before the ESDF sweep.
 
 One process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI on ROCm; "gloo" on CPU in the tests).
-The exchange is two fixed-size all-gathers (counts, then indices padded to `max_blocks`), so the message size is
-static (<= 8 x 48 KiB at max_blocks = 4096): latency-bound on the point-to-point xGMI links, no host copy, no sync.
+The exchange is ONE fixed-size all-gather per frame: each rank contributes a packed int32 buffer [1 + max_blocks, 3]
+whose row 0 holds the count and rows 1.. the block indices (<= 48 KiB at max_blocks = 4096, 8 ranks: 384 KiB gathered).
+The message is latency-bound on the point-to-point xGMI links (one RCCL launch, no host copy, no sync, the count never
+leaves the device), so it is started asynchronously right after the depth pass and joined before the ESDF sweep: the
+colour integration of the same frame runs while the collective is in flight.
 The reference has no multi-GPU path at all (nvblox_ros/include/nvblox_ros/nvblox_node.hpp:298-332: <=4 cameras share
 one queue on one GPU), so this is new design.
 """
@@ -18,26 +21,37 @@ class DirtyBlockExchange:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.max_blocks = int(max_blocks)
-        self.idx = torch.zeros((self.max_blocks, 3), dtype=torch.int32, device=device)
-        self.cnt = torch.zeros((1,), dtype=torch.int32, device=device)
-        self.all_idx = torch.zeros((self.world, self.max_blocks, 3), dtype=torch.int32, device=device)
-        self.all_cnt = torch.zeros((self.world,), dtype=torch.int32, device=device)
+        self.buf = torch.zeros((self.max_blocks + 1, 3), dtype=torch.int32, device=device)        # row 0 = (count, 0, 0)
+        self.all_buf = torch.zeros((self.world, self.max_blocks + 1, 3), dtype=torch.int32, device=device)
+        # views (no copies): what the C-ABI reads / writes
+        self.cnt = self.buf[0, 0:1]
+        self.idx = self.buf[1:]
+        self.all_cnt = self.all_buf[:, 0, 0]
+        self.all_idx = self.all_buf[:, 1:]
 
-    def all_gather(self):
-        """all-gather self.idx / self.cnt into self.all_idx / self.all_cnt (no-op copy when world == 1)."""
+    def all_gather(self, async_op=False):
+        """all-gather self.buf into self.all_buf (local copy when world == 1).  Returns the Work handle if async_op."""
         if self.world == 1:
-            self.all_idx[0].copy_(self.idx); self.all_cnt.copy_(self.cnt)
-            return
-        dist.all_gather_into_tensor(self.all_cnt, self.cnt, group=self.group)
-        dist.all_gather_into_tensor(self.all_idx.view(-1, 3), self.idx, group=self.group)
+            self.all_buf[0].copy_(self.buf)
+            return None
+        return dist.all_gather_into_tensor(self.all_buf.view(-1, 3), self.buf, group=self.group, async_op=async_op)
 
-    def exchange(self, mapper):
-        """Export this GPU's dirty TSDF block indices, all-gather, mark every peer's blocks ESDF-dirty locally."""
+    # -- split-phase exchange (bench.py): start after integrateDepth, finish before updateEsdf
+    def start(self, mapper):
+        """Export this GPU's dirty TSDF block indices (device kernel, count stays on the device) and launch the all-gather."""
         mapper.esdf_dirty_list(self.idx, self.cnt)
-        self.all_gather()
+        return self.all_gather(async_op=True)
+
+    def finish(self, mapper, work):
+        """Join the all-gather, then mark every peer's blocks ESDF-dirty locally (count read on the device)."""
+        if work is not None:
+            work.wait()
         for r in range(self.world):
             if r != self.rank:
                 mapper.mark_esdf_dirty(self.all_idx[r], self.all_cnt[r:r + 1], self.max_blocks)
+
+    def exchange(self, mapper):
+        self.finish(mapper, self.start(mapper))
 
     def union_host(self):
         """Host-side union of the gathered lists (tests / diagnostics only; synchronises)."""

@@ -23,7 +23,8 @@ def _worker(rank, world, port, q):
     n = 10 + 7 * rank
     mine = rng.integers(-20, 20, size=(n, 3)).astype(np.int32)
     ex.idx[:n] = torch.from_numpy(mine); ex.cnt[0] = n
-    ex.all_gather()
+    work = ex.all_gather(async_op=True)      # split-phase, as bench.py uses it around the colour pass
+    work.wait()
     got = ex.union_host()
     # expected union computed independently from the known seeds
     want = set()
