@@ -3,7 +3,7 @@
 //
 // Two launches per depth frame, no host round trip in between:
 //   k_mark_view      one wavefront per 8x8 tile of the sub-sampled ray grid.  Phase 1: each lane walks its ray through
-//                    the block grid (Amanatides-Woo) and drops the block keys into a 4 KiB LDS set (rays of one tile
+//                    the block grid (Amanatides-Woo) and drops the block keys into a 4-8 KiB LDS set (rays of one tile
 //                    share almost all their blocks) -- no HBM access inside the walk.  Phase 2 (flush): the set is
 //                    compacted (ballot + popcount) and ONE key per lane goes to HBM: CAS insert-if-absent into the hash
 //                    (device-side allocation from the slot stack), per-entry frame stamp, and a wave-aggregated append
@@ -29,6 +29,7 @@ using namespace nvbx;
 struct CameraSensor {
   static constexpr bool kLongRays = false;
   static constexpr int kTileRows = 8, kTileCols = 8;     // rays per wavefront: one 8x8 tile of the ray grid
+  static constexpr int kSetSize = 512, kFlushRounds = 2; // a tile crosses < 100 blocks: 4 KiB set, 128 keys per flush pass
   // end point (camera frame) of the ray through the centre of pixel (prow, pcol) at depth `de` along the optical axis
   __device__ void ray_end(const Frame& f, int prow, int pcol, float de, float* pc) const {
     const float rx = (((float)pcol + 0.5f) - f.cu) / f.fu;
@@ -53,6 +54,7 @@ struct LidarSensor {
   // long rays: the walk is a serial chain per ray and the flushes dominate, so fewer rays per wavefront = more
   // wavefronts in flight (16384 rays -> 1024 waves); all 64 lanes still work in the flushes
   static constexpr int kTileRows = 4, kTileCols = 4;
+  static constexpr int kSetSize = 1024, kFlushRounds = 6; // early flush at 256 keys: 6 x 64 >= 256 + one step's additions
   nvbx_lidar_model l;
   const float2* el_tab; const float2* az_tab;
   float max_diff_m, max_ray_dist_m;
@@ -104,9 +106,7 @@ struct LidarSensor {
   }
 };
 
-constexpr int LSET = 1024;          // LDS dedup set entries per wave-tile (8 B each)
-constexpr int LSET_FLUSH = 256;     // early-flush threshold (long rays): keeps the set <= ~30 % full, probes short
-constexpr int FLUSH_ROUNDS = 6;     // keys per lane handled by one phase-wise flush pass (6 x 64 >= LSET_FLUSH + 64)
+constexpr int LSET_FLUSH = 256;     // early-flush threshold (long rays): keeps the 1024-entry set <= ~30 % full, probes short
 
 __device__ inline void unpack_key(u64 key, int32_t* x, int32_t* y, int32_t* z) {
   *x = (int32_t)(key & 0x1FFFFFull) - (1 << 20);
@@ -156,8 +156,10 @@ __device__ inline void view_append(int32_t* cnt, int4* view_list, int32_t list_c
 }
 
 // insert `key` into the tile's LDS set; false = probe window exhausted (caller sends the key to HBM itself)
+template <int LSET>
 __device__ inline bool lset_insert(u64* lset, const int32_t* cur, u64 key, bool* added) {
-  const uint32_t lh = (index_hash(cur[0], cur[1], cur[2]) * 2654435761u) >> 22;   // 10 bits
+  static_assert((LSET & (LSET - 1)) == 0, "power of two");
+  const uint32_t lh = ((index_hash(cur[0], cur[1], cur[2]) * 2654435761u) >> 16) & (LSET - 1);
   *added = false;
 #pragma unroll 1
   for (int p = 0; p < 16; p++) {
@@ -177,15 +179,15 @@ __device__ inline void dda_step(int32_t* cur, const int32_t* step, float* tmax, 
   else { cur[2] += step[2]; tmax[2] = tmax[2] + tdelta[2]; }
 }
 // Flush: compact the set (ballot + popcount), then every key goes to HBM with the dependent round trips taken
-// PHASE-WISE over up to 6 keys per lane at once: (A) the first TWO probe positions of every key are loaded together
+// PHASE-WISE over up to R keys per lane at once: (A) the first TWO probe positions of every key are loaded together
 // (covers ~98 % of lookups at our load factor), (B) resolved -- a key further down its probe chain, a new block, or a
 // slot not published yet takes the general mark_block path, (C) the frame-stamp exchanges of all keys not yet stamped
 // are issued together, (D) ONE wave-aggregated returning atomicAdd reserves view-list space for all first-stampers,
 // (E) records are stored.  A camera tile flushes ~60 keys in one such pass; a long LiDAR bundle 256+ keys per pass
 // instead of 64 per dependent round.  Whole wave must call.
+template <int LSET, int R>
 __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* lkeys, int32_t* cnt, int4* view_list, int32_t list_cap,
                                  int lane, bool clear) {
-  constexpr int R = FLUSH_ROUNDS;
   __syncthreads();
   int32_t nk = 0;
 #pragma unroll
@@ -197,7 +199,7 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
     if (clear) lset[i * 64 + lane] = KEY_EMPTY;
   }
   __syncthreads();
-  for (int32_t kb = 0; kb < nk; kb += R * 64) {              // one pass per 384 keys (wave-uniform)
+  for (int32_t kb = 0; kb < nk; kb += R * 64) {              // one pass per R x 64 keys (wave-uniform)
     const int rounds = min(R, (nk - kb + 63) >> 6);
     u64 key[R]; uint32_t h[R]; uint4 e0[R], e1[R]; bool have[R];
     // (A) first two probe positions, all in flight
@@ -260,6 +262,7 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
 
 template <typename Img, typename Sensor>
 __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Sensor sensor, int4* view_list, int32_t list_cap) {
+  constexpr int LSET = Sensor::kSetSize, FR = Sensor::kFlushRounds;
   __shared__ u64 lset[LSET];
   __shared__ u64 lkeys[LSET];
   const int lane = threadIdx.x;
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
     for (int32_t k = 0; k <= nsteps; k++) {
       bool added;
       const u64 key = pack_key(cur[0], cur[1], cur[2]);
-      const bool spill = !lset_insert(lset, cur, key, &added);
+      const bool spill = !lset_insert<LSET>(lset, cur, key, &added);
       if (__ballot(spill)) {                     // probe window exhausted (rare): this key goes to HBM directly
         int4 rec = make_int4(0, 0, 0, 0);
         const bool first = spill && mark_block(m, key, f.frame_id, &rec);
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
       }
       dda_step(cur, step, tmax, tdelta);
     }
-    flush_set(m, f, lset, lkeys, cnt, view_list, list_cap, lane, false);
+    flush_set<LSET, FR>(m, f, lset, lkeys, cnt, view_list, list_cap, lane, false);
     return;
   }
   // LiDAR: hundreds of steps per ray and little sharing at long range -- wave-uniform loop, flush whenever the set is
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
     u64 key = KEY_EMPTY;
     if (k <= nsteps) {
       key = pack_key(cur[0], cur[1], cur[2]);
-      spill = !lset_insert(lset, cur, key, &added);
+      spill = !lset_insert<LSET>(lset, cur, key, &added);
       dda_step(cur, step, tmax, tdelta);
     }
     nset += (int32_t)__popcll(__ballot(added));
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
       view_append(cnt, view_list, list_cap, first, rec, lane);
     }
     const bool last = __ballot(k + 1 <= nsteps) == 0ull;
-    if (last || nset > LSET_FLUSH) { flush_set(m, f, lset, lkeys, cnt, view_list, list_cap, lane, !last); nset = 0; }
+    if (last || nset > LSET_FLUSH) { flush_set<LSET, FR>(m, f, lset, lkeys, cnt, view_list, list_cap, lane, !last); nset = 0; }
   }
 }
 

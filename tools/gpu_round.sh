@@ -15,3 +15,7 @@ if [ "$2" = "pmc" ]; then
 fi
 find gpurun_out/$TAG -name "*.csv" | head -20
 find gpurun_out/$TAG -name "*kernel_stats.csv" -exec cat {} \;
+# LiDAR workload (configs[4]): bench line + kernel stats
+timeout 600 python bench.py --workload lidar --steps 100 --warmup 10 > gpurun_out/$TAG/bench_lidar.json 2> gpurun_out/$TAG/bench_lidar.err; echo "lidar bench rc=$?"; cat gpurun_out/$TAG/bench_lidar.json
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/stats_lidar -o stats -- python $R/bench.py --workload lidar --steps 50 --warmup 5 > /dev/null 2> $R/gpurun_out/$TAG/prof_lidar.err); echo "rocprof lidar rc=$?"
+find gpurun_out/$TAG/stats_lidar -name "*kernel_stats.csv" -exec cat {} \;
