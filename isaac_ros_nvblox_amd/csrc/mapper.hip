@@ -391,9 +391,9 @@ extern "C" int nvbx_get_counters(nvbx_mapper* m, nvbx_counters* out) {
   out->esdf_blocks_swept = m->esdf_epoch ? c[rec + 5] : 0;
   out->esdf_window_voxels = m->esdf_epoch ? c[rec + 6] : 0;
   const int mrec = C_MESH_OUT + 4 * (int)((m->mesh_epoch + 1) & 1);   // record of the last finished mesh update
-  out->mesh_blocks_updated = m->mesh_epoch ? c[mrec + 0] : 0;
-  out->mesh_vertices = m->mesh_epoch ? c[mrec + 1] : 0;
-  out->mesh_triangles = m->mesh_epoch ? c[mrec + 2] : 0;
+  out->mesh_blocks_updated = m->mesh_epoch ? c[mrec + 1] : 0;
+  out->mesh_vertices = m->mesh_epoch ? (uint32_t)c[mrec + 2] : 0;
+  out->mesh_triangles = m->mesh_epoch ? (uint32_t)c[mrec + 3] : 0;
   out->capacity_overflow = c[C_OVERFLOW];
   return NVBX_OK;
 }

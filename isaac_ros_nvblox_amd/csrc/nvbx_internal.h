@@ -44,7 +44,8 @@ enum {
                        //   +0..3 dirty window min_x, min_y, max_x, max_y (block coords), +4 columns re-marked,
                        //   +5 ESDF blocks swept, +6 window voxels, +7 unused
   C_ESDF_AABB = 32,    // [32..35] AABB of all ESDF blocks: min_x, min_y, max_x, max_y
-  C_MESH_OUT = 36,     // [36..43] two parity-indexed records {blocks, vertices, triangles, pad} of mesh update e
+  C_MESH_OUT = 36,     // [36..43] two parity-indexed records of mesh update e: {list entries, blocks meshed,
+                       //   u64 arena cursor = vertices (low 32) | triangles (high 32)}
   C_LIVE = 44,         // live hash entries
   C_TMP = 45,          // scratch counter (point cloud compaction etc.)
   C_NUM = 48
