@@ -41,7 +41,7 @@ __device__ inline uint32_t resolve_tsdf_slot(const DMap& m, u64 key, uint32_t h,
 __global__ __launch_bounds__(256) void k_sphere_trace(DMap m, Frame f, float* synth, int32_t srows, int32_t scols, int32_t max_steps,
                                                       float max_len, float eps_m) {
   const int tid = threadIdx.x;
-  if (blockIdx.x == 0 && tid == 0) m.counters[C_COLOR_COUNT] = 0;
+  if (blockIdx.x == 0 && tid == 0) list_reset(m, S_LIST_COLOR);
   const int lane = tid & 63;
   const int sub = lane & (RAY_LANES - 1);              // sample index within the ray's group
   const int gsh = lane & ~(RAY_LANES - 1);             // first lane of the group (= shift of its bits in a ballot)
@@ -124,7 +124,7 @@ __device__ inline uint32_t blend_u8(float c0, float w0, float c1, float w1) {
 // together) -> block vote -> {synthetic depth gather, colour gather} (both addressed by the projection, fetched
 // together) -> store.
 __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, const uint8_t* rgb, const float* synth, int32_t srows, int32_t scols,
-                                                         int32_t* color_list, int32_t* mesh_dirty, int32_t mesh_cnt) {
+                                                         int32_t mesh_list) {
   __shared__ int s_out[6];
   __shared__ int s_band;
   const int32_t hw = m.counters[C_HIGH_WATER];
@@ -160,8 +160,8 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, const 
     if (!in_view || !s_band) continue;                // uniform
     if (tid == 0) {
       const uint32_t old = atomicOr(&m.slot_flags[slot], F_COLOR | F_DIRTY_MESH);
-      if (!(old & F_DIRTY_MESH)) mesh_dirty[atomicAdd(&m.counters[mesh_cnt], 1)] = slot;
-      color_list[atomicAdd(&m.counters[C_COLOR_COUNT], 1)] = slot;
+      if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, slot);
+      list_append(m, S_LIST_COLOR, slot);
     }
     float pc[3];
     apply_rt(f.R_CL, f.t_CL, voxel_center(bx, vx, f.block_size, f.voxel_size), voxel_center(by, vy, f.block_size, f.voxel_size),
@@ -230,7 +230,7 @@ extern "C" int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int3
   NVBX_LAUNCH(m, k_sphere_trace, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), m->d, f, m->synth, srows, scols, m->p.sphere_tracing_max_steps,
                      m->p.sphere_tracing_max_ray_length_m, m->p.sphere_tracing_surface_eps_vox * m->p.voxel_size);
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
-  NVBX_LAUNCH(m, k_integrate_color, dim3(grid), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->color_list, m->mesh_dirty_live(), m->mesh_dirty_counter());
+  NVBX_LAUNCH(m, k_integrate_color, dim3(grid), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->mesh_list_live());
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }

@@ -48,16 +48,17 @@ __device__ inline uint32_t any_slot(const DMap& m, int32_t x, int32_t y, int32_t
   return resolve_any(m, pack_key(x, y, z), h, ld_entry(m, h));
 }
 
-// Dependent-access chain: {dirty count, dirty slot} -> {flags, Index3D} -> {hash entries of the ESDF block and of the
+// Dependent-access chain: {shard counts of the dirty list} -> {dirty slot} -> {flags, Index3D} -> {hash entries of the ESDF block and of the
 // TSDF z-band blocks, one per lane, in flight together} -> {column stamp exchange || TSDF column loads} -> store.
-__global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a, const int32_t* dirty) {
+__global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a) {
   const int lane = threadIdx.x;
   const int vx = lane & 7, vy = lane >> 3;
-  int32_t ts0 = dirty[blockIdx.x];                         // speculative: valid iff blockIdx.x < n (gridDim.x <= capacity)
-  const int32_t n = m.counters[C_ESDF_DIRTY];
+  ListView lv;
+  const int32_t n = list_open(m, S_LIST_ESDF_DIRTY, &lv);
   const int nz = a.bz_hi - a.bz_lo + 1;                    // TSDF blocks spanned by the slice z band (<= 62)
+  const int srec = S_ESDF_REC + (int)(a.epoch & 1), sh = my_shard();
   for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const uint32_t tslot = (uint32_t)(i == (int32_t)blockIdx.x ? ts0 : dirty[i]);
+    const uint32_t tslot = (uint32_t)list_at(m, S_LIST_ESDF_DIRTY, lv, i);
     const uint32_t tflags = m.slot_flags[tslot];
     const int32_t bx = m.slot_index[3 * tslot], by = m.slot_index[3 * tslot + 1], bz = m.slot_index[3 * tslot + 2];
     if (lane == 0) atomicAnd(&m.slot_flags[tslot], ~F_DIRTY_ESDF);
@@ -74,15 +75,21 @@ __global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a, const int3
     uint32_t eslot = __shfl(qslot, 0);
     const bool e_exists = slot_ok(eslot) && (m.slot_flags[slot_ok(eslot) ? eslot : 0] & F_ESDF);
     if (!(tflags & F_TSDF) && !e_exists) continue;          // uniform
-    int first = 0;
+    int first = 0, fresh = 0;
     if (lane == 0) {
       if (!slot_ok(eslot)) {                                // new column: insert (device-side allocation)
         bool is_new;
         const int32_t h = hash_insert(m, bx, by, a.bz_out, F_ESDF, &is_new);
         if (h >= 0) { do { eslot = ld_slot_acquire(&m.table[h]); } while (eslot == SLOT_INVALID); }
+        fresh = is_new;                                     // (hash_insert gave the new slot its F_ESDF flag)
+      } else if (!e_exists) {
+        fresh = !(atomicOr(&m.slot_flags[eslot], F_ESDF) & F_ESDF);   // an existing (TSDF) block joins the ESDF layer now
       }
       if (slot_ok(eslot)) {
-        atomicOr(&m.slot_flags[eslot], F_ESDF);
+        if (fresh) {                                        // the layer's AABB only grows when a block joins the layer
+          atomicMin(&m.counters[C_ESDF_AABB + 0], bx); atomicMin(&m.counters[C_ESDF_AABB + 1], by);
+          atomicMax(&m.counters[C_ESDF_AABB + 2], bx); atomicMax(&m.counters[C_ESDF_AABB + 3], by);
+        }
         first = atomicExch(&m.slot_stamp[eslot], a.epoch) != a.epoch;
       }
     }
@@ -111,12 +118,10 @@ __global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a, const int3
     }
     eslot = __shfl(eslot, 0); first = __shfl(first, 0);
     if (!first || !slot_ok(eslot)) continue;                // column already re-marked in this update
-    if (lane == 0) {
-      atomicMin(&m.counters[a.rec + 0], bx); atomicMin(&m.counters[a.rec + 1], by);
-      atomicMax(&m.counters[a.rec + 2], bx); atomicMax(&m.counters[a.rec + 3], by);
-      atomicMin(&m.counters[C_ESDF_AABB + 0], bx); atomicMin(&m.counters[C_ESDF_AABB + 1], by);
-      atomicMax(&m.counters[C_ESDF_AABB + 2], bx); atomicMax(&m.counters[C_ESDF_AABB + 3], by);
-      atomicAdd(&m.counters[a.rec + 4], 1);
+    if (lane == 0) {                                         // window record: this workgroup's shard copy
+      atomicMin(shc_at(m, srec, sh, 0), bx); atomicMin(shc_at(m, srec, sh, 1), by);
+      atomicMax(shc_at(m, srec, sh, 2), bx); atomicMax(shc_at(m, srec, sh, 3), by);
+      atomicAdd(shc_at(m, srec, sh, 4), 1);
     }
     m.esdf[(size_t)eslot * 512 + a.vz_out * 64 + lane] = make_uint2(__float_as_uint(a.max_sq), esdf_meta(0, 0, 0, observed, inside, site));
     const u64 bits = __ballot(site != 0);          // bit (x + 8y) of the block's slice plane
@@ -135,16 +140,22 @@ __global__ __launch_bounds__(256) void k_esdf_edt(DMap m, EsdfArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int vx = lane & 7, vy = lane >> 3;
-  // sweep window = dirty AABB of this update + R (in blocks), decided on the device
-  const int32_t x0 = m.counters[a.rec + 0], y0 = m.counters[a.rec + 1], x1 = m.counters[a.rec + 2], y1 = m.counters[a.rec + 3];
+  // sweep window = dirty AABB of this update (min / max over the shard copies) + R (in blocks), decided on the device
+  const int srec = S_ESDF_REC + (int)(a.epoch & 1), srec_next = S_ESDF_REC + (int)((a.epoch + 1) & 1);
+  int32_t x0 = INT32_MAX, y0 = INT32_MAX, x1 = INT32_MIN, y1 = INT32_MIN;
+#pragma unroll
+  for (int s = 0; s < NSH; s++) {
+    x0 = min(x0, *shc_at(m, srec, s, 0)); y0 = min(y0, *shc_at(m, srec, s, 1));
+    x1 = max(x1, *shc_at(m, srec, s, 2)); y1 = max(y1, *shc_at(m, srec, s, 3));
+  }
   const bool ok = x0 <= x1 && y0 <= y1;
   const int32_t wx0 = x0 - a.rb, wy0 = y0 - a.rb, ww = x1 - x0 + 1 + 2 * a.rb, wh = y1 - y0 + 1 + 2 * a.rb;
-  if (blockIdx.x == 0 && tid == 0) {
-    m.counters[C_ESDF_DIRTY] = 0;                                 // dirty list consumed by k_esdf_mark
-    m.counters[a.rec_next + 0] = INT32_MAX; m.counters[a.rec_next + 1] = INT32_MAX;
-    m.counters[a.rec_next + 2] = INT32_MIN; m.counters[a.rec_next + 3] = INT32_MIN;
-    m.counters[a.rec_next + 4] = 0; m.counters[a.rec_next + 5] = 0; m.counters[a.rec_next + 6] = 0;
-    if (ok) m.counters[a.rec + 6] = ww * 8 * wh * 8;
+  if (blockIdx.x == 0 && tid < NSH) {                             // next update's record, one shard per thread
+    *shc_at(m, srec_next, tid, 0) = INT32_MAX; *shc_at(m, srec_next, tid, 1) = INT32_MAX;
+    *shc_at(m, srec_next, tid, 2) = INT32_MIN; *shc_at(m, srec_next, tid, 3) = INT32_MIN;
+    *shc_at(m, srec_next, tid, 4) = 0; *shc_at(m, srec_next, tid, 5) = 0;
+    *shc_at(m, S_LIST_ESDF_DIRTY, tid, 0) = 0;                     // dirty list consumed by k_esdf_mark
+    if (tid == 0) { m.counters[a.rec_next + 6] = 0; if (ok) m.counters[a.rec + 6] = ww * 8 * wh * 8; }
   }
   if (!ok) return;
   const int nn = 2 * a.rb + 1;                // neighbourhood side in blocks
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(256) void k_esdf_edt(DMap m, EsdfArgs a) {
       } else {
         *vp = make_uint2(__float_as_uint(a.max_sq), vflags);
       }
-      if (lane == 0) atomicAdd(&m.counters[a.rec + 5], 1);
+      if (lane == 0) atomicAdd(shc_at(m, srec, my_shard(), 5), 1);
     }
   }
 }
@@ -247,7 +258,7 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
     NVBX_HIP(hipStreamWaitEvent(m->side, m->ev_main, 0));
     s = m->side;
   }
-  NVBX_LAUNCH_ON(m, s, k_esdf_mark, dim3((unsigned)std::min<int64_t>(m->capacity, 1024)), dim3(64), m->d, a, m->esdf_dirty);
+  NVBX_LAUNCH_ON(m, s, k_esdf_mark, dim3((unsigned)std::min<int64_t>(m->capacity, 1024)), dim3(64), m->d, a);
   NVBX_LAUNCH_ON(m, s, k_esdf_edt, dim3(1024), dim3(256), m->d, a);
   NVBX_HIP(hipGetLastError());
   if (m->use_side) { NVBX_HIP(hipEventRecord(m->ev_side, m->side)); m->side_pending = true; }
@@ -407,35 +418,36 @@ extern "C" int nvbx_esdf_dense_grid(nvbx_mapper* m, const int32_t min_vox[3], co
 }
 
 // ------------------------------------------------------------------------------------------------ multi-GPU hooks
-__global__ void k_export_dirty(DMap m, const int32_t* dirty, int32_t* out_idx, int32_t* out_count, int32_t cap) {
-  int32_t n = m.counters[C_ESDF_DIRTY]; if (n > cap) n = cap;
+__global__ void k_export_dirty(DMap m, int32_t* out_idx, int32_t* out_count, int32_t cap) {
+  ListView lv;
+  int32_t n = list_open(m, S_LIST_ESDF_DIRTY, &lv); if (n > cap) n = cap;
   if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = n;
   for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int32_t s = dirty[i];
+    const int32_t s = list_at(m, S_LIST_ESDF_DIRTY, lv, i);
     out_idx[3 * i] = m.slot_index[3 * s]; out_idx[3 * i + 1] = m.slot_index[3 * s + 1]; out_idx[3 * i + 2] = m.slot_index[3 * s + 2];
   }
 }
 extern "C" int nvbx_esdf_dirty_list(nvbx_mapper* m, int32_t* indices_dev_out, int32_t* count_dev_out, int64_t capacity) {
   if (!m || !indices_dev_out || !count_dev_out || capacity <= 0) return NVBX_E_INVALID;
   if (m->join_side()) return NVBX_E_DEVICE;
-  NVBX_LAUNCH(m, k_export_dirty, dim3(64), dim3(256), m->d, m->esdf_dirty, indices_dev_out, count_dev_out, (int32_t)std::min<int64_t>(capacity, m->capacity));
+  NVBX_LAUNCH(m, k_export_dirty, dim3(64), dim3(256), m->d, indices_dev_out, count_dev_out, (int32_t)std::min<int64_t>(capacity, m->capacity));
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }
 // Union step after the all-gather: blocks another GPU updated that exist locally as TSDF blocks become ESDF-dirty here.
-__global__ void k_import_dirty(DMap m, const int32_t* idx, const int32_t* count, int64_t max_count, int32_t* dirty) {
+__global__ void k_import_dirty(DMap m, const int32_t* idx, const int32_t* count, int64_t max_count) {
   int64_t n = *count; if (n > max_count) n = max_count;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t s = find_slot(m, idx[3 * i], idx[3 * i + 1], idx[3 * i + 2], F_TSDF);
     if (!slot_ok(s)) continue;
     const uint32_t old = atomicOr(&m.slot_flags[s], F_DIRTY_ESDF);
-    if (!(old & F_DIRTY_ESDF)) dirty[atomicAdd(&m.counters[C_ESDF_DIRTY], 1)] = (int32_t)s;
+    if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)s);
   }
 }
 extern "C" int nvbx_mark_esdf_dirty(nvbx_mapper* m, const int32_t* indices_dev, const int32_t* count_dev, int64_t max_count) {
   if (!m || !indices_dev || !count_dev || max_count < 0) return NVBX_E_INVALID;
   if (m->join_side()) return NVBX_E_DEVICE;
-  NVBX_LAUNCH(m, k_import_dirty, dim3(64), dim3(256), m->d, indices_dev, count_dev, max_count, m->esdf_dirty);
+  NVBX_LAUNCH(m, k_import_dirty, dim3(64), dim3(256), m->d, indices_dev, count_dev, max_count);
   NVBX_HIP(hipGetLastError());
   return m->mark_main();
 }

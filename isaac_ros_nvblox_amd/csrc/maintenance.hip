@@ -17,8 +17,7 @@ __device__ inline void free_slot(DMap& m, uint32_t slot) {   // one thread
   atomicSub(&m.counters[C_LIVE], 1);
 }
 
-__global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, int32_t* esdf_dirty,
-                                               int32_t* mesh_dirty, int32_t mesh_cnt) {
+__global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, int32_t mesh_list) {
   __shared__ int s_alive;
   const int32_t hw = m.counters[C_HIGH_WATER];
   const int tid = threadIdx.x;
@@ -48,8 +47,8 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
         atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH));
         if (!(flags & F_ESDF)) free_slot(m, (uint32_t)slot);
       }
-      if (!(old & F_DIRTY_ESDF)) esdf_dirty[atomicAdd(&m.counters[C_ESDF_DIRTY], 1)] = slot;
-      if (!(old & F_DIRTY_MESH)) mesh_dirty[atomicAdd(&m.counters[mesh_cnt], 1)] = slot;
+      if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, slot);
+      if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, slot);
     }
   }
 }
@@ -116,7 +115,7 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   if (m->join_side()) return NVBX_E_DEVICE;
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
   NVBX_LAUNCH(m, k_decay, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
-                     exclude_last_view ? m->last_view_frame : 0u, m->esdf_dirty, m->mesh_dirty_live(), m->mesh_dirty_counter());
+                     exclude_last_view ? m->last_view_frame : 0u, m->mesh_list_live());
   return rebuild_table(m);
 }
 

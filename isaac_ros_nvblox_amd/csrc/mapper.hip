@@ -23,11 +23,15 @@ extern "C" const char* nvbx_last_error(void) { return nvbx::g_err.c_str(); }
 __global__ void k_init_map(DMap m) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m.capacity) { m.free_stack[i] = m.capacity - 1 - i; m.slot_flags[i] = 0; m.slot_stamp[i] = 0xFFFFFFFFu; }
+  if (i < (uint32_t)(S_NUM * NSH * SH_STRIDE)) {       // sharded counters: zero, ESDF window records min = +inf / max = -inf
+    const int id = (int)i / (NSH * SH_STRIDE), field = (int)i % SH_STRIDE;
+    int32_t v = 0;
+    if (id == S_ESDF_REC || id == S_ESDF_REC + 1) { if (field < 2) v = INT32_MAX; else if (field < 4) v = INT32_MIN; }
+    m.shc[i] = v;
+  }
   if (i < C_NUM) {
     int32_t v = 0;
     if (i == C_FREE_TOP) v = (int32_t)m.capacity;
-    const int r = (int)i - C_ESDF_UPD;
-    if (r >= 0 && r < 16) { const int k = r & 7; if (k < 2) v = INT32_MAX; else if (k < 4) v = INT32_MIN; }
     const int a = (int)i - C_ESDF_AABB;
     if (a >= 0 && a < 4) v = a < 2 ? INT32_MAX : INT32_MIN;
     m.counters[i] = v;
@@ -57,6 +61,17 @@ __global__ void k_list_to_indices(DMap m, const int32_t* list, int32_t stride, i
   }
 }
 
+// sharded work list (slot ids) -> Index3D, written to out[0..n) in list order; *n_out = entries
+__global__ void k_shardlist_to_indices(DMap m, int list, int32_t* out, int32_t cap, int32_t* n_out) {
+  ListView v; int32_t n = list_open(m, list, &v); if (n > cap) n = cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = n;
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t s = (uint32_t)list_at(m, list, v, i);
+    if (slot_ok(s) && m.slot_flags[s]) { out[3 * i] = m.slot_index[3 * s]; out[3 * i + 1] = m.slot_index[3 * s + 1]; out[3 * i + 2] = m.slot_index[3 * s + 2]; }
+    else { out[3 * i] = INT32_MIN; out[3 * i + 1] = INT32_MIN; out[3 * i + 2] = INT32_MIN; }
+  }
+}
+
 // gather n blocks of `layer` into a dense buffer in the REFERENCE voxel struct layout (z + 8y + 64x order).
 // found[i] = 1 if the block exists.  One 512-thread workgroup per block.
 __global__ __launch_bounds__(512) void k_gather_blocks(DMap m, uint32_t layer, const int32_t* idx, int32_t n, uint8_t* out, int32_t* found) {
@@ -80,7 +95,7 @@ __global__ __launch_bounds__(512) void k_gather_blocks(DMap m, uint32_t layer, c
 
 // allocateBlockAtIndex + whole-block write from reference structs
 __global__ __launch_bounds__(512) void k_scatter_block(DMap m, uint32_t layer, int32_t x, int32_t y, int32_t z, const uint8_t* in,
-                                                       int32_t* esdf_dirty, int32_t* mesh_dirty, int32_t mesh_cnt, int32_t bz_out, int32_t vz_out) {
+                                                       int32_t mesh_list, int32_t bz_out, int32_t vz_out) {
   __shared__ uint32_t s_slot;
   __shared__ u64 s_sites;
   const int t = threadIdx.x;
@@ -93,8 +108,8 @@ __global__ __launch_bounds__(512) void k_scatter_block(DMap m, uint32_t layer, i
       if (layer == F_TSDF) add |= F_DIRTY_ESDF | F_DIRTY_MESH;
       const uint32_t old = atomicOr(&m.slot_flags[s], add);
       if (layer == F_TSDF) {
-        if (!(old & F_DIRTY_ESDF)) esdf_dirty[atomicAdd(&m.counters[C_ESDF_DIRTY], 1)] = (int32_t)s;
-        if (!(old & F_DIRTY_MESH)) mesh_dirty[atomicAdd(&m.counters[mesh_cnt], 1)] = (int32_t)s;
+        if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)s);
+        if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, (int32_t)s);
       }
       if (layer == F_ESDF) {
         atomicMin(&m.counters[C_ESDF_AABB + 0], x); atomicMin(&m.counters[C_ESDF_AABB + 1], y);
@@ -139,9 +154,8 @@ static int alloc_all(nvbx_mapper* m) {
   NVBX_HIP(hipMalloc(&d.color, cap * 4096));
   NVBX_HIP(hipMalloc(&d.esdf, cap * 4096));
   NVBX_HIP(hipMalloc(&m->view_list, cap * 16));    // int4 {slot, x, y, z} per block in view
-  NVBX_HIP(hipMalloc(&m->esdf_dirty, cap * 4));
-  NVBX_HIP(hipMalloc(&m->mesh_dirty, cap * 8));
-  NVBX_HIP(hipMalloc(&m->color_list, cap * 4));
+  NVBX_HIP(hipMalloc(&d.lists, (size_t)N_LISTS * NSH * cap * 4));
+  NVBX_HIP(hipMalloc(&d.shc, S_NUM * NSH * SH_STRIDE * 4));
   NVBX_HIP(hipMalloc(&m->export_idx, cap * 12));
   NVBX_HIP(hipMalloc(&m->export_count, 64));
   NVBX_HIP(hipMalloc(&d.site_bits, cap * 8));
@@ -155,6 +169,7 @@ static int alloc_all(nvbx_mapper* m) {
   m->staging_bytes = 8 << 20;
   NVBX_HIP(hipMalloc(&m->staging, m->staging_bytes));
   NVBX_HIP(hipHostMalloc(&m->h_counters, C_NUM * 4));
+  NVBX_HIP(hipHostMalloc(&m->h_shc, S_NUM * NSH * SH_STRIDE * 4));
   return NVBX_OK;
 }
 
@@ -167,7 +182,7 @@ static int reset_map(nvbx_mapper* m) {
   NVBX_HIP(hipMemsetAsync(d.esdf, 0, cap * 4096, m->stream));
   NVBX_HIP(hipMemsetAsync(d.site_bits, 0, cap * 8, m->stream));
   NVBX_HIP(hipMemsetAsync(m->export_count, 0, 64, m->stream));
-  const int64_t n = std::max<int64_t>(cap, C_NUM);
+  const int64_t n = std::max<int64_t>(cap, std::max<int64_t>(C_NUM, S_NUM * NSH * SH_STRIDE));
   NVBX_LAUNCH(m, k_init_map, dim3((unsigned)((n + 255) / 256)), dim3(256), d);
   NVBX_HIP(hipGetLastError());
   m->frame_id = 0; m->esdf_epoch = 0; m->mesh_epoch = 0; m->last_view_frame = 0; m->synth_rows = m->synth_cols = 0;
@@ -177,6 +192,7 @@ static int reset_map(nvbx_mapper* m) {
 int nvbx_mapper::fetch_counters() {
   if (join_side()) return NVBX_E_DEVICE;
   NVBX_HIP(hipMemcpyAsync(h_counters, d.counters, C_NUM * 4, hipMemcpyDeviceToHost, stream));
+  NVBX_HIP(hipMemcpyAsync(h_shc, d.shc, S_NUM * NSH * SH_STRIDE * 4, hipMemcpyDeviceToHost, stream));
   NVBX_HIP(hipStreamSynchronize(stream));
   return NVBX_OK;
 }
@@ -259,10 +275,11 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   if (m->side) (void)hipStreamDestroy(m->side);
   DMap& d = m->d;
   void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.tsdf, d.color, d.esdf,
-                  m->view_list, m->esdf_dirty, m->mesh_dirty, m->color_list, m->export_idx, m->export_count, d.site_bits,
+                  m->view_list, d.lists, d.shc, m->export_idx, m->export_count, d.site_bits,
                   m->synth, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (m->h_counters) (void)hipHostFree(m->h_counters);
+  if (m->h_shc) (void)hipHostFree(m->h_shc);
   if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
   return NVBX_OK;
@@ -338,7 +355,19 @@ extern "C" int64_t nvbx_last_depth_view(nvbx_mapper* m, nvbx_index3d* out, int64
 }
 extern "C" int64_t nvbx_last_color_view(nvbx_mapper* m, nvbx_index3d* out, int64_t capacity) {
   if (!m) return NVBX_E_INVALID;
-  return list_indices(m, m->color_list, 1, C_COLOR_COUNT, 0, out, capacity);
+  if (m->join_side()) return NVBX_E_DEVICE;
+  NVBX_LAUNCH(m, k_shardlist_to_indices, dim3(64), dim3(256), m->d, (int)S_LIST_COLOR, m->export_idx, (int32_t)m->capacity, m->export_count);
+  int32_t n32 = 0;
+  NVBX_HIP(hipMemcpyAsync(&n32, m->export_count, 4, hipMemcpyDeviceToHost, m->stream));
+  NVBX_HIP(hipStreamSynchronize(m->stream));
+  const int64_t n = n32, k = std::min<int64_t>(n, capacity);
+  if (out && k > 0) {
+    std::vector<nvbx_index3d> tmp((size_t)n);
+    NVBX_HIP(hipMemcpy(tmp.data(), m->export_idx, (size_t)n * 12, hipMemcpyDeviceToHost));
+    sort_indices(tmp.data(), n);
+    memcpy(out, tmp.data(), (size_t)k * 12);
+  }
+  return n;
 }
 
 static size_t ref_voxel_bytes(uint32_t layer) { return layer == F_ESDF ? sizeof(nvbx_esdf_voxel) : 8; }
@@ -373,7 +402,7 @@ extern "C" int nvbx_set_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, 
   NVBX_HIP(hipMemcpyAsync(m->staging, voxels_in, bb, hipMemcpyHostToDevice, m->stream));
   const EsdfArgs ea = m->make_esdf_args();
   NVBX_LAUNCH(m, k_scatter_block, dim3(1), dim3(512), m->d, layer, idx.x, idx.y, idx.z, (const uint8_t*)m->staging,
-                     m->esdf_dirty, m->mesh_dirty_live(), m->mesh_dirty_counter(), ea.bz_out, ea.vz_out);
+                     m->mesh_list_live(), ea.bz_out, ea.vz_out);
   NVBX_HIP(hipStreamSynchronize(m->stream));
   return NVBX_OK;
 }
@@ -385,15 +414,15 @@ extern "C" int nvbx_get_counters(nvbx_mapper* m, nvbx_counters* out) {
   memset(out, 0, sizeof(*out));
   out->blocks_allocated = c[C_LIVE];
   out->tsdf_blocks_in_view = m->last_view_frame ? c[C_VIEW_COUNT + (m->last_view_frame & 3)] : 0;
-  out->color_blocks_updated = c[C_COLOR_COUNT];
-  const int rec = C_ESDF_UPD + 8 * (int)((m->esdf_epoch + 1) & 1);   // record of the last finished update (epoch - 1)
-  out->esdf_columns_marked = m->esdf_epoch ? c[rec + 4] : 0;
-  out->esdf_blocks_swept = m->esdf_epoch ? c[rec + 5] : 0;
-  out->esdf_window_voxels = m->esdf_epoch ? c[rec + 6] : 0;
-  const int mrec = C_MESH_OUT + 4 * (int)((m->mesh_epoch + 1) & 1);   // record of the last finished mesh update
-  out->mesh_blocks_updated = m->mesh_epoch ? c[mrec + 1] : 0;
-  out->mesh_vertices = m->mesh_epoch ? (uint32_t)c[mrec + 2] : 0;
-  out->mesh_triangles = m->mesh_epoch ? (uint32_t)c[mrec + 3] : 0;
+  out->color_blocks_updated = m->shc_sum(S_LIST_COLOR, 0);
+  const int epar = (int)((m->esdf_epoch + 1) & 1);                    // record of the last finished update (epoch - 1)
+  out->esdf_columns_marked = m->esdf_epoch ? m->shc_sum(S_ESDF_REC + epar, 4) : 0;
+  out->esdf_blocks_swept = m->esdf_epoch ? m->shc_sum(S_ESDF_REC + epar, 5) : 0;
+  out->esdf_window_voxels = m->esdf_epoch ? c[C_ESDF_UPD + 8 * epar + 6] : 0;
+  const int mpar = (int)((m->mesh_epoch + 1) & 1);                    // record of the last finished mesh update
+  out->mesh_blocks_updated = m->mesh_epoch ? m->shc_sum(S_MESH_REC + mpar, 0) : 0;
+  out->mesh_vertices = m->mesh_epoch ? m->shc_sum(S_MESH_REC + mpar, 2) : 0;
+  out->mesh_triangles = m->mesh_epoch ? m->shc_sum(S_MESH_REC + mpar, 3) : 0;
   out->capacity_overflow = c[C_OVERFLOW];
   return NVBX_OK;
 }

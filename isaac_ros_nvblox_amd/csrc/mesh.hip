@@ -29,10 +29,11 @@ constexpr int NLAT = 729, NEDGE = 2187, MAXTRI = 2560;
 struct MeshArgs {
   float voxel_size, block_size, min_weight;
   int32_t full;          // 1: every TSDF block, 0: dirty list
-  int32_t dirty_cnt;     // counter index of the live dirty list
-  int32_t next_cnt;      // counter index of the other parity's list (reset here)
-  int32_t rec, rec_next; // C_MESH_OUT records
-  int64_t vert_cap, tri_cap;
+  int32_t dirty_list;    // S_LIST_* id of the list to mesh
+  int32_t next_list;     // the other parity's list (reset here; blocks dirtied from now on go there)
+  int32_t rec, rec_next; // C_MESH_OUT records (list entries)
+  int32_t srec, srec_next; // S_MESH_REC sharded records (blocks meshed, arena cursors)
+  int64_t vert_cap, tri_cap;   // per shard region of the arenas
 };
 
 // exclusive scan over the 512 threads of the workgroup; returns this thread's offset, *total = sum
@@ -57,7 +58,7 @@ __device__ inline void edge_decode(int eid, int* li, int* lj, int* axis, int* lx
   *lj = *li + (*axis == 0 ? 81 : (*axis == 1 ? 9 : 1));
 }
 
-__global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, const int32_t* dirty, float* o_vert, float* o_nrm, uint32_t* o_col,
+__global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert, float* o_nrm, uint32_t* o_col,
                                               int32_t* o_tri, MeshRecord* o_rec) {
   __shared__ float s_d[NLAT];
   __shared__ uint8_t s_valid[NLAT];
@@ -70,14 +71,18 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, const int32_t*
   __shared__ int s_base[3];
   const int tid = threadIdx.x;
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
-  if (blockIdx.x == 0 && tid == 0) {
-    m.counters[a.next_cnt] = 0;
-    m.counters[a.rec_next + 0] = 0; m.counters[a.rec_next + 1] = 0; m.counters[a.rec_next + 2] = 0; m.counters[a.rec_next + 3] = 0;
+  if (blockIdx.x == 0 && tid < NSH) {                                   // next update's records, one shard per thread
+    *shc_at(m, a.next_list, tid, 0) = 0;
+    *shc_at(m, a.srec_next, tid, 0) = 0; *shc_at(m, a.srec_next, tid, 2) = 0; *shc_at(m, a.srec_next, tid, 3) = 0;
+    if (tid == 0) m.counters[a.rec_next + 0] = 0;
   }
-  const int32_t n = a.full ? m.counters[C_HIGH_WATER] : m.counters[a.dirty_cnt];
+  ListView lv;
+  const int32_t nlist = list_open(m, a.dirty_list, &lv);
+  const int32_t n = a.full ? m.counters[C_HIGH_WATER] : nlist;
   if (blockIdx.x == 0 && tid == 0) m.counters[a.rec + 0] = n;           // records o_rec[0..n): one per list entry, invalid ones marked
+  const int sh = my_shard();
   for (int32_t it = blockIdx.x; it < n; it += gridDim.x) {
-    const uint32_t slot = a.full ? (uint32_t)it : (uint32_t)dirty[it];
+    const uint32_t slot = a.full ? (uint32_t)it : (uint32_t)list_at(m, a.dirty_list, lv, it);
     const uint32_t flags = m.slot_flags[slot];
     if (!(flags & F_TSDF)) {                                             // uniform: block was deallocated meanwhile (or, full mode, is no TSDF block)
       if (tid == 0) {
@@ -139,13 +144,15 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, const int32_t*
     if (tid == 0) {
       // ONE returning atomic per block: the vertex and triangle arena cursors share a 64-bit word (three separate
       // counters cost 3 x ~12 ns x #blocks of serialised L2 atomics: 8.4 of the kernel's 28 us at 300 blocks)
-      const u64 cur = atomicAdd(reinterpret_cast<u64*>(&m.counters[a.rec + 2]), (u64)(uint32_t)V | ((u64)(uint32_t)T << 32));
-      int vb = (int)(uint32_t)(cur & 0xFFFFFFFFull);
-      int tb = (int)(uint32_t)(cur >> 32);
-      atomicAdd(&m.counters[a.rec + 1], 1);                               // blocks meshed (not waited for)
+      // The arenas are split into NSH regions with one cursor each (this workgroup's shard), so concurrent blocks
+      // do not serialise on one word.
+      const u64 cur = atomicAdd(reinterpret_cast<u64*>(shc_at(m, a.srec, sh, 2)), (u64)(uint32_t)V | ((u64)(uint32_t)T << 32));
+      const int64_t vl = (int64_t)(cur & 0xFFFFFFFFull), tl = (int64_t)(cur >> 32);
+      atomicAdd(shc_at(m, a.srec, sh, 0), 1);                             // blocks meshed (not waited for)
       const int bi = it;
       int nv = V, nt = T;
-      if ((int64_t)vb + V > a.vert_cap || (int64_t)tb + T > a.tri_cap) { atomicExch(&m.counters[C_OVERFLOW], 1); nv = 0; nt = 0; vb = -1; }
+      int vb = (int)((int64_t)sh * a.vert_cap + vl), tb = (int)((int64_t)sh * a.tri_cap + tl);
+      if (vl + V > a.vert_cap || tl + T > a.tri_cap) { atomicExch(&m.counters[C_OVERFLOW], 1); nv = 0; nt = 0; vb = -1; }
       MeshRecord r; r.x = bx; r.y = by; r.z = bz; r.vbase = vb; r.nvert = nv; r.tbase = tb; r.ntri = nt; r.pad = 0;
       o_rec[bi] = r;
       s_base[0] = vb; s_base[1] = tb;
@@ -229,11 +236,12 @@ extern "C" int nvbx_update_color_mesh(nvbx_mapper* m, int32_t update_full_layer)
   a.voxel_size = m->p.voxel_size; a.block_size = m->p.voxel_size * 8.0f; a.min_weight = m->p.mesh_min_weight;
   a.full = update_full_layer ? 1 : 0;
   const int par = (int)(m->mesh_epoch & 1);
-  a.dirty_cnt = C_MESH_DIRTY + par; a.next_cnt = C_MESH_DIRTY + (par ^ 1);
+  a.dirty_list = S_LIST_MESH_DIRTY + par; a.next_list = S_LIST_MESH_DIRTY + (par ^ 1);
   a.rec = C_MESH_OUT + 4 * par; a.rec_next = C_MESH_OUT + 4 * (par ^ 1);
-  a.vert_cap = m->mesh_vert_cap; a.tri_cap = m->mesh_tri_cap;
+  a.srec = S_MESH_REC + par; a.srec_next = S_MESH_REC + (par ^ 1);
+  a.vert_cap = m->mesh_vert_cap / NSH; a.tri_cap = m->mesh_tri_cap / NSH;
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
-  NVBX_LAUNCH(m, k_mesh, dim3(grid), dim3(512), m->d, a, m->mesh_dirty_live(), m->mesh_vert, m->mesh_nrm, (uint32_t*)m->mesh_col,
+  NVBX_LAUNCH(m, k_mesh, dim3(grid), dim3(512), m->d, a, m->mesh_vert, m->mesh_nrm, (uint32_t*)m->mesh_col,
                      m->mesh_tri, m->mesh_rec);
   NVBX_HIP(hipGetLastError());
   m->mesh_epoch++;
@@ -245,10 +253,14 @@ extern "C" int nvbx_mesh_sizes(nvbx_mapper* m, int64_t* n_blocks, int64_t* n_ver
   if (!m || !n_blocks || !n_vertices || !n_triangles) return NVBX_E_INVALID;
   if (m->mesh_epoch == 0) { *n_blocks = *n_vertices = *n_triangles = 0; return NVBX_OK; }
   if (m->fetch_counters()) return NVBX_E_DEVICE;
-  const int rec = C_MESH_OUT + 4 * (int)((m->mesh_epoch + 1) & 1);
-  *n_blocks = m->h_counters[rec + 1];
-  *n_vertices = std::min<int64_t>((uint32_t)m->h_counters[rec + 2], m->mesh_vert_cap);
-  *n_triangles = std::min<int64_t>((uint32_t)m->h_counters[rec + 3], m->mesh_tri_cap);
+  const int par = (int)((m->mesh_epoch + 1) & 1);
+  *n_blocks = m->shc_sum(S_MESH_REC + par, 0);
+  int64_t nv = 0, nt = 0;
+  for (int s = 0; s < NSH; s++) {      // a shard region that overflowed holds at most its capacity
+    nv += std::min<int64_t>((uint32_t)m->h_shc[((S_MESH_REC + par) * NSH + s) * SH_STRIDE + 2], m->mesh_vert_cap / NSH);
+    nt += std::min<int64_t>((uint32_t)m->h_shc[((S_MESH_REC + par) * NSH + s) * SH_STRIDE + 3], m->mesh_tri_cap / NSH);
+  }
+  *n_vertices = nv; *n_triangles = nt;
   return NVBX_OK;
 }
 
@@ -265,13 +277,31 @@ extern "C" int nvbx_mesh_copy(nvbx_mapper* m, nvbx_index3d* block_indices, int32
   NVBX_HIP(hipMemcpy(rec.data(), m->mesh_rec, (size_t)nraw * sizeof(MeshRecord), hipMemcpyDeviceToHost));
   rec.erase(std::remove_if(rec.begin(), rec.end(), [](const MeshRecord& r) { return r.x == INT32_MIN; }), rec.end());
   if ((int64_t)rec.size() != nb) { set_error("mesh record count mismatch"); return NVBX_E_DEVICE; }
-  std::vector<float> v((size_t)nv * 3), n((size_t)nv * 3); std::vector<uint8_t> c((size_t)nv * 4); std::vector<int32_t> t((size_t)nt * 3);
-  if (nv) {
-    NVBX_HIP(hipMemcpy(v.data(), m->mesh_vert, (size_t)nv * 12, hipMemcpyDeviceToHost));
-    NVBX_HIP(hipMemcpy(n.data(), m->mesh_nrm, (size_t)nv * 12, hipMemcpyDeviceToHost));
-    NVBX_HIP(hipMemcpy(c.data(), m->mesh_col, (size_t)nv * 4, hipMemcpyDeviceToHost));
+  // download the used prefix of every shard region of the arenas; records address them by absolute position
+  const int par = (int)((m->mesh_epoch + 1) & 1);
+  const int64_t vreg = m->mesh_vert_cap / NSH, treg = m->mesh_tri_cap / NSH;
+  std::vector<int64_t> voff(NSH + 1, 0), toff(NSH + 1, 0);
+  for (int s = 0; s < NSH; s++) {
+    voff[s + 1] = voff[s] + std::min<int64_t>((uint32_t)m->h_shc[((S_MESH_REC + par) * NSH + s) * SH_STRIDE + 2], vreg);
+    toff[s + 1] = toff[s] + std::min<int64_t>((uint32_t)m->h_shc[((S_MESH_REC + par) * NSH + s) * SH_STRIDE + 3], treg);
   }
-  if (nt) NVBX_HIP(hipMemcpy(t.data(), m->mesh_tri, (size_t)nt * 12, hipMemcpyDeviceToHost));
+  std::vector<float> v((size_t)nv * 3 + 3), n((size_t)nv * 3 + 3); std::vector<uint8_t> c((size_t)nv * 4 + 4); std::vector<int32_t> t((size_t)nt * 3 + 3);
+  for (int s = 0; s < NSH; s++) {
+    const int64_t cv = voff[s + 1] - voff[s], ct = toff[s + 1] - toff[s];
+    if (cv) {
+      NVBX_HIP(hipMemcpy(v.data() + voff[s] * 3, m->mesh_vert + (size_t)s * vreg * 3, (size_t)cv * 12, hipMemcpyDeviceToHost));
+      NVBX_HIP(hipMemcpy(n.data() + voff[s] * 3, m->mesh_nrm + (size_t)s * vreg * 3, (size_t)cv * 12, hipMemcpyDeviceToHost));
+      NVBX_HIP(hipMemcpy(c.data() + voff[s] * 4, m->mesh_col + (size_t)s * vreg * 4, (size_t)cv * 4, hipMemcpyDeviceToHost));
+    }
+    if (ct) NVBX_HIP(hipMemcpy(t.data() + toff[s] * 3, m->mesh_tri + (size_t)s * treg * 3, (size_t)ct * 12, hipMemcpyDeviceToHost));
+  }
+  // absolute arena position -> position in the packed host copies
+  for (auto& r : rec) {
+    if (r.vbase < 0) continue;
+    const int sv = (int)(r.vbase / vreg), st = (int)(r.tbase / treg);
+    r.vbase = (int32_t)(voff[sv] + (r.vbase - (int64_t)sv * vreg));
+    r.tbase = (int32_t)(toff[st] + (r.tbase - (int64_t)st * treg));
+  }
   std::vector<int> order((size_t)nb);
   for (int64_t i = 0; i < nb; i++) order[(size_t)i] = (int)i;
   std::sort(order.begin(), order.end(), [&](int a, int b) {

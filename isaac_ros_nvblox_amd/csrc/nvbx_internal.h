@@ -37,19 +37,33 @@ enum {
   C_HIGH_WATER = 1,    // 1 + highest slot ever handed out
   C_OVERFLOW = 2,      // sticky capacity-overflow flag
   C_VIEW_COUNT = 4,    // [4..7]  ring of per-frame view-list counts (frame & 3)
-  C_ESDF_DIRTY = 8,    // number of entries in esdf_dirty list
-  C_MESH_DIRTY = 9,    // [9..10] entries in the mesh_dirty list of mesh-update parity 0 / 1
-  C_COLOR_COUNT = 11,  // blocks updated by the last colour frame
-  C_ESDF_UPD = 16,     // [16..31] two parity-indexed records of 8 ints for ESDF update e (record e & 1):
-                       //   +0..3 dirty window min_x, min_y, max_x, max_y (block coords), +4 columns re-marked,
-                       //   +5 ESDF blocks swept, +6 window voxels, +7 unused
+  C_ESDF_UPD = 16,     // [16..31] two parity-indexed records of 8 ints for ESDF update e (record e & 1): only
+                       //   +6 (window voxels) lives here; the contended fields are sharded (S_ESDF_REC below)
   C_ESDF_AABB = 32,    // [32..35] AABB of all ESDF blocks: min_x, min_y, max_x, max_y
-  C_MESH_OUT = 36,     // [36..43] two parity-indexed records of mesh update e: {list entries, blocks meshed,
-                       //   u64 arena cursor = vertices (low 32) | triangles (high 32)}
+  C_MESH_OUT = 36,     // [36..43] two parity-indexed records of mesh update e: {+0 list entries}; the contended
+                       //   fields are sharded (S_MESH_REC below)
   C_LIVE = 44,         // live hash entries
   C_TMP = 45,          // scratch counter (point cloud compaction etc.)
   C_NUM = 48
 };
+
+// ---- sharded counters.  A counter that every workgroup of a launch bumps serialises at ~12 ns per atomic in the
+// memory-side atomic unit (276 blocks x 2 list appends = 6.6 us inside a 7 us kernel).  Every such counter therefore
+// exists NSH times, one copy per 64-B line, and a workgroup uses copy blockIdx.x & 7 (= its XCD); readers sum / reduce
+// the copies.  Layout of DMap::shc: [(id * NSH + shard) * SH_STRIDE + field].
+constexpr int NSH = 8;
+constexpr int SH_STRIDE = 16;
+enum {
+  S_LIST_ESDF_DIRTY = 0,   // work list: TSDF slots dirtied since the last ESDF update        (field 0 = entries)
+  S_LIST_MESH_DIRTY = 1,   // [1..2] work list of mesh-update parity 0 / 1                    (field 0 = entries)
+  S_LIST_COLOR = 3,        // slots updated by the last colour frame                          (field 0 = entries)
+  S_ESDF_REC = 4,          // [4..5] parity-indexed ESDF update record: 0..3 dirty window min_x, min_y, max_x, max_y
+                           //   (block coords), 4 columns re-marked, 5 ESDF blocks swept
+  S_MESH_REC = 6,          // [6..7] parity-indexed mesh update record: 0 blocks meshed, 2..3 u64 arena cursor of this
+                           //   shard's arena region = vertices (low 32) | triangles (high 32)
+  S_NUM = 8
+};
+constexpr int N_LISTS = 4;
 
 struct DMap {
   Entry* table; uint32_t mask; uint32_t shift;   // table size = mask + 1 = 2^(32 - shift)
@@ -64,6 +78,8 @@ struct DMap {
   uint2* color;
   uint2* esdf;
   u64* site_bits;           // per slot: site mask of the block's ESDF slice plane (bit x + 8y); 0 for non-ESDF slots
+  int32_t* shc;             // sharded counters (S_* above)
+  int32_t* lists;           // N_LISTS x NSH x capacity slot ids: list l, shard s starts at ((l * NSH + s) * capacity)
 };
 
 // Per-call camera / pose / parameter bundle (kernel argument, lives in SGPRs).
@@ -98,6 +114,37 @@ __host__ __device__ inline uint32_t table_pos(const DMap& m, int32_t x, int32_t 
 }
 
 #ifdef __HIPCC__
+__device__ inline int32_t* shc_at(const DMap& m, int id, int shard, int field) { return &m.shc[(id * NSH + shard) * SH_STRIDE + field]; }
+__device__ inline int my_shard() { return (int)(blockIdx.x & (NSH - 1)); }
+
+// append to a sharded work list (any thread; the counter is the caller's XCD copy)
+__device__ inline void list_append(const DMap& m, int list, int32_t v) {
+  const int sh = my_shard();
+  const int32_t p = atomicAdd(shc_at(m, list, sh, 0), 1);
+  if (p < (int32_t)m.capacity) m.lists[((size_t)list * NSH + sh) * m.capacity + p] = v;
+}
+// reader side: prefix of the shard counts, then item i of the concatenation
+struct ListView { int32_t pre[NSH + 1]; };
+__device__ inline int32_t list_open(const DMap& m, int list, ListView* v) {
+  int32_t c[NSH];
+#pragma unroll
+  for (int s = 0; s < NSH; s++) c[s] = *shc_at(m, list, s, 0);         // 8 independent loads
+  v->pre[0] = 0;
+#pragma unroll
+  for (int s = 0; s < NSH; s++) v->pre[s + 1] = v->pre[s] + min(c[s], (int32_t)m.capacity);
+  return v->pre[NSH];
+}
+__device__ inline int32_t list_at(const DMap& m, int list, const ListView& v, int32_t i) {
+  int s = 0; int32_t base = 0;                 // (selects only: a dynamically indexed pre[] would live in scratch memory)
+#pragma unroll
+  for (int q = 1; q < NSH; q++) if (i >= v.pre[q]) { s = q; base = v.pre[q]; }
+  return m.lists[((size_t)list * NSH + s) * m.capacity + (i - base)];
+}
+__device__ inline void list_reset(const DMap& m, int list) {            // one thread
+#pragma unroll
+  for (int s = 0; s < NSH; s++) *shc_at(m, list, s, 0) = 0;
+}
+
 __device__ inline int32_t floor_div8(int32_t v) { return v >> 3; }
 __device__ inline int32_t mod8(int32_t v) { return v & 7; }
 

@@ -47,9 +47,7 @@ struct nvbx_mapper {
   nvbx::DMap d{};
   // lists (device)
   int32_t* view_list = nullptr;      // int4 {slot, x, y, z} of the blocks in view of the last depth frame
-  int32_t* esdf_dirty = nullptr;     // slots dirtied since the last ESDF update
-  int32_t* mesh_dirty = nullptr;     // 2 x capacity: slots dirtied since the last mesh update (list of parity mesh_epoch & 1 is live)
-  int32_t* color_list = nullptr;     // slots updated by the last colour frame
+  // (the ESDF-dirty / mesh-dirty / colour work lists are sharded and live in d.lists / d.shc, nvbx_internal.h)
   int32_t* export_idx = nullptr;     // int32[capacity][3] scratch for multi-GPU export of the dirty list
   int32_t* export_count = nullptr;
   // LiDAR beam direction tables (float2 {sin, cos}: rows elevations then cols azimuths), rebuilt when the model changes
@@ -66,8 +64,9 @@ struct nvbx_mapper {
   uint32_t frame_id = 0;
   uint32_t esdf_epoch = 0;
   uint32_t mesh_epoch = 0;
-  int32_t* mesh_dirty_live() const { return mesh_dirty + (int64_t)(mesh_epoch & 1) * capacity; }
-  int mesh_dirty_counter() const { return nvbx::C_MESH_DIRTY + (int)(mesh_epoch & 1); }
+  int mesh_list_live() const { return nvbx::S_LIST_MESH_DIRTY + (int)(mesh_epoch & 1); }   // mesh-dirty list being filled
+  int32_t* h_shc = nullptr;          // pinned mirror of d.shc
+  int64_t shc_sum(int id, int field) const { int64_t t = 0; for (int s = 0; s < nvbx::NSH; s++) t += h_shc[(id * nvbx::NSH + s) * nvbx::SH_STRIDE + field]; return t; }
   uint32_t last_view_frame = 0;
   // C-ABI helpers implemented across the .hip files
   nvbx::Frame make_frame(const float T_L_C[16], const nvbx_camera* cam, int32_t rows, int32_t cols, int32_t subsample) const;

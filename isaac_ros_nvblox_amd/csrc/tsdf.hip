@@ -349,7 +349,7 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
 // and the flag / dirty-list atomics of lane 0 are issued first and consumed last.
 template <typename Img, typename Sensor>
 __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img depth, Sensor sensor, const int4* view_list, int32_t list_cap,
-                                                        int32_t* esdf_dirty, int32_t* mesh_dirty, int32_t mesh_cnt) {
+                                                        int32_t mesh_list) {
   int4 rec = view_list[blockIdx.x];                       // speculative: valid iff blockIdx.x < n (gridDim.x <= list_cap)
   int32_t n = m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
   if (n > list_cap) n = list_cap;
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img dep
       }
     }
     if (tid == 0) {
-      if (!(old & F_DIRTY_ESDF)) esdf_dirty[atomicAdd(&m.counters[C_ESDF_DIRTY], 1)] = (int32_t)slot;
-      if (!(old & F_DIRTY_MESH)) mesh_dirty[atomicAdd(&m.counters[mesh_cnt], 1)] = (int32_t)slot;
+      if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)slot);
+      if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, (int32_t)slot);
     }
   }
 }
@@ -399,7 +399,7 @@ static int integrate_depth_impl(nvbx_mapper* m, Img img, const Sensor& sensor, c
   NVBX_LAUNCH(m, (k_mark_view<Img, Sensor>), dim3(tiles), dim3(64), m->d, f, img, sensor, (int4*)m->view_list, (int32_t)m->capacity);
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);
   NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor>), dim3(grid), dim3(512), m->d, f, img, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
-                     m->esdf_dirty, m->mesh_dirty_live(), m->mesh_dirty_counter());
+                     m->mesh_list_live());
   NVBX_HIP(hipGetLastError());
   m->last_view_frame = m->frame_id;
   return m->mark_main();
