@@ -214,6 +214,10 @@ int nvbx_mesh_copy(nvbx_mapper* m, nvbx_index3d* block_indices, int32_t* vertex_
  * on the device; max_count bounds it). */
 int nvbx_esdf_dirty_list(nvbx_mapper* m, int32_t* indices_dev_out, int32_t* count_dev_out, int64_t capacity);
 int nvbx_mark_esdf_dirty(nvbx_mapper* m, const int32_t* indices_dev, const int32_t* count_dev, int64_t max_count);
+/* The same for the whole all-gathered buffer in ONE launch: gathered_dev is int32 [world][1 + max_count][3], row 0 of
+ * each rank = (count, -, -), rows 1.. = block indices (the packed layout isaac_ros_nvblox_amd/dist.py all-gathers);
+ * rank `self_rank`'s own list is skipped. */
+int nvbx_mark_esdf_dirty_gathered(nvbx_mapper* m, const int32_t* gathered_dev, int32_t world, int32_t self_rank, int64_t max_count);
 
 /* ---- instrumentation (timing::Timer analogue for the per-kernel roofline line of bench.py) -----------------------
  * While enabled every kernel launch is bracketed by a hipEvent pair on the mapper stream. nvbx_get_profile returns a

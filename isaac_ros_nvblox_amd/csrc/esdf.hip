@@ -451,3 +451,25 @@ extern "C" int nvbx_mark_esdf_dirty(nvbx_mapper* m, const int32_t* indices_dev, 
   NVBX_HIP(hipGetLastError());
   return m->mark_main();
 }
+
+// all peers' lists in one launch (blockIdx.y = rank)
+__global__ void k_import_dirty_gathered(DMap m, const int32_t* g, int32_t self_rank, int64_t max_count) {
+  const int32_t r = (int32_t)blockIdx.y;
+  if (r == self_rank) return;
+  const int32_t* base = g + (size_t)r * (size_t)(max_count + 1) * 3;
+  int64_t n = base[0]; if (n > max_count) n = max_count;
+  const int32_t* idx = base + 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t s = find_slot(m, idx[3 * i], idx[3 * i + 1], idx[3 * i + 2], F_TSDF);
+    if (!slot_ok(s)) continue;
+    const uint32_t old = atomicOr(&m.slot_flags[s], F_DIRTY_ESDF);
+    if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)s);
+  }
+}
+extern "C" int nvbx_mark_esdf_dirty_gathered(nvbx_mapper* m, const int32_t* gathered_dev, int32_t world, int32_t self_rank, int64_t max_count) {
+  if (!m || !gathered_dev || world < 1 || max_count < 0) return NVBX_E_INVALID;
+  if (m->join_side()) return NVBX_E_DEVICE;
+  if (world > 1 || self_rank < 0) NVBX_LAUNCH(m, k_import_dirty_gathered, dim3(16, (unsigned)world), dim3(256), m->d, gathered_dev, self_rank, max_count);
+  NVBX_HIP(hipGetLastError());
+  return m->mark_main();
+}

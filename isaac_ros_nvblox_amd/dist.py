@@ -46,9 +46,8 @@ class DirtyBlockExchange:
         """Join the all-gather, then mark every peer's blocks ESDF-dirty locally (count read on the device)."""
         if work is not None:
             work.wait()
-        for r in range(self.world):
-            if r != self.rank:
-                mapper.mark_esdf_dirty(self.all_idx[r], self.all_cnt[r:r + 1], self.max_blocks)
+        if self.world > 1:      # one launch for all peers' lists (not one per peer)
+            mapper.mark_esdf_dirty_gathered(self.all_buf, self.world, self.rank, self.max_blocks)
 
     def exchange(self, mapper):
         self.finish(mapper, self.start(mapper))

@@ -311,6 +311,10 @@ class Mapper:
     def mark_esdf_dirty(self, idx_tensor, count_tensor, max_count):
         self._check(self.lib.nvbx_mark_esdf_dirty(self._h, C.c_void_p(idx_tensor.data_ptr()), C.c_void_p(count_tensor.data_ptr()), int(max_count)))
 
+    def mark_esdf_dirty_gathered(self, gathered, world, self_rank, max_count):
+        """gathered: int32 device tensor [world, 1 + max_count, 3] (row 0 = count); one launch for all peers."""
+        self._check(self.lib.nvbx_mark_esdf_dirty_gathered(self._h, C.c_void_p(gathered.data_ptr()), int(world), int(self_rank), int(max_count)))
+
     # -- instrumentation
     def set_profiling(self, enable):
         self._check(self.lib.nvbx_set_profiling(self._h, int(enable)))

@@ -33,7 +33,11 @@ def test_dirty_list_exchange_matches_oracle(oracle_mod, hip_lib):
         # union: each mapper marks the peer's list
         for r in range(2):
             p = 1 - r
-            gs[r].mark_esdf_dirty(exs[p].idx, exs[p].cnt, 4096)
+            if step % 2 == 0:
+                gs[r].mark_esdf_dirty(exs[p].idx, exs[p].cnt, 4096)
+            else:      # the one-launch form bench.py uses: a 2-rank gathered buffer, own rank skipped
+                gathered = torch.stack([exs[0].buf, exs[1].buf])
+                gs[r].mark_esdf_dirty_gathered(gathered, 2, r, 4096)
             os_[r].mark_esdf_dirty(lists[p])
             gs[r].update_esdf(); os_[r].update_esdf()
             ig, ag = gs[r].esdf_slice_image(1000.0); io, ao = os_[r].esdf_slice_image(1000.0)
