@@ -2,6 +2,7 @@
 // nvblox_node.cpp / layer_publishing.cpp / fuser_node.cpp), implemented as inline wrappers over the C-ABI of
 // libnvblox_hip.so (include/nvblox_hip.h).  Single-caller, stream-ordered like the reference (nvblox_node.cpp:99,456-459).
 #pragma once
+#include <cmath>
 #include <memory>
 #include <optional>
 #include <string>
@@ -29,6 +30,17 @@ constexpr LayerTypeBitMask kTsdf = NVBX_LAYER_TSDF, kColor = NVBX_LAYER_COLOR, k
 struct BlockExclusionParams {   // layer_publishing.cpp:702-707
   Vector3f exclusion_center_m; float exclusion_height_m = -1.f; float exclusion_radius_m = -1.f; float block_size_m = 0.f;
 };
+
+// SerializedLayer<VoxelType> as layer_publishing.cpp:271-339,368-377 reads it: block_indices, block_offsets (n + 1,
+// in voxels), voxels (flat, 512 per block in the reference's z + 8y + 64x order)
+template <typename VoxelType>
+struct SerializedLayer {
+  std::vector<Index3D> block_indices;
+  std::vector<int> block_offsets;
+  std::vector<VoxelType> voxels;
+};
+using SerializedTsdfLayer = SerializedLayer<TsdfVoxel>;
+using SerializedColorLayer = SerializedLayer<ColorVoxel>;
 
 class Mapper {
  public:
@@ -142,10 +154,29 @@ class Mapper {
   TsdfIntegratorView tsdf_integrator() const { return TsdfIntegratorView{this}; }
 
   // -- serialization of the mesh for publishing (layer_publishing.cpp:702-711,770-776; mesh_conversions.cpp:62-104)
-  void serializeSelectedLayers(LayerTypeBitMask layers, float /*bandwidth_limit_mbps*/ = -1.f, const BlockExclusionParams& = BlockExclusionParams()) {
+  // Voxel layers: every allocated TSDF block inside the exclusion cylinder (radius / height around the centre; negative =
+  // unlimited) is gathered on the GPU (k_gather_blocks) and copied out; the colour layer is serialized over the SAME block
+  // list, as the publisher requires (layer_publishing.cpp:316,452-459).  The reference's streamer additionally rations
+  // blocks per call by bandwidth_limit_mbps; this implementation sends the whole selection every call.
+  void serializeSelectedLayers(LayerTypeBitMask layers, float /*bandwidth_limit_mbps*/ = -1.f, const BlockExclusionParams& ex = BlockExclusionParams()) {
     if (layers & LayerType::kColorMesh) serializeColorMesh();
+    if (layers & (LayerType::kTsdf | LayerType::kColor)) {
+      std::vector<Index3D> sel;
+      const float bs = tsdf_layer_.block_size();
+      for (const Index3D& b : tsdf_layer_.getAllBlockIndices()) {
+        const Vector3f c = getCenterPositionFromBlockIndex(bs, b);
+        const float dx = c.x() - ex.exclusion_center_m.x(), dy = c.y() - ex.exclusion_center_m.y(), dz = c.z() - ex.exclusion_center_m.z();
+        if (ex.exclusion_radius_m >= 0.f && dx * dx + dy * dy > ex.exclusion_radius_m * ex.exclusion_radius_m) continue;
+        if (ex.exclusion_height_m >= 0.f && std::fabs(dz) > ex.exclusion_height_m) continue;
+        sel.push_back(b);
+      }
+      if (layers & LayerType::kTsdf) serialized_tsdf_ = gatherLayer<TsdfVoxel>(NVBX_LAYER_TSDF, sel);
+      if (layers & LayerType::kColor) serialized_color_ = gatherLayer<ColorVoxel>(NVBX_LAYER_COLOR, sel);
+    }
   }
   std::shared_ptr<SerializedColorMeshLayer> serializedColorMeshLayer() const { return serialized_mesh_; }
+  std::shared_ptr<const SerializedTsdfLayer> serializedTsdfLayer() const { return serialized_tsdf_; }
+  std::shared_ptr<const SerializedColorLayer> serializedColorLayer() const { return serialized_color_; }
 
   // .nvblx save/load is outside the hot path and not provided by libnvblox_hip: report failure
   // through the reference's bool convention (nvblox_node.cpp:1668,1703).
@@ -158,6 +189,17 @@ class Mapper {
 
  private:
   void rebuildViews() { tsdf_layer_ = TsdfLayer(m_, voxel_size_m_); color_layer_ = ColorLayer(m_, voxel_size_m_); esdf_layer_ = EsdfLayer(m_, voxel_size_m_); }
+  template <typename VoxelType>
+  std::shared_ptr<SerializedLayer<VoxelType>> gatherLayer(uint32_t layer, const std::vector<Index3D>& sel) const {
+    auto out = std::make_shared<SerializedLayer<VoxelType>>();
+    out->block_indices = sel;
+    out->block_offsets.resize(sel.size() + 1);
+    for (size_t i = 0; i <= sel.size(); i++) out->block_offsets[i] = (int)(i * 512);
+    out->voxels.assign(sel.size() * 512, VoxelType());
+    if (!sel.empty())   // blocks without this layer (e.g. no colour yet) stay default-initialised
+      checkNvbx(nvbx_get_blocks(m_, layer, reinterpret_cast<const nvbx_index3d*>(sel.data()), (int64_t)sel.size(), out->voxels.data(), nullptr), "nvbx_get_blocks");
+    return out;
+  }
   void serializeColorMesh() {
     int64_t nb = 0, nv = 0, nt = 0;
     checkNvbx(nvbx_mesh_sizes(m_, &nb, &nv, &nt), "nvbx_mesh_sizes");
@@ -183,6 +225,8 @@ class Mapper {
   std::vector<Index3D> cleared_blocks_;
   DepthImage last_depth_frame_from_pointcloud_{MemoryType::kDevice};
   std::shared_ptr<SerializedColorMeshLayer> serialized_mesh_ = std::make_shared<SerializedColorMeshLayer>();
+  std::shared_ptr<SerializedTsdfLayer> serialized_tsdf_ = std::make_shared<SerializedTsdfLayer>();
+  std::shared_ptr<SerializedColorLayer> serialized_color_ = std::make_shared<SerializedColorLayer>();
 };
 
 }  // namespace nvblox

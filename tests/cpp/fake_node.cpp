@@ -186,6 +186,23 @@ int main(int argc, char** argv) {
   node.processEsdf(&slice, &width, &height, &aabb, &occ);
   size_t mb = 0, mv = 0, mt = 0; double vsum = 0.0;
   node.publishMesh(&mb, &mv, &mt, &vsum);
+  // layer_publishing.cpp:696-711,744-763: colour streaming needs the TSDF layer too, both over the same block list
+  LayerTypeBitMask layers_to_serialize = LayerType::kColor;
+  if (layers_to_serialize & LayerType::kColor) { layers_to_serialize |= LayerType::kTsdf; }
+  BlockExclusionParams block_exclusion_params{
+    .exclusion_center_m = node.T_L_C_depth_.translation(), .exclusion_height_m = -1.f, .exclusion_radius_m = 2.0f,
+    .block_size_m = node.static_mapper_->tsdf_layer().block_size()};
+  node.static_mapper_->serializeSelectedLayers(layers_to_serialize, -1.f, block_exclusion_params);
+  const auto st = node.static_mapper_->serializedTsdfLayer(); const auto sc = node.static_mapper_->serializedColorLayer();
+  if (st->block_indices.size() != sc->block_indices.size()) { std::fprintf(stderr, "layer block lists differ\n"); return 1; }
+  size_t ser_visible = 0;
+  for (size_t i = 0; i < st->block_indices.size(); i++) {
+    const int offset_layer1 = st->block_offsets[i], offset_layer2 = sc->block_offsets[i];
+    for (int lin_index = 0; lin_index < st->block_offsets[i + 1] - offset_layer1; lin_index++) {
+      const TsdfVoxel& v1 = st->voxels[offset_layer1 + lin_index]; const ColorVoxel& v2 = sc->voxels[offset_layer2 + lin_index];
+      if (v1.weight > 0.1f && std::fabs(v1.distance) < 0.05f && v2.weight > 0.f) ser_visible++;      // the TSDF visibility filter (:142-193)
+    }
+  }
   // summary the Python test compares with the ctypes path
   const TsdfLayer& tsdf = node.static_mapper_->tsdf_layer();
   double tsdf_sum = 0.0; size_t observed = 0;
@@ -194,8 +211,8 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < slice.size(); i++) { if (slice[i] < 999.0f) { slice_sum += slice[i]; known++; } if (occ[i] == 100) occupied++; }
   std::printf("{\"tsdf_blocks\": %d, \"color_blocks\": %d, \"esdf_blocks\": %d, \"tsdf_observed\": %zu, \"tsdf_sum\": %.9g, "
               "\"slice_width\": %d, \"slice_height\": %d, \"slice_known\": %zu, \"slice_sum\": %.9g, \"occupied\": %zu, "
-              "\"aabb_min\": [%.6f, %.6f, %.6f], \"mesh_blocks\": %zu, \"mesh_vertices\": %zu, \"mesh_triangle_indices\": %zu, \"mesh_vertex_sum\": %.9g}\n",
+              "\"serialized_blocks\": %zu, \"serialized_visible\": %zu, \"aabb_min\": [%.6f, %.6f, %.6f], \"mesh_blocks\": %zu, \"mesh_vertices\": %zu, \"mesh_triangle_indices\": %zu, \"mesh_vertex_sum\": %.9g}\n",
               tsdf.numAllocatedBlocks(), node.static_mapper_->color_layer().numAllocatedBlocks(), node.static_mapper_->esdf_layer().numAllocatedBlocks(),
-              observed, tsdf_sum, width, height, known, slice_sum, occupied, aabb.min().x(), aabb.min().y(), aabb.min().z(), mb, mv, mt, vsum);
+              observed, tsdf_sum, width, height, known, slice_sum, occupied, st->block_indices.size(), ser_visible, aabb.min().x(), aabb.min().y(), aabb.min().z(), mb, mv, mt, vsum);
   return 0;
 }

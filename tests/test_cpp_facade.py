@@ -81,6 +81,15 @@ def test_facade_matches_ctypes_path(hip_lib, tmp_path):
     assert abs(got["slice_sum"] - float(img[known].astype(np.float64).sum())) <= 1e-6 * max(1.0, abs(got["slice_sum"]))
     assert got["occupied"] == int((img[known] <= 0).sum())
     assert np.allclose(got["aabb_min"], aabb[:3], atol=1e-6)
+    # serialized TSDF + colour layers inside the 2 m exclusion radius around the last camera position
+    T_last = np.asarray(fr[-1][2], np.float64)
+    ctr = (idx + 0.5) * 0.4
+    inside = ((ctr[:, 0] - T_last[0, 3]) ** 2 + (ctr[:, 1] - T_last[1, 3]) ** 2) <= 4.0
+    assert got["serialized_blocks"] == int(inside.sum())
+    cb, cfound = g.get_blocks(M.LAYER_COLOR, idx[inside])
+    tb = blocks[inside]
+    vis = (tb["weight"] > 0.1) & (np.abs(tb["distance"]) < 0.05) & (cb["weight"] > 0) & cfound[:, None]
+    assert got["serialized_visible"] == int(vis.sum())
     assert got["mesh_blocks"] == len(mesh)
     assert got["mesh_vertices"] == sum(len(v["vertices"]) for v in mesh.values())
     assert got["mesh_triangle_indices"] == 3 * sum(len(v["triangles"]) for v in mesh.values())
