@@ -18,18 +18,6 @@ using namespace nvbx;
 // ESDF-only slots are zeroed, maintenance.hip), and weight 0 reads as "unobserved" exactly like a missing block.
 constexpr int RAY_LANES = 8;    // lanes cooperating on one ray = samples fetched per round trip (4: 13.7, 8: 13.4, 16: 14.5, 32: 21.4 us)
 
-// finish a lookup whose first probe `e` at `h` is already loaded (16 B): slot of any block with `key`, or SLOT_NONE
-__device__ inline uint32_t resolve_tsdf_slot(const DMap& m, u64 key, uint32_t h, uint4 e) {
-  for (uint32_t probe = 0; probe <= m.mask; ++probe) {
-    const u64 k = ((u64)e.y << 32) | (u64)e.x;
-    if (k == key) return slot_ok(e.z) ? e.z : SLOT_NONE;
-    if (k == KEY_EMPTY) return SLOT_NONE;
-    h = (h + 1) & m.mask;
-    e = *reinterpret_cast<const uint4*>(&m.table[h]);
-  }
-  return SLOT_NONE;
-}
-
 // [U] SphereTracer::cast restated, sample-parallel.  The serial march t <- t + tsdf(t) (nearest voxel) is a chain of
 // dependent HBM round trips (hash entry, then voxel) plus ~150 ALU ops per step, and a ray takes 10-20 steps.  But the
 // step is PREDICTABLE: exactly `trunc` through free (clamped) or unobserved space, and the same small value while the
@@ -67,7 +55,7 @@ __global__ __launch_bounds__(256) void k_sphere_trace(DMap m, Frame f, float* sy
     const int32_t bx = gx >> 3, by = gy >> 3, bz = gz >> 3;
     const uint32_t h = done ? 0u : table_pos(m, bx, by, bz);
     const uint4 e = *reinterpret_cast<const uint4*>(&m.table[h]);
-    const uint32_t slot = done ? SLOT_NONE : resolve_tsdf_slot(m, pack_key(bx, by, bz), h, e);
+    const uint32_t slot = done ? SLOT_NONE : resolve_any(m, pack_key(bx, by, bz), h, e);
     const float2 v = m.tsdf[slot_ok(slot) ? (size_t)slot * 512 + (gz & 7) + 8 * (gy & 7) + 64 * (gx & 7) : 0];
     // classify the sample as the serial loop body would, assuming every earlier sample of the round kept the prediction
     const bool in_bounds = (i + sub < max_steps) && (tc < max_len);
@@ -229,7 +217,7 @@ extern "C" int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int3
   const int64_t nthreads = (int64_t)srows * scols * RAY_LANES;
   NVBX_LAUNCH(m, k_sphere_trace, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), m->d, f, m->synth, srows, scols, m->p.sphere_tracing_max_steps,
                      m->p.sphere_tracing_max_ray_length_m, m->p.sphere_tracing_surface_eps_vox * m->p.voxel_size);
-  const int grid = (int)std::min<int64_t>(m->capacity, 2048);
+  const int grid = (int)std::min<int64_t>(m->capacity, 1024);     // one resident batch of 512-thread workgroups
   NVBX_LAUNCH(m, k_integrate_color, dim3(grid), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->mesh_list_live());
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;

@@ -29,25 +29,6 @@ constexpr int EDT_MAX_NN = 2 * EDT_MAX_RB + 1;      // 17 x 17 neighbourhood
 constexpr int EDT_MAX_ROWS = 8 + 2 * 63;            // 134 rows of the local strip
 constexpr int EDT_ROW_WORDS = 5;                    // zero pad word + 3 data words (<= 136 bits) + zero pad word
 
-// 16-B entry at a probe position
-__device__ inline uint4 ld_entry(const DMap& m, uint32_t h) { return *reinterpret_cast<const uint4*>(&m.table[h]); }
-
-// finish a lookup whose first probe `e` at `h` is already loaded: slot of any block with `key` (no layer check) or SLOT_NONE
-__device__ inline uint32_t resolve_any(const DMap& m, u64 key, uint32_t h, uint4 e) {
-  for (uint32_t probe = 0; probe <= m.mask; ++probe) {
-    const u64 k = ((u64)e.y << 32) | (u64)e.x;
-    if (k == key) return slot_ok(e.z) ? e.z : SLOT_NONE;
-    if (k == KEY_EMPTY) return SLOT_NONE;
-    h = (h + 1) & m.mask;
-    e = ld_entry(m, h);
-  }
-  return SLOT_NONE;
-}
-__device__ inline uint32_t any_slot(const DMap& m, int32_t x, int32_t y, int32_t z) {
-  const uint32_t h = table_pos(m, x, y, z);
-  return resolve_any(m, pack_key(x, y, z), h, ld_entry(m, h));
-}
-
 // Dependent-access chain: {shard counts of the dirty list} -> {dirty slot} -> {flags, Index3D} -> {hash entries of the ESDF block and of the
 // TSDF z-band blocks, one per lane, in flight together} -> {column stamp exchange || TSDF column loads} -> store.
 __global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a) {

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
   __shared__ int32_t s_vid[NEDGE];
   __shared__ uint16_t s_tri_edges[MAXTRI * 3];
   __shared__ uint32_t s_nslot[8];
-  __shared__ uint32_t s_nflags[8];
+  __shared__ uint16_t s_vedge[NEDGE];     // welded vertex id -> lattice edge id
   __shared__ int s_part[8];
   __shared__ int s_base[3];
   const int tid = threadIdx.x;
@@ -94,11 +94,10 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
     }
     const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
     __syncthreads();                                                     // previous iteration done with LDS
-    if (tid < 8) {
-      const uint32_t ns = tid == 0 ? slot : find_slot(m, bx + (tid & 1), by + ((tid >> 1) & 1), bz + ((tid >> 2) & 1), F_TSDF);
-      s_nslot[tid] = ns;
-      s_nflags[tid] = slot_ok(ns) ? m.slot_flags[ns] : 0u;
-    }
+    if (tid < 8)      // neighbour blocks: no layer-flag load (a slot without TSDF / colour reads zero weights, nvbx_internal.h)
+      s_nslot[tid] = tid == 0 ? slot
+                   : (a.min_weight > 0.0f ? any_slot(m, bx + (tid & 1), by + ((tid >> 1) & 1), bz + ((tid >> 2) & 1))
+                                          : find_slot(m, bx + (tid & 1), by + ((tid >> 1) & 1), bz + ((tid >> 2) & 1), F_TSDF));   // (weight 0 would pass a min_weight of 0)
     if (tid == 0) { atomicAnd(&m.slot_flags[slot], ~F_DIRTY_MESH); atomicOr(&m.slot_flags[slot], F_MESH); }
     for (int e = tid; e < NEDGE; e += 512) s_first[e] = INT32_MAX;
     __syncthreads();
@@ -140,7 +139,10 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
     int V;
     int voff = block_scan_512(cnt, s_part, tid, &V);
 #pragma unroll
-    for (int k = 0; k < 5; k++) { const int e = tid * 5 + k; if (e < NEDGE) s_vid[e] = (s_first[e] != INT32_MAX) ? voff++ : -1; }
+    for (int k = 0; k < 5; k++) {
+      const int e = tid * 5 + k;
+      if (e < NEDGE) { const bool on = s_first[e] != INT32_MAX; if (on) s_vedge[voff] = (uint16_t)e; s_vid[e] = on ? voff++ : -1; }
+    }
     if (tid == 0) {
       // ONE returning atomic per block: the vertex and triangle arena cursors share a 64-bit word (three separate
       // counters cost 3 x ~12 ns x #blocks of serialised L2 atomics: 8.4 of the kernel's 28 us at 300 blocks)
@@ -162,12 +164,10 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
     if (vbase < 0) continue;                                             // uniform (arena overflow)
     // emit vertices
     const int32_t b3[3] = {bx, by, bz};
+    // one welded vertex per thread (a block has ~25-150 of them): balanced, unlike walking the 2187 edge ids
 #pragma unroll 1
-    for (int k = 0; k < 5; k++) {
-      const int e = tid * 5 + k;
-      if (e >= NEDGE) break;
-      const int vid = s_vid[e];
-      if (vid < 0) continue;
+    for (int vid = tid; vid < V; vid += 512) {
+      const int e = s_vedge[vid];
       int li, lj, axis, lx, ly, lz;
       edge_decode(e, &li, &lj, &axis, &lx, &ly, &lz);
       const float da = s_d[li], db = s_d[lj];
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
       const int cz = lc % 9, cy = (lc / 9) % 9, cx = lc / 81;
       const int nb = (cx >> 3) | ((cy >> 3) << 1) | ((cz >> 3) << 2);
       uint32_t rgba = 127u | (127u << 8) | (127u << 16);
-      if (s_nflags[nb] & F_COLOR) {
+      if (slot_ok(s_nslot[nb])) {
         const uint2 cv = m.color[(size_t)s_nslot[nb] * 512 + (cz & 7) + 8 * (cy & 7) + 64 * (cx & 7)];
         if (__uint_as_float(cv.y) > 0.0f) rgba = cv.x & 0x00FFFFFFu;
       }
@@ -240,7 +240,9 @@ extern "C" int nvbx_update_color_mesh(nvbx_mapper* m, int32_t update_full_layer)
   a.rec = C_MESH_OUT + 4 * par; a.rec_next = C_MESH_OUT + 4 * (par ^ 1);
   a.srec = S_MESH_REC + par; a.srec_next = S_MESH_REC + (par ^ 1);
   a.vert_cap = m->mesh_vert_cap / NSH; a.tri_cap = m->mesh_tri_cap / NSH;
-  const int grid = (int)std::min<int64_t>(m->capacity, 2048);
+  // 37 KB of LDS per workgroup -> 4 resident per CU: keep the grid within one resident batch (a 2048-workgroup grid ran
+  // as two batches, the second waiting ~10 us for the first to drain); longer lists are covered by the grid-stride loop
+  const int grid = (int)std::min<int64_t>(m->capacity, 768);
   NVBX_LAUNCH(m, k_mesh, dim3(grid), dim3(512), m->d, a, m->mesh_vert, m->mesh_nrm, (uint32_t*)m->mesh_col,
                      m->mesh_tri, m->mesh_rec);
   NVBX_HIP(hipGetLastError());

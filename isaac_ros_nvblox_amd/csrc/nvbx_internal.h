@@ -173,6 +173,26 @@ __device__ inline uint32_t find_slot(const DMap& m, int32_t x, int32_t y, int32_
   return (m.slot_flags[s] & layer) ? s : SLOT_NONE;
 }
 
+// Lookups WITHOUT a layer-flag check (one 16-B entry load per probe = key + slot + stamp).  Valid wherever the pool of a
+// slot that lacks the layer reads as "nothing there": the TSDF and colour pools and site_bits of such slots are all-zero
+// (zeroed on free, never written otherwise), and weight 0 means unobserved / uncoloured exactly like a missing block.
+__device__ inline uint4 ld_entry(const DMap& m, uint32_t h) { return *reinterpret_cast<const uint4*>(&m.table[h]); }
+// finish a lookup whose first probe `e` at `h` is already loaded: slot of any block with `key`, or SLOT_NONE
+__device__ inline uint32_t resolve_any(const DMap& m, u64 key, uint32_t h, uint4 e) {
+  for (uint32_t probe = 0; probe <= m.mask; ++probe) {
+    const u64 k = ((u64)e.y << 32) | (u64)e.x;
+    if (k == key) return slot_ok(e.z) ? e.z : SLOT_NONE;
+    if (k == KEY_EMPTY) return SLOT_NONE;
+    h = (h + 1) & m.mask;
+    e = ld_entry(m, h);
+  }
+  return SLOT_NONE;
+}
+__device__ inline uint32_t any_slot(const DMap& m, int32_t x, int32_t y, int32_t z) {
+  const uint32_t h = table_pos(m, x, y, z);
+  return resolve_any(m, pack_key(x, y, z), h, ld_entry(m, h));
+}
+
 // Insert-if-absent. Device-scope CAS on the key decides the winner; the winner pops a pool slot and publishes it with
 // an agent-scope store.  `is_new` tells the caller it won.  Returns the entry index or -1 (table full).
 __device__ inline int32_t hash_insert(const DMap& m, int32_t x, int32_t y, int32_t z, uint32_t layer_flags, bool* is_new) {
