@@ -111,3 +111,17 @@ def test_camera_facing_unmapped_space_then_back(oracle_mod, hip_lib):
     assert (bg["distance"][bg["weight"] > 0] > 0).mean() > 0.9     # nearly everything within 1 m is free space
     g.update_color_mesh(); o.update_mesh()
     assert sum(len(v["triangles"]) for v in g.mesh().values()) == sum(len(o.mesh_block(i)["triangles"]) for i in io)
+
+
+def test_side_stream_option_keeps_parity():
+    """NVBX_SIDE_STREAM=1 (ESDF update on a side stream beside the colour pass) must not change results:
+    run the colour / ESDF / mesh / multi-mapper parity tests in a subprocess with the option on."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NVBX_SIDE_STREAM="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_parity.py", "tests/test_gpu_multi.py",
+                        "-k", "esdf or color or mesh or decay or dirty"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
