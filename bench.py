@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--unique-frames", type=int, default=50, help="distinct rendered frames cycled through (HBM-resident)")
-    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the same workload timed on the CPU oracle")
+    ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="camera", choices=["camera", "lidar"],
                     help="camera = BASELINE.json configs[1] (the metric's configuration, default); lidar = configs[4] "
