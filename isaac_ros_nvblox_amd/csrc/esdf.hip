@@ -7,12 +7,13 @@
 // Per update, TWO launches, all sizes decided on the device (no host read-back, no scratch image):
 //   k_esdf_mark    one wave per dirty TSDF block: insert the ESDF block (x, y, z_slice), de-duplicate columns with an
 //                  epoch stamp, scan the TSDF z-band (each lane owns one (x,y) column = 64 contiguous bytes per TSDF
-//                  block) -> observed / inside / site flags, site mask = __ballot; grows the dirty window (atomicMin/Max).
-//   k_esdf_edt     one wave per ESDF block of the window (dirty AABB + R): gathers the site masks of the (2R/8+1)^2
+//                  block) -> observed / inside / site flags, site mask = __ballot; grows the dirty window (atomicMin/Max on
+//                  the workgroup's shard of the window record).
+//   k_esdf_edt     four waves per ESDF block of the window (dirty AABB + R): gathers the site masks of the (2R/8+1)^2
 //                  surrounding blocks through the hash into LDS, expands them to a local row bitmap, finds the nearest
 //                  site along x by clz/ctz on 64-bit words (row pass, int8 dx in LDS), then minimises dy^2 + dx^2 over dy
-//                  in order of increasing |dy| with early exit (column pass) and writes {sq, parent, flags} back as one
-//                  8-byte store per lane.
+//                  in order of increasing |dy| with early exit (column pass, split over the 4 waves and merged by a packed
+//                  integer min) and writes {sq, parent, flags} back as one 8-byte store per lane.
 // Call sites served: nvblox_ros/src/lib/nvblox_node.cpp:781 (updateEsdf), :836-844 (sliceLayerToDistanceImage),
 // :917-919 (occupancyGridFromSliceImage); conversions/esdf_slice_conversions.cu:33-73; esdf_and_gradients_conversions.cu:88-125.
 #include <algorithm>

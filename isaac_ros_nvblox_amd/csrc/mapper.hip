@@ -50,14 +50,13 @@ __global__ void k_collect_indices(DMap m, uint32_t layer, int32_t* out, int32_t 
 }
 __global__ void k_zero_tmp(DMap m) { m.counters[C_TMP] = 0; }
 
-// list (hash-entry ids or slots) -> Index3D
-__global__ void k_list_to_indices(DMap m, const int32_t* list, int32_t stride, int32_t count_idx, int32_t is_entry, int32_t* out, int32_t cap) {
+// view list ({slot, x, y, z} records of one frame) -> Index3D
+__global__ void k_viewlist_to_indices(DMap m, const int4* list, int32_t count_idx, int32_t* out, int32_t cap) {
   int32_t n = m.counters[count_idx]; if (n > cap) n = cap;
   for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    uint32_t s = (uint32_t)list[(int64_t)i * stride];
-    if (is_entry) s = m.table[s].slot;
-    if (slot_ok(s) && m.slot_flags[s]) { out[3 * i] = m.slot_index[3 * s]; out[3 * i + 1] = m.slot_index[3 * s + 1]; out[3 * i + 2] = m.slot_index[3 * s + 2]; }
-    else { out[3 * i] = INT32_MIN; out[3 * i + 1] = INT32_MIN; out[3 * i + 2] = INT32_MIN; }
+    const int4 r = list[i];
+    const bool ok = slot_ok((uint32_t)r.x) && m.slot_flags[(uint32_t)r.x];
+    out[3 * i] = ok ? r.y : INT32_MIN; out[3 * i + 1] = ok ? r.z : INT32_MIN; out[3 * i + 2] = ok ? r.w : INT32_MIN;
   }
 }
 
@@ -334,11 +333,13 @@ extern "C" int64_t nvbx_block_indices(nvbx_mapper* m, uint32_t layer, nvbx_index
 }
 extern "C" int64_t nvbx_num_blocks(nvbx_mapper* m, uint32_t layer) { return nvbx_block_indices(m, layer, nullptr, 0); }
 
-static int64_t list_indices(nvbx_mapper* m, const int32_t* list, int stride, int count_idx, int is_entry, nvbx_index3d* out, int64_t capacity) {
+extern "C" int64_t nvbx_last_depth_view(nvbx_mapper* m, nvbx_index3d* out, int64_t capacity) {
+  if (!m) return NVBX_E_INVALID;
+  if (m->last_view_frame == 0) return 0;
   if (m->join_side()) return NVBX_E_DEVICE;
-  NVBX_LAUNCH(m, k_list_to_indices, dim3(64), dim3(256), m->d, list, stride, count_idx, is_entry, m->export_idx, (int32_t)m->capacity);
+  NVBX_LAUNCH(m, k_viewlist_to_indices, dim3(64), dim3(256), m->d, (const int4*)m->view_list, C_VIEW_COUNT + (int)(m->last_view_frame & 3), m->export_idx, (int32_t)m->capacity);
   if (m->fetch_counters()) return NVBX_E_DEVICE;
-  int64_t n = m->h_counters[count_idx]; if (n > m->capacity) n = m->capacity;
+  int64_t n = m->h_counters[C_VIEW_COUNT + (m->last_view_frame & 3)]; if (n > m->capacity) n = m->capacity;
   const int64_t k = std::min<int64_t>(n, capacity);
   if (out && k > 0) {
     std::vector<nvbx_index3d> tmp((size_t)n);
@@ -347,11 +348,6 @@ static int64_t list_indices(nvbx_mapper* m, const int32_t* list, int stride, int
     memcpy(out, tmp.data(), (size_t)k * 12);
   }
   return n;
-}
-extern "C" int64_t nvbx_last_depth_view(nvbx_mapper* m, nvbx_index3d* out, int64_t capacity) {
-  if (!m) return NVBX_E_INVALID;
-  if (m->last_view_frame == 0) return 0;
-  return list_indices(m, m->view_list, 4, C_VIEW_COUNT + (int)(m->last_view_frame & 3), 0, out, capacity);
 }
 extern "C" int64_t nvbx_last_color_view(nvbx_mapper* m, nvbx_index3d* out, int64_t capacity) {
   if (!m) return NVBX_E_INVALID;

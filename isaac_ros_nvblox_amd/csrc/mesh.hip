@@ -4,9 +4,10 @@
 // blocks, found by 8 hash probes) is staged in LDS once; thread = cube in z + 8y + 64x order.  Triangle offsets come
 // from a block-wide exclusive scan (wave shuffles + 8 partials), vertices are welded by construction: every vertex
 // lives on one lattice edge (corner, axis), `atomicMin` in LDS records the first triangle of each crossed edge, a
-// second scan over the 2187 possible edges numbers the vertices in ascending edge id.  A single returning atomicAdd per
-// block reserves space in the pre-allocated vertex / triangle arenas, so there is no count -> host -> alloc -> emit
-// round trip ([U] MeshIntegrator is two-pass with a host sync in between).
+// second scan over the 2187 possible edges numbers the vertices in ascending edge id and records vertex id -> edge id, so
+// that every thread emits exactly one vertex.  A single returning 64-bit atomicAdd per block (vertex | triangle cursor of
+// the workgroup's shard region) reserves space in the pre-allocated arenas, so there is no count -> host -> alloc ->
+// emit round trip ([U] MeshIntegrator is two-pass with a host sync in between).
 // Ordering contract (shared with the oracle): vertices ascending edge id ((lx*9+ly)*9+lz)*3+axis; triangles in cube
 // order then table order; vertex normal = normal of the first triangle referencing it; colour = nearest colour voxel.
 // Call sites served: nvblox_ros/src/lib/layer_publishing.cpp:686-689, nvblox_node.cpp:1611; output contract
