@@ -42,6 +42,18 @@ struct SerializedLayer {
 using SerializedTsdfLayer = SerializedLayer<TsdfVoxel>;
 using SerializedColorLayer = SerializedLayer<ColorVoxel>;
 
+// BoundingShape (sphere or AABB) as built by the EsdfAndGradients service's clearing request
+// (conversions/esdf_and_gradients_conversions.cu:127-180) and passed to Mapper::clearTsdfInsideShapes (nvblox_node.cpp:1834)
+struct BoundingSphere { Vector3f center; float radius = 0.f; BoundingSphere() = default; BoundingSphere(const Vector3f& c, float r) : center(c), radius(r) {} };
+class BoundingShape {
+ public:
+  BoundingShape(const BoundingSphere& s) { c_.kind = 0; for (int i = 0; i < 3; i++) { c_.a[i] = s.center[i]; c_.b[i] = 0.f; } c_.b[0] = s.radius; }   // NOLINT
+  BoundingShape(const AxisAlignedBoundingBox& b) { c_.kind = 1; for (int i = 0; i < 3; i++) { c_.a[i] = b.min()[i]; c_.b[i] = b.max()[i]; } }          // NOLINT
+  const nvbx_bounding_shape& c_abi() const { return c_; }
+ private:
+  nvbx_bounding_shape c_{};
+};
+
 class Mapper {
  public:
   static constexpr int64_t kDefaultBlockCapacity = 1 << 16;   // 64 k blocks = 768 MiB of voxel pools in HBM
@@ -114,6 +126,11 @@ class Mapper {
     const std::vector<Index3D> after = tsdf_layer_.getAllBlockIndices();   // both sorted
     size_t j = 0;
     for (const auto& b : before) { while (j < after.size() && after[j] < b) j++; if (j >= after.size() || !(after[j] == b)) cleared_blocks_.push_back(b); }
+  }
+  void clearTsdfInsideShapes(const std::vector<BoundingShape>& shapes) {   // nvblox_node.cpp:1834
+    std::vector<nvbx_bounding_shape> c; c.reserve(shapes.size());
+    for (const auto& s : shapes) c.push_back(s.c_abi());
+    checkNvbx(nvbx_clear_tsdf_inside_shapes(m_, c.data(), (int32_t)c.size()), "nvbx_clear_tsdf_inside_shapes");
   }
   // layer_publishing.cpp:716: blocks removed since the last call
   std::vector<Index3D> getClearedBlocks(const std::vector<uint32_t>& = {}) { std::vector<Index3D> out; out.swap(cleared_blocks_); return out; }

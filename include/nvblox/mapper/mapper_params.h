@@ -8,7 +8,7 @@
 
 namespace nvblox {
 
-enum class WorkspaceBoundsType { kUnbounded, kHeightBounds, kBoundingBox };   // mapper_initialization.cpp:44-60
+enum class WorkspaceBoundsType { kUnbounded = 0, kHeightBounds = 1, kBoundingBox = 2 };   // mapper_initialization.cpp:62-80
 enum class EsdfMode { k3D, k2D };                                             // node_params.hpp:86-91
 enum class MappingType { kStaticTsdf, kStaticOccupancy, kDynamic, kHumanWithStaticTsdf, kHumanWithStaticOccupancy };
 enum class ProjectiveLayerType { kTsdf, kOccupancy, kNone };
@@ -92,6 +92,11 @@ struct MapperParams {
     p.lidar_linear_interpolation_max_allowable_difference_vox = 2.0f;
     p.lidar_nearest_interpolation_max_allowable_dist_to_ray_vox = 0.5f;
     p.invalid_depth_decay_factor = projective_integrator_params.projective_tsdf_integrator_invalid_depth_decay_factor;
+    p.workspace_bounds_type = (int32_t)view_calculator_params.workspace_bounds_type;
+    p.workspace_bounds_min_corner_m[0] = view_calculator_params.workspace_bounds_min_corner_x_m; p.workspace_bounds_min_corner_m[1] = view_calculator_params.workspace_bounds_min_corner_y_m;
+    p.workspace_bounds_min_corner_m[2] = view_calculator_params.workspace_bounds_min_height_m;
+    p.workspace_bounds_max_corner_m[0] = view_calculator_params.workspace_bounds_max_corner_x_m; p.workspace_bounds_max_corner_m[1] = view_calculator_params.workspace_bounds_max_corner_y_m;
+    p.workspace_bounds_max_corner_m[2] = view_calculator_params.workspace_bounds_max_height_m;
     return p;
   }
 };

@@ -87,6 +87,9 @@ typedef struct {
   float lidar_max_integration_distance_m; /* lidar_projective_integrator_max_integration_distance_m (mapper_initialization.cpp:271-276) */
   float lidar_linear_interpolation_max_allowable_difference_vox;    /* [U] 2.0: bilinear taps must agree within this */
   float lidar_nearest_interpolation_max_allowable_dist_to_ray_vox;  /* [U] 0.5: nearest-beam fallback acceptance */
+  int32_t workspace_bounds_type;          /* 0 unbounded, 1 height_bounds, 2 bounding_box (mapper_initialization.cpp:62-80,337-358) */
+  float workspace_bounds_min_corner_m[3]; /* workspace_bounds_min_corner_{x,y}_m, workspace_bounds_min_height_m */
+  float workspace_bounds_max_corner_m[3]; /* workspace_bounds_max_corner_{x,y}_m, workspace_bounds_max_height_m */
   float invalid_depth_decay_factor;       /* projective_tsdf_integrator_invalid_depth_decay_factor (mapper_initialization.cpp:294-300;
                                              -1 = off, nvblox_base.yaml:80; 0.8 in nvblox_dynamics.yaml:11) */
 } nvbx_mapper_params;
@@ -159,6 +162,13 @@ int nvbx_update_color_mesh(nvbx_mapper* m, int32_t update_full_layer);
 int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view);
 /* Mapper::clearOutsideRadius(center, radius) -- nvblox_node.cpp:1566-1583 */
 int nvbx_clear_outside_radius(nvbx_mapper* m, const float center[3], float radius);
+
+/* Mapper::clearTsdfInsideShapes(std::vector<BoundingShape>) -- nvblox_node.cpp:1834 (the EsdfAndGradients service's
+ * clearing request, conversions/esdf_and_gradients_conversions.cu:127-180).  A shape is a sphere (kind 0: centre, radius)
+ * or an axis-aligned box (kind 1: min corner, max corner); TSDF voxels whose centre lies inside any shape are reset to
+ * unobserved (distance 0, weight 0) and their blocks become ESDF / mesh dirty. */
+typedef struct { int32_t kind; float a[3]; float b[3]; } nvbx_bounding_shape;   /* sphere: a = centre, b[0] = radius; box: a = min, b = max */
+int nvbx_clear_tsdf_inside_shapes(nvbx_mapper* m, const nvbx_bounding_shape* shapes_host, int32_t n_shapes);
 
 /* ---- ESDF slice (EsdfSlicer) ------------------------------------------------------------------------------------
  * EsdfSlicer::sliceLayerToDistanceImage(esdf_layer, slice_height, unknown_value, &aabb, &Image<float>) --

@@ -35,6 +35,9 @@ class Params(C.Structure):
         ("lidar_max_integration_distance_m", C.c_float),
         ("lidar_linear_interpolation_max_allowable_difference_vox", C.c_float),
         ("lidar_nearest_interpolation_max_allowable_dist_to_ray_vox", C.c_float),
+        ("workspace_bounds_type", C.c_int32),
+        ("workspace_bounds_min_corner_m", C.c_float * 3),
+        ("workspace_bounds_max_corner_m", C.c_float * 3),
         ("invalid_depth_decay_factor", C.c_float),
     ]
 
@@ -47,6 +50,10 @@ class Camera(C.Structure):
 class Lidar(C.Structure):
     _fields_ = [("num_azimuth_divisions", C.c_int32), ("num_elevation_divisions", C.c_int32),
                 ("min_valid_range_m", C.c_float), ("min_elevation_rad", C.c_float), ("max_elevation_rad", C.c_float)]
+
+
+class BoundingShape(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("a", C.c_float * 3), ("b", C.c_float * 3)]
 
 
 class Index3D(C.Structure):
@@ -79,6 +86,7 @@ SIGNATURES = {
     "nvbx_update_color_mesh": (C.c_int, [_vp, _i32]),
     "nvbx_decay_tsdf": (C.c_int, [_vp, _i32]),
     "nvbx_clear_outside_radius": (C.c_int, [_vp, _vp, _f]),
+    "nvbx_clear_tsdf_inside_shapes": (C.c_int, [_vp, _vp, _i32]),
     "nvbx_esdf_slice_size": (C.c_int, [_vp, _pi32, _pi32, _vp]),
     "nvbx_esdf_slice_to_image": (C.c_int, [_vp, _f, _vp, _i64, _pi32, _pi32, _vp]),
     "nvbx_esdf_slice_to_host": (C.c_int, [_vp, _f, _vp, _i64, _pi32, _pi32, _vp]),

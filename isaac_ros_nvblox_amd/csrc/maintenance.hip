@@ -71,6 +71,50 @@ __global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float c
   }
 }
 
+// Mapper::clearTsdfInsideShapes (nvblox_node.cpp:1834): one workgroup per TSDF block, lane = voxel; the shape list sits in
+// kernel-argument space (<= 16 shapes per launch)
+struct ShapeArgs { int32_t n; nvbx_bounding_shape s[16]; };
+__global__ __launch_bounds__(512) void k_clear_shapes(DMap m, ShapeArgs sh, float vs, float bs, int32_t mesh_list) {
+  __shared__ int s_touched;
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  const int tid = threadIdx.x;
+  const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
+  for (int32_t slot = blockIdx.x; slot < hw; slot += gridDim.x) {
+    if (!(m.slot_flags[slot] & F_TSDF)) continue;
+    __syncthreads();
+    if (tid == 0) s_touched = 0;
+    __syncthreads();
+    const float px = voxel_center(m.slot_index[3 * slot], vx, bs, vs), py = voxel_center(m.slot_index[3 * slot + 1], vy, bs, vs),
+                pz = voxel_center(m.slot_index[3 * slot + 2], vz, bs, vs);
+    bool inside = false;
+    for (int k = 0; k < sh.n && !inside; k++) {
+      const nvbx_bounding_shape& q = sh.s[k];
+      if (q.kind == 0) { const float dx = px - q.a[0], dy = py - q.a[1], dz = pz - q.a[2]; inside = ((dx * dx + dy * dy) + dz * dz) <= q.b[0] * q.b[0]; }
+      else inside = px >= q.a[0] && py >= q.a[1] && pz >= q.a[2] && px <= q.b[0] && py <= q.b[1] && pz <= q.b[2];
+    }
+    if (inside) { m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f); s_touched = 1; }
+    __syncthreads();
+    if (tid == 0 && s_touched) {
+      const uint32_t old = atomicOr(&m.slot_flags[slot], F_DIRTY_ESDF | F_DIRTY_MESH);
+      if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, slot);
+      if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, slot);
+    }
+  }
+}
+extern "C" int nvbx_clear_tsdf_inside_shapes(nvbx_mapper* m, const nvbx_bounding_shape* shapes_host, int32_t n_shapes) {
+  if (!m || n_shapes < 0 || (n_shapes > 0 && !shapes_host)) return NVBX_E_INVALID;
+  NVBX_HIP(hipSetDevice(m->device));
+  if (m->join_side()) return NVBX_E_DEVICE;
+  const int grid = (int)std::min<int64_t>(m->capacity, 1024);
+  for (int32_t o = 0; o < n_shapes; o += 16) {
+    ShapeArgs a{}; a.n = std::min(16, n_shapes - o);
+    for (int i = 0; i < a.n; i++) a.s[i] = shapes_host[o + i];
+    NVBX_LAUNCH(m, k_clear_shapes, dim3(grid), dim3(512), m->d, a, m->p.voxel_size, m->p.voxel_size * 8.0f, m->mesh_list_live());
+  }
+  NVBX_HIP(hipGetLastError());
+  return m->mark_main();
+}
+
 // rebuild: (1) remember each live slot's view stamp, (2) memset table, (3) re-insert live slots, recompute ESDF AABB
 __global__ void k_save_stamps(DMap m, uint32_t* tmp) {
   const int32_t hw = m.counters[C_HIGH_WATER];

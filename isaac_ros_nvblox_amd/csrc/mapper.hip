@@ -214,6 +214,8 @@ Frame nvbx_mapper::make_frame(const float T[16], const nvbx_camera* cam, int32_t
   f.max_dist = p.max_integration_distance_m; f.max_weight = p.max_weight;
   f.weighting_mode = p.weighting_mode; f.interp_nearest = p.depth_interp_nearest;
   f.invalid_decay = p.invalid_depth_decay_factor;
+  f.ws_type = p.workspace_bounds_type;
+  for (int i = 0; i < 3; i++) { f.ws_min[i] = p.workspace_bounds_min_corner_m[i]; f.ws_max[i] = p.workspace_bounds_max_corner_m[i]; }
   f.subsample = subsample < 1 ? 1 : subsample;
   f.n_ray_rows = 0; f.n_ray_cols = 0;
   f.frame_id = frame_id;

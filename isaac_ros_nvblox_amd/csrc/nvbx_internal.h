@@ -91,6 +91,7 @@ struct Frame {
   float voxel_size, block_size, trunc, max_dist, max_weight;
   int32_t weighting_mode, interp_nearest;
   float invalid_decay;      // invalid_depth_decay_factor (< 0 = off)
+  int32_t ws_type; float ws_min[3], ws_max[3];   // workspace bounds of the view calculator (0 = unbounded)
   int32_t subsample;        // raycast / sphere-tracing subsampling
   int32_t n_ray_rows, n_ray_cols;
   uint32_t frame_id;

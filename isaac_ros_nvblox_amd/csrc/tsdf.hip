@@ -155,6 +155,19 @@ __device__ inline void view_append(int32_t* cnt, int4* view_list, int32_t list_c
   }
 }
 
+// [U] workspace bounds of the view calculator (workspace_bounds_type, mapper_initialization.cpp:337-358): a block is kept
+// iff its cube overlaps the bounds (height bounds: z only)
+__device__ inline bool block_in_workspace(const Frame& f, const int32_t* cur) {
+  if (f.ws_type == 0) return true;
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    if (f.ws_type == 1 && a < 2) continue;
+    const float lo = (float)cur[a] * f.block_size, hi = (float)(cur[a] + 1) * f.block_size;
+    if (!(hi > f.ws_min[a]) || !(lo < f.ws_max[a])) ok = false;
+  }
+  return ok;
+}
 // insert `key` into the tile's LDS set; false = probe window exhausted (caller sends the key to HBM itself)
 template <int LSET>
 __device__ inline bool lset_insert(u64* lset, const int32_t* cur, u64 key, bool* added) {
@@ -311,7 +324,7 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
     for (int32_t k = 0; k <= nsteps; k++) {
       bool added;
       const u64 key = pack_key(cur[0], cur[1], cur[2]);
-      const bool spill = !lset_insert<LSET>(lset, cur, key, &added);
+      const bool spill = block_in_workspace(f, cur) && !lset_insert<LSET>(lset, cur, key, &added);
       if (__ballot(spill)) {                     // probe window exhausted (rare): this key goes to HBM directly
         int4 rec = make_int4(0, 0, 0, 0);
         const bool first = spill && mark_block(m, key, f.frame_id, &rec);
@@ -330,7 +343,7 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
     u64 key = KEY_EMPTY;
     if (k <= nsteps) {
       key = pack_key(cur[0], cur[1], cur[2]);
-      spill = !lset_insert<LSET>(lset, cur, key, &added);
+      spill = block_in_workspace(f, cur) && !lset_insert<LSET>(lset, cur, key, &added);
       dda_step(cur, step, tmax, tdelta);
     }
     nset += (int32_t)__popcll(__ballot(added));

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Camera, Counters, Index3D, Lidar, Params
+from ._lib import BoundingShape, Camera, Counters, Index3D, Lidar, Params
 
 LAYER_TSDF, LAYER_COLOR, LAYER_ESDF, LAYER_MESH = 1, 2, 4, 8
 
@@ -195,6 +195,16 @@ class Mapper:
     def clear_outside_radius(self, center, radius):
         c = np.asarray(center, np.float32)
         self._check(self.lib.nvbx_clear_outside_radius(self._h, _np_ptr(c), float(radius)))
+
+    def clear_tsdf_inside_shapes(self, shapes):
+        """shapes: list of ("sphere", centre, radius) / ("aabb", min_corner, max_corner)."""
+        arr = (BoundingShape * max(1, len(shapes)))()
+        for i, sh in enumerate(shapes):
+            if sh[0] == "sphere":
+                arr[i].kind = 0; arr[i].a[:] = [float(v) for v in sh[1]]; arr[i].b[:] = [float(sh[2]), 0.0, 0.0]
+            else:
+                arr[i].kind = 1; arr[i].a[:] = [float(v) for v in sh[1]]; arr[i].b[:] = [float(v) for v in sh[2]]
+        self._check(self.lib.nvbx_clear_tsdf_inside_shapes(self._h, C.cast(arr, C.c_void_p), len(shapes)))
 
     # -- queries (synchronise)
     def counters(self):

@@ -41,6 +41,9 @@ class OrcParams(C.Structure):
         ("lidar_max_integration_distance_m", C.c_float),
         ("lidar_linear_interpolation_max_allowable_difference_vox", C.c_float),
         ("lidar_nearest_interpolation_max_allowable_dist_to_ray_vox", C.c_float),
+        ("workspace_bounds_type", C.c_int32),
+        ("workspace_bounds_min_corner_m", C.c_float * 3),
+        ("workspace_bounds_max_corner_m", C.c_float * 3),
         ("invalid_depth_decay_factor", C.c_float),
     ]
 
@@ -107,6 +110,7 @@ def lib():
         L.orc_mesh_counts.restype = C.c_int; L.orc_mesh_counts.argtypes = [vp, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
         L.orc_mesh_get.restype = C.c_int; L.orc_mesh_get.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
         L.orc_decay_tsdf.restype = i64; L.orc_decay_tsdf.argtypes = [vp, C.c_int]
+        L.orc_clear_tsdf_inside_shapes.restype = i64; L.orc_clear_tsdf_inside_shapes.argtypes = [vp, vp, i32]
         L.orc_clear_outside_radius.restype = i64; L.orc_clear_outside_radius.argtypes = [vp, vp, C.c_float]
         L.orc_mark_esdf_dirty.restype = i64; L.orc_mark_esdf_dirty.argtypes = [vp, vp, i64]
         L.orc_esdf_dirty_list.restype = i64; L.orc_esdf_dirty_list.argtypes = [vp, vp, i64]
@@ -241,6 +245,14 @@ class OracleMap:
 
     def decay_tsdf(self, exclude_last_view=True):
         return lib().orc_decay_tsdf(self._h, int(exclude_last_view))
+
+    def clear_tsdf_inside_shapes(self, shapes):
+        rows = []
+        for sh in shapes:
+            rows.append([0.0] + [float(v) for v in sh[1]] + [float(sh[2]), 0.0, 0.0] if sh[0] == "sphere"
+                        else [1.0] + [float(v) for v in sh[1]] + [float(v) for v in sh[2]])
+        a = np.ascontiguousarray(np.asarray(rows, np.float32).reshape(-1, 7))
+        return lib().orc_clear_tsdf_inside_shapes(self._h, _p(a), a.shape[0])
 
     def clear_outside_radius(self, center, radius):
         c = np.asarray(center, np.float32)

@@ -79,6 +79,9 @@ typedef struct {
   float lidar_max_integration_distance_m;  /* lidar_projective_integrator_max_integration_distance_m, mapper_initialization.cpp:271-276 */
   float lidar_linear_interpolation_max_allowable_difference_vox;   /* [U] 2.0 */
   float lidar_nearest_interpolation_max_allowable_dist_to_ray_vox; /* [U] 0.5 */
+  int32_t workspace_bounds_type;        /* 0 unbounded, 1 height_bounds, 2 bounding_box (mapper_initialization.cpp:62-80) */
+  float workspace_bounds_min_corner_m[3];
+  float workspace_bounds_max_corner_m[3];
   float invalid_depth_decay_factor;     /* projective_tsdf_integrator_invalid_depth_decay_factor; < 0 = off */
 } OrcParams;
 
@@ -296,7 +299,20 @@ static inline float weight_fn(int mode, float d_meas, float d_vox, float trunc) 
 /* ------------------------------------------------------------------ view calculation */
 /* [U] ViewCalculator::getBlocksInImageViewRaycast restated: one ray per subsampled pixel (overhang clamped to the
  * border), end point at depth+trunc (clipped to max integration distance), Amanatides-Woo walk through the block grid. */
+/* [U] workspace bounds of the view calculator: a block is kept iff its cube overlaps the bounds (height bounds: the z
+ * interval only; bounding box: all three axes); unbounded keeps everything. */
+static int block_in_workspace(const OrcParams* p, Idx3 i) {
+  if (p->workspace_bounds_type == 0) return 1;
+  const float bs = p->voxel_size * 8.0f;
+  const int32_t idx[3] = {i.x, i.y, i.z};
+  for (int a = (p->workspace_bounds_type == 1 ? 2 : 0); a < 3; a++) {
+    const float lo = (float)idx[a] * bs, hi = (float)(idx[a] + 1) * bs;
+    if (!(hi > p->workspace_bounds_min_corner_m[a]) || !(lo < p->workspace_bounds_max_corner_m[a])) return 0;
+  }
+  return 1;
+}
 static void view_push(OrcMap* m, Idx3 i) {
+  if (!block_in_workspace(&m->p, i)) return;
   Block* b = map_get_or_create(m, i);
   if (b->stamp_view == m->frame) return;
   b->stamp_view = m->frame;
@@ -1090,6 +1106,34 @@ int64_t orc_clear_outside_radius(OrcMap* m, const float* c, float r) {
   m->count = keep;
   if (removed) map_rebuild(m);
   return removed;
+}
+
+/* Mapper::clearTsdfInsideShapes restated (nvblox_node.cpp:1834): voxels whose centre is inside a sphere / box are reset.
+ * shapes: n x 7 floats {kind, a0, a1, a2, b0, b1, b2}. */
+int64_t orc_clear_tsdf_inside_shapes(OrcMap* m, const float* shapes, int32_t n) {
+  const float vs = m->p.voxel_size, bs = vs * 8.0f;
+  int64_t cleared = 0;
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    if (!(b->flags & L_TSDF)) continue;
+    int touched = 0;
+    for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) for (int z = 0; z < 8; z++) {
+      const float px = voxel_center(b->idx.x, x, bs, vs), py = voxel_center(b->idx.y, y, bs, vs), pz = voxel_center(b->idx.z, z, bs, vs);
+      int inside = 0;
+      for (int32_t k = 0; k < n && !inside; k++) {
+        const float* s7 = shapes + 7 * k;
+        if (s7[0] == 0.0f) {
+          const float dx = px - s7[1], dy = py - s7[2], dz = pz - s7[3];
+          inside = ((dx * dx + dy * dy) + dz * dz) <= s7[4] * s7[4];
+        } else {
+          inside = px >= s7[1] && py >= s7[2] && pz >= s7[3] && px <= s7[4] && py <= s7[5] && pz <= s7[6];
+        }
+      }
+      if (inside) { TsdfVoxel* v = &b->tsdf[z + 8 * y + 64 * x]; v->distance = 0.0f; v->weight = 0.0f; touched = 1; cleared++; }
+    }
+    if (touched) { b->dirty_esdf = 1; b->dirty_mesh = 1; }
+  }
+  return cleared;
 }
 
 /* multi-GPU union step: TSDF blocks another mapper updated become ESDF-dirty here if they exist locally */

@@ -209,6 +209,15 @@ int main(int argc, char** argv) {
   callFunctionOnAllVoxels<TsdfVoxel>(tsdf, [&](const Index3D&, const Index3D&, const TsdfVoxel* v) { if (v->weight > 0.f) { tsdf_sum += (double)v->distance * (double)v->weight; observed++; } });
   double slice_sum = 0.0; size_t known = 0, occupied = 0;
   for (size_t i = 0; i < slice.size(); i++) { if (slice[i] < 999.0f) { slice_sum += slice[i]; known++; } if (occ[i] == 100) occupied++; }
+  // save_ply service (nvblox_node.cpp:1609-1613) and the EsdfAndGradients clearing request (nvblox_node.cpp:1834)
+  node.static_mapper_->updateColorMesh(UpdateFullLayer::kYes);
+  node.static_mapper_->serializeSelectedLayers(LayerType::kColorMesh);
+  const bool ply_ok = io::outputColorMeshLayerToPly(*node.static_mapper_->serializedColorMeshLayer(), std::string(argv[1]) + ".ply");
+  std::vector<BoundingShape> shapes_to_clear;
+  shapes_to_clear.push_back(BoundingShape(BoundingSphere(Vector3f(100.f, 100.f, 100.f), 0.5f)));       // far away: a no-op on this map
+  shapes_to_clear.push_back(BoundingShape(AxisAlignedBoundingBox(Vector3f(90.f, 90.f, 90.f), Vector3f(91.f, 91.f, 91.f))));
+  node.static_mapper_->clearTsdfInsideShapes(shapes_to_clear);
+  if (!ply_ok) { std::fprintf(stderr, "ply export failed\n"); return 1; }
   std::printf("{\"tsdf_blocks\": %d, \"color_blocks\": %d, \"esdf_blocks\": %d, \"tsdf_observed\": %zu, \"tsdf_sum\": %.9g, "
               "\"slice_width\": %d, \"slice_height\": %d, \"slice_known\": %zu, \"slice_sum\": %.9g, \"occupied\": %zu, "
               "\"serialized_blocks\": %zu, \"serialized_visible\": %zu, \"aabb_min\": [%.6f, %.6f, %.6f], \"mesh_blocks\": %zu, \"mesh_vertices\": %zu, \"mesh_triangle_indices\": %zu, \"mesh_vertex_sum\": %.9g}\n",

@@ -59,6 +59,8 @@ def test_facade_matches_ctypes_path(hip_lib, tmp_path):
     r = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     got = json.loads(r.stdout.strip().splitlines()[-1])
+    ply = open(str(path) + ".ply").read().splitlines()
+    assert ply[0] == "ply" and int(ply[2].split()[-1]) > 1000        # element vertex N
 
     g = M.Mapper(M.default_params(), block_capacity=1 << 14)
     for d, rgb, T in fr:

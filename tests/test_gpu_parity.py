@@ -91,6 +91,53 @@ def test_invalid_depth_decay_parity(oracle_mod, hip_lib):
     assert (np.abs(bg["weight"] - np.float32(2.0 * 0.8 * 0.8)) < 1e-5).sum() > 100
 
 
+@pytest.mark.parametrize("bounds", [(1, (0, 0, 0.3), (0, 0, 1.9)), (2, (-1.0, -2.0, 0.0), (2.5, 1.0, 2.2))])
+def test_workspace_bounds_parity(oracle_mod, hip_lib, bounds):
+    """workspace_bounds_type height_bounds / bounding_box (mapper_initialization.cpp:337-358, nvblox_base.yaml:88-94):
+    blocks outside the bounds are neither allocated nor integrated."""
+    from isaac_ros_nvblox_amd import mapper as M
+    btype, lo, hi = bounds
+    pg = M.default_params(); pg.workspace_bounds_type = btype
+    pg.workspace_bounds_min_corner_m[:] = lo; pg.workspace_bounds_max_corner_m[:] = hi
+    po = H.copy_params(pg, oracle_mod.OrcParams)
+    g = M.Mapper(pg, block_capacity=1 << 14); o = oracle_mod.OracleMap(po)
+    for d, rgb, T in H.frames(3, H.SMALL_CAM, color=False, stride=13):
+        g.integrate_depth(d, T, H.SMALL_CAM); o.integrate_depth(d, T, H.SMALL_CAM)
+        assert H.idx_set(g.last_view()) == H.idx_set(o.last_view())
+    n, worst = compare_layer(M, g, o, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
+    idx = g.block_indices(M.LAYER_TSDF)
+    assert n > 30
+    assert ((idx[:, 2] + 1) * 0.4 > lo[2]).all() and (idx[:, 2] * 0.4 < hi[2]).all()
+    if btype == 2:
+        assert ((idx[:, 0] + 1) * 0.4 > lo[0]).all() and (idx[:, 0] * 0.4 < hi[0]).all()
+    # and the unbounded map is strictly larger
+    g2 = M.Mapper(M.default_params(), block_capacity=1 << 14)
+    for d, rgb, T in H.frames(3, H.SMALL_CAM, color=False, stride=13):
+        g2.integrate_depth(d, T, H.SMALL_CAM)
+    assert g2.num_blocks(M.LAYER_TSDF) > n
+
+
+def test_clear_tsdf_inside_shapes_parity(oracle_mod, hip_lib):
+    """Mapper::clearTsdfInsideShapes (nvblox_node.cpp:1834): sphere + box, then ESDF / mesh follow."""
+    M, g, o = make_pair(oracle_mod)
+    for d, rgb, T in H.frames(3, H.SMALL_CAM, color=False, stride=9):
+        g.integrate_depth(d, T, H.SMALL_CAM); o.integrate_depth(d, T, H.SMALL_CAM)
+    g.update_esdf(); o.update_esdf(); g.update_color_mesh(); o.update_mesh()
+    shapes = [("sphere", (1.5, 1.0, 0.6), 0.8), ("aabb", (-3.1, -2.6, -0.1), (-1.0, 0.0, 1.0))]
+    g.clear_tsdf_inside_shapes(shapes); n_cleared = o.clear_tsdf_inside_shapes(shapes)
+    assert n_cleared > 1000
+    compare_layer(M, g, o, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
+    g.update_esdf(); o.update_esdf()
+    sg, _ = g.esdf_slice_image(); so, _ = o.esdf_slice_image()
+    assert sg.shape == so.shape and np.abs(sg - so).max() <= TOL
+    g.update_color_mesh(); o.update_mesh()
+    mg = g.mesh()
+    assert len(mg) > 0
+    for idx, mb in mg.items():
+        mo = o.mesh_block(np.array(idx, np.int32))
+        assert np.array_equal(mb["triangles"], mo["triangles"])
+
+
 def test_esdf_parity(oracle_mod, hip_lib):
     M, g, o = make_pair(oracle_mod)
     fr = H.frames(8, H.SMALL_CAM, color=False, stride=11)
