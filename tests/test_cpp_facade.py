@@ -20,6 +20,11 @@ def build_fake_node():
     return exe
 
 
+def test_fuser_loop_example_compiles(hip_lib):
+    subprocess.check_call(["make", "-C", CPP, "fuser_loop"], stdout=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(CPP, "fuser_loop"))
+
+
 def test_facade_compiles_and_links(hip_lib):
     """g++ -std=c++17 on a translation unit that mirrors processDepthImage / processColorImage / processEsdf /
     sliceAndPublishEsdf / serializeAndpublishSubscribedLayers call expressions (reference lines quoted in the source)."""
@@ -108,3 +113,29 @@ def test_facade_lidar_pointcloud(hip_lib):
     got = json.loads(r.stdout.strip().splitlines()[-1])
     assert got["range_valid"] == 256 * 16 and abs(got["range_mean"] - 6.0) < 1e-3
     assert got["lidar_blocks"] > 500
+
+
+@pytest.mark.gpu
+def test_fuser_loop_cpp_host(hip_lib, tmp_path):
+    """The C++ fuser loop (examples/fuser_loop.cpp, shape of fuser_node.cpp:202-224) at the bench configuration: the C++
+    host reaches the same GPU-bound frame time as bench.py's ctypes host."""
+    from isaac_ros_nvblox_amd import synthetic as S
+    subprocess.check_call(["make", "-C", CPP, "fuser_loop"], stdout=subprocess.DEVNULL)
+    cam = S.REPLICA_LIKE_CAM
+    sc = S.Scene()
+    path = tmp_path / "frames.bin"
+    n = 25
+    with open(path, "wb") as f:
+        f.write(np.array([n, cam[5], cam[4]], np.int32).tobytes())
+        f.write(np.array(cam[:4], np.float32).tobytes())
+        for i in range(n):
+            T = S.trajectory_pose(i * 8, 200)
+            d, rgb = S.render(sc, T, cam)
+            f.write(np.asarray(T, np.float32).reshape(4, 4).tobytes()); f.write(d.tobytes()); f.write(rgb.tobytes())
+    r = subprocess.run([os.path.join(CPP, "fuser_loop"), str(path), "400", "1", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["frames"] == 400 and got["tsdf_blocks"] > 1000
+    assert 0.01 < got["ms_per_frame"] < 0.5, got            # README RTX 5090 sum for the same three components: 0.7 ms
+    assert "tsdf/integrate" in r.stderr and "esdf/integrate" in r.stderr      # the reference's core timer tags
+    print(got)
