@@ -268,6 +268,9 @@ def main():
     cpu = None
     if not args.no_cpu_baseline:
         import oracle
+        # 8 OpenMP threads: the oracle's parallel regions are one frame's blocks (a few hundred tasks), which stop scaling
+        # there (1 thread 7.6 ms, 8 threads 3.4 ms, 256 threads 620 ms per frame on the EPYC 9575F host -- BASELINE.md 3)
+        oracle.set_num_threads(min(8, os.cpu_count() or 1))
         po = oracle.OrcParams()
         for name, _ in oracle.OrcParams._fields_:
             setattr(po, name, getattr(g.params, name))
@@ -283,7 +286,7 @@ def main():
         cdt = time.perf_counter() - t
         cpu = {"value": round(nf / cdt, 3), "unit": "frames/s", "cores": int(oracle.num_threads()), "kind": "port",
                "ms_per_frame": round(cdt / nf * 1e3, 2),
-               "sample": "%d frames of the same 640x480 sequence, TSDF+Color+ESDF, oracle/nvblox_oracle.c with OpenMP" % nf}
+               "sample": "%d frames of the same 640x480 sequence, TSDF+Color+ESDF, oracle/nvblox_oracle.c, OpenMP with %d threads" % (nf, int(oracle.num_threads()))}
 
     out = {
         "metric": "frames/s, TSDF+Color+ESDF integrate per frame, synthetic Replica-like 640x480 @0.05m",

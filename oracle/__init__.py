@@ -88,6 +88,7 @@ def lib():
         L.orc_set_params.argtypes = [vp, C.POINTER(OrcParams)]
         L.orc_destroy.argtypes = [vp]
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_index_hash.restype = C.c_uint32; L.orc_index_hash.argtypes = [i32, i32, i32]
         L.orc_integrate_depth.restype = i64; L.orc_integrate_depth.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
         L.orc_integrate_lidar_depth.restype = i64; L.orc_integrate_lidar_depth.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
@@ -257,6 +258,10 @@ class OracleMap:
     def clear_outside_radius(self, center, radius):
         c = np.asarray(center, np.float32)
         return lib().orc_clear_outside_radius(self._h, _p(c), float(radius))
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
 
 
 def num_threads():

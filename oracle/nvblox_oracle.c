@@ -193,6 +193,13 @@ void orc_destroy(OrcMap* m) {
   for (int64_t k = 0; k < m->count; k++) block_free(m->order[k]);
   free(m->table); free(m->order); free(m->view); free(m->cview); free(m->synth); free(m);
 }
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
