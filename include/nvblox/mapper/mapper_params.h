@@ -92,6 +92,7 @@ struct MapperParams {
     p.lidar_linear_interpolation_max_allowable_difference_vox = 2.0f;
     p.lidar_nearest_interpolation_max_allowable_dist_to_ray_vox = 0.5f;
     p.invalid_depth_decay_factor = projective_integrator_params.projective_tsdf_integrator_invalid_depth_decay_factor;
+    p.do_depth_preprocessing = do_depth_preprocessing ? 1 : 0; p.depth_preprocessing_num_dilations = depth_preprocessing_num_dilations;
     p.workspace_bounds_type = (int32_t)view_calculator_params.workspace_bounds_type;
     p.workspace_bounds_min_corner_m[0] = view_calculator_params.workspace_bounds_min_corner_x_m; p.workspace_bounds_min_corner_m[1] = view_calculator_params.workspace_bounds_min_corner_y_m;
     p.workspace_bounds_min_corner_m[2] = view_calculator_params.workspace_bounds_min_height_m;

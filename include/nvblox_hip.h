@@ -90,6 +90,8 @@ typedef struct {
   int32_t workspace_bounds_type;          /* 0 unbounded, 1 height_bounds, 2 bounding_box (mapper_initialization.cpp:62-80,337-358) */
   float workspace_bounds_min_corner_m[3]; /* workspace_bounds_min_corner_{x,y}_m, workspace_bounds_min_height_m */
   float workspace_bounds_max_corner_m[3]; /* workspace_bounds_max_corner_{x,y}_m, workspace_bounds_max_height_m */
+  int32_t do_depth_preprocessing;         /* do_depth_preprocessing (mapper_initialization.cpp:238-243; false in every shipped config) */
+  int32_t depth_preprocessing_num_dilations; /* depth_preprocessing_num_dilations: invalid-depth regions grow by this many pixels */
   float invalid_depth_decay_factor;       /* projective_tsdf_integrator_invalid_depth_decay_factor (mapper_initialization.cpp:294-300;
                                              -1 = off, nvblox_base.yaml:80; 0.8 in nvblox_dynamics.yaml:11) */
 } nvbx_mapper_params;

@@ -38,6 +38,8 @@ class Params(C.Structure):
         ("workspace_bounds_type", C.c_int32),
         ("workspace_bounds_min_corner_m", C.c_float * 3),
         ("workspace_bounds_max_corner_m", C.c_float * 3),
+        ("do_depth_preprocessing", C.c_int32),
+        ("depth_preprocessing_num_dilations", C.c_int32),
         ("invalid_depth_decay_factor", C.c_float),
     ]
 

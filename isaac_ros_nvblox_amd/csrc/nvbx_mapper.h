@@ -52,6 +52,8 @@ struct nvbx_mapper {
   int32_t* export_count = nullptr;
   // LiDAR beam direction tables (float2 {sin, cos}: rows elevations then cols azimuths), rebuilt when the model changes
   void* lidar_tab = nullptr; size_t lidar_tab_cap = 0; nvbx_lidar lidar_cached{}; std::vector<float> lidar_host;
+  // depth preprocessing scratch (dilated depth image)
+  float* depth_pre = nullptr; int64_t depth_pre_cap = 0;
   // colour scratch
   float* synth = nullptr; int64_t synth_cap = 0; int32_t synth_rows = 0, synth_cols = 0;
   // mesh arena

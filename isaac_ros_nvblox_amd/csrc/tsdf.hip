@@ -418,12 +418,44 @@ static int integrate_depth_impl(nvbx_mapper* m, Img img, const Sensor& sensor, c
   return m->mark_main();
 }
 
+// [U] DepthPreprocessor (do_depth_preprocessing, depth_preprocessing_num_dilations): invalid-depth regions grow by n pixels.
+// One thread per pixel; the (2n+1)^2 window is read through L1/L2 (the image is 1.2 MB).  Output in metres (f32).
+template <typename Img>
+__global__ void k_dilate_invalid(Img in, int32_t rows, int32_t cols, int32_t n, float* out) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    bool bad = false;
+    for (int dr = -n; dr <= n && !bad; dr++) {
+      const int rr = r + dr; if (rr < 0 || rr >= rows) continue;
+      for (int dc = -n; dc <= n; dc++) {
+        const int cc = c + dc; if (cc < 0 || cc >= cols) continue;
+        if (!(in((int64_t)rr * cols + cc) > 0.0f)) { bad = true; break; }
+      }
+    }
+    out[i] = bad ? 0.0f : in(i);
+  }
+}
+
 template <typename Img>
 static int integrate_camera(nvbx_mapper* m, Img img, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera) {
   NVBX_HIP(hipSetDevice(m->device));
   if (m->join_side()) return NVBX_E_DEVICE;     // k_integrate_tsdf writes what k_esdf_mark reads
   m->frame_id++;
   const Frame f = m->make_frame(T_L_C, camera, rows, cols, m->p.raycast_subsampling_factor);
+  if (m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0) {
+    const int64_t npx = (int64_t)rows * cols;
+    if (npx > m->depth_pre_cap) {
+      NVBX_HIP(hipStreamSynchronize(m->stream));
+      if (m->depth_pre) NVBX_HIP(hipFree(m->depth_pre));
+      m->depth_pre = nullptr; m->depth_pre_cap = 0;
+      NVBX_HIP(hipMalloc(&m->depth_pre, (size_t)npx * 4));
+      m->depth_pre_cap = npx;
+    }
+    NVBX_LAUNCH(m, (k_dilate_invalid<Img>), dim3((unsigned)std::min<int64_t>((npx + 255) / 256, 4096)), dim3(256), img, rows, cols,
+                m->p.depth_preprocessing_num_dilations, m->depth_pre);
+    return integrate_depth_impl(m, DepthF32{m->depth_pre}, CameraSensor{}, f);
+  }
   return integrate_depth_impl(m, img, CameraSensor{}, f);
 }
 

@@ -82,6 +82,8 @@ typedef struct {
   int32_t workspace_bounds_type;        /* 0 unbounded, 1 height_bounds, 2 bounding_box (mapper_initialization.cpp:62-80) */
   float workspace_bounds_min_corner_m[3];
   float workspace_bounds_max_corner_m[3];
+  int32_t do_depth_preprocessing;       /* do_depth_preprocessing */
+  int32_t depth_preprocessing_num_dilations;
   float invalid_depth_decay_factor;     /* projective_tsdf_integrator_invalid_depth_decay_factor; < 0 = off */
 } OrcParams;
 
@@ -416,7 +418,28 @@ static void tsdf_integrate_block(const OrcParams* p, Block* b, const float* dept
   }
 }
 
-int64_t orc_integrate_depth(OrcMap* m, const float* depth, int rows, int cols, const float* T_L_C16, const float* cam6) {
+/* [U] DepthPreprocessor (do_depth_preprocessing / depth_preprocessing_num_dilations, mapper_initialization.cpp:238-243):
+ * regions of invalid depth (<= 0) are dilated by n pixels (n 3x3 dilations = a (2n+1)^2 square) before integration, which
+ * removes the unreliable rim of pixels around depth holes. */
+static float* dilate_invalid(const float* depth, int rows, int cols, int n) {
+  float* out = (float*)malloc(sizeof(float) * (size_t)rows * cols);
+#pragma omp parallel for
+  for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) {
+    int bad = 0;
+    for (int dr = -n; dr <= n && !bad; dr++) for (int dc = -n; dc <= n; dc++) {
+      const int rr = r + dr, cc = c + dc;
+      if (rr < 0 || cc < 0 || rr >= rows || cc >= cols) continue;
+      if (!(depth[(int64_t)rr * cols + cc] > 0.0f)) { bad = 1; break; }
+    }
+    out[(int64_t)r * cols + c] = bad ? 0.0f : depth[(int64_t)r * cols + c];
+  }
+  return out;
+}
+
+int64_t orc_integrate_depth(OrcMap* m, const float* depth_in, int rows, int cols, const float* T_L_C16, const float* cam6) {
+  float* pre = NULL;
+  if (m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0) pre = dilate_invalid(depth_in, rows, cols, m->p.depth_preprocessing_num_dilations);
+  const float* depth = pre ? pre : depth_in;
   Rt T_L_C, T_C_L; rt_from_T(T_L_C16, &T_L_C, &T_C_L);
   Cam k = cam_from(cam6);
   m->frame++;
@@ -427,6 +450,7 @@ int64_t orc_integrate_depth(OrcMap* m, const float* depth, int rows, int cols, c
     Block* b = map_find(m, m->view[i]);
     tsdf_integrate_block(&m->p, b, depth, rows, cols, &T_C_L, &k);
   }
+  free(pre);
   return n;
 }
 

@@ -138,6 +138,22 @@ def test_clear_tsdf_inside_shapes_parity(oracle_mod, hip_lib):
         assert np.array_equal(mb["triangles"], mo["triangles"])
 
 
+def test_depth_preprocessing_parity(oracle_mod, hip_lib):
+    """do_depth_preprocessing / depth_preprocessing_num_dilations (mapper_initialization.cpp:238-243): invalid-depth regions are
+    dilated before integration; f32 and u16-mm inputs."""
+    M, g, o = make_pair(oracle_mod, do_depth_preprocessing=1, depth_preprocessing_num_dilations=3)
+    for k, (d, rgb, T) in enumerate(H.frames(3, H.SMALL_CAM, color=False, stride=7)):
+        d = d.copy(); d[20:40, 50:90] = 0.0; d[100:104, 10:14] = 0.0
+        if k == 2:
+            mm = np.round(d * 1000.0).astype(np.uint16)
+            g.integrate_depth(mm, T, H.SMALL_CAM); o.integrate_depth(mm.astype(np.float32) * np.float32(1.0 / 1000.0), T, H.SMALL_CAM)
+        else:
+            g.integrate_depth(d, T, H.SMALL_CAM); o.integrate_depth(d, T, H.SMALL_CAM)
+        assert H.idx_set(g.last_view()) == H.idx_set(o.last_view())
+    n, worst = compare_layer(M, g, o, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
+    assert n > 100
+
+
 def test_esdf_parity(oracle_mod, hip_lib):
     M, g, o = make_pair(oracle_mod)
     fr = H.frames(8, H.SMALL_CAM, color=False, stride=11)
