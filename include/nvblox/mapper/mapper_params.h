@@ -4,6 +4,7 @@
 #pragma once
 #include "nvblox/core/types.h"
 #include "nvblox/integrators/weighting_function.h"
+#include "nvblox/utils/params.h"
 #include "nvblox_hip.h"
 
 namespace nvblox {
@@ -13,6 +14,57 @@ enum class EsdfMode { k3D, k2D };                                             //
 enum class MappingType { kStaticTsdf, kStaticOccupancy, kDynamic, kHumanWithStaticTsdf, kHumanWithStaticOccupancy };
 enum class ProjectiveLayerType { kTsdf, kOccupancy, kNone };
 enum class UpdateFullLayer { kNo, kYes };
+
+
+// Parameter descriptions the ROS layer declares and reads through (mapper_initialization.cpp:113-228, 231-466).  Names are
+// the ROS parameter names of nvblox_base.yaml:66-110; defaults are the values shipped there (the core's own defaults are
+// not visible in the reference tree).
+constexpr Param<bool>::Description kDoDepthPrepocessingParamDesc{"do_depth_preprocessing", false, "Dilate invalid-depth regions before integration."};
+constexpr Param<int>::Description kDepthPreprocessingNumDilationsParamDesc{"depth_preprocessing_num_dilations", 3, "Pixels by which invalid-depth regions grow."};
+constexpr Param<float>::Description kEsdfSliceMinHeightParamDesc{"esdf_slice_min_height", 0.0f, "Lower bound of the TSDF z band of the 2-D ESDF slice [m]."};
+constexpr Param<float>::Description kEsdfSliceMaxHeightParamDesc{"esdf_slice_max_height", 1.0f, "Upper bound of the TSDF z band of the 2-D ESDF slice [m]."};
+constexpr Param<float>::Description kEsdfSliceHeightParamDesc{"esdf_slice_height", 1.0f, "Output height of the 2-D ESDF slice [m]."};
+constexpr Param<float>::Description kSliceHeightAbovePlaneMParamDesc{"slice_height_above_plane_m", 0.0f, "Slice height above the ground plane [m] (ground-plane mode)."};
+constexpr Param<float>::Description kSliceHeightThicknessMParamDesc{"slice_height_thickness_m", 0.0f, "Slice thickness [m] (ground-plane mode)."};
+constexpr Param<float>::Description kProjectiveIntegratorMaxIntegrationDistanceMParamDesc{"projective_integrator_max_integration_distance_m", 5.0f, "Maximum camera integration distance [m]."};
+constexpr Param<float>::Description kLidarProjectiveIntegratorMaxIntegrationDistanceMParamDesc{"lidar_projective_integrator_max_integration_distance_m", 10.0f, "Maximum LiDAR integration distance [m]."};
+constexpr Param<float>::Description kProjectiveIntegratorTruncationDistanceVoxParamDesc{"projective_integrator_truncation_distance_vox", 4.0f, "TSDF truncation distance [voxels]."};
+constexpr Param<WeightingFunctionType>::Description kProjectiveIntegratorWeightingModeParamDesc{"projective_integrator_weighting_mode", WeightingFunctionType::kInverseSquareTsdfDistancePenalty, "Measurement weighting function."};
+constexpr Param<float>::Description kProjectiveIntegratorMaxWeightParamDesc{"projective_integrator_max_weight", 5.0f, "Weight clamp."};
+constexpr Param<float>::Description kProjectiveTsdfIntegratorInvalidDepthDecayFactor{"projective_tsdf_integrator_invalid_depth_decay_factor", -1.0f, "Weight decay of voxels projecting onto invalid depth (< 0: off)."};
+constexpr Param<float>::Description kFreeRegionOccupancyProbabilityParamDesc{"free_region_occupancy_probability", 0.45f, "Occupancy integrator (not provided by libnvblox_hip)."};
+constexpr Param<float>::Description kOccupiedRegionOccupancyProbabilityParamDesc{"occupied_region_occupancy_probability", 0.55f, "Occupancy integrator (not provided by libnvblox_hip)."};
+constexpr Param<float>::Description kUnobservedRegionOccupancyProbabilityParamDesc{"unobserved_region_occupancy_probability", 0.5f, "Occupancy integrator (not provided by libnvblox_hip)."};
+constexpr Param<float>::Description kOccupiedRegionHalfWidthMParamDesc{"occupied_region_half_width_m", 0.1f, "Occupancy integrator (not provided by libnvblox_hip)."};
+constexpr Param<int>::Description kRaycastSubsamplingFactorParamDesc{"raycast_subsampling_factor", 4, "Depth image sub-sampling of the view calculation rays."};
+constexpr Param<WorkspaceBoundsType>::Description kWorkspaceBoundsTypeParamDesc{"workspace_bounds_type", WorkspaceBoundsType::kUnbounded, "unbounded / height_bounds / bounding_box."};
+constexpr Param<float>::Description kWorkspaceBoundsMinHeightParamDesc{"workspace_bounds_min_height_m", -0.5f, "Workspace bounds [m]."};
+constexpr Param<float>::Description kWorkspaceBoundsMaxHeightParamDesc{"workspace_bounds_max_height_m", 2.0f, "Workspace bounds [m]."};
+constexpr Param<float>::Description kWorkspaceBoundsMinCornerXParamDesc{"workspace_bounds_min_corner_x_m", 0.0f, "Workspace bounds [m]."};
+constexpr Param<float>::Description kWorkspaceBoundsMaxCornerXParamDesc{"workspace_bounds_max_corner_x_m", 0.0f, "Workspace bounds [m]."};
+constexpr Param<float>::Description kWorkspaceBoundsMinCornerYParamDesc{"workspace_bounds_min_corner_y_m", 0.0f, "Workspace bounds [m]."};
+constexpr Param<float>::Description kWorkspaceBoundsMaxCornerYParamDesc{"workspace_bounds_max_corner_y_m", 0.0f, "Workspace bounds [m]."};
+constexpr Param<float>::Description kEsdfIntegratorMinWeightParamDesc{"esdf_integrator_min_weight", 0.1f, "Minimum TSDF weight for a voxel to count as observed."};
+constexpr Param<float>::Description kEsdfIntegratorMaxSiteDistanceVoxParamDesc{"esdf_integrator_max_site_distance_vox", 2.0f, "Maximum |TSDF| of a site [voxels]."};
+constexpr Param<float>::Description kEsdfIntegratorMaxDistanceMParamDesc{"esdf_integrator_max_distance_m", 2.0f, "ESDF cut-off distance [m]."};
+constexpr Param<float>::Description kMeshIntegratorMinWeightParamDesc{"mesh_integrator_min_weight", 0.1f, "Minimum TSDF weight of a meshed corner."};
+constexpr Param<bool>::Description kMeshIntegratorWeldVerticesParamDesc{"mesh_integrator_weld_vertices", true, "Weld vertices per block."};
+constexpr Param<bool>::Description kDecayIntegratorDeallocateDecayedBlocks{"decay_integrator_deallocate_decayed_blocks", true, "Deallocate fully decayed blocks."};
+constexpr Param<float>::Description kTsdfDecayFactorParamDesc{"tsdf_decay_factor", 0.95f, "Weight multiplier per decay step."};
+constexpr Param<float>::Description kTsdfDecayedWeightThresholdDesc{"tsdf_decayed_weight_threshold", 0.001f, "Blocks whose weights are all below this are deallocated."};
+constexpr Param<bool>::Description kTsdfSetFreeDistanceOnDecayedDesc{"tsdf_set_free_distance_on_decayed", false, "(not provided by libnvblox_hip)."};
+constexpr Param<float>::Description kTsdfDecayedFreeDistanceVoxDesc{"tsdf_decayed_free_distance_vox", 4.0f, "(not provided by libnvblox_hip)."};
+constexpr Param<float>::Description kFreeRegionDecayProbabilityParamDesc{"free_region_decay_probability", 0.55f, "Occupancy decay (not provided by libnvblox_hip)."};
+constexpr Param<float>::Description kOccupiedRegionDecayProbabilityParamDesc{"occupied_region_decay_probability", 0.4f, "Occupancy decay (not provided by libnvblox_hip)."};
+constexpr Param<bool>::Description kOccupancyDecayToFreeParamDesc{"occupancy_decay_to_free", false, "Occupancy decay (not provided by libnvblox_hip)."};
+constexpr Param<float>::Description kMaxTsdfDistanceForOccupancyMParamDesc{"max_tsdf_distance_for_occupancy_m", 0.15f, "Freespace integrator (not provided by libnvblox_hip)."};
+constexpr Param<int>::Description kMaxUnobservedToKeepConsecutiveOccupancyMsParamDesc{"max_unobserved_to_keep_consecutive_occupancy_ms", 200, "Freespace integrator (not provided by libnvblox_hip)."};
+constexpr Param<int>::Description kMinDurationSinceOccupiedForFreespaceMsParamDesc{"min_duration_since_occupied_for_freespace_ms", 1000, "Freespace integrator (not provided by libnvblox_hip)."};
+constexpr Param<int>::Description kMinConsecutiveOccupancyDurationForResetMsParamDesc{"min_consecutive_occupancy_duration_for_reset_ms", 2000, "Freespace integrator (not provided by libnvblox_hip)."};
+constexpr Param<bool>::Description kCheckNeighborhoodParamDesc{"check_neighborhood", true, "Freespace integrator (not provided by libnvblox_hip)."};
+constexpr Param<bool>::Description kInitializeToHighConfidenceFreespaceParamDesc{"initialize_to_high_confidence_freespace", false, "Freespace integrator (not provided by libnvblox_hip)."};
+constexpr Param<int>::Description kConnectedMaskComponentSizeThresholdParamDesc{"connected_mask_component_size_threshold", 2000, "MultiMapper (dynamic mapping; not provided by libnvblox_hip)."};
+constexpr Param<bool>::Description kRemoveSmallConnectedComponentsParamDesc{"remove_small_connected_components", true, "MultiMapper (dynamic mapping; not provided by libnvblox_hip)."};
 
 struct ProjectiveIntegratorParams {
   float projective_integrator_max_integration_distance_m = 7.0f;

@@ -15,6 +15,16 @@
 
 using namespace nvblox;
 
+// node_params.hpp:84 + nvblox_node.cpp:90-95: node-level parameters are nvblox::Param<T> built from constexpr descriptions
+constexpr Param<float>::Description kVoxelSizeParamDesc{"voxel_size", .05F, "Voxel size (in meters) to use for the map."};
+constexpr StringParam::Description kGlobalFrameParamDesc{"global_frame", "odom", "The name of the TF frame to be used as the global frame."};
+
+// mapper_initialization.cpp:156-229 declareMapperParameters / utils.hpp:60-82: what the ROS layer does with a core description
+template <typename T>
+static std::string declareParameter(const std::string& name_prefix, const typename Param<T>::Description& desc) {
+  return name_prefix + "." + desc.name + " = " + std::to_string(desc.default_value) + "  # " + desc.help_string;
+}
+
 struct FakeNode {
   // nvblox_node.hpp:470-488,539,548: members of NvbloxNode
   std::shared_ptr<CudaStream> cuda_stream_;
@@ -27,7 +37,14 @@ struct FakeNode {
   struct { float voxel_size = 0.05f; MappingType mapping_type = MappingType::kStaticTsdf; EsdfMode esdf_mode = EsdfMode::k2D;
            float distance_map_unknown_value_optimistic = 1000.0f; } params_;
 
+  Param<float> voxel_size{kVoxelSizeParamDesc};
+  StringParam global_frame{kGlobalFrameParamDesc};
+
   FakeNode() {
+    params_.voxel_size = voxel_size.get();
+    if (global_frame.get() != "odom" ||
+        declareParameter<float>("static_mapper", kEsdfSliceHeightParamDesc).find("static_mapper.esdf_slice_height") != 0 ||
+        declareParameter<int>("static_mapper", kDepthPreprocessingNumDilationsParamDesc).empty()) { std::fprintf(stderr, "param descriptions broken\n"); std::exit(1); }
     // nvblox_node.cpp:91
     cuda_stream_ = CudaStream::createCudaStream(static_cast<CudaStreamType>(2));
     // nvblox_node.cpp:186-190
