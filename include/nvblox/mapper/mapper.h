@@ -111,6 +111,13 @@ class Mapper {
     checkNvbx(nvbx_integrate_color(m_, reinterpret_cast<const uint8_t*>(color_frame.dataConstPtr()), color_frame.rows(), color_frame.cols(), T, &camera.c_abi()),
               "nvbx_integrate_color");
   }
+  // bgra8 colour (4 bytes per pixel): the ToRgba<Bgra> reorder of image_conversions_thrust.cu:60-65 fused into the fetch
+  void integrateColorBgra8(const Image<uint32_t>& bgra_frame, const Transform& T_L_C, const Camera& camera) {
+    timing::Timer t("color/integrate");
+    float T[16]; T_L_C.toRowMajor(T);
+    checkNvbx(nvbx_integrate_color_bgra8(m_, reinterpret_cast<const uint8_t*>(bgra_frame.dataConstPtr()), bgra_frame.rows(), bgra_frame.cols(), T, &camera.c_abi()),
+              "nvbx_integrate_color_bgra8");
+  }
   void updateEsdf() { timing::Timer t("esdf/integrate"); checkNvbx(nvbx_update_esdf(m_), "nvbx_update_esdf"); }
   void updateColorMesh(UpdateFullLayer update_full_layer = UpdateFullLayer::kNo) {
     timing::Timer t("mesh/integrate");

@@ -156,6 +156,11 @@ int nvbx_depth_image_from_pointcloud(nvbx_mapper* m, const float* points_xyz_dev
  * rgb_dev: rows*cols*3 bytes, nvblox::Color order r,g,b (image_conversions.cpp:100-101). */
 int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                          const nvbx_camera* camera);
+/* Same, colour given as bgra8 (4 bytes per pixel): fuses conversions::colorImageFromNitrosViewAsync's ToRgba<Bgra>
+ * channel reorder (conversions/image_conversions_thrust.cu:60-65, image_conversions.cpp:170-176) into the integrator's
+ * colour fetch (one aligned 4-byte load per tap). */
+int nvbx_integrate_color_bgra8(nvbx_mapper* m, const uint8_t* bgra_dev, int32_t rows, int32_t cols, const float T_L_C[16],
+                               const nvbx_camera* camera);
 /* MultiMapper::updateEsdf() (EsdfMode::k2D) -- nvblox_node.cpp:781 */
 int nvbx_update_esdf(nvbx_mapper* m);
 /* Mapper::updateColorMesh(UpdateFullLayer) -- layer_publishing.cpp:686-689, nvblox_node.cpp:1611 */

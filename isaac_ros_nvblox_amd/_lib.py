@@ -82,6 +82,7 @@ SIGNATURES = {
     "nvbx_integrate_depth": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera)]),
     "nvbx_integrate_depth_u16mm": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera)]),
     "nvbx_integrate_color": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera)]),
+    "nvbx_integrate_color_bgra8": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera)]),
     "nvbx_integrate_lidar_depth": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Lidar)]),
     "nvbx_depth_image_from_pointcloud": (C.c_int, [_vp, _vp, _i64, C.POINTER(Lidar), _vp]),
     "nvbx_update_esdf": (C.c_int, [_vp]),

@@ -98,6 +98,16 @@ __global__ __launch_bounds__(256) void k_sphere_trace(DMap m, Frame f, float* sy
   if (valid && sub == 0) synth[(int64_t)r * scols + c] = hit ? t * dcz : 0.0f;
 }
 
+// colour source: rgb8 (nvblox::Color, 3 bytes) or bgra8 (4 bytes, channel reorder of ToRgba<Bgra> fused into the fetch)
+struct PixRgb8 {
+  const uint8_t* p;
+  __device__ void tap(int64_t i, float* c) const { const uint8_t* q = p + i * 3; c[0] = (float)q[0]; c[1] = (float)q[1]; c[2] = (float)q[2]; }
+};
+struct PixBgra8 {
+  const uint32_t* p;     // little endian: b | g << 8 | r << 16 | a << 24
+  __device__ void tap(int64_t i, float* c) const { const uint32_t v = p[i]; c[0] = (float)((v >> 16) & 0xFF); c[1] = (float)((v >> 8) & 0xFF); c[2] = (float)(v & 0xFF); }
+};
+
 __device__ inline uint32_t blend_u8(float c0, float w0, float c1, float w1) {
   const float tw = w0 + w1;
   const float a = w0 / tw, b = w1 / tw;
@@ -111,7 +121,8 @@ __device__ inline uint32_t blend_u8(float c0, float w0, float c1, float w1) {
 // Dependent-access chain: {slot flags, Index3D, TSDF voxel, colour voxel} (all addressed by the slot id alone, fetched
 // together) -> block vote -> {synthetic depth gather, colour gather} (both addressed by the projection, fetched
 // together) -> store.
-__global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, const uint8_t* rgb, const float* synth, int32_t srows, int32_t scols,
+template <typename Pix>
+__global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rgb, const float* synth, int32_t srows, int32_t scols,
                                                          int32_t mesh_list) {
   __shared__ int s_out[6];
   __shared__ int s_band;
@@ -171,12 +182,10 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, const 
     const bool s_ok = !(sx0 < 0 || sy0 < 0 || sx0 + 1 > scols - 1 || sy0 + 1 > srows - 1);
     if (!c_ok || !s_ok) continue;
     const float* sp = synth + (int64_t)sy0 * scols + sx0;
-    const uint8_t* p00 = rgb + ((int64_t)y0 * f.cols + x0) * 3;
-    const uint8_t* p01 = p00 + (int64_t)f.cols * 3;
+    const int64_t i00 = (int64_t)y0 * f.cols + x0;
     const float s00 = sp[0], s10 = sp[1], s01 = sp[scols], s11 = sp[scols + 1];
     float t00[3], t10[3], t01[3], t11[3];
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) { t00[ch] = (float)p00[ch]; t10[ch] = (float)p00[3 + ch]; t01[ch] = (float)p01[ch]; t11[ch] = (float)p01[3 + ch]; }
+    rgb.tap(i00, t00); rgb.tap(i00 + 1, t10); rgb.tap(i00 + f.cols, t01); rgb.tap(i00 + f.cols + 1, t11);
     if (!(s00 > 0.0f) || !(s10 > 0.0f) || !(s01 > 0.0f) || !(s11 > 0.0f)) continue;
     const float sax = usc - sfx, say = vsc - sfy;
     const float stop = (1.0f - sax) * s00 + sax * s10;
@@ -199,9 +208,8 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, const 
   }
 }
 
-extern "C" int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16],
-                                    const nvbx_camera* camera) {
-  if (!m || !rgb_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_color: invalid argument"); return NVBX_E_INVALID; }
+template <typename Pix>
+static int integrate_color_impl(nvbx_mapper* m, Pix rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera) {
   NVBX_HIP(hipSetDevice(m->device));
   Frame f = m->make_frame(T_L_C, camera, rows, cols, m->p.sphere_tracing_subsampling);
   const int32_t srows = rows / f.subsample, scols = cols / f.subsample;
@@ -218,9 +226,20 @@ extern "C" int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int3
   NVBX_LAUNCH(m, k_sphere_trace, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), m->d, f, m->synth, srows, scols, m->p.sphere_tracing_max_steps,
                      m->p.sphere_tracing_max_ray_length_m, m->p.sphere_tracing_surface_eps_vox * m->p.voxel_size);
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);     // one resident batch of 512-thread workgroups
-  NVBX_LAUNCH(m, k_integrate_color, dim3(grid), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->mesh_list_live());
+  NVBX_LAUNCH(m, (k_integrate_color<Pix>), dim3(grid), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->mesh_list_live());
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
+}
+
+extern "C" int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16],
+                                    const nvbx_camera* camera) {
+  if (!m || !rgb_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_color: invalid argument"); return NVBX_E_INVALID; }
+  return integrate_color_impl(m, PixRgb8{rgb_dev}, rows, cols, T_L_C, camera);
+}
+extern "C" int nvbx_integrate_color_bgra8(nvbx_mapper* m, const uint8_t* bgra_dev, int32_t rows, int32_t cols, const float T_L_C[16],
+                                          const nvbx_camera* camera) {
+  if (!m || !bgra_dev || !T_L_C || !camera || rows <= 0 || cols <= 0 || ((uintptr_t)bgra_dev & 3)) { set_error("nvbx_integrate_color_bgra8: invalid argument"); return NVBX_E_INVALID; }
+  return integrate_color_impl(m, PixBgra8{reinterpret_cast<const uint32_t*>(bgra_dev)}, rows, cols, T_L_C, camera);
 }
 
 extern "C" int nvbx_get_synthetic_depth(nvbx_mapper* m, float* out_host, int64_t capacity, int32_t* rows, int32_t* cols) {

@@ -156,9 +156,14 @@ class Mapper:
         return img
 
     def integrate_color(self, rgb, T_L_C, cam):
+        """rgb8 [rows, cols, 3] or bgra8 [rows, cols, 4] (the two encodings image_conversions.cpp:170-176 accepts)."""
         d = self._dev(rgb, self._torch.uint8)
-        assert d.dim() == 3 and d.shape[2] == 3
+        assert d.dim() == 3 and d.shape[2] in (3, 4)
         T = self._T(T_L_C); k = self._cam(cam)
+        if d.shape[2] == 4:
+            self._check(self.lib.nvbx_integrate_color_bgra8(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k)))
+            self._keep_c = [d]
+            return
         self._check(self.lib.nvbx_integrate_color(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k)))
         self._keep_c = [d]
 

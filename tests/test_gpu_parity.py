@@ -183,6 +183,18 @@ def test_color_parity(oracle_mod, hip_lib):
     assert n > 20
 
 
+def test_color_bgra8_fused_conversion(oracle_mod, hip_lib):
+    """bgra8 colour input (image_conversions.cpp:170-176, ToRgba<Bgra> image_conversions_thrust.cu:60-65) fused into the fetch."""
+    M, g, o = make_pair(oracle_mod)
+    for d, rgb, T in H.frames(3, H.SMALL_CAM, color=True, stride=6):
+        rgb = rgb.copy(); rgb[..., 1] = (rgb[..., 1] // 2); rgb[..., 2] = 255 - rgb[..., 2]     # make the three channels distinct
+        bgra = np.concatenate([rgb[..., ::-1], np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=2)
+        g.integrate_depth(d, T, H.SMALL_CAM); o.integrate_depth(d, T, H.SMALL_CAM)
+        g.integrate_color(bgra, T, H.SMALL_CAM); o.integrate_color(rgb, T, H.SMALL_CAM)
+    n, worst = compare_layer(M, g, o, M.LAYER_COLOR, oracle_mod.L_COLOR, fields_tol=("weight",), lsb_fields=("r", "g", "b"))
+    assert n > 20
+
+
 def test_mesh_parity(oracle_mod, hip_lib):
     M, g, o = make_pair(oracle_mod)
     for d, rgb, T in H.frames(4, H.SMALL_CAM, color=True, stride=8):
