@@ -30,6 +30,8 @@ struct CameraSensor {
   static constexpr bool kLongRays = false;
   static constexpr int kTileRows = 8, kTileCols = 8;     // rays per wavefront: one 8x8 tile of the ray grid
   static constexpr int kSetSize = 512, kFlushRounds = 2; // a tile crosses < 100 blocks: 4 KiB set, 128 keys per flush pass
+  static constexpr int kSegments = 1;                    // lanes per ray
+  static constexpr int kProbeDepth = 2;                  // hash probe positions fetched up front per key in a flush
   // end point (camera frame) of the ray through the centre of pixel (prow, pcol) at depth `de` along the optical axis
   __device__ void ray_end(const Frame& f, int prow, int pcol, float de, float* pc) const {
     const float rx = (((float)pcol + 0.5f) - f.cu) / f.fu;
@@ -55,6 +57,11 @@ struct LidarSensor {
   // wavefronts in flight (16384 rays -> 1024 waves); all 64 lanes still work in the flushes
   static constexpr int kTileRows = 4, kTileCols = 4;
   static constexpr int kSetSize = 1024, kFlushRounds = 6; // early flush at 256 keys: 6 x 64 >= 256 + one step's additions
+  // A 200 m ray is ~250 dependent block steps.  Four lanes share a ray: lane s replays the (cheap, insert-free) traversal up
+  // to its quarter -- the same float operations in the same order, so the state is bit-identical -- and then walks only its
+  // quarter with set inserts: 4 x 4 rays x 4 segments = 64 busy lanes, ~63 instead of ~250 insert steps per wavefront.
+  static constexpr int kSegments = 4;
+  static constexpr int kProbeDepth = 4;
   nvbx_lidar_model l;
   const float2* el_tab; const float2* az_tab;
   float max_diff_m, max_ray_dist_m;
@@ -192,13 +199,13 @@ __device__ inline void dda_step(int32_t* cur, const int32_t* step, float* tmax, 
   else { cur[2] += step[2]; tmax[2] = tmax[2] + tdelta[2]; }
 }
 // Flush: compact the set (ballot + popcount), then every key goes to HBM with the dependent round trips taken
-// PHASE-WISE over up to R keys per lane at once: (A) the first TWO probe positions of every key are loaded together
-// (covers ~98 % of lookups at our load factor), (B) resolved -- a key further down its probe chain, a new block, or a
+// PHASE-WISE over up to R keys per lane at once: (A) the first PD probe positions of every key are loaded together
+// (2 cover ~98 % of lookups at a room-sized map's load factor, 4 are used for the larger LiDAR maps), (B) resolved -- a key further down its probe chain, a new block, or a
 // slot not published yet takes the general mark_block path, (C) the frame-stamp exchanges of all keys not yet stamped
 // are issued together, (D) ONE wave-aggregated returning atomicAdd reserves view-list space for all first-stampers,
 // (E) records are stored.  A camera tile flushes ~60 keys in one such pass; a long LiDAR bundle 256+ keys per pass
 // instead of 64 per dependent round.  Whole wave must call.
-template <int LSET, int R>
+template <int LSET, int R, int PD>
 __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* lkeys, int32_t* cnt, int4* view_list, int32_t list_cap,
                                  int lane, bool clear) {
   __syncthreads();
@@ -214,8 +221,8 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
   __syncthreads();
   for (int32_t kb = 0; kb < nk; kb += R * 64) {              // one pass per R x 64 keys (wave-uniform)
     const int rounds = min(R, (nk - kb + 63) >> 6);
-    u64 key[R]; uint32_t h[R]; uint4 e0[R], e1[R]; bool have[R];
-    // (A) first two probe positions, all in flight
+    u64 key[R]; uint32_t h[R]; uint4 e[R][PD]; bool have[R];
+    // (A) the first PD probe positions of every key, all in flight
 #pragma unroll
     for (int r = 0; r < R; r++) {
       have[r] = r < rounds && (kb + r * 64 + lane) < nk;
@@ -225,8 +232,8 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
     }
 #pragma unroll
     for (int r = 0; r < R; r++) if (r < rounds) {
-      e0[r] = *reinterpret_cast<const uint4*>(&m.table[h[r]]);
-      e1[r] = *reinterpret_cast<const uint4*>(&m.table[(h[r] + 1) & m.mask]);
+#pragma unroll
+      for (int q = 0; q < PD; q++) e[r][q] = *reinterpret_cast<const uint4*>(&m.table[(h[r] + q) & m.mask]);
     }
     // (B) resolve + (C) stamp exchanges in flight
     bool fast[R], first[R]; uint32_t old[R], slot[R]; int4 rec[R];
@@ -234,10 +241,13 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
     for (int r = 0; r < R; r++) {
       fast[r] = false; first[r] = false; old[r] = f.frame_id; slot[r] = SLOT_INVALID; rec[r] = make_int4(0, 0, 0, 0);
       if (r < rounds && have[r]) {
-        const u64 k0 = ((u64)e0[r].y << 32) | (u64)e0[r].x, k1 = ((u64)e1[r].y << 32) | (u64)e1[r].x;
-        uint32_t hh = h[r], st = 0;
-        if (k0 == key[r]) { slot[r] = e0[r].z; st = e0[r].w; fast[r] = true; }
-        else if (k0 != KEY_EMPTY && k1 == key[r]) { slot[r] = e1[r].z; st = e1[r].w; hh = (h[r] + 1) & m.mask; fast[r] = true; }
+        uint32_t hh = h[r], st = 0; bool open = true;        // open: no EMPTY entry seen yet on the probe chain
+#pragma unroll
+        for (int q = 0; q < PD; q++) {
+          const u64 kq = ((u64)e[r][q].y << 32) | (u64)e[r][q].x;
+          if (open && !fast[r] && kq == key[r]) { slot[r] = e[r][q].z; st = e[r][q].w; hh = (h[r] + q) & m.mask; fast[r] = true; }
+          if (kq == KEY_EMPTY) open = false;
+        }
         if (slot[r] == SLOT_INVALID) fast[r] = false;              // being inserted right now: general path waits for the slot
         if (fast[r] && st != f.frame_id) old[r] = atomicExch(&m.table[hh].stamp, f.frame_id);
       }
@@ -283,11 +293,13 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
   if (blockIdx.x == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
   __syncthreads();
 
-  constexpr int TR = Sensor::kTileRows, TC = Sensor::kTileCols;
+  constexpr int TR = Sensor::kTileRows, TC = Sensor::kTileCols, NSEG = Sensor::kSegments;
+  static_assert(TR * TC * NSEG <= 64, "one wavefront per tile");
   const int tiles_x = (f.n_ray_cols + TC - 1) / TC;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int ri = ty * TR + lane / TC, ci = tx * TC + lane % TC;
-  bool active = lane < TR * TC && ri < f.n_ray_rows && ci < f.n_ray_cols;
+  const int ray = lane / NSEG, seg = lane % NSEG;
+  const int ri = ty * TR + ray / TC, ci = tx * TC + ray % TC;
+  bool active = ray < TR * TC && ri < f.n_ray_rows && ci < f.n_ray_cols;
 
   int32_t cur[3] = {0, 0, 0}, step[3] = {0, 0, 0}, nsteps = -1;
   float tmax[3] = {0, 0, 0}, tdelta[3] = {0, 0, 0};
@@ -318,6 +330,14 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
       }
     }
   }
+  // this lane's share of the ray: steps [k0, k1]; the traversal state is advanced to k0 without touching the set
+  int32_t k0 = 0, k1 = nsteps;
+  if (NSEG > 1 && nsteps >= 0) {
+    const int32_t q = (nsteps + NSEG) / NSEG;                  // ceil((nsteps + 1) / NSEG)
+    k0 = seg * q; k1 = min(nsteps, k0 + q - 1);
+    if (k0 > nsteps) k1 = -1;                                   // short ray: nothing left for this segment
+    for (int32_t k = 0; k < k0 && k0 <= nsteps; k++) dda_step(cur, step, tmax, tdelta);
+  }
   int32_t* cnt = &m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
   if (!Sensor::kLongRays) {
     // camera: a tile's rays cross < 100 blocks in ~20 steps -- walk every ray to its end, then flush once
@@ -332,16 +352,16 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
       }
       dda_step(cur, step, tmax, tdelta);
     }
-    flush_set<LSET, FR>(m, f, lset, lkeys, cnt, view_list, list_cap, lane, false);
+    flush_set<LSET, FR, Sensor::kProbeDepth>(m, f, lset, lkeys, cnt, view_list, list_cap, lane, false);
     return;
   }
   // LiDAR: hundreds of steps per ray and little sharing at long range -- wave-uniform loop, flush whenever the set is
   // half full
   int32_t nset = 0;                                   // keys in the LDS set (wave-uniform)
-  for (int32_t k = 0; __ballot(k <= nsteps) != 0ull; k++) {
+  for (int32_t j = 0; __ballot(k0 + j <= k1) != 0ull; j++) {
     bool spill = false, added = false;
     u64 key = KEY_EMPTY;
-    if (k <= nsteps) {
+    if (k0 + j <= k1) {
       key = pack_key(cur[0], cur[1], cur[2]);
       spill = block_in_workspace(f, cur) && !lset_insert<LSET>(lset, cur, key, &added);
       dda_step(cur, step, tmax, tdelta);
@@ -352,8 +372,8 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
       const bool first = spill && mark_block(m, key, f.frame_id, &rec);
       view_append(cnt, view_list, list_cap, first, rec, lane);
     }
-    const bool last = __ballot(k + 1 <= nsteps) == 0ull;
-    if (last || nset > LSET_FLUSH) { flush_set<LSET, FR>(m, f, lset, lkeys, cnt, view_list, list_cap, lane, !last); nset = 0; }
+    const bool last = __ballot(k0 + j + 1 <= k1) == 0ull;
+    if (last || nset > LSET_FLUSH) { flush_set<LSET, FR, Sensor::kProbeDepth>(m, f, lset, lkeys, cnt, view_list, list_cap, lane, !last); nset = 0; }
   }
 }
 
