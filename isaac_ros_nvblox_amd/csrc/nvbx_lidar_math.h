@@ -45,7 +45,11 @@ NVBX_HD float nvbx_atan01f(float x) {
 NVBX_HD float nvbx_atan2f(float y, float x) {
   const float ax = fabsf(x), ay = fabsf(y);
   if (ax == 0.0f && ay == 0.0f) return 0.0f;
-  float a = (ax >= ay) ? nvbx_atan01f(ay / ax) : (NVBX_HALF_PI_F - nvbx_atan01f(ax / ay));
+  /* one division and one polynomial for both octants (operands selected first): same operations as
+   * (ax >= ay) ? atan01(ay / ax) : pi/2 - atan01(ax / ay) */
+  const float num = (ax >= ay) ? ay : ax, den = (ax >= ay) ? ax : ay;
+  float a = nvbx_atan01f(num / den);
+  if (!(ax >= ay)) a = NVBX_HALF_PI_F - a;
   if (x < 0.0f) a = NVBX_PI_F - a;
   return y < 0.0f ? -a : a;
 }
