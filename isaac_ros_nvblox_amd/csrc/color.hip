@@ -126,15 +126,24 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rg
                                                          int32_t mesh_list) {
   __shared__ int s_out[6];
   __shared__ int s_band;
-  const int32_t hw = m.counters[C_HIGH_WATER];
   const int tid = threadIdx.x;
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
-  for (int32_t slot = blockIdx.x; slot < hw; slot += gridDim.x) {
-    const uint32_t flags = m.slot_flags[slot];
-    const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
-    const float2 tv = m.tsdf[(size_t)slot * 512 + tid];          // zero for slots without a TSDF block
-    uint2* cp = &m.color[(size_t)slot * 512 + tid];
-    const uint2 cur = *cp;
+  // the first slot's data is requested beside the high-water mark (gridDim.x <= capacity, so the addresses are valid)
+  int32_t slot = blockIdx.x;
+  uint32_t flags = m.slot_flags[slot];
+  int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
+  float2 tv = m.tsdf[(size_t)slot * 512 + tid];                  // zero for slots without a TSDF block
+  uint2* cp = &m.color[(size_t)slot * 512 + tid];
+  uint2 cur = *cp;
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  for (; slot < hw; slot += gridDim.x) {
+    if (slot != (int32_t)blockIdx.x) {
+      flags = m.slot_flags[slot];
+      bx = m.slot_index[3 * slot]; by = m.slot_index[3 * slot + 1]; bz = m.slot_index[3 * slot + 2];
+      tv = m.tsdf[(size_t)slot * 512 + tid];
+      cp = &m.color[(size_t)slot * 512 + tid];
+      cur = *cp;
+    }
     if (!(flags & F_TSDF)) continue;     // uniform
     __syncthreads();
     if (tid < 6) s_out[tid] = 0;

@@ -289,10 +289,6 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
   __shared__ u64 lset[LSET];
   __shared__ u64 lkeys[LSET];
   const int lane = threadIdx.x;
-  for (int i = lane; i < LSET; i += 64) lset[i] = KEY_EMPTY;
-  if (blockIdx.x == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
-  __syncthreads();
-
   constexpr int TR = Sensor::kTileRows, TC = Sensor::kTileCols, NSEG = Sensor::kSegments;
   static_assert(TR * TC * NSEG <= 64, "one wavefront per tile");
   const int tiles_x = (f.n_ray_cols + TC - 1) / TC;
@@ -300,13 +296,17 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
   const int ray = lane / NSEG, seg = lane % NSEG;
   const int ri = ty * TR + ray / TC, ci = tx * TC + ray % TC;
   bool active = ray < TR * TC && ri < f.n_ray_rows && ci < f.n_ray_cols;
+  // the ray's depth pixel is requested first: its HBM round trip overlaps the LDS set initialisation
+  int prow = ri * f.subsample; if (prow >= f.rows) prow = f.rows - 1;
+  int pcol = ci * f.subsample; if (pcol >= f.cols) pcol = f.cols - 1;
+  const float d = active ? depth((int64_t)prow * f.cols + pcol) : 0.0f;
+  for (int i = lane; i < LSET; i += 64) lset[i] = KEY_EMPTY;
+  if (blockIdx.x == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
+  __syncthreads();
 
   int32_t cur[3] = {0, 0, 0}, step[3] = {0, 0, 0}, nsteps = -1;
   float tmax[3] = {0, 0, 0}, tdelta[3] = {0, 0, 0};
   if (active) {
-    int prow = ri * f.subsample; if (prow >= f.rows) prow = f.rows - 1;
-    int pcol = ci * f.subsample; if (pcol >= f.cols) pcol = f.cols - 1;
-    const float d = depth((int64_t)prow * f.cols + pcol);
     if (!(d > 0.0f)) active = false;
     else {
       float de = d + f.trunc;
@@ -342,15 +342,27 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
   if (!Sensor::kLongRays) {
     // camera: a tile's rays cross < 100 blocks in ~20 steps -- walk every ray to its end, then flush once
     for (int32_t k = 0; k <= nsteps; k++) {
-      bool added;
       const u64 key = pack_key(cur[0], cur[1], cur[2]);
-      const bool spill = block_in_workspace(f, cur) && !lset_insert<LSET>(lset, cur, key, &added);
+      const bool inside = block_in_workspace(f, cur);
+      const uint32_t lh = ((index_hash(cur[0], cur[1], cur[2]) * 2654435761u) >> 16) & (LSET - 1);
+      // first probe issued, the traversal step runs in the shadow of the LDS round trip, then the result is looked at
+      u64 old = KEY_EMPTY;
+      if (inside) old = atomicCAS(&lset[lh], KEY_EMPTY, key);
+      dda_step(cur, step, tmax, tdelta);
+      bool spill = false;
+      if (inside && old != KEY_EMPTY && old != key) {          // occupied by another block: continue along the probe window
+        spill = true;
+#pragma unroll 1
+        for (int p = 1; p < 16; p++) {
+          const u64 o2 = atomicCAS(&lset[(lh + p) & (LSET - 1)], KEY_EMPTY, key);
+          if (o2 == KEY_EMPTY || o2 == key) { spill = false; break; }
+        }
+      }
       if (__ballot(spill)) {                     // probe window exhausted (rare): this key goes to HBM directly
         int4 rec = make_int4(0, 0, 0, 0);
         const bool first = spill && mark_block(m, key, f.frame_id, &rec);
         view_append(cnt, view_list, list_cap, first, rec, lane);
       }
-      dda_step(cur, step, tmax, tdelta);
     }
     flush_set<LSET, FR, Sensor::kProbeDepth>(m, f, lset, lkeys, cnt, view_list, list_cap, lane, false);
     return;
