@@ -34,7 +34,9 @@ def algorithmic_bytes(kernel, c, rows, cols):
     if kernel.startswith("k_mark_view"):
         return (rows // 4) * (cols // 4) * 4 + Nv * 16 * 2          # sub-sampled depth read + one hash entry RMW per block in view
     if kernel.startswith("k_integrate_color"):
-        return rows * cols * 3 + (rows // 4) * (cols // 4) * 4 + Na * B + Nc * B * 2   # colour + synthetic depth + TSDF band scan + colour RMW
+        # colour + synthetic depth + TSDF band scan + colour RMW, plus the ESDF site marking that rides in the same launch
+        # (TSDF z-band of the re-marked columns read, slice plane + site mask written)
+        return rows * cols * 3 + (rows // 4) * (cols // 4) * 4 + Na * B + Nc * B * 2 + Nu * 2 * B + Nu * 520
     if kernel.startswith("k_sphere_trace"):
         return (rows // 4) * (cols // 4) * 4 + Nc * B                # synthetic depth write + TSDF blocks read once
     if kernel.startswith("k_esdf_mark"):

@@ -11,6 +11,7 @@
 // Call site served: nvblox_ros/src/lib/nvblox_node.cpp:1264.
 #include <algorithm>
 #include "nvbx_mapper.h"
+#include "nvbx_esdf_mark.h"
 
 using namespace nvbx;
 
@@ -121,9 +122,14 @@ __device__ inline uint32_t blend_u8(float c0, float w0, float c1, float w1) {
 // Dependent-access chain: {slot flags, Index3D, TSDF voxel, colour voxel} (all addressed by the slot id alone, fetched
 // together) -> block vote -> {synthetic depth gather, colour gather} (both addressed by the projection, fetched
 // together) -> store.
+// Workgroups [0, n_color_wg) integrate colour; workgroups beyond that (if any) are ESDF marking workers (first wavefront only).
 template <typename Pix>
 __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rgb, const float* synth, int32_t srows, int32_t scols,
-                                                         int32_t mesh_list) {
+                                                         int32_t mesh_list, int32_t n_color_wg, EsdfArgs ea) {
+  if ((int32_t)blockIdx.x >= n_color_wg) {
+    if (threadIdx.x < 64) esdf_mark_worker(m, ea, (int)blockIdx.x - n_color_wg, (int)gridDim.x - n_color_wg);
+    return;
+  }
   __shared__ int s_out[6];
   __shared__ int s_band;
   const int tid = threadIdx.x;
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rg
   uint2* cp = &m.color[(size_t)slot * 512 + tid];
   uint2 cur = *cp;
   const int32_t hw = m.counters[C_HIGH_WATER];
-  for (; slot < hw; slot += gridDim.x) {
+  for (; slot < hw; slot += n_color_wg) {
     if (slot != (int32_t)blockIdx.x) {
       flags = m.slot_flags[slot];
       bx = m.slot_index[3 * slot]; by = m.slot_index[3 * slot + 1]; bz = m.slot_index[3 * slot + 2];
@@ -235,7 +241,15 @@ static int integrate_color_impl(nvbx_mapper* m, Pix rgb_dev, int32_t rows, int32
   NVBX_LAUNCH(m, k_sphere_trace, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), m->d, f, m->synth, srows, scols, m->p.sphere_tracing_max_steps,
                      m->p.sphere_tracing_max_ray_length_m, m->p.sphere_tracing_surface_eps_vox * m->p.voxel_size);
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);     // one resident batch of 512-thread workgroups
-  NVBX_LAUNCH(m, (k_integrate_color<Pix>), dim3(grid), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->mesh_list_live());
+  // ESDF site marking of the blocks dirtied since the last marking pass rides in this launch (256 extra single-wavefront
+  // workers): it reads only the TSDF, like the colour pass, and a following updateEsdf then needs the EDT kernel only
+  int mark_wg = 0;
+  EsdfArgs ea = m->make_esdf_args();
+  if (m->dirty_since_mark && !m->premark_consumed && ea.bz_hi >= ea.bz_lo && ea.bz_hi - ea.bz_lo + 1 <= 63) {
+    m->mark_pass++; ea.mark_pass = m->mark_pass; mark_wg = 256;
+    m->dirty_since_mark = false; m->premark_consumed = true;
+  }
+  NVBX_LAUNCH(m, (k_integrate_color<Pix>), dim3(grid + mark_wg), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->mesh_list_live(), (int32_t)grid, ea);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }

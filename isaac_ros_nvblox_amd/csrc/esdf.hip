@@ -21,6 +21,7 @@
 #include <cstring>
 #include <vector>
 #include "nvbx_mapper.h"
+#include "nvbx_esdf_mark.h"
 
 using namespace nvbx;
 
@@ -30,86 +31,7 @@ constexpr int EDT_MAX_NN = 2 * EDT_MAX_RB + 1;      // 17 x 17 neighbourhood
 constexpr int EDT_MAX_ROWS = 8 + 2 * 63;            // 134 rows of the local strip
 constexpr int EDT_ROW_WORDS = 5;                    // zero pad word + 3 data words (<= 136 bits) + zero pad word
 
-// Dependent-access chain: {shard counts of the dirty list} -> {dirty slot} -> {flags, Index3D} -> {hash entries of the ESDF block and of the
-// TSDF z-band blocks, one per lane, in flight together} -> {column stamp exchange || TSDF column loads} -> store.
-__global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a) {
-  const int lane = threadIdx.x;
-  const int vx = lane & 7, vy = lane >> 3;
-  ListView lv;
-  const int32_t n = list_open(m, S_LIST_ESDF_DIRTY, &lv);
-  const int nz = a.bz_hi - a.bz_lo + 1;                    // TSDF blocks spanned by the slice z band (<= 62)
-  const int srec = S_ESDF_REC + (int)(a.epoch & 1), sh = my_shard();
-  for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    const uint32_t tslot = (uint32_t)list_at(m, S_LIST_ESDF_DIRTY, lv, i);
-    const uint32_t tflags = m.slot_flags[tslot];
-    const int32_t bx = m.slot_index[3 * tslot], by = m.slot_index[3 * tslot + 1], bz = m.slot_index[3 * tslot + 2];
-    if (lane == 0) atomicAnd(&m.slot_flags[tslot], ~F_DIRTY_ESDF);
-    // a dirty TSDF block of the z band dirties its column; a block that lost its TSDF (decay) only re-marks an
-    // existing column
-    if (bz < a.bz_lo || bz > a.bz_hi) continue;
-    // lane 0: the ESDF block (x, y, z_slice); lanes 1..nz: the TSDF blocks of the band -- one probe each, together
-    const int32_t qz = lane == 0 ? a.bz_out : a.bz_lo + lane - 1;
-    const bool probing = lane <= nz;
-    const u64 qkey = pack_key(bx, by, qz);
-    const uint32_t qh = probing ? table_pos(m, bx, by, qz) : 0u;
-    const uint4 qe = ld_entry(m, qh);
-    uint32_t qslot = probing ? resolve_any(m, qkey, qh, qe) : SLOT_NONE;
-    uint32_t eslot = __shfl(qslot, 0);
-    const bool e_exists = slot_ok(eslot) && (m.slot_flags[slot_ok(eslot) ? eslot : 0] & F_ESDF);
-    if (!(tflags & F_TSDF) && !e_exists) continue;          // uniform
-    int first = 0, fresh = 0;
-    if (lane == 0) {
-      if (!slot_ok(eslot)) {                                // new column: insert (device-side allocation)
-        bool is_new;
-        const int32_t h = hash_insert(m, bx, by, a.bz_out, F_ESDF, &is_new);
-        if (h >= 0) { do { eslot = ld_slot_acquire(&m.table[h]); } while (eslot == SLOT_INVALID); }
-        fresh = is_new;                                     // (hash_insert gave the new slot its F_ESDF flag)
-      } else if (!e_exists) {
-        fresh = !(atomicOr(&m.slot_flags[eslot], F_ESDF) & F_ESDF);   // an existing (TSDF) block joins the ESDF layer now
-      }
-      if (slot_ok(eslot)) {
-        if (fresh) {                                        // the layer's AABB only grows when a block joins the layer
-          atomicMin(&m.counters[C_ESDF_AABB + 0], bx); atomicMin(&m.counters[C_ESDF_AABB + 1], by);
-          atomicMax(&m.counters[C_ESDF_AABB + 2], bx); atomicMax(&m.counters[C_ESDF_AABB + 3], by);
-        }
-        first = atomicExch(&m.slot_stamp[eslot], a.epoch) != a.epoch;
-      }
-    }
-    // TSDF columns of the band: this lane's (x, y) column of block bzz is voxels 64*vx + 8*vy + 0..7 = 64 contiguous bytes
-    // (weight 0 -- also what a slot without a TSDF block reads -- contributes nothing)
-    int observed = 0, inside = 0, site = 0;
-    for (int32_t q = 0; q < nz; ++q) {
-      const uint32_t ts = __shfl(qslot, q + 1);
-      if (!slot_ok(ts)) continue;                           // uniform
-      const int32_t bzz = a.bz_lo + q;
-      const float4* col = reinterpret_cast<const float4*>(&m.tsdf[(size_t)ts * 512 + 64 * vx + 8 * vy]);
-      float dz[8], wz[8];
-#pragma unroll
-      for (int w = 0; w < 4; w++) { const float4 v = col[w]; dz[2 * w] = v.x; wz[2 * w] = v.y; dz[2 * w + 1] = v.z; wz[2 * w + 1] = v.w; }
-#pragma unroll
-      for (int z = 0; z < 8; z++) {
-        const int32_t kz = bzz * 8 + z;
-        if (kz < a.kz_min || kz > a.kz_max) continue;
-        if (wz[z] >= a.min_weight) {
-          observed = 1;
-          const int in = dz[z] <= 0.0f;
-          if (in) inside = 1;
-          if ((a.site_rule == 1 || in) && fabsf(dz[z]) <= a.site_dist_m) site = 1;
-        }
-      }
-    }
-    eslot = __shfl(eslot, 0); first = __shfl(first, 0);
-    if (!first || !slot_ok(eslot)) continue;                // column already re-marked in this update
-    if (lane == 0) {                                         // window record: this workgroup's shard copy
-      atomicMin(shc_at(m, srec, sh, 0), bx); atomicMin(shc_at(m, srec, sh, 1), by);
-      atomicMax(shc_at(m, srec, sh, 2), bx); atomicMax(shc_at(m, srec, sh, 3), by);
-      atomicAdd(shc_at(m, srec, sh, 4), 1);
-    }
-    m.esdf[(size_t)eslot * 512 + a.vz_out * 64 + lane] = make_uint2(__float_as_uint(a.max_sq), esdf_meta(0, 0, 0, observed, inside, site));
-    const u64 bits = __ballot(site != 0);          // bit (x + 8y) of the block's slice plane
-    if (lane == 0) m.site_bits[eslot] = bits;
-  }
-}
+__global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a) { esdf_mark_worker(m, a, (int)blockIdx.x, (int)gridDim.x); }
 
 // Four wavefronts per ESDF block.  Dependent-access chain: {window record} -> {hash entries of the (2rb+1)^2
 // neighbourhood, own block included} -> {site masks, own layer flag, own voxel flags} -> LDS phases -> store.
@@ -230,6 +152,7 @@ __global__ __launch_bounds__(256) void k_esdf_edt(DMap m, EsdfArgs a) {
 extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
   if (!m) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));
+  if (m->dirty_since_mark) m->mark_pass++;
   const EsdfArgs a = m->make_esdf_args();
   if (m->p.esdf_max_distance_m / m->p.voxel_size >= 64.0f) { set_error("esdf_max_distance_m / voxel_size must be < 64 voxels"); return NVBX_E_INVALID; }
   if (a.bz_hi - a.bz_lo + 1 > 63 || a.bz_hi < a.bz_lo) { set_error("esdf slice z band must span 1..63 blocks"); return NVBX_E_INVALID; }
@@ -240,7 +163,9 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
     NVBX_HIP(hipStreamWaitEvent(m->side, m->ev_main, 0));
     s = m->side;
   }
-  NVBX_LAUNCH_ON(m, s, k_esdf_mark, dim3((unsigned)std::min<int64_t>(m->capacity, 1024)), dim3(64), m->d, a);
+  // marking pass only if something was dirtied since the last pass (integrateColor runs one fused into its own launch)
+  if (m->dirty_since_mark) NVBX_LAUNCH_ON(m, s, k_esdf_mark, dim3((unsigned)std::min<int64_t>(m->capacity, 1024)), dim3(64), m->d, a);
+  m->dirty_since_mark = false; m->premark_consumed = false;          // k_esdf_edt resets the dirty list
   NVBX_LAUNCH_ON(m, s, k_esdf_edt, dim3(1024), dim3(256), m->d, a);
   NVBX_HIP(hipGetLastError());
   if (m->use_side) { NVBX_HIP(hipEventRecord(m->ev_side, m->side)); m->side_pending = true; }
@@ -412,6 +337,7 @@ __global__ void k_export_dirty(DMap m, int32_t* out_idx, int32_t* out_count, int
 extern "C" int nvbx_esdf_dirty_list(nvbx_mapper* m, int32_t* indices_dev_out, int32_t* count_dev_out, int64_t capacity) {
   if (!m || !indices_dev_out || !count_dev_out || capacity <= 0) return NVBX_E_INVALID;
   if (m->join_side()) return NVBX_E_DEVICE;
+  // (a list already consumed by a marking pass still names the blocks dirtied since the last updateEsdf: export it as is)
   NVBX_LAUNCH(m, k_export_dirty, dim3(64), dim3(256), m->d, indices_dev_out, count_dev_out, (int32_t)std::min<int64_t>(capacity, m->capacity));
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
@@ -429,6 +355,7 @@ __global__ void k_import_dirty(DMap m, const int32_t* idx, const int32_t* count,
 extern "C" int nvbx_mark_esdf_dirty(nvbx_mapper* m, const int32_t* indices_dev, const int32_t* count_dev, int64_t max_count) {
   if (!m || !indices_dev || !count_dev || max_count < 0) return NVBX_E_INVALID;
   if (m->join_side()) return NVBX_E_DEVICE;
+  if (m->begin_dirtying()) return NVBX_E_DEVICE;
   NVBX_LAUNCH(m, k_import_dirty, dim3(64), dim3(256), m->d, indices_dev, count_dev, max_count);
   NVBX_HIP(hipGetLastError());
   return m->mark_main();
@@ -451,6 +378,7 @@ __global__ void k_import_dirty_gathered(DMap m, const int32_t* g, int32_t self_r
 extern "C" int nvbx_mark_esdf_dirty_gathered(nvbx_mapper* m, const int32_t* gathered_dev, int32_t world, int32_t self_rank, int64_t max_count) {
   if (!m || !gathered_dev || world < 1 || max_count < 0) return NVBX_E_INVALID;
   if (m->join_side()) return NVBX_E_DEVICE;
+  if (m->begin_dirtying()) return NVBX_E_DEVICE;
   if (world > 1 || self_rank < 0) NVBX_LAUNCH(m, k_import_dirty_gathered, dim3(16, (unsigned)world), dim3(256), m->d, gathered_dev, self_rank, max_count);
   NVBX_HIP(hipGetLastError());
   return m->mark_main();

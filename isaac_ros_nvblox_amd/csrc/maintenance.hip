@@ -105,6 +105,7 @@ extern "C" int nvbx_clear_tsdf_inside_shapes(nvbx_mapper* m, const nvbx_bounding
   if (!m || n_shapes < 0 || (n_shapes > 0 && !shapes_host)) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));
   if (m->join_side()) return NVBX_E_DEVICE;
+  if (m->begin_dirtying()) return NVBX_E_DEVICE;
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);
   for (int32_t o = 0; o < n_shapes; o += 16) {
     ShapeArgs a{}; a.n = std::min(16, n_shapes - o);
@@ -157,6 +158,7 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   if (!m) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));
   if (m->join_side()) return NVBX_E_DEVICE;
+  if (m->begin_dirtying()) return NVBX_E_DEVICE;
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
   NVBX_LAUNCH(m, k_decay, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
                      exclude_last_view ? m->last_view_frame : 0u, m->mesh_list_live());

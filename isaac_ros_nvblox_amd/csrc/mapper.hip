@@ -184,6 +184,7 @@ static int reset_map(nvbx_mapper* m) {
   const int64_t n = std::max<int64_t>(cap, std::max<int64_t>(C_NUM, S_NUM * NSH * SH_STRIDE));
   NVBX_LAUNCH(m, k_init_map, dim3((unsigned)((n + 255) / 256)), dim3(256), d);
   NVBX_HIP(hipGetLastError());
+  m->dirty_since_mark = false; m->premark_consumed = false; m->mark_pass = 0;
   m->frame_id = 0; m->esdf_epoch = 0; m->mesh_epoch = 0; m->last_view_frame = 0; m->synth_rows = m->synth_cols = 0;
   return NVBX_OK;
 }
@@ -235,7 +236,7 @@ EsdfArgs nvbx_mapper::make_esdf_args() const {
   c.rb = (c.ri + 7) / 8;
   c.site_dist_m = p.esdf_max_site_distance_vox * vs;
   c.min_weight = p.esdf_min_weight; c.voxel_size = vs; c.site_rule = p.esdf_site_rule;
-  c.epoch = esdf_epoch;
+  c.epoch = esdf_epoch; c.mark_pass = mark_pass;
   c.rec = C_ESDF_UPD + 8 * (int)(esdf_epoch & 1); c.rec_next = C_ESDF_UPD + 8 * (int)((esdf_epoch + 1) & 1);
   return c;
 }
@@ -396,6 +397,7 @@ extern "C" int nvbx_get_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, 
 extern "C" int nvbx_set_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, const void* voxels_in) {
   if (!m || !voxels_in || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF)) return NVBX_E_INVALID;
   if (m->join_side()) return NVBX_E_DEVICE;
+  if (m->begin_dirtying()) return NVBX_E_DEVICE;
   const size_t bb = 512 * ref_voxel_bytes(layer);
   NVBX_HIP(hipMemcpyAsync(m->staging, voxels_in, bb, hipMemcpyHostToDevice, m->stream));
   const EsdfArgs ea = m->make_esdf_args();
@@ -437,6 +439,11 @@ void nvbx_mapper::span_begin(const char* name, hipStream_t st) {
 }
 void nvbx_mapper::span_end(hipStream_t st) { (void)hipEventRecord(spans.back().b, st); }
 
+__global__ void k_reset_esdf_dirty_list(DMap m) { if (threadIdx.x < NSH) *shc_at(m, S_LIST_ESDF_DIRTY, threadIdx.x, 0) = 0; }
+int nvbx_mapper::reset_consumed_list() {
+  if (premark_consumed) { NVBX_LAUNCH(this, k_reset_esdf_dirty_list, dim3(1), dim3(64), d); premark_consumed = false; }
+  return NVBX_OK;
+}
 int nvbx_mapper::join_side() {
   main_dirty = true;
   if (side_pending) { NVBX_HIP(hipStreamWaitEvent(stream, ev_side, 0)); side_pending = false; }

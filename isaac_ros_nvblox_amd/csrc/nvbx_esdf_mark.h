@@ -1,0 +1,92 @@
+// nvbx_esdf_mark.h -- the ESDF site-marking worker (first half of MultiMapper::updateEsdf), shared by k_esdf_mark (esdf.hip)
+// and by k_integrate_color (color.hip), which runs it in extra workgroups of its own launch: marking depends only on the
+// TSDF, exactly like colour integration, so the two overlap inside one launch and a following updateEsdf needs the EDT only.
+#pragma once
+#include "nvbx_mapper.h"
+
+namespace nvbx {
+
+// Dependent-access chain: {shard counts of the dirty list} -> {dirty slot} -> {flags, Index3D} -> {hash entries of the ESDF block and of the
+// TSDF z-band blocks, one per lane, in flight together} -> {column stamp exchange || TSDF column loads} -> store.
+// `wg` of `nwg` single-wavefront workers; called by k_esdf_mark and by the marking workgroups fused into k_integrate_color.
+__device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg, int nwg) {
+  const int lane = threadIdx.x & 63;
+  const int vx = lane & 7, vy = lane >> 3;
+  ListView lv;
+  const int32_t n = list_open(m, S_LIST_ESDF_DIRTY, &lv);
+  const int nz = a.bz_hi - a.bz_lo + 1;                    // TSDF blocks spanned by the slice z band (<= 62)
+  const int srec = S_ESDF_REC + (int)(a.epoch & 1), sh = my_shard();
+  for (int32_t i = wg; i < n; i += nwg) {
+    const uint32_t tslot = (uint32_t)list_at(m, S_LIST_ESDF_DIRTY, lv, i);
+    const uint32_t tflags = m.slot_flags[tslot];
+    const int32_t bx = m.slot_index[3 * tslot], by = m.slot_index[3 * tslot + 1], bz = m.slot_index[3 * tslot + 2];
+    if (lane == 0) atomicAnd(&m.slot_flags[tslot], ~F_DIRTY_ESDF);
+    // a dirty TSDF block of the z band dirties its column; a block that lost its TSDF (decay) only re-marks an
+    // existing column
+    if (bz < a.bz_lo || bz > a.bz_hi) continue;
+    // lane 0: the ESDF block (x, y, z_slice); lanes 1..nz: the TSDF blocks of the band -- one probe each, together
+    const int32_t qz = lane == 0 ? a.bz_out : a.bz_lo + lane - 1;
+    const bool probing = lane <= nz;
+    const u64 qkey = pack_key(bx, by, qz);
+    const uint32_t qh = probing ? table_pos(m, bx, by, qz) : 0u;
+    const uint4 qe = ld_entry(m, qh);
+    uint32_t qslot = probing ? resolve_any(m, qkey, qh, qe) : SLOT_NONE;
+    uint32_t eslot = __shfl(qslot, 0);
+    const bool e_exists = slot_ok(eslot) && (m.slot_flags[slot_ok(eslot) ? eslot : 0] & F_ESDF);
+    if (!(tflags & F_TSDF) && !e_exists) continue;          // uniform
+    int first = 0, fresh = 0;
+    if (lane == 0) {
+      if (!slot_ok(eslot)) {                                // new column: insert (device-side allocation)
+        bool is_new;
+        const int32_t h = hash_insert(m, bx, by, a.bz_out, F_ESDF, &is_new);
+        if (h >= 0) { do { eslot = ld_slot_acquire(&m.table[h]); } while (eslot == SLOT_INVALID); }
+        fresh = is_new;                                     // (hash_insert gave the new slot its F_ESDF flag)
+      } else if (!e_exists) {
+        fresh = !(atomicOr(&m.slot_flags[eslot], F_ESDF) & F_ESDF);   // an existing (TSDF) block joins the ESDF layer now
+      }
+      if (slot_ok(eslot)) {
+        if (fresh) {                                        // the layer's AABB only grows when a block joins the layer
+          atomicMin(&m.counters[C_ESDF_AABB + 0], bx); atomicMin(&m.counters[C_ESDF_AABB + 1], by);
+          atomicMax(&m.counters[C_ESDF_AABB + 2], bx); atomicMax(&m.counters[C_ESDF_AABB + 3], by);
+        }
+        first = atomicExch(&m.slot_stamp[eslot], a.mark_pass) != a.mark_pass;
+      }
+    }
+    // TSDF columns of the band: this lane's (x, y) column of block bzz is voxels 64*vx + 8*vy + 0..7 = 64 contiguous bytes
+    // (weight 0 -- also what a slot without a TSDF block reads -- contributes nothing)
+    int observed = 0, inside = 0, site = 0;
+    for (int32_t q = 0; q < nz; ++q) {
+      const uint32_t ts = __shfl(qslot, q + 1);
+      if (!slot_ok(ts)) continue;                           // uniform
+      const int32_t bzz = a.bz_lo + q;
+      const float4* col = reinterpret_cast<const float4*>(&m.tsdf[(size_t)ts * 512 + 64 * vx + 8 * vy]);
+      float dz[8], wz[8];
+#pragma unroll
+      for (int w = 0; w < 4; w++) { const float4 v = col[w]; dz[2 * w] = v.x; wz[2 * w] = v.y; dz[2 * w + 1] = v.z; wz[2 * w + 1] = v.w; }
+#pragma unroll
+      for (int z = 0; z < 8; z++) {
+        const int32_t kz = bzz * 8 + z;
+        if (kz < a.kz_min || kz > a.kz_max) continue;
+        if (wz[z] >= a.min_weight) {
+          observed = 1;
+          const int in = dz[z] <= 0.0f;
+          if (in) inside = 1;
+          if ((a.site_rule == 1 || in) && fabsf(dz[z]) <= a.site_dist_m) site = 1;
+        }
+      }
+    }
+    eslot = __shfl(eslot, 0); first = __shfl(first, 0);
+    if (!first || !slot_ok(eslot)) continue;                // column already re-marked in this marking pass
+    if (lane == 0) {                                         // window record: this workgroup's shard copy
+      atomicMin(shc_at(m, srec, sh, 0), bx); atomicMin(shc_at(m, srec, sh, 1), by);
+      atomicMax(shc_at(m, srec, sh, 2), bx); atomicMax(shc_at(m, srec, sh, 3), by);
+      atomicAdd(shc_at(m, srec, sh, 4), 1);
+    }
+    m.esdf[(size_t)eslot * 512 + a.vz_out * 64 + lane] = make_uint2(__float_as_uint(a.max_sq), esdf_meta(0, 0, 0, observed, inside, site));
+    const u64 bits = __ballot(site != 0);          // bit (x + 8y) of the block's slice plane
+    if (lane == 0) m.site_bits[eslot] = bits;
+  }
+}
+
+
+}  // namespace nvbx

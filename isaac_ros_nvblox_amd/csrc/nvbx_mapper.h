@@ -17,6 +17,7 @@ struct EsdfArgs {
   float max_sq, site_dist_m, min_weight, voxel_size;
   int32_t site_rule;
   uint32_t epoch;
+  uint32_t mark_pass;               // stamp of this marking pass (column de-duplication within one pass)
   int32_t rec;                      // C_ESDF_UPD + 8 * (epoch & 1)
   int32_t rec_next;                 // record of the next epoch (reset by this update)
 };
@@ -65,6 +66,12 @@ struct nvbx_mapper {
   int32_t* h_counters = nullptr;     // pinned
   uint32_t frame_id = 0;
   uint32_t esdf_epoch = 0;
+  uint32_t mark_pass = 0;            // ESDF marking passes launched so far
+  // ESDF marking state: `dirty_since_mark` = TSDF changed since the last marking pass; `premark_consumed` = the dirty list
+  // was processed by a pass that no EDT followed yet, so it must be emptied before anything is appended to it
+  bool dirty_since_mark = false, premark_consumed = false;
+  int reset_consumed_list();         // empty a consumed dirty list (tiny launch; rare paths only)
+  int begin_dirtying() { const int rc = reset_consumed_list(); dirty_since_mark = true; return rc; }
   uint32_t mesh_epoch = 0;
   int mesh_list_live() const { return nvbx::S_LIST_MESH_DIRTY + (int)(mesh_epoch & 1); }   // mesh-dirty list being filled
   int32_t* h_shc = nullptr;          // pinned mirror of d.shc

@@ -284,7 +284,7 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
 }
 
 template <typename Img, typename Sensor>
-__global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Sensor sensor, int4* view_list, int32_t list_cap) {
+__global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Sensor sensor, int4* view_list, int32_t list_cap, int32_t reset_esdf_dirty) {
   constexpr int LSET = Sensor::kSetSize, FR = Sensor::kFlushRounds;
   __shared__ u64 lset[LSET];
   __shared__ u64 lkeys[LSET];
@@ -302,6 +302,8 @@ __global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Se
   const float d = active ? depth((int64_t)prow * f.cols + pcol) : 0.0f;
   for (int i = lane; i < LSET; i += 64) lset[i] = KEY_EMPTY;
   if (blockIdx.x == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
+  // an ESDF dirty list already consumed by a marking pass (fused into integrateColor) is emptied before k_integrate_tsdf appends
+  if (reset_esdf_dirty && blockIdx.x == 0 && lane < NSH) *shc_at(m, S_LIST_ESDF_DIRTY, lane, 0) = 0;
   __syncthreads();
 
   int32_t cur[3] = {0, 0, 0}, step[3] = {0, 0, 0}, nsteps = -1;
@@ -441,7 +443,8 @@ static int integrate_depth_impl(nvbx_mapper* m, Img img, const Sensor& sensor, c
   f.n_ray_rows = (f.rows + s - 1 + s - 1) / s;   // indices i with i*s < rows + s - 1
   f.n_ray_cols = (f.cols + s - 1 + s - 1) / s;
   const int tiles = ((f.n_ray_rows + Sensor::kTileRows - 1) / Sensor::kTileRows) * ((f.n_ray_cols + Sensor::kTileCols - 1) / Sensor::kTileCols);
-  NVBX_LAUNCH(m, (k_mark_view<Img, Sensor>), dim3(tiles), dim3(64), m->d, f, img, sensor, (int4*)m->view_list, (int32_t)m->capacity);
+  NVBX_LAUNCH(m, (k_mark_view<Img, Sensor>), dim3(tiles), dim3(64), m->d, f, img, sensor, (int4*)m->view_list, (int32_t)m->capacity, (int32_t)(m->premark_consumed ? 1 : 0));
+  m->premark_consumed = false; m->dirty_since_mark = true;
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);
   NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor>), dim3(grid), dim3(512), m->d, f, img, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
                      m->mesh_list_live());
