@@ -170,6 +170,7 @@ def main():
             g.update_color_mesh()
 
     def barrier():
+        g.synchronize()          # launches anything the mapper holds back (the EDT of the last updateEsdf) and waits for its stream
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -197,10 +198,10 @@ def main():
 
     # ---- rank 0 extras (outside the timed region): per-component times, per-kernel roofline, CPU baseline
     def timed(fn, n):
-        torch.cuda.synchronize(dev); t = time.perf_counter()
+        g.synchronize(); torch.cuda.synchronize(dev); t = time.perf_counter()
         for i in range(n):
             fn(i)
-        torch.cuda.synchronize(dev)
+        g.synchronize(); torch.cuda.synchronize(dev)
         return (time.perf_counter() - t) / n * 1e3
 
     base = args.warmup + args.steps

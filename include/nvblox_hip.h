@@ -11,7 +11,7 @@
  *     GPU, everything else is host memory.
  *   - all work is enqueued on the mapper's stream (the reference is single-caller, stream-ordered:
  *     nvblox_ros/src/lib/nvblox_node.cpp:99,456-459).  Functions that return host-visible results synchronise that
- *     stream; the integrate / update calls do not.
+ *     stream; the integrate / update calls do not.  (One piece of work may be enqueued one call late: see nvbx_update_esdf.)
  *   - return value: 0 = ok, negative = error (NVBX_E_*).  Nothing throws across the boundary; device faults are
  *     reported through nvbx_last_error().  (Reference convention: bool for I/O, CHECK/abort for programmer errors,
  *     checkCudaErrors -> exit(99): nvblox_ros_common/src/check_cuda_errors.cpp:24-32.)
@@ -161,7 +161,13 @@ int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, i
  * colour fetch (one aligned 4-byte load per tap). */
 int nvbx_integrate_color_bgra8(nvbx_mapper* m, const uint8_t* bgra_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                const nvbx_camera* camera);
-/* MultiMapper::updateEsdf() (EsdfMode::k2D) -- nvblox_node.cpp:781 */
+/* MultiMapper::updateEsdf() (EsdfMode::k2D) -- nvblox_node.cpp:781.
+ * Scheduling note: the site-marking half runs at once (or already ran inside the preceding nvbx_integrate_color launch);
+ * the distance-transform half may be HELD BACK until the next entry point of this mapper: nvbx_integrate_depth[_u16mm]
+ * runs it inside its first launch, beside the view marking it does not interact with; every other entry point -- all
+ * queries, nvbx_synchronize, colour / LiDAR integration, mesh, maintenance -- enqueues it first.  Results observed through
+ * this API are therefore always those of the completed update; a caller that only synchronises the raw stream and calls
+ * nothing else leaves the transform un-enqueued until its next call.  NVBX_DEFER_EDT=0 in the environment disables this. */
 int nvbx_update_esdf(nvbx_mapper* m);
 /* Mapper::updateColorMesh(UpdateFullLayer) -- layer_publishing.cpp:686-689, nvblox_node.cpp:1611 */
 int nvbx_update_color_mesh(nvbx_mapper* m, int32_t update_full_layer);

@@ -22,131 +22,15 @@
 #include <vector>
 #include "nvbx_mapper.h"
 #include "nvbx_esdf_mark.h"
+#include "nvbx_esdf_edt.h"
 
 using namespace nvbx;
 
-constexpr int8_t DX_NONE = 127;
-constexpr int EDT_MAX_RB = 8;                       // ri <= 63 voxels -> <= 8 blocks each side
-constexpr int EDT_MAX_NN = 2 * EDT_MAX_RB + 1;      // 17 x 17 neighbourhood
-constexpr int EDT_MAX_ROWS = 8 + 2 * 63;            // 134 rows of the local strip
-constexpr int EDT_ROW_WORDS = 5;                    // zero pad word + 3 data words (<= 136 bits) + zero pad word
-
 __global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a) { esdf_mark_worker(m, a, (int)blockIdx.x, (int)gridDim.x); }
 
-// Four wavefronts per ESDF block.  Dependent-access chain: {window record} -> {hash entries of the (2rb+1)^2
-// neighbourhood, own block included} -> {site masks, own layer flag, own voxel flags} -> LDS phases -> store.
 __global__ __launch_bounds__(256) void k_esdf_edt(DMap m, EsdfArgs a) {
-  __shared__ u64 s_bits[EDT_MAX_NN * EDT_MAX_NN];
-  __shared__ u64 s_rows[EDT_MAX_ROWS * EDT_ROW_WORDS];
-  __shared__ int8_t s_dx[EDT_MAX_ROWS * 8];
-  __shared__ int32_t s_part[4 * 64];
-  __shared__ uint32_t s_own[2];               // own slot, own layer flags
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int vx = lane & 7, vy = lane >> 3;
-  // sweep window = dirty AABB of this update (min / max over the shard copies) + R (in blocks), decided on the device
-  const int srec = S_ESDF_REC + (int)(a.epoch & 1), srec_next = S_ESDF_REC + (int)((a.epoch + 1) & 1);
-  int32_t x0 = INT32_MAX, y0 = INT32_MAX, x1 = INT32_MIN, y1 = INT32_MIN;
-#pragma unroll
-  for (int s = 0; s < NSH; s++) {
-    x0 = min(x0, *shc_at(m, srec, s, 0)); y0 = min(y0, *shc_at(m, srec, s, 1));
-    x1 = max(x1, *shc_at(m, srec, s, 2)); y1 = max(y1, *shc_at(m, srec, s, 3));
-  }
-  const bool ok = x0 <= x1 && y0 <= y1;
-  const int32_t wx0 = x0 - a.rb, wy0 = y0 - a.rb, ww = x1 - x0 + 1 + 2 * a.rb, wh = y1 - y0 + 1 + 2 * a.rb;
-  if (blockIdx.x == 0 && tid < NSH) {                             // next update's record, one shard per thread
-    *shc_at(m, srec_next, tid, 0) = INT32_MAX; *shc_at(m, srec_next, tid, 1) = INT32_MAX;
-    *shc_at(m, srec_next, tid, 2) = INT32_MIN; *shc_at(m, srec_next, tid, 3) = INT32_MIN;
-    *shc_at(m, srec_next, tid, 4) = 0; *shc_at(m, srec_next, tid, 5) = 0;
-    *shc_at(m, S_LIST_ESDF_DIRTY, tid, 0) = 0;                     // dirty list consumed by k_esdf_mark
-    if (tid == 0) { m.counters[a.rec_next + 6] = 0; if (ok) m.counters[a.rec + 6] = ww * 8 * wh * 8; }
-  }
-  if (!ok) return;
-  const int nn = 2 * a.rb + 1;                // neighbourhood side in blocks
-  const int ctr = a.rb * nn + a.rb;           // own block's position in the neighbourhood
-  const int rows = 8 + 2 * a.ri;              // local strip: rows Y0 - ri .. Y0 + 7 + ri
-  const int yoff = 8 * a.rb - a.ri;           // strip row 0 in neighbourhood voxel rows
-  const int32_t ncell = ww * wh;
-  for (int32_t c = blockIdx.x; c < ncell; c += gridDim.x) {
-    const int32_t cy = c / ww, cx = c - cy * ww;
-    const int32_t bx = wx0 + cx, by = wy0 + cy;
-    __syncthreads();                     // previous block's LDS reads are done
-    // 1. site masks of the nn x nn surrounding blocks (zero where there is no block: site_bits of non-ESDF slots is 0)
-    for (int q = tid; q < nn * nn; q += 256) {
-      const int qy = q / nn, qx = q - qy * nn;
-      const uint32_t s = any_slot(m, bx + qx - a.rb, by + qy - a.rb, a.bz_out);
-      s_bits[q] = slot_ok(s) ? m.site_bits[s] : 0ull;
-      if (q == ctr) { s_own[0] = s; s_own[1] = slot_ok(s) ? m.slot_flags[s] : 0u; }
-    }
-    __syncthreads();
-    const uint32_t es = s_own[0];
-    if (!slot_ok(es) || !(s_own[1] & F_ESDF)) continue;          // uniform: no ESDF block in this window cell
-    uint2* vp = &m.esdf[(size_t)es * 512 + a.vz_out * 64 + lane];
-    uint32_t vflags = 0;
-    if (wave == 0) vflags = vp->y & ESDF_FLAG_MASK;               // issued early, consumed at the store
-    // 2. row bitmap: word w of row r holds neighbourhood voxel columns 64(w-1) .. 64(w-1)+63 (bit = column & 63)
-    for (int q = tid; q < rows * EDT_ROW_WORDS; q += 256) {
-      const int r = q / EDT_ROW_WORDS, w = q - r * EDT_ROW_WORDS;
-      u64 word = 0ull;
-      if (w >= 1 && w <= 3) {
-        const int yy = r + yoff, qy = yy >> 3, sh = 8 * (yy & 7);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-          const int qx = (w - 1) * 8 + b;
-          if (qx < nn) word |= ((s_bits[qy * nn + qx] >> sh) & 0xFFull) << (8 * b);
-        }
-      }
-      s_rows[q] = word;
-    }
-    __syncthreads();
-    // 3. row pass: nearest site along x within ri (ties -> -x), for the block's own 8 columns on every strip row
-    for (int q = tid; q < rows * 8; q += 256) {
-      const int r = q >> 3, X = 8 * a.rb + (q & 7);
-      const u64* row = &s_rows[r * EDT_ROW_WORDS];
-      const int wi = 1 + (X >> 6), b = X & 63;
-      const u64 cur = row[wi], prev = row[wi - 1], next = row[wi + 1];
-      const u64 left = (b == 63) ? cur : ((cur << (63 - b)) | (prev >> (b + 1)));   // bit 63 <-> x, bit 62 <-> x-1, ...
-      const u64 right = (b == 0) ? cur : ((cur >> b) | (next << (64 - b)));         // bit 0 <-> x, bit 1 <-> x+1, ...
-      const int dl = left ? __clzll((long long)left) : 64;
-      const int dr = right ? (__ffsll((long long)right) - 1) : 64;
-      int8_t v = DX_NONE;
-      if (dl <= dr) { if (dl <= a.ri) v = (int8_t)(-dl); }
-      else { if (dr <= a.ri) v = (int8_t)dr; }
-      s_dx[q] = v;
-    }
-    __syncthreads();
-    // 4. column pass: argmin over dy of (dy^2 + dx^2, dy) -- the oracle scans dy ascending with strict improvement,
-    //    i.e. the smallest dy among equal distances.  Wave w takes |dy| = w, w+4, ... (increasing, stop at dy^2 > best);
-    //    the four partial minima are merged with the same lexicographic rule.
-    int32_t best = INT32_MAX, bdx = 0, bdy = 0;
-    for (int ady = wave; ady <= a.ri; ady += 4) {
-      if (ady * ady > best) break;
-#pragma unroll
-      for (int sgn = 0; sgn < 2; sgn++) {
-        if (sgn == 1 && ady == 0) continue;
-        const int dy = sgn == 0 ? -ady : ady;
-        const int8_t dx = s_dx[(vy + a.ri + dy) * 8 + vx];
-        if (dx == DX_NONE) continue;
-        const int32_t sq = dy * dy + (int32_t)dx * dx;
-        if (sq < best || (sq == best && dy < bdy)) { best = sq; bdx = dx; bdy = dy; }
-      }
-    }
-    // pack (sq, dy, dx) so that integer min == lexicographic (sq, dy) min: sq < 2^13, dy + 64 < 2^7, dx + 64 < 2^7
-    s_part[wave * 64 + lane] = best == INT32_MAX ? INT32_MAX : ((best << 14) | ((bdy + 64) << 7) | (bdx + 64));
-    __syncthreads();
-    if (wave == 0) {
-      int32_t p = s_part[lane];
-#pragma unroll
-      for (int w = 1; w < 4; w++) { const int32_t o = s_part[w * 64 + lane]; if (o < p) p = o; }
-      if (p != INT32_MAX && (float)(p >> 14) <= a.max_sq) {
-        const int32_t fdx = (p & 127) - 64, fdy = ((p >> 7) & 127) - 64;
-        *vp = make_uint2(__float_as_uint((float)(p >> 14)), vflags | ((uint32_t)(uint8_t)(int8_t)fdx) | (((uint32_t)(uint8_t)(int8_t)fdy) << 8));
-      } else {
-        *vp = make_uint2(__float_as_uint(a.max_sq), vflags);
-      }
-      if (lane == 0) atomicAdd(shc_at(m, srec, my_shard(), 5), 1);
-    }
-  }
+  __shared__ EdtShared sh;
+  esdf_edt_worker(m, a, (int)blockIdx.x, (int)gridDim.x, &sh);
 }
 
 extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
@@ -166,7 +50,13 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
   // marking pass only if something was dirtied since the last pass (integrateColor runs one fused into its own launch)
   if (m->dirty_since_mark) NVBX_LAUNCH_ON(m, s, k_esdf_mark, dim3((unsigned)std::min<int64_t>(m->capacity, 1024)), dim3(64), m->d, a);
   m->dirty_since_mark = false; m->premark_consumed = false;          // k_esdf_edt resets the dirty list
-  NVBX_LAUNCH_ON(m, s, k_esdf_edt, dim3(1024), dim3(256), m->d, a);
+  if (m->defer_edt && !m->use_side) {
+    // The EDT is held back until the next entry point: the next camera depth frame runs it inside its first launch (beside
+    // the view marking, which it does not interact with); every other entry point launches it first (flush_edt).
+    m->edt_pending = true; m->edt_args = a;
+  } else {
+    NVBX_LAUNCH_ON(m, s, k_esdf_edt, dim3(1024), dim3(256), m->d, a);
+  }
   NVBX_HIP(hipGetLastError());
   if (m->use_side) { NVBX_HIP(hipEventRecord(m->ev_side, m->side)); m->side_pending = true; }
   m->esdf_epoch++;
@@ -382,4 +272,14 @@ extern "C" int nvbx_mark_esdf_dirty_gathered(nvbx_mapper* m, const int32_t* gath
   if (world > 1 || self_rank < 0) NVBX_LAUNCH(m, k_import_dirty_gathered, dim3(16, (unsigned)world), dim3(256), m->d, gathered_dev, self_rank, max_count);
   NVBX_HIP(hipGetLastError());
   return m->mark_main();
+}
+
+// launch a held-back EDT now (every entry point except the camera integrateDepth, which lets it ride in k_mark_view)
+int nvbx_mapper::flush_edt() {
+  if (edt_pending) {
+    edt_pending = false;
+    NVBX_LAUNCH(this, k_esdf_edt, dim3(1024), dim3(256), d, edt_args);
+    NVBX_HIP(hipGetLastError());
+  }
+  return NVBX_OK;
 }

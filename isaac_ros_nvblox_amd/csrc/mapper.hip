@@ -184,7 +184,7 @@ static int reset_map(nvbx_mapper* m) {
   const int64_t n = std::max<int64_t>(cap, std::max<int64_t>(C_NUM, S_NUM * NSH * SH_STRIDE));
   NVBX_LAUNCH(m, k_init_map, dim3((unsigned)((n + 255) / 256)), dim3(256), d);
   NVBX_HIP(hipGetLastError());
-  m->dirty_since_mark = false; m->premark_consumed = false; m->mark_pass = 0;
+  m->dirty_since_mark = false; m->premark_consumed = false; m->mark_pass = 0; m->edt_pending = false;
   m->frame_id = 0; m->esdf_epoch = 0; m->mesh_epoch = 0; m->last_view_frame = 0; m->synth_rows = m->synth_cols = 0;
   return NVBX_OK;
 }
@@ -254,6 +254,7 @@ extern "C" int nvbx_mapper_create(int device, void* hip_stream, const nvbx_mappe
   // ESDF on a side stream beside colour integration: off by default, NVBX_SIDE_STREAM=1 enables (the
   // cross-stream hand-off costs ~10 us each way on this runtime, which eats most of the overlap)
   { const char* e = getenv("NVBX_SIDE_STREAM"); m->use_side = (e && e[0] == '1'); }
+  { const char* e = getenv("NVBX_DEFER_EDT"); m->defer_edt = !(e && e[0] == '0'); }
   if (m->use_side) {
     if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming) != hipSuccess ||
@@ -445,6 +446,7 @@ int nvbx_mapper::reset_consumed_list() {
   return NVBX_OK;
 }
 int nvbx_mapper::join_side() {
+  if (flush_edt()) return NVBX_E_DEVICE;
   main_dirty = true;
   if (side_pending) { NVBX_HIP(hipStreamWaitEvent(stream, ev_side, 0)); side_pending = false; }
   return NVBX_OK;

@@ -70,6 +70,9 @@ struct nvbx_mapper {
   // ESDF marking state: `dirty_since_mark` = TSDF changed since the last marking pass; `premark_consumed` = the dirty list
   // was processed by a pass that no EDT followed yet, so it must be emptied before anything is appended to it
   bool dirty_since_mark = false, premark_consumed = false;
+  // held-back EDT of the last updateEsdf (NVBX_DEFER_EDT=0 disables): see nvbx_update_esdf
+  bool defer_edt = true, edt_pending = false; nvbx::EsdfArgs edt_args{};
+  int flush_edt();
   int reset_consumed_list();         // empty a consumed dirty list (tiny launch; rare paths only)
   int begin_dirtying() { const int rc = reset_consumed_list(); dirty_since_mark = true; return rc; }
   uint32_t mesh_epoch = 0;

@@ -21,6 +21,7 @@
 #include <vector>
 #include "nvbx_mapper.h"
 #include "nvbx_lidar_math.h"
+#include "nvbx_esdf_edt.h"
 
 using namespace nvbx;
 
@@ -32,6 +33,7 @@ struct CameraSensor {
   static constexpr int kSetSize = 512, kFlushRounds = 2; // a tile crosses < 100 blocks: 4 KiB set, 128 keys per flush pass
   static constexpr int kSegments = 1;                    // lanes per ray
   static constexpr int kProbeDepth = 2;                  // hash probe positions fetched up front per key in a flush
+  static constexpr int kThreads = 256;                   // 4 waves: the tile uses the first, a riding EDT workgroup all four
   // end point (camera frame) of the ray through the centre of pixel (prow, pcol) at depth `de` along the optical axis
   __device__ void ray_end(const Frame& f, int prow, int pcol, float de, float* pc) const {
     const float rx = (((float)pcol + 0.5f) - f.cu) / f.fu;
@@ -62,6 +64,7 @@ struct LidarSensor {
   // quarter with set inserts: 4 x 4 rays x 4 segments = 64 busy lanes, ~63 instead of ~250 insert steps per wavefront.
   static constexpr int kSegments = 4;
   static constexpr int kProbeDepth = 4;
+  static constexpr int kThreads = 64;
   nvbx_lidar_model l;
   const float2* el_tab; const float2* az_tab;
   float max_diff_m, max_ray_dist_m;
@@ -283,11 +286,24 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
   __syncthreads();
 }
 
+// Workgroups [0, n_tile_wg) mark the view (first wavefront only); workgroups beyond that (camera launches only, when an EDT
+// was held back by updateEsdf) are EDT workers with all four wavefronts.
 template <typename Img, typename Sensor>
-__global__ __launch_bounds__(64) void k_mark_view(DMap m, Frame f, Img depth, Sensor sensor, int4* view_list, int32_t list_cap, int32_t reset_esdf_dirty) {
+__global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, Frame f, Img depth, Sensor sensor, int4* view_list, int32_t list_cap,
+                                                                int32_t reset_esdf_dirty, int32_t n_tile_wg, EsdfArgs ea) {
   constexpr int LSET = Sensor::kSetSize, FR = Sensor::kFlushRounds;
-  __shared__ u64 lset[LSET];
-  __shared__ u64 lkeys[LSET];
+  constexpr size_t kMarkBytes = 2 * LSET * sizeof(u64);
+  constexpr size_t kSmem = (Sensor::kThreads == 256 && sizeof(EdtShared) > kMarkBytes) ? sizeof(EdtShared) : kMarkBytes;
+  __shared__ __align__(16) unsigned char smem[kSmem];
+  if (Sensor::kThreads == 256) {
+    if ((int32_t)blockIdx.x >= n_tile_wg) {
+      esdf_edt_worker(m, ea, (int)blockIdx.x - n_tile_wg, (int)gridDim.x - n_tile_wg, reinterpret_cast<EdtShared*>(smem));
+      return;
+    }
+    if (threadIdx.x >= 64) return;            // a tile is one wavefront
+  }
+  u64* lset = reinterpret_cast<u64*>(smem);
+  u64* lkeys = lset + LSET;
   const int lane = threadIdx.x;
   constexpr int TR = Sensor::kTileRows, TC = Sensor::kTileCols, NSEG = Sensor::kSegments;
   static_assert(TR * TC * NSEG <= 64, "one wavefront per tile");
@@ -443,7 +459,14 @@ static int integrate_depth_impl(nvbx_mapper* m, Img img, const Sensor& sensor, c
   f.n_ray_rows = (f.rows + s - 1 + s - 1) / s;   // indices i with i*s < rows + s - 1
   f.n_ray_cols = (f.cols + s - 1 + s - 1) / s;
   const int tiles = ((f.n_ray_rows + Sensor::kTileRows - 1) / Sensor::kTileRows) * ((f.n_ray_cols + Sensor::kTileCols - 1) / Sensor::kTileCols);
-  NVBX_LAUNCH(m, (k_mark_view<Img, Sensor>), dim3(tiles), dim3(64), m->d, f, img, sensor, (int4*)m->view_list, (int32_t)m->capacity, (int32_t)(m->premark_consumed ? 1 : 0));
+  // a held-back EDT rides in this launch (camera: 256-thread workgroups); the LiDAR launch is 64 threads wide, so flush first
+  int edt_wg = 0; EsdfArgs ea = m->edt_args;
+  if (m->edt_pending) {
+    if (Sensor::kThreads == 256) { edt_wg = 256; m->edt_pending = false; }
+    else if (m->flush_edt()) return NVBX_E_DEVICE;
+  }
+  NVBX_LAUNCH(m, (k_mark_view<Img, Sensor>), dim3(tiles + edt_wg), dim3(Sensor::kThreads), m->d, f, img, sensor, (int4*)m->view_list, (int32_t)m->capacity,
+              (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)tiles, ea);
   m->premark_consumed = false; m->dirty_since_mark = true;
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);
   NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor>), dim3(grid), dim3(512), m->d, f, img, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
@@ -475,7 +498,9 @@ __global__ void k_dilate_invalid(Img in, int32_t rows, int32_t cols, int32_t n, 
 template <typename Img>
 static int integrate_camera(nvbx_mapper* m, Img img, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera) {
   NVBX_HIP(hipSetDevice(m->device));
-  if (m->join_side()) return NVBX_E_DEVICE;     // k_integrate_tsdf writes what k_esdf_mark reads
+  { const bool pend = m->edt_pending; m->edt_pending = false;       // (join_side would launch a held-back EDT; it rides in k_mark_view instead)
+    const int rc = m->join_side(); m->edt_pending = pend; if (rc) return NVBX_E_DEVICE; }
+  if (m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0 && m->flush_edt()) return NVBX_E_DEVICE;   // first launch is the dilation
   m->frame_id++;
   const Frame f = m->make_frame(T_L_C, camera, rows, cols, m->p.raycast_subsampling_factor);
   if (m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0) {
