@@ -9,7 +9,7 @@
 
 using namespace nvbx;
 
-constexpr uint32_t LAYER_MASK = F_TSDF | F_COLOR | F_ESDF | F_MESH;
+constexpr uint32_t LAYER_MASK = F_TSDF | F_COLOR | F_ESDF | F_MESH | F_ESDF_PENDING;   // a slot carrying any of these is live
 
 __device__ inline void free_slot(DMap& m, uint32_t slot) {   // one thread
   const int32_t pos = atomicAdd(&m.counters[C_FREE_TOP], 1);
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
       else {
         old = atomicOr(&m.slot_flags[slot], F_DIRTY_ESDF | F_DIRTY_MESH);
         atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH));
-        if (!(flags & F_ESDF)) free_slot(m, (uint32_t)slot);
+        if (!(flags & (F_ESDF | F_ESDF_PENDING))) free_slot(m, (uint32_t)slot);
       }
       if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, slot);
       if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, slot);
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float c
     if (flags & F_TSDF) m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f);
     if (flags & F_COLOR) m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
     if (flags & F_ESDF) m.esdf[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
-    if (tid == 0) { atomicAnd(&m.slot_flags[slot], ~LAYER_MASK); m.site_bits[slot] = 0ull; free_slot(m, (uint32_t)slot); }
+    if (tid == 0) { atomicAnd(&m.slot_flags[slot], ~LAYER_MASK); m.site_bits[slot] = 0ull; m.obs_bits[slot] = 0ull; m.inside_bits[slot] = 0ull; free_slot(m, (uint32_t)slot); }
   }
 }
 

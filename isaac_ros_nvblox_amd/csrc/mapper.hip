@@ -96,7 +96,7 @@ __global__ __launch_bounds__(512) void k_gather_blocks(DMap m, uint32_t layer, c
 __global__ __launch_bounds__(512) void k_scatter_block(DMap m, uint32_t layer, int32_t x, int32_t y, int32_t z, const uint8_t* in,
                                                        int32_t mesh_list, int32_t bz_out, int32_t vz_out) {
   __shared__ uint32_t s_slot;
-  __shared__ u64 s_sites;
+  __shared__ u64 s_sites, s_obs, s_ins;
   const int t = threadIdx.x;
   if (t == 0) {
     bool is_new; const int32_t h = hash_insert(m, x, y, z, layer, &is_new);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512) void k_scatter_block(DMap m, uint32_t layer, i
         atomicMax(&m.counters[C_ESDF_AABB + 2], x); atomicMax(&m.counters[C_ESDF_AABB + 3], y);
       }
     }
-    s_slot = s; s_sites = 0ull;
+    s_slot = s; s_sites = 0ull; s_obs = 0ull; s_ins = 0ull;
   }
   __syncthreads();
   const uint32_t s = s_slot;
@@ -129,9 +129,13 @@ __global__ __launch_bounds__(512) void k_scatter_block(DMap m, uint32_t layer, i
         make_uint2(__float_as_uint(v.squared_distance_vox),
                    esdf_meta(v.parent_direction[0], v.parent_direction[1], v.parent_direction[2], v.observed, v.is_inside, v.is_site));
     // keep the slice plane's site mask (what k_esdf_edt reads) consistent with the written voxels
-    if (z == bz_out && vz == vz_out && v.is_site) atomicOr(&s_sites, 1ull << (vx + 8 * vy));
+    if (z == bz_out && vz == vz_out) {
+      if (v.is_site) atomicOr(&s_sites, 1ull << (vx + 8 * vy));
+      if (v.observed) atomicOr(&s_obs, 1ull << (vx + 8 * vy));
+      if (v.is_inside) atomicOr(&s_ins, 1ull << (vx + 8 * vy));
+    }
     __syncthreads();
-    if (t == 0) m.site_bits[s] = (z == bz_out) ? s_sites : 0ull;
+    if (t == 0) { m.site_bits[s] = (z == bz_out) ? s_sites : 0ull; m.obs_bits[s] = (z == bz_out) ? s_obs : 0ull; m.inside_bits[s] = (z == bz_out) ? s_ins : 0ull; }
   }
 }
 
@@ -158,6 +162,8 @@ static int alloc_all(nvbx_mapper* m) {
   NVBX_HIP(hipMalloc(&m->export_idx, cap * 12));
   NVBX_HIP(hipMalloc(&m->export_count, 64));
   NVBX_HIP(hipMalloc(&d.site_bits, cap * 8));
+  NVBX_HIP(hipMalloc(&d.obs_bits, cap * 8));
+  NVBX_HIP(hipMalloc(&d.inside_bits, cap * 8));
   // mesh arena
   m->mesh_vert_cap = std::min<int64_t>(cap * 192, 48ll << 20); m->mesh_tri_cap = m->mesh_vert_cap * 2;
   NVBX_HIP(hipMalloc(&m->mesh_vert, m->mesh_vert_cap * 12));
@@ -180,6 +186,8 @@ static int reset_map(nvbx_mapper* m) {
   NVBX_HIP(hipMemsetAsync(d.color, 0, cap * 4096, m->stream));
   NVBX_HIP(hipMemsetAsync(d.esdf, 0, cap * 4096, m->stream));
   NVBX_HIP(hipMemsetAsync(d.site_bits, 0, cap * 8, m->stream));
+  NVBX_HIP(hipMemsetAsync(d.obs_bits, 0, cap * 8, m->stream));
+  NVBX_HIP(hipMemsetAsync(d.inside_bits, 0, cap * 8, m->stream));
   NVBX_HIP(hipMemsetAsync(m->export_count, 0, 64, m->stream));
   const int64_t n = std::max<int64_t>(cap, std::max<int64_t>(C_NUM, S_NUM * NSH * SH_STRIDE));
   NVBX_LAUNCH(m, k_init_map, dim3((unsigned)((n + 255) / 256)), dim3(256), d);
@@ -278,7 +286,7 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   if (m->side) (void)hipStreamDestroy(m->side);
   DMap& d = m->d;
   void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.tsdf, d.color, d.esdf,
-                  m->view_list, d.lists, d.shc, m->export_idx, m->export_count, d.site_bits,
+                  m->view_list, d.lists, d.shc, m->export_idx, m->export_count, d.site_bits, d.obs_bits, d.inside_bits,
                   m->synth, m->depth_pre, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (m->h_counters) (void)hipHostFree(m->h_counters);

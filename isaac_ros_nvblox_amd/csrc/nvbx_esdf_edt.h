@@ -20,11 +20,12 @@ struct EdtShared {
   u64 s_rows[EDT_MAX_ROWS * EDT_ROW_WORDS];
   int32_t s_part[4 * 64];
   uint32_t s_own[2];               // own slot, own layer flags
+  u64 s_masks[2];                  // own observed / inside masks
   int8_t s_dx[EDT_MAX_ROWS * 8];
 };
 // worker `wg` of `nwg` 256-thread workgroups; called by k_esdf_edt and by the EDT workgroups riding in k_mark_view
 __device__ inline void esdf_edt_worker(const DMap& m, const EsdfArgs& a, int wg, int nwg, EdtShared* sh_) {
-  u64* s_bits = sh_->s_bits; u64* s_rows = sh_->s_rows; int8_t* s_dx = sh_->s_dx; int32_t* s_part = sh_->s_part; uint32_t* s_own = sh_->s_own;
+  u64* s_bits = sh_->s_bits; u64* s_rows = sh_->s_rows; int8_t* s_dx = sh_->s_dx; int32_t* s_part = sh_->s_part; uint32_t* s_own = sh_->s_own; u64* s_masks = sh_->s_masks;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int vx = lane & 7, vy = lane >> 3;
@@ -60,14 +61,23 @@ __device__ inline void esdf_edt_worker(const DMap& m, const EsdfArgs& a, int wg,
       const int qy = q / nn, qx = q - qy * nn;
       const uint32_t s = any_slot(m, bx + qx - a.rb, by + qy - a.rb, a.bz_out);
       s_bits[q] = slot_ok(s) ? m.site_bits[s] : 0ull;
-      if (q == ctr) { s_own[0] = s; s_own[1] = slot_ok(s) ? m.slot_flags[s] : 0u; }
+      if (q == ctr) {
+        s_own[0] = s; s_own[1] = slot_ok(s) ? m.slot_flags[s] : 0u;
+        s_masks[0] = slot_ok(s) ? m.obs_bits[s] : 0ull; s_masks[1] = slot_ok(s) ? m.inside_bits[s] : 0ull;
+      }
     }
     __syncthreads();
     const uint32_t es = s_own[0];
-    if (!slot_ok(es) || !(s_own[1] & F_ESDF)) continue;          // uniform: no ESDF block in this window cell
+    if (!slot_ok(es) || !(s_own[1] & (F_ESDF | F_ESDF_PENDING))) continue;   // uniform: no ESDF block in this window cell
+    if ((s_own[1] & F_ESDF_PENDING) && tid == 0) {                // the block joins the ESDF layer with this update
+      atomicOr(&m.slot_flags[es], F_ESDF); atomicAnd(&m.slot_flags[es], ~F_ESDF_PENDING);
+      atomicMin(&m.counters[C_ESDF_AABB + 0], bx); atomicMin(&m.counters[C_ESDF_AABB + 1], by);
+      atomicMax(&m.counters[C_ESDF_AABB + 2], bx); atomicMax(&m.counters[C_ESDF_AABB + 3], by);
+    }
     uint2* vp = &m.esdf[(size_t)es * 512 + a.vz_out * 64 + lane];
-    uint32_t vflags = 0;
-    if (wave == 0) vflags = vp->y & ESDF_FLAG_MASK;               // issued early, consumed at the store
+    // voxel flags = the masks of the last marking pass (own site mask = centre of the neighbourhood)
+    const uint32_t vflags = (((s_masks[0] >> lane) & 1ull) ? ESDF_OBSERVED : 0u) | (((s_masks[1] >> lane) & 1ull) ? ESDF_INSIDE : 0u) |
+                            (((s_bits[ctr] >> lane) & 1ull) ? ESDF_SITE : 0u);
     // 2. row bitmap: word w of row r holds neighbourhood voxel columns 64(w-1) .. 64(w-1)+63 (bit = column & 63)
     for (int q = tid; q < rows * EDT_ROW_WORDS; q += 256) {
       const int r = q / EDT_ROW_WORDS, w = q - r * EDT_ROW_WORDS;

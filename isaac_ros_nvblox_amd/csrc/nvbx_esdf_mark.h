@@ -32,23 +32,17 @@ __device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg
     const uint4 qe = ld_entry(m, qh);
     uint32_t qslot = probing ? resolve_any(m, qkey, qh, qe) : SLOT_NONE;
     uint32_t eslot = __shfl(qslot, 0);
-    const bool e_exists = slot_ok(eslot) && (m.slot_flags[slot_ok(eslot) ? eslot : 0] & F_ESDF);
+    const bool e_exists = slot_ok(eslot) && (m.slot_flags[slot_ok(eslot) ? eslot : 0] & (F_ESDF | F_ESDF_PENDING));
     if (!(tflags & F_TSDF) && !e_exists) continue;          // uniform
-    int first = 0, fresh = 0;
+    int first = 0;
     if (lane == 0) {
       if (!slot_ok(eslot)) {                                // new column: insert (device-side allocation)
         bool is_new;
-        const int32_t h = hash_insert(m, bx, by, a.bz_out, F_ESDF, &is_new);
+        const int32_t h = hash_insert(m, bx, by, a.bz_out, F_ESDF_PENDING, &is_new);
         if (h >= 0) { do { eslot = ld_slot_acquire(&m.table[h]); } while (eslot == SLOT_INVALID); }
-        fresh = is_new;                                     // (hash_insert gave the new slot its F_ESDF flag)
-      } else if (!e_exists) {
-        fresh = !(atomicOr(&m.slot_flags[eslot], F_ESDF) & F_ESDF);   // an existing (TSDF) block joins the ESDF layer now
       }
       if (slot_ok(eslot)) {
-        if (fresh) {                                        // the layer's AABB only grows when a block joins the layer
-          atomicMin(&m.counters[C_ESDF_AABB + 0], bx); atomicMin(&m.counters[C_ESDF_AABB + 1], by);
-          atomicMax(&m.counters[C_ESDF_AABB + 2], bx); atomicMax(&m.counters[C_ESDF_AABB + 3], by);
-        }
+        if (!e_exists) atomicOr(&m.slot_flags[eslot], F_ESDF_PENDING);   // joins the ESDF layer when the EDT of this update runs
         first = atomicExch(&m.slot_stamp[eslot], a.mark_pass) != a.mark_pass;
       }
     }
@@ -82,9 +76,10 @@ __device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg
       atomicMax(shc_at(m, srec, sh, 2), bx); atomicMax(shc_at(m, srec, sh, 3), by);
       atomicAdd(shc_at(m, srec, sh, 4), 1);
     }
-    m.esdf[(size_t)eslot * 512 + a.vz_out * 64 + lane] = make_uint2(__float_as_uint(a.max_sq), esdf_meta(0, 0, 0, observed, inside, site));
-    const u64 bits = __ballot(site != 0);          // bit (x + 8y) of the block's slice plane
-    if (lane == 0) m.site_bits[eslot] = bits;
+    // the column's masks (bit x + 8y of the block's slice plane); the voxels themselves are written by the EDT only, so a
+    // marking pass changes nothing the API can observe
+    const u64 sbits = __ballot(site != 0), obits = __ballot(observed != 0), ibits = __ballot(inside != 0);
+    if (lane == 0) { m.site_bits[eslot] = sbits; m.obs_bits[eslot] = obits; m.inside_bits[eslot] = ibits; }
   }
 }
 

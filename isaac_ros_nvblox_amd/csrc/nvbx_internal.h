@@ -9,7 +9,8 @@
 //                are memcpy); one slot id addresses the TSDF, colour and ESDF block of the same Index3D.
 //   esdf       : capacity x 512 x 8 B, voxel order x + 8y + 64z so that the 2-D slice plane of a block is one
 //                contiguous 512-B line = one 8-byte access per lane of one wavefront; packed {f32 sq, u32 meta}.
-//   site_bits  : capacity x 8 B, the slice plane's site mask of each ESDF block (one __ballot word)
+//   site/obs/inside_bits : capacity x 8 B each, the slice plane's site / observed / inside masks of each ESDF block (one
+//                __ballot word each), written by the marking pass and applied to the voxels by the distance transform
 // All voxel types are 8 bytes -> every block of every layer is 4 KiB and a 512-thread workgroup (8 wave64) moves one
 // block with one coalesced 8-B access per lane.
 #pragma once
@@ -28,6 +29,9 @@ __host__ __device__ inline bool slot_ok(uint32_t s) { return s < SLOT_NONE; }
 // slot_flags bits
 constexpr uint32_t F_TSDF = 1u, F_COLOR = 2u, F_ESDF = 4u, F_MESH = 8u;
 constexpr uint32_t F_DIRTY_ESDF = 1u << 8, F_DIRTY_MESH = 1u << 9;
+// the block was given an ESDF column by a marking pass but joins the ESDF layer (F_ESDF, layer AABB) only when the distance
+// transform of that update runs: marking never changes anything the API can observe
+constexpr uint32_t F_ESDF_PENDING = 1u << 10;
 
 struct Entry { u64 key; uint32_t slot; uint32_t stamp; };
 
@@ -78,6 +82,8 @@ struct DMap {
   uint2* color;
   uint2* esdf;
   u64* site_bits;           // per slot: site mask of the block's ESDF slice plane (bit x + 8y); 0 for non-ESDF slots
+  u64* obs_bits;            // per slot: observed mask of the slice plane, as of the last marking pass
+  u64* inside_bits;         // per slot: inside mask of the slice plane, as of the last marking pass
   int32_t* shc;             // sharded counters (S_* above)
   int32_t* lists;           // N_LISTS x NSH x capacity slot ids: list l, shard s starts at ((l * NSH + s) * capacity)
 };

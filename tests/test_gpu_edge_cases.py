@@ -125,3 +125,37 @@ def test_side_stream_option_keeps_parity():
                         "-k", "esdf or color or mesh or decay or dirty"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_esdf_layer_changes_only_in_update_esdf(oracle_mod, hip_lib):
+    """The ESDF site marking rides in the colour-integration launch and the distance transform may be held back until the
+    next call -- but what the API shows must behave like the reference: the ESDF layer changes in
+    updateEsdf and nowhere else, and every query sees completed updates."""
+    M, g, o = pair(oracle_mod, cap=1 << 14)
+    fr = H.frames(4, H.SMALL_CAM, color=True, stride=9)
+    for d, rgb, T in fr[:2]:
+        g.integrate_depth(d, T, H.SMALL_CAM); g.integrate_color(rgb, T, H.SMALL_CAM)
+        o.integrate_depth(d, T, H.SMALL_CAM); o.integrate_color(rgb, T, H.SMALL_CAM)
+    g.update_esdf(); o.update_esdf()
+    idx0 = g.block_indices(M.LAYER_ESDF); blk0, _ = g.get_blocks(M.LAYER_ESDF, idx0); img0, aabb0 = g.esdf_slice_image()
+    assert np.array_equal(idx0, o.block_indices(oracle_mod.L_ESDF))
+    # new depth + colour: marking happens inside the colour launch, but nothing observable may change
+    for d, rgb, T in fr[2:]:
+        g.integrate_depth(d, T, H.SMALL_CAM); g.integrate_color(rgb, T, H.SMALL_CAM)
+        o.integrate_depth(d, T, H.SMALL_CAM); o.integrate_color(rgb, T, H.SMALL_CAM)
+        idx1 = g.block_indices(M.LAYER_ESDF); blk1, _ = g.get_blocks(M.LAYER_ESDF, idx1); img1, aabb1 = g.esdf_slice_image()
+        assert np.array_equal(idx0, idx1) and np.array_equal(aabb0, aabb1) and np.array_equal(img0, img1)
+        for f_ in ("squared_distance_vox", "parent_direction", "is_inside", "observed", "is_site"):
+            assert np.array_equal(blk0[f_], blk1[f_]), f_
+    # ... until updateEsdf, after which every query path sees the completed update (held-back EDT included)
+    g.update_esdf(); o.update_esdf()
+    img2, _ = g.esdf_slice_image(); ref, _ = o.esdf_slice_image()
+    assert img2.shape == ref.shape and np.abs(img2 - ref).max() <= 1e-4 and not np.array_equal(img2.shape, ()) 
+    g.update_esdf(); o.update_esdf()                              # nothing dirty: held back again, then read through another path
+    idx2 = g.block_indices(M.LAYER_ESDF)
+    assert np.array_equal(idx2, o.block_indices(oracle_mod.L_ESDF)) and len(idx2) >= len(idx0)
+    blk2, _ = g.get_blocks(M.LAYER_ESDF, idx2)
+    for k, i in enumerate(idx2):
+        bo = o.get_block(oracle_mod.L_ESDF, i)
+        for f_ in ("squared_distance_vox", "parent_direction", "is_inside", "observed", "is_site"):
+            assert np.array_equal(blk2[k][f_], bo[f_]), (f_, i)
