@@ -263,10 +263,15 @@ def main():
                           "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                 "longest_kernel": {"kernel": longest, "avg_launch_us": round(kern[longest]["avg_us"], 3),
                                    "achieved": round(kern[longest]["achieved_GBps"], 2), "frac": round(kern[longest]["achieved_GBps"] / HBM_PEAK_GBS, 5)},
-                "note": "kernel = the non-mesh kernel with the most algorithmic HBM bytes per frame (no kernel dominates by time: six "
-                        "launches of 7-11 us each); durations from hipEvent pairs on the mapper stream. 640x480 @ 0.05 m moves ~15 MB/frame "
-                        "in 6 dependent launches, so every kernel is bound by its dependent-access chain and launch cost rather than by "
-                        "HBM bytes (DESIGN.md 2); per-kernel achieved GB/s under `kernels`, whole frame under `frame`"}
+                "note": "kernel = the non-mesh kernel with the most algorithmic HBM bytes per frame (no kernel dominates by time: four "
+                        "dependent launches of 6-11 us each; k_integrate_color also carries the ESDF site marking, k_mark_view the "
+                        "held-back EDT of the previous update -- DESIGN.md 2.4); durations from hipEvent pairs on the mapper stream "
+                        "(~2.5 us above rocprofv3's). 640x480 @ 0.05 m moves ~15 MB/frame, so every kernel is bound by its "
+                        "dependent-access chain and launch cost rather than by HBM bytes (DESIGN.md 2); per-kernel achieved GB/s under "
+                        "`kernels`, whole frame under `frame`",
+                "components_note": "ms_components are measured per call in isolation: the EDT of updateEsdf is held back and runs "
+                                   "inside the next depth frame's first launch, so `esdf` shows the marking launch only and "
+                                   "the sum of the three is not ms_per_step"}
 
     cpu = None
     if not args.no_cpu_baseline:
