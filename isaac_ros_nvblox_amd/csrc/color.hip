@@ -122,20 +122,22 @@ __device__ inline uint32_t blend_u8(float c0, float w0, float c1, float w1) {
 // Dependent-access chain: {slot flags, Index3D, TSDF voxel, colour voxel} (all addressed by the slot id alone, fetched
 // together) -> block vote -> {synthetic depth gather, colour gather} (both addressed by the projection, fetched
 // together) -> store.
-// Workgroups [0, n_color_wg) integrate colour; workgroups beyond that (if any) are ESDF marking workers (first wavefront only).
+// Workgroups [0, n_mark_wg) are ESDF marking workers (first wavefront only; dispatched first so that they start at once and
+// do not queue for a CU slot behind the resident batch of colour workgroups); the n_color_wg after them integrate colour.
 template <typename Pix>
 __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rgb, const float* synth, int32_t srows, int32_t scols,
-                                                         int32_t mesh_list, int32_t n_color_wg, EsdfArgs ea) {
-  if ((int32_t)blockIdx.x >= n_color_wg) {
-    if (threadIdx.x < 64) esdf_mark_worker(m, ea, (int)blockIdx.x - n_color_wg, (int)gridDim.x - n_color_wg);
+                                                         int32_t mesh_list, int32_t n_mark_wg, EsdfArgs ea) {
+  if ((int32_t)blockIdx.x < n_mark_wg) {
+    if (threadIdx.x < 64) esdf_mark_worker(m, ea, (int)blockIdx.x, n_mark_wg);
     return;
   }
+  const int32_t wg = (int32_t)blockIdx.x - n_mark_wg, n_color_wg = (int32_t)gridDim.x - n_mark_wg;
   __shared__ int s_out[6];
   __shared__ int s_band;
   const int tid = threadIdx.x;
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
   // the first slot's data is requested beside the high-water mark (gridDim.x <= capacity, so the addresses are valid)
-  int32_t slot = blockIdx.x;
+  int32_t slot = wg;
   uint32_t flags = m.slot_flags[slot];
   int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
   float2 tv = m.tsdf[(size_t)slot * 512 + tid];                  // zero for slots without a TSDF block
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rg
   uint2 cur = *cp;
   const int32_t hw = m.counters[C_HIGH_WATER];
   for (; slot < hw; slot += n_color_wg) {
-    if (slot != (int32_t)blockIdx.x) {
+    if (slot != wg) {
       flags = m.slot_flags[slot];
       bx = m.slot_index[3 * slot]; by = m.slot_index[3 * slot + 1]; bz = m.slot_index[3 * slot + 2];
       tv = m.tsdf[(size_t)slot * 512 + tid];
@@ -250,7 +252,7 @@ static int integrate_color_impl(nvbx_mapper* m, Pix rgb_dev, int32_t rows, int32
     m->mark_pass++; ea.mark_pass = m->mark_pass; mark_wg = 256;
     m->dirty_since_mark = false; m->premark_consumed = true;
   }
-  NVBX_LAUNCH(m, (k_integrate_color<Pix>), dim3(grid + mark_wg), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->mesh_list_live(), (int32_t)grid, ea);
+  NVBX_LAUNCH(m, (k_integrate_color<Pix>), dim3(grid + mark_wg), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->mesh_list_live(), (int32_t)mark_wg, ea);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }

@@ -286,18 +286,18 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
   __syncthreads();
 }
 
-// Workgroups [0, n_tile_wg) mark the view (first wavefront only); workgroups beyond that (camera launches only, when an EDT
-// was held back by updateEsdf) are EDT workers with all four wavefronts.
+// Workgroups [0, n_edt_wg) (camera launches only, when an EDT was held back by updateEsdf) are EDT workers with all four
+// wavefronts -- dispatched first: the EDT is the longer chain; the workgroups after them mark the view (first wavefront only).
 template <typename Img, typename Sensor>
 __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, Frame f, Img depth, Sensor sensor, int4* view_list, int32_t list_cap,
-                                                                int32_t reset_esdf_dirty, int32_t n_tile_wg, EsdfArgs ea) {
+                                                                int32_t reset_esdf_dirty, int32_t n_edt_wg, EsdfArgs ea) {
   constexpr int LSET = Sensor::kSetSize, FR = Sensor::kFlushRounds;
   constexpr size_t kMarkBytes = 2 * LSET * sizeof(u64);
   constexpr size_t kSmem = (Sensor::kThreads == 256 && sizeof(EdtShared) > kMarkBytes) ? sizeof(EdtShared) : kMarkBytes;
   __shared__ __align__(16) unsigned char smem[kSmem];
   if (Sensor::kThreads == 256) {
-    if ((int32_t)blockIdx.x >= n_tile_wg) {
-      esdf_edt_worker(m, ea, (int)blockIdx.x - n_tile_wg, (int)gridDim.x - n_tile_wg, reinterpret_cast<EdtShared*>(smem));
+    if ((int32_t)blockIdx.x < n_edt_wg) {
+      esdf_edt_worker(m, ea, (int)blockIdx.x, n_edt_wg, reinterpret_cast<EdtShared*>(smem));
       return;
     }
     if (threadIdx.x >= 64) return;            // a tile is one wavefront
@@ -308,7 +308,8 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, Frame f,
   constexpr int TR = Sensor::kTileRows, TC = Sensor::kTileCols, NSEG = Sensor::kSegments;
   static_assert(TR * TC * NSEG <= 64, "one wavefront per tile");
   const int tiles_x = (f.n_ray_cols + TC - 1) / TC;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int tile = (int)blockIdx.x - (Sensor::kThreads == 256 ? n_edt_wg : 0);
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int ray = lane / NSEG, seg = lane % NSEG;
   const int ri = ty * TR + ray / TC, ci = tx * TC + ray % TC;
   bool active = ray < TR * TC && ri < f.n_ray_rows && ci < f.n_ray_cols;
@@ -317,9 +318,9 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, Frame f,
   int pcol = ci * f.subsample; if (pcol >= f.cols) pcol = f.cols - 1;
   const float d = active ? depth((int64_t)prow * f.cols + pcol) : 0.0f;
   for (int i = lane; i < LSET; i += 64) lset[i] = KEY_EMPTY;
-  if (blockIdx.x == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
+  if (tile == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
   // an ESDF dirty list already consumed by a marking pass (fused into integrateColor) is emptied before k_integrate_tsdf appends
-  if (reset_esdf_dirty && blockIdx.x == 0 && lane < NSH) *shc_at(m, S_LIST_ESDF_DIRTY, lane, 0) = 0;
+  if (reset_esdf_dirty && tile == 0 && lane < NSH) *shc_at(m, S_LIST_ESDF_DIRTY, lane, 0) = 0;
   __syncthreads();
 
   int32_t cur[3] = {0, 0, 0}, step[3] = {0, 0, 0}, nsteps = -1;
@@ -466,7 +467,7 @@ static int integrate_depth_impl(nvbx_mapper* m, Img img, const Sensor& sensor, c
     else if (m->flush_edt()) return NVBX_E_DEVICE;
   }
   NVBX_LAUNCH(m, (k_mark_view<Img, Sensor>), dim3(tiles + edt_wg), dim3(Sensor::kThreads), m->d, f, img, sensor, (int4*)m->view_list, (int32_t)m->capacity,
-              (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)tiles, ea);
+              (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)edt_wg, ea);
   m->premark_consumed = false; m->dirty_since_mark = true;
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);
   NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor>), dim3(grid), dim3(512), m->d, f, img, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
