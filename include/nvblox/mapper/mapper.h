@@ -204,8 +204,9 @@ class Mapper {
 
   // .nvblx save/load is outside the hot path and not provided by libnvblox_hip: report failure
   // through the reference's bool convention (nvblox_node.cpp:1668,1703).
-  bool saveLayerCake(const std::string&) const { return false; }
-  bool loadMap(const std::string&) { return false; }
+  // nvblox_node.cpp:1668,1703: recoverable I/O errors are reported as `false` (nvbx_last_error() has the reason)
+  bool saveLayerCake(const std::string& path) const { return nvbx_save_map(m_, path.c_str()) == NVBX_OK; }
+  bool loadMap(const std::string& path) { return nvbx_load_map(m_, path.c_str()) == NVBX_OK; }
 
   void synchronize() const { checkNvbx(nvbx_synchronize(m_), "nvbx_synchronize"); }
   nvbx_mapper* c_handle() const { return m_; }

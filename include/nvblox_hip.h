@@ -34,6 +34,7 @@ extern "C" {
 #define NVBX_E_DEVICE (-2)    /* HIP runtime error, see nvbx_last_error() */
 #define NVBX_E_CAPACITY (-3)  /* block pool / arena / window capacity exceeded */
 #define NVBX_E_NOTFOUND (-4)
+#define NVBX_E_IO (-5)        /* file could not be opened / read / written, or is not a map file */
 
 /* layer selectors (bit mask), mirrors the reference's LayerType usage in layer_publishing.cpp:675-826 */
 #define NVBX_LAYER_TSDF 1u
@@ -207,6 +208,14 @@ int nvbx_pointcloud_from_slice(nvbx_mapper* m, const float* image_dev, int32_t r
 int nvbx_esdf_dense_grid(nvbx_mapper* m, const int32_t min_vox[3], const int32_t size_vox[3], float default_value,
                          float* grid_dev);
 
+/* ---- map file (Mapper::saveLayerCake(path) -> bool, loadMap(path) -> bool: nvblox_node.cpp:1668,1703) -------------------
+ * TSDF + colour + ESDF layers as {Index3D, 512 reference voxel structs} per block in a little-endian container of our own
+ * (the reference's .nvblx format lives in the absent nvblox core).  load replaces the map: it is cleared first, the file's
+ * voxel size must equal the mapper's, loaded TSDF blocks are ESDF- and mesh-dirty.  Errors: NVBX_E_IO, NVBX_E_INVALID
+ * (voxel size), NVBX_E_CAPACITY; a file that fails validation leaves the current map untouched. */
+int nvbx_save_map(nvbx_mapper* m, const char* path);
+int nvbx_load_map(nvbx_mapper* m, const char* path);
+
 /* ---- layer access (Layer<VoxelBlock> accessors; synchronise) ----------------------------------------------------
  * layer.numAllocatedBlocks(), getAllBlockIndices(), getBlockAtIndex(), allocateBlockAtIndex(),
  * callFunctionOnAllVoxels -- test_esdf_and_gradient_conversions.cpp:85-92,114,118 */
@@ -214,6 +223,8 @@ int64_t nvbx_num_blocks(nvbx_mapper* m, uint32_t layer);
 int64_t nvbx_block_indices(nvbx_mapper* m, uint32_t layer, nvbx_index3d* out, int64_t capacity);
 int nvbx_get_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, void* voxels_out /* 512 reference structs */);
 int nvbx_set_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, const void* voxels_in);
+/* batched allocateBlockAtIndex + whole-block write: voxels_in[n][512] reference structs (TSDF blocks become ESDF- and mesh-dirty) */
+int nvbx_set_blocks(nvbx_mapper* m, uint32_t layer, const nvbx_index3d* idx, int64_t n, const void* voxels_in);
 /* batched getBlockAtIndex: n blocks into voxels_out[n][512]; found_out[i] = 1 if block i exists (may be NULL) */
 int nvbx_get_blocks(nvbx_mapper* m, uint32_t layer, const nvbx_index3d* idx, int64_t n, void* voxels_out, int32_t* found_out);
 /* blocks touched by the last integrateDepth / integrateColor (what Mapper records as "blocks to update") */

@@ -101,6 +101,9 @@ SIGNATURES = {
     "nvbx_get_block": (C.c_int, [_vp, C.c_uint32, Index3D, _vp]),
     "nvbx_set_block": (C.c_int, [_vp, C.c_uint32, Index3D, _vp]),
     "nvbx_get_blocks": (C.c_int, [_vp, C.c_uint32, _vp, _i64, _vp, _vp]),
+    "nvbx_set_blocks": (C.c_int, [_vp, C.c_uint32, _vp, _i64, _vp]),
+    "nvbx_save_map": (C.c_int, [_vp, C.c_char_p]),
+    "nvbx_load_map": (C.c_int, [_vp, C.c_char_p]),
     "nvbx_last_depth_view": (_i64, [_vp, _vp, _i64]),
     "nvbx_last_color_view": (_i64, [_vp, _vp, _i64]),
     "nvbx_get_synthetic_depth": (C.c_int, [_vp, _vp, _i64, _pi32, _pi32]),

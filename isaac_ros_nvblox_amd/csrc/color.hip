@@ -250,7 +250,7 @@ static int integrate_color_impl(nvbx_mapper* m, Pix rgb_dev, int32_t rows, int32
   EsdfArgs ea = m->make_esdf_args();
   if (m->dirty_since_mark && !m->premark_consumed && ea.bz_hi >= ea.bz_lo && ea.bz_hi - ea.bz_lo + 1 <= 63) {
     m->mark_pass++; ea.mark_pass = m->mark_pass; mark_wg = 256;
-    m->dirty_since_mark = false; m->premark_consumed = true;
+    m->dirty_since_mark = false; m->premark_consumed = true; m->unresolved_marks = true;
   }
   NVBX_LAUNCH(m, (k_integrate_color<Pix>), dim3(grid + mark_wg), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->mesh_list_live(), (int32_t)mark_wg, ea);
   NVBX_HIP(hipGetLastError());

@@ -50,6 +50,7 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
   // marking pass only if something was dirtied since the last pass (integrateColor runs one fused into its own launch)
   if (m->dirty_since_mark) NVBX_LAUNCH_ON(m, s, k_esdf_mark, dim3((unsigned)std::min<int64_t>(m->capacity, 1024)), dim3(64), m->d, a);
   m->dirty_since_mark = false; m->premark_consumed = false;          // k_esdf_edt resets the dirty list
+  m->unresolved_marks = false; m->pass_at_last_edt = m->mark_pass;    // the EDT enqueued below resolves every marking pass so far
   if (m->defer_edt && !m->use_side) {
     // The EDT is held back until the next entry point: the next camera depth frame runs it inside its first launch (beside
     // the view marking, which it does not interact with); every other entry point launches it first (flush_edt).
@@ -272,6 +273,58 @@ extern "C" int nvbx_mark_esdf_dirty_gathered(nvbx_mapper* m, const int32_t* gath
   if (world > 1 || self_rank < 0) NVBX_LAUNCH(m, k_import_dirty_gathered, dim3(16, (unsigned)world), dim3(256), m->d, gathered_dev, self_rank, max_count);
   NVBX_HIP(hipGetLastError());
   return m->mark_main();
+}
+
+// Take back the marking passes that no distance transform has followed yet (nvbx_mapper.h: unresolved_marks).  A marking pass
+// consumes ESDF-dirty flags and creates PENDING columns from the TSDF as it is at that moment; if blocks are deallocated
+// before the update runs, the update must start from the dirty set and the TSDF of THAT moment instead.  One wavefront per
+// slot: (a) a TSDF slot whose dirty flag an unresolved pass consumed is dirty again (and back on the list); (b) an ESDF
+// column an unresolved pass re-marked gets the masks of its voxels back (what the last distance transform wrote), a column
+// that was only PENDING disappears.  Slots freed here are unlinked by the hash rebuild of the calling operation.
+__global__ __launch_bounds__(64) void k_undo_marks(DMap m, uint32_t pass_floor, int32_t srec, int32_t vz_out) {
+  const int lane = threadIdx.x;
+  // (the update's window record keeps the undone passes' extent: the distance transform is exact on any window that
+  // contains the changes, and the record may also hold the extent of ESDF blocks dropped by clearOutsideRadius)
+  if (blockIdx.x == 0 && lane < NSH) *shc_at(m, srec, lane, 4) = 0;     // columns re-marked: counted again by the pass that follows
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  for (int32_t s = blockIdx.x; s < hw; s += gridDim.x) {
+    const uint32_t flags = m.slot_flags[s], cons = m.slot_consumed[s], stamp = m.slot_stamp[s];
+    const bool cons_unres = cons != STAMP_NEVER && (int32_t)(cons - pass_floor) > 0;
+    const bool stamp_unres = stamp != STAMP_NEVER && (int32_t)(stamp - pass_floor) > 0;
+    if (cons_unres && lane == 0) {
+      m.slot_consumed[s] = STAMP_NEVER;
+      if (flags & (F_TSDF | F_COLOR | F_ESDF | F_MESH | F_ESDF_PENDING)) {
+        const uint32_t old = atomicOr(&m.slot_flags[s], F_DIRTY_ESDF);
+        if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, s);
+      }
+    }
+    if (stamp_unres) {
+      if (flags & F_ESDF) {
+        const uint32_t meta = m.esdf[(size_t)s * 512 + vz_out * 64 + lane].y;
+        const u64 sb = __ballot((meta & ESDF_SITE) != 0), ob = __ballot((meta & ESDF_OBSERVED) != 0), ib = __ballot((meta & ESDF_INSIDE) != 0);
+        if (lane == 0) { m.site_bits[s] = sb; m.obs_bits[s] = ob; m.inside_bits[s] = ib; m.slot_stamp[s] = STAMP_NEVER; }
+      } else if ((flags & F_ESDF_PENDING) && lane == 0) {
+        atomicAnd(&m.slot_flags[s], ~F_ESDF_PENDING);
+        m.site_bits[s] = 0ull; m.obs_bits[s] = 0ull; m.inside_bits[s] = 0ull; m.slot_stamp[s] = STAMP_NEVER;
+        if (!(flags & (F_TSDF | F_COLOR | F_ESDF | F_MESH))) {
+          atomicAnd(&m.slot_flags[s], ~(F_DIRTY_ESDF | F_DIRTY_MESH));
+          const int32_t pos = atomicAdd(&m.counters[C_FREE_TOP], 1);
+          m.free_stack[pos] = (uint32_t)s;
+          atomicSub(&m.counters[C_LIVE], 1);
+        }
+      }
+    }
+  }
+}
+int nvbx_mapper::undo_marks() {
+  if (!unresolved_marks) return NVBX_OK;
+  if (reset_consumed_list()) return NVBX_E_DEVICE;           // a consumed list is emptied; the kernel re-appends what is dirty again
+  const EsdfArgs a = make_esdf_args();
+  NVBX_LAUNCH(this, k_undo_marks, dim3((unsigned)std::min<int64_t>(capacity, 2048)), dim3(64), d, pass_at_last_edt,
+              (int32_t)(S_ESDF_REC + (int)(a.epoch & 1)), a.vz_out);
+  NVBX_HIP(hipGetLastError());
+  unresolved_marks = false; dirty_since_mark = true;
+  return NVBX_OK;
 }
 
 // launch a held-back EDT now (every entry point except the camera integrateDepth, which lets it ride in k_mark_view)

@@ -14,10 +14,15 @@ constexpr uint32_t LAYER_MASK = F_TSDF | F_COLOR | F_ESDF | F_MESH | F_ESDF_PEND
 __device__ inline void free_slot(DMap& m, uint32_t slot) {   // one thread
   const int32_t pos = atomicAdd(&m.counters[C_FREE_TOP], 1);
   m.free_stack[pos] = slot;
+  m.slot_consumed[slot] = STAMP_NEVER; m.slot_stamp[slot] = STAMP_NEVER;
   atomicSub(&m.counters[C_LIVE], 1);
 }
 
-__global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, int32_t mesh_list) {
+// A block whose weights all fall below the threshold is deallocated.  If it lies in the ESDF z band and its column already has
+// an ESDF block, that column is flagged for a re-mark (F_ESDF_REMARK) and put on the ESDF work list -- the flag lives on the
+// ESDF slot, which survives, not on the TSDF slot, which may be freed and recycled before the update runs.
+__global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, int32_t mesh_list,
+                                               int32_t bz_lo, int32_t bz_hi, int32_t bz_out) {
   __shared__ int s_alive;
   const int32_t hw = m.counters[C_HIGH_WATER];
   const int tid = threadIdx.x;
@@ -41,19 +46,31 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
     }
     if (tid == 0) {
       uint32_t old;
-      if (alive) old = atomicOr(&m.slot_flags[slot], F_DIRTY_ESDF | F_DIRTY_MESH);
-      else {
+      if (alive) {
         old = atomicOr(&m.slot_flags[slot], F_DIRTY_ESDF | F_DIRTY_MESH);
+        if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, slot);
+      } else {
+        old = atomicOr(&m.slot_flags[slot], F_DIRTY_MESH);
         atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH));
-        if (!(flags & (F_ESDF | F_ESDF_PENDING))) free_slot(m, (uint32_t)slot);
+        const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
+        if (bz >= bz_lo && bz <= bz_hi) {
+          const uint32_t es = any_slot(m, bx, by, bz_out);          // (the table is rebuilt after this kernel, not during it)
+          if (slot_ok(es) && (m.slot_flags[es] & F_ESDF)) {
+            const uint32_t eold = atomicOr(&m.slot_flags[es], F_ESDF_REMARK | F_DIRTY_ESDF);
+            if (!(eold & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)es);
+          }
+        }
+        if (!(flags & (F_ESDF | F_ESDF_PENDING))) { atomicAnd(&m.slot_flags[slot], ~F_DIRTY_ESDF); free_slot(m, (uint32_t)slot); }
       }
-      if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, slot);
       if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, slot);
     }
   }
 }
 
-__global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float cy, float cz, float r2, float bs) {
+// `srec`: window record of the next ESDF update.  An ESDF block that is dropped takes its sites with it: the distances of
+// every voxel within the search radius of those sites are stale, so the block joins the next update's window (the
+// distance transform is exact on any window that contains every change of the site set).
+__global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float cy, float cz, float r2, float bs, int32_t srec) {
   const int32_t hw = m.counters[C_HIGH_WATER];
   const int tid = threadIdx.x;
   for (int32_t slot = blockIdx.x; slot < hw; slot += gridDim.x) {
@@ -67,7 +84,15 @@ __global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float c
     if (flags & F_TSDF) m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f);
     if (flags & F_COLOR) m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
     if (flags & F_ESDF) m.esdf[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
-    if (tid == 0) { atomicAnd(&m.slot_flags[slot], ~LAYER_MASK); m.site_bits[slot] = 0ull; m.obs_bits[slot] = 0ull; m.inside_bits[slot] = 0ull; free_slot(m, (uint32_t)slot); }
+    if (tid == 0) {
+      if ((flags & F_ESDF) && m.site_bits[slot] != 0ull) {
+        const int sh = my_shard(); const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1];
+        atomicMin(shc_at(m, srec, sh, 0), bx); atomicMin(shc_at(m, srec, sh, 1), by);
+        atomicMax(shc_at(m, srec, sh, 2), bx); atomicMax(shc_at(m, srec, sh, 3), by);
+      }
+      atomicAnd(&m.slot_flags[slot], ~(LAYER_MASK | F_DIRTY_ESDF | F_DIRTY_MESH | F_ESDF_REMARK));
+      m.site_bits[slot] = 0ull; m.obs_bits[slot] = 0ull; m.inside_bits[slot] = 0ull; free_slot(m, (uint32_t)slot);
+    }
   }
 }
 
@@ -158,10 +183,12 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   if (!m) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));
   if (m->join_side()) return NVBX_E_DEVICE;
+  if (m->undo_marks()) return NVBX_E_DEVICE;          // decay deallocates: unresolved marking passes are taken back first
   if (m->begin_dirtying()) return NVBX_E_DEVICE;
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
+  const EsdfArgs ea = m->make_esdf_args();
   NVBX_LAUNCH(m, k_decay, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
-                     exclude_last_view ? m->last_view_frame : 0u, m->mesh_list_live());
+                     exclude_last_view ? m->last_view_frame : 0u, m->mesh_list_live(), ea.bz_lo, ea.bz_hi, ea.bz_out);
   return rebuild_table(m);
 }
 
@@ -169,7 +196,9 @@ extern "C" int nvbx_clear_outside_radius(nvbx_mapper* m, const float center[3], 
   if (!m || !center) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));
   if (m->join_side()) return NVBX_E_DEVICE;
+  if (m->undo_marks()) return NVBX_E_DEVICE;          // deallocates: unresolved marking passes are taken back first
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
-  NVBX_LAUNCH(m, k_clear_outside, dim3(grid), dim3(512), m->d, center[0], center[1], center[2], radius * radius, m->p.voxel_size * 8.0f);
+  NVBX_LAUNCH(m, k_clear_outside, dim3(grid), dim3(512), m->d, center[0], center[1], center[2], radius * radius, m->p.voxel_size * 8.0f,
+              (int32_t)(S_ESDF_REC + (int)(m->esdf_epoch & 1)));
   return rebuild_table(m);
 }

@@ -22,7 +22,7 @@ extern "C" const char* nvbx_last_error(void) { return nvbx::g_err.c_str(); }
 // ------------------------------------------------------------------------------------------------ utility kernels
 __global__ void k_init_map(DMap m) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < m.capacity) { m.free_stack[i] = m.capacity - 1 - i; m.slot_flags[i] = 0; m.slot_stamp[i] = 0xFFFFFFFFu; }
+  if (i < m.capacity) { m.free_stack[i] = m.capacity - 1 - i; m.slot_flags[i] = 0; m.slot_stamp[i] = STAMP_NEVER; m.slot_consumed[i] = STAMP_NEVER; }
   if (i < (uint32_t)(S_NUM * NSH * SH_STRIDE)) {       // sharded counters: zero, ESDF window records min = +inf / max = -inf
     const int id = (int)i / (NSH * SH_STRIDE), field = (int)i % SH_STRIDE;
     int32_t v = 0;
@@ -92,12 +92,14 @@ __global__ __launch_bounds__(512) void k_gather_blocks(DMap m, uint32_t layer, c
   }
 }
 
-// allocateBlockAtIndex + whole-block write from reference structs
-__global__ __launch_bounds__(512) void k_scatter_block(DMap m, uint32_t layer, int32_t x, int32_t y, int32_t z, const uint8_t* in,
-                                                       int32_t mesh_list, int32_t bz_out, int32_t vz_out) {
+// allocateBlockAtIndex + whole-block write from reference structs: workgroup i writes block idx[i] from in[i][512]
+__global__ __launch_bounds__(512) void k_scatter_blocks(DMap m, uint32_t layer, const int32_t* idx, const uint8_t* in_all, size_t block_bytes,
+                                                        int32_t mesh_list, int32_t bz_out, int32_t vz_out) {
   __shared__ uint32_t s_slot;
   __shared__ u64 s_sites, s_obs, s_ins;
   const int t = threadIdx.x;
+  const int32_t x = idx[3 * blockIdx.x], y = idx[3 * blockIdx.x + 1], z = idx[3 * blockIdx.x + 2];
+  const uint8_t* in = in_all + (size_t)blockIdx.x * block_bytes;
   if (t == 0) {
     bool is_new; const int32_t h = hash_insert(m, x, y, z, layer, &is_new);
     uint32_t s = SLOT_NONE;
@@ -153,6 +155,7 @@ static int alloc_all(nvbx_mapper* m) {
   NVBX_HIP(hipMalloc(&d.slot_index, cap * 12));
   NVBX_HIP(hipMalloc(&d.slot_entry, cap * 4));
   NVBX_HIP(hipMalloc(&d.slot_stamp, cap * 4));
+  NVBX_HIP(hipMalloc(&d.slot_consumed, cap * 4));
   NVBX_HIP(hipMalloc(&d.tsdf, cap * 4096));
   NVBX_HIP(hipMalloc(&d.color, cap * 4096));
   NVBX_HIP(hipMalloc(&d.esdf, cap * 4096));
@@ -193,6 +196,7 @@ static int reset_map(nvbx_mapper* m) {
   NVBX_LAUNCH(m, k_init_map, dim3((unsigned)((n + 255) / 256)), dim3(256), d);
   NVBX_HIP(hipGetLastError());
   m->dirty_since_mark = false; m->premark_consumed = false; m->mark_pass = 0; m->edt_pending = false;
+  m->unresolved_marks = false; m->pass_at_last_edt = 0;
   m->frame_id = 0; m->esdf_epoch = 0; m->mesh_epoch = 0; m->last_view_frame = 0; m->synth_rows = m->synth_cols = 0;
   return NVBX_OK;
 }
@@ -285,7 +289,7 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   if (m->ev_side) (void)hipEventDestroy(m->ev_side);
   if (m->side) (void)hipStreamDestroy(m->side);
   DMap& d = m->d;
-  void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.tsdf, d.color, d.esdf,
+  void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.slot_consumed, d.tsdf, d.color, d.esdf,
                   m->view_list, d.lists, d.shc, m->export_idx, m->export_count, d.site_bits, d.obs_bits, d.inside_bits,
                   m->synth, m->depth_pre, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -403,16 +407,107 @@ extern "C" int nvbx_get_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, 
   if (rc) return rc;
   return found ? NVBX_OK : NVBX_E_NOTFOUND;
 }
-extern "C" int nvbx_set_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, const void* voxels_in) {
-  if (!m || !voxels_in || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF)) return NVBX_E_INVALID;
+extern "C" int nvbx_set_blocks(nvbx_mapper* m, uint32_t layer, const nvbx_index3d* idx, int64_t n, const void* voxels_in) {
+  if (!m || (n > 0 && (!voxels_in || !idx)) || n < 0 || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF)) return NVBX_E_INVALID;
   if (m->join_side()) return NVBX_E_DEVICE;
   if (m->begin_dirtying()) return NVBX_E_DEVICE;
   const size_t bb = 512 * ref_voxel_bytes(layer);
-  NVBX_HIP(hipMemcpyAsync(m->staging, voxels_in, bb, hipMemcpyHostToDevice, m->stream));
   const EsdfArgs ea = m->make_esdf_args();
-  NVBX_LAUNCH(m, k_scatter_block, dim3(1), dim3(512), m->d, layer, idx.x, idx.y, idx.z, (const uint8_t*)m->staging,
-                     m->mesh_list_live(), ea.bz_out, ea.vz_out);
-  NVBX_HIP(hipStreamSynchronize(m->stream));
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)((m->staging_bytes - 65536) / (bb + 16)));
+  for (int64_t o = 0; o < n; o += chunk) {
+    const int64_t c = std::min(chunk, n - o);
+    int32_t* d_idx = (int32_t*)m->staging;
+    uint8_t* d_in = (uint8_t*)m->staging + (((size_t)c * 16 + 255) & ~(size_t)255);
+    NVBX_HIP(hipMemcpyAsync(d_idx, idx + o, (size_t)c * 12, hipMemcpyHostToDevice, m->stream));
+    NVBX_HIP(hipMemcpyAsync(d_in, (const uint8_t*)voxels_in + (size_t)o * bb, (size_t)c * bb, hipMemcpyHostToDevice, m->stream));
+    NVBX_LAUNCH(m, k_scatter_blocks, dim3((unsigned)c), dim3(512), m->d, layer, (const int32_t*)d_idx, (const uint8_t*)d_in, bb,
+                (int32_t)m->mesh_list_live(), ea.bz_out, ea.vz_out);
+    NVBX_HIP(hipStreamSynchronize(m->stream));
+  }
+  return NVBX_OK;
+}
+extern "C" int nvbx_set_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, const void* voxels_in) {
+  return nvbx_set_blocks(m, layer, &idx, 1, voxels_in);
+}
+
+// ------------------------------------------------------------------------------------------------ map file
+// Mapper::saveLayerCake / loadMap (nvblox_node.cpp:1668,1703).  The reference's .nvblx container is defined in the absent
+// nvblox core; this is our own little-endian container of the same content: the TSDF, colour and ESDF layers as
+// {Index3D, 512 reference voxel structs} per block.  Layout: MapFileHeader, then per layer MapLayerHeader,
+// int32[n][3] indices (sorted), voxel structs.
+namespace {
+struct MapFileHeader { char magic[8]; uint32_t version; float voxel_size; uint32_t n_layers; uint32_t reserved; };
+struct MapLayerHeader { uint32_t layer; uint32_t voxel_bytes; uint64_t n_blocks; };
+const char kMapMagic[8] = {'N', 'V', 'B', 'X', 'M', 'A', 'P', '1'};
+struct FileCloser { FILE* f; ~FileCloser() { if (f) fclose(f); } };
+}  // namespace
+
+extern "C" int nvbx_save_map(nvbx_mapper* m, const char* path) {
+  if (!m || !path) { set_error("nvbx_save_map: invalid argument"); return NVBX_E_INVALID; }
+  FileCloser fc{fopen(path, "wb")};
+  if (!fc.f) { set_error("nvbx_save_map: cannot open file for writing"); return NVBX_E_IO; }
+  const uint32_t layers[3] = {F_TSDF, F_COLOR, F_ESDF};
+  MapFileHeader h{}; memcpy(h.magic, kMapMagic, 8); h.version = 1; h.voxel_size = m->p.voxel_size; h.n_layers = 3;
+  if (fwrite(&h, sizeof(h), 1, fc.f) != 1) { set_error("nvbx_save_map: write failed"); return NVBX_E_IO; }
+  for (uint32_t layer : layers) {
+    const int64_t n = nvbx_num_blocks(m, layer);
+    if (n < 0) return (int)n;
+    std::vector<nvbx_index3d> idx((size_t)std::max<int64_t>(n, 1));
+    if (n > 0 && nvbx_block_indices(m, layer, idx.data(), n) < 0) return NVBX_E_DEVICE;
+    const size_t bb = 512 * ref_voxel_bytes(layer);
+    MapLayerHeader lh{layer, (uint32_t)ref_voxel_bytes(layer), (uint64_t)n};
+    if (fwrite(&lh, sizeof(lh), 1, fc.f) != 1) { set_error("nvbx_save_map: write failed"); return NVBX_E_IO; }
+    if (n > 0 && fwrite(idx.data(), 12, (size_t)n, fc.f) != (size_t)n) { set_error("nvbx_save_map: write failed"); return NVBX_E_IO; }
+    const int64_t chunk = 4096;                      // blocks per round trip (16-40 MiB of host memory)
+    std::vector<uint8_t> buf((size_t)std::min<int64_t>(std::max<int64_t>(n, 1), chunk) * bb);
+    for (int64_t o = 0; o < n; o += chunk) {
+      const int64_t c = std::min(chunk, n - o);
+      const int rc = nvbx_get_blocks(m, layer, idx.data() + o, c, buf.data(), nullptr);
+      if (rc) return rc;
+      if (fwrite(buf.data(), bb, (size_t)c, fc.f) != (size_t)c) { set_error("nvbx_save_map: write failed"); return NVBX_E_IO; }
+    }
+  }
+  return NVBX_OK;
+}
+
+extern "C" int nvbx_load_map(nvbx_mapper* m, const char* path) {
+  if (!m || !path) { set_error("nvbx_load_map: invalid argument"); return NVBX_E_INVALID; }
+  FileCloser fc{fopen(path, "rb")};
+  if (!fc.f) { set_error("nvbx_load_map: cannot open file"); return NVBX_E_IO; }
+  MapFileHeader h{};
+  if (fread(&h, sizeof(h), 1, fc.f) != 1 || memcmp(h.magic, kMapMagic, 8) != 0 || h.version != 1) { set_error("nvbx_load_map: not a libnvblox_hip map file"); return NVBX_E_IO; }
+  if (fabsf(h.voxel_size - m->p.voxel_size) > 1e-6f * m->p.voxel_size) { set_error("nvbx_load_map: voxel size of the file differs from the mapper's"); return NVBX_E_INVALID; }
+  // validate the whole file before the current map is touched
+  struct Section { MapLayerHeader lh; long idx_off, vox_off; };
+  std::vector<Section> sections;
+  for (uint32_t l = 0; l < h.n_layers; l++) {
+    Section sc{};
+    if (fread(&sc.lh, sizeof(sc.lh), 1, fc.f) != 1) { set_error("nvbx_load_map: truncated file"); return NVBX_E_IO; }
+    if (!(sc.lh.layer == F_TSDF || sc.lh.layer == F_COLOR || sc.lh.layer == F_ESDF) || sc.lh.voxel_bytes != ref_voxel_bytes(sc.lh.layer)) {
+      set_error("nvbx_load_map: unknown layer record"); return NVBX_E_IO; }
+    if ((int64_t)sc.lh.n_blocks > m->capacity) { set_error("nvbx_load_map: map has more blocks than the mapper's block capacity"); return NVBX_E_CAPACITY; }
+    sc.idx_off = ftell(fc.f); sc.vox_off = sc.idx_off + (long)(sc.lh.n_blocks * 12);
+    if (fseek(fc.f, sc.vox_off + (long)(sc.lh.n_blocks * 512 * sc.lh.voxel_bytes), SEEK_SET) != 0) { set_error("nvbx_load_map: truncated file"); return NVBX_E_IO; }
+    sections.push_back(sc);
+  }
+  { const long end = ftell(fc.f); fseek(fc.f, 0, SEEK_END); if (ftell(fc.f) < end) { set_error("nvbx_load_map: truncated file"); return NVBX_E_IO; } }
+  int rc = nvbx_mapper_clear(m);
+  if (rc) return rc;
+  for (const Section& sc : sections) {
+    const int64_t n = (int64_t)sc.lh.n_blocks;
+    const size_t bb = 512 * (size_t)sc.lh.voxel_bytes;
+    std::vector<nvbx_index3d> idx((size_t)std::max<int64_t>(n, 1));
+    fseek(fc.f, sc.idx_off, SEEK_SET);
+    if (n > 0 && fread(idx.data(), 12, (size_t)n, fc.f) != (size_t)n) { set_error("nvbx_load_map: read failed"); return NVBX_E_IO; }
+    const int64_t chunk = 4096;
+    std::vector<uint8_t> buf((size_t)std::min<int64_t>(std::max<int64_t>(n, 1), chunk) * bb);
+    for (int64_t o = 0; o < n; o += chunk) {
+      const int64_t c = std::min(chunk, n - o);
+      if (fread(buf.data(), bb, (size_t)c, fc.f) != (size_t)c) { set_error("nvbx_load_map: read failed"); return NVBX_E_IO; }
+      rc = nvbx_set_blocks(m, sc.lh.layer, idx.data() + o, c, buf.data());
+      if (rc) return rc;
+    }
+  }
   return NVBX_OK;
 }
 

@@ -69,6 +69,7 @@ __device__ inline void esdf_edt_worker(const DMap& m, const EsdfArgs& a, int wg,
     __syncthreads();
     const uint32_t es = s_own[0];
     if (!slot_ok(es) || !(s_own[1] & (F_ESDF | F_ESDF_PENDING))) continue;   // uniform: no ESDF block in this window cell
+    if ((s_own[1] & F_ESDF_REMARK) && tid == 0) atomicAnd(&m.slot_flags[es], ~F_ESDF_REMARK);     // resolved by this update
     if ((s_own[1] & F_ESDF_PENDING) && tid == 0) {                // the block joins the ESDF layer with this update
       atomicOr(&m.slot_flags[es], F_ESDF); atomicAnd(&m.slot_flags[es], ~F_ESDF_PENDING);
       atomicMin(&m.counters[C_ESDF_AABB + 0], bx); atomicMin(&m.counters[C_ESDF_AABB + 1], by);

@@ -20,10 +20,10 @@ __device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg
     const uint32_t tslot = (uint32_t)list_at(m, S_LIST_ESDF_DIRTY, lv, i);
     const uint32_t tflags = m.slot_flags[tslot];
     const int32_t bx = m.slot_index[3 * tslot], by = m.slot_index[3 * tslot + 1], bz = m.slot_index[3 * tslot + 2];
-    if (lane == 0) atomicAnd(&m.slot_flags[tslot], ~F_DIRTY_ESDF);
-    // a dirty TSDF block of the z band dirties its column; a block that lost its TSDF (decay) only re-marks an
-    // existing column
-    if (bz < a.bz_lo || bz > a.bz_hi) continue;
+    if (lane == 0) { atomicAnd(&m.slot_flags[tslot], ~F_DIRTY_ESDF); m.slot_consumed[tslot] = a.mark_pass; }
+    // a dirty TSDF block of the z band dirties its column; an ESDF slot flagged F_ESDF_REMARK (a TSDF block of its band was
+    // deallocated by decay) re-marks its own column
+    if (!(tflags & F_ESDF_REMARK) && (bz < a.bz_lo || bz > a.bz_hi)) continue;
     // lane 0: the ESDF block (x, y, z_slice); lanes 1..nz: the TSDF blocks of the band -- one probe each, together
     const int32_t qz = lane == 0 ? a.bz_out : a.bz_lo + lane - 1;
     const bool probing = lane <= nz;
@@ -33,7 +33,7 @@ __device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg
     uint32_t qslot = probing ? resolve_any(m, qkey, qh, qe) : SLOT_NONE;
     uint32_t eslot = __shfl(qslot, 0);
     const bool e_exists = slot_ok(eslot) && (m.slot_flags[slot_ok(eslot) ? eslot : 0] & (F_ESDF | F_ESDF_PENDING));
-    if (!(tflags & F_TSDF) && !e_exists) continue;          // uniform
+    if (!(tflags & F_TSDF) && !(e_exists && (tflags & F_ESDF_REMARK))) continue;          // uniform
     int first = 0;
     if (lane == 0) {
       if (!slot_ok(eslot)) {                                // new column: insert (device-side allocation)

@@ -23,6 +23,7 @@ typedef unsigned long long u64;
 
 constexpr u64 KEY_EMPTY = ~0ull;
 constexpr uint32_t SLOT_INVALID = 0xFFFFFFFFu;   // entry inserted, slot not published yet
+constexpr uint32_t STAMP_NEVER = 0xFFFFFFFFu;
 constexpr uint32_t SLOT_NONE = 0xFFFFFFFEu;      // entry exists but the pool was exhausted
 __host__ __device__ inline bool slot_ok(uint32_t s) { return s < SLOT_NONE; }
 
@@ -32,6 +33,9 @@ constexpr uint32_t F_DIRTY_ESDF = 1u << 8, F_DIRTY_MESH = 1u << 9;
 // the block was given an ESDF column by a marking pass but joins the ESDF layer (F_ESDF, layer AABB) only when the distance
 // transform of that update runs: marking never changes anything the API can observe
 constexpr uint32_t F_ESDF_PENDING = 1u << 10;
+// on an ESDF slot: a TSDF block of this column's z band was deallocated (decay), so the column must be re-marked by the next
+// ESDF update although no TSDF block of it may be dirty (or even exist); cleared by the distance transform of that update
+constexpr uint32_t F_ESDF_REMARK = 1u << 11;
 
 struct Entry { u64 key; uint32_t slot; uint32_t stamp; };
 
@@ -77,7 +81,9 @@ struct DMap {
   uint32_t* slot_flags;
   int32_t* slot_index;      // 3 ints per slot
   uint32_t* slot_entry;     // slot -> hash entry
-  uint32_t* slot_stamp;     // ESDF epoch stamp per slot (column de-duplication)
+  uint32_t* slot_stamp;     // ESDF slot: marking pass that last re-marked this column (de-duplication within a pass)
+  uint32_t* slot_consumed;  // TSDF slot: marking pass that last consumed its ESDF-dirty flag (STAMP_NEVER = none); lets a
+                            //   deallocating operation take back marking passes that no distance transform has followed yet
   float2* tsdf;
   uint2* color;
   uint2* esdf;

@@ -70,6 +70,12 @@ struct nvbx_mapper {
   // ESDF marking state: `dirty_since_mark` = TSDF changed since the last marking pass; `premark_consumed` = the dirty list
   // was processed by a pass that no EDT followed yet, so it must be emptied before anything is appended to it
   bool dirty_since_mark = false, premark_consumed = false;
+  // `unresolved_marks` = a marking pass ran that no distance transform has followed yet (its columns are only PENDING):
+  // an operation that deallocates blocks takes such passes back first (undo_marks, esdf.hip), so that the ESDF update that
+  // eventually runs sees exactly the dirty set the reference semantics define at that moment.  `pass_at_last_edt` =
+  // mark_pass when the last distance transform was enqueued (passes above it are the unresolved ones).
+  bool unresolved_marks = false; uint32_t pass_at_last_edt = 0;
+  int undo_marks();
   // held-back EDT of the last updateEsdf (NVBX_DEFER_EDT=0 disables): see nvbx_update_esdf
   bool defer_edt = true, edt_pending = false; nvbx::EsdfArgs edt_args{};
   int flush_edt();

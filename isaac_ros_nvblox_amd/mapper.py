@@ -251,6 +251,19 @@ class Mapper:
         data = np.ascontiguousarray(data, _DT[layer]); assert data.size == 512
         self._check(self.lib.nvbx_set_block(self._h, layer, Index3D(int(idx[0]), int(idx[1]), int(idx[2])), _np_ptr(data)))
 
+    def set_blocks(self, layer, indices, data):
+        idx = np.ascontiguousarray(np.asarray(indices, np.int32).reshape(-1, 3))
+        data = np.ascontiguousarray(data, _DT[layer]); assert data.size == 512 * idx.shape[0]
+        self._check(self.lib.nvbx_set_blocks(self._h, layer, _np_ptr(idx), idx.shape[0], _np_ptr(data)))
+
+    def save_map(self, path):
+        """Mapper::saveLayerCake (nvblox_node.cpp:1668): TSDF + colour + ESDF layers to one file."""
+        self._check(self.lib.nvbx_save_map(self._h, str(path).encode()))
+
+    def load_map(self, path):
+        """Mapper::loadMap (nvblox_node.cpp:1703): replaces the map with the file's layers."""
+        self._check(self.lib.nvbx_load_map(self._h, str(path).encode()))
+
     def synthetic_depth(self):
         r, c = C.c_int32(), C.c_int32()
         self._check(self.lib.nvbx_get_synthetic_depth(self._h, None, 0, C.byref(r), C.byref(c)))

@@ -99,6 +99,14 @@ def sequence(n, scene=None, cam=REPLICA_LIKE_CAM, n_frames_in_loop=200, yaw_offs
         yield depth, rgb, T
 
 
+def redwood_like_scene(frame, fps=30.0):
+    """BASELINE.json configs[2] stand-in: room 8 x 6 x 2.8 m with one box translating at 0.5 m/s along +x
+    (a dynamic object), frame index -> Scene."""
+    x0 = -3.0 + 0.5 * (frame / fps)
+    return Scene(room_min=(-4.0, -3.0, 0.0), room_max=(4.0, 3.0, 2.8), sphere_c=(2.0, -1.5, 0.5), sphere_r=0.5,
+                 box_min=(x0, 1.0, 0.0), box_max=(x0 + 0.6, 1.6, 1.2))
+
+
 # ------------------------------------------------------------------------------------------------ spinning LiDAR
 # BASELINE.json configs[4] / SURVEY.md 8(d) [D]: Lidar(1024, 64, min_range 0.1, vfov 45 deg), ground plane + 40 boxes
 # in a 300 x 300 m area (default_rng(1)), ranges beyond 200 m invalid.  Lidar tuple = (azimuth divisions, elevation
