@@ -218,6 +218,24 @@ def main():
         g.integrate_depth(depth_dev[(base + i) % nu], poses[(base + i) % nu], cam); g.update_color_mesh()
     comp["mesh"] = max(0.0, timed(mesh_only, n2) - comp["tsdf"])
 
+    # per-frame latency (SURVEY 8d timing protocol): every frame is waited for, so this is the latency a caller sees, not the
+    # pipelined throughput of the timed region.  wall = host clock around the three calls + synchronize (includes the host's
+    # wake-up after the stream drains); gpu = hipEvent pair on the mapper stream around the same three calls.
+    lat_wall, lat_gpu = [], []
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n2)]
+    for i in range(n2):
+        t = time.perf_counter()
+        ev[i][0].record(stream)
+        step(base + i, exchange=False)
+        g.flush()                            # enqueue the held-back EDT of this frame's updateEsdf
+        ev[i][1].record(stream)
+        g.synchronize(); torch.cuda.synchronize(dev)
+        lat_wall.append((time.perf_counter() - t) * 1e3)
+    lat_gpu = [a.elapsed_time(b) for a, b in ev]
+    pct = lambda v: {"mean": round(float(np.mean(v)), 4), "p50": round(float(np.percentile(v, 50)), 4), "p99": round(float(np.percentile(v, 99)), 4)}
+    latency = {"frames": n2, "wall_ms": pct(lat_wall), "gpu_ms": pct(lat_gpu),
+               "note": "one frame at a time with a synchronize after each (the ESDF distance transform then runs as its own launch)"}
+
     # per-kernel durations with hipEvent pairs on the mapper stream, same frames, mesh included
     g.set_profiling(True)
     counts_acc = {}
@@ -307,6 +325,7 @@ def main():
                    "unique_frames": nu},
         "ms_per_frame": round(ms_per_step, 4),
         "ms_components": {k_: round(v_, 4) for k_, v_ in comp.items()},
+        "frame_latency": latency,
         "readme_rtx5090_ms": README_RTX5090_MS,
         "speedup_vs_readme_rtx5090_tsdf_color_esdf": round(0.7 / ms_per_step, 2),
         "per_frame_counts": {k_: round(v_, 1) for k_, v_ in counts.items()},

@@ -209,6 +209,7 @@ class Mapper {
   bool loadMap(const std::string& path) { return nvbx_load_map(m_, path.c_str()) == NVBX_OK; }
 
   void synchronize() const { checkNvbx(nvbx_synchronize(m_), "nvbx_synchronize"); }
+  void flush() const { checkNvbx(nvbx_flush(m_), "nvbx_flush"); }      // enqueue held-back work without waiting
   nvbx_mapper* c_handle() const { return m_; }
   const std::shared_ptr<CudaStream>& cuda_stream() const { return cuda_stream_; }
 

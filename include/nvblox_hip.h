@@ -131,6 +131,9 @@ int nvbx_mapper_set_params(nvbx_mapper* m, const nvbx_mapper_params* params);
 int nvbx_mapper_get_params(const nvbx_mapper* m, nvbx_mapper_params* out);
 /* CudaStream::synchronize -- conversions/esdf_slice_conversions.cu:107-108 */
 int nvbx_synchronize(nvbx_mapper* m);
+/* Enqueue everything the mapper holds back (the distance transform of the last nvbx_update_esdf, see there) on its stream
+ * WITHOUT waiting: for callers that order their own work behind the mapper's with stream events instead of a host sync. */
+int nvbx_flush(nvbx_mapper* m);
 const char* nvbx_last_error(void);
 /* Mapper::clear / fresh map (load_map path re-creates the mapper: nvblox_node.cpp:1698-1703) */
 int nvbx_mapper_clear(nvbx_mapper* m);

@@ -77,6 +77,7 @@ SIGNATURES = {
     "nvbx_mapper_set_params": (C.c_int, [_vp, C.POINTER(Params)]),
     "nvbx_mapper_get_params": (C.c_int, [_vp, C.POINTER(Params)]),
     "nvbx_synchronize": (C.c_int, [_vp]),
+    "nvbx_flush": (C.c_int, [_vp]),
     "nvbx_last_error": (C.c_char_p, []),
     "nvbx_mapper_clear": (C.c_int, [_vp]),
     "nvbx_integrate_depth": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera)]),

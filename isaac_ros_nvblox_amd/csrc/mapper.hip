@@ -315,6 +315,11 @@ extern "C" int nvbx_synchronize(nvbx_mapper* m) {
   NVBX_HIP(hipStreamSynchronize(m->stream));
   return NVBX_OK;
 }
+extern "C" int nvbx_flush(nvbx_mapper* m) {
+  if (!m) return NVBX_E_INVALID;
+  NVBX_HIP(hipSetDevice(m->device));
+  return m->join_side();
+}
 extern "C" int nvbx_mapper_clear(nvbx_mapper* m) {
   if (!m) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));

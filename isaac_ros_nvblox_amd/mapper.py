@@ -108,6 +108,10 @@ class Mapper:
     def synchronize(self):
         self._check(self.lib.nvbx_synchronize(self._h))
 
+    def flush(self):
+        """Enqueue held-back work (the EDT of the last update_esdf) without waiting."""
+        self._check(self.lib.nvbx_flush(self._h))
+
     def clear(self):
         self._check(self.lib.nvbx_mapper_clear(self._h))
 

@@ -235,6 +235,14 @@ int main(int argc, char** argv) {
   shapes_to_clear.push_back(BoundingShape(AxisAlignedBoundingBox(Vector3f(90.f, 90.f, 90.f), Vector3f(91.f, 91.f, 91.f))));
   node.static_mapper_->clearTsdfInsideShapes(shapes_to_clear);
   if (!ply_ok) { std::fprintf(stderr, "ply export failed\n"); return 1; }
+  // save_map / load_map services (nvblox_node.cpp:1668, 1703): bool results, a missing file is a recoverable error
+  const std::string filename = std::string(argv[1]) + ".map";
+  const bool save_ok = node.static_mapper_->saveLayerCake(filename);
+  const int blocks_before = node.static_mapper_->tsdf_layer().numAllocatedBlocks();
+  const bool load_missing = node.static_mapper_->loadMap(filename + ".does_not_exist");
+  const bool load_ok = node.static_mapper_->loadMap(filename);
+  if (!save_ok || load_missing || !load_ok || node.static_mapper_->tsdf_layer().numAllocatedBlocks() != blocks_before) {
+    std::fprintf(stderr, "map save/load failed: save %d load_missing %d load %d\n", (int)save_ok, (int)load_missing, (int)load_ok); return 1; }
   std::printf("{\"tsdf_blocks\": %d, \"color_blocks\": %d, \"esdf_blocks\": %d, \"tsdf_observed\": %zu, \"tsdf_sum\": %.9g, "
               "\"slice_width\": %d, \"slice_height\": %d, \"slice_known\": %zu, \"slice_sum\": %.9g, \"occupied\": %zu, "
               "\"serialized_blocks\": %zu, \"serialized_visible\": %zu, \"aabb_min\": [%.6f, %.6f, %.6f], \"mesh_blocks\": %zu, \"mesh_vertices\": %zu, \"mesh_triangle_indices\": %zu, \"mesh_vertex_sum\": %.9g}\n",
