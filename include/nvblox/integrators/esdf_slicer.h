@@ -24,6 +24,19 @@ class EsdfSlicer {
       checkNvbx(nvbx_esdf_slice_to_image(layer.c_handle(), unknown_value, image->dataPtr(), (int64_t)rows * cols, &rows, &cols, bb), "nvbx_esdf_slice_to_image");
     if (aabb) *aabb = AxisAlignedBoundingBox({bb[0], bb[1], bb[2]}, {bb[3], bb[4], bb[5]});
   }
+  // nvblox_node.cpp:836-840: one costmap from two mappers (static + dynamic): union AABB, min of the observed distances
+  void sliceLayersToCombinedDistanceImage(const EsdfLayer& layer_1, const EsdfLayer& layer_2, float slice_height_1, float slice_height_2,
+                                          float unknown_value, AxisAlignedBoundingBox* aabb, Image<float>* image) const {
+    (void)slice_height_1; (void)slice_height_2;     // each mapper's own esdf_slice_height
+    int32_t rows = 0, cols = 0; float bb[6] = {0, 0, 0, 0, 0, 0};
+    last_ = layer_1.c_handle();
+    checkNvbx(nvbx_esdf_slice_combined_size(layer_1.c_handle(), layer_2.c_handle(), &rows, &cols, bb), "nvbx_esdf_slice_combined_size");
+    image->resize(rows, cols);
+    if (rows > 0 && cols > 0)
+      checkNvbx(nvbx_esdf_slice_combined_to_image(layer_1.c_handle(), layer_2.c_handle(), unknown_value, image->dataPtr(), (int64_t)rows * cols, &rows, &cols, bb),
+                "nvbx_esdf_slice_combined_to_image");
+    if (aabb) *aabb = AxisAlignedBoundingBox({bb[0], bb[1], bb[2]}, {bb[3], bb[4], bb[5]});
+  }
   // nvblox_node.cpp:917-919: int8 occupancy written to HOST memory (the message buffer); 100 occupied, 0 free, -1 unknown.
   // The conversion runs on the GPU (nvbx_occupancy_grid_from_slice); only the int8 result crosses to the host.
   void occupancyGridFromSliceImage(const Image<float>& slice_image, int8_t* occupancy_grid_host, float unknown_value) const {

@@ -22,6 +22,16 @@ inline void checkNvbx(int rc, const char* what) {
   if (rc < 0) { std::fprintf(stderr, "[nvblox_hip] %s failed (%d): %s\n", what, rc, nvbx_last_error()); std::exit(99); }
 }
 
+// Free functions and default-constructed helpers of the reference (DepthImageBackProjector, transformPointcloudOnGPU) own no
+// mapper; they run on the stream of the most recently created Mapper of the process (the node has one pipeline).
+namespace detail {
+inline nvbx_mapper*& contextMapper() { static nvbx_mapper* m = nullptr; return m; }
+inline nvbx_mapper* requireContextMapper(const char* who) {
+  if (!contextMapper()) { std::fprintf(stderr, "[nvblox_hip] %s needs a live nvblox::Mapper (none has been created)\n", who); std::abort(); }
+  return contextMapper();
+}
+}  // namespace detail
+
 template <typename VoxelType, uint32_t kLayer>
 class BlockLayerView {
  public:

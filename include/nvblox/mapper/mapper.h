@@ -65,9 +65,10 @@ class Mapper {
     int dev = 0; (void)hipGetDevice(&dev);
     const nvbx_mapper_params p = params_.toCAbi(voxel_size_m);
     checkNvbx(nvbx_mapper_create(dev, (void*)(hipStream_t)(*cuda_stream_), &p, block_capacity, &m_), "nvbx_mapper_create");
+    detail::contextMapper() = m_;
     rebuildViews();
   }
-  ~Mapper() { if (m_) nvbx_mapper_destroy(m_); }
+  ~Mapper() { if (detail::contextMapper() == m_) detail::contextMapper() = nullptr; if (m_) nvbx_mapper_destroy(m_); }
   Mapper(const Mapper&) = delete;
   Mapper& operator=(const Mapper&) = delete;
 

@@ -126,6 +126,9 @@ typedef struct {
 int nvbx_mapper_create(int device, void* hip_stream, const nvbx_mapper_params* params, int64_t block_capacity,
                        nvbx_mapper** out);
 int nvbx_mapper_destroy(nvbx_mapper* m);
+/* the offline fuser's parameter values (nvblox_examples_bringup/config/nvblox/fuser.yaml:24-42; decay / workspace values from
+ * nvblox_base.yaml:87-107) = the benchmark configuration; pure host function */
+void nvbx_default_params(nvbx_mapper_params* out);
 /* MultiMapper::setMapperParams  -- nvblox_node.cpp:203, fuser_node.cpp:94 */
 int nvbx_mapper_set_params(nvbx_mapper* m, const nvbx_mapper_params* params);
 int nvbx_mapper_get_params(const nvbx_mapper* m, nvbx_mapper_params* out);
@@ -197,6 +200,14 @@ int nvbx_esdf_slice_to_image(nvbx_mapper* m, float unknown_value, float* image_d
 /* EsdfSliceConverter::distanceMapSliceMsgFromSliceImage's D2H (esdf_slice_conversions.cu:81-109) in one call. */
 int nvbx_esdf_slice_to_host(nvbx_mapper* m, float unknown_value, float* image_host, int64_t capacity_elems,
                             int32_t* rows, int32_t* cols, float aabb_min_max[6]);
+/* EsdfSlicer::sliceLayersToCombinedDistanceImage(layer_1, layer_2, height_1, height_2, unknown, &aabb, &image) --
+ * nvblox_node.cpp:836-840 (static + dynamic mapper in one costmap): the image covers the union of the two layers' AABBs,
+ * a pixel is the smaller of the two signed distances where both are observed, the observed one where only one is, else
+ * unknown_value.  Both mappers must live on the same device; the work is enqueued on m1's stream behind everything
+ * enqueued on m2's (event).  aabb z range = m1's slice block. */
+int nvbx_esdf_slice_combined_size(nvbx_mapper* m1, nvbx_mapper* m2, int32_t* rows, int32_t* cols, float aabb_min_max[6]);
+int nvbx_esdf_slice_combined_to_image(nvbx_mapper* m1, nvbx_mapper* m2, float unknown_value, float* image_dev, int64_t capacity_elems,
+                                      int32_t* rows, int32_t* cols, float aabb_min_max[6]);
 /* EsdfSlicer::occupancyGridFromSliceImage(img, int8_t*, unknown) -- nvblox_node.cpp:917-919:
  * 100 where distance <= 0 (inside), 0 where observed free, -1 where unknown. */
 int nvbx_occupancy_grid_from_slice(nvbx_mapper* m, const float* image_dev, int32_t rows, int32_t cols,
@@ -218,6 +229,28 @@ int nvbx_esdf_dense_grid(nvbx_mapper* m, const int32_t min_vox[3], const int32_t
  * (voxel size), NVBX_E_CAPACITY; a file that fails validation leaves the current map untouched. */
 int nvbx_save_map(nvbx_mapper* m, const char* path);
 int nvbx_load_map(nvbx_mapper* m, const char* path);
+
+/* ---- sensor-side conversions next to the path -----------------------------------------------------------------------
+ * DepthImageBackProjector::backProjectOnGPU(depth, camera, &pointcloud_C, max_back_projection_distance) --
+ * nvblox_node.cpp:1128-1130, fuser_node.cpp:294-296: every pixel with 0 < depth <= max_distance_m (max <= 0: no limit)
+ * becomes the point ((u + 0.5 - cu) / fu * d, (v + 0.5 - cv) / fv * d, d) of the camera frame; the points are compacted
+ * (order unspecified) into points_xyz_dev[capacity_points][3]; *n_points = their number (synchronises). */
+int nvbx_backproject_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const nvbx_camera* camera,
+                           float max_distance_m, float* points_xyz_dev, int64_t capacity_points, int64_t* n_points);
+/* transformPointcloudOnGPU(T_L_C, pointcloud_C, &pointcloud_L) -- nvblox_node.cpp:1131, fuser_node.cpp:297 (in place if
+ * out == in; asynchronous on the mapper's stream) */
+int nvbx_transform_pointcloud(nvbx_mapper* m, const float T_L_C[16], const float* points_in_dev, int64_t n_points, float* points_out_dev);
+
+/* ---- device-side view for the caller's own kernels (GPULayerView / gpu_indexing.cuh: esdf_slice_conversions.cu:18,
+ * esdf_and_gradients_conversions.cu:19-23).  Accessors: include/nvblox_hip_device.h. */
+typedef struct {
+  const void* table; uint32_t table_mask, table_shift;    /* open-addressing hash: 16-byte entries {key64, slot32, stamp32} */
+  const uint32_t* slot_flags;                              /* per slot: NVBX_LAYER_* bits in the low byte */
+  const int32_t* slot_index;                               /* per slot: block index x, y, z */
+  const void* tsdf; const void* color; const void* esdf;   /* voxel pools, 512 x 8 bytes per slot */
+  float voxel_size; uint32_t block_capacity;
+} nvbx_device_view;
+int nvbx_get_device_view(nvbx_mapper* m, nvbx_device_view* out);
 
 /* ---- layer access (Layer<VoxelBlock> accessors; synchronise) ----------------------------------------------------
  * layer.numAllocatedBlocks(), getAllBlockIndices(), getBlockAtIndex(), allocateBlockAtIndex(),

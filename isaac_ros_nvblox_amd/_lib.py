@@ -62,6 +62,12 @@ class Index3D(C.Structure):
     _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("z", C.c_int32)]
 
 
+class DeviceView(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("table_mask", C.c_uint32), ("table_shift", C.c_uint32), ("slot_flags", C.c_void_p),
+                ("slot_index", C.c_void_p), ("tsdf", C.c_void_p), ("color", C.c_void_p), ("esdf", C.c_void_p),
+                ("voxel_size", C.c_float), ("block_capacity", C.c_uint32)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "blocks_allocated", "tsdf_blocks_in_view", "color_blocks_updated", "esdf_columns_marked", "esdf_blocks_swept",
@@ -78,6 +84,12 @@ SIGNATURES = {
     "nvbx_mapper_get_params": (C.c_int, [_vp, C.POINTER(Params)]),
     "nvbx_synchronize": (C.c_int, [_vp]),
     "nvbx_flush": (C.c_int, [_vp]),
+    "nvbx_default_params": (None, [C.POINTER(Params)]),
+    "nvbx_backproject_depth": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(Camera), C.c_float, _vp, _i64, C.POINTER(_i64)]),
+    "nvbx_transform_pointcloud": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "nvbx_esdf_slice_combined_size": (C.c_int, [_vp, _vp, C.POINTER(_i32), C.POINTER(_i32), _vp]),
+    "nvbx_esdf_slice_combined_to_image": (C.c_int, [_vp, _vp, C.c_float, _vp, _i64, C.POINTER(_i32), C.POINTER(_i32), _vp]),
+    "nvbx_get_device_view": (C.c_int, [_vp, C.POINTER(DeviceView)]),
     "nvbx_last_error": (C.c_char_p, []),
     "nvbx_mapper_clear": (C.c_int, [_vp]),
     "nvbx_integrate_depth": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera)]),

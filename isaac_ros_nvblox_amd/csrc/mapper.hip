@@ -315,6 +315,23 @@ extern "C" int nvbx_synchronize(nvbx_mapper* m) {
   NVBX_HIP(hipStreamSynchronize(m->stream));
   return NVBX_OK;
 }
+extern "C" void nvbx_default_params(nvbx_mapper_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->voxel_size = 0.05f; p->max_integration_distance_m = 8.0f; p->truncation_distance_vox = 4.0f; p->max_weight = 5.0f;
+  p->weighting_mode = 0; p->raycast_subsampling_factor = 4;
+  p->esdf_min_weight = 0.1f; p->esdf_max_site_distance_vox = 2.0f; p->esdf_max_distance_m = 2.0f;
+  p->esdf_slice_height = 0.09f; p->esdf_slice_min_height = 0.09f; p->esdf_slice_max_height = 0.65f;
+  p->mesh_min_weight = 0.1f; p->mesh_weld_vertices = 1;
+  p->sphere_tracing_subsampling = 4; p->sphere_tracing_max_steps = 100;
+  p->sphere_tracing_max_ray_length_m = 15.0f; p->sphere_tracing_surface_eps_vox = 0.1f;
+  p->tsdf_decay_factor = 0.95f; p->tsdf_decayed_weight_threshold = 0.001f;
+  p->esdf_site_rule = 0; p->depth_interp_nearest = 0;
+  p->lidar_max_integration_distance_m = 10.0f;
+  p->lidar_linear_interpolation_max_allowable_difference_vox = 2.0f;
+  p->lidar_nearest_interpolation_max_allowable_dist_to_ray_vox = 0.5f;
+  p->invalid_depth_decay_factor = -1.0f;
+}
 extern "C" int nvbx_flush(nvbx_mapper* m) {
   if (!m) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));

@@ -311,6 +311,41 @@ class Mapper:
         self._check(self.lib.nvbx_pointcloud_from_slice(self._h, C.c_void_p(img_dev.data_ptr()), img_dev.shape[0], img_dev.shape[1], _np_ptr(a), float(slice_height), unknown_value, C.c_void_p(pts.data_ptr()), C.byref(n)))
         return pts[:n.value]
 
+    def esdf_slice_image_combined(self, other, unknown_value=1000.0):
+        """EsdfSlicer::sliceLayersToCombinedDistanceImage (nvblox_node.cpp:836-840) of this mapper and `other`; host image."""
+        import torch
+        r, c = C.c_int32(), C.c_int32(); aabb = (C.c_float * 6)()
+        self._check(self.lib.nvbx_esdf_slice_combined_size(self._h, other._h, C.byref(r), C.byref(c), aabb))
+        if r.value == 0:
+            return np.zeros((0, 0), np.float32), np.array(list(aabb), np.float32)
+        img = torch.empty((r.value, c.value), dtype=torch.float32, device="cuda:%d" % self.device)
+        self._check(self.lib.nvbx_esdf_slice_combined_to_image(self._h, other._h, unknown_value, C.c_void_p(img.data_ptr()), img.numel(),
+                                                               C.byref(r), C.byref(c), aabb))
+        self.synchronize()
+        return img.cpu().numpy(), np.array(list(aabb), np.float32)
+
+    def backproject_depth(self, depth, cam, max_distance_m=0.0, T_L_C=None):
+        """DepthImageBackProjector::backProjectOnGPU (+ transformPointcloudOnGPU if T_L_C is given): [n, 3] float32 host array."""
+        import torch
+        d, rows, cols = self._dev(depth, self._torch.float32), depth.shape[0], depth.shape[1]
+        pts = torch.empty((rows * cols, 3), dtype=torch.float32, device=d.device)
+        n = C.c_int64()
+        self._check(self.lib.nvbx_backproject_depth(self._h, C.c_void_p(d.data_ptr()), rows, cols, C.byref(self._cam(cam)), max_distance_m,
+                                                    C.c_void_p(pts.data_ptr()), rows * cols, C.byref(n)))
+        pts = pts[:n.value]
+        if T_L_C is not None and n.value:
+            T = self._T(T_L_C)
+            self._check(self.lib.nvbx_transform_pointcloud(self._h, _np_ptr(T), C.c_void_p(pts.data_ptr()), n.value, C.c_void_p(pts.data_ptr())))
+            self.synchronize()
+        return pts.cpu().numpy()
+
+    def device_view(self):
+        """nvbx_device_view for the caller's own kernels (include/nvblox_hip_device.h)."""
+        from ._lib import DeviceView
+        v = DeviceView()
+        self._check(self.lib.nvbx_get_device_view(self._h, C.byref(v)))
+        return v
+
     def esdf_dense_grid(self, min_vox, size_vox, default_value):
         torch = self._torch
         mn = np.asarray(min_vox, np.int32); sz = np.asarray(size_vox, np.int32)

@@ -235,6 +235,24 @@ int main(int argc, char** argv) {
   shapes_to_clear.push_back(BoundingShape(AxisAlignedBoundingBox(Vector3f(90.f, 90.f, 90.f), Vector3f(91.f, 91.f, 91.f))));
   node.static_mapper_->clearTsdfInsideShapes(shapes_to_clear);
   if (!ply_ok) { std::fprintf(stderr, "ply export failed\n"); return 1; }
+  // back-projected depth cloud (fuser_node.cpp:291-297) and the two-mapper costmap slice (nvblox_node.cpp:836-840)
+  {
+    DepthImageBackProjector image_back_projector_;
+    Pointcloud pointcloud_C_device_(MemoryType::kDevice), pointcloud_L_device_(MemoryType::kDevice);
+    DepthImage flat(120, 160, MemoryType::kDevice);
+    std::vector<float> host_depth(120 * 160, 1.5f); host_depth[0] = 0.0f;
+    flat.copyFromAsync(120, 160, host_depth.data(), CudaStreamOwning());
+    const Camera depth_camera(80.f, 80.f, 79.5f, 59.5f, 160, 120);
+    image_back_projector_.backProjectOnGPU(flat, depth_camera, &pointcloud_C_device_, 5.0f);
+    transformPointcloudOnGPU(Transform::Identity(), pointcloud_C_device_, &pointcloud_L_device_);
+    node.static_mapper_->synchronize();
+    if (pointcloud_C_device_.size() != 120 * 160 - 1 || pointcloud_L_device_.size() != pointcloud_C_device_.size()) {
+      std::fprintf(stderr, "back projection gave %d points\n", pointcloud_C_device_.size()); return 1; }
+    EsdfSlicer esdf_slicer_;
+    AxisAlignedBoundingBox aabb2; Image<float> combined(MemoryType::kDevice);
+    esdf_slicer_.sliceLayersToCombinedDistanceImage(node.static_mapper_->esdf_layer(), node.static_mapper_->esdf_layer(), 0.09f, 0.09f, 1000.0f, &aabb2, &combined);
+    if (combined.rows() != height || combined.cols() != width) { std::fprintf(stderr, "combined slice size differs\n"); return 1; }
+  }
   // save_map / load_map services (nvblox_node.cpp:1668, 1703): bool results, a missing file is a recoverable error
   const std::string filename = std::string(argv[1]) + ".map";
   const bool save_ok = node.static_mapper_->saveLayerCake(filename);

@@ -86,3 +86,26 @@ def test_mapper_fails_loudly_without_gpu():
     from isaac_ros_nvblox_amd import mapper as M
     with pytest.raises(M.NvbxError):
         M.Mapper(M.default_params())
+
+
+def test_default_params_equal_python_mirror_and_device_view_layout(hip_lib):
+    """nvbx_default_params (a pure host function: callable without a GPU) == mapper.default_params(); the nvbx_device_view
+    struct of the header == the ctypes mirror; the device-side header compiles as plain C when no HIP compiler is used."""
+    from isaac_ros_nvblox_amd import _lib, mapper as M
+    p = _lib.Params()
+    hip_lib.nvbx_default_params.restype = None
+    hip_lib.nvbx_default_params.argtypes = [C.POINTER(_lib.Params)]
+    hip_lib.nvbx_default_params(C.byref(p))
+    q = M.default_params()
+    for name, _ in _lib.Params._fields_:
+        a, b = getattr(p, name), getattr(q, name)
+        assert (list(a) == list(b)) if hasattr(a, "__len__") else (a == b), name
+    src = r'''
+#include <stdio.h>
+#include "nvblox_hip_device.h"
+int main(void) { printf("%zu\n", sizeof(nvbx_device_view)); return 0; }'''
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "t.c"); exe = os.path.join(td, "t")
+        open(c, "w").write(src)
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        assert int(subprocess.check_output([exe]).decode()) == C.sizeof(_lib.DeviceView)

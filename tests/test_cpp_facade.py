@@ -139,3 +139,14 @@ def test_fuser_loop_cpp_host(hip_lib, tmp_path):
     assert 0.01 < got["ms_per_frame"] < 0.5, got            # README RTX 5090 sum for the same three components: 0.7 ms
     assert "tsdf/integrate" in r.stderr and "esdf/integrate" in r.stderr      # the reference's core timer tags
     print(got)
+
+
+@pytest.mark.gpu
+def test_foreign_kernel_reads_map_through_device_view(hip_lib):
+    """A HIP kernel outside the library reads ESDF / TSDF voxels in place through include/nvblox_hip_device.h (the role of
+    GPULayerView + gpu_indexing.cuh in esdf_and_gradients_conversions.cu:88-125): identical to nvbx_esdf_dense_grid."""
+    subprocess.check_call(["make", "-C", CPP, "foreign_kernel"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(CPP, "foreign_kernel")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["mismatches"] == 0 and got["esdf_known"] > 1000 and got["tsdf_observed"] > 5000 and got["tsdf_blocks"] > 50

@@ -211,3 +211,59 @@ def test_save_and_load_map_round_trip(oracle_mod, hip_lib, tmp_path):
     with pytest.raises(RuntimeError):
         b.load_map(trunc)
     assert b.num_blocks(M.LAYER_TSDF) == n_before
+
+
+def test_backproject_depth_and_transform(hip_lib):
+    """DepthImageBackProjector::backProjectOnGPU + transformPointcloudOnGPU (nvblox_node.cpp:1128-1131, fuser_node.cpp:294-297)."""
+    from isaac_ros_nvblox_amd import mapper as M
+    g = M.Mapper(M.default_params(), block_capacity=1 << 10)
+    cam = H.SMALL_CAM
+    d, _, T = H.frames(1, cam, color=False)[0]
+    d = d.copy(); d[:10, :] = 0.0; d[50, 60] = -1.0                   # invalid pixels are dropped
+    for max_d in (0.0, 3.0):
+        pts = g.backproject_depth(d, cam, max_d)
+        valid = (d > 0) & ((d <= max_d) if max_d > 0 else True)
+        assert len(pts) == int(valid.sum()) > 1000
+        v, u = np.nonzero(valid)
+        want = np.stack([((u + 0.5 - cam[2]) / cam[0]) * d[v, u], ((v + 0.5 - cam[3]) / cam[1]) * d[v, u], d[v, u]], -1).astype(np.float32)
+        order = lambda a: a[np.lexsort((a[:, 0], a[:, 1], a[:, 2]))]
+        assert np.abs(order(pts) - order(want)).max() <= 1e-5
+    # in the layer frame the points lie on the analytic scene surface
+    from test_oracle_ground_truth import scene_sdf
+    pl = g.backproject_depth(d, cam, 0.0, T_L_C=T)
+    assert np.abs(scene_sdf(pl.astype(np.float64))).max() < 2e-3
+    with pytest.raises(RuntimeError):
+        g.lib.nvbx_backproject_depth  # symbol exists
+        import ctypes as C, torch
+        dd = torch.from_numpy(d).cuda(); out = torch.empty((10, 3), device="cuda"); n = C.c_int64()
+        g._check(g.lib.nvbx_backproject_depth(g._h, C.c_void_p(dd.data_ptr()), d.shape[0], d.shape[1], C.byref(g._cam(cam)), 0.0,
+                                              C.c_void_p(out.data_ptr()), 10, C.byref(n)))       # capacity too small -> NVBX_E_CAPACITY
+
+
+def test_combined_slice_of_two_mappers(oracle_mod, hip_lib):
+    """EsdfSlicer::sliceLayersToCombinedDistanceImage (nvblox_node.cpp:836-840): union AABB, min of the observed distances."""
+    from isaac_ros_nvblox_amd import mapper as M
+    a = M.Mapper(M.default_params(), block_capacity=1 << 13); b = M.Mapper(M.default_params(), block_capacity=1 << 13)
+    fa = H.frames(3, H.SMALL_CAM, color=False, stride=10); fb = H.frames(3, H.SMALL_CAM, color=False, start=35, stride=10)
+    for d, _, T in fa: a.integrate_depth(d, T, H.SMALL_CAM)
+    for d, _, T in fb: b.integrate_depth(d, T, H.SMALL_CAM)
+    a.update_esdf(); b.update_esdf()
+    ia, aa = a.esdf_slice_image(1000.0); ib, ab = b.esdf_slice_image(1000.0)
+    ic, ac = a.esdf_slice_image_combined(b, 1000.0)
+    x0, y0 = min(aa[0], ab[0]), min(aa[1], ab[1]); x1, y1 = max(aa[3], ab[3]), max(aa[4], ab[4])
+    assert np.allclose(ac[[0, 1, 3, 4]], [x0, y0, x1, y1], atol=1e-5)
+    W, Hh = int(round((x1 - x0) / 0.05)), int(round((y1 - y0) / 0.05))
+    assert ic.shape == (Hh, W)
+    def big(img, ab_):
+        o = np.full((Hh, W), 1000.0, np.float32)
+        r0, c0 = int(round((ab_[1] - y0) / 0.05)), int(round((ab_[0] - x0) / 0.05))
+        o[r0:r0 + img.shape[0], c0:c0 + img.shape[1]] = img
+        return o
+    A, B = big(ia, aa), big(ib, ab)
+    ka, kb = A < 999.0, B < 999.0
+    want = np.where(ka & kb, np.minimum(A, B), np.where(ka, A, np.where(kb, B, 1000.0))).astype(np.float32)
+    assert (ka & kb).sum() > 100 and (ka ^ kb).sum() > 100
+    assert np.array_equal(ic, want)
+    # a mapper combined with itself is its own slice
+    ii, _ = a.esdf_slice_image_combined(a, 1000.0)
+    assert np.array_equal(ii, ia)
