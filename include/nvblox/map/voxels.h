@@ -8,6 +8,7 @@
 namespace nvblox {
 
 struct TsdfVoxel { float distance = 0.f; float weight = 0.f; };
+struct OccupancyVoxel { float log_odds = 0.f; };      // layer_publishing.cpp:140-154
 struct ColorVoxel { Color color; uint8_t pad_ = 0; float weight = 0.f; };
 struct EsdfVoxel {
   float squared_distance_vox = 0.f;

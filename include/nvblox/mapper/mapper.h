@@ -63,7 +63,7 @@ class Mapper {
       : voxel_size_m_(voxel_size_m), projective_layer_type_(projective_layer_type), cuda_stream_(std::move(cuda_stream)) {
     (void)memory_type;   // blocks always live in HBM (MemoryType::kDevice, nvblox_node.cpp:190)
     int dev = 0; (void)hipGetDevice(&dev);
-    const nvbx_mapper_params p = params_.toCAbi(voxel_size_m);
+    const nvbx_mapper_params p = params_.toCAbi(voxel_size_m, projective_layer_type_);
     checkNvbx(nvbx_mapper_create(dev, (void*)(hipStream_t)(*cuda_stream_), &p, block_capacity, &m_), "nvbx_mapper_create");
     detail::contextMapper() = m_;
     rebuildViews();
@@ -74,7 +74,7 @@ class Mapper {
 
   void setMapperParams(const MapperParams& params) {
     params_ = params;
-    const nvbx_mapper_params p = params_.toCAbi(voxel_size_m_);
+    const nvbx_mapper_params p = params_.toCAbi(voxel_size_m_, projective_layer_type_);
     checkNvbx(nvbx_mapper_set_params(m_, &p), "nvbx_mapper_set_params");
   }
   const MapperParams& params() const { return params_; }
@@ -125,6 +125,7 @@ class Mapper {
     checkNvbx(nvbx_update_color_mesh(m_, update_full_layer == UpdateFullLayer::kYes ? 1 : 0), "nvbx_update_color_mesh");
   }
   void updateMesh(UpdateFullLayer f = UpdateFullLayer::kNo) { updateColorMesh(f); }
+  void decayOccupancyAllVoxels() { checkNvbx(nvbx_decay_occupancy(m_), "nvbx_decay_occupancy"); }   // nvblox_node.cpp:928 (occupancy mappers)
   void decayTsdf() { checkNvbx(nvbx_decay_tsdf(m_, 0), "nvbx_decay_tsdf"); }
   template <typename SensorType>
   void decayTsdfExcludeLastView() { checkNvbx(nvbx_decay_tsdf(m_, 1), "nvbx_decay_tsdf"); }   // nvblox_node.cpp:935
@@ -146,6 +147,7 @@ class Mapper {
 
   // -- layers
   const TsdfLayer& tsdf_layer() const { return tsdf_layer_; }
+  const OccupancyLayer& occupancy_layer() const { return occupancy_layer_; }       // empty unless ProjectiveLayerType::kOccupancy
   const ColorLayer& color_layer() const { return color_layer_; }
   const EsdfLayer& esdf_layer() const { return esdf_layer_; }
   TsdfLayer& tsdf_layer() { return tsdf_layer_; }
@@ -177,6 +179,7 @@ class Mapper {
   };
   EsdfIntegratorView esdf_integrator() const { return EsdfIntegratorView{this}; }
   TsdfIntegratorView tsdf_integrator() const { return TsdfIntegratorView{this}; }
+  TsdfIntegratorView occupancy_integrator() const { return TsdfIntegratorView{this}; }     // max_integration_distance_m(): nvblox_node.cpp:1130
 
   // -- serialization of the mesh for publishing (layer_publishing.cpp:702-711,770-776; mesh_conversions.cpp:62-104)
   // Voxel layers: every allocated TSDF block inside the exclusion cylinder (radius / height around the centre; negative =
@@ -185,6 +188,7 @@ class Mapper {
   // blocks per call by bandwidth_limit_mbps; this implementation sends the whole selection every call.
   void serializeSelectedLayers(LayerTypeBitMask layers, float /*bandwidth_limit_mbps*/ = -1.f, const BlockExclusionParams& ex = BlockExclusionParams()) {
     if (layers & LayerType::kColorMesh) serializeColorMesh();
+    if (layers & LayerType::kOccupancy) serialized_occupancy_ = gatherLayer<OccupancyVoxel>(NVBX_LAYER_OCCUPANCY, occupancy_layer_.getAllBlockIndices());
     if (layers & (LayerType::kTsdf | LayerType::kColor)) {
       std::vector<Index3D> sel;
       const float bs = tsdf_layer_.block_size();
@@ -200,11 +204,11 @@ class Mapper {
     }
   }
   std::shared_ptr<SerializedColorMeshLayer> serializedColorMeshLayer() const { return serialized_mesh_; }
+  // layer_publishing.cpp:798-822 (dynamic mapper): all occupancy blocks, refreshed by serializeSelectedLayers(LayerType::kOccupancy, ...)
+  std::shared_ptr<const SerializedLayer<OccupancyVoxel>> serializedOccupancyLayer() const { return serialized_occupancy_; }
   std::shared_ptr<const SerializedTsdfLayer> serializedTsdfLayer() const { return serialized_tsdf_; }
   std::shared_ptr<const SerializedColorLayer> serializedColorLayer() const { return serialized_color_; }
 
-  // .nvblx save/load is outside the hot path and not provided by libnvblox_hip: report failure
-  // through the reference's bool convention (nvblox_node.cpp:1668,1703).
   // nvblox_node.cpp:1668,1703: recoverable I/O errors are reported as `false` (nvbx_last_error() has the reason)
   bool saveLayerCake(const std::string& path) const { return nvbx_save_map(m_, path.c_str()) == NVBX_OK; }
   bool loadMap(const std::string& path) { return nvbx_load_map(m_, path.c_str()) == NVBX_OK; }
@@ -215,7 +219,7 @@ class Mapper {
   const std::shared_ptr<CudaStream>& cuda_stream() const { return cuda_stream_; }
 
  private:
-  void rebuildViews() { tsdf_layer_ = TsdfLayer(m_, voxel_size_m_); color_layer_ = ColorLayer(m_, voxel_size_m_); esdf_layer_ = EsdfLayer(m_, voxel_size_m_); }
+  void rebuildViews() { occupancy_layer_ = OccupancyLayer(m_, voxel_size_m_); tsdf_layer_ = TsdfLayer(m_, voxel_size_m_); color_layer_ = ColorLayer(m_, voxel_size_m_); esdf_layer_ = EsdfLayer(m_, voxel_size_m_); }
   template <typename VoxelType>
   std::shared_ptr<SerializedLayer<VoxelType>> gatherLayer(uint32_t layer, const std::vector<Index3D>& sel) const {
     auto out = std::make_shared<SerializedLayer<VoxelType>>();
@@ -248,11 +252,12 @@ class Mapper {
   std::shared_ptr<CudaStream> cuda_stream_;
   MapperParams params_;
   nvbx_mapper* m_ = nullptr;
-  TsdfLayer tsdf_layer_; ColorLayer color_layer_; EsdfLayer esdf_layer_;
+  TsdfLayer tsdf_layer_; OccupancyLayer occupancy_layer_; ColorLayer color_layer_; EsdfLayer esdf_layer_;
   std::vector<Index3D> cleared_blocks_;
   DepthImage last_depth_frame_from_pointcloud_{MemoryType::kDevice};
   std::shared_ptr<SerializedColorMeshLayer> serialized_mesh_ = std::make_shared<SerializedColorMeshLayer>();
   std::shared_ptr<SerializedTsdfLayer> serialized_tsdf_ = std::make_shared<SerializedTsdfLayer>();
+  std::shared_ptr<SerializedLayer<OccupancyVoxel>> serialized_occupancy_ = std::make_shared<SerializedLayer<OccupancyVoxel>>();
   std::shared_ptr<SerializedColorLayer> serialized_color_ = std::make_shared<SerializedColorLayer>();
 };
 

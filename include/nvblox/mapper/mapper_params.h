@@ -54,9 +54,9 @@ constexpr Param<float>::Description kTsdfDecayFactorParamDesc{"tsdf_decay_factor
 constexpr Param<float>::Description kTsdfDecayedWeightThresholdDesc{"tsdf_decayed_weight_threshold", 0.001f, "Blocks whose weights are all below this are deallocated."};
 constexpr Param<bool>::Description kTsdfSetFreeDistanceOnDecayedDesc{"tsdf_set_free_distance_on_decayed", false, "(not provided by libnvblox_hip)."};
 constexpr Param<float>::Description kTsdfDecayedFreeDistanceVoxDesc{"tsdf_decayed_free_distance_vox", 4.0f, "(not provided by libnvblox_hip)."};
-constexpr Param<float>::Description kFreeRegionDecayProbabilityParamDesc{"free_region_decay_probability", 0.55f, "Occupancy decay (not provided by libnvblox_hip)."};
-constexpr Param<float>::Description kOccupiedRegionDecayProbabilityParamDesc{"occupied_region_decay_probability", 0.4f, "Occupancy decay (not provided by libnvblox_hip)."};
-constexpr Param<bool>::Description kOccupancyDecayToFreeParamDesc{"occupancy_decay_to_free", false, "Occupancy decay (not provided by libnvblox_hip)."};
+constexpr Param<float>::Description kFreeRegionDecayProbabilityParamDesc{"free_region_decay_probability", 0.55f, "Occupancy decay towards free instead of unknown (not provided by libnvblox_hip: decay stops at unknown)."};
+constexpr Param<float>::Description kOccupiedRegionDecayProbabilityParamDesc{"occupied_region_decay_probability", 0.4f, "Occupancy decay towards free instead of unknown (not provided by libnvblox_hip: decay stops at unknown)."};
+constexpr Param<bool>::Description kOccupancyDecayToFreeParamDesc{"occupancy_decay_to_free", false, "Occupancy decay towards free instead of unknown (not provided by libnvblox_hip: decay stops at unknown)."};
 constexpr Param<float>::Description kMaxTsdfDistanceForOccupancyMParamDesc{"max_tsdf_distance_for_occupancy_m", 0.15f, "Freespace integrator (not provided by libnvblox_hip)."};
 constexpr Param<int>::Description kMaxUnobservedToKeepConsecutiveOccupancyMsParamDesc{"max_unobserved_to_keep_consecutive_occupancy_ms", 200, "Freespace integrator (not provided by libnvblox_hip)."};
 constexpr Param<int>::Description kMinDurationSinceOccupiedForFreespaceMsParamDesc{"min_duration_since_occupied_for_freespace_ms", 1000, "Freespace integrator (not provided by libnvblox_hip)."};
@@ -119,9 +119,16 @@ struct MapperParams {
   FreespaceIntegratorParams freespace_integrator_params;
 
   // what libnvblox_hip consumes
-  nvbx_mapper_params toCAbi(float voxel_size) const {
+  nvbx_mapper_params toCAbi(float voxel_size, ProjectiveLayerType layer_type = ProjectiveLayerType::kTsdf) const {
     nvbx_mapper_params p{};
     p.voxel_size = voxel_size;
+    p.projective_layer_type = layer_type == ProjectiveLayerType::kOccupancy ? 1 : 0;
+    p.free_region_occupancy_probability = occupancy_integrator_params.free_region_occupancy_probability;
+    p.occupied_region_occupancy_probability = occupancy_integrator_params.occupied_region_occupancy_probability;
+    p.unobserved_region_occupancy_probability = occupancy_integrator_params.unobserved_region_occupancy_probability;
+    p.occupied_region_half_width_m = occupancy_integrator_params.occupied_region_half_width_m;
+    p.free_region_decay_probability = occupancy_decay_integrator_params.free_region_decay_probability;
+    p.occupied_region_decay_probability = occupancy_decay_integrator_params.occupied_region_decay_probability;
     p.max_integration_distance_m = projective_integrator_params.projective_integrator_max_integration_distance_m;
     p.truncation_distance_vox = projective_integrator_params.projective_integrator_truncation_distance_vox;
     p.max_weight = projective_integrator_params.projective_integrator_max_weight;

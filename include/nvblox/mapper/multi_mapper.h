@@ -1,6 +1,6 @@
 // nvblox/mapper/multi_mapper.h -- nvblox::MultiMapper as constructed and driven by NvbloxNode / FuserNode
 // (nvblox_node.cpp:187-210,781,1058-1062,1261-1264; fuser_node.cpp:85-94).  libnvblox_hip implements the static-TSDF
-// mapping type (BASELINE.json north_star); the masked / dynamic / LiDAR-pointcloud overloads exist so the node
+// mapping type (BASELINE.json north_star) and static occupancy (nvblox_base.yaml:9); the masked / dynamic / LiDAR-pointcloud overloads exist so the node
 // compiles, and abort with a clear message if reached (the reference aborts on programmer errors).
 #pragma once
 #include <cstdio>
@@ -16,9 +16,12 @@ class MultiMapper {
   MultiMapper(float voxel_size_m, MappingType mapping_type, EsdfMode esdf_mode, MemoryType memory_type = MemoryType::kDevice,
               std::shared_ptr<CudaStream> cuda_stream = std::make_shared<CudaStreamOwning>(), int64_t block_capacity = Mapper::kDefaultBlockCapacity)
       : mapping_type_(mapping_type), esdf_mode_(esdf_mode), cuda_stream_(cuda_stream) {
-    if (mapping_type != MappingType::kStaticTsdf) unsupported("mapping types other than MappingType::kStaticTsdf");
+    if (mapping_type != MappingType::kStaticTsdf && mapping_type != MappingType::kStaticOccupancy)
+      unsupported("mapping types other than MappingType::kStaticTsdf / kStaticOccupancy");
     if (esdf_mode != EsdfMode::k2D) unsupported("EsdfMode::k3D");
-    background_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type, ProjectiveLayerType::kTsdf, cuda_stream, block_capacity);
+    background_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type,
+                                                  mapping_type == MappingType::kStaticOccupancy ? ProjectiveLayerType::kOccupancy : ProjectiveLayerType::kTsdf,
+                                                  cuda_stream, block_capacity);
     // the foreground (dynamic / human) mapper is never fed in static mode; keep a minimal one so the handle is valid
     foreground_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type, ProjectiveLayerType::kNone, cuda_stream, 64);
   }

@@ -41,6 +41,7 @@ extern "C" {
 #define NVBX_LAYER_COLOR 2u
 #define NVBX_LAYER_ESDF 4u
 #define NVBX_LAYER_MESH 8u
+#define NVBX_LAYER_OCCUPANCY 16u   /* occupancy mappers only; shares the projective voxel pool with TSDF */
 
 typedef struct nvbx_mapper nvbx_mapper; /* replaces nvblox::Mapper (one per GPU / stream) */
 
@@ -49,6 +50,7 @@ typedef struct { float fu, fv, cu, cv; int32_t width, height; } nvbx_camera; /* 
 
 /* Voxel structs as the reference's consumers read them. */
 typedef struct { float distance, weight; } nvbx_tsdf_voxel;            /* layer_publishing.cpp:111,179 */
+typedef struct { float log_odds; } nvbx_occupancy_voxel;                /* layer_publishing.cpp:140-154 (OccupancyVoxel::log_odds) */
 typedef struct { uint8_t r, g, b, pad; float weight; } nvbx_color_voxel; /* layer_publishing.cpp:62-76; Color = 3 x u8 */
 typedef struct {                                                        /* esdf_and_gradients_conversions.cu:33-44 */
   float squared_distance_vox; int32_t parent_direction[3]; uint8_t is_inside, observed, is_site, pad;
@@ -95,6 +97,15 @@ typedef struct {
   int32_t depth_preprocessing_num_dilations; /* depth_preprocessing_num_dilations: invalid-depth regions grow by this many pixels */
   float invalid_depth_decay_factor;       /* projective_tsdf_integrator_invalid_depth_decay_factor (mapper_initialization.cpp:294-300;
                                              -1 = off, nvblox_base.yaml:80; 0.8 in nvblox_dynamics.yaml:11) */
+  /* -- occupancy mappers: Mapper(voxel_size, memory_type, ProjectiveLayerType::kOccupancy) -- mapping_type static_occupancy
+   *    (nvblox_base.yaml:9) and the dynamic / human mapper (specializations/nvblox_segmentation.yaml:9-22) */
+  int32_t projective_layer_type;          /* 0 = TSDF (default), 1 = occupancy (log-odds) */
+  float free_region_occupancy_probability;      /* mapper_initialization.cpp:309-312; 0.45 nvblox_base.yaml:82 */
+  float occupied_region_occupancy_probability;  /* :315-317; 0.55 */
+  float unobserved_region_occupancy_probability;/* :320-322; 0.5 */
+  float occupied_region_half_width_m;           /* :327; 0.1 */
+  float free_region_decay_probability;          /* occupancy decay, :416; 0.55 */
+  float occupied_region_decay_probability;      /* :421; 0.30 in the shipped configs */
 } nvbx_mapper_params;
 
 /* nvblox::Lidar(num_azimuth_divisions, num_elevation_divisions, min_valid_range_m, vertical_fov_rad) or
@@ -180,6 +191,9 @@ int nvbx_update_esdf(nvbx_mapper* m);
 int nvbx_update_color_mesh(nvbx_mapper* m, int32_t update_full_layer);
 /* Mapper::decayTsdfExcludeLastView<Camera>() / decayTsdf -- nvblox_node.cpp:931-936 */
 int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view);
+/* Mapper::decayOccupancyAllVoxels() -- nvblox_node.cpp:925-929 (occupancy mappers): log-odds move towards 0 (unknown) by the
+ * log-odds of free_region_decay_probability / occupied_region_decay_probability and stop there; all-unknown blocks are deallocated */
+int nvbx_decay_occupancy(nvbx_mapper* m);
 /* Mapper::clearOutsideRadius(center, radius) -- nvblox_node.cpp:1566-1583 */
 int nvbx_clear_outside_radius(nvbx_mapper* m, const float center[3], float radius);
 

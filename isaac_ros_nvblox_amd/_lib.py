@@ -41,6 +41,13 @@ class Params(C.Structure):
         ("do_depth_preprocessing", C.c_int32),
         ("depth_preprocessing_num_dilations", C.c_int32),
         ("invalid_depth_decay_factor", C.c_float),
+        ("projective_layer_type", C.c_int32),
+        ("free_region_occupancy_probability", C.c_float),
+        ("occupied_region_occupancy_probability", C.c_float),
+        ("unobserved_region_occupancy_probability", C.c_float),
+        ("occupied_region_half_width_m", C.c_float),
+        ("free_region_decay_probability", C.c_float),
+        ("occupied_region_decay_probability", C.c_float),
     ]
 
 
@@ -84,6 +91,7 @@ SIGNATURES = {
     "nvbx_mapper_get_params": (C.c_int, [_vp, C.POINTER(Params)]),
     "nvbx_synchronize": (C.c_int, [_vp]),
     "nvbx_flush": (C.c_int, [_vp]),
+    "nvbx_decay_occupancy": (C.c_int, [_vp]),
     "nvbx_default_params": (None, [C.POINTER(Params)]),
     "nvbx_backproject_depth": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(Camera), C.c_float, _vp, _i64, C.POINTER(_i64)]),
     "nvbx_transform_pointcloud": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),

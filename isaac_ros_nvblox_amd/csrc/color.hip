@@ -228,6 +228,7 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rg
 template <typename Pix>
 static int integrate_color_impl(nvbx_mapper* m, Pix rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera) {
   NVBX_HIP(hipSetDevice(m->device));
+  if (m->p.projective_layer_type == 1) return NVBX_OK;      // occupancy mappers carry no colour (the occlusion test sphere-traces a TSDF)
   if (m->flush_edt()) return NVBX_E_DEVICE;      // a held-back EDT must precede this launch's marking pass (it reads the site masks)
   Frame f = m->make_frame(T_L_C, camera, rows, cols, m->p.sphere_tracing_subsampling);
   const int32_t srows = rows / f.subsample, scols = cols / f.subsample;

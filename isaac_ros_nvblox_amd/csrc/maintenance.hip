@@ -179,8 +179,60 @@ static int rebuild_table(nvbx_mapper* m) {
   return NVBX_OK;
 }
 
+// [U] OccupancyDecayIntegrator (Mapper::decayOccupancyAllVoxels, nvblox_node.cpp:925-929): every log-odds value moves towards 0
+// (probability 0.5 = unknown) by the log-odds of its region's decay probability and stops there; a block whose voxels are all
+// unknown again is deallocated.
+__global__ __launch_bounds__(512) void k_decay_occupancy(DMap m, float lo_free_decay, float lo_occupied_decay, int32_t bz_lo, int32_t bz_hi, int32_t bz_out) {
+  __shared__ int s_alive;
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  const int tid = threadIdx.x;
+  for (int32_t slot = blockIdx.x; slot < hw; slot += gridDim.x) {
+    const uint32_t flags = m.slot_flags[slot];
+    if (!(flags & F_TSDF)) continue;
+    __syncthreads();
+    if (tid == 0) s_alive = 0;
+    __syncthreads();
+    float2 v = m.tsdf[(size_t)slot * 512 + tid];
+    if (v.x > 0.0f) { v.x = v.x + lo_occupied_decay; if (v.x < 0.0f) v.x = 0.0f; }
+    else if (v.x < 0.0f) { v.x = v.x + lo_free_decay; if (v.x > 0.0f) v.x = 0.0f; }
+    if (v.x != 0.0f) s_alive = 1;
+    m.tsdf[(size_t)slot * 512 + tid] = make_float2(v.x, 0.0f);
+    __syncthreads();
+    if (tid == 0) {
+      if (s_alive) {
+        const uint32_t old = atomicOr(&m.slot_flags[slot], F_DIRTY_ESDF);
+        if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, slot);
+      } else {
+        atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH));
+        const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
+        if (bz >= bz_lo && bz <= bz_hi) {
+          const uint32_t es = any_slot(m, bx, by, bz_out);
+          if (slot_ok(es) && (m.slot_flags[es] & F_ESDF)) {
+            const uint32_t eold = atomicOr(&m.slot_flags[es], F_ESDF_REMARK | F_DIRTY_ESDF);
+            if (!(eold & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)es);
+          }
+        }
+        if (!(flags & (F_ESDF | F_ESDF_PENDING))) { atomicAnd(&m.slot_flags[slot], ~(F_DIRTY_ESDF | F_DIRTY_MESH)); free_slot(m, (uint32_t)slot); }
+      }
+    }
+  }
+}
+extern "C" int nvbx_decay_occupancy(nvbx_mapper* m) {
+  if (!m) return NVBX_E_INVALID;
+  if (m->p.projective_layer_type != 1) { set_error("nvbx_decay_occupancy: not an occupancy mapper"); return NVBX_E_INVALID; }
+  NVBX_HIP(hipSetDevice(m->device));
+  if (m->join_side()) return NVBX_E_DEVICE;
+  if (m->undo_marks()) return NVBX_E_DEVICE;
+  if (m->begin_dirtying()) return NVBX_E_DEVICE;
+  const EsdfArgs ea = m->make_esdf_args();
+  NVBX_LAUNCH(m, k_decay_occupancy, dim3((unsigned)std::min<int64_t>(m->capacity, 2048)), dim3(512), m->d,
+              log_odds(m->p.free_region_decay_probability), log_odds(m->p.occupied_region_decay_probability), ea.bz_lo, ea.bz_hi, ea.bz_out);
+  return rebuild_table(m);
+}
+
 extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   if (!m) return NVBX_E_INVALID;
+  if (m->p.projective_layer_type == 1) { set_error("nvbx_decay_tsdf: occupancy mapper (use nvbx_decay_occupancy)"); return NVBX_E_INVALID; }
   NVBX_HIP(hipSetDevice(m->device));
   if (m->join_side()) return NVBX_E_DEVICE;
   if (m->undo_marks()) return NVBX_E_DEVICE;          // decay deallocates: unresolved marking passes are taken back first

@@ -73,13 +73,15 @@ __global__ void k_shardlist_to_indices(DMap m, int list, int32_t* out, int32_t c
 
 // gather n blocks of `layer` into a dense buffer in the REFERENCE voxel struct layout (z + 8y + 64x order).
 // found[i] = 1 if the block exists.  One 512-thread workgroup per block.
-__global__ __launch_bounds__(512) void k_gather_blocks(DMap m, uint32_t layer, const int32_t* idx, int32_t n, uint8_t* out, int32_t* found) {
+// `layer` is the INTERNAL flag; occupancy = 1: the projective pool holds log-odds and leaves as nvbx_occupancy_voxel {f32}
+__global__ __launch_bounds__(512) void k_gather_blocks(DMap m, uint32_t layer, int32_t occupancy, const int32_t* idx, int32_t n, uint8_t* out, int32_t* found) {
   const int i = blockIdx.x; if (i >= n) return;
   const uint32_t s = find_slot(m, idx[3 * i], idx[3 * i + 1], idx[3 * i + 2], layer);
   const int t = threadIdx.x;
   if (t == 0) found[i] = slot_ok(s) ? 1 : 0;
   if (!slot_ok(s)) return;
-  if (layer == F_TSDF) { reinterpret_cast<float2*>(out)[(size_t)i * 512 + t] = m.tsdf[(size_t)s * 512 + t]; }
+  if (layer == F_TSDF && occupancy) { reinterpret_cast<float*>(out)[(size_t)i * 512 + t] = m.tsdf[(size_t)s * 512 + t].x; }
+  else if (layer == F_TSDF) { reinterpret_cast<float2*>(out)[(size_t)i * 512 + t] = m.tsdf[(size_t)s * 512 + t]; }
   else if (layer == F_COLOR) { reinterpret_cast<uint2*>(out)[(size_t)i * 512 + t] = m.color[(size_t)s * 512 + t]; }
   else if (layer == F_ESDF) {
     const int x = t >> 6, y = (t >> 3) & 7, z = t & 7;             // reference order
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(512) void k_gather_blocks(DMap m, uint32_t layer, c
 }
 
 // allocateBlockAtIndex + whole-block write from reference structs: workgroup i writes block idx[i] from in[i][512]
-__global__ __launch_bounds__(512) void k_scatter_blocks(DMap m, uint32_t layer, const int32_t* idx, const uint8_t* in_all, size_t block_bytes,
+__global__ __launch_bounds__(512) void k_scatter_blocks(DMap m, uint32_t layer, int32_t occupancy, const int32_t* idx, const uint8_t* in_all, size_t block_bytes,
                                                         int32_t mesh_list, int32_t bz_out, int32_t vz_out) {
   __shared__ uint32_t s_slot;
   __shared__ u64 s_sites, s_obs, s_ins;
@@ -122,7 +124,8 @@ __global__ __launch_bounds__(512) void k_scatter_blocks(DMap m, uint32_t layer, 
   __syncthreads();
   const uint32_t s = s_slot;
   if (!slot_ok(s)) return;
-  if (layer == F_TSDF) m.tsdf[(size_t)s * 512 + t] = reinterpret_cast<const float2*>(in)[t];
+  if (layer == F_TSDF && occupancy) m.tsdf[(size_t)s * 512 + t] = make_float2(reinterpret_cast<const float*>(in)[t], 0.0f);
+  else if (layer == F_TSDF) m.tsdf[(size_t)s * 512 + t] = reinterpret_cast<const float2*>(in)[t];
   else if (layer == F_COLOR) m.color[(size_t)s * 512 + t] = reinterpret_cast<const uint2*>(in)[t];
   else if (layer == F_ESDF) {
     const int vx = t >> 6, vy = (t >> 3) & 7, vz = t & 7;
@@ -209,6 +212,9 @@ int nvbx_mapper::fetch_counters() {
   return NVBX_OK;
 }
 
+// log-odds of a probability, evaluated on the host in float (the oracle does the same with the same libm)
+float nvbx::log_odds(float p) { return logf(p / (1.0f - p)); }
+
 // T_L_C row-major 4x4 -> forward and inverse rigid transforms, fixed evaluation order (matches oracle rt_from_T)
 Frame nvbx_mapper::make_frame(const float T[16], const nvbx_camera* cam, int32_t rows, int32_t cols, int32_t subsample) const {
   Frame f{};
@@ -227,6 +233,9 @@ Frame nvbx_mapper::make_frame(const float T[16], const nvbx_camera* cam, int32_t
   f.max_dist = p.max_integration_distance_m; f.max_weight = p.max_weight;
   f.weighting_mode = p.weighting_mode; f.interp_nearest = p.depth_interp_nearest;
   f.invalid_decay = p.invalid_depth_decay_factor;
+  f.occupancy = p.projective_layer_type == 1 ? 1 : 0;
+  f.lo_free = log_odds(p.free_region_occupancy_probability); f.lo_occupied = log_odds(p.occupied_region_occupancy_probability);
+  f.lo_unobserved = log_odds(p.unobserved_region_occupancy_probability); f.occ_half_width = p.occupied_region_half_width_m;
   f.ws_type = p.workspace_bounds_type;
   for (int i = 0; i < 3; i++) { f.ws_min[i] = p.workspace_bounds_min_corner_m[i]; f.ws_max[i] = p.workspace_bounds_max_corner_m[i]; }
   f.subsample = subsample < 1 ? 1 : subsample;
@@ -247,7 +256,7 @@ EsdfArgs nvbx_mapper::make_esdf_args() const {
   c.ri = (int32_t)floorf(r); if (c.ri > 63) c.ri = 63; if (c.ri < 1) c.ri = 1;
   c.rb = (c.ri + 7) / 8;
   c.site_dist_m = p.esdf_max_site_distance_vox * vs;
-  c.min_weight = p.esdf_min_weight; c.voxel_size = vs; c.site_rule = p.esdf_site_rule;
+  c.min_weight = p.esdf_min_weight; c.voxel_size = vs; c.site_rule = p.projective_layer_type == 1 ? 2 : p.esdf_site_rule;
   c.epoch = esdf_epoch; c.mark_pass = mark_pass;
   c.rec = C_ESDF_UPD + 8 * (int)(esdf_epoch & 1); c.rec_next = C_ESDF_UPD + 8 * (int)((esdf_epoch + 1) & 1);
   return c;
@@ -331,6 +340,10 @@ extern "C" void nvbx_default_params(nvbx_mapper_params* p) {
   p->lidar_linear_interpolation_max_allowable_difference_vox = 2.0f;
   p->lidar_nearest_interpolation_max_allowable_dist_to_ray_vox = 0.5f;
   p->invalid_depth_decay_factor = -1.0f;
+  p->projective_layer_type = 0;
+  p->free_region_occupancy_probability = 0.45f; p->occupied_region_occupancy_probability = 0.55f;
+  p->unobserved_region_occupancy_probability = 0.5f; p->occupied_region_half_width_m = 0.1f;
+  p->free_region_decay_probability = 0.55f; p->occupied_region_decay_probability = 0.30f;
 }
 extern "C" int nvbx_flush(nvbx_mapper* m) {
   if (!m) return NVBX_E_INVALID;
@@ -345,7 +358,15 @@ extern "C" int nvbx_mapper_clear(nvbx_mapper* m) {
 }
 
 // ------------------------------------------------------------------------------------------------ C-ABI: layer access
-static bool single_layer(uint32_t layer) { return layer == F_TSDF || layer == F_COLOR || layer == F_ESDF || layer == F_MESH; }
+static bool single_layer(uint32_t layer) { return layer == F_TSDF || layer == F_COLOR || layer == F_ESDF || layer == F_MESH || layer == NVBX_LAYER_OCCUPANCY; }
+// API layer id -> internal slot flag; 0 = this mapper cannot hold that layer (it reads as empty).  The projective layer of a
+// mapper (TSDF or occupancy, Mapper's ProjectiveLayerType) lives in the same pool under the same internal flag.
+static uint32_t internal_layer(const nvbx_mapper* m, uint32_t layer) {
+  const bool occ = m->p.projective_layer_type == 1;
+  if (layer == NVBX_LAYER_OCCUPANCY) return occ ? F_TSDF : 0u;
+  if (layer == F_TSDF) return occ ? 0u : F_TSDF;
+  return layer;
+}
 
 static void sort_indices(nvbx_index3d* v, int64_t n) {
   std::sort(v, v + n, [](const nvbx_index3d& a, const nvbx_index3d& b) {
@@ -354,6 +375,8 @@ static void sort_indices(nvbx_index3d* v, int64_t n) {
 
 extern "C" int64_t nvbx_block_indices(nvbx_mapper* m, uint32_t layer, nvbx_index3d* out, int64_t capacity) {
   if (!m || !single_layer(layer)) return NVBX_E_INVALID;
+  layer = internal_layer(m, layer);
+  if (!layer) return 0;
   if (m->join_side()) return NVBX_E_DEVICE;
   NVBX_LAUNCH(m, k_zero_tmp, dim3(1), dim3(1), m->d);
   NVBX_LAUNCH(m, k_collect_indices, dim3(256), dim3(256), m->d, layer, m->export_idx, (int32_t)m->capacity);
@@ -404,19 +427,21 @@ extern "C" int64_t nvbx_last_color_view(nvbx_mapper* m, nvbx_index3d* out, int64
   return n;
 }
 
-static size_t ref_voxel_bytes(uint32_t layer) { return layer == F_ESDF ? sizeof(nvbx_esdf_voxel) : 8; }
+static size_t ref_voxel_bytes(uint32_t layer) { return layer == F_ESDF ? sizeof(nvbx_esdf_voxel) : (layer == NVBX_LAYER_OCCUPANCY ? sizeof(nvbx_occupancy_voxel) : 8); }
 
 extern "C" int nvbx_get_blocks(nvbx_mapper* m, uint32_t layer, const nvbx_index3d* idx, int64_t n, void* voxels_out, int32_t* found_out) {
-  if (!m || !idx || !voxels_out || n < 0 || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF)) return NVBX_E_INVALID;
+  if (!m || !idx || !voxels_out || n < 0 || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF || layer == NVBX_LAYER_OCCUPANCY)) return NVBX_E_INVALID;
   if (m->join_side()) return NVBX_E_DEVICE;
   const size_t bb = 512 * ref_voxel_bytes(layer);
+  const uint32_t ilayer = internal_layer(m, layer);
+  if (!ilayer) { if (found_out) memset(found_out, 0, (size_t)n * 4); return NVBX_OK; }
   const int64_t chunk = std::max<int64_t>(1, (int64_t)((m->staging_bytes - 65536) / (bb + 16)));
   for (int64_t o = 0; o < n; o += chunk) {
     const int64_t c = std::min(chunk, n - o);
     int32_t* d_idx = (int32_t*)m->staging; int32_t* d_found = d_idx + 3 * c;
     uint8_t* d_out = (uint8_t*)m->staging + (((size_t)c * 16 + 255) & ~(size_t)255);
     NVBX_HIP(hipMemcpyAsync(d_idx, idx + o, (size_t)c * 12, hipMemcpyHostToDevice, m->stream));
-    NVBX_LAUNCH(m, k_gather_blocks, dim3((unsigned)c), dim3(512), m->d, layer, d_idx, (int32_t)c, d_out, d_found);
+    NVBX_LAUNCH(m, k_gather_blocks, dim3((unsigned)c), dim3(512), m->d, ilayer, (int32_t)(layer == NVBX_LAYER_OCCUPANCY), d_idx, (int32_t)c, d_out, d_found);
     NVBX_HIP(hipMemcpyAsync((uint8_t*)voxels_out + (size_t)o * bb, d_out, (size_t)c * bb, hipMemcpyDeviceToHost, m->stream));
     if (found_out) NVBX_HIP(hipMemcpyAsync(found_out + o, d_found, (size_t)c * 4, hipMemcpyDeviceToHost, m->stream));
     NVBX_HIP(hipStreamSynchronize(m->stream));
@@ -430,7 +455,9 @@ extern "C" int nvbx_get_block(nvbx_mapper* m, uint32_t layer, nvbx_index3d idx, 
   return found ? NVBX_OK : NVBX_E_NOTFOUND;
 }
 extern "C" int nvbx_set_blocks(nvbx_mapper* m, uint32_t layer, const nvbx_index3d* idx, int64_t n, const void* voxels_in) {
-  if (!m || (n > 0 && (!voxels_in || !idx)) || n < 0 || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF)) return NVBX_E_INVALID;
+  if (!m || (n > 0 && (!voxels_in || !idx)) || n < 0 || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF || layer == NVBX_LAYER_OCCUPANCY)) return NVBX_E_INVALID;
+  const uint32_t ilayer = internal_layer(m, layer);
+  if (!ilayer) { set_error("nvbx_set_blocks: this mapper's projective layer type does not hold that layer"); return NVBX_E_INVALID; }
   if (m->join_side()) return NVBX_E_DEVICE;
   if (m->begin_dirtying()) return NVBX_E_DEVICE;
   const size_t bb = 512 * ref_voxel_bytes(layer);
@@ -442,7 +469,7 @@ extern "C" int nvbx_set_blocks(nvbx_mapper* m, uint32_t layer, const nvbx_index3
     uint8_t* d_in = (uint8_t*)m->staging + (((size_t)c * 16 + 255) & ~(size_t)255);
     NVBX_HIP(hipMemcpyAsync(d_idx, idx + o, (size_t)c * 12, hipMemcpyHostToDevice, m->stream));
     NVBX_HIP(hipMemcpyAsync(d_in, (const uint8_t*)voxels_in + (size_t)o * bb, (size_t)c * bb, hipMemcpyHostToDevice, m->stream));
-    NVBX_LAUNCH(m, k_scatter_blocks, dim3((unsigned)c), dim3(512), m->d, layer, (const int32_t*)d_idx, (const uint8_t*)d_in, bb,
+    NVBX_LAUNCH(m, k_scatter_blocks, dim3((unsigned)c), dim3(512), m->d, ilayer, (int32_t)(layer == NVBX_LAYER_OCCUPANCY), (const int32_t*)d_idx, (const uint8_t*)d_in, bb,
                 (int32_t)m->mesh_list_live(), ea.bz_out, ea.vz_out);
     NVBX_HIP(hipStreamSynchronize(m->stream));
   }
@@ -468,7 +495,7 @@ extern "C" int nvbx_save_map(nvbx_mapper* m, const char* path) {
   if (!m || !path) { set_error("nvbx_save_map: invalid argument"); return NVBX_E_INVALID; }
   FileCloser fc{fopen(path, "wb")};
   if (!fc.f) { set_error("nvbx_save_map: cannot open file for writing"); return NVBX_E_IO; }
-  const uint32_t layers[3] = {F_TSDF, F_COLOR, F_ESDF};
+  const uint32_t layers[3] = {m->p.projective_layer_type == 1 ? NVBX_LAYER_OCCUPANCY : F_TSDF, F_COLOR, F_ESDF};
   MapFileHeader h{}; memcpy(h.magic, kMapMagic, 8); h.version = 1; h.voxel_size = m->p.voxel_size; h.n_layers = 3;
   if (fwrite(&h, sizeof(h), 1, fc.f) != 1) { set_error("nvbx_save_map: write failed"); return NVBX_E_IO; }
   for (uint32_t layer : layers) {
@@ -505,7 +532,8 @@ extern "C" int nvbx_load_map(nvbx_mapper* m, const char* path) {
   for (uint32_t l = 0; l < h.n_layers; l++) {
     Section sc{};
     if (fread(&sc.lh, sizeof(sc.lh), 1, fc.f) != 1) { set_error("nvbx_load_map: truncated file"); return NVBX_E_IO; }
-    if (!(sc.lh.layer == F_TSDF || sc.lh.layer == F_COLOR || sc.lh.layer == F_ESDF) || sc.lh.voxel_bytes != ref_voxel_bytes(sc.lh.layer)) {
+    if (!(sc.lh.layer == F_TSDF || sc.lh.layer == F_COLOR || sc.lh.layer == F_ESDF || sc.lh.layer == NVBX_LAYER_OCCUPANCY) ||
+        sc.lh.voxel_bytes != ref_voxel_bytes(sc.lh.layer) || (sc.lh.n_blocks > 0 && !internal_layer(m, sc.lh.layer))) {
       set_error("nvbx_load_map: unknown layer record"); return NVBX_E_IO; }
     if ((int64_t)sc.lh.n_blocks > m->capacity) { set_error("nvbx_load_map: map has more blocks than the mapper's block capacity"); return NVBX_E_CAPACITY; }
     sc.idx_off = ftell(fc.f); sc.vox_off = sc.idx_off + (long)(sc.lh.n_blocks * 12);

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
 extern "C" int nvbx_update_color_mesh(nvbx_mapper* m, int32_t update_full_layer) {
   if (!m) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));
+  if (m->p.projective_layer_type == 1) return NVBX_OK;      // "Mesh integration is not implemented for occupancy layers" (nvblox_node.cpp:186)
   if (m->join_side()) return NVBX_E_DEVICE;
   MeshArgs a{};
   a.voxel_size = m->p.voxel_size; a.block_size = m->p.voxel_size * 8.0f; a.min_weight = m->p.mesh_min_weight;

@@ -61,7 +61,10 @@ __device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg
       for (int z = 0; z < 8; z++) {
         const int32_t kz = bzz * 8 + z;
         if (kz < a.kz_min || kz > a.kz_max) continue;
-        if (wz[z] >= a.min_weight) {
+        if (a.site_rule == 2) {          // occupancy layer {log_odds, -}: [U] OccupancySiteFunctor -- known iff log-odds != 0, site = inside = occupied (p > 0.5)
+          if (dz[z] != 0.0f) observed = 1;
+          if (dz[z] > 0.0f) { inside = 1; site = 1; }
+        } else if (wz[z] >= a.min_weight) {
           observed = 1;
           const int in = dz[z] <= 0.0f;
           if (in) inside = 1;

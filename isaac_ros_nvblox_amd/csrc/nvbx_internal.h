@@ -103,6 +103,8 @@ struct Frame {
   float voxel_size, block_size, trunc, max_dist, max_weight;
   int32_t weighting_mode, interp_nearest;
   float invalid_decay;      // invalid_depth_decay_factor (< 0 = off)
+  // occupancy mappers (projective_layer_type 1): the projective pool holds {log_odds, 0}; log-odds updates of the three regions
+  int32_t occupancy; float lo_free, lo_occupied, lo_unobserved, occ_half_width;
   int32_t ws_type; float ws_min[3], ws_max[3];   // workspace bounds of the view calculator (0 = unbounded)
   int32_t subsample;        // raycast / sphere-tracing subsampling
   int32_t n_ray_rows, n_ray_cols;
@@ -299,6 +301,18 @@ __device__ inline int interp_depth(const Img& img, int rows, int cols, float u, 
   const float bot = (1.0f - ax) * f01 + ax * f11;
   *out = (1.0f - ay) * top + ay * bot;
   return 1;
+}
+
+// [U] ProjectiveOccupancyIntegrator: log-odds update of a voxel at depth `vd` along the ray whose surface was measured at `ds`
+constexpr float OCC_LOG_ODDS_CLAMP = 10.0f;
+__device__ inline float occupancy_update(const Frame& f, float cur, float ds, float vd) {
+  float upd = f.lo_unobserved;
+  if (vd < ds - f.occ_half_width) upd = f.lo_free;
+  else if (vd <= ds + f.occ_half_width) upd = f.lo_occupied;
+  float v = cur + upd;
+  if (v > OCC_LOG_ODDS_CLAMP) v = OCC_LOG_ODDS_CLAMP;
+  if (v < -OCC_LOG_ODDS_CLAMP) v = -OCC_LOG_ODDS_CLAMP;
+  return v;
 }
 
 __device__ inline float weight_fn(int mode, float d_meas, float d_vox, float trunc) {

@@ -24,6 +24,7 @@ struct EsdfArgs {
 
 struct MeshRecord { int32_t x, y, z, vbase, nvert, tbase, ntri, pad; };
 
+float log_odds(float p);
 void set_error(const char* what, hipError_t e);
 void set_error(const char* what);
 

@@ -433,16 +433,20 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img dep
              voxel_center(rec_c.w, vz, f.block_size, f.voxel_size), pc);
     float ds = 0.0f, vd = 0.0f;
     const int got = sensor.sample(f, depth, pc, &ds, &vd);
-    if (got < 0 && f.invalid_decay >= 0.0f) *vp = make_float2(cur_c.x, cur_c.y * f.invalid_decay);
-    if (got > 0) {
-      const float sdf = ds - vd;
-      if (!(sdf < -f.trunc)) {
-        const float wm = weight_fn(f.weighting_mode, ds, vd, f.trunc);
-        const float wsum = wm + cur_c.y;
-        if (wsum > 0.0f) {
-          float fused = (sdf * wm + cur_c.x * cur_c.y) / wsum;
-          if (fused > 0.0f) fused = fminf(f.trunc, fused); else fused = fmaxf(-f.trunc, fused);
-          *vp = make_float2(fused, fminf(wsum, f.max_weight));
+    if (f.occupancy) {            // occupancy mapper: the pool holds log-odds (nvbx_internal.h occupancy_update)
+      if (got > 0) *vp = make_float2(occupancy_update(f, cur_c.x, ds, vd), 0.0f);
+    } else {
+      if (got < 0 && f.invalid_decay >= 0.0f) *vp = make_float2(cur_c.x, cur_c.y * f.invalid_decay);
+      if (got > 0) {
+        const float sdf = ds - vd;
+        if (!(sdf < -f.trunc)) {
+          const float wm = weight_fn(f.weighting_mode, ds, vd, f.trunc);
+          const float wsum = wm + cur_c.y;
+          if (wsum > 0.0f) {
+            float fused = (sdf * wm + cur_c.x * cur_c.y) / wsum;
+            if (fused > 0.0f) fused = fminf(f.trunc, fused); else fused = fmaxf(-f.trunc, fused);
+            *vp = make_float2(fused, fminf(wsum, f.max_weight));
+          }
         }
       }
     }

@@ -10,13 +10,14 @@ import numpy as np
 from . import _lib
 from ._lib import BoundingShape, Camera, Counters, Index3D, Lidar, Params
 
-LAYER_TSDF, LAYER_COLOR, LAYER_ESDF, LAYER_MESH = 1, 2, 4, 8
+LAYER_TSDF, LAYER_COLOR, LAYER_ESDF, LAYER_MESH, LAYER_OCCUPANCY = 1, 2, 4, 8, 16
 
 TSDF_DT = np.dtype([("distance", "<f4"), ("weight", "<f4")])
 COLOR_DT = np.dtype([("r", "u1"), ("g", "u1"), ("b", "u1"), ("pad", "u1"), ("weight", "<f4")])
 ESDF_DT = np.dtype([("squared_distance_vox", "<f4"), ("parent_direction", "<i4", (3,)),
                     ("is_inside", "u1"), ("observed", "u1"), ("is_site", "u1"), ("pad", "u1")])
-_DT = {LAYER_TSDF: TSDF_DT, LAYER_COLOR: COLOR_DT, LAYER_ESDF: ESDF_DT}
+OCCUPANCY_DT = np.dtype([("log_odds", "<f4")])
+_DT = {LAYER_TSDF: TSDF_DT, LAYER_COLOR: COLOR_DT, LAYER_ESDF: ESDF_DT, LAYER_OCCUPANCY: OCCUPANCY_DT}
 
 
 def default_params(**kw):
@@ -33,7 +34,10 @@ def default_params(**kw):
         esdf_site_rule=0, depth_interp_nearest=0,
         lidar_max_integration_distance_m=10.0,
         lidar_linear_interpolation_max_allowable_difference_vox=2.0,
-        lidar_nearest_interpolation_max_allowable_dist_to_ray_vox=0.5, invalid_depth_decay_factor=-1.0)
+        lidar_nearest_interpolation_max_allowable_dist_to_ray_vox=0.5, invalid_depth_decay_factor=-1.0,
+        projective_layer_type=0, free_region_occupancy_probability=0.45, occupied_region_occupancy_probability=0.55,
+        unobserved_region_occupancy_probability=0.5, occupied_region_half_width_m=0.1,
+        free_region_decay_probability=0.55, occupied_region_decay_probability=0.30)
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -200,6 +204,10 @@ class Mapper:
 
     def decay_tsdf(self, exclude_last_view=True):
         self._check(self.lib.nvbx_decay_tsdf(self._h, int(exclude_last_view)))
+
+    def decay_occupancy(self):
+        """Mapper::decayOccupancyAllVoxels (nvblox_node.cpp:925-929); occupancy mappers only."""
+        self._check(self.lib.nvbx_decay_occupancy(self._h))
 
     def clear_outside_radius(self, center, radius):
         c = np.asarray(center, np.float32)

@@ -47,6 +47,13 @@ class OrcParams(C.Structure):
         ("do_depth_preprocessing", C.c_int32),
         ("depth_preprocessing_num_dilations", C.c_int32),
         ("invalid_depth_decay_factor", C.c_float),
+        ("projective_layer_type", C.c_int32),
+        ("free_region_occupancy_probability", C.c_float),
+        ("occupied_region_occupancy_probability", C.c_float),
+        ("unobserved_region_occupancy_probability", C.c_float),
+        ("occupied_region_half_width_m", C.c_float),
+        ("free_region_decay_probability", C.c_float),
+        ("occupied_region_decay_probability", C.c_float),
     ]
 
 
@@ -63,7 +70,10 @@ def default_params(**kw):
         tsdf_decay_factor=0.95, tsdf_decayed_weight_threshold=0.001,
         esdf_site_rule=0, depth_interp_nearest=0, lidar_max_integration_distance_m=10.0,
         lidar_linear_interpolation_max_allowable_difference_vox=2.0,
-        lidar_nearest_interpolation_max_allowable_dist_to_ray_vox=0.5, invalid_depth_decay_factor=-1.0)
+        lidar_nearest_interpolation_max_allowable_dist_to_ray_vox=0.5, invalid_depth_decay_factor=-1.0,
+        projective_layer_type=0, free_region_occupancy_probability=0.45, occupied_region_occupancy_probability=0.55,
+        unobserved_region_occupancy_probability=0.5, occupied_region_half_width_m=0.1,
+        free_region_decay_probability=0.55, occupied_region_decay_probability=0.30)
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -113,6 +123,7 @@ def lib():
         L.orc_mesh_counts.restype = C.c_int; L.orc_mesh_counts.argtypes = [vp, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
         L.orc_mesh_get.restype = C.c_int; L.orc_mesh_get.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
         L.orc_decay_tsdf.restype = i64; L.orc_decay_tsdf.argtypes = [vp, C.c_int]
+        L.orc_decay_occupancy.restype = i64; L.orc_decay_occupancy.argtypes = [vp]
         L.orc_clear_tsdf_inside_shapes.restype = i64; L.orc_clear_tsdf_inside_shapes.argtypes = [vp, vp, i32]
         L.orc_clear_outside_radius.restype = i64; L.orc_clear_outside_radius.argtypes = [vp, vp, C.c_float]
         L.orc_mark_esdf_dirty.restype = i64; L.orc_mark_esdf_dirty.argtypes = [vp, vp, i64]
@@ -245,6 +256,9 @@ class OracleMap:
         out = np.zeros((1 << 18, 3), np.int32)
         n = lib().orc_esdf_dirty_list(self._h, _p(out), out.shape[0])
         return out[:n].copy()
+
+    def decay_occupancy(self):
+        return lib().orc_decay_occupancy(self._h)
 
     def decay_tsdf(self, exclude_last_view=True):
         return lib().orc_decay_tsdf(self._h, int(exclude_last_view))

@@ -85,6 +85,10 @@ typedef struct {
   int32_t do_depth_preprocessing;       /* do_depth_preprocessing */
   int32_t depth_preprocessing_num_dilations;
   float invalid_depth_decay_factor;     /* projective_tsdf_integrator_invalid_depth_decay_factor; < 0 = off */
+  int32_t projective_layer_type;        /* 0 = TSDF, 1 = occupancy */
+  float free_region_occupancy_probability, occupied_region_occupancy_probability, unobserved_region_occupancy_probability;
+  float occupied_region_half_width_m;
+  float free_region_decay_probability, occupied_region_decay_probability;
 } OrcParams;
 
 enum { W_CONSTANT = 0, W_CONSTANT_DROPOFF = 1, W_INVERSE_SQUARE = 2, W_INVERSE_SQUARE_DROPOFF = 3,
@@ -385,6 +389,8 @@ static void view_calc(OrcMap* m, const float* depth, int rows, int cols, const R
   }
 }
 
+static float log_odds(float p) { return logf(p / (1.0f - p)); }
+
 /* ------------------------------------------------------------------ TSDF */
 /* [U] ProjectiveTsdfIntegrator::integrateFrame -> integrateBlocksKernel + UpdateTsdfVoxelFunctor restated. */
 static void tsdf_integrate_block(const OrcParams* p, Block* b, const float* depth, int rows, int cols, const Rt* T_C_L, const Cam* k) {
@@ -400,6 +406,21 @@ static void tsdf_integrate_block(const OrcParams* p, Block* b, const float* dept
     float ds;
     TsdfVoxel* vx = &b->tsdf[z + 8 * y + 64 * x];
     const int got = interp_depth(depth, rows, cols, u, v, p->depth_interp_nearest, &ds);
+    if (p->projective_layer_type == 1) {
+      /* [U] ProjectiveOccupancyIntegrator restated: log-odds update by region along the ray (free in front of the measured
+       * surface, occupied within +-occupied_region_half_width_m of it, "unobserved" behind), clamped to +-10.  The log-odds
+       * live in TsdfVoxel.distance of the projective layer; weight stays 0. */
+      if (got > 0) {
+        float upd = log_odds(p->unobserved_region_occupancy_probability);
+        if (vd < ds - p->occupied_region_half_width_m) upd = log_odds(p->free_region_occupancy_probability);
+        else if (vd <= ds + p->occupied_region_half_width_m) upd = log_odds(p->occupied_region_occupancy_probability);
+        float v = vx->distance + upd;
+        if (v > 10.0f) v = 10.0f;
+        if (v < -10.0f) v = -10.0f;
+        vx->distance = v; vx->weight = 0.0f;
+      }
+      continue;
+    }
     if (got < 0 && p->invalid_depth_decay_factor >= 0.0f) {
       /* [U] invalid depth where the voxel projects: the surface estimate there loses confidence */
       vx->weight = vx->weight * p->invalid_depth_decay_factor;
@@ -843,7 +864,10 @@ int64_t orc_update_esdf(OrcMap* m) {
         Block* b = map_find(m, ti);
         if (!b || !(b->flags & L_TSDF)) continue;
         const TsdfVoxel* tv = &b->tsdf[mod8(kz) + 8 * y + 64 * x];
-        if (tv->weight >= p->esdf_min_weight) {
+        if (p->projective_layer_type == 1) {     /* [U] OccupancySiteFunctor: known iff log-odds != 0; site = inside = occupied */
+          if (tv->distance != 0.0f) observed = 1;
+          if (tv->distance > 0.0f) { inside = 1; site = 1; }
+        } else if (tv->weight >= p->esdf_min_weight) {
           observed = 1;
           const int in = tv->distance <= 0.0f;
           if (in) inside = 1;
@@ -1117,6 +1141,45 @@ int64_t orc_decay_tsdf(OrcMap* m, int exclude_last_view) {
     if (drop && !(b->flags & L_ESDF)) { block_free(b); removed++; }
     else {
       if (drop) { free(b->tsdf); b->tsdf = NULL; free(b->color); b->color = NULL; b->flags &= ~(uint32_t)(L_TSDF | L_COLOR | L_MESH); removed++; }
+      m->order[keep++] = b;
+    }
+  }
+  m->count = keep;
+  if (removed) map_rebuild(m);
+  return removed;
+}
+/* [U] Mapper::decayOccupancyAllVoxels restated (nvblox_node.cpp:925-929): log-odds move towards 0 by the log-odds of the
+ * region's decay probability and stop there; all-unknown blocks are deallocated (ESDF column re-marked like decayTsdf). */
+int64_t orc_decay_occupancy(OrcMap* m) {
+  const OrcParams* p = &m->p;
+  const float lo_free = log_odds(p->free_region_decay_probability), lo_occ = log_odds(p->occupied_region_decay_probability);
+  int64_t removed = 0, keep = 0;
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    int drop = 0;
+    if (b->flags & L_TSDF) {
+      int alive = 0;
+      for (int i = 0; i < NVOX; i++) {
+        float v = b->tsdf[i].distance;
+        if (v > 0.0f) { v = v + lo_occ; if (v < 0.0f) v = 0.0f; }
+        else if (v < 0.0f) { v = v + lo_free; if (v > 0.0f) v = 0.0f; }
+        b->tsdf[i].distance = v; b->tsdf[i].weight = 0.0f;
+        if (v != 0.0f) alive = 1;
+      }
+      if (alive) b->dirty_esdf = 1;
+      else {
+        drop = 1;
+        const EsdfCfg ec = esdf_cfg(p);
+        if (b->idx.z >= floor_div8(ec.kz_min) && b->idx.z <= floor_div8(ec.kz_max)) {
+          Idx3 ei = {b->idx.x, b->idx.y, floor_div8(ec.kz_out)};
+          Block* eb = map_find(m, ei);
+          if (eb && (eb->flags & L_ESDF)) eb->remark_esdf = 1;
+        }
+      }
+    }
+    if (drop && !(b->flags & L_ESDF)) { block_free(b); removed++; }
+    else {
+      if (drop) { free(b->tsdf); b->tsdf = NULL; free(b->color); b->color = NULL; b->flags &= ~(uint32_t)(L_TSDF | L_COLOR | L_MESH); b->dirty_esdf = 0; removed++; }
       m->order[keep++] = b;
     }
   }

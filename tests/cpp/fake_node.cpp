@@ -253,6 +253,26 @@ int main(int argc, char** argv) {
     esdf_slicer_.sliceLayersToCombinedDistanceImage(node.static_mapper_->esdf_layer(), node.static_mapper_->esdf_layer(), 0.09f, 0.09f, 1000.0f, &aabb2, &combined);
     if (combined.rows() != height || combined.cols() != width) { std::fprintf(stderr, "combined slice size differs\n"); return 1; }
   }
+  // mapping_type "static_occupancy" (nvblox_base.yaml:9): an occupancy MultiMapper fed the same way; decayOccupancyAllVoxels
+  {
+    MultiMapper occ(0.05f, MappingType::kStaticOccupancy, EsdfMode::k2D, MemoryType::kDevice, std::make_shared<CudaStreamOwning>(), 1 << 12);
+    DepthImage flat(120, 160, MemoryType::kDevice);
+    std::vector<float> host_depth(120 * 160, 1.5f);
+    flat.copyFromAsync(120, 160, host_depth.data(), CudaStreamOwning());
+    const Camera depth_camera(80.f, 80.f, 79.5f, 59.5f, 160, 120);
+    occ.integrateDepth(flat, Transform::Identity(), depth_camera);
+    occ.updateEsdf();
+    std::shared_ptr<Mapper> dynamic_mapper_ = occ.background_mapper();
+    const int occ_blocks = dynamic_mapper_->occupancy_layer().numAllocatedBlocks();
+    size_t occupied_voxels = 0;
+    callFunctionOnAllVoxels<OccupancyVoxel>(dynamic_mapper_->occupancy_layer(), [&](const Index3D&, const Index3D&, const OccupancyVoxel* v) { if (v->log_odds > 1e-3f) occupied_voxels++; });
+    dynamic_mapper_->decayOccupancyAllVoxels();
+    dynamic_mapper_->serializeSelectedLayers(LayerType::kOccupancy);
+    if (occ_blocks < 10 || occupied_voxels < 100 || dynamic_mapper_->tsdf_layer().numAllocatedBlocks() != 0 ||
+        dynamic_mapper_->serializedOccupancyLayer()->block_indices.size() != (size_t)dynamic_mapper_->occupancy_layer().numAllocatedBlocks() ||
+        !(dynamic_mapper_->occupancy_integrator().max_integration_distance_m() > 0.f)) {
+      std::fprintf(stderr, "occupancy mapper: %d blocks, %zu occupied voxels\n", occ_blocks, occupied_voxels); return 1; }
+  }
   // save_map / load_map services (nvblox_node.cpp:1668, 1703): bool results, a missing file is a recoverable error
   const std::string filename = std::string(argv[1]) + ".map";
   const bool save_ok = node.static_mapper_->saveLayerCake(filename);

@@ -287,3 +287,72 @@ def test_decay_and_clear_parity(oracle_mod, hip_lib):
     c = (float(T[0, 3]), float(T[1, 3]), 1.0)
     g.clear_outside_radius(c, 2.0); o.clear_outside_radius(c, 2.0)
     compare_layer(M, g, o, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
+
+
+def compare_occupancy(M, g, o, oracle_mod):
+    ig = g.block_indices(M.LAYER_OCCUPANCY); io = o.block_indices(oracle_mod.L_TSDF)
+    assert np.array_equal(ig, io), (len(ig), len(io))
+    bg, found = g.get_blocks(M.LAYER_OCCUPANCY, ig)
+    assert found.all()
+    for k, idx in enumerate(io):
+        assert np.array_equal(bg[k]["log_odds"], o.get_block(oracle_mod.L_TSDF, idx)["distance"]), idx     # adds and compares only: bit-exact
+    return len(io), bg
+
+
+def test_occupancy_mapper_parity(oracle_mod, hip_lib):
+    """Mapper(voxel_size, memory_type, ProjectiveLayerType::kOccupancy): mapping_type static_occupancy (nvblox_base.yaml:9) and the
+    dynamic mapper of the segmentation configuration (specializations/nvblox_segmentation.yaml:9-22): log-odds integration,
+    ESDF from occupancy, decayOccupancyAllVoxels with deallocation, clearing; colour and mesh are no-ops."""
+    occ = dict(projective_layer_type=1, free_region_occupancy_probability=0.3, occupied_region_occupancy_probability=0.9,
+               unobserved_region_occupancy_probability=0.35, occupied_region_half_width_m=0.2,
+               free_region_decay_probability=0.55, occupied_region_decay_probability=0.30, max_integration_distance_m=5.0)
+    M, g, o = make_pair(oracle_mod, **occ)
+    fr = H.frames(5, H.SMALL_CAM, color=True, stride=9)
+    for d, rgb, T in fr:
+        g.integrate_depth(d, T, H.SMALL_CAM); o.integrate_depth(d, T, H.SMALL_CAM)
+        g.integrate_color(rgb, T, H.SMALL_CAM)                                   # no-op on an occupancy mapper
+        assert H.idx_set(g.last_view()) == H.idx_set(o.last_view())
+    n, bg = compare_occupancy(M, g, o, oracle_mod)
+    lo = bg["log_odds"]
+    assert n > 100 and (lo > 0).sum() > 1000 and (lo < 0).sum() > 10000 and np.abs(lo).max() <= 10.0
+    assert g.num_blocks(M.LAYER_TSDF) == 0 and g.num_blocks(M.LAYER_COLOR) == 0
+    g.update_color_mesh(); assert len(g.mesh()) == 0
+    g.update_esdf(); o.update_esdf()
+    sg, ag = g.esdf_slice_image(); so, ao = o.esdf_slice_image()
+    assert sg.shape == so.shape and np.array_equal(sg, so) and (sg <= 0).sum() > 50 and (np.abs(sg - 1000.0) > 1).mean() > 0.2
+    n_before = n
+    for k in range(14):
+        g.decay_occupancy(); o.decay_occupancy()
+        if k % 4 == 3:
+            n, _ = compare_occupancy(M, g, o, oracle_mod)
+            g.update_esdf(); o.update_esdf()
+            sg, _ = g.esdf_slice_image(); so, _ = o.esdf_slice_image()
+            assert sg.shape == so.shape and np.array_equal(sg, so)
+    assert n < n_before                                                          # fully decayed blocks were deallocated
+    d, rgb, T = fr[2]
+    g.integrate_depth(d, T, H.SMALL_CAM); o.integrate_depth(d, T, H.SMALL_CAM)
+    c = (float(T[0, 3]), float(T[1, 3]), 1.0)
+    g.clear_outside_radius(c, 2.5); o.clear_outside_radius(c, 2.5)
+    compare_occupancy(M, g, o, oracle_mod)
+    g.update_esdf(); o.update_esdf()
+    sg, _ = g.esdf_slice_image(); so, _ = o.esdf_slice_image()
+    assert sg.shape == so.shape and np.array_equal(sg, so)
+    with pytest.raises(RuntimeError):
+        g.decay_tsdf(True)                                                       # wrong decay for this layer type
+    assert g.counters()["capacity_overflow"] == 0
+
+
+def test_occupancy_map_file_round_trip(hip_lib, tmp_path):
+    from isaac_ros_nvblox_amd import mapper as M
+    a = M.Mapper(M.default_params(projective_layer_type=1), block_capacity=1 << 12)
+    for d, _, T in H.frames(2, H.SMALL_CAM, color=False, stride=9):
+        a.integrate_depth(d, T, H.SMALL_CAM)
+    a.update_esdf()
+    p = tmp_path / "occ.nvbxmap"; a.save_map(p)
+    b = M.Mapper(M.default_params(projective_layer_type=1), block_capacity=1 << 12); b.load_map(p)
+    ia = a.block_indices(M.LAYER_OCCUPANCY)
+    assert len(ia) > 50 and np.array_equal(ia, b.block_indices(M.LAYER_OCCUPANCY))
+    assert a.get_blocks(M.LAYER_OCCUPANCY, ia)[0].tobytes() == b.get_blocks(M.LAYER_OCCUPANCY, ia)[0].tobytes()
+    t = M.Mapper(M.default_params(), block_capacity=1 << 12)
+    with pytest.raises(RuntimeError):
+        t.load_map(p)                                                            # a TSDF mapper cannot hold an occupancy layer
