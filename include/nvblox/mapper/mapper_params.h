@@ -164,6 +164,7 @@ struct MapperParams {
 struct MultiMapperParams {   // multi_mapper.* parameters (mapper_initialization.cpp: getMultiMapperParamsFromROS)
   int connected_mask_component_size_threshold = 2000;
   int remove_small_connected_components = 1;
+  float mask_occlusion_threshold_m = 0.25f;     // [U] ImageMasker occlusion test (nvbx_split_depth_by_mask)
 };
 
 }  // namespace nvblox

@@ -1,7 +1,7 @@
 // nvblox/mapper/multi_mapper.h -- nvblox::MultiMapper as constructed and driven by NvbloxNode / FuserNode
 // (nvblox_node.cpp:187-210,781,1058-1062,1261-1264; fuser_node.cpp:85-94).  libnvblox_hip implements the static-TSDF
-// mapping type (BASELINE.json north_star) and static occupancy (nvblox_base.yaml:9); the masked / dynamic / LiDAR-pointcloud overloads exist so the node
-// compiles, and abort with a clear message if reached (the reference aborts on programmer errors).
+// mapping type (BASELINE.json north_star), static occupancy (nvblox_base.yaml:9) and the two human mapping types (mask-split
+// depth / colour, occupancy foreground mapper); MappingType::kDynamic and LiDAR motion compensation abort with a clear message (the reference aborts on programmer errors).
 #pragma once
 #include <cstdio>
 #include <cstdlib>
@@ -16,14 +16,15 @@ class MultiMapper {
   MultiMapper(float voxel_size_m, MappingType mapping_type, EsdfMode esdf_mode, MemoryType memory_type = MemoryType::kDevice,
               std::shared_ptr<CudaStream> cuda_stream = std::make_shared<CudaStreamOwning>(), int64_t block_capacity = Mapper::kDefaultBlockCapacity)
       : mapping_type_(mapping_type), esdf_mode_(esdf_mode), cuda_stream_(cuda_stream) {
-    if (mapping_type != MappingType::kStaticTsdf && mapping_type != MappingType::kStaticOccupancy)
-      unsupported("mapping types other than MappingType::kStaticTsdf / kStaticOccupancy");
+    if (mapping_type == MappingType::kDynamic) unsupported("MappingType::kDynamic (freespace layer + dynamic detection)");
     if (esdf_mode != EsdfMode::k2D) unsupported("EsdfMode::k3D");
-    background_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type,
-                                                  mapping_type == MappingType::kStaticOccupancy ? ProjectiveLayerType::kOccupancy : ProjectiveLayerType::kTsdf,
+    const bool occupancy_background = mapping_type == MappingType::kStaticOccupancy || mapping_type == MappingType::kHumanWithStaticOccupancy;
+    human_ = mapping_type == MappingType::kHumanWithStaticTsdf || mapping_type == MappingType::kHumanWithStaticOccupancy;
+    background_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type, occupancy_background ? ProjectiveLayerType::kOccupancy : ProjectiveLayerType::kTsdf,
                                                   cuda_stream, block_capacity);
-    // the foreground (dynamic / human) mapper is never fed in static mode; keep a minimal one so the handle is valid
-    foreground_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type, ProjectiveLayerType::kNone, cuda_stream, 64);
+    // the foreground (human) mapper is an occupancy mapper (specializations/nvblox_segmentation.yaml:9-22); it is fed by the
+    // masked overloads only.  In the static modes it stays empty but valid.
+    foreground_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type, ProjectiveLayerType::kOccupancy, cuda_stream, human_ ? block_capacity / 4 : 64);
   }
   void setMapperParams(const MapperParams& background, const MapperParams& foreground) { background_mapper_->setMapperParams(background); foreground_mapper_->setMapperParams(foreground); }
   void setMapperParams(const MapperParams& params) { background_mapper_->setMapperParams(params); }   // fuser_node.cpp:94
@@ -35,7 +36,24 @@ class MultiMapper {
     (void)update_time_ms;   // consumed by the freespace layer only (dynamic mapping)
     background_mapper_->integrateDepth(depth, T_L_C, camera);
   }
-  void integrateDepth(const DepthImage&, const MonoImage&, const Transform&, const Transform&, const Camera&, const Camera&) { unsupported("masked depth integration (human mapping)"); }
+  // nvblox_node.cpp:1057-1060: the depth image is split by the mask (ImageMasker::splitImageOnGPU; mask camera related to the
+  // depth camera by T_CM_CD); unmasked depth -> background mapper, masked depth -> foreground (human) occupancy mapper
+  void integrateDepth(const DepthImage& depth, const MonoImage& mask, const Transform& T_L_CD, const Transform& T_CM_CD, const Camera& depth_camera,
+                      const Camera& mask_camera, std::optional<Time> update_time_ms = std::nullopt) {
+    (void)update_time_ms;
+    if (!human_) unsupported("masked depth integration outside the human mapping types");
+    depth_background_.resize(depth.rows(), depth.cols()); depth_foreground_.resize(depth.rows(), depth.cols());
+    depth_overlay_.resize(depth.rows(), depth.cols());
+    float T[16]; T_CM_CD.toRowMajor(T);
+    checkNvbx(nvbx_split_depth_by_mask(background_mapper_->c_handle(), depth.dataConstPtr(), depth.rows(), depth.cols(), mask.dataConstPtr(), mask.rows(), mask.cols(),
+                                       T, &depth_camera.c_abi(), &mask_camera.c_abi(), multi_params_.mask_occlusion_threshold_m, depth_background_.dataPtr(),
+                                       depth_foreground_.dataPtr(), reinterpret_cast<uint8_t*>(depth_overlay_.dataPtr())), "nvbx_split_depth_by_mask");
+    background_mapper_->integrateDepth(depth_background_, T_L_CD, depth_camera);
+    foreground_mapper_->integrateDepth(depth_foreground_, T_L_CD, depth_camera);
+  }
+  const DepthImage& getLastDepthFrameForeground() const { return depth_foreground_; }      // nvblox_node.cpp:1126
+  const DepthImage& getLastDepthFrameBackground() const { return depth_background_; }
+  const ColorImage& getLastDepthFrameMaskOverlay() const { return depth_overlay_; }        // nvblox_node.cpp:1147
   // nvblox_node.cpp:1382-1384.  Per-point motion compensation (use_lidar_motion_compensation, node_params.hpp:152) needs
   // per-point timestamps that this Pointcloud does not carry: run the node with use_lidar_motion_compensation:=false.
   void integrateDepth(const Pointcloud& pointcloud, const Transform& T_L_C, const Lidar& lidar, bool use_lidar_motion_compensation = false,
@@ -47,8 +65,15 @@ class MultiMapper {
   }
   const DepthImage& getLastDepthFrameFromPointcloud() const { return background_mapper_->getLastDepthFrameFromPointcloud(); }
   void integrateColor(const ColorImage& color, const Transform& T_L_C, const Camera& camera) { background_mapper_->integrateColor(color, T_L_C, camera); }
-  void integrateColor(const ColorImage&, const MonoImage&, const Transform&, const Camera&) { unsupported("masked colour integration (human mapping)"); }
-  void updateEsdf() { background_mapper_->updateEsdf(); }
+  // nvblox_node.cpp:1261-1262: the masked pixels are removed from the colour image before the background mapper integrates it
+  void integrateColor(const ColorImage& color, const MonoImage& mask, const Transform& T_L_C, const Camera& camera) {
+    if (!human_) unsupported("masked colour integration outside the human mapping types");
+    color_background_.resize(color.rows(), color.cols());
+    checkNvbx(nvbx_split_color_by_mask(background_mapper_->c_handle(), reinterpret_cast<const uint8_t*>(color.dataConstPtr()), color.rows(), color.cols(),
+                                       mask.dataConstPtr(), reinterpret_cast<uint8_t*>(color_background_.dataPtr()), nullptr), "nvbx_split_color_by_mask");
+    background_mapper_->integrateColor(color_background_, T_L_C, camera);
+  }
+  void updateEsdf() { background_mapper_->updateEsdf(); if (human_) foreground_mapper_->updateEsdf(); }
   void updateColorMesh(UpdateFullLayer f = UpdateFullLayer::kNo) { background_mapper_->updateColorMesh(f); }
 
   MappingType mapping_type() const { return mapping_type_; }
@@ -59,6 +84,9 @@ class MultiMapper {
     std::fprintf(stderr, "[nvblox_hip] %s is outside the MI355X hot path of this library (static TSDF + colour + 2-D ESDF + mesh)\n", what);
     std::abort();
   }
+  bool human_ = false;
+  DepthImage depth_background_{MemoryType::kDevice}, depth_foreground_{MemoryType::kDevice};
+  ColorImage depth_overlay_{MemoryType::kDevice}, color_background_{MemoryType::kDevice};
   MappingType mapping_type_; EsdfMode esdf_mode_;
   std::shared_ptr<CudaStream> cuda_stream_;
   std::shared_ptr<Mapper> background_mapper_, foreground_mapper_;

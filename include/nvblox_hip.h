@@ -255,6 +255,23 @@ int nvbx_backproject_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows,
  * out == in; asynchronous on the mapper's stream) */
 int nvbx_transform_pointcloud(nvbx_mapper* m, const float T_L_C[16], const float* points_in_dev, int64_t n_points, float* points_out_dev);
 
+/* ---- mask splitting (human / people-segmentation mapping) ------------------------------------------------------------
+ * [U] ImageMasker::splitImageOnGPU as used by MultiMapper::integrateDepth(depth, mask, T_L_CD, T_CM_CD, depth_cam, mask_cam) --
+ * nvblox_node.cpp:1018-1060: every valid depth pixel is lifted to 3-D, moved into the mask camera (T_CM_CD = T_L_CM^-1 T_L_CD)
+ * and projected; it is MASKED if it lands on a non-zero mask pixel and is not occluded there (its depth in the mask camera is
+ * within occlusion_threshold_m of the nearest depth pixel that landed on the same mask pixel).  depth_unmasked gets the pixel
+ * if it is not masked, depth_masked if it is; the other image gets NVBX_MASKED_DEPTH_INVALID (-1, an invalid depth for the
+ * integrators).  overlay_rgb (may be NULL): grey depth with masked pixels tinted red (debug image).  Asynchronous. */
+#define NVBX_MASKED_DEPTH_INVALID (-1.0f)
+int nvbx_split_depth_by_mask(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const uint8_t* mask_dev,
+                             int32_t mask_rows, int32_t mask_cols, const float T_CM_CD[16], const nvbx_camera* depth_camera,
+                             const nvbx_camera* mask_camera, float occlusion_threshold_m, float* depth_unmasked_dev,
+                             float* depth_masked_dev, uint8_t* overlay_rgb_dev);
+/* MultiMapper::integrateColor(color, mask, T_L_C, camera) -- nvblox_node.cpp:1261-1262 (mask and colour share the camera):
+ * [U] masked pixels are black in rgb_unmasked and the only non-black ones in rgb_masked (either output may be NULL). */
+int nvbx_split_color_by_mask(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, int32_t cols, const uint8_t* mask_dev,
+                             uint8_t* rgb_unmasked_dev, uint8_t* rgb_masked_dev);
+
 /* ---- device-side view for the caller's own kernels (GPULayerView / gpu_indexing.cuh: esdf_slice_conversions.cu:18,
  * esdf_and_gradients_conversions.cu:19-23).  Accessors: include/nvblox_hip_device.h. */
 typedef struct {

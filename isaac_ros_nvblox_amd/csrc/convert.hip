@@ -146,6 +146,90 @@ extern "C" int nvbx_esdf_slice_combined_to_image(nvbx_mapper* m1, nvbx_mapper* m
   return NVBX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ mask splitting
+struct MaskGeom { Rt T; float dfu, dfv, dcu, dcv, mfu, mfv, mcu, mcv; int32_t rows, cols, mrows, mcols; };
+// depth pixel i -> index of the mask pixel it lands on (or -1) and its depth in the mask camera
+__device__ inline int32_t mask_pixel(const MaskGeom& g, int32_t r, int32_t c, float d, float* z_cm) {
+  const float rx = (((float)c + 0.5f) - g.dcu) / g.dfu, ry = (((float)r + 0.5f) - g.dcv) / g.dfv;
+  float p[3]; apply_rt(g.T.R, g.T.t, d * rx, d * ry, d, p);
+  *z_cm = p[2];
+  if (p[2] <= 0.0f) return -1;
+  const float u = g.mfu * (p[0] / p[2]) + g.mcu, v = g.mfv * (p[1] / p[2]) + g.mcv;
+  const int32_t mc = (int32_t)floorf(u), mr = (int32_t)floorf(v);
+  if (mc < 0 || mr < 0 || mc >= g.mcols || mr >= g.mrows) return -1;
+  return mr * g.mcols + mc;
+}
+__global__ __launch_bounds__(256) void k_mask_zmin(MaskGeom g, const float* depth, uint32_t* zmin) {
+  const int64_t n = (int64_t)g.rows * g.cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = depth[i];
+    if (!(d > 0.0f)) continue;
+    float z; const int32_t mi = mask_pixel(g, (int32_t)(i / g.cols), (int32_t)(i % g.cols), d, &z);
+    if (mi >= 0) atomicMin(&zmin[mi], __float_as_uint(z));       // positive floats order like their bit patterns
+  }
+}
+__global__ __launch_bounds__(256) void k_split_depth(MaskGeom g, const float* depth, const uint8_t* mask, const uint32_t* zmin, float thr,
+                                                     float* unmasked, float* masked, uint8_t* overlay) {
+  const int64_t n = (int64_t)g.rows * g.cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = depth[i];
+    bool is_masked = false;
+    if (d > 0.0f) {
+      float z; const int32_t mi = mask_pixel(g, (int32_t)(i / g.cols), (int32_t)(i % g.cols), d, &z);
+      if (mi >= 0 && mask[mi] != 0 && z <= __uint_as_float(zmin[mi]) + thr) is_masked = true;
+    }
+    unmasked[i] = (d > 0.0f && is_masked) ? NVBX_MASKED_DEPTH_INVALID : d;
+    masked[i] = (d > 0.0f && is_masked) ? d : NVBX_MASKED_DEPTH_INVALID;
+    if (overlay) {
+      float gv = d > 0.0f ? d * (255.0f / 5.0f) : 0.0f; if (gv > 255.0f) gv = 255.0f;
+      const uint8_t q = (uint8_t)gv;
+      overlay[3 * i] = is_masked ? 255 : q; overlay[3 * i + 1] = q; overlay[3 * i + 2] = q;
+    }
+  }
+}
+extern "C" int nvbx_split_depth_by_mask(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const uint8_t* mask_dev,
+                                        int32_t mask_rows, int32_t mask_cols, const float T_CM_CD[16], const nvbx_camera* dc,
+                                        const nvbx_camera* mc, float occlusion_threshold_m, float* unmasked_dev, float* masked_dev, uint8_t* overlay_dev) {
+  if (!m || !depth_dev || !mask_dev || !T_CM_CD || !dc || !mc || !unmasked_dev || !masked_dev || rows <= 0 || cols <= 0 || mask_rows <= 0 || mask_cols <= 0) {
+    set_error("nvbx_split_depth_by_mask: invalid argument"); return NVBX_E_INVALID; }
+  NVBX_HIP(hipSetDevice(m->device));
+  const int64_t mn = (int64_t)mask_rows * mask_cols;
+  if (mn > m->mask_zmin_cap) {
+    NVBX_HIP(hipStreamSynchronize(m->stream));
+    if (m->mask_zmin) NVBX_HIP(hipFree(m->mask_zmin));
+    m->mask_zmin = nullptr; m->mask_zmin_cap = 0;
+    NVBX_HIP(hipMalloc(&m->mask_zmin, (size_t)mn * 4));
+    m->mask_zmin_cap = mn;
+  }
+  MaskGeom g;
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) g.T.R[3 * i + j] = T_CM_CD[4 * i + j]; g.T.t[i] = T_CM_CD[4 * i + 3]; }
+  g.dfu = dc->fu; g.dfv = dc->fv; g.dcu = dc->cu; g.dcv = dc->cv; g.mfu = mc->fu; g.mfv = mc->fv; g.mcu = mc->cu; g.mcv = mc->cv;
+  g.rows = rows; g.cols = cols; g.mrows = mask_rows; g.mcols = mask_cols;
+  NVBX_HIP(hipMemsetAsync(m->mask_zmin, 0x7F, (size_t)mn * 4, m->stream));        // 0x7F7F7F7F = 3.4e38
+  const unsigned grid = (unsigned)std::min<int64_t>(((int64_t)rows * cols + 255) / 256, 2048);
+  NVBX_LAUNCH(m, k_mask_zmin, dim3(grid), dim3(256), g, depth_dev, m->mask_zmin);
+  NVBX_LAUNCH(m, k_split_depth, dim3(grid), dim3(256), g, depth_dev, mask_dev, (const uint32_t*)m->mask_zmin, occlusion_threshold_m, unmasked_dev, masked_dev, overlay_dev);
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;
+}
+__global__ __launch_bounds__(256) void k_split_color(const uint8_t* rgb, const uint8_t* mask, int64_t n, uint8_t* unmasked, uint8_t* masked) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool mk = mask[i] != 0;
+    const uint8_t r = rgb[3 * i], gg = rgb[3 * i + 1], b = rgb[3 * i + 2];
+    if (unmasked) { unmasked[3 * i] = mk ? 0 : r; unmasked[3 * i + 1] = mk ? 0 : gg; unmasked[3 * i + 2] = mk ? 0 : b; }
+    if (masked) { masked[3 * i] = mk ? r : 0; masked[3 * i + 1] = mk ? gg : 0; masked[3 * i + 2] = mk ? b : 0; }
+  }
+}
+extern "C" int nvbx_split_color_by_mask(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, int32_t cols, const uint8_t* mask_dev,
+                                        uint8_t* rgb_unmasked_dev, uint8_t* rgb_masked_dev) {
+  if (!m || !rgb_dev || !mask_dev || rows <= 0 || cols <= 0 || (!rgb_unmasked_dev && !rgb_masked_dev)) { set_error("nvbx_split_color_by_mask: invalid argument"); return NVBX_E_INVALID; }
+  NVBX_HIP(hipSetDevice(m->device));
+  const int64_t n = (int64_t)rows * cols;
+  NVBX_LAUNCH(m, k_split_color, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), rgb_dev, mask_dev, n, rgb_unmasked_dev, rgb_masked_dev);
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ device view
 extern "C" int nvbx_get_device_view(nvbx_mapper* m, nvbx_device_view* out) {
   if (!m || !out) return NVBX_E_INVALID;

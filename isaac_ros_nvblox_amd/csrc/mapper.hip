@@ -300,7 +300,7 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   DMap& d = m->d;
   void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.slot_consumed, d.tsdf, d.color, d.esdf,
                   m->view_list, d.lists, d.shc, m->export_idx, m->export_count, d.site_bits, d.obs_bits, d.inside_bits,
-                  m->synth, m->depth_pre, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
+                  m->synth, m->depth_pre, m->mask_zmin, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (m->h_counters) (void)hipHostFree(m->h_counters);
   if (m->h_shc) (void)hipHostFree(m->h_shc);

@@ -54,6 +54,8 @@ struct nvbx_mapper {
   int32_t* export_count = nullptr;
   // LiDAR beam direction tables (float2 {sin, cos}: rows elevations then cols azimuths), rebuilt when the model changes
   void* lidar_tab = nullptr; size_t lidar_tab_cap = 0; nvbx_lidar lidar_cached{}; std::vector<float> lidar_host;
+  // mask splitting scratch: nearest depth (in the mask camera) that landed on each mask pixel
+  uint32_t* mask_zmin = nullptr; int64_t mask_zmin_cap = 0;
   // depth preprocessing scratch (dilated depth image)
   float* depth_pre = nullptr; int64_t depth_pre_cap = 0;
   // colour scratch

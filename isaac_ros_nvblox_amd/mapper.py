@@ -347,6 +347,28 @@ class Mapper:
             self.synchronize()
         return pts.cpu().numpy()
 
+    def split_depth_by_mask(self, depth, mask, T_CM_CD, depth_cam, mask_cam, occlusion_threshold_m=0.25, overlay=False):
+        """ImageMasker::splitImageOnGPU (MultiMapper::integrateDepth with a mask): device tensors (unmasked, masked[, overlay])."""
+        torch = self._torch
+        d = self._dev(depth, torch.float32); mk = self._dev(mask, torch.uint8)
+        un = torch.empty_like(d); ma = torch.empty_like(d)
+        ov = torch.empty(d.shape + (3,), dtype=torch.uint8, device=d.device) if overlay else None
+        self._check(self.lib.nvbx_split_depth_by_mask(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], C.c_void_p(mk.data_ptr()),
+                                                      mk.shape[0], mk.shape[1], _np_ptr(self._T(T_CM_CD)), C.byref(self._cam(depth_cam)),
+                                                      C.byref(self._cam(mask_cam)), float(occlusion_threshold_m), C.c_void_p(un.data_ptr()),
+                                                      C.c_void_p(ma.data_ptr()), C.c_void_p(ov.data_ptr()) if overlay else None))
+        self.synchronize()       # (the outputs are torch tensors: torch's stream is not the mapper's)
+        return (un, ma, ov) if overlay else (un, ma)
+
+    def split_color_by_mask(self, rgb, mask):
+        torch = self._torch
+        c = self._dev(rgb, torch.uint8); mk = self._dev(mask, torch.uint8)
+        un = torch.empty_like(c); ma = torch.empty_like(c)
+        self._check(self.lib.nvbx_split_color_by_mask(self._h, C.c_void_p(c.data_ptr()), c.shape[0], c.shape[1], C.c_void_p(mk.data_ptr()),
+                                                      C.c_void_p(un.data_ptr()), C.c_void_p(ma.data_ptr())))
+        self.synchronize()
+        return un, ma
+
     def device_view(self):
         """nvbx_device_view for the caller's own kernels (include/nvblox_hip_device.h)."""
         from ._lib import DeviceView

@@ -105,6 +105,7 @@ def lib():
         L.orc_integrate_depth.restype = i64; L.orc_integrate_depth.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
         L.orc_integrate_lidar_depth.restype = i64; L.orc_integrate_lidar_depth.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
         L.orc_depth_image_from_pointcloud.argtypes = [vp, i64, vp, vp]
+        L.orc_split_depth_by_mask.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_float, vp, vp]
         L.orc_lidar_project.restype = C.c_int; L.orc_lidar_project.argtypes = [vp, vp, f32p, f32p]
         L.orc_atan2f.restype = C.c_float; L.orc_atan2f.argtypes = [C.c_float, C.c_float]
         L.orc_integrate_color.restype = i64; L.orc_integrate_color.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
@@ -289,6 +290,16 @@ def depth_image_from_pointcloud(points, lidar):
     img = np.zeros((int(lidar[1]), int(lidar[0])), np.float32)
     lib().orc_depth_image_from_pointcloud(_p(pts), pts.shape[0], _p(l5), _p(img))
     return img
+
+
+def split_depth_by_mask(depth, mask, T_CM_CD, depth_cam, mask_cam, occlusion_threshold_m):
+    d = np.ascontiguousarray(depth, np.float32); mk = np.ascontiguousarray(mask, np.uint8)
+    T = np.ascontiguousarray(np.asarray(T_CM_CD, np.float32).reshape(4, 4))
+    dc = np.asarray(depth_cam, np.float32); mc = np.asarray(mask_cam, np.float32)
+    un = np.zeros_like(d); ma = np.zeros_like(d)
+    lib().orc_split_depth_by_mask(_p(d), d.shape[0], d.shape[1], _p(mk), mk.shape[0], mk.shape[1], _p(T), _p(dc), _p(mc),
+                                  float(occlusion_threshold_m), _p(un), _p(ma))
+    return un, ma
 
 
 def lidar_project(lidar, p):

@@ -1230,6 +1230,46 @@ int64_t orc_clear_tsdf_inside_shapes(OrcMap* m, const float* shapes, int32_t n) 
   return cleared;
 }
 
+/* ------------------------------------------------------------------ mask splitting (human mapping) */
+/* [U] ImageMasker::splitImageOnGPU restated (MultiMapper::integrateDepth with a mask, nvblox_node.cpp:1018-1060): a valid depth
+ * pixel is lifted, moved into the mask camera by T_CM_CD and projected; masked iff it lands on a non-zero mask pixel and its
+ * depth there is within `thr` of the nearest depth pixel landing on the same mask pixel.  Invalid value -1. */
+static int32_t mask_pixel(const Rt* T, const Cam* dc, const Cam* mc, int32_t mrows, int32_t mcols, int32_t r, int32_t c, float d, float* z_cm) {
+  const float rx = (((float)c + 0.5f) - dc->cu) / dc->fu, ry = (((float)r + 0.5f) - dc->cv) / dc->fv;
+  float p[3]; rt_apply(T, d * rx, d * ry, d, p);
+  *z_cm = p[2];
+  if (p[2] <= 0.0f) return -1;
+  const float u = mc->fu * (p[0] / p[2]) + mc->cu, v = mc->fv * (p[1] / p[2]) + mc->cv;
+  const int32_t cc = (int32_t)floorf(u), rr = (int32_t)floorf(v);
+  if (cc < 0 || rr < 0 || cc >= mcols || rr >= mrows) return -1;
+  return rr * mcols + cc;
+}
+void orc_split_depth_by_mask(const float* depth, int32_t rows, int32_t cols, const uint8_t* mask, int32_t mrows, int32_t mcols,
+                             const float* T_CM_CD, const float* dcam6, const float* mcam6, float thr, float* unmasked, float* masked) {
+  Rt T, Tinv; rt_from_T(T_CM_CD, &T, &Tinv);
+  const Cam dc = cam_from(dcam6), mc = cam_from(mcam6);
+  float* zmin = (float*)malloc(sizeof(float) * (size_t)mrows * mcols);
+  for (int64_t i = 0; i < (int64_t)mrows * mcols; i++) zmin[i] = 3.0e38f;
+  for (int32_t r = 0; r < rows; r++) for (int32_t c = 0; c < cols; c++) {
+    const float d = depth[(int64_t)r * cols + c];
+    if (!(d > 0.0f)) continue;
+    float z; const int32_t mi = mask_pixel(&T, &dc, &mc, mrows, mcols, r, c, d, &z);
+    if (mi >= 0 && z < zmin[mi]) zmin[mi] = z;
+  }
+  for (int32_t r = 0; r < rows; r++) for (int32_t c = 0; c < cols; c++) {
+    const int64_t i = (int64_t)r * cols + c;
+    const float d = depth[i];
+    int is_masked = 0;
+    if (d > 0.0f) {
+      float z; const int32_t mi = mask_pixel(&T, &dc, &mc, mrows, mcols, r, c, d, &z);
+      if (mi >= 0 && mask[mi] != 0 && z <= zmin[mi] + thr) is_masked = 1;
+    }
+    unmasked[i] = (d > 0.0f && is_masked) ? -1.0f : d;
+    masked[i] = (d > 0.0f && is_masked) ? d : -1.0f;
+  }
+  free(zmin);
+}
+
 /* multi-GPU union step: TSDF blocks another mapper updated become ESDF-dirty here if they exist locally */
 int64_t orc_mark_esdf_dirty(OrcMap* m, const int32_t* idx, int64_t n) {
   int64_t hit = 0;

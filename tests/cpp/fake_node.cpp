@@ -273,6 +273,30 @@ int main(int argc, char** argv) {
         !(dynamic_mapper_->occupancy_integrator().max_integration_distance_m() > 0.f)) {
       std::fprintf(stderr, "occupancy mapper: %d blocks, %zu occupied voxels\n", occ_blocks, occupied_voxels); return 1; }
   }
+  // mapping_type "human_with_static_tsdf" (specializations/nvblox_segmentation.yaml): the masked overloads of nvblox_node.cpp:1057-1060,1261-1262
+  {
+    auto multi_mapper_ = std::make_shared<MultiMapper>(0.05f, MappingType::kHumanWithStaticTsdf, EsdfMode::k2D, MemoryType::kDevice,
+                                                       std::make_shared<CudaStreamOwning>(), 1 << 12);
+    DepthImage depth_image_(120, 160, MemoryType::kDevice); MonoImage mask_image_(120, 160, MemoryType::kDevice); ColorImage color_image_(120, 160, MemoryType::kDevice);
+    std::vector<float> host_depth(120 * 160, 2.0f); std::vector<uint8_t> host_mask(120 * 160, 0); std::vector<Color> host_color(120 * 160, Color(200, 100, 50));
+    for (int r = 40; r < 100; r++) for (int c = 60; c < 100; c++) { host_mask[r * 160 + c] = 255; host_depth[r * 160 + c] = 1.2f; }      // a person 1.2 m away
+    depth_image_.copyFromAsync(120, 160, host_depth.data(), CudaStreamOwning());
+    mask_image_.copyFromAsync(120, 160, host_mask.data(), CudaStreamOwning());
+    color_image_.copyFromAsync(120, 160, host_color.data(), CudaStreamOwning());
+    const Camera depth_camera_(80.f, 80.f, 79.5f, 59.5f, 160, 120), mask_camera(80.f, 80.f, 79.5f, 59.5f, 160, 120);
+    const Transform T_L_C_depth_ = Transform::Identity(), T_CM_CD = Transform::Identity();
+    multi_mapper_->integrateDepth(depth_image_, mask_image_, T_L_C_depth_, T_CM_CD, depth_camera_, mask_camera);
+    multi_mapper_->integrateColor(color_image_, mask_image_, T_L_C_depth_, depth_camera_);
+    multi_mapper_->updateEsdf();
+    const DepthImage& depth_image_only_humans = multi_mapper_->getLastDepthFrameForeground();
+    DepthImageBackProjector image_back_projector_; Pointcloud human_pointcloud_C_device_(MemoryType::kDevice);
+    image_back_projector_.backProjectOnGPU(depth_image_only_humans, depth_camera_, &human_pointcloud_C_device_,
+                                           multi_mapper_->foreground_mapper()->occupancy_integrator().max_integration_distance_m());
+    const int human_blocks = multi_mapper_->foreground_mapper()->occupancy_layer().numAllocatedBlocks();
+    const int static_blocks = multi_mapper_->background_mapper()->tsdf_layer().numAllocatedBlocks();
+    if (human_pointcloud_C_device_.size() != 60 * 40 || human_blocks < 5 || static_blocks < 50 || multi_mapper_->getLastDepthFrameMaskOverlay().rows() != 120) {
+      std::fprintf(stderr, "human mapping: %d human points, %d human blocks, %d static blocks\n", human_pointcloud_C_device_.size(), human_blocks, static_blocks); return 1; }
+  }
   // save_map / load_map services (nvblox_node.cpp:1668, 1703): bool results, a missing file is a recoverable error
   const std::string filename = std::string(argv[1]) + ".map";
   const bool save_ok = node.static_mapper_->saveLayerCake(filename);

@@ -356,3 +356,51 @@ def test_occupancy_map_file_round_trip(hip_lib, tmp_path):
     t = M.Mapper(M.default_params(), block_capacity=1 << 12)
     with pytest.raises(RuntimeError):
         t.load_map(p)                                                            # a TSDF mapper cannot hold an occupancy layer
+
+
+def test_mask_split_and_human_mapping_parity(oracle_mod, hip_lib):
+    """MultiMapper::integrateDepth(depth, mask, T_L_CD, T_CM_CD, depth_cam, mask_cam) (nvblox_node.cpp:1018-1060) as the
+    human-mapping configuration runs it (specializations/nvblox_segmentation.yaml): the depth image is split by the mask
+    (mask camera offset from the depth camera, occlusion test), the unmasked part goes into the static TSDF mapper, the
+    masked part into the occupancy mapper.  Split images bit-exact; both maps equal to the oracle fed the same way."""
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    mask_cam = (85.0, 85.0, 79.5, 59.5, 160, 120)
+    T_CM_CD = np.eye(4, dtype=np.float32); T_CM_CD[0, 3] = 0.06; T_CM_CD[1, 3] = -0.01      # a colour camera 6 cm beside the depth camera
+    occ = dict(projective_layer_type=1, free_region_occupancy_probability=0.3, occupied_region_occupancy_probability=0.9,
+               unobserved_region_occupancy_probability=0.35, occupied_region_half_width_m=0.2, max_integration_distance_m=5.0)
+    _, gs, os_ = make_pair(oracle_mod)
+    _, gd, od = make_pair(oracle_mod, **occ)
+    for k, (d, rgb, T) in enumerate(H.frames(4, cam, color=True, stride=7)):
+        d = d.copy(); d[:6, :] = 0.0
+        mask = np.zeros((120, 160), np.uint8)
+        mask[30:100, 50 + 5 * k:95 + 5 * k] = 1 + k                                # the "person": any non-zero value
+        un_g, ma_g, ov = gs.split_depth_by_mask(d, mask, T_CM_CD, cam, mask_cam, 0.25, overlay=True)
+        un_o, ma_o = oracle_mod.split_depth_by_mask(d, mask, T_CM_CD, cam, mask_cam, 0.25)
+        un_g, ma_g = un_g.cpu().numpy(), ma_g.cpu().numpy()
+        assert np.array_equal(un_g, un_o) and np.array_equal(ma_g, ma_o)
+        n_masked = int((ma_g > 0).sum())
+        assert 1000 < n_masked < 5000 and ((un_g > 0) & (ma_g > 0)).sum() == 0 and np.array_equal((un_g > 0) | (ma_g > 0), d > 0)
+        assert (ov.cpu().numpy()[..., 0] == 255).sum() >= n_masked
+        gs.integrate_depth(un_g, T, cam); os_.integrate_depth(un_o, T, cam)         # background: static TSDF
+        gd.integrate_depth(ma_g, T, cam); od.integrate_depth(ma_o, T, cam)         # foreground: occupancy
+        cu, cm = gs.split_color_by_mask(rgb, mask)
+        cu = cu.cpu().numpy(); cm = cm.cpu().numpy()
+        assert np.array_equal(cu, np.where(mask[..., None] != 0, 0, rgb)) and np.array_equal(cm, np.where(mask[..., None] != 0, rgb, 0))
+    compare_layer(M, gs, os_, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
+    n, _ = compare_occupancy(M, gd, od, oracle_mod)
+    assert n > 10
+    gs.update_esdf(); os_.update_esdf(); gd.update_esdf(); od.update_esdf()
+    for g, o in ((gs, os_), (gd, od)):
+        sg, _ = g.esdf_slice_image(); so, _ = o.esdf_slice_image()
+        assert sg.shape == so.shape and np.abs(sg - so).max() <= TOL
+    comb, _ = gs.esdf_slice_image_combined(gd)                                     # the combined costmap of nvblox_node.cpp:836-840
+    assert (comb < 999.0).sum() >= (gs.esdf_slice_image()[0] < 999.0).sum()
+    # occlusion test: a background pixel far behind the person that lands on the same mask pixel is NOT masked
+    d2 = np.full((120, 160), 4.0, np.float32); d2[:, 80:] = 1.0                    # near surface on the right half
+    m2 = np.ones((120, 160), np.uint8)
+    Tshift = np.eye(4, dtype=np.float32); Tshift[0, 3] = -0.5                      # strong parallax: far pixels slide onto near ones' mask pixels
+    un2, ma2 = gs.split_depth_by_mask(d2, m2, Tshift, cam, cam, 0.25)
+    un2o, ma2o = oracle_mod.split_depth_by_mask(d2, m2, Tshift, cam, cam, 0.25)
+    assert np.array_equal(un2.cpu().numpy(), un2o) and np.array_equal(ma2.cpu().numpy(), ma2o)
+    assert ((un2o > 0) & (d2 == 4.0)).sum() > 50                                   # occluded far pixels stay in the background image
