@@ -162,3 +162,46 @@ def test_mc_table_is_watertight_on_a_sphere():
     for (a, b), c in edge_count.items():
         assert c == 1 and edge_count.get((b, a), 0) == 1
     assert out_ok == len(edge_count) // 3      # all normals point to the positive (outside) side
+
+
+def test_occupancy_oracle_against_analytic_scene(oracle_mod):
+    """Occupancy restatement vs maths it cannot have been fitted to: after a few frames, voxels the oracle calls occupied
+    (log-odds > 0) lie within the occupied half width (+ a voxel diagonal) of the analytic surface along the viewing ray,
+    confidently free voxels lie in free space, and log-odds stay inside the clamp."""
+    p = oracle_mod.default_params(projective_layer_type=1, free_region_occupancy_probability=0.3,
+                                  occupied_region_occupancy_probability=0.9, unobserved_region_occupancy_probability=0.5,
+                                  occupied_region_half_width_m=0.1, max_integration_distance_m=6.0)
+    o = oracle_mod.OracleMap(p)
+    for d, rgb, T in H.frames(4, H.SMALL_CAM, color=False, stride=5):
+        o.integrate_depth(d, T, H.SMALL_CAM)
+    occ_d, free_d = [], []
+    gx, gy, gz = np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij")
+    for idx in o.block_indices(oracle_mod.L_TSDF):
+        lo = o.get_block(oracle_mod.L_TSDF, idx)["distance"].reshape(8, 8, 8)
+        pts = (np.stack([gx, gy, gz], -1) + idx * 8 + 0.5) * 0.05
+        sd = scene_sdf(pts)
+        assert np.abs(lo).max() <= 10.0
+        occ_d.append(np.abs(sd[lo > 1.0])); free_d.append(sd[lo < -2.0])
+    occ_d = np.concatenate(occ_d); free_d = np.concatenate(free_d)
+    assert occ_d.size > 2000 and free_d.size > 20000
+    # projective distance >= Euclidean distance: an occupied voxel is at most half width (0.1) + voxel diagonal from the surface
+    assert np.percentile(occ_d, 99) < 0.1 + 0.05 * np.sqrt(3.0) + 1e-3
+    assert (free_d > 0.0).mean() > 0.995
+    # ESDF from occupancy: sites exactly where the slice band holds an occupied voxel
+    o.update_esdf()
+    img, _ = o.esdf_slice_image(1000.0)
+    assert (img <= 0.0).sum() > 20 and (img[img < 999.0] <= 2.0 + 1e-4).all()
+
+
+def test_mask_split_oracle_identity_and_parallax(oracle_mod):
+    d = np.full((60, 80), 2.0, np.float32); d[:5] = 0.0
+    mask = np.zeros((60, 80), np.uint8); mask[20:40, 30:50] = 7
+    cam = (40.0, 40.0, 39.5, 29.5, 80, 60)
+    un, ma = oracle_mod.split_depth_by_mask(d, mask, np.eye(4, dtype=np.float32), cam, cam, 0.25)
+    assert np.array_equal(ma > 0, (mask != 0) & (d > 0)) and np.array_equal(un > 0, (mask == 0) & (d > 0))
+    assert np.array_equal(un[:5], d[:5]) and np.array_equal(ma[:5], np.full((5, 80), -1.0, np.float32))    # invalid depth stays invalid
+    # mask camera 0.1 m to the right: at 2 m depth and fu = 40 the mask appears shifted by exactly 2 px in the depth image
+    T = np.eye(4, dtype=np.float32); T[0, 3] = -0.1
+    un2, ma2 = oracle_mod.split_depth_by_mask(d, mask, T, cam, cam, 0.25)
+    want = np.zeros_like(mask); want[20:40, 32:52] = 1
+    assert np.array_equal(ma2 > 0, (want != 0) & (d > 0))
