@@ -2,8 +2,11 @@
 // nvblox_node.cpp / layer_publishing.cpp / fuser_node.cpp), implemented as inline wrappers over the C-ABI of
 // libnvblox_hip.so (include/nvblox_hip.h).  Single-caller, stream-ordered like the reference (nvblox_node.cpp:99,456-459).
 #pragma once
+#include <chrono>
 #include <cmath>
+#include <deque>
 #include <memory>
+#include <unordered_map>
 #include <optional>
 #include <string>
 #include <vector>
@@ -123,6 +126,7 @@ class Mapper {
   void updateColorMesh(UpdateFullLayer update_full_layer = UpdateFullLayer::kNo) {
     timing::Timer t("mesh/integrate");
     checkNvbx(nvbx_update_color_mesh(m_, update_full_layer == UpdateFullLayer::kYes ? 1 : 0), "nvbx_update_color_mesh");
+    mesh_updates_++;
   }
   void updateMesh(UpdateFullLayer f = UpdateFullLayer::kNo) { updateColorMesh(f); }
   void decayOccupancyAllVoxels() { checkNvbx(nvbx_decay_occupancy(m_), "nvbx_decay_occupancy"); }   // nvblox_node.cpp:928 (occupancy mappers)
@@ -184,10 +188,13 @@ class Mapper {
   // -- serialization of the mesh for publishing (layer_publishing.cpp:702-711,770-776; mesh_conversions.cpp:62-104)
   // Voxel layers: every allocated TSDF block inside the exclusion cylinder (radius / height around the centre; negative =
   // unlimited) is gathered on the GPU (k_gather_blocks) and copied out; the colour layer is serialized over the SAME block
-  // list, as the publisher requires (layer_publishing.cpp:316,452-459).  The reference's streamer additionally rations
-  // blocks per call by bandwidth_limit_mbps; this implementation sends the whole selection every call.
-  void serializeSelectedLayers(LayerTypeBitMask layers, float /*bandwidth_limit_mbps*/ = -1.f, const BlockExclusionParams& ex = BlockExclusionParams()) {
-    if (layers & LayerType::kColorMesh) serializeColorMesh();
+  // list, as the publisher requires (layer_publishing.cpp:316,452-459).
+  // Mesh streaming is rationed like the reference's layer streamer (layer_streamer_bandwidth_limit_mbps, nvblox_base.yaml:110):
+  // the blocks of every mesh update since the last call join a queue (a newer mesh of a queued block replaces it in place),
+  // and each call sends the oldest blocks that fit into bandwidth_limit_mbps x (time since the last call, at most 1 s); at
+  // least one block is sent so that the queue always drains.  bandwidth_limit_mbps < 0: no limit.  The voxel layers are sent whole.
+  void serializeSelectedLayers(LayerTypeBitMask layers, float bandwidth_limit_mbps = -1.f, const BlockExclusionParams& ex = BlockExclusionParams()) {
+    if (layers & LayerType::kColorMesh) serializeColorMesh(bandwidth_limit_mbps);
     if (layers & LayerType::kOccupancy) serialized_occupancy_ = gatherLayer<OccupancyVoxel>(NVBX_LAYER_OCCUPANCY, occupancy_layer_.getAllBlockIndices());
     if (layers & (LayerType::kTsdf | LayerType::kColor)) {
       std::vector<Index3D> sel;
@@ -204,6 +211,7 @@ class Mapper {
     }
   }
   std::shared_ptr<SerializedColorMeshLayer> serializedColorMeshLayer() const { return serialized_mesh_; }
+  size_t numMeshBlocksAwaitingStreaming() const { return pending_order_.size(); }     // queued by the bandwidth limit
   // layer_publishing.cpp:798-822 (dynamic mapper): all occupancy blocks, refreshed by serializeSelectedLayers(LayerType::kOccupancy, ...)
   std::shared_ptr<const SerializedLayer<OccupancyVoxel>> serializedOccupancyLayer() const { return serialized_occupancy_; }
   std::shared_ptr<const SerializedTsdfLayer> serializedTsdfLayer() const { return serialized_tsdf_; }
@@ -231,7 +239,47 @@ class Mapper {
       checkNvbx(nvbx_get_blocks(m_, layer, reinterpret_cast<const nvbx_index3d*>(sel.data()), (int64_t)sel.size(), out->voxels.data(), nullptr), "nvbx_get_blocks");
     return out;
   }
-  void serializeColorMesh() {
+  struct PendingBlockMesh { std::vector<Vector3f> v, n; std::vector<Color> c; std::vector<int32_t> t; };
+  void serializeColorMesh(float bandwidth_limit_mbps) {
+    if (mesh_updates_ != mesh_updates_fetched_) {          // a mesh update happened since the last call: queue its blocks
+      mesh_updates_fetched_ = mesh_updates_;
+      auto fresh = fetchLastMeshUpdate();
+      for (size_t b = 0; b < fresh->block_indices.size(); b++) {
+        const Index3D& idx = fresh->block_indices[b];
+        PendingBlockMesh pm;
+        const size_t v0 = (size_t)fresh->vertex_block_offsets[b], v1 = (size_t)fresh->vertex_block_offsets[b + 1];
+        const size_t t0 = (size_t)fresh->triangle_index_block_offsets[b], t1 = (size_t)fresh->triangle_index_block_offsets[b + 1];
+        pm.v.assign(fresh->vertices.begin() + v0, fresh->vertices.begin() + v1); pm.n.assign(fresh->vertex_normals.begin() + v0, fresh->vertex_normals.begin() + v1);
+        pm.c.assign(fresh->vertex_appearances.begin() + v0, fresh->vertex_appearances.begin() + v1);
+        pm.t.assign(fresh->triangle_indices.begin() + t0, fresh->triangle_indices.begin() + t1);
+        if (pending_mesh_.find(idx) == pending_mesh_.end()) pending_order_.push_back(idx);
+        pending_mesh_[idx] = std::move(pm);
+      }
+    }
+    const auto now = std::chrono::steady_clock::now();
+    double dt = last_mesh_stream_valid_ ? std::chrono::duration<double>(now - last_mesh_stream_).count() : 1.0;
+    if (dt > 1.0) dt = 1.0;
+    last_mesh_stream_ = now; last_mesh_stream_valid_ = true;
+    const double budget = bandwidth_limit_mbps < 0.f ? -1.0 : (double)bandwidth_limit_mbps * 1e6 / 8.0 * dt;
+    auto s = std::make_shared<SerializedColorMeshLayer>();
+    s->vertex_block_offsets.push_back(0); s->triangle_index_block_offsets.push_back(0);
+    double sent = 0.0;
+    while (!pending_order_.empty()) {
+      const Index3D idx = pending_order_.front();
+      const PendingBlockMesh& pm = pending_mesh_[idx];
+      const double bytes = 12.0 + (double)pm.v.size() * (12 + 12 + 3) + (double)pm.t.size() * 4;
+      if (budget >= 0.0 && sent > 0.0 && sent + bytes > budget) break;
+      sent += bytes;
+      s->block_indices.push_back(idx);
+      s->vertices.insert(s->vertices.end(), pm.v.begin(), pm.v.end()); s->vertex_normals.insert(s->vertex_normals.end(), pm.n.begin(), pm.n.end());
+      s->vertex_appearances.insert(s->vertex_appearances.end(), pm.c.begin(), pm.c.end());
+      s->triangle_indices.insert(s->triangle_indices.end(), pm.t.begin(), pm.t.end());
+      s->vertex_block_offsets.push_back((int32_t)s->vertices.size()); s->triangle_index_block_offsets.push_back((int32_t)s->triangle_indices.size());
+      pending_mesh_.erase(idx); pending_order_.pop_front();
+    }
+    serialized_mesh_ = s;
+  }
+  std::shared_ptr<SerializedColorMeshLayer> fetchLastMeshUpdate() {
     int64_t nb = 0, nv = 0, nt = 0;
     checkNvbx(nvbx_mesh_sizes(m_, &nb, &nv, &nt), "nvbx_mesh_sizes");
     auto s = std::make_shared<SerializedColorMeshLayer>();
@@ -244,7 +292,7 @@ class Mapper {
                              reinterpret_cast<float*>(s->vertex_normals.data()), rgba.data(), s->triangle_indices.data()), "nvbx_mesh_copy");
     for (size_t i = 0; i < (size_t)nv; i++) s->vertex_appearances[i] = Color(rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2]);
     for (auto& o : s->triangle_index_block_offsets) o *= 3;   // triangles -> indices
-    serialized_mesh_ = s;
+    return s;
   }
 
   float voxel_size_m_;
@@ -254,6 +302,9 @@ class Mapper {
   nvbx_mapper* m_ = nullptr;
   TsdfLayer tsdf_layer_; OccupancyLayer occupancy_layer_; ColorLayer color_layer_; EsdfLayer esdf_layer_;
   std::vector<Index3D> cleared_blocks_;
+  uint64_t mesh_updates_ = 0, mesh_updates_fetched_ = 0;
+  std::unordered_map<Index3D, PendingBlockMesh, Index3DHash> pending_mesh_; std::deque<Index3D> pending_order_;
+  std::chrono::steady_clock::time_point last_mesh_stream_{}; bool last_mesh_stream_valid_ = false;
   DepthImage last_depth_frame_from_pointcloud_{MemoryType::kDevice};
   std::shared_ptr<SerializedColorMeshLayer> serialized_mesh_ = std::make_shared<SerializedColorMeshLayer>();
   std::shared_ptr<SerializedTsdfLayer> serialized_tsdf_ = std::make_shared<SerializedTsdfLayer>();

@@ -297,6 +297,23 @@ int main(int argc, char** argv) {
     if (human_pointcloud_C_device_.size() != 60 * 40 || human_blocks < 5 || static_blocks < 50 || multi_mapper_->getLastDepthFrameMaskOverlay().rows() != 120) {
       std::fprintf(stderr, "human mapping: %d human points, %d human blocks, %d static blocks\n", human_pointcloud_C_device_.size(), human_blocks, static_blocks); return 1; }
   }
+  // mesh streaming under a bandwidth limit (layer_streamer_bandwidth_limit_mbps, layer_publishing.cpp:702-711): a full-layer
+  // mesh update is rationed over several calls, every block arrives exactly once
+  {
+    node.static_mapper_->updateColorMesh(UpdateFullLayer::kYes);
+    node.static_mapper_->serializeSelectedLayers(LayerType::kColorMesh);                // no limit: the whole update at once
+    const size_t full_blocks = node.static_mapper_->serializedColorMeshLayer()->block_indices.size();
+    node.static_mapper_->updateColorMesh(UpdateFullLayer::kYes);
+    size_t total_blocks = 0, calls = 0, first_call_blocks = 0;
+    do {
+      node.static_mapper_->serializeSelectedLayers(LayerType::kColorMesh, 0.8f);        // 0.8 Mbit/s x <= 1 s = <= 100 kB per call
+      const size_t nb = node.static_mapper_->serializedColorMeshLayer()->block_indices.size();
+      if (calls == 0) first_call_blocks = nb;
+      total_blocks += nb; calls++;
+    } while (node.static_mapper_->numMeshBlocksAwaitingStreaming() > 0 && calls < 100000);
+    if (total_blocks != full_blocks || calls < 2 || first_call_blocks == 0 || first_call_blocks >= full_blocks) {
+      std::fprintf(stderr, "rationed mesh streaming: %zu of %zu blocks in %zu calls (first call %zu)\n", total_blocks, full_blocks, calls, first_call_blocks); return 1; }
+  }
   // save_map / load_map services (nvblox_node.cpp:1668, 1703): bool results, a missing file is a recoverable error
   const std::string filename = std::string(argv[1]) + ".map";
   const bool save_ok = node.static_mapper_->saveLayerCake(filename);
