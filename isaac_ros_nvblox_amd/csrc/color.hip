@@ -119,9 +119,8 @@ __device__ inline uint32_t blend_u8(float c0, float w0, float c1, float w1) {
   return (uint32_t)v;
 }
 
-// Dependent-access chain: {slot flags, Index3D, TSDF voxel, colour voxel} (all addressed by the slot id alone, fetched
-// together) -> block vote -> {synthetic depth gather, colour gather} (both addressed by the projection, fetched
-// together) -> store.
+// Dependent-access chain: {slot flags, Index3D, TSDF voxel} (all addressed by the slot id alone, fetched together)
+// -> block vote -> {synthetic depth gather, colour gather, colour voxel} (fetched together) -> store.
 // Workgroups [0, n_mark_wg) are ESDF marking workers (first wavefront only; dispatched first so that they start at once and
 // do not queue for a CU slot behind the resident batch of colour workgroups); the n_color_wg after them integrate colour.
 template <typename Pix>
@@ -141,16 +140,12 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rg
   uint32_t flags = m.slot_flags[slot];
   int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
   float2 tv = m.tsdf[(size_t)slot * 512 + tid];                  // zero for slots without a TSDF block
-  uint2* cp = &m.color[(size_t)slot * 512 + tid];
-  uint2 cur = *cp;
   const int32_t hw = m.counters[C_HIGH_WATER];
   for (; slot < hw; slot += n_color_wg) {
     if (slot != wg) {
       flags = m.slot_flags[slot];
       bx = m.slot_index[3 * slot]; by = m.slot_index[3 * slot + 1]; bz = m.slot_index[3 * slot + 2];
       tv = m.tsdf[(size_t)slot * 512 + tid];
-      cp = &m.color[(size_t)slot * 512 + tid];
-      cur = *cp;
     }
     if (!(flags & F_TSDF)) continue;     // uniform
     __syncthreads();
@@ -200,6 +195,10 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rg
     if (!c_ok || !s_ok) continue;
     const float* sp = synth + (int64_t)sy0 * scols + sx0;
     const int64_t i00 = (int64_t)y0 * f.cols + x0;
+    // (the colour voxel is only needed for the blend: it travels with the taps, not with the vote's inputs -- blocks
+    // outside the truncation band or the frustum, most of the map, never fetch it)
+    uint2* cp = &m.color[(size_t)slot * 512 + tid];
+    const uint2 cur = *cp;
     const float s00 = sp[0], s10 = sp[1], s01 = sp[scols], s11 = sp[scols + 1];
     float t00[3], t10[3], t01[3], t11[3];
     rgb.tap(i00, t00); rgb.tap(i00 + 1, t10); rgb.tap(i00 + f.cols, t01); rgb.tap(i00 + f.cols + 1, t11);
