@@ -62,11 +62,12 @@ class Mapper {
   static constexpr int64_t kDefaultBlockCapacity = 1 << 16;   // 64 k blocks = 768 MiB of voxel pools in HBM
 
   Mapper(float voxel_size_m, MemoryType memory_type = MemoryType::kDevice, ProjectiveLayerType projective_layer_type = ProjectiveLayerType::kTsdf,
-         std::shared_ptr<CudaStream> cuda_stream = std::make_shared<CudaStreamOwning>(), int64_t block_capacity = kDefaultBlockCapacity)
-      : voxel_size_m_(voxel_size_m), projective_layer_type_(projective_layer_type), cuda_stream_(std::move(cuda_stream)) {
+         std::shared_ptr<CudaStream> cuda_stream = std::make_shared<CudaStreamOwning>(), int64_t block_capacity = kDefaultBlockCapacity,
+         EsdfMode esdf_mode = EsdfMode::k2D)
+      : voxel_size_m_(voxel_size_m), projective_layer_type_(projective_layer_type), esdf_mode_(esdf_mode), cuda_stream_(std::move(cuda_stream)) {
     (void)memory_type;   // blocks always live in HBM (MemoryType::kDevice, nvblox_node.cpp:190)
     int dev = 0; (void)hipGetDevice(&dev);
-    const nvbx_mapper_params p = params_.toCAbi(voxel_size_m, projective_layer_type_);
+    const nvbx_mapper_params p = params_.toCAbi(voxel_size_m, projective_layer_type_, esdf_mode_);
     checkNvbx(nvbx_mapper_create(dev, (void*)(hipStream_t)(*cuda_stream_), &p, block_capacity, &m_), "nvbx_mapper_create");
     detail::contextMapper() = m_;
     rebuildViews();
@@ -77,7 +78,7 @@ class Mapper {
 
   void setMapperParams(const MapperParams& params) {
     params_ = params;
-    const nvbx_mapper_params p = params_.toCAbi(voxel_size_m_, projective_layer_type_);
+    const nvbx_mapper_params p = params_.toCAbi(voxel_size_m_, projective_layer_type_, esdf_mode_);
     checkNvbx(nvbx_mapper_set_params(m_, &p), "nvbx_mapper_set_params");
   }
   const MapperParams& params() const { return params_; }
@@ -159,6 +160,7 @@ class Mapper {
   EsdfLayer& esdf_layer() { return esdf_layer_; }
   float voxel_size_m() const { return voxel_size_m_; }
   ProjectiveLayerType projective_layer_type() const { return projective_layer_type_; }
+  EsdfMode esdf_mode() const { return esdf_mode_; }
 
   // -- integrator parameter accessors used by the node (nvblox_node.cpp:136,1509,1513,1529-1533)
   struct EsdfIntegratorView {
@@ -297,6 +299,7 @@ class Mapper {
 
   float voxel_size_m_;
   ProjectiveLayerType projective_layer_type_;
+  EsdfMode esdf_mode_ = EsdfMode::k2D;
   std::shared_ptr<CudaStream> cuda_stream_;
   MapperParams params_;
   nvbx_mapper* m_ = nullptr;

@@ -119,9 +119,10 @@ struct MapperParams {
   FreespaceIntegratorParams freespace_integrator_params;
 
   // what libnvblox_hip consumes
-  nvbx_mapper_params toCAbi(float voxel_size, ProjectiveLayerType layer_type = ProjectiveLayerType::kTsdf) const {
+  nvbx_mapper_params toCAbi(float voxel_size, ProjectiveLayerType layer_type = ProjectiveLayerType::kTsdf, EsdfMode esdf_mode = EsdfMode::k2D) const {
     nvbx_mapper_params p{};
     p.voxel_size = voxel_size;
+    p.esdf_mode = esdf_mode == EsdfMode::k3D ? 1 : 0;
     p.projective_layer_type = layer_type == ProjectiveLayerType::kOccupancy ? 1 : 0;
     p.free_region_occupancy_probability = occupancy_integrator_params.free_region_occupancy_probability;
     p.occupied_region_occupancy_probability = occupancy_integrator_params.occupied_region_occupancy_probability;

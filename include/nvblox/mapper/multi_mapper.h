@@ -17,14 +17,13 @@ class MultiMapper {
               std::shared_ptr<CudaStream> cuda_stream = std::make_shared<CudaStreamOwning>(), int64_t block_capacity = Mapper::kDefaultBlockCapacity)
       : mapping_type_(mapping_type), esdf_mode_(esdf_mode), cuda_stream_(cuda_stream) {
     if (mapping_type == MappingType::kDynamic) unsupported("MappingType::kDynamic (freespace layer + dynamic detection)");
-    if (esdf_mode != EsdfMode::k2D) unsupported("EsdfMode::k3D");
     const bool occupancy_background = mapping_type == MappingType::kStaticOccupancy || mapping_type == MappingType::kHumanWithStaticOccupancy;
     human_ = mapping_type == MappingType::kHumanWithStaticTsdf || mapping_type == MappingType::kHumanWithStaticOccupancy;
     background_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type, occupancy_background ? ProjectiveLayerType::kOccupancy : ProjectiveLayerType::kTsdf,
-                                                  cuda_stream, block_capacity);
+                                                  cuda_stream, block_capacity, esdf_mode);
     // the foreground (human) mapper is an occupancy mapper (specializations/nvblox_segmentation.yaml:9-22); it is fed by the
     // masked overloads only.  In the static modes it stays empty but valid.
-    foreground_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type, ProjectiveLayerType::kOccupancy, cuda_stream, human_ ? block_capacity / 4 : 64);
+    foreground_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type, ProjectiveLayerType::kOccupancy, cuda_stream, human_ ? block_capacity / 4 : 64, esdf_mode);
   }
   void setMapperParams(const MapperParams& background, const MapperParams& foreground) { background_mapper_->setMapperParams(background); foreground_mapper_->setMapperParams(foreground); }
   void setMapperParams(const MapperParams& params) { background_mapper_->setMapperParams(params); }   // fuser_node.cpp:94

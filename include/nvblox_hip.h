@@ -106,6 +106,8 @@ typedef struct {
   float occupied_region_half_width_m;           /* :327; 0.1 */
   float free_region_decay_probability;          /* occupancy decay, :416; 0.55 */
   float occupied_region_decay_probability;      /* :421; 0.30 in the shipped configs */
+  int32_t esdf_mode;                      /* node param esdf_mode, node_params.hpp:90: 0 = "2d" (default, the slice), 1 = "3d" (every voxel
+                                             of every updated block; MultiMapper(voxel_size, mapping_type, EsdfMode::k3D, ...), nvblox_node.cpp:187-190) */
 } nvbx_mapper_params;
 
 /* nvblox::Lidar(num_azimuth_divisions, num_elevation_divisions, min_valid_range_m, vertical_fov_rad) or

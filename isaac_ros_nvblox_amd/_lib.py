@@ -48,6 +48,7 @@ class Params(C.Structure):
         ("occupied_region_half_width_m", C.c_float),
         ("free_region_decay_probability", C.c_float),
         ("occupied_region_decay_probability", C.c_float),
+        ("esdf_mode", C.c_int32),
     ]
 
 

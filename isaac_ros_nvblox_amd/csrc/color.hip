@@ -248,7 +248,7 @@ static int integrate_color_impl(nvbx_mapper* m, Pix rgb_dev, int32_t rows, int32
   // workers): it reads only the TSDF, like the colour pass, and a following updateEsdf then needs the EDT kernel only
   int mark_wg = 0;
   EsdfArgs ea = m->make_esdf_args();
-  if (m->dirty_since_mark && !m->premark_consumed && ea.bz_hi >= ea.bz_lo && ea.bz_hi - ea.bz_lo + 1 <= 63) {
+  if (m->p.esdf_mode == 0 && m->dirty_since_mark && !m->premark_consumed && ea.bz_hi >= ea.bz_lo && ea.bz_hi - ea.bz_lo + 1 <= 63) {
     m->mark_pass++; ea.mark_pass = m->mark_pass; mark_wg = 256;
     m->dirty_since_mark = false; m->premark_consumed = true; m->unresolved_marks = true;
   }

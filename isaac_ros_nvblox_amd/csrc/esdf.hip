@@ -36,6 +36,11 @@ __global__ __launch_bounds__(256) void k_esdf_edt(DMap m, EsdfArgs a) {
 extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
   if (!m) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));
+  if (m->p.esdf_mode == 1) {                       // EsdfMode::k3D: esdf3d.hip
+    if (m->p.esdf_max_distance_m / m->p.voxel_size >= 64.0f) { set_error("esdf_max_distance_m / voxel_size must be < 64 voxels"); return NVBX_E_INVALID; }
+    if (m->join_side()) return NVBX_E_DEVICE;
+    return m->update_esdf_3d();
+  }
   if (m->dirty_since_mark) m->mark_pass++;
   const EsdfArgs a = m->make_esdf_args();
   if (m->p.esdf_max_distance_m / m->p.voxel_size >= 64.0f) { set_error("esdf_max_distance_m / voxel_size must be < 64 voxels"); return NVBX_E_INVALID; }

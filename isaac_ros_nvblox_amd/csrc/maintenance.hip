@@ -54,7 +54,7 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
         atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH));
         const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
         if (bz >= bz_lo && bz <= bz_hi) {
-          const uint32_t es = any_slot(m, bx, by, bz_out);          // (the table is rebuilt after this kernel, not during it)
+          const uint32_t es = bz_out == INT32_MIN ? (uint32_t)slot : any_slot(m, bx, by, bz_out);   // 3-D ESDF: the block's own slot (the table is rebuilt after this kernel, not during it)
           if (slot_ok(es) && (m.slot_flags[es] & F_ESDF)) {
             const uint32_t eold = atomicOr(&m.slot_flags[es], F_ESDF_REMARK | F_DIRTY_ESDF);
             if (!(eold & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)es);
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
 // `srec`: window record of the next ESDF update.  An ESDF block that is dropped takes its sites with it: the distances of
 // every voxel within the search radius of those sites are stale, so the block joins the next update's window (the
 // distance transform is exact on any window that contains every change of the site set).
-__global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float cy, float cz, float r2, float bs, int32_t srec) {
+__global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float cy, float cz, float r2, float bs, int32_t srec, int32_t esdf3d) {
   const int32_t hw = m.counters[C_HIGH_WATER];
   const int tid = threadIdx.x;
   for (int32_t slot = blockIdx.x; slot < hw; slot += gridDim.x) {
@@ -85,7 +85,11 @@ __global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float c
     if (flags & F_COLOR) m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
     if (flags & F_ESDF) m.esdf[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
     if (tid == 0) {
-      if ((flags & F_ESDF) && m.site_bits[slot] != 0ull) {
+      if ((flags & F_ESDF) && esdf3d) {                  // 3-D ESDF: the dropped block joins the next update's 3-D window
+        const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
+        atomicMin(&m.counters[C_ESDF3_WIN + 0], bx); atomicMin(&m.counters[C_ESDF3_WIN + 1], by); atomicMin(&m.counters[C_ESDF3_WIN + 2], bz);
+        atomicMax(&m.counters[C_ESDF3_WIN + 3], bx); atomicMax(&m.counters[C_ESDF3_WIN + 4], by); atomicMax(&m.counters[C_ESDF3_WIN + 5], bz);
+      } else if ((flags & F_ESDF) && m.site_bits[slot] != 0ull) {
         const int sh = my_shard(); const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1];
         atomicMin(shc_at(m, srec, sh, 0), bx); atomicMin(shc_at(m, srec, sh, 1), by);
         atomicMax(shc_at(m, srec, sh, 2), bx); atomicMax(shc_at(m, srec, sh, 3), by);
@@ -148,7 +152,7 @@ __global__ void k_save_stamps(DMap m, uint32_t* tmp) {
     tmp[s] = (m.slot_flags[s] & LAYER_MASK) ? m.table[m.slot_entry[s]].stamp : 0xFFFFFFFFu;
   if (blockIdx.x == 0 && threadIdx.x < 4) m.counters[C_ESDF_AABB + threadIdx.x] = threadIdx.x < 2 ? INT32_MAX : INT32_MIN;
 }
-__global__ void k_reinsert(DMap m, const uint32_t* tmp) {
+__global__ void k_reinsert(DMap m, const uint32_t* tmp, int32_t bz_out) {
   const int32_t hw = m.counters[C_HIGH_WATER];
   for (int32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < hw; s += gridDim.x * blockDim.x) {
     const uint32_t flags = m.slot_flags[s];
@@ -163,7 +167,7 @@ __global__ void k_reinsert(DMap m, const uint32_t* tmp) {
     }
     m.table[h].slot = (uint32_t)s; m.table[h].stamp = tmp[s];
     m.slot_entry[s] = h;
-    if (flags & F_ESDF) {
+    if ((flags & F_ESDF) && z == bz_out) {       // the slicer's image covers the ESDF blocks of the slice plane
       atomicMin(&m.counters[C_ESDF_AABB + 0], x); atomicMin(&m.counters[C_ESDF_AABB + 1], y);
       atomicMax(&m.counters[C_ESDF_AABB + 2], x); atomicMax(&m.counters[C_ESDF_AABB + 3], y);
     }
@@ -174,7 +178,7 @@ static int rebuild_table(nvbx_mapper* m) {
   uint32_t* tmp = (uint32_t*)m->export_idx;   // capacity * 12 bytes scratch >= capacity * 4
   NVBX_LAUNCH(m, k_save_stamps, dim3(256), dim3(256), m->d, tmp);
   NVBX_HIP(hipMemsetAsync(m->d.table, 0xFF, ((size_t)m->d.mask + 1) * sizeof(Entry), m->stream));
-  NVBX_LAUNCH(m, k_reinsert, dim3(256), dim3(256), m->d, tmp);
+  NVBX_LAUNCH(m, k_reinsert, dim3(256), dim3(256), m->d, tmp, m->make_esdf_args().bz_out);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(512) void k_decay_occupancy(DMap m, float lo_free_d
         atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH));
         const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
         if (bz >= bz_lo && bz <= bz_hi) {
-          const uint32_t es = any_slot(m, bx, by, bz_out);
+          const uint32_t es = bz_out == INT32_MIN ? (uint32_t)slot : any_slot(m, bx, by, bz_out);
           if (slot_ok(es) && (m.slot_flags[es] & F_ESDF)) {
             const uint32_t eold = atomicOr(&m.slot_flags[es], F_ESDF_REMARK | F_DIRTY_ESDF);
             if (!(eold & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)es);
@@ -224,7 +228,8 @@ extern "C" int nvbx_decay_occupancy(nvbx_mapper* m) {
   if (m->join_side()) return NVBX_E_DEVICE;
   if (m->undo_marks()) return NVBX_E_DEVICE;
   if (m->begin_dirtying()) return NVBX_E_DEVICE;
-  const EsdfArgs ea = m->make_esdf_args();
+  EsdfArgs ea = m->make_esdf_args();
+  if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
   NVBX_LAUNCH(m, k_decay_occupancy, dim3((unsigned)std::min<int64_t>(m->capacity, 2048)), dim3(512), m->d,
               log_odds(m->p.free_region_decay_probability), log_odds(m->p.occupied_region_decay_probability), ea.bz_lo, ea.bz_hi, ea.bz_out);
   return rebuild_table(m);
@@ -238,7 +243,8 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   if (m->undo_marks()) return NVBX_E_DEVICE;          // decay deallocates: unresolved marking passes are taken back first
   if (m->begin_dirtying()) return NVBX_E_DEVICE;
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
-  const EsdfArgs ea = m->make_esdf_args();
+  EsdfArgs ea = m->make_esdf_args();
+  if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
   NVBX_LAUNCH(m, k_decay, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
                      exclude_last_view ? m->last_view_frame : 0u, m->mesh_list_live(), ea.bz_lo, ea.bz_hi, ea.bz_out);
   return rebuild_table(m);
@@ -251,6 +257,6 @@ extern "C" int nvbx_clear_outside_radius(nvbx_mapper* m, const float center[3], 
   if (m->undo_marks()) return NVBX_E_DEVICE;          // deallocates: unresolved marking passes are taken back first
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
   NVBX_LAUNCH(m, k_clear_outside, dim3(grid), dim3(512), m->d, center[0], center[1], center[2], radius * radius, m->p.voxel_size * 8.0f,
-              (int32_t)(S_ESDF_REC + (int)(m->esdf_epoch & 1)));
+              (int32_t)(S_ESDF_REC + (int)(m->esdf_epoch & 1)), (int32_t)(m->p.esdf_mode == 1));
   return rebuild_table(m);
 }

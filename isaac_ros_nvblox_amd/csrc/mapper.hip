@@ -34,6 +34,8 @@ __global__ void k_init_map(DMap m) {
     if (i == C_FREE_TOP) v = (int32_t)m.capacity;
     const int a = (int)i - C_ESDF_AABB;
     if (a >= 0 && a < 4) v = a < 2 ? INT32_MAX : INT32_MIN;
+    const int w3 = (int)i - C_ESDF3_WIN;
+    if (w3 >= 0 && w3 < 6) v = w3 < 3 ? INT32_MAX : INT32_MIN;
     m.counters[i] = v;
   }
 }
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(512) void k_scatter_blocks(DMap m, uint32_t layer, 
         if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)s);
         if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, (int32_t)s);
       }
-      if (layer == F_ESDF) {
+      if (layer == F_ESDF && z == bz_out) {     // (3-D ESDF: only the slice plane's blocks span the slicer's image)
         atomicMin(&m.counters[C_ESDF_AABB + 0], x); atomicMin(&m.counters[C_ESDF_AABB + 1], y);
         atomicMax(&m.counters[C_ESDF_AABB + 2], x); atomicMax(&m.counters[C_ESDF_AABB + 3], y);
       }
@@ -300,7 +302,7 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   DMap& d = m->d;
   void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.slot_consumed, d.tsdf, d.color, d.esdf,
                   m->view_list, d.lists, d.shc, m->export_idx, m->export_count, d.site_bits, d.obs_bits, d.inside_bits,
-                  m->synth, m->depth_pre, m->mask_zmin, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
+                  m->synth, m->depth_pre, m->mask_zmin, m->esdf3_scratch, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (m->h_counters) (void)hipHostFree(m->h_counters);
   if (m->h_shc) (void)hipHostFree(m->h_shc);
@@ -344,6 +346,7 @@ extern "C" void nvbx_default_params(nvbx_mapper_params* p) {
   p->free_region_occupancy_probability = 0.45f; p->occupied_region_occupancy_probability = 0.55f;
   p->unobserved_region_occupancy_probability = 0.5f; p->occupied_region_half_width_m = 0.1f;
   p->free_region_decay_probability = 0.55f; p->occupied_region_decay_probability = 0.30f;
+  p->esdf_mode = 0;
 }
 extern "C" int nvbx_flush(nvbx_mapper* m) {
   if (!m) return NVBX_E_INVALID;
@@ -573,6 +576,7 @@ extern "C" int nvbx_get_counters(nvbx_mapper* m, nvbx_counters* out) {
   out->esdf_columns_marked = m->esdf_epoch ? m->shc_sum(S_ESDF_REC + epar, 4) : 0;
   out->esdf_blocks_swept = m->esdf_epoch ? m->shc_sum(S_ESDF_REC + epar, 5) : 0;
   out->esdf_window_voxels = m->esdf_epoch ? c[C_ESDF_UPD + 8 * epar + 6] : 0;
+  if (m->p.esdf_mode == 1) { out->esdf_columns_marked = m->esdf3_blocks_marked; out->esdf_blocks_swept = m->esdf3_window_voxels / 512; out->esdf_window_voxels = m->esdf3_window_voxels; }
   const int mpar = (int)((m->mesh_epoch + 1) & 1);                    // record of the last finished mesh update
   out->mesh_blocks_updated = m->mesh_epoch ? m->shc_sum(S_MESH_REC + mpar, 0) : 0;
   out->mesh_vertices = m->mesh_epoch ? m->shc_sum(S_MESH_REC + mpar, 2) : 0;

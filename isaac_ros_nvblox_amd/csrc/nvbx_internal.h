@@ -45,6 +45,7 @@ enum {
   C_HIGH_WATER = 1,    // 1 + highest slot ever handed out
   C_OVERFLOW = 2,      // sticky capacity-overflow flag
   C_VIEW_COUNT = 4,    // [4..7]  ring of per-frame view-list counts (frame & 3)
+  C_ESDF3_WIN = 8,     // [8..14] 3-D ESDF: block AABB changed since the last update (min x,y,z, max x,y,z) + blocks marked
   C_ESDF_UPD = 16,     // [16..31] two parity-indexed records of 8 ints for ESDF update e (record e & 1): only
                        //   +6 (window voxels) lives here; the contended fields are sharded (S_ESDF_REC below)
   C_ESDF_AABB = 32,    // [32..35] AABB of all ESDF blocks: min_x, min_y, max_x, max_y

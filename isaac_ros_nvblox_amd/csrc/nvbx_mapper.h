@@ -79,6 +79,9 @@ struct nvbx_mapper {
   // mark_pass when the last distance transform was enqueued (passes above it are the unresolved ones).
   bool unresolved_marks = false; uint32_t pass_at_last_edt = 0;
   int undo_marks();
+  // EsdfMode::k3D (esdf3d.hip)
+  int update_esdf_3d();
+  void* esdf3_scratch = nullptr; int64_t esdf3_scratch_bytes = 0; int64_t esdf3_blocks_marked = 0, esdf3_window_voxels = 0;
   // held-back EDT of the last updateEsdf (NVBX_DEFER_EDT=0 disables): see nvbx_update_esdf
   bool defer_edt = true, edt_pending = false; nvbx::EsdfArgs edt_args{};
   int flush_edt();

@@ -54,6 +54,7 @@ class OrcParams(C.Structure):
         ("occupied_region_half_width_m", C.c_float),
         ("free_region_decay_probability", C.c_float),
         ("occupied_region_decay_probability", C.c_float),
+        ("esdf_mode", C.c_int32),
     ]
 
 
@@ -73,7 +74,7 @@ def default_params(**kw):
         lidar_nearest_interpolation_max_allowable_dist_to_ray_vox=0.5, invalid_depth_decay_factor=-1.0,
         projective_layer_type=0, free_region_occupancy_probability=0.45, occupied_region_occupancy_probability=0.55,
         unobserved_region_occupancy_probability=0.5, occupied_region_half_width_m=0.1,
-        free_region_decay_probability=0.55, occupied_region_decay_probability=0.30)
+        free_region_decay_probability=0.55, occupied_region_decay_probability=0.30, esdf_mode=0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p

@@ -89,6 +89,7 @@ typedef struct {
   float free_region_occupancy_probability, occupied_region_occupancy_probability, unobserved_region_occupancy_probability;
   float occupied_region_half_width_m;
   float free_region_decay_probability, occupied_region_decay_probability;
+  int32_t esdf_mode;                    /* 0 = 2-D slice, 1 = 3-D */
 } OrcParams;
 
 enum { W_CONSTANT = 0, W_CONSTANT_DROPOFF = 1, W_INVERSE_SQUARE = 2, W_INVERSE_SQUARE_DROPOFF = 3,
@@ -834,7 +835,116 @@ static EsdfCfg esdf_cfg(const OrcParams* p) {
 /* Exact 2-D Euclidean distance transform of the slice with cut-off: row pass (nearest site along x, ties -> -x),
  * column pass (dy ascending, strict improvement).  Restates what [U] EsdfIntegrator's sweep/propagate loop
  * converges to on a convex allocated region; DESIGN.md "ESDF semantics" states the difference elsewhere. */
+/* EsdfMode::k3D (node param esdf_mode "3d", node_params.hpp:90): [U] restated as the same thing in three dimensions.  Every
+ * dirty TSDF block gets an ESDF block of the same index; every voxel is observed / inside / site by its own TSDF voxel (or
+ * occupancy log-odds); a block whose TSDF was deallocated is re-marked (nothing observed).  Distances: exact 3-D Euclidean
+ * distance transform with cut-off over all ESDF blocks -- x pass (nearest site along x, ties -> -x), y pass and z pass (minimum
+ * of d^2 + previous result over +-ri, ties -> the smaller offset). */
+static int64_t update_esdf_3d(OrcMap* m) {
+  const OrcParams* p = &m->p;
+  const EsdfCfg c = esdf_cfg(p);
+  int64_t n_dirty = 0;
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    int want = 0;
+    if ((b->flags & L_TSDF) && b->dirty_esdf) { b->dirty_esdf = 0; want = 1; }
+    if (b->remark_esdf) { b->remark_esdf = 0; if (b->flags & L_ESDF) want = 1; }
+    if (!want) continue;
+    ensure_layer(b, L_ESDF);
+    n_dirty++;
+    for (int i = 0; i < NVOX; i++) {
+      int observed = 0, inside = 0, site = 0;
+      if (b->flags & L_TSDF) {
+        const TsdfVoxel* tv = &b->tsdf[i];
+        if (p->projective_layer_type == 1) {
+          if (tv->distance != 0.0f) observed = 1;
+          if (tv->distance > 0.0f) { inside = 1; site = 1; }
+        } else if (tv->weight >= p->esdf_min_weight) {
+          observed = 1;
+          const int in = tv->distance <= 0.0f;
+          if (in) inside = 1;
+          if ((p->esdf_site_rule == 1 || in) && fabsf(tv->distance) <= c.site_dist_m) site = 1;
+        }
+      }
+      b->esdf[i].observed = (uint8_t)observed; b->esdf[i].is_inside = (uint8_t)inside; b->esdf[i].is_site = (uint8_t)site;
+    }
+  }
+  m->esdf_epoch++;
+  int32_t lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    if (!(b->flags & L_ESDF)) continue;
+    const int32_t v[3] = {b->idx.x, b->idx.y, b->idx.z};
+    for (int a = 0; a < 3; a++) { if (v[a] < lo[a]) lo[a] = v[a]; if (v[a] > hi[a]) hi[a] = v[a]; }
+  }
+  if (lo[0] > hi[0]) return 0;
+  const int64_t W = (int64_t)(hi[0] - lo[0] + 1) * 8, H = (int64_t)(hi[1] - lo[1] + 1) * 8, D = (int64_t)(hi[2] - lo[2] + 1) * 8;
+  const int64_t N = W * H * D;
+  uint8_t* site = (uint8_t*)calloc((size_t)N, 1);
+  int16_t* dxs = (int16_t*)malloc((size_t)N * sizeof(int16_t));       /* x pass: offset to the nearest site along x */
+  int32_t* sqy = (int32_t*)malloc((size_t)N * sizeof(int32_t));       /* y pass: squared distance in the xy plane */
+  int16_t* dys = (int16_t*)malloc((size_t)N * sizeof(int16_t));
+  int16_t* dxy = (int16_t*)malloc((size_t)N * sizeof(int16_t));
+  const int16_t NONE = 32767;
+#define G3(x, y, z) (((int64_t)(z) * H + (y)) * W + (x))
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    if (!(b->flags & L_ESDF)) continue;
+    for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) for (int z = 0; z < 8; z++)
+      site[G3((int64_t)(b->idx.x - lo[0]) * 8 + x, (int64_t)(b->idx.y - lo[1]) * 8 + y, (int64_t)(b->idx.z - lo[2]) * 8 + z)] = b->esdf[z + 8 * y + 64 * x].is_site;
+  }
+#pragma omp parallel for
+  for (int64_t z = 0; z < D; z++) for (int64_t y = 0; y < H; y++) for (int64_t x = 0; x < W; x++) {
+    int16_t best = NONE;
+    for (int32_t d = 0; d <= c.ri; d++) {
+      if (x - d >= 0 && site[G3(x - d, y, z)]) { best = (int16_t)(-d); break; }
+      if (x + d < W && site[G3(x + d, y, z)]) { best = (int16_t)d; break; }
+    }
+    dxs[G3(x, y, z)] = best;
+  }
+#pragma omp parallel for
+  for (int64_t z = 0; z < D; z++) for (int64_t y = 0; y < H; y++) for (int64_t x = 0; x < W; x++) {
+    int32_t best = INT32_MAX; int16_t bdy = 0, bdx = 0;
+    for (int32_t dy = -c.ri; dy <= c.ri; dy++) {
+      const int64_t yy = y + dy;
+      if (yy < 0 || yy >= H) continue;
+      const int16_t dx = dxs[G3(x, yy, z)];
+      if (dx == NONE) continue;
+      const int32_t sq = dy * dy + (int32_t)dx * dx;
+      if (sq < best) { best = sq; bdy = (int16_t)dy; bdx = dx; }
+    }
+    sqy[G3(x, y, z)] = best; dys[G3(x, y, z)] = bdy; dxy[G3(x, y, z)] = bdx;
+  }
+#pragma omp parallel for
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    if (!(b->flags & L_ESDF)) continue;
+    for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) for (int z = 0; z < 8; z++) {
+      const int64_t gx = (int64_t)(b->idx.x - lo[0]) * 8 + x, gy = (int64_t)(b->idx.y - lo[1]) * 8 + y, gz = (int64_t)(b->idx.z - lo[2]) * 8 + z;
+      int32_t best = INT32_MAX, bdz = 0; int64_t bi = -1;
+      for (int32_t dz = -c.ri; dz <= c.ri; dz++) {
+        const int64_t zz = gz + dz;
+        if (zz < 0 || zz >= D) continue;
+        const int32_t s2 = sqy[G3(gx, gy, zz)];
+        if (s2 == INT32_MAX) continue;
+        const int32_t sq = dz * dz + s2;
+        if (sq < best) { best = sq; bdz = dz; bi = G3(gx, gy, zz); }
+      }
+      EsdfVoxel* ev = &b->esdf[z + 8 * y + 64 * x];
+      if (best != INT32_MAX && (float)best <= c.max_sq) {
+        ev->sq = (float)best; ev->parent[0] = dxy[bi]; ev->parent[1] = dys[bi]; ev->parent[2] = bdz;
+      } else {
+        ev->sq = c.max_sq; ev->parent[0] = 0; ev->parent[1] = 0; ev->parent[2] = 0;
+      }
+    }
+  }
+#undef G3
+  free(site); free(dxs); free(sqy); free(dys); free(dxy);
+  return n_dirty;
+}
+
 int64_t orc_update_esdf(OrcMap* m) {
+  if (m->p.esdf_mode == 1) return update_esdf_3d(m);
   const OrcParams* p = &m->p;
   const EsdfCfg c = esdf_cfg(p);
   const int32_t bz_out = floor_div8(c.kz_out), vz_out = mod8(c.kz_out);
@@ -1131,7 +1241,8 @@ int64_t orc_decay_tsdf(OrcMap* m, int exclude_last_view) {
       if (!alive) {
         drop = 1;
         const EsdfCfg ec = esdf_cfg(p);
-        if (b->idx.z >= floor_div8(ec.kz_min) && b->idx.z <= floor_div8(ec.kz_max)) {
+        if (p->esdf_mode == 1) { if (b->flags & L_ESDF) b->remark_esdf = 1; }      /* 3-D: the block's own ESDF block */
+        else if (b->idx.z >= floor_div8(ec.kz_min) && b->idx.z <= floor_div8(ec.kz_max)) {
           Idx3 ei = {b->idx.x, b->idx.y, floor_div8(ec.kz_out)};
           Block* eb = map_find(m, ei);
           if (eb && (eb->flags & L_ESDF)) eb->remark_esdf = 1;
@@ -1170,7 +1281,8 @@ int64_t orc_decay_occupancy(OrcMap* m) {
       else {
         drop = 1;
         const EsdfCfg ec = esdf_cfg(p);
-        if (b->idx.z >= floor_div8(ec.kz_min) && b->idx.z <= floor_div8(ec.kz_max)) {
+        if (p->esdf_mode == 1) { if (b->flags & L_ESDF) b->remark_esdf = 1; }      /* 3-D: the block's own ESDF block */
+        else if (b->idx.z >= floor_div8(ec.kz_min) && b->idx.z <= floor_div8(ec.kz_max)) {
           Idx3 ei = {b->idx.x, b->idx.y, floor_div8(ec.kz_out)};
           Block* eb = map_find(m, ei);
           if (eb && (eb->flags & L_ESDF)) eb->remark_esdf = 1;

@@ -314,6 +314,21 @@ int main(int argc, char** argv) {
     if (total_blocks != full_blocks || calls < 2 || first_call_blocks == 0 || first_call_blocks >= full_blocks) {
       std::fprintf(stderr, "rationed mesh streaming: %zu of %zu blocks in %zu calls (first call %zu)\n", total_blocks, full_blocks, calls, first_call_blocks); return 1; }
   }
+  // esdf_mode "3d" (node_params.hpp:90; nvblox_node.cpp:187-190): the ESDF of every voxel, sampled like the EsdfAndGradients service does
+  {
+    MultiMapper m3(0.05f, MappingType::kStaticTsdf, EsdfMode::k3D, MemoryType::kDevice, std::make_shared<CudaStreamOwning>(), 1 << 12);
+    DepthImage flat(120, 160, MemoryType::kDevice);
+    std::vector<float> host_depth(120 * 160, 1.5f);
+    flat.copyFromAsync(120, 160, host_depth.data(), CudaStreamOwning());
+    m3.integrateDepth(flat, Transform::Identity(), Camera(80.f, 80.f, 79.5f, 59.5f, 160, 120));
+    m3.updateEsdf();
+    const EsdfLayer& e3 = m3.background_mapper()->esdf_layer();
+    size_t sites = 0, known = 0; int zmin = 1 << 30, zmax = -(1 << 30);
+    callFunctionOnAllVoxels<EsdfVoxel>(e3, [&](const Index3D& b, const Index3D&, const EsdfVoxel* v) {
+      if (v->is_site) sites++; if (v->observed) known++; zmin = std::min(zmin, b.z()); zmax = std::max(zmax, b.z()); });
+    if (e3.numAllocatedBlocks() != m3.background_mapper()->tsdf_layer().numAllocatedBlocks() || sites < 1000 || known < 10000 || zmax - zmin < 3) {
+      std::fprintf(stderr, "3-D ESDF: %d blocks, %zu sites, %zu observed, z %d..%d\n", e3.numAllocatedBlocks(), sites, known, zmin, zmax); return 1; }
+  }
   // save_map / load_map services (nvblox_node.cpp:1668, 1703): bool results, a missing file is a recoverable error
   const std::string filename = std::string(argv[1]) + ".map";
   const bool save_ok = node.static_mapper_->saveLayerCake(filename);

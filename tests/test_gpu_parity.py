@@ -404,3 +404,67 @@ def test_mask_split_and_human_mapping_parity(oracle_mod, hip_lib):
     un2o, ma2o = oracle_mod.split_depth_by_mask(d2, m2, Tshift, cam, cam, 0.25)
     assert np.array_equal(un2.cpu().numpy(), un2o) and np.array_equal(ma2.cpu().numpy(), ma2o)
     assert ((un2o > 0) & (d2 == 4.0)).sum() > 50                                   # occluded far pixels stay in the background image
+
+
+def compare_esdf3(M, g, o, oracle_mod):
+    n, _ = compare_layer(M, g, o, M.LAYER_ESDF, oracle_mod.L_ESDF,
+                         fields_exact=("squared_distance_vox", "parent_direction", "is_inside", "observed", "is_site"))
+    return n
+
+
+def test_esdf_3d_parity(oracle_mod, hip_lib):
+    """EsdfMode::k3D (esdf_mode "3d", node_params.hpp:90): every voxel of every updated block; the whole ESDF layer (squared
+    distances, parent directions, flags) bit-exact against the oracle over incremental updates, decay with deallocation and
+    radius clearing; the distances are the true 3-D Euclidean distance transform (brute force on a sub-volume); slice and dense
+    query read the same layer."""
+    M, g, o = make_pair(oracle_mod, esdf_mode=1, esdf_max_distance_m=1.0, tsdf_decay_factor=0.5, tsdf_decayed_weight_threshold=0.3,
+                        max_integration_distance_m=4.0)
+    fr = H.frames(5, H.SMALL_CAM, color=False, stride=8)
+    for k, (d, rgb, T) in enumerate(fr):
+        g.integrate_depth(d, T, H.SMALL_CAM); o.integrate_depth(d, T, H.SMALL_CAM)
+        if k in (1, 4):
+            g.update_esdf(); o.update_esdf()                             # incremental: the second update re-computes a window only
+            n = compare_esdf3(M, g, o, oracle_mod)
+    assert n > 150 and H.idx_set(g.block_indices(M.LAYER_ESDF)) == H.idx_set(g.block_indices(M.LAYER_TSDF))
+    # brute force 3-D EDT on the GPU's own sites, a 5 x 5 x 3 block sub-volume in the middle of the map
+    idx = g.block_indices(M.LAYER_ESDF)
+    b, _ = g.get_blocks(M.LAYER_ESDF, idx)
+    lo = idx.min(0); hi = idx.max(0)
+    dims = (hi - lo + 1) * 8
+    site = np.zeros(dims, bool); sq = np.full(dims, -1.0, np.float32)
+    for k, i in enumerate(idx):
+        s = (i - lo) * 8
+        blk = b[k].reshape(8, 8, 8)                                      # [x][y][z]
+        site[s[0]:s[0] + 8, s[1]:s[1] + 8, s[2]:s[2] + 8] = blk["is_site"].astype(bool)
+        sq[s[0]:s[0] + 8, s[1]:s[1] + 8, s[2]:s[2] + 8] = blk["squared_distance_vox"]
+    pts = np.argwhere(site)
+    assert len(pts) > 2000
+    c = dims // 2
+    sub = np.stack(np.meshgrid(np.arange(c[0] - 20, c[0] + 20), np.arange(c[1] - 20, c[1] + 20), np.arange(max(c[2] - 12, 0), min(c[2] + 12, dims[2])),
+                               indexing="ij"), -1).reshape(-1, 3)
+    sub = sub[sq[sub[:, 0], sub[:, 1], sub[:, 2]] >= 0.0]                 # voxels of allocated blocks
+    max_sq = np.float32((np.float32(1.0) / np.float32(0.05)) ** 2)
+    best = np.full(len(sub), np.inf)
+    for s0 in range(0, len(pts), 4000):
+        d2 = ((sub[:, None, :] - pts[None, s0:s0 + 4000, :]) ** 2).sum(-1)
+        best = np.minimum(best, d2.min(1))
+    want = np.where(best <= max_sq, best, max_sq).astype(np.float32)
+    assert len(sub) > 10000 and np.array_equal(sq[sub[:, 0], sub[:, 1], sub[:, 2]], want)
+    # slice + dense query read the 3-D layer
+    sg, ag = g.esdf_slice_image(); so, ao = o.esdf_slice_image()
+    assert sg.shape == so.shape and np.abs(sg - so).max() <= TOL and np.allclose(ag, ao)
+    mn = (np.median(idx, axis=0).astype(np.int32) * 8 - np.array([20, 18, 10])).astype(np.int32); size = np.array([40, 36, 20], np.int32)
+    dg = g.esdf_dense_grid(mn, size, 1000.0); do_ = o.esdf_dense_grid(mn, size, 1000.0)
+    assert np.array_equal(dg, do_) and (dg < 999.0).mean() > 0.1
+    # deallocation: decay until blocks die, radius clearing; ESDF follows
+    for _ in range(3):
+        g.decay_tsdf(True); o.decay_tsdf(True)
+    g.update_esdf(); o.update_esdf()
+    compare_esdf3(M, g, o, oracle_mod)
+    d, rgb, T = fr[0]
+    g.integrate_depth(d, T, H.SMALL_CAM); o.integrate_depth(d, T, H.SMALL_CAM)
+    cpos = (float(T[0, 3]), float(T[1, 3]), 1.0)
+    g.clear_outside_radius(cpos, 2.2); o.clear_outside_radius(cpos, 2.2)
+    g.update_esdf(); o.update_esdf()
+    compare_esdf3(M, g, o, oracle_mod)
+    assert g.counters()["capacity_overflow"] == 0
