@@ -104,7 +104,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--unique-frames", type=int, default=50, help="distinct rendered frames cycled through (HBM-resident)")
-    ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the same workload timed on the CPU oracle")
+    ap.add_argument("--cpu-frames", type=int, default=48, help="minimum number of frames of the same workload timed on the CPU oracle")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline keeps integrating (cycling the same frames) until this much CPU wall time has passed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="camera", choices=["camera", "lidar"],
                     help="camera = BASELINE.json configs[1] (the metric's configuration, default); lidar = configs[4] "
@@ -306,9 +307,12 @@ def main():
             d, c_, T = host_frames[k]
             o.integrate_depth(d, T, cam); o.integrate_color(c_, T, cam); o.update_esdf()
         t = time.perf_counter()
-        for k in range(nf):
+        k = 0
+        while k < nf or (time.perf_counter() - t < args.cpu_seconds and k < 20000):     # a bounded sample: ~10-30 s of CPU work
             d, c_, T = host_frames[(2 + k) % nu]
             o.integrate_depth(d, T, cam); o.integrate_color(c_, T, cam); o.update_esdf()
+            k += 1
+        nf = k
         cdt = time.perf_counter() - t
         cpu = {"value": round(nf / cdt, 3), "unit": "frames/s", "cores": int(oracle.num_threads()), "kind": "port",
                "ms_per_frame": round(cdt / nf * 1e3, 2),
