@@ -63,3 +63,36 @@ def test_hip_path_reproduces_golden(hip_lib):
     g.update_esdf(); g.update_color_mesh()
     a = _GpuAsOracle(g)
     check(MG.summarize(a, a), 1e-4, 1)
+
+
+# ------------------------------------------------------------------------------------------------ mapping modes fixture
+spec2 = importlib.util.spec_from_file_location("make_golden_modes", os.path.join(HERE, "golden", "make_golden_modes.py"))
+MM = importlib.util.module_from_spec(spec2); spec2.loader.exec_module(MM)
+GM = np.load(os.path.join(HERE, "golden", "tiny_modes.npz"))
+
+
+def check_modes(s):
+    for k in ("split_unmasked", "split_masked", "occ_indices", "occ_log_odds", "occ_slice", "occ_aabb", "esdf3_indices", "esdf3_sq",
+              "esdf3_parent", "esdf3_flags"):
+        assert s[k].shape == GM[k].shape, k
+        assert np.array_equal(s[k], GM[k]), k            # integer / log-odds / squared-distance work: bit-exact
+
+
+def test_oracle_reproduces_modes_golden(oracle_mod):
+    split = lambda d, mk: oracle_mod.split_depth_by_mask(d, mk, MM.t_cm_cd(), MM.CAM, MM.MASK_CAM, 0.25)
+    mk_map = lambda **kw: oracle_mod.OracleMap(oracle_mod.default_params(**kw))
+    splits, occ, e3 = MM.run(split, mk_map, GM["depth_mm"], GM["masks"], GM["poses"])
+    check_modes(MM.summarize(splits, occ, e3, oracle_mod.L_TSDF, oracle_mod.L_ESDF, "distance"))
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_modes_golden(hip_lib):
+    from isaac_ros_nvblox_amd import mapper as M
+    helper = M.Mapper(M.default_params(), block_capacity=256)
+
+    def split(d, mk):
+        un, ma = helper.split_depth_by_mask(d, mk, MM.t_cm_cd(), MM.CAM, MM.MASK_CAM, 0.25)
+        return un.cpu().numpy(), ma.cpu().numpy()
+    mk_map = lambda **kw: M.Mapper(M.default_params(**kw), block_capacity=1 << 12)
+    splits, occ, e3 = MM.run(split, mk_map, GM["depth_mm"], GM["masks"], GM["poses"])
+    check_modes(MM.summarize(splits, occ, e3, M.LAYER_OCCUPANCY, M.LAYER_ESDF, "log_odds"))
