@@ -324,7 +324,8 @@ int nvbx_mark_esdf_dirty_gathered(nvbx_mapper* m, const int32_t* gathered_dev, i
 
 /* ---- instrumentation (timing::Timer analogue for the per-kernel roofline line of bench.py) -----------------------
  * While enabled every kernel launch is bracketed by a hipEvent pair on the mapper stream. nvbx_get_profile returns a
- * JSON object {"kernel": {"count": n, "total_ms": t}}. */
+ * JSON object {"kernel": {"count": n, "total_ms": t}}; the entry "_empty_event_pair" is the span of event pairs with nothing between
+ * them = what the instrumentation itself adds to the span of one launch (subtract it once per launch). */
 int nvbx_set_profiling(nvbx_mapper* m, int32_t enable);
 int nvbx_get_profile(nvbx_mapper* m, char* json_out, int64_t capacity);
 

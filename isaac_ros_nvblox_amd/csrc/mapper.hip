@@ -314,6 +314,13 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
 extern "C" int nvbx_mapper_set_params(nvbx_mapper* m, const nvbx_mapper_params* params) {
   if (!m || !params) return NVBX_E_INVALID;
   if (params->voxel_size != m->p.voxel_size) { set_error("voxel_size cannot change after creation"); return NVBX_E_INVALID; }
+  if (params->projective_layer_type != m->p.projective_layer_type || params->esdf_mode != m->p.esdf_mode) {
+    // what the voxels of the existing map MEAN would change under it (the reference fixes both at construction too)
+    if (nvbx_num_blocks(m, F_TSDF | 0u) != 0 || nvbx_num_blocks(m, NVBX_LAYER_OCCUPANCY) != 0 || nvbx_num_blocks(m, F_ESDF) != 0) {
+      set_error("projective_layer_type / esdf_mode can only change while the map is empty"); return NVBX_E_INVALID;
+    }
+  }
+  if (m->join_side()) return NVBX_E_DEVICE;        // work enqueued under the old parameters (a held-back EDT) is launched first
   m->p = *params; return NVBX_OK;
 }
 extern "C" int nvbx_mapper_get_params(const nvbx_mapper* m, nvbx_mapper_params* out) {
@@ -636,6 +643,16 @@ extern "C" int nvbx_get_profile(nvbx_mapper* m, char* json_out, int64_t capacity
     bool hit = false;
     for (auto& a : acc) if (!strcmp(a.name, s.name)) { a.n++; a.ms += ms; hit = true; break; }
     if (!hit) acc.push_back({s.name, 1, ms});
+  }
+  // what a hipEvent pair adds to the span of ONE launch: pairs with nothing between them, on the same (now idle) stream
+  {
+    const int kPairs = 32; double ms_sum = 0.0; int n_ok = 0;
+    std::vector<hipEvent_t> ev;
+    for (int i = 0; i < 2 * kPairs; i++) { ev.push_back(m->get_event()); (void)hipEventRecord(ev.back(), m->stream); }
+    NVBX_HIP(hipStreamSynchronize(m->stream));
+    for (int i = 0; i < kPairs; i++) { float ms = 0.0f; if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) { ms_sum += ms; n_ok++; } }
+    for (hipEvent_t e : ev) m->event_pool.push_back(e);
+    if (n_ok) acc.push_back({"_empty_event_pair", n_ok, ms_sum});
   }
   std::string out = "{";
   for (size_t i = 0; i < acc.size(); i++) {

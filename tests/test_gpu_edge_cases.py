@@ -267,3 +267,19 @@ def test_combined_slice_of_two_mappers(oracle_mod, hip_lib):
     # a mapper combined with itself is its own slice
     ii, _ = a.esdf_slice_image_combined(a, 1000.0)
     assert np.array_equal(ii, ia)
+
+
+def test_layer_type_and_esdf_mode_are_fixed_once_the_map_has_content(hip_lib):
+    from isaac_ros_nvblox_amd import mapper as M
+    g = M.Mapper(M.default_params(), block_capacity=1 << 10)
+    g.set_params(M.default_params(esdf_mode=1)); g.set_params(M.default_params())          # empty map: allowed
+    d, _, T = H.frames(1, H.SMALL_CAM, color=False)[0]
+    g.integrate_depth(d, T, H.SMALL_CAM)
+    for kw in (dict(projective_layer_type=1), dict(esdf_mode=1), dict(voxel_size=0.1)):
+        with pytest.raises(RuntimeError):
+            g.set_params(M.default_params(**kw))
+    g.set_params(M.default_params(max_integration_distance_m=3.0))                        # ordinary knobs: any time
+    g.clear()
+    g.set_params(M.default_params(projective_layer_type=1))                               # empty again
+    g.integrate_depth(d, T, H.SMALL_CAM)
+    assert g.num_blocks(M.LAYER_OCCUPANCY) > 10 and g.num_blocks(M.LAYER_TSDF) == 0
