@@ -120,7 +120,7 @@ def main():
     import torch
     import torch.distributed as dist
     from isaac_ros_nvblox_amd import mapper as M, synthetic as S
-    from isaac_ros_nvblox_amd.dist import DirtyBlockExchange, camera_yaw_offset_deg
+    from isaac_ros_nvblox_amd.dist import PipelinedDirtyBlockExchange, camera_yaw_offset_deg
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -156,7 +156,7 @@ def main():
     stream = torch.cuda.Stream(dev)      # one explicit stream for torch ops, RCCL hand-off and every mapper kernel
     torch.cuda.set_stream(stream)
     g = M.Mapper(M.default_params(), device=local_rank, block_capacity=1 << 15, stream=stream.cuda_stream)
-    ex = DirtyBlockExchange(4096, dev) if world > 1 else None
+    ex = PipelinedDirtyBlockExchange(4096, dev) if world > 1 else None      # one packed all-gather per frame, joined one frame later
 
     dargs = [g.prepare_depth(depth_dev[k], poses[k], cam) for k in range(nu)]
     cargs = [g.prepare_color(rgb_dev[k], poses[k], cam) for k in range(nu)]
@@ -165,15 +165,18 @@ def main():
         k = i % nu
         xg = ex if exchange else None            # rank-0-only passes after the timed region must not enter a collective
         g.integrate_prepared(dargs[k])          # MultiMapper::integrateDepth
-        work = xg.start(g) if xg is not None else None   # dirty block indices: export + async RCCL all-gather (needs only the depth pass)
-        g.integrate_prepared(cargs[k])          # MultiMapper::integrateColor (runs while the all-gather is in flight)
         if xg is not None:
-            xg.finish(g, work)                   # join, mark the peers' blocks ESDF-dirty
+            xg.start(g)                          # dirty block indices: export + async RCCL all-gather (needs only the depth pass)
+        g.integrate_prepared(cargs[k])          # MultiMapper::integrateColor
+        if xg is not None:
+            xg.finish_previous(g)                # join the PREVIOUS frame's all-gather, mark the peers' blocks ESDF-dirty
         g.update_esdf()                          # MultiMapper::updateEsdf
         if mesh:
             g.update_color_mesh()
 
     def barrier():
+        if ex is not None:
+            ex.drain(g)          # the all-gather still in flight is joined and applied inside the timed region
         g.synchronize()          # launches anything the mapper holds back (the EDT of the last updateEsdf) and waits for its stream
         torch.cuda.synchronize(dev)
         if world > 1:

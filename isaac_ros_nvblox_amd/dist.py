@@ -61,6 +61,41 @@ class DirtyBlockExchange:
         return out
 
 
+class PipelinedDirtyBlockExchange:
+    """The same exchange, software-pipelined by one frame: frame i's all-gather is started after its depth pass and joined
+    just before frame i+1's ESDF update, so the collective has a whole frame of GPU work (colour(i), ESDF(i), depth(i+1),
+    colour(i+1)) to hide its latency behind instead of one colour pass.  Every list is still applied exactly once, one ESDF
+    update later than in the unpipelined form -- for the peers' lists that is immaterial (each GPU sweeps its OWN TSDF over
+    the union; a peer's update of a block changes nothing in the local layer).  Two buffer sets alternate, so the buffers of
+    the collective in flight are never written.  drain() joins the last one (call it before reading results / timing)."""
+
+    def __init__(self, max_blocks, device, group=None):
+        self.slots = [DirtyBlockExchange(max_blocks, device, group), DirtyBlockExchange(max_blocks, device, group)]
+        self.world = self.slots[0].world
+        self.frame = 0
+        self.pending = None          # (slot, work) of the frame whose lists have not been applied yet
+        self.started = None          # (slot, work) of the current frame
+
+    def start(self, mapper):
+        """After integrateDepth of the current frame."""
+        slot = self.slots[self.frame & 1]
+        self.started = (slot, slot.start(mapper))
+        self.frame += 1
+
+    def finish_previous(self, mapper):
+        """Before updateEsdf of the current frame: apply the PREVIOUS frame's gathered lists; the current frame's stay in flight."""
+        if self.pending is not None:
+            slot, work = self.pending
+            slot.finish(mapper, work)
+        self.pending, self.started = self.started, None
+
+    def drain(self, mapper):
+        if self.pending is not None:
+            slot, work = self.pending
+            slot.finish(mapper, work)
+            self.pending = None
+
+
 def camera_yaw_offset_deg(rank, world):
     """Config 4 of BASELINE.json: cameras on the same rig circle at 45 degree yaw offsets."""
     return 45.0 * (rank % 8)

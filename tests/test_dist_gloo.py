@@ -62,3 +62,57 @@ def test_single_process_exchange_is_identity():
     ex.idx[:3] = torch.tensor([[1, 2, 3], [4, 5, 6], [1, 2, 3]], dtype=torch.int32); ex.cnt[0] = 3
     ex.all_gather()
     assert ex.union_host() == {(1, 2, 3), (4, 5, 6)}
+
+
+class _StubMapper:
+    """Stands in for Mapper in the pipelined exchange: exports a per-frame list that encodes (rank, frame), records what is applied."""
+    def __init__(self, rank):
+        self.rank = rank; self.frame = 0; self.applied = []
+
+    def esdf_dirty_list(self, idx_out, count_out):
+        n = 3 + self.rank + (self.frame % 2)
+        idx_out[:n] = torch.tensor([[self.rank, self.frame, k] for k in range(n)], dtype=torch.int32)
+        count_out[0] = n
+
+    def mark_esdf_dirty_gathered(self, gathered, world, self_rank, max_count):
+        got = []
+        for r in range(world):
+            if r == self_rank:
+                continue
+            c = int(gathered[r, 0, 0]); got += [tuple(v) for v in gathered[r, 1:1 + c].tolist()]
+        self.applied.append(got)
+
+
+def _pipelined_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isaac_ros_nvblox_amd.dist import PipelinedDirtyBlockExchange
+    ex = PipelinedDirtyBlockExchange(16, torch.device("cpu"))
+    m = _StubMapper(rank)
+    n_frames = 5
+    for f in range(n_frames):           # bench.py's step: depth, start, colour, finish_previous, updateEsdf
+        m.frame = f
+        ex.start(m)
+        ex.finish_previous(m)
+    ex.drain(m)
+    peer = 1 - rank
+    want = [[(peer, f, k) for k in range(3 + peer + (f % 2))] for f in range(n_frames)]
+    # frame 0's finish_previous had nothing to apply; every frame's peer list is applied exactly once, in order, the last by drain()
+    ok = m.applied == want
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_exchange_applies_every_list_once_one_frame_late_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
