@@ -167,9 +167,8 @@ def main():
         g.integrate_prepared(dargs[k])          # MultiMapper::integrateDepth
         if xg is not None:
             xg.start(g)                          # dirty block indices: export + async RCCL all-gather (needs only the depth pass)
-        g.integrate_prepared(cargs[k])          # MultiMapper::integrateColor
-        if xg is not None:
-            xg.finish_previous(g)                # join the PREVIOUS frame's all-gather, mark the peers' blocks ESDF-dirty
+            xg.finish_previous(g, deferred=True) # join the PREVIOUS frame's all-gather; its union step rides in the colour launch below
+        g.integrate_prepared(cargs[k])          # MultiMapper::integrateColor (+ marking of own and peers' dirty blocks)
         g.update_esdf()                          # MultiMapper::updateEsdf
         if mesh:
             g.update_color_mesh()

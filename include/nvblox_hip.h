@@ -321,6 +321,10 @@ int nvbx_mark_esdf_dirty(nvbx_mapper* m, const int32_t* indices_dev, const int32
  * each rank = (count, -, -), rows 1.. = block indices (the packed layout isaac_ros_nvblox_amd/dist.py all-gathers);
  * rank `self_rank`'s own list is skipped. */
 int nvbx_mark_esdf_dirty_gathered(nvbx_mapper* m, const int32_t* gathered_dev, int32_t world, int32_t self_rank, int64_t max_count);
+/* The same union step, held back: it is performed by extra workgroups of the next nvbx_integrate_color launch (beside the marking
+ * of the mapper's own dirty blocks) -- no launch of its own -- or first thing by any other entry point that comes before.  The
+ * gathered buffer must stay valid and unchanged until then.  For the pipelined exchange of bench.py / dist.py. */
+int nvbx_mark_esdf_dirty_gathered_deferred(nvbx_mapper* m, const int32_t* gathered_dev, int32_t world, int32_t self_rank, int64_t max_count);
 
 /* ---- instrumentation (timing::Timer analogue for the per-kernel roofline line of bench.py) -----------------------
  * While enabled every kernel launch is bracketed by a hipEvent pair on the mapper stream. nvbx_get_profile returns a

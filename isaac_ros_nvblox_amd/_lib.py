@@ -137,6 +137,7 @@ SIGNATURES = {
     "nvbx_esdf_dirty_list": (C.c_int, [_vp, _vp, _vp, _i64]),
     "nvbx_mark_esdf_dirty": (C.c_int, [_vp, _vp, _vp, _i64]),
     "nvbx_mark_esdf_dirty_gathered": (C.c_int, [_vp, _vp, _i32, _i32, _i64]),
+    "nvbx_mark_esdf_dirty_gathered_deferred": (C.c_int, [_vp, _vp, _i32, _i32, _i64]),
     "nvbx_set_profiling": (C.c_int, [_vp, _i32]),
     "nvbx_get_profile": (C.c_int, [_vp, C.c_char_p, _i64]),
 }

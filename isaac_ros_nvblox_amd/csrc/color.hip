@@ -125,9 +125,15 @@ __device__ inline uint32_t blend_u8(float c0, float w0, float c1, float w1) {
 // do not queue for a CU slot behind the resident batch of colour workgroups); the n_color_wg after them integrate colour.
 template <typename Pix>
 __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rgb, const float* synth, int32_t srows, int32_t scols,
-                                                         int32_t mesh_list, int32_t n_mark_wg, EsdfArgs ea) {
+                                                         int32_t mesh_list, int32_t n_mark_wg, EsdfArgs ea, ImportArgs imp) {
   if ((int32_t)blockIdx.x < n_mark_wg) {
-    if (threadIdx.x < 64) esdf_mark_worker(m, ea, (int)blockIdx.x, n_mark_wg);
+    if (threadIdx.x < 64) {
+      // workers [0, n_own) re-mark the mapper's own dirty blocks, workers [n_own, n_mark_wg) the peers' gathered lists
+      // (multi-GPU union step held back by nvbx_mark_esdf_dirty_gathered_deferred); one marking pass, one column stamp
+      const int32_t n_own = n_mark_wg - imp.n_wg;
+      if ((int32_t)blockIdx.x < n_own) esdf_mark_worker(m, ea, (int)blockIdx.x, n_own);
+      else esdf_import_mark_worker(m, ea, imp, (int)blockIdx.x - n_own);
+    }
     return;
   }
   const int32_t wg = (int32_t)blockIdx.x - n_mark_wg, n_color_wg = (int32_t)gridDim.x - n_mark_wg;
@@ -248,11 +254,19 @@ static int integrate_color_impl(nvbx_mapper* m, Pix rgb_dev, int32_t rows, int32
   // workers): it reads only the TSDF, like the colour pass, and a following updateEsdf then needs the EDT kernel only
   int mark_wg = 0;
   EsdfArgs ea = m->make_esdf_args();
-  if (m->p.esdf_mode == 0 && m->dirty_since_mark && !m->premark_consumed && ea.bz_hi >= ea.bz_lo && ea.bz_hi - ea.bz_lo + 1 <= 63) {
-    m->mark_pass++; ea.mark_pass = m->mark_pass; mark_wg = 256;
-    m->dirty_since_mark = false; m->premark_consumed = true; m->unresolved_marks = true;
+  ImportArgs imp{};
+  const bool own = m->p.esdf_mode == 0 && m->dirty_since_mark && !m->premark_consumed && ea.bz_hi >= ea.bz_lo && ea.bz_hi - ea.bz_lo + 1 <= 63;
+  if (own || m->import_pending) {
+    m->mark_pass++; ea.mark_pass = m->mark_pass; m->unresolved_marks = true;
+    if (own) { mark_wg = 256; m->dirty_since_mark = false; m->premark_consumed = true; }
+    if (m->import_pending) {             // (only ever set in 2-D mode with a valid band: nvbx_mark_esdf_dirty_gathered_deferred)
+      imp.g = m->import_ptr; imp.world = m->import_world; imp.self_rank = m->import_rank; imp.max_count = m->import_max;
+      { const int n_peers = std::max(1, (m->import_rank >= 0 && m->import_rank < m->import_world) ? m->import_world - 1 : m->import_world);
+        imp.n_wg = n_peers * std::max(32, std::min(256, 1024 / n_peers)); }       // ~one list entry per worker at a few hundred blocks per peer
+      mark_wg += imp.n_wg; m->import_pending = false;
+    }
   }
-  NVBX_LAUNCH(m, (k_integrate_color<Pix>), dim3(grid + mark_wg), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->mesh_list_live(), (int32_t)mark_wg, ea);
+  NVBX_LAUNCH(m, (k_integrate_color<Pix>), dim3(grid + mark_wg), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->mesh_list_live(), (int32_t)mark_wg, ea, imp);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }

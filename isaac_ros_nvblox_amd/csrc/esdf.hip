@@ -41,6 +41,7 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
     if (m->join_side()) return NVBX_E_DEVICE;
     return m->update_esdf_3d();
   }
+  if (m->flush_import()) return NVBX_E_DEVICE;     // a held-back union step belongs to this update
   if (m->dirty_since_mark) m->mark_pass++;
   const EsdfArgs a = m->make_esdf_args();
   if (m->p.esdf_max_distance_m / m->p.voxel_size >= 64.0f) { set_error("esdf_max_distance_m / voxel_size must be < 64 voxels"); return NVBX_E_INVALID; }
@@ -271,11 +272,36 @@ __global__ void k_import_dirty_gathered(DMap m, const int32_t* g, int32_t self_r
     if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)s);
   }
 }
+// 2-D ESDF: lookup AND site marking of every peer's blocks in one launch (one wavefront per list entry, blockIdx.y = rank): the
+// block is re-marked on the spot, exactly as a marking pass would after finding it on the dirty list, so the ESDF update that
+// follows needs no marking launch of its own for the peers' lists (and no list reset before them).
+__global__ __launch_bounds__(64) void k_import_mark_gathered(DMap m, EsdfArgs a, const int32_t* g, int32_t self_rank, int64_t max_count) {
+  const int32_t r = (int32_t)blockIdx.y;
+  if (r == self_rank) return;
+  const int32_t* base = g + (size_t)r * (size_t)(max_count + 1) * 3;
+  int64_t n = base[0]; if (n > max_count) n = max_count;
+  const int32_t* idx = base + 3;
+  const int srec = S_ESDF_REC + (int)(a.epoch & 1), sh = my_shard();
+  for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const uint32_t s = find_slot(m, idx[3 * i], idx[3 * i + 1], idx[3 * i + 2], F_TSDF);        // (uniform: every lane asks the same)
+    if (!slot_ok(s)) continue;
+    esdf_mark_entry(m, a, s, srec, sh);
+  }
+}
 extern "C" int nvbx_mark_esdf_dirty_gathered(nvbx_mapper* m, const int32_t* gathered_dev, int32_t world, int32_t self_rank, int64_t max_count) {
   if (!m || !gathered_dev || world < 1 || max_count < 0) return NVBX_E_INVALID;
   if (m->join_side()) return NVBX_E_DEVICE;
-  if (m->begin_dirtying()) return NVBX_E_DEVICE;
-  if (world > 1 || self_rank < 0) NVBX_LAUNCH(m, k_import_dirty_gathered, dim3(16, (unsigned)world), dim3(256), m->d, gathered_dev, self_rank, max_count);
+  if (!(world > 1 || self_rank < 0)) return NVBX_OK;
+  const EsdfArgs probe = m->make_esdf_args();
+  if (m->p.esdf_mode == 0 && probe.bz_hi >= probe.bz_lo && probe.bz_hi - probe.bz_lo + 1 <= 63) {
+    m->mark_pass++;
+    const EsdfArgs a = m->make_esdf_args();
+    m->unresolved_marks = true;                    // (a marking pass that no distance transform has followed yet)
+    NVBX_LAUNCH(m, k_import_mark_gathered, dim3(256, (unsigned)world), dim3(64), m->d, a, gathered_dev, self_rank, max_count);
+  } else {
+    if (m->begin_dirtying()) return NVBX_E_DEVICE;
+    NVBX_LAUNCH(m, k_import_dirty_gathered, dim3(16, (unsigned)world), dim3(256), m->d, gathered_dev, self_rank, max_count);
+  }
   NVBX_HIP(hipGetLastError());
   return m->mark_main();
 }
@@ -329,6 +355,31 @@ int nvbx_mapper::undo_marks() {
               (int32_t)(S_ESDF_REC + (int)(a.epoch & 1)), a.vz_out);
   NVBX_HIP(hipGetLastError());
   unresolved_marks = false; dirty_since_mark = true;
+  return NVBX_OK;
+}
+
+// Deferred form of the union step: remembered, and performed by extra workgroups of the next integrateColor launch (beside the
+// marking of the mapper's own dirty blocks, same marking pass) -- or by flush_import() if any other entry point comes first.
+// The gathered buffer must stay valid and unchanged until then.
+extern "C" int nvbx_mark_esdf_dirty_gathered_deferred(nvbx_mapper* m, const int32_t* gathered_dev, int32_t world, int32_t self_rank, int64_t max_count) {
+  if (!m || !gathered_dev || world < 1 || max_count < 0) return NVBX_E_INVALID;
+  if (m->flush_import()) return NVBX_E_DEVICE;                   // at most one held-back union step
+  if (!(world > 1 || self_rank < 0)) return NVBX_OK;
+  const EsdfArgs probe = m->make_esdf_args();
+  if (!(m->p.esdf_mode == 0 && probe.bz_hi >= probe.bz_lo && probe.bz_hi - probe.bz_lo + 1 <= 63))
+    return nvbx_mark_esdf_dirty_gathered(m, gathered_dev, world, self_rank, max_count);
+  m->import_pending = true; m->import_ptr = gathered_dev; m->import_world = world; m->import_rank = self_rank; m->import_max = max_count;
+  return NVBX_OK;
+}
+int nvbx_mapper::flush_import() {
+  if (!import_pending) return NVBX_OK;
+  import_pending = false;
+  if (flush_edt()) return NVBX_E_DEVICE;                         // the EDT of the previous update reads the masks this marking overwrites
+  mark_pass++;
+  const EsdfArgs a = make_esdf_args();
+  unresolved_marks = true;
+  NVBX_LAUNCH(this, k_import_mark_gathered, dim3(256, (unsigned)import_world), dim3(64), d, a, import_ptr, import_rank, import_max);
+  NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }
 

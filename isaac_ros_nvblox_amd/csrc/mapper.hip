@@ -200,7 +200,7 @@ static int reset_map(nvbx_mapper* m) {
   const int64_t n = std::max<int64_t>(cap, std::max<int64_t>(C_NUM, S_NUM * NSH * SH_STRIDE));
   NVBX_LAUNCH(m, k_init_map, dim3((unsigned)((n + 255) / 256)), dim3(256), d);
   NVBX_HIP(hipGetLastError());
-  m->dirty_since_mark = false; m->premark_consumed = false; m->mark_pass = 0; m->edt_pending = false;
+  m->dirty_since_mark = false; m->premark_consumed = false; m->mark_pass = 0; m->edt_pending = false; m->import_pending = false;
   m->unresolved_marks = false; m->pass_at_last_edt = 0;
   m->frame_id = 0; m->esdf_epoch = 0; m->mesh_epoch = 0; m->last_view_frame = 0; m->synth_rows = m->synth_cols = 0;
   return NVBX_OK;
@@ -611,6 +611,7 @@ int nvbx_mapper::reset_consumed_list() {
 }
 int nvbx_mapper::join_side() {
   if (flush_edt()) return NVBX_E_DEVICE;
+  if (flush_import()) return NVBX_E_DEVICE;
   main_dirty = true;
   if (side_pending) { NVBX_HIP(hipStreamWaitEvent(stream, ev_side, 0)); side_pending = false; }
   return NVBX_OK;

@@ -8,83 +8,104 @@ namespace nvbx {
 
 // Dependent-access chain: {shard counts of the dirty list} -> {dirty slot} -> {flags, Index3D} -> {hash entries of the ESDF block and of the
 // TSDF z-band blocks, one per lane, in flight together} -> {column stamp exchange || TSDF column loads} -> store.
-// `wg` of `nwg` single-wavefront workers; called by k_esdf_mark and by the marking workgroups fused into k_integrate_color.
-__device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg, int nwg) {
+// One list entry (one wavefront): re-mark the ESDF column of TSDF slot `tslot` (or of the ESDF slot itself if it is flagged REMARK).
+__device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_t tslot, int srec, int sh) {
   const int lane = threadIdx.x & 63;
   const int vx = lane & 7, vy = lane >> 3;
-  ListView lv;
-  const int32_t n = list_open(m, S_LIST_ESDF_DIRTY, &lv);
   const int nz = a.bz_hi - a.bz_lo + 1;                    // TSDF blocks spanned by the slice z band (<= 62)
-  const int srec = S_ESDF_REC + (int)(a.epoch & 1), sh = my_shard();
-  for (int32_t i = wg; i < n; i += nwg) {
-    const uint32_t tslot = (uint32_t)list_at(m, S_LIST_ESDF_DIRTY, lv, i);
-    const uint32_t tflags = m.slot_flags[tslot];
-    const int32_t bx = m.slot_index[3 * tslot], by = m.slot_index[3 * tslot + 1], bz = m.slot_index[3 * tslot + 2];
-    if (lane == 0) { atomicAnd(&m.slot_flags[tslot], ~F_DIRTY_ESDF); m.slot_consumed[tslot] = a.mark_pass; }
-    // a dirty TSDF block of the z band dirties its column; an ESDF slot flagged F_ESDF_REMARK (a TSDF block of its band was
-    // deallocated by decay) re-marks its own column
-    if (!(tflags & F_ESDF_REMARK) && (bz < a.bz_lo || bz > a.bz_hi)) continue;
-    // lane 0: the ESDF block (x, y, z_slice); lanes 1..nz: the TSDF blocks of the band -- one probe each, together
-    const int32_t qz = lane == 0 ? a.bz_out : a.bz_lo + lane - 1;
-    const bool probing = lane <= nz;
-    const u64 qkey = pack_key(bx, by, qz);
-    const uint32_t qh = probing ? table_pos(m, bx, by, qz) : 0u;
-    const uint4 qe = ld_entry(m, qh);
-    uint32_t qslot = probing ? resolve_any(m, qkey, qh, qe) : SLOT_NONE;
-    uint32_t eslot = __shfl(qslot, 0);
-    const bool e_exists = slot_ok(eslot) && (m.slot_flags[slot_ok(eslot) ? eslot : 0] & (F_ESDF | F_ESDF_PENDING));
-    if (!(tflags & F_TSDF) && !(e_exists && (tflags & F_ESDF_REMARK))) continue;          // uniform
-    int first = 0;
-    if (lane == 0) {
-      if (!slot_ok(eslot)) {                                // new column: insert (device-side allocation)
-        bool is_new;
-        const int32_t h = hash_insert(m, bx, by, a.bz_out, F_ESDF_PENDING, &is_new);
-        if (h >= 0) { do { eslot = ld_slot_acquire(&m.table[h]); } while (eslot == SLOT_INVALID); }
-      }
-      if (slot_ok(eslot)) {
-        if (!e_exists) atomicOr(&m.slot_flags[eslot], F_ESDF_PENDING);   // joins the ESDF layer when the EDT of this update runs
-        first = atomicExch(&m.slot_stamp[eslot], a.mark_pass) != a.mark_pass;
-      }
+  const uint32_t tflags = m.slot_flags[tslot];
+  const int32_t bx = m.slot_index[3 * tslot], by = m.slot_index[3 * tslot + 1], bz = m.slot_index[3 * tslot + 2];
+  if (lane == 0) { atomicAnd(&m.slot_flags[tslot], ~F_DIRTY_ESDF); m.slot_consumed[tslot] = a.mark_pass; }
+  // a dirty TSDF block of the z band dirties its column; an ESDF slot flagged F_ESDF_REMARK (a TSDF block of its band was
+  // deallocated by decay) re-marks its own column
+  if (!(tflags & F_ESDF_REMARK) && (bz < a.bz_lo || bz > a.bz_hi)) return;
+  // lane 0: the ESDF block (x, y, z_slice); lanes 1..nz: the TSDF blocks of the band -- one probe each, together
+  const int32_t qz = lane == 0 ? a.bz_out : a.bz_lo + lane - 1;
+  const bool probing = lane <= nz;
+  const u64 qkey = pack_key(bx, by, qz);
+  const uint32_t qh = probing ? table_pos(m, bx, by, qz) : 0u;
+  const uint4 qe = ld_entry(m, qh);
+  uint32_t qslot = probing ? resolve_any(m, qkey, qh, qe) : SLOT_NONE;
+  uint32_t eslot = __shfl(qslot, 0);
+  const bool e_exists = slot_ok(eslot) && (m.slot_flags[slot_ok(eslot) ? eslot : 0] & (F_ESDF | F_ESDF_PENDING));
+  if (!(tflags & F_TSDF) && !(e_exists && (tflags & F_ESDF_REMARK))) return;          // uniform
+  int first = 0;
+  if (lane == 0) {
+    if (!slot_ok(eslot)) {                                // new column: insert (device-side allocation)
+      bool is_new;
+      const int32_t h = hash_insert(m, bx, by, a.bz_out, F_ESDF_PENDING, &is_new);
+      if (h >= 0) { do { eslot = ld_slot_acquire(&m.table[h]); } while (eslot == SLOT_INVALID); }
     }
-    // TSDF columns of the band: this lane's (x, y) column of block bzz is voxels 64*vx + 8*vy + 0..7 = 64 contiguous bytes
-    // (weight 0 -- also what a slot without a TSDF block reads -- contributes nothing)
-    int observed = 0, inside = 0, site = 0;
-    for (int32_t q = 0; q < nz; ++q) {
-      const uint32_t ts = __shfl(qslot, q + 1);
-      if (!slot_ok(ts)) continue;                           // uniform
-      const int32_t bzz = a.bz_lo + q;
-      const float4* col = reinterpret_cast<const float4*>(&m.tsdf[(size_t)ts * 512 + 64 * vx + 8 * vy]);
-      float dz[8], wz[8];
-#pragma unroll
-      for (int w = 0; w < 4; w++) { const float4 v = col[w]; dz[2 * w] = v.x; wz[2 * w] = v.y; dz[2 * w + 1] = v.z; wz[2 * w + 1] = v.w; }
-#pragma unroll
-      for (int z = 0; z < 8; z++) {
-        const int32_t kz = bzz * 8 + z;
-        if (kz < a.kz_min || kz > a.kz_max) continue;
-        if (a.site_rule == 2) {          // occupancy layer {log_odds, -}: [U] OccupancySiteFunctor -- known iff log-odds != 0, site = inside = occupied (p > 0.5)
-          if (dz[z] != 0.0f) observed = 1;
-          if (dz[z] > 0.0f) { inside = 1; site = 1; }
-        } else if (wz[z] >= a.min_weight) {
-          observed = 1;
-          const int in = dz[z] <= 0.0f;
-          if (in) inside = 1;
-          if ((a.site_rule == 1 || in) && fabsf(dz[z]) <= a.site_dist_m) site = 1;
-        }
-      }
+    if (slot_ok(eslot)) {
+      if (!e_exists) atomicOr(&m.slot_flags[eslot], F_ESDF_PENDING);   // joins the ESDF layer when the EDT of this update runs
+      first = atomicExch(&m.slot_stamp[eslot], a.mark_pass) != a.mark_pass;
     }
-    eslot = __shfl(eslot, 0); first = __shfl(first, 0);
-    if (!first || !slot_ok(eslot)) continue;                // column already re-marked in this marking pass
-    if (lane == 0) {                                         // window record: this workgroup's shard copy
-      atomicMin(shc_at(m, srec, sh, 0), bx); atomicMin(shc_at(m, srec, sh, 1), by);
-      atomicMax(shc_at(m, srec, sh, 2), bx); atomicMax(shc_at(m, srec, sh, 3), by);
-      atomicAdd(shc_at(m, srec, sh, 4), 1);
-    }
-    // the column's masks (bit x + 8y of the block's slice plane); the voxels themselves are written by the EDT only, so a
-    // marking pass changes nothing the API can observe
-    const u64 sbits = __ballot(site != 0), obits = __ballot(observed != 0), ibits = __ballot(inside != 0);
-    if (lane == 0) { m.site_bits[eslot] = sbits; m.obs_bits[eslot] = obits; m.inside_bits[eslot] = ibits; }
   }
+  // TSDF columns of the band: this lane's (x, y) column of block bzz is voxels 64*vx + 8*vy + 0..7 = 64 contiguous bytes
+  // (weight 0 -- also what a slot without a TSDF block reads -- contributes nothing)
+  int observed = 0, inside = 0, site = 0;
+  for (int32_t q = 0; q < nz; ++q) {
+    const uint32_t ts = __shfl(qslot, q + 1);
+    if (!slot_ok(ts)) continue;                           // uniform
+    const int32_t bzz = a.bz_lo + q;
+    const float4* col = reinterpret_cast<const float4*>(&m.tsdf[(size_t)ts * 512 + 64 * vx + 8 * vy]);
+    float dz[8], wz[8];
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const float4 v = col[w]; dz[2 * w] = v.x; wz[2 * w] = v.y; dz[2 * w + 1] = v.z; wz[2 * w + 1] = v.w; }
+#pragma unroll
+    for (int z = 0; z < 8; z++) {
+      const int32_t kz = bzz * 8 + z;
+      if (kz < a.kz_min || kz > a.kz_max) continue;
+      if (a.site_rule == 2) {          // occupancy layer {log_odds, -}: [U] OccupancySiteFunctor -- known iff log-odds != 0, site = inside = occupied (p > 0.5)
+        if (dz[z] != 0.0f) observed = 1;
+        if (dz[z] > 0.0f) { inside = 1; site = 1; }
+      } else if (wz[z] >= a.min_weight) {
+        observed = 1;
+        const int in = dz[z] <= 0.0f;
+        if (in) inside = 1;
+        if ((a.site_rule == 1 || in) && fabsf(dz[z]) <= a.site_dist_m) site = 1;
+      }
+    }
+  }
+  eslot = __shfl(eslot, 0); first = __shfl(first, 0);
+  if (!first || !slot_ok(eslot)) return;                // column already re-marked in this marking pass
+  if (lane == 0) {                                         // window record: this workgroup's shard copy
+    atomicMin(shc_at(m, srec, sh, 0), bx); atomicMin(shc_at(m, srec, sh, 1), by);
+    atomicMax(shc_at(m, srec, sh, 2), bx); atomicMax(shc_at(m, srec, sh, 3), by);
+    atomicAdd(shc_at(m, srec, sh, 4), 1);
+  }
+  // the column's masks (bit x + 8y of the block's slice plane); the voxels themselves are written by the EDT only, so a
+  // marking pass changes nothing the API can observe
+  const u64 sbits = __ballot(site != 0), obits = __ballot(observed != 0), ibits = __ballot(inside != 0);
+  if (lane == 0) { m.site_bits[eslot] = sbits; m.obs_bits[eslot] = obits; m.inside_bits[eslot] = ibits; }
 }
 
+// `wg` of `nwg` single-wavefront workers; called by k_esdf_mark and by the marking workgroups fused into k_integrate_color.
+__device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg, int nwg) {
+  ListView lv;
+  const int32_t n = list_open(m, S_LIST_ESDF_DIRTY, &lv);
+  const int srec = S_ESDF_REC + (int)(a.epoch & 1), sh = my_shard();
+  for (int32_t i = wg; i < n; i += nwg) esdf_mark_entry(m, a, (uint32_t)list_at(m, S_LIST_ESDF_DIRTY, lv, i), srec, sh);
+}
+
+// The peers' gathered dirty lists (multi-GPU union step): g = int32 [world][1 + max_count][3], row 0 of a rank = its count.
+struct ImportArgs { const int32_t* g; int32_t world, self_rank; int64_t max_count; int32_t n_wg; };
+// worker `w` of imp.n_wg single-wavefront workers over all peers' entries: look the block up, re-mark its column on the spot
+__device__ inline void esdf_import_mark_worker(const DMap& m, const EsdfArgs& a, const ImportArgs& imp, int w) {
+  const int srec = S_ESDF_REC + (int)(a.epoch & 1), sh = my_shard();
+  const int n_peers = imp.self_rank >= 0 && imp.self_rank < imp.world ? imp.world - 1 : imp.world;
+  const int per_rank = max(1, imp.n_wg / max(1, n_peers));       // workers are dealt to the peers in turn
+  const int peer = w / per_rank, wi = w - peer * per_rank;
+  if (peer >= n_peers) return;
+  const int32_t r = (n_peers < imp.world && peer >= imp.self_rank) ? peer + 1 : peer;  // skip the own rank
+  const int32_t* base = imp.g + (size_t)r * (size_t)(imp.max_count + 1) * 3;
+  int64_t n = base[0]; if (n > imp.max_count) n = imp.max_count;
+  const int32_t* idx = base + 3;
+  for (int64_t i = wi; i < n; i += per_rank) {
+    const uint32_t s = find_slot(m, idx[3 * i], idx[3 * i + 1], idx[3 * i + 2], F_TSDF);
+    if (!slot_ok(s)) continue;
+    esdf_mark_entry(m, a, s, srec, sh);
+  }
+}
 
 }  // namespace nvbx

@@ -85,6 +85,10 @@ struct nvbx_mapper {
   // held-back EDT of the last updateEsdf (NVBX_DEFER_EDT=0 disables): see nvbx_update_esdf
   bool defer_edt = true, edt_pending = false; nvbx::EsdfArgs edt_args{};
   int flush_edt();
+  // held-back union step of the multi-GPU exchange (nvbx_mark_esdf_dirty_gathered_deferred): rides in the next integrateColor
+  // launch beside the marking of the mapper's own dirty blocks; every other entry point launches it first (flush_import)
+  bool import_pending = false; const int32_t* import_ptr = nullptr; int32_t import_world = 0, import_rank = 0; int64_t import_max = 0;
+  int flush_import();
   int reset_consumed_list();         // empty a consumed dirty list (tiny launch; rare paths only)
   int begin_dirtying() { const int rc = reset_consumed_list(); dirty_since_mark = true; return rc; }
   uint32_t mesh_epoch = 0;

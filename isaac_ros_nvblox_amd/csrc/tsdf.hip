@@ -503,8 +503,10 @@ __global__ void k_dilate_invalid(Img in, int32_t rows, int32_t cols, int32_t n, 
 template <typename Img>
 static int integrate_camera(nvbx_mapper* m, Img img, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera) {
   NVBX_HIP(hipSetDevice(m->device));
-  { const bool pend = m->edt_pending; m->edt_pending = false;       // (join_side would launch a held-back EDT; it rides in k_mark_view instead)
-    const int rc = m->join_side(); m->edt_pending = pend; if (rc) return NVBX_E_DEVICE; }
+  { const bool pend = m->edt_pending, ipend = m->import_pending; m->edt_pending = false; m->import_pending = false;
+    // (join_side would launch a held-back EDT / union step; the EDT rides in k_mark_view instead, the union step stays held back
+    //  for the next integrateColor -- it belongs to the NEXT ESDF update and touches nothing this launch reads)
+    const int rc = m->join_side(); m->edt_pending = pend; m->import_pending = ipend; if (rc) return NVBX_E_DEVICE; }
   if (m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0 && m->flush_edt()) return NVBX_E_DEVICE;   // first launch is the dilation
   m->frame_id++;
   const Frame f = m->make_frame(T_L_C, camera, rows, cols, m->p.raycast_subsampling_factor);

@@ -42,12 +42,16 @@ class DirtyBlockExchange:
         mapper.esdf_dirty_list(self.idx, self.cnt)
         return self.all_gather(async_op=True)
 
-    def finish(self, mapper, work):
-        """Join the all-gather, then mark every peer's blocks ESDF-dirty locally (count read on the device)."""
+    def finish(self, mapper, work, deferred=False):
+        """Join the all-gather, then mark every peer's blocks ESDF-dirty locally (count read on the device).  deferred: the
+        marking rides in the mapper's next integrate_color launch instead of a launch of its own."""
         if work is not None:
             work.wait()
         if self.world > 1:      # one launch for all peers' lists (not one per peer)
-            mapper.mark_esdf_dirty_gathered(self.all_buf, self.world, self.rank, self.max_blocks)
+            if deferred:
+                mapper.mark_esdf_dirty_gathered(self.all_buf, self.world, self.rank, self.max_blocks, deferred=True)
+            else:
+                mapper.mark_esdf_dirty_gathered(self.all_buf, self.world, self.rank, self.max_blocks)
 
     def exchange(self, mapper):
         self.finish(mapper, self.start(mapper))
@@ -82,11 +86,12 @@ class PipelinedDirtyBlockExchange:
         self.started = (slot, slot.start(mapper))
         self.frame += 1
 
-    def finish_previous(self, mapper):
-        """Before updateEsdf of the current frame: apply the PREVIOUS frame's gathered lists; the current frame's stay in flight."""
+    def finish_previous(self, mapper, deferred=False):
+        """Between integrateDepth and updateEsdf of the current frame: apply the PREVIOUS frame's gathered lists; the current
+        frame's stay in flight.  deferred=True (call it BEFORE integrateColor): the marking rides in that colour launch."""
         if self.pending is not None:
             slot, work = self.pending
-            slot.finish(mapper, work)
+            slot.finish(mapper, work, deferred=deferred)
         self.pending, self.started = self.started, None
 
     def drain(self, mapper):

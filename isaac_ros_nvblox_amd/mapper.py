@@ -408,9 +408,11 @@ class Mapper:
     def mark_esdf_dirty(self, idx_tensor, count_tensor, max_count):
         self._check(self.lib.nvbx_mark_esdf_dirty(self._h, C.c_void_p(idx_tensor.data_ptr()), C.c_void_p(count_tensor.data_ptr()), int(max_count)))
 
-    def mark_esdf_dirty_gathered(self, gathered, world, self_rank, max_count):
-        """gathered: int32 device tensor [world, 1 + max_count, 3] (row 0 = count); one launch for all peers."""
-        self._check(self.lib.nvbx_mark_esdf_dirty_gathered(self._h, C.c_void_p(gathered.data_ptr()), int(world), int(self_rank), int(max_count)))
+    def mark_esdf_dirty_gathered(self, gathered, world, self_rank, max_count, deferred=False):
+        """gathered: int32 device tensor [world, 1 + max_count, 3] (row 0 = count); one launch for all peers -- or, deferred,
+        no launch at all: the next integrate_color carries it (the tensor must stay alive and unchanged until then)."""
+        fn = self.lib.nvbx_mark_esdf_dirty_gathered_deferred if deferred else self.lib.nvbx_mark_esdf_dirty_gathered
+        self._check(fn(self._h, C.c_void_p(gathered.data_ptr()), int(world), int(self_rank), int(max_count)))
 
     # -- instrumentation
     def set_profiling(self, enable):

@@ -74,7 +74,7 @@ class _StubMapper:
         idx_out[:n] = torch.tensor([[self.rank, self.frame, k] for k in range(n)], dtype=torch.int32)
         count_out[0] = n
 
-    def mark_esdf_dirty_gathered(self, gathered, world, self_rank, max_count):
+    def mark_esdf_dirty_gathered(self, gathered, world, self_rank, max_count, deferred=False):
         got = []
         for r in range(world):
             if r == self_rank:
@@ -90,10 +90,10 @@ def _pipelined_worker(rank, world, port, q):
     ex = PipelinedDirtyBlockExchange(16, torch.device("cpu"))
     m = _StubMapper(rank)
     n_frames = 5
-    for f in range(n_frames):           # bench.py's step: depth, start, colour, finish_previous, updateEsdf
+    for f in range(n_frames):           # bench.py's step: depth, start, finish_previous (deferred), colour, updateEsdf
         m.frame = f
         ex.start(m)
-        ex.finish_previous(m)
+        ex.finish_previous(m, deferred=True)
     ex.drain(m)
     peer = 1 - rank
     want = [[(peer, f, k) for k in range(3 + peer + (f % 2))] for f in range(n_frames)]

@@ -17,10 +17,12 @@ def test_dirty_list_exchange_matches_oracle(oracle_mod, hip_lib):
     os_ = [oracle_mod.OracleMap(po) for _ in range(2)]
     dev = torch.device("cuda", 0)
     exs = [DirtyBlockExchange(4096, dev) for _ in range(2)]
-    for step in range(3):
+    colour = {}
+    for step in range(4):
         for r in range(2):
-            d, rgb, T = H.frames(1, H.SMALL_CAM, start=step * 12, color=False, yaw_offset_deg=45.0 * r)[0]
+            d, rgb, T = H.frames(1, H.SMALL_CAM, start=step * 12, color=True, yaw_offset_deg=45.0 * r)[0]
             gs[r].integrate_depth(d, T, H.SMALL_CAM); os_[r].integrate_depth(d, T, H.SMALL_CAM)
+            colour[r] = (rgb, T)
         # export
         lists = []
         for r in range(2):
@@ -33,11 +35,16 @@ def test_dirty_list_exchange_matches_oracle(oracle_mod, hip_lib):
         # union: each mapper marks the peer's list
         for r in range(2):
             p = 1 - r
-            if step % 2 == 0:
+            if step == 0:
                 gs[r].mark_esdf_dirty(exs[p].idx, exs[p].cnt, 4096)
-            else:      # the one-launch form bench.py uses: a 2-rank gathered buffer, own rank skipped
+            elif step == 1:      # one launch for all peers: a 2-rank gathered buffer, own rank skipped; lookup + marking fused
                 gathered = torch.stack([exs[0].buf, exs[1].buf])
                 gs[r].mark_esdf_dirty_gathered(gathered, 2, r, 4096)
+            else:                # the form bench.py uses: held back, carried by the next integrateColor launch (step 2) or
+                gathered = torch.stack([exs[0].buf, exs[1].buf])     # launched first thing by updateEsdf (step 3: no colour frame)
+                gs[r].mark_esdf_dirty_gathered(gathered, 2, r, 4096, deferred=True)
+                if step == 2:
+                    gs[r].integrate_color(colour[r][0], colour[r][1], H.SMALL_CAM); os_[r].integrate_color(colour[r][0], colour[r][1], H.SMALL_CAM)
             os_[r].mark_esdf_dirty(lists[p])
             gs[r].update_esdf(); os_[r].update_esdf()
             ig, ag = gs[r].esdf_slice_image(1000.0); io, ao = os_[r].esdf_slice_image(1000.0)
