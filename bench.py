@@ -164,6 +164,8 @@ def main():
     def step(i, mesh=False, exchange=True):
         k = i % nu
         xg = ex if exchange else None            # rank-0-only passes after the timed region must not enter a collective
+        if xg is not None:
+            xg.before_depth(g)                   # the depth pass writes this frame's block indices into the exchange buffer itself
         g.integrate_prepared(dargs[k])          # MultiMapper::integrateDepth
         if xg is not None:
             xg.start(g)                          # dirty block indices: export + async RCCL all-gather (needs only the depth pass)
@@ -176,6 +178,7 @@ def main():
     def barrier():
         if ex is not None:
             ex.drain(g)          # the all-gather still in flight is joined and applied inside the timed region
+            g.set_view_export(None)
         g.synchronize()          # launches anything the mapper holds back (the EDT of the last updateEsdf) and waits for its stream
         torch.cuda.synchronize(dev)
         if world > 1:

@@ -310,6 +310,11 @@ int nvbx_mesh_copy(nvbx_mapper* m, nvbx_index3d* block_indices, int32_t* vertex_
                    int32_t* triangle_offsets /* n_blocks+1 */, float* vertices, float* normals, uint8_t* colors,
                    int32_t* triangles);
 
+/* The exchange message without an export launch: once a buffer is registered (host state only), every nvbx_integrate_depth /
+ * _lidar_depth also writes the Index3D of the blocks it updates into it -- int32 [1 + capacity][3], row 0 = {count, 0, 0} -- from
+ * inside its TSDF-update launch.  (The blocks of THIS depth frame; nvbx_esdf_dirty_list also covers decay / clearing / set_block.)
+ * NULL unregisters.  The buffer must stay valid while registered. */
+int nvbx_set_view_export(nvbx_mapper* m, int32_t* packed_dev, int64_t capacity);
 /* ---- multi-GPU (one camera per GPU, all-gather of updated block indices before the ESDF sweep) -----
  * nvbx_esdf_dirty_list writes the Index3D of the TSDF blocks dirtied since the last updateEsdf into caller-owned
  * device buffers (indices int32[capacity][3], count int32[1], clamped to capacity) -- asynchronous, no host copy.

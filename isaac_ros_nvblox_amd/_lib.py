@@ -93,6 +93,7 @@ SIGNATURES = {
     "nvbx_synchronize": (C.c_int, [_vp]),
     "nvbx_flush": (C.c_int, [_vp]),
     "nvbx_decay_occupancy": (C.c_int, [_vp]),
+    "nvbx_set_view_export": (C.c_int, [_vp, _vp, _i64]),
     "nvbx_split_depth_by_mask": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, C.POINTER(Camera), C.POINTER(Camera), C.c_float, _vp, _vp, _vp]),
     "nvbx_split_color_by_mask": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "nvbx_default_params": (None, [C.POINTER(Params)]),

@@ -239,6 +239,13 @@ extern "C" int nvbx_esdf_dirty_list(nvbx_mapper* m, int32_t* indices_dev_out, in
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }
+// Registration only (no launch): every following integrateDepth writes the Index3D of the blocks it updates, packed as
+// int32 [1 + capacity][3] with row 0 = {count, 0, 0}, into this caller-owned device buffer (NULL: off).
+extern "C" int nvbx_set_view_export(nvbx_mapper* m, int32_t* packed_dev, int64_t capacity) {
+  if (!m || capacity < 0) return NVBX_E_INVALID;
+  m->view_export = packed_dev; m->view_export_cap = packed_dev ? std::min<int64_t>(capacity, m->capacity) : 0;
+  return NVBX_OK;
+}
 // Union step after the all-gather: blocks another GPU updated that exist locally as TSDF blocks become ESDF-dirty here.
 __global__ void k_import_dirty(DMap m, const int32_t* idx, const int32_t* count, int64_t max_count) {
   int64_t n = *count; if (n > max_count) n = max_count;

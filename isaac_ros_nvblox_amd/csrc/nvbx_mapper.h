@@ -89,6 +89,7 @@ struct nvbx_mapper {
   // launch beside the marking of the mapper's own dirty blocks; every other entry point launches it first (flush_import)
   bool import_pending = false; const int32_t* import_ptr = nullptr; int32_t import_world = 0, import_rank = 0; int64_t import_max = 0;
   int flush_import();
+  int32_t* view_export = nullptr; int64_t view_export_cap = 0;      // nvbx_set_view_export
   int reset_consumed_list();         // empty a consumed dirty list (tiny launch; rare paths only)
   int begin_dirtying() { const int rc = reset_consumed_list(); dirty_since_mark = true; return rc; }
   uint32_t mesh_epoch = 0;

@@ -413,15 +413,19 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, Frame f,
 // and the flag / dirty-list atomics of lane 0 are issued first and consumed last.
 template <typename Img, typename Sensor>
 __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img depth, Sensor sensor, const int4* view_list, int32_t list_cap,
-                                                        int32_t mesh_list) {
+                                                        int32_t mesh_list, int32_t* view_export, int32_t view_export_cap) {
   int4 rec = view_list[blockIdx.x];                       // speculative: valid iff blockIdx.x < n (gridDim.x <= list_cap)
   int32_t n = m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
   if (n > list_cap) n = list_cap;
   const int tid = threadIdx.x;
+  // nvbx_set_view_export: the frame's block indices also go to a caller-owned packed buffer [1 + cap][3] (row 0 = count) --
+  // the message of the multi-GPU exchange, written here instead of by an export launch
+  if (view_export && blockIdx.x == 0 && tid == 0) { view_export[0] = min(n, view_export_cap); view_export[1] = 0; view_export[2] = 0; }
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
   for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
     if (i != (int32_t)blockIdx.x) rec = view_list[i];
     const int4 rec_c = rec;
+    if (view_export && tid == 0 && i < view_export_cap) { int32_t* e = view_export + 3 * (1 + (int64_t)i); e[0] = rec_c.y; e[1] = rec_c.z; e[2] = rec_c.w; }
     const uint32_t slot = (uint32_t)rec_c.x;               // pool slot (stable across hash rebuilds)
     if (!slot_ok(slot)) continue;
     float2* vp = &m.tsdf[(size_t)slot * 512 + tid];
@@ -475,7 +479,7 @@ static int integrate_depth_impl(nvbx_mapper* m, Img img, const Sensor& sensor, c
   m->premark_consumed = false; m->dirty_since_mark = true;
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);
   NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor>), dim3(grid), dim3(512), m->d, f, img, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
-                     m->mesh_list_live());
+                     m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap);
   NVBX_HIP(hipGetLastError());
   m->last_view_frame = m->frame_id;
   return m->mark_main();

@@ -37,9 +37,11 @@ class DirtyBlockExchange:
         return dist.all_gather_into_tensor(self.all_buf.view(-1, 3), self.buf, group=self.group, async_op=async_op)
 
     # -- split-phase exchange (bench.py): start after integrateDepth, finish before updateEsdf
-    def start(self, mapper):
-        """Export this GPU's dirty TSDF block indices (device kernel, count stays on the device) and launch the all-gather."""
-        mapper.esdf_dirty_list(self.idx, self.cnt)
+    def start(self, mapper, export=True):
+        """Export this GPU's dirty TSDF block indices (device kernel, count stays on the device) and launch the all-gather.
+        export=False: the mapper has already written the message (Mapper.set_view_export(self.buf) before integrate_depth)."""
+        if export:
+            mapper.esdf_dirty_list(self.idx, self.cnt)
         return self.all_gather(async_op=True)
 
     def finish(self, mapper, work, deferred=False):
@@ -80,10 +82,16 @@ class PipelinedDirtyBlockExchange:
         self.pending = None          # (slot, work) of the frame whose lists have not been applied yet
         self.started = None          # (slot, work) of the current frame
 
+    def before_depth(self, mapper):
+        """Optional, before integrateDepth of the current frame: the depth pass itself writes the message (no export launch)."""
+        mapper.set_view_export(self.slots[self.frame & 1].buf)
+        self.registered = True
+
     def start(self, mapper):
         """After integrateDepth of the current frame."""
         slot = self.slots[self.frame & 1]
-        self.started = (slot, slot.start(mapper))
+        self.started = (slot, slot.start(mapper, export=not getattr(self, "registered", False)))
+        self.registered = False
         self.frame += 1
 
     def finish_previous(self, mapper, deferred=False):

@@ -405,6 +405,15 @@ class Mapper:
         into caller-owned device tensors (async)."""
         self._check(self.lib.nvbx_esdf_dirty_list(self._h, C.c_void_p(idx_out.data_ptr()), C.c_void_p(count_out.data_ptr()), int(idx_out.shape[0])))
 
+    def set_view_export(self, packed_tensor):
+        """Register (or, with None, unregister) an int32 device tensor [1 + cap, 3]: every following integrate_depth writes the indices
+        of the blocks it updates into it (row 0 = count) from inside its own launch.  The tensor must stay alive while registered."""
+        if packed_tensor is None:
+            self._check(self.lib.nvbx_set_view_export(self._h, None, 0)); self._view_export = None
+        else:
+            self._view_export = packed_tensor
+            self._check(self.lib.nvbx_set_view_export(self._h, C.c_void_p(packed_tensor.data_ptr()), int(packed_tensor.shape[0]) - 1))
+
     def mark_esdf_dirty(self, idx_tensor, count_tensor, max_count):
         self._check(self.lib.nvbx_mark_esdf_dirty(self._h, C.c_void_p(idx_tensor.data_ptr()), C.c_void_p(count_tensor.data_ptr()), int(max_count)))
 

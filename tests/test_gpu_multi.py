@@ -18,11 +18,19 @@ def test_dirty_list_exchange_matches_oracle(oracle_mod, hip_lib):
     dev = torch.device("cuda", 0)
     exs = [DirtyBlockExchange(4096, dev) for _ in range(2)]
     colour = {}
+    view_bufs = [torch.zeros((4097, 3), dtype=torch.int32, device=dev) for _ in range(2)]
     for step in range(4):
         for r in range(2):
             d, rgb, T = H.frames(1, H.SMALL_CAM, start=step * 12, color=True, yaw_offset_deg=45.0 * r)[0]
+            if step == 3:
+                gs[r].set_view_export(view_bufs[r])          # the depth pass writes its block list itself (no export launch)
             gs[r].integrate_depth(d, T, H.SMALL_CAM); os_[r].integrate_depth(d, T, H.SMALL_CAM)
             colour[r] = (rgb, T)
+            if step == 3:
+                gs[r].synchronize()
+                nvw = int(view_bufs[r][0, 0].item())
+                assert H.idx_set(view_bufs[r][1:1 + nvw].cpu().numpy()) == H.idx_set(os_[r].last_view()) and nvw == len(os_[r].last_view())
+                gs[r].set_view_export(None)
         # export
         lists = []
         for r in range(2):

@@ -13,15 +13,16 @@ g = M.Mapper(M.default_params(), device=0, block_capacity=1 << 15, stream=stream
 da = [g.prepare_depth(d, T, cam) for d, _, T in fr]; ca = [g.prepare_color(c, T, cam) for _, c, T in fr]
 ex = DirtyBlockExchange(4096, dev)
 gathered = torch.zeros((2, 4097, 3), dtype=torch.int32, device=dev)
-def step(i, mode):  # 0: single GPU; 1: + export; 2: + union step as its own launch; 3: + union step riding in the colour launch
+def step(i, mode):  # 0: single GPU; 1: + export launch; 2: + union step as its own launch; 3: union step riding in the colour launch; 4: 3 with the export written by the depth pass
     k = i % 50
     g.integrate_prepared(da[k])
-    if mode >= 1: g.esdf_dirty_list(ex.idx, ex.cnt)
-    if mode == 3: g.mark_esdf_dirty_gathered(gathered, 2, 0, 4096, deferred=True)
+    if 1 <= mode <= 3: g.esdf_dirty_list(ex.idx, ex.cnt)
+    if mode >= 3: g.mark_esdf_dirty_gathered(gathered, 2, 0, 4096, deferred=True)
     g.integrate_prepared(ca[k])
     if mode == 2: g.mark_esdf_dirty_gathered(gathered, 2, 0, 4096)
     g.update_esdf()
-for mode in (0, 1, 2, 3):
+for mode in (0, 1, 2, 3, 4):
+    g.set_view_export(ex.buf if mode == 4 else None)
     for i in range(30): step(i, min(mode, 1))
     gathered[1].copy_(ex.buf)      # stands in for the all-gather result (the peer's list = an own list: every block exists locally)
     g.synchronize(); torch.cuda.synchronize(); t = time.perf_counter()
