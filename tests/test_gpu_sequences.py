@@ -109,3 +109,41 @@ def test_redwood_like_decay_dynamic_sequence(oracle_mod, hip_lib):
     b, _ = g.get_blocks(M.LAYER_TSDF, idx)
     w = b["weight"][b["weight"] > 0]
     assert (np.abs(w - np.round(w)) > 1e-3).mean() > 0.5
+
+
+def test_long_soak_parity(oracle_mod, hip_lib):
+    """400 frames of a wandering camera with colour, an ESDF update every 3rd frame, decay every 7th, radius clearing every 40th and
+    a mesh update every 25th -- thousands of block allocations, deallocations, slot re-use and hash rebuilds; the maps are
+    compared with the oracle every 50 frames.  Guards the device-side allocator / hash / work lists against rare races."""
+    rng = np.random.default_rng(7)
+    M, g, o = make_pair(oracle_mod, tsdf_decay_factor=0.8, tsdf_decayed_weight_threshold=0.15, max_integration_distance_m=5.0)
+    sc = S.Scene()
+    pos = np.array([0.0, 0.0, 1.4]); yaw = 0.0
+    live_hist = []
+    for f in range(400):
+        yaw += float(rng.uniform(-0.25, 0.35)); pos[:2] += rng.uniform(-0.08, 0.08, 2); pos[:2] = np.clip(pos[:2], -1.8, 1.8)
+        pos[2] = float(np.clip(pos[2] + rng.uniform(-0.03, 0.03), 0.9, 2.0))
+        T = S.look_pose(pos.copy(), yaw, float(rng.uniform(-0.5, 0.2)))
+        d, rgb = S.render(sc, T, CAM, max_range=(5.0 if f % 5 else None))
+        g.integrate_depth(d, T, CAM); o.integrate_depth(d, T, CAM)
+        g.integrate_color(rgb, T, CAM); o.integrate_color(rgb, T, CAM)
+        if f % 3 == 2:
+            g.update_esdf(); o.update_esdf()
+        if f % 7 == 6:
+            g.decay_tsdf(True); o.decay_tsdf(True)
+        if f % 40 == 39:
+            c = (float(pos[0]), float(pos[1]), float(pos[2]))
+            g.clear_outside_radius(c, 3.0); o.clear_outside_radius(c, 3.0)
+        if f % 25 == 24:
+            g.update_color_mesh(); o.update_mesh()
+        if f % 50 == 49:
+            compare_layer(M, g, o, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
+            compare_layer(M, g, o, M.LAYER_COLOR, oracle_mod.L_COLOR, fields_tol=("weight",), lsb_fields=("r", "g", "b"))
+            g.update_esdf(); o.update_esdf()
+            sg, _ = g.esdf_slice_image(); so, _ = o.esdf_slice_image()
+            assert sg.shape == so.shape and np.abs(sg - so).max() <= TOL, f
+            live_hist.append(g.num_blocks(M.LAYER_TSDF))
+    g.update_color_mesh(full=True); o.update_mesh(full=True)
+    assert check_all(M, oracle_mod, g, o) > 1000
+    c = g.counters()
+    assert c["capacity_overflow"] == 0 and min(live_hist) > 200 and c["blocks_allocated"] < (1 << 14)
