@@ -79,6 +79,7 @@ class BlockLayerView {
 
 using TsdfLayer = BlockLayerView<TsdfVoxel, NVBX_LAYER_TSDF>;
 using OccupancyLayer = BlockLayerView<OccupancyVoxel, NVBX_LAYER_OCCUPANCY>;
+using FreespaceLayer = BlockLayerView<FreespaceVoxel, NVBX_LAYER_FREESPACE>;
 using ColorLayer = BlockLayerView<ColorVoxel, NVBX_LAYER_COLOR>;
 using EsdfLayer = BlockLayerView<EsdfVoxel, NVBX_LAYER_ESDF>;
 

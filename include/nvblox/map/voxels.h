@@ -9,6 +9,9 @@ namespace nvblox {
 
 struct TsdfVoxel { float distance = 0.f; float weight = 0.f; };
 struct OccupancyVoxel { float log_odds = 0.f; };      // layer_publishing.cpp:140-154
+// layer_publishing.cpp:129-137,158-165
+struct FreespaceVoxel { Time last_occupied_timestamp_ms; Time consecutive_occupancy_duration_ms; bool is_high_confidence_freespace = false; uint8_t initialized_ = 0; uint8_t pad_[6] = {0, 0, 0, 0, 0, 0}; };
+static_assert(sizeof(FreespaceVoxel) == sizeof(nvbx_freespace_voxel), "C-ABI block copies are memcpy");
 struct ColorVoxel { Color color; uint8_t pad_ = 0; float weight = 0.f; };
 struct EsdfVoxel {
   float squared_distance_vox = 0.f;

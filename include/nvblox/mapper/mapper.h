@@ -28,7 +28,7 @@ namespace nvblox {
 using LayerTypeBitMask = uint32_t;
 namespace LayerType {
 constexpr LayerTypeBitMask kTsdf = NVBX_LAYER_TSDF, kColor = NVBX_LAYER_COLOR, kEsdf = NVBX_LAYER_ESDF, kColorMesh = NVBX_LAYER_MESH,
-                           kFreespace = 16u, kOccupancy = 32u;
+                           kFreespace = NVBX_LAYER_FREESPACE, kOccupancy = NVBX_LAYER_OCCUPANCY;
 }
 struct BlockExclusionParams {   // layer_publishing.cpp:702-707
   Vector3f exclusion_center_m; float exclusion_height_m = -1.f; float exclusion_radius_m = -1.f; float block_size_m = 0.f;
@@ -84,6 +84,7 @@ class Mapper {
   const MapperParams& params() const { return params_; }
 
   // -- integration (asynchronous on the mapper's stream); README timer tags tsdf/integrate, color/integrate, ...
+  void setUpdateTime(Time update_time_ms) { checkNvbx(nvbx_set_time_ms(m_, (int64_t)update_time_ms), "nvbx_set_time_ms"); }     // freespace layer clock
   void integrateDepth(const DepthImage& depth_frame, const Transform& T_L_C, const Camera& camera) {
     timing::Timer t("tsdf/integrate");
     float T[16]; T_L_C.toRowMajor(T);
@@ -153,6 +154,7 @@ class Mapper {
   // -- layers
   const TsdfLayer& tsdf_layer() const { return tsdf_layer_; }
   const OccupancyLayer& occupancy_layer() const { return occupancy_layer_; }       // empty unless ProjectiveLayerType::kOccupancy
+  const FreespaceLayer& freespace_layer() const { return freespace_layer_; }       // empty unless ProjectiveLayerType::kTsdfWithFreespace
   const ColorLayer& color_layer() const { return color_layer_; }
   const EsdfLayer& esdf_layer() const { return esdf_layer_; }
   TsdfLayer& tsdf_layer() { return tsdf_layer_; }
@@ -198,6 +200,7 @@ class Mapper {
   void serializeSelectedLayers(LayerTypeBitMask layers, float bandwidth_limit_mbps = -1.f, const BlockExclusionParams& ex = BlockExclusionParams()) {
     if (layers & LayerType::kColorMesh) serializeColorMesh(bandwidth_limit_mbps);
     if (layers & LayerType::kOccupancy) serialized_occupancy_ = gatherLayer<OccupancyVoxel>(NVBX_LAYER_OCCUPANCY, occupancy_layer_.getAllBlockIndices());
+    if (layers & LayerType::kFreespace) serialized_freespace_ = gatherLayer<FreespaceVoxel>(NVBX_LAYER_FREESPACE, freespace_layer_.getAllBlockIndices());
     if (layers & (LayerType::kTsdf | LayerType::kColor)) {
       std::vector<Index3D> sel;
       const float bs = tsdf_layer_.block_size();
@@ -216,6 +219,7 @@ class Mapper {
   size_t numMeshBlocksAwaitingStreaming() const { return pending_order_.size(); }     // queued by the bandwidth limit
   // layer_publishing.cpp:798-822 (dynamic mapper): all occupancy blocks, refreshed by serializeSelectedLayers(LayerType::kOccupancy, ...)
   std::shared_ptr<const SerializedLayer<OccupancyVoxel>> serializedOccupancyLayer() const { return serialized_occupancy_; }
+  std::shared_ptr<const SerializedLayer<FreespaceVoxel>> serializedFreespaceLayer() const { return serialized_freespace_; }     // layer_publishing.cpp:694-698
   std::shared_ptr<const SerializedTsdfLayer> serializedTsdfLayer() const { return serialized_tsdf_; }
   std::shared_ptr<const SerializedColorLayer> serializedColorLayer() const { return serialized_color_; }
 
@@ -229,7 +233,7 @@ class Mapper {
   const std::shared_ptr<CudaStream>& cuda_stream() const { return cuda_stream_; }
 
  private:
-  void rebuildViews() { occupancy_layer_ = OccupancyLayer(m_, voxel_size_m_); tsdf_layer_ = TsdfLayer(m_, voxel_size_m_); color_layer_ = ColorLayer(m_, voxel_size_m_); esdf_layer_ = EsdfLayer(m_, voxel_size_m_); }
+  void rebuildViews() { freespace_layer_ = FreespaceLayer(m_, voxel_size_m_); occupancy_layer_ = OccupancyLayer(m_, voxel_size_m_); tsdf_layer_ = TsdfLayer(m_, voxel_size_m_); color_layer_ = ColorLayer(m_, voxel_size_m_); esdf_layer_ = EsdfLayer(m_, voxel_size_m_); }
   template <typename VoxelType>
   std::shared_ptr<SerializedLayer<VoxelType>> gatherLayer(uint32_t layer, const std::vector<Index3D>& sel) const {
     auto out = std::make_shared<SerializedLayer<VoxelType>>();
@@ -303,7 +307,7 @@ class Mapper {
   std::shared_ptr<CudaStream> cuda_stream_;
   MapperParams params_;
   nvbx_mapper* m_ = nullptr;
-  TsdfLayer tsdf_layer_; OccupancyLayer occupancy_layer_; ColorLayer color_layer_; EsdfLayer esdf_layer_;
+  TsdfLayer tsdf_layer_; FreespaceLayer freespace_layer_; OccupancyLayer occupancy_layer_; ColorLayer color_layer_; EsdfLayer esdf_layer_;
   std::vector<Index3D> cleared_blocks_;
   uint64_t mesh_updates_ = 0, mesh_updates_fetched_ = 0;
   std::unordered_map<Index3D, PendingBlockMesh, Index3DHash> pending_mesh_; std::deque<Index3D> pending_order_;
@@ -312,6 +316,7 @@ class Mapper {
   std::shared_ptr<SerializedColorMeshLayer> serialized_mesh_ = std::make_shared<SerializedColorMeshLayer>();
   std::shared_ptr<SerializedTsdfLayer> serialized_tsdf_ = std::make_shared<SerializedTsdfLayer>();
   std::shared_ptr<SerializedLayer<OccupancyVoxel>> serialized_occupancy_ = std::make_shared<SerializedLayer<OccupancyVoxel>>();
+  std::shared_ptr<SerializedLayer<FreespaceVoxel>> serialized_freespace_ = std::make_shared<SerializedLayer<FreespaceVoxel>>();
   std::shared_ptr<SerializedColorLayer> serialized_color_ = std::make_shared<SerializedColorLayer>();
 };
 

@@ -12,7 +12,7 @@ namespace nvblox {
 enum class WorkspaceBoundsType { kUnbounded = 0, kHeightBounds = 1, kBoundingBox = 2 };   // mapper_initialization.cpp:62-80
 enum class EsdfMode { k3D, k2D };                                             // node_params.hpp:86-91
 enum class MappingType { kStaticTsdf, kStaticOccupancy, kDynamic, kHumanWithStaticTsdf, kHumanWithStaticOccupancy };
-enum class ProjectiveLayerType { kTsdf, kOccupancy, kNone };
+enum class ProjectiveLayerType { kTsdf, kOccupancy, kTsdfWithFreespace, kNone };     // (layer_publishing.cpp:747 uses kTsdfWithFreespace)
 enum class UpdateFullLayer { kNo, kYes };
 
 
@@ -123,7 +123,13 @@ struct MapperParams {
     nvbx_mapper_params p{};
     p.voxel_size = voxel_size;
     p.esdf_mode = esdf_mode == EsdfMode::k3D ? 1 : 0;
-    p.projective_layer_type = layer_type == ProjectiveLayerType::kOccupancy ? 1 : 0;
+    p.projective_layer_type = layer_type == ProjectiveLayerType::kOccupancy ? 1 : (layer_type == ProjectiveLayerType::kTsdfWithFreespace ? 2 : 0);
+    p.max_tsdf_distance_for_occupancy_m = freespace_integrator_params.max_tsdf_distance_for_occupancy_m;
+    p.max_unobserved_to_keep_consecutive_occupancy_ms = (int32_t)(int64_t)freespace_integrator_params.max_unobserved_to_keep_consecutive_occupancy_ms;
+    p.min_duration_since_occupied_for_freespace_ms = (int32_t)(int64_t)freespace_integrator_params.min_duration_since_occupied_for_freespace_ms;
+    p.min_consecutive_occupancy_duration_for_reset_ms = (int32_t)(int64_t)freespace_integrator_params.min_consecutive_occupancy_duration_for_reset_ms;
+    p.check_neighborhood = freespace_integrator_params.check_neighborhood ? 1 : 0;
+    p.initialize_to_high_confidence_freespace = freespace_integrator_params.initialize_to_high_confidence_freespace ? 1 : 0;
     p.free_region_occupancy_probability = occupancy_integrator_params.free_region_occupancy_probability;
     p.occupied_region_occupancy_probability = occupancy_integrator_params.occupied_region_occupancy_probability;
     p.unobserved_region_occupancy_probability = occupancy_integrator_params.unobserved_region_occupancy_probability;
@@ -163,7 +169,7 @@ struct MapperParams {
 };
 
 struct MultiMapperParams {   // multi_mapper.* parameters (mapper_initialization.cpp: getMultiMapperParamsFromROS)
-  int connected_mask_component_size_threshold = 2000;
+  int connected_mask_component_size_threshold = 2000;   // pixels (mapper_initialization.cpp:130)
   int remove_small_connected_components = 1;
   float mask_occlusion_threshold_m = 0.25f;     // [U] ImageMasker occlusion test (nvbx_split_depth_by_mask)
 };

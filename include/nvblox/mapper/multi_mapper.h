@@ -1,7 +1,8 @@
 // nvblox/mapper/multi_mapper.h -- nvblox::MultiMapper as constructed and driven by NvbloxNode / FuserNode
 // (nvblox_node.cpp:187-210,781,1058-1062,1261-1264; fuser_node.cpp:85-94).  libnvblox_hip implements the static-TSDF
 // mapping type (BASELINE.json north_star), static occupancy (nvblox_base.yaml:9) and the two human mapping types (mask-split
-// depth / colour, occupancy foreground mapper); MappingType::kDynamic and LiDAR motion compensation abort with a clear message (the reference aborts on programmer errors).
+// depth / colour, occupancy foreground mapper) and the dynamic mapping type (freespace layer, dynamic-pixel detection, mask clean-up);
+// LiDAR motion compensation aborts with a clear message (the reference aborts on programmer errors).
 #pragma once
 #include <cstdio>
 #include <cstdlib>
@@ -16,14 +17,15 @@ class MultiMapper {
   MultiMapper(float voxel_size_m, MappingType mapping_type, EsdfMode esdf_mode, MemoryType memory_type = MemoryType::kDevice,
               std::shared_ptr<CudaStream> cuda_stream = std::make_shared<CudaStreamOwning>(), int64_t block_capacity = Mapper::kDefaultBlockCapacity)
       : mapping_type_(mapping_type), esdf_mode_(esdf_mode), cuda_stream_(cuda_stream) {
-    if (mapping_type == MappingType::kDynamic) unsupported("MappingType::kDynamic (freespace layer + dynamic detection)");
     const bool occupancy_background = mapping_type == MappingType::kStaticOccupancy || mapping_type == MappingType::kHumanWithStaticOccupancy;
     human_ = mapping_type == MappingType::kHumanWithStaticTsdf || mapping_type == MappingType::kHumanWithStaticOccupancy;
-    background_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type, occupancy_background ? ProjectiveLayerType::kOccupancy : ProjectiveLayerType::kTsdf,
+    dynamic_ = mapping_type == MappingType::kDynamic;
+    background_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type,
+                                                  occupancy_background ? ProjectiveLayerType::kOccupancy : (dynamic_ ? ProjectiveLayerType::kTsdfWithFreespace : ProjectiveLayerType::kTsdf),
                                                   cuda_stream, block_capacity, esdf_mode);
     // the foreground (human) mapper is an occupancy mapper (specializations/nvblox_segmentation.yaml:9-22); it is fed by the
     // masked overloads only.  In the static modes it stays empty but valid.
-    foreground_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type, ProjectiveLayerType::kOccupancy, cuda_stream, human_ ? block_capacity / 4 : 64, esdf_mode);
+    foreground_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type, ProjectiveLayerType::kOccupancy, cuda_stream, (human_ || dynamic_) ? block_capacity / 4 : 64, esdf_mode);
   }
   void setMapperParams(const MapperParams& background, const MapperParams& foreground) { background_mapper_->setMapperParams(background); foreground_mapper_->setMapperParams(foreground); }
   void setMapperParams(const MapperParams& params) { background_mapper_->setMapperParams(params); }   // fuser_node.cpp:94
@@ -32,9 +34,34 @@ class MultiMapper {
   std::shared_ptr<Mapper> foreground_mapper() const { return foreground_mapper_; }
 
   void integrateDepth(const DepthImage& depth, const Transform& T_L_C, const Camera& camera, std::optional<Time> update_time_ms = std::nullopt) {
-    (void)update_time_ms;   // consumed by the freespace layer only (dynamic mapping)
-    background_mapper_->integrateDepth(depth, T_L_C, camera);
+    if (!dynamic_) { background_mapper_->integrateDepth(depth, T_L_C, camera); return; }
+    // MappingType::kDynamic (nvblox_dynamics.yaml): pixels whose points lie in high-confidence freespace are dynamic; the mask is
+    // cleaned of small components, splits the depth image; static part -> TSDF + freespace update, dynamic part -> occupancy mapper
+    nvbx_mapper* m = background_mapper_->c_handle();
+    const int rows = depth.rows(), cols = depth.cols();
+    dynamic_mask_.resize(rows, cols); depth_background_.resize(rows, cols); depth_foreground_.resize(rows, cols); depth_overlay_.resize(rows, cols);
+    float T[16]; T_L_C.toRowMajor(T);
+    const float max_d = background_mapper_->tsdf_integrator().max_integration_distance_m();
+    checkNvbx(nvbx_detect_dynamics(m, depth.dataConstPtr(), rows, cols, T, &camera.c_abi(), max_d, dynamic_mask_.dataPtr()), "nvbx_detect_dynamics");
+    if (multi_params_.remove_small_connected_components)
+      checkNvbx(nvbx_remove_small_components(m, dynamic_mask_.dataPtr(), rows, cols, multi_params_.connected_mask_component_size_threshold), "nvbx_remove_small_components");
+    float I[16]; Transform::Identity().toRowMajor(I);
+    checkNvbx(nvbx_split_depth_by_mask(m, depth.dataConstPtr(), rows, cols, dynamic_mask_.dataConstPtr(), rows, cols, I, &camera.c_abi(), &camera.c_abi(),
+                                       multi_params_.mask_occlusion_threshold_m, depth_background_.dataPtr(), depth_foreground_.dataPtr(),
+                                       reinterpret_cast<uint8_t*>(depth_overlay_.dataPtr())), "nvbx_split_depth_by_mask");
+    if (update_time_ms) background_mapper_->setUpdateTime(*update_time_ms);
+    background_mapper_->integrateDepth(depth_background_, T_L_C, camera);
+    foreground_mapper_->integrateDepth(depth_foreground_, T_L_C, camera);
+    last_dynamic_T_L_C_ = T_L_C; last_dynamic_camera_ = camera;
   }
+  // nvblox_node.cpp:1098,1108 (dynamic mapping): the dynamic part of the last depth frame as points of the layer frame / as an overlay
+  const Pointcloud& getLastDynamicPointcloud() {
+    DepthImageBackProjector bp; Pointcloud pc_C(MemoryType::kDevice);
+    bp.backProjectOnGPU(depth_foreground_, last_dynamic_camera_, &pc_C, 0.0f);
+    transformPointcloudOnGPU(last_dynamic_T_L_C_, pc_C, &dynamic_pointcloud_);
+    return dynamic_pointcloud_;
+  }
+  const ColorImage& getLastDynamicFrameMaskOverlay() const { return depth_overlay_; }
   // nvblox_node.cpp:1057-1060: the depth image is split by the mask (ImageMasker::splitImageOnGPU; mask camera related to the
   // depth camera by T_CM_CD); unmasked depth -> background mapper, masked depth -> foreground (human) occupancy mapper
   void integrateDepth(const DepthImage& depth, const MonoImage& mask, const Transform& T_L_CD, const Transform& T_CM_CD, const Camera& depth_camera,
@@ -72,7 +99,7 @@ class MultiMapper {
                                        mask.dataConstPtr(), reinterpret_cast<uint8_t*>(color_background_.dataPtr()), nullptr), "nvbx_split_color_by_mask");
     background_mapper_->integrateColor(color_background_, T_L_C, camera);
   }
-  void updateEsdf() { background_mapper_->updateEsdf(); if (human_) foreground_mapper_->updateEsdf(); }
+  void updateEsdf() { background_mapper_->updateEsdf(); if (human_ || dynamic_) foreground_mapper_->updateEsdf(); }
   void updateColorMesh(UpdateFullLayer f = UpdateFullLayer::kNo) { background_mapper_->updateColorMesh(f); }
 
   MappingType mapping_type() const { return mapping_type_; }
@@ -83,7 +110,10 @@ class MultiMapper {
     std::fprintf(stderr, "[nvblox_hip] %s is outside the MI355X hot path of this library (static TSDF + colour + 2-D ESDF + mesh)\n", what);
     std::abort();
   }
-  bool human_ = false;
+  bool human_ = false, dynamic_ = false;
+  MonoImage dynamic_mask_{MemoryType::kDevice};
+  Pointcloud dynamic_pointcloud_{MemoryType::kDevice};
+  Transform last_dynamic_T_L_C_; Camera last_dynamic_camera_;
   DepthImage depth_background_{MemoryType::kDevice}, depth_foreground_{MemoryType::kDevice};
   ColorImage depth_overlay_{MemoryType::kDevice}, color_background_{MemoryType::kDevice};
   MappingType mapping_type_; EsdfMode esdf_mode_;

@@ -42,6 +42,7 @@ extern "C" {
 #define NVBX_LAYER_ESDF 4u
 #define NVBX_LAYER_MESH 8u
 #define NVBX_LAYER_OCCUPANCY 16u   /* occupancy mappers only; shares the projective voxel pool with TSDF */
+#define NVBX_LAYER_FREESPACE 32u   /* projective_layer_type 2 only */
 
 typedef struct nvbx_mapper nvbx_mapper; /* replaces nvblox::Mapper (one per GPU / stream) */
 
@@ -50,6 +51,8 @@ typedef struct { float fu, fv, cu, cv; int32_t width, height; } nvbx_camera; /* 
 
 /* Voxel structs as the reference's consumers read them. */
 typedef struct { float distance, weight; } nvbx_tsdf_voxel;            /* layer_publishing.cpp:111,179 */
+/* FreespaceVoxel: layer_publishing.cpp:129-137,158-165 (consecutive_occupancy_duration_ms, is_high_confidence_freespace) */
+typedef struct { int64_t last_occupied_timestamp_ms; int64_t consecutive_occupancy_duration_ms; uint8_t is_high_confidence_freespace; uint8_t initialized; uint8_t pad[6]; } nvbx_freespace_voxel;
 typedef struct { float log_odds; } nvbx_occupancy_voxel;                /* layer_publishing.cpp:140-154 (OccupancyVoxel::log_odds) */
 typedef struct { uint8_t r, g, b, pad; float weight; } nvbx_color_voxel; /* layer_publishing.cpp:62-76; Color = 3 x u8 */
 typedef struct {                                                        /* esdf_and_gradients_conversions.cu:33-44 */
@@ -99,7 +102,7 @@ typedef struct {
                                              -1 = off, nvblox_base.yaml:80; 0.8 in nvblox_dynamics.yaml:11) */
   /* -- occupancy mappers: Mapper(voxel_size, memory_type, ProjectiveLayerType::kOccupancy) -- mapping_type static_occupancy
    *    (nvblox_base.yaml:9) and the dynamic / human mapper (specializations/nvblox_segmentation.yaml:9-22) */
-  int32_t projective_layer_type;          /* 0 = TSDF (default), 1 = occupancy (log-odds) */
+  int32_t projective_layer_type;          /* 0 = TSDF (default), 1 = occupancy (log-odds), 2 = TSDF with a freespace layer */
   float free_region_occupancy_probability;      /* mapper_initialization.cpp:309-312; 0.45 nvblox_base.yaml:82 */
   float occupied_region_occupancy_probability;  /* :315-317; 0.55 */
   float unobserved_region_occupancy_probability;/* :320-322; 0.5 */
@@ -108,6 +111,14 @@ typedef struct {
   float occupied_region_decay_probability;      /* :421; 0.30 in the shipped configs */
   int32_t esdf_mode;                      /* node param esdf_mode, node_params.hpp:90: 0 = "2d" (default, the slice), 1 = "3d" (every voxel
                                              of every updated block; MultiMapper(voxel_size, mapping_type, EsdfMode::k3D, ...), nvblox_node.cpp:187-190) */
+  /* -- freespace integrator of a projective_layer_type 2 mapper (MappingType::kDynamic's static mapper = TSDF with freespace,
+   *    layer_publishing.cpp:747; parameters mapper_initialization.cpp:430-462, values nvblox_dynamics.yaml:12-18) */
+  float max_tsdf_distance_for_occupancy_m;                    /* 0.15 */
+  int32_t max_unobserved_to_keep_consecutive_occupancy_ms;    /* 200 */
+  int32_t min_duration_since_occupied_for_freespace_ms;       /* 1000 (250 in nvblox_dynamics.yaml) */
+  int32_t min_consecutive_occupancy_duration_for_reset_ms;    /* 2000 */
+  int32_t check_neighborhood;                                 /* 1 */
+  int32_t initialize_to_high_confidence_freespace;            /* 0 */
 } nvbx_mapper_params;
 
 /* nvblox::Lidar(num_azimuth_divisions, num_elevation_divisions, min_valid_range_m, vertical_fov_rad) or
@@ -273,6 +284,19 @@ int nvbx_split_depth_by_mask(nvbx_mapper* m, const float* depth_dev, int32_t row
  * [U] masked pixels are black in rgb_unmasked and the only non-black ones in rgb_masked (either output may be NULL). */
 int nvbx_split_color_by_mask(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, int32_t cols, const uint8_t* mask_dev,
                              uint8_t* rgb_unmasked_dev, uint8_t* rgb_masked_dev);
+
+/* ---- dynamic mapping (MappingType::kDynamic, nvblox_dynamics.yaml) -----------------------------------------------------------
+ * update_time_ms of MultiMapper::integrateDepth(depth, T_L_C, camera, update_time_ms) (nvblox_node.cpp:1062): host state, read by the
+ * next nvbx_integrate_depth of a projective_layer_type 2 mapper, which then also updates the freespace layer of the blocks in view
+ * ([U] FreespaceIntegrator, semantics in DESIGN.md 3). */
+int nvbx_set_time_ms(nvbx_mapper* m, int64_t update_time_ms);
+/* [U] DynamicsDetection::computeDynamics: mask_dev[rows][cols] (u8) = 1 where a valid depth pixel (<= max_distance_m if > 0) lies in a
+ * high-confidence-freespace voxel, else 0.  Asynchronous. */
+int nvbx_detect_dynamics(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera,
+                         float max_distance_m, uint8_t* mask_dev);
+/* [U] removeSmallConnectedComponents (multi_mapper connected_mask_component_size_threshold, mapper_initialization.cpp:130): erases the
+ * 8-connected components of non-zero pixels smaller than min_size.  In place; synchronises (iterates to convergence). */
+int nvbx_remove_small_components(nvbx_mapper* m, uint8_t* mask_dev, int32_t rows, int32_t cols, int32_t min_size);
 
 /* ---- device-side view for the caller's own kernels (GPULayerView / gpu_indexing.cuh: esdf_slice_conversions.cu:18,
  * esdf_and_gradients_conversions.cu:19-23).  Accessors: include/nvblox_hip_device.h. */

@@ -49,6 +49,12 @@ class Params(C.Structure):
         ("free_region_decay_probability", C.c_float),
         ("occupied_region_decay_probability", C.c_float),
         ("esdf_mode", C.c_int32),
+        ("max_tsdf_distance_for_occupancy_m", C.c_float),
+        ("max_unobserved_to_keep_consecutive_occupancy_ms", C.c_int32),
+        ("min_duration_since_occupied_for_freespace_ms", C.c_int32),
+        ("min_consecutive_occupancy_duration_for_reset_ms", C.c_int32),
+        ("check_neighborhood", C.c_int32),
+        ("initialize_to_high_confidence_freespace", C.c_int32),
     ]
 
 
@@ -93,6 +99,9 @@ SIGNATURES = {
     "nvbx_synchronize": (C.c_int, [_vp]),
     "nvbx_flush": (C.c_int, [_vp]),
     "nvbx_decay_occupancy": (C.c_int, [_vp]),
+    "nvbx_set_time_ms": (C.c_int, [_vp, C.c_int64]),
+    "nvbx_detect_dynamics": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera), C.c_float, _vp]),
+    "nvbx_remove_small_components": (C.c_int, [_vp, _vp, _i32, _i32, _i32]),
     "nvbx_set_view_export": (C.c_int, [_vp, _vp, _i64]),
     "nvbx_split_depth_by_mask": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, C.POINTER(Camera), C.POINTER(Camera), C.c_float, _vp, _vp, _vp]),
     "nvbx_split_color_by_mask": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),

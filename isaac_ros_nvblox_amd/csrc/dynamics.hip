@@ -1,0 +1,193 @@
+// dynamics.hip -- the pieces MappingType::kDynamic adds around the hot path (nvblox_examples_bringup/config/nvblox/specializations/
+// nvblox_dynamics.yaml; freespace parameters mapper_initialization.cpp:430-462): the freespace layer of the static mapper, the
+// detection of dynamic depth pixels against it, and the clean-up of the dynamic mask.  The split of the depth image by that mask
+// and the occupancy mapper the dynamic part goes to are the human-mapping pieces (convert.hip, tsdf.hip).
+// All of it is [U] restated in oracle/nvblox_oracle.c (its freespace, dynamics-detection and component-filter restatements);
+// integer timestamps, flags and masks compare bit-exactly.
+#include <algorithm>
+#include <cmath>
+#include "nvbx_mapper.h"
+
+using namespace nvbx;
+
+struct FreespaceArgs {
+  int64_t now_ms;
+  float max_tsdf_distance; int32_t keep_ms, free_after_ms, reset_after_ms, check_neighborhood, init_free;
+};
+
+int nvbx_mapper::ensure_freespace_pool() {
+  if (d.freespace) return NVBX_OK;
+  NVBX_HIP(hipMalloc(&d.freespace, (size_t)capacity * 512 * 16));
+  NVBX_HIP(hipMemsetAsync(d.freespace, 0, (size_t)capacity * 512 * 16, stream));
+  return NVBX_OK;
+}
+
+// One 512-thread workgroup per block of the depth frame's view list (thread = voxel, TSDF order z + 8y + 64x).  The occupied
+// predicate of the 6-neighbourhood comes from a 10^3 lattice in LDS: own voxels + the touching faces of the 6 neighbour blocks.
+__global__ __launch_bounds__(512) void k_update_freespace(DMap m, const int4* view_list, int32_t list_cap, int32_t cnt_idx, FreespaceArgs a) {
+  __shared__ uint8_t s_occ[10 * 10 * 10];
+  __shared__ uint32_t s_nb[6];
+  int32_t n = m.counters[cnt_idx]; if (n > list_cap) n = list_cap;
+  const int tid = threadIdx.x;
+  const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
+  for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const int4 rec = view_list[i];
+    const uint32_t slot = (uint32_t)rec.x;
+    if (!slot_ok(slot) || !(m.slot_flags[slot] & F_TSDF)) continue;          // uniform
+    __syncthreads();
+    const float2 tv = m.tsdf[(size_t)slot * 512 + tid];
+    const bool observed = tv.y > 0.0f;
+    bool occupied = observed && tv.x < a.max_tsdf_distance;
+    if (a.check_neighborhood) {
+      for (int q = tid; q < 1000; q += 512) s_occ[q] = 0;
+      if (tid < 6) {
+        const int dx = tid == 0 ? -1 : (tid == 1 ? 1 : 0), dy = tid == 2 ? -1 : (tid == 3 ? 1 : 0), dz = tid == 4 ? -1 : (tid == 5 ? 1 : 0);
+        s_nb[tid] = any_slot(m, rec.y + dx, rec.z + dy, rec.w + dz);          // TSDF pool of a slot without that layer is all-zero
+      }
+      __syncthreads();
+      s_occ[((vx + 1) * 10 + (vy + 1)) * 10 + vz + 1] = occupied ? 1 : 0;
+      if (tid < 384) {                                                          // 6 faces x 64 voxels
+        const int f = tid >> 6, u = (tid >> 3) & 7, w = tid & 7;
+        const uint32_t ns = s_nb[f];
+        if (slot_ok(ns)) {
+          int nx, ny, nz, lx, ly, lz;                                           // voxel in the neighbour block, cell in the lattice
+          if (f == 0) { nx = 7; ny = u; nz = w; lx = 0; ly = u + 1; lz = w + 1; }
+          else if (f == 1) { nx = 0; ny = u; nz = w; lx = 9; ly = u + 1; lz = w + 1; }
+          else if (f == 2) { nx = u; ny = 7; nz = w; lx = u + 1; ly = 0; lz = w + 1; }
+          else if (f == 3) { nx = u; ny = 0; nz = w; lx = u + 1; ly = 9; lz = w + 1; }
+          else if (f == 4) { nx = u; ny = w; nz = 7; lx = u + 1; ly = w + 1; lz = 0; }
+          else { nx = u; ny = w; nz = 0; lx = u + 1; ly = w + 1; lz = 9; }
+          const float2 nv = m.tsdf[(size_t)ns * 512 + nz + 8 * ny + 64 * nx];
+          s_occ[(lx * 10 + ly) * 10 + lz] = (nv.y > 0.0f && nv.x < a.max_tsdf_distance) ? 1 : 0;
+        }
+      }
+      __syncthreads();
+      if (!occupied) {
+        const int c = ((vx + 1) * 10 + (vy + 1)) * 10 + vz + 1;
+        occupied = s_occ[c - 100] | s_occ[c + 100] | s_occ[c - 10] | s_occ[c + 10] | s_occ[c - 1] | s_occ[c + 1];
+      }
+    }
+    int4* fp = &m.freespace[(size_t)slot * 512 + tid];
+    int4 v = *fp;
+    int64_t last = (int64_t)(((u64)(uint32_t)v.y << 32) | (u64)(uint32_t)v.x);
+    int32_t consec = v.z; uint32_t fl = (uint32_t)v.w;
+    if (!(fl & 2u)) { fl = 2u | (a.init_free ? 1u : 0u); last = a.now_ms; consec = 0; }
+    if (observed) {
+      if (occupied) {
+        const int64_t gap = a.now_ms - last;
+        consec = gap <= (int64_t)a.keep_ms ? (int32_t)((int64_t)consec + gap) : 0;
+        last = a.now_ms;
+        if (consec >= a.reset_after_ms) fl &= ~1u;
+      } else if (a.now_ms - last >= (int64_t)a.free_after_ms) fl |= 1u;
+    }
+    *fp = make_int4((int32_t)(uint32_t)((u64)last & 0xFFFFFFFFull), (int32_t)(uint32_t)((u64)last >> 32), consec, (int32_t)fl);
+    if (tid == 0) atomicOr(&m.slot_flags[slot], F_FREESPACE);
+  }
+}
+
+int nvbx_mapper::update_freespace() {
+  if (ensure_freespace_pool()) return NVBX_E_DEVICE;
+  FreespaceArgs a;
+  a.now_ms = time_ms; a.max_tsdf_distance = p.max_tsdf_distance_for_occupancy_m; a.keep_ms = p.max_unobserved_to_keep_consecutive_occupancy_ms;
+  a.free_after_ms = p.min_duration_since_occupied_for_freespace_ms; a.reset_after_ms = p.min_consecutive_occupancy_duration_for_reset_ms;
+  a.check_neighborhood = p.check_neighborhood; a.init_free = p.initialize_to_high_confidence_freespace;
+  NVBX_LAUNCH(this, k_update_freespace, dim3((unsigned)std::min<int64_t>(capacity, 1024)), dim3(512), d, (const int4*)view_list, (int32_t)capacity,
+              (int32_t)(C_VIEW_COUNT + (int)(frame_id & 3)), a);
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;
+}
+
+extern "C" int nvbx_set_time_ms(nvbx_mapper* m, int64_t update_time_ms) {
+  if (!m) return NVBX_E_INVALID;
+  m->time_ms = update_time_ms;
+  return NVBX_OK;
+}
+
+struct RtCam { float R[9], t[3], fu, fv, cu, cv; };
+__global__ __launch_bounds__(256) void k_detect_dynamics(DMap m, RtCam g, const float* depth, int32_t rows, int32_t cols, float max_d, float vs, uint8_t* mask) {
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint8_t out = 0;
+    const float d = depth[i];
+    if (d > 0.0f && !(max_d > 0.0f && d > max_d)) {
+      const int32_t r = (int32_t)(i / cols), c = (int32_t)(i - (int64_t)r * cols);
+      const float rx = (((float)c + 0.5f) - g.cu) / g.fu, ry = (((float)r + 0.5f) - g.cv) / g.fv;
+      float pl[3]; apply_rt(g.R, g.t, d * rx, d * ry, d, pl);
+      const int32_t gx = (int32_t)floorf(pl[0] / vs), gy = (int32_t)floorf(pl[1] / vs), gz = (int32_t)floorf(pl[2] / vs);
+      const uint32_t s = find_slot(m, gx >> 3, gy >> 3, gz >> 3, F_FREESPACE);
+      if (slot_ok(s) && (m.freespace[(size_t)s * 512 + (gz & 7) + 8 * (gy & 7) + 64 * (gx & 7)].w & 1)) out = 1;
+    }
+    mask[i] = out;
+  }
+}
+extern "C" int nvbx_detect_dynamics(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera,
+                                    float max_distance_m, uint8_t* mask_dev) {
+  if (!m || !depth_dev || !T_L_C || !camera || !mask_dev || rows <= 0 || cols <= 0) { set_error("nvbx_detect_dynamics: invalid argument"); return NVBX_E_INVALID; }
+  NVBX_HIP(hipSetDevice(m->device));
+  if (m->join_side()) return NVBX_E_DEVICE;
+  const int64_t n = (int64_t)rows * cols;
+  if (!m->d.freespace) { NVBX_HIP(hipMemsetAsync(mask_dev, 0, (size_t)n, m->stream)); return NVBX_OK; }    // no freespace layer yet: nothing is dynamic
+  RtCam g;
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) g.R[3 * i + j] = T_L_C[4 * i + j]; g.t[i] = T_L_C[4 * i + 3]; }
+  g.fu = camera->fu; g.fv = camera->fv; g.cu = camera->cu; g.cv = camera->cv;
+  NVBX_LAUNCH(m, k_detect_dynamics, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), m->d, g, depth_dev, rows, cols, max_distance_m,
+              m->p.voxel_size, mask_dev);
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ connected components
+// Label = smallest pixel index of the component: min over the 8-neighbourhood + pointer jumping, iterated to a fixed point.
+__global__ __launch_bounds__(256) void k_cc_init(const uint8_t* mask, int64_t n, int32_t* label, int32_t* size) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { label[i] = mask[i] ? (int32_t)i : -1; size[i] = 0; }
+}
+__global__ __launch_bounds__(256) void k_cc_step(int32_t rows, int32_t cols, int32_t* label, int32_t* changed) {
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t cur = label[i];
+    if (cur < 0) continue;
+    const int32_t r = (int32_t)(i / cols), c = (int32_t)(i - (int64_t)r * cols);
+    int32_t best = cur;
+    for (int dr = -1; dr <= 1; dr++) for (int dc = -1; dc <= 1; dc++) {
+      const int32_t rr = r + dr, cc = c + dc;
+      if (rr < 0 || cc < 0 || rr >= rows || cc >= cols) continue;
+      const int32_t l = label[(int64_t)rr * cols + cc];
+      if (l >= 0 && l < best) best = l;
+    }
+    for (int k = 0; k < 4; k++) { const int32_t l = label[best]; if (l >= 0 && l < best) best = l; else break; }     // pointer jumping
+    if (best < cur) { atomicMin(&label[i], best); *changed = 1; }
+  }
+}
+__global__ __launch_bounds__(256) void k_cc_count(int64_t n, const int32_t* label, int32_t* size) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { const int32_t l = label[i]; if (l >= 0) atomicAdd(&size[l], 1); }
+}
+__global__ __launch_bounds__(256) void k_cc_filter(int64_t n, const int32_t* label, const int32_t* size, int32_t min_size, uint8_t* mask) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { const int32_t l = label[i]; if (l >= 0 && size[l] < min_size) mask[i] = 0; }
+}
+extern "C" int nvbx_remove_small_components(nvbx_mapper* m, uint8_t* mask_dev, int32_t rows, int32_t cols, int32_t min_size) {
+  if (!m || !mask_dev || rows <= 0 || cols <= 0) { set_error("nvbx_remove_small_components: invalid argument"); return NVBX_E_INVALID; }
+  NVBX_HIP(hipSetDevice(m->device));
+  const int64_t n = (int64_t)rows * cols;
+  if (2 * n + 16 > m->cc_scratch_elems) {
+    NVBX_HIP(hipStreamSynchronize(m->stream));
+    if (m->cc_scratch) NVBX_HIP(hipFree(m->cc_scratch));
+    m->cc_scratch = nullptr; m->cc_scratch_elems = 0;
+    NVBX_HIP(hipMalloc(&m->cc_scratch, (size_t)(2 * n + 16) * 4));
+    m->cc_scratch_elems = 2 * n + 16;
+  }
+  int32_t* label = m->cc_scratch; int32_t* size = label + n; int32_t* changed = size + n;
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+  NVBX_LAUNCH(m, k_cc_init, dim3(grid), dim3(256), (const uint8_t*)mask_dev, n, label, size);
+  for (int round = 0; round < 4096; round++) {                  // 8 propagation steps per host check; converges in a few rounds
+    NVBX_HIP(hipMemsetAsync(changed, 0, 4, m->stream));
+    for (int k = 0; k < 8; k++) NVBX_LAUNCH(m, k_cc_step, dim3(grid), dim3(256), rows, cols, label, changed);
+    int32_t h = 0;
+    NVBX_HIP(hipMemcpyAsync(&h, changed, 4, hipMemcpyDeviceToHost, m->stream));
+    NVBX_HIP(hipStreamSynchronize(m->stream));
+    if (!h) break;
+  }
+  NVBX_LAUNCH(m, k_cc_count, dim3(grid), dim3(256), n, (const int32_t*)label, size);
+  NVBX_LAUNCH(m, k_cc_filter, dim3(grid), dim3(256), n, (const int32_t*)label, (const int32_t*)size, min_size, mask_dev);
+  NVBX_HIP(hipStreamSynchronize(m->stream));
+  return NVBX_OK;
+}

@@ -9,7 +9,7 @@
 
 using namespace nvbx;
 
-constexpr uint32_t LAYER_MASK = F_TSDF | F_COLOR | F_ESDF | F_MESH | F_ESDF_PENDING;   // a slot carrying any of these is live
+constexpr uint32_t LAYER_MASK = F_TSDF | F_COLOR | F_ESDF | F_MESH | F_ESDF_PENDING | F_FREESPACE;   // a slot carrying any of these is live
 
 __device__ inline void free_slot(DMap& m, uint32_t slot) {   // one thread
   const int32_t pos = atomicAdd(&m.counters[C_FREE_TOP], 1);
@@ -43,6 +43,7 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
     } else {
       m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f);
       m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
+      if (flags & F_FREESPACE) m.freespace[(size_t)slot * 512 + tid] = make_int4(0, 0, 0, 0);
     }
     if (tid == 0) {
       uint32_t old;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
         if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, slot);
       } else {
         old = atomicOr(&m.slot_flags[slot], F_DIRTY_MESH);
-        atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH));
+        atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH | F_FREESPACE));
         const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
         if (bz >= bz_lo && bz <= bz_hi) {
           const uint32_t es = bz_out == INT32_MIN ? (uint32_t)slot : any_slot(m, bx, by, bz_out);   // 3-D ESDF: the block's own slot (the table is rebuilt after this kernel, not during it)
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float c
     if (flags & F_TSDF) m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f);
     if (flags & F_COLOR) m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
     if (flags & F_ESDF) m.esdf[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
+    if (flags & F_FREESPACE) m.freespace[(size_t)slot * 512 + tid] = make_int4(0, 0, 0, 0);
     if (tid == 0) {
       if ((flags & F_ESDF) && esdf3d) {                  // 3-D ESDF: the dropped block joins the next update's 3-D window
         const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];

@@ -85,6 +85,15 @@ __global__ __launch_bounds__(512) void k_gather_blocks(DMap m, uint32_t layer, i
   if (layer == F_TSDF && occupancy) { reinterpret_cast<float*>(out)[(size_t)i * 512 + t] = m.tsdf[(size_t)s * 512 + t].x; }
   else if (layer == F_TSDF) { reinterpret_cast<float2*>(out)[(size_t)i * 512 + t] = m.tsdf[(size_t)s * 512 + t]; }
   else if (layer == F_COLOR) { reinterpret_cast<uint2*>(out)[(size_t)i * 512 + t] = m.color[(size_t)s * 512 + t]; }
+  else if (layer == F_FREESPACE) {
+    const int4 v = m.freespace[(size_t)s * 512 + t];
+    nvbx_freespace_voxel o;
+    o.last_occupied_timestamp_ms = (int64_t)(((u64)(uint32_t)v.y << 32) | (u64)(uint32_t)v.x);
+    o.consecutive_occupancy_duration_ms = (int64_t)v.z;
+    o.is_high_confidence_freespace = (uint8_t)(v.w & 1); o.initialized = (uint8_t)((v.w >> 1) & 1);
+    for (int q = 0; q < 6; q++) o.pad[q] = 0;
+    reinterpret_cast<nvbx_freespace_voxel*>(out)[(size_t)i * 512 + t] = o;
+  }
   else if (layer == F_ESDF) {
     const int x = t >> 6, y = (t >> 3) & 7, z = t & 7;             // reference order
     const uint2 v = m.esdf[(size_t)s * 512 + x + 8 * y + 64 * z];  // device order
@@ -197,6 +206,7 @@ static int reset_map(nvbx_mapper* m) {
   NVBX_HIP(hipMemsetAsync(d.obs_bits, 0, cap * 8, m->stream));
   NVBX_HIP(hipMemsetAsync(d.inside_bits, 0, cap * 8, m->stream));
   NVBX_HIP(hipMemsetAsync(m->export_count, 0, 64, m->stream));
+  if (d.freespace) NVBX_HIP(hipMemsetAsync(d.freespace, 0, cap * 512 * 16, m->stream));
   const int64_t n = std::max<int64_t>(cap, std::max<int64_t>(C_NUM, S_NUM * NSH * SH_STRIDE));
   NVBX_LAUNCH(m, k_init_map, dim3((unsigned)((n + 255) / 256)), dim3(256), d);
   NVBX_HIP(hipGetLastError());
@@ -302,7 +312,7 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   DMap& d = m->d;
   void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.slot_consumed, d.tsdf, d.color, d.esdf,
                   m->view_list, d.lists, d.shc, m->export_idx, m->export_count, d.site_bits, d.obs_bits, d.inside_bits,
-                  m->synth, m->depth_pre, m->mask_zmin, m->esdf3_scratch, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
+                  m->synth, m->depth_pre, m->mask_zmin, m->esdf3_scratch, m->cc_scratch, d.freespace, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (m->h_counters) (void)hipHostFree(m->h_counters);
   if (m->h_shc) (void)hipHostFree(m->h_shc);
@@ -354,6 +364,9 @@ extern "C" void nvbx_default_params(nvbx_mapper_params* p) {
   p->unobserved_region_occupancy_probability = 0.5f; p->occupied_region_half_width_m = 0.1f;
   p->free_region_decay_probability = 0.55f; p->occupied_region_decay_probability = 0.30f;
   p->esdf_mode = 0;
+  p->max_tsdf_distance_for_occupancy_m = 0.15f; p->max_unobserved_to_keep_consecutive_occupancy_ms = 200;
+  p->min_duration_since_occupied_for_freespace_ms = 1000; p->min_consecutive_occupancy_duration_for_reset_ms = 2000;
+  p->check_neighborhood = 1; p->initialize_to_high_confidence_freespace = 0;
 }
 extern "C" int nvbx_flush(nvbx_mapper* m) {
   if (!m) return NVBX_E_INVALID;
@@ -368,13 +381,14 @@ extern "C" int nvbx_mapper_clear(nvbx_mapper* m) {
 }
 
 // ------------------------------------------------------------------------------------------------ C-ABI: layer access
-static bool single_layer(uint32_t layer) { return layer == F_TSDF || layer == F_COLOR || layer == F_ESDF || layer == F_MESH || layer == NVBX_LAYER_OCCUPANCY; }
+static bool single_layer(uint32_t layer) { return layer == F_TSDF || layer == F_COLOR || layer == F_ESDF || layer == F_MESH || layer == NVBX_LAYER_OCCUPANCY || layer == F_FREESPACE; }
 // API layer id -> internal slot flag; 0 = this mapper cannot hold that layer (it reads as empty).  The projective layer of a
 // mapper (TSDF or occupancy, Mapper's ProjectiveLayerType) lives in the same pool under the same internal flag.
 static uint32_t internal_layer(const nvbx_mapper* m, uint32_t layer) {
   const bool occ = m->p.projective_layer_type == 1;
   if (layer == NVBX_LAYER_OCCUPANCY) return occ ? F_TSDF : 0u;
   if (layer == F_TSDF) return occ ? 0u : F_TSDF;
+  if (layer == F_FREESPACE) return m->d.freespace ? F_FREESPACE : 0u;
   return layer;
 }
 
@@ -437,10 +451,10 @@ extern "C" int64_t nvbx_last_color_view(nvbx_mapper* m, nvbx_index3d* out, int64
   return n;
 }
 
-static size_t ref_voxel_bytes(uint32_t layer) { return layer == F_ESDF ? sizeof(nvbx_esdf_voxel) : (layer == NVBX_LAYER_OCCUPANCY ? sizeof(nvbx_occupancy_voxel) : 8); }
+static size_t ref_voxel_bytes(uint32_t layer) { return layer == F_ESDF ? sizeof(nvbx_esdf_voxel) : (layer == NVBX_LAYER_OCCUPANCY ? sizeof(nvbx_occupancy_voxel) : (layer == F_FREESPACE ? sizeof(nvbx_freespace_voxel) : 8)); }
 
 extern "C" int nvbx_get_blocks(nvbx_mapper* m, uint32_t layer, const nvbx_index3d* idx, int64_t n, void* voxels_out, int32_t* found_out) {
-  if (!m || !idx || !voxels_out || n < 0 || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF || layer == NVBX_LAYER_OCCUPANCY)) return NVBX_E_INVALID;
+  if (!m || !idx || !voxels_out || n < 0 || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF || layer == NVBX_LAYER_OCCUPANCY || layer == F_FREESPACE)) return NVBX_E_INVALID;
   if (m->join_side()) return NVBX_E_DEVICE;
   const size_t bb = 512 * ref_voxel_bytes(layer);
   const uint32_t ilayer = internal_layer(m, layer);

@@ -29,6 +29,7 @@ __host__ __device__ inline bool slot_ok(uint32_t s) { return s < SLOT_NONE; }
 
 // slot_flags bits
 constexpr uint32_t F_TSDF = 1u, F_COLOR = 2u, F_ESDF = 4u, F_MESH = 8u;
+constexpr uint32_t F_FREESPACE = 32u;      // (16 is the API id of the occupancy layer, which lives under F_TSDF)
 constexpr uint32_t F_DIRTY_ESDF = 1u << 8, F_DIRTY_MESH = 1u << 9;
 // the block was given an ESDF column by a marking pass but joins the ESDF layer (F_ESDF, layer AABB) only when the distance
 // transform of that update runs: marking never changes anything the API can observe
@@ -88,6 +89,9 @@ struct DMap {
   float2* tsdf;
   uint2* color;
   uint2* esdf;
+  // freespace layer of a TSDF-with-freespace mapper (dynamic mapping): {i64 last_occupied_ms, i32 consecutive_ms, u32 bit0 =
+  // high-confidence freespace, bit1 = initialised}; voxel order z + 8y + 64x; allocated when first needed, all-zero for free slots
+  int4* freespace;
   u64* site_bits;           // per slot: site mask of the block's ESDF slice plane (bit x + 8y); 0 for non-ESDF slots
   u64* obs_bits;            // per slot: observed mask of the slice plane, as of the last marking pass
   u64* inside_bits;         // per slot: inside mask of the slice plane, as of the last marking pass

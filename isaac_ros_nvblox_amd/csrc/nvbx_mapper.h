@@ -79,6 +79,11 @@ struct nvbx_mapper {
   // mark_pass when the last distance transform was enqueued (passes above it are the unresolved ones).
   bool unresolved_marks = false; uint32_t pass_at_last_edt = 0;
   int undo_marks();
+  // dynamic mapping (dynamics.hip)
+  int64_t time_ms = 0;               // update_time_ms of the next integrateDepth
+  int ensure_freespace_pool();
+  int update_freespace();            // after the TSDF update of a depth frame (projective_layer_type 2)
+  int32_t* cc_scratch = nullptr; int64_t cc_scratch_elems = 0;
   // EsdfMode::k3D (esdf3d.hip)
   int update_esdf_3d();
   void* esdf3_scratch = nullptr; int64_t esdf3_scratch_bytes = 0; int64_t esdf3_blocks_marked = 0, esdf3_window_voxels = 0;

@@ -482,6 +482,7 @@ static int integrate_depth_impl(nvbx_mapper* m, Img img, const Sensor& sensor, c
                      m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap);
   NVBX_HIP(hipGetLastError());
   m->last_view_frame = m->frame_id;
+  if (m->p.projective_layer_type == 2 && m->update_freespace()) return NVBX_E_DEVICE;     // TSDF with freespace (dynamic mapping)
   return m->mark_main();
 }
 

@@ -10,14 +10,16 @@ import numpy as np
 from . import _lib
 from ._lib import BoundingShape, Camera, Counters, Index3D, Lidar, Params
 
-LAYER_TSDF, LAYER_COLOR, LAYER_ESDF, LAYER_MESH, LAYER_OCCUPANCY = 1, 2, 4, 8, 16
+LAYER_TSDF, LAYER_COLOR, LAYER_ESDF, LAYER_MESH, LAYER_OCCUPANCY, LAYER_FREESPACE = 1, 2, 4, 8, 16, 32
 
 TSDF_DT = np.dtype([("distance", "<f4"), ("weight", "<f4")])
 COLOR_DT = np.dtype([("r", "u1"), ("g", "u1"), ("b", "u1"), ("pad", "u1"), ("weight", "<f4")])
 ESDF_DT = np.dtype([("squared_distance_vox", "<f4"), ("parent_direction", "<i4", (3,)),
                     ("is_inside", "u1"), ("observed", "u1"), ("is_site", "u1"), ("pad", "u1")])
 OCCUPANCY_DT = np.dtype([("log_odds", "<f4")])
-_DT = {LAYER_TSDF: TSDF_DT, LAYER_COLOR: COLOR_DT, LAYER_ESDF: ESDF_DT, LAYER_OCCUPANCY: OCCUPANCY_DT}
+FREESPACE_DT = np.dtype([("last_occupied_timestamp_ms", "<i8"), ("consecutive_occupancy_duration_ms", "<i8"),
+                         ("is_high_confidence_freespace", "u1"), ("initialized", "u1"), ("pad", "u1", (6,))])
+_DT = {LAYER_TSDF: TSDF_DT, LAYER_COLOR: COLOR_DT, LAYER_ESDF: ESDF_DT, LAYER_OCCUPANCY: OCCUPANCY_DT, LAYER_FREESPACE: FREESPACE_DT}
 
 
 def default_params(**kw):
@@ -37,7 +39,10 @@ def default_params(**kw):
         lidar_nearest_interpolation_max_allowable_dist_to_ray_vox=0.5, invalid_depth_decay_factor=-1.0,
         projective_layer_type=0, free_region_occupancy_probability=0.45, occupied_region_occupancy_probability=0.55,
         unobserved_region_occupancy_probability=0.5, occupied_region_half_width_m=0.1,
-        free_region_decay_probability=0.55, occupied_region_decay_probability=0.30, esdf_mode=0)
+        free_region_decay_probability=0.55, occupied_region_decay_probability=0.30, esdf_mode=0,
+        max_tsdf_distance_for_occupancy_m=0.15, max_unobserved_to_keep_consecutive_occupancy_ms=200,
+        min_duration_since_occupied_for_freespace_ms=1000, min_consecutive_occupancy_duration_for_reset_ms=2000,
+        check_neighborhood=1, initialize_to_high_confidence_freespace=0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -204,6 +209,27 @@ class Mapper:
 
     def decay_tsdf(self, exclude_last_view=True):
         self._check(self.lib.nvbx_decay_tsdf(self._h, int(exclude_last_view)))
+
+    def set_time_ms(self, t):
+        """update_time_ms of the next integrate_depth (freespace layer of a projective_layer_type 2 mapper)."""
+        self._check(self.lib.nvbx_set_time_ms(self._h, int(t)))
+
+    def detect_dynamics(self, depth, T_L_C, cam, max_distance_m=0.0):
+        """DynamicsDetection::computeDynamics: uint8 device tensor [rows, cols], 1 = the pixel's point lies in high-confidence freespace."""
+        torch = self._torch
+        d = self._dev(depth, torch.float32)
+        mask = torch.empty(d.shape, dtype=torch.uint8, device=d.device)
+        self._check(self.lib.nvbx_detect_dynamics(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(self._T(T_L_C)),
+                                                  C.byref(self._cam(cam)), float(max_distance_m), C.c_void_p(mask.data_ptr())))
+        self.synchronize()
+        return mask
+
+    def remove_small_components(self, mask, min_size):
+        torch = self._torch
+        mk = self._dev(mask, torch.uint8).clone()
+        torch.cuda.current_stream(mk.device).synchronize()      # the clone ran on torch's stream, the library works on the mapper's
+        self._check(self.lib.nvbx_remove_small_components(self._h, C.c_void_p(mk.data_ptr()), mk.shape[0], mk.shape[1], int(min_size)))
+        return mk
 
     def decay_occupancy(self):
         """Mapper::decayOccupancyAllVoxels (nvblox_node.cpp:925-929); occupancy mappers only."""

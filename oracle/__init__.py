@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libnvblox_oracle.so")
 
-L_TSDF, L_COLOR, L_ESDF, L_MESH = 1, 2, 4, 8
+L_TSDF, L_COLOR, L_ESDF, L_MESH, L_FREESPACE = 1, 2, 4, 8, 32
 
 
 class OrcParams(C.Structure):
@@ -55,6 +55,12 @@ class OrcParams(C.Structure):
         ("free_region_decay_probability", C.c_float),
         ("occupied_region_decay_probability", C.c_float),
         ("esdf_mode", C.c_int32),
+        ("max_tsdf_distance_for_occupancy_m", C.c_float),
+        ("max_unobserved_to_keep_consecutive_occupancy_ms", C.c_int32),
+        ("min_duration_since_occupied_for_freespace_ms", C.c_int32),
+        ("min_consecutive_occupancy_duration_for_reset_ms", C.c_int32),
+        ("check_neighborhood", C.c_int32),
+        ("initialize_to_high_confidence_freespace", C.c_int32),
     ]
 
 
@@ -74,7 +80,10 @@ def default_params(**kw):
         lidar_nearest_interpolation_max_allowable_dist_to_ray_vox=0.5, invalid_depth_decay_factor=-1.0,
         projective_layer_type=0, free_region_occupancy_probability=0.45, occupied_region_occupancy_probability=0.55,
         unobserved_region_occupancy_probability=0.5, occupied_region_half_width_m=0.1,
-        free_region_decay_probability=0.55, occupied_region_decay_probability=0.30, esdf_mode=0)
+        free_region_decay_probability=0.55, occupied_region_decay_probability=0.30, esdf_mode=0,
+        max_tsdf_distance_for_occupancy_m=0.15, max_unobserved_to_keep_consecutive_occupancy_ms=200,
+        min_duration_since_occupied_for_freespace_ms=1000, min_consecutive_occupancy_duration_for_reset_ms=2000,
+        check_neighborhood=1, initialize_to_high_confidence_freespace=0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -126,6 +135,9 @@ def lib():
         L.orc_mesh_get.restype = C.c_int; L.orc_mesh_get.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
         L.orc_decay_tsdf.restype = i64; L.orc_decay_tsdf.argtypes = [vp, C.c_int]
         L.orc_decay_occupancy.restype = i64; L.orc_decay_occupancy.argtypes = [vp]
+        L.orc_set_time_ms.argtypes = [vp, C.c_int64]
+        L.orc_detect_dynamics.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_float, vp]
+        L.orc_remove_small_components.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
         L.orc_clear_tsdf_inside_shapes.restype = i64; L.orc_clear_tsdf_inside_shapes.argtypes = [vp, vp, i32]
         L.orc_clear_outside_radius.restype = i64; L.orc_clear_outside_radius.argtypes = [vp, vp, C.c_float]
         L.orc_mark_esdf_dirty.restype = i64; L.orc_mark_esdf_dirty.argtypes = [vp, vp, i64]
@@ -138,7 +150,9 @@ TSDF_DT = np.dtype([("distance", "<f4"), ("weight", "<f4")])
 COLOR_DT = np.dtype([("r", "u1"), ("g", "u1"), ("b", "u1"), ("pad", "u1"), ("weight", "<f4")])
 ESDF_DT = np.dtype([("squared_distance_vox", "<f4"), ("parent_direction", "<i4", (3,)),
                     ("is_inside", "u1"), ("observed", "u1"), ("is_site", "u1"), ("pad", "u1")])
-_DT = {L_TSDF: TSDF_DT, L_COLOR: COLOR_DT, L_ESDF: ESDF_DT}
+FREESPACE_DT = np.dtype([("last_occupied_timestamp_ms", "<i8"), ("consecutive_occupancy_duration_ms", "<i8"),
+                         ("is_high_confidence_freespace", "u1"), ("initialized", "u1"), ("pad", "u1", (6,))])
+_DT = {L_TSDF: TSDF_DT, L_COLOR: COLOR_DT, L_ESDF: ESDF_DT, L_FREESPACE: FREESPACE_DT}
 
 
 def _p(a):
@@ -262,6 +276,14 @@ class OracleMap:
     def decay_occupancy(self):
         return lib().orc_decay_occupancy(self._h)
 
+    def set_time_ms(self, t):
+        lib().orc_set_time_ms(self._h, int(t))
+
+    def detect_dynamics(self, depth, T_L_C, cam, max_distance_m=0.0):
+        d = np.ascontiguousarray(depth, np.float32); mask = np.zeros(d.shape, np.uint8)
+        lib().orc_detect_dynamics(self._h, _p(d), d.shape[0], d.shape[1], _p(self._T(T_L_C)), _p(self._cam(cam)), float(max_distance_m), _p(mask))
+        return mask
+
     def decay_tsdf(self, exclude_last_view=True):
         return lib().orc_decay_tsdf(self._h, int(exclude_last_view))
 
@@ -291,6 +313,12 @@ def depth_image_from_pointcloud(points, lidar):
     img = np.zeros((int(lidar[1]), int(lidar[0])), np.float32)
     lib().orc_depth_image_from_pointcloud(_p(pts), pts.shape[0], _p(l5), _p(img))
     return img
+
+
+def remove_small_components(mask, min_size):
+    mk = np.ascontiguousarray(mask, np.uint8).copy()
+    lib().orc_remove_small_components(_p(mk), mk.shape[0], mk.shape[1], int(min_size))
+    return mk
 
 
 def split_depth_by_mask(depth, mask, T_CM_CD, depth_cam, mask_cam, occlusion_threshold_m):

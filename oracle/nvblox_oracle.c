@@ -50,6 +50,8 @@ typedef struct { int32_t x, y, z; } Idx3;
 typedef struct { float distance, weight; } TsdfVoxel;
 typedef struct { uint8_t r, g, b, pad; float weight; } ColorVoxel;
 typedef struct { float sq; int32_t parent[3]; uint8_t is_inside, observed, is_site, pad; } EsdfVoxel;
+/* FreespaceVoxel (layer_publishing.cpp:129-137,158-165: consecutive_occupancy_duration_ms, is_high_confidence_freespace) */
+typedef struct { int64_t last_occupied_timestamp_ms; int64_t consecutive_occupancy_duration_ms; uint8_t is_high_confidence_freespace; uint8_t initialized; uint8_t pad[6]; } FreespaceVoxel;
 
 /* Parameter block: mirrors the reference's MapperParams fields that touch this path
  * (mapper_initialization.cpp:246-380).  Layout shared with tests via ctypes. */
@@ -90,6 +92,10 @@ typedef struct {
   float occupied_region_half_width_m;
   float free_region_decay_probability, occupied_region_decay_probability;
   int32_t esdf_mode;                    /* 0 = 2-D slice, 1 = 3-D */
+  /* freespace integrator (projective_layer_type 2 = TSDF with freespace; mapper_initialization.cpp:430-462, nvblox_dynamics.yaml:12-18) */
+  float max_tsdf_distance_for_occupancy_m;
+  int32_t max_unobserved_to_keep_consecutive_occupancy_ms, min_duration_since_occupied_for_freespace_ms,
+          min_consecutive_occupancy_duration_for_reset_ms, check_neighborhood, initialize_to_high_confidence_freespace;
 } OrcParams;
 
 enum { W_CONSTANT = 0, W_CONSTANT_DROPOFF = 1, W_INVERSE_SQUARE = 2, W_INVERSE_SQUARE_DROPOFF = 3,
@@ -109,17 +115,19 @@ typedef struct Block {
   TsdfVoxel* tsdf;        /* [512] */
   ColorVoxel* color;      /* [512] */
   EsdfVoxel* esdf;        /* [512] */
+  FreespaceVoxel* fs;     /* [512] */
   MeshBlock mesh;
   int32_t stamp_view, stamp_esdf, dirty_esdf, dirty_mesh, remark_esdf;
 } Block;
 
-enum { L_TSDF = 1, L_COLOR = 2, L_ESDF = 4, L_MESH = 8 };
+enum { L_TSDF = 1, L_COLOR = 2, L_ESDF = 4, L_MESH = 8, L_FREESPACE = 32 };
 
 typedef struct {
   OrcParams p;
   Block** table; int64_t cap; int64_t count;   /* open addressing, hash = x + 17191 y + 17191^2 z */
   Block** order; int64_t order_cap;            /* insertion order */
   int32_t frame, esdf_epoch;
+  int64_t time_ms;                             /* update_time_ms of the next integrateDepth (freespace layer) */
   Idx3* view; int64_t n_view, view_cap;        /* blocks in view of last depth frame */
   Idx3* cview; int64_t n_cview, cview_cap;     /* blocks updated by last colour frame */
   float* synth; int synth_rows, synth_cols;    /* last synthetic depth image (sphere tracing) */
@@ -173,7 +181,7 @@ static Block* map_get_or_create(OrcMap* m, Idx3 i) {
   return b;
 }
 static void block_free(Block* b) {
-  free(b->tsdf); free(b->color); free(b->esdf);
+  free(b->tsdf); free(b->color); free(b->esdf); free(b->fs);
   free(b->mesh.vert); free(b->mesh.nrm); free(b->mesh.col); free(b->mesh.tri);
   free(b);
 }
@@ -186,6 +194,7 @@ static void ensure_layer(Block* b, uint32_t layer) {
   if (layer == L_TSDF) b->tsdf = (TsdfVoxel*)calloc(NVOX, sizeof(TsdfVoxel));
   if (layer == L_COLOR) b->color = (ColorVoxel*)calloc(NVOX, sizeof(ColorVoxel));
   if (layer == L_ESDF) b->esdf = (EsdfVoxel*)calloc(NVOX, sizeof(EsdfVoxel));
+  if (layer == L_FREESPACE) b->fs = (FreespaceVoxel*)calloc(NVOX, sizeof(FreespaceVoxel));
   b->flags |= layer;
 }
 
@@ -458,6 +467,105 @@ static float* dilate_invalid(const float* depth, int rows, int cols, int n) {
   return out;
 }
 
+/* ------------------------------------------------------------------ freespace layer (dynamic mapping) */
+/* [U] FreespaceIntegrator::updateFreespaceLayer restated (MappingType::kDynamic; parameters mapper_initialization.cpp:430-462,
+ * values nvblox_dynamics.yaml:12-18).  Every voxel of the blocks in the depth view, after the TSDF update, at time `now`:
+ *   first touch: last_occupied = now, duration 0, high confidence = initialize_to_high_confidence_freespace;
+ *   observed (w > 0) and occupied (d < max_tsdf_distance_for_occupancy_m; with check_neighborhood also if a 6-neighbour is):
+ *     the consecutive occupancy duration grows by the gap since the last occupied observation if that gap is at most
+ *     max_unobserved_to_keep_consecutive_occupancy_ms, else restarts at 0; after min_consecutive_occupancy_duration_for_reset_ms
+ *     of it the voxel is no longer high-confidence freespace (it has become part of the static world);
+ *   observed and free: high-confidence freespace once min_duration_since_occupied_for_freespace_ms have passed since it was
+ *     last occupied (a moving object passing through does not reset it -- that is what makes it detectable). */
+static int tsdf_occupied(const OrcMap* m, int32_t gx, int32_t gy, int32_t gz) {
+  Idx3 bi = {floor_div8(gx), floor_div8(gy), floor_div8(gz)};
+  const Block* b = map_find(m, bi);
+  if (!b || !(b->flags & L_TSDF)) return 0;
+  const TsdfVoxel* v = &b->tsdf[mod8(gz) + 8 * mod8(gy) + 64 * mod8(gx)];
+  return v->weight > 0.0f && v->distance < m->p.max_tsdf_distance_for_occupancy_m;
+}
+static void freespace_update(OrcMap* m) {
+  const OrcParams* p = &m->p;
+  const int64_t now = m->time_ms;
+  for (int64_t i = 0; i < m->n_view; i++) {
+    Block* b = map_find(m, m->view[i]);
+    if (!b || !(b->flags & L_TSDF)) continue;
+    ensure_layer(b, L_FREESPACE);
+    for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) for (int z = 0; z < 8; z++) {
+      const int li = z + 8 * y + 64 * x;
+      FreespaceVoxel* f = &b->fs[li];
+      if (!f->initialized) { f->initialized = 1; f->last_occupied_timestamp_ms = now; f->consecutive_occupancy_duration_ms = 0;
+                             f->is_high_confidence_freespace = p->initialize_to_high_confidence_freespace ? 1 : 0; }
+      const TsdfVoxel* tv = &b->tsdf[li];
+      if (!(tv->weight > 0.0f)) continue;
+      const int32_t gx = b->idx.x * 8 + x, gy = b->idx.y * 8 + y, gz = b->idx.z * 8 + z;
+      int occupied = tv->distance < p->max_tsdf_distance_for_occupancy_m;
+      if (!occupied && p->check_neighborhood)
+        occupied = tsdf_occupied(m, gx - 1, gy, gz) || tsdf_occupied(m, gx + 1, gy, gz) || tsdf_occupied(m, gx, gy - 1, gz) ||
+                   tsdf_occupied(m, gx, gy + 1, gz) || tsdf_occupied(m, gx, gy, gz - 1) || tsdf_occupied(m, gx, gy, gz + 1);
+      if (occupied) {
+        const int64_t gap = now - f->last_occupied_timestamp_ms;
+        f->consecutive_occupancy_duration_ms = gap <= (int64_t)p->max_unobserved_to_keep_consecutive_occupancy_ms ? f->consecutive_occupancy_duration_ms + gap : 0;
+        f->last_occupied_timestamp_ms = now;
+        if (f->consecutive_occupancy_duration_ms >= (int64_t)p->min_consecutive_occupancy_duration_for_reset_ms) f->is_high_confidence_freespace = 0;
+      } else if (now - f->last_occupied_timestamp_ms >= (int64_t)p->min_duration_since_occupied_for_freespace_ms) {
+        f->is_high_confidence_freespace = 1;
+      }
+    }
+  }
+}
+void orc_set_time_ms(OrcMap* m, int64_t t) { m->time_ms = t; }
+
+/* [U] DynamicsDetection::computeDynamics restated: a valid depth pixel (within max_distance) whose 3-D point lies in a
+ * high-confidence-freespace voxel is dynamic. */
+void orc_detect_dynamics(const OrcMap* m, const float* depth, int32_t rows, int32_t cols, const float* T_L_C16, const float* cam6, float max_distance_m, uint8_t* mask) {
+  Rt T_L_C, T_C_L; rt_from_T(T_L_C16, &T_L_C, &T_C_L);
+  const Cam k = cam_from(cam6);
+  const float vs = m->p.voxel_size;
+  for (int32_t r = 0; r < rows; r++) for (int32_t c = 0; c < cols; c++) {
+    const int64_t i = (int64_t)r * cols + c;
+    mask[i] = 0;
+    const float d = depth[i];
+    if (!(d > 0.0f) || (max_distance_m > 0.0f && d > max_distance_m)) continue;
+    const float rx = (((float)c + 0.5f) - k.cu) / k.fu, ry = (((float)r + 0.5f) - k.cv) / k.fv;
+    float pl[3]; rt_apply(&T_L_C, d * rx, d * ry, d, pl);
+    const int32_t gx = (int32_t)floorf(pl[0] / vs), gy = (int32_t)floorf(pl[1] / vs), gz = (int32_t)floorf(pl[2] / vs);
+    Idx3 bi = {floor_div8(gx), floor_div8(gy), floor_div8(gz)};
+    const Block* b = map_find(m, bi);
+    if (!b || !(b->flags & L_FREESPACE)) continue;
+    if (b->fs[mod8(gz) + 8 * mod8(gy) + 64 * mod8(gx)].is_high_confidence_freespace) mask[i] = 1;
+  }
+}
+/* [U] removeSmallConnectedComponents (multi_mapper.connected_mask_component_size_threshold, mapper_initialization.cpp:130): 8-connected
+ * components of the non-zero mask pixels smaller than min_size are erased. */
+void orc_remove_small_components(uint8_t* mask, int32_t rows, int32_t cols, int32_t min_size) {
+  const int64_t n = (int64_t)rows * cols;
+  int32_t* label = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+  int64_t* stack = (int64_t*)malloc((size_t)n * sizeof(int64_t));
+  for (int64_t i = 0; i < n; i++) label[i] = -1;
+  for (int64_t s0 = 0; s0 < n; s0++) {
+    if (!mask[s0] || label[s0] >= 0) continue;
+    int64_t top = 0, size = 0; stack[top++] = s0; label[s0] = (int32_t)s0;
+    int64_t first = 0;
+    (void)first;
+    /* first pass: flood fill, count */
+    int64_t head = 0;
+    while (head < top) {
+      const int64_t i = stack[head++]; size++;
+      const int32_t r = (int32_t)(i / cols), c = (int32_t)(i % cols);
+      for (int dr = -1; dr <= 1; dr++) for (int dc = -1; dc <= 1; dc++) {
+        if (!dr && !dc) continue;
+        const int32_t rr = r + dr, cc = c + dc;
+        if (rr < 0 || cc < 0 || rr >= rows || cc >= cols) continue;
+        const int64_t j = (int64_t)rr * cols + cc;
+        if (mask[j] && label[j] < 0) { label[j] = (int32_t)s0; stack[top++] = j; }
+      }
+    }
+    if (size < min_size) for (int64_t q = 0; q < top; q++) mask[stack[q]] = 0;
+  }
+  free(label); free(stack);
+}
+
 int64_t orc_integrate_depth(OrcMap* m, const float* depth_in, int rows, int cols, const float* T_L_C16, const float* cam6) {
   float* pre = NULL;
   if (m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0) pre = dilate_invalid(depth_in, rows, cols, m->p.depth_preprocessing_num_dilations);
@@ -472,6 +580,7 @@ int64_t orc_integrate_depth(OrcMap* m, const float* depth_in, int rows, int cols
     Block* b = map_find(m, m->view[i]);
     tsdf_integrate_block(&m->p, b, depth, rows, cols, &T_C_L, &k);
   }
+  if (m->p.projective_layer_type == 2) freespace_update(m);
   free(pre);
   return n;
 }
@@ -647,6 +756,7 @@ int orc_get_block(const OrcMap* m, uint32_t layer, int32_t x, int32_t y, int32_t
   if (layer == L_TSDF) memcpy(out, b->tsdf, NVOX * sizeof(TsdfVoxel));
   else if (layer == L_COLOR) memcpy(out, b->color, NVOX * sizeof(ColorVoxel));
   else if (layer == L_ESDF) memcpy(out, b->esdf, NVOX * sizeof(EsdfVoxel));
+  else if (layer == L_FREESPACE) memcpy(out, b->fs, NVOX * sizeof(FreespaceVoxel));
   else return 0;
   return 1;
 }
@@ -1251,7 +1361,7 @@ int64_t orc_decay_tsdf(OrcMap* m, int exclude_last_view) {
     }
     if (drop && !(b->flags & L_ESDF)) { block_free(b); removed++; }
     else {
-      if (drop) { free(b->tsdf); b->tsdf = NULL; free(b->color); b->color = NULL; b->flags &= ~(uint32_t)(L_TSDF | L_COLOR | L_MESH); removed++; }
+      if (drop) { free(b->tsdf); b->tsdf = NULL; free(b->color); b->color = NULL; free(b->fs); b->fs = NULL; b->flags &= ~(uint32_t)(L_TSDF | L_COLOR | L_MESH | L_FREESPACE); removed++; }
       m->order[keep++] = b;
     }
   }
@@ -1291,7 +1401,7 @@ int64_t orc_decay_occupancy(OrcMap* m) {
     }
     if (drop && !(b->flags & L_ESDF)) { block_free(b); removed++; }
     else {
-      if (drop) { free(b->tsdf); b->tsdf = NULL; free(b->color); b->color = NULL; b->flags &= ~(uint32_t)(L_TSDF | L_COLOR | L_MESH); b->dirty_esdf = 0; removed++; }
+      if (drop) { free(b->tsdf); b->tsdf = NULL; free(b->color); b->color = NULL; free(b->fs); b->fs = NULL; b->flags &= ~(uint32_t)(L_TSDF | L_COLOR | L_MESH | L_FREESPACE); b->dirty_esdf = 0; removed++; }
       m->order[keep++] = b;
     }
   }

@@ -329,6 +329,33 @@ int main(int argc, char** argv) {
     if (e3.numAllocatedBlocks() != m3.background_mapper()->tsdf_layer().numAllocatedBlocks() || sites < 1000 || known < 10000 || zmax - zmin < 3) {
       std::fprintf(stderr, "3-D ESDF: %d blocks, %zu sites, %zu observed, z %d..%d\n", e3.numAllocatedBlocks(), sites, known, zmin, zmax); return 1; }
   }
+  // mapping_type "dynamic" (specializations/nvblox_dynamics.yaml): freespace layer, dynamic-pixel detection, mask clean-up, occupancy mapper
+  {
+    auto multi_mapper_ = std::make_shared<MultiMapper>(0.05f, MappingType::kDynamic, EsdfMode::k2D, MemoryType::kDevice, std::make_shared<CudaStreamOwning>(), 1 << 12);
+    MapperParams sp; sp.freespace_integrator_params.min_duration_since_occupied_for_freespace_ms = Time(250);
+    MapperParams dp; dp.occupancy_integrator_params.occupied_region_occupancy_probability = 0.9f; dp.occupancy_integrator_params.free_region_occupancy_probability = 0.2f;
+    multi_mapper_->setMapperParams(sp, dp);
+    MultiMapperParams mmp; mmp.connected_mask_component_size_threshold = 50;
+    multi_mapper_->setMultiMapperParams(mmp);
+    const Camera depth_camera_(80.f, 80.f, 79.5f, 59.5f, 160, 120);
+    DepthImage depth_image_(120, 160, MemoryType::kDevice);
+    std::vector<float> wall(120 * 160, 3.0f), with_object = wall;
+    for (int r = 40; r < 90; r++) for (int c = 60; c < 100; c++) with_object[r * 160 + c] = 1.5f;          // something appears 1.5 m away, in mapped freespace
+    int64_t t_ms = 0;
+    for (int k = 0; k < 8; k++, t_ms += 100) {
+      depth_image_.copyFromAsync(120, 160, wall.data(), CudaStreamOwning());
+      multi_mapper_->integrateDepth(depth_image_, Transform::Identity(), depth_camera_, Time(t_ms));
+    }
+    depth_image_.copyFromAsync(120, 160, with_object.data(), CudaStreamOwning());
+    multi_mapper_->integrateDepth(depth_image_, Transform::Identity(), depth_camera_, Time(t_ms));
+    multi_mapper_->updateEsdf();
+    const int dynamic_points = multi_mapper_->getLastDynamicPointcloud().size();
+    size_t free_voxels = 0;
+    callFunctionOnAllVoxels<FreespaceVoxel>(multi_mapper_->background_mapper()->freespace_layer(), [&](const Index3D&, const Index3D&, const FreespaceVoxel* v) { if (v->is_high_confidence_freespace) free_voxels++; });
+    const int dyn_blocks = multi_mapper_->foreground_mapper()->occupancy_layer().numAllocatedBlocks();
+    if (dynamic_points < 1500 || dynamic_points > 50 * 40 || free_voxels < 10000 || dyn_blocks < 3) {
+      std::fprintf(stderr, "dynamic mapping: %d dynamic points, %zu freespace voxels, %d dynamic blocks\n", dynamic_points, free_voxels, dyn_blocks); return 1; }
+  }
   // save_map / load_map services (nvblox_node.cpp:1668, 1703): bool results, a missing file is a recoverable error
   const std::string filename = std::string(argv[1]) + ".map";
   const bool save_ok = node.static_mapper_->saveLayerCake(filename);

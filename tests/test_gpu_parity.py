@@ -468,3 +468,83 @@ def test_esdf_3d_parity(oracle_mod, hip_lib):
     g.update_esdf(); o.update_esdf()
     compare_esdf3(M, g, o, oracle_mod)
     assert g.counters()["capacity_overflow"] == 0
+
+
+def test_dynamic_mapping_parity(oracle_mod, hip_lib):
+    """MappingType::kDynamic (nvblox_dynamics.yaml): the static mapper carries a freespace layer (projective_layer_type 2); depth
+    pixels whose points fall into high-confidence freespace are dynamic; the mask is cleaned of small components, splits the
+    depth image, and the dynamic part feeds an occupancy mapper.  Freespace voxels (timestamps, durations, flags), dynamic masks,
+    cleaned masks and both maps are bit-exact against the oracle."""
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    fs = dict(projective_layer_type=2, max_integration_distance_m=5.0, invalid_depth_decay_factor=0.8, max_tsdf_distance_for_occupancy_m=0.15,
+              max_unobserved_to_keep_consecutive_occupancy_ms=200, min_duration_since_occupied_for_freespace_ms=250,
+              min_consecutive_occupancy_duration_for_reset_ms=600, check_neighborhood=1, initialize_to_high_confidence_freespace=0)
+    occ = dict(projective_layer_type=1, free_region_occupancy_probability=0.2, occupied_region_occupancy_probability=0.9,
+               unobserved_region_occupancy_probability=0.35, occupied_region_half_width_m=0.15, max_integration_distance_m=5.0)
+    _, gs, os_ = make_pair(oracle_mod, **fs)
+    _, gd, od = make_pair(oracle_mod, **occ)
+    static_scene = S.Scene()
+    T = S.trajectory_pose(0, 200)
+    eye = np.eye(4, dtype=np.float32)
+
+    def frame(scene, t_ms, pose):
+        d, _ = S.render(scene, pose, cam, color=False)
+        mg = gs.detect_dynamics(d, pose, cam, 5.0); mo = os_.detect_dynamics(d, pose, cam, 5.0)
+        assert np.array_equal(mg.cpu().numpy(), mo)
+        cg = gs.remove_small_components(mg, 40); co = oracle_mod.remove_small_components(mo, 40)
+        assert np.array_equal(cg.cpu().numpy(), co)
+        un_g, ma_g = gs.split_depth_by_mask(d, cg, eye, cam, cam, 0.25)
+        un_o, ma_o = oracle_mod.split_depth_by_mask(d, co, eye, cam, cam, 0.25)
+        assert np.array_equal(un_g.cpu().numpy(), un_o) and np.array_equal(ma_g.cpu().numpy(), ma_o)
+        gs.set_time_ms(t_ms); os_.set_time_ms(t_ms)
+        gs.integrate_depth(un_g, pose, cam); os_.integrate_depth(un_o, pose, cam)
+        gd.integrate_depth(ma_g, pose, cam); od.integrate_depth(ma_o, pose, cam)
+        return mo, co
+
+    def compare_freespace():
+        ig = gs.block_indices(M.LAYER_FREESPACE); io = os_.block_indices(oracle_mod.L_FREESPACE)
+        assert np.array_equal(ig, io) and len(io) > 50
+        bg, found = gs.get_blocks(M.LAYER_FREESPACE, ig)
+        assert found.all()
+        n_free = 0
+        for k, idx in enumerate(io):
+            bo = os_.get_block(oracle_mod.L_FREESPACE, idx)
+            for f in ("last_occupied_timestamp_ms", "consecutive_occupancy_duration_ms", "is_high_confidence_freespace", "initialized"):
+                assert np.array_equal(bg[k][f], bo[f]), (f, idx)
+            n_free += int(bo["is_high_confidence_freespace"].sum())
+        return n_free
+
+    # 1. the static room, observed for 0.9 s at 10 Hz from a slowly turning camera: free voxels become high-confidence freespace
+    t = 0
+    for k in range(10):
+        mo, _ = frame(static_scene, t, S.trajectory_pose(k, 200)); t += 100
+        if k < 3:
+            assert mo.sum() == 0                      # nothing can be dynamic before any freespace exists
+    n_free = compare_freespace()
+    assert n_free > 20000
+    # 2. an object appears in the middle of the room: its pixels are dynamic, the mask survives the clean-up, the static TSDF stays clean
+    moving = S.Scene(box_min=(1.6, -0.3, 0.0), box_max=(2.0, 0.3, 1.3))
+    n_dyn = []
+    for k in range(5):
+        mo, co = frame(moving, t, S.trajectory_pose(9, 200)); t += 100
+        n_dyn.append(int(co.sum()))
+    assert min(n_dyn) > 150, n_dyn
+    compare_freespace()
+    compare_layer(M, gs, os_, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
+    n, _ = compare_occupancy(M, gd, od, oracle_mod)
+    assert n > 3
+    # 3. the object stays for a second: the voxels it occupies reach the reset duration and stop being freespace -> it turns static
+    #    (frames integrate the FULL depth into the static mapper here, as a long-standing object would be)
+    d, _ = S.render(moving, S.trajectory_pose(9, 200), cam, color=False)
+    for k in range(12):
+        gs.set_time_ms(t); os_.set_time_ms(t)
+        gs.integrate_depth(d, S.trajectory_pose(9, 200), cam); os_.integrate_depth(d, S.trajectory_pose(9, 200), cam); t += 100
+    compare_freespace()
+    mg = gs.detect_dynamics(d, S.trajectory_pose(9, 200), cam, 5.0).cpu().numpy(); mo = os_.detect_dynamics(d, S.trajectory_pose(9, 200), cam, 5.0)
+    assert np.array_equal(mg, mo) and mo.sum() < 0.2 * n_dyn[0]
+    # connected components on a random blob mask (many sizes, touching diagonally)
+    rng = np.random.default_rng(5)
+    mk = (rng.random((120, 160)) < 0.42).astype(np.uint8)
+    for thr in (2, 9, 60, 400):
+        assert np.array_equal(gs.remove_small_components(mk, thr).cpu().numpy(), oracle_mod.remove_small_components(mk, thr)), thr
