@@ -13,7 +13,10 @@
  * that module and anchors every data-layout / parameter decision on the
  * reference's own call sites.  The single golden test the reference holds for
  * this path (nvblox_ros/test/unit_tests/test_esdf_and_gradient_conversions.cpp:
- * 36-157) is reproduced in tests/test_kat_esdf_grid.py against orc_esdf_dense_grid().
+ * 36-157) is reproduced in tests/test_oracle_kat.py against orc_esdf_dense_grid().
+ * Also restated here, equally unpinned ([U] everywhere the core's source would be needed): the LiDAR integrator, occupancy
+ * mappers and their decay, the 3-D ESDF, the mask split of the human mapping types, the freespace layer / dynamics detection /
+ * connected-component clean-up of the dynamic mapping type, decay and clearing.
  *
  * Anchors inside /root/reference (file:line):
  *   block = 8x8x8 voxels, linear index z + 8*y + 64*x ... nvblox_ros/src/lib/layer_publishing.cpp:335,501
