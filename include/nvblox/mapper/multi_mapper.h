@@ -2,7 +2,7 @@
 // (nvblox_node.cpp:187-210,781,1058-1062,1261-1264; fuser_node.cpp:85-94).  libnvblox_hip implements the static-TSDF
 // mapping type (BASELINE.json north_star), static occupancy (nvblox_base.yaml:9) and the two human mapping types (mask-split
 // depth / colour, occupancy foreground mapper) and the dynamic mapping type (freespace layer, dynamic-pixel detection, mask clean-up);
-// LiDAR motion compensation aborts with a clear message (the reference aborts on programmer errors).
+// every overload the node calls is implemented (the reference aborts on programmer errors).
 #pragma once
 #include <cstdio>
 #include <cstdlib>
@@ -80,14 +80,21 @@ class MultiMapper {
   const DepthImage& getLastDepthFrameForeground() const { return depth_foreground_; }      // nvblox_node.cpp:1126
   const DepthImage& getLastDepthFrameBackground() const { return depth_background_; }
   const ColorImage& getLastDepthFrameMaskOverlay() const { return depth_overlay_; }        // nvblox_node.cpp:1147
-  // nvblox_node.cpp:1382-1384.  Per-point motion compensation (use_lidar_motion_compensation, node_params.hpp:152) needs
-  // per-point timestamps that this Pointcloud does not carry: run the node with use_lidar_motion_compensation:=false.
+  // nvblox_node.cpp:1339-1384.  With use_lidar_motion_compensation the cloud carries per-point times within the scan and the node
+  // supplies the sensor pose at scan end and the scan duration: the points are de-skewed into the sensor frame at scan start first.
   void integrateDepth(const Pointcloud& pointcloud, const Transform& T_L_C, const Lidar& lidar, bool use_lidar_motion_compensation = false,
                       std::optional<Transform> T_L_S_scan_end = std::nullopt, std::optional<Time> scan_duration_ms = std::nullopt,
                       std::optional<Time> update_time_ms = std::nullopt) {
-    (void)T_L_S_scan_end; (void)scan_duration_ms; (void)update_time_ms;
-    if (use_lidar_motion_compensation) unsupported("LiDAR motion compensation (set use_lidar_motion_compensation:=false)");
-    background_mapper_->integrateLidarPointcloud(pointcloud, T_L_C, lidar);
+    if (update_time_ms) background_mapper_->setUpdateTime(*update_time_ms);
+    if (!use_lidar_motion_compensation) { background_mapper_->integrateLidarPointcloud(pointcloud, T_L_C, lidar); return; }
+    if (!T_L_S_scan_end || !scan_duration_ms || !pointcloud.hasTimestamps())
+      unsupported("LiDAR motion compensation without per-point timestamps / scan-end pose / scan duration");
+    deskewed_.resize((size_t)pointcloud.size());
+    float T0[16], T1[16]; T_L_C.toRowMajor(T0); T_L_S_scan_end->toRowMajor(T1);
+    checkNvbx(nvbx_motion_compensate_pointcloud(background_mapper_->c_handle(), reinterpret_cast<const float*>(pointcloud.dataConstPtr()), pointcloud.timestampsConstPtr(),
+                                                pointcloud.size(), T0, T1, (float)(int64_t)*scan_duration_ms, reinterpret_cast<float*>(deskewed_.dataPtr())),
+              "nvbx_motion_compensate_pointcloud");
+    background_mapper_->integrateLidarPointcloud(deskewed_, T_L_C, lidar);
   }
   const DepthImage& getLastDepthFrameFromPointcloud() const { return background_mapper_->getLastDepthFrameFromPointcloud(); }
   void integrateColor(const ColorImage& color, const Transform& T_L_C, const Camera& camera) { background_mapper_->integrateColor(color, T_L_C, camera); }
@@ -112,7 +119,7 @@ class MultiMapper {
   }
   bool human_ = false, dynamic_ = false;
   MonoImage dynamic_mask_{MemoryType::kDevice};
-  Pointcloud dynamic_pointcloud_{MemoryType::kDevice};
+  Pointcloud dynamic_pointcloud_{MemoryType::kDevice}, deskewed_{MemoryType::kDevice};
   Transform last_dynamic_T_L_C_; Camera last_dynamic_camera_;
   DepthImage depth_background_{MemoryType::kDevice}, depth_foreground_{MemoryType::kDevice};
   ColorImage depth_overlay_{MemoryType::kDevice}, color_background_{MemoryType::kDevice};

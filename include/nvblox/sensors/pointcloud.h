@@ -15,7 +15,7 @@ namespace nvblox {
 class Pointcloud {
  public:
   explicit Pointcloud(MemoryType memory_type = MemoryType::kDevice) : memory_type_(memory_type) {}
-  ~Pointcloud() { if (data_) (void)hipFree(data_); }
+  ~Pointcloud() { if (data_) (void)hipFree(data_); if (times_) (void)hipFree(times_); }
   Pointcloud(const Pointcloud&) = delete;
   Pointcloud& operator=(const Pointcloud&) = delete;
   int size() const { return (int)size_; }
@@ -29,6 +29,14 @@ class Pointcloud {
     size_ = n;
   }
   void copyFromAsync(const std::vector<Vector3f>& points, const CudaStream& stream) { copyFromAsync(points.data(), points.size(), stream); }
+  // per-point time within the scan in milliseconds (loaded only for LiDAR motion compensation, nvblox_node.cpp:1339-1348)
+  void copyTimestampsFromAsync(const float* rel_time_ms, size_t n, const CudaStream& stream) {
+    if (n > times_cap_) { if (times_) (void)hipFree(times_); (void)hipMalloc((void**)&times_, n * sizeof(float)); times_cap_ = n; }
+    if (n) (void)hipMemcpyAsync(times_, rel_time_ms, n * sizeof(float), hipMemcpyDefault, stream);
+    times_size_ = n;
+  }
+  bool hasTimestamps() const { return times_size_ == size_ && size_ > 0; }
+  const float* timestampsConstPtr() const { return times_; }
   void copyFromAsync(const Vector3f* points, size_t n, const CudaStream& stream) {
     resizeAsync(n, stream);
     if (n) (void)hipMemcpyAsync(data_, points, n * sizeof(Vector3f), hipMemcpyDefault, stream);
@@ -36,6 +44,7 @@ class Pointcloud {
  private:
   Vector3f* data_ = nullptr;
   size_t size_ = 0, cap_ = 0;
+  float* times_ = nullptr; size_t times_size_ = 0, times_cap_ = 0;
   MemoryType memory_type_;
 };
 

@@ -183,6 +183,12 @@ int nvbx_integrate_lidar_depth(nvbx_mapper* m, const float* range_dev, int32_t r
  * range image; NaN points and points outside the model are skipped; several points in one pixel: one of them wins. */
 int nvbx_depth_image_from_pointcloud(nvbx_mapper* m, const float* points_xyz_dev, int64_t n_points, const nvbx_lidar* lidar,
                                      float* range_dev);
+/* [U] LiDAR motion compensation (use_lidar_motion_compensation, nvblox_node.cpp:1339-1384): every point carries its time within the
+ * scan (rel_time_ms, 0 = scan start = the time T_L_S_start refers to); the sensor pose at that time is interpolated between
+ * T_L_S_start and T_L_S_end (translation linearly, rotation by normalised quaternion interpolation) and the point is re-expressed
+ * in the sensor frame at scan start.  Out may alias in.  Asynchronous.  Feed the result to nvbx_depth_image_from_pointcloud. */
+int nvbx_motion_compensate_pointcloud(nvbx_mapper* m, const float* points_in_dev, const float* rel_time_ms_dev, int64_t n_points,
+                                      const float T_L_S_start[16], const float T_L_S_end[16], float scan_duration_ms, float* points_out_dev);
 /* MultiMapper::integrateColor(const ColorImage&, const Transform&, const Camera&) -- nvblox_node.cpp:1264.
  * rgb_dev: rows*cols*3 bytes, nvblox::Color order r,g,b (image_conversions.cpp:100-101). */
 int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16],

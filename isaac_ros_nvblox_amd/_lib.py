@@ -99,6 +99,7 @@ SIGNATURES = {
     "nvbx_synchronize": (C.c_int, [_vp]),
     "nvbx_flush": (C.c_int, [_vp]),
     "nvbx_decay_occupancy": (C.c_int, [_vp]),
+    "nvbx_motion_compensate_pointcloud": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, C.c_float, _vp]),
     "nvbx_set_time_ms": (C.c_int, [_vp, C.c_int64]),
     "nvbx_detect_dynamics": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera), C.c_float, _vp]),
     "nvbx_remove_small_components": (C.c_int, [_vp, _vp, _i32, _i32, _i32]),

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include "nvbx_mapper.h"
+#include "nvbx_motion_math.h"
 
 using namespace nvbx;
 
@@ -67,6 +68,30 @@ extern "C" int nvbx_transform_pointcloud(nvbx_mapper* m, const float T_L_C[16], 
   Rt T;
   for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) T.R[3 * i + j] = T_L_C[4 * i + j]; T.t[i] = T_L_C[4 * i + 3]; }
   NVBX_LAUNCH(m, k_transform_points, dim3((unsigned)std::min<int64_t>((n_points + 255) / 256, 2048)), dim3(256), T, points_in_dev, n_points, points_out_dev);
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ LiDAR motion compensation
+__global__ __launch_bounds__(256) void k_motion_compensate(nvbx_rel_motion mo, const float* in, const float* rel_ms, int64_t n, float inv_duration, float* out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float a = rel_ms[i] * inv_duration;
+    if (!(a > 0.0f)) a = 0.0f;
+    if (a > 1.0f) a = 1.0f;
+    const float p[3] = {in[3 * i], in[3 * i + 1], in[3 * i + 2]};
+    float o[3]; nvbx_motion_compensate_point(&mo, a, p, o);
+    out[3 * i] = o[0]; out[3 * i + 1] = o[1]; out[3 * i + 2] = o[2];
+  }
+}
+extern "C" int nvbx_motion_compensate_pointcloud(nvbx_mapper* m, const float* points_in_dev, const float* rel_time_ms_dev, int64_t n_points,
+                                                 const float T_L_S_start[16], const float T_L_S_end[16], float scan_duration_ms, float* points_out_dev) {
+  if (!m || !T_L_S_start || !T_L_S_end || n_points < 0 || (n_points > 0 && (!points_in_dev || !rel_time_ms_dev || !points_out_dev)) || !(scan_duration_ms > 0.0f)) {
+    set_error("nvbx_motion_compensate_pointcloud: invalid argument"); return NVBX_E_INVALID; }
+  if (n_points == 0) return NVBX_OK;
+  NVBX_HIP(hipSetDevice(m->device));
+  const nvbx_rel_motion mo = nvbx_rel_motion_make(T_L_S_start, T_L_S_end);
+  NVBX_LAUNCH(m, k_motion_compensate, dim3((unsigned)std::min<int64_t>((n_points + 255) / 256, 2048)), dim3(256), mo, points_in_dev, rel_time_ms_dev, n_points,
+              1.0f / scan_duration_ms, points_out_dev);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }

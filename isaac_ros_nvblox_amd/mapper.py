@@ -158,6 +158,18 @@ class Mapper:
         T = self._T(T_L_C); k = self._lidar(lidar)
         return (self.lib.nvbx_integrate_lidar_depth, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k), (d, T, k))
 
+    def motion_compensate_pointcloud(self, points, rel_time_ms, T_L_S_start, T_L_S_end, scan_duration_ms):
+        """LiDAR motion compensation: points [n, 3] measured at rel_time_ms [n] within the scan -> sensor frame at scan start (device tensor)."""
+        torch = self._torch
+        p = self._dev(np.ascontiguousarray(points, np.float32) if not isinstance(points, torch.Tensor) else points, torch.float32)
+        t = self._dev(np.ascontiguousarray(rel_time_ms, np.float32) if not isinstance(rel_time_ms, torch.Tensor) else rel_time_ms, torch.float32)
+        out = torch.empty_like(p)
+        self._check(self.lib.nvbx_motion_compensate_pointcloud(self._h, C.c_void_p(p.data_ptr()), C.c_void_p(t.data_ptr()), p.shape[0],
+                                                               _np_ptr(self._T(T_L_S_start)), _np_ptr(self._T(T_L_S_end)), float(scan_duration_ms),
+                                                               C.c_void_p(out.data_ptr())))
+        self.synchronize()
+        return out
+
     def depth_image_from_pointcloud(self, points, lidar):
         torch = self._torch
         p = self._dev(points, torch.float32)

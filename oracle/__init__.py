@@ -136,6 +136,7 @@ def lib():
         L.orc_decay_tsdf.restype = i64; L.orc_decay_tsdf.argtypes = [vp, C.c_int]
         L.orc_decay_occupancy.restype = i64; L.orc_decay_occupancy.argtypes = [vp]
         L.orc_set_time_ms.argtypes = [vp, C.c_int64]
+        L.orc_motion_compensate_pointcloud.argtypes = [vp, vp, i64, vp, vp, C.c_float, vp]
         L.orc_detect_dynamics.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_float, vp]
         L.orc_remove_small_components.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
         L.orc_clear_tsdf_inside_shapes.restype = i64; L.orc_clear_tsdf_inside_shapes.argtypes = [vp, vp, i32]
@@ -313,6 +314,14 @@ def depth_image_from_pointcloud(points, lidar):
     img = np.zeros((int(lidar[1]), int(lidar[0])), np.float32)
     lib().orc_depth_image_from_pointcloud(_p(pts), pts.shape[0], _p(l5), _p(img))
     return img
+
+
+def motion_compensate_pointcloud(points, rel_time_ms, T_L_S_start, T_L_S_end, scan_duration_ms):
+    p = np.ascontiguousarray(points, np.float32); t = np.ascontiguousarray(rel_time_ms, np.float32)
+    T0 = np.ascontiguousarray(np.asarray(T_L_S_start, np.float32).reshape(4, 4)); T1 = np.ascontiguousarray(np.asarray(T_L_S_end, np.float32).reshape(4, 4))
+    out = np.zeros_like(p)
+    lib().orc_motion_compensate_pointcloud(_p(p), _p(t), p.shape[0], _p(T0), _p(T1), float(scan_duration_ms), _p(out))
+    return out
 
 
 def remove_small_components(mask, min_size):

@@ -45,6 +45,7 @@
 /* The LiDAR sensor model (projection, atan2 polynomial) is shared with the product so both sides produce identical
  * bits for the projection; a product header included by test infrastructure, not the other way round. */
 #include "../isaac_ros_nvblox_amd/csrc/nvbx_lidar_math.h"
+#include "../isaac_ros_nvblox_amd/csrc/nvbx_motion_math.h"
 
 #define VPS 8
 #define NVOX 512
@@ -1453,6 +1454,18 @@ int64_t orc_clear_tsdf_inside_shapes(OrcMap* m, const float* shapes, int32_t n) 
     if (touched) { b->dirty_esdf = 1; b->dirty_mesh = 1; }
   }
   return cleared;
+}
+
+/* [U] LiDAR motion compensation restated (nvbx_motion_math.h holds the shared per-point arithmetic) */
+void orc_motion_compensate_pointcloud(const float* in, const float* rel_ms, int64_t n, const float* T0, const float* T1, float duration_ms, float* out) {
+  const nvbx_rel_motion mo = nvbx_rel_motion_make(T0, T1);
+  const float inv = 1.0f / duration_ms;
+  for (int64_t i = 0; i < n; i++) {
+    float a = rel_ms[i] * inv;
+    if (!(a > 0.0f)) a = 0.0f;
+    if (a > 1.0f) a = 1.0f;
+    nvbx_motion_compensate_point(&mo, a, in + 3 * i, out + 3 * i);
+  }
 }
 
 /* ------------------------------------------------------------------ mask splitting (human mapping) */

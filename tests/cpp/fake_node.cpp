@@ -174,6 +174,19 @@ static int lidarMain() {
   cuda_stream_->synchronize();
   size_t valid = 0; double sum = 0.0;
   for (float v : host) if (v > 0.f) { valid++; sum += v; }
+  // the same scan with use_lidar_motion_compensation (nvblox_node.cpp:1339-1384): per-point times, pose at scan end, scan duration;
+  // with identical start / end poses the de-skewed cloud is the cloud itself
+  {
+    auto mm2 = std::make_shared<MultiMapper>(0.1f, MappingType::kStaticTsdf, EsdfMode::k2D, MemoryType::kDevice, cuda_stream_);
+    mm2->setMapperParams(p);
+    std::vector<float> rel_ms(pts.size());
+    for (size_t i = 0; i < pts.size(); i++) rel_ms[i] = 100.0f * (float)i / (float)pts.size();
+    nvblox_pointcloud.copyTimestampsFromAsync(rel_ms.data(), rel_ms.size(), *cuda_stream_);
+    mm2->integrateDepth(nvblox_pointcloud, T_L_C, lidar, true, std::optional<Transform>(T_L_C), std::optional<Time>(Time(100)), update_time_ms);
+    cuda_stream_->synchronize();
+    if (mm2->background_mapper()->tsdf_layer().numAllocatedBlocks() != multi_mapper_->background_mapper()->tsdf_layer().numAllocatedBlocks()) {
+      std::fprintf(stderr, "motion-compensated scan gave a different map\n"); return 1; }
+  }
   std::printf("{\"lidar_blocks\": %d, \"range_valid\": %zu, \"range_mean\": %.6f}\n",
               multi_mapper_->background_mapper()->tsdf_layer().numAllocatedBlocks(), valid, valid ? sum / valid : 0.0);
   return 0;
