@@ -34,9 +34,12 @@ def algorithmic_bytes(kernel, c, rows, cols):
     if kernel.startswith("k_mark_view"):
         return (rows // 4) * (cols // 4) * 4 + Nv * 16 * 2          # sub-sampled depth read + one hash entry RMW per block in view
     if kernel.startswith("k_integrate_color"):
-        # colour + synthetic depth + TSDF band scan + colour RMW, plus the ESDF site marking that rides in the same launch
-        # (TSDF z-band of the re-marked columns read, slice plane + site mask written)
-        return rows * cols * 3 + (rows // 4) * (cols // 4) * 4 + Na * B + Nc * B * 2 + Nu * 2 * B + Nu * 520
+        # SURVEY 8(d) bytes_color minus the sphere tracer's share: colour image + synthetic depth read + TSDF of the band blocks
+        # + colour RMW of the band blocks, plus the ESDF site marking that rides in the same launch (bytes_esdf's first term:
+        # TSDF z-band of the re-marked columns read; slice plane masks written).  NOT counted: the kernel's speculative read of
+        # EVERY allocated TSDF block for the band vote (N_a x 4 KiB, see `band_scan_bytes`) -- it buys one dependent round
+        # trip and shows up as `traffic` above the algorithmic bytes.
+        return rows * cols * 3 + (rows // 4) * (cols // 4) * 4 + Nc * B + Nc * B * 2 + Nu * 2 * B + Nu * 520
     if kernel.startswith("k_sphere_trace"):
         return (rows // 4) * (cols // 4) * 4 + Nc * B                # synthetic depth write + TSDF blocks read once
     if kernel.startswith("k_esdf_mark"):
@@ -280,6 +283,7 @@ def main():
         us = max(0.1, v_["total_ms"] / v_["count"] * 1e3 - ev_overhead_us)
         ab = algorithmic_bytes(short(k_), counts, rows, cols)
         kern[short(k_)] = {"avg_us": us, "launches_per_frame": v_["count"] / n2, "algorithmic_bytes": int(ab),
+                           **({"band_scan_bytes": int((counts["blocks_allocated"] - counts["color_blocks_updated"]) * 4096)} if short(k_).startswith("k_integrate_color") else {}),
                            "achieved_GBps": (ab / (us * 1e-6) / 1e9) if us > 0 else 0.0,
                            "hbm_traffic_bytes": pmc.get(short(k_), {}).get("hbm_bytes_per_launch")}
     hot = [k_ for k_ in kern if not k_.startswith("k_mesh")]
