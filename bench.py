@@ -36,9 +36,8 @@ def algorithmic_bytes(kernel, c, rows, cols):
     if kernel.startswith("k_integrate_color"):
         # SURVEY 8(d) bytes_color minus the sphere tracer's share: colour image + synthetic depth read + TSDF of the band blocks
         # + colour RMW of the band blocks, plus the ESDF site marking that rides in the same launch (bytes_esdf's first term:
-        # TSDF z-band of the re-marked columns read; slice plane masks written).  NOT counted: the kernel's speculative read of
-        # EVERY allocated TSDF block for the band vote (N_a x 4 KiB, see `band_scan_bytes`) -- it buys one dependent round
-        # trip and shows up as `traffic` above the algorithmic bytes.
+        # TSDF z-band of the re-marked columns read; slice plane masks written).  (The kernel itself no longer reads the TSDF for
+        # the band vote -- an exact per-block flag kept by the TSDF writers decides it -- so its traffic is below this figure.)
         return rows * cols * 3 + (rows // 4) * (cols // 4) * 4 + Nc * B + Nc * B * 2 + Nu * 2 * B + Nu * 520
     if kernel.startswith("k_sphere_trace"):
         return (rows // 4) * (cols // 4) * 4 + Nc * B                # synthetic depth write + TSDF blocks read once
@@ -283,7 +282,6 @@ def main():
         us = max(0.1, v_["total_ms"] / v_["count"] * 1e3 - ev_overhead_us)
         ab = algorithmic_bytes(short(k_), counts, rows, cols)
         kern[short(k_)] = {"avg_us": us, "launches_per_frame": v_["count"] / n2, "algorithmic_bytes": int(ab),
-                           **({"band_scan_bytes": int((counts["blocks_allocated"] - counts["color_blocks_updated"]) * 4096)} if short(k_).startswith("k_integrate_color") else {}),
                            "achieved_GBps": (ab / (us * 1e-6) / 1e9) if us > 0 else 0.0,
                            "hbm_traffic_bytes": pmc.get(short(k_), {}).get("hbm_bytes_per_launch")}
     hot = [k_ for k_ in kern if not k_.startswith("k_mesh")]

@@ -119,8 +119,8 @@ __device__ inline uint32_t blend_u8(float c0, float w0, float c1, float w1) {
   return (uint32_t)v;
 }
 
-// Dependent-access chain: {slot flags, Index3D, TSDF voxel} (all addressed by the slot id alone, fetched together)
-// -> block vote -> {synthetic depth gather, colour gather, colour voxel} (fetched together) -> store.
+// Dependent-access chain: {slot flags (incl. the exact band flag), Index3D} (addressed by the slot id alone, fetched together)
+// -> frustum vote -> {synthetic depth gather, colour gather, colour voxel} (fetched together) -> store.
 // Workgroups [0, n_mark_wg) are ESDF marking workers (first wavefront only; dispatched first so that they start at once and
 // do not queue for a CU slot behind the resident batch of colour workgroups); the n_color_wg after them integrate colour.
 template <typename Pix>
@@ -138,25 +138,23 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rg
   }
   const int32_t wg = (int32_t)blockIdx.x - n_mark_wg, n_color_wg = (int32_t)gridDim.x - n_mark_wg;
   __shared__ int s_out[6];
-  __shared__ int s_band;
   const int tid = threadIdx.x;
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
   // the first slot's data is requested beside the high-water mark (gridDim.x <= capacity, so the addresses are valid)
   int32_t slot = wg;
   uint32_t flags = m.slot_flags[slot];
   int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
-  float2 tv = m.tsdf[(size_t)slot * 512 + tid];                  // zero for slots without a TSDF block
   const int32_t hw = m.counters[C_HIGH_WATER];
   for (; slot < hw; slot += n_color_wg) {
     if (slot != wg) {
       flags = m.slot_flags[slot];
       bx = m.slot_index[3 * slot]; by = m.slot_index[3 * slot + 1]; bz = m.slot_index[3 * slot + 2];
-      tv = m.tsdf[(size_t)slot * 512 + tid];
     }
-    if (!(flags & F_TSDF)) continue;     // uniform
+    // the band vote ("any voxel with weight > 0 and |distance| < truncation") is the slot's F_BAND flag, kept exact by every
+    // kernel that writes TSDF voxels (nvbx_internal.h): no TSDF read here at all
+    if (!(flags & F_TSDF) || !(flags & F_BAND)) continue;     // uniform
     __syncthreads();
     if (tid < 6) s_out[tid] = 0;
-    if (tid == 6) s_band = 0;
     __syncthreads();
     if (tid < 8) {   // frustum: count corners outside each plane
       float pc[3];
@@ -169,12 +167,11 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rg
       if (pc[2] < 0.0f) atomicAdd(&s_out[4], 1);
       if (f.max_dist > 0.0f && pc[2] > f.max_dist) atomicAdd(&s_out[5], 1);
     }
-    if (tv.y > 1e-4f && fabsf(tv.x) < f.trunc) s_band = 1;   // benign race: all writers store 1
     __syncthreads();
     bool in_view = true;
 #pragma unroll
     for (int q = 0; q < 6; q++) if (s_out[q] == 8) in_view = false;
-    if (!in_view || !s_band) continue;                // uniform
+    if (!in_view) continue;                // uniform
     if (tid == 0) {
       const uint32_t old = atomicOr(&m.slot_flags[slot], F_COLOR | F_DIRTY_MESH);
       if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, slot);

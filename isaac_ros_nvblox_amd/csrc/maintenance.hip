@@ -22,7 +22,7 @@ __device__ inline void free_slot(DMap& m, uint32_t slot) {   // one thread
 // an ESDF block, that column is flagged for a re-mark (F_ESDF_REMARK) and put on the ESDF work list -- the flag lives on the
 // ESDF slot, which survives, not on the TSDF slot, which may be freed and recycled before the update runs.
 __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, int32_t mesh_list,
-                                               int32_t bz_lo, int32_t bz_hi, int32_t bz_out) {
+                                               int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc) {
   __shared__ int s_alive;
   const int32_t hw = m.counters[C_HIGH_WATER];
   const int tid = threadIdx.x;
@@ -38,8 +38,10 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
     if (!(tv.y < thresh)) s_alive = 1;
     __syncthreads();
     const bool alive = s_alive != 0;
+    const int any_band = __syncthreads_or((alive && in_band(tv.x, tv.y, trunc)) ? 1 : 0);
     if (alive) {
       m.tsdf[(size_t)slot * 512 + tid] = tv;
+      if (tid == 0) { if (any_band) atomicOr(&m.slot_flags[slot], F_BAND); else atomicAnd(&m.slot_flags[slot], ~F_BAND); }
     } else {
       m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f);
       m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
         if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, slot);
       } else {
         old = atomicOr(&m.slot_flags[slot], F_DIRTY_MESH);
-        atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH | F_FREESPACE));
+        atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH | F_FREESPACE | F_BAND));
         const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
         if (bz >= bz_lo && bz <= bz_hi) {
           const uint32_t es = bz_out == INT32_MIN ? (uint32_t)slot : any_slot(m, bx, by, bz_out);   // 3-D ESDF: the block's own slot (the table is rebuilt after this kernel, not during it)
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float c
         atomicMin(shc_at(m, srec, sh, 0), bx); atomicMin(shc_at(m, srec, sh, 1), by);
         atomicMax(shc_at(m, srec, sh, 2), bx); atomicMax(shc_at(m, srec, sh, 3), by);
       }
-      atomicAnd(&m.slot_flags[slot], ~(LAYER_MASK | F_DIRTY_ESDF | F_DIRTY_MESH | F_ESDF_REMARK));
+      atomicAnd(&m.slot_flags[slot], ~(LAYER_MASK | F_DIRTY_ESDF | F_DIRTY_MESH | F_ESDF_REMARK | F_BAND));
       m.site_bits[slot] = 0ull; m.obs_bits[slot] = 0ull; m.inside_bits[slot] = 0ull; free_slot(m, (uint32_t)slot);
     }
   }
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float c
 // Mapper::clearTsdfInsideShapes (nvblox_node.cpp:1834): one workgroup per TSDF block, lane = voxel; the shape list sits in
 // kernel-argument space (<= 16 shapes per launch)
 struct ShapeArgs { int32_t n; nvbx_bounding_shape s[16]; };
-__global__ __launch_bounds__(512) void k_clear_shapes(DMap m, ShapeArgs sh, float vs, float bs, int32_t mesh_list) {
+__global__ __launch_bounds__(512) void k_clear_shapes(DMap m, ShapeArgs sh, float vs, float bs, int32_t mesh_list, float trunc, int32_t occupancy) {
   __shared__ int s_touched;
   const int32_t hw = m.counters[C_HIGH_WATER];
   const int tid = threadIdx.x;
@@ -123,7 +125,10 @@ __global__ __launch_bounds__(512) void k_clear_shapes(DMap m, ShapeArgs sh, floa
       if (q.kind == 0) { const float dx = px - q.a[0], dy = py - q.a[1], dz = pz - q.a[2]; inside = ((dx * dx + dy * dy) + dz * dz) <= q.b[0] * q.b[0]; }
       else inside = px >= q.a[0] && py >= q.a[1] && pz >= q.a[2] && px <= q.b[0] && py <= q.b[1] && pz <= q.b[2];
     }
-    if (inside) { m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f); s_touched = 1; }
+    float2 fin = m.tsdf[(size_t)slot * 512 + tid];
+    if (inside) { fin = make_float2(0.0f, 0.0f); m.tsdf[(size_t)slot * 512 + tid] = fin; s_touched = 1; }
+    const int any_band = __syncthreads_or((!occupancy && in_band(fin.x, fin.y, trunc)) ? 1 : 0);
+    if (tid == 0 && s_touched && !occupancy) { if (any_band) atomicOr(&m.slot_flags[slot], F_BAND); else atomicAnd(&m.slot_flags[slot], ~F_BAND); }
     __syncthreads();
     if (tid == 0 && s_touched) {
       const uint32_t old = atomicOr(&m.slot_flags[slot], F_DIRTY_ESDF | F_DIRTY_MESH);
@@ -141,7 +146,8 @@ extern "C" int nvbx_clear_tsdf_inside_shapes(nvbx_mapper* m, const nvbx_bounding
   for (int32_t o = 0; o < n_shapes; o += 16) {
     ShapeArgs a{}; a.n = std::min(16, n_shapes - o);
     for (int i = 0; i < a.n; i++) a.s[i] = shapes_host[o + i];
-    NVBX_LAUNCH(m, k_clear_shapes, dim3(grid), dim3(512), m->d, a, m->p.voxel_size, m->p.voxel_size * 8.0f, m->mesh_list_live());
+    NVBX_LAUNCH(m, k_clear_shapes, dim3(grid), dim3(512), m->d, a, m->p.voxel_size, m->p.voxel_size * 8.0f, m->mesh_list_live(),
+                m->p.truncation_distance_vox * m->p.voxel_size, (int32_t)(m->p.projective_layer_type == 1));
   }
   NVBX_HIP(hipGetLastError());
   return m->mark_main();
@@ -248,7 +254,8 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   EsdfArgs ea = m->make_esdf_args();
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
   NVBX_LAUNCH(m, k_decay, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
-                     exclude_last_view ? m->last_view_frame : 0u, m->mesh_list_live(), ea.bz_lo, ea.bz_hi, ea.bz_out);
+                     exclude_last_view ? m->last_view_frame : 0u, m->mesh_list_live(), ea.bz_lo, ea.bz_hi, ea.bz_out,
+                     m->p.truncation_distance_vox * m->p.voxel_size);
   return rebuild_table(m);
 }
 

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512) void k_gather_blocks(DMap m, uint32_t layer, i
 
 // allocateBlockAtIndex + whole-block write from reference structs: workgroup i writes block idx[i] from in[i][512]
 __global__ __launch_bounds__(512) void k_scatter_blocks(DMap m, uint32_t layer, int32_t occupancy, const int32_t* idx, const uint8_t* in_all, size_t block_bytes,
-                                                        int32_t mesh_list, int32_t bz_out, int32_t vz_out) {
+                                                        int32_t mesh_list, int32_t bz_out, int32_t vz_out, float trunc) {
   __shared__ uint32_t s_slot;
   __shared__ u64 s_sites, s_obs, s_ins;
   const int t = threadIdx.x;
@@ -136,7 +136,12 @@ __global__ __launch_bounds__(512) void k_scatter_blocks(DMap m, uint32_t layer, 
   const uint32_t s = s_slot;
   if (!slot_ok(s)) return;
   if (layer == F_TSDF && occupancy) m.tsdf[(size_t)s * 512 + t] = make_float2(reinterpret_cast<const float*>(in)[t], 0.0f);
-  else if (layer == F_TSDF) m.tsdf[(size_t)s * 512 + t] = reinterpret_cast<const float2*>(in)[t];
+  else if (layer == F_TSDF) {
+    const float2 v = reinterpret_cast<const float2*>(in)[t];
+    m.tsdf[(size_t)s * 512 + t] = v;
+    const int any_band = __syncthreads_or(in_band(v.x, v.y, trunc) ? 1 : 0);        // (uniform branch: the whole workgroup is here)
+    if (t == 0) { if (any_band) atomicOr(&m.slot_flags[s], F_BAND); else atomicAnd(&m.slot_flags[s], ~F_BAND); }
+  }
   else if (layer == F_COLOR) m.color[(size_t)s * 512 + t] = reinterpret_cast<const uint2*>(in)[t];
   else if (layer == F_ESDF) {
     const int vx = t >> 6, vy = (t >> 3) & 7, vz = t & 7;
@@ -152,6 +157,16 @@ __global__ __launch_bounds__(512) void k_scatter_blocks(DMap m, uint32_t layer, 
     }
     __syncthreads();
     if (t == 0) { m.site_bits[s] = (z == bz_out) ? s_sites : 0ull; m.obs_bits[s] = (z == bz_out) ? s_obs : 0ull; m.inside_bits[s] = (z == bz_out) ? s_ins : 0ull; }
+  }
+}
+
+__global__ __launch_bounds__(512) void k_recompute_band(DMap m, float trunc) {
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  for (int32_t slot = blockIdx.x; slot < hw; slot += gridDim.x) {
+    if (!(m.slot_flags[slot] & F_TSDF)) continue;             // uniform
+    const float2 v = m.tsdf[(size_t)slot * 512 + threadIdx.x];
+    const int any_band = __syncthreads_or(in_band(v.x, v.y, trunc) ? 1 : 0);
+    if (threadIdx.x == 0) { if (any_band) atomicOr(&m.slot_flags[slot], F_BAND); else atomicAnd(&m.slot_flags[slot], ~F_BAND); }
   }
 }
 
@@ -331,7 +346,13 @@ extern "C" int nvbx_mapper_set_params(nvbx_mapper* m, const nvbx_mapper_params* 
     }
   }
   if (m->join_side()) return NVBX_E_DEVICE;        // work enqueued under the old parameters (a held-back EDT) is launched first
-  m->p = *params; return NVBX_OK;
+  const bool trunc_changed = params->truncation_distance_vox != m->p.truncation_distance_vox;
+  m->p = *params;
+  if (trunc_changed && m->p.projective_layer_type != 1) {       // F_BAND is defined by the truncation distance: recompute it for every TSDF block
+    NVBX_LAUNCH(m, k_recompute_band, dim3((unsigned)std::min<int64_t>(m->capacity, 2048)), dim3(512), m->d, m->p.truncation_distance_vox * m->p.voxel_size);
+    NVBX_HIP(hipGetLastError());
+  }
+  return NVBX_OK;
 }
 extern "C" int nvbx_mapper_get_params(const nvbx_mapper* m, nvbx_mapper_params* out) {
   if (!m || !out) return NVBX_E_INVALID;
@@ -494,7 +515,7 @@ extern "C" int nvbx_set_blocks(nvbx_mapper* m, uint32_t layer, const nvbx_index3
     NVBX_HIP(hipMemcpyAsync(d_idx, idx + o, (size_t)c * 12, hipMemcpyHostToDevice, m->stream));
     NVBX_HIP(hipMemcpyAsync(d_in, (const uint8_t*)voxels_in + (size_t)o * bb, (size_t)c * bb, hipMemcpyHostToDevice, m->stream));
     NVBX_LAUNCH(m, k_scatter_blocks, dim3((unsigned)c), dim3(512), m->d, ilayer, (int32_t)(layer == NVBX_LAYER_OCCUPANCY), (const int32_t*)d_idx, (const uint8_t*)d_in, bb,
-                (int32_t)m->mesh_list_live(), ea.bz_out, ea.vz_out);
+                (int32_t)m->mesh_list_live(), ea.bz_out, ea.vz_out, m->p.truncation_distance_vox * m->p.voxel_size);
     NVBX_HIP(hipStreamSynchronize(m->stream));
   }
   return NVBX_OK;

@@ -37,6 +37,12 @@ constexpr uint32_t F_ESDF_PENDING = 1u << 10;
 // on an ESDF slot: a TSDF block of this column's z band was deallocated (decay), so the column must be re-marked by the next
 // ESDF update although no TSDF block of it may be dirty (or even exist); cleared by the distance transform of that update
 constexpr uint32_t F_ESDF_REMARK = 1u << 11;
+// on a TSDF slot: EXACTLY "some voxel of the block lies in the truncation band (weight > 1e-4 and |distance| < truncation
+// distance)" -- the block-level vote of the colour integrator, kept up to date by every kernel that writes TSDF voxels
+// (integration, decay, clearing, block upload; recomputed for all blocks if the truncation distance changes), so that
+// integrateColor decides it from the flags it loads anyway instead of reading 4 KiB of TSDF per allocated block
+constexpr uint32_t F_BAND = 1u << 12;
+__host__ __device__ inline bool in_band(float d, float w, float trunc) { return w > 1e-4f && fabsf(d) < trunc; }
 
 struct Entry { u64 key; uint32_t slot; uint32_t stamp; };
 

@@ -437,10 +437,11 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img dep
              voxel_center(rec_c.w, vz, f.block_size, f.voxel_size), pc);
     float ds = 0.0f, vd = 0.0f;
     const int got = sensor.sample(f, depth, pc, &ds, &vd);
+    float2 fin = cur_c;            // the voxel as this launch leaves it
     if (f.occupancy) {            // occupancy mapper: the pool holds log-odds (nvbx_internal.h occupancy_update)
       if (got > 0) *vp = make_float2(occupancy_update(f, cur_c.x, ds, vd), 0.0f);
     } else {
-      if (got < 0 && f.invalid_decay >= 0.0f) *vp = make_float2(cur_c.x, cur_c.y * f.invalid_decay);
+      if (got < 0 && f.invalid_decay >= 0.0f) { fin = make_float2(cur_c.x, cur_c.y * f.invalid_decay); *vp = fin; }
       if (got > 0) {
         const float sdf = ds - vd;
         if (!(sdf < -f.trunc)) {
@@ -449,10 +450,13 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img dep
           if (wsum > 0.0f) {
             float fused = (sdf * wm + cur_c.x * cur_c.y) / wsum;
             if (fused > 0.0f) fused = fminf(f.trunc, fused); else fused = fmaxf(-f.trunc, fused);
-            *vp = make_float2(fused, fminf(wsum, f.max_weight));
+            fin = make_float2(fused, fminf(wsum, f.max_weight)); *vp = fin;
           }
         }
       }
+      // block-level band vote for the colour integrator (F_BAND, nvbx_internal.h): exact, so set AND cleared here
+      const int any_band = __syncthreads_or(in_band(fin.x, fin.y, f.trunc) ? 1 : 0);
+      if (tid == 0) { if (any_band) atomicOr(&m.slot_flags[slot], F_BAND); else atomicAnd(&m.slot_flags[slot], ~F_BAND); }
     }
     if (tid == 0) {
       if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)slot);
