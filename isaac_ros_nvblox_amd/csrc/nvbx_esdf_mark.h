@@ -81,11 +81,19 @@ __device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_
 }
 
 // `wg` of `nwg` single-wavefront workers; called by k_esdf_mark and by the marking workgroups fused into k_integrate_color.
+// Worker w serves shard (w & 7) of the dirty list, entries (w >> 3), (w >> 3) + nwg / 8, ...: the entry's address does not
+// depend on the other shards' counts, so the shard's count and the worker's first entry are fetched together (one dependent
+// round trip less than a prefix over all eight counts followed by the entry).
 __device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg, int nwg) {
-  ListView lv;
-  const int32_t n = list_open(m, S_LIST_ESDF_DIRTY, &lv);
+  const int per = nwg >> 3;                               // workers per shard
+  const int sh_l = wg & (NSH - 1), j0 = wg >> 3;
+  if (per < 1 || j0 >= per) return;
+  const int32_t* base = &m.lists[((size_t)S_LIST_ESDF_DIRTY * NSH + sh_l) * m.capacity];
+  const int32_t first = base[j0];                         // speculative: valid iff j0 < cnt (j0 < per <= capacity)
+  int32_t cnt = *shc_at(m, S_LIST_ESDF_DIRTY, sh_l, 0);
+  if (cnt > (int32_t)m.capacity) cnt = (int32_t)m.capacity;
   const int srec = S_ESDF_REC + (int)(a.epoch & 1), sh = my_shard();
-  for (int32_t i = wg; i < n; i += nwg) esdf_mark_entry(m, a, (uint32_t)list_at(m, S_LIST_ESDF_DIRTY, lv, i), srec, sh);
+  for (int32_t j = j0; j < cnt; j += per) esdf_mark_entry(m, a, (uint32_t)(j == j0 ? first : base[j]), srec, sh);
 }
 
 // The peers' gathered dirty lists (multi-GPU union step): g = int32 [world][1 + max_count][3], row 0 of a rank = its count.
