@@ -151,8 +151,15 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rg
       bx = m.slot_index[3 * slot]; by = m.slot_index[3 * slot + 1]; bz = m.slot_index[3 * slot + 2];
     }
     // the band vote ("any voxel with weight > 0 and |distance| < truncation") is the slot's F_BAND flag, kept exact by every
-    // kernel that writes TSDF voxels (nvbx_internal.h): no TSDF read here at all
-    if (!(flags & F_TSDF) || !(flags & F_BAND)) continue;     // uniform
+    // kernel that writes TSDF voxels (nvbx_internal.h): no TSDF read here -- unless a LiDAR scan left the block STALE, in which
+    // case this workgroup votes from the TSDF once and repairs the bits
+    if (!(flags & F_TSDF)) continue;     // uniform
+    if (flags & F_BAND_STALE) {          // uniform
+      const float2 tv = m.tsdf[(size_t)slot * 512 + tid];
+      const bool pred = in_band(tv.x, tv.y, f.trunc);
+      publish_band(m.slot_flags, (uint32_t)slot, tid, pred);
+      if (!__syncthreads_or(pred ? 1 : 0)) continue;
+    } else if (!(flags & F_BAND)) continue;
     __syncthreads();
     if (tid < 6) s_out[tid] = 0;
     __syncthreads();

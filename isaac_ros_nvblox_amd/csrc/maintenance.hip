@@ -38,10 +38,9 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
     if (!(tv.y < thresh)) s_alive = 1;
     __syncthreads();
     const bool alive = s_alive != 0;
-    const int any_band = __syncthreads_or((alive && in_band(tv.x, tv.y, trunc)) ? 1 : 0);
     if (alive) {
       m.tsdf[(size_t)slot * 512 + tid] = tv;
-      if (tid == 0) { if (any_band) atomicOr(&m.slot_flags[slot], F_BAND); else atomicAnd(&m.slot_flags[slot], ~F_BAND); }
+      publish_band(m.slot_flags, (uint32_t)slot, tid, in_band(tv.x, tv.y, trunc));
     } else {
       m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f);
       m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
@@ -54,7 +53,7 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
         if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, slot);
       } else {
         old = atomicOr(&m.slot_flags[slot], F_DIRTY_MESH);
-        atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH | F_FREESPACE | F_BAND));
+        atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH | F_FREESPACE | F_BAND | F_BAND_STALE));
         const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
         if (bz >= bz_lo && bz <= bz_hi) {
           const uint32_t es = bz_out == INT32_MIN ? (uint32_t)slot : any_slot(m, bx, by, bz_out);   // 3-D ESDF: the block's own slot (the table is rebuilt after this kernel, not during it)
@@ -98,7 +97,7 @@ __global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float c
         atomicMin(shc_at(m, srec, sh, 0), bx); atomicMin(shc_at(m, srec, sh, 1), by);
         atomicMax(shc_at(m, srec, sh, 2), bx); atomicMax(shc_at(m, srec, sh, 3), by);
       }
-      atomicAnd(&m.slot_flags[slot], ~(LAYER_MASK | F_DIRTY_ESDF | F_DIRTY_MESH | F_ESDF_REMARK | F_BAND));
+      atomicAnd(&m.slot_flags[slot], ~(LAYER_MASK | F_DIRTY_ESDF | F_DIRTY_MESH | F_ESDF_REMARK | F_BAND | F_BAND_STALE));
       m.site_bits[slot] = 0ull; m.obs_bits[slot] = 0ull; m.inside_bits[slot] = 0ull; free_slot(m, (uint32_t)slot);
     }
   }
@@ -127,9 +126,8 @@ __global__ __launch_bounds__(512) void k_clear_shapes(DMap m, ShapeArgs sh, floa
     }
     float2 fin = m.tsdf[(size_t)slot * 512 + tid];
     if (inside) { fin = make_float2(0.0f, 0.0f); m.tsdf[(size_t)slot * 512 + tid] = fin; s_touched = 1; }
-    const int any_band = __syncthreads_or((!occupancy && in_band(fin.x, fin.y, trunc)) ? 1 : 0);
-    if (tid == 0 && s_touched && !occupancy) { if (any_band) atomicOr(&m.slot_flags[slot], F_BAND); else atomicAnd(&m.slot_flags[slot], ~F_BAND); }
     __syncthreads();
+    if (s_touched && !occupancy) publish_band(m.slot_flags, (uint32_t)slot, tid, in_band(fin.x, fin.y, trunc));      // (s_touched is uniform after the barrier)
     if (tid == 0 && s_touched) {
       const uint32_t old = atomicOr(&m.slot_flags[slot], F_DIRTY_ESDF | F_DIRTY_MESH);
       if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, slot);

@@ -139,8 +139,7 @@ __global__ __launch_bounds__(512) void k_scatter_blocks(DMap m, uint32_t layer, 
   else if (layer == F_TSDF) {
     const float2 v = reinterpret_cast<const float2*>(in)[t];
     m.tsdf[(size_t)s * 512 + t] = v;
-    const int any_band = __syncthreads_or(in_band(v.x, v.y, trunc) ? 1 : 0);        // (uniform branch: the whole workgroup is here)
-    if (t == 0) { if (any_band) atomicOr(&m.slot_flags[s], F_BAND); else atomicAnd(&m.slot_flags[s], ~F_BAND); }
+    publish_band(m.slot_flags, s, t, in_band(v.x, v.y, trunc));        // (uniform branch: every wavefront is here)
   }
   else if (layer == F_COLOR) m.color[(size_t)s * 512 + t] = reinterpret_cast<const uint2*>(in)[t];
   else if (layer == F_ESDF) {
@@ -165,8 +164,7 @@ __global__ __launch_bounds__(512) void k_recompute_band(DMap m, float trunc) {
   for (int32_t slot = blockIdx.x; slot < hw; slot += gridDim.x) {
     if (!(m.slot_flags[slot] & F_TSDF)) continue;             // uniform
     const float2 v = m.tsdf[(size_t)slot * 512 + threadIdx.x];
-    const int any_band = __syncthreads_or(in_band(v.x, v.y, trunc) ? 1 : 0);
-    if (threadIdx.x == 0) { if (any_band) atomicOr(&m.slot_flags[slot], F_BAND); else atomicAnd(&m.slot_flags[slot], ~F_BAND); }
+    publish_band(m.slot_flags, (uint32_t)slot, (int)threadIdx.x, in_band(v.x, v.y, trunc));
   }
 }
 

@@ -41,8 +41,25 @@ constexpr uint32_t F_ESDF_REMARK = 1u << 11;
 // distance)" -- the block-level vote of the colour integrator, kept up to date by every kernel that writes TSDF voxels
 // (integration, decay, clearing, block upload; recomputed for all blocks if the truncation distance changes), so that
 // integrateColor decides it from the flags it loads anyway instead of reading 4 KiB of TSDF per allocated block
-constexpr uint32_t F_BAND = 1u << 12;
+// Eight bits, one per x-slab of the block = per wavefront of the 512-thread kernels that write TSDF voxels (thread = voxel
+// z + 8y + 64x, wavefront w holds x = w): each wavefront owns its bit and sets / clears it from its own ballot, so the flag is
+// exact without a workgroup barrier (a barrier per block cost the VALU-bound LiDAR integration 24 %).
+constexpr uint32_t F_BAND_SHIFT = 12, F_BAND = 0xFFu << F_BAND_SHIFT;
+// The LiDAR integration (VALU-bound, ~10^5 blocks per scan) does not keep the bits: it marks the block STALE with the flag atomic
+// it issues anyway, and the first colour integration that meets a stale block votes from the TSDF once and repairs the bits.
+constexpr uint32_t F_BAND_STALE = 1u << 20;
 __host__ __device__ inline bool in_band(float d, float w, float trunc) { return w > 1e-4f && fabsf(d) < trunc; }
+#ifdef __HIPCC__
+// called by ALL lanes of a wavefront of a 512-thread block-per-workgroup kernel; `pred` = this lane's voxel is in the band
+__device__ inline void publish_band(uint32_t* slot_flags, uint32_t slot, int tid, bool pred) {
+  const unsigned long long b = __ballot(pred);
+  if ((tid & 63) == 0) {
+    const uint32_t bit = 1u << (F_BAND_SHIFT + (tid >> 6));
+    if (b) atomicOr(&slot_flags[slot], bit); else atomicAnd(&slot_flags[slot], ~bit);
+    if (tid == 0) atomicAnd(&slot_flags[slot], ~F_BAND_STALE);          // all eight bits are being written: exact again
+  }
+}
+#endif
 
 struct Entry { u64 key; uint32_t slot; uint32_t stamp; };
 

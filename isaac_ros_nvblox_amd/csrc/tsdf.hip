@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img dep
     float2* vp = &m.tsdf[(size_t)slot * 512 + tid];
     const float2 cur_c = *vp;
     uint32_t old = 0;
-    if (tid == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH);
+    if (tid == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH | ((Sensor::kLongRays && !f.occupancy) ? F_BAND_STALE : 0u));
     float pc[3];
     apply_rt(f.R_CL, f.t_CL, voxel_center(rec_c.y, vx, f.block_size, f.voxel_size), voxel_center(rec_c.z, vy, f.block_size, f.voxel_size),
              voxel_center(rec_c.w, vz, f.block_size, f.voxel_size), pc);
@@ -454,9 +454,12 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img dep
           }
         }
       }
-      // block-level band vote for the colour integrator (F_BAND, nvbx_internal.h): exact, so set AND cleared here
-      const int any_band = __syncthreads_or(in_band(fin.x, fin.y, f.trunc) ? 1 : 0);
-      if (tid == 0) { if (any_band) atomicOr(&m.slot_flags[slot], F_BAND); else atomicAnd(&m.slot_flags[slot], ~F_BAND); }
+      // band vote for the colour integrator (F_BAND, nvbx_internal.h): exact, so set AND cleared here, one bit per wavefront
+      if (!Sensor::kLongRays) {      // (LiDAR: marked stale above instead)
+        // one workgroup per block and a few hundred blocks: a block-wide vote and ONE atomic are cheaper here than a bit per wavefront
+        const int any_band = __syncthreads_or(in_band(fin.x, fin.y, f.trunc) ? 1 : 0);
+        if (tid == 0) { if (any_band) atomicOr(&m.slot_flags[slot], F_BAND); else atomicAnd(&m.slot_flags[slot], ~F_BAND); if (old & F_BAND_STALE) atomicAnd(&m.slot_flags[slot], ~F_BAND_STALE); }
+      }
     }
     if (tid == 0) {
       if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)slot);

@@ -182,3 +182,30 @@ def test_motion_compensation_gpu_parity(oracle_mod, hip_lib):
     want = oracle_mod.motion_compensate_pointcloud(pts, t_ms, T0, T1, 100.0)
     assert np.array_equal(out, want)                          # shared arithmetic: bit-exact
     assert np.linalg.norm(out - truth, axis=1).max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_lidar_depth_then_camera_colour_parity(oracle_mod, hip_lib):
+    """A LiDAR scan builds the TSDF, a camera frame colours it (use_lidar + a colour camera): the LiDAR integration leaves the
+    colour integrator's per-block band flags stale and the colour launch repairs them from the TSDF -- same colour layer as the
+    oracle; a second colour frame (flags repaired) and a camera depth frame in between (flags kept exact) as well."""
+    from isaac_ros_nvblox_amd import mapper as M
+    from test_gpu_parity import make_pair, compare_layer
+    lidar = (256, 32, 0.1, -np.deg2rad(30.0), np.deg2rad(30.0))
+    Mm, g, o = make_pair(oracle_mod, lidar_max_integration_distance_m=8.0, raycast_subsampling_factor=2)
+    sc = S.Scene()
+    T_l = np.eye(4, dtype=np.float32); T_l[:3, 3] = [0.2, -0.1, 1.3]
+    rng_img = S.render_lidar(sc, T_l, lidar, max_range=8.0)
+    g.integrate_lidar_depth(rng_img, T_l, lidar); o.integrate_lidar_depth(rng_img, T_l, lidar)
+    cam = H.SMALL_CAM
+    frames = H.frames(3, cam, color=True, stride=15)
+    d, rgb, T = frames[0]
+    g.integrate_color(rgb, T, cam); o.integrate_color(rgb, T, cam)
+    n, _ = compare_layer(Mm, g, o, Mm.LAYER_COLOR, oracle_mod.L_COLOR, fields_tol=("weight",), lsb_fields=("r", "g", "b"))
+    assert n > 20
+    g.integrate_color(frames[1][1], frames[1][2], cam); o.integrate_color(frames[1][1], frames[1][2], cam)
+    g.integrate_depth(frames[2][0], frames[2][2], cam); o.integrate_depth(frames[2][0], frames[2][2], cam)
+    g.integrate_lidar_depth(rng_img, T_l, lidar); o.integrate_lidar_depth(rng_img, T_l, lidar)
+    g.integrate_color(frames[2][1], frames[2][2], cam); o.integrate_color(frames[2][1], frames[2][2], cam)
+    compare_layer(Mm, g, o, Mm.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
+    compare_layer(Mm, g, o, Mm.LAYER_COLOR, oracle_mod.L_COLOR, fields_tol=("weight",), lsb_fields=("r", "g", "b"))
