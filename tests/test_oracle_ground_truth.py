@@ -205,3 +205,78 @@ def test_mask_split_oracle_identity_and_parallax(oracle_mod):
     un2, ma2 = oracle_mod.split_depth_by_mask(d, mask, T, cam, cam, 0.25)
     want = np.zeros_like(mask); want[20:40, 32:52] = 1
     assert np.array_equal(ma2 > 0, (want != 0) & (d > 0))
+
+
+def test_freespace_oracle_timeline(oracle_mod):
+    """The freespace restatement on a hand-checkable timeline: a wall 2 m in front of a fixed camera.  Free voxels in front of it
+    turn into high-confidence freespace exactly min_duration_since_occupied_for_freespace_ms after they were first seen; the
+    wall's voxels never do, and their consecutive occupancy duration grows by the frame period."""
+    cam = (40.0, 40.0, 39.5, 29.5, 80, 60)
+    p = oracle_mod.default_params(projective_layer_type=2, max_integration_distance_m=4.0, min_duration_since_occupied_for_freespace_ms=250,
+                                  max_unobserved_to_keep_consecutive_occupancy_ms=200, min_consecutive_occupancy_duration_for_reset_ms=600,
+                                  check_neighborhood=0)
+    o = oracle_mod.OracleMap(p)
+    T = np.array([[0, 0, 1, 0], [-1, 0, 0, 0], [0, -1, 0, 1.0], [0, 0, 0, 1]], np.float32)      # camera z along +x of the layer frame
+    depth = np.full((60, 80), 2.0, np.float32)
+
+    def voxel(layer, gx, gy, gz):
+        b = o.get_block(layer, np.array([gx >> 3, gy >> 3, gz >> 3], np.int32))
+        return None if b is None else b[(gz & 7) + 8 * (gy & 7) + 64 * (gx & 7)]
+    free_v, wall_v = (20, 0, 20), (40, 0, 20)            # 1.0 m and 2.0 m along +x at height 1 m (voxel 0.05 m)
+    hist = []
+    for k in range(9):
+        o.set_time_ms(100 * k)
+        o.integrate_depth(depth, T, cam)
+        f, w = voxel(oracle_mod.L_FREESPACE, *free_v), voxel(oracle_mod.L_FREESPACE, *wall_v)
+        hist.append((int(f["is_high_confidence_freespace"]), int(w["is_high_confidence_freespace"]), int(w["consecutive_occupancy_duration_ms"]), int(w["last_occupied_timestamp_ms"])))
+    assert [h[0] for h in hist] == [0, 0, 0, 1, 1, 1, 1, 1, 1]          # 250 ms after t = 0 -> the frame at t = 300
+    assert all(h[1] == 0 for h in hist)                                    # the wall is never freespace
+    assert [h[2] for h in hist] == [0, 100, 200, 300, 400, 500, 600, 700, 800] and hist[-1][3] == 800
+    # the mask of dynamic pixels: an object at 1 m in known freespace is dynamic, the wall is not
+    obj = depth.copy(); obj[20:40, 30:50] = 1.0
+    mask = o.detect_dynamics(obj, T, cam, 4.0)
+    assert mask[20:40, 30:50].all() and mask.sum() == 20 * 20
+    # standing still for more than the reset duration, its voxels stop being freespace
+    for k in range(9, 18):
+        o.set_time_ms(100 * k); o.integrate_depth(obj, T, cam)
+    assert o.detect_dynamics(obj, T, cam, 4.0).sum() < 0.5 * 20 * 20
+
+
+def test_remove_small_components_oracle_vs_scipy(oracle_mod):
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(11)
+    for density in (0.2, 0.42, 0.6):
+        mk = (rng.random((90, 130)) < density).astype(np.uint8)
+        lab, n = ndi.label(mk, structure=np.ones((3, 3)))
+        sizes = ndi.sum(mk, lab, index=np.arange(1, n + 1))
+        for thr in (2, 7, 50):
+            want = mk.copy(); want[np.isin(lab, np.nonzero(sizes < thr)[0] + 1)] = 0
+            assert np.array_equal(oracle_mod.remove_small_components(mk, thr), want), (density, thr)
+
+
+def test_esdf_3d_oracle_equals_bruteforce(oracle_mod):
+    """The 3-D ESDF restatement (x / y / z passes with cut-off) is the exact Euclidean distance transform of its own sites."""
+    o = oracle_mod.OracleMap(oracle_mod.default_params(esdf_mode=1, esdf_max_distance_m=0.5, max_integration_distance_m=3.0))
+    cam = (40.0, 40.0, 39.5, 29.5, 80, 60)
+    for d, rgb, T in H.frames(2, cam, color=False, stride=12):
+        o.integrate_depth(d, T, cam)
+    o.update_esdf()
+    idx = o.block_indices(oracle_mod.L_ESDF)
+    assert len(idx) > 100 and H.idx_set(idx) == H.idx_set(o.block_indices(oracle_mod.L_TSDF))
+    lo = idx.min(0); dims = (idx.max(0) - lo + 1) * 8
+    site = np.zeros(dims, bool); sq = np.full(dims, -1.0, np.float32)
+    for i in idx:
+        b = o.get_block(oracle_mod.L_ESDF, i).reshape(8, 8, 8); s = (i - lo) * 8
+        site[s[0]:s[0] + 8, s[1]:s[1] + 8, s[2]:s[2] + 8] = b["is_site"].astype(bool)
+        sq[s[0]:s[0] + 8, s[1]:s[1] + 8, s[2]:s[2] + 8] = b["squared_distance_vox"]
+        assert (np.abs(b["parent_direction"]).max() <= 10)
+        within = b["squared_distance_vox"] < 100.0
+        assert np.array_equal((b["parent_direction"].astype(np.int64) ** 2).sum(-1)[within], b["squared_distance_vox"][within].astype(np.int64))
+    pts = np.argwhere(site); assert len(pts) > 500
+    sub = np.argwhere(sq >= 0.0)
+    sub = sub[np.random.default_rng(0).choice(len(sub), 4000, replace=False)]
+    best = np.full(len(sub), np.inf)
+    for s0 in range(0, len(pts), 4000):
+        best = np.minimum(best, ((sub[:, None, :] - pts[None, s0:s0 + 4000, :]) ** 2).sum(-1).min(1))
+    want = np.where(best <= 100.0, best, 100.0).astype(np.float32)
+    assert np.array_equal(sq[sub[:, 0], sub[:, 1], sub[:, 2]], want)
