@@ -338,7 +338,8 @@ int main(int argc, char** argv) {
     const EsdfLayer& e3 = m3.background_mapper()->esdf_layer();
     size_t sites = 0, known = 0; int zmin = 1 << 30, zmax = -(1 << 30);
     callFunctionOnAllVoxels<EsdfVoxel>(e3, [&](const Index3D& b, const Index3D&, const EsdfVoxel* v) {
-      if (v->is_site) sites++; if (v->observed) known++; zmin = std::min(zmin, b.z()); zmax = std::max(zmax, b.z()); });
+      sites += v->is_site ? 1 : 0; known += v->observed ? 1 : 0;
+      zmin = std::min(zmin, b.z()); zmax = std::max(zmax, b.z()); });
     if (e3.numAllocatedBlocks() != m3.background_mapper()->tsdf_layer().numAllocatedBlocks() || sites < 1000 || known < 10000 || zmax - zmin < 3) {
       std::fprintf(stderr, "3-D ESDF: %d blocks, %zu sites, %zu observed, z %d..%d\n", e3.numAllocatedBlocks(), sites, known, zmin, zmax); return 1; }
   }
