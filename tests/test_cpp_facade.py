@@ -150,3 +150,20 @@ def test_foreign_kernel_reads_map_through_device_view(hip_lib):
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
     got = json.loads(r.stdout.strip().splitlines()[-1])
     assert got["mismatches"] == 0 and got["esdf_known"] > 1000 and got["tsdf_observed"] > 5000 and got["tsdf_blocks"] > 50
+
+
+def test_c_abi_compiles_as_plain_c(hip_lib):
+    """include/nvblox_hip.h is a C header: a C99 translation unit using it builds with gcc and links the library."""
+    subprocess.check_call(["make", "-C", CPP, "c_abi_minimal"], stdout=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(CPP, "c_abi_minimal"))
+
+
+@pytest.mark.gpu
+def test_c_abi_minimal_from_plain_c(hip_lib):
+    """examples/c_abi_minimal.c: depth + colour + ESDF + mesh through the C-ABI from a C program (no C++, no hipcc)."""
+    subprocess.check_call(["make", "-C", CPP, "c_abi_minimal"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(CPP, "c_abi_minimal")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["tsdf_blocks"] > 20 and got["slice_known"] > 100 and got["mesh_triangles"] > 100
+    assert 0.0 <= got["slice_min_m"] < 0.1          # the wall's own columns are sites
