@@ -166,4 +166,4 @@ def test_c_abi_minimal_from_plain_c(hip_lib):
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
     got = json.loads(r.stdout.strip().splitlines()[-1])
     assert got["tsdf_blocks"] > 20 and got["slice_known"] > 100 and got["mesh_triangles"] > 100
-    assert 0.0 <= got["slice_min_m"] < 0.1          # the wall's own columns are sites
+    assert -0.5 < got["slice_min_m"] < 0.1          # the wall's columns: sites, and negative just behind the surface
