@@ -278,11 +278,13 @@ static int integrate_color_impl(nvbx_mapper* m, Pix rgb_dev, int32_t rows, int32
 extern "C" int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                     const nvbx_camera* camera) {
   if (!m || !rgb_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_color: invalid argument"); return NVBX_E_INVALID; }
+  if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_color: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
   return integrate_color_impl(m, PixRgb8{rgb_dev}, rows, cols, T_L_C, camera);
 }
 extern "C" int nvbx_integrate_color_bgra8(nvbx_mapper* m, const uint8_t* bgra_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                           const nvbx_camera* camera) {
   if (!m || !bgra_dev || !T_L_C || !camera || rows <= 0 || cols <= 0 || ((uintptr_t)bgra_dev & 3)) { set_error("nvbx_integrate_color_bgra8: invalid argument"); return NVBX_E_INVALID; }
+  if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_color_bgra8: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
   return integrate_color_impl(m, PixBgra8{reinterpret_cast<const uint32_t*>(bgra_dev)}, rows, cols, T_L_C, camera);
 }
 

@@ -41,11 +41,13 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
     if (m->join_side()) return NVBX_E_DEVICE;
     return m->update_esdf_3d();
   }
+  // (parameters are validated before any state of this update changes)
+  if (m->p.esdf_max_distance_m / m->p.voxel_size >= 64.0f) { set_error("esdf_max_distance_m / voxel_size must be < 64 voxels"); return NVBX_E_INVALID; }
+  { const EsdfArgs chk = m->make_esdf_args();
+    if (chk.bz_hi - chk.bz_lo + 1 > 63 || chk.bz_hi < chk.bz_lo) { set_error("esdf slice z band must span 1..63 blocks"); return NVBX_E_INVALID; } }
   if (m->flush_import()) return NVBX_E_DEVICE;     // a held-back union step belongs to this update
   if (m->dirty_since_mark) m->mark_pass++;
   const EsdfArgs a = m->make_esdf_args();
-  if (m->p.esdf_max_distance_m / m->p.voxel_size >= 64.0f) { set_error("esdf_max_distance_m / voxel_size must be < 64 voxels"); return NVBX_E_INVALID; }
-  if (a.bz_hi - a.bz_lo + 1 > 63 || a.bz_hi < a.bz_lo) { set_error("esdf slice z band must span 1..63 blocks"); return NVBX_E_INVALID; }
   hipStream_t s = m->stream;
   if (m->use_side) {
     // run behind the last non-colour operation, beside any colour integration enqueued after it

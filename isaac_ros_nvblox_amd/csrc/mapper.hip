@@ -81,7 +81,11 @@ __global__ __launch_bounds__(512) void k_gather_blocks(DMap m, uint32_t layer, i
   const uint32_t s = find_slot(m, idx[3 * i], idx[3 * i + 1], idx[3 * i + 2], layer);
   const int t = threadIdx.x;
   if (t == 0) found[i] = slot_ok(s) ? 1 : 0;
-  if (!slot_ok(s)) return;
+  if (!slot_ok(s)) {            // absent block: zeros, never stale staging bytes
+    const size_t vb = layer == F_ESDF ? sizeof(nvbx_esdf_voxel) : (layer == F_FREESPACE ? sizeof(nvbx_freespace_voxel) : ((layer == F_TSDF && occupancy) ? 4 : 8));
+    for (size_t q = t; q < 512 * vb / 4; q += 512) reinterpret_cast<uint32_t*>(out + (size_t)i * 512 * vb)[q] = 0u;
+    return;
+  }
   if (layer == F_TSDF && occupancy) { reinterpret_cast<float*>(out)[(size_t)i * 512 + t] = m.tsdf[(size_t)s * 512 + t].x; }
   else if (layer == F_TSDF) { reinterpret_cast<float2*>(out)[(size_t)i * 512 + t] = m.tsdf[(size_t)s * 512 + t]; }
   else if (layer == F_COLOR) { reinterpret_cast<uint2*>(out)[(size_t)i * 512 + t] = m.color[(size_t)s * 512 + t]; }
@@ -327,6 +331,8 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
                   m->view_list, d.lists, d.shc, m->export_idx, m->export_count, d.site_bits, d.obs_bits, d.inside_bits,
                   m->synth, m->depth_pre, m->mask_zmin, m->esdf3_scratch, m->cc_scratch, d.freespace, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (auto& s : m->spans) { if (s.a) (void)hipEventDestroy(s.a); if (s.b) (void)hipEventDestroy(s.b); }
+  for (hipEvent_t e : m->event_pool) if (e) (void)hipEventDestroy(e);
   if (m->h_counters) (void)hipHostFree(m->h_counters);
   if (m->h_shc) (void)hipHostFree(m->h_shc);
   if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
@@ -643,6 +649,9 @@ int nvbx_mapper::reset_consumed_list() {
   return NVBX_OK;
 }
 int nvbx_mapper::join_side() {
+  // every entry point passes here before its first HIP call: make this mapper's device current (hosts with one mapper per GPU in
+  // one process); a thread-local read when it already is
+  { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != device) NVBX_HIP(hipSetDevice(device)); }
   if (flush_edt()) return NVBX_E_DEVICE;
   if (flush_import()) return NVBX_E_DEVICE;
   main_dirty = true;

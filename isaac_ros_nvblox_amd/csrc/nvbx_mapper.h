@@ -30,6 +30,12 @@ void set_error(const char* what);
 
 }  // namespace nvbx
 
+// the camera model must describe the image that is handed over with it: the kernels bound projections by (width, height) and
+// address pixels by (rows, cols)
+static inline bool nvbx_camera_matches(const nvbx_camera* c, int32_t rows, int32_t cols) {
+  return c && c->width == cols && c->height == rows && c->fu > 0.0f && c->fv > 0.0f;
+}
+
 struct nvbx_mapper {
   int device = 0;
   hipStream_t stream = nullptr;

@@ -541,11 +541,13 @@ static int integrate_camera(nvbx_mapper* m, Img img, int32_t rows, int32_t cols,
 extern "C" int nvbx_integrate_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                     const nvbx_camera* camera) {
   if (!m || !depth_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_depth: invalid argument"); return NVBX_E_INVALID; }
+  if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_depth: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
   return integrate_camera(m, DepthF32{depth_dev}, rows, cols, T_L_C, camera);
 }
 extern "C" int nvbx_integrate_depth_u16mm(nvbx_mapper* m, const uint16_t* depth_mm_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                           const nvbx_camera* camera) {
   if (!m || !depth_mm_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_depth_u16mm: invalid argument"); return NVBX_E_INVALID; }
+  if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_depth_u16mm: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
   return integrate_camera(m, DepthU16mm{depth_mm_dev}, rows, cols, T_L_C, camera);
 }
 

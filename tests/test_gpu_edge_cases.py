@@ -283,3 +283,22 @@ def test_layer_type_and_esdf_mode_are_fixed_once_the_map_has_content(hip_lib):
     g.set_params(M.default_params(projective_layer_type=1))                               # empty again
     g.integrate_depth(d, T, H.SMALL_CAM)
     assert g.num_blocks(M.LAYER_OCCUPANCY) > 10 and g.num_blocks(M.LAYER_TSDF) == 0
+
+
+def test_camera_model_must_describe_the_image(hip_lib):
+    """A camera whose width/height differ from the image's cols/rows (or with a non-positive focal length) is refused before
+    any launch -- the kernels bound projections by the model and address pixels by the image; absent blocks read as zeros."""
+    from isaac_ros_nvblox_amd import mapper as M
+    g = M.Mapper(M.default_params(), block_capacity=1 << 10)
+    d, rgb, T = H.frames(1, H.SMALL_CAM, color=True)[0]
+    for cam in ((80.0, 80.0, 79.5, 59.5, 320, 240), (80.0, 80.0, 79.5, 59.5, 120, 160), (0.0, 80.0, 79.5, 59.5, 160, 120)):
+        with pytest.raises(M.NvbxError, match="camera"):
+            g.integrate_depth(d, T, cam)
+        with pytest.raises(M.NvbxError, match="camera"):
+            g.integrate_color(rgb, T, cam)
+    assert g.num_blocks(M.LAYER_TSDF) == 0
+    g.integrate_depth(d, T, H.SMALL_CAM)
+    have = g.block_indices(M.LAYER_TSDF)[:1]
+    idx = np.concatenate([have, np.array([[1000, 1000, 1000]], np.int32)])
+    vox, found = g.get_blocks(M.LAYER_TSDF, idx)
+    assert list(found) == [1, 0] and not np.asarray(vox[1]).view(np.uint8).any() and np.asarray(vox[0]).view(np.uint8).any()
