@@ -46,7 +46,7 @@ extern "C" {
 
 typedef struct nvbx_mapper nvbx_mapper; /* replaces nvblox::Mapper (one per GPU / stream) */
 
-typedef struct { int32_t x, y, z; } nvbx_index3d;                      /* nvblox::Index3D */
+typedef struct { int32_t x, y, z; } nvbx_index3d;                      /* nvblox::Index3D; addressable range [-2^20, 2^20) per axis (419 km at 0.05 m voxels): poses / indices beyond it are refused with NVBX_E_INVALID */
 typedef struct { float fu, fv, cu, cv; int32_t width, height; } nvbx_camera; /* nvblox::Camera */
 
 /* Voxel structs as the reference's consumers read them. */

@@ -236,6 +236,8 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rg
 
 template <typename Pix>
 static int integrate_color_impl(nvbx_mapper* m, Pix rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera) {
+  if (!nvbx_pose_in_range(T_L_C, m->p.voxel_size * 8.0f, m->p.sphere_tracing_max_ray_length_m + m->p.max_integration_distance_m)) {
+    set_error("integrate color: T_L_C is not finite or lies outside the addressable block range (+-2^20 blocks)"); return NVBX_E_INVALID; }
   NVBX_HIP(hipSetDevice(m->device));
   if (m->p.projective_layer_type == 1) return NVBX_OK;      // occupancy mappers carry no colour (the occlusion test sphere-traces a TSDF)
   if (m->flush_edt()) return NVBX_E_DEVICE;      // a held-back EDT must precede this launch's marking pass (it reads the site masks)

@@ -291,11 +291,34 @@ EsdfArgs nvbx_mapper::make_esdf_args() const {
   return c;
 }
 
+// Parameter values the kernels' loop bounds and address arithmetic rely on (the reference CHECKs the same kind of thing in its
+// setters and aborts; here the call fails with NVBX_E_INVALID).  Returns nullptr if fine, else what is wrong.
+static const char* params_problem(const nvbx_mapper_params* p) {
+  auto pos = [](float v) { return std::isfinite(v) && v > 0.0f; };
+  if (!pos(p->voxel_size)) return "voxel_size must be > 0";
+  if (!pos(p->max_integration_distance_m)) return "max_integration_distance_m must be > 0 (it bounds the view rays)";
+  if (!pos(p->lidar_max_integration_distance_m)) return "lidar_max_integration_distance_m must be > 0 (it bounds the view rays)";
+  if (p->max_integration_distance_m / (p->voxel_size * 8.0f) > 65536.0f || p->lidar_max_integration_distance_m / (p->voxel_size * 8.0f) > 65536.0f)
+    return "integration distance exceeds 65536 blocks";
+  if (!pos(p->truncation_distance_vox)) return "truncation_distance_vox must be > 0";
+  if (!pos(p->max_weight)) return "max_weight must be > 0";
+  if (p->projective_layer_type < 0 || p->projective_layer_type > 2) return "projective_layer_type must be 0 (TSDF), 1 (occupancy) or 2 (TSDF + freespace)";
+  if (p->esdf_mode < 0 || p->esdf_mode > 1) return "esdf_mode must be 0 (2-D) or 1 (3-D)";
+  if (p->sphere_tracing_max_steps < 0 || p->sphere_tracing_max_steps > (1 << 20)) return "sphere_tracing_max_steps out of range";
+  if (p->projective_layer_type == 1) {
+    auto prob = [](float v) { return v > 0.0f && v < 1.0f; };
+    if (!prob(p->free_region_occupancy_probability) || !prob(p->occupied_region_occupancy_probability) || !prob(p->unobserved_region_occupancy_probability) ||
+        !prob(p->free_region_decay_probability) || !prob(p->occupied_region_decay_probability)) return "occupancy probabilities must lie strictly between 0 and 1";
+  }
+  return nullptr;
+}
+
 // ------------------------------------------------------------------------------------------------ C-ABI: lifetime
 extern "C" int nvbx_mapper_create(int device, void* hip_stream, const nvbx_mapper_params* params, int64_t block_capacity, nvbx_mapper** out) {
-  if (!params || !out || block_capacity < 64 || block_capacity > (1ll << 24) || !(params->voxel_size > 0.0f)) {
-    set_error("nvbx_mapper_create: invalid argument"); return NVBX_E_INVALID;
+  if (!params || !out || block_capacity < 64 || block_capacity > (1ll << 24)) {
+    set_error("nvbx_mapper_create: invalid argument (null pointer, or block_capacity outside 64 .. 2^24)"); return NVBX_E_INVALID;
   }
+  if (const char* why = params_problem(params)) { set_error(why); return NVBX_E_INVALID; }
   NVBX_HIP(hipSetDevice(device));
   nvbx_mapper* m = new nvbx_mapper();
   m->device = device; m->p = *params; m->capacity = block_capacity;
@@ -342,6 +365,7 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
 
 extern "C" int nvbx_mapper_set_params(nvbx_mapper* m, const nvbx_mapper_params* params) {
   if (!m || !params) return NVBX_E_INVALID;
+  if (const char* why = params_problem(params)) { set_error(why); return NVBX_E_INVALID; }
   if (params->voxel_size != m->p.voxel_size) { set_error("voxel_size cannot change after creation"); return NVBX_E_INVALID; }
   if (params->projective_layer_type != m->p.projective_layer_type || params->esdf_mode != m->p.esdf_mode) {
     // what the voxels of the existing map MEAN would change under it (the reference fixes both at construction too)
@@ -507,6 +531,7 @@ extern "C" int nvbx_set_blocks(nvbx_mapper* m, uint32_t layer, const nvbx_index3
   if (!m || (n > 0 && (!voxels_in || !idx)) || n < 0 || !(layer == F_TSDF || layer == F_COLOR || layer == F_ESDF || layer == NVBX_LAYER_OCCUPANCY)) return NVBX_E_INVALID;
   const uint32_t ilayer = internal_layer(m, layer);
   if (!ilayer) { set_error("nvbx_set_blocks: this mapper's projective layer type does not hold that layer"); return NVBX_E_INVALID; }
+  for (int64_t i = 0; i < n; i++) if (!nvbx_index_in_range(idx[i].x, idx[i].y, idx[i].z)) { set_error("nvbx_set_blocks: block index outside +-2^20"); return NVBX_E_INVALID; }
   if (m->join_side()) return NVBX_E_DEVICE;
   if (m->begin_dirtying()) return NVBX_E_DEVICE;
   const size_t bb = 512 * ref_voxel_bytes(layer);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <cmath>
 #include <vector>
 #include "../../include/nvblox_hip.h"
 #include "nvbx_internal.h"
@@ -34,6 +35,18 @@ void set_error(const char* what);
 // address pixels by (rows, cols)
 static inline bool nvbx_camera_matches(const nvbx_camera* c, int32_t rows, int32_t cols) {
   return c && c->width == cols && c->height == rows && c->fu > 0.0f && c->fv > 0.0f;
+}
+
+// Block indices are 21 bits per axis in the hash key (pack_key): a sensor pose is accepted only if it is finite and everything
+// within `reach` metres of it stays inside [-2^20, 2^20) blocks (419 km at 0.05 m voxels) -- beyond that keys would alias.
+static inline bool nvbx_pose_in_range(const float T[16], float block_size, float reach) {
+  for (int i = 0; i < 16; i++) if (!std::isfinite(T[i])) return false;
+  const float lim = ((float)(1 << 20) - 2.0f) * block_size - reach;
+  return std::fabs(T[3]) < lim && std::fabs(T[7]) < lim && std::fabs(T[11]) < lim;
+}
+static inline bool nvbx_index_in_range(int32_t x, int32_t y, int32_t z) {
+  const int32_t L = 1 << 20;
+  return x >= -L && x < L && y >= -L && y < L && z >= -L && z < L;
 }
 
 struct nvbx_mapper {

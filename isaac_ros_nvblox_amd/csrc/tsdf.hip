@@ -514,6 +514,8 @@ __global__ void k_dilate_invalid(Img in, int32_t rows, int32_t cols, int32_t n, 
 
 template <typename Img>
 static int integrate_camera(nvbx_mapper* m, Img img, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera) {
+  if (!nvbx_pose_in_range(T_L_C, m->p.voxel_size * 8.0f, m->p.max_integration_distance_m + 2.0f * m->p.truncation_distance_vox * m->p.voxel_size)) {
+    set_error("integrate depth: T_L_C is not finite or lies outside the addressable block range (+-2^20 blocks)"); return NVBX_E_INVALID; }
   NVBX_HIP(hipSetDevice(m->device));
   { const bool pend = m->edt_pending, ipend = m->import_pending; m->edt_pending = false; m->import_pending = false;
     // (join_side would launch a held-back EDT / union step; the EDT rides in k_mark_view instead, the union step stays held back
@@ -590,6 +592,8 @@ extern "C" int nvbx_integrate_lidar_depth(nvbx_mapper* m, const float* range_dev
   if (!m || !range_dev || !T_L_C || !lidar_ok(lidar) || rows != lidar->num_elevation_divisions || cols != lidar->num_azimuth_divisions) {
     set_error("nvbx_integrate_lidar_depth: invalid argument (range image must be elevation x azimuth divisions)"); return NVBX_E_INVALID;
   }
+  if (!nvbx_pose_in_range(T_L_C, m->p.voxel_size * 8.0f, m->p.lidar_max_integration_distance_m + 2.0f * m->p.truncation_distance_vox * m->p.voxel_size)) {
+    set_error("nvbx_integrate_lidar_depth: T_L_C is not finite or lies outside the addressable block range (+-2^20 blocks)"); return NVBX_E_INVALID; }
   NVBX_HIP(hipSetDevice(m->device));
   if (m->join_side()) return NVBX_E_DEVICE;
   const nvbx_lidar_model l = nvbx_lidar_make(cols, rows, lidar->min_valid_range_m, lidar->min_elevation_rad, lidar->max_elevation_rad);

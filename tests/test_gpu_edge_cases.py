@@ -302,3 +302,37 @@ def test_camera_model_must_describe_the_image(hip_lib):
     idx = np.concatenate([have, np.array([[1000, 1000, 1000]], np.int32)])
     vox, found = g.get_blocks(M.LAYER_TSDF, idx)
     assert list(found) == [1, 0] and not np.asarray(vox[1]).view(np.uint8).any() and np.asarray(vox[0]).view(np.uint8).any()
+
+
+def test_poses_outside_the_addressable_range_are_refused(hip_lib):
+    """Hash keys hold 21 bits per axis: a non-finite pose, or one further out than 2^20 blocks, is an error, not an alias."""
+    from isaac_ros_nvblox_amd import mapper as M
+    g = M.Mapper(M.default_params(), block_capacity=1 << 10)
+    d, rgb, T = H.frames(1, H.SMALL_CAM, color=True)[0]
+    far = np.array(T, np.float32); far[0, 3] = 5.0e5
+    nan = np.array(T, np.float32); nan[1, 1] = np.nan
+    for bad in (far, nan):
+        with pytest.raises(M.NvbxError, match="addressable"):
+            g.integrate_depth(d, bad, H.SMALL_CAM)
+        with pytest.raises(M.NvbxError, match="addressable"):
+            g.integrate_color(rgb, bad, H.SMALL_CAM)
+    with pytest.raises(M.NvbxError):
+        g.set_blocks(M.LAYER_TSDF, [[1 << 20, 0, 0]], np.zeros((1, 512), M._DT[M.LAYER_TSDF]))
+    assert g.num_blocks(M.LAYER_TSDF) == 0
+    ok = np.array(T, np.float32); ok[0, 3] += 4.0e5          # 400 km out: fine
+    g.integrate_depth(d, ok, H.SMALL_CAM)
+    assert g.num_blocks(M.LAYER_TSDF) > 10
+
+
+@pytest.mark.parametrize("kw", [dict(max_integration_distance_m=0.0), dict(lidar_max_integration_distance_m=float("inf")),
+                                dict(truncation_distance_vox=-1.0), dict(projective_layer_type=3), dict(esdf_mode=2),
+                                dict(projective_layer_type=1, free_region_occupancy_probability=1.0)])
+def test_parameter_values_the_kernels_rely_on_are_checked(hip_lib, kw):
+    """Values that bound the kernels' ray walks and address arithmetic are refused at creation and in set_params."""
+    from isaac_ros_nvblox_amd import mapper as M
+    with pytest.raises(M.NvbxError):
+        M.Mapper(M.default_params(**kw), block_capacity=1 << 10)
+    g = M.Mapper(M.default_params(), block_capacity=1 << 10)
+    with pytest.raises(M.NvbxError):
+        g.set_params(M.default_params(**kw))
+    g.set_params(M.default_params(max_integration_distance_m=4.0))
