@@ -21,36 +21,75 @@ __device__ inline void free_slot(DMap& m, uint32_t slot) {   // one thread
 // A block whose weights all fall below the threshold is deallocated.  If it lies in the ESDF z band and its column already has
 // an ESDF block, that column is flagged for a re-mark (F_ESDF_REMARK) and put on the ESDF work list -- the flag lives on the
 // ESDF slot, which survives, not on the TSDF slot, which may be freed and recycled before the update runs.
+// HBM-streaming form: DB blocks per workgroup iteration (DB independent 8-B loads per thread in flight), the per-block
+// bookkeeping (dirty flags, work lists, deallocation) done by DB lanes in parallel, and work-list entries collected in LDS and
+// appended in batches -- one returning atomic per ~60 blocks instead of two per block on eight counters (146 k same-address
+// atomics serialise at ~12 ns each; a returning atomic in every iteration stalls the whole workgroup ~1 us).
+constexpr int DB = 4, DQ = 64;
+struct DecayQueues { int32_t q[2][DQ]; int n[2]; int32_t base[2]; };
+__device__ inline void decay_flush(const DMap& m, DecayQueues* dq, const int32_t lists[2], int tid) {   // whole workgroup, between barriers
+  if (tid < 2 && dq->n[tid] > 0) dq->base[tid] = atomicAdd(shc_at(m, lists[tid], my_shard(), 0), dq->n[tid]);
+  __syncthreads();
+  const int l = tid >> 6, k = tid & 63;               // wave 0 writes list 0, wave 1 list 1
+  if (l < 2 && k < dq->n[l]) {
+    const int32_t p = dq->base[l] + k;
+    if (p < (int32_t)m.capacity) m.lists[((size_t)lists[l] * NSH + my_shard()) * m.capacity + p] = dq->q[l][k];
+  }
+  __syncthreads();
+  if (tid < 2) dq->n[tid] = 0;
+  __syncthreads();
+}
 __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, int32_t mesh_list,
                                                int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc) {
-  __shared__ int s_alive;
+  __shared__ int s_alive[DB];
+  __shared__ DecayQueues dq;
   const int32_t hw = m.counters[C_HIGH_WATER];
   const int tid = threadIdx.x;
-  for (int32_t slot = blockIdx.x; slot < hw; slot += gridDim.x) {
-    const uint32_t flags = m.slot_flags[slot];
-    if (!(flags & F_TSDF)) continue;
-    if (exclude_stamp && m.table[m.slot_entry[slot]].stamp == exclude_stamp) continue;
-    __syncthreads();
-    if (tid == 0) s_alive = 0;
-    __syncthreads();
-    float2 tv = m.tsdf[(size_t)slot * 512 + tid];
-    tv.y = tv.y * factor;
-    if (!(tv.y < thresh)) s_alive = 1;
-    __syncthreads();
-    const bool alive = s_alive != 0;
-    if (alive) {
-      m.tsdf[(size_t)slot * 512 + tid] = tv;
-      publish_band(m.slot_flags, (uint32_t)slot, tid, in_band(tv.x, tv.y, trunc));
-    } else {
-      m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f);
-      m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
-      if (flags & F_FREESPACE) m.freespace[(size_t)slot * 512 + tid] = make_int4(0, 0, 0, 0);
+  const int32_t lists[2] = {S_LIST_ESDF_DIRTY, mesh_list};
+  if (tid < 2) dq.n[tid] = 0;
+  __syncthreads();
+  for (int32_t base = blockIdx.x * DB; base < hw; base += gridDim.x * DB) {       // (uniform loop: every thread sees the same `hw`)
+    if (dq.n[0] > DQ - DB || dq.n[1] > DQ - DB) decay_flush(m, &dq, lists, tid);   // uniform: dq.n was last written before a barrier
+    uint32_t flags[DB]; bool act[DB];
+#pragma unroll
+    for (int j = 0; j < DB; j++) { const int32_t slot = base + j; flags[j] = slot < hw ? m.slot_flags[slot] : 0u; act[j] = (flags[j] & F_TSDF) != 0; }
+    if (exclude_stamp) {
+      uint32_t ent[DB];
+#pragma unroll
+      for (int j = 0; j < DB; j++) ent[j] = act[j] ? m.slot_entry[base + j] : 0u;
+#pragma unroll
+      for (int j = 0; j < DB; j++) if (act[j] && m.table[ent[j]].stamp == exclude_stamp) act[j] = false;
     }
-    if (tid == 0) {
+    if (tid < DB) s_alive[tid] = 0;
+    __syncthreads();
+    float2 tv[DB];
+#pragma unroll
+    for (int j = 0; j < DB; j++) tv[j] = act[j] ? m.tsdf[(size_t)(base + j) * 512 + tid] : make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int j = 0; j < DB; j++) if (act[j]) {
+      tv[j].y = tv[j].y * factor;
+      if (__ballot(!(tv[j].y < thresh)) != 0ull && (tid & 63) == 0) s_alive[j] = 1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < DB; j++) if (act[j]) {
+      const int32_t slot = base + j;
+      if (s_alive[j]) {
+        m.tsdf[(size_t)slot * 512 + tid] = tv[j];
+        publish_band(m.slot_flags, (uint32_t)slot, tid, in_band(tv[j].x, tv[j].y, trunc));
+      } else {
+        m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f);
+        m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
+        if (flags[j] & F_FREESPACE) m.freespace[(size_t)slot * 512 + tid] = make_int4(0, 0, 0, 0);
+      }
+    }
+    if (tid < DB && act[tid]) {                         // lane j keeps the books of block j
+      const int32_t slot = base + tid;
+      const uint32_t fl = flags[tid];
       uint32_t old;
-      if (alive) {
+      if (s_alive[tid]) {
         old = atomicOr(&m.slot_flags[slot], F_DIRTY_ESDF | F_DIRTY_MESH);
-        if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, slot);
+        if (!(old & F_DIRTY_ESDF)) dq.q[0][atomicAdd(&dq.n[0], 1)] = slot;
       } else {
         old = atomicOr(&m.slot_flags[slot], F_DIRTY_MESH);
         atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH | F_FREESPACE | F_BAND | F_BAND_STALE));
@@ -59,14 +98,16 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
           const uint32_t es = bz_out == INT32_MIN ? (uint32_t)slot : any_slot(m, bx, by, bz_out);   // 3-D ESDF: the block's own slot (the table is rebuilt after this kernel, not during it)
           if (slot_ok(es) && (m.slot_flags[es] & F_ESDF)) {
             const uint32_t eold = atomicOr(&m.slot_flags[es], F_ESDF_REMARK | F_DIRTY_ESDF);
-            if (!(eold & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)es);
+            if (!(eold & F_DIRTY_ESDF)) dq.q[0][atomicAdd(&dq.n[0], 1)] = (int32_t)es;
           }
         }
-        if (!(flags & (F_ESDF | F_ESDF_PENDING))) { atomicAnd(&m.slot_flags[slot], ~F_DIRTY_ESDF); free_slot(m, (uint32_t)slot); }
+        if (!(fl & (F_ESDF | F_ESDF_PENDING))) { atomicAnd(&m.slot_flags[slot], ~F_DIRTY_ESDF); free_slot(m, (uint32_t)slot); }
       }
-      if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, slot);
+      if (!(old & F_DIRTY_MESH)) dq.q[1][atomicAdd(&dq.n[1], 1)] = slot;
     }
+    __syncthreads();
   }
+  decay_flush(m, &dq, lists, tid);
 }
 
 // `srec`: window record of the next ESDF update.  An ESDF block that is dropped takes its sites with it: the distances of

@@ -1,0 +1,41 @@
+"""HBM rate of the whole-map maintenance kernels on a LARGE map (the LiDAR map of `bench.py --workload lidar`: ~150 k blocks,
+0.6 GB of TSDF) -- the launches of the path that really stream HBM, unlike the per-frame camera kernels.
+Usage: python tools/maintenance_bw.py   -> one JSON line"""
+import json, sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from isaac_ros_nvblox_amd import mapper as M, synthetic as S
+
+dev = torch.device("cuda", 0)
+lidar = S.SPINNING_LIDAR
+sc = S.LidarScene()
+stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream)
+p = M.default_params(voxel_size=0.1, lidar_max_integration_distance_m=200.0, raycast_subsampling_factor=2, tsdf_decay_factor=0.999)
+g = M.Mapper(p, device=0, block_capacity=1 << 19, stream=stream.cuda_stream)
+for i in range(16):
+    T = S.lidar_pose(i, 400)
+    g.integrate_lidar_depth(torch.from_numpy(S.render_lidar(sc, T, lidar, max_range=200.0)).to(dev), T, lidar)
+g.update_esdf(); g.update_color_mesh(); g.synchronize()
+nb = g.num_blocks(M.LAYER_TSDF)
+g.set_profiling(True)
+for _ in range(5):
+    g.decay_tsdf(exclude_last_view=False)
+g.clear_outside_radius([0.0, 0.0, 0.0], 1.0e4)       # nothing is outside: the scan itself
+g.update_color_mesh(full=True)
+prof = g.profile(); g.set_profiling(False)
+out = {"tsdf_blocks": int(nb), "kernels": {}}
+for k, v in prof.items():
+    if k.startswith("_"):
+        continue
+    us = v["total_ms"] / v["count"] * 1e3
+    name = k.strip().split("(")[0].split("<")[0].split()[0]
+    ab = None
+    if "decay" in name:
+        ab = nb * 4096 * 2           # every TSDF voxel read and written back
+    elif "mesh" in name:
+        ab = nb * 4096 * 2           # TSDF + colour voxels of every block read once (neighbour faces from cache), vertices out
+    e = {"count": v["count"], "avg_us": round(us, 1)}
+    if ab:
+        e["algorithmic_bytes"] = int(ab); e["achieved_GBps"] = round(ab / (us * 1e-6) / 1e9, 1); e["frac_of_8TBps"] = round(ab / (us * 1e-6) / 8e12, 3)
+    out["kernels"][name] = e
+print(json.dumps(out))
