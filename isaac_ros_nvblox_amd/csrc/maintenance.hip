@@ -25,7 +25,7 @@ __device__ inline void free_slot(DMap& m, uint32_t slot) {   // one thread
 // bookkeeping (dirty flags, work lists, deallocation) done by DB lanes in parallel, and work-list entries collected in LDS and
 // appended in batches -- one returning atomic per ~60 blocks instead of two per block on eight counters (146 k same-address
 // atomics serialise at ~12 ns each; a returning atomic in every iteration stalls the whole workgroup ~1 us).
-constexpr int DB = 4, DQ = 64;
+constexpr int DB = 8, DQ = 64;
 struct DecayQueues { int32_t q[2][DQ]; int n[2]; int32_t base[2]; };
 __device__ inline void decay_flush(const DMap& m, DecayQueues* dq, const int32_t lists[2], int tid) {   // whole workgroup, between barriers
   if (tid < 2 && dq->n[tid] > 0) dq->base[tid] = atomicAdd(shc_at(m, lists[tid], my_shard(), 0), dq->n[tid]);
@@ -41,18 +41,22 @@ __device__ inline void decay_flush(const DMap& m, DecayQueues* dq, const int32_t
 }
 __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, int32_t mesh_list,
                                                int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc) {
-  __shared__ int s_alive[DB];
+  __shared__ int s_alive[2][DB];                         // by iteration parity: no barrier between the books of one iteration and the loads of the next
   __shared__ DecayQueues dq;
   const int32_t hw = m.counters[C_HIGH_WATER];
   const int tid = threadIdx.x;
   const int32_t lists[2] = {S_LIST_ESDF_DIRTY, mesh_list};
   if (tid < 2) dq.n[tid] = 0;
-  __syncthreads();
-  for (int32_t base = blockIdx.x * DB; base < hw; base += gridDim.x * DB) {       // (uniform loop: every thread sees the same `hw`)
-    if (dq.n[0] > DQ - DB || dq.n[1] > DQ - DB) decay_flush(m, &dq, lists, tid);   // uniform: dq.n was last written before a barrier
+  uint32_t nflags[DB];                                   // flags of the NEXT iteration's blocks, fetched one iteration ahead
+#pragma unroll
+  for (int j = 0; j < DB; j++) { const int32_t slot = (int32_t)blockIdx.x * DB + j; nflags[j] = slot < hw ? m.slot_flags[slot] : 0u; }
+  int par = 0;
+  for (int32_t base = blockIdx.x * DB; base < hw; base += gridDim.x * DB, par ^= 1) {       // (uniform loop: every thread sees the same `hw`)
     uint32_t flags[DB]; bool act[DB];
 #pragma unroll
-    for (int j = 0; j < DB; j++) { const int32_t slot = base + j; flags[j] = slot < hw ? m.slot_flags[slot] : 0u; act[j] = (flags[j] & F_TSDF) != 0; }
+    for (int j = 0; j < DB; j++) { flags[j] = nflags[j]; act[j] = (flags[j] & F_TSDF) != 0; }
+#pragma unroll
+    for (int j = 0; j < DB; j++) { const int32_t slot = base + (int32_t)gridDim.x * DB + j; nflags[j] = slot < hw ? m.slot_flags[slot] : 0u; }
     if (exclude_stamp) {
       uint32_t ent[DB];
 #pragma unroll
@@ -60,21 +64,24 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
 #pragma unroll
       for (int j = 0; j < DB; j++) if (act[j] && m.table[ent[j]].stamp == exclude_stamp) act[j] = false;
     }
-    if (tid < DB) s_alive[tid] = 0;
-    __syncthreads();
+    // this iteration's voxels are requested before the barrier: seven wavefronts stream on while lanes of wavefront 0 still keep
+    // the previous iteration's books (returning atomics)
     float2 tv[DB];
 #pragma unroll
     for (int j = 0; j < DB; j++) tv[j] = act[j] ? m.tsdf[(size_t)(base + j) * 512 + tid] : make_float2(0.0f, 0.0f);
+    if (tid < DB) s_alive[par][tid] = 0;
+    __syncthreads();
+    if (dq.n[0] > DQ - DB || dq.n[1] > DQ - DB) decay_flush(m, &dq, lists, tid);   // uniform: every push of the previous iteration precedes the barrier above
 #pragma unroll
     for (int j = 0; j < DB; j++) if (act[j]) {
       tv[j].y = tv[j].y * factor;
-      if (__ballot(!(tv[j].y < thresh)) != 0ull && (tid & 63) == 0) s_alive[j] = 1;
+      if (__ballot(!(tv[j].y < thresh)) != 0ull && (tid & 63) == 0) s_alive[par][j] = 1;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < DB; j++) if (act[j]) {
       const int32_t slot = base + j;
-      if (s_alive[j]) {
+      if (s_alive[par][j]) {
         m.tsdf[(size_t)slot * 512 + tid] = tv[j];
         publish_band(m.slot_flags, (uint32_t)slot, tid, in_band(tv[j].x, tv[j].y, trunc));
       } else {
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
       const int32_t slot = base + tid;
       const uint32_t fl = flags[tid];
       uint32_t old;
-      if (s_alive[tid]) {
+      if (s_alive[par][tid]) {
         old = atomicOr(&m.slot_flags[slot], F_DIRTY_ESDF | F_DIRTY_MESH);
         if (!(old & F_DIRTY_ESDF)) dq.q[0][atomicAdd(&dq.n[0], 1)] = slot;
       } else {
@@ -105,8 +112,8 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
       }
       if (!(old & F_DIRTY_MESH)) dq.q[1][atomicAdd(&dq.n[1], 1)] = slot;
     }
-    __syncthreads();
   }
+  __syncthreads();
   decay_flush(m, &dq, lists, tid);
 }
 
