@@ -39,6 +39,10 @@ __device__ inline void decay_flush(const DMap& m, DecayQueues* dq, const int32_t
   if (tid < 2) dq->n[tid] = 0;
   __syncthreads();
 }
+// OCC = false: TSDF decay (weight *= factor; a block lives while any weight >= thresh).  OCC = true: occupancy decay (`factor` /
+// `thresh` carry the log-odds steps of the free / occupied regions; every value moves towards 0 and stops there; a block lives
+// while any value != 0) -- [U] OccupancyDecayIntegrator, Mapper::decayOccupancyAllVoxels (nvblox_node.cpp:925-929).
+template <bool OCC>
 __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, int32_t mesh_list,
                                                int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc) {
   __shared__ int s_alive[2][DB];                         // by iteration parity: no barrier between the books of one iteration and the loads of the next
@@ -74,8 +78,16 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
     if (dq.n[0] > DQ - DB || dq.n[1] > DQ - DB) decay_flush(m, &dq, lists, tid);   // uniform: every push of the previous iteration precedes the barrier above
 #pragma unroll
     for (int j = 0; j < DB; j++) if (act[j]) {
-      tv[j].y = tv[j].y * factor;
-      if (__ballot(!(tv[j].y < thresh)) != 0ull && (tid & 63) == 0) s_alive[par][j] = 1;
+      bool live;
+      if (OCC) {
+        float v = tv[j].x;
+        if (v > 0.0f) { v = v + thresh; if (v < 0.0f) v = 0.0f; }
+        else if (v < 0.0f) { v = v + factor; if (v > 0.0f) v = 0.0f; }
+        tv[j] = make_float2(v, 0.0f); live = v != 0.0f;
+      } else {
+        tv[j].y = tv[j].y * factor; live = !(tv[j].y < thresh);
+      }
+      if (__ballot(live) != 0ull && (tid & 63) == 0) s_alive[par][j] = 1;
     }
     __syncthreads();
 #pragma unroll
@@ -83,22 +95,25 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
       const int32_t slot = base + j;
       if (s_alive[par][j]) {
         m.tsdf[(size_t)slot * 512 + tid] = tv[j];
-        publish_band(m.slot_flags, (uint32_t)slot, tid, in_band(tv[j].x, tv[j].y, trunc));
+        if (!OCC) publish_band(m.slot_flags, (uint32_t)slot, tid, in_band(tv[j].x, tv[j].y, trunc));
       } else {
         m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f);
-        m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
-        if (flags[j] & F_FREESPACE) m.freespace[(size_t)slot * 512 + tid] = make_int4(0, 0, 0, 0);
+        if (!OCC) {                                      // (occupancy mappers carry neither colour nor freespace)
+          m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
+          if (flags[j] & F_FREESPACE) m.freespace[(size_t)slot * 512 + tid] = make_int4(0, 0, 0, 0);
+        }
       }
     }
     if (tid < DB && act[tid]) {                         // lane j keeps the books of block j
       const int32_t slot = base + tid;
       const uint32_t fl = flags[tid];
-      uint32_t old;
+      uint32_t old = F_DIRTY_MESH;                       // (occupancy: no mesh, nothing joins the mesh list)
       if (s_alive[par][tid]) {
-        old = atomicOr(&m.slot_flags[slot], F_DIRTY_ESDF | F_DIRTY_MESH);
-        if (!(old & F_DIRTY_ESDF)) dq.q[0][atomicAdd(&dq.n[0], 1)] = slot;
+        const uint32_t o = atomicOr(&m.slot_flags[slot], OCC ? F_DIRTY_ESDF : (F_DIRTY_ESDF | F_DIRTY_MESH));
+        if (!OCC) old = o;
+        if (!(o & F_DIRTY_ESDF)) dq.q[0][atomicAdd(&dq.n[0], 1)] = slot;
       } else {
-        old = atomicOr(&m.slot_flags[slot], F_DIRTY_MESH);
+        if (!OCC) old = atomicOr(&m.slot_flags[slot], F_DIRTY_MESH);
         atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH | F_FREESPACE | F_BAND | F_BAND_STALE));
         const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
         if (bz >= bz_lo && bz <= bz_hi) {
@@ -108,7 +123,7 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
             if (!(eold & F_DIRTY_ESDF)) dq.q[0][atomicAdd(&dq.n[0], 1)] = (int32_t)es;
           }
         }
-        if (!(fl & (F_ESDF | F_ESDF_PENDING))) { atomicAnd(&m.slot_flags[slot], ~F_DIRTY_ESDF); free_slot(m, (uint32_t)slot); }
+        if (!(fl & (F_ESDF | F_ESDF_PENDING))) { atomicAnd(&m.slot_flags[slot], OCC ? ~(F_DIRTY_ESDF | F_DIRTY_MESH) : ~F_DIRTY_ESDF); free_slot(m, (uint32_t)slot); }
       }
       if (!(old & F_DIRTY_MESH)) dq.q[1][atomicAdd(&dq.n[1], 1)] = slot;
     }
@@ -237,44 +252,6 @@ static int rebuild_table(nvbx_mapper* m) {
   return NVBX_OK;
 }
 
-// [U] OccupancyDecayIntegrator (Mapper::decayOccupancyAllVoxels, nvblox_node.cpp:925-929): every log-odds value moves towards 0
-// (probability 0.5 = unknown) by the log-odds of its region's decay probability and stops there; a block whose voxels are all
-// unknown again is deallocated.
-__global__ __launch_bounds__(512) void k_decay_occupancy(DMap m, float lo_free_decay, float lo_occupied_decay, int32_t bz_lo, int32_t bz_hi, int32_t bz_out) {
-  __shared__ int s_alive;
-  const int32_t hw = m.counters[C_HIGH_WATER];
-  const int tid = threadIdx.x;
-  for (int32_t slot = blockIdx.x; slot < hw; slot += gridDim.x) {
-    const uint32_t flags = m.slot_flags[slot];
-    if (!(flags & F_TSDF)) continue;
-    __syncthreads();
-    if (tid == 0) s_alive = 0;
-    __syncthreads();
-    float2 v = m.tsdf[(size_t)slot * 512 + tid];
-    if (v.x > 0.0f) { v.x = v.x + lo_occupied_decay; if (v.x < 0.0f) v.x = 0.0f; }
-    else if (v.x < 0.0f) { v.x = v.x + lo_free_decay; if (v.x > 0.0f) v.x = 0.0f; }
-    if (v.x != 0.0f) s_alive = 1;
-    m.tsdf[(size_t)slot * 512 + tid] = make_float2(v.x, 0.0f);
-    __syncthreads();
-    if (tid == 0) {
-      if (s_alive) {
-        const uint32_t old = atomicOr(&m.slot_flags[slot], F_DIRTY_ESDF);
-        if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, slot);
-      } else {
-        atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH));
-        const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
-        if (bz >= bz_lo && bz <= bz_hi) {
-          const uint32_t es = bz_out == INT32_MIN ? (uint32_t)slot : any_slot(m, bx, by, bz_out);
-          if (slot_ok(es) && (m.slot_flags[es] & F_ESDF)) {
-            const uint32_t eold = atomicOr(&m.slot_flags[es], F_ESDF_REMARK | F_DIRTY_ESDF);
-            if (!(eold & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)es);
-          }
-        }
-        if (!(flags & (F_ESDF | F_ESDF_PENDING))) { atomicAnd(&m.slot_flags[slot], ~(F_DIRTY_ESDF | F_DIRTY_MESH)); free_slot(m, (uint32_t)slot); }
-      }
-    }
-  }
-}
 extern "C" int nvbx_decay_occupancy(nvbx_mapper* m) {
   if (!m) return NVBX_E_INVALID;
   if (m->p.projective_layer_type != 1) { set_error("nvbx_decay_occupancy: not an occupancy mapper"); return NVBX_E_INVALID; }
@@ -284,8 +261,9 @@ extern "C" int nvbx_decay_occupancy(nvbx_mapper* m) {
   if (m->begin_dirtying()) return NVBX_E_DEVICE;
   EsdfArgs ea = m->make_esdf_args();
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
-  NVBX_LAUNCH(m, k_decay_occupancy, dim3((unsigned)std::min<int64_t>(m->capacity, 2048)), dim3(512), m->d,
-              log_odds(m->p.free_region_decay_probability), log_odds(m->p.occupied_region_decay_probability), ea.bz_lo, ea.bz_hi, ea.bz_out);
+  NVBX_LAUNCH(m, k_decay<true>, dim3((unsigned)std::min<int64_t>(m->capacity, 2048)), dim3(512), m->d,
+              log_odds(m->p.free_region_decay_probability), log_odds(m->p.occupied_region_decay_probability), 0u, (int32_t)m->mesh_list_live(),
+              ea.bz_lo, ea.bz_hi, ea.bz_out, 0.0f);
   return rebuild_table(m);
 }
 
@@ -299,7 +277,7 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
   EsdfArgs ea = m->make_esdf_args();
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
-  NVBX_LAUNCH(m, k_decay, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
+  NVBX_LAUNCH(m, k_decay<false>, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
                      exclude_last_view ? m->last_view_frame : 0u, m->mesh_list_live(), ea.bz_lo, ea.bz_hi, ea.bz_out,
                      m->p.truncation_distance_vox * m->p.voxel_size);
   return rebuild_table(m);
