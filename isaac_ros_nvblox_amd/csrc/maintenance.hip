@@ -245,9 +245,10 @@ __global__ void k_reinsert(DMap m, const uint32_t* tmp, int32_t bz_out) {
 
 static int rebuild_table(nvbx_mapper* m) {
   uint32_t* tmp = (uint32_t*)m->export_idx;   // capacity * 12 bytes scratch >= capacity * 4
-  NVBX_LAUNCH(m, k_save_stamps, dim3(256), dim3(256), m->d, tmp);
+  const unsigned rg = (unsigned)std::min<int64_t>((m->capacity + 255) / 256, 2048);       // one thread per slot up to 512 k slots
+  NVBX_LAUNCH(m, k_save_stamps, dim3(rg), dim3(256), m->d, tmp);
   NVBX_HIP(hipMemsetAsync(m->d.table, 0xFF, ((size_t)m->d.mask + 1) * sizeof(Entry), m->stream));
-  NVBX_LAUNCH(m, k_reinsert, dim3(256), dim3(256), m->d, tmp, m->make_esdf_args().bz_out);
+  NVBX_LAUNCH(m, k_reinsert, dim3(rg), dim3(256), m->d, tmp, m->make_esdf_args().bz_out);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }
