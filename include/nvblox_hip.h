@@ -146,7 +146,10 @@ typedef struct {
 /* ---- lifetime --------------------------------------------------------------------------------------------------
  * nvblox::MultiMapper(voxel_size, MappingType, EsdfMode, MemoryType::kDevice, shared_ptr<CudaStream>)
  *   nvblox_ros/src/lib/nvblox_node.cpp:187-190, fuser_node.cpp:85-89.  `hip_stream` may be NULL (library-owned stream).
- * block_capacity = number of 8^3 blocks the HBM pools are sized for (3 x 4 KiB per block). */
+ * block_capacity = number of 8^3 blocks the HBM pools are sized for (3 x 4 KiB per block), 64 .. 2^24.
+ * Parameter values the kernels' loop bounds rely on are checked here and in nvbx_mapper_set_params (NVBX_E_INVALID, reason in
+ * nvbx_last_error): voxel_size, both integration distances, truncation distance and max_weight > 0 and finite,
+ * projective_layer_type in 0..2, esdf_mode in 0..1, occupancy probabilities strictly inside (0, 1). */
 int nvbx_mapper_create(int device, void* hip_stream, const nvbx_mapper_params* params, int64_t block_capacity,
                        nvbx_mapper** out);
 int nvbx_mapper_destroy(nvbx_mapper* m);
@@ -166,6 +169,9 @@ const char* nvbx_last_error(void);
 int nvbx_mapper_clear(nvbx_mapper* m);
 
 /* ---- integration (asynchronous on the mapper stream) --------------------------------------------------------------
+ * Argument checks (NVBX_E_INVALID, nothing launched): the camera's width / height must equal the image's cols / rows and its
+ * focal lengths be > 0; T_L_C must be finite and keep everything within the integration distance inside the addressable block
+ * range (nvbx_index3d).  Every entry point makes the mapper's device the calling thread's current device and leaves it so.
  * MultiMapper::integrateDepth(const DepthImage&, const Transform& T_L_C, const Camera&, Time) -- nvblox_node.cpp:1062 */
 int nvbx_integrate_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                          const nvbx_camera* camera);
