@@ -167,3 +167,19 @@ def test_c_abi_minimal_from_plain_c(hip_lib):
     got = json.loads(r.stdout.strip().splitlines()[-1])
     assert got["tsdf_blocks"] > 20 and got["slice_known"] > 100 and got["mesh_triangles"] > 100
     assert -0.5 < got["slice_min_m"] < 0.1          # the wall's columns: sites, and negative just behind the surface
+
+
+def test_reference_kat_compiles_over_the_facade(hip_lib):
+    subprocess.check_call(["make", "-C", CPP, "kat_esdf_and_gradients"], stdout=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(CPP, "kat_esdf_and_gradients"))
+
+
+@pytest.mark.gpu
+def test_reference_kat_esdf_and_gradient_conversions_cpp(hip_lib):
+    """nvblox_ros/test/unit_tests/test_esdf_and_gradient_conversions.cpp (FloatGrid + EsdfValues), the reference's golden test
+    of this path, as a C++ program over the façade (Unified3DGrid, EsdfLayer, callFunctionOnAllVoxels, getAABBOfAllocatedBlocks,
+    voxelLayerToDenseVoxelGridInAABBAsync) and libnvblox_hip.so -- same expectations, same 1e-6 tolerance."""
+    subprocess.check_call(["make", "-C", CPP, "kat_esdf_and_gradients"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(CPP, "kat_esdf_and_gradients")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == {"failures": 0}
