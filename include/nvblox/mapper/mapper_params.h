@@ -2,6 +2,8 @@
 // (nvblox_ros/src/lib/mapper_initialization.cpp:231-466).  Members outside the static TSDF / colour / ESDF-2D / mesh
 // path are carried (so getMapperParamsFromROS compiles) but ignored by libnvblox_hip; toCAbi() lists what is consumed.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include "nvblox/core/types.h"
 #include "nvblox/integrators/weighting_function.h"
 #include "nvblox/utils/params.h"
@@ -120,6 +122,12 @@ struct MapperParams {
 
   // what libnvblox_hip consumes
   nvbx_mapper_params toCAbi(float voxel_size, ProjectiveLayerType layer_type = ProjectiveLayerType::kTsdf, EsdfMode esdf_mode = EsdfMode::k2D) const {
+    // switches libnvblox_hip does not provide are refused loudly, never ignored (the reference CHECK-fails on
+    // parameter errors in the same way)
+    if (tsdf_decay_integrator_params.tsdf_set_free_distance_on_decayed || occupancy_decay_integrator_params.occupancy_decay_to_free) {
+      std::fprintf(stderr, "[nvblox_hip] tsdf_set_free_distance_on_decayed / occupancy_decay_to_free are not provided by libnvblox_hip\n");
+      std::abort();
+    }
     nvbx_mapper_params p{};
     p.voxel_size = voxel_size;
     p.esdf_mode = esdf_mode == EsdfMode::k3D ? 1 : 0;
