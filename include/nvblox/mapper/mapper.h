@@ -82,6 +82,12 @@ class Mapper {
     checkNvbx(nvbx_mapper_set_params(m_, &p), "nvbx_mapper_set_params");
   }
   const MapperParams& params() const { return params_; }
+  // nvblox_node.cpp:120 (through MultiMapper::getParameterTree)
+  parameters::ParameterTreeNode getParameterTree(const std::string& name_remap = "mapper") const {
+    parameters::ParameterTreeNode t = params_.getParameterTree(name_remap);
+    t.children().value().insert(t.children().value().begin(), parameters::ParameterTreeNode("voxel_size_m", voxel_size_m_));
+    return t;
+  }
 
   // -- integration (asynchronous on the mapper's stream); README timer tags tsdf/integrate, color/integrate, ...
   void setUpdateTime(Time update_time_ms) { checkNvbx(nvbx_set_time_ms(m_, (int64_t)update_time_ms), "nvbx_set_time_ms"); }     // freespace layer clock

@@ -4,6 +4,7 @@
 #pragma once
 #include <cstdio>
 #include <cstdlib>
+#include "nvblox/core/parameter_tree.h"
 #include "nvblox/core/types.h"
 #include "nvblox/integrators/weighting_function.h"
 #include "nvblox/utils/params.h"
@@ -51,22 +52,22 @@ constexpr Param<float>::Description kEsdfIntegratorMaxSiteDistanceVoxParamDesc{"
 constexpr Param<float>::Description kEsdfIntegratorMaxDistanceMParamDesc{"esdf_integrator_max_distance_m", 2.0f, "ESDF cut-off distance [m]."};
 constexpr Param<float>::Description kMeshIntegratorMinWeightParamDesc{"mesh_integrator_min_weight", 0.1f, "Minimum TSDF weight of a meshed corner."};
 constexpr Param<bool>::Description kMeshIntegratorWeldVerticesParamDesc{"mesh_integrator_weld_vertices", true, "Weld vertices per block."};
-constexpr Param<bool>::Description kDecayIntegratorDeallocateDecayedBlocks{"decay_integrator_deallocate_decayed_blocks", true, "Deallocate fully decayed blocks."};
+constexpr Param<bool>::Description kDecayIntegratorDeallocateDecayedBlocks{"decay_integrator_deallocate_decayed_blocks", true, "Deallocate fully decayed blocks (false is not provided by libnvblox_hip)."};
 constexpr Param<float>::Description kTsdfDecayFactorParamDesc{"tsdf_decay_factor", 0.95f, "Weight multiplier per decay step."};
 constexpr Param<float>::Description kTsdfDecayedWeightThresholdDesc{"tsdf_decayed_weight_threshold", 0.001f, "Blocks whose weights are all below this are deallocated."};
 constexpr Param<bool>::Description kTsdfSetFreeDistanceOnDecayedDesc{"tsdf_set_free_distance_on_decayed", false, "(not provided by libnvblox_hip)."};
 constexpr Param<float>::Description kTsdfDecayedFreeDistanceVoxDesc{"tsdf_decayed_free_distance_vox", 4.0f, "(not provided by libnvblox_hip)."};
 constexpr Param<float>::Description kFreeRegionDecayProbabilityParamDesc{"free_region_decay_probability", 0.55f, "Occupancy decay towards free instead of unknown (not provided by libnvblox_hip: decay stops at unknown)."};
-constexpr Param<float>::Description kOccupiedRegionDecayProbabilityParamDesc{"occupied_region_decay_probability", 0.4f, "Occupancy decay towards free instead of unknown (not provided by libnvblox_hip: decay stops at unknown)."};
+constexpr Param<float>::Description kOccupiedRegionDecayProbabilityParamDesc{"occupied_region_decay_probability", 0.4f, "Decay probability applied to occupied voxels (log-odds step towards unknown)."};
 constexpr Param<bool>::Description kOccupancyDecayToFreeParamDesc{"occupancy_decay_to_free", false, "Occupancy decay towards free instead of unknown (not provided by libnvblox_hip: decay stops at unknown)."};
-constexpr Param<float>::Description kMaxTsdfDistanceForOccupancyMParamDesc{"max_tsdf_distance_for_occupancy_m", 0.15f, "Freespace integrator (not provided by libnvblox_hip)."};
-constexpr Param<int>::Description kMaxUnobservedToKeepConsecutiveOccupancyMsParamDesc{"max_unobserved_to_keep_consecutive_occupancy_ms", 200, "Freespace integrator (not provided by libnvblox_hip)."};
-constexpr Param<int>::Description kMinDurationSinceOccupiedForFreespaceMsParamDesc{"min_duration_since_occupied_for_freespace_ms", 1000, "Freespace integrator (not provided by libnvblox_hip)."};
-constexpr Param<int>::Description kMinConsecutiveOccupancyDurationForResetMsParamDesc{"min_consecutive_occupancy_duration_for_reset_ms", 2000, "Freespace integrator (not provided by libnvblox_hip)."};
-constexpr Param<bool>::Description kCheckNeighborhoodParamDesc{"check_neighborhood", true, "Freespace integrator (not provided by libnvblox_hip)."};
-constexpr Param<bool>::Description kInitializeToHighConfidenceFreespaceParamDesc{"initialize_to_high_confidence_freespace", false, "Freespace integrator (not provided by libnvblox_hip)."};
-constexpr Param<int>::Description kConnectedMaskComponentSizeThresholdParamDesc{"connected_mask_component_size_threshold", 2000, "MultiMapper (dynamic mapping; not provided by libnvblox_hip)."};
-constexpr Param<bool>::Description kRemoveSmallConnectedComponentsParamDesc{"remove_small_connected_components", true, "MultiMapper (dynamic mapping; not provided by libnvblox_hip)."};
+constexpr Param<float>::Description kMaxTsdfDistanceForOccupancyMParamDesc{"max_tsdf_distance_for_occupancy_m", 0.15f, "Freespace integrator (dynamic mapping)."};
+constexpr Param<int>::Description kMaxUnobservedToKeepConsecutiveOccupancyMsParamDesc{"max_unobserved_to_keep_consecutive_occupancy_ms", 200, "Freespace integrator (dynamic mapping)."};
+constexpr Param<int>::Description kMinDurationSinceOccupiedForFreespaceMsParamDesc{"min_duration_since_occupied_for_freespace_ms", 1000, "Freespace integrator (dynamic mapping)."};
+constexpr Param<int>::Description kMinConsecutiveOccupancyDurationForResetMsParamDesc{"min_consecutive_occupancy_duration_for_reset_ms", 2000, "Freespace integrator (dynamic mapping)."};
+constexpr Param<bool>::Description kCheckNeighborhoodParamDesc{"check_neighborhood", true, "Freespace integrator (dynamic mapping)."};
+constexpr Param<bool>::Description kInitializeToHighConfidenceFreespaceParamDesc{"initialize_to_high_confidence_freespace", false, "Freespace integrator (dynamic mapping)."};
+constexpr Param<int>::Description kConnectedMaskComponentSizeThresholdParamDesc{"connected_mask_component_size_threshold", 2000, "MultiMapper (dynamic / human mapping): mask clean-up."};
+constexpr Param<bool>::Description kRemoveSmallConnectedComponentsParamDesc{"remove_small_connected_components", true, "MultiMapper (dynamic / human mapping): mask clean-up."};
 
 struct ProjectiveIntegratorParams {
   float projective_integrator_max_integration_distance_m = 7.0f;
@@ -120,12 +121,59 @@ struct MapperParams {
   OccupancyDecayIntegratorParams occupancy_decay_integrator_params;
   FreespaceIntegratorParams freespace_integrator_params;
 
+  // Mapper::getParameterTree (nvblox_node.cpp:120): every knob by the name mapper_initialization.cpp declares it under
+  parameters::ParameterTreeNode getParameterTree(const std::string& name = "mapper") const {
+    using N = parameters::ParameterTreeNode;
+    const auto& pi = projective_integrator_params; const auto& vc = view_calculator_params; const auto& es = esdf_integrator_params;
+    const auto& fs = freespace_integrator_params;
+    return N(name, std::vector<N>{
+        N("do_depth_preprocessing", do_depth_preprocessing), N("depth_preprocessing_num_dilations", depth_preprocessing_num_dilations),
+        N("projective_integrator", std::vector<N>{
+            N("projective_integrator_max_integration_distance_m", pi.projective_integrator_max_integration_distance_m),
+            N("lidar_projective_integrator_max_integration_distance_m", pi.lidar_projective_integrator_max_integration_distance_m),
+            N("projective_integrator_truncation_distance_vox", pi.projective_integrator_truncation_distance_vox),
+            N("projective_integrator_weighting_mode", pi.projective_integrator_weighting_mode),
+            N("projective_integrator_max_weight", pi.projective_integrator_max_weight),
+            N("projective_tsdf_integrator_invalid_depth_decay_factor", pi.projective_tsdf_integrator_invalid_depth_decay_factor)}),
+        N("view_calculator", std::vector<N>{
+            N("raycast_subsampling_factor", vc.raycast_subsampling_factor), N("workspace_bounds_type", vc.workspace_bounds_type),
+            N("workspace_bounds_min_height_m", vc.workspace_bounds_min_height_m), N("workspace_bounds_max_height_m", vc.workspace_bounds_max_height_m),
+            N("workspace_bounds_min_corner_x_m", vc.workspace_bounds_min_corner_x_m), N("workspace_bounds_max_corner_x_m", vc.workspace_bounds_max_corner_x_m),
+            N("workspace_bounds_min_corner_y_m", vc.workspace_bounds_min_corner_y_m), N("workspace_bounds_max_corner_y_m", vc.workspace_bounds_max_corner_y_m)}),
+        N("esdf_integrator", std::vector<N>{
+            N("esdf_integrator_min_weight", es.esdf_integrator_min_weight), N("esdf_integrator_max_site_distance_vox", es.esdf_integrator_max_site_distance_vox),
+            N("esdf_integrator_max_distance_m", es.esdf_integrator_max_distance_m), N("esdf_slice_min_height", es.esdf_slice_min_height),
+            N("esdf_slice_max_height", es.esdf_slice_max_height), N("esdf_slice_height", es.esdf_slice_height)}),
+        N("mesh_integrator", std::vector<N>{
+            N("mesh_integrator_min_weight", mesh_integrator_params.mesh_integrator_min_weight),
+            N("mesh_integrator_weld_vertices", mesh_integrator_params.mesh_integrator_weld_vertices)}),
+        N("decay_integrators", std::vector<N>{
+            N("decay_integrator_deallocate_decayed_blocks", decay_integrator_base_params.decay_integrator_deallocate_decayed_blocks),
+            N("tsdf_decay_factor", tsdf_decay_integrator_params.tsdf_decay_factor),
+            N("tsdf_decayed_weight_threshold", tsdf_decay_integrator_params.tsdf_decayed_weight_threshold),
+            N("free_region_decay_probability", occupancy_decay_integrator_params.free_region_decay_probability),
+            N("occupied_region_decay_probability", occupancy_decay_integrator_params.occupied_region_decay_probability)}),
+        N("occupancy_integrator", std::vector<N>{
+            N("free_region_occupancy_probability", occupancy_integrator_params.free_region_occupancy_probability),
+            N("occupied_region_occupancy_probability", occupancy_integrator_params.occupied_region_occupancy_probability),
+            N("unobserved_region_occupancy_probability", occupancy_integrator_params.unobserved_region_occupancy_probability),
+            N("occupied_region_half_width_m", occupancy_integrator_params.occupied_region_half_width_m)}),
+        N("freespace_integrator", std::vector<N>{
+            N("max_tsdf_distance_for_occupancy_m", fs.max_tsdf_distance_for_occupancy_m),
+            N("max_unobserved_to_keep_consecutive_occupancy_ms", static_cast<int64_t>(fs.max_unobserved_to_keep_consecutive_occupancy_ms)),
+            N("min_duration_since_occupied_for_freespace_ms", static_cast<int64_t>(fs.min_duration_since_occupied_for_freespace_ms)),
+            N("min_consecutive_occupancy_duration_for_reset_ms", static_cast<int64_t>(fs.min_consecutive_occupancy_duration_for_reset_ms)),
+            N("check_neighborhood", fs.check_neighborhood), N("initialize_to_high_confidence_freespace", fs.initialize_to_high_confidence_freespace)})});
+  }
+
   // what libnvblox_hip consumes
   nvbx_mapper_params toCAbi(float voxel_size, ProjectiveLayerType layer_type = ProjectiveLayerType::kTsdf, EsdfMode esdf_mode = EsdfMode::k2D) const {
     // switches libnvblox_hip does not provide are refused loudly, never ignored (the reference CHECK-fails on
     // parameter errors in the same way)
-    if (tsdf_decay_integrator_params.tsdf_set_free_distance_on_decayed || occupancy_decay_integrator_params.occupancy_decay_to_free) {
-      std::fprintf(stderr, "[nvblox_hip] tsdf_set_free_distance_on_decayed / occupancy_decay_to_free are not provided by libnvblox_hip\n");
+    if (tsdf_decay_integrator_params.tsdf_set_free_distance_on_decayed || occupancy_decay_integrator_params.occupancy_decay_to_free ||
+        !decay_integrator_base_params.decay_integrator_deallocate_decayed_blocks) {
+      std::fprintf(stderr, "[nvblox_hip] tsdf_set_free_distance_on_decayed = true / occupancy_decay_to_free = true / "
+                           "decay_integrator_deallocate_decayed_blocks = false are not provided by libnvblox_hip\n");
       std::abort();
     }
     nvbx_mapper_params p{};

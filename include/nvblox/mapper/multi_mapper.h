@@ -30,6 +30,14 @@ class MultiMapper {
   void setMapperParams(const MapperParams& background, const MapperParams& foreground) { background_mapper_->setMapperParams(background); foreground_mapper_->setMapperParams(foreground); }
   void setMapperParams(const MapperParams& params) { background_mapper_->setMapperParams(params); }   // fuser_node.cpp:94
   void setMultiMapperParams(const MultiMapperParams& p) { multi_params_ = p; }
+  // nvblox_node.cpp:120: the subtree the node hangs under its own parameters and prints at start-up
+  parameters::ParameterTreeNode getParameterTree() const {
+    using N = parameters::ParameterTreeNode;
+    return N("multi_mapper", std::vector<N>{
+        N("connected_mask_component_size_threshold", multi_params_.connected_mask_component_size_threshold),
+        N("remove_small_connected_components", multi_params_.remove_small_connected_components),
+        background_mapper_->getParameterTree("background_mapper"), foreground_mapper_->getParameterTree("foreground_mapper")});
+  }
   std::shared_ptr<Mapper> background_mapper() const { return background_mapper_; }
   std::shared_ptr<Mapper> foreground_mapper() const { return foreground_mapper_; }
 

@@ -202,9 +202,17 @@ int main(int argc, char** argv) {
   const int n = hdr[0], rows = hdr[1], cols = hdr[2];
   warmupCuda();                                                             // fuser_node_main.cpp:38
   FakeNode node;
+  {   // nvblox_node.cpp:119-124: the mapper's parameter subtree hangs under the node's own and is printed at start-up
+    parameters::ParameterTreeNode parameter_tree_{"nvblox_node", {}};
+    parameter_tree_.children().value().push_back(node.multi_mapper_->getParameterTree());
+    const std::string txt = parameters::parameterTreeToString(parameter_tree_);
+    if (txt.find("  multi_mapper:\n") == std::string::npos || txt.find("background_mapper:") == std::string::npos ||
+        txt.find("esdf_slice_height: 0.09") == std::string::npos) { std::fprintf(stderr, "parameter tree:\n%s", txt.c_str()); return 1; }
+  }
   const Camera camera(k[0], k[1], k[2], k[3], cols, rows);                  // image_conversions.cpp:27-32
   std::vector<float> depth((size_t)rows * cols); std::vector<Color> rgb((size_t)rows * cols); float T[16];
   for (int i = 0; i < n; i++) {
+    timing::Rates::tick("ros/tick");                                      // nvblox_node.cpp:588
     if (std::fread(T, 4, 16, f) != 16 || std::fread(depth.data(), 4, depth.size(), f) != depth.size() || std::fread(rgb.data(), 3, rgb.size(), f) != rgb.size()) return 2;
     const Transform T_L_C = Transform::fromRowMajor(T);
     node.processDepthImage(depth.data(), rows, cols, T_L_C, camera);

@@ -183,3 +183,41 @@ def test_reference_kat_esdf_and_gradient_conversions_cpp(hip_lib):
     r = subprocess.run([os.path.join(CPP, "kat_esdf_and_gradients")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
     assert json.loads(r.stdout.strip().splitlines()[-1]) == {"failures": 0}
+
+
+def _read_grey_png(path):
+    """Minimal PNG reader for the writer's own subset (8-bit grey, filter 0): chunk CRCs checked, pixels via zlib."""
+    import struct
+    import zlib
+    b = open(path, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(b):
+        n, = struct.unpack(">I", b[pos:pos + 4]); t = b[pos + 4:pos + 8]; d = b[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(t + d) & 0xFFFFFFFF == crc
+        chunks.append((t, d)); pos += 12 + n
+    assert [t for t, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, ctype = struct.unpack(">IIBB", chunks[0][1][:10])
+    assert (depth, ctype) == (8, 0)
+    raw = zlib.decompress(chunks[1][1])
+    assert len(raw) == (w + 1) * h and all(raw[r * (w + 1)] == 0 for r in range(h))
+    return np.array([list(raw[r * (w + 1) + 1:(r + 1) * (w + 1)]) for r in range(h)], np.uint8)
+
+
+def test_host_utilities_of_the_facade(tmp_path):
+    """timing::Rates / Delays, parameters::ParameterTreeNode + MapperParams::getParameterTree, saveOccupancyGridAsPng / Yaml
+    (nvblox_node.cpp:72-75,119-124,140-168,469-477): host-only C++ of the façade, built with g++ and run here; the PNGs are
+    decoded independently (zlib) and compared with the grid (row 0 of the image = largest y; 0 occupied / 254 free / 205 unknown)."""
+    subprocess.check_call(["make", "-C", CPP, "host_utils_test"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(CPP, "host_utils_test"), str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    small = _read_grey_png(tmp_path / "nvbx_occ.png")
+    assert small.tolist() == [[205] * 4, [254] * 4, [0] * 4]
+    big = _read_grey_png(tmp_path / "nvbx_occ_big.png")
+    rr, cc = np.meshgrid(np.arange(300), np.arange(301), indexing="ij")
+    k = (rr + 2 * cc) % 3
+    want = np.where(k == 0, 0, np.where(k == 1, 254, 205)).astype(np.uint8)[::-1]
+    assert big.shape == (300, 301) and np.array_equal(big, want)
+    y = open(tmp_path / "nvbx_occ.yaml").read()
+    assert "image: nvbx_occ.png" in y and "resolution: 0.05" in y and "origin: [-1.2, 0.4, 0.0]" in y and "occupied_thresh: 0.65" in y and "free_thresh: 0.25" in y
