@@ -6,7 +6,11 @@
 #include <string>
 #include "nvblox/core/parameter_tree.h"
 #include "nvblox/integrators/occupancy_conversions.h"
+#include "nvblox/io/layer_io.h"
+#include <memory>
 #include "nvblox/mapper/mapper_params.h"
+#include "nvblox/mesh/mesh.h"
+#include "nvblox/utils/art.h"
 #include "nvblox/utils/delays.h"
 #include "nvblox/utils/rates.h"
 
@@ -51,6 +55,36 @@ int main(int argc, char** argv) {
   std::vector<int8_t> big((size_t)300 * 301);
   for (size_t r = 0; r < 300; r++) for (size_t c = 0; c < 301; c++) big[r * 301 + c] = (int8_t)(((r + 2 * c) % 3 == 0) ? 100 : (((r + 2 * c) % 3 == 1) ? 0 : -1));
   CHECK_T(conversions::saveOccupancyGridAsPng(out_dir + "/nvbx_occ_big.png", 0.25f, 0.65f, 300, 301, big));
+  // SerializedColorMeshLayer per-block iteration as the marker path does it (mesh_conversions.cpp:149-155)
+  SerializedColorMeshLayer mesh;
+  mesh.block_indices = {Index3D(0, 0, 0), Index3D(1, 0, 0)};
+  mesh.vertices = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {5, 5, 5}, {6, 5, 5}, {5, 6, 5}, {5, 5, 6}};
+  mesh.vertex_normals = mesh.vertices; mesh.vertex_appearances.assign(7, Color(1, 2, 3)); mesh.vertex_appearances[4] = Color(9, 8, 7);
+  mesh.vertex_block_offsets = {0, 3, 7}; mesh.triangle_indices = {0, 1, 2, 0, 1, 2, 1, 2, 3}; mesh.triangle_index_block_offsets = {0, 3, 9};
+  int walked = 0; float sum_x = 0.f; int reds = 0;
+  for (size_t i_block = 0; i_block < mesh.block_indices.size(); i_block++)
+    for (auto itr = mesh.triangleBlockItr(i_block); itr != mesh.triangleBlockItr(i_block + 1); ++itr) {
+      sum_x += mesh.getVertex(i_block, *itr).x(); reds += mesh.getAppearance(i_block, *itr).r; walked++;
+    }
+  CHECK_T(walked == 9 && mesh.getNumTriangleIndicesInBlock(1) == 6 && mesh.getNumVerticesInBlock(1) == 4);
+  CHECK_T(std::fabs(sum_x - (1.f + (5 + 6 + 5) + (6 + 5 + 5))) < 1e-6f && reds == 7 * 1 + 2 * 9);
+  CHECK_T(mesh.vertexBlockItr(1) - mesh.vertexBlockItr(0) == 3 && mesh.appearanceBlockItr(2) == mesh.vertex_appearances.end());
+  CHECK_T(art::PrintNvbloxFrog().find("nvblox") != std::string::npos);
+  // outputVoxelLayerToPly over a stand-in layer (the façade's views have the same four members, backed by the GPU map)
+  struct FakeEsdfLayer {
+    float voxel_size() const { return 0.05f; } float block_size() const { return 0.4f; }
+    std::vector<Index3D> getAllBlockIndices() const { return {Index3D(1, 0, -1), Index3D(7, 7, 7)}; }
+    std::shared_ptr<VoxelBlock<EsdfVoxel>> getBlockAtIndex(const Index3D& b) const {
+      if (b.x() != 1) return nullptr;                                   // a listed block that vanished: skipped
+      auto blk = std::make_shared<VoxelBlock<EsdfVoxel>>();
+      blk->voxels[0][0][0].observed = true; blk->voxels[0][0][0].squared_distance_vox = 16.f;                      // +0.2 m
+      blk->voxels[7][3][2].observed = true; blk->voxels[7][3][2].squared_distance_vox = 4.f; blk->voxels[7][3][2].is_inside = true;   // -0.1 m
+      blk->voxels[1][1][1].squared_distance_vox = 9.f;                   // not observed: no point
+      return blk;
+    }
+  } fake_layer;
+  CHECK_T(io::outputVoxelLayerToPly(fake_layer, out_dir + "/nvbx_esdf.ply"));
+  CHECK_T(!io::outputVoxelLayerToPly(fake_layer, out_dir + "/no/such/dir/x.ply"));
   std::printf("{\"failures\": %d}\n", failures);
   return failures ? 1 : 0;
 }

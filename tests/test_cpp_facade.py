@@ -207,7 +207,7 @@ def _read_grey_png(path):
 
 def test_host_utilities_of_the_facade(tmp_path):
     """timing::Rates / Delays, parameters::ParameterTreeNode + MapperParams::getParameterTree, saveOccupancyGridAsPng / Yaml
-    (nvblox_node.cpp:72-75,119-124,140-168,469-477): host-only C++ of the façade, built with g++ and run here; the PNGs are
+    (nvblox_node.cpp:72-75,119-124,140-168,469-477), SerializedColorMeshLayer block iterators, io::outputVoxelLayerToPly: host-only C++ of the façade, built with g++ and run here; the PNGs are
     decoded independently (zlib) and compared with the grid (row 0 of the image = largest y; 0 occupied / 254 free / 205 unknown)."""
     subprocess.check_call(["make", "-C", CPP, "host_utils_test"], stdout=subprocess.DEVNULL)
     r = subprocess.run([os.path.join(CPP, "host_utils_test"), str(tmp_path)], capture_output=True, text=True, timeout=120)
@@ -219,5 +219,8 @@ def test_host_utilities_of_the_facade(tmp_path):
     k = (rr + 2 * cc) % 3
     want = np.where(k == 0, 0, np.where(k == 1, 254, 205)).astype(np.uint8)[::-1]
     assert big.shape == (300, 301) and np.array_equal(big, want)
+    ply = open(tmp_path / "nvbx_esdf.ply").read().splitlines()
+    assert ply[2] == "element vertex 2" and ply[-2].split() == ["0.425000", "0.025000", "-0.375000", "0.200000"] \
+        and ply[-1].split() == ["0.775000", "0.175000", "-0.275000", "-0.100000"]
     y = open(tmp_path / "nvbx_occ.yaml").read()
     assert "image: nvbx_occ.png" in y and "resolution: 0.05" in y and "origin: [-1.2, 0.4, 0.0]" in y and "occupied_thresh: 0.65" in y and "free_thresh: 0.25" in y
