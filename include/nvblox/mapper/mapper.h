@@ -142,11 +142,7 @@ class Mapper {
   template <typename SensorType>
   void decayTsdfExcludeLastView() { checkNvbx(nvbx_decay_tsdf(m_, 1), "nvbx_decay_tsdf"); }   // nvblox_node.cpp:935
   void clearOutsideRadius(const Vector3f& center, float radius) {   // nvblox_node.cpp:1575
-    const std::vector<Index3D> before = tsdf_layer_.getAllBlockIndices();
     checkNvbx(nvbx_clear_outside_radius(m_, center.data(), radius), "nvbx_clear_outside_radius");
-    const std::vector<Index3D> after = tsdf_layer_.getAllBlockIndices();   // both sorted
-    size_t j = 0;
-    for (const auto& b : before) { while (j < after.size() && after[j] < b) j++; if (j >= after.size() || !(after[j] == b)) cleared_blocks_.push_back(b); }
   }
   void clearTsdfInsideShapes(const std::vector<BoundingShape>& shapes) {   // nvblox_node.cpp:1834
     std::vector<nvbx_bounding_shape> c; c.reserve(shapes.size());
@@ -154,7 +150,16 @@ class Mapper {
     checkNvbx(nvbx_clear_tsdf_inside_shapes(m_, c.data(), (int32_t)c.size()), "nvbx_clear_tsdf_inside_shapes");
   }
   // layer_publishing.cpp:716: blocks removed since the last call
-  std::vector<Index3D> getClearedBlocks(const std::vector<uint32_t>& = {}) { std::vector<Index3D> out; out.swap(cleared_blocks_); return out; }
+  // (decay and radius clearing record the blocks they deallocate on the device: nvbx_take_cleared_blocks)
+  std::vector<Index3D> getClearedBlocks(const std::vector<uint32_t>& = {}) {
+    std::vector<Index3D> out(256);
+    for (;;) {
+      const int64_t n = nvbx_take_cleared_blocks(m_, reinterpret_cast<nvbx_index3d*>(out.data()), (int64_t)out.size());
+      checkNvbx(n < 0 ? (int)n : 0, "nvbx_take_cleared_blocks");
+      if (n <= (int64_t)out.size()) { out.resize((size_t)n); return out; }
+      out.resize((size_t)n);            // list left untouched by the short call: take it with room for all of it
+    }
+  }
   void clear() { checkNvbx(nvbx_mapper_clear(m_), "nvbx_mapper_clear"); }
 
   // -- layers
@@ -314,7 +319,6 @@ class Mapper {
   MapperParams params_;
   nvbx_mapper* m_ = nullptr;
   TsdfLayer tsdf_layer_; FreespaceLayer freespace_layer_; OccupancyLayer occupancy_layer_; ColorLayer color_layer_; EsdfLayer esdf_layer_;
-  std::vector<Index3D> cleared_blocks_;
   uint64_t mesh_updates_ = 0, mesh_updates_fetched_ = 0;
   std::unordered_map<Index3D, PendingBlockMesh, Index3DHash> pending_mesh_; std::deque<Index3D> pending_order_;
   std::chrono::steady_clock::time_point last_mesh_stream_{}; bool last_mesh_stream_valid_ = false;

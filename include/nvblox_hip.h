@@ -119,6 +119,21 @@ typedef struct {
   int32_t min_consecutive_occupancy_duration_for_reset_ms;    /* 2000 */
   int32_t check_neighborhood;                                 /* 1 */
   int32_t initialize_to_high_confidence_freespace;            /* 0 */
+  /* -- [U] open choices (SURVEY.md 8a "open choices the oracle must expose as switches"): the arithmetic lives in the absent
+   *    nvblox core, so every recollection that could be wrong is a switch implemented on BOTH sides (these kernels and
+   *    oracle/nvblox_oracle.c) and parity-tested in both positions -- pinning to the real core is then a flag flip.
+   *    0 is always the default behaviour documented in DESIGN.md section 3. */
+  int32_t tsdf_weighting_variant;          /* formulas of the four non-trivial WeightingFunctionType modes: 0 = set A, 1 = set B */
+  int32_t tsdf_skip_at_negative_truncation;/* voxel exactly at sdf == -truncation: 0 = integrated (skip iff sdf < -trunc), 1 = skipped (skip iff sdf <= -trunc) */
+  int32_t tsdf_weight_clamp_before_blend;  /* 0 = blend with the unclamped sum, then w = min(w + w_m, max_weight); 1 = sum clamped first,
+                                              distance blended as a running average over the clamped sum */
+  float color_occlusion_threshold_vox;     /* colour occlusion test |synthetic depth - voxel depth| <= this (voxels); < 0 = the truncation distance */
+  int32_t esdf_propagation;                /* 0 = exact Euclidean distance transform; 1 = synchronous 4-neighbour parent propagation to its fixed
+                                              point, restricted to allocated ESDF blocks (the reference's sweep / propagate loop class) */
+  int32_t mesh_ambiguity_rule;             /* marching-cubes ambiguous faces: 0 = inside corners cut off separately, 1 = inside corners joined,
+                                              2 = complement-symmetric table (rule 0 for <= 4 inside corners, else rule 1: the classic table's behaviour) */
+  int32_t mesh_normal_rule;                /* welded vertex normal: 0 = normal of the first triangle referencing it, 1 = area-weighted mean of the
+                                              block's triangles referencing it */
 } nvbx_mapper_params;
 
 /* nvblox::Lidar(num_azimuth_divisions, num_elevation_divisions, min_valid_range_m, vertical_fov_rad) or
@@ -164,6 +179,11 @@ int nvbx_synchronize(nvbx_mapper* m);
 /* Enqueue everything the mapper holds back (the distance transform of the last nvbx_update_esdf, see there) on its stream
  * WITHOUT waiting: for callers that order their own work behind the mapper's with stream events instead of a host sync. */
 int nvbx_flush(nvbx_mapper* m);
+/* The hipStream_t all of the mapper's work is enqueued on (the one handed to nvbx_mapper_create, or the library-owned one):
+ * implicit conversion of nvblox::CudaStream to cudaStream_t -- conversions/esdf_slice_conversions.cu:107-108.  A caller that
+ * reads / writes buffers it shares with the mapper on ANOTHER stream (e.g. an RCCL collective on the framework's stream) orders
+ * the two with events on this handle. */
+int nvbx_get_stream(nvbx_mapper* m, void** hip_stream_out);
 const char* nvbx_last_error(void);
 /* Mapper::clear / fresh map (load_map path re-creates the mapper: nvblox_node.cpp:1698-1703) */
 int nvbx_mapper_clear(nvbx_mapper* m);
@@ -221,6 +241,12 @@ int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view);
 int nvbx_decay_occupancy(nvbx_mapper* m);
 /* Mapper::clearOutsideRadius(center, radius) -- nvblox_node.cpp:1566-1583 */
 int nvbx_clear_outside_radius(nvbx_mapper* m, const float center[3], float radius);
+
+/* Mapper::getClearedBlocks(layer_types) -- layer_publishing.cpp:716,804: Index3D (sorted, unique) of the projective-layer (TSDF /
+ * occupancy) blocks that decayTsdf / decayOccupancyAllVoxels / clearOutsideRadius deallocated since the last call; the list is
+ * emptied.  Returns their number n; if n > capacity nothing is written and the list is kept (call again with room for n);
+ * synchronises. */
+int64_t nvbx_take_cleared_blocks(nvbx_mapper* m, nvbx_index3d* out, int64_t capacity);
 
 /* Mapper::clearTsdfInsideShapes(std::vector<BoundingShape>) -- nvblox_node.cpp:1834 (the EsdfAndGradients service's
  * clearing request, conversions/esdf_and_gradients_conversions.cu:127-180).  A shape is a sphere (kind 0: centre, radius)

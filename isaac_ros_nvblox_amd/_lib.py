@@ -55,6 +55,13 @@ class Params(C.Structure):
         ("min_consecutive_occupancy_duration_for_reset_ms", C.c_int32),
         ("check_neighborhood", C.c_int32),
         ("initialize_to_high_confidence_freespace", C.c_int32),
+        ("tsdf_weighting_variant", C.c_int32),
+        ("tsdf_skip_at_negative_truncation", C.c_int32),
+        ("tsdf_weight_clamp_before_blend", C.c_int32),
+        ("color_occlusion_threshold_vox", C.c_float),
+        ("esdf_propagation", C.c_int32),
+        ("mesh_ambiguity_rule", C.c_int32),
+        ("mesh_normal_rule", C.c_int32),
     ]
 
 
@@ -98,6 +105,8 @@ SIGNATURES = {
     "nvbx_mapper_get_params": (C.c_int, [_vp, C.POINTER(Params)]),
     "nvbx_synchronize": (C.c_int, [_vp]),
     "nvbx_flush": (C.c_int, [_vp]),
+    "nvbx_take_cleared_blocks": (C.c_int64, [_vp, _vp, _i64]),
+    "nvbx_get_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
     "nvbx_decay_occupancy": (C.c_int, [_vp]),
     "nvbx_motion_compensate_pointcloud": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, C.c_float, _vp]),
     "nvbx_set_time_ms": (C.c_int, [_vp, C.c_int64]),

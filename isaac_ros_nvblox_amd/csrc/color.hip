@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rg
     const float stop = (1.0f - sax) * s00 + sax * s10;
     const float sbot = (1.0f - sax) * s01 + sax * s11;
     const float sd = (1.0f - say) * stop + say * sbot;
-    if (fabsf(sd - vd) > f.trunc) continue;
+    if (fabsf(sd - vd) > f.occlusion_thresh) continue;      // [U] occlusion test (color_occlusion_threshold_vox)
     const float ax = uc - fx, ay = vc - fy;
     float c[3];
 #pragma unroll

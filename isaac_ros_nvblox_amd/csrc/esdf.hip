@@ -33,6 +33,127 @@ __global__ __launch_bounds__(256) void k_esdf_edt(DMap m, EsdfArgs a) {
   esdf_edt_worker(m, a, (int)blockIdx.x, (int)gridDim.x, &sh);
 }
 
+// ------------------------------------------------------------------------------------------------ esdf_propagation = 1
+// [U] open choice (nvbx_mapper_params::esdf_propagation): the reference's EsdfIntegrator sweeps parent directions inside blocks and
+// across block faces until nothing changes.  That class of algorithm is restated as SYNCHRONOUS 4-neighbour parent propagation to
+// its fixed point, restricted to the allocated ESDF blocks of the slice (a voxel can only learn of a site through a chain of
+// allocated neighbours): state = packed (sq << 14 | dy + 64 << 7 | dx + 64) of the best known site, integer min = lexicographic
+// (sq, dy, dx) min = the tie rule of the exact transform; every round each voxel takes the min over itself and its four axis
+// neighbours' sites re-expressed from its own position, subject to the cut-off.  Every update recomputes the whole slice (the
+// fixed point of vector propagation depends on history; a full synchronous recompute is the one definition both sides can share).
+// Not the benchmark path: three small kernels + a host loop that reads a "changed" flag every PROP_BATCH rounds.
+constexpr int PROP_BATCH = 16;
+constexpr int32_t PROP_NONE = INT32_MAX;
+__device__ inline bool prop_block(const DMap& m, const EsdfArgs& a, int32_t s, uint32_t* flags_out) {
+  const uint32_t flags = m.slot_flags[s];
+  *flags_out = flags;
+  return (flags & (F_ESDF | F_ESDF_PENDING)) && m.slot_index[3 * s + 2] == a.bz_out;
+}
+__global__ __launch_bounds__(64) void k_esdf_prop_init(DMap m, EsdfArgs a, int32_t plane_a) {
+  const int lane = threadIdx.x;
+  const int srec = S_ESDF_REC + (int)(a.epoch & 1), srec_next = S_ESDF_REC + (int)((a.epoch + 1) & 1);
+  if (blockIdx.x == 0 && lane < NSH) {            // the book-keeping esdf_edt_worker does for the exact transform
+    *shc_at(m, srec_next, lane, 0) = INT32_MAX; *shc_at(m, srec_next, lane, 1) = INT32_MAX;
+    *shc_at(m, srec_next, lane, 2) = INT32_MIN; *shc_at(m, srec_next, lane, 3) = INT32_MIN;
+    *shc_at(m, srec_next, lane, 4) = 0; *shc_at(m, srec_next, lane, 5) = 0;
+    *shc_at(m, S_LIST_ESDF_DIRTY, lane, 0) = 0;
+    if (lane == 0) m.counters[a.rec_next + 6] = 0;
+  }
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  for (int32_t s = blockIdx.x; s < hw; s += gridDim.x) {
+    uint32_t flags;
+    if (!prop_block(m, a, s, &flags)) continue;      // uniform
+    if (lane == 0) {
+      if (flags & F_ESDF_REMARK) atomicAnd(&m.slot_flags[s], ~F_ESDF_REMARK);
+      if (flags & F_ESDF_PENDING) {
+        const int32_t bx = m.slot_index[3 * s], by = m.slot_index[3 * s + 1];
+        atomicOr(&m.slot_flags[s], F_ESDF); atomicAnd(&m.slot_flags[s], ~F_ESDF_PENDING);
+        atomicMin(&m.counters[C_ESDF_AABB + 0], bx); atomicMin(&m.counters[C_ESDF_AABB + 1], by);
+        atomicMax(&m.counters[C_ESDF_AABB + 2], bx); atomicMax(&m.counters[C_ESDF_AABB + 3], by);
+      }
+      atomicAdd(shc_at(m, srec, my_shard(), 5), 1);
+      atomicAdd(&m.counters[a.rec + 6], 64);
+    }
+    const bool site = (m.site_bits[s] >> lane) & 1ull;
+    m.esdf[(size_t)s * 512 + plane_a * 64 + lane] = make_uint2((uint32_t)(site ? ((64 << 7) | 64) : PROP_NONE), 0u);
+  }
+}
+// candidate: the neighbour at offset (ox, oy) knows a site at (dx, dy) from ITSELF -> (dx + ox, dy + oy) from here
+__device__ inline int32_t prop_candidate(int32_t nb, int ox, int oy, float max_sq) {
+  if (nb == PROP_NONE) return PROP_NONE;
+  const int32_t dx = (nb & 127) - 64 + ox, dy = ((nb >> 7) & 127) - 64 + oy;
+  const int32_t sq = dx * dx + dy * dy;
+  if (!((float)sq <= max_sq) || dx < -63 || dx > 63 || dy < -63 || dy > 63) return PROP_NONE;
+  return (sq << 14) | ((dy + 64) << 7) | (dx + 64);
+}
+__global__ __launch_bounds__(64) void k_esdf_prop_iter(DMap m, EsdfArgs a, int32_t src, int32_t dst, int32_t* changed) {
+  const int lane = threadIdx.x;
+  const int vx = lane & 7, vy = lane >> 3;
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  for (int32_t s = blockIdx.x; s < hw; s += gridDim.x) {
+    uint32_t flags;
+    if (!prop_block(m, a, s, &flags)) continue;      // uniform
+    const int32_t bx = m.slot_index[3 * s], by = m.slot_index[3 * s + 1];
+    // the four face-neighbour blocks (lanes 0..3 probe, every lane gets the slots); only blocks of the ESDF layer take part
+    uint32_t ns = SLOT_NONE;
+    if (lane < 4) {
+      const int ox = lane == 0 ? -1 : (lane == 1 ? 1 : 0), oy = lane == 2 ? -1 : (lane == 3 ? 1 : 0);
+      ns = any_slot(m, bx + ox, by + oy, a.bz_out);
+      if (slot_ok(ns) && !(m.slot_flags[ns] & F_ESDF)) ns = SLOT_NONE;
+    }
+    const uint32_t n_xm = __shfl(ns, 0), n_xp = __shfl(ns, 1), n_ym = __shfl(ns, 2), n_yp = __shfl(ns, 3);
+    const int32_t own = (int32_t)m.esdf[(size_t)s * 512 + src * 64 + lane].x;
+    // neighbours inside the block by shuffle, across a face from the neighbour block's border voxel
+    int32_t v_xm = __shfl(own, (lane + 63) & 63), v_xp = __shfl(own, (lane + 1) & 63), v_ym = __shfl(own, (lane + 56) & 63), v_yp = __shfl(own, (lane + 8) & 63);
+    if (vx == 0) v_xm = slot_ok(n_xm) ? (int32_t)m.esdf[(size_t)n_xm * 512 + src * 64 + 8 * vy + 7].x : PROP_NONE;
+    if (vx == 7) v_xp = slot_ok(n_xp) ? (int32_t)m.esdf[(size_t)n_xp * 512 + src * 64 + 8 * vy + 0].x : PROP_NONE;
+    if (vy == 0) v_ym = slot_ok(n_ym) ? (int32_t)m.esdf[(size_t)n_ym * 512 + src * 64 + 8 * 7 + vx].x : PROP_NONE;
+    if (vy == 7) v_yp = slot_ok(n_yp) ? (int32_t)m.esdf[(size_t)n_yp * 512 + src * 64 + 8 * 0 + vx].x : PROP_NONE;
+    int32_t best = own;
+    best = min(best, prop_candidate(v_xm, -1, 0, a.max_sq)); best = min(best, prop_candidate(v_xp, 1, 0, a.max_sq));
+    best = min(best, prop_candidate(v_ym, 0, -1, a.max_sq)); best = min(best, prop_candidate(v_yp, 0, 1, a.max_sq));
+    m.esdf[(size_t)s * 512 + dst * 64 + lane] = make_uint2((uint32_t)best, 0u);
+    if (__ballot(best != own) != 0ull && lane == 0) atomicOr(changed, 1);
+  }
+}
+__global__ __launch_bounds__(64) void k_esdf_prop_final(DMap m, EsdfArgs a, int32_t src, int32_t other) {
+  const int lane = threadIdx.x;
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  for (int32_t s = blockIdx.x; s < hw; s += gridDim.x) {
+    uint32_t flags;
+    if (!prop_block(m, a, s, &flags)) continue;
+    const int32_t p = (int32_t)m.esdf[(size_t)s * 512 + src * 64 + lane].x;
+    const uint32_t vflags = (((m.obs_bits[s] >> lane) & 1ull) ? ESDF_OBSERVED : 0u) | (((m.inside_bits[s] >> lane) & 1ull) ? ESDF_INSIDE : 0u) |
+                            (((m.site_bits[s] >> lane) & 1ull) ? ESDF_SITE : 0u);
+    m.esdf[(size_t)s * 512 + src * 64 + lane] = make_uint2(0u, 0u);          // the scratch planes leave as they were: zero
+    m.esdf[(size_t)s * 512 + other * 64 + lane] = make_uint2(0u, 0u);
+    uint2 out = make_uint2(__float_as_uint(a.max_sq), vflags);
+    if (p != PROP_NONE) {
+      const int32_t fdx = (p & 127) - 64, fdy = ((p >> 7) & 127) - 64;
+      out = make_uint2(__float_as_uint((float)(p >> 14)), vflags | ((uint32_t)(uint8_t)(int8_t)fdx) | (((uint32_t)(uint8_t)(int8_t)fdy) << 8));
+    }
+    m.esdf[(size_t)s * 512 + a.vz_out * 64 + lane] = out;
+  }
+}
+static int run_esdf_propagation(nvbx_mapper* m, const EsdfArgs& a) {
+  const int32_t pa = (a.vz_out + 1) & 7, pb = (a.vz_out + 2) & 7;
+  const unsigned grid = (unsigned)std::min<int64_t>(m->capacity, 2048);
+  int32_t* flag = m->export_count;                 // 64-byte device scratch
+  NVBX_LAUNCH(m, k_esdf_prop_init, dim3(grid), dim3(64), m->d, a, pa);
+  int32_t src = pa, dst = pb;
+  for (int rounds = 0; rounds < (1 << 14); rounds += PROP_BATCH) {
+    NVBX_HIP(hipMemsetAsync(flag, 0, 4, m->stream));
+    for (int k = 0; k < PROP_BATCH; k++) { NVBX_LAUNCH(m, k_esdf_prop_iter, dim3(grid), dim3(64), m->d, a, src, dst, flag); std::swap(src, dst); }
+    int32_t h = 0;
+    NVBX_HIP(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, m->stream));
+    NVBX_HIP(hipStreamSynchronize(m->stream));
+    if (!h) break;                                   // a whole batch without a change: fixed point (PROP_BATCH is even: src == pa again)
+  }
+  NVBX_LAUNCH(m, k_esdf_prop_final, dim3(grid), dim3(64), m->d, a, src, dst);
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;
+}
+
 extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
   if (!m) return NVBX_E_INVALID;
   NVBX_HIP(hipSetDevice(m->device));
@@ -45,10 +166,21 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
   if (m->p.esdf_max_distance_m / m->p.voxel_size >= 64.0f) { set_error("esdf_max_distance_m / voxel_size must be < 64 voxels"); return NVBX_E_INVALID; }
   { const EsdfArgs chk = m->make_esdf_args();
     if (chk.bz_hi - chk.bz_lo + 1 > 63 || chk.bz_hi < chk.bz_lo) { set_error("esdf slice z band must span 1..63 blocks"); return NVBX_E_INVALID; } }
+  // a distance transform still held back by the PREVIOUS update goes first: this update's marking pass overwrites the masks
+  // and the parity-indexed window record it reads, and edt_args holds one update only (two updates back to back)
+  if (m->flush_edt()) return NVBX_E_DEVICE;
   if (m->flush_import()) return NVBX_E_DEVICE;     // a held-back union step belongs to this update
   if (m->dirty_since_mark) m->mark_pass++;
   const EsdfArgs a = m->make_esdf_args();
   hipStream_t s = m->stream;
+  if (m->p.esdf_propagation == 1) {                // [U] open choice: iterative propagation instead of the exact transform (above)
+    if (m->join_side()) return NVBX_E_DEVICE;
+    if (m->dirty_since_mark) NVBX_LAUNCH(m, k_esdf_mark, dim3((unsigned)std::min<int64_t>(m->capacity, 1024)), dim3(64), m->d, a);
+    m->dirty_since_mark = false; m->premark_consumed = false; m->unresolved_marks = false; m->pass_at_last_edt = m->mark_pass;
+    const int rc = run_esdf_propagation(m, a);
+    m->esdf_epoch++;
+    return rc;
+  }
   if (m->use_side) {
     // run behind the last non-colour operation, beside any colour integration enqueued after it
     if (m->main_dirty) { if (m->mark_main()) return NVBX_E_DEVICE; }

@@ -5,6 +5,8 @@
 // (memset + one insert per live slot).  Call sites served: nvblox_ros/src/lib/nvblox_node.cpp:931-936 (decayTsdf...),
 // :1566-1583 (clearOutsideRadius); parameters nvblox_base.yaml:103-107.
 #include <algorithm>
+#include <cstring>
+#include <vector>
 #include "nvbx_mapper.h"
 
 using namespace nvbx;
@@ -26,17 +28,22 @@ __device__ inline void free_slot(DMap& m, uint32_t slot) {   // one thread
 // appended in batches -- one returning atomic per ~60 blocks instead of two per block on eight counters (146 k same-address
 // atomics serialise at ~12 ns each; a returning atomic in every iteration stalls the whole workgroup ~1 us).
 constexpr int DB = 8, DQ = 64;
-struct DecayQueues { int32_t q[2][DQ]; int n[2]; int32_t base[2]; };
-__device__ inline void decay_flush(const DMap& m, DecayQueues* dq, const int32_t lists[2], int tid) {   // whole workgroup, between barriers
+struct DecayQueues { int32_t q[3][DQ]; int n[3]; int32_t base[3]; };     // 0: ESDF-dirty list, 1: mesh-dirty list, 2: deallocated blocks
+__device__ inline void decay_flush(const DMap& m, DecayQueues* dq, const int32_t lists[2], int32_t* cleared_idx, int tid) {   // whole workgroup, between barriers
   if (tid < 2 && dq->n[tid] > 0) dq->base[tid] = atomicAdd(shc_at(m, lists[tid], my_shard(), 0), dq->n[tid]);
+  if (tid == 2 && dq->n[2] > 0) dq->base[2] = atomicAdd(&m.counters[C_CLEARED], dq->n[2]);
   __syncthreads();
-  const int l = tid >> 6, k = tid & 63;               // wave 0 writes list 0, wave 1 list 1
+  const int l = tid >> 6, k = tid & 63;               // wave 0 writes list 0, wave 1 list 1, wave 2 the cleared-block indices
   if (l < 2 && k < dq->n[l]) {
     const int32_t p = dq->base[l] + k;
     if (p < (int32_t)m.capacity) m.lists[((size_t)lists[l] * NSH + my_shard()) * m.capacity + p] = dq->q[l][k];
   }
+  if (l == 2 && k < dq->n[2]) {
+    const int32_t p = dq->base[2] + k, s = dq->q[2][k];
+    if (p < (int32_t)m.capacity) { cleared_idx[3 * p] = m.slot_index[3 * s]; cleared_idx[3 * p + 1] = m.slot_index[3 * s + 1]; cleared_idx[3 * p + 2] = m.slot_index[3 * s + 2]; }
+  }
   __syncthreads();
-  if (tid < 2) dq->n[tid] = 0;
+  if (tid < 3) dq->n[tid] = 0;
   __syncthreads();
 }
 // OCC = false: TSDF decay (weight *= factor; a block lives while any weight >= thresh).  OCC = true: occupancy decay (`factor` /
@@ -44,13 +51,13 @@ __device__ inline void decay_flush(const DMap& m, DecayQueues* dq, const int32_t
 // while any value != 0) -- [U] OccupancyDecayIntegrator, Mapper::decayOccupancyAllVoxels (nvblox_node.cpp:925-929).
 template <bool OCC>
 __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, int32_t mesh_list,
-                                               int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc) {
+                                               int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc, int32_t* cleared_idx) {
   __shared__ int s_alive[2][DB];                         // by iteration parity: no barrier between the books of one iteration and the loads of the next
   __shared__ DecayQueues dq;
   const int32_t hw = m.counters[C_HIGH_WATER];
   const int tid = threadIdx.x;
   const int32_t lists[2] = {S_LIST_ESDF_DIRTY, mesh_list};
-  if (tid < 2) dq.n[tid] = 0;
+  if (tid < 3) dq.n[tid] = 0;
   uint32_t nflags[DB];                                   // flags of the NEXT iteration's blocks, fetched one iteration ahead
 #pragma unroll
   for (int j = 0; j < DB; j++) { const int32_t slot = (int32_t)blockIdx.x * DB + j; nflags[j] = slot < hw ? m.slot_flags[slot] : 0u; }
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
     for (int j = 0; j < DB; j++) tv[j] = act[j] ? m.tsdf[(size_t)(base + j) * 512 + tid] : make_float2(0.0f, 0.0f);
     if (tid < DB) s_alive[par][tid] = 0;
     __syncthreads();
-    if (dq.n[0] > DQ - DB || dq.n[1] > DQ - DB) decay_flush(m, &dq, lists, tid);   // uniform: every push of the previous iteration precedes the barrier above
+    if (dq.n[0] > DQ - 2 * DB || dq.n[1] > DQ - DB || dq.n[2] > DQ - DB) decay_flush(m, &dq, lists, cleared_idx, tid);   // uniform: every push of the previous iteration precedes the barrier above
 #pragma unroll
     for (int j = 0; j < DB; j++) if (act[j]) {
       bool live;
@@ -114,6 +121,7 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
         if (!(o & F_DIRTY_ESDF)) dq.q[0][atomicAdd(&dq.n[0], 1)] = slot;
       } else {
         if (!OCC) old = atomicOr(&m.slot_flags[slot], F_DIRTY_MESH);
+        dq.q[2][atomicAdd(&dq.n[2], 1)] = slot;          // Mapper::getClearedBlocks (layer_publishing.cpp:716): the viewer deletes it
         atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH | F_FREESPACE | F_BAND | F_BAND_STALE));
         const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
         if (bz >= bz_lo && bz <= bz_hi) {
@@ -129,13 +137,13 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
     }
   }
   __syncthreads();
-  decay_flush(m, &dq, lists, tid);
+  decay_flush(m, &dq, lists, cleared_idx, tid);
 }
 
 // `srec`: window record of the next ESDF update.  An ESDF block that is dropped takes its sites with it: the distances of
 // every voxel within the search radius of those sites are stale, so the block joins the next update's window (the
 // distance transform is exact on any window that contains every change of the site set).
-__global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float cy, float cz, float r2, float bs, int32_t srec, int32_t esdf3d) {
+__global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float cy, float cz, float r2, float bs, int32_t srec, int32_t esdf3d, int32_t* cleared_idx) {
   const int32_t hw = m.counters[C_HIGH_WATER];
   const int tid = threadIdx.x;
   for (int32_t slot = blockIdx.x; slot < hw; slot += gridDim.x) {
@@ -151,6 +159,10 @@ __global__ __launch_bounds__(512) void k_clear_outside(DMap m, float cx, float c
     if (flags & F_ESDF) m.esdf[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
     if (flags & F_FREESPACE) m.freespace[(size_t)slot * 512 + tid] = make_int4(0, 0, 0, 0);
     if (tid == 0) {
+      if (flags & F_TSDF) {                              // Mapper::getClearedBlocks (layer_publishing.cpp:716)
+        const int32_t p = atomicAdd(&m.counters[C_CLEARED], 1);
+        if (p < (int32_t)m.capacity) { cleared_idx[3 * p] = m.slot_index[3 * slot]; cleared_idx[3 * p + 1] = m.slot_index[3 * slot + 1]; cleared_idx[3 * p + 2] = m.slot_index[3 * slot + 2]; }
+      }
       if ((flags & F_ESDF) && esdf3d) {                  // 3-D ESDF: the dropped block joins the next update's 3-D window
         const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
         atomicMin(&m.counters[C_ESDF3_WIN + 0], bx); atomicMin(&m.counters[C_ESDF3_WIN + 1], by); atomicMin(&m.counters[C_ESDF3_WIN + 2], bz);
@@ -264,7 +276,7 @@ extern "C" int nvbx_decay_occupancy(nvbx_mapper* m) {
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
   NVBX_LAUNCH(m, k_decay<true>, dim3((unsigned)std::min<int64_t>(m->capacity, 2048)), dim3(512), m->d,
               log_odds(m->p.free_region_decay_probability), log_odds(m->p.occupied_region_decay_probability), 0u, (int32_t)m->mesh_list_live(),
-              ea.bz_lo, ea.bz_hi, ea.bz_out, 0.0f);
+              ea.bz_lo, ea.bz_hi, ea.bz_out, 0.0f, m->cleared_idx);
   return rebuild_table(m);
 }
 
@@ -279,8 +291,8 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   EsdfArgs ea = m->make_esdf_args();
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
   NVBX_LAUNCH(m, k_decay<false>, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
-                     exclude_last_view ? m->last_view_frame : 0u, m->mesh_list_live(), ea.bz_lo, ea.bz_hi, ea.bz_out,
-                     m->p.truncation_distance_vox * m->p.voxel_size);
+                     exclude_last_view ? m->last_camera_view_frame : 0u, m->mesh_list_live(), ea.bz_lo, ea.bz_hi, ea.bz_out,
+                     m->p.truncation_distance_vox * m->p.voxel_size, m->cleared_idx);
   return rebuild_table(m);
 }
 
@@ -291,6 +303,27 @@ extern "C" int nvbx_clear_outside_radius(nvbx_mapper* m, const float center[3], 
   if (m->undo_marks()) return NVBX_E_DEVICE;          // deallocates: unresolved marking passes are taken back first
   const int grid = (int)std::min<int64_t>(m->capacity, 2048);
   NVBX_LAUNCH(m, k_clear_outside, dim3(grid), dim3(512), m->d, center[0], center[1], center[2], radius * radius, m->p.voxel_size * 8.0f,
-              (int32_t)(S_ESDF_REC + (int)(m->esdf_epoch & 1)), (int32_t)(m->p.esdf_mode == 1));
+              (int32_t)(S_ESDF_REC + (int)(m->esdf_epoch & 1)), (int32_t)(m->p.esdf_mode == 1), m->cleared_idx);
   return rebuild_table(m);
+}
+
+// Mapper::getClearedBlocks (layer_publishing.cpp:716): projective-layer blocks deallocated (decay, radius clearing) since the last call
+__global__ void k_zero_cleared(DMap m) { m.counters[C_CLEARED] = 0; }
+extern "C" int64_t nvbx_take_cleared_blocks(nvbx_mapper* m, nvbx_index3d* out, int64_t capacity) {
+  if (!m || capacity < 0 || (capacity > 0 && !out)) return NVBX_E_INVALID;
+  if (m->fetch_counters()) return NVBX_E_DEVICE;
+  int64_t n = m->h_counters[C_CLEARED];
+  if (n > m->capacity) n = m->capacity;       // (more deallocations than the pool has blocks between two calls: the oldest ones win)
+  if (n == 0) return 0;
+  std::vector<nvbx_index3d> tmp((size_t)n);
+  NVBX_HIP(hipMemcpy(tmp.data(), m->cleared_idx, (size_t)n * 12, hipMemcpyDeviceToHost));
+  auto less = [](const nvbx_index3d& a, const nvbx_index3d& b) { if (a.x != b.x) return a.x < b.x; if (a.y != b.y) return a.y < b.y; return a.z < b.z; };
+  std::sort(tmp.begin(), tmp.end(), less);
+  tmp.erase(std::unique(tmp.begin(), tmp.end(), [](const nvbx_index3d& a, const nvbx_index3d& b) { return a.x == b.x && a.y == b.y && a.z == b.z; }), tmp.end());
+  const int64_t u = (int64_t)tmp.size();
+  if (u > capacity) return u;                  // too small: nothing is consumed, the caller comes back with room for u
+  memcpy(out, tmp.data(), (size_t)u * 12);
+  NVBX_LAUNCH(m, k_zero_cleared, dim3(1), dim3(1), m->d);
+  NVBX_HIP(hipGetLastError());
+  return u;
 }

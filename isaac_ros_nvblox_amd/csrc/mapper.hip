@@ -120,7 +120,8 @@ __global__ __launch_bounds__(512) void k_scatter_blocks(DMap m, uint32_t layer, 
   if (t == 0) {
     bool is_new; const int32_t h = hash_insert(m, x, y, z, layer, &is_new);
     uint32_t s = SLOT_NONE;
-    if (h >= 0) s = m.table[h].slot;
+    // (a duplicate index in one batch: the workgroup that lost the insert waits for the winner to publish the slot, as mark_block does)
+    if (h >= 0) { do { s = ld_slot_acquire(&m.table[h]); } while (s == SLOT_INVALID); }
     if (slot_ok(s)) {
       uint32_t add = layer;
       if (layer == F_TSDF) add |= F_DIRTY_ESDF | F_DIRTY_MESH;
@@ -195,6 +196,7 @@ static int alloc_all(nvbx_mapper* m) {
   NVBX_HIP(hipMalloc(&d.shc, S_NUM * NSH * SH_STRIDE * 4));
   NVBX_HIP(hipMalloc(&m->export_idx, cap * 12));
   NVBX_HIP(hipMalloc(&m->export_count, 64));
+  NVBX_HIP(hipMalloc(&m->cleared_idx, cap * 12));
   NVBX_HIP(hipMalloc(&d.site_bits, cap * 8));
   NVBX_HIP(hipMalloc(&d.obs_bits, cap * 8));
   NVBX_HIP(hipMalloc(&d.inside_bits, cap * 8));
@@ -229,7 +231,7 @@ static int reset_map(nvbx_mapper* m) {
   NVBX_HIP(hipGetLastError());
   m->dirty_since_mark = false; m->premark_consumed = false; m->mark_pass = 0; m->edt_pending = false; m->import_pending = false;
   m->unresolved_marks = false; m->pass_at_last_edt = 0;
-  m->frame_id = 0; m->esdf_epoch = 0; m->mesh_epoch = 0; m->last_view_frame = 0; m->synth_rows = m->synth_cols = 0;
+  m->frame_id = 0; m->esdf_epoch = 0; m->mesh_epoch = 0; m->last_view_frame = 0; m->last_camera_view_frame = 0; m->synth_rows = m->synth_cols = 0;
   return NVBX_OK;
 }
 
@@ -262,6 +264,8 @@ Frame nvbx_mapper::make_frame(const float T[16], const nvbx_camera* cam, int32_t
   f.max_dist = p.max_integration_distance_m; f.max_weight = p.max_weight;
   f.weighting_mode = p.weighting_mode; f.interp_nearest = p.depth_interp_nearest;
   f.invalid_decay = p.invalid_depth_decay_factor;
+  f.weighting_variant = p.tsdf_weighting_variant; f.skip_at_neg_trunc = p.tsdf_skip_at_negative_truncation; f.clamp_before_blend = p.tsdf_weight_clamp_before_blend;
+  f.occlusion_thresh = p.color_occlusion_threshold_vox < 0.0f ? f.trunc : p.color_occlusion_threshold_vox * p.voxel_size;
   f.occupancy = p.projective_layer_type == 1 ? 1 : 0;
   f.lo_free = log_odds(p.free_region_occupancy_probability); f.lo_occupied = log_odds(p.occupied_region_occupancy_probability);
   f.lo_unobserved = log_odds(p.unobserved_region_occupancy_probability); f.occ_half_width = p.occupied_region_half_width_m;
@@ -304,6 +308,9 @@ static const char* params_problem(const nvbx_mapper_params* p) {
   if (!pos(p->max_weight)) return "max_weight must be > 0";
   if (p->projective_layer_type < 0 || p->projective_layer_type > 2) return "projective_layer_type must be 0 (TSDF), 1 (occupancy) or 2 (TSDF + freespace)";
   if (p->esdf_mode < 0 || p->esdf_mode > 1) return "esdf_mode must be 0 (2-D) or 1 (3-D)";
+  if (p->tsdf_weighting_variant < 0 || p->tsdf_weighting_variant > 1 || p->esdf_propagation < 0 || p->esdf_propagation > 1 ||
+      p->mesh_ambiguity_rule < 0 || p->mesh_ambiguity_rule > 2 || p->mesh_normal_rule < 0 || p->mesh_normal_rule > 1) return "open-choice switch out of range";
+  if (p->esdf_propagation == 1 && p->esdf_mode == 1) return "esdf_propagation 1 (iterative) is defined for the 2-D slice only";
   if (p->sphere_tracing_max_steps < 0 || p->sphere_tracing_max_steps > (1 << 20)) return "sphere_tracing_max_steps out of range";
   if (p->projective_layer_type == 1) {
     auto prob = [](float v) { return v > 0.0f && v < 1.0f; };
@@ -351,7 +358,7 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   if (m->side) (void)hipStreamDestroy(m->side);
   DMap& d = m->d;
   void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.slot_consumed, d.tsdf, d.color, d.esdf,
-                  m->view_list, d.lists, d.shc, m->export_idx, m->export_count, d.site_bits, d.obs_bits, d.inside_bits,
+                  m->view_list, d.lists, d.shc, m->export_idx, m->export_count, m->cleared_idx, d.site_bits, d.obs_bits, d.inside_bits,
                   m->synth, m->depth_pre, m->mask_zmin, m->esdf3_scratch, m->cc_scratch, d.freespace, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& s : m->spans) { if (s.a) (void)hipEventDestroy(s.a); if (s.b) (void)hipEventDestroy(s.b); }
@@ -416,6 +423,13 @@ extern "C" void nvbx_default_params(nvbx_mapper_params* p) {
   p->max_tsdf_distance_for_occupancy_m = 0.15f; p->max_unobserved_to_keep_consecutive_occupancy_ms = 200;
   p->min_duration_since_occupied_for_freespace_ms = 1000; p->min_consecutive_occupancy_duration_for_reset_ms = 2000;
   p->check_neighborhood = 1; p->initialize_to_high_confidence_freespace = 0;
+  p->tsdf_weighting_variant = 0; p->tsdf_skip_at_negative_truncation = 0; p->tsdf_weight_clamp_before_blend = 0;
+  p->color_occlusion_threshold_vox = -1.0f; p->esdf_propagation = 0; p->mesh_ambiguity_rule = 0; p->mesh_normal_rule = 0;
+}
+extern "C" int nvbx_get_stream(nvbx_mapper* m, void** hip_stream_out) {
+  if (!m || !hip_stream_out) return NVBX_E_INVALID;
+  *hip_stream_out = (void*)m->stream;
+  return NVBX_OK;
 }
 extern "C" int nvbx_flush(nvbx_mapper* m) {
   if (!m) return NVBX_E_INVALID;
@@ -600,6 +614,7 @@ extern "C" int nvbx_load_map(nvbx_mapper* m, const char* path) {
   MapFileHeader h{};
   if (fread(&h, sizeof(h), 1, fc.f) != 1 || memcmp(h.magic, kMapMagic, 8) != 0 || h.version != 1) { set_error("nvbx_load_map: not a libnvblox_hip map file"); return NVBX_E_IO; }
   if (fabsf(h.voxel_size - m->p.voxel_size) > 1e-6f * m->p.voxel_size) { set_error("nvbx_load_map: voxel size of the file differs from the mapper's"); return NVBX_E_INVALID; }
+  if (h.n_layers > 16) { set_error("nvbx_load_map: implausible layer count"); return NVBX_E_IO; }
   // validate the whole file before the current map is touched
   struct Section { MapLayerHeader lh; long idx_off, vox_off; };
   std::vector<Section> sections;
@@ -609,7 +624,7 @@ extern "C" int nvbx_load_map(nvbx_mapper* m, const char* path) {
     if (!(sc.lh.layer == F_TSDF || sc.lh.layer == F_COLOR || sc.lh.layer == F_ESDF || sc.lh.layer == NVBX_LAYER_OCCUPANCY) ||
         sc.lh.voxel_bytes != ref_voxel_bytes(sc.lh.layer) || (sc.lh.n_blocks > 0 && !internal_layer(m, sc.lh.layer))) {
       set_error("nvbx_load_map: unknown layer record"); return NVBX_E_IO; }
-    if ((int64_t)sc.lh.n_blocks > m->capacity) { set_error("nvbx_load_map: map has more blocks than the mapper's block capacity"); return NVBX_E_CAPACITY; }
+    if (sc.lh.n_blocks > (uint64_t)m->capacity) { set_error("nvbx_load_map: map has more blocks than the mapper's block capacity"); return NVBX_E_CAPACITY; }
     sc.idx_off = ftell(fc.f); sc.vox_off = sc.idx_off + (long)(sc.lh.n_blocks * 12);
     if (fseek(fc.f, sc.vox_off + (long)(sc.lh.n_blocks * 512 * sc.lh.voxel_bytes), SEEK_SET) != 0) { set_error("nvbx_load_map: truncated file"); return NVBX_E_IO; }
     sections.push_back(sc);

@@ -19,9 +19,14 @@
 
 using namespace nvbx;
 
-__constant__ int8_t MC_TRI_C[256][16] = {
+// marching-cubes triangle tables, one per ambiguity rule (nvbx_mapper_params::mesh_ambiguity_rule; tools/gen_mc_table.py)
+__constant__ int8_t MC_TRI_C[3][256][16] = {{
 #include "mc_table.inc"
-};
+}, {
+#include "mc_table_r1.inc"
+}, {
+#include "mc_table_r2.inc"
+}};
 __constant__ int8_t MC_EDGE_BASE_C[12][3] = {{0,0,0},{1,0,0},{0,1,0},{0,0,0},{0,0,1},{1,0,1},{0,1,1},{0,0,1},{0,0,0},{1,0,0},{1,1,0},{0,1,0}};
 __constant__ int8_t MC_EDGE_AXIS_C[12] = {0,1,0,1,0,1,0,1,2,2,2,2};
 
@@ -30,6 +35,7 @@ constexpr int NLAT = 729, NEDGE = 2187, MAXTRI = 2560;
 struct MeshArgs {
   float voxel_size, block_size, min_weight;
   int32_t full;          // 1: every TSDF block, 0: dirty list
+  int32_t rule, normal_rule;   // [U] open choices: ambiguity rule (table), welded-vertex normal rule
   int32_t dirty_list;    // S_LIST_* id of the list to mesh
   int32_t next_list;     // the other parity's list (reset here; blocks dirtied from now on go there)
   int32_t rec, rec_next; // C_MESH_OUT records (list entries)
@@ -120,13 +126,14 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
       if (s_d[li] < 0.0f) cube |= 1 << c;
     }
     int ntri = 0;
-    if (ok && cube != 0 && cube != 255) { while (ntri < 5 && MC_TRI_C[cube][3 * ntri] >= 0) ntri++; }
+    const int8_t* tri_row = MC_TRI_C[a.rule][cube];
+    if (ok && cube != 0 && cube != 255) { while (ntri < 5 && tri_row[3 * ntri] >= 0) ntri++; }
     int T;
     const int toff = block_scan_512(ntri, s_part, tid, &T);
     for (int j = 0; j < ntri; j++) {
 #pragma unroll
       for (int q = 0; q < 3; q++) {
-        const int e = MC_TRI_C[cube][3 * j + q];
+        const int e = tri_row[3 * j + q];
         const int eid = (((vx + MC_EDGE_BASE_C[e][0]) * 9 + (vy + MC_EDGE_BASE_C[e][1])) * 9 + (vz + MC_EDGE_BASE_C[e][2])) * 3 + MC_EDGE_AXIS_C[e];
         s_tri_edges[3 * (toff + j) + q] = (uint16_t)eid;
         atomicMin(&s_first[eid], toff + j);
@@ -191,27 +198,33 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
         if (__uint_as_float(cv.y) > 0.0f) rgba = cv.x & 0x00FFFFFFu;
       }
       rgba |= 255u << 24;
-      // normal: first triangle referencing this vertex
-      const int tf = s_first[e];
-      float tp[3][3];
+      // normal: rule 0 = the first triangle referencing this vertex; rule 1 = area-weighted mean (sum of the unnormalised
+      // triangle normals, ascending triangle index) of the block's triangles referencing it
+      float nn[3] = {0.0f, 0.0f, 0.0f};
+      const int t_lo = a.normal_rule == 0 ? s_first[e] : 0, t_hi = a.normal_rule == 0 ? s_first[e] + 1 : T;
+#pragma unroll 1
+      for (int tf = t_lo; tf < t_hi; tf++) {
+        if (a.normal_rule != 0 && s_tri_edges[3 * tf] != e && s_tri_edges[3 * tf + 1] != e && s_tri_edges[3 * tf + 2] != e) continue;
+        float tp[3][3];
 #pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const int eq = s_tri_edges[3 * tf + q];
-        int qi, qj, qa, qx, qy, qz;
-        edge_decode(eq, &qi, &qj, &qa, &qx, &qy, &qz);
-        const float ea = s_d[qi], eb = s_d[qj];
-        const float tt = ea / (ea - eb);
-        const int32_t q3[3] = {qx, qy, qz};
+        for (int q = 0; q < 3; q++) {
+          const int eq = s_tri_edges[3 * tf + q];
+          int qi, qj, qa, qx, qy, qz;
+          edge_decode(eq, &qi, &qj, &qa, &qx, &qy, &qz);
+          const float ea = s_d[qi], eb = s_d[qj];
+          const float tt = ea / (ea - eb);
+          const int32_t q3[3] = {qx, qy, qz};
 #pragma unroll
-        for (int w = 0; w < 3; w++) {
-          float pos = ((float)b3[w] * a.block_size + (float)q3[w] * a.voxel_size) + a.voxel_size * 0.5f;
-          if (w == qa) pos = pos + tt * a.voxel_size;
-          tp[q][w] = pos;
+          for (int w = 0; w < 3; w++) {
+            float pos = ((float)b3[w] * a.block_size + (float)q3[w] * a.voxel_size) + a.voxel_size * 0.5f;
+            if (w == qa) pos = pos + tt * a.voxel_size;
+            tp[q][w] = pos;
+          }
         }
+        const float e1[3] = {tp[1][0] - tp[0][0], tp[1][1] - tp[0][1], tp[1][2] - tp[0][2]};
+        const float e2[3] = {tp[2][0] - tp[0][0], tp[2][1] - tp[0][1], tp[2][2] - tp[0][2]};
+        nn[0] = nn[0] + (e1[1] * e2[2] - e1[2] * e2[1]); nn[1] = nn[1] + (e1[2] * e2[0] - e1[0] * e2[2]); nn[2] = nn[2] + (e1[0] * e2[1] - e1[1] * e2[0]);
       }
-      const float e1[3] = {tp[1][0] - tp[0][0], tp[1][1] - tp[0][1], tp[1][2] - tp[0][2]};
-      const float e2[3] = {tp[2][0] - tp[0][0], tp[2][1] - tp[0][1], tp[2][2] - tp[0][2]};
-      float nn[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
       const float len = sqrtf((nn[0] * nn[0] + nn[1] * nn[1]) + nn[2] * nn[2]);
       if (len > 0.0f) { nn[0] = nn[0] / len; nn[1] = nn[1] / len; nn[2] = nn[2] / len; }
       const size_t o = (size_t)(vbase + vid);
@@ -237,6 +250,7 @@ extern "C" int nvbx_update_color_mesh(nvbx_mapper* m, int32_t update_full_layer)
   MeshArgs a{};
   a.voxel_size = m->p.voxel_size; a.block_size = m->p.voxel_size * 8.0f; a.min_weight = m->p.mesh_min_weight;
   a.full = update_full_layer ? 1 : 0;
+  a.rule = m->p.mesh_ambiguity_rule; a.normal_rule = m->p.mesh_normal_rule;
   const int par = (int)(m->mesh_epoch & 1);
   a.dirty_list = S_LIST_MESH_DIRTY + par; a.next_list = S_LIST_MESH_DIRTY + (par ^ 1);
   a.rec = C_MESH_OUT + 4 * par; a.rec_next = C_MESH_OUT + 4 * (par ^ 1);

@@ -77,6 +77,7 @@ enum {
                        //   fields are sharded (S_MESH_REC below)
   C_LIVE = 44,         // live hash entries
   C_TMP = 45,          // scratch counter (point cloud compaction etc.)
+  C_CLEARED = 46,      // entries of the cleared-block list (nvbx_take_cleared_blocks)
   C_NUM = 48
 };
 
@@ -130,6 +131,8 @@ struct Frame {
   int32_t rows, cols;
   float voxel_size, block_size, trunc, max_dist, max_weight;
   int32_t weighting_mode, interp_nearest;
+  // [U] open-choice switches (include/nvblox_hip.h): weighting formula set, sdf == -trunc edge, clamp order, colour occlusion threshold (m)
+  int32_t weighting_variant, skip_at_neg_trunc, clamp_before_blend; float occlusion_thresh;
   float invalid_decay;      // invalid_depth_decay_factor (< 0 = off)
   // occupancy mappers (projective_layer_type 1): the projective pool holds {log_odds, 0}; log-odds updates of the three regions
   int32_t occupancy; float lo_free, lo_occupied, lo_unobserved, occ_half_width;
@@ -343,21 +346,50 @@ __device__ inline float occupancy_update(const Frame& f, float cur, float ds, fl
   return v;
 }
 
-__device__ inline float weight_fn(int mode, float d_meas, float d_vox, float trunc) {
+// WeightingFunctionType (mapper_initialization.cpp:31-42).  constant = 1 and inverse-square = 1 / d^2 are unambiguous; the other
+// four formulas are [U]/[D] and come in two sets (nvbx_mapper_params::tsdf_weighting_variant; oracle weight_fn, same lines):
+//   set A: dropoff = linear ramp 1 -> 0 between the surface and -trunc behind it; tsdf-distance penalty = trunc / sdf for voxels
+//          more than trunc in front of the surface; linear-with-max = min(1, 1 / d)
+//   set B: dropoff starts one voxel behind the surface, (trunc + sdf) / (trunc - voxel) (the voxblox form); tsdf-distance penalty =
+//          quadratic ramp ((trunc + sdf) / trunc)^2 behind the surface; linear-with-max = max(0.01, 1 - d / max_integration_distance)
+__device__ inline float weight_fn(int mode, int variant, float d_meas, float d_vox, float trunc, float voxel_size, float max_dist) {
   float w = 1.0f;
   if (mode == 2 || mode == 3 || mode == 4) {
     w = 1.0f / (d_meas * d_meas);
   } else if (mode == 5) {
-    w = 1.0f / d_meas;
-    if (w > 1.0f) w = 1.0f;
+    if (variant == 0) { w = 1.0f / d_meas; if (w > 1.0f) w = 1.0f; }
+    else { w = 1.0f - d_meas / max_dist; if (w < 0.01f) w = 0.01f; }
   }
   const float sdf = d_meas - d_vox;
   if (mode == 1 || mode == 3) {
-    if (sdf < 0.0f) { float g = (trunc + sdf) / trunc; if (g < 0.0f) g = 0.0f; w = w * g; }
+    if (variant == 0) {
+      if (sdf < 0.0f) { float g = (trunc + sdf) / trunc; if (g < 0.0f) g = 0.0f; w = w * g; }
+    } else if (sdf < -voxel_size) {
+      float g = 0.0f;
+      if (trunc > voxel_size) { g = (trunc + sdf) / (trunc - voxel_size); if (g < 0.0f) g = 0.0f; }
+      w = w * g;
+    }
   } else if (mode == 4) {
-    if (sdf > trunc) w = w * (trunc / sdf);
+    if (variant == 0) { if (sdf > trunc) w = w * (trunc / sdf); }
+    else if (sdf < 0.0f) { float g = (trunc + sdf) / trunc; if (g < 0.0f) g = 0.0f; w = w * (g * g); }
   }
   return w;
+}
+// [U] UpdateTsdfVoxelFunctor: fuses the measurement into *v; false if the measurement does not touch the voxel.
+// Switches: skip_at_neg_trunc (the voxel exactly at sdf == -trunc), clamp_before_blend (max_weight clamp order).
+__device__ inline bool tsdf_fuse(const Frame& f, float2* v, float ds, float vd) {
+  const float2 cur = *v;
+  const float sdf = ds - vd;
+  if (f.skip_at_neg_trunc ? (sdf <= -f.trunc) : (sdf < -f.trunc)) return false;
+  const float wm = weight_fn(f.weighting_mode, f.weighting_variant, ds, vd, f.trunc, f.voxel_size, f.max_dist);
+  const float wsum = wm + cur.y;
+  if (!(wsum > 0.0f)) return false;
+  float fused, wnew = fminf(wsum, f.max_weight);
+  if (!f.clamp_before_blend) fused = (sdf * wm + cur.x * cur.y) / wsum;
+  else { float wp = wnew - wm; if (wp < 0.0f) wp = 0.0f; fused = (sdf * wm + cur.x * wp) / (wm + wp); }
+  if (fused > 0.0f) fused = fminf(f.trunc, fused); else fused = fmaxf(-f.trunc, fused);
+  *v = make_float2(fused, wnew);
+  return true;
 }
 
 // ESDF packed voxel: {f32 squared_distance_vox, u32 meta}; meta = dx | dy<<8 | dz<<16 (int8 each) | observed<<24 | inside<<25 | site<<26

@@ -71,6 +71,7 @@ struct nvbx_mapper {
   // (the ESDF-dirty / mesh-dirty / colour work lists are sharded and live in d.lists / d.shc, nvbx_internal.h)
   int32_t* export_idx = nullptr;     // int32[capacity][3] scratch for multi-GPU export of the dirty list
   int32_t* export_count = nullptr;
+  int32_t* cleared_idx = nullptr;    // int32[capacity][3]: Index3D of projective-layer blocks deallocated since nvbx_take_cleared_blocks
   // LiDAR beam direction tables (float2 {sin, cos}: rows elevations then cols azimuths), rebuilt when the model changes
   void* lidar_tab = nullptr; size_t lidar_tab_cap = 0; nvbx_lidar lidar_cached{}; std::vector<float> lidar_host;
   // mask splitting scratch: nearest depth (in the mask camera) that landed on each mask pixel
@@ -121,6 +122,9 @@ struct nvbx_mapper {
   int32_t* h_shc = nullptr;          // pinned mirror of d.shc
   int64_t shc_sum(int id, int field) const { int64_t t = 0; for (int s = 0; s < nvbx::NSH; s++) t += h_shc[(id * nvbx::NSH + s) * nvbx::SH_STRIDE + field]; return t; }
   uint32_t last_view_frame = 0;
+  // frame stamp of the last CAMERA depth frame: decayTsdfExcludeLastView<Camera> spares the camera's view only -- a LiDAR scan in
+  // between must not take its place (nvblox_node.cpp:931-936: 'lidar views are not excluded')
+  uint32_t last_camera_view_frame = 0;
   // C-ABI helpers implemented across the .hip files
   nvbx::Frame make_frame(const float T_L_C[16], const nvbx_camera* cam, int32_t rows, int32_t cols, int32_t subsample) const;
   nvbx::EsdfArgs make_esdf_args() const;

@@ -442,18 +442,7 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img dep
       if (got > 0) *vp = make_float2(occupancy_update(f, cur_c.x, ds, vd), 0.0f);
     } else {
       if (got < 0 && f.invalid_decay >= 0.0f) { fin = make_float2(cur_c.x, cur_c.y * f.invalid_decay); *vp = fin; }
-      if (got > 0) {
-        const float sdf = ds - vd;
-        if (!(sdf < -f.trunc)) {
-          const float wm = weight_fn(f.weighting_mode, ds, vd, f.trunc);
-          const float wsum = wm + cur_c.y;
-          if (wsum > 0.0f) {
-            float fused = (sdf * wm + cur_c.x * cur_c.y) / wsum;
-            if (fused > 0.0f) fused = fminf(f.trunc, fused); else fused = fmaxf(-f.trunc, fused);
-            fin = make_float2(fused, fminf(wsum, f.max_weight)); *vp = fin;
-          }
-        }
-      }
+      if (got > 0 && tsdf_fuse(f, &fin, ds, vd)) *vp = fin;
       // band vote for the colour integrator (F_BAND, nvbx_internal.h): exact, so set AND cleared here, one bit per wavefront
       if (!Sensor::kLongRays) {      // (LiDAR: marked stale above instead)
         // one workgroup per block and a few hundred blocks: a block-wide vote and ONE atomic are cheaper here than a bit per wavefront
@@ -489,6 +478,7 @@ static int integrate_depth_impl(nvbx_mapper* m, Img img, const Sensor& sensor, c
                      m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap);
   NVBX_HIP(hipGetLastError());
   m->last_view_frame = m->frame_id;
+  if (!Sensor::kLongRays) m->last_camera_view_frame = m->frame_id;
   if (m->p.projective_layer_type == 2 && m->update_freespace()) return NVBX_E_DEVICE;     // TSDF with freespace (dynamic mapping)
   return m->mark_main();
 }

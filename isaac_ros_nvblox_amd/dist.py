@@ -36,19 +36,37 @@ class DirtyBlockExchange:
             return None
         return dist.all_gather_into_tensor(self.all_buf.view(-1, 3), self.buf, group=self.group, async_op=async_op)
 
+    # -- stream ordering.  The mapper writes self.buf / reads self.all_buf on ITS stream (Mapper(stream=None) owns a non-blocking
+    #    stream); the collective runs on torch's current stream (RCCL's own stream is ordered behind it by torch).  When the two
+    #    differ, events order them; when the mapper was created on torch's current stream there is nothing to do.
+    def _streams(self, mapper):
+        if not self.buf.is_cuda or not hasattr(mapper, "torch_stream"):
+            return None, None
+        cur = torch.cuda.current_stream(self.buf.device)
+        ms = mapper.torch_stream()
+        if ms.cuda_stream == cur.cuda_stream:
+            return None, None
+        return ms, cur
+
     # -- split-phase exchange (bench.py): start after integrateDepth, finish before updateEsdf
     def start(self, mapper, export=True):
         """Export this GPU's dirty TSDF block indices (device kernel, count stays on the device) and launch the all-gather.
         export=False: the mapper has already written the message (Mapper.set_view_export(self.buf) before integrate_depth)."""
         if export:
             mapper.esdf_dirty_list(self.idx, self.cnt)
+        ms, cur = self._streams(mapper)
+        if ms is not None:
+            cur.wait_stream(ms)              # the collective reads self.buf only after the mapper's stream has written it
         return self.all_gather(async_op=True)
 
     def finish(self, mapper, work, deferred=False):
         """Join the all-gather, then mark every peer's blocks ESDF-dirty locally (count read on the device).  deferred: the
         marking rides in the mapper's next integrate_color launch instead of a launch of its own."""
         if work is not None:
-            work.wait()
+            work.wait()                      # orders torch's current stream behind the collective
+        ms, cur = self._streams(mapper)
+        if ms is not None:
+            ms.wait_stream(cur)              # ... and the mapper's stream behind torch's: the union step reads all_buf after it landed
         if self.world > 1:      # one launch for all peers' lists (not one per peer)
             if deferred:
                 mapper.mark_esdf_dirty_gathered(self.all_buf, self.world, self.rank, self.max_blocks, deferred=True)

@@ -42,7 +42,9 @@ def default_params(**kw):
         free_region_decay_probability=0.55, occupied_region_decay_probability=0.30, esdf_mode=0,
         max_tsdf_distance_for_occupancy_m=0.15, max_unobserved_to_keep_consecutive_occupancy_ms=200,
         min_duration_since_occupied_for_freespace_ms=1000, min_consecutive_occupancy_duration_for_reset_ms=2000,
-        check_neighborhood=1, initialize_to_high_confidence_freespace=0)
+        check_neighborhood=1, initialize_to_high_confidence_freespace=0,
+        tsdf_weighting_variant=0, tsdf_skip_at_negative_truncation=0, tsdf_weight_clamp_before_blend=0,
+        color_occlusion_threshold_vox=-1.0, esdf_propagation=0, mesh_ambiguity_rule=0, mesh_normal_rule=0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -116,6 +118,18 @@ class Mapper:
 
     def synchronize(self):
         self._check(self.lib.nvbx_synchronize(self._h))
+
+    def stream_handle(self):
+        """The raw hipStream_t of the mapper (int)."""
+        h = C.c_void_p()
+        self._check(self.lib.nvbx_get_stream(self._h, C.byref(h)))
+        return h.value or 0
+
+    def torch_stream(self):
+        """The mapper's stream as a torch stream object (for event ordering against work on torch's streams)."""
+        if getattr(self, "_tstream", None) is None:
+            self._tstream = self._torch.cuda.ExternalStream(self.stream_handle(), device="cuda:%d" % self.device)
+        return self._tstream
 
     def flush(self):
         """Enqueue held-back work (the EDT of the last update_esdf) without waiting."""
@@ -250,6 +264,12 @@ class Mapper:
     def clear_outside_radius(self, center, radius):
         c = np.asarray(center, np.float32)
         self._check(self.lib.nvbx_clear_outside_radius(self._h, _np_ptr(c), float(radius)))
+
+    def take_cleared_blocks(self):
+        """Mapper::getClearedBlocks (layer_publishing.cpp:716): blocks deallocated by decay / radius clearing since the last call."""
+        out = np.zeros((self.capacity, 3), np.int32)
+        n = self._check(self.lib.nvbx_take_cleared_blocks(self._h, _np_ptr(out), out.shape[0]))
+        return out[:n].copy()
 
     def clear_tsdf_inside_shapes(self, shapes):
         """shapes: list of ("sphere", centre, radius) / ("aabb", min_corner, max_corner)."""

@@ -61,6 +61,13 @@ class OrcParams(C.Structure):
         ("min_consecutive_occupancy_duration_for_reset_ms", C.c_int32),
         ("check_neighborhood", C.c_int32),
         ("initialize_to_high_confidence_freespace", C.c_int32),
+        ("tsdf_weighting_variant", C.c_int32),
+        ("tsdf_skip_at_negative_truncation", C.c_int32),
+        ("tsdf_weight_clamp_before_blend", C.c_int32),
+        ("color_occlusion_threshold_vox", C.c_float),
+        ("esdf_propagation", C.c_int32),
+        ("mesh_ambiguity_rule", C.c_int32),
+        ("mesh_normal_rule", C.c_int32),
     ]
 
 
@@ -83,7 +90,9 @@ def default_params(**kw):
         free_region_decay_probability=0.55, occupied_region_decay_probability=0.30, esdf_mode=0,
         max_tsdf_distance_for_occupancy_m=0.15, max_unobserved_to_keep_consecutive_occupancy_ms=200,
         min_duration_since_occupied_for_freespace_ms=1000, min_consecutive_occupancy_duration_for_reset_ms=2000,
-        check_neighborhood=1, initialize_to_high_confidence_freespace=0)
+        check_neighborhood=1, initialize_to_high_confidence_freespace=0,
+        tsdf_weighting_variant=0, tsdf_skip_at_negative_truncation=0, tsdf_weight_clamp_before_blend=0,
+        color_occlusion_threshold_vox=-1.0, esdf_propagation=0, mesh_ambiguity_rule=0, mesh_normal_rule=0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -141,6 +150,7 @@ def lib():
         L.orc_remove_small_components.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
         L.orc_clear_tsdf_inside_shapes.restype = i64; L.orc_clear_tsdf_inside_shapes.argtypes = [vp, vp, i32]
         L.orc_clear_outside_radius.restype = i64; L.orc_clear_outside_radius.argtypes = [vp, vp, C.c_float]
+        L.orc_take_cleared_blocks.restype = i64; L.orc_take_cleared_blocks.argtypes = [vp, vp, i64]
         L.orc_mark_esdf_dirty.restype = i64; L.orc_mark_esdf_dirty.argtypes = [vp, vp, i64]
         L.orc_esdf_dirty_list.restype = i64; L.orc_esdf_dirty_list.argtypes = [vp, vp, i64]
         _lib = L
@@ -299,6 +309,11 @@ class OracleMap:
     def clear_outside_radius(self, center, radius):
         c = np.asarray(center, np.float32)
         return lib().orc_clear_outside_radius(self._h, _p(c), float(radius))
+
+    def take_cleared_blocks(self):
+        out = np.zeros((1 << 16, 3), np.int32)
+        n = lib().orc_take_cleared_blocks(self._h, _p(out), out.shape[0])
+        return out[:n].copy()
 
 
 def set_num_threads(n):

@@ -100,6 +100,10 @@ typedef struct {
   float max_tsdf_distance_for_occupancy_m;
   int32_t max_unobserved_to_keep_consecutive_occupancy_ms, min_duration_since_occupied_for_freespace_ms,
           min_consecutive_occupancy_duration_for_reset_ms, check_neighborhood, initialize_to_high_confidence_freespace;
+  /* [U] open choices as switches (include/nvblox_hip.h, same names): every one implemented here and in the HIP kernels */
+  int32_t tsdf_weighting_variant, tsdf_skip_at_negative_truncation, tsdf_weight_clamp_before_blend;
+  float color_occlusion_threshold_vox;
+  int32_t esdf_propagation, mesh_ambiguity_rule, mesh_normal_rule;
 } OrcParams;
 
 enum { W_CONSTANT = 0, W_CONSTANT_DROPOFF = 1, W_INVERSE_SQUARE = 2, W_INVERSE_SQUARE_DROPOFF = 3,
@@ -131,15 +135,22 @@ typedef struct {
   Block** table; int64_t cap; int64_t count;   /* open addressing, hash = x + 17191 y + 17191^2 z */
   Block** order; int64_t order_cap;            /* insertion order */
   int32_t frame, esdf_epoch;
+  int32_t camera_frame;                        /* frame stamp of the last CAMERA depth frame (decayTsdfExcludeLastView<Camera>, nvblox_node.cpp:931-936) */
   int64_t time_ms;                             /* update_time_ms of the next integrateDepth (freespace layer) */
   Idx3* view; int64_t n_view, view_cap;        /* blocks in view of last depth frame */
   Idx3* cview; int64_t n_cview, cview_cap;     /* blocks updated by last colour frame */
   float* synth; int synth_rows, synth_cols;    /* last synthetic depth image (sphere tracing) */
+  Idx3* cleared; int64_t n_cleared, cleared_cap; /* Mapper::getClearedBlocks (layer_publishing.cpp:716): projective blocks deallocated since the last take */
 } OrcMap;
 
-static const int8_t MC_TRI[256][16] = {
+/* one table per ambiguity rule (OrcParams.mesh_ambiguity_rule; tools/gen_mc_table.py) */
+static const int8_t MC_TRI[3][256][16] = {{
 #include "mc_table.inc"
-};
+}, {
+#include "mc_table_r1.inc"
+}, {
+#include "mc_table_r2.inc"
+}};
 
 /* ------------------------------------------------------------------ hashing */
 static inline uint32_t idx_hash(Idx3 i) {
@@ -211,7 +222,7 @@ void orc_set_params(OrcMap* m, const OrcParams* p) { m->p = *p; }
 void orc_destroy(OrcMap* m) {
   if (!m) return;
   for (int64_t k = 0; k < m->count; k++) block_free(m->order[k]);
-  free(m->table); free(m->order); free(m->view); free(m->cview); free(m->synth); free(m);
+  free(m->table); free(m->order); free(m->view); free(m->cview); free(m->synth); free(m->cleared); free(m);
 }
 void orc_set_num_threads(int n) {
 #ifdef _OPENMP
@@ -303,24 +314,50 @@ static inline int interp_depth(const float* img, int rows, int cols, float u, fl
   return 1;
 }
 
-/* WeightingFunction (mapper_initialization.cpp:31-42 names the six modes; formulas [U]/[D]) */
-static inline float weight_fn(int mode, float d_meas, float d_vox, float trunc) {
+/* WeightingFunction (mapper_initialization.cpp:31-42 names the six modes).  constant and inverse-square are unambiguous; the
+ * other four formulas are [U]/[D] and exist in two sets (OrcParams.tsdf_weighting_variant):
+ *   A: dropoff = linear ramp 1 -> 0 from the surface to -trunc behind it; tsdf-distance penalty = trunc / sdf for voxels more than
+ *      trunc in front of the surface; linear-with-max = min(1, 1 / d)
+ *   B: dropoff starts one voxel behind the surface, (trunc + sdf) / (trunc - voxel); tsdf-distance penalty = ((trunc + sdf) / trunc)^2
+ *      behind the surface; linear-with-max = max(0.01, 1 - d / max_integration_distance) */
+static inline float weight_fn(int mode, int variant, float d_meas, float d_vox, float trunc, float voxel_size, float max_dist) {
   float w = 1.0f;
   if (mode == W_INVERSE_SQUARE || mode == W_INVERSE_SQUARE_DROPOFF || mode == W_INVERSE_SQUARE_TSDF_DISTANCE_PENALTY) {
     w = 1.0f / (d_meas * d_meas);
   } else if (mode == W_LINEAR_WITH_MAX) {
-    w = 1.0f / d_meas;                       /* [D] linear-in-inverse-depth, capped at 1 (i.e. full weight inside 1 m) */
-    if (w > 1.0f) w = 1.0f;
+    if (variant == 0) { w = 1.0f / d_meas; if (w > 1.0f) w = 1.0f; }
+    else { w = 1.0f - d_meas / max_dist; if (w < 0.01f) w = 0.01f; }
   }
   const float sdf = d_meas - d_vox;
   if (mode == W_CONSTANT_DROPOFF || mode == W_INVERSE_SQUARE_DROPOFF) {
-    /* 1 in front of the surface, linear ramp to 0 at -trunc behind it */
-    if (sdf < 0.0f) { float f = (trunc + sdf) / trunc; if (f < 0.0f) f = 0.0f; w = w * f; }
+    if (variant == 0) {
+      if (sdf < 0.0f) { float f = (trunc + sdf) / trunc; if (f < 0.0f) f = 0.0f; w = w * f; }
+    } else if (sdf < -voxel_size) {
+      float f = 0.0f;
+      if (trunc > voxel_size) { f = (trunc + sdf) / (trunc - voxel_size); if (f < 0.0f) f = 0.0f; }
+      w = w * f;
+    }
   } else if (mode == W_INVERSE_SQUARE_TSDF_DISTANCE_PENALTY) {
-    /* [D] voxels further than trunc in front of the surface are down-weighted by trunc/sdf */
-    if (sdf > trunc) w = w * (trunc / sdf);
+    if (variant == 0) { if (sdf > trunc) w = w * (trunc / sdf); }
+    else if (sdf < 0.0f) { float f = (trunc + sdf) / trunc; if (f < 0.0f) f = 0.0f; w = w * (f * f); }
   }
   return w;
+}
+/* [U] UpdateTsdfVoxelFunctor restated, with the open choices as switches: the voxel exactly at sdf == -trunc
+ * (tsdf_skip_at_negative_truncation) and the max_weight clamp order (tsdf_weight_clamp_before_blend).  `max_dist` = the sensor's
+ * max integration distance (camera / LiDAR).  Returns 1 if the voxel was updated. */
+static inline int tsdf_fuse(const OrcParams* p, TsdfVoxel* vx, float ds, float vd, float trunc, float max_dist) {
+  const float sdf = ds - vd;
+  if (p->tsdf_skip_at_negative_truncation ? (sdf <= -trunc) : (sdf < -trunc)) return 0;
+  const float wm = weight_fn(p->weighting_mode, p->tsdf_weighting_variant, ds, vd, trunc, p->voxel_size, max_dist);
+  const float wsum = wm + vx->weight;
+  if (!(wsum > 0.0f)) return 0;
+  float fused; const float wnew = fminf(wsum, p->max_weight);
+  if (!p->tsdf_weight_clamp_before_blend) fused = (sdf * wm + vx->distance * vx->weight) / wsum;
+  else { float wp = wnew - wm; if (wp < 0.0f) wp = 0.0f; fused = (sdf * wm + vx->distance * wp) / (wm + wp); }
+  if (fused > 0.0f) fused = fminf(trunc, fused); else fused = fmaxf(-trunc, fused);
+  vx->distance = fused; vx->weight = wnew;
+  return 1;
 }
 
 /* ------------------------------------------------------------------ view calculation */
@@ -441,15 +478,7 @@ static void tsdf_integrate_block(const OrcParams* p, Block* b, const float* dept
       continue;
     }
     if (got <= 0) continue;
-    const float sdf = ds - vd;
-    if (sdf < -trunc) continue;
-    const float wm = weight_fn(p->weighting_mode, ds, vd, trunc);
-    const float wsum = wm + vx->weight;
-    if (!(wsum > 0.0f)) continue;
-    float fused = (sdf * wm + vx->distance * vx->weight) / wsum;
-    if (fused > 0.0f) fused = fminf(trunc, fused); else fused = fmaxf(-trunc, fused);
-    vx->distance = fused;
-    vx->weight = fminf(wsum, p->max_weight);
+    tsdf_fuse(p, vx, ds, vd, trunc, p->max_integration_distance_m);
   }
 }
 
@@ -576,7 +605,7 @@ int64_t orc_integrate_depth(OrcMap* m, const float* depth_in, int rows, int cols
   const float* depth = pre ? pre : depth_in;
   Rt T_L_C, T_C_L; rt_from_T(T_L_C16, &T_L_C, &T_C_L);
   Cam k = cam_from(cam6);
-  m->frame++;
+  m->frame++; m->camera_frame = m->frame;
   view_calc(m, depth, rows, cols, &T_L_C, &k);
   const int64_t n = m->n_view;
 #pragma omp parallel for schedule(dynamic, 8)
@@ -679,16 +708,7 @@ int64_t orc_integrate_lidar_depth(OrcMap* m, const float* range, int rows, int c
       float pc[3]; rt_apply(&T_C_L, voxel_center(b->idx.x, x, bs, vs), voxel_center(b->idx.y, y, bs, vs), voxel_center(b->idx.z, z, bs, vs), pc);
       float ds, vd;
       if (!lidar_sample(p, &tab, range, rows, cols, pc, max_dist, &ds, &vd)) continue;
-      const float sdf = ds - vd;
-      if (sdf < -trunc) continue;
-      TsdfVoxel* vx = &b->tsdf[z + 8 * y + 64 * x];
-      const float wm = weight_fn(p->weighting_mode, ds, vd, trunc);
-      const float wsum = wm + vx->weight;
-      if (!(wsum > 0.0f)) continue;
-      float fused = (sdf * wm + vx->distance * vx->weight) / wsum;
-      if (fused > 0.0f) fused = fminf(trunc, fused); else fused = fmaxf(-trunc, fused);
-      vx->distance = fused;
-      vx->weight = fminf(wsum, p->max_weight);
+      tsdf_fuse(p, &b->tsdf[z + 8 * y + 64 * x], ds, vd, trunc, max_dist);
     }
   }
   free(tab.el); free(tab.az);
@@ -912,7 +932,7 @@ int64_t orc_integrate_color(OrcMap* m, const uint8_t* rgb, int rows, int cols, c
       if (p->max_integration_distance_m > 0.0f && vd > p->max_integration_distance_m) continue;
       float sd;
       if (interp_depth(m->synth, m->synth_rows, m->synth_cols, u / (float)f, v / (float)f, 0, &sd) <= 0) continue;
-      if (fabsf(sd - vd) > trunc) continue;
+      if (fabsf(sd - vd) > (p->color_occlusion_threshold_vox < 0.0f ? trunc : p->color_occlusion_threshold_vox * vs)) continue;   /* [U] occlusion test */
       float c[3];
       if (!interp_color(rgb, rows, cols, u, v, c)) continue;
       ColorVoxel* cv = &b->color[z + 8 * y + 64 * x];
@@ -1057,6 +1077,72 @@ static int64_t update_esdf_3d(OrcMap* m) {
   return n_dirty;
 }
 
+/* [U] open choice esdf_propagation = 1: the reference's sweep / propagate loop restated as synchronous 4-neighbour parent
+ * propagation to its fixed point over the allocated ESDF blocks of the slice (a voxel learns of a site only through a chain
+ * of allocated axis neighbours); key = (sq, dy, dx) lexicographic = the exact transform's tie rule; cut-off max_sq; the whole
+ * slice is recomputed from its sites on every update.  Dense arrays over the blocks' AABB; `dom` = voxel belongs to a block. */
+static void esdf_propagate(OrcMap* m, const EsdfCfg* c, int32_t bz_out, int32_t vz_out) {
+  int32_t bx0 = INT32_MAX, bx1 = INT32_MIN, by0 = INT32_MAX, by1 = INT32_MIN;
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    if (!(b->flags & L_ESDF) || b->idx.z != bz_out) continue;
+    if (b->idx.x < bx0) bx0 = b->idx.x; if (b->idx.x > bx1) bx1 = b->idx.x;
+    if (b->idx.y < by0) by0 = b->idx.y; if (b->idx.y > by1) by1 = b->idx.y;
+  }
+  if (bx0 > bx1) return;
+  const int64_t W = (int64_t)(bx1 - bx0 + 1) * 8, H = (int64_t)(by1 - by0 + 1) * 8;
+  const int32_t NONE = INT32_MAX;
+  uint8_t* dom = (uint8_t*)calloc((size_t)(W * H), 1);
+  int32_t* cur = (int32_t*)malloc((size_t)(W * H) * sizeof(int32_t));
+  int32_t* nxt = (int32_t*)malloc((size_t)(W * H) * sizeof(int32_t));
+  for (int64_t i = 0; i < W * H; i++) cur[i] = NONE;
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    if (!(b->flags & L_ESDF) || b->idx.z != bz_out) continue;
+    for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) {
+      const int64_t g = ((int64_t)(b->idx.y - by0) * 8 + y) * W + (int64_t)(b->idx.x - bx0) * 8 + x;
+      dom[g] = 1;
+      if (b->esdf[vz_out + 8 * y + 64 * x].is_site) cur[g] = (64 << 7) | 64;
+    }
+  }
+  static const int OX[4] = {-1, 1, 0, 0}, OY[4] = {0, 0, -1, 1};
+  for (int round = 0; round < (1 << 14); round++) {
+    int changed = 0;
+#pragma omp parallel for reduction(|:changed)
+    for (int64_t y = 0; y < H; y++) for (int64_t x = 0; x < W; x++) {
+      const int64_t g = y * W + x;
+      if (!dom[g]) { nxt[g] = NONE; continue; }
+      int32_t best = cur[g];
+      for (int k = 0; k < 4; k++) {
+        const int64_t nx = x + OX[k], ny = y + OY[k];
+        if (nx < 0 || ny < 0 || nx >= W || ny >= H || !dom[ny * W + nx]) continue;
+        const int32_t nb = cur[ny * W + nx];
+        if (nb == NONE) continue;
+        const int32_t dx = (nb & 127) - 64 + OX[k], dy = ((nb >> 7) & 127) - 64 + OY[k];
+        const int32_t sq = dx * dx + dy * dy;
+        if (!((float)sq <= c->max_sq) || dx < -63 || dx > 63 || dy < -63 || dy > 63) continue;
+        const int32_t cand = (sq << 14) | ((dy + 64) << 7) | (dx + 64);
+        if (cand < best) best = cand;
+      }
+      nxt[g] = best;
+      if (best != cur[g]) changed = 1;
+    }
+    int32_t* t = cur; cur = nxt; nxt = t;
+    if (!changed) break;
+  }
+  for (int64_t q = 0; q < m->count; q++) {
+    Block* b = m->order[q];
+    if (!(b->flags & L_ESDF) || b->idx.z != bz_out) continue;
+    for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) {
+      const int32_t pk = cur[((int64_t)(b->idx.y - by0) * 8 + y) * W + (int64_t)(b->idx.x - bx0) * 8 + x];
+      EsdfVoxel* ev = &b->esdf[vz_out + 8 * y + 64 * x];
+      if (pk != NONE) { ev->sq = (float)(pk >> 14); ev->parent[0] = (pk & 127) - 64; ev->parent[1] = ((pk >> 7) & 127) - 64; ev->parent[2] = 0; }
+      else { ev->sq = c->max_sq; ev->parent[0] = 0; ev->parent[1] = 0; ev->parent[2] = 0; }
+    }
+  }
+  free(dom); free(cur); free(nxt);
+}
+
 int64_t orc_update_esdf(OrcMap* m) {
   if (m->p.esdf_mode == 1) return update_esdf_3d(m);
   const OrcParams* p = &m->p;
@@ -1103,6 +1189,7 @@ int64_t orc_update_esdf(OrcMap* m) {
     }
   }
   m->esdf_epoch++;
+  if (p->esdf_propagation == 1) { esdf_propagate(m, &c, bz_out, vz_out); return n_dirty; }
   /* 2. exact EDT over all ESDF blocks of the slice (the HIP path windows this; result identical) */
   int32_t bx0 = INT32_MAX, bx1 = INT32_MIN, by0 = INT32_MAX, by1 = INT32_MIN;
   for (int64_t q = 0; q < m->count; q++) {
@@ -1256,9 +1343,10 @@ static int mesh_block(OrcMap* m, Block* b) {
       if (d[li] < 0.0f) cube |= 1 << c;
     }
     if (!ok || cube == 0 || cube == 255) continue;
-    for (int t = 0; MC_TRI[cube][t] >= 0; t += 3) {
+    const int8_t* row = MC_TRI[p->mesh_ambiguity_rule][cube];
+    for (int t = 0; row[t] >= 0; t += 3) {
       for (int q = 0; q < 3; q++) {
-        const int e = MC_TRI[cube][t + q];
+        const int e = row[t + q];
         const int eid = (((x + MC_EDGE_BASE[e][0]) * L + (y + MC_EDGE_BASE[e][1])) * L + (z + MC_EDGE_BASE[e][2])) * 3 + MC_EDGE_AXIS[e];
         tri_edges[3 * ntri + q] = eid;
         if (edge_first_tri[eid] < 0) edge_first_tri[eid] = ntri;
@@ -1300,10 +1388,16 @@ static int mesh_block(OrcMap* m, Block* b) {
   for (int eid = 0; eid < 9 * 9 * 9 * 3; eid++) {
     const int32_t v = edge_vid[eid];
     if (v < 0) continue;
-    const int32_t t = edge_first_tri[eid];
-    const float* p0 = &mb->vert[3 * mb->tri[3 * t]]; const float* p1 = &mb->vert[3 * mb->tri[3 * t + 1]]; const float* p2 = &mb->vert[3 * mb->tri[3 * t + 2]];
-    const float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
-    float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    /* normal rule 0: the first triangle referencing the vertex; rule 1: sum of the unnormalised normals (= area-weighted mean) of
+     * every triangle of the block referencing it, ascending triangle index */
+    float n[3] = {0.0f, 0.0f, 0.0f};
+    const int32_t t_lo = p->mesh_normal_rule == 0 ? edge_first_tri[eid] : 0, t_hi = p->mesh_normal_rule == 0 ? edge_first_tri[eid] + 1 : ntri;
+    for (int32_t t = t_lo; t < t_hi; t++) {
+      if (p->mesh_normal_rule != 0 && mb->tri[3 * t] != v && mb->tri[3 * t + 1] != v && mb->tri[3 * t + 2] != v) continue;
+      const float* p0 = &mb->vert[3 * mb->tri[3 * t]]; const float* p1 = &mb->vert[3 * mb->tri[3 * t + 1]]; const float* p2 = &mb->vert[3 * mb->tri[3 * t + 2]];
+      const float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+      n[0] = n[0] + (e1[1] * e2[2] - e1[2] * e2[1]); n[1] = n[1] + (e1[2] * e2[0] - e1[0] * e2[2]); n[2] = n[2] + (e1[0] * e2[1] - e1[1] * e2[0]);
+    }
     const float len = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
     if (len > 0.0f) { n[0] = n[0] / len; n[1] = n[1] / len; n[2] = n[2] / len; }
     mb->nrm[3 * v] = n[0]; mb->nrm[3 * v + 1] = n[1]; mb->nrm[3 * v + 2] = n[2];
@@ -1340,6 +1434,10 @@ int orc_mesh_get(const OrcMap* m, int32_t x, int32_t y, int32_t z, float* vert, 
 }
 
 /* ------------------------------------------------------------------ decay / clearing */
+static void cleared_push(OrcMap* m, Idx3 i) {
+  if (m->n_cleared + 1 > m->cleared_cap) { m->cleared_cap = m->cleared_cap ? m->cleared_cap * 2 : 1024; m->cleared = (Idx3*)realloc(m->cleared, (size_t)m->cleared_cap * sizeof(Idx3)); }
+  m->cleared[m->n_cleared++] = i;
+}
 /* Mapper::decayTsdf restated (nvblox_node.cpp:931-936; params nvblox_base.yaml:103-107): weight *= factor for every
  * TSDF voxel of every block NOT in the last depth view; block deallocated when all weights < threshold. */
 int64_t orc_decay_tsdf(OrcMap* m, int exclude_last_view) {
@@ -1348,12 +1446,12 @@ int64_t orc_decay_tsdf(OrcMap* m, int exclude_last_view) {
   for (int64_t q = 0; q < m->count; q++) {
     Block* b = m->order[q];
     int drop = 0;
-    if ((b->flags & L_TSDF) && !(exclude_last_view && b->stamp_view == m->frame)) {
+    if ((b->flags & L_TSDF) && !(exclude_last_view && m->camera_frame > 0 && b->stamp_view == m->camera_frame)) {
       int alive = 0;
       for (int i = 0; i < NVOX; i++) { b->tsdf[i].weight = b->tsdf[i].weight * p->tsdf_decay_factor; if (!(b->tsdf[i].weight < p->tsdf_decayed_weight_threshold)) alive = 1; }
       b->dirty_esdf = 1; b->dirty_mesh = 1;
       if (!alive) {
-        drop = 1;
+        drop = 1; cleared_push(m, b->idx);
         const EsdfCfg ec = esdf_cfg(p);
         if (p->esdf_mode == 1) { if (b->flags & L_ESDF) b->remark_esdf = 1; }      /* 3-D: the block's own ESDF block */
         else if (b->idx.z >= floor_div8(ec.kz_min) && b->idx.z <= floor_div8(ec.kz_max)) {
@@ -1393,7 +1491,7 @@ int64_t orc_decay_occupancy(OrcMap* m) {
       }
       if (alive) b->dirty_esdf = 1;
       else {
-        drop = 1;
+        drop = 1; cleared_push(m, b->idx);
         const EsdfCfg ec = esdf_cfg(p);
         if (p->esdf_mode == 1) { if (b->flags & L_ESDF) b->remark_esdf = 1; }      /* 3-D: the block's own ESDF block */
         else if (b->idx.z >= floor_div8(ec.kz_min) && b->idx.z <= floor_div8(ec.kz_max)) {
@@ -1421,11 +1519,25 @@ int64_t orc_clear_outside_radius(OrcMap* m, const float* c, float r) {
     Block* b = m->order[q];
     float dx = ((float)b->idx.x * bs + bs * 0.5f) - c[0], dy = ((float)b->idx.y * bs + bs * 0.5f) - c[1], dz = ((float)b->idx.z * bs + bs * 0.5f) - c[2];
     float d2 = (dx * dx + dy * dy) + dz * dz;
-    if (d2 > r * r) { block_free(b); removed++; } else m->order[keep++] = b;
+    if (d2 > r * r) { if (b->flags & L_TSDF) cleared_push(m, b->idx); block_free(b); removed++; } else m->order[keep++] = b;
   }
   m->count = keep;
   if (removed) map_rebuild(m);
   return removed;
+}
+
+/* Mapper::getClearedBlocks restated at call-site level (layer_publishing.cpp:716): sorted unique indices, list emptied */
+static int idx_cmp(const void* a, const void* b);
+int64_t orc_take_cleared_blocks(OrcMap* m, int32_t* out, int64_t cap) {
+  qsort(m->cleared, (size_t)m->n_cleared, sizeof(Idx3), idx_cmp);
+  int64_t u = 0;
+  for (int64_t i = 0; i < m->n_cleared; i++) {
+    if (i > 0 && idx_cmp(&m->cleared[i], &m->cleared[i - 1]) == 0) continue;
+    if (u < cap) { out[3 * u] = m->cleared[i].x; out[3 * u + 1] = m->cleared[i].y; out[3 * u + 2] = m->cleared[i].z; }
+    u++;
+  }
+  m->n_cleared = 0;
+  return u;
 }
 
 /* Mapper::clearTsdfInsideShapes restated (nvblox_node.cpp:1834): voxels whose centre is inside a sphere / box are reset.

@@ -43,7 +43,7 @@ def compare_layer(M, g, o, layer_g, layer_o, fields_exact=(), fields_tol=(), lsb
     return len(io), worst
 
 
-@pytest.mark.parametrize("weighting_mode", [0, 4])
+@pytest.mark.parametrize("weighting_mode", [0, 1, 2, 3, 4, 5])     # all six WeightingFunctionType values (mapper_initialization.cpp:31-42)
 def test_tsdf_parity_small(oracle_mod, hip_lib, weighting_mode):
     M, g, o = make_pair(oracle_mod, weighting_mode=weighting_mode)
     for d, rgb, T in H.frames(6, H.SMALL_CAM, color=False, stride=7):

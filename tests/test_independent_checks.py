@@ -1,0 +1,198 @@
+"""Checks that do NOT share code with the product (CPU, no GPU, nothing from csrc/ imported or re-used):
+
+* the LiDAR projection the oracle takes from the product header csrc/nvbx_lidar_math.h (so HIP-vs-oracle parity compares that
+  code with itself) is restated here with numpy's arcsin / arctan2 in float64 exactly as the reference's own script does
+  (/root/reference/nvblox_ros/scripts/calculate_lidar_params.py:50-58: elevation = arcsin(z / r), azimuth = arctan2(y, x),
+  equal angular bins) -- pixel bins must agree on >= 10^5 random points away from bin edges, including the azimuth wrap;
+* the three generated marching-cubes tables are checked against brute-force sign topology: per case every triangle edge on a
+  cube face is a boundary edge (used once), every interior edge is shared by exactly two triangles with opposite direction
+  (closed, consistently oriented surface), the face boundary separates exactly the inside from the outside corners of that
+  face, the normals point to the positive side; rules 0 and 1 are crack-free across every shared face (all 4096 two-cube
+  sign configurations), rule 2 (the classic table's complement symmetry) is not -- the known defect.
+"""
+import itertools
+
+import numpy as np
+
+import oracle
+
+CORNERS = np.array([(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)], float)
+EDGES = [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)]
+
+
+# ------------------------------------------------------------------------------------------------ LiDAR projection
+def numpy_lidar_pixel(lidar, pts):
+    """Pixel (row, col) of each point and its distance to the nearest bin edge (in pixels), float64, libm."""
+    cols, rows, min_range, min_el, max_el = lidar
+    r = np.linalg.norm(pts, axis=1)
+    el = np.arcsin(np.clip(pts[:, 2] / r, -1.0, 1.0))
+    az = np.arctan2(pts[:, 1], pts[:, 0])
+    rpp_el = (max_el - min_el) / (rows - 1); rpp_az = 2.0 * np.pi / cols
+    # beam (k, j) through the pixel centre (j + 0.5, k + 0.5): corner-referenced coordinates
+    u = (az + np.pi) / rpp_az + 0.5
+    v = (max_el - el) / rpp_el + 0.5
+    u = np.where(u >= cols, u - cols, u)
+    inside = (v >= 0) & (v < rows) & (r >= min_range)
+    margin = np.minimum(np.abs(u - np.round(u)), np.abs(v - np.round(v)))
+    return np.floor(v).astype(int), np.floor(u).astype(int), inside, margin
+
+
+def test_lidar_projection_against_numpy_restatement():
+    rng = np.random.default_rng(3)
+    for lidar in [(1024, 64, 0.1, -np.deg2rad(22.5), np.deg2rad(22.5)), (512, 16, 0.5, -np.deg2rad(15.0), np.deg2rad(10.0)),
+                  (2048, 128, 0.1, -np.deg2rad(45.0), np.deg2rad(45.0))]:
+        n = 200000
+        el = rng.uniform(lidar[3] - 0.08, lidar[4] + 0.08, n); az = rng.uniform(-np.pi, np.pi, n)     # the field of view + a rim outside it
+        d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], 1)
+        pts = (d * rng.uniform(0.2, 180.0, (n, 1))).astype(np.float32)
+        # force a share of the points onto the azimuth seam (y ~ 0, x < 0) and the axes
+        pts[:2000, 1] = rng.normal(0.0, 1e-3, 2000).astype(np.float32); pts[:2000, 0] = -np.abs(pts[:2000, 0])
+        pts[2000:2200, 0] = 0.0; pts[2200:2400, 1] = 0.0
+        row, col, inside, margin = numpy_lidar_pixel(lidar, pts.astype(np.float64))
+        checked = 0
+        for i in range(n):
+            if margin[i] < 2e-3:             # the polynomial atan2 of the product differs from libm by < 2e-7 rad = ~1e-4 px here
+                continue
+            got = oracle.lidar_project(lidar, pts[i])
+            if not inside[i]:
+                # outside the vertical field of view (with margin): the product must reject it too
+                if np.abs(np.arcsin(np.clip(pts[i, 2] / np.linalg.norm(pts[i]), -1, 1))) > max(abs(lidar[3]), abs(lidar[4])) + 0.01:
+                    assert got is None
+                continue
+            assert got is not None, (lidar, pts[i])
+            assert (int(np.floor(got[1])), int(np.floor(got[0]))) == (row[i], col[i]), (lidar, pts[i], got, row[i], col[i])
+            checked += 1
+        assert checked >= 100000, checked
+
+
+def test_lidar_beam_through_pixel_centre_round_trip():
+    """Independent of the projection code: the direction of beam (k, j) built with numpy sin / cos projects to (j + .5, k + .5)."""
+    lidar = (1024, 64, 0.1, -np.deg2rad(22.5), np.deg2rad(22.5))
+    cols, rows, _, min_el, max_el = lidar
+    for k in (0, 1, 31, 62, 63):
+        for j in (0, 1, 511, 512, 1023):
+            el = max_el - k * (max_el - min_el) / (rows - 1); az = -np.pi + j * 2 * np.pi / cols
+            p = 17.0 * np.array([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
+            u, v = oracle.lidar_project(lidar, p.astype(np.float32))
+            assert abs(u - (j + 0.5)) < 2e-3 and abs(v - (k + 0.5)) < 2e-3, (k, j, u, v)
+
+
+# ------------------------------------------------------------------------------------------------ marching cubes
+def load_table(name):
+    rows = []
+    for line in open(name):
+        line = line.strip()
+        if line.startswith("{"):
+            rows.append([int(x) for x in line.strip("{},").split(",")])
+    assert len(rows) == 256
+    return [[tuple(r[3 * t:3 * t + 3]) for t in range(5) if r[3 * t] >= 0] for r in rows]
+
+
+def tables():
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "isaac_ros_nvblox_amd", "csrc")
+    return [load_table(os.path.join(d, n)) for n in ("mc_table.inc", "mc_table_r1.inc", "mc_table_r2.inc")]
+
+
+def edge_faces(e):
+    """Cube faces (axis, side) that contain lattice edge e."""
+    a, b = CORNERS[EDGES[e][0]], CORNERS[EDGES[e][1]]
+    return {(ax, int(a[ax])) for ax in range(3) if a[ax] == b[ax]}
+
+
+def edge_mid(e):
+    return 0.5 * (CORNERS[EDGES[e][0]] + CORNERS[EDGES[e][1]])
+
+
+def face_segments(tris):
+    """Directed triangle edges that lie in a cube face -> {face: [(e_from, e_to), ...]}; interior edges -> directed-use counter."""
+    on_face, interior = {}, {}
+    for t in tris:
+        for k in range(3):
+            a, b = t[k], t[(k + 1) % 3]
+            common = edge_faces(a) & edge_faces(b)
+            if common:
+                assert len(common) == 1
+                on_face.setdefault(next(iter(common)), []).append((a, b))
+            else:
+                interior[(a, b)] = interior.get((a, b), 0) + 1
+    return on_face, interior
+
+
+def test_marching_cubes_tables_against_brute_force_topology():
+    for rule, table in enumerate(tables()):
+        for case in range(256):
+            inside = [(case >> i) & 1 for i in range(8)]
+            tris = table[case]
+            crossed = {e for e, (a, b) in enumerate(EDGES) if inside[a] != inside[b]}
+            used = {e for t in tris for e in t}
+            assert used == crossed, (rule, case)                       # a vertex on exactly the sign-changing edges
+            on_face, interior = face_segments(tris)
+            # closed, consistently oriented: every interior edge is used once in each direction
+            for (a, b), n in interior.items():
+                assert n == 1 and interior.get((b, a), 0) == 1, (rule, case, a, b)
+            for face, segs_all in on_face.items():
+                ax, side = face
+                # (a fan triangulation may put a diagonal -- even a whole flat triangle -- into the face plane: a segment used in
+                #  both directions is such a diagonal, not part of the surface's boundary on the face)
+                segs = [sg for sg in segs_all if (sg[1], sg[0]) not in segs_all]
+                fc = [i for i in range(8) if CORNERS[i][ax] == side]
+                n_in = sum(inside[i] for i in fc)
+                assert len(segs) == len(set(segs))                     # boundary edges are used once
+                # the boundary on a face has one segment per pair of crossings: 1 (two crossings) or 2 (ambiguous face)
+                n_cross = sum(1 for e in crossed if face in edge_faces(e))
+                assert len(segs) == n_cross // 2 and n_in not in (0, 4), (rule, case, face)
+            # orientation: normals point from the inside (negative) corners to the outside
+            for t in tris:
+                p = [edge_mid(e) for e in t]
+                nrm = np.cross(p[1] - p[0], p[2] - p[0])
+                if np.linalg.norm(nrm) < 1e-12:
+                    continue
+                c = sum(p) / 3.0
+                # the nearest corner along -normal is inside, along +normal outside (test with the signed corner distances)
+                sd = [(np.dot(CORNERS[i] - c, nrm), inside[i]) for i in range(8)]
+                neg = [ins for s, ins in sd if s < -1e-9]; pos = [ins for s, ins in sd if s > 1e-9]
+                assert (not neg or any(neg)) and (not pos or not all(pos)), (rule, case, t)
+
+
+def shared_face_segments(table, case, ax, side):
+    """Undirected boundary segments of `case` on face (ax, side), as frozensets of edge mid-points projected onto the face."""
+    on_face, _ = face_segments(table[case])
+    out = set()
+    segs_all = on_face.get((ax, side), [])
+    for a, b in [sg for sg in segs_all if (sg[1], sg[0]) not in segs_all]:
+        pa, pb = np.delete(edge_mid(a), ax), np.delete(edge_mid(b), ax)
+        out.add(frozenset([tuple(pa), tuple(pb)]))
+    return out
+
+
+def test_marching_cubes_rules_0_and_1_are_crack_free_rule_2_is_not():
+    t = tables()
+    cracks = [0, 0, 0]
+    # two cubes sharing the x face: cube A corners + cube B corners = 12 lattice points, B's x=0 face = A's x=1 face
+    a_face = [i for i in range(8) if CORNERS[i][0] == 1]; b_face = [i for i in range(8) if CORNERS[i][0] == 0]
+    pair = {ia: ib for ia in a_face for ib in b_face if tuple(CORNERS[ia][1:]) == tuple(CORNERS[ib][1:])}
+    for bits in itertools.product((0, 1), repeat=12):
+        sa = list(bits[:8])
+        sb = [0] * 8
+        free = iter(bits[8:])
+        for ib in range(8):
+            if ib in b_face:
+                ia = [k for k, v in pair.items() if v == ib][0]
+                sb[ib] = sa[ia]
+            else:
+                sb[ib] = next(free)
+        ca = sum(v << i for i, v in enumerate(sa)); cb = sum(v << i for i, v in enumerate(sb))
+        for rule in range(3):
+            if shared_face_segments(t[rule], ca, 0, 1) != shared_face_segments(t[rule], cb, 0, 0):
+                cracks[rule] += 1
+    assert cracks[0] == 0 and cracks[1] == 0, cracks
+    assert cracks[2] > 0, cracks          # complement-symmetric tables disagree on ambiguous faces: the classic table's cracks
+
+
+def test_oracle_and_product_tables_are_the_same_files():
+    """(both trees are written by tools/gen_mc_table.py; the checks above are what makes the content trustworthy)"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for n in ("mc_table.inc", "mc_table_r1.inc", "mc_table_r2.inc"):
+        assert open(os.path.join(root, "oracle", n)).read() == open(os.path.join(root, "isaac_ros_nvblox_amd", "csrc", n)).read()

@@ -5,9 +5,16 @@ No table is copied from anywhere: for every corner-sign configuration the
 iso-surface polygons are found by tracing directed segments over the six cube
 faces (inside region kept on the left when the face is seen from outside the
 cube), chaining them into closed loops and fan-triangulating each loop.  The
-ambiguous face (two diagonal inside corners) is always resolved by cutting off
-each inside corner separately; the rule depends only on the four face-corner
-signs, so two cubes sharing a face always agree and the mesh is crack free.
+ambiguous face (two diagonal inside corners) is resolved by a RULE that depends
+only on the four face-corner signs, so two cubes sharing a face always agree
+and the mesh is crack free:
+  rule 0 (mc_table.inc)    each inside corner is cut off separately
+  rule 1 (mc_table_r1.inc) each outside corner is cut off separately (inside corners joined)
+A third table reproduces the behaviour of the classic published table, which is
+complement-symmetric instead of face-consistent (and therefore can crack):
+  rule 2 (mc_table_r2.inc) rule 0 for cases with <= 4 inside corners, else rule 1
+(nvbx_mapper_params::mesh_ambiguity_rule; [U] which of these the reference's
+table implements cannot be read off /root/reference -- the core is absent.)
 
 Corner i is "inside" when bit i of the case index is set (distance < 0).
 Triangles are wound so that their normal points to the positive-distance
@@ -41,7 +48,7 @@ def directed(ea, eb, p_in, n):
     left = np.dot(np.cross(np.array(n,float), d), p_in-mid(ea))
     return (ea,eb) if left > 0 else (eb,ea)
 
-def case_loops(case):
+def case_loops(case, rule=0):
     inside = [(case>>i)&1 for i in range(8)]
     nxt = {}
     for cyc,n in FACES:
@@ -58,10 +65,18 @@ def case_loops(case):
             segs.append((cross[0],cross[1],CORNERS[ins[0]]))
         else:  # 4 crossings: diagonal inside corners, cut each off separately
             assert len(cross)==4 and len(ins)==2
-            for c in ins:
-                k = cyc.index(c)
-                e1 = EDGE_ID[(cyc[(k-1)%4],c)]; e2 = EDGE_ID[(c,cyc[(k+1)%4])]
-                segs.append((e1,e2,CORNERS[c]))
+            if rule == 0:
+                for c in ins:
+                    k = cyc.index(c)
+                    e1 = EDGE_ID[(cyc[(k-1)%4],c)]; e2 = EDGE_ID[(c,cyc[(k+1)%4])]
+                    segs.append((e1,e2,CORNERS[c]))
+            else:      # cut off each OUTSIDE corner: the inside region (it contains the face centre) joins the two inside corners
+                centre = sum(CORNERS[c] for c in cyc) / 4.0
+                for c in cyc:
+                    if inside[c]: continue
+                    k = cyc.index(c)
+                    e1 = EDGE_ID[(cyc[(k-1)%4],c)]; e2 = EDGE_ID[(c,cyc[(k+1)%4])]
+                    segs.append((e1,e2,centre))
         for ea,eb,p in segs:
             f,t = directed(ea,eb,p,n)
             assert f not in nxt, "edge has two outgoing segments"
@@ -79,13 +94,13 @@ def case_loops(case):
     assert len(seen) == len(nxt)
     return loops
 
-def build():
+def build(rule=0):
     # decide global winding with case 1 (corner 0 inside): normal must point away from corner 0
     table = []
     flip = None
     for case in range(256):
         tris = []
-        for loop in case_loops(case):
+        for loop in case_loops(case, rule):
             assert len(loop) >= 3
             for k in range(1,len(loop)-1):
                 tris.append((loop[0],loop[k],loop[k+1]))
@@ -101,24 +116,31 @@ def build():
         assert len(table[case]) <= 5, (case, len(table[case]))
     return table
 
-def main():
-    table = build()
-    ntri = [len(t) for t in table]
+def emit(table, title):
     lines = []
-    lines.append("/* GENERATED by tools/gen_mc_table.py -- do not edit. 256 x 16 edge ids, -1 terminated. */")
+    lines.append("/* GENERATED by tools/gen_mc_table.py -- do not edit. 256 x 16 edge ids, -1 terminated. %s */" % title)
     lines.append("/* corners: 0:(0,0,0) 1:(1,0,0) 2:(1,1,0) 3:(0,1,0) 4:(0,0,1) 5:(1,0,1) 6:(1,1,1) 7:(0,1,1) */")
     lines.append("/* edges: 0:0-1 1:1-2 2:2-3 3:3-0 4:4-5 5:5-6 6:6-7 7:7-4 8:0-4 9:1-5 10:2-6 11:3-7 */")
     for case,tris in enumerate(table):
         flat = [e for t in tris for e in t]
         flat += [-1]*(16-len(flat))
         lines.append("{" + ",".join("%2d"%v for v in flat) + "},")
-    txt = "\n".join(lines)+"\n"
+    return "\n".join(lines)+"\n"
+
+def main():
     import os
+    t0 = build(0); t1 = build(1)
+    t2 = [t0[c] if bin(c).count("1") <= 4 else t1[c] for c in range(256)]
+    texts = {"mc_table.inc": emit(t0, "rule 0"), "mc_table_r1.inc": emit(t1, "rule 1"), "mc_table_r2.inc": emit(t2, "rule 2")}
+    # arguments: the rule-0 file of every tree (oracle/mc_table.inc, csrc/mc_table.inc); the other rules go beside it
     for p in sys.argv[1:]:
-        if os.path.exists(p) and open(p).read() == txt:
-            continue          # keep mtimes stable so make does not rebuild
-        open(p,"w").write(txt)
-    print("max tris", max(ntri), "total", sum(ntri))
+        d = os.path.dirname(p)
+        for name, txt in texts.items():
+            q = os.path.join(d, name)
+            if os.path.exists(q) and open(q).read() == txt:
+                continue          # keep mtimes stable so make does not rebuild
+            open(q,"w").write(txt)
+    print("max tris", max(len(t) for t in t0 + t1 + t2), "total", sum(len(t) for t in t0), sum(len(t) for t in t1), sum(len(t) for t in t2))
 
 if __name__ == "__main__":
     main()
