@@ -166,6 +166,14 @@ struct MapperParams {
             N("check_neighborhood", fs.check_neighborhood), N("initialize_to_high_confidence_freespace", fs.initialize_to_high_confidence_freespace)})});
   }
 
+  // [U] open choices of libnvblox_hip (include/nvblox_hip.h): not reference parameters -- the switches that pin this
+  // implementation to the real nvblox core once its source can be read; defaults = the documented behaviour
+  struct HipOpenChoices {
+    int tsdf_weighting_variant = 0, tsdf_skip_at_negative_truncation = 0, tsdf_weight_clamp_before_blend = 0;
+    float color_occlusion_threshold_vox = -1.0f;
+    int esdf_propagation = 0, mesh_ambiguity_rule = 0, mesh_normal_rule = 0, esdf_site_rule = 0, depth_interp_nearest = 0;
+  } hip_open_choices;
+
   // what libnvblox_hip consumes
   nvbx_mapper_params toCAbi(float voxel_size, ProjectiveLayerType layer_type = ProjectiveLayerType::kTsdf, EsdfMode esdf_mode = EsdfMode::k2D) const {
     // switches libnvblox_hip does not provide are refused loudly, never ignored (the reference CHECK-fails on
@@ -176,7 +184,8 @@ struct MapperParams {
                            "decay_integrator_deallocate_decayed_blocks = false are not provided by libnvblox_hip\n");
       std::abort();
     }
-    nvbx_mapper_params p{};
+    nvbx_mapper_params p;
+    nvbx_default_params(&p);      // every field this function does not set keeps the library default (incl. the [U] open-choice switches)
     p.voxel_size = voxel_size;
     p.esdf_mode = esdf_mode == EsdfMode::k3D ? 1 : 0;
     p.projective_layer_type = layer_type == ProjectiveLayerType::kOccupancy ? 1 : (layer_type == ProjectiveLayerType::kTsdfWithFreespace ? 2 : 0);
@@ -209,7 +218,6 @@ struct MapperParams {
     p.sphere_tracing_max_ray_length_m = 15.0f; p.sphere_tracing_surface_eps_vox = 0.1f;
     p.tsdf_decay_factor = tsdf_decay_integrator_params.tsdf_decay_factor;
     p.tsdf_decayed_weight_threshold = tsdf_decay_integrator_params.tsdf_decayed_weight_threshold;
-    p.esdf_site_rule = 0; p.depth_interp_nearest = 0;
     p.lidar_max_integration_distance_m = projective_integrator_params.lidar_projective_integrator_max_integration_distance_m;
     p.lidar_linear_interpolation_max_allowable_difference_vox = 2.0f;
     p.lidar_nearest_interpolation_max_allowable_dist_to_ray_vox = 0.5f;
@@ -220,6 +228,10 @@ struct MapperParams {
     p.workspace_bounds_min_corner_m[2] = view_calculator_params.workspace_bounds_min_height_m;
     p.workspace_bounds_max_corner_m[0] = view_calculator_params.workspace_bounds_max_corner_x_m; p.workspace_bounds_max_corner_m[1] = view_calculator_params.workspace_bounds_max_corner_y_m;
     p.workspace_bounds_max_corner_m[2] = view_calculator_params.workspace_bounds_max_height_m;
+    p.tsdf_weighting_variant = hip_open_choices.tsdf_weighting_variant; p.tsdf_skip_at_negative_truncation = hip_open_choices.tsdf_skip_at_negative_truncation;
+    p.tsdf_weight_clamp_before_blend = hip_open_choices.tsdf_weight_clamp_before_blend; p.color_occlusion_threshold_vox = hip_open_choices.color_occlusion_threshold_vox;
+    p.esdf_propagation = hip_open_choices.esdf_propagation; p.mesh_ambiguity_rule = hip_open_choices.mesh_ambiguity_rule; p.mesh_normal_rule = hip_open_choices.mesh_normal_rule;
+    p.esdf_site_rule = hip_open_choices.esdf_site_rule; p.depth_interp_nearest = hip_open_choices.depth_interp_nearest;
     return p;
   }
 };
