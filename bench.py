@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- ms/frame and frames/s of the TSDF + Color + ESDF hot path (mesh timed beside it) on MI355X.
+"""bench.py -- throughput of the nvblox hot path on MI355X, one JSON line per run (rank 0).
 
-Workload (BASELINE.json configs[1], SURVEY.md 8d [D]): synthetic Replica-like room, 640x480 depth + colour, 0.05 m voxels,
-fuser.yaml integrator parameters, camera on the circle trajectory; ESDF updated every frame (worst case).  A "step" is
-one frame: integrateDepth + integrateColor + updateEsdf, inputs already resident in HBM.  N > 1: one camera per GPU
-(45 degree yaw offsets on the same rig, config 4), block-index all-gather over RCCL before every ESDF sweep, weak scaling.
+Workloads (BASELINE.json `configs`; synthetic stand-ins of SURVEY.md 8d [D] -- no dataset on disk, no network):
+  camera   configs[1], the metric's configuration (default): Replica-like room, 640x480 depth + colour, 0.05 m voxels, fuser.yaml
+           parameters; step = integrateDepth + integrateColor + updateEsdf of one frame, inputs resident in HBM.  N > 1 GPUs: one
+           camera per GPU (45 deg yaw offsets, configs[3]), all-gather of dirty block indices over RCCL before every ESDF sweep.
+  multicam configs[3] on ONE GPU, --cameras C (1..8): the reference's own multi-camera mode (<= 4 cameras feed one mapper,
+           nvblox_node.hpp:298-332); step = C depth frames + C colour frames + one ESDF update; value = camera-frames/s.
+  decay    configs[2]: Redwood-like room with a moving box, MappingType::kDynamic: freespace layer + dynamics detection + mask
+           clean-up + occupancy mapper for the dynamic part, invalid_depth_decay 0.8, TSDF / occupancy decay every 6th frame.
+  lidar    configs[4]: 1024x64 spinning LiDAR, 0.10 m voxels, 200 m; step = one scan.  N > 1 GPUs: azimuth sectors.
 
-Prints ONE JSON line (rank 0).  `value` = frames/s of the whole job (all ranks' frames / max-over-ranks time).
+Timing: W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both sides (max over ranks);
+blocks are repeated until >= 50 ms have been timed (`repeats`), `ms_per_step` / `value` come from the MEDIAN block.
+`roofline` is quoted for the LONGEST kernel of the step (by time); the kernel with the most bytes is listed beside it.
 """
 import argparse
 import json
+import math
 import os
+import re
 import sys
 import time
 
@@ -20,110 +29,161 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-README_RTX5090_MS = {"tsdf": 0.1, "color": 0.3, "esdf": 0.3, "mesh": 0.3}   # /root/reference README.md:69-97 (Replica)
+README_RTX5090_MS = {"tsdf": 0.1, "color": 0.3, "esdf": 0.3, "mesh": 0.3, "dynamics": 0.7}   # /root/reference README.md:69-106 (Replica)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+MIN_TIMED_MS = 50.0
 
 
-def algorithmic_bytes(kernel, c, rows, cols):
-    """SURVEY.md 8(d) per-frame algorithmic bytes of one launch of `kernel`, from the measured per-frame counts."""
+def short(name):
+    m = re.match(r"\s*(?:void\s+)?(k_[a-z_0-9]+)", name)
+    return m.group(1) if m else name.strip()
+
+
+def algorithmic_bytes(kernel, c, rows, cols, sub_ray=4, sub_trace=4, n_cam=1):
+    """SURVEY.md 8(d) algorithmic bytes of ONE launch of `kernel`, from the measured per-launch counts `c`."""
     B = 4096
-    Nv, Nc, Na = c["tsdf_blocks_in_view"], c["color_blocks_updated"], c["blocks_allocated"]
-    Nu, Ne, Wv = c["esdf_columns_marked"], c["esdf_blocks_swept"], c["esdf_window_voxels"]
+    Nv, Nc, Na = c.get("tsdf_blocks_in_view", 0), c.get("color_blocks_updated", 0), c.get("blocks_allocated", 0)
+    Nu, Ne = c.get("esdf_columns_marked", 0), c.get("esdf_blocks_swept", 0)
     if kernel.startswith("k_integrate_tsdf"):
-        return rows * cols * 4 + Nv * (12 + 8) + Nv * B * 2
+        return n_cam * rows * cols * 4 + Nv * (12 + 8) + Nv * B * 2
     if kernel.startswith("k_mark_view"):
-        return (rows // 4) * (cols // 4) * 4 + Nv * 16 * 2          # sub-sampled depth read + one hash entry RMW per block in view
+        return n_cam * (rows // sub_ray) * (cols // sub_ray) * 4 + Nv * 16 * 2          # sub-sampled depth read + one hash entry RMW per block in view
     if kernel.startswith("k_integrate_color"):
-        # SURVEY 8(d) bytes_color minus the sphere tracer's share: colour image + synthetic depth read + TSDF of the band blocks
-        # + colour RMW of the band blocks, plus the ESDF site marking that rides in the same launch (bytes_esdf's first term:
-        # TSDF z-band of the re-marked columns read; slice plane masks written).  (The kernel itself no longer reads the TSDF for
-        # the band vote -- an exact per-block flag kept by the TSDF writers decides it -- so its traffic is below this figure.)
-        return rows * cols * 3 + (rows // 4) * (cols // 4) * 4 + Nc * B + Nc * B * 2 + Nu * 2 * B + Nu * 520
+        # colour image + synthetic depth read + colour RMW of the band blocks (the band vote is a per-block flag: no TSDF read),
+        # plus the ESDF site marking that rides in the same launch (TSDF z-band of the re-marked columns read, masks written)
+        return n_cam * (rows * cols * 3 + (rows // sub_trace) * (cols // sub_trace) * 4) + Nc * B * 2 + Nu * 2 * B + Nu * 24
     if kernel.startswith("k_sphere_trace"):
-        return (rows // 4) * (cols // 4) * 4 + Nc * B                # synthetic depth write + TSDF blocks read once
+        return n_cam * (rows // sub_trace) * (cols // sub_trace) * 4 + Nc * B           # synthetic depth write + TSDF blocks read once
     if kernel.startswith("k_esdf_mark"):
-        return Nu * 2 * B + Nu * 512 + Nu * 8                       # TSDF z-band (k_z = 2 blocks) read + slice plane + site mask written
+        return Nu * 2 * B + Nu * 24                                  # TSDF z-band (k_z = 2 blocks) read + three mask words written
     if kernel.startswith("k_esdf_edt"):
-        return Ne * (512 * 2 + 121 * (16 + 8))                      # plane RMW + 11x11 neighbour hash entries and site masks per swept block
+        return Ne * (512 * 2 + 121 * (16 + 8))                       # plane RMW + 11x11 neighbour hash entries and site masks per swept block
     if kernel.startswith("k_mesh"):
-        return int(c["mesh_blocks_updated"] * B * (1.42 + 1.0) + c["mesh_vertices"] * 28 + c["mesh_triangles"] * 12)
+        return int(c.get("mesh_blocks_updated", 0) * B * (1.42 + 1.0) + c.get("mesh_vertices", 0) * 28 + c.get("mesh_triangles", 0) * 12)
+    if kernel.startswith("k_decay"):
+        return Na * (B * 2 + 16)                                     # every projective voxel read + written, flags
+    if kernel.startswith("k_update_freespace"):
+        return Nv * (B + 2 * 512 * 16)                               # TSDF read, freespace voxels (16 B) read + written
+    if kernel.startswith("k_detect_dynamics") or kernel.startswith("k_split_depth") or kernel.startswith("k_mask_zmin"):
+        return rows * cols * (4 + 4 + 1)
+    if kernel.startswith("k_cc_"):
+        return rows * cols * 8
+    if kernel.startswith("k_save_stamps") or kernel.startswith("k_reinsert"):
+        return Na * 32
     return 0
 
 
-def main_lidar(args):
-    """configs[4]: one step = integrateDepth of one 1024x64 LiDAR scan (range image resident in HBM), 0.10 m voxels, 200 m."""
-    import torch
-    from isaac_ros_nvblox_amd import mapper as M, synthetic as S
-    assert args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1, "the LiDAR workload line is single-GPU"
-    dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
-    lidar = S.SPINNING_LIDAR
-    sc = S.LidarScene()
-    nu = max(2, min(args.unique_frames, 16))
-    scans = []
-    for i in range(nu):
-        T = S.lidar_pose(i, 400)
-        scans.append((torch.from_numpy(S.render_lidar(sc, T, lidar, max_range=200.0)).to(dev), T))
-    stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream)
-    p = M.default_params(voxel_size=0.1, lidar_max_integration_distance_m=200.0, raycast_subsampling_factor=2)
-    g = M.Mapper(p, device=0, block_capacity=1 << 19, stream=stream.cuda_stream)
-    largs = [g.prepare_lidar(r, T, lidar) for r, T in scans]
-    for i in range(args.warmup):
-        g.integrate_prepared(largs[i % nu])
-    torch.cuda.synchronize(dev); t0 = time.perf_counter()
-    for i in range(args.steps):
-        g.integrate_prepared(largs[(args.warmup + i) % nu])
-    torch.cuda.synchronize(dev); dt = time.perf_counter() - t0
-    ms = dt / args.steps * 1e3
-    g.set_profiling(True)
-    nv = []
-    for i in range(min(args.steps, 40)):
-        g.integrate_prepared(largs[i % nu]); nv.append(g.counters()["tsdf_blocks_in_view"])
-    prof = g.profile(); g.set_profiling(False)
-    c = g.counters(); Nv = float(np.mean(nv))
+def load_pmc(workload):
+    """HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_round.sh, tools/summarize_profile.py)."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        pmc = json.load(open(path))
+    except Exception:
+        return {}
+    if workload in pmc and isinstance(pmc[workload], dict) and not any(k.startswith("FETCH") for k in pmc[workload]):
+        return pmc[workload]
+    return pmc if workload == "camera" else {}
+
+
+class Timer:
+    """Blocks of exactly `steps` steps; each block bracketed by barrier(); max over ranks; repeated until MIN_TIMED_MS."""
+
+    def __init__(self, torch, dist, dev, world):
+        self.torch, self.dist, self.dev, self.world = torch, dist, dev, world
+
+    def block(self, run, barrier, steps, first):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            run(first + i)
+        barrier()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            tt = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    def run(self, run, barrier, steps, warmup, min_ms=MIN_TIMED_MS, max_repeats=400):
+        for i in range(warmup):
+            run(i)
+        dts = []
+        first = warmup
+        while True:
+            dts.append(self.block(run, barrier, steps, first)); first += steps
+            if (sum(dts) * 1e3 >= min_ms and len(dts) >= 3) or len(dts) >= max_repeats:     # (same decision on every rank: dt is all-reduced)
+                break
+        return float(np.median(dts)), dts, first
+
+
+def kernel_table(prof, counts, ms_per_step, n_steps, bytes_fn, pmc, exclude_from_calibration=("k_mesh",)):
+    """hipEvent spans per launch -> {kernel: avg_us, launches_per_step, algorithmic bytes, achieved GB/s, PMC traffic}.
+    A hipEvent pair around ONE launch adds its own cost to the span; calibration: the launches of the timed step must add up to the
+    un-instrumented step time, the excess is split evenly over them."""
+    ev_pair = prof.pop("_empty_event_pair", None)
+    empty_pair_us = (ev_pair["total_ms"] / ev_pair["count"] * 1e3) if ev_pair else 0.0
+    in_step = [k for k in prof if not short(k).startswith(exclude_from_calibration)]
+    raw_sum_us = sum(prof[k]["total_ms"] / n_steps * 1e3 for k in in_step)
+    n_launch = sum(prof[k]["count"] / n_steps for k in in_step)
+    ev_overhead_us = max(0.0, (raw_sum_us - ms_per_step * 1e3) / max(1.0, n_launch))
     kern = {}
-    prof.pop("_empty_event_pair", None)
-    raw_sum_us = sum(v_["total_ms"] / v_["count"] * 1e3 for v_ in prof.values())
-    ev_overhead_us = max(0.0, (raw_sum_us - ms * 1e3) / max(1, len(prof)))     # launches must add up to the un-instrumented scan time
-    for k_, v_ in prof.items():
-        us = max(0.1, v_["total_ms"] / v_["count"] * 1e3 - ev_overhead_us)
-        name = "k_integrate_tsdf" if "integrate" in k_ else "k_mark_view"
-        ab = (64 * 1024 * 4 + Nv * (16 + 4096 * 2)) if name == "k_integrate_tsdf" else (32 * 512 * 4 + Nv * 16 * 2)
-        kern[name] = {"avg_us": round(us, 2), "algorithmic_bytes": int(ab), "achieved_GBps": round(ab / (us * 1e-6) / 1e9, 1)}
-    dom = max(kern, key=lambda k_: kern[k_]["avg_us"])
-    out = {"metric": "scans/s, LiDAR projective TSDF integrate, synthetic 1024x64 @0.10m, 200 m", "value": round(args.steps / dt, 2),
-           "unit": "scans/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "configs[4]: synthetic 1024x64 spinning LiDAR (SURVEY 8d), 0.10 m voxels, 200 m range, ray subsampling 2"},
-           "per_scan_counts": {"tsdf_blocks_in_view": round(Nv, 1), "blocks_allocated": c["blocks_allocated"], "capacity_overflow": c["capacity_overflow"]},
-           "kernels": kern,
-           "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(kern[dom]["achieved_GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
-                        "algorithmic_bytes_per_launch": kern[dom]["algorithmic_bytes"], "avg_launch_us": kern[dom]["avg_us"]},
-           "cpu_baseline": None}
-    print(json.dumps(out))
+    for k, v in prof.items():
+        us = max(0.1, v["total_ms"] / v["count"] * 1e3 - ev_overhead_us)
+        ab = bytes_fn(short(k), counts)
+        name = short(k)
+        if name in kern:       # template instances of one kernel (e.g. two depth sources): merge
+            o = kern[name]; n0, n1 = o["launches_per_step"], v["count"] / n_steps
+            o["avg_us"] = (o["avg_us"] * n0 + us * n1) / (n0 + n1); o["launches_per_step"] = n0 + n1
+            continue
+        kern[name] = {"avg_us": us, "launches_per_step": v["count"] / n_steps, "algorithmic_bytes": int(ab),
+                      "achieved_GBps": (ab / (us * 1e-6) / 1e9) if us > 0 else 0.0,
+                      "hbm_traffic_bytes": pmc.get(name, {}).get("hbm_bytes_per_launch")}
+    return kern, ev_overhead_us, empty_pair_us
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--unique-frames", type=int, default=50, help="distinct rendered frames cycled through (HBM-resident)")
-    ap.add_argument("--cpu-frames", type=int, default=48, help="minimum number of frames of the same workload timed on the CPU oracle")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline keeps integrating (cycling the same frames) until this much CPU wall time has passed")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="camera", choices=["camera", "lidar"],
-                    help="camera = BASELINE.json configs[1] (the metric's configuration, default); lidar = configs[4] "
-                         "(1024x64 spinning LiDAR, 0.10 m voxels, 200 m), the configuration where HBM bytes dominate")
-    args = ap.parse_args()
-    if args.workload == "lidar":
-        return main_lidar(args)
+def roofline_of(kern, ms_per_step, ev_overhead_us, empty_pair_us, note, skip=("k_mesh",)):
+    hot = [k for k in kern if not k.startswith(skip) and kern[k]["algorithmic_bytes"] > 0]
+    longest = max(hot, key=lambda k: kern[k]["avg_us"] * kern[k]["launches_per_step"])
+    most = max(hot, key=lambda k: kern[k]["algorithmic_bytes"] * kern[k]["launches_per_step"])
+    frame_bytes = sum(kern[k]["algorithmic_bytes"] * kern[k]["launches_per_step"] for k in hot)
+    k = kern[longest]
+    return {"bound": "hbm", "kernel": longest, "achieved": round(k["achieved_GBps"], 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(k["achieved_GBps"] / HBM_PEAK_GBS, 5), "traffic": k["hbm_traffic_bytes"],
+            "algorithmic_bytes_per_launch": int(k["algorithmic_bytes"]), "avg_launch_us": round(k["avg_us"], 3),
+            "launches_per_step": round(k["launches_per_step"], 2),
+            "event_pair_overhead_us": round(ev_overhead_us, 3), "empty_event_pair_us": round(empty_pair_us, 3),
+            "step": {"algorithmic_bytes": int(frame_bytes), "achieved": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+                     "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "most_bytes_kernel": {"kernel": most, "avg_launch_us": round(kern[most]["avg_us"], 3), "achieved": round(kern[most]["achieved_GBps"], 2),
+                                  "frac": round(kern[most]["achieved_GBps"] / HBM_PEAK_GBS, 5), "traffic": kern[most]["hbm_traffic_bytes"]},
+            "note": note}
 
+
+def kernels_json(kern):
+    return {k: {"avg_us": round(v["avg_us"], 3), "launches_per_step": round(v["launches_per_step"], 2), "algorithmic_bytes": v["algorithmic_bytes"],
+                "achieved_GBps": round(v["achieved_GBps"], 1), "hbm_traffic_bytes": v["hbm_traffic_bytes"]} for k, v in kern.items()}
+
+
+def copy_params(oracle, p):
+    po = oracle.OrcParams()
+    for name, _ in oracle.OrcParams._fields_:
+        setattr(po, name, getattr(p, name))
+    return po
+
+
+def cpu_sample(step_cpu, seconds, min_steps, unit, what, oracle):
+    """The oracle (a port: there is no CPU path in the reference) on a bounded sample of the same workload."""
+    t = time.perf_counter(); k = 0
+    while k < min_steps or (time.perf_counter() - t < seconds and k < 100000):
+        step_cpu(k); k += 1
+    dt = time.perf_counter() - t
+    return {"value": round(k / dt, 3), "unit": unit, "cores": int(oracle.num_threads()), "kind": "port", "ms_per_step": round(dt / k * 1e3, 3),
+            "sample": "%d %s, oracle/nvblox_oracle.c, OpenMP with %d threads" % (k, what, int(oracle.num_threads()))}
+
+
+def init_dist(args):
     import torch
     import torch.distributed as dist
-    from isaac_ros_nvblox_amd import mapper as M, synthetic as S
-    from isaac_ros_nvblox_amd.dist import PipelinedDirtyBlockExchange, camera_yaw_offset_deg
-
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("NVBX_BENCH_SAME_DEVICE") == "1":
@@ -139,40 +199,253 @@ def main():
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    return torch, dist, rank, world, local_rank, dev
+
+
+def finish_dist(dist, world):
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+# ====================================================================================================== lidar (configs[4])
+def main_lidar(args):
+    """One step = integrateDepth of one 1024x64 LiDAR scan (range image resident in HBM), 0.10 m voxels, 200 m.  N > 1 GPUs: the scan's
+    azimuth range is cut into N sectors, rank r integrates the beams of sector r into its own map (strong scaling of one sensor; the
+    sector maps are disjoint wedges apart from the blocks on the cuts -- DESIGN.md 6)."""
+    from isaac_ros_nvblox_amd import mapper as M, synthetic as S
+    torch, dist, rank, world, local_rank, dev = init_dist(args)
+    lidar = S.SPINNING_LIDAR
+    sc = S.LidarScene()
+    nu = max(2, min(args.unique_frames, 16))
+    host = []
+    for i in range(nu):
+        T = S.lidar_pose(i, 400)
+        img = S.render_lidar(sc, T, lidar, max_range=200.0)
+        if world > 1:                                  # this rank's azimuth sector: the other beams are "no return"
+            cols = img.shape[1]; lo, hi = rank * cols // world, (rank + 1) * cols // world
+            mask = np.zeros(cols, bool); mask[lo:hi] = True
+            img = np.where(mask[None, :], img, np.float32(0.0)).astype(np.float32)
+        host.append((img, T))
+    scans = [(torch.from_numpy(r).to(dev), T) for r, T in host]
+    stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream)
+    p = M.default_params(voxel_size=0.1, lidar_max_integration_distance_m=200.0, raycast_subsampling_factor=2)
+    g = M.Mapper(p, device=local_rank, block_capacity=1 << 19, stream=stream.cuda_stream)
+    largs = [g.prepare_lidar(r, T, lidar) for r, T in scans]
+
+    def barrier():
+        g.synchronize(); torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    tm = Timer(torch, dist, dev, world)
+    dt, dts, nxt = tm.run(lambda i: g.integrate_prepared(largs[i % nu]), barrier, args.steps, args.warmup)
+    ms = dt / args.steps * 1e3
+    if rank != 0:
+        return finish_dist(dist, world)
+    n2 = min(args.steps, 40)
+    g.set_profiling(True)
+    nv = []
+    for i in range(n2):
+        g.integrate_prepared(largs[i % nu]); nv.append(g.counters()["tsdf_blocks_in_view"])
+    prof = g.profile(); g.set_profiling(False)
+    c = g.counters(); counts = dict(c); counts["tsdf_blocks_in_view"] = float(np.mean(nv))
+    rows, cols = lidar[1], lidar[0]
+    kern, evo, emp = kernel_table(prof, counts, ms, n2, lambda k, cc: algorithmic_bytes(k, cc, rows, cols, sub_ray=2), load_pmc("lidar"))
+    cpu = None
+    if not args.no_cpu_baseline:
+        import oracle
+        oracle.set_num_threads(min(8, os.cpu_count() or 1))
+        o = oracle.OracleMap(copy_params(oracle, g.params))
+        o.integrate_lidar_depth(host[0][0], host[0][1], lidar)          # warm the map like the GPU warm-up does
+        cpu = cpu_sample(lambda k: o.integrate_lidar_depth(host[(1 + k) % nu][0], host[(1 + k) % nu][1], lidar), args.cpu_seconds, 2, "scans/s",
+                         "scans of the same 1024x64 sequence (0.10 m voxels, 200 m)", oracle)
+    out = {"metric": "scans/s, LiDAR projective TSDF integrate, synthetic 1024x64 @0.10m, 200 m", "value": round(args.steps / dt, 2),
+           "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": len(dts), "ms_per_step": round(ms, 4),
+           "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[4]: synthetic 1024x64 spinning LiDAR (SURVEY 8d), 0.10 m voxels, 200 m range, ray subsampling 2",
+                      "parallelism": "azimuth sectors, one per GPU" if world > 1 else "single GPU"},
+           "per_step_counts": {"tsdf_blocks_in_view": round(counts["tsdf_blocks_in_view"], 1), "blocks_allocated": c["blocks_allocated"], "capacity_overflow": c["capacity_overflow"]},
+           "block_ms": [round(d / args.steps * 1e3, 4) for d in dts[:16]],
+           "kernels": kernels_json(kern),
+           "roofline": roofline_of(kern, ms, evo, emp, "longest kernel of the scan; durations = hipEvent spans on the mapper stream minus the calibrated "
+                                   "instrumentation cost; compare profiles/*_lidar_kernel_stats.csv", skip=()),
+           "cpu_baseline": cpu}
+    print(json.dumps(out))
+    finish_dist(dist, world)
+
+
+# ====================================================================================================== decay (configs[2])
+def main_decay(args):
+    """Redwood-like dynamic scene, MappingType::kDynamic: per frame  detect dynamics -> remove small components -> split depth ->
+    integrateDepth(static, TSDF + freespace, invalid-depth decay) -> integrateDepth(dynamic, occupancy) -> integrateColor -> updateEsdf
+    (both mappers); every 6th frame decayTsdfExcludeLastView + decayOccupancyAllVoxels (5 Hz at 30 Hz input, nvblox_base.yaml:13-23)."""
+    from isaac_ros_nvblox_amd import mapper as M, synthetic as S
+    torch, dist, rank, world, local_rank, dev = init_dist(args)
+    assert world == 1, "the decay workload line is single-GPU"
+    cam = S.REPLICA_LIKE_CAM; rows, cols = cam[5], cam[4]
+    nu = max(6, min(args.unique_frames, 48))
+    host = []
+    for i in range(nu):
+        sc = S.redwood_like_scene(i * 6)
+        T = S.trajectory_pose(i * (200 // nu), 200, radius=1.2, height=1.4)
+        d, rgb = S.render(sc, T, cam, max_range=5.0)
+        host.append((d, rgb, T))
+    depth_dev = [torch.from_numpy(d).to(dev) for d, _, _ in host]
+    rgb_dev = [torch.from_numpy(c).to(dev) for _, c, _ in host]
+    poses = [T for _, _, T in host]
+    stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream)
+    fs = dict(projective_layer_type=2, max_integration_distance_m=5.0, invalid_depth_decay_factor=0.8, tsdf_decay_factor=0.95,
+              min_duration_since_occupied_for_freespace_ms=250)                     # nvblox_dynamics.yaml:11-18
+    occ = dict(projective_layer_type=1, max_integration_distance_m=5.0)
+    gs = M.Mapper(M.default_params(**fs), device=local_rank, block_capacity=1 << 15, stream=stream.cuda_stream)
+    gd = M.Mapper(M.default_params(**occ), device=local_rank, block_capacity=1 << 13, stream=stream.cuda_stream)
+    eye = np.eye(4, dtype=np.float32)
+    mask = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
+    un = torch.empty((rows, cols), dtype=torch.float32, device=dev); ma = torch.empty_like(un)
+    t_ms = [0]
+
+    def step(i):
+        k = i % nu
+        gs.detect_dynamics_into(depth_dev[k], poses[k], cam, 5.0, mask)
+        gs.remove_small_components_inplace(mask, 2000)             # multi_mapper connected_mask_component_size_threshold (mapper_initialization.cpp:130)
+        gs.split_depth_by_mask_into(depth_dev[k], mask, eye, cam, cam, 0.25, un, ma)
+        gs.set_time_ms(t_ms[0]); t_ms[0] += 33
+        gs.integrate_depth(un, poses[k], cam)
+        gd.integrate_depth(ma, poses[k], cam)
+        gs.integrate_color(rgb_dev[k], poses[k], cam)
+        gs.update_esdf(); gd.update_esdf()
+        if i % 6 == 5:
+            gs.decay_tsdf(True); gd.decay_occupancy()
+
+    def barrier():
+        gs.synchronize(); gd.synchronize(); torch.cuda.synchronize(dev)
+
+    tm = Timer(torch, dist, dev, world)
+    dt, dts, nxt = tm.run(step, barrier, args.steps, args.warmup)
+    ms = dt / args.steps * 1e3
+    n2 = min(max(6, args.steps), 60)
+    gs.set_profiling(True); gd.set_profiling(True)
+    acc = {}
+    for i in range(n2):
+        step(nxt + i)
+        if i % 6 == 0:
+            for k_, v_ in gs.counters().items():
+                acc.setdefault(k_, []).append(v_)
+    prof = gs.profile(); prof_d = gd.profile()
+    gs.set_profiling(False); gd.set_profiling(False)
+    for k_, v_ in prof_d.items():          # the dynamic (occupancy) mapper's launches join the static mapper's under the same kernel names
+        if k_ == "_empty_event_pair":
+            continue
+        if k_ in prof:
+            prof[k_] = {"count": prof[k_]["count"] + v_["count"], "total_ms": prof[k_]["total_ms"] + v_["total_ms"]}
+        else:
+            prof[k_] = v_
+    counts = {k_: float(np.mean(v_)) for k_, v_ in acc.items()}
+    kern, evo, emp = kernel_table(prof, counts, ms, n2, lambda k, cc: algorithmic_bytes(k, cc, rows, cols), load_pmc("decay"))
+    cpu = None
+    if not args.no_cpu_baseline:
+        import oracle
+        oracle.set_num_threads(min(8, os.cpu_count() or 1))
+        os_ = oracle.OracleMap(copy_params(oracle, gs.params)); od = oracle.OracleMap(copy_params(oracle, gd.params))
+        tc = [0]
+
+        def cstep(i):
+            d, rgb, T = host[i % nu]
+            mk = os_.detect_dynamics(d, T, cam, 5.0)
+            mk = oracle.remove_small_components(mk, 2000)
+            u_, m_ = oracle.split_depth_by_mask(d, mk, eye, cam, cam, 0.25)
+            os_.set_time_ms(tc[0]); tc[0] += 33
+            os_.integrate_depth(u_, T, cam); od.integrate_depth(m_, T, cam)
+            os_.integrate_color(rgb, T, cam)
+            os_.update_esdf(); od.update_esdf()
+            if i % 6 == 5:
+                os_.decay_tsdf(True); od.decay_occupancy()
+        cstep(0); cstep(1)
+        cpu = cpu_sample(lambda k: cstep(2 + k), args.cpu_seconds, 6, "frames/s", "frames of the same 640x480 dynamic sequence (all of the step)", oracle)
+    c = gs.counters()
+    out = {"metric": "frames/s, dynamic mapping frame (dynamics + TSDF/freespace + occupancy + Color + ESDF, decay every 6th), synthetic Redwood-like 640x480 @0.05m",
+           "value": round(args.steps / dt, 2), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "repeats": len(dts),
+           "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[2]: synthetic Redwood-like room 8x6x2.8 m with a box moving at 0.5 m/s (SURVEY 8d), 640x480 depth+colour "
+                                  "limited to 5 m, 0.05 m voxels, MappingType::kDynamic (freespace layer, dynamics detection, occupancy mapper), "
+                                  "invalid_depth_decay 0.8, tsdf_decay 0.95 + occupancy decay every 6th frame", "unique_frames": nu},
+           "readme_rtx5090_ms": README_RTX5090_MS,
+           "per_step_counts": {k_: round(v_, 1) for k_, v_ in counts.items()},
+           "block_ms": [round(d / args.steps * 1e3, 4) for d in dts[:16]],
+           "kernels": kernels_json(kern),
+           "roofline": roofline_of(kern, ms, evo, emp, "longest kernel of the dynamic-mapping step (launches of the static and the dynamic mapper "
+                                   "together); remove_small_components iterates to convergence with a host read per batch of rounds, so the step is not "
+                                   "purely stream-ordered like the camera workload"),
+           "cpu_baseline": cpu, "capacity_overflow": c["capacity_overflow"]}
+    print(json.dumps(out))
+
+
+# ====================================================================================================== camera / multicam
+def main_camera(args):
+    from isaac_ros_nvblox_amd import mapper as M, synthetic as S
+    from isaac_ros_nvblox_amd.dist import PipelinedDirtyBlockExchange, camera_yaw_offset_deg
+    torch, dist, rank, world, local_rank, dev = init_dist(args)
+    multicam = args.workload == "multicam"
+    ncam = max(1, min(8, args.cameras)) if multicam else 1
+    assert not (multicam and world > 1), "multicam is the ONE-GPU form of configs[3]; N GPUs: --workload camera --gpus N"
 
     cam = S.REPLICA_LIKE_CAM
     rows, cols = cam[5], cam[4]
     scene = S.Scene()
     nu = max(2, min(args.unique_frames, args.steps + args.warmup))
+    if multicam:
+        nu = max(2, min(nu, 24))
     stride = max(1, 200 // nu)
-    yaw = camera_yaw_offset_deg(rank, world)
-    host_frames = []
-    for i in range(nu):
-        T = S.trajectory_pose(i * stride, 200, yaw_offset_deg=yaw)
-        d, rgb = S.render(scene, T, cam)
-        host_frames.append((d, rgb, T))
-    depth_dev = [torch.from_numpy(d).to(dev) for d, _, _ in host_frames]
-    rgb_dev = [torch.from_numpy(c).to(dev) for _, c, _ in host_frames]
-    poses = [T for _, _, T in host_frames]
+
+    def render_cam(ci):
+        yaw = camera_yaw_offset_deg(rank if not multicam else ci, 8)
+        fr = []
+        for i in range(nu):
+            T = S.trajectory_pose(i * stride, 200, yaw_offset_deg=yaw)
+            d, rgb = S.render(scene, T, cam)
+            fr.append((d, rgb, T))
+        return fr
+    host_cams = [render_cam(ci) for ci in range(8 if multicam else 1)]      # (multicam: all 8 rendered once, the sweep uses prefixes)
+    depth_dev = [[torch.from_numpy(d).to(dev) for d, _, _ in fr] for fr in host_cams]
+    rgb_dev = [[torch.from_numpy(c).to(dev) for _, c, _ in fr] for fr in host_cams]
+    poses = [[T for _, _, T in fr] for fr in host_cams]
+    host_frames = host_cams[0]
 
     stream = torch.cuda.Stream(dev)      # one explicit stream for torch ops, RCCL hand-off and every mapper kernel
     torch.cuda.set_stream(stream)
     g = M.Mapper(M.default_params(), device=local_rank, block_capacity=1 << 15, stream=stream.cuda_stream)
     ex = PipelinedDirtyBlockExchange(4096, dev) if world > 1 else None      # one packed all-gather per frame, joined one frame later
 
-    dargs = [g.prepare_depth(depth_dev[k], poses[k], cam) for k in range(nu)]
-    cargs = [g.prepare_color(rgb_dev[k], poses[k], cam) for k in range(nu)]
+    dargs = [[g.prepare_depth(depth_dev[ci][k], poses[ci][k], cam) for k in range(nu)] for ci in range(len(host_cams))]
+    cargs = [[g.prepare_color(rgb_dev[ci][k], poses[ci][k], cam) for k in range(nu)] for ci in range(len(host_cams))]
+    batch_ok = hasattr(g, "integrate_depth_batch")
+    bd = {}; bc = {}
+    if multicam and batch_ok:
+        for n_ in (1, 2, 4, 8):
+            bd[n_] = [g.prepare_depth_batch([depth_dev[ci][k] for ci in range(n_)], [poses[ci][k] for ci in range(n_)], cam) for k in range(nu)]
+            bc[n_] = [g.prepare_color_batch([rgb_dev[ci][k] for ci in range(n_)], [poses[ci][k] for ci in range(n_)], cam) for k in range(nu)]
 
-    def step(i, mesh=False, exchange=True):
+    def step(i, mesh=False, exchange=True, n=None, batched=None):
+        n = ncam if n is None else n
         k = i % nu
+        use_batch = (multicam and batch_ok and n in bd) if batched is None else batched
         xg = ex if exchange else None            # rank-0-only passes after the timed region must not enter a collective
         if xg is not None:
             xg.before_depth(g)                   # the depth pass writes this frame's block indices into the exchange buffer itself
-        g.integrate_prepared(dargs[k])          # MultiMapper::integrateDepth
+        if use_batch:
+            g.integrate_prepared_batch(bd[n][k])     # n cameras' depth frames: ONE view-marking launch + ONE TSDF-update launch
+        else:
+            for ci in range(n):
+                g.integrate_prepared(dargs[ci][k])   # MultiMapper::integrateDepth
         if xg is not None:
             xg.start(g)                          # dirty block indices: export + async RCCL all-gather (needs only the depth pass)
             xg.finish_previous(g, deferred=True) # join the PREVIOUS frame's all-gather; its union step rides in the colour launch below
-        g.integrate_prepared(cargs[k])          # MultiMapper::integrateColor (+ marking of own and peers' dirty blocks)
+        if use_batch:
+            g.integrate_prepared_batch(bc[n][k])
+        else:
+            for ci in range(n):
+                g.integrate_prepared(cargs[ci][k])   # MultiMapper::integrateColor (+ marking of own and peers' dirty blocks)
         g.update_esdf()                          # MultiMapper::updateEsdf
         if mesh:
             g.update_color_mesh()
@@ -187,25 +460,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    tm = Timer(torch, dist, dev, world)
+    dt, dts, base = tm.run(step, barrier, args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
-    fps = world * args.steps / dt
+    fps = world * ncam * args.steps / dt
 
     if rank != 0:
-        if world > 1:
-            dist.barrier(); dist.destroy_process_group()
-        return
+        return finish_dist(dist, world)
 
     # ---- rank 0 extras (outside the timed region): per-component times, per-kernel roofline, CPU baseline
     def timed(fn, n):
@@ -215,24 +476,32 @@ def main():
         g.synchronize(); torch.cuda.synchronize(dev)
         return (time.perf_counter() - t) / n * 1e3
 
-    base = args.warmup + args.steps
     n2 = min(args.steps, 100)
     comp = {}
-    comp["tsdf"] = timed(lambda i: g.integrate_depth(depth_dev[(base + i) % nu], poses[(base + i) % nu], cam), n2)
-    comp["color"] = timed(lambda i: g.integrate_color(rgb_dev[(base + i) % nu], poses[(base + i) % nu], cam), n2)
+    sweep = None
+    if not multicam:
+        comp["tsdf"] = timed(lambda i: g.integrate_prepared(dargs[0][(base + i) % nu]), n2)
+        comp["color"] = timed(lambda i: g.integrate_prepared(cargs[0][(base + i) % nu]), n2)
 
-    def esdf_only(i):
-        g.integrate_depth(depth_dev[(base + i) % nu], poses[(base + i) % nu], cam); g.update_esdf()
-    comp["esdf"] = max(0.0, timed(esdf_only, n2) - comp["tsdf"])
+        def esdf_only(i):
+            g.integrate_prepared(dargs[0][(base + i) % nu]); g.update_esdf()
+        comp["esdf"] = max(0.0, timed(esdf_only, n2) - comp["tsdf"])
 
-    def mesh_only(i):
-        g.integrate_depth(depth_dev[(base + i) % nu], poses[(base + i) % nu], cam); g.update_color_mesh()
-    comp["mesh"] = max(0.0, timed(mesh_only, n2) - comp["tsdf"])
+        def mesh_only(i):
+            g.integrate_prepared(dargs[0][(base + i) % nu]); g.update_color_mesh()
+        comp["mesh"] = max(0.0, timed(mesh_only, n2) - comp["tsdf"])
+    else:
+        # 1 / 2 / 4 / 8 cameras through one mapper: sequential calls vs one batched launch set
+        sweep = {}
+        for n_ in (1, 2, 4, 8):
+            e = {"sequential_ms": round(timed(lambda i: step(base + i, n=n_, batched=False), n2), 4)}
+            if batch_ok:
+                e["batched_ms"] = round(timed(lambda i: step(base + i, n=n_, batched=True), n2), 4)
+            sweep[str(n_)] = e
 
     # per-frame latency (SURVEY 8d timing protocol): every frame is waited for, so this is the latency a caller sees, not the
-    # pipelined throughput of the timed region.  wall = host clock around the three calls + synchronize (includes the host's
-    # wake-up after the stream drains); gpu = hipEvent pair on the mapper stream around the same three calls.
-    lat_wall, lat_gpu = [], []
+    # pipelined throughput of the timed region.
+    lat_wall = []
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n2)]
     for i in range(n2):
         t = time.perf_counter()
@@ -245,7 +514,8 @@ def main():
     lat_gpu = [a.elapsed_time(b) for a, b in ev]
     pct = lambda v: {"mean": round(float(np.mean(v)), 4), "p50": round(float(np.percentile(v, 50)), 4), "p99": round(float(np.percentile(v, 99)), 4)}
     latency = {"frames": n2, "wall_ms": pct(lat_wall), "gpu_ms": pct(lat_gpu),
-               "note": "one frame at a time with a synchronize after each (the ESDF distance transform then runs as its own launch)"}
+               "note": "one step at a time with a synchronize after each (the ESDF distance transform then runs as its own launch); wall = host "
+                       "clock around the calls + synchronize -- the figure comparable to the README's host timers"}
 
     # per-kernel durations with hipEvent pairs on the mapper stream, same frames, mesh included
     g.set_profiling(True)
@@ -253,64 +523,22 @@ def main():
     for i in range(n2):
         step(base + i, mesh=True, exchange=False)
         if i % 10 == 0:
-            c = g.counters()
-            for k_, v_ in c.items():
+            for k_, v_ in g.counters().items():
                 counts_acc.setdefault(k_, []).append(v_)
     prof = g.profile()
     g.set_profiling(False)
     counts = {k_: float(np.mean(v_)) for k_, v_ in counts_acc.items()}
-    import re
-    short = lambda k_: re.match(r"\s*(k_[a-z_0-9]+)", k_).group(1)
-    pmc = {}
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/gpu_round.sh)
-    if os.path.exists(pmc_path):
-        try:
-            pmc = json.load(open(pmc_path))
-        except Exception:
-            pmc = {}
-    kern = {}
-    ev_pair = prof.pop("_empty_event_pair", None)
-    empty_pair_us = (ev_pair["total_ms"] / ev_pair["count"] * 1e3) if ev_pair else 0.0
-    # A hipEvent pair around ONE launch adds its own cost to the span.  Calibration: the launches of the timed frame (everything
-    # but the mesh and the stand-alone EDT, which rides in k_mark_view there) must add up to the un-instrumented frame time
-    # measured above; the excess is the instrumentation, split evenly over those launches.
-    frame_launches = [k_ for k_ in prof if not (short(k_).startswith("k_mesh") or short(k_).startswith("k_esdf_edt"))]
-    raw_sum_us = sum(prof[k_]["total_ms"] / n2 * 1e3 for k_ in frame_launches)
-    n_frame_launches = sum(prof[k_]["count"] / n2 for k_ in frame_launches)
-    ev_overhead_us = max(0.0, (raw_sum_us - ms_per_step * 1e3) / max(1.0, n_frame_launches))
-    for k_, v_ in prof.items():
-        us = max(0.1, v_["total_ms"] / v_["count"] * 1e3 - ev_overhead_us)
-        ab = algorithmic_bytes(short(k_), counts, rows, cols)
-        kern[short(k_)] = {"avg_us": us, "launches_per_frame": v_["count"] / n2, "algorithmic_bytes": int(ab),
-                           "achieved_GBps": (ab / (us * 1e-6) / 1e9) if us > 0 else 0.0,
-                           "hbm_traffic_bytes": pmc.get(short(k_), {}).get("hbm_bytes_per_launch")}
-    hot = [k_ for k_ in kern if not k_.startswith("k_mesh")]
-    # No kernel dominates the frame by time (six launches of 7-11 us each, profiles/*_kernel_stats.csv), so the HBM roofline
-    # is quoted for the kernel that moves the most bytes; the longest one is named beside it and every kernel is listed.
-    dom = max(hot, key=lambda k_: kern[k_]["algorithmic_bytes"] * kern[k_]["launches_per_frame"])
-    longest = max(hot, key=lambda k_: kern[k_]["avg_us"] * kern[k_]["launches_per_frame"])
-    dom_bytes = kern[dom]["algorithmic_bytes"]
-    dom_us = kern[dom]["avg_us"]
-    achieved = kern[dom]["achieved_GBps"]
-    traffic = kern[dom]["hbm_traffic_bytes"]
-    frame_bytes = sum(kern[k_]["algorithmic_bytes"] * kern[k_]["launches_per_frame"] for k_ in hot)
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_us": round(dom_us, 3), "event_pair_overhead_us": round(ev_overhead_us, 3), "empty_event_pair_us": round(empty_pair_us, 3),
-                "frame": {"algorithmic_bytes": int(frame_bytes), "achieved": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
-                          "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-                "longest_kernel": {"kernel": longest, "avg_launch_us": round(kern[longest]["avg_us"], 3),
-                                   "achieved": round(kern[longest]["achieved_GBps"], 2), "frac": round(kern[longest]["achieved_GBps"] / HBM_PEAK_GBS, 5)},
-                "note": "kernel = the non-mesh kernel with the most algorithmic HBM bytes per frame (no kernel dominates by time: four "
-                        "dependent launches of 6-11 us each; k_integrate_color also carries the ESDF site marking, k_mark_view the "
-                        "held-back EDT of the previous update -- DESIGN.md 2.4); durations = span of a hipEvent pair around each launch on the mapper stream minus `event_pair_overhead_us`, the "
-                        "instrumentation cost per launch calibrated so that the frame's launches add up to the un-instrumented frame time; "
-                        "compare rocprofv3's kernel-trace averages in profiles/*_kernel_stats.csv. 640x480 @ 0.05 m moves ~15 MB/frame, so every kernel is bound by its "
-                        "dependent-access chain and launch cost rather than by HBM bytes (DESIGN.md 2); per-kernel achieved GB/s under "
-                        "`kernels`, whole frame under `frame`",
-                "components_note": "ms_components are measured per call in isolation: the EDT of updateEsdf is held back and runs "
-                                   "inside the next depth frame's first launch, so `esdf` shows the marking launch only and "
-                                   "the sum of the three is not ms_per_step"}
+    launches_cam = ncam if not (multicam and batch_ok and ncam in bd) else 1
+    kern, ev_overhead_us, empty_pair_us = kernel_table(
+        prof, counts, ms_per_step, n2, lambda k, cc: algorithmic_bytes(k, cc, rows, cols, n_cam=(ncam // launches_cam)), load_pmc(args.workload),
+        exclude_from_calibration=("k_mesh", "k_esdf_edt"))
+    roofline = roofline_of(
+        kern, ms_per_step, ev_overhead_us, empty_pair_us,
+        "kernel = the LONGEST non-mesh kernel of the step by time (k_integrate_color also carries the ESDF site marking, k_mark_view the held-back "
+        "EDT of the previous update -- DESIGN.md 2.4); durations = span of a hipEvent pair around each launch on the mapper stream minus "
+        "`event_pair_overhead_us`, the instrumentation cost per launch calibrated so that the step's launches add up to the un-instrumented "
+        "step time; compare rocprofv3's kernel-trace averages in profiles/*_kernel_stats.csv.  640x480 @ 0.05 m moves ~10 MB per camera frame, "
+        "so every kernel is bound by its dependent-access chain and launch cost rather than by HBM bytes (DESIGN.md 2)")
 
     cpu = None
     if not args.no_cpu_baseline:
@@ -318,50 +546,69 @@ def main():
         # 8 OpenMP threads: the oracle's parallel regions are one frame's blocks (a few hundred tasks), which stop scaling
         # there (1 thread 7.6 ms, 8 threads 3.4 ms, 256 threads 620 ms per frame on the EPYC 9575F host -- BASELINE.md 3)
         oracle.set_num_threads(min(8, os.cpu_count() or 1))
-        po = oracle.OrcParams()
-        for name, _ in oracle.OrcParams._fields_:
-            setattr(po, name, getattr(g.params, name))
-        o = oracle.OracleMap(po)
-        nf = max(2, args.cpu_frames)
-        for k in range(2):    # warm the map like the GPU warm-up does
-            d, c_, T = host_frames[k]
-            o.integrate_depth(d, T, cam); o.integrate_color(c_, T, cam); o.update_esdf()
-        t = time.perf_counter()
-        k = 0
-        while k < nf or (time.perf_counter() - t < args.cpu_seconds and k < 20000):     # a bounded sample: ~10-30 s of CPU work
-            d, c_, T = host_frames[(2 + k) % nu]
-            o.integrate_depth(d, T, cam); o.integrate_color(c_, T, cam); o.update_esdf()
-            k += 1
-        nf = k
-        cdt = time.perf_counter() - t
-        cpu = {"value": round(nf / cdt, 3), "unit": "frames/s", "cores": int(oracle.num_threads()), "kind": "port",
-               "ms_per_frame": round(cdt / nf * 1e3, 2),
-               "sample": "%d frames of the same 640x480 sequence, TSDF+Color+ESDF, oracle/nvblox_oracle.c, OpenMP with %d threads" % (nf, int(oracle.num_threads()))}
+        o = oracle.OracleMap(copy_params(oracle, g.params))
+
+        def cstep(k):
+            for ci in range(ncam):
+                d, c_, T = host_cams[ci][k % nu]; o.integrate_depth(d, T, cam)
+            for ci in range(ncam):
+                d, c_, T = host_cams[ci][k % nu]; o.integrate_color(c_, T, cam)
+            o.update_esdf()
+        cstep(0); cstep(1)
+        cpu = cpu_sample(lambda k: cstep(2 + k), args.cpu_seconds, max(2, args.cpu_frames // ncam), "steps/s" if multicam else "frames/s",
+                         "steps of the same 640x480 sequence (%d camera%s per step), TSDF+Color+ESDF" % (ncam, "" if ncam == 1 else "s"), oracle)
+        if multicam:
+            cpu["value"] = round(cpu["value"] * ncam, 3); cpu["unit"] = "frames/s"
 
     out = {
         "metric": "frames/s, TSDF+Color+ESDF integrate per frame, synthetic Replica-like 640x480 @0.05m",
-        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": len(dts),
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: synthetic Replica-like room (SURVEY 8d), 640x480 depth+colour, 0.05 m voxels, "
+        "config": {"workload": ("configs[3] on one GPU: %d cameras (45 deg yaw offsets) through one mapper, %s; " % (ncam, "one batched launch set per step" if (batch_ok and ncam in bd) else "sequential calls") if multicam else "configs[1]: ") +
+                               "synthetic Replica-like room (SURVEY 8d), 640x480 depth+colour, 0.05 m voxels, "
                                "fuser.yaml params, TSDF+Color+ESDF every frame (mesh timed separately)",
-                   "cameras_per_gpu": 1, "parallelism": "one camera per GPU, RCCL all-gather of dirty block indices" if world > 1 else "single GPU",
+                   "cameras_per_gpu": ncam, "parallelism": "one camera per GPU, RCCL all-gather of dirty block indices" if world > 1 else "single GPU",
                    "unique_frames": nu},
-        "ms_per_frame": round(ms_per_step, 4),
+        "ms_per_frame": round(ms_per_step / ncam, 4),
+        "block_ms": [round(d / args.steps * 1e3, 4) for d in dts[:16]],
         "ms_components": {k_: round(v_, 4) for k_, v_ in comp.items()},
+        "components_note": "ms_components are measured per call in isolation: the EDT of updateEsdf is held back and runs inside the next depth "
+                           "frame's first launch, so `esdf` shows the marking launch only and the sum of the three is not ms_per_step",
         "frame_latency": latency,
         "readme_rtx5090_ms": README_RTX5090_MS,
-        "speedup_vs_readme_rtx5090_tsdf_color_esdf": round(0.7 / ms_per_step, 2),
-        "per_frame_counts": {k_: round(v_, 1) for k_, v_ in counts.items()},
-        "kernels": {k_: {"avg_us": round(v_["avg_us"], 3), "launches_per_frame": round(v_["launches_per_frame"], 2),
-                         "algorithmic_bytes": v_["algorithmic_bytes"], "achieved_GBps": round(v_["achieved_GBps"], 1),
-                         "hbm_traffic_bytes": v_["hbm_traffic_bytes"]} for k_, v_ in kern.items()},
+        "speedup_vs_readme_rtx5090_tsdf_color_esdf": round(0.7 / (ms_per_step / ncam), 2),
+        "speedup_note": "indicative only: the README figures are host timers on the real Replica scene; the comparable figure here is frame_latency.wall_ms",
+        "per_step_counts": {k_: round(v_, 1) for k_, v_ in counts.items()},
+        "kernels": kernels_json(kern),
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    if sweep is not None:
+        out["camera_sweep_ms_per_step"] = sweep
     print(json.dumps(out))
-    if world > 1:
-        dist.barrier(); dist.destroy_process_group()
+    finish_dist(dist, world)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--unique-frames", type=int, default=50, help="distinct rendered frames cycled through (HBM-resident)")
+    ap.add_argument("--cpu-frames", type=int, default=48, help="minimum number of frames of the same workload timed on the CPU oracle")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline keeps integrating (cycling the same frames) until this much CPU wall time has passed")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cameras", type=int, default=4, help="multicam: cameras per step (1..8)")
+    ap.add_argument("--workload", default="camera", choices=["camera", "multicam", "decay", "lidar"],
+                    help="camera = BASELINE.json configs[1] (the metric's configuration, default); multicam = configs[3] on one GPU; "
+                         "decay = configs[2]; lidar = configs[4]")
+    args = ap.parse_args()
+    if args.workload == "lidar":
+        return main_lidar(args)
+    if args.workload == "decay":
+        return main_decay(args)
+    return main_camera(args)
 
 
 if __name__ == "__main__":

@@ -250,6 +250,22 @@ class Mapper:
         self.synchronize()
         return mask
 
+    # -- no-sync forms for a stream-ordered caller (outputs pre-allocated on the mapper's device; the caller's tensors must live on
+    #    the mapper's stream or be ordered against it)
+    def detect_dynamics_into(self, depth_dev, T_L_C, cam, max_distance_m, mask_out):
+        self._check(self.lib.nvbx_detect_dynamics(self._h, C.c_void_p(depth_dev.data_ptr()), depth_dev.shape[0], depth_dev.shape[1], _np_ptr(self._T(T_L_C)),
+                                                  C.byref(self._cam(cam)), float(max_distance_m), C.c_void_p(mask_out.data_ptr())))
+
+    def remove_small_components_inplace(self, mask_dev, min_size):
+        """(the C-ABI call itself iterates to convergence and synchronises)"""
+        self._check(self.lib.nvbx_remove_small_components(self._h, C.c_void_p(mask_dev.data_ptr()), mask_dev.shape[0], mask_dev.shape[1], int(min_size)))
+
+    def split_depth_by_mask_into(self, depth_dev, mask_dev, T_CM_CD, depth_cam, mask_cam, occlusion_threshold_m, unmasked_out, masked_out):
+        self._check(self.lib.nvbx_split_depth_by_mask(self._h, C.c_void_p(depth_dev.data_ptr()), depth_dev.shape[0], depth_dev.shape[1],
+                                                      C.c_void_p(mask_dev.data_ptr()), mask_dev.shape[0], mask_dev.shape[1], _np_ptr(self._T(T_CM_CD)),
+                                                      C.byref(self._cam(depth_cam)), C.byref(self._cam(mask_cam)), float(occlusion_threshold_m),
+                                                      C.c_void_p(unmasked_out.data_ptr()), C.c_void_p(masked_out.data_ptr()), None))
+
     def remove_small_components(self, mask, min_size):
         torch = self._torch
         mk = self._dev(mask, torch.uint8).clone()

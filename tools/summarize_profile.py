@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Digest rocprofv3 output (gpurun_out/...) into the tracked summaries under profiles/.
 
-usage: summarize_profile.py TAG STATS_DIR [PMC_FETCH_DIR PMC_WRITE_DIR]
-  - copies *_kernel_stats.csv to profiles/TAG_kernel_stats.csv
+usage: summarize_profile.py TAG STATS_DIR [PMC_FETCH_DIR PMC_WRITE_DIR] [--workload W]
+  - copies *_kernel_stats.csv to profiles/TAG_kernel_stats.csv (W != camera: profiles/TAG_W_kernel_stats.csv)
   - per kernel: mean FETCH_SIZE / WRITE_SIZE per launch -> HBM bytes per launch, with the gfx950 correction of
     /opt/skills/guides/MI355X_MICROARCH.md (HBM section): units are KiB, FETCH_SIZE counts 64 B per 128-B request on wide
-    coalesced reads (x2).  Written to profiles/TAG_pmc.json and profiles/pmc_latest.json (read by bench.py `traffic`).
+    coalesced reads (x2).  Written to profiles/TAG[_W]_pmc.json and merged into profiles/pmc_latest.json under the workload's
+    key (read by bench.py `traffic`).
 """
 import csv
 import glob
@@ -36,21 +37,36 @@ def counter_means(d, counter):
 
 
 def main():
-    tag, stats_dir = sys.argv[1], sys.argv[2]
+    argv = list(sys.argv[1:])
+    workload = "camera"
+    if "--workload" in argv:
+        i = argv.index("--workload"); workload = argv[i + 1]; del argv[i:i + 2]
+    tag, stats_dir = argv[0], argv[1]
+    suffix = "" if workload == "camera" else "_" + workload
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     for f in glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True):
-        shutil.copy(f, os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag))
-    if len(sys.argv) >= 5:
-        fetch = counter_means(sys.argv[3], "FETCH_SIZE")
-        write = counter_means(sys.argv[4], "WRITE_SIZE")
+        shutil.copy(f, os.path.join(ROOT, "profiles", "%s%s_kernel_stats.csv" % (tag, suffix)))
+    if len(argv) >= 4:
+        fetch = counter_means(argv[2], "FETCH_SIZE")
+        write = counter_means(argv[3], "WRITE_SIZE")
         out = {}
         for k in sorted(set(fetch) | set(write)):
+            if not k.startswith("k_"):
+                continue
             fk, wk = fetch.get(k, 0.0), write.get(k, 0.0)
             out[k] = {"FETCH_SIZE_KiB": round(fk, 3), "WRITE_SIZE_KiB": round(wk, 3),
                       "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024),
                       "note": "2x FETCH_SIZE gfx950 correction (calibrated for 16-B/lane streams; our 8-B/lane accesses are uncalibrated)"}
-        for name in ("%s_pmc.json" % tag, "pmc_latest.json"):
-            json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
+        json.dump(out, open(os.path.join(ROOT, "profiles", "%s%s_pmc.json" % (tag, suffix)), "w"), indent=1)
+        latest_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        try:
+            latest = json.load(open(latest_path))
+        except Exception:
+            latest = {}
+        if any(k.startswith("k_") or k.startswith("__amd") for k in latest):      # round-1 layout (flat = camera)
+            latest = {"camera": {k: v for k, v in latest.items() if k.startswith("k_")}}
+        latest[workload] = out
+        json.dump(latest, open(latest_path, "w"), indent=1)
         print(json.dumps(out, indent=1))
 
 
