@@ -224,6 +224,19 @@ int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, i
  * colour fetch (one aligned 4-byte load per tap). */
 int nvbx_integrate_color_bgra8(nvbx_mapper* m, const uint8_t* bgra_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                const nvbx_camera* camera);
+/* ---- camera batches: the reference's multi-camera mode (up to four cameras feed ONE mapper through one queue, an integrateDepth /
+ * integrateColor call per camera frame: nvblox_ros/include/nvblox_ros/nvblox_node.hpp:298-332, nvblox_node.cpp:247-292) as ONE launch
+ * set.  n (1 .. NVBX_MAX_BATCH) frames of the same image size; depth_dev / rgb_dev = n device image pointers (host array), T_L_C =
+ * n x 16 floats, cameras = n structs.  DEFINED as equal to the n separate calls in order 0 .. n-1 -- map contents bit for bit, the
+ * "last view" queries (nvbx_last_depth_view / _color_view, decayTsdfExcludeLastView, nvbx_get_synthetic_depth) report camera n-1's --
+ * but with one view-marking + one TSDF-update launch (depth) and one sphere-tracing + one colour launch for all n cameras: at
+ * 640x480 a frame is launch / latency bound, so a batch of 8 costs far less than 8 frames.  Mappers with a freespace layer and depth
+ * dilation fall back to the separate calls. */
+#define NVBX_MAX_BATCH 8
+int nvbx_integrate_depth_batch(nvbx_mapper* m, int32_t n, const float* const* depth_dev, int32_t rows, int32_t cols, const float* T_L_C,
+                               const nvbx_camera* cameras);
+int nvbx_integrate_color_batch(nvbx_mapper* m, int32_t n, const uint8_t* const* rgb_dev, int32_t rows, int32_t cols, const float* T_L_C,
+                               const nvbx_camera* cameras);
 /* MultiMapper::updateEsdf() (EsdfMode::k2D) -- nvblox_node.cpp:781.
  * Scheduling note: the site-marking half runs at once (or already ran inside the preceding nvbx_integrate_color launch);
  * the distance-transform half may be HELD BACK until the next entry point of this mapper: nvbx_integrate_depth[_u16mm]

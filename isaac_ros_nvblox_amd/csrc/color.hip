@@ -27,18 +27,36 @@ constexpr int RAY_LANES = 8;    // lanes cooperating on one ray = samples fetche
 // probes and voxel loads are in flight together, and the group consumes the samples in order with ballots while each
 // sample's step equals the prediction.  The first sample that breaks it supplies the next t and the next prediction.
 // The sequence of t values -- and so the result -- is bit-identical to the one-sample-at-a-time march.
-__global__ __launch_bounds__(256) void k_sphere_trace(DMap m, Frame f, float* synth, int32_t srows, int32_t scols, int32_t max_steps,
+// The colour frames of one launch set: one frame, or a batch of up to MAX_BATCH (nvbx_integrate_color_batch); kernel arguments.
+template <int NB> struct PoseSet { Frame f[NB]; int32_t n; };
+template <typename Pix, int NB> struct FrameSetC { Frame f[NB]; Pix img[NB]; int32_t n; };
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_sphere_trace(DMap m, PoseSet<NB> poses, float* synth_all, int32_t srows, int32_t scols, int32_t max_steps,
                                                       float max_len, float eps_m) {
   const int tid = threadIdx.x;
   if (blockIdx.x == 0 && tid == 0) list_reset(m, S_LIST_COLOR);
   const int lane = tid & 63;
   const int sub = lane & (RAY_LANES - 1);              // sample index within the ray's group
   const int gsh = lane & ~(RAY_LANES - 1);             // first lane of the group (= shift of its bits in a ballot)
-  const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + tid) / RAY_LANES;
-  const bool valid = ray < (int64_t)srows * scols;
-  const int r = valid ? (int)(ray / scols) : 0, c = valid ? (int)(ray - (int64_t)r * scols) : 0;
-  const float rx = (((float)(c * f.subsample) + 0.5f) - f.cu) / f.fu;
-  const float ry = (((float)(r * f.subsample) + 0.5f) - f.cv) / f.fv;
+  // XCD-aware ray -> workgroup mapping.  Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2: with rays
+  // dealt out in row-major order every XCD marches through EVERY part of the frustum and fetches its own copy of every TSDF block
+  // and hash line (PMC: 6.6 MB of HBM traffic for 1.0 MB of blocks).  Instead a workgroup takes an 8 x 4 patch of rays, and the
+  // patches are numbered so that the workgroups of one XCD (blockIdx.x & 7) own a contiguous band of patch rows.
+  constexpr int PW = 8, PH = (256 / RAY_LANES) / PW;       // 32 rays per 256-thread workgroup
+  const int patches_x = (scols + PW - 1) / PW, patches_y = (srows + PH - 1) / PH;
+  const int n_patch = patches_x * patches_y, per_xcd = (n_patch + NSH - 1) / NSH;
+  const int cam = NB > 1 ? (int)blockIdx.x / (NSH * per_xcd) : 0;          // batch: NSH * per_xcd workgroups per camera, camera after camera
+  const int wg = (int)blockIdx.x - cam * (NSH * per_xcd);
+  const Frame& f = poses.f[cam];
+  float* synth = synth_all + (size_t)cam * srows * scols;
+  const int patch = (wg & (NSH - 1)) * per_xcd + (wg >> 3);
+  const int pr = tid / RAY_LANES;                            // ray within the patch
+  const int py = patch / patches_x, px = patch - py * patches_x;
+  const int r = py * PH + pr / PW, c = px * PW + pr % PW;
+  const bool valid = cam < poses.n && patch < n_patch && (wg >> 3) < per_xcd && r < srows && c < scols;
+  const float rx = (((float)((valid ? c : 0) * f.subsample) + 0.5f) - f.cu) / f.fu;
+  const float ry = (((float)((valid ? r : 0) * f.subsample) + 0.5f) - f.cv) / f.fv;
   const float n = sqrtf((rx * rx + ry * ry) + 1.0f);
   const float dcx = rx / n, dcy = ry / n, dcz = 1.0f / n;
   float dl[3];
@@ -123,8 +141,8 @@ __device__ inline uint32_t blend_u8(float c0, float w0, float c1, float w1) {
 // -> frustum vote -> {synthetic depth gather, colour gather, colour voxel} (fetched together) -> store.
 // Workgroups [0, n_mark_wg) are ESDF marking workers (first wavefront only; dispatched first so that they start at once and
 // do not queue for a CU slot behind the resident batch of colour workgroups); the n_color_wg after them integrate colour.
-template <typename Pix>
-__global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rgb, const float* synth, int32_t srows, int32_t scols,
+template <typename Pix, int NB>
+__global__ __launch_bounds__(512) void k_integrate_color(DMap m, FrameSetC<Pix, NB> fs, const float* synth_all, int32_t srows, int32_t scols,
                                                          int32_t mesh_list, int32_t n_mark_wg, EsdfArgs ea, ImportArgs imp) {
   if ((int32_t)blockIdx.x < n_mark_wg) {
     if (threadIdx.x < 64) {
@@ -137,9 +155,11 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rg
     return;
   }
   const int32_t wg = (int32_t)blockIdx.x - n_mark_wg, n_color_wg = (int32_t)gridDim.x - n_mark_wg;
-  __shared__ int s_out[6];
+  __shared__ int s_out[NB][6];
   const int tid = threadIdx.x;
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
+  const Frame& f0 = fs.f[0];
+  const int ncam = NB > 1 ? fs.n : 1;
   // the first slot's data is requested beside the high-water mark (gridDim.x <= capacity, so the addresses are valid)
   int32_t slot = wg;
   uint32_t flags = m.slot_flags[slot];
@@ -156,104 +176,128 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, Frame f, Pix rg
     if (!(flags & F_TSDF)) continue;     // uniform
     if (flags & F_BAND_STALE) {          // uniform
       const float2 tv = m.tsdf[(size_t)slot * 512 + tid];
-      const bool pred = in_band(tv.x, tv.y, f.trunc);
+      const bool pred = in_band(tv.x, tv.y, f0.trunc);
       publish_band(m.slot_flags, (uint32_t)slot, tid, pred);
       if (!__syncthreads_or(pred ? 1 : 0)) continue;
     } else if (!(flags & F_BAND)) continue;
     __syncthreads();
-    if (tid < 6) s_out[tid] = 0;
+    if (tid < 6 * NB) (&s_out[0][0])[tid] = 0;
     __syncthreads();
-    if (tid < 8) {   // frustum: count corners outside each plane
+    if (tid < 8 * ncam) {   // frustum: count corners outside each plane, 8 lanes per camera
+      const int c = tid >> 3, q = tid & 7;
+      const Frame& f = fs.f[c];
       float pc[3];
-      apply_rt(f.R_CL, f.t_CL, (float)(bx + (tid & 1)) * f.block_size, (float)(by + ((tid >> 1) & 1)) * f.block_size,
-               (float)(bz + ((tid >> 2) & 1)) * f.block_size, pc);
-      if (f.fu * pc[0] + f.cu * pc[2] < 0.0f) atomicAdd(&s_out[0], 1);
-      if (f.fu * pc[0] + (f.cu - (float)f.w) * pc[2] > 0.0f) atomicAdd(&s_out[1], 1);
-      if (f.fv * pc[1] + f.cv * pc[2] < 0.0f) atomicAdd(&s_out[2], 1);
-      if (f.fv * pc[1] + (f.cv - (float)f.h) * pc[2] > 0.0f) atomicAdd(&s_out[3], 1);
-      if (pc[2] < 0.0f) atomicAdd(&s_out[4], 1);
-      if (f.max_dist > 0.0f && pc[2] > f.max_dist) atomicAdd(&s_out[5], 1);
+      apply_rt(f.R_CL, f.t_CL, (float)(bx + (q & 1)) * f.block_size, (float)(by + ((q >> 1) & 1)) * f.block_size,
+               (float)(bz + ((q >> 2) & 1)) * f.block_size, pc);
+      if (f.fu * pc[0] + f.cu * pc[2] < 0.0f) atomicAdd(&s_out[c][0], 1);
+      if (f.fu * pc[0] + (f.cu - (float)f.w) * pc[2] > 0.0f) atomicAdd(&s_out[c][1], 1);
+      if (f.fv * pc[1] + f.cv * pc[2] < 0.0f) atomicAdd(&s_out[c][2], 1);
+      if (f.fv * pc[1] + (f.cv - (float)f.h) * pc[2] > 0.0f) atomicAdd(&s_out[c][3], 1);
+      if (pc[2] < 0.0f) atomicAdd(&s_out[c][4], 1);
+      if (f.max_dist > 0.0f && pc[2] > f.max_dist) atomicAdd(&s_out[c][5], 1);
     }
     __syncthreads();
-    bool in_view = true;
+    uint32_t in_view = 0u;               // cameras whose frustum the block touches (uniform)
+    for (int c = 0; c < ncam; c++) {
+      bool iv = true;
 #pragma unroll
-    for (int q = 0; q < 6; q++) if (s_out[q] == 8) in_view = false;
+      for (int q = 0; q < 6; q++) if (s_out[c][q] == 8) iv = false;
+      if (iv) in_view |= 1u << c;
+    }
     if (!in_view) continue;                // uniform
     if (tid == 0) {
       const uint32_t old = atomicOr(&m.slot_flags[slot], F_COLOR | F_DIRTY_MESH);
       if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, slot);
-      list_append(m, S_LIST_COLOR, slot);
+      if ((in_view >> (ncam - 1)) & 1u) list_append(m, S_LIST_COLOR, slot);    // "the last colour view" = the last camera's, as separate calls would leave it
     }
-    float pc[3];
-    apply_rt(f.R_CL, f.t_CL, voxel_center(bx, vx, f.block_size, f.voxel_size), voxel_center(by, vy, f.block_size, f.voxel_size),
-             voxel_center(bz, vz, f.block_size, f.voxel_size), pc);
-    float u, v;
-    if (!cam_project(f, pc, &u, &v)) continue;
-    const float vd = pc[2];
-    if (f.max_dist > 0.0f && vd > f.max_dist) continue;
-    // bilinear taps of the colour image (interpolate2DLinear<Color>) and of the synthetic depth: addresses first, then
-    // all 4 + 12 loads in flight together
-    const float uc = u - 0.5f, vc = v - 0.5f;
-    const float fx = floorf(uc), fy = floorf(vc);
-    const int x0 = (int)fx, y0 = (int)fy;
-    const bool c_ok = !(x0 < 0 || y0 < 0 || x0 + 1 > f.cols - 1 || y0 + 1 > f.rows - 1);
-    const float us = u / (float)f.subsample, vs_ = v / (float)f.subsample;
-    const float usc = us - 0.5f, vsc = vs_ - 0.5f;
-    const float sfx = floorf(usc), sfy = floorf(vsc);
-    const int sx0 = (int)sfx, sy0 = (int)sfy;
-    const bool s_ok = !(sx0 < 0 || sy0 < 0 || sx0 + 1 > scols - 1 || sy0 + 1 > srows - 1);
-    if (!c_ok || !s_ok) continue;
-    const float* sp = synth + (int64_t)sy0 * scols + sx0;
-    const int64_t i00 = (int64_t)y0 * f.cols + x0;
-    // (the colour voxel is only needed for the blend: it travels with the taps, not with the vote's inputs -- blocks
-    // outside the truncation band or the frustum, most of the map, never fetch it)
+    const float lx = voxel_center(bx, vx, f0.block_size, f0.voxel_size), ly = voxel_center(by, vy, f0.block_size, f0.voxel_size),
+                lz = voxel_center(bz, vz, f0.block_size, f0.voxel_size);
     uint2* cp = &m.color[(size_t)slot * 512 + tid];
-    const uint2 cur = *cp;
-    const float s00 = sp[0], s10 = sp[1], s01 = sp[scols], s11 = sp[scols + 1];
-    float t00[3], t10[3], t01[3], t11[3];
-    rgb.tap(i00, t00); rgb.tap(i00 + 1, t10); rgb.tap(i00 + f.cols, t01); rgb.tap(i00 + f.cols + 1, t11);
-    if (!(s00 > 0.0f) || !(s10 > 0.0f) || !(s01 > 0.0f) || !(s11 > 0.0f)) continue;
-    const float sax = usc - sfx, say = vsc - sfy;
-    const float stop = (1.0f - sax) * s00 + sax * s10;
-    const float sbot = (1.0f - sax) * s01 + sax * s11;
-    const float sd = (1.0f - say) * stop + say * sbot;
-    if (fabsf(sd - vd) > f.occlusion_thresh) continue;      // [U] occlusion test (color_occlusion_threshold_vox)
-    const float ax = uc - fx, ay = vc - fy;
-    float c[3];
+    uint2 cur = make_uint2(0u, 0u);
+    bool loaded = false, touched = false;
+    // the cameras' blends are applied to the voxel in order, in registers: exactly what separate integrateColor calls would leave
+#pragma unroll 1
+    for (int c = 0; c < ncam; c++) {
+      if (!((in_view >> c) & 1u)) continue;              // uniform
+      const Frame& f = fs.f[c];
+      const float* synth = synth_all + (size_t)c * srows * scols;
+      float pc[3];
+      apply_rt(f.R_CL, f.t_CL, lx, ly, lz, pc);
+      float u, v;
+      if (!cam_project(f, pc, &u, &v)) continue;
+      const float vd = pc[2];
+      if (f.max_dist > 0.0f && vd > f.max_dist) continue;
+      // bilinear taps of the colour image (interpolate2DLinear<Color>) and of the synthetic depth: addresses first, then
+      // all 4 + 12 loads in flight together
+      const float uc = u - 0.5f, vc = v - 0.5f;
+      const float fx = floorf(uc), fy = floorf(vc);
+      const int x0 = (int)fx, y0 = (int)fy;
+      const bool c_ok = !(x0 < 0 || y0 < 0 || x0 + 1 > f.cols - 1 || y0 + 1 > f.rows - 1);
+      const float us = u / (float)f.subsample, vs_ = v / (float)f.subsample;
+      const float usc = us - 0.5f, vsc = vs_ - 0.5f;
+      const float sfx = floorf(usc), sfy = floorf(vsc);
+      const int sx0 = (int)sfx, sy0 = (int)sfy;
+      const bool s_ok = !(sx0 < 0 || sy0 < 0 || sx0 + 1 > scols - 1 || sy0 + 1 > srows - 1);
+      if (!c_ok || !s_ok) continue;
+      const float* sp = synth + (int64_t)sy0 * scols + sx0;
+      const int64_t i00 = (int64_t)y0 * f.cols + x0;
+      // (the colour voxel is only needed for the blend: it travels with the taps, not with the vote's inputs -- blocks
+      // outside the truncation band or the frustum, most of the map, never fetch it)
+      if (!loaded) { cur = *cp; loaded = true; }
+      const float s00 = sp[0], s10 = sp[1], s01 = sp[scols], s11 = sp[scols + 1];
+      float t00[3], t10[3], t01[3], t11[3];
+      fs.img[c].tap(i00, t00); fs.img[c].tap(i00 + 1, t10); fs.img[c].tap(i00 + f.cols, t01); fs.img[c].tap(i00 + f.cols + 1, t11);
+      if (!(s00 > 0.0f) || !(s10 > 0.0f) || !(s01 > 0.0f) || !(s11 > 0.0f)) continue;
+      const float sax = usc - sfx, say = vsc - sfy;
+      const float stop = (1.0f - sax) * s00 + sax * s10;
+      const float sbot = (1.0f - sax) * s01 + sax * s11;
+      const float sd = (1.0f - say) * stop + say * sbot;
+      if (fabsf(sd - vd) > f.occlusion_thresh) continue;      // [U] occlusion test (color_occlusion_threshold_vox)
+      const float ax = uc - fx, ay = vc - fy;
+      float cc[3];
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-      const float top = (1.0f - ax) * t00[ch] + ax * t10[ch];
-      const float bot = (1.0f - ax) * t01[ch] + ax * t11[ch];
-      c[ch] = (1.0f - ay) * top + ay * bot;
+      for (int ch = 0; ch < 3; ch++) {
+        const float top = (1.0f - ax) * t00[ch] + ax * t10[ch];
+        const float bot = (1.0f - ax) * t01[ch] + ax * t11[ch];
+        cc[ch] = (1.0f - ay) * top + ay * bot;
+      }
+      const float w0 = __uint_as_float(cur.y);
+      const uint32_t r8 = blend_u8((float)(cur.x & 0xFF), w0, cc[0], 1.0f);
+      const uint32_t g8 = blend_u8((float)((cur.x >> 8) & 0xFF), w0, cc[1], 1.0f);
+      const uint32_t b8 = blend_u8((float)((cur.x >> 16) & 0xFF), w0, cc[2], 1.0f);
+      cur = make_uint2(r8 | (g8 << 8) | (b8 << 16), __float_as_uint(fminf(w0 + 1.0f, f.max_weight)));
+      touched = true;
     }
-    const float w0 = __uint_as_float(cur.y);
-    const uint32_t r8 = blend_u8((float)(cur.x & 0xFF), w0, c[0], 1.0f);
-    const uint32_t g8 = blend_u8((float)((cur.x >> 8) & 0xFF), w0, c[1], 1.0f);
-    const uint32_t b8 = blend_u8((float)((cur.x >> 16) & 0xFF), w0, c[2], 1.0f);
-    *cp = make_uint2(r8 | (g8 << 8) | (b8 << 16), __float_as_uint(fminf(w0 + 1.0f, f.max_weight)));
+    if (touched) *cp = cur;
   }
 }
 
-template <typename Pix>
-static int integrate_color_impl(nvbx_mapper* m, Pix rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera) {
-  if (!nvbx_pose_in_range(T_L_C, m->p.voxel_size * 8.0f, m->p.sphere_tracing_max_ray_length_m + m->p.max_integration_distance_m)) {
-    set_error("integrate color: T_L_C is not finite or lies outside the addressable block range (+-2^20 blocks)"); return NVBX_E_INVALID; }
+// n colour frames (n = 1: MultiMapper::integrateColor; n > 1: nvbx_integrate_color_batch) of one image size -> one launch set
+template <typename Pix, int NB>
+static int integrate_colors(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t rows, int32_t cols, const float* T_L_C /* n x 16 */, const nvbx_camera* cameras) {
+  for (int c = 0; c < n; c++)
+    if (!nvbx_pose_in_range(T_L_C + 16 * c, m->p.voxel_size * 8.0f, m->p.sphere_tracing_max_ray_length_m + m->p.max_integration_distance_m)) {
+      set_error("integrate color: T_L_C is not finite or lies outside the addressable block range (+-2^20 blocks)"); return NVBX_E_INVALID; }
   NVBX_HIP(hipSetDevice(m->device));
   if (m->p.projective_layer_type == 1) return NVBX_OK;      // occupancy mappers carry no colour (the occlusion test sphere-traces a TSDF)
   if (m->flush_edt()) return NVBX_E_DEVICE;      // a held-back EDT must precede this launch's marking pass (it reads the site masks)
-  Frame f = m->make_frame(T_L_C, camera, rows, cols, m->p.sphere_tracing_subsampling);
+  FrameSetC<Pix, NB> fs{}; fs.n = n;
+  PoseSet<NB> ps{}; ps.n = n;
+  for (int c = 0; c < n; c++) { fs.f[c] = m->make_frame(T_L_C + 16 * c, cameras + c, rows, cols, m->p.sphere_tracing_subsampling); fs.img[c] = imgs[c]; ps.f[c] = fs.f[c]; }
+  const Frame& f = fs.f[0];
   const int32_t srows = rows / f.subsample, scols = cols / f.subsample;
   if (srows < 2 || scols < 2) { set_error("colour image too small for the sphere-tracing subsampling"); return NVBX_E_INVALID; }
-  if ((int64_t)srows * scols > m->synth_cap) {
+  if ((int64_t)srows * scols * n > m->synth_cap) {
     NVBX_HIP(hipStreamSynchronize(m->stream));
     if (m->synth) NVBX_HIP(hipFree(m->synth));
     m->synth = nullptr; m->synth_cap = 0;
-    NVBX_HIP(hipMalloc(&m->synth, (size_t)srows * scols * 4));
-    m->synth_cap = (int64_t)srows * scols;
+    NVBX_HIP(hipMalloc(&m->synth, (size_t)srows * scols * n * 4));
+    m->synth_cap = (int64_t)srows * scols * n;
   }
-  m->synth_rows = srows; m->synth_cols = scols;
-  const int64_t nthreads = (int64_t)srows * scols * RAY_LANES;
-  NVBX_LAUNCH(m, k_sphere_trace, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), m->d, f, m->synth, srows, scols, m->p.sphere_tracing_max_steps,
+  m->synth_rows = srows; m->synth_cols = scols; m->synth_last = n - 1;
+  // one 256-thread workgroup per 8 x 4 patch of rays, NSH x ceil(patches / NSH) workgroups per camera (XCD-banded numbering, see the kernel)
+  const int st_patches = ((scols + 7) / 8) * ((srows + (256 / RAY_LANES / 8) - 1) / (256 / RAY_LANES / 8));
+  NVBX_LAUNCH(m, (k_sphere_trace<NB>), dim3((unsigned)(NSH * ((st_patches + NSH - 1) / NSH) * n)), dim3(256), m->d, ps, m->synth, srows, scols, m->p.sphere_tracing_max_steps,
                      m->p.sphere_tracing_max_ray_length_m, m->p.sphere_tracing_surface_eps_vox * m->p.voxel_size);
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);     // one resident batch of 512-thread workgroups
   // ESDF site marking of the blocks dirtied since the last marking pass rides in this launch (256 extra single-wavefront
@@ -261,7 +305,7 @@ static int integrate_color_impl(nvbx_mapper* m, Pix rgb_dev, int32_t rows, int32
   int mark_wg = 0;
   EsdfArgs ea = m->make_esdf_args();
   ImportArgs imp{};
-  const bool own = m->p.esdf_mode == 0 && m->dirty_since_mark && !m->premark_consumed && ea.bz_hi >= ea.bz_lo && ea.bz_hi - ea.bz_lo + 1 <= 63;
+  const bool own = m->p.esdf_mode == 0 && m->p.esdf_propagation == 0 && m->dirty_since_mark && !m->premark_consumed && ea.bz_hi >= ea.bz_lo && ea.bz_hi - ea.bz_lo + 1 <= 63;
   if (own || m->import_pending) {
     m->mark_pass++; ea.mark_pass = m->mark_pass; m->unresolved_marks = true;
     if (own) { mark_wg = 256; m->dirty_since_mark = false; m->premark_consumed = true; }
@@ -272,7 +316,7 @@ static int integrate_color_impl(nvbx_mapper* m, Pix rgb_dev, int32_t rows, int32
       mark_wg += imp.n_wg; m->import_pending = false;
     }
   }
-  NVBX_LAUNCH(m, (k_integrate_color<Pix>), dim3(grid + mark_wg), dim3(512), m->d, f, rgb_dev, m->synth, srows, scols, m->mesh_list_live(), (int32_t)mark_wg, ea, imp);
+  NVBX_LAUNCH(m, (k_integrate_color<Pix, NB>), dim3(grid + mark_wg), dim3(512), m->d, fs, m->synth, srows, scols, m->mesh_list_live(), (int32_t)mark_wg, ea, imp);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }
@@ -281,13 +325,26 @@ extern "C" int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int3
                                     const nvbx_camera* camera) {
   if (!m || !rgb_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_color: invalid argument"); return NVBX_E_INVALID; }
   if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_color: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
-  return integrate_color_impl(m, PixRgb8{rgb_dev}, rows, cols, T_L_C, camera);
+  const PixRgb8 img{rgb_dev};
+  return integrate_colors<PixRgb8, 1>(m, 1, &img, rows, cols, T_L_C, camera);
 }
 extern "C" int nvbx_integrate_color_bgra8(nvbx_mapper* m, const uint8_t* bgra_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                           const nvbx_camera* camera) {
   if (!m || !bgra_dev || !T_L_C || !camera || rows <= 0 || cols <= 0 || ((uintptr_t)bgra_dev & 3)) { set_error("nvbx_integrate_color_bgra8: invalid argument"); return NVBX_E_INVALID; }
   if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_color_bgra8: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
-  return integrate_color_impl(m, PixBgra8{reinterpret_cast<const uint32_t*>(bgra_dev)}, rows, cols, T_L_C, camera);
+  const PixBgra8 img{reinterpret_cast<const uint32_t*>(bgra_dev)};
+  return integrate_colors<PixBgra8, 1>(m, 1, &img, rows, cols, T_L_C, camera);
+}
+// Up to NVBX_MAX_BATCH colour frames (rgb8, same image size) in ONE launch set: see include/nvblox_hip.h
+extern "C" int nvbx_integrate_color_batch(nvbx_mapper* m, int32_t n, const uint8_t* const* rgb_dev, int32_t rows, int32_t cols, const float* T_L_C,
+                                          const nvbx_camera* cameras) {
+  if (!m || n < 1 || n > MAX_BATCH || !rgb_dev || !T_L_C || !cameras || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_color_batch: invalid argument (1 <= n <= 8)"); return NVBX_E_INVALID; }
+  for (int c = 0; c < n; c++)
+    if (!rgb_dev[c] || !nvbx_camera_matches(cameras + c, rows, cols)) { set_error("nvbx_integrate_color_batch: every camera's width/height must equal the images' cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
+  if (n == 1) return nvbx_integrate_color(m, rgb_dev[0], rows, cols, T_L_C, cameras);
+  PixRgb8 imgs[MAX_BATCH];
+  for (int c = 0; c < n; c++) imgs[c] = PixRgb8{rgb_dev[c]};
+  return integrate_colors<PixRgb8, MAX_BATCH>(m, n, imgs, rows, cols, T_L_C, cameras);
 }
 
 extern "C" int nvbx_get_synthetic_depth(nvbx_mapper* m, float* out_host, int64_t capacity, int32_t* rows, int32_t* cols) {
@@ -296,7 +353,7 @@ extern "C" int nvbx_get_synthetic_depth(nvbx_mapper* m, float* out_host, int64_t
   const int64_t n = (int64_t)m->synth_rows * m->synth_cols;
   if (!out_host || n == 0) return NVBX_OK;
   if (n > capacity) return NVBX_E_CAPACITY;
-  NVBX_HIP(hipMemcpyAsync(out_host, m->synth, n * 4, hipMemcpyDeviceToHost, m->stream));
+  NVBX_HIP(hipMemcpyAsync(out_host, m->synth + (size_t)m->synth_last * n, n * 4, hipMemcpyDeviceToHost, m->stream));    // (a batch: its last camera's image)
   NVBX_HIP(hipStreamSynchronize(m->stream));
   return NVBX_OK;
 }

@@ -50,7 +50,7 @@ __device__ inline void decay_flush(const DMap& m, DecayQueues* dq, const int32_t
 // `thresh` carry the log-odds steps of the free / occupied regions; every value moves towards 0 and stops there; a block lives
 // while any value != 0) -- [U] OccupancyDecayIntegrator, Mapper::decayOccupancyAllVoxels (nvblox_node.cpp:925-929).
 template <bool OCC>
-__global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, int32_t mesh_list,
+__global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, uint32_t exclude_mask, int32_t mesh_list,
                                                int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc, int32_t* cleared_idx) {
   __shared__ int s_alive[2][DB];                         // by iteration parity: no barrier between the books of one iteration and the loads of the next
   __shared__ DecayQueues dq;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thres
 #pragma unroll
       for (int j = 0; j < DB; j++) ent[j] = act[j] ? m.slot_entry[base + j] : 0u;
 #pragma unroll
-      for (int j = 0; j < DB; j++) if (act[j] && m.table[ent[j]].stamp == exclude_stamp) act[j] = false;
+      for (int j = 0; j < DB; j++) if (act[j]) { const uint32_t st = m.table[ent[j]].stamp; if (stamp_frame(st) == exclude_stamp && (st & exclude_mask)) act[j] = false; }
     }
     // this iteration's voxels are requested before the barrier: seven wavefronts stream on while lanes of wavefront 0 still keep
     // the previous iteration's books (returning atomics)
@@ -275,7 +275,7 @@ extern "C" int nvbx_decay_occupancy(nvbx_mapper* m) {
   EsdfArgs ea = m->make_esdf_args();
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
   NVBX_LAUNCH(m, k_decay<true>, dim3((unsigned)std::min<int64_t>(m->capacity, 2048)), dim3(512), m->d,
-              log_odds(m->p.free_region_decay_probability), log_odds(m->p.occupied_region_decay_probability), 0u, (int32_t)m->mesh_list_live(),
+              log_odds(m->p.free_region_decay_probability), log_odds(m->p.occupied_region_decay_probability), 0u, 0u, (int32_t)m->mesh_list_live(),
               ea.bz_lo, ea.bz_hi, ea.bz_out, 0.0f, m->cleared_idx);
   return rebuild_table(m);
 }
@@ -291,7 +291,7 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   EsdfArgs ea = m->make_esdf_args();
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
   NVBX_LAUNCH(m, k_decay<false>, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
-                     exclude_last_view ? m->last_camera_view_frame : 0u, m->mesh_list_live(), ea.bz_lo, ea.bz_hi, ea.bz_out,
+                     exclude_last_view ? m->last_camera_view_frame : 0u, m->last_camera_view_mask, m->mesh_list_live(), ea.bz_lo, ea.bz_hi, ea.bz_out,
                      m->p.truncation_distance_vox * m->p.voxel_size, m->cleared_idx);
   return rebuild_table(m);
 }

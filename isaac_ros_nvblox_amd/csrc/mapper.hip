@@ -52,12 +52,14 @@ __global__ void k_collect_indices(DMap m, uint32_t layer, int32_t* out, int32_t 
 }
 __global__ void k_zero_tmp(DMap m) { m.counters[C_TMP] = 0; }
 
-// view list ({slot, x, y, z} records of one frame) -> Index3D
-__global__ void k_viewlist_to_indices(DMap m, const int4* list, int32_t count_idx, int32_t* out, int32_t cap) {
+// view list ({slot, x, y, z} records of one frame) -> Index3D.  cam_mask != 0 (the frame was a batch): only the blocks the
+// cameras of the mask had in view -- "the last depth view" of a batch is its last camera's, as separate calls would leave it.
+__global__ void k_viewlist_to_indices(DMap m, const int4* list, int32_t count_idx, uint32_t cam_mask, int32_t* out, int32_t cap) {
   int32_t n = m.counters[count_idx]; if (n > cap) n = cap;
   for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int4 r = list[i];
-    const bool ok = slot_ok((uint32_t)r.x) && m.slot_flags[(uint32_t)r.x];
+    bool ok = slot_ok((uint32_t)r.x) && m.slot_flags[(uint32_t)r.x];
+    if (ok && cam_mask && !(m.table[m.slot_entry[(uint32_t)r.x]].stamp & cam_mask)) ok = false;
     out[3 * i] = ok ? r.y : INT32_MIN; out[3 * i + 1] = ok ? r.z : INT32_MIN; out[3 * i + 2] = ok ? r.w : INT32_MIN;
   }
 }
@@ -485,16 +487,17 @@ extern "C" int64_t nvbx_last_depth_view(nvbx_mapper* m, nvbx_index3d* out, int64
   if (!m) return NVBX_E_INVALID;
   if (m->last_view_frame == 0) return 0;
   if (m->join_side()) return NVBX_E_DEVICE;
-  NVBX_LAUNCH(m, k_viewlist_to_indices, dim3(64), dim3(256), m->d, (const int4*)m->view_list, C_VIEW_COUNT + (int)(m->last_view_frame & 3), m->export_idx, (int32_t)m->capacity);
+  const uint32_t cam_mask = m->last_view_batch > 1 ? (1u << (m->last_view_batch - 1)) : 0u;
+  NVBX_LAUNCH(m, k_viewlist_to_indices, dim3(64), dim3(256), m->d, (const int4*)m->view_list, C_VIEW_COUNT + (int)(m->last_view_frame & 3), cam_mask, m->export_idx, (int32_t)m->capacity);
   if (m->fetch_counters()) return NVBX_E_DEVICE;
   int64_t n = m->h_counters[C_VIEW_COUNT + (m->last_view_frame & 3)]; if (n > m->capacity) n = m->capacity;
+  std::vector<nvbx_index3d> tmp((size_t)std::max<int64_t>(n, 1));
+  if (n > 0) NVBX_HIP(hipMemcpy(tmp.data(), m->export_idx, (size_t)n * 12, hipMemcpyDeviceToHost));
+  tmp.resize((size_t)n);
+  tmp.erase(std::remove_if(tmp.begin(), tmp.end(), [](const nvbx_index3d& i) { return i.x == INT32_MIN; }), tmp.end());   // deallocated since / not in the mask
+  n = (int64_t)tmp.size();
   const int64_t k = std::min<int64_t>(n, capacity);
-  if (out && k > 0) {
-    std::vector<nvbx_index3d> tmp((size_t)n);
-    NVBX_HIP(hipMemcpy(tmp.data(), m->export_idx, (size_t)n * 12, hipMemcpyDeviceToHost));
-    sort_indices(tmp.data(), n);
-    memcpy(out, tmp.data(), (size_t)k * 12);
-  }
+  if (out && k > 0) { sort_indices(tmp.data(), n); memcpy(out, tmp.data(), (size_t)k * 12); }
   return n;
 }
 extern "C" int64_t nvbx_last_color_view(nvbx_mapper* m, nvbx_index3d* out, int64_t capacity) {

@@ -62,6 +62,12 @@ __device__ inline void publish_band(uint32_t* slot_flags, uint32_t slot, int tid
 #endif
 
 struct Entry { u64 key; uint32_t slot; uint32_t stamp; };
+// Entry::stamp = (view frame id << 8) | camera mask: the depth frame (or batch of up to 8 camera frames integrated by ONE launch set,
+// nvbx_integrate_depth_batch) that last had the block in view, and which cameras of that batch saw it.  Frame ids are 24 bits
+// (1 .. STAMP_FRAME_MAX; the host resets every stamp when the counter would wrap); STAMP_NEVER = all ones never matches.
+constexpr uint32_t STAMP_FRAME_MAX = 0xFFFFF0u;
+constexpr int MAX_BATCH = 8;
+__host__ __device__ inline uint32_t stamp_frame(uint32_t s) { return s >> 8; }
 
 // counters[] indices (device int32 array, mirrored to pinned host memory on demand)
 enum {
@@ -139,7 +145,8 @@ struct Frame {
   int32_t ws_type; float ws_min[3], ws_max[3];   // workspace bounds of the view calculator (0 = unbounded)
   int32_t subsample;        // raycast / sphere-tracing subsampling
   int32_t n_ray_rows, n_ray_cols;
-  uint32_t frame_id;
+  uint32_t frame_id;        // 24-bit view frame id (Entry::stamp)
+  uint32_t cam_bit;         // 1 << index of this camera in its batch (1 for a single frame)
 };
 
 __host__ __device__ inline u64 pack_key(int32_t x, int32_t y, int32_t z) {

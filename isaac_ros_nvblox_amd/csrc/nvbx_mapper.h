@@ -79,7 +79,7 @@ struct nvbx_mapper {
   // depth preprocessing scratch (dilated depth image)
   float* depth_pre = nullptr; int64_t depth_pre_cap = 0;
   // colour scratch
-  float* synth = nullptr; int64_t synth_cap = 0; int32_t synth_rows = 0, synth_cols = 0;
+  float* synth = nullptr; int64_t synth_cap = 0; int32_t synth_rows = 0, synth_cols = 0, synth_last = 0;
   // mesh arena
   float* mesh_vert = nullptr; float* mesh_nrm = nullptr; uint8_t* mesh_col = nullptr; int32_t* mesh_tri = nullptr;
   nvbx::MeshRecord* mesh_rec = nullptr;
@@ -125,6 +125,8 @@ struct nvbx_mapper {
   // frame stamp of the last CAMERA depth frame: decayTsdfExcludeLastView<Camera> spares the camera's view only -- a LiDAR scan in
   // between must not take its place (nvblox_node.cpp:931-936: 'lidar views are not excluded')
   uint32_t last_camera_view_frame = 0;
+  uint32_t last_camera_view_mask = 1;  // camera bit (Entry::stamp) of the last camera of that frame / batch
+  int32_t last_view_batch = 1;         // frames in the last depth launch set
   // C-ABI helpers implemented across the .hip files
   nvbx::Frame make_frame(const float T_L_C[16], const nvbx_camera* cam, int32_t rows, int32_t cols, int32_t subsample) const;
   nvbx::EsdfArgs make_esdf_args() const;

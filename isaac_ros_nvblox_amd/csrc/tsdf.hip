@@ -124,18 +124,29 @@ __device__ inline void unpack_key(u64 key, int32_t* x, int32_t* y, int32_t* z) {
   *z = (int32_t)((key >> 42) & 0x1FFFFFull) - (1 << 20);
 }
 
-// One block key -> HBM: insert-if-absent, stamp the entry with this frame, and report whether THIS call was the first
-// of the frame to do so (the caller then appends {slot, x, y, z} to the view list exactly once).  The common case -- the
+// Claim an entry's stamp word for (frame, camera bit); `cur` = the word as last seen.  True iff THIS call moved the entry to the
+// frame (the caller then appends the block to the view list exactly once); otherwise it only makes sure the camera's bit is set.
+__device__ inline bool stamp_claim(uint32_t* p, uint32_t cur, uint32_t frame_id, uint32_t cam_bit) {
+  const uint32_t want = (frame_id << 8) | cam_bit;
+  for (;;) {
+    if (stamp_frame(cur) == frame_id) { if (!(cur & cam_bit)) atomicOr(p, cam_bit); return false; }
+    const uint32_t old = atomicCAS(p, cur, want);
+    if (old == cur) return true;
+    cur = old;                          // another tile got there first (or `cur` was a guess): look again
+  }
+}
+// One block key -> HBM: insert-if-absent, stamp the entry with this frame (and this camera's bit), and report whether THIS call was
+// the first of the frame to do so (the caller then appends {slot, x, y, z} to the view list exactly once).  The common case -- the
 // block exists and a neighbouring tile has stamped it already -- is ONE 16-B load: key, slot and stamp arrive together.
-__device__ inline bool mark_block(const DMap& m, u64 key, uint32_t frame_id, int4* rec_out) {
+__device__ inline bool mark_block(const DMap& m, u64 key, uint32_t frame_id, uint32_t cam_bit, int4* rec_out) {
   int32_t x, y, z; unpack_key(key, &x, &y, &z);
   uint32_t h = table_pos(m, x, y, z);
-  uint32_t slot = SLOT_INVALID;
+  uint32_t slot = SLOT_INVALID, cur = STAMP_NEVER;
   bool found = false;
   for (uint32_t probe = 0; probe <= m.mask; ++probe) {
     const uint4 e = *reinterpret_cast<const uint4*>(&m.table[h]);
     const u64 k = ((u64)e.y << 32) | (u64)e.x;
-    if (k == key) { if (e.w == frame_id) return false; slot = e.z; found = true; break; }
+    if (k == key) { if (stamp_frame(e.w) == frame_id && (e.w & cam_bit)) return false; slot = e.z; cur = e.w; found = true; break; }
     if (k == KEY_EMPTY) break;           // (may be a stale EMPTY: hash_insert's CAS is the truth)
     h = (h + 1) & m.mask;
   }
@@ -145,7 +156,7 @@ __device__ inline bool mark_block(const DMap& m, u64 key, uint32_t frame_id, int
     if (hi < 0) return false;
     h = (uint32_t)hi;
   }
-  if (atomicExch(&m.table[h].stamp, frame_id) == frame_id) return false;
+  if (!stamp_claim(&m.table[h].stamp, cur, frame_id, cam_bit)) return false;
   while (slot == SLOT_INVALID) slot = ld_slot_acquire(&m.table[h]);     // the inserting lane publishes right after its CAS
   *rec_out = make_int4((int32_t)slot, x, y, z);
   return true;
@@ -239,10 +250,11 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
       for (int q = 0; q < PD; q++) e[r][q] = *reinterpret_cast<const uint4*>(&m.table[(h[r] + q) & m.mask]);
     }
     // (B) resolve + (C) stamp exchanges in flight
-    bool fast[R], first[R]; uint32_t old[R], slot[R]; int4 rec[R];
+    bool fast[R], first[R], claim[R]; uint32_t old[R], seen[R], slot[R], hpos[R]; int4 rec[R];
+    const uint32_t want = (f.frame_id << 8) | f.cam_bit;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      fast[r] = false; first[r] = false; old[r] = f.frame_id; slot[r] = SLOT_INVALID; rec[r] = make_int4(0, 0, 0, 0);
+      fast[r] = false; first[r] = false; claim[r] = false; old[r] = 0u; seen[r] = 0u; hpos[r] = 0u; slot[r] = SLOT_INVALID; rec[r] = make_int4(0, 0, 0, 0);
       if (r < rounds && have[r]) {
         uint32_t hh = h[r], st = 0; bool open = true;        // open: no EMPTY entry seen yet on the probe chain
 #pragma unroll
@@ -252,17 +264,21 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
           if (kq == KEY_EMPTY) open = false;
         }
         if (slot[r] == SLOT_INVALID) fast[r] = false;              // being inserted right now: general path waits for the slot
-        if (fast[r] && st != f.frame_id) old[r] = atomicExch(&m.table[hh].stamp, f.frame_id);
+        if (fast[r]) {
+          hpos[r] = hh; seen[r] = st;
+          if (stamp_frame(st) != f.frame_id) { claim[r] = true; old[r] = atomicCAS(&m.table[hh].stamp, st, want); }   // the returning atomics of a pass: in flight together
+          else if (!(st & f.cam_bit)) atomicOr(&m.table[hh].stamp, f.cam_bit);     // stamped by another camera of this batch: add our bit (not waited for)
+        }
       }
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
       if (r < rounds && have[r]) {
         if (fast[r]) {
-          first[r] = old[r] != f.frame_id;
+          first[r] = claim[r] && (old[r] == seen[r] || stamp_claim(&m.table[hpos[r]].stamp, old[r], f.frame_id, f.cam_bit));   // (a lost CAS: another tile claimed it, add our bit)
           if (first[r]) { int32_t x, y, z; unpack_key(key[r], &x, &y, &z); rec[r] = make_int4((int32_t)slot[r], x, y, z); }
         } else {
-          first[r] = mark_block(m, key[r], f.frame_id, &rec[r]);     // longer probe chain, new block, or slot not published yet
+          first[r] = mark_block(m, key[r], f.frame_id, f.cam_bit, &rec[r]);     // longer probe chain, new block, or slot not published yet
         }
       }
     }
@@ -288,8 +304,13 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
 
 // Workgroups [0, n_edt_wg) (camera launches only, when an EDT was held back by updateEsdf) are EDT workers with all four
 // wavefronts -- dispatched first: the EDT is the longer chain; the workgroups after them mark the view (first wavefront only).
-template <typename Img, typename Sensor>
-__global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, Frame f, Img depth, Sensor sensor, int4* view_list, int32_t list_cap,
+// The frames of one launch set: ONE depth frame, or a batch of up to MAX_BATCH camera frames of the same image size that
+// nvbx_integrate_depth_batch integrates with one view-marking launch and one TSDF-update launch (the reference feeds up to four
+// cameras through one mapper, one integrateDepth call each: nvblox_node.hpp:298-332).  Kernel argument (SGPRs / scalar loads).
+template <typename Img, int NB> struct FrameSet { Frame f[NB]; Img img[NB]; int32_t n; };
+
+template <typename Img, typename Sensor, int NB>
+__global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet<Img, NB> fs, Sensor sensor, int4* view_list, int32_t list_cap,
                                                                 int32_t reset_esdf_dirty, int32_t n_edt_wg, EsdfArgs ea) {
   constexpr int LSET = Sensor::kSetSize, FR = Sensor::kFlushRounds;
   constexpr size_t kMarkBytes = 2 * LSET * sizeof(u64);
@@ -307,20 +328,30 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, Frame f,
   const int lane = threadIdx.x;
   constexpr int TR = Sensor::kTileRows, TC = Sensor::kTileCols, NSEG = Sensor::kSegments;
   static_assert(TR * TC * NSEG <= 64, "one wavefront per tile");
-  const int tiles_x = (f.n_ray_cols + TC - 1) / TC;
-  const int tile = (int)blockIdx.x - (Sensor::kThreads == 256 ? n_edt_wg : 0);
+  const Frame& f0 = fs.f[0];                    // (image size, subsampling and view frame id are the same for every frame of a batch)
+  const int tiles_x = (f0.n_ray_cols + TC - 1) / TC, tiles_y = (f0.n_ray_rows + TR - 1) / TR;
+  // XCD-aware numbering: workgroups go round-robin over the 8 XCDs (each with its own L2), so the tiles of one XCD (wg & 7) are a
+  // contiguous band of tile rows -- neighbouring tiles share most of their blocks, i.e. their hash lines (n_edt_wg is a multiple of 8)
+  const int wg_all = (int)blockIdx.x - (Sensor::kThreads == 256 ? n_edt_wg : 0);
+  const int n_tiles = tiles_x * tiles_y, per_xcd = (n_tiles + NSH - 1) / NSH;
+  const int cam = NB > 1 ? wg_all / (NSH * per_xcd) : 0;        // batch: NSH * per_xcd workgroups per camera, camera after camera
+  const int wg = wg_all - cam * (NSH * per_xcd);
+  const Frame& f = fs.f[cam];
+  const Img& depth = fs.img[cam];
+  const int tile = (wg & (NSH - 1)) * per_xcd + (wg >> 3);
+  const bool tile_ok = (wg >> 3) < per_xcd && tile < n_tiles && cam < fs.n;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int ray = lane / NSEG, seg = lane % NSEG;
   const int ri = ty * TR + ray / TC, ci = tx * TC + ray % TC;
-  bool active = ray < TR * TC && ri < f.n_ray_rows && ci < f.n_ray_cols;
+  bool active = tile_ok && ray < TR * TC && ri < f.n_ray_rows && ci < f.n_ray_cols;
   // the ray's depth pixel is requested first: its HBM round trip overlaps the LDS set initialisation
   int prow = ri * f.subsample; if (prow >= f.rows) prow = f.rows - 1;
   int pcol = ci * f.subsample; if (pcol >= f.cols) pcol = f.cols - 1;
   const float d = active ? depth((int64_t)prow * f.cols + pcol) : 0.0f;
   for (int i = lane; i < LSET; i += 64) lset[i] = KEY_EMPTY;
-  if (tile == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
+  if (wg_all == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
   // an ESDF dirty list already consumed by a marking pass (fused into integrateColor) is emptied before k_integrate_tsdf appends
-  if (reset_esdf_dirty && tile == 0 && lane < NSH) *shc_at(m, S_LIST_ESDF_DIRTY, lane, 0) = 0;
+  if (reset_esdf_dirty && wg_all == 0 && lane < NSH) *shc_at(m, S_LIST_ESDF_DIRTY, lane, 0) = 0;
   __syncthreads();
 
   int32_t cur[3] = {0, 0, 0}, step[3] = {0, 0, 0}, nsteps = -1;
@@ -379,7 +410,7 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, Frame f,
       }
       if (__ballot(spill)) {                     // probe window exhausted (rare): this key goes to HBM directly
         int4 rec = make_int4(0, 0, 0, 0);
-        const bool first = spill && mark_block(m, key, f.frame_id, &rec);
+        const bool first = spill && mark_block(m, key, f.frame_id, f.cam_bit, &rec);
         view_append(cnt, view_list, list_cap, first, rec, lane);
       }
     }
@@ -400,7 +431,7 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, Frame f,
     nset += (int32_t)__popcll(__ballot(added));
     if (__ballot(spill)) {
       int4 rec = make_int4(0, 0, 0, 0);
-      const bool first = spill && mark_block(m, key, f.frame_id, &rec);
+      const bool first = spill && mark_block(m, key, f.frame_id, f.cam_bit, &rec);
       view_append(cnt, view_list, list_cap, first, rec, lane);
     }
     const bool last = __ballot(k0 + j + 1 <= k1) == 0ull;
@@ -411,11 +442,12 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, Frame f,
 // Dependent-access chain: {view count, view record} -> {depth gather, voxel} -> store.  The record of the first block
 // is fetched speculatively beside the count, the voxel is fetched before the projection decides whether it is needed,
 // and the flag / dirty-list atomics of lane 0 are issued first and consumed last.
-template <typename Img, typename Sensor>
-__global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img depth, Sensor sensor, const int4* view_list, int32_t list_cap,
+template <typename Img, typename Sensor, int NB>
+__global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, FrameSet<Img, NB> fs, Sensor sensor, const int4* view_list, int32_t list_cap,
                                                         int32_t mesh_list, int32_t* view_export, int32_t view_export_cap) {
+  const Frame& f0 = fs.f[0];
   int4 rec = view_list[blockIdx.x];                       // speculative: valid iff blockIdx.x < n (gridDim.x <= list_cap)
-  int32_t n = m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
+  int32_t n = m.counters[C_VIEW_COUNT + (f0.frame_id & 3)];
   if (n > list_cap) n = list_cap;
   const int tid = threadIdx.x;
   // nvbx_set_view_export: the frame's block indices also go to a caller-owned packed buffer [1 + cap][3] (row 0 = count) --
@@ -430,23 +462,36 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img dep
     if (!slot_ok(slot)) continue;
     float2* vp = &m.tsdf[(size_t)slot * 512 + tid];
     const float2 cur_c = *vp;
+    // batch: which cameras had this block in view = the mask k_mark_view left in the entry's stamp (uniform per block)
+    uint32_t cams = 1u;
+    if (NB > 1) cams = __builtin_amdgcn_readfirstlane(m.table[m.slot_entry[slot]].stamp & 0xFFu);
     uint32_t old = 0;
-    if (tid == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH | ((Sensor::kLongRays && !f.occupancy) ? F_BAND_STALE : 0u));
-    float pc[3];
-    apply_rt(f.R_CL, f.t_CL, voxel_center(rec_c.y, vx, f.block_size, f.voxel_size), voxel_center(rec_c.z, vy, f.block_size, f.voxel_size),
-             voxel_center(rec_c.w, vz, f.block_size, f.voxel_size), pc);
-    float ds = 0.0f, vd = 0.0f;
-    const int got = sensor.sample(f, depth, pc, &ds, &vd);
-    float2 fin = cur_c;            // the voxel as this launch leaves it
-    if (f.occupancy) {            // occupancy mapper: the pool holds log-odds (nvbx_internal.h occupancy_update)
-      if (got > 0) *vp = make_float2(occupancy_update(f, cur_c.x, ds, vd), 0.0f);
-    } else {
-      if (got < 0 && f.invalid_decay >= 0.0f) { fin = make_float2(cur_c.x, cur_c.y * f.invalid_decay); *vp = fin; }
-      if (got > 0 && tsdf_fuse(f, &fin, ds, vd)) *vp = fin;
+    if (tid == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH | ((Sensor::kLongRays && !f0.occupancy) ? F_BAND_STALE : 0u));
+    const float lx = voxel_center(rec_c.y, vx, f0.block_size, f0.voxel_size), ly = voxel_center(rec_c.z, vy, f0.block_size, f0.voxel_size),
+                lz = voxel_center(rec_c.w, vz, f0.block_size, f0.voxel_size);
+    float2 fin = cur_c;            // the voxel as this launch leaves it: the cameras' updates applied in order, exactly as separate calls would
+    bool touched = false;
+#pragma unroll 1
+    for (int c = 0; c < (NB > 1 ? fs.n : 1); c++) {
+      if (NB > 1 && !((cams >> c) & 1u)) continue;       // uniform
+      const Frame& f = fs.f[c];
+      float pc[3];
+      apply_rt(f.R_CL, f.t_CL, lx, ly, lz, pc);
+      float ds = 0.0f, vd = 0.0f;
+      const int got = sensor.sample(f, fs.img[c], pc, &ds, &vd);
+      if (f.occupancy) {            // occupancy mapper: the pool holds log-odds (nvbx_internal.h occupancy_update)
+        if (got > 0) { fin = make_float2(occupancy_update(f, fin.x, ds, vd), 0.0f); touched = true; }
+      } else {
+        if (got < 0 && f.invalid_decay >= 0.0f) { fin = make_float2(fin.x, fin.y * f.invalid_decay); touched = true; }
+        if (got > 0 && tsdf_fuse(f, &fin, ds, vd)) touched = true;
+      }
+    }
+    if (touched) *vp = fin;
+    if (!f0.occupancy) {
       // band vote for the colour integrator (F_BAND, nvbx_internal.h): exact, so set AND cleared here, one bit per wavefront
       if (!Sensor::kLongRays) {      // (LiDAR: marked stale above instead)
         // one workgroup per block and a few hundred blocks: a block-wide vote and ONE atomic are cheaper here than a bit per wavefront
-        const int any_band = __syncthreads_or(in_band(fin.x, fin.y, f.trunc) ? 1 : 0);
+        const int any_band = __syncthreads_or(in_band(fin.x, fin.y, f0.trunc) ? 1 : 0);
         if (tid == 0) { if (any_band) atomicOr(&m.slot_flags[slot], F_BAND); else atomicAnd(&m.slot_flags[slot], ~F_BAND); if (old & F_BAND_STALE) atomicAnd(&m.slot_flags[slot], ~F_BAND_STALE); }
       }
     }
@@ -457,30 +502,50 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, Frame f, Img dep
   }
 }
 
-template <typename Img, typename Sensor>
-static int integrate_depth_impl(nvbx_mapper* m, Img img, const Sensor& sensor, const Frame& f0) {
-  Frame f = f0;
-  const int s = f.subsample;
-  f.n_ray_rows = (f.rows + s - 1 + s - 1) / s;   // indices i with i*s < rows + s - 1
-  f.n_ray_cols = (f.cols + s - 1 + s - 1) / s;
-  const int tiles = ((f.n_ray_rows + Sensor::kTileRows - 1) / Sensor::kTileRows) * ((f.n_ray_cols + Sensor::kTileCols - 1) / Sensor::kTileCols);
+template <typename Img, typename Sensor, int NB>
+static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sensor& sensor) {
+  const int s = fs.f[0].subsample;
+  for (int c = 0; c < fs.n; c++) {
+    fs.f[c].n_ray_rows = (fs.f[c].rows + s - 1 + s - 1) / s;   // indices i with i*s < rows + s - 1
+    fs.f[c].n_ray_cols = (fs.f[c].cols + s - 1 + s - 1) / s;
+    fs.f[c].cam_bit = 1u << c;
+  }
+  const Frame& f = fs.f[0];
+  const int n_tiles = ((f.n_ray_rows + Sensor::kTileRows - 1) / Sensor::kTileRows) * ((f.n_ray_cols + Sensor::kTileCols - 1) / Sensor::kTileCols);
+  const int tiles = NSH * ((n_tiles + NSH - 1) / NSH) * fs.n;   // padded: the tiles of one XCD are a contiguous band (k_mark_view); camera after camera
   // a held-back EDT rides in this launch (camera: 256-thread workgroups); the LiDAR launch is 64 threads wide, so flush first
   int edt_wg = 0; EsdfArgs ea = m->edt_args;
   if (m->edt_pending) {
     if (Sensor::kThreads == 256) { edt_wg = 256; m->edt_pending = false; }
     else if (m->flush_edt()) return NVBX_E_DEVICE;
   }
-  NVBX_LAUNCH(m, (k_mark_view<Img, Sensor>), dim3(tiles + edt_wg), dim3(Sensor::kThreads), m->d, f, img, sensor, (int4*)m->view_list, (int32_t)m->capacity,
+  NVBX_LAUNCH(m, (k_mark_view<Img, Sensor, NB>), dim3(tiles + edt_wg), dim3(Sensor::kThreads), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
               (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)edt_wg, ea);
   m->premark_consumed = false; m->dirty_since_mark = true;
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);
-  NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor>), dim3(grid), dim3(512), m->d, f, img, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
+  NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor, NB>), dim3(grid), dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
                      m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap);
   NVBX_HIP(hipGetLastError());
   m->last_view_frame = m->frame_id;
-  if (!Sensor::kLongRays) m->last_camera_view_frame = m->frame_id;
+  if (!Sensor::kLongRays) { m->last_camera_view_frame = m->frame_id; m->last_camera_view_mask = 1u << (fs.n - 1); }   // (a batch: the LAST camera's view, as separate calls would leave it)
+  m->last_view_batch = fs.n;
   if (m->p.projective_layer_type == 2 && m->update_freespace()) return NVBX_E_DEVICE;     // TSDF with freespace (dynamic mapping)
   return m->mark_main();
+}
+// the 24-bit view frame id of Entry::stamp: before it would wrap, every stamp is reset (once per 16.7 M depth frames)
+__global__ void k_reset_stamps(DMap m) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= m.mask; i += gridDim.x * blockDim.x) m.table[i].stamp = STAMP_NEVER;
+  if (blockIdx.x == 0 && threadIdx.x < 4) m.counters[C_VIEW_COUNT + threadIdx.x] = 0;
+}
+static int next_frame_id(nvbx_mapper* m) {
+  if (m->frame_id >= STAMP_FRAME_MAX) {
+    if (m->join_side()) return NVBX_E_DEVICE;
+    NVBX_LAUNCH(m, k_reset_stamps, dim3(1024), dim3(256), m->d);
+    NVBX_HIP(hipGetLastError());
+    m->frame_id = 0; m->last_view_frame = 0; m->last_camera_view_frame = 0;
+  }
+  m->frame_id++;
+  return NVBX_OK;
 }
 
 // [U] DepthPreprocessor (do_depth_preprocessing, depth_preprocessing_num_dilations): invalid-depth regions grow by n pixels.
@@ -502,19 +567,23 @@ __global__ void k_dilate_invalid(Img in, int32_t rows, int32_t cols, int32_t n, 
   }
 }
 
-template <typename Img>
-static int integrate_camera(nvbx_mapper* m, Img img, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera) {
-  if (!nvbx_pose_in_range(T_L_C, m->p.voxel_size * 8.0f, m->p.max_integration_distance_m + 2.0f * m->p.truncation_distance_vox * m->p.voxel_size)) {
-    set_error("integrate depth: T_L_C is not finite or lies outside the addressable block range (+-2^20 blocks)"); return NVBX_E_INVALID; }
+// n camera frames (n = 1: MultiMapper::integrateDepth; n > 1: nvbx_integrate_depth_batch) of one image size -> one launch set
+template <typename Img, int NB>
+static int integrate_cameras(nvbx_mapper* m, int32_t n, const Img* imgs, int32_t rows, int32_t cols, const float* T_L_C /* n x 16 */, const nvbx_camera* cameras) {
+  for (int c = 0; c < n; c++)
+    if (!nvbx_pose_in_range(T_L_C + 16 * c, m->p.voxel_size * 8.0f, m->p.max_integration_distance_m + 2.0f * m->p.truncation_distance_vox * m->p.voxel_size)) {
+      set_error("integrate depth: T_L_C is not finite or lies outside the addressable block range (+-2^20 blocks)"); return NVBX_E_INVALID; }
   NVBX_HIP(hipSetDevice(m->device));
   { const bool pend = m->edt_pending, ipend = m->import_pending; m->edt_pending = false; m->import_pending = false;
     // (join_side would launch a held-back EDT / union step; the EDT rides in k_mark_view instead, the union step stays held back
     //  for the next integrateColor -- it belongs to the NEXT ESDF update and touches nothing this launch reads)
     const int rc = m->join_side(); m->edt_pending = pend; m->import_pending = ipend; if (rc) return NVBX_E_DEVICE; }
-  if (m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0 && m->flush_edt()) return NVBX_E_DEVICE;   // first launch is the dilation
-  m->frame_id++;
-  const Frame f = m->make_frame(T_L_C, camera, rows, cols, m->p.raycast_subsampling_factor);
-  if (m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0) {
+  const bool dilate = m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0;
+  if (dilate && m->flush_edt()) return NVBX_E_DEVICE;   // first launch is the dilation
+  { const int rc = next_frame_id(m); if (rc) return rc; }
+  FrameSet<Img, NB> fs{}; fs.n = n;
+  for (int c = 0; c < n; c++) { fs.f[c] = m->make_frame(T_L_C + 16 * c, cameras + c, rows, cols, m->p.raycast_subsampling_factor); fs.img[c] = imgs[c]; }
+  if (dilate) {             // (single frames only: nvbx_integrate_depth_batch falls back to separate calls)
     const int64_t npx = (int64_t)rows * cols;
     if (npx > m->depth_pre_cap) {
       NVBX_HIP(hipStreamSynchronize(m->stream));
@@ -523,24 +592,42 @@ static int integrate_camera(nvbx_mapper* m, Img img, int32_t rows, int32_t cols,
       NVBX_HIP(hipMalloc(&m->depth_pre, (size_t)npx * 4));
       m->depth_pre_cap = npx;
     }
-    NVBX_LAUNCH(m, (k_dilate_invalid<Img>), dim3((unsigned)std::min<int64_t>((npx + 255) / 256, 4096)), dim3(256), img, rows, cols,
+    NVBX_LAUNCH(m, (k_dilate_invalid<Img>), dim3((unsigned)std::min<int64_t>((npx + 255) / 256, 4096)), dim3(256), imgs[0], rows, cols,
                 m->p.depth_preprocessing_num_dilations, m->depth_pre);
-    return integrate_depth_impl(m, DepthF32{m->depth_pre}, CameraSensor{}, f);
+    FrameSet<DepthF32, 1> fd{}; fd.n = 1; fd.f[0] = fs.f[0]; fd.img[0] = DepthF32{m->depth_pre};
+    return integrate_depth_impl<DepthF32, CameraSensor, 1>(m, fd, CameraSensor{});
   }
-  return integrate_depth_impl(m, img, CameraSensor{}, f);
+  return integrate_depth_impl<Img, CameraSensor, NB>(m, fs, CameraSensor{});
 }
 
 extern "C" int nvbx_integrate_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                     const nvbx_camera* camera) {
   if (!m || !depth_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_depth: invalid argument"); return NVBX_E_INVALID; }
   if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_depth: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
-  return integrate_camera(m, DepthF32{depth_dev}, rows, cols, T_L_C, camera);
+  const DepthF32 img{depth_dev};
+  return integrate_cameras<DepthF32, 1>(m, 1, &img, rows, cols, T_L_C, camera);
 }
 extern "C" int nvbx_integrate_depth_u16mm(nvbx_mapper* m, const uint16_t* depth_mm_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                           const nvbx_camera* camera) {
   if (!m || !depth_mm_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_depth_u16mm: invalid argument"); return NVBX_E_INVALID; }
   if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_depth_u16mm: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
-  return integrate_camera(m, DepthU16mm{depth_mm_dev}, rows, cols, T_L_C, camera);
+  const DepthU16mm img{depth_mm_dev};
+  return integrate_cameras<DepthU16mm, 1>(m, 1, &img, rows, cols, T_L_C, camera);
+}
+// Up to NVBX_MAX_BATCH camera frames (same image size) in ONE launch set: see include/nvblox_hip.h
+extern "C" int nvbx_integrate_depth_batch(nvbx_mapper* m, int32_t n, const float* const* depth_dev, int32_t rows, int32_t cols, const float* T_L_C,
+                                          const nvbx_camera* cameras) {
+  if (!m || n < 1 || n > MAX_BATCH || !depth_dev || !T_L_C || !cameras || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_depth_batch: invalid argument (1 <= n <= 8)"); return NVBX_E_INVALID; }
+  for (int c = 0; c < n; c++)
+    if (!depth_dev[c] || !nvbx_camera_matches(cameras + c, rows, cols)) { set_error("nvbx_integrate_depth_batch: every camera's width/height must equal the images' cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
+  // what a batch cannot express falls back to the separate calls it is defined by: per-frame freespace time stamps, depth dilation
+  if (n == 1 || m->p.projective_layer_type == 2 || (m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0)) {
+    for (int c = 0; c < n; c++) { const int rc = nvbx_integrate_depth(m, depth_dev[c], rows, cols, T_L_C + 16 * c, cameras + c); if (rc) return rc; }
+    return NVBX_OK;
+  }
+  DepthF32 imgs[MAX_BATCH];
+  for (int c = 0; c < n; c++) imgs[c] = DepthF32{depth_dev[c]};
+  return integrate_cameras<DepthF32, MAX_BATCH>(m, n, imgs, rows, cols, T_L_C, cameras);
 }
 
 // ------------------------------------------------------------------------------------------------ LiDAR
@@ -588,14 +675,15 @@ extern "C" int nvbx_integrate_lidar_depth(nvbx_mapper* m, const float* range_dev
   if (m->join_side()) return NVBX_E_DEVICE;
   const nvbx_lidar_model l = nvbx_lidar_make(cols, rows, lidar->min_valid_range_m, lidar->min_elevation_rad, lidar->max_elevation_rad);
   const int rc = ensure_lidar_tables(m, lidar, l); if (rc) return rc;
-  m->frame_id++;
+  { const int rc2 = next_frame_id(m); if (rc2) return rc2; }
   nvbx_camera none{1.f, 1.f, 0.f, 0.f, cols, rows};
-  Frame f = m->make_frame(T_L_C, &none, rows, cols, m->p.raycast_subsampling_factor);
-  f.max_dist = m->p.lidar_max_integration_distance_m;
+  FrameSet<DepthF32, 1> fs{}; fs.n = 1; fs.img[0] = DepthF32{range_dev};
+  fs.f[0] = m->make_frame(T_L_C, &none, rows, cols, m->p.raycast_subsampling_factor);
+  fs.f[0].max_dist = m->p.lidar_max_integration_distance_m;
   LidarSensor s{l, (const float2*)m->lidar_tab, (const float2*)m->lidar_tab + rows,
                 m->p.lidar_linear_interpolation_max_allowable_difference_vox * m->p.voxel_size,
                 m->p.lidar_nearest_interpolation_max_allowable_dist_to_ray_vox * m->p.voxel_size};
-  return integrate_depth_impl(m, DepthF32{range_dev}, s, f);
+  return integrate_depth_impl<DepthF32, LidarSensor, 1>(m, fs, s);
 }
 
 // depthImageFromPointcloudKernel (conversions/pointcloud_conversions.cu:118-150): last writer wins

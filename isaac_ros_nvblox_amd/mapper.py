@@ -220,6 +220,34 @@ class Mapper:
         T = self._T(T_L_C); k = self._cam(cam)
         return (self.lib.nvbx_integrate_color, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k), (d, T, k))
 
+    # -- camera batches (nvbx_integrate_depth_batch / _color_batch): n frames of one image size in ONE launch set
+    def _batch(self, fn, imgs, dtype, poses, cams):
+        n = len(imgs)
+        d = [self._dev(i, dtype) for i in imgs]
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in d])
+        T = np.ascontiguousarray(np.stack([self._T(p) for p in poses]).reshape(n, 16))
+        if not isinstance(cams, (list, tuple)) or not isinstance(cams[0], (list, tuple, Camera)):
+            cams = [cams] * n
+        ks = (Camera * n)(*[self._cam(k) for k in cams])
+        return (fn, n, ptrs, d[0].shape[0], d[0].shape[1], _np_ptr(T), ks, (d, T))
+
+    def prepare_depth_batch(self, depths, poses, cams):
+        return self._batch(self.lib.nvbx_integrate_depth_batch, depths, self._torch.float32, poses, cams)
+
+    def prepare_color_batch(self, rgbs, poses, cams):
+        return self._batch(self.lib.nvbx_integrate_color_batch, rgbs, self._torch.uint8, poses, cams)
+
+    def integrate_prepared_batch(self, a):
+        rc = a[0](self._h, a[1], a[2], a[3], a[4], a[5], a[6])
+        if rc < 0:
+            self._check(rc)
+
+    def integrate_depth_batch(self, depths, poses, cams):
+        a = self.prepare_depth_batch(depths, poses, cams); self.integrate_prepared_batch(a); self._keep = [a]
+
+    def integrate_color_batch(self, rgbs, poses, cams):
+        a = self.prepare_color_batch(rgbs, poses, cams); self.integrate_prepared_batch(a); self._keep_c = [a]
+
     def integrate_prepared(self, a):
         rc = a[0](self._h, a[1], a[2], a[3], a[4], a[5])
         if rc < 0:
