@@ -41,6 +41,12 @@ struct Vector3i {
   }
 };
 using Index3D = Vector3i;
+struct Vector2f {
+  float v[2] = {0.f, 0.f};
+  Vector2f() = default;
+  Vector2f(float x, float y) : v{x, y} {}
+  float x() const { return v[0]; } float y() const { return v[1]; }
+};
 static_assert(sizeof(Vector3f) == 12 && sizeof(Index3D) == 12, "Eigen-compatible sizes");
 
 // nvblox_rviz_plugin/include/nvblox_rviz_plugin/nvblox_hash_utils.h:40-50 (copy of nvblox/core/hash.h in the reference)
@@ -50,6 +56,19 @@ struct Index3DHash {
   std::size_t operator()(const Index3D& index) const {
     return static_cast<unsigned int>(index.x() + index.y() * sl + index.z() * sl2);
   }
+};
+
+// nvblox::Plane as the node's ground-plane visualisation reads it (visualization.cpp:43-69: getHeightAtXY): n . p + d = 0
+class Plane {
+ public:
+  Plane() = default;
+  Plane(const Vector3f& normal, float d) : n_(normal), d_(d) {}
+  const Vector3f& normal() const { return n_; }
+  float d() const { return d_; }
+  float getHeightAtXY(const Vector2f& xy) const { return n_.z() != 0.f ? -(n_.x() * xy.x() + n_.y() * xy.y() + d_) / n_.z() : 0.f; }
+ private:
+  Vector3f n_{0.f, 0.f, 1.f};
+  float d_ = 0.f;
 };
 
 // Eigen::Isometry3f stand-in: column-major 4x4 (Eigen's default storage), rigid transform p_A = T_A_B * p_B.

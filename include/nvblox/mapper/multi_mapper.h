@@ -8,12 +8,24 @@
 #include <cstdlib>
 #include <memory>
 #include <optional>
+#include <vector>
 #include "nvblox/mapper/mapper.h"
 
 namespace nvblox {
 
+// MultiMapper::ground_plane_estimator() as the node's debug visualisation reads it (nvblox_node.cpp:1456,1474).  Ground-plane
+// estimation itself (TSDF zero crossings near the floor + a RANSAC plane) is outside the hot path of this library: the
+// accessors exist so that the node compiles and runs unchanged, and report "no estimate" -- the node then publishes nothing
+// (`if (maybe_tsdf_zero_crossings)` / `if (maybe_plane)`).
+class GroundPlaneEstimator {
+ public:
+  std::optional<std::vector<Vector3f>> tsdf_zero_crossings_ground_candidates() const { return std::nullopt; }
+  std::optional<Plane> ground_plane() const { return std::nullopt; }
+};
+
 class MultiMapper {
  public:
+  const GroundPlaneEstimator& ground_plane_estimator() const { return ground_plane_estimator_; }
   MultiMapper(float voxel_size_m, MappingType mapping_type, EsdfMode esdf_mode, MemoryType memory_type = MemoryType::kDevice,
               std::shared_ptr<CudaStream> cuda_stream = std::make_shared<CudaStreamOwning>(), int64_t block_capacity = Mapper::kDefaultBlockCapacity)
       : mapping_type_(mapping_type), esdf_mode_(esdf_mode), cuda_stream_(cuda_stream) {
@@ -125,6 +137,7 @@ class MultiMapper {
     std::fprintf(stderr, "[nvblox_hip] %s is outside the MI355X hot path of this library (static TSDF + colour + 2-D ESDF + mesh)\n", what);
     std::abort();
   }
+  GroundPlaneEstimator ground_plane_estimator_;
   bool human_ = false, dynamic_ = false;
   MonoImage dynamic_mask_{MemoryType::kDevice};
   Pointcloud dynamic_pointcloud_{MemoryType::kDevice}, deskewed_{MemoryType::kDevice};

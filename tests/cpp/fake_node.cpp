@@ -5,6 +5,7 @@
 // usage: fake_node <frames.bin> [mesh]      prints one JSON line.
 // frames.bin: int32 n, rows, cols; float fu, fv, cu, cv; then n x { float T_L_C[16] row-major, float depth[rows*cols], uint8 rgb[rows*cols*3] }
 #include <cmath>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -334,6 +335,22 @@ int main(int argc, char** argv) {
     } while (node.static_mapper_->numMeshBlocksAwaitingStreaming() > 0 && calls < 100000);
     if (total_blocks != full_blocks || calls < 2 || first_call_blocks == 0 || first_call_blocks >= full_blocks) {
       std::fprintf(stderr, "rationed mesh streaming: %zu of %zu blocks in %zu calls (first call %zu)\n", total_blocks, full_blocks, calls, first_call_blocks); return 1; }
+    // voxel-layer streams under the same limit (layer_publishing.cpp:702-711): nearest blocks first, cut at the budget
+    {
+      BlockExclusionParams ex; ex.exclusion_center_m = Vector3f(0.5f, 0.25f, 1.0f); ex.exclusion_height_m = -1.0f; ex.exclusion_radius_m = -1.0f;
+      node.static_mapper_->serializeSelectedLayers(LayerType::kTsdf | LayerType::kColor, -1.0f, ex);
+      const std::vector<Index3D> all = node.static_mapper_->serializedTsdfLayer()->block_indices;
+      node.static_mapper_->serializeSelectedLayers(LayerType::kTsdf | LayerType::kColor, 4.0f, ex);        // 4 Mbit/s x <= 1 s = 500 kB = 61 blocks of 8204 B
+      const std::vector<Index3D> some = node.static_mapper_->serializedTsdfLayer()->block_indices;
+      const float bs = node.static_mapper_->tsdf_layer().block_size();
+      auto d2 = [&](const Index3D& b) { const Vector3f c = getCenterPositionFromBlockIndex(bs, b); const Vector3f d = c - ex.exclusion_center_m; return d.x() * d.x() + d.y() * d.y() + d.z() * d.z(); };
+      float far_kept = 0.f, near_dropped = 1e30f;
+      for (const Index3D& b : some) far_kept = std::max(far_kept, d2(b));
+      for (const Index3D& b : all) if (!std::binary_search(some.begin(), some.end(), b)) near_dropped = std::min(near_dropped, d2(b));
+      if (some.empty() || some.size() > 61 || some.size() >= all.size() || far_kept > near_dropped ||
+          node.static_mapper_->serializedColorLayer()->block_indices.size() != some.size()) {
+        std::fprintf(stderr, "rationed voxel-layer streaming: %zu of %zu blocks, farthest kept %g nearest dropped %g\n", some.size(), all.size(), far_kept, near_dropped); return 1; }
+    }
   }
   // esdf_mode "3d" (node_params.hpp:90; nvblox_node.cpp:187-190): the ESDF of every voxel, sampled like the EsdfAndGradients service does
   {

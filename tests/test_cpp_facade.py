@@ -224,3 +224,126 @@ def test_host_utilities_of_the_facade(tmp_path):
         and ply[-1].split() == ["0.775000", "0.175000", "-0.275000", "-0.100000"]
     y = open(tmp_path / "nvbx_occ.yaml").read()
     assert "image: nvbx_occ.png" in y and "resolution: 0.05" in y and "origin: [-1.2, 0.4, 0.0]" in y and "occupied_thresh: 0.65" in y and "free_thresh: 0.25" in y
+
+
+# ---------------------------------------------------------------------------------------------- FuserNode over fuser.h + datasets/*
+def write_png(path, arr):
+    """Minimal PNG writer (zlib): uint16 [h, w] grey or uint8 [h, w, 3] RGB, filter 0 -- what the dataset loaders must decode."""
+    import struct
+    import zlib
+    arr = np.asarray(arr)
+    if arr.dtype == np.uint16:
+        h, w = arr.shape; depth, ctype = 16, 0
+        rows = arr.astype(">u2").tobytes()
+        stride = w * 2
+    else:
+        h, w, _ = arr.shape; depth, ctype = 8, 2
+        rows = np.ascontiguousarray(arr, np.uint8).tobytes()
+        stride = w * 3
+    raw = b"".join(b"\x00" + rows[r * stride:(r + 1) * stride] for r in range(h))
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def write_dataset(kind, root, frames, cam):
+    """The on-disk layouts the three loaders read (include/nvblox/datasets/*.h); returns the depth images as the loader will see them."""
+    os.makedirs(root, exist_ok=True)
+    seen = []
+    if kind == "3dmatch":
+        seq = os.path.join(root, "seq-01"); os.makedirs(seq)
+        with open(os.path.join(root, "camera-intrinsics.txt"), "w") as f:
+            f.write("%r 0 %r\n0 %r %r\n0 0 1\n" % (cam[0], cam[2], cam[1], cam[3]))
+        for i, (d, rgb, T) in enumerate(frames):
+            mm = np.round(d * 1000.0).astype(np.uint16); mm[d <= 0] = 65535          # 3DMatch marks invalid depth with 65535
+            write_png(os.path.join(seq, "frame-%06d.depth.png" % i), mm)
+            write_png(os.path.join(seq, "frame-%06d.color.png" % i), rgb)
+            np.savetxt(os.path.join(seq, "frame-%06d.pose.txt" % i), np.asarray(T, np.float64).reshape(4, 4), fmt="%.9g")
+            seen.append(np.where(mm == 65535, np.float32(0), mm.astype(np.float32) * np.float32(1.0 / 1000.0)).astype(np.float32))
+    elif kind == "replica":
+        os.makedirs(os.path.join(root, "results"))
+        with open(os.path.join(root, "cam_params.json"), "w") as f:
+            json.dump({"camera": {"w": cam[4], "h": cam[5], "fx": cam[0], "fy": cam[1], "cx": cam[2], "cy": cam[3], "scale": 6553.5}}, f)
+        with open(os.path.join(root, "traj.txt"), "w") as f:
+            for _, _, T in frames:
+                f.write(" ".join("%.9g" % v for v in np.asarray(T, np.float64).reshape(16)) + "\n")
+        for i, (d, rgb, T) in enumerate(frames):
+            raw = np.round(d * 6553.5).astype(np.uint16)
+            write_png(os.path.join(root, "results", "depth%06d.png" % i), raw)
+            write_png(os.path.join(root, "results", "frame%06d.png" % i), rgb)
+            seen.append((raw.astype(np.float32) * (np.float32(1.0) / np.float32(6553.5))).astype(np.float32))
+    else:   # redwood: 1-based numbering, .log trajectory
+        os.makedirs(os.path.join(root, "depth")); os.makedirs(os.path.join(root, "image"))
+        with open(os.path.join(root, "trajectory.log"), "w") as f:
+            for i, (_, _, T) in enumerate(frames):
+                f.write("%d %d %d\n" % (i, i, i + 1))
+                for row in np.asarray(T, np.float64).reshape(4, 4):
+                    f.write(" ".join("%.9g" % v for v in row) + "\n")
+        for i, (d, rgb, T) in enumerate(frames):
+            mm = np.round(d * 1000.0).astype(np.uint16)
+            write_png(os.path.join(root, "depth", "%05d.png" % (i + 1)), mm)
+            write_png(os.path.join(root, "image", "%05d.png" % (i + 1)), rgb)
+            seen.append((mm.astype(np.float32) * np.float32(1.0 / 1000.0)).astype(np.float32))
+    return seen
+
+
+def test_fake_fuser_node_compiles():
+    subprocess.check_call(["make", "-C", CPP, "fake_fuser_node"], stdout=subprocess.DEVNULL)
+    out = subprocess.run(["ldd", os.path.join(CPP, "fake_fuser_node")], capture_output=True, text=True).stdout
+    assert "libnvblox_hip.so" in out
+
+
+def test_png_round_trip_through_the_dataset_image_loader(tmp_path):
+    """The loaders' PNG decoder (include/nvblox/datasets/image_loader.h) against this writer, incl. a filtered file made by zlib at
+    another level: host-only check through a tiny C++ program."""
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "nvblox/datasets/image_loader.h"\n#include <cstdio>\nint main(int argc, char** argv) { nvblox::datasets::image_io::DecodedImage im;\n'
+                   ' if (!nvblox::datasets::image_io::decode(argv[1], &im)) return 1; unsigned long long s = 0; for (auto v : im.data) s += v;\n'
+                   ' std::printf("%d %d %d %d %llu\\n", im.rows, im.cols, im.channels, im.bit_depth, s); return 0; }\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", str(src), "-o", str(exe), "-lz"])
+    rng = np.random.default_rng(0)
+    a16 = rng.integers(0, 65536, (37, 53), dtype=np.uint16); a8 = rng.integers(0, 256, (19, 31, 3), dtype=np.uint8)
+    write_png(tmp_path / "a16.png", a16); write_png(tmp_path / "a8.png", a8)
+    for p, a, ch, bd in ((tmp_path / "a16.png", a16, 1, 16), (tmp_path / "a8.png", a8, 3, 8)):
+        out = subprocess.run([str(exe), str(p)], capture_output=True, text=True)
+        assert out.returncode == 0
+        r, c, k, b, s = (int(v) for v in out.stdout.split())
+        assert (r, c, k, b) == (a.shape[0], a.shape[1], ch, bd) and s == int(a.astype(np.uint64).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["3dmatch", "replica", "redwood"])
+def test_fuser_node_over_dataset_loaders(hip_lib, tmp_path, kind):
+    """FuserNode (fuser_node.cpp:44-97,202-313 as tests/cpp/fake_fuser_node.cpp) over datasets::<kind>::createFuser on a dataset
+    directory of that layout == the same frames through the ctypes path."""
+    from isaac_ros_nvblox_amd import mapper as M, synthetic as S
+    subprocess.check_call(["make", "-C", CPP, "fake_fuser_node"], stdout=subprocess.DEVNULL)
+    cam = (525.0, 525.0, 319.5, 239.5, 640, 480) if kind == "redwood" else (85.0, 78.0, 81.3, 58.1, 161, 119)
+    fr = H.frames(3, cam, color=True, stride=11)
+    root = str(tmp_path / kind)
+    seen = write_dataset(kind, root, fr, cam)
+    r = subprocess.run([os.path.join(CPP, "fake_fuser_node"), kind, root], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["frames"] == 3 and got["bad_frames"] == 0 and got["color_frames"] == 3
+    g = M.Mapper(M.default_params(), block_capacity=1 << 15)
+    mesh_vertices = 0; mesh_blocks = 0
+    for d, (_, rgb, T) in zip(seen, fr):
+        g.integrate_depth(d, T, cam); g.integrate_color(rgb, T, cam); g.update_color_mesh(); g.update_esdf()
+        m = g.mesh(); mesh_blocks += len(m); mesh_vertices += sum(len(v["vertices"]) for v in m.values())
+    idx = g.block_indices(M.LAYER_TSDF)
+    blocks, _ = g.get_blocks(M.LAYER_TSDF, idx)
+    w = blocks["weight"].astype(np.float64); d_ = blocks["distance"].astype(np.float64)
+    assert got["tsdf_blocks"] == len(idx) and got["tsdf_observed"] == int((w > 0).sum())
+    assert abs(got["tsdf_sum"] - float((d_ * w)[w > 0].sum())) <= 1e-6 * max(1.0, abs(got["tsdf_sum"]))
+    assert got["color_blocks"] == g.num_blocks(M.LAYER_COLOR) and got["esdf_blocks"] == g.num_blocks(M.LAYER_ESDF)
+    assert abs(got["depth_sum"] - float(sum(float(s.astype(np.float64).sum()) for s in seen))) <= 1e-3 * got["depth_sum"] / 1e3 + 1.0
+    assert got["mesh_blocks_sent"] == mesh_blocks and got["mesh_vertices_sent"] == mesh_vertices
+    img, _ = g.esdf_slice_image()
+    assert got["slice_pixels"] == img.size and got["back_projected_points"] > 1000 and got["serialized_tsdf_blocks"] > 50
+    # a directory that is not a dataset: createFuser returns nullptr and the node exits with an error, as the reference does
+    bad = subprocess.run([os.path.join(CPP, "fake_fuser_node"), kind, str(tmp_path / "nothing")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "failed" in bad.stderr
