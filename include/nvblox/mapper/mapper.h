@@ -59,7 +59,7 @@ class BoundingShape {
 
 class Mapper {
  public:
-  static constexpr int64_t kDefaultBlockCapacity = 1 << 16;   // 64 k blocks = 768 MiB of voxel pools in HBM
+  static constexpr int64_t kDefaultBlockCapacity = 0;   // automatic: ~4 % of the free HBM (2^16 .. 2^20 blocks), doubling on demand (nvbx_mapper_create)
 
   Mapper(float voxel_size_m, MemoryType memory_type = MemoryType::kDevice, ProjectiveLayerType projective_layer_type = ProjectiveLayerType::kTsdf,
          std::shared_ptr<CudaStream> cuda_stream = std::make_shared<CudaStreamOwning>(), int64_t block_capacity = kDefaultBlockCapacity,

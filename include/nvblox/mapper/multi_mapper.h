@@ -37,7 +37,7 @@ class MultiMapper {
                                                   cuda_stream, block_capacity, esdf_mode);
     // the foreground (human) mapper is an occupancy mapper (specializations/nvblox_segmentation.yaml:9-22); it is fed by the
     // masked overloads only.  In the static modes it stays empty but valid.
-    foreground_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type, ProjectiveLayerType::kOccupancy, cuda_stream, (human_ || dynamic_) ? block_capacity / 4 : 64, esdf_mode);
+    foreground_mapper_ = std::make_shared<Mapper>(voxel_size_m, memory_type, ProjectiveLayerType::kOccupancy, cuda_stream, (human_ || dynamic_) ? (block_capacity ? block_capacity / 4 : (int64_t)1 << 14) : 64, esdf_mode);      // (grows on demand)
   }
   void setMapperParams(const MapperParams& background, const MapperParams& foreground) { background_mapper_->setMapperParams(background); foreground_mapper_->setMapperParams(foreground); }
   void setMapperParams(const MapperParams& params) { background_mapper_->setMapperParams(params); }   // fuser_node.cpp:94

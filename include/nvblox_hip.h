@@ -161,13 +161,23 @@ typedef struct {
 /* ---- lifetime --------------------------------------------------------------------------------------------------
  * nvblox::MultiMapper(voxel_size, MappingType, EsdfMode, MemoryType::kDevice, shared_ptr<CudaStream>)
  *   nvblox_ros/src/lib/nvblox_node.cpp:187-190, fuser_node.cpp:85-89.  `hip_stream` may be NULL (library-owned stream).
- * block_capacity = number of 8^3 blocks the HBM pools are sized for (3 x 4 KiB per block), 64 .. 2^24.
+ * block_capacity = number of 8^3 blocks the HBM pools are sized for initially (3 x 4 KiB per block), 64 .. 2^24, or 0 = automatic
+ * (about 4 % of the free HBM, 2^16 .. 2^20 blocks); the pools grow on demand, see nvbx_mapper_set_max_capacity.
  * Parameter values the kernels' loop bounds rely on are checked here and in nvbx_mapper_set_params (NVBX_E_INVALID, reason in
  * nvbx_last_error): voxel_size, both integration distances, truncation distance and max_weight > 0 and finite,
  * projective_layer_type in 0..2, esdf_mode in 0..1, occupancy probabilities strictly inside (0, 1). */
 int nvbx_mapper_create(int device, void* hip_stream, const nvbx_mapper_params* params, int64_t block_capacity,
                        nvbx_mapper** out);
 int nvbx_mapper_destroy(nvbx_mapper* m);
+/* Pool growth.  The reference's layers allocate blocks on demand (Layer::allocateBlockAtIndex -- test_esdf_and_gradient_conversions.cpp:87);
+ * here `block_capacity` is the INITIAL size of the HBM pools: before a frame is enqueued the integrate calls look at the number of free
+ * slots the GPU last reported (pinned host memory, no synchronisation) and, below half, double every pool (contents kept, hash rebuilt
+ * on the device; the call synchronises once) up to max_block_capacity (default 2^22, NVBX_MAX_BLOCKS in the environment; at most 2^24).
+ * max_block_capacity <= the current capacity: fixed pools -- an allocation beyond them is dropped and reported through
+ * nvbx_counters::capacity_overflow, never fatal.  Device pointers handed out by nvbx_get_device_view are valid until the next call
+ * that can allocate.  nvbx_mapper_capacity = the current capacity. */
+int nvbx_mapper_set_max_capacity(nvbx_mapper* m, int64_t max_block_capacity);
+int64_t nvbx_mapper_capacity(nvbx_mapper* m);
 /* the offline fuser's parameter values (nvblox_examples_bringup/config/nvblox/fuser.yaml:24-42; decay / workspace values from
  * nvblox_base.yaml:87-107) = the benchmark configuration; pure host function */
 void nvbx_default_params(nvbx_mapper_params* out);

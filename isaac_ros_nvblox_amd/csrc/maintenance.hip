@@ -327,3 +327,130 @@ extern "C" int64_t nvbx_take_cleared_blocks(nvbx_mapper* m, nvbx_index3d* out, i
   NVBX_HIP(hipGetLastError());
   return u;
 }
+
+// ------------------------------------------------------------------------------------------------ pool growth
+// The reference allocates voxel blocks on demand (Layer::allocateBlockAtIndex); here the pools are flat HBM arrays addressed by slot
+// id, so "on demand" = the arrays double before they run out.  Every capacity-sized array is re-allocated at the new size, its
+// contents copied (slot ids, and with them every list entry and record, stay valid), the new slots are pushed on the free stack and
+// the hash table is rebuilt at twice the size on the device.  Rare (a doubling), so it simply synchronises the stream.
+__global__ void k_grow_free_stack(DMap m, uint32_t old_cap, uint32_t new_cap) {
+  const int32_t top = m.counters[C_FREE_TOP];
+  const uint32_t added = new_cap - old_cap;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < added; i += gridDim.x * blockDim.x) m.free_stack[top + i] = new_cap - 1u - i;   // the smallest new id pops first
+}
+__global__ void k_grow_commit(DMap m, int32_t added) { m.counters[C_FREE_TOP] += added; m.host_mirror[0] = m.counters[C_FREE_TOP]; }
+__global__ void k_remap_mesh_records(MeshRecord* rec, int32_t n, int64_t old_vreg, int64_t new_vreg, int64_t old_treg, int64_t new_treg) {
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    MeshRecord r = rec[i];
+    if (r.x == INT32_MIN || r.vbase < 0) continue;
+    const int64_t sv = r.vbase / old_vreg, st = r.tbase / old_treg;
+    r.vbase = (int32_t)(sv * new_vreg + (r.vbase - sv * old_vreg)); r.tbase = (int32_t)(st * new_treg + (r.tbase - st * old_treg));
+    rec[i] = r;
+  }
+}
+
+namespace {
+struct PoolArr { void** p; size_t bytes_per_block; int fill; };
+template <typename T> PoolArr arr(T** p, size_t bpb, int fill) { return PoolArr{reinterpret_cast<void**>(p), bpb, fill}; }
+}  // namespace
+
+int nvbx_mapper::grow_map(int64_t new_cap) {
+  if (new_cap <= capacity) return NVBX_OK;
+  if (new_cap > (1ll << 24)) new_cap = 1ll << 24;
+  const int64_t old_cap = capacity;
+  if (join_side()) return NVBX_E_DEVICE;                     // held-back launches go first: they were sized for the old arrays
+  if (fetch_counters()) return NVBX_E_DEVICE;                // (synchronises; the mesh arena cursors are needed below)
+  // enough HBM?  (voxel pools dominate: 3-4 x 4 KiB per block; old and new copies of ONE array coexist at a time)
+  { size_t free_b = 0, total_b = 0; NVBX_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t need = (size_t)new_cap * 4096 + ((size_t)new_cap - (size_t)old_cap) * (3 * 4096 + (d.freespace ? 8192 : 0) + 512) + (64u << 20);
+    if (free_b < need) { set_error("pool growth: not enough free HBM, the block pools stay at their size"); max_capacity = capacity; return NVBX_OK; } }
+  const uint32_t stamp_bytes = (uint32_t)sizeof(uint32_t);
+  uint32_t* saved = nullptr;
+  NVBX_HIP(hipMalloc(&saved, (size_t)old_cap * stamp_bytes));
+  const unsigned rg = (unsigned)std::min<int64_t>((old_cap + 255) / 256, 2048);
+  NVBX_LAUNCH(this, k_save_stamps, dim3(rg), dim3(256), d, saved);          // view stamps live in the table that is about to be replaced
+  std::vector<PoolArr> arrs = {
+      arr(&d.free_stack, 4, -1), arr(&d.slot_flags, 4, 0), arr(&d.slot_index, 12, 0), arr(&d.slot_entry, 4, 0), arr(&d.slot_stamp, 4, 0xFF),
+      arr(&d.slot_consumed, 4, 0xFF), arr(&d.tsdf, 4096, 0), arr(&d.color, 4096, 0), arr(&d.esdf, 4096, 0), arr(&view_list, 16, -1),
+      arr(&export_idx, 12, -1), arr(&cleared_idx, 12, -1), arr(&d.site_bits, 8, 0), arr(&d.obs_bits, 8, 0), arr(&d.inside_bits, 8, 0),
+      arr(&mesh_rec, sizeof(MeshRecord), -1)};
+  if (d.freespace) arrs.push_back(arr(&d.freespace, 512 * 16, 0));
+  for (const PoolArr& a : arrs) {
+    void* np = nullptr;
+    NVBX_HIP(hipMalloc(&np, a.bytes_per_block * (size_t)new_cap));
+    NVBX_HIP(hipMemcpyAsync(np, *a.p, a.bytes_per_block * (size_t)old_cap, hipMemcpyDeviceToDevice, stream));
+    if (a.fill >= 0) NVBX_HIP(hipMemsetAsync((char*)np + a.bytes_per_block * (size_t)old_cap, a.fill, a.bytes_per_block * (size_t)(new_cap - old_cap), stream));
+    NVBX_HIP(hipStreamSynchronize(stream));
+    NVBX_HIP(hipFree(*a.p));
+    *a.p = np;
+  }
+  {   // work lists: [list][shard][capacity] -- every segment moves to its place in the wider layout (entry counts live in d.shc)
+    int32_t* nl = nullptr;
+    NVBX_HIP(hipMalloc(&nl, (size_t)N_LISTS * NSH * (size_t)new_cap * 4));
+    for (int q = 0; q < N_LISTS * NSH; q++)
+      NVBX_HIP(hipMemcpyAsync(nl + (size_t)q * new_cap, d.lists + (size_t)q * old_cap, (size_t)old_cap * 4, hipMemcpyDeviceToDevice, stream));
+    NVBX_HIP(hipStreamSynchronize(stream));
+    NVBX_HIP(hipFree(d.lists)); d.lists = nl;
+  }
+  {   // mesh arenas: NSH shard regions each; the used prefix of every region (last mesh update) moves, the records are re-based
+    const int64_t new_vcap = std::min<int64_t>(new_cap * 192, 48ll << 20), new_tcap = new_vcap * 2;
+    if (new_vcap > mesh_vert_cap) {
+      const int64_t ovr = mesh_vert_cap / NSH, otr = mesh_tri_cap / NSH, nvr = new_vcap / NSH, ntr = new_tcap / NSH;
+      float* nv = nullptr; float* nn = nullptr; uint8_t* nc = nullptr; int32_t* nt = nullptr;
+      NVBX_HIP(hipMalloc(&nv, new_vcap * 12)); NVBX_HIP(hipMalloc(&nn, new_vcap * 12)); NVBX_HIP(hipMalloc(&nc, new_vcap * 4)); NVBX_HIP(hipMalloc(&nt, new_tcap * 12));
+      if (mesh_epoch) {
+        const int par = (int)((mesh_epoch + 1) & 1);
+        for (int sh = 0; sh < NSH; sh++) {
+          const int64_t uv = std::min<int64_t>((uint32_t)h_shc[((S_MESH_REC + par) * NSH + sh) * SH_STRIDE + 2], ovr);
+          const int64_t ut = std::min<int64_t>((uint32_t)h_shc[((S_MESH_REC + par) * NSH + sh) * SH_STRIDE + 3], otr);
+          if (uv) {
+            NVBX_HIP(hipMemcpyAsync(nv + sh * nvr * 3, mesh_vert + sh * ovr * 3, (size_t)uv * 12, hipMemcpyDeviceToDevice, stream));
+            NVBX_HIP(hipMemcpyAsync(nn + sh * nvr * 3, mesh_nrm + sh * ovr * 3, (size_t)uv * 12, hipMemcpyDeviceToDevice, stream));
+            NVBX_HIP(hipMemcpyAsync(nc + sh * nvr * 4, mesh_col + sh * ovr * 4, (size_t)uv * 4, hipMemcpyDeviceToDevice, stream));
+          }
+          if (ut) NVBX_HIP(hipMemcpyAsync(nt + sh * ntr * 3, mesh_tri + sh * otr * 3, (size_t)ut * 12, hipMemcpyDeviceToDevice, stream));
+        }
+        const int32_t nraw = h_counters[C_MESH_OUT + 4 * par + 0];
+        if (nraw > 0) NVBX_LAUNCH(this, k_remap_mesh_records, dim3(64), dim3(256), mesh_rec, std::min<int32_t>(nraw, (int32_t)old_cap), ovr, nvr, otr, ntr);
+      }
+      NVBX_HIP(hipStreamSynchronize(stream));
+      NVBX_HIP(hipFree(mesh_vert)); NVBX_HIP(hipFree(mesh_nrm)); NVBX_HIP(hipFree(mesh_col)); NVBX_HIP(hipFree(mesh_tri));
+      mesh_vert = nv; mesh_nrm = nn; mesh_col = nc; mesh_tri = nt; mesh_vert_cap = new_vcap; mesh_tri_cap = new_tcap;
+    }
+  }
+  {   // hash table at twice the size, rebuilt from the live slots on the device
+    uint64_t tsz = 1; while (tsz < (uint64_t)new_cap * 2) tsz <<= 1;
+    Entry* nt = nullptr;
+    NVBX_HIP(hipMalloc(&nt, tsz * sizeof(Entry)));
+    NVBX_HIP(hipFree(d.table)); d.table = nt;
+    d.mask = (uint32_t)(tsz - 1);
+    { uint32_t lg = 0; while ((1ull << lg) < tsz) lg++; d.shift = 32u - lg; }
+    NVBX_HIP(hipMemsetAsync(d.table, 0xFF, tsz * sizeof(Entry), stream));
+  }
+  d.capacity = (uint32_t)new_cap; capacity = new_cap;
+  NVBX_LAUNCH(this, k_grow_free_stack, dim3(256), dim3(256), d, (uint32_t)old_cap, (uint32_t)new_cap);
+  NVBX_LAUNCH(this, k_grow_commit, dim3(1), dim3(1), d, (int32_t)(new_cap - old_cap));
+  NVBX_LAUNCH(this, k_reinsert, dim3(rg), dim3(256), d, saved, make_esdf_args().bz_out);
+  NVBX_HIP(hipStreamSynchronize(stream));
+  NVBX_HIP(hipFree(saved));
+  if (view_export_cap > 0) view_export_cap = std::min<int64_t>(view_export_cap, capacity);
+  growths++;
+  return NVBX_OK;
+}
+
+// before a frame is enqueued: fewer than half of the slots free (as of the last frame the GPU has finished) -> double
+int nvbx_mapper::maybe_grow(int64_t extra_blocks_wanted) {
+  if (capacity >= max_capacity) return NVBX_OK;
+  const int64_t free_seen = __atomic_load_n(&h_mirror[0], __ATOMIC_RELAXED);
+  int64_t target = capacity;
+  while (target < max_capacity && (free_seen + (target - capacity) - extra_blocks_wanted) * 2 < target) target *= 2;      // at least half free afterwards
+  if (target > max_capacity) target = max_capacity;
+  if (target == capacity) return NVBX_OK;
+  return grow_map(target);
+}
+extern "C" int nvbx_mapper_set_max_capacity(nvbx_mapper* m, int64_t max_block_capacity) {
+  if (!m) return NVBX_E_INVALID;
+  m->max_capacity = std::max<int64_t>(m->capacity, std::min<int64_t>(max_block_capacity, 1ll << 24));
+  return NVBX_OK;
+}
+extern "C" int64_t nvbx_mapper_capacity(nvbx_mapper* m) { return m ? m->capacity : NVBX_E_INVALID; }

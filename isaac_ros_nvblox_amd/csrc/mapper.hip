@@ -213,6 +213,9 @@ static int alloc_all(nvbx_mapper* m) {
   NVBX_HIP(hipMalloc(&m->staging, m->staging_bytes));
   NVBX_HIP(hipHostMalloc(&m->h_counters, C_NUM * 4));
   NVBX_HIP(hipHostMalloc(&m->h_shc, S_NUM * NSH * SH_STRIDE * 4));
+  NVBX_HIP(hipHostMalloc(&m->h_mirror, 64, hipHostMallocMapped));
+  { void* dp = nullptr; NVBX_HIP(hipHostGetDevicePointer(&dp, m->h_mirror, 0)); d.host_mirror = (int32_t*)dp; }
+  m->h_mirror[0] = (int32_t)cap;
   return NVBX_OK;
 }
 
@@ -233,6 +236,7 @@ static int reset_map(nvbx_mapper* m) {
   NVBX_HIP(hipGetLastError());
   m->dirty_since_mark = false; m->premark_consumed = false; m->mark_pass = 0; m->edt_pending = false; m->import_pending = false;
   m->unresolved_marks = false; m->pass_at_last_edt = 0;
+  if (m->h_mirror) m->h_mirror[0] = (int32_t)m->capacity;
   m->frame_id = 0; m->esdf_epoch = 0; m->mesh_epoch = 0; m->last_view_frame = 0; m->last_camera_view_frame = 0; m->synth_rows = m->synth_cols = 0;
   return NVBX_OK;
 }
@@ -324,13 +328,22 @@ static const char* params_problem(const nvbx_mapper_params* p) {
 
 // ------------------------------------------------------------------------------------------------ C-ABI: lifetime
 extern "C" int nvbx_mapper_create(int device, void* hip_stream, const nvbx_mapper_params* params, int64_t block_capacity, nvbx_mapper** out) {
-  if (!params || !out || block_capacity < 64 || block_capacity > (1ll << 24)) {
-    set_error("nvbx_mapper_create: invalid argument (null pointer, or block_capacity outside 64 .. 2^24)"); return NVBX_E_INVALID;
+  if (!params || !out || (block_capacity != 0 && (block_capacity < 64 || block_capacity > (1ll << 24)))) {
+    set_error("nvbx_mapper_create: invalid argument (null pointer, or block_capacity outside 64 .. 2^24 and not 0 = automatic)"); return NVBX_E_INVALID;
   }
   if (const char* why = params_problem(params)) { set_error(why); return NVBX_E_INVALID; }
   NVBX_HIP(hipSetDevice(device));
+  if (block_capacity == 0) {      // automatic: ~4 % of the free HBM (12.4 KiB per block), 2^16 .. 2^20 blocks (1 M blocks = 12 GiB of a 288 GB MI355X); grows on demand
+    size_t free_b = 0, total_b = 0; NVBX_HIP(hipMemGetInfo(&free_b, &total_b));
+    int64_t want = (int64_t)((double)free_b * 0.04 / 12700.0), cap = 1ll << 16;
+    while (cap * 2 <= want && cap < (1ll << 20)) cap *= 2;
+    block_capacity = cap;
+  }
   nvbx_mapper* m = new nvbx_mapper();
   m->device = device; m->p = *params; m->capacity = block_capacity;
+  // the pools double on demand up to this many blocks (nvbx_mapper_set_max_capacity; NVBX_MAX_BLOCKS in the environment)
+  m->max_capacity = std::max<int64_t>(block_capacity, 1ll << 22);
+  { const char* e = getenv("NVBX_MAX_BLOCKS"); if (e && atoll(e) > 0) m->max_capacity = std::max<int64_t>(block_capacity, std::min<int64_t>(atoll(e), 1ll << 24)); }
   if (hip_stream) { m->stream = (hipStream_t)hip_stream; m->own_stream = false; }
   else { hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking); if (e != hipSuccess) { set_error("hipStreamCreate", e); delete m; return NVBX_E_DEVICE; } m->own_stream = true; }
   // ESDF on a side stream beside colour integration: off by default, NVBX_SIDE_STREAM=1 enables (the
@@ -367,6 +380,7 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   for (hipEvent_t e : m->event_pool) if (e) (void)hipEventDestroy(e);
   if (m->h_counters) (void)hipHostFree(m->h_counters);
   if (m->h_shc) (void)hipHostFree(m->h_shc);
+  if (m->h_mirror) (void)hipHostFree(m->h_mirror);
   if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
   return NVBX_OK;
@@ -550,6 +564,11 @@ extern "C" int nvbx_set_blocks(nvbx_mapper* m, uint32_t layer, const nvbx_index3
   if (!ilayer) { set_error("nvbx_set_blocks: this mapper's projective layer type does not hold that layer"); return NVBX_E_INVALID; }
   for (int64_t i = 0; i < n; i++) if (!nvbx_index_in_range(idx[i].x, idx[i].y, idx[i].z)) { set_error("nvbx_set_blocks: block index outside +-2^20"); return NVBX_E_INVALID; }
   if (m->join_side()) return NVBX_E_DEVICE;
+  if (m->capacity < m->max_capacity) {          // explicit allocation (allocateBlockAtIndex, loadMap): room for all of it, plus the usual head-room
+    if (m->fetch_counters()) return NVBX_E_DEVICE;
+    m->h_mirror[0] = m->h_counters[C_FREE_TOP];
+    const int rcg = m->maybe_grow(n); if (rcg) return rcg;
+  }
   if (m->begin_dirtying()) return NVBX_E_DEVICE;
   const size_t bb = 512 * ref_voxel_bytes(layer);
   const EsdfArgs ea = m->make_esdf_args();

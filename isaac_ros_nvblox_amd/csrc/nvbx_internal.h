@@ -127,6 +127,7 @@ struct DMap {
   u64* inside_bits;         // per slot: inside mask of the slice plane, as of the last marking pass
   int32_t* shc;             // sharded counters (S_* above)
   int32_t* lists;           // N_LISTS x NSH x capacity slot ids: list l, shard s starts at ((l * NSH + s) * capacity)
+  int32_t* host_mirror;     // pinned host memory, device-mapped: [0] = free slots as of the last TSDF-update launch (pool growth, mapper.hip)
 };
 
 // Per-call camera / pose / parameter bundle (kernel argument, lives in SGPRs).

@@ -65,6 +65,14 @@ struct nvbx_mapper {
   int mark_main();              // record ev_main on `stream` (call right after a non-colour operation)
   nvbx_mapper_params p{};
   int64_t capacity = 0;
+  // Pool growth (the reference allocates blocks on demand; here the pools double before they run out): kernels mirror the number of
+  // free slots into pinned host memory (DMap::host_mirror), every integrate call looks at it first and, below half, doubles every
+  // capacity-sized array + rebuilds the hash on the device (grow_map, maintenance.hip).  max_capacity == capacity: fixed pools.
+  int64_t max_capacity = 0;
+  int32_t* h_mirror = nullptr;       // host view of DMap::host_mirror
+  int maybe_grow(int64_t extra_blocks_wanted = 0);
+  int grow_map(int64_t new_capacity);
+  int64_t growths = 0;
   nvbx::DMap d{};
   // lists (device)
   int32_t* view_list = nullptr;      // int4 {slot, x, y, z} of the blocks in view of the last depth frame

@@ -453,6 +453,8 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, FrameSet<Img, NB
   // nvbx_set_view_export: the frame's block indices also go to a caller-owned packed buffer [1 + cap][3] (row 0 = count) --
   // the message of the multi-GPU exchange, written here instead of by an export launch
   if (view_export && blockIdx.x == 0 && tid == 0) { view_export[0] = min(n, view_export_cap); view_export[1] = 0; view_export[2] = 0; }
+  // pool growth: the free-slot count after this frame's allocations goes to pinned host memory (not waited for)
+  if (blockIdx.x == 0 && tid == 64) __hip_atomic_store(&m.host_mirror[0], m.counters[C_FREE_TOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
   for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
     if (i != (int32_t)blockIdx.x) rec = view_list[i];
@@ -578,6 +580,7 @@ static int integrate_cameras(nvbx_mapper* m, int32_t n, const Img* imgs, int32_t
     // (join_side would launch a held-back EDT / union step; the EDT rides in k_mark_view instead, the union step stays held back
     //  for the next integrateColor -- it belongs to the NEXT ESDF update and touches nothing this launch reads)
     const int rc = m->join_side(); m->edt_pending = pend; m->import_pending = ipend; if (rc) return NVBX_E_DEVICE; }
+  { const int rc = m->maybe_grow(); if (rc) return rc; }          // (before anything of this frame is enqueued)
   const bool dilate = m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0;
   if (dilate && m->flush_edt()) return NVBX_E_DEVICE;   // first launch is the dilation
   { const int rc = next_frame_id(m); if (rc) return rc; }
@@ -675,6 +678,7 @@ extern "C" int nvbx_integrate_lidar_depth(nvbx_mapper* m, const float* range_dev
   if (m->join_side()) return NVBX_E_DEVICE;
   const nvbx_lidar_model l = nvbx_lidar_make(cols, rows, lidar->min_valid_range_m, lidar->min_elevation_rad, lidar->max_elevation_rad);
   const int rc = ensure_lidar_tables(m, lidar, l); if (rc) return rc;
+  { const int rcg = m->maybe_grow(); if (rcg) return rcg; }
   { const int rc2 = next_frame_id(m); if (rc2) return rc2; }
   nvbx_camera none{1.f, 1.f, 0.f, 0.f, cols, rows};
   FrameSet<DepthF32, 1> fs{}; fs.n = 1; fs.img[0] = DepthF32{range_dev};

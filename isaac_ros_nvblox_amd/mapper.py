@@ -59,7 +59,7 @@ def _np_ptr(a):
 
 
 class Mapper:
-    def __init__(self, params=None, device=0, block_capacity=1 << 15, stream=None):
+    def __init__(self, params=None, device=0, block_capacity=1 << 15, stream=None, max_block_capacity=None):
         import torch
         if not torch.cuda.is_available():
             raise NvbxError("no HIP device visible: the product path has no CPU fallback")
@@ -71,8 +71,18 @@ class Mapper:
         torch.cuda.set_device(device)
         s = C.c_void_p(stream) if stream else None
         self._check(self.lib.nvbx_mapper_create(device, s, C.byref(self.params), block_capacity, C.byref(self._h)))
-        self.capacity = block_capacity
+        self._capacity0 = block_capacity
         self._keep = []
+        if max_block_capacity is not None:
+            self.set_max_capacity(max_block_capacity)
+
+    @property
+    def capacity(self):
+        """Current block capacity of the HBM pools (they double on demand up to max_block_capacity)."""
+        return int(self.lib.nvbx_mapper_capacity(self._h))
+
+    def set_max_capacity(self, max_blocks):
+        self._check(self.lib.nvbx_mapper_set_max_capacity(self._h, int(max_blocks)))
 
     def _check(self, rc):
         if rc < 0:

@@ -57,17 +57,72 @@ def test_ragged_image_sizes(oracle_mod, hip_lib, shape):
 
 
 def test_block_pool_exhaustion_is_reported_not_fatal(oracle_mod, hip_lib):
-    """More blocks in view than the pool holds: the sticky overflow flag is raised, allocated blocks stay consistent, and
-    the mapper keeps working after clear()."""
+    """FIXED pools (max capacity = capacity) and more blocks in view than they hold: the sticky overflow flag is raised, allocated
+    blocks stay consistent, and the mapper keeps working after clear()."""
     M, g, o = pair(oracle_mod, cap=128)
+    g.set_max_capacity(128)
     d, rgb, T = H.frames(1, H.SMALL_CAM, color=False)[0]
     g.integrate_depth(d, T, H.SMALL_CAM)
     c = g.counters()
     assert c["capacity_overflow"] != 0
-    assert g.num_blocks(M.LAYER_TSDF) <= 128
+    assert g.num_blocks(M.LAYER_TSDF) <= 128 and g.capacity == 128
     g.update_esdf(); g.update_color_mesh(); g.synchronize()      # must not hang or fault
     g.clear()
     assert g.num_blocks(M.LAYER_TSDF) == 0
+
+
+def test_pools_grow_on_demand_without_data_loss(oracle_mod, hip_lib):
+    """The reference allocates blocks on demand; here the pools double before they run out (nvbx_mapper_set_max_capacity).  A map that
+    ends up 3x larger than the initial pools == the oracle's, with ESDF / mesh / colour state carried across every doubling."""
+    M, g, o = pair(oracle_mod, cap=1024)
+    caps = [g.capacity]
+    for k, (d, rgb, T) in enumerate(H.frames(10, H.SMALL_CAM, color=True, stride=17)):
+        g.integrate_depth(d, T, H.SMALL_CAM); o.integrate_depth(d, T, H.SMALL_CAM)
+        assert H.idx_set(g.last_view()) == H.idx_set(o.last_view())
+        g.integrate_color(rgb, T, H.SMALL_CAM); o.integrate_color(rgb, T, H.SMALL_CAM)
+        g.update_esdf(); o.update_esdf()                  # (the distance transform stays held back across a growth)
+        if k % 3 == 2:
+            g.update_color_mesh(); o.update_mesh()        # (and so does the last mesh update's arena content)
+        caps.append(g.capacity)
+    assert caps[-1] >= 4096 and caps[0] == 1024 and sorted(caps) == caps
+    assert g.counters()["capacity_overflow"] == 0
+    from test_gpu_parity import compare_layer
+    n, _ = compare_layer(M, g, o, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
+    assert n > 1500
+    compare_layer(M, g, o, M.LAYER_COLOR, oracle_mod.L_COLOR, fields_tol=("weight",), lsb_fields=("r", "g", "b"))
+    compare_layer(M, g, o, M.LAYER_ESDF, oracle_mod.L_ESDF, fields_exact=("squared_distance_vox", "parent_direction", "is_inside", "observed", "is_site"))
+    g.update_color_mesh(full=True); o.update_mesh(full=True)
+    mg = g.mesh()
+    for idx in o.block_indices(oracle_mod.L_TSDF):
+        assert np.array_equal(mg[tuple(idx)]["triangles"], o.mesh_block(idx)["triangles"])
+
+
+def test_mesh_of_the_last_update_survives_a_growth(oracle_mod, hip_lib):
+    M, g, o = pair(oracle_mod, cap=1024)
+    fr = H.frames(4, H.SMALL_CAM, color=False, stride=23)
+    g.integrate_depth(fr[0][0], fr[0][2], H.SMALL_CAM)
+    g.update_color_mesh()
+    before = g.mesh()
+    cap0 = g.capacity
+    for d, rgb, T in fr[1:]:
+        g.integrate_depth(d, T, H.SMALL_CAM); g.synchronize()
+    assert g.capacity > cap0
+    after = g.mesh()                                           # still the FIRST update's mesh (no update since), re-based into the wider arenas
+    assert set(before) == set(after) and len(before) > 50
+    for k in before:
+        assert np.array_equal(before[k]["vertices"], after[k]["vertices"]) and np.array_equal(before[k]["triangles"], after[k]["triangles"])
+
+
+def test_explicit_allocation_grows_the_pools(hip_lib):
+    """allocateBlockAtIndex / loadMap through nvbx_set_blocks: room is made for the whole batch."""
+    from isaac_ros_nvblox_amd import mapper as M
+    g = M.Mapper(M.default_params(), block_capacity=256)
+    idx = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(12), indexing="ij"), -1).reshape(-1, 3).astype(np.int32)    # 1728 blocks
+    data = np.zeros((len(idx), 512), M.TSDF_DT); data["distance"] = 0.1; data["weight"] = 1.0
+    g.set_blocks(M.LAYER_TSDF, idx, data)
+    assert g.num_blocks(M.LAYER_TSDF) == 1728 and g.capacity >= 2048 and g.counters()["capacity_overflow"] == 0
+    b, found = g.get_blocks(M.LAYER_TSDF, idx[::97])
+    assert found.all() and (b["weight"] == 1.0).all()
 
 
 def test_clear_then_reuse_matches_fresh_mapper(oracle_mod, hip_lib):

@@ -143,6 +143,29 @@ def test_lidar_full_config_properties(hip_lib):
     assert len(miss) == 0, miss[:5]
 
 
+@pytest.mark.gpu
+def test_lidar_config_with_automatic_and_growing_pools(hip_lib):
+    """configs[4] through the capacity the facade's reference-signature MultiMapper constructor uses (0 = automatic) and through pools
+    that start far too small for the map and grow: no block is dropped once the pools have caught up, the maps agree."""
+    from isaac_ros_nvblox_amd import mapper as M
+    pg = M.default_params(voxel_size=0.1, lidar_max_integration_distance_m=200.0, raycast_subsampling_factor=2, weighting_mode=0)
+    sc = S.LidarScene()
+    ga = M.Mapper(pg, block_capacity=0)                       # automatic
+    gg = M.Mapper(pg, block_capacity=1 << 19)
+    assert ga.capacity >= (1 << 16)
+    for i in range(3):
+        T = S.lidar_pose(i * 3)
+        img = S.render_lidar(sc, T, S.SPINNING_LIDAR, max_range=200.0)
+        ga.integrate_lidar_depth(img, T, S.SPINNING_LIDAR); gg.integrate_lidar_depth(img, T, S.SPINNING_LIDAR)
+        ga.synchronize()
+    assert ga.counters()["capacity_overflow"] == 0 and gg.counters()["capacity_overflow"] == 0
+    ia, ig = ga.block_indices(M.LAYER_TSDF), gg.block_indices(M.LAYER_TSDF)
+    assert np.array_equal(ia, ig) and len(ia) > 100000
+    sample = ia[:: max(1, len(ia) // 400)]
+    ba, _ = ga.get_blocks(M.LAYER_TSDF, sample); bg, _ = gg.get_blocks(M.LAYER_TSDF, sample)
+    assert np.array_equal(ba["distance"], bg["distance"]) and np.array_equal(ba["weight"], bg["weight"])
+
+
 def _moving_scan(n=4000, seed=3):
     """A sensor translating 0.3 m and yawing 6 degrees during a 100 ms scan of a static point set."""
     rng = np.random.default_rng(seed)
