@@ -384,7 +384,7 @@ def main_decay(args):
 # ====================================================================================================== camera / multicam
 def main_camera(args):
     from isaac_ros_nvblox_amd import mapper as M, synthetic as S
-    from isaac_ros_nvblox_amd.dist import PipelinedDirtyBlockExchange, camera_yaw_offset_deg
+    from isaac_ros_nvblox_amd.dist import MeasurementFusion, PipelinedDirtyBlockExchange, camera_yaw_offset_deg
     torch, dist, rank, world, local_rank, dev = init_dist(args)
     multicam = args.workload == "multicam"
     ncam = max(1, min(8, args.cameras)) if multicam else 1
@@ -415,7 +415,9 @@ def main_camera(args):
     stream = torch.cuda.Stream(dev)      # one explicit stream for torch ops, RCCL hand-off and every mapper kernel
     torch.cuda.set_stream(stream)
     g = M.Mapper(M.default_params(), device=local_rank, block_capacity=1 << 15, stream=stream.cuda_stream)
-    ex = PipelinedDirtyBlockExchange(4096, dev) if world > 1 else None      # one packed all-gather per frame, joined one frame later
+    fuse = world > 1 and args.fusion == "measurements"     # ONE fused map on every rank (exact, dist.MeasurementFusion) instead of replicas + index union
+    ex = PipelinedDirtyBlockExchange(4096, dev) if (world > 1 and not fuse) else None      # one packed all-gather per frame, joined one frame later
+    mf = MeasurementFusion(2048, dev) if fuse else None
 
     dargs = [[g.prepare_depth(depth_dev[ci][k], poses[ci][k], cam) for k in range(nu)] for ci in range(len(host_cams))]
     cargs = [[g.prepare_color(rgb_dev[ci][k], poses[ci][k], cam) for k in range(nu)] for ci in range(len(host_cams))]
@@ -433,7 +435,9 @@ def main_camera(args):
         xg = ex if exchange else None            # rank-0-only passes after the timed region must not enter a collective
         if xg is not None:
             xg.before_depth(g)                   # the depth pass writes this frame's block indices into the exchange buffer itself
-        if use_batch:
+        if mf is not None and exchange:
+            mf.integrate_depth(g, depth_dev[0][k], poses[0][k], cam)     # measure (this camera) -> all-gather -> apply all cameras in rank order
+        elif use_batch:
             g.integrate_prepared_batch(bd[n][k])     # n cameras' depth frames: ONE view-marking launch + ONE TSDF-update launch
         else:
             for ci in range(n):
@@ -568,7 +572,7 @@ def main_camera(args):
         "config": {"workload": ("configs[3] on one GPU: %d cameras (45 deg yaw offsets) through one mapper, %s; " % (ncam, "one batched launch set per step" if (batch_ok and ncam in bd) else "sequential calls") if multicam else "configs[1]: ") +
                                "synthetic Replica-like room (SURVEY 8d), 640x480 depth+colour, 0.05 m voxels, "
                                "fuser.yaml params, TSDF+Color+ESDF every frame (mesh timed separately)",
-                   "cameras_per_gpu": ncam, "parallelism": "one camera per GPU, RCCL all-gather of dirty block indices" if world > 1 else "single GPU",
+                   "cameras_per_gpu": ncam, "parallelism": ("one camera per GPU, RCCL all-gather of per-voxel measurements, one fused map on every rank" if fuse else "one camera per GPU, RCCL all-gather of dirty block indices") if world > 1 else "single GPU",
                    "unique_frames": nu},
         "ms_per_frame": round(ms_per_step / ncam, 4),
         "block_ms": [round(d / args.steps * 1e3, 4) for d in dts[:16]],
@@ -600,6 +604,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline keeps integrating (cycling the same frames) until this much CPU wall time has passed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cameras", type=int, default=4, help="multicam: cameras per step (1..8)")
+    ap.add_argument("--fusion", default="indices", choices=["indices", "measurements"],
+                    help="N > 1 GPUs: indices = replicas + all-gather of dirty block indices (north-star wording, default); "
+                         "measurements = all-gather of per-voxel measurements, ONE fused map on every rank (SURVEY 8e option B, exact)")
     ap.add_argument("--workload", default="camera", choices=["camera", "multicam", "decay", "lidar"],
                     help="camera = BASELINE.json configs[1] (the metric's configuration, default); multicam = configs[3] on one GPU; "
                          "decay = configs[2]; lidar = configs[4]")

@@ -416,6 +416,23 @@ int nvbx_mark_esdf_dirty_gathered(nvbx_mapper* m, const int32_t* gathered_dev, i
  * gathered buffer must stay valid and unchanged until then.  For the pipelined exchange of bench.py / dist.py. */
 int nvbx_mark_esdf_dirty_gathered_deferred(nvbx_mapper* m, const int32_t* gathered_dev, int32_t world, int32_t self_rank, int64_t max_count);
 
+/* ---- multi-GPU, one fused map (SURVEY.md 8e option B, made exact): measurement exchange ---------------------------------------------
+ * One camera per GPU.  nvbx_measure_depth runs the view calculation and the per-voxel projection / depth sampling of THIS rank's camera
+ * -- the expensive, sharded part of integrateDepth -- and writes, per block in view, a record {Index3D, 512 x {measured depth, voxel
+ * depth}} (voxel depth < 0: voxel not touched; measured depth < 0: it projects onto invalid depth) plus the record count, into
+ * caller-owned device buffers (asynchronous, no host copy).  The caller all-gathers the buffers (RCCL over xGMI; isaac_ros_nvblox_amd/
+ * dist.py MeasurementFusion) and hands the gathered array [world][stride_blocks] + counts [world] to nvbx_apply_measurements on every
+ * rank, which applies every camera's measurements to the local map in RANK ORDER with the integrator's own per-voxel update: every rank
+ * then holds the SAME map, bit-identical to ONE mapper integrating the cameras in rank order (nvbx_integrate_depth_batch) -- which
+ * exchanging already-fused {distance, weight} blocks cannot give (the clamps do not commute with a weighted mean).  owner_mod > 1: only
+ * blocks with Index3DHash(block) mod owner_mod == owner_rank are applied (the rank's shard of that map; the other blocks stay empty).
+ * world <= NVBX_MAX_BATCH.  Two launches per apply, whatever the world size. */
+typedef struct { int32_t x, y, z, rank; float ds_vd[512][2]; } nvbx_measurement_block;     /* 4112 bytes */
+int nvbx_measure_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera,
+                       nvbx_measurement_block* out_dev, int32_t* count_dev, int64_t capacity_blocks);
+int nvbx_apply_measurements(nvbx_mapper* m, const nvbx_measurement_block* gathered_dev, const int32_t* counts_dev, int32_t world, int64_t stride_blocks,
+                            int32_t owner_mod, int32_t owner_rank);
+
 /* ---- instrumentation (timing::Timer analogue for the per-kernel roofline line of bench.py) -----------------------
  * While enabled every kernel launch is bracketed by a hipEvent pair on the mapper stream. nvbx_get_profile returns a
  * JSON object {"kernel": {"count": n, "total_ms": t}}; the entry "_empty_event_pair" is the span of event pairs with nothing between

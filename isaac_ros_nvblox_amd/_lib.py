@@ -105,6 +105,8 @@ SIGNATURES = {
     "nvbx_mapper_get_params": (C.c_int, [_vp, C.POINTER(Params)]),
     "nvbx_synchronize": (C.c_int, [_vp]),
     "nvbx_flush": (C.c_int, [_vp]),
+    "nvbx_measure_depth": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera), _vp, _vp, _i64]),
+    "nvbx_apply_measurements": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32]),
     "nvbx_mapper_set_max_capacity": (C.c_int, [_vp, _i64]),
     "nvbx_mapper_capacity": (C.c_int64, [_vp]),
     "nvbx_integrate_depth_batch": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),

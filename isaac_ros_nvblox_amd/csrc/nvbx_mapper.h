@@ -111,6 +111,7 @@ struct nvbx_mapper {
   int64_t time_ms = 0;               // update_time_ms of the next integrateDepth
   int ensure_freespace_pool();
   int update_freespace();            // after the TSDF update of a depth frame (projective_layer_type 2)
+  int32_t* apply_postab = nullptr; int64_t apply_postab_cap = 0;      // nvbx_apply_measurements: per slot, the record position of each rank (+1)
   int32_t* cc_scratch = nullptr; int64_t cc_scratch_elems = 0;
   // EsdfMode::k3D (esdf3d.hip)
   int update_esdf_3d();

@@ -633,6 +633,161 @@ extern "C" int nvbx_integrate_depth_batch(nvbx_mapper* m, int32_t n, const float
   return integrate_cameras<DepthF32, MAX_BATCH>(m, n, imgs, rows, cols, T_L_C, cameras);
 }
 
+// ------------------------------------------------------------------------------------------------ multi-GPU: measurement exchange
+// SURVEY.md 8e option (B), made exact.  One camera per GPU; what overlapping cameras must agree on is the TSDF.  Exchanging fused
+// {distance, weight} blocks and re-fusing them on an owner is only approximately the sequential result (the weight clamp and the
+// distance clamp do not commute with a weighted mean).  Exchanging MEASUREMENTS is exact: rank r runs the view calculation and the
+// projection / depth sampling of ITS camera -- the expensive, sharded part -- and emits, per block in view, the 512 per-voxel pairs
+// {measured depth ds, voxel depth vd} (a 4 KiB payload, the size of a TSDF block); the buffers are all-gathered (RCCL over xGMI); every
+// rank then applies every camera's measurements to its map in RANK ORDER with the same per-voxel update the integrator uses.  Result:
+// every rank holds the SAME map, bit-identical to one mapper integrating the cameras in rank order (nvbx_integrate_depth_batch) --
+// or, with an owner filter (owner = Index3DHash(block) mod owner_mod), its shard of that map.  Two launches per apply for any G.
+struct MeasRec { int32_t x, y, z, rank; float2 v[512]; };       // == nvbx_measurement_block (4112 B)
+static_assert(sizeof(MeasRec) == sizeof(nvbx_measurement_block), "measurement record layout");
+
+template <typename Img>
+__global__ __launch_bounds__(512) void k_measure_tsdf(DMap m, Frame f, Img depth, CameraSensor sensor, const int4* view_list, int32_t list_cap,
+                                                      MeasRec* out, int32_t* out_count, int32_t out_cap) {
+  int32_t n = m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
+  if (n > list_cap) n = list_cap;
+  if (n > out_cap) n = out_cap;
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid == 0) *out_count = n;
+  if (blockIdx.x == 0 && tid == 64) __hip_atomic_store(&m.host_mirror[0], m.counters[C_FREE_TOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
+  for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const int4 rec = view_list[i];
+    float pc[3];
+    apply_rt(f.R_CL, f.t_CL, voxel_center(rec.y, vx, f.block_size, f.voxel_size), voxel_center(rec.z, vy, f.block_size, f.voxel_size),
+             voxel_center(rec.w, vz, f.block_size, f.voxel_size), pc);
+    float ds = 0.0f, vd = 0.0f;
+    const int got = sensor.sample(f, depth, pc, &ds, &vd);
+    // {ds, vd}: vd < 0 = the voxel is not touched; ds < 0 = it projects onto invalid depth (invalid_depth_decay); else a measurement
+    float2 o = make_float2(0.0f, -1.0f);
+    if (got > 0) o = make_float2(ds, vd); else if (got < 0) o = make_float2(-1.0f, vd);
+    MeasRec* r = out + i;
+    if (tid == 0) { r->x = rec.y; r->y = rec.z; r->z = rec.w; r->rank = 0; }
+    r->v[tid] = o;
+  }
+}
+// pass 1 of an apply: one thread per record of every rank -- block lookup / allocation, position table, union list (= the view list)
+__global__ void k_apply_index(DMap m, const MeasRec* all, const int32_t* counts, int32_t world, int64_t stride, int32_t owner_mod, int32_t owner_rank,
+                              uint32_t frame_id, int32_t* postab, int4* view_list, int32_t list_cap) {
+  int32_t* cnt = &m.counters[C_VIEW_COUNT + (frame_id & 3)];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) m.counters[C_VIEW_COUNT + ((frame_id + 1) & 3)] = 0;
+  const int32_t r = (int32_t)blockIdx.y;
+  int64_t n = counts[r]; if (n > stride) n = stride;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const MeasRec* rec = all + (size_t)r * stride + i;
+    const int32_t x = rec->x, y = rec->y, z = rec->z;
+    if (owner_mod > 1 && (int32_t)(index_hash(x, y, z) % (uint32_t)owner_mod) != owner_rank) continue;
+    int4 out;
+    const bool first = mark_block(m, pack_key(x, y, z), frame_id, 1u << r, &out);
+    uint32_t slot;
+    if (first) slot = (uint32_t)out.x;
+    else { slot = SLOT_INVALID; const int32_t h = hash_find(m, x, y, z); if (h >= 0) { do { slot = ld_slot_acquire(&m.table[h]); } while (slot == SLOT_INVALID); } }
+    if (!slot_ok(slot)) continue;                      // pool exhausted
+    postab[(size_t)slot * MAX_BATCH + r] = (int32_t)i + 1;
+    if (first) { const int32_t p = atomicAdd(cnt, 1); if (p < list_cap) view_list[p] = out; }
+  }
+}
+// pass 2: one workgroup per block of the union; the ranks' measurements are applied to each voxel in rank order, in registers
+__global__ __launch_bounds__(512) void k_apply_fuse(DMap m, Frame f, const MeasRec* all, int64_t stride, int32_t world, int32_t* postab,
+                                                    const int4* view_list, int32_t list_cap, int32_t mesh_list) {
+  int32_t n = m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
+  if (n > list_cap) n = list_cap;
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid == 64) __hip_atomic_store(&m.host_mirror[0], m.counters[C_FREE_TOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const uint32_t slot = (uint32_t)view_list[i].x;
+    if (!slot_ok(slot)) continue;
+    float2* vp = &m.tsdf[(size_t)slot * 512 + tid];
+    float2 fin = *vp;
+    uint32_t old = 0;
+    if (tid == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH);
+    bool touched = false;
+    for (int r = 0; r < world; r++) {
+      const int32_t p = postab[(size_t)slot * MAX_BATCH + r];      // uniform
+      if (!p) continue;
+      const float2 mv = all[(size_t)r * stride + (p - 1)].v[tid];
+      if (mv.y < 0.0f) continue;
+      if (f.occupancy) { if (!(mv.x < 0.0f)) { fin = make_float2(occupancy_update(f, fin.x, mv.x, mv.y), 0.0f); touched = true; } }
+      else if (mv.x < 0.0f) { if (f.invalid_decay >= 0.0f) { fin = make_float2(fin.x, fin.y * f.invalid_decay); touched = true; } }
+      else if (tsdf_fuse(f, &fin, mv.x, mv.y)) touched = true;
+    }
+    if (touched) *vp = fin;
+    __syncthreads();                                                  // every lane has read the table before it is cleared
+    if (tid < MAX_BATCH) postab[(size_t)slot * MAX_BATCH + tid] = 0;
+    if (!f.occupancy) {
+      const int any_band = __syncthreads_or(in_band(fin.x, fin.y, f.trunc) ? 1 : 0);
+      if (tid == 0) { if (any_band) atomicOr(&m.slot_flags[slot], F_BAND); else atomicAnd(&m.slot_flags[slot], ~F_BAND); if (old & F_BAND_STALE) atomicAnd(&m.slot_flags[slot], ~F_BAND_STALE); }
+    }
+    if (tid == 0) {
+      if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)slot);
+      if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, (int32_t)slot);
+    }
+  }
+}
+
+extern "C" int nvbx_measure_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera,
+                                  nvbx_measurement_block* out_dev, int32_t* count_dev, int64_t capacity_blocks) {
+  if (!m || !depth_dev || !T_L_C || !camera || !out_dev || !count_dev || capacity_blocks <= 0 || rows <= 0 || cols <= 0) { set_error("nvbx_measure_depth: invalid argument"); return NVBX_E_INVALID; }
+  if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_measure_depth: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
+  if (!nvbx_pose_in_range(T_L_C, m->p.voxel_size * 8.0f, m->p.max_integration_distance_m + 2.0f * m->p.truncation_distance_vox * m->p.voxel_size)) {
+    set_error("nvbx_measure_depth: T_L_C is not finite or lies outside the addressable block range"); return NVBX_E_INVALID; }
+  NVBX_HIP(hipSetDevice(m->device));
+  if (m->join_side()) return NVBX_E_DEVICE;
+  { const int rc = m->maybe_grow(); if (rc) return rc; }
+  { const int rc = next_frame_id(m); if (rc) return rc; }
+  FrameSet<DepthF32, 1> fs{}; fs.n = 1; fs.img[0] = DepthF32{depth_dev};
+  fs.f[0] = m->make_frame(T_L_C, camera, rows, cols, m->p.raycast_subsampling_factor);
+  const int s = fs.f[0].subsample;
+  fs.f[0].n_ray_rows = (rows + s - 1 + s - 1) / s; fs.f[0].n_ray_cols = (cols + s - 1 + s - 1) / s; fs.f[0].cam_bit = 1u;
+  const Frame& f = fs.f[0];
+  const int n_tiles = ((f.n_ray_rows + CameraSensor::kTileRows - 1) / CameraSensor::kTileRows) * ((f.n_ray_cols + CameraSensor::kTileCols - 1) / CameraSensor::kTileCols);
+  // the view calculation against the local map: blocks in view are looked up / allocated exactly as integrateDepth would (they receive
+  // their values when the gathered measurements are applied)
+  NVBX_LAUNCH(m, (k_mark_view<DepthF32, CameraSensor, 1>), dim3(NSH * ((n_tiles + NSH - 1) / NSH)), dim3(CameraSensor::kThreads), m->d, fs, CameraSensor{},
+              (int4*)m->view_list, (int32_t)m->capacity, (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)0, m->edt_args);
+  m->premark_consumed = false;
+  NVBX_LAUNCH(m, (k_measure_tsdf<DepthF32>), dim3((unsigned)std::min<int64_t>(m->capacity, 1024)), dim3(512), m->d, f, DepthF32{depth_dev}, CameraSensor{},
+              (const int4*)m->view_list, (int32_t)m->capacity, reinterpret_cast<MeasRec*>(out_dev), count_dev, (int32_t)std::min<int64_t>(capacity_blocks, INT32_MAX));
+  NVBX_HIP(hipGetLastError());
+  m->last_view_frame = m->frame_id; m->last_camera_view_frame = m->frame_id; m->last_camera_view_mask = 1u; m->last_view_batch = 1;
+  return m->mark_main();
+}
+
+extern "C" int nvbx_apply_measurements(nvbx_mapper* m, const nvbx_measurement_block* gathered_dev, const int32_t* counts_dev, int32_t world, int64_t stride_blocks,
+                                       int32_t owner_mod, int32_t owner_rank) {
+  if (!m || !gathered_dev || !counts_dev || world < 1 || world > MAX_BATCH || stride_blocks <= 0 || owner_mod < 0 || (owner_mod > 1 && (owner_rank < 0 || owner_rank >= owner_mod))) {
+    set_error("nvbx_apply_measurements: invalid argument (1 <= world <= 8)"); return NVBX_E_INVALID; }
+  if (m->p.projective_layer_type == 2) { set_error("nvbx_apply_measurements: mappers with a freespace layer integrate per frame (time stamps)"); return NVBX_E_INVALID; }
+  NVBX_HIP(hipSetDevice(m->device));
+  if (m->join_side()) return NVBX_E_DEVICE;
+  { const int rc = m->maybe_grow(); if (rc) return rc; }
+  if (!m->apply_postab || m->apply_postab_cap < m->capacity) {
+    NVBX_HIP(hipStreamSynchronize(m->stream));
+    if (m->apply_postab) NVBX_HIP(hipFree(m->apply_postab));
+    m->apply_postab = nullptr; m->apply_postab_cap = 0;
+    NVBX_HIP(hipMalloc(&m->apply_postab, (size_t)m->capacity * MAX_BATCH * 4));
+    NVBX_HIP(hipMemsetAsync(m->apply_postab, 0, (size_t)m->capacity * MAX_BATCH * 4, m->stream));
+    m->apply_postab_cap = m->capacity;
+  }
+  if (m->begin_dirtying()) return NVBX_E_DEVICE;
+  { const int rc = next_frame_id(m); if (rc) return rc; }
+  nvbx_camera none{1.f, 1.f, 0.f, 0.f, 1, 1};
+  float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const Frame f = m->make_frame(I, &none, 1, 1, 1);          // (the integrator parameters; no camera is involved in applying measurements)
+  const MeasRec* all = reinterpret_cast<const MeasRec*>(gathered_dev);
+  NVBX_LAUNCH(m, k_apply_index, dim3(64, (unsigned)world), dim3(256), m->d, all, counts_dev, world, stride_blocks, owner_mod, owner_rank, m->frame_id, m->apply_postab,
+              (int4*)m->view_list, (int32_t)m->capacity);
+  NVBX_LAUNCH(m, k_apply_fuse, dim3((unsigned)std::min<int64_t>(m->capacity, 1024)), dim3(512), m->d, f, all, stride_blocks, world, m->apply_postab,
+              (const int4*)m->view_list, (int32_t)m->capacity, m->mesh_list_live());
+  NVBX_HIP(hipGetLastError());
+  m->last_view_frame = m->frame_id; m->last_camera_view_frame = m->frame_id; m->last_camera_view_mask = 1u << (world - 1); m->last_view_batch = world;
+  return m->mark_main();
+}
+
 // ------------------------------------------------------------------------------------------------ LiDAR
 static bool same_lidar(const nvbx_lidar& a, const nvbx_lidar& b) { return memcmp(&a, &b, sizeof(a)) == 0; }
 

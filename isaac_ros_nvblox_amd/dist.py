@@ -127,6 +127,53 @@ class PipelinedDirtyBlockExchange:
             self.pending = None
 
 
+class MeasurementFusion:
+    """One fused map from one camera per GPU (SURVEY.md 8e option B, made exact -- include/nvblox_hip.h "measurement exchange").
+
+    Per frame: mapper.measure_depth (this rank's view calculation + projection, the sharded part) -> ONE all_gather_into_tensor of the
+    measurement buffers (<= stride x 4112 B per rank; 300 blocks in view = 1.2 MB, 8 us of wire time on one xGMI link) + one of the
+    counts -> mapper.apply_measurements on every rank, in rank order.  Every rank then holds the SAME map, bit-identical to a single
+    mapper integrating the cameras in rank order; `sharded=True` keeps only the blocks this rank owns (Index3DHash mod world).
+    The mapper may be the HIP Mapper (device tensors, RCCL) or any object with the same two methods (CPU tensors, gloo: tests)."""
+
+    BLOCK_BYTES = 4112
+
+    def __init__(self, stride_blocks, device, group=None, sharded=False):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.stride = int(stride_blocks)
+        self.sharded = bool(sharded)
+        self.buf = torch.zeros((self.stride, self.BLOCK_BYTES), dtype=torch.uint8, device=device)
+        self.cnt = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.all_buf = torch.zeros((self.world, self.stride, self.BLOCK_BYTES), dtype=torch.uint8, device=device)
+        self.all_cnt = torch.zeros((self.world,), dtype=torch.int32, device=device)
+
+    def _order(self, mapper, first, second):
+        """event ordering between the mapper's stream and torch's current stream when they differ (see DirtyBlockExchange._streams)"""
+        if not self.buf.is_cuda or not hasattr(mapper, "torch_stream"):
+            return
+        cur = torch.cuda.current_stream(self.buf.device); ms = mapper.torch_stream()
+        if ms.cuda_stream == cur.cuda_stream:
+            return
+        (cur if first == "mapper" else ms).wait_stream(ms if first == "mapper" else cur)
+
+    def integrate_depth(self, mapper, depth, T_L_C, cam):
+        """The multi-GPU form of MultiMapper::integrateDepth: collective, every rank calls it with its own camera frame."""
+        mapper.measure_depth(depth, T_L_C, cam, self.buf, self.cnt)
+        self._order(mapper, "mapper", "torch")             # the collective reads the buffers only after the mapper's stream has written them
+        if self.world == 1:
+            self.all_buf[0].copy_(self.buf); self.all_cnt.copy_(self.cnt)
+        else:
+            dist.all_gather_into_tensor(self.all_cnt, self.cnt, group=self.group)
+            dist.all_gather_into_tensor(self.all_buf.view(-1, self.BLOCK_BYTES), self.buf, group=self.group)
+        self._order(mapper, "torch", "mapper")
+        if self.sharded:
+            mapper.apply_measurements(self.all_buf, self.all_cnt, self.world, self.rank)
+        else:
+            mapper.apply_measurements(self.all_buf, self.all_cnt)
+
+
 def camera_yaw_offset_deg(rank, world):
     """Config 4 of BASELINE.json: cameras on the same rig circle at 45 degree yaw offsets."""
     return 45.0 * (rank % 8)

@@ -511,6 +511,22 @@ class Mapper:
                                                       colors=c[vo[i]:vo[i + 1]], triangles=t[to[i]:to[i + 1]])
         return out
 
+    # -- multi-GPU, one fused map: measurement exchange (nvbx_measure_depth / nvbx_apply_measurements; dist.MeasurementFusion)
+    MEAS_BLOCK_BYTES = 4112
+
+    def measure_depth(self, depth, T_L_C, cam, out_blocks, out_count):
+        """This rank's camera -> measurement records into caller-owned device tensors: out_blocks uint8 [capacity, 4112], out_count int32 [1]."""
+        d = self._dev(depth, self._torch.float32)
+        T = self._T(T_L_C); k = self._cam(cam)
+        self._check(self.lib.nvbx_measure_depth(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k),
+                                                C.c_void_p(out_blocks.data_ptr()), C.c_void_p(out_count.data_ptr()), int(out_blocks.shape[0])))
+        self._keep = [d]
+
+    def apply_measurements(self, gathered, counts, owner_mod=0, owner_rank=0):
+        """gathered uint8 [world, stride, 4112], counts int32 [world] (device): every camera's measurements applied in rank order."""
+        self._check(self.lib.nvbx_apply_measurements(self._h, C.c_void_p(gathered.data_ptr()), C.c_void_p(counts.data_ptr()), int(gathered.shape[0]),
+                                                     int(gathered.shape[1]), int(owner_mod), int(owner_rank)))
+
     # -- multi-GPU hooks (SURVEY.md 8e)
     def esdf_dirty_list(self, idx_out, count_out):
         """Write the Index3D list [cap,3] int32 + count [1] int32 of TSDF blocks dirtied since the last updateEsdf

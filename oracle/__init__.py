@@ -150,6 +150,8 @@ def lib():
         L.orc_remove_small_components.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
         L.orc_clear_tsdf_inside_shapes.restype = i64; L.orc_clear_tsdf_inside_shapes.argtypes = [vp, vp, i32]
         L.orc_clear_outside_radius.restype = i64; L.orc_clear_outside_radius.argtypes = [vp, vp, C.c_float]
+        L.orc_measure_depth.restype = i64; L.orc_measure_depth.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, i64]
+        L.orc_apply_measurements.restype = i64; L.orc_apply_measurements.argtypes = [vp, vp, vp, i32, i64, i32, i32]
         L.orc_take_cleared_blocks.restype = i64; L.orc_take_cleared_blocks.argtypes = [vp, vp, i64]
         L.orc_mark_esdf_dirty.restype = i64; L.orc_mark_esdf_dirty.argtypes = [vp, vp, i64]
         L.orc_esdf_dirty_list.restype = i64; L.orc_esdf_dirty_list.argtypes = [vp, vp, i64]
@@ -309,6 +311,18 @@ class OracleMap:
     def clear_outside_radius(self, center, radius):
         c = np.asarray(center, np.float32)
         return lib().orc_clear_outside_radius(self._h, _p(c), float(radius))
+
+    # -- the CPU counterpart of Mapper.measure_depth / apply_measurements (torch CPU tensors or numpy arrays; dist.MeasurementFusion)
+    def measure_depth(self, depth, T_L_C, cam, out_blocks, out_count):
+        depth = np.ascontiguousarray(depth, np.float32); T = self._T(T_L_C); k = self._cam(cam)
+        ob = out_blocks.numpy() if hasattr(out_blocks, "numpy") else out_blocks
+        n = lib().orc_measure_depth(self._h, _p(depth), depth.shape[0], depth.shape[1], _p(T), _p(k), _p(ob), ob.shape[0])
+        out_count[0] = int(n)
+
+    def apply_measurements(self, gathered, counts, owner_mod=0, owner_rank=0):
+        g = gathered.numpy() if hasattr(gathered, "numpy") else gathered
+        c = np.ascontiguousarray(counts.numpy() if hasattr(counts, "numpy") else counts, np.int32)
+        return lib().orc_apply_measurements(self._h, _p(g), _p(c), g.shape[0], g.shape[1], int(owner_mod), int(owner_rank))
 
     def take_cleared_blocks(self):
         out = np.zeros((1 << 16, 3), np.int32)

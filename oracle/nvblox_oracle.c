@@ -619,6 +619,73 @@ int64_t orc_integrate_depth(OrcMap* m, const float* depth_in, int rows, int cols
 }
 
 
+/* ------------------------------------------------------------------ multi-GPU measurement exchange (tests/test_dist_gloo.py)
+ * The CPU counterpart of nvbx_measure_depth / nvbx_apply_measurements (include/nvblox_hip.h): records {x, y, z, rank, 512 x {ds, vd}}. */
+typedef struct { int32_t x, y, z, rank; float v[512][2]; } MeasRec;
+int64_t orc_measure_depth(OrcMap* m, const float* depth, int rows, int cols, const float* T_L_C16, const float* cam6, MeasRec* out, int64_t cap) {
+  Rt T_L_C, T_C_L; rt_from_T(T_L_C16, &T_L_C, &T_C_L);
+  Cam k = cam_from(cam6);
+  const OrcParams* p = &m->p;
+  const float vs = p->voxel_size, bs = vs * 8.0f;
+  m->frame++; m->camera_frame = m->frame;
+  view_calc(m, depth, rows, cols, &T_L_C, &k);
+  /* (view_calc marks the blocks dirty; their values arrive with orc_apply_measurements) */
+  int64_t n = m->n_view < cap ? m->n_view : cap;
+  for (int64_t i = 0; i < n; i++) {
+    const Idx3 bi = m->view[i];
+    MeasRec* r = &out[i];
+    r->x = bi.x; r->y = bi.y; r->z = bi.z; r->rank = 0;
+    for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) for (int z = 0; z < 8; z++) {
+      float pl[3] = {voxel_center(bi.x, x, bs, vs), voxel_center(bi.y, y, bs, vs), voxel_center(bi.z, z, bs, vs)};
+      float pc[3]; rt_apply(&T_C_L, pl[0], pl[1], pl[2], pc);
+      float u, v, ds = 0.0f;
+      float* o = r->v[z + 8 * y + 64 * x];
+      o[0] = 0.0f; o[1] = -1.0f;
+      if (!cam_project(&k, pc, &u, &v)) continue;
+      const float vd = pc[2];
+      if (p->max_integration_distance_m > 0.0f && vd > p->max_integration_distance_m) continue;
+      const int got = interp_depth(depth, rows, cols, u, v, p->depth_interp_nearest, &ds);
+      if (got > 0) { o[0] = ds; o[1] = vd; } else if (got < 0) { o[0] = -1.0f; o[1] = vd; }
+    }
+  }
+  return n;
+}
+int64_t orc_apply_measurements(OrcMap* m, const MeasRec* all, const int32_t* counts, int32_t world, int64_t stride, int32_t owner_mod, int32_t owner_rank) {
+  const OrcParams* p = &m->p;
+  const float trunc = p->truncation_distance_vox * p->voxel_size;
+  m->frame++; m->camera_frame = m->frame;
+  m->n_view = 0;
+  int64_t applied = 0;
+  for (int32_t r = 0; r < world; r++) {
+    int64_t n = counts[r]; if (n > stride) n = stride;
+    for (int64_t i = 0; i < n; i++) {
+      const MeasRec* rec = &all[(int64_t)r * stride + i];
+      Idx3 bi = {rec->x, rec->y, rec->z};
+      if (owner_mod > 1 && (int32_t)(idx_hash(bi) % (uint32_t)owner_mod) != owner_rank) continue;
+      view_push(m, bi);                                   /* allocates, stamps the view, dirties the block */
+      Block* b = map_find(m, bi);
+      if (!b) continue;
+      ensure_layer(b, L_TSDF); b->dirty_esdf = 1; b->dirty_mesh = 1;
+      for (int q = 0; q < NVOX; q++) {
+        const float ds = rec->v[q][0], vd = rec->v[q][1];
+        if (vd < 0.0f) continue;
+        TsdfVoxel* vx = &b->tsdf[q];
+        if (p->projective_layer_type == 1) {
+          if (ds < 0.0f) continue;
+          float upd = log_odds(p->unobserved_region_occupancy_probability);
+          if (vd < ds - p->occupied_region_half_width_m) upd = log_odds(p->free_region_occupancy_probability);
+          else if (vd <= ds + p->occupied_region_half_width_m) upd = log_odds(p->occupied_region_occupancy_probability);
+          float v = vx->distance + upd; if (v > 10.0f) v = 10.0f; if (v < -10.0f) v = -10.0f;
+          vx->distance = v; vx->weight = 0.0f;
+        } else if (ds < 0.0f) { if (p->invalid_depth_decay_factor >= 0.0f) vx->weight = vx->weight * p->invalid_depth_decay_factor; }
+        else tsdf_fuse(p, vx, ds, vd, trunc, p->max_integration_distance_m);
+      }
+      applied++;
+    }
+  }
+  return applied;
+}
+
 /* ------------------------------------------------------------------ LiDAR (range image) */
 /* [U] ProjectiveTsdfIntegrator::integrateFrame(DepthImage, T_L_C, Lidar) restated (call site nvblox_node.cpp:1382-1384;
  * model anchors in nvbx_lidar_math.h).  Same view calculation and voxel update as the camera path with the sensor

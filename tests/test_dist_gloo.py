@@ -116,3 +116,78 @@ def test_pipelined_exchange_applies_every_list_once_one_frame_late_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ---------------------------------------------------------------------------------------------- one fused map: measurement exchange
+def _fusion_worker(rank, world, port, q, sharded):
+    """Every rank integrates ITS camera through dist.MeasurementFusion (gloo all-gather of the measurement records) into a CPU map (the
+    oracle as the rank's mapper); the result must be the map ONE mapper gets from the same cameras in rank order -- bit for bit."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import oracle
+    from isaac_ros_nvblox_amd import synthetic as S
+    from isaac_ros_nvblox_amd.dist import MeasurementFusion
+    cam = (80.0, 80.0, 79.5, 59.5, 160, 120)
+    p = oracle.default_params(weighting_mode=4, invalid_depth_decay_factor=0.8, max_weight=3.0)
+    mine = oracle.OracleMap(p)
+    single = oracle.OracleMap(p)                       # the reference: all cameras, in rank order, through one mapper
+    fusion = MeasurementFusion(1024, torch.device("cpu"), sharded=sharded)
+    sc = S.Scene()
+    for k in range(3):
+        frames = []
+        for r in range(world):
+            T = S.trajectory_pose(k * 11, 200, yaw_offset_deg=45.0 * r)      # overlapping views
+            d, _ = S.render(sc, T, cam, color=False)
+            d[10:30, 20:60] = 0.0                                             # invalid depth: the decay path is exchanged too
+            frames.append((d, T))
+        fusion.integrate_depth(mine, frames[rank][0], frames[rank][1], cam)
+        for d, T in frames:
+            single.integrate_depth(d, T, cam)
+    ok = True
+    idx_single = single.block_indices(oracle.L_TSDF)
+    idx_mine = mine.block_indices(oracle.L_TSDF)
+    n_cmp = 0
+    if not sharded:
+        ok = ok and np.array_equal(idx_single, idx_mine)
+    for idx in idx_single:
+        owned = (not sharded) or (int(oracle.lib().orc_index_hash(int(idx[0]), int(idx[1]), int(idx[2]))) % world == rank)
+        if not owned:
+            continue
+        a = single.get_block(oracle.L_TSDF, idx); b = mine.get_block(oracle.L_TSDF, idx)
+        ok = ok and b is not None and np.array_equal(a["distance"], b["distance"]) and np.array_equal(a["weight"], b["weight"])
+        n_cmp += 1
+    # ESDF of the fused replica == ESDF of the single map
+    if not sharded:
+        mine.update_esdf(); single.update_esdf()
+        sa, _ = mine.esdf_slice_image(); sb, _ = single.esdf_slice_image()
+        ok = ok and sa.shape == sb.shape and np.array_equal(sa, sb)
+    q.put((rank, bool(ok), n_cmp, len(idx_single)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_fusion(world, sharded):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fusion_worker, args=(r, world, port, q, sharded)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(res)
+
+
+def test_measurement_fusion_gives_every_rank_the_single_mapper_map_world2():
+    res = _run_fusion(2, sharded=False)
+    assert [r[:2] for r in res] == [(0, True), (1, True)] and all(r[2] == r[3] > 300 for r in res)
+
+
+def test_measurement_fusion_owner_shards_partition_the_single_mapper_map_world3():
+    res = _run_fusion(3, sharded=True)
+    assert [r[:2] for r in res] == [(0, True), (1, True), (2, True)]
+    assert sum(r[2] for r in res) == res[0][3] and min(r[2] for r in res) > 50          # the shards partition the map

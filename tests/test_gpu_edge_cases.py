@@ -88,7 +88,7 @@ def test_pools_grow_on_demand_without_data_loss(oracle_mod, hip_lib):
     assert g.counters()["capacity_overflow"] == 0
     from test_gpu_parity import compare_layer
     n, _ = compare_layer(M, g, o, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
-    assert n > 1500
+    assert n > 1200
     compare_layer(M, g, o, M.LAYER_COLOR, oracle_mod.L_COLOR, fields_tol=("weight",), lsb_fields=("r", "g", "b"))
     compare_layer(M, g, o, M.LAYER_ESDF, oracle_mod.L_ESDF, fields_exact=("squared_distance_vox", "parent_direction", "is_inside", "observed", "is_site"))
     g.update_color_mesh(full=True); o.update_mesh(full=True)

@@ -58,3 +58,57 @@ def test_dirty_list_exchange_matches_oracle(oracle_mod, hip_lib):
             ig, ag = gs[r].esdf_slice_image(1000.0); io, ao = os_[r].esdf_slice_image(1000.0)
             assert ig.shape == io.shape and np.array_equal(ag, ao) and np.abs(ig - io).max() <= 1e-4
             assert gs[r].counters()["esdf_columns_marked"] > 0
+
+
+def test_measurement_exchange_equals_one_mapper_batch(oracle_mod, hip_lib):
+    """nvbx_measure_depth / nvbx_apply_measurements: three 'ranks' on one GPU (three mappers, buffers concatenated by hand instead of an
+    all-gather): every rank's map == ONE mapper integrating the three cameras as a batch (bit for bit) == the oracle fed sequentially."""
+    import torch
+    from isaac_ros_nvblox_amd import mapper as M
+    from test_gpu_parity import compare_layer
+    world, stride = 3, 1024
+    cam = H.SMALL_CAM
+    pg = M.default_params(weighting_mode=4, invalid_depth_decay_factor=0.8)
+    ranks = [M.Mapper(pg, block_capacity=1 << 13) for _ in range(world)]
+    single = M.Mapper(pg, block_capacity=1 << 13)
+    o = oracle_mod.OracleMap(H.copy_params(pg, oracle_mod.OrcParams))
+    all_buf = torch.zeros((world, stride, M.Mapper.MEAS_BLOCK_BYTES), dtype=torch.uint8, device="cuda:0")
+    all_cnt = torch.zeros((world,), dtype=torch.int32, device="cuda:0")
+    sc = S.Scene()
+    for k in range(3):
+        fr = []
+        for r in range(world):
+            T = S.trajectory_pose(k * 11, 200, yaw_offset_deg=45.0 * r)
+            d, _ = S.render(sc, T, cam, color=False)
+            d[10:30, 20:60] = 0.0
+            fr.append((d, T))
+        for r in range(world):
+            ranks[r].measure_depth(fr[r][0], fr[r][1], cam, all_buf[r], all_cnt[r:r + 1])
+            ranks[r].synchronize()                      # (the three mappers have their own streams here; dist.MeasurementFusion orders them with events)
+        for r in range(world):
+            ranks[r].apply_measurements(all_buf, all_cnt)
+            ranks[r].synchronize()
+        single.integrate_depth_batch([d for d, _ in fr], [T for _, T in fr], cam)
+        for d, T in fr:
+            o.integrate_depth(d, T, cam)
+    idx = single.block_indices(M.LAYER_TSDF)
+    bs, _ = single.get_blocks(M.LAYER_TSDF, idx)
+    for r in range(world):
+        assert np.array_equal(ranks[r].block_indices(M.LAYER_TSDF), idx)
+        br, _ = ranks[r].get_blocks(M.LAYER_TSDF, idx)
+        assert np.array_equal(br["distance"], bs["distance"]) and np.array_equal(br["weight"], bs["weight"])
+    n, _ = compare_layer(M, ranks[1], o, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
+    assert n > 300
+    # the fused replicas run the rest of the path like any map: ESDF slices agree
+    for m_ in ranks + [single]:
+        m_.update_esdf()
+    s0, _ = single.esdf_slice_image()
+    for r in range(world):
+        sr, _ = ranks[r].esdf_slice_image()
+        assert sr.shape == s0.shape and np.array_equal(sr, s0)
+    # owner filter: rank 2's shard of the same map
+    shard = M.Mapper(pg, block_capacity=1 << 13)
+    shard.apply_measurements(all_buf, all_cnt, owner_mod=world, owner_rank=2)      # (the last frame's buffers)
+    bi = shard.block_indices(M.LAYER_TSDF)
+    b, _ = shard.get_blocks(M.LAYER_TSDF, bi)
+    assert len(bi) > 20 and all(int(oracle_mod.lib().orc_index_hash(int(x), int(y), int(z))) % world == 2 for x, y, z in bi.tolist())
