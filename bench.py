@@ -417,7 +417,7 @@ def main_camera(args):
     g = M.Mapper(M.default_params(), device=local_rank, block_capacity=1 << 15, stream=stream.cuda_stream)
     fuse = world > 1 and args.fusion == "measurements"     # ONE fused map on every rank (exact, dist.MeasurementFusion) instead of replicas + index union
     ex = PipelinedDirtyBlockExchange(4096, dev) if (world > 1 and not fuse) else None      # one packed all-gather per frame, joined one frame later
-    mf = MeasurementFusion(2048, dev) if fuse else None
+    mf = MeasurementFusion(1024, dev) if fuse else None      # 1024 records x 4112 B = 4.2 MB per rank and frame (~300 blocks in view are used)
 
     dargs = [[g.prepare_depth(depth_dev[ci][k], poses[ci][k], cam) for k in range(nu)] for ci in range(len(host_cams))]
     cargs = [[g.prepare_color(rgb_dev[ci][k], poses[ci][k], cam) for k in range(nu)] for ci in range(len(host_cams))]

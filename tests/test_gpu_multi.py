@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import helpers as H
+from isaac_ros_nvblox_amd import synthetic as S
 
 pytestmark = pytest.mark.gpu
 
