@@ -310,11 +310,15 @@ int nvbx_pointcloud_from_slice(nvbx_mapper* m, const float* image_dev, int32_t r
 int nvbx_esdf_dense_grid(nvbx_mapper* m, const int32_t min_vox[3], const int32_t size_vox[3], float default_value,
                          float* grid_dev);
 
-/* ---- map file (Mapper::saveLayerCake(path) -> bool, loadMap(path) -> bool: nvblox_node.cpp:1668,1703) -------------------
- * TSDF + colour + ESDF layers as {Index3D, 512 reference voxel structs} per block in a little-endian container of our own
- * (the reference's .nvblx format lives in the absent nvblox core).  load replaces the map: it is cleared first, the file's
- * voxel size must equal the mapper's, loaded TSDF blocks are ESDF- and mesh-dirty.  Errors: NVBX_E_IO, NVBX_E_INVALID
- * (voxel size), NVBX_E_CAPACITY; a file that fails validation leaves the current map untouched. */
+/* ---- map file (Mapper::saveLayerCake(path) -> bool, loadMap(path) -> bool: nvblox_node.cpp:1663-1668,1698-1703) -----------------
+ * A path ending in .nvblx is written as an SQLITE database, like the reference's layer cake: table layers(layer_type, voxel_size,
+ * block_size, voxel_bytes, num_blocks) + one table <layer_type>_blocks(index_x, index_y, index_z, data BLOB) per layer (tsdf_layer,
+ * color_layer, esdf_layer, occupancy_layer; data = 512 reference voxel structs).  [U] The schema is a guess at upstream's (the
+ * serializer lives in the absent core): files open with any sqlite3 tool, interoperability with upstream's reader is unverified.
+ * libsqlite3 is loaded at run time; any other path (or no libsqlite3) uses a compact little-endian container of our own.  load
+ * recognises either by its magic and replaces the map: it is cleared first, the file's voxel size must equal the mapper's, loaded TSDF
+ * blocks are ESDF- and mesh-dirty.  Errors: NVBX_E_IO, NVBX_E_INVALID (voxel size), NVBX_E_CAPACITY; a file that fails validation
+ * leaves the current map untouched. */
 int nvbx_save_map(nvbx_mapper* m, const char* path);
 int nvbx_load_map(nvbx_mapper* m, const char* path);
 

@@ -601,8 +601,164 @@ const char kMapMagic[8] = {'N', 'V', 'B', 'X', 'M', 'A', 'P', '1'};
 struct FileCloser { FILE* f; ~FileCloser() { if (f) fclose(f); } };
 }  // namespace
 
+// ---- .nvblx: the layer cake as an SQLite database ([U]: the reference's serializer (nvblox/serialization, absent) stores the layers in
+// an SQLite file, saveLayerCake / loadMap of nvblox_node.cpp:1663-1703 take a *.nvblx path; the schema below is a guess at that layout,
+// so files are readable with any sqlite3 tool but NOT verified against upstream's):
+//   layers(layer_type TEXT PRIMARY KEY, voxel_size REAL, block_size REAL, voxel_bytes INTEGER, num_blocks INTEGER)
+//   <layer_type>_blocks(index_x INTEGER, index_y INTEGER, index_z INTEGER, data BLOB, PRIMARY KEY(index_x, index_y, index_z))
+// with layer_type in {tsdf_layer, color_layer, esdf_layer, occupancy_layer}; data = the block's 512 voxels as the reference's
+// structs in z + 8y + 64x order.  libsqlite3 is loaded at run time (dlopen): no header / link dependency; without it (or for a path
+// that does not end in .nvblx) the compact container of our own is written / read.
+#include <dlfcn.h>
+namespace {
+struct Sqlite {
+  void* lib = nullptr;
+  int (*open)(const char*, void**) = nullptr; int (*close)(void*) = nullptr;
+  int (*exec)(void*, const char*, int (*)(void*, int, char**, char**), void*, char**) = nullptr;
+  int (*prepare)(void*, const char*, int, void**, const char**) = nullptr;
+  int (*bind_int)(void*, int, int) = nullptr; int (*bind_double)(void*, int, double) = nullptr;
+  int (*bind_text)(void*, int, const char*, int, void (*)(void*)) = nullptr; int (*bind_blob)(void*, int, const void*, int, void (*)(void*)) = nullptr;
+  int (*step)(void*) = nullptr; int (*reset)(void*) = nullptr; int (*finalize)(void*) = nullptr;
+  int (*column_int)(void*, int) = nullptr; double (*column_double)(void*, int) = nullptr; const void* (*column_blob)(void*, int) = nullptr;
+  int (*column_bytes)(void*, int) = nullptr; const unsigned char* (*column_text)(void*, int) = nullptr;
+  bool ok() const { return lib != nullptr; }
+};
+const Sqlite& sqlite() {
+  static Sqlite s = [] {
+    Sqlite q;
+    for (const char* name : {"libsqlite3.so.0", "libsqlite3.so"}) { q.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (q.lib) break; }
+    if (!q.lib) return q;
+    auto sym = [&](const char* n) { void* p = dlsym(q.lib, n); if (!p) q.lib = nullptr; return p; };
+    void* lib = q.lib;
+#define NVBX_SQL(field, name) *(void**)(&q.field) = sym(name)
+    NVBX_SQL(open, "sqlite3_open"); NVBX_SQL(close, "sqlite3_close"); NVBX_SQL(exec, "sqlite3_exec"); NVBX_SQL(prepare, "sqlite3_prepare_v2");
+    NVBX_SQL(bind_int, "sqlite3_bind_int"); NVBX_SQL(bind_double, "sqlite3_bind_double"); NVBX_SQL(bind_text, "sqlite3_bind_text"); NVBX_SQL(bind_blob, "sqlite3_bind_blob");
+    NVBX_SQL(step, "sqlite3_step"); NVBX_SQL(reset, "sqlite3_reset"); NVBX_SQL(finalize, "sqlite3_finalize"); NVBX_SQL(column_int, "sqlite3_column_int");
+    NVBX_SQL(column_double, "sqlite3_column_double"); NVBX_SQL(column_blob, "sqlite3_column_blob"); NVBX_SQL(column_bytes, "sqlite3_column_bytes");
+    NVBX_SQL(column_text, "sqlite3_column_text");
+#undef NVBX_SQL
+    if (!q.lib) { dlclose(lib); }
+    return q;
+  }();
+  return s;
+}
+constexpr int kSqlOk = 0, kSqlRow = 100, kSqlDone = 101;
+struct LayerName { uint32_t layer; const char* name; };
+const LayerName kLayerNames[] = {{F_TSDF, "tsdf_layer"}, {F_COLOR, "color_layer"}, {F_ESDF, "esdf_layer"}, {NVBX_LAYER_OCCUPANCY, "occupancy_layer"}};
+bool ends_with(const char* s, const char* suffix) { const size_t a = strlen(s), b = strlen(suffix); return a >= b && strcmp(s + a - b, suffix) == 0; }
+struct DbCloser { void* db; ~DbCloser() { if (db) sqlite().close(db); } };
+struct StmtCloser { void* st; ~StmtCloser() { if (st) sqlite().finalize(st); } };
+}  // namespace
+
+static int save_map_nvblx(nvbx_mapper* m, const char* path) {
+  const Sqlite& q = sqlite();
+  remove(path);
+  DbCloser db{nullptr};
+  if (q.open(path, &db.db) != kSqlOk) { set_error("nvbx_save_map: cannot create the .nvblx (SQLite) file"); return NVBX_E_IO; }
+  if (q.exec(db.db, "PRAGMA journal_mode=OFF; PRAGMA synchronous=OFF; BEGIN;"
+                    "CREATE TABLE layers(layer_type TEXT PRIMARY KEY, voxel_size REAL, block_size REAL, voxel_bytes INTEGER, num_blocks INTEGER);", nullptr, nullptr, nullptr) != kSqlOk) {
+    set_error("nvbx_save_map: SQLite schema"); return NVBX_E_IO; }
+  const uint32_t layers[3] = {m->p.projective_layer_type == 1 ? NVBX_LAYER_OCCUPANCY : F_TSDF, F_COLOR, F_ESDF};
+  for (uint32_t layer : layers) {
+    const char* name = nullptr; for (const LayerName& ln : kLayerNames) if (ln.layer == layer) name = ln.name;
+    const int64_t n = nvbx_num_blocks(m, layer);
+    if (n < 0) return (int)n;
+    std::vector<nvbx_index3d> idx((size_t)std::max<int64_t>(n, 1));
+    if (n > 0 && nvbx_block_indices(m, layer, idx.data(), n) < 0) return NVBX_E_DEVICE;
+    const size_t bb = 512 * ref_voxel_bytes(layer);
+    char sql[256];
+    snprintf(sql, sizeof(sql), "CREATE TABLE %s_blocks(index_x INTEGER, index_y INTEGER, index_z INTEGER, data BLOB, PRIMARY KEY(index_x, index_y, index_z));", name);
+    if (q.exec(db.db, sql, nullptr, nullptr, nullptr) != kSqlOk) { set_error("nvbx_save_map: SQLite create table"); return NVBX_E_IO; }
+    {
+      StmtCloser st{nullptr};
+      if (q.prepare(db.db, "INSERT INTO layers VALUES(?, ?, ?, ?, ?);", -1, &st.st, nullptr) != kSqlOk) { set_error("nvbx_save_map: SQLite prepare"); return NVBX_E_IO; }
+      q.bind_text(st.st, 1, name, -1, nullptr); q.bind_double(st.st, 2, (double)m->p.voxel_size); q.bind_double(st.st, 3, (double)(m->p.voxel_size * 8.0f));
+      q.bind_int(st.st, 4, (int)ref_voxel_bytes(layer)); q.bind_int(st.st, 5, (int)n);
+      if (q.step(st.st) != kSqlDone) { set_error("nvbx_save_map: SQLite insert"); return NVBX_E_IO; }
+    }
+    snprintf(sql, sizeof(sql), "INSERT INTO %s_blocks VALUES(?, ?, ?, ?);", name);
+    StmtCloser st{nullptr};
+    if (q.prepare(db.db, sql, -1, &st.st, nullptr) != kSqlOk) { set_error("nvbx_save_map: SQLite prepare"); return NVBX_E_IO; }
+    const int64_t chunk = 4096;
+    std::vector<uint8_t> buf((size_t)std::min<int64_t>(std::max<int64_t>(n, 1), chunk) * bb);
+    for (int64_t o = 0; o < n; o += chunk) {
+      const int64_t c = std::min(chunk, n - o);
+      const int rc = nvbx_get_blocks(m, layer, idx.data() + o, c, buf.data(), nullptr);
+      if (rc) return rc;
+      for (int64_t i = 0; i < c; i++) {
+        q.reset(st.st);
+        q.bind_int(st.st, 1, idx[(size_t)(o + i)].x); q.bind_int(st.st, 2, idx[(size_t)(o + i)].y); q.bind_int(st.st, 3, idx[(size_t)(o + i)].z);
+        q.bind_blob(st.st, 4, buf.data() + (size_t)i * bb, (int)bb, nullptr);          // (static: the buffer outlives the step)
+        if (q.step(st.st) != kSqlDone) { set_error("nvbx_save_map: SQLite insert block"); return NVBX_E_IO; }
+      }
+    }
+  }
+  if (q.exec(db.db, "COMMIT;", nullptr, nullptr, nullptr) != kSqlOk) { set_error("nvbx_save_map: SQLite commit"); return NVBX_E_IO; }
+  return NVBX_OK;
+}
+
+static int load_map_nvblx(nvbx_mapper* m, const char* path) {
+  const Sqlite& q = sqlite();
+  DbCloser db{nullptr};
+  if (q.open(path, &db.db) != kSqlOk) { set_error("nvbx_load_map: cannot open the .nvblx (SQLite) file"); return NVBX_E_IO; }
+  // validate before the current map is touched: the layer table, voxel size, voxel struct sizes, block counts, blob sizes
+  struct L { uint32_t layer; std::string name; int64_t n; size_t bb; };
+  std::vector<L> found;
+  {
+    StmtCloser st{nullptr};
+    if (q.prepare(db.db, "SELECT layer_type, voxel_size, voxel_bytes, num_blocks FROM layers;", -1, &st.st, nullptr) != kSqlOk) { set_error("nvbx_load_map: not an .nvblx layer cake"); return NVBX_E_IO; }
+    int rc;
+    while ((rc = q.step(st.st)) == kSqlRow) {
+      const char* nm = (const char*)q.column_text(st.st, 0);
+      uint32_t layer = 0; for (const LayerName& ln : kLayerNames) if (nm && !strcmp(nm, ln.name)) layer = ln.layer;
+      const double vs = q.column_double(st.st, 1); const int vb = q.column_int(st.st, 2); const int64_t n = q.column_int(st.st, 3);
+      if (!layer || vb != (int)ref_voxel_bytes(layer) || n < 0) { set_error("nvbx_load_map: unknown layer record"); return NVBX_E_IO; }
+      if (fabs(vs - (double)m->p.voxel_size) > 1e-6 * m->p.voxel_size) { set_error("nvbx_load_map: voxel size of the file differs from the mapper's"); return NVBX_E_INVALID; }
+      if (n > 0 && !internal_layer(m, layer)) { set_error("nvbx_load_map: the file holds a layer this mapper's projective layer type cannot"); return NVBX_E_IO; }
+      if (n > (1ll << 24)) { set_error("nvbx_load_map: implausible block count"); return NVBX_E_CAPACITY; }
+      found.push_back({layer, nm, n, 512 * ref_voxel_bytes(layer)});
+    }
+    if (rc != kSqlDone || found.empty()) { set_error("nvbx_load_map: not an .nvblx layer cake"); return NVBX_E_IO; }
+  }
+  for (const L& l : found) {
+    char sql[256]; snprintf(sql, sizeof(sql), "SELECT COUNT(*), MIN(LENGTH(data)), MAX(LENGTH(data)) FROM %s_blocks;", l.name.c_str());
+    StmtCloser st{nullptr};
+    if (q.prepare(db.db, sql, -1, &st.st, nullptr) != kSqlOk || q.step(st.st) != kSqlRow) { set_error("nvbx_load_map: block table missing"); return NVBX_E_IO; }
+    const int64_t cnt = q.column_int(st.st, 0);
+    if (cnt != l.n || (cnt > 0 && (q.column_int(st.st, 1) != (int)l.bb || q.column_int(st.st, 2) != (int)l.bb))) { set_error("nvbx_load_map: block table does not match its layer record"); return NVBX_E_IO; }
+  }
+  int rc = nvbx_mapper_clear(m);
+  if (rc) return rc;
+  for (const L& l : found) {
+    char sql[256]; snprintf(sql, sizeof(sql), "SELECT index_x, index_y, index_z, data FROM %s_blocks;", l.name.c_str());
+    StmtCloser st{nullptr};
+    if (q.prepare(db.db, sql, -1, &st.st, nullptr) != kSqlOk) { set_error("nvbx_load_map: SQLite prepare"); return NVBX_E_IO; }
+    const int64_t chunk = 2048;
+    std::vector<nvbx_index3d> idx; std::vector<uint8_t> buf;
+    idx.reserve((size_t)chunk); buf.reserve((size_t)chunk * l.bb);
+    int s;
+    for (;;) {
+      s = q.step(st.st);
+      if (s == kSqlRow) {
+        idx.push_back({q.column_int(st.st, 0), q.column_int(st.st, 1), q.column_int(st.st, 2)});
+        const uint8_t* blob = (const uint8_t*)q.column_blob(st.st, 3);
+        buf.insert(buf.end(), blob, blob + l.bb);
+      }
+      if ((s != kSqlRow || (int64_t)idx.size() == chunk) && !idx.empty()) {
+        rc = nvbx_set_blocks(m, l.layer, idx.data(), (int64_t)idx.size(), buf.data());
+        if (rc) return rc;
+        idx.clear(); buf.clear();
+      }
+      if (s != kSqlRow) break;
+    }
+    if (s != kSqlDone) { set_error("nvbx_load_map: SQLite read"); return NVBX_E_IO; }
+  }
+  return NVBX_OK;
+}
+
 extern "C" int nvbx_save_map(nvbx_mapper* m, const char* path) {
   if (!m || !path) { set_error("nvbx_save_map: invalid argument"); return NVBX_E_INVALID; }
+  if (ends_with(path, ".nvblx") && sqlite().ok()) return save_map_nvblx(m, path);
   FileCloser fc{fopen(path, "wb")};
   if (!fc.f) { set_error("nvbx_save_map: cannot open file for writing"); return NVBX_E_IO; }
   const uint32_t layers[3] = {m->p.projective_layer_type == 1 ? NVBX_LAYER_OCCUPANCY : F_TSDF, F_COLOR, F_ESDF};
@@ -633,6 +789,13 @@ extern "C" int nvbx_load_map(nvbx_mapper* m, const char* path) {
   if (!m || !path) { set_error("nvbx_load_map: invalid argument"); return NVBX_E_INVALID; }
   FileCloser fc{fopen(path, "rb")};
   if (!fc.f) { set_error("nvbx_load_map: cannot open file"); return NVBX_E_IO; }
+  { char magic[16] = {0};                             // an SQLite database = an .nvblx layer cake
+    if (fread(magic, 1, 16, fc.f) == 16 && !memcmp(magic, "SQLite format 3", 16)) {
+      if (!sqlite().ok()) { set_error("nvbx_load_map: the file is an SQLite .nvblx but libsqlite3 cannot be loaded"); return NVBX_E_IO; }
+      fclose(fc.f); fc.f = nullptr;
+      return load_map_nvblx(m, path);
+    }
+    fseek(fc.f, 0, SEEK_SET); }
   MapFileHeader h{};
   if (fread(&h, sizeof(h), 1, fc.f) != 1 || memcmp(h.magic, kMapMagic, 8) != 0 || h.version != 1) { set_error("nvbx_load_map: not a libnvblox_hip map file"); return NVBX_E_IO; }
   if (fabsf(h.voxel_size - m->p.voxel_size) > 1e-6f * m->p.voxel_size) { set_error("nvbx_load_map: voxel size of the file differs from the mapper's"); return NVBX_E_INVALID; }

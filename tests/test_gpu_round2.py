@@ -114,3 +114,54 @@ def test_set_blocks_with_duplicate_indices(hip_lib):
         assert g.num_blocks(M.LAYER_TSDF) == 2
         b, found = g.get_blocks(M.LAYER_TSDF, [[1, 2, 3], [4, 5, 6]])
         assert found.all() and (b["distance"] == np.float32(0.125)).all() and (b["weight"] == 1.0).all()
+
+
+def test_nvblx_layer_cake_is_an_sqlite_database(oracle_mod, hip_lib, tmp_path):
+    """saveLayerCake / loadMap on a *.nvblx path (nvblox_node.cpp:1663-1703): an SQLite file that Python's own sqlite3 module reads
+    (an independent reader: block indices and voxel blobs equal the layer accessors'), and that loads back into an identical map."""
+    import sqlite3
+    M, g, o = make_pair(oracle_mod)
+    for d, rgb, T in H.frames(3, H.SMALL_CAM, color=True, stride=9):
+        g.integrate_depth(d, T, H.SMALL_CAM); g.integrate_color(rgb, T, H.SMALL_CAM)
+    g.update_esdf()
+    path = tmp_path / "map.nvblx"
+    g.save_map(path)
+    assert path.read_bytes()[:15] == b"SQLite format 3"
+    db = sqlite3.connect(str(path))
+    layers = {r[0]: r[1:] for r in db.execute("SELECT layer_type, voxel_size, block_size, voxel_bytes, num_blocks FROM layers")}
+    assert set(layers) == {"tsdf_layer", "color_layer", "esdf_layer"}
+    assert abs(layers["tsdf_layer"][0] - 0.05) < 1e-7 and abs(layers["tsdf_layer"][1] - 0.4) < 1e-6
+    for name, layer, dt in (("tsdf_layer", M.LAYER_TSDF, M.TSDF_DT), ("color_layer", M.LAYER_COLOR, M.COLOR_DT), ("esdf_layer", M.LAYER_ESDF, M.ESDF_DT)):
+        rows = db.execute("SELECT index_x, index_y, index_z, data FROM %s_blocks ORDER BY index_x, index_y, index_z" % name).fetchall()
+        idx = g.block_indices(layer)
+        assert layers[name][2] == dt.itemsize and layers[name][3] == len(idx) == len(rows)
+        assert np.array_equal(np.array([r[:3] for r in rows], np.int32), idx)
+        blocks, _ = g.get_blocks(layer, idx)
+        for k in range(0, len(rows), 37):
+            assert rows[k][3] == blocks[k].tobytes()
+    db.close()
+    g2 = M.Mapper(M.default_params(), block_capacity=1 << 12)
+    g2.load_map(path)
+    for layer, fields in ((M.LAYER_TSDF, ("distance", "weight")), (M.LAYER_COLOR, ("r", "g", "b", "weight")), (M.LAYER_ESDF, ESDF_FIELDS)):
+        ia, ib = g.block_indices(layer), g2.block_indices(layer)
+        assert np.array_equal(ia, ib)
+        ba, _ = g.get_blocks(layer, ia); bb, _ = g2.get_blocks(layer, ib)
+        for f in fields:
+            assert np.array_equal(ba[f], bb[f]), (layer, f)
+    # the loaded map keeps working: a further ESDF update gives the slice of the original
+    g.update_esdf(); g2.update_esdf()
+    sa, _ = g.esdf_slice_image(); sb, _ = g2.esdf_slice_image()
+    assert sa.shape == sb.shape and np.array_equal(sa, sb)
+    # a truncated / foreign SQLite file is refused and the map stays
+    bad = tmp_path / "bad.nvblx"
+    con = sqlite3.connect(str(bad)); con.execute("CREATE TABLE t(x)"); con.commit(); con.close()
+    n0 = g2.num_blocks(M.LAYER_TSDF)
+    with pytest.raises(M.NvbxError):
+        g2.load_map(bad)
+    assert g2.num_blocks(M.LAYER_TSDF) == n0
+    # any other extension: the compact container, still loadable
+    p2 = tmp_path / "map.bin"
+    g.save_map(p2)
+    assert p2.read_bytes()[:8] == b"NVBXMAP1"
+    g2.load_map(p2)
+    assert np.array_equal(g2.block_indices(M.LAYER_TSDF), g.block_indices(M.LAYER_TSDF))
