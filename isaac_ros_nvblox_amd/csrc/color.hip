@@ -29,7 +29,7 @@ constexpr int RAY_LANES = 8;    // lanes cooperating on one ray = samples fetche
 // The sequence of t values -- and so the result -- is bit-identical to the one-sample-at-a-time march.
 // The colour frames of one launch set: one frame, or a batch of up to MAX_BATCH (nvbx_integrate_color_batch); kernel arguments.
 template <int NB> struct PoseSet { Frame f[NB]; int32_t n; };
-template <typename Pix, int NB> struct FrameSetC { Frame f[NB]; Pix img[NB]; int32_t n; };
+template <typename Pix, int NB> struct FrameSetC { Frame f[NB]; Pix img[NB]; int32_t n; int32_t chunk; };
 
 template <int NB>
 __global__ __launch_bounds__(256) void k_sphere_trace(DMap m, PoseSet<NB> poses, float* synth_all, int32_t srows, int32_t scols, int32_t max_steps,
@@ -160,26 +160,42 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, FrameSetC<Pix, 
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
   const Frame& f0 = fs.f[0];
   const int ncam = NB > 1 ? fs.n : 1;
-  // the first slot's data is requested beside the high-water mark (gridDim.x <= capacity, so the addresses are valid)
-  int32_t slot = wg;
-  uint32_t flags = m.slot_flags[slot];
-  int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
+  // Candidate discovery.  Every allocated slot has to be looked at (O(map) flags, not O(view)): with one slot per workgroup iteration a
+  // 10^5-block map costs ~150 dependent flag loads per workgroup.  So a workgroup takes `chunk` CONSECUTIVE slots per iteration (a
+  // host hint, 1 .. 64, from the high-water mark the GPU last reported): lane l of every wavefront loads the flags and Index3D of slot
+  // base + l, a ballot picks the blocks in the truncation band, and only those are visited.  chunk = 1 is the room-sized case: the
+  // first slot's data is requested beside the high-water mark (indices clamped, so the addresses are valid).
+  const int chunk = fs.chunk;
+  const int lane_c = tid & 63;
+  const int32_t cap = (int32_t)m.capacity;
+  int32_t base = wg * chunk;
+  int32_t ls = min(base + lane_c, cap - 1);
+  uint32_t lflags = lane_c < chunk ? m.slot_flags[ls] : 0u;
+  int32_t lbx = 0, lby = 0, lbz = 0;
+  if (lane_c < chunk) { lbx = m.slot_index[3 * ls]; lby = m.slot_index[3 * ls + 1]; lbz = m.slot_index[3 * ls + 2]; }
   const int32_t hw = m.counters[C_HIGH_WATER];
-  for (; slot < hw; slot += n_color_wg) {
-    if (slot != wg) {
-      flags = m.slot_flags[slot];
-      bx = m.slot_index[3 * slot]; by = m.slot_index[3 * slot + 1]; bz = m.slot_index[3 * slot + 2];
+  for (; base < hw; base += n_color_wg * chunk) {
+    if (base != wg * chunk) {
+      ls = min(base + lane_c, cap - 1);
+      lflags = lane_c < chunk ? m.slot_flags[ls] : 0u;
+      if (lane_c < chunk) { lbx = m.slot_index[3 * ls]; lby = m.slot_index[3 * ls + 1]; lbz = m.slot_index[3 * ls + 2]; }
     }
     // the band vote ("any voxel with weight > 0 and |distance| < truncation") is the slot's F_BAND flag, kept exact by every
     // kernel that writes TSDF voxels (nvbx_internal.h): no TSDF read here -- unless a LiDAR scan left the block STALE, in which
     // case this workgroup votes from the TSDF once and repairs the bits
-    if (!(flags & F_TSDF)) continue;     // uniform
+    u64 cand = __ballot(lane_c < chunk && base + lane_c < hw && (lflags & F_TSDF) && (lflags & (F_BAND | F_BAND_STALE)));     // (the same in all eight wavefronts)
+  while (cand) {
+    const int cj = __ffsll((long long)cand) - 1;
+    cand &= cand - 1ull;
+    const int32_t slot = base + cj;
+    const uint32_t flags = __shfl(lflags, cj);
+    const int32_t bx = __shfl(lbx, cj), by = __shfl(lby, cj), bz = __shfl(lbz, cj);
     if (flags & F_BAND_STALE) {          // uniform
       const float2 tv = m.tsdf[(size_t)slot * 512 + tid];
       const bool pred = in_band(tv.x, tv.y, f0.trunc);
       publish_band(m.slot_flags, (uint32_t)slot, tid, pred);
       if (!__syncthreads_or(pred ? 1 : 0)) continue;
-    } else if (!(flags & F_BAND)) continue;
+    }
     __syncthreads();
     if (tid < 6 * NB) (&s_out[0][0])[tid] = 0;
     __syncthreads();
@@ -270,6 +286,7 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, FrameSetC<Pix, 
     }
     if (touched) *cp = cur;
   }
+  }
 }
 
 // n colour frames (n = 1: MultiMapper::integrateColor; n > 1: nvbx_integrate_color_batch) of one image size -> one launch set
@@ -285,6 +302,10 @@ static int integrate_colors(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t 
   PoseSet<NB> ps{}; ps.n = n;
   for (int c = 0; c < n; c++) { fs.f[c] = m->make_frame(T_L_C + 16 * c, cameras + c, rows, cols, m->p.sphere_tracing_subsampling); fs.img[c] = imgs[c]; ps.f[c] = fs.f[c]; }
   const Frame& f = fs.f[0];
+  { // slots per workgroup iteration of k_integrate_color's candidate scan: from the high-water mark the GPU last reported (a hint only)
+    const int64_t hw_seen = std::max<int64_t>(1, __atomic_load_n(&m->h_mirror[1], __ATOMIC_RELAXED));
+    int ch = 1; while (ch < 64 && (int64_t)ch * std::min<int64_t>(m->capacity, 1024) < hw_seen) ch *= 2;
+    fs.chunk = ch; }
   const int32_t srows = rows / f.subsample, scols = cols / f.subsample;
   if (srows < 2 || scols < 2) { set_error("colour image too small for the sphere-tracing subsampling"); return NVBX_E_INVALID; }
   if ((int64_t)srows * scols * n > m->synth_cap) {

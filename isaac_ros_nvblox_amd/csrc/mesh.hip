@@ -65,8 +65,31 @@ __device__ inline void edge_decode(int eid, int* li, int* lj, int* axis, int* lx
   *lj = *li + (*axis == 0 ? 81 : (*axis == 1 ? 9 : 1));
 }
 
+// Full-layer meshing (UpdateFullLayer::kYes) of a large map is mostly free space: a block whose own and +x/+y/+z neighbour blocks hold
+// no observed voxel with a negative distance cannot contain a zero crossing.  A streaming pre-pass (every TSDF voxel read once, eight
+// blocks per workgroup iteration, no barriers) leaves one byte per slot -- "has an observed negative voxel" -- and k_mesh then skips
+// such blocks after its eight hash probes, before touching a voxel.  (The exact per-slot band flag F_BAND would do the same for
+// camera-built maps, but LiDAR integration leaves it stale; the pre-pass is exact for every map and costs ~0.2 ms per 10^5 blocks.)
+__global__ __launch_bounds__(512) void k_mesh_prepass(DMap m, float min_weight, uint8_t* neg_any) {
+  constexpr int PB = 8;
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  const int tid = threadIdx.x;
+  for (int32_t base = blockIdx.x * PB; base < hw; base += gridDim.x * PB) {
+    float2 tv[PB];
+#pragma unroll
+    for (int j = 0; j < PB; j++) {
+      const int32_t slot = base + j;
+      const bool act = slot < hw && (m.slot_flags[slot < hw ? slot : 0] & F_TSDF);
+      tv[j] = act ? m.tsdf[(size_t)slot * 512 + tid] : make_float2(0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int j = 0; j < PB; j++)
+      if (__ballot(tv[j].y >= min_weight && tv[j].x < 0.0f) != 0ull && (tid & 63) == 0) neg_any[base + j] = 1;
+  }
+}
+
 __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert, float* o_nrm, uint32_t* o_col,
-                                              int32_t* o_tri, MeshRecord* o_rec) {
+                                              int32_t* o_tri, MeshRecord* o_rec, const uint8_t* neg_any) {
   __shared__ float s_d[NLAT];
   __shared__ uint8_t s_valid[NLAT];
   __shared__ int32_t s_first[NEDGE];
@@ -106,8 +129,19 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
                    : (a.min_weight > 0.0f ? any_slot(m, bx + (tid & 1), by + ((tid >> 1) & 1), bz + ((tid >> 2) & 1))
                                           : find_slot(m, bx + (tid & 1), by + ((tid >> 1) & 1), bz + ((tid >> 2) & 1), F_TSDF));   // (weight 0 would pass a min_weight of 0)
     if (tid == 0) { atomicAnd(&m.slot_flags[slot], ~F_DIRTY_MESH); atomicOr(&m.slot_flags[slot], F_MESH); }
-    for (int e = tid; e < NEDGE; e += 512) s_first[e] = INT32_MAX;
     __syncthreads();
+    if (neg_any) {                                                       // full-layer mode: no negative voxel in reach -> no triangle (uniform)
+      int reach = 0;
+      if (tid < 8) { const uint32_t ns = s_nslot[tid]; reach = slot_ok(ns) ? (int)neg_any[ns] : 0; }
+      if (!__syncthreads_or(reach)) {
+        if (tid == 0) {
+          atomicAdd(shc_at(m, a.srec, sh, 0), 1);
+          MeshRecord r; r.x = bx; r.y = by; r.z = bz; r.vbase = 0; r.nvert = 0; r.tbase = 0; r.ntri = 0; r.pad = 0;
+          o_rec[it] = r;
+        }
+        continue;
+      }
+    }
     for (int li = tid; li < NLAT; li += 512) {
       const int lz = li % 9, ly = (li / 9) % 9, lx = li / 81;
       const uint32_t ns = s_nslot[(lx >> 3) | ((ly >> 3) << 1) | ((lz >> 3) << 2)];
@@ -128,8 +162,18 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
     int ntri = 0;
     const int8_t* tri_row = MC_TRI_C[a.rule][cube];
     if (ok && cube != 0 && cube != 255) { while (ntri < 5 && tri_row[3 * ntri] >= 0) ntri++; }
+    // a block without a triangle (free space, unobserved): an empty record, no scans, no arena reservation (uniform)
+    if (!__syncthreads_or(ntri)) {
+      if (tid == 0) {
+        atomicAdd(shc_at(m, a.srec, sh, 0), 1);
+        MeshRecord r; r.x = bx; r.y = by; r.z = bz; r.vbase = 0; r.nvert = 0; r.tbase = 0; r.ntri = 0; r.pad = 0;
+        o_rec[it] = r;
+      }
+      continue;
+    }
+    for (int e = tid; e < NEDGE; e += 512) s_first[e] = INT32_MAX;
     int T;
-    const int toff = block_scan_512(ntri, s_part, tid, &T);
+    const int toff = block_scan_512(ntri, s_part, tid, &T);      // (its barriers also order the initialisation above before the atomicMin below)
     for (int j = 0; j < ntri; j++) {
 #pragma unroll
       for (int q = 0; q < 3; q++) {
@@ -259,8 +303,14 @@ extern "C" int nvbx_update_color_mesh(nvbx_mapper* m, int32_t update_full_layer)
   // 37 KB of LDS per workgroup -> 4 resident per CU: keep the grid within one resident batch (a 2048-workgroup grid ran
   // as two batches, the second waiting ~10 us for the first to drain); longer lists are covered by the grid-stride loop
   const int grid = (int)std::min<int64_t>(m->capacity, 768);
+  const uint8_t* neg_any = nullptr;
+  if (a.full) {            // one byte per slot in the export scratch (capacity x 12 bytes)
+    NVBX_HIP(hipMemsetAsync(m->export_idx, 0, (size_t)m->capacity, m->stream));
+    NVBX_LAUNCH(m, k_mesh_prepass, dim3((unsigned)std::min<int64_t>((m->capacity + 7) / 8, 2048)), dim3(512), m->d, a.min_weight, (uint8_t*)m->export_idx);
+    neg_any = (const uint8_t*)m->export_idx;
+  }
   NVBX_LAUNCH(m, k_mesh, dim3(grid), dim3(512), m->d, a, m->mesh_vert, m->mesh_nrm, (uint32_t*)m->mesh_col,
-                     m->mesh_tri, m->mesh_rec);
+                     m->mesh_tri, m->mesh_rec, neg_any);
   NVBX_HIP(hipGetLastError());
   m->mesh_epoch++;
   return NVBX_OK;

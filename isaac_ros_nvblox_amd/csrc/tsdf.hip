@@ -455,6 +455,7 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, FrameSet<Img, NB
   if (view_export && blockIdx.x == 0 && tid == 0) { view_export[0] = min(n, view_export_cap); view_export[1] = 0; view_export[2] = 0; }
   // pool growth: the free-slot count after this frame's allocations goes to pinned host memory (not waited for)
   if (blockIdx.x == 0 && tid == 64) __hip_atomic_store(&m.host_mirror[0], m.counters[C_FREE_TOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (blockIdx.x == 0 && tid == 128) __hip_atomic_store(&m.host_mirror[1], m.counters[C_HIGH_WATER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
   for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
     if (i != (int32_t)blockIdx.x) rec = view_list[i];
