@@ -737,8 +737,7 @@ static int lidar_sample(const OrcParams* p, const LidarTab* t, const float* img,
   float dir[3]; lidar_dir(t, rr, c, dir);
   float dot = pc[0] * dir[0]; dot = dot + pc[1] * dir[1]; dot = dot + pc[2] * dir[2];
   const float ex = pc[0] - dot * dir[0], ey = pc[1] - dot * dir[1], ez = pc[2] - dot * dir[2];
-  const float dist = sqrtf((ex * ex + ey * ey) + ez * ez);
-  if (dist > max_ray) return 0;
+  if ((ex * ex + ey * ey) + ez * ez > max_ray * max_ray) return 0;       /* squared point-to-ray distance against the squared threshold */
   *ds = d;
   return 1;
 }
