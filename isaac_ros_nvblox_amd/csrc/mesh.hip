@@ -111,8 +111,8 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
   const int32_t n = a.full ? m.counters[C_HIGH_WATER] : nlist;
   if (blockIdx.x == 0 && tid == 0) m.counters[a.rec + 0] = n;           // records o_rec[0..n): one per list entry, invalid ones marked
   const int sh = my_shard();
-  for (int32_t it = blockIdx.x; it < n; it += gridDim.x) {
-    const uint32_t slot = a.full ? (uint32_t)it : (uint32_t)list_at(m, a.dirty_list, lv, it);
+  // one block: record index `it`, pool slot `slot` (whole workgroup; `return` = next block)
+  auto mesh_block = [&](const int32_t it, const uint32_t slot) {
     const uint32_t flags = m.slot_flags[slot];
     if (!(flags & F_TSDF)) {                                             // uniform: block was deallocated meanwhile (or, full mode, is no TSDF block)
       if (tid == 0) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
         MeshRecord r; r.x = INT32_MIN; r.y = 0; r.z = 0; r.vbase = -1; r.nvert = 0; r.tbase = 0; r.ntri = 0; r.pad = 0;
         o_rec[it] = r;
       }
-      continue;
+      return;
     }
     const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
     __syncthreads();                                                     // previous iteration done with LDS
@@ -130,18 +130,6 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
                                           : find_slot(m, bx + (tid & 1), by + ((tid >> 1) & 1), bz + ((tid >> 2) & 1), F_TSDF));   // (weight 0 would pass a min_weight of 0)
     if (tid == 0) { atomicAnd(&m.slot_flags[slot], ~F_DIRTY_MESH); atomicOr(&m.slot_flags[slot], F_MESH); }
     __syncthreads();
-    if (neg_any) {                                                       // full-layer mode: no negative voxel in reach -> no triangle (uniform)
-      int reach = 0;
-      if (tid < 8) { const uint32_t ns = s_nslot[tid]; reach = slot_ok(ns) ? (int)neg_any[ns] : 0; }
-      if (!__syncthreads_or(reach)) {
-        if (tid == 0) {
-          atomicAdd(shc_at(m, a.srec, sh, 0), 1);
-          MeshRecord r; r.x = bx; r.y = by; r.z = bz; r.vbase = 0; r.nvert = 0; r.tbase = 0; r.ntri = 0; r.pad = 0;
-          o_rec[it] = r;
-        }
-        continue;
-      }
-    }
     for (int li = tid; li < NLAT; li += 512) {
       const int lz = li % 9, ly = (li / 9) % 9, lx = li / 81;
       const uint32_t ns = s_nslot[(lx >> 3) | ((ly >> 3) << 1) | ((lz >> 3) << 2)];
@@ -169,7 +157,7 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
         MeshRecord r; r.x = bx; r.y = by; r.z = bz; r.vbase = 0; r.nvert = 0; r.tbase = 0; r.ntri = 0; r.pad = 0;
         o_rec[it] = r;
       }
-      continue;
+      return;
     }
     for (int e = tid; e < NEDGE; e += 512) s_first[e] = INT32_MAX;
     int T;
@@ -213,7 +201,7 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
     }
     __syncthreads();
     const int vbase = s_base[0], tbase = s_base[1];
-    if (vbase < 0) continue;                                             // uniform (arena overflow)
+    if (vbase < 0) return;                                             // uniform (arena overflow)
     // emit vertices
     const int32_t b3[3] = {bx, by, bz};
     // one welded vertex per thread (a block has ~25-150 of them): balanced, unlike walking the 2187 edge ids
@@ -282,6 +270,53 @@ __global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert,
       o_tri[3 * o] = s_vid[s_tri_edges[3 * (toff + j)]];
       o_tri[3 * o + 1] = s_vid[s_tri_edges[3 * (toff + j) + 1]];
       o_tri[3 * o + 2] = s_vid[s_tri_edges[3 * (toff + j) + 2]];
+    }
+  };
+  if (!a.full) {
+    for (int32_t it = blockIdx.x; it < n; it += gridDim.x) mesh_block(it, (uint32_t)list_at(m, a.dirty_list, lv, it));
+    return;
+  }
+  // Full layer (record index == slot).  Most of a large map is free space, and per block the test "can it hold a zero crossing" is a
+  // chain of dependent loads (flags -> Index3D -> 7 hash probes -> 8 bytes of neg_any): one block per workgroup iteration made the
+  // full-layer launch latency-bound.  So the first wavefront tests 64 consecutive slots at once, one per lane, writes the empty
+  // records of the blocks without a negative voxel in reach itself, and only the candidates run the meshing path.
+  __shared__ u64 s_cand;
+  for (int32_t base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
+    __syncthreads();
+    if (tid < 64) {
+      const int32_t slot = base + tid;
+      bool tsdf = false, reach = false;
+      if (slot < n) {
+        const uint32_t flags = m.slot_flags[slot];
+        tsdf = (flags & F_TSDF) != 0;
+        MeshRecord r; r.x = INT32_MIN; r.y = 0; r.z = 0; r.vbase = -1; r.nvert = 0; r.tbase = 0; r.ntri = 0; r.pad = 0;
+        if (tsdf) {
+          const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
+          reach = neg_any[slot] != 0;
+#pragma unroll
+          for (int q = 1; q < 8; q++) {
+            const uint32_t ns = any_slot(m, bx + (q & 1), by + ((q >> 1) & 1), bz + ((q >> 2) & 1));
+            if (slot_ok(ns) && neg_any[ns]) reach = true;
+          }
+          if (!reach) {                                    // no zero crossing possible: the empty record of a meshed block
+            atomicAnd(&m.slot_flags[slot], ~F_DIRTY_MESH); atomicOr(&m.slot_flags[slot], F_MESH);
+            r.x = bx; r.y = by; r.z = bz; r.vbase = 0;
+            o_rec[slot] = r;
+          }
+        } else {
+          if (flags & F_DIRTY_MESH) atomicAnd(&m.slot_flags[slot], ~F_DIRTY_MESH);
+          o_rec[slot] = r;
+        }
+      }
+      const u64 skipped = __ballot(tsdf && !reach), cand = __ballot(tsdf && reach);
+      if (tid == 0) { if (skipped) atomicAdd(shc_at(m, a.srec, sh, 0), (int32_t)__popcll(skipped)); s_cand = cand; }
+    }
+    __syncthreads();
+    u64 cand = s_cand;
+    while (cand) {
+      const int cj = __ffsll((long long)cand) - 1;
+      cand &= cand - 1ull;
+      mesh_block(base + cj, (uint32_t)(base + cj));
     }
   }
 }
