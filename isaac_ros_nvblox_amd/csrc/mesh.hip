@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512) void k_mesh_prepass(DMap m, float min_weight, 
   }
 }
 
-__global__ __launch_bounds__(512) void k_mesh(DMap m, MeshArgs a, float* o_vert, float* o_nrm, uint32_t* o_col,
+__global__ __launch_bounds__(512, 4) void k_mesh(DMap m, MeshArgs a, float* o_vert, float* o_nrm, uint32_t* o_col,
                                               int32_t* o_tri, MeshRecord* o_rec, const uint8_t* neg_any) {
   __shared__ float s_d[NLAT];
   __shared__ uint8_t s_valid[NLAT];
