@@ -304,7 +304,8 @@ static int integrate_colors(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t 
   const Frame& f = fs.f[0];
   { // slots per workgroup iteration of k_integrate_color's candidate scan: from the high-water mark the GPU last reported (a hint only)
     const int64_t hw_seen = std::max<int64_t>(1, __atomic_load_n(&m->h_mirror[1], __ATOMIC_RELAXED));
-    int ch = 1; while (ch < 64 && (int64_t)ch * std::min<int64_t>(m->capacity, 1024) < hw_seen) ch *= 2;
+    int ch = 1; while (ch < 64 && (int64_t)ch * std::min<int64_t>(m->capacity, 1024) * 4 < hw_seen) ch *= 2;     // (up to 4 iterations of single slots: a room-sized map keeps
+                                                                                                        //  the stride-grid pairing, which balances the in-band blocks better than runs of neighbours)
     fs.chunk = ch; }
   const int32_t srows = rows / f.subsample, scols = cols / f.subsample;
   if (srows < 2 || scols < 2) { set_error("colour image too small for the sphere-tracing subsampling"); return NVBX_E_INVALID; }
