@@ -347,3 +347,20 @@ def test_fuser_node_over_dataset_loaders(hip_lib, tmp_path, kind):
     # a directory that is not a dataset: createFuser returns nullptr and the node exits with an error, as the reference does
     bad = subprocess.run([os.path.join(CPP, "fake_fuser_node"), kind, str(tmp_path / "nothing")], capture_output=True, text=True)
     assert bad.returncode == 1 and "failed" in bad.stderr
+
+
+def test_rccl_fusion_example_compiles():
+    subprocess.check_call(["make", "-C", CPP, "rccl_fusion"], stdout=subprocess.DEVNULL)
+    out = subprocess.run(["ldd", os.path.join(CPP, "rccl_fusion")], capture_output=True, text=True).stdout
+    assert "librccl" in out and "libnvblox_hip.so" in out
+
+
+@pytest.mark.gpu
+def test_rccl_fusion_example_runs(hip_lib):
+    """examples/rccl_fusion.cpp: measure -> ncclAllGather (RCCL) -> apply, from C++ through the C-ABI; with the GPUs present (one on the
+    test box) every rank's map must equal the single mapper's batch."""
+    subprocess.check_call(["make", "-C", CPP, "rccl_fusion"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(CPP, "rccl_fusion"), "8", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["gpus"] >= 1 and got["ranks_differing_from_single_mapper"] == 0 and got["tsdf_blocks"] > 100
