@@ -374,9 +374,7 @@ def main_decay(args):
            "per_step_counts": {k_: round(v_, 1) for k_, v_ in counts.items()},
            "block_ms": [round(d / args.steps * 1e3, 4) for d in dts[:16]],
            "kernels": kernels_json(kern),
-           "roofline": roofline_of(kern, ms, evo, emp, "longest kernel of the dynamic-mapping step (launches of the static and the dynamic mapper "
-                                   "together); remove_small_components iterates to convergence with a host read per batch of rounds, so the step is not "
-                                   "purely stream-ordered like the camera workload"),
+           "roofline": roofline_of(kern, ms, evo, emp, "longest kernel of the dynamic-mapping step (launches of the static and the dynamic mapper together)"),
            "cpu_baseline": cpu, "capacity_overflow": c["capacity_overflow"]}
     print(json.dumps(out))
 

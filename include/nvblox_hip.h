@@ -360,7 +360,7 @@ int nvbx_set_time_ms(nvbx_mapper* m, int64_t update_time_ms);
 int nvbx_detect_dynamics(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera,
                          float max_distance_m, uint8_t* mask_dev);
 /* [U] removeSmallConnectedComponents (multi_mapper connected_mask_component_size_threshold, mapper_initialization.cpp:130): erases the
- * 8-connected components of non-zero pixels smaller than min_size.  In place; synchronises (iterates to convergence). */
+ * 8-connected components of non-zero pixels smaller than min_size.  In place; asynchronous on the mapper's stream (lock-free union-find). */
 int nvbx_remove_small_components(nvbx_mapper* m, uint8_t* mask_dev, int32_t rows, int32_t cols, int32_t min_size);
 
 /* ---- device-side view for the caller's own kernels (GPULayerView / gpu_indexing.cuh: esdf_slice_conversions.cu:18,

@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnvblox_hip.so")
+LIB_PATH = os.environ.get("NVBX_LIB") or os.path.join(_HERE, "libnvblox_hip.so")      # (NVBX_LIB: a tuning variant of the same library, tools/)
 
 
 class Params(C.Structure):

@@ -137,29 +137,59 @@ extern "C" int nvbx_detect_dynamics(nvbx_mapper* m, const float* depth_dev, int3
 }
 
 // ------------------------------------------------------------------------------------------------ connected components
-// Label = smallest pixel index of the component: min over the 8-neighbourhood + pointer jumping, iterated to a fixed point.
+// [U] removeSmallConnectedComponents: 8-connected components of the non-zero pixels smaller than min_size are erased.  The output
+// depends only on the component SIZES, so the labelling is free: lock-free union-find over the label image (root = smallest pixel
+// index; every pixel unites with its W / NW / N / NE neighbours, roots are merged with atomicMin and retried until stable), one
+// flatten pass, a wave-aggregated size count and the filter -- five launches, no iteration on the host, no synchronisation
+// (round 1 iterated min-propagation to a fixed point with a host read every 8 rounds: ~10 launches + a stream drain per batch).
+__device__ inline int32_t cc_find(const int32_t* label, int32_t x) {
+  int32_t p = __hip_atomic_load(&label[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (p != x) { x = p; p = __hip_atomic_load(&label[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  return x;
+}
+__device__ inline void cc_union(int32_t* label, int32_t a, int32_t b) {
+  for (;;) {
+    a = cc_find(label, a); b = cc_find(label, b);
+    if (a == b) return;
+    if (a > b) { const int32_t t = a; a = b; b = t; }          // a < b: b's root hangs under a
+    const int32_t old = atomicMin(&label[b], a);
+    if (old == b) return;                                       // b was still a root: merged
+    b = old;                                                    // somebody re-rooted b meanwhile: unite a with that
+  }
+}
 __global__ __launch_bounds__(256) void k_cc_init(const uint8_t* mask, int64_t n, int32_t* label, int32_t* size) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { label[i] = mask[i] ? (int32_t)i : -1; size[i] = 0; }
 }
-__global__ __launch_bounds__(256) void k_cc_step(int32_t rows, int32_t cols, int32_t* label, int32_t* changed) {
+__global__ __launch_bounds__(256) void k_cc_union(const uint8_t* mask, int32_t rows, int32_t cols, int32_t* label) {
   const int64_t n = (int64_t)rows * cols;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    int32_t cur = label[i];
-    if (cur < 0) continue;
+    if (!mask[i]) continue;
     const int32_t r = (int32_t)(i / cols), c = (int32_t)(i - (int64_t)r * cols);
-    int32_t best = cur;
-    for (int dr = -1; dr <= 1; dr++) for (int dc = -1; dc <= 1; dc++) {
-      const int32_t rr = r + dr, cc = c + dc;
-      if (rr < 0 || cc < 0 || rr >= rows || cc >= cols) continue;
-      const int32_t l = label[(int64_t)rr * cols + cc];
-      if (l >= 0 && l < best) best = l;
+    if (c > 0 && mask[i - 1]) cc_union(label, (int32_t)i, (int32_t)i - 1);
+    if (r > 0) {
+      const int64_t up = i - cols;
+      if (mask[up]) cc_union(label, (int32_t)i, (int32_t)up);
+      if (c > 0 && mask[up - 1]) cc_union(label, (int32_t)i, (int32_t)up - 1);
+      if (c + 1 < cols && mask[up + 1]) cc_union(label, (int32_t)i, (int32_t)up + 1);
     }
-    for (int k = 0; k < 4; k++) { const int32_t l = label[best]; if (l >= 0 && l < best) best = l; else break; }     // pointer jumping
-    if (best < cur) { atomicMin(&label[i], best); *changed = 1; }
   }
 }
-__global__ __launch_bounds__(256) void k_cc_count(int64_t n, const int32_t* label, int32_t* size) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { const int32_t l = label[i]; if (l >= 0) atomicAdd(&size[l], 1); }
+// flatten (label = root) and count: the lanes of a wavefront that share a root add their number with ONE atomic (a blob's pixels are
+// neighbours in memory: 64 same-address atomics per wavefront would serialise)
+__global__ __launch_bounds__(256) void k_cc_count(int64_t n, int32_t* label, int32_t* size) {
+  const int64_t n_pad = (n + 63) & ~(int64_t)63;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t l = -1;
+    if (i < n) { l = label[i]; if (l >= 0) { l = cc_find(label, l); label[i] = l; } }
+    u64 todo = __ballot(l >= 0);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int32_t ll = __shfl(l, leader);
+      const u64 same = __ballot(l == ll) & todo;
+      if ((int)(threadIdx.x & 63) == leader) atomicAdd(&size[ll], (int32_t)__popcll(same));
+      todo &= ~same;
+    }
+  }
 }
 __global__ __launch_bounds__(256) void k_cc_filter(int64_t n, const int32_t* label, const int32_t* size, int32_t min_size, uint8_t* mask) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { const int32_t l = label[i]; if (l >= 0 && size[l] < min_size) mask[i] = 0; }
@@ -175,19 +205,12 @@ extern "C" int nvbx_remove_small_components(nvbx_mapper* m, uint8_t* mask_dev, i
     NVBX_HIP(hipMalloc(&m->cc_scratch, (size_t)(2 * n + 16) * 4));
     m->cc_scratch_elems = 2 * n + 16;
   }
-  int32_t* label = m->cc_scratch; int32_t* size = label + n; int32_t* changed = size + n;
+  int32_t* label = m->cc_scratch; int32_t* size = label + n;
   const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
   NVBX_LAUNCH(m, k_cc_init, dim3(grid), dim3(256), (const uint8_t*)mask_dev, n, label, size);
-  for (int round = 0; round < 4096; round++) {                  // 8 propagation steps per host check; converges in a few rounds
-    NVBX_HIP(hipMemsetAsync(changed, 0, 4, m->stream));
-    for (int k = 0; k < 8; k++) NVBX_LAUNCH(m, k_cc_step, dim3(grid), dim3(256), rows, cols, label, changed);
-    int32_t h = 0;
-    NVBX_HIP(hipMemcpyAsync(&h, changed, 4, hipMemcpyDeviceToHost, m->stream));
-    NVBX_HIP(hipStreamSynchronize(m->stream));
-    if (!h) break;
-  }
-  NVBX_LAUNCH(m, k_cc_count, dim3(grid), dim3(256), n, (const int32_t*)label, size);
+  NVBX_LAUNCH(m, k_cc_union, dim3(grid), dim3(256), (const uint8_t*)mask_dev, rows, cols, label);
+  NVBX_LAUNCH(m, k_cc_count, dim3(grid), dim3(256), n, label, size);
   NVBX_LAUNCH(m, k_cc_filter, dim3(grid), dim3(256), n, (const int32_t*)label, (const int32_t*)size, min_size, mask_dev);
-  NVBX_HIP(hipStreamSynchronize(m->stream));
-  return NVBX_OK;
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;                  // asynchronous on the mapper's stream, like the other image operations
 }

@@ -55,14 +55,19 @@ struct CameraSensor {
 // Lidar: nvbx_lidar_math.h.  el_tab[k] = {sin, cos} of beam row k's elevation, az_tab[j] = {sin, cos} of column j's azimuth.
 struct LidarSensor {
   static constexpr bool kLongRays = true;
-  // long rays: the walk is a serial chain per ray and the flushes dominate, so fewer rays per wavefront = more
-  // wavefronts in flight (16384 rays -> 1024 waves); all 64 lanes still work in the flushes
-  static constexpr int kTileRows = 4, kTileCols = 4;
+  // long rays: the walk is a serial chain per ray and the flushes are chains of dependent HBM round trips, so the lever is the number
+  // of wavefronts in flight: FEW rays per wavefront, MANY lanes per ray.  A 200 m ray is ~250 dependent block steps; its lanes share
+  // it: lane s replays the (cheap, insert-free) traversal up to its segment -- the same float operations in the same order, so the
+  // state is bit-identical -- and then walks only its segment with set inserts.  Measured (tools/lidar_tile_sweep.sh, 1024x64 beams,
+  // ray subsampling 2, us per scan): 4x4 rays x 4 segments 155 | 2x4x8 113 | 2x2x16 82 | 1x4x16 74 | 1x2x32 75 | 1x1x64 111.
+#ifndef NVBX_LIDAR_TR
+#define NVBX_LIDAR_TR 1
+#define NVBX_LIDAR_TC 4
+#define NVBX_LIDAR_SEG 16
+#endif
+  static constexpr int kTileRows = NVBX_LIDAR_TR, kTileCols = NVBX_LIDAR_TC;      // (tuning knobs: tools/lidar_tile_sweep.sh)
   static constexpr int kSetSize = 1024, kFlushRounds = 6; // early flush at 256 keys: 6 x 64 >= 256 + one step's additions
-  // A 200 m ray is ~250 dependent block steps.  Four lanes share a ray: lane s replays the (cheap, insert-free) traversal up
-  // to its quarter -- the same float operations in the same order, so the state is bit-identical -- and then walks only its
-  // quarter with set inserts: 4 x 4 rays x 4 segments = 64 busy lanes, ~63 instead of ~250 insert steps per wavefront.
-  static constexpr int kSegments = 4;
+  static constexpr int kSegments = NVBX_LIDAR_SEG;
   static constexpr int kProbeDepth = 4;
   static constexpr int kThreads = 64;
   nvbx_lidar_model l;

@@ -295,7 +295,7 @@ class Mapper:
                                                   C.byref(self._cam(cam)), float(max_distance_m), C.c_void_p(mask_out.data_ptr())))
 
     def remove_small_components_inplace(self, mask_dev, min_size):
-        """(the C-ABI call itself iterates to convergence and synchronises)"""
+        """(asynchronous on the mapper's stream)"""
         self._check(self.lib.nvbx_remove_small_components(self._h, C.c_void_p(mask_dev.data_ptr()), mask_dev.shape[0], mask_dev.shape[1], int(min_size)))
 
     def split_depth_by_mask_into(self, depth_dev, mask_dev, T_CM_CD, depth_cam, mask_cam, occlusion_threshold_m, unmasked_out, masked_out):
@@ -309,6 +309,7 @@ class Mapper:
         mk = self._dev(mask, torch.uint8).clone()
         torch.cuda.current_stream(mk.device).synchronize()      # the clone ran on torch's stream, the library works on the mapper's
         self._check(self.lib.nvbx_remove_small_components(self._h, C.c_void_p(mk.data_ptr()), mk.shape[0], mk.shape[1], int(min_size)))
+        self.synchronize()          # (the call is asynchronous on the mapper's stream; the tensor goes back to torch's)
         return mk
 
     def decay_occupancy(self):
