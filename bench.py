@@ -17,7 +17,6 @@ blocks are repeated until >= 50 ms have been timed (`repeats`), `ms_per_step` / 
 """
 import argparse
 import json
-import math
 import os
 import re
 import sys

@@ -29,9 +29,14 @@ using namespace nvbx;
 // Camera(fu, fv, cu, cv, w, h): conversions/image_conversions.cpp:27-32.  Everything it needs is in Frame.
 struct CameraSensor {
   static constexpr bool kLongRays = false;
-  static constexpr int kTileRows = 8, kTileCols = 8;     // rays per wavefront: one 8x8 tile of the ray grid
+#ifndef NVBX_CAM_TR
+#define NVBX_CAM_TR 8
+#define NVBX_CAM_TC 8
+#define NVBX_CAM_SEG 1
+#endif
+  static constexpr int kTileRows = NVBX_CAM_TR, kTileCols = NVBX_CAM_TC;     // rays per wavefront: one tile of the ray grid (tools/lidar_tile_sweep.sh cam)
   static constexpr int kSetSize = 512, kFlushRounds = 2; // a tile crosses < 100 blocks: 4 KiB set, 128 keys per flush pass
-  static constexpr int kSegments = 1;                    // lanes per ray
+  static constexpr int kSegments = NVBX_CAM_SEG;         // lanes per ray
   static constexpr int kProbeDepth = 2;                  // hash probe positions fetched up front per key in a flush
   static constexpr int kThreads = 256;                   // 4 waves: the tile uses the first, a riding EDT workgroup all four
   // end point (camera frame) of the ray through the centre of pixel (prow, pcol) at depth `de` along the optical axis
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   int32_t* cnt = &m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
   if (!Sensor::kLongRays) {
     // camera: a tile's rays cross < 100 blocks in ~20 steps -- walk every ray to its end, then flush once
-    for (int32_t k = 0; k <= nsteps; k++) {
+    for (int32_t k = k0; k <= k1; k++) {                   // (this lane's segment of the ray; the whole ray if it is not shared)
       const u64 key = pack_key(cur[0], cur[1], cur[2]);
       const bool inside = block_in_workspace(f, cur);
       const uint32_t lh = ((index_hash(cur[0], cur[1], cur[2]) * 2654435761u) >> 16) & (LSET - 1);

@@ -32,8 +32,10 @@ for k, v in prof.items():
     ab = None
     if "decay" in name:
         ab = nb * 4096 * 2           # every TSDF voxel read and written back
+    elif name == "k_mesh_prepass":
+        ab = nb * 4096               # every TSDF voxel read once (one byte per block written)
     elif "mesh" in name:
-        ab = nb * 4096 * 2           # TSDF + colour voxels of every block read once (neighbour faces from cache), vertices out
+        ab = nb * 4096 * 2           # round-1 accounting of the full-layer mesh: TSDF + colour voxels of every block (the pre-pass now spares most of it)
     e = {"count": v["count"], "avg_us": round(us, 1)}
     if ab:
         e["algorithmic_bytes"] = int(ab); e["achieved_GBps"] = round(ab / (us * 1e-6) / 1e9, 1); e["frac_of_8TBps"] = round(ab / (us * 1e-6) / 8e12, 3)
