@@ -96,6 +96,24 @@ class Mapper {
     float T[16]; T_L_C.toRowMajor(T);
     checkNvbx(nvbx_integrate_depth(m_, depth_frame.dataConstPtr(), depth_frame.rows(), depth_frame.cols(), T, &camera.c_abi()), "nvbx_integrate_depth");
   }
+  // The frames of up to 8 cameras of one image size as ONE launch set (nvbx_integrate_depth_batch / _color_batch): defined as equal to
+  // the separate calls in order; what the node's per-tick loop over its camera queues (nvblox_node.cpp:247-292) can hand over at once.
+  void integrateDepthBatch(const std::vector<const DepthImage*>& depth_frames, const std::vector<Transform>& T_L_C, const std::vector<Camera>& cameras) {
+    timing::Timer t("tsdf/integrate");
+    const int n = (int)depth_frames.size();
+    if (n == 0) return;
+    std::vector<const float*> ptr((size_t)n); std::vector<float> T((size_t)n * 16); std::vector<nvbx_camera> cams((size_t)n);
+    for (int i = 0; i < n; i++) { ptr[(size_t)i] = depth_frames[(size_t)i]->dataConstPtr(); T_L_C[(size_t)i].toRowMajor(&T[(size_t)i * 16]); cams[(size_t)i] = cameras[(size_t)i].c_abi(); }
+    checkNvbx(nvbx_integrate_depth_batch(m_, n, ptr.data(), depth_frames[0]->rows(), depth_frames[0]->cols(), T.data(), cams.data()), "nvbx_integrate_depth_batch");
+  }
+  void integrateColorBatch(const std::vector<const ColorImage*>& color_frames, const std::vector<Transform>& T_L_C, const std::vector<Camera>& cameras) {
+    timing::Timer t("color/integrate");
+    const int n = (int)color_frames.size();
+    if (n == 0) return;
+    std::vector<const uint8_t*> ptr((size_t)n); std::vector<float> T((size_t)n * 16); std::vector<nvbx_camera> cams((size_t)n);
+    for (int i = 0; i < n; i++) { ptr[(size_t)i] = reinterpret_cast<const uint8_t*>(color_frames[(size_t)i]->dataConstPtr()); T_L_C[(size_t)i].toRowMajor(&T[(size_t)i * 16]); cams[(size_t)i] = cameras[(size_t)i].c_abi(); }
+    checkNvbx(nvbx_integrate_color_batch(m_, n, ptr.data(), color_frames[0]->rows(), color_frames[0]->cols(), T.data(), cams.data()), "nvbx_integrate_color_batch");
+  }
   // 16-bit millimetre depth: fuses conversions::depthImageFromNitrosViewAsync (image_conversions_thrust.cu:39-45)
   void integrateDepth(const Image<uint16_t>& depth_mm, const Transform& T_L_C, const Camera& camera) {
     timing::Timer t("tsdf/integrate");

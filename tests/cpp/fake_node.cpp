@@ -335,6 +335,24 @@ int main(int argc, char** argv) {
     } while (node.static_mapper_->numMeshBlocksAwaitingStreaming() > 0 && calls < 100000);
     if (total_blocks != full_blocks || calls < 2 || first_call_blocks == 0 || first_call_blocks >= full_blocks) {
       std::fprintf(stderr, "rationed mesh streaming: %zu of %zu blocks in %zu calls (first call %zu)\n", total_blocks, full_blocks, calls, first_call_blocks); return 1; }
+    // camera batches through the facade: the same two frames as ONE launch set == two calls (block sets and voxel sums)
+    {
+      DepthImage d0(MemoryType::kDevice), d1(MemoryType::kDevice); ColorImage c0(MemoryType::kDevice), c1(MemoryType::kDevice);
+      std::vector<float> hd((size_t)rows * cols, 2.0f), hd2((size_t)rows * cols, 2.6f); std::vector<Color> hc((size_t)rows * cols, Color(10, 200, 90));
+      d0.copyFromAsync(rows, cols, hd.data(), *node.cuda_stream_); d1.copyFromAsync(rows, cols, hd2.data(), *node.cuda_stream_);
+      c0.copyFromAsync(rows, cols, hc.data(), *node.cuda_stream_); c1.copyFromAsync(rows, cols, hc.data(), *node.cuda_stream_);
+      node.cuda_stream_->synchronize();
+      Transform Ta = Transform::Identity(), Tb = Transform::Identity(); Tb.setTranslation(Vector3f(0.3f, 0.1f, 0.0f));
+      Mapper batched(0.05f, MemoryType::kDevice, ProjectiveLayerType::kTsdf, node.cuda_stream_), separate(0.05f, MemoryType::kDevice, ProjectiveLayerType::kTsdf, node.cuda_stream_);
+      batched.integrateDepthBatch({&d0, &d1}, {Ta, Tb}, {camera, camera}); batched.integrateColorBatch({&c0, &c1}, {Ta, Tb}, {camera, camera});
+      separate.integrateDepth(d0, Ta, camera); separate.integrateDepth(d1, Tb, camera); separate.integrateColor(c0, Ta, camera); separate.integrateColor(c1, Tb, camera);
+      double sa = 0.0, sb = 0.0; size_t na = 0, nb2 = 0;
+      callFunctionOnAllVoxels<TsdfVoxel>(batched.tsdf_layer(), [&](const Index3D&, const Index3D&, const TsdfVoxel* v) { if (v->weight > 0.f) { sa += (double)v->distance * v->weight; na++; } });
+      callFunctionOnAllVoxels<TsdfVoxel>(separate.tsdf_layer(), [&](const Index3D&, const Index3D&, const TsdfVoxel* v) { if (v->weight > 0.f) { sb += (double)v->distance * v->weight; nb2++; } });
+      if (na != nb2 || na < 1000 || sa != sb || batched.tsdf_layer().numAllocatedBlocks() != separate.tsdf_layer().numAllocatedBlocks() ||
+          batched.color_layer().numAllocatedBlocks() != separate.color_layer().numAllocatedBlocks()) {
+        std::fprintf(stderr, "camera batch: %zu vs %zu observed voxels, sums %.9g vs %.9g\n", na, nb2, sa, sb); return 1; }
+    }
     // voxel-layer streams under the same limit (layer_publishing.cpp:702-711): nearest blocks first, cut at the budget
     {
       BlockExclusionParams ex; ex.exclusion_center_m = Vector3f(0.5f, 0.25f, 1.0f); ex.exclusion_height_m = -1.0f; ex.exclusion_radius_m = -1.0f;

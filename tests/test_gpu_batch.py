@@ -122,3 +122,29 @@ def test_batch_argument_checks(hip_lib):
     with pytest.raises(M.NvbxError):
         g.integrate_depth_batch([fr[0][0], fr[1][0]], [fr[0][2], fr[1][2]], [H.SMALL_CAM, (80.0, 80.0, 79.5, 59.5, 161, 120)])   # camera != image
     assert g.num_blocks(M.LAYER_TSDF) == 0
+
+
+def test_batches_and_measurement_exchange_across_pool_growth(oracle_mod, hip_lib):
+    """Small initial pools: the batch and the measurement-exchange paths grow them like the plain calls do, with the same result."""
+    import torch
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    pg = M.default_params()
+    gb = M.Mapper(pg, block_capacity=1024); gm = M.Mapper(pg, block_capacity=1024); gs = M.Mapper(pg, block_capacity=1 << 14)
+    all_buf = torch.zeros((4, 1024, M.Mapper.MEAS_BLOCK_BYTES), dtype=torch.uint8, device="cuda:0")
+    all_cnt = torch.zeros((4,), dtype=torch.int32, device="cuda:0")
+    for k in range(4):
+        fr = rig_frames(4, k * 2)
+        gb.integrate_depth_batch([d for d, _, _ in fr], [T for _, _, T in fr], cam); gb.synchronize()
+        for d, _, T in fr:
+            gs.integrate_depth(d, T, cam)
+        # one mapper playing all four ranks: measure each camera, apply all
+        tmp = [M.Mapper(pg, block_capacity=1024) for _ in range(4)]
+        for r, (d, _, T) in enumerate(fr):
+            tmp[r].measure_depth(d, T, cam, all_buf[r], all_cnt[r:r + 1]); tmp[r].synchronize()
+        gm.apply_measurements(all_buf, all_cnt); gm.synchronize()
+    assert gb.capacity > 1024 and gm.capacity > 1024
+    assert gb.counters()["capacity_overflow"] == 0 and gm.counters()["capacity_overflow"] == 0
+    n = layers_equal(M, gb, gs, M.LAYER_TSDF, ("distance", "weight"))
+    layers_equal(M, gm, gs, M.LAYER_TSDF, ("distance", "weight"))
+    assert n > 1100
