@@ -155,6 +155,11 @@ __host__ __device__ inline u64 pack_key(int32_t x, int32_t y, int32_t z) {
   return (((u64)(int64_t)x + B) & 0x1FFFFFull) | ((((u64)(int64_t)y + B) & 0x1FFFFFull) << 21) |
          ((((u64)(int64_t)z + B) & 0x1FFFFFull) << 42);
 }
+__host__ __device__ inline void unpack_key(u64 key, int32_t* x, int32_t* y, int32_t* z) {
+  *x = (int32_t)(key & 0x1FFFFFull) - (1 << 20);
+  *y = (int32_t)((key >> 21) & 0x1FFFFFull) - (1 << 20);
+  *z = (int32_t)((key >> 42) & 0x1FFFFFull) - (1 << 20);
+}
 __host__ __device__ inline uint32_t index_hash(int32_t x, int32_t y, int32_t z) {
   // nvblox_hash_utils.h:43-48 -- uint32 wrap-around is identical to truncating the size_t sum
   return (uint32_t)x + (uint32_t)y * 17191u + (uint32_t)z * (17191u * 17191u);

@@ -128,11 +128,6 @@ struct LidarSensor {
 
 constexpr int LSET_FLUSH = 256;     // early-flush threshold (long rays): keeps the 1024-entry set <= ~30 % full, probes short
 
-__device__ inline void unpack_key(u64 key, int32_t* x, int32_t* y, int32_t* z) {
-  *x = (int32_t)(key & 0x1FFFFFull) - (1 << 20);
-  *y = (int32_t)((key >> 21) & 0x1FFFFFull) - (1 << 20);
-  *z = (int32_t)((key >> 42) & 0x1FFFFFull) - (1 << 20);
-}
 
 // Claim an entry's stamp word for (frame, camera bit); `cur` = the word as last seen.  True iff THIS call moved the entry to the
 // frame (the caller then appends the block to the view list exactly once); otherwise it only makes sure the camera's bit is set.
