@@ -195,12 +195,17 @@ int nvbx_flush(nvbx_mapper* m);
  * the two with events on this handle. */
 int nvbx_get_stream(nvbx_mapper* m, void** hip_stream_out);
 const char* nvbx_last_error(void);
+/* Arithmetic self-test (no reference counterpart; test infrastructure of the boundary): evaluates the library's own division and
+ * square-root sequences (csrc/nvbx_arith.h: the compiler's IEEE sequences without their range-scaling steps) on device arrays --
+ * quot[i] = a[i] / b[i], root[i] = sqrt(|a[i]|) -- on the current device's null stream and waits.  tests/test_gpu_arith.py compares
+ * the results with IEEE float division / square root bit for bit: the CPU oracle uses the plain operators. */
+int nvbx_selftest_arith(const float* a_dev, const float* b_dev, float* quot_dev, float* root_dev, int64_t n);
 /* Mapper::clear / fresh map (load_map path re-creates the mapper: nvblox_node.cpp:1698-1703) */
 int nvbx_mapper_clear(nvbx_mapper* m);
 
 /* ---- integration (asynchronous on the mapper stream) --------------------------------------------------------------
  * Argument checks (NVBX_E_INVALID, nothing launched): the camera's width / height must equal the image's cols / rows and its
- * focal lengths be > 0; T_L_C must be finite and keep everything within the integration distance inside the addressable block
+ * focal lengths be > 0; image sides are 1 .. 32768 (pixel indices are 31-bit on the device); T_L_C must be finite and keep everything within the integration distance inside the addressable block
  * range (nvbx_index3d).  Every entry point makes the mapper's device the calling thread's current device and leaves it so.
  * MultiMapper::integrateDepth(const DepthImage&, const Transform& T_L_C, const Camera&, Time) -- nvblox_node.cpp:1062 */
 int nvbx_integrate_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16],

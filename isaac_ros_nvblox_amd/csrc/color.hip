@@ -120,11 +120,11 @@ __global__ __launch_bounds__(256) void k_sphere_trace(DMap m, PoseSet<NB> poses,
 // colour source: rgb8 (nvblox::Color, 3 bytes) or bgra8 (4 bytes, channel reorder of ToRgba<Bgra> fused into the fetch)
 struct PixRgb8 {
   const uint8_t* p;
-  __device__ void tap(int64_t i, float* c) const { const uint8_t* q = p + i * 3; c[0] = (float)q[0]; c[1] = (float)q[1]; c[2] = (float)q[2]; }
+  __device__ void tap(int32_t i, float* c) const { const uint8_t* q = p + (int64_t)i * 3; c[0] = (float)q[0]; c[1] = (float)q[1]; c[2] = (float)q[2]; }
 };
 struct PixBgra8 {
   const uint32_t* p;     // little endian: b | g << 8 | r << 16 | a << 24
-  __device__ void tap(int64_t i, float* c) const { const uint32_t v = p[i]; c[0] = (float)((v >> 16) & 0xFF); c[1] = (float)((v >> 8) & 0xFF); c[2] = (float)(v & 0xFF); }
+  __device__ void tap(int32_t i, float* c) const { const uint32_t v = p[i]; c[0] = (float)((v >> 16) & 0xFF); c[1] = (float)((v >> 8) & 0xFF); c[2] = (float)(v & 0xFF); }
 };
 
 __device__ inline uint32_t blend_u8(float c0, float w0, float c1, float w1) {
@@ -255,8 +255,8 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, FrameSetC<Pix, 
       const int sx0 = (int)sfx, sy0 = (int)sfy;
       const bool s_ok = !(sx0 < 0 || sy0 < 0 || sx0 + 1 > scols - 1 || sy0 + 1 > srows - 1);
       if (!c_ok || !s_ok) continue;
-      const float* sp = synth + (int64_t)sy0 * scols + sx0;
-      const int64_t i00 = (int64_t)y0 * f.cols + x0;
+      const float* sp = synth + pix(sy0, sx0, scols);
+      const int32_t i00 = pix(y0, x0, f.cols);
       // (the colour voxel is only needed for the blend: it travels with the taps, not with the vote's inputs -- blocks
       // outside the truncation band or the frustum, most of the map, never fetch it)
       if (!loaded) { cur = *cp; loaded = true; }
@@ -345,14 +345,14 @@ static int integrate_colors(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t 
 
 extern "C" int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                     const nvbx_camera* camera) {
-  if (!m || !rgb_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_color: invalid argument"); return NVBX_E_INVALID; }
+  if (!m || !rgb_dev || !T_L_C || !camera || !image_dims_ok(rows, cols)) { set_error("nvbx_integrate_color: invalid argument (image sides 1 .. 32768)"); return NVBX_E_INVALID; }
   if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_color: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
   const PixRgb8 img{rgb_dev};
   return integrate_colors<PixRgb8, 1>(m, 1, &img, rows, cols, T_L_C, camera);
 }
 extern "C" int nvbx_integrate_color_bgra8(nvbx_mapper* m, const uint8_t* bgra_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                           const nvbx_camera* camera) {
-  if (!m || !bgra_dev || !T_L_C || !camera || rows <= 0 || cols <= 0 || ((uintptr_t)bgra_dev & 3)) { set_error("nvbx_integrate_color_bgra8: invalid argument"); return NVBX_E_INVALID; }
+  if (!m || !bgra_dev || !T_L_C || !camera || !image_dims_ok(rows, cols) || ((uintptr_t)bgra_dev & 3)) { set_error("nvbx_integrate_color_bgra8: invalid argument"); return NVBX_E_INVALID; }
   if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_color_bgra8: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
   const PixBgra8 img{reinterpret_cast<const uint32_t*>(bgra_dev)};
   return integrate_colors<PixBgra8, 1>(m, 1, &img, rows, cols, T_L_C, camera);
@@ -360,7 +360,7 @@ extern "C" int nvbx_integrate_color_bgra8(nvbx_mapper* m, const uint8_t* bgra_de
 // Up to NVBX_MAX_BATCH colour frames (rgb8, same image size) in ONE launch set: see include/nvblox_hip.h
 extern "C" int nvbx_integrate_color_batch(nvbx_mapper* m, int32_t n, const uint8_t* const* rgb_dev, int32_t rows, int32_t cols, const float* T_L_C,
                                           const nvbx_camera* cameras) {
-  if (!m || n < 1 || n > MAX_BATCH || !rgb_dev || !T_L_C || !cameras || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_color_batch: invalid argument (1 <= n <= 8)"); return NVBX_E_INVALID; }
+  if (!m || n < 1 || n > MAX_BATCH || !rgb_dev || !T_L_C || !cameras || !image_dims_ok(rows, cols)) { set_error("nvbx_integrate_color_batch: invalid argument (1 <= n <= 8, image sides 1 .. 32768)"); return NVBX_E_INVALID; }
   for (int c = 0; c < n; c++)
     if (!rgb_dev[c] || !nvbx_camera_matches(cameras + c, rows, cols)) { set_error("nvbx_integrate_color_batch: every camera's width/height must equal the images' cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
   if (n == 1) return nvbx_integrate_color(m, rgb_dev[0], rows, cols, T_L_C, cameras);

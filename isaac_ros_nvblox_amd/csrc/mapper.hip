@@ -442,6 +442,19 @@ extern "C" void nvbx_default_params(nvbx_mapper_params* p) {
   p->tsdf_weighting_variant = 0; p->tsdf_skip_at_negative_truncation = 0; p->tsdf_weight_clamp_before_blend = 0;
   p->color_occlusion_threshold_vox = -1.0f; p->esdf_propagation = 0; p->mesh_ambiguity_rule = 0; p->mesh_normal_rule = 0;
 }
+__global__ void k_selftest_arith(const float* a, const float* b, float* q, float* r, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    q[i] = NVBX_DIV(a[i], b[i]);
+    r[i] = NVBX_SQRT(fabsf(a[i]));
+  }
+}
+extern "C" int nvbx_selftest_arith(const float* a_dev, const float* b_dev, float* quot_dev, float* root_dev, int64_t n) {
+  if (!a_dev || !b_dev || !quot_dev || !root_dev || n < 0) { set_error("nvbx_selftest_arith: invalid argument"); return NVBX_E_INVALID; }
+  if (n > 0) k_selftest_arith<<<dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256)>>>(a_dev, b_dev, quot_dev, root_dev, n);
+  NVBX_HIP(hipGetLastError());
+  NVBX_HIP(hipDeviceSynchronize());
+  return NVBX_OK;
+}
 extern "C" int nvbx_get_stream(nvbx_mapper* m, void** hip_stream_out) {
   if (!m || !hip_stream_out) return NVBX_E_INVALID;
   *hip_stream_out = (void*)m->stream;

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "nvbx_arith.h"
 
 namespace nvbx {
 
@@ -67,6 +68,8 @@ struct Entry { u64 key; uint32_t slot; uint32_t stamp; };
 // (1 .. STAMP_FRAME_MAX; the host resets every stamp when the counter would wrap); STAMP_NEVER = all ones never matches.
 constexpr uint32_t STAMP_FRAME_MAX = 0xFFFFF0u;
 constexpr int MAX_BATCH = 8;
+constexpr int MAX_IMAGE_DIM = 32768;   // image sides accepted by the C-ABI (pixel indices then fit 31 bits, see pix())
+inline bool image_dims_ok(int64_t rows, int64_t cols) { return rows > 0 && cols > 0 && rows <= MAX_IMAGE_DIM && cols <= MAX_IMAGE_DIM; }
 __host__ __device__ inline uint32_t stamp_frame(uint32_t s) { return s >> 8; }
 
 // counters[] indices (device int32 array, mirrored to pinned host memory on demand)
@@ -313,15 +316,18 @@ __device__ inline float voxel_center(int32_t bi, int32_t vi, float bs, float vs)
 }
 __device__ inline bool cam_project(const Frame& f, const float* p, float* u, float* v) {
   if (p[2] <= 0.0f) return false;
-  *u = f.fu * (p[0] / p[2]) + f.cu;
-  *v = f.fv * (p[1] / p[2]) + f.cv;
-  if (*u < 0.0f || *v < 0.0f || *u > (float)f.w || *v > (float)f.h) return false;
-  return true;
+  *u = f.fu * NVBX_DIV(p[0], p[2]) + f.cu;          // (NVBX_DIV: the IEEE quotient, nvbx_arith.h)
+  *v = f.fv * NVBX_DIV(p[1], p[2]) + f.cv;
+  return *u >= 0.0f && *v >= 0.0f && *u <= (float)f.w && *v <= (float)f.h;      // (written so that a NaN is outside the image)
 }
 
-struct DepthF32 { const float* p; __device__ float operator()(int64_t i) const { return p[i]; } };
+// Pixel index r * cols + c.  Image sides are at most MAX_IMAGE_DIM (checked at the C-ABI: image_dims_ok), so the full-rate 24-bit
+// multiply is exact and the index fits 31 bits -- the 64-bit multiply-add the compiler emits for int64 index math is quarter rate,
+// and the integrators compute four of them per voxel.
+__device__ inline int32_t pix(int r, int c, int cols) { return __mul24(r, cols) + c; }
+struct DepthF32 { const float* p; __device__ float operator()(int32_t i) const { return p[i]; } };
 struct DepthU16mm {   // conversions/image_conversions_thrust.cu:39-45 fused into the read
-  const uint16_t* p; __device__ float operator()(int64_t i) const { return (float)p[i] * (1.0f / 1000.0f); } };
+  const uint16_t* p; __device__ float operator()(int32_t i) const { return (float)p[i] * (1.0f / 1000.0f); } };
 
 // returns 1 = value, 0 = no sample (outside the image), -1 = a depth tap is invalid (<= 0)
 template <typename Img>
@@ -329,7 +335,7 @@ __device__ inline int interp_depth(const Img& img, int rows, int cols, float u, 
   if (nearest) {
     const int c = (int)floorf(u), r = (int)floorf(v);
     if (c < 0 || r < 0 || c >= cols || r >= rows) return 0;
-    const float d = img((int64_t)r * cols + c);
+    const float d = img(pix(r, c, cols));
     if (!(d > 0.0f)) return -1;
     *out = d; return 1;
   }
@@ -338,8 +344,8 @@ __device__ inline int interp_depth(const Img& img, int rows, int cols, float u, 
   const int x0 = (int)fx, y0 = (int)fy;
   if (x0 < 0 || y0 < 0 || x0 + 1 > cols - 1 || y0 + 1 > rows - 1) return 0;
   const float ax = uc - fx, ay = vc - fy;
-  const float f00 = img((int64_t)y0 * cols + x0), f10 = img((int64_t)y0 * cols + x0 + 1);
-  const float f01 = img((int64_t)(y0 + 1) * cols + x0), f11 = img((int64_t)(y0 + 1) * cols + x0 + 1);
+  const int32_t i00 = pix(y0, x0, cols);
+  const float f00 = img(i00), f10 = img(i00 + 1), f01 = img(i00 + cols), f11 = img(i00 + cols + 1);
   if (!(f00 > 0.0f) || !(f10 > 0.0f) || !(f01 > 0.0f) || !(f11 > 0.0f)) return -1;
   const float top = (1.0f - ax) * f00 + ax * f10;
   const float bot = (1.0f - ax) * f01 + ax * f11;
@@ -398,11 +404,28 @@ __device__ inline bool tsdf_fuse(const Frame& f, float2* v, float ds, float vd) 
   const float wsum = wm + cur.y;
   if (!(wsum > 0.0f)) return false;
   float fused, wnew = fminf(wsum, f.max_weight);
-  if (!f.clamp_before_blend) fused = (sdf * wm + cur.x * cur.y) / wsum;
-  else { float wp = wnew - wm; if (wp < 0.0f) wp = 0.0f; fused = (sdf * wm + cur.x * wp) / (wm + wp); }
+  if (!f.clamp_before_blend) fused = NVBX_DIV(sdf * wm + cur.x * cur.y, wsum);
+  else { float wp = wnew - wm; if (wp < 0.0f) wp = 0.0f; fused = NVBX_DIV(sdf * wm + cur.x * wp, wm + wp); }
   if (fused > 0.0f) fused = fminf(f.trunc, fused); else fused = fmaxf(-f.trunc, fused);
   *v = make_float2(fused, wnew);
   return true;
+}
+
+// The same for the configuration almost every caller runs -- constant weighting, clamp after the blend (frame_is_plain) -- with the
+// mode switches folded at compile time: identical arithmetic (w = 1: sdf * 1 is sdf), none of the uniform branching.
+__device__ inline bool tsdf_fuse_plain(const Frame& f, float2* v, float ds, float vd) {
+  const float2 cur = *v;
+  const float sdf = ds - vd;
+  if (f.skip_at_neg_trunc ? (sdf <= -f.trunc) : (sdf < -f.trunc)) return false;
+  const float wsum = 1.0f + cur.y;
+  if (!(wsum > 0.0f)) return false;
+  float fused = NVBX_DIV(sdf + cur.x * cur.y, wsum);
+  if (fused > 0.0f) fused = fminf(f.trunc, fused); else fused = fmaxf(-f.trunc, fused);
+  *v = make_float2(fused, fminf(wsum, f.max_weight));
+  return true;
+}
+__host__ __device__ inline bool frame_is_plain(const Frame& f) {
+  return !f.occupancy && f.weighting_mode == 0 && !f.clamp_before_blend && !(f.invalid_decay >= 0.0f);
 }
 
 // ESDF packed voxel: {f32 squared_distance_vox, u32 meta}; meta = dx | dy<<8 | dz<<16 (int8 each) | observed<<24 | inside<<25 | site<<26

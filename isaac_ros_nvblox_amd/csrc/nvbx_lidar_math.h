@@ -1,6 +1,6 @@
 /* nvbx_lidar_math.h -- spinning-LiDAR sensor model shared by the HIP kernels and (for bit-parity of the projection) by
- * the CPU oracle.  Plain C; every operation is an IEEE add / mul / div / sqrt in a fixed order (both sides build with
- * -ffp-contract=off), so host and device produce identical bits -- libm's atan2f/acosf and the device's ocml versions
+ * the CPU oracle.  Plain C; every operation is an IEEE add / mul / fma / div / sqrt in a fixed order (both sides build with
+ * -ffp-contract=off; fused multiply-adds are written out, nvbx_arith.h), so host and device produce identical bits -- libm's atan2f/acosf and the device's ocml versions
  * differ in the last ulp, which would flip pixel taps and block boundaries between the two.
  *
  * Model ([U] nvblox sensors/lidar restated; anchors in the reference: Lidar(w, h, min_range, vfov) and
@@ -15,6 +15,7 @@
 #define NVBX_LIDAR_MATH_H_
 #include <math.h>
 #include <stdint.h>
+#include "nvbx_arith.h"
 
 #if defined(__HIPCC__)
 #define NVBX_HD __host__ __device__ inline
@@ -28,22 +29,18 @@
 
 /* atan(num / den) for 0 <= num <= den, den > 0: Cephes atanf scheme (reduction at tan(pi/8), degree-4 polynomial in x^2),
  * |err| < 2e-7.  ONE division: the reduced argument (t - 1) / (t + 1) with t = num / den is (num - den) / (num + den), so the
- * operands are selected first and divided once (an IEEE division is ~11 VALU instructions on gfx950; the LiDAR integrator
- * evaluates two atan2 per voxel and is VALU-bound). */
+ * operands are selected first and divided once; the polynomial is a Horner chain of fused multiply-adds (the LiDAR integrator
+ * evaluates this per voxel and is VALU-bound). */
 NVBX_HD float nvbx_atan_ratio(float num, float den) {
   float y0 = 0.0f, n = num, d = den;
   if (num > 0.414213568f * den) { y0 = NVBX_QUARTER_PI_F; n = num - den; d = num + den; }
-  const float x = n / d;
+  const float x = NVBX_DIV(n, d);
   const float z = x * x;
-  float p = 8.05374449538e-2f * z;
-  p = p - 1.38776856032e-1f;
+  float p = NVBX_FMA(8.05374449538e-2f, z, -1.38776856032e-1f);
+  p = NVBX_FMA(p, z, 1.99777106478e-1f);
+  p = NVBX_FMA(p, z, -3.33329491539e-1f);
   p = p * z;
-  p = p + 1.99777106478e-1f;
-  p = p * z;
-  p = p - 3.33329491539e-1f;
-  p = p * z;
-  p = p * x;
-  p = p + x;
+  p = NVBX_FMA(p, x, x);
   return y0 + p;
 }
 NVBX_HD float nvbx_atan2f(float y, float x) {
@@ -55,6 +52,17 @@ NVBX_HD float nvbx_atan2f(float y, float x) {
   if (!(ax >= ay)) a = NVBX_HALF_PI_F - a;
   if (x < 0.0f) a = NVBX_PI_F - a;
   return y < 0.0f ? -a : a;
+}
+/* asin(s) for |s| <= 0.5 (elevations up to 30 degrees: every beam of a spinning LiDAR): s + s^3 P(s^2), P = degree-4 minimax fit
+ * on [0, 0.51] (tools/fit_asin.py), |err| < 4e-8 in float.  No square root, no reduction. */
+NVBX_HD float nvbx_asin_small(float s) {
+  const float z = s * s;
+  float p = NVBX_FMA(4.511628299951553e-2f, z, 2.232578955590725e-2f);
+  p = NVBX_FMA(p, z, 4.5879658311605453e-2f);
+  p = NVBX_FMA(p, z, 7.491616904735565e-2f);
+  p = NVBX_FMA(p, z, 1.666686236858368e-1f);
+  p = p * z;
+  return NVBX_FMA(p, s, s);
 }
 
 typedef struct {
@@ -72,18 +80,27 @@ NVBX_HD nvbx_lidar_model nvbx_lidar_make(int32_t cols, int32_t rows, float min_r
   l.ppr_el = 1.0f / l.rpp_el; l.ppr_az = 1.0f / l.rpp_az;
   return l;
 }
-NVBX_HD float nvbx_lidar_range(const float* p) { return sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]); }
+NVBX_HD float nvbx_lidar_range(const float* p) { return NVBX_SQRT((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]); }
 
-/* Lidar::project: p (sensor frame) -> corner-referenced image coordinates (u along azimuth, v along elevation) */
+/* Lidar::project: p (sensor frame), r = its range -> corner-referenced image coordinates (u along azimuth, v along elevation).
+ * Elevation = asin(z / r): the range is needed anyway (it is the voxel's depth), so the common case costs one division and a short
+ * polynomial instead of a second square root (rho), an octant selection and the atan reduction; steeper than 30 degrees (never a
+ * beam of the sensors this models, but a voxel next to the sensor can be) falls back to atan2(z, rho). */
 NVBX_HD int nvbx_lidar_project(const nvbx_lidar_model* l, const float* p, float r, float* u, float* v) {
-  if (r < l->min_valid_range_m || !(r > 0.0f)) return 0;
-  const float rho = sqrtf(p[0] * p[0] + p[1] * p[1]);
-  const float el = nvbx_atan2f(p[2], rho);
+  if (r < l->min_valid_range_m || !(r > 0.0f) || !(r < 1.0e18f)) return 0;
+  const float s = NVBX_DIV(p[2], r);
+  float el = nvbx_asin_small(s);
+  if (NVBX_ANY_LANE(fabsf(s) > 0.5f)) {
+    float rho2 = p[0] * p[0] + p[1] * p[1];
+    NVBX_KEEP_HERE(rho2);
+    if (fabsf(s) > 0.5f) el = nvbx_atan2f(p[2], NVBX_SQRT(rho2));
+  }
+  const float vv = NVBX_FMA(l->max_el - el, l->ppr_el, 0.5f);
+  if (vv < 0.0f || vv >= (float)l->rows) return 0;              /* outside the vertical field of view */
   const float az = nvbx_atan2f(p[1], p[0]);
-  float uu = (az + NVBX_PI_F) * l->ppr_az + 0.5f;
-  const float vv = (l->max_el - el) * l->ppr_el + 0.5f;
+  float uu = NVBX_FMA(az + NVBX_PI_F, l->ppr_az, 0.5f);
   if (uu >= (float)l->cols) uu = uu - (float)l->cols;           /* azimuth wrap-around */
-  if (vv < 0.0f || vv >= (float)l->rows || uu < 0.0f) return 0; /* outside the vertical field of view */
+  if (uu < 0.0f) return 0;
   *u = uu; *v = vv;
   return 1;
 }

@@ -99,28 +99,28 @@ struct LidarSensor {
     const float fx = floorf(uc), fy = floorf(vc);
     const int x0 = (int)fx, y0 = (int)fy;
     if (!(x0 < 0 || y0 < 0 || x0 + 1 > f.cols - 1 || y0 + 1 > f.rows - 1)) {
-      const float f00 = img((int64_t)y0 * f.cols + x0), f10 = img((int64_t)y0 * f.cols + x0 + 1);
-      const float f01 = img((int64_t)(y0 + 1) * f.cols + x0), f11 = img((int64_t)(y0 + 1) * f.cols + x0 + 1);
+      const int32_t i00 = pix(y0, x0, f.cols);
+      const float f00 = img(i00), f10 = img(i00 + 1), f01 = img(i00 + f.cols), f11 = img(i00 + f.cols + 1);
       if (f00 > 0.0f && f10 > 0.0f && f01 > 0.0f && f11 > 0.0f) {
         const float mx = fmaxf(fmaxf(f00, f10), fmaxf(f01, f11)), mn = fminf(fminf(f00, f10), fminf(f01, f11));
         if (mx - mn <= max_diff_m) {
           const float ax = uc - fx, ay = vc - fy;
-          const float top = (1.0f - ax) * f00 + ax * f10;
-          const float bot = (1.0f - ax) * f01 + ax * f11;
-          *ds = (1.0f - ay) * top + ay * bot;
+          const float top = __builtin_fmaf(ax, f10, (1.0f - ax) * f00);
+          const float bot = __builtin_fmaf(ax, f11, (1.0f - ax) * f01);
+          *ds = __builtin_fmaf(ay, bot, (1.0f - ay) * top);
           return 1;
         }
       }
     }
     const int c = (int)floorf(u), rr = (int)floorf(v);
     if (c < 0 || rr < 0 || c >= f.cols || rr >= f.rows) return 0;
-    const float d = img((int64_t)rr * f.cols + c);
+    const float d = img(pix(rr, c, f.cols));
     if (!(d > 0.0f)) return 0;
     float dir[3]; beam_dir(rr, c, dir);
-    float dot = pc[0] * dir[0]; dot = dot + pc[1] * dir[1]; dot = dot + pc[2] * dir[2];
-    const float ex = pc[0] - dot * dir[0], ey = pc[1] - dot * dir[1], ez = pc[2] - dot * dir[2];
+    const float dot = __builtin_fmaf(pc[2], dir[2], __builtin_fmaf(pc[1], dir[1], pc[0] * dir[0]));
+    const float ex = __builtin_fmaf(-dot, dir[0], pc[0]), ey = __builtin_fmaf(-dot, dir[1], pc[1]), ez = __builtin_fmaf(-dot, dir[2], pc[2]);
     // (squared distances compared: one IEEE square root less per voxel on the VALU-bound LiDAR path; the oracle does the same)
-    if ((ex * ex + ey * ey) + ez * ez > max_ray_dist_m * max_ray_dist_m) return 0;
+    if (__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) > max_ray_dist_m * max_ray_dist_m) return 0;
     *ds = d;
     return 1;
   }
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   // the ray's depth pixel is requested first: its HBM round trip overlaps the LDS set initialisation
   int prow = ri * f.subsample; if (prow >= f.rows) prow = f.rows - 1;
   int pcol = ci * f.subsample; if (pcol >= f.cols) pcol = f.cols - 1;
-  const float d = active ? depth((int64_t)prow * f.cols + pcol) : 0.0f;
+  const float d = active ? depth(pix(prow, pcol, f.cols)) : 0.0f;
   for (int i = lane; i < LSET; i += 64) lset[i] = KEY_EMPTY;
   if (wg_all == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
   // an ESDF dirty list already consumed by a marking pass (fused into integrateColor) is emptied before k_integrate_tsdf appends
@@ -447,8 +447,13 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
 // Dependent-access chain: {view count, view record} -> {depth gather, voxel} -> store.  The record of the first block
 // is fetched speculatively beside the count, the voxel is fetched before the projection decides whether it is needed,
 // and the flag / dirty-list atomics of lane 0 are issued first and consumed last.
-template <typename Img, typename Sensor, int NB>
-__global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, FrameSet<Img, NB> fs, Sensor sensor, const int4* view_list, int32_t list_cap,
+// Occupancy: 8 waves per SIMD (four of these workgroups per CU) is asked for explicitly -- the kernel's ~100 scalar registers would
+// otherwise cost the eighth wave, and on the LiDAR map (112 k blocks per scan) residency is throughput; the grid is exactly the 1024
+// workgroups that are then resident together (tools/integ_grid_sweep.sh: 768 / 1024 workgroups at 6 waves 499 / 569 us, 1024 at 8 waves 430-470).
+// Plain = every camera of the launch is frame_is_plain() (nvbx_internal.h): the occupancy / weighting-mode / decay switches fold away
+// at compile time -- same arithmetic, 12 % fewer issue cycles on the LiDAR launch (tools/variant_ab.sh).
+template <typename Img, typename Sensor, int NB, bool Plain>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_integrate_tsdf(DMap m, FrameSet<Img, NB> fs, Sensor sensor, const int4* view_list, int32_t list_cap,
                                                         int32_t mesh_list, int32_t* view_export, int32_t view_export_cap) {
   const Frame& f0 = fs.f[0];
   int4 rec = view_list[blockIdx.x];                       // speculative: valid iff blockIdx.x < n (gridDim.x <= list_cap)
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, FrameSet<Img, NB
     uint32_t cams = 1u;
     if (NB > 1) cams = __builtin_amdgcn_readfirstlane(m.table[m.slot_entry[slot]].stamp & 0xFFu);
     uint32_t old = 0;
-    if (tid == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH | ((Sensor::kLongRays && !f0.occupancy) ? F_BAND_STALE : 0u));
+    if (tid == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH | ((Sensor::kLongRays && (Plain || !f0.occupancy)) ? F_BAND_STALE : 0u));
     const float lx = voxel_center(rec_c.y, vx, f0.block_size, f0.voxel_size), ly = voxel_center(rec_c.z, vy, f0.block_size, f0.voxel_size),
                 lz = voxel_center(rec_c.w, vz, f0.block_size, f0.voxel_size);
     float2 fin = cur_c;            // the voxel as this launch leaves it: the cameras' updates applied in order, exactly as separate calls would
@@ -487,7 +492,9 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, FrameSet<Img, NB
       apply_rt(f.R_CL, f.t_CL, lx, ly, lz, pc);
       float ds = 0.0f, vd = 0.0f;
       const int got = sensor.sample(f, fs.img[c], pc, &ds, &vd);
-      if (f.occupancy) {            // occupancy mapper: the pool holds log-odds (nvbx_internal.h occupancy_update)
+      if (Plain) {
+        if (got > 0 && tsdf_fuse_plain(f, &fin, ds, vd)) touched = true;
+      } else if (f.occupancy) {     // occupancy mapper: the pool holds log-odds (nvbx_internal.h occupancy_update)
         if (got > 0) { fin = make_float2(occupancy_update(f, fin.x, ds, vd), 0.0f); touched = true; }
       } else {
         if (got < 0 && f.invalid_decay >= 0.0f) { fin = make_float2(fin.x, fin.y * f.invalid_decay); touched = true; }
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf(DMap m, FrameSet<Img, NB
       }
     }
     if (touched) *vp = fin;
-    if (!f0.occupancy) {
+    if (Plain || !f0.occupancy) {
       // band vote for the colour integrator (F_BAND, nvbx_internal.h): exact, so set AND cleared here, one bit per wavefront
       if (!Sensor::kLongRays) {      // (LiDAR: marked stale above instead)
         // one workgroup per block and a few hundred blocks: a block-wide vote and ONE atomic are cheaper here than a bit per wavefront
@@ -530,9 +537,15 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   NVBX_LAUNCH(m, (k_mark_view<Img, Sensor, NB>), dim3(tiles + edt_wg), dim3(Sensor::kThreads), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
               (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)edt_wg, ea);
   m->premark_consumed = false; m->dirty_since_mark = true;
-  const int grid = (int)std::min<int64_t>(m->capacity, 1024);
-  NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor, NB>), dim3(grid), dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
-                     m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap);
+  // grid-stride over the view list: exactly the 1024 workgroups that are resident together (4 per CU)
+  static const int grid_cap = getenv("NVBX_INTEG_GRID") ? atoi(getenv("NVBX_INTEG_GRID")) : 1024;    // (env: tools/integ_grid_sweep.sh)
+  const int grid = (int)std::min<int64_t>(m->capacity, grid_cap);
+  bool plain = true;
+  for (int c = 0; c < fs.n; c++) plain = plain && frame_is_plain(fs.f[c]);
+  if (plain) NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor, NB, true>), dim3(grid), dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
+                         m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap);
+  else NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor, NB, false>), dim3(grid), dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
+                   m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap);
   NVBX_HIP(hipGetLastError());
   m->last_view_frame = m->frame_id;
   if (!Sensor::kLongRays) { m->last_camera_view_frame = m->frame_id; m->last_camera_view_mask = 1u << (fs.n - 1); }   // (a batch: the LAST camera's view, as separate calls would leave it)
@@ -568,7 +581,7 @@ __global__ void k_dilate_invalid(Img in, int32_t rows, int32_t cols, int32_t n, 
       const int rr = r + dr; if (rr < 0 || rr >= rows) continue;
       for (int dc = -n; dc <= n; dc++) {
         const int cc = c + dc; if (cc < 0 || cc >= cols) continue;
-        if (!(in((int64_t)rr * cols + cc) > 0.0f)) { bad = true; break; }
+        if (!(in(pix(rr, cc, cols)) > 0.0f)) { bad = true; break; }
       }
     }
     out[i] = bad ? 0.0f : in(i);
@@ -611,14 +624,14 @@ static int integrate_cameras(nvbx_mapper* m, int32_t n, const Img* imgs, int32_t
 
 extern "C" int nvbx_integrate_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                     const nvbx_camera* camera) {
-  if (!m || !depth_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_depth: invalid argument"); return NVBX_E_INVALID; }
+  if (!m || !depth_dev || !T_L_C || !camera || !image_dims_ok(rows, cols)) { set_error("nvbx_integrate_depth: invalid argument (image sides 1 .. 32768)"); return NVBX_E_INVALID; }
   if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_depth: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
   const DepthF32 img{depth_dev};
   return integrate_cameras<DepthF32, 1>(m, 1, &img, rows, cols, T_L_C, camera);
 }
 extern "C" int nvbx_integrate_depth_u16mm(nvbx_mapper* m, const uint16_t* depth_mm_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                           const nvbx_camera* camera) {
-  if (!m || !depth_mm_dev || !T_L_C || !camera || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_depth_u16mm: invalid argument"); return NVBX_E_INVALID; }
+  if (!m || !depth_mm_dev || !T_L_C || !camera || !image_dims_ok(rows, cols)) { set_error("nvbx_integrate_depth_u16mm: invalid argument (image sides 1 .. 32768)"); return NVBX_E_INVALID; }
   if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_depth_u16mm: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
   const DepthU16mm img{depth_mm_dev};
   return integrate_cameras<DepthU16mm, 1>(m, 1, &img, rows, cols, T_L_C, camera);
@@ -626,7 +639,7 @@ extern "C" int nvbx_integrate_depth_u16mm(nvbx_mapper* m, const uint16_t* depth_
 // Up to NVBX_MAX_BATCH camera frames (same image size) in ONE launch set: see include/nvblox_hip.h
 extern "C" int nvbx_integrate_depth_batch(nvbx_mapper* m, int32_t n, const float* const* depth_dev, int32_t rows, int32_t cols, const float* T_L_C,
                                           const nvbx_camera* cameras) {
-  if (!m || n < 1 || n > MAX_BATCH || !depth_dev || !T_L_C || !cameras || rows <= 0 || cols <= 0) { set_error("nvbx_integrate_depth_batch: invalid argument (1 <= n <= 8)"); return NVBX_E_INVALID; }
+  if (!m || n < 1 || n > MAX_BATCH || !depth_dev || !T_L_C || !cameras || !image_dims_ok(rows, cols)) { set_error("nvbx_integrate_depth_batch: invalid argument (1 <= n <= 8, image sides 1 .. 32768)"); return NVBX_E_INVALID; }
   for (int c = 0; c < n; c++)
     if (!depth_dev[c] || !nvbx_camera_matches(cameras + c, rows, cols)) { set_error("nvbx_integrate_depth_batch: every camera's width/height must equal the images' cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
   // what a batch cannot express falls back to the separate calls it is defined by: per-frame freespace time stamps, depth dilation
@@ -737,7 +750,7 @@ __global__ __launch_bounds__(512) void k_apply_fuse(DMap m, Frame f, const MeasR
 
 extern "C" int nvbx_measure_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera,
                                   nvbx_measurement_block* out_dev, int32_t* count_dev, int64_t capacity_blocks) {
-  if (!m || !depth_dev || !T_L_C || !camera || !out_dev || !count_dev || capacity_blocks <= 0 || rows <= 0 || cols <= 0) { set_error("nvbx_measure_depth: invalid argument"); return NVBX_E_INVALID; }
+  if (!m || !depth_dev || !T_L_C || !camera || !out_dev || !count_dev || capacity_blocks <= 0 || !image_dims_ok(rows, cols)) { set_error("nvbx_measure_depth: invalid argument"); return NVBX_E_INVALID; }
   if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_measure_depth: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
   if (!nvbx_pose_in_range(T_L_C, m->p.voxel_size * 8.0f, m->p.max_integration_distance_m + 2.0f * m->p.truncation_distance_vox * m->p.voxel_size)) {
     set_error("nvbx_measure_depth: T_L_C is not finite or lies outside the addressable block range"); return NVBX_E_INVALID; }
@@ -825,7 +838,8 @@ static int ensure_lidar_tables(nvbx_mapper* m, const nvbx_lidar* ld, const nvbx_
 }
 
 static bool lidar_ok(const nvbx_lidar* ld) {
-  return ld && ld->num_azimuth_divisions >= 2 && ld->num_elevation_divisions >= 2 && ld->max_elevation_rad > ld->min_elevation_rad;
+  return ld && ld->num_azimuth_divisions >= 2 && ld->num_elevation_divisions >= 2 && ld->max_elevation_rad > ld->min_elevation_rad &&
+         image_dims_ok(ld->num_elevation_divisions, ld->num_azimuth_divisions);
 }
 
 extern "C" int nvbx_integrate_lidar_depth(nvbx_mapper* m, const float* range_dev, int32_t rows, int32_t cols, const float T_L_C[16],

@@ -723,9 +723,9 @@ static int lidar_sample(const OrcParams* p, const LidarTab* t, const float* img,
       const float mx = fmaxf(fmaxf(f00, f10), fmaxf(f01, f11)), mn = fminf(fminf(f00, f10), fminf(f01, f11));
       if (mx - mn <= max_diff) {
         const float ax = uc - fx, ay = vc - fy;
-        const float top = (1.0f - ax) * f00 + ax * f10;
-        const float bot = (1.0f - ax) * f01 + ax * f11;
-        *ds = (1.0f - ay) * top + ay * bot;
+        const float top = fmaf(ax, f10, (1.0f - ax) * f00);          /* fused multiply-adds written out (one rounding each), as in the kernel */
+        const float bot = fmaf(ax, f11, (1.0f - ax) * f01);
+        *ds = fmaf(ay, bot, (1.0f - ay) * top);
         return 1;
       }
     }
@@ -735,9 +735,9 @@ static int lidar_sample(const OrcParams* p, const LidarTab* t, const float* img,
   const float d = img[(int64_t)rr * cols + c];
   if (!(d > 0.0f)) return 0;
   float dir[3]; lidar_dir(t, rr, c, dir);
-  float dot = pc[0] * dir[0]; dot = dot + pc[1] * dir[1]; dot = dot + pc[2] * dir[2];
-  const float ex = pc[0] - dot * dir[0], ey = pc[1] - dot * dir[1], ez = pc[2] - dot * dir[2];
-  if ((ex * ex + ey * ey) + ez * ez > max_ray * max_ray) return 0;       /* squared point-to-ray distance against the squared threshold */
+  const float dot = fmaf(pc[2], dir[2], fmaf(pc[1], dir[1], pc[0] * dir[0]));
+  const float ex = fmaf(-dot, dir[0], pc[0]), ey = fmaf(-dot, dir[1], pc[1]), ez = fmaf(-dot, dir[2], pc[2]);
+  if (fmaf(ez, ez, fmaf(ey, ey, ex * ex)) > max_ray * max_ray) return 0;       /* squared point-to-ray distance against the squared threshold */
   *ds = d;
   return 1;
 }

@@ -121,6 +121,8 @@ def test_batch_argument_checks(hip_lib):
         g.integrate_depth_batch([fr[0][0]] * 9, [fr[0][2]] * 9, H.SMALL_CAM)               # more than NVBX_MAX_BATCH
     with pytest.raises(M.NvbxError):
         g.integrate_depth_batch([fr[0][0], fr[1][0]], [fr[0][2], fr[1][2]], [H.SMALL_CAM, (80.0, 80.0, 79.5, 59.5, 161, 120)])   # camera != image
+    with pytest.raises(M.NvbxError):                                                       # image sides above 32768 are refused (31-bit pixel indices)
+        g.integrate_depth(np.ones((40000, 4), np.float32), fr[0][2], (80.0, 80.0, 1.5, 19999.5, 4, 40000))
     assert g.num_blocks(M.LAYER_TSDF) == 0
 
 
