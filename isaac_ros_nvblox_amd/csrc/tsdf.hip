@@ -456,10 +456,15 @@ template <typename Img, typename Sensor, int NB, bool Plain>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_integrate_tsdf(DMap m, FrameSet<Img, NB> fs, Sensor sensor, const int4* view_list, int32_t list_cap,
                                                         int32_t mesh_list, int32_t* view_export, int32_t view_export_cap) {
   const Frame& f0 = fs.f[0];
-  int4 rec = view_list[blockIdx.x];                       // speculative: valid iff blockIdx.x < n (gridDim.x <= list_cap)
+  const int tid = threadIdx.x, lane = tid & 63;
+  // The view records are taken 64 at a time: lane j of every wavefront fetches the record of the j-th block this workgroup will
+  // process next (speculatively, beside the count) and transforms that block's origin into the sensor frame; the block loop then
+  // reads slot and origin out of lane j (v_readlane: scalar operands from there on).  The record fetch leaves the per-block
+  // dependent chain and the 3 x 3 transform is paid once per block and wavefront instead of once per voxel.
+  int32_t mine = (int32_t)blockIdx.x + lane * (int32_t)gridDim.x;
+  int4 rec = mine < list_cap ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
   int32_t n = m.counters[C_VIEW_COUNT + (f0.frame_id & 3)];
   if (n > list_cap) n = list_cap;
-  const int tid = threadIdx.x;
   // nvbx_set_view_export: the frame's block indices also go to a caller-owned packed buffer [1 + cap][3] (row 0 = count) --
   // the message of the multi-GPU exchange, written here instead of by an export launch
   if (view_export && blockIdx.x == 0 && tid == 0) { view_export[0] = min(n, view_export_cap); view_export[1] = 0; view_export[2] = 0; }
@@ -467,52 +472,66 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   if (blockIdx.x == 0 && tid == 64) __hip_atomic_store(&m.host_mirror[0], m.counters[C_FREE_TOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (blockIdx.x == 0 && tid == 128) __hip_atomic_store(&m.host_mirror[1], m.counters[C_HIGH_WATER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
-  for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
-    if (i != (int32_t)blockIdx.x) rec = view_list[i];
-    const int4 rec_c = rec;
-    if (view_export && tid == 0 && i < view_export_cap) { int32_t* e = view_export + 3 * (1 + (int64_t)i); e[0] = rec_c.y; e[1] = rec_c.z; e[2] = rec_c.w; }
-    const uint32_t slot = (uint32_t)rec_c.x;               // pool slot (stable across hash rebuilds)
-    if (!slot_ok(slot)) continue;
-    float2* vp = &m.tsdf[(size_t)slot * 512 + tid];
-    const float2 cur_c = *vp;
-    // batch: which cameras had this block in view = the mask k_mark_view left in the entry's stamp (uniform per block)
-    uint32_t cams = 1u;
-    if (NB > 1) cams = __builtin_amdgcn_readfirstlane(m.table[m.slot_entry[slot]].stamp & 0xFFu);
-    uint32_t old = 0;
-    if (tid == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH | ((Sensor::kLongRays && (Plain || !f0.occupancy)) ? F_BAND_STALE : 0u));
-    const float lx = voxel_center(rec_c.y, vx, f0.block_size, f0.voxel_size), ly = voxel_center(rec_c.z, vy, f0.block_size, f0.voxel_size),
-                lz = voxel_center(rec_c.w, vz, f0.block_size, f0.voxel_size);
-    float2 fin = cur_c;            // the voxel as this launch leaves it: the cameras' updates applied in order, exactly as separate calls would
-    bool touched = false;
+  float off0[3] = {0.0f, 0.0f, 0.0f};
+  if (NB == 1) sensor_voxel_offset(f0, vx, vy, vz, off0);          // (a batch rotates the offset per camera inside the loop)
+  for (int32_t i0 = blockIdx.x; i0 < n; i0 += 64 * (int32_t)gridDim.x) {
+    if (i0 != (int32_t)blockIdx.x) { mine = i0 + lane * (int32_t)gridDim.x; rec = mine < n ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0); }
+    if (view_export && tid < 64 && mine < n && mine < view_export_cap) { int32_t* e = view_export + 3 * (1 + (int64_t)mine); e[0] = rec.y; e[1] = rec.z; e[2] = rec.w; }
+    float org[3] = {0.0f, 0.0f, 0.0f};
+    if (NB == 1) sensor_block_origin(f0, rec.y, rec.z, rec.w, org);
+    const int32_t cnt = min(64, (n - i0 + (int32_t)gridDim.x - 1) / (int32_t)gridDim.x);     // blocks of this round (uniform)
 #pragma unroll 1
-    for (int c = 0; c < (NB > 1 ? fs.n : 1); c++) {
-      if (NB > 1 && !((cams >> c) & 1u)) continue;       // uniform
-      const Frame& f = fs.f[c];
-      float pc[3];
-      apply_rt(f.R_CL, f.t_CL, lx, ly, lz, pc);
-      float ds = 0.0f, vd = 0.0f;
-      const int got = sensor.sample(f, fs.img[c], pc, &ds, &vd);
-      if (Plain) {
-        if (got > 0 && tsdf_fuse_plain(f, &fin, ds, vd)) touched = true;
-      } else if (f.occupancy) {     // occupancy mapper: the pool holds log-odds (nvbx_internal.h occupancy_update)
-        if (got > 0) { fin = make_float2(occupancy_update(f, fin.x, ds, vd), 0.0f); touched = true; }
-      } else {
-        if (got < 0 && f.invalid_decay >= 0.0f) { fin = make_float2(fin.x, fin.y * f.invalid_decay); touched = true; }
-        if (got > 0 && tsdf_fuse(f, &fin, ds, vd)) touched = true;
+    for (int32_t j = 0; j < cnt; j++) {
+      const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane(rec.x, j);               // pool slot (stable across hash rebuilds)
+      if (!slot_ok(slot)) continue;
+      float2* vp = &m.tsdf[(size_t)slot * 512 + tid];
+      const float2 cur_c = *vp;
+      // batch: which cameras had this block in view = the mask k_mark_view left in the entry's stamp (uniform per block)
+      uint32_t cams = 1u;
+      if (NB > 1) cams = __builtin_amdgcn_readfirstlane(m.table[m.slot_entry[slot]].stamp & 0xFFu);
+      uint32_t old = 0;
+      if (tid == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH | ((Sensor::kLongRays && (Plain || !f0.occupancy)) ? F_BAND_STALE : 0u));
+      const int32_t bx = __builtin_amdgcn_readlane(rec.y, j), by = __builtin_amdgcn_readlane(rec.z, j), bz = __builtin_amdgcn_readlane(rec.w, j);
+      float2 fin = cur_c;            // the voxel as this launch leaves it: the cameras' updates applied in order, exactly as separate calls would
+      bool touched = false;
+#pragma unroll 1
+      for (int c = 0; c < (NB > 1 ? fs.n : 1); c++) {
+        if (NB > 1 && !((cams >> c) & 1u)) continue;       // uniform
+        const Frame& f = fs.f[c];
+        float pc[3];
+        if (NB == 1) {
+          pc[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(org[0]), j)) + off0[0];
+          pc[1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(org[1]), j)) + off0[1];
+          pc[2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(org[2]), j)) + off0[2];
+        } else {
+          float o[3], d[3];
+          sensor_block_origin(f, bx, by, bz, o); sensor_voxel_offset(f, vx, vy, vz, d);
+          pc[0] = o[0] + d[0]; pc[1] = o[1] + d[1]; pc[2] = o[2] + d[2];
+        }
+        float ds = 0.0f, vd = 0.0f;
+        const int got = sensor.sample(f, fs.img[c], pc, &ds, &vd);
+        if (Plain) {
+          if (got > 0 && tsdf_fuse_plain(f, &fin, ds, vd)) touched = true;
+        } else if (f.occupancy) {     // occupancy mapper: the pool holds log-odds (nvbx_internal.h occupancy_update)
+          if (got > 0) { fin = make_float2(occupancy_update(f, fin.x, ds, vd), 0.0f); touched = true; }
+        } else {
+          if (got < 0 && f.invalid_decay >= 0.0f) { fin = make_float2(fin.x, fin.y * f.invalid_decay); touched = true; }
+          if (got > 0 && tsdf_fuse(f, &fin, ds, vd)) touched = true;
+        }
       }
-    }
-    if (touched) *vp = fin;
-    if (Plain || !f0.occupancy) {
-      // band vote for the colour integrator (F_BAND, nvbx_internal.h): exact, so set AND cleared here, one bit per wavefront
-      if (!Sensor::kLongRays) {      // (LiDAR: marked stale above instead)
-        // one workgroup per block and a few hundred blocks: a block-wide vote and ONE atomic are cheaper here than a bit per wavefront
-        const int any_band = __syncthreads_or(in_band(fin.x, fin.y, f0.trunc) ? 1 : 0);
-        if (tid == 0) { if (any_band) atomicOr(&m.slot_flags[slot], F_BAND); else atomicAnd(&m.slot_flags[slot], ~F_BAND); if (old & F_BAND_STALE) atomicAnd(&m.slot_flags[slot], ~F_BAND_STALE); }
+      if (touched) *vp = fin;
+      if (Plain || !f0.occupancy) {
+        // band vote for the colour integrator (F_BAND, nvbx_internal.h): exact, so set AND cleared here, one bit per wavefront
+        if (!Sensor::kLongRays) {      // (LiDAR: marked stale above instead)
+          // one workgroup per block and a few hundred blocks: a block-wide vote and ONE atomic are cheaper here than a bit per wavefront
+          const int any_band = __syncthreads_or(in_band(fin.x, fin.y, f0.trunc) ? 1 : 0);
+          if (tid == 0) { if (any_band) atomicOr(&m.slot_flags[slot], F_BAND); else atomicAnd(&m.slot_flags[slot], ~F_BAND); if (old & F_BAND_STALE) atomicAnd(&m.slot_flags[slot], ~F_BAND_STALE); }
+        }
       }
-    }
-    if (tid == 0) {
-      if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)slot);
-      if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, (int32_t)slot);
+      if (tid == 0) {
+        if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)slot);
+        if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, (int32_t)slot);
+      }
     }
   }
 }
@@ -676,9 +695,9 @@ __global__ __launch_bounds__(512) void k_measure_tsdf(DMap m, Frame f, Img depth
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
   for (int32_t i = blockIdx.x; i < n; i += gridDim.x) {
     const int4 rec = view_list[i];
-    float pc[3];
-    apply_rt(f.R_CL, f.t_CL, voxel_center(rec.y, vx, f.block_size, f.voxel_size), voxel_center(rec.z, vy, f.block_size, f.voxel_size),
-             voxel_center(rec.w, vz, f.block_size, f.voxel_size), pc);
+    float pc[3], org[3], off[3];             // (the voxel centre exactly as k_integrate_tsdf evaluates it: the fused map is bit-identical)
+    sensor_block_origin(f, rec.y, rec.z, rec.w, org); sensor_voxel_offset(f, vx, vy, vz, off);
+    pc[0] = org[0] + off[0]; pc[1] = org[1] + off[1]; pc[2] = org[2] + off[2];
     float ds = 0.0f, vd = 0.0f;
     const int got = sensor.sample(f, depth, pc, &ds, &vd);
     // {ds, vd}: vd < 0 = the voxel is not touched; ds < 0 = it projects onto invalid depth (invalid_depth_decay); else a measurement

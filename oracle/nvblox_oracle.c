@@ -276,6 +276,17 @@ static inline float voxel_center(int32_t bi, int32_t vi, float bs, float vs) {
   return ((float)bi * bs + (float)vi * vs) + vs * 0.5f;
 }
 
+/* The TSDF / occupancy integrators' voxel centre in the sensor frame: the block's origin is transformed once, the offset of the
+ * voxel's centre inside the block is rotated, and the two are added (the kernels evaluate exactly these two terms: the first is
+ * uniform per block, the second per voxel position -- csrc/nvbx_internal.h sensor_block_origin / sensor_voxel_offset). */
+static inline void voxel_in_sensor(const Rt* T_C_L, int32_t bx, int32_t by, int32_t bz, int x, int y, int z, float bs, float vs, float* pc) {
+  float org[3], off[3];
+  const float h = vs * 0.5f;
+  rt_apply(T_C_L, (float)bx * bs, (float)by * bs, (float)bz * bs, org);
+  rt_rotate(T_C_L, (float)x * vs + h, (float)y * vs + h, (float)z * vs + h, off);
+  pc[0] = org[0] + off[0]; pc[1] = org[1] + off[1]; pc[2] = org[2] + off[2];
+}
+
 typedef struct { float fu, fv, cu, cv; int32_t w, h; } Cam;
 static Cam cam_from(const float* c) { Cam k = {c[0], c[1], c[2], c[3], (int32_t)c[4], (int32_t)c[5]}; return k; }
 
@@ -448,8 +459,7 @@ static void tsdf_integrate_block(const OrcParams* p, Block* b, const float* dept
   const float vs = p->voxel_size, bs = vs * 8.0f;
   const float trunc = p->truncation_distance_vox * vs;
   for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) for (int z = 0; z < 8; z++) {
-    float pl[3] = {voxel_center(b->idx.x, x, bs, vs), voxel_center(b->idx.y, y, bs, vs), voxel_center(b->idx.z, z, bs, vs)};
-    float pc[3]; rt_apply(T_C_L, pl[0], pl[1], pl[2], pc);
+    float pc[3]; voxel_in_sensor(T_C_L, b->idx.x, b->idx.y, b->idx.z, x, y, z, bs, vs, pc);
     float u, v;
     if (!cam_project(k, pc, &u, &v)) continue;
     const float vd = pc[2];
@@ -636,8 +646,7 @@ int64_t orc_measure_depth(OrcMap* m, const float* depth, int rows, int cols, con
     MeasRec* r = &out[i];
     r->x = bi.x; r->y = bi.y; r->z = bi.z; r->rank = 0;
     for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) for (int z = 0; z < 8; z++) {
-      float pl[3] = {voxel_center(bi.x, x, bs, vs), voxel_center(bi.y, y, bs, vs), voxel_center(bi.z, z, bs, vs)};
-      float pc[3]; rt_apply(&T_C_L, pl[0], pl[1], pl[2], pc);
+      float pc[3]; voxel_in_sensor(&T_C_L, bi.x, bi.y, bi.z, x, y, z, bs, vs, pc);
       float u, v, ds = 0.0f;
       float* o = r->v[z + 8 * y + 64 * x];
       o[0] = 0.0f; o[1] = -1.0f;
@@ -771,7 +780,7 @@ int64_t orc_integrate_lidar_depth(OrcMap* m, const float* range, int rows, int c
   for (int64_t i = 0; i < n; i++) {
     Block* b = map_find(m, m->view[i]);
     for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) for (int z = 0; z < 8; z++) {
-      float pc[3]; rt_apply(&T_C_L, voxel_center(b->idx.x, x, bs, vs), voxel_center(b->idx.y, y, bs, vs), voxel_center(b->idx.z, z, bs, vs), pc);
+      float pc[3]; voxel_in_sensor(&T_C_L, b->idx.x, b->idx.y, b->idx.z, x, y, z, bs, vs, pc);
       float ds, vd;
       if (!lidar_sample(p, &tab, range, rows, cols, pc, max_dist, &ds, &vd)) continue;
       tsdf_fuse(p, &b->tsdf[z + 8 * y + 64 * x], ds, vd, trunc, max_dist);
