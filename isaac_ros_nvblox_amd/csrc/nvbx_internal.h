@@ -357,6 +357,7 @@ __device__ inline int interp_depth(const Img& img, int rows, int cols, float u, 
   const float ax = uc - fx, ay = vc - fy;
   const int32_t i00 = pix(y0, x0, cols);
   const float f00 = img(i00), f10 = img(i00 + 1), f01 = img(i00 + cols), f11 = img(i00 + cols + 1);
+  __builtin_amdgcn_sched_barrier(0);        // both rows' loads in flight before the first tap is looked at (else: two serial round trips)
   if (!(f00 > 0.0f) || !(f10 > 0.0f) || !(f01 > 0.0f) || !(f11 > 0.0f)) return -1;
   const float top = (1.0f - ax) * f00 + ax * f10;
   const float bot = (1.0f - ax) * f01 + ax * f11;

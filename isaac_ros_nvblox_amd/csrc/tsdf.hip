@@ -101,6 +101,7 @@ struct LidarSensor {
     if (!(x0 < 0 || y0 < 0 || x0 + 1 > f.cols - 1 || y0 + 1 > f.rows - 1)) {
       const int32_t i00 = pix(y0, x0, f.cols);
       const float f00 = img(i00), f10 = img(i00 + 1), f01 = img(i00 + f.cols), f11 = img(i00 + f.cols + 1);
+      __builtin_amdgcn_sched_barrier(0);      // both rows' loads in flight before the first tap is looked at (else: two serial round trips)
       if (f00 > 0.0f && f10 > 0.0f && f01 > 0.0f && f11 > 0.0f) {
         const float mx = fmaxf(fmaxf(f00, f10), fmaxf(f01, f11)), mn = fminf(fminf(f00, f10), fminf(f01, f11));
         if (mx - mn <= max_diff_m) {
@@ -479,9 +480,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (view_export && tid < 64 && mine < n && mine < view_export_cap) { int32_t* e = view_export + 3 * (1 + (int64_t)mine); e[0] = rec.y; e[1] = rec.z; e[2] = rec.w; }
     float org[3] = {0.0f, 0.0f, 0.0f};
     if (NB == 1) sensor_block_origin(f0, rec.y, rec.z, rec.w, org);
-    const int32_t cnt = min(64, (n - i0 + (int32_t)gridDim.x - 1) / (int32_t)gridDim.x);     // blocks of this round (uniform)
 #pragma unroll 1
-    for (int32_t j = 0; j < cnt; j++) {
+    for (int32_t j = 0; j < 64 && i0 + j * (int32_t)gridDim.x < n; j++) {               // (uniform)
       const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane(rec.x, j);               // pool slot (stable across hash rebuilds)
       if (!slot_ok(slot)) continue;
       float2* vp = &m.tsdf[(size_t)slot * 512 + tid];
