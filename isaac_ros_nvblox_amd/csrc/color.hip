@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void k_sphere_trace(DMap m, PoseSet<NB> poses,
   const bool valid = cam < poses.n && patch < n_patch && (wg >> 3) < per_xcd && r < srows && c < scols;
   const float rx = (((float)((valid ? c : 0) * f.subsample) + 0.5f) - f.cu) / f.fu;
   const float ry = (((float)((valid ? r : 0) * f.subsample) + 0.5f) - f.cv) / f.fv;
-  const float n = sqrtf((rx * rx + ry * ry) + 1.0f);
-  const float dcx = rx / n, dcy = ry / n, dcz = 1.0f / n;
+  const float n = NVBX_SQRT((rx * rx + ry * ry) + 1.0f);          // (NVBX_SQRT / NVBX_DIV: the IEEE results, shorter sequences -- nvbx_arith.h)
+  const float dcx = NVBX_DIV(rx, n), dcy = NVBX_DIV(ry, n), dcz = NVBX_DIV(1.0f, n);
   float dl[3];
   rotate(f.R_LC, dcx, dcy, dcz, dl);
   // group-uniform march state (replicated in the group's lanes)
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_sphere_trace(DMap m, PoseSet<NB> poses,
     float tc = t;
     for (int j = 0; j < RAY_LANES - 1; j++) if (j < sub) tc = tc + ps;
     const float px = f.t_LC[0] + tc * dl[0], py = f.t_LC[1] + tc * dl[1], pz = f.t_LC[2] + tc * dl[2];
-    const int32_t gx = (int32_t)floorf(px / f.voxel_size), gy = (int32_t)floorf(py / f.voxel_size), gz = (int32_t)floorf(pz / f.voxel_size);
+    const int32_t gx = (int32_t)floorf(NVBX_DIV(px, f.voxel_size)), gy = (int32_t)floorf(NVBX_DIV(py, f.voxel_size)), gz = (int32_t)floorf(NVBX_DIV(pz, f.voxel_size));
     const int32_t bx = gx >> 3, by = gy >> 3, bz = gz >> 3;
     const uint32_t h = done ? 0u : table_pos(m, bx, by, bz);
     const uint4 e = *reinterpret_cast<const uint4*>(&m.table[h]);
@@ -129,7 +129,7 @@ struct PixBgra8 {
 
 __device__ inline uint32_t blend_u8(float c0, float w0, float c1, float w1) {
   const float tw = w0 + w1;
-  const float a = w0 / tw, b = w1 / tw;
+  const float a = NVBX_DIV(w0, tw), b = NVBX_DIV(w1, tw);
   float v = c0 * a + c1 * b;
   v = floorf(v + 0.5f);
   if (v < 0.0f) v = 0.0f;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, FrameSetC<Pix, 
       const float fx = floorf(uc), fy = floorf(vc);
       const int x0 = (int)fx, y0 = (int)fy;
       const bool c_ok = !(x0 < 0 || y0 < 0 || x0 + 1 > f.cols - 1 || y0 + 1 > f.rows - 1);
-      const float us = u / (float)f.subsample, vs_ = v / (float)f.subsample;
+      const float us = NVBX_DIV(u, (float)f.subsample), vs_ = NVBX_DIV(v, (float)f.subsample);
       const float usc = us - 0.5f, vsc = vs_ - 0.5f;
       const float sfx = floorf(usc), sfy = floorf(vsc);
       const int sx0 = (int)sfx, sy0 = (int)sfy;
@@ -263,6 +263,8 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, FrameSetC<Pix, 
       const float s00 = sp[0], s10 = sp[1], s01 = sp[scols], s11 = sp[scols + 1];
       float t00[3], t10[3], t01[3], t11[3];
       fs.img[c].tap(i00, t00); fs.img[c].tap(i00 + 1, t10); fs.img[c].tap(i00 + f.cols, t01); fs.img[c].tap(i00 + f.cols + 1, t11);
+      // (the compiler sinks the colour taps below the occlusion test -- two round trips for a voxel that passes, none for the many that
+      // fail; pinning them above it was measured: 9.5 -> 10.9 us)
       if (!(s00 > 0.0f) || !(s10 > 0.0f) || !(s01 > 0.0f) || !(s11 > 0.0f)) continue;
       const float sax = usc - sfx, say = vsc - sfy;
       const float stop = (1.0f - sax) * s00 + sax * s10;
