@@ -83,12 +83,21 @@ NVBX_HD nvbx_lidar_model nvbx_lidar_make(int32_t cols, int32_t rows, float min_r
 NVBX_HD float nvbx_lidar_range(const float* p) { return NVBX_SQRT((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]); }
 
 /* Lidar::project: p (sensor frame), r = its range -> corner-referenced image coordinates (u along azimuth, v along elevation).
- * Elevation = asin(z / r): the range is needed anyway (it is the voxel's depth), so the common case costs one division and a short
- * polynomial instead of a second square root (rho), an octant selection and the atan reduction; steeper than 30 degrees (never a
- * beam of the sensors this models, but a voxel next to the sensor can be) falls back to atan2(z, rho). */
+ * Elevation = asin(z / r): the range is needed anyway (it is the voxel's depth), so the common case is a short polynomial instead
+ * of a second square root (rho), an octant selection and the atan reduction; steeper than 30 degrees (never a beam of the sensors
+ * this models, but a voxel next to the sensor can be) falls back to atan2(z, rho).
+ * ONE reciprocal serves both angles: with (n, d) the azimuth's reduced operands (nvbx_atan_ratio's selection), q = 1 / (r d) gives
+ * sin(elevation) = (z d) q and the reduced tangent n / d = (n r) q -- four multiplications for the second IEEE division. */
 NVBX_HD int nvbx_lidar_project(const nvbx_lidar_model* l, const float* p, float r, float* u, float* v) {
   if (r < l->min_valid_range_m || !(r > 0.0f) || !(r < 1.0e18f)) return 0;
-  const float s = NVBX_DIV(p[2], r);
+  const float ax = fabsf(p[0]), ay = fabsf(p[1]);
+  const int hi = !(ax >= ay);                                   /* second octant: azimuth = pi/2 - atan(ax / ay) */
+  const float num = hi ? ax : ay, den = hi ? ay : ax;           /* 0 <= num <= den */
+  float y0 = 0.0f, n = num, d = den;
+  if (num > 0.414213568f * den) { y0 = NVBX_QUARTER_PI_F; n = num - den; d = num + den; }
+  if (den == 0.0f) d = 1.0f;                                    /* on the sensor's z axis: n = 0, azimuth 0 by convention */
+  const float q = NVBX_DIV(1.0f, r * d);
+  const float s = (p[2] * d) * q;
   float el = nvbx_asin_small(s);
   if (NVBX_ANY_LANE(fabsf(s) > 0.5f)) {
     float rho2 = p[0] * p[0] + p[1] * p[1];
@@ -97,7 +106,17 @@ NVBX_HD int nvbx_lidar_project(const nvbx_lidar_model* l, const float* p, float 
   }
   const float vv = NVBX_FMA(l->max_el - el, l->ppr_el, 0.5f);
   if (vv < 0.0f || vv >= (float)l->rows) return 0;              /* outside the vertical field of view */
-  const float az = nvbx_atan2f(p[1], p[0]);
+  const float t = (n * r) * q;
+  const float z = t * t;
+  float c = NVBX_FMA(8.05374449538e-2f, z, -1.38776856032e-1f);        /* nvbx_atan_ratio's polynomial */
+  c = NVBX_FMA(c, z, 1.99777106478e-1f);
+  c = NVBX_FMA(c, z, -3.33329491539e-1f);
+  c = c * z;
+  c = NVBX_FMA(c, t, t);
+  float az = y0 + c;
+  if (hi) az = NVBX_HALF_PI_F - az;
+  if (p[0] < 0.0f) az = NVBX_PI_F - az;
+  if (p[1] < 0.0f) az = -az;
   float uu = NVBX_FMA(az + NVBX_PI_F, l->ppr_az, 0.5f);
   if (uu >= (float)l->cols) uu = uu - (float)l->cols;           /* azimuth wrap-around */
   if (uu < 0.0f) return 0;
