@@ -49,8 +49,10 @@ __device__ inline void decay_flush(const DMap& m, DecayQueues* dq, const int32_t
 // OCC = false: TSDF decay (weight *= factor; a block lives while any weight >= thresh).  OCC = true: occupancy decay (`factor` /
 // `thresh` carry the log-odds steps of the free / occupied regions; every value moves towards 0 and stops there; a block lives
 // while any value != 0) -- [U] OccupancyDecayIntegrator, Mapper::decayOccupancyAllVoxels (nvblox_node.cpp:925-929).
+// (8 waves per SIMD asked for explicitly -- ~100 SGPRs would cost the eighth -- and a grid of several resident rounds: 368 -> 326 us on the
+// 146 k-block map, tools/decay_grid_sweep.sh)
 template <bool OCC>
-__global__ __launch_bounds__(512) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, uint32_t exclude_mask, int32_t mesh_list,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, uint32_t exclude_mask, int32_t mesh_list,
                                                int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc, int32_t* cleared_idx) {
   __shared__ int s_alive[2][DB];                         // by iteration parity: no barrier between the books of one iteration and the loads of the next
   __shared__ DecayQueues dq;
@@ -274,7 +276,7 @@ extern "C" int nvbx_decay_occupancy(nvbx_mapper* m) {
   if (m->begin_dirtying()) return NVBX_E_DEVICE;
   EsdfArgs ea = m->make_esdf_args();
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
-  NVBX_LAUNCH(m, k_decay<true>, dim3((unsigned)std::min<int64_t>(m->capacity, 2048)), dim3(512), m->d,
+  NVBX_LAUNCH(m, k_decay<true>, dim3((unsigned)std::min<int64_t>(m->capacity, 4096)), dim3(512), m->d,
               log_odds(m->p.free_region_decay_probability), log_odds(m->p.occupied_region_decay_probability), 0u, 0u, (int32_t)m->mesh_list_live(),
               ea.bz_lo, ea.bz_hi, ea.bz_out, 0.0f, m->cleared_idx);
   return rebuild_table(m);
@@ -287,7 +289,8 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   if (m->join_side()) return NVBX_E_DEVICE;
   if (m->undo_marks()) return NVBX_E_DEVICE;          // decay deallocates: unresolved marking passes are taken back first
   if (m->begin_dirtying()) return NVBX_E_DEVICE;
-  const int grid = (int)std::min<int64_t>(m->capacity, 2048);
+  static const int decay_grid = getenv("NVBX_DECAY_GRID") ? atoi(getenv("NVBX_DECAY_GRID")) : 4096;      // (env: tools/decay_grid_sweep.sh)
+  const int grid = (int)std::min<int64_t>(m->capacity, decay_grid);
   EsdfArgs ea = m->make_esdf_args();
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
   NVBX_LAUNCH(m, k_decay<false>, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
