@@ -141,6 +141,7 @@ __device__ inline uint32_t blend_u8(float c0, float w0, float c1, float w1) {
 // -> frustum vote -> {synthetic depth gather, colour gather, colour voxel} (fetched together) -> store.
 // Workgroups [0, n_mark_wg) are ESDF marking workers (first wavefront only; dispatched first so that they start at once and
 // do not queue for a CU slot behind the resident batch of colour workgroups); the n_color_wg after them integrate colour.
+// (7 waves/SIMD at 67 VGPRs; forcing the eighth -- amdgpu_waves_per_eu(8, 8), 63 VGPRs -- was measured: 9.5 -> 10.3 us, rejected)
 template <typename Pix, int NB>
 __global__ __launch_bounds__(512) void k_integrate_color(DMap m, FrameSetC<Pix, NB> fs, const float* synth_all, int32_t srows, int32_t scols,
                                                          int32_t mesh_list, int32_t n_mark_wg, EsdfArgs ea, ImportArgs imp) {

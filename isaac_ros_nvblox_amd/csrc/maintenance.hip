@@ -290,7 +290,9 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   if (m->undo_marks()) return NVBX_E_DEVICE;          // decay deallocates: unresolved marking passes are taken back first
   if (m->begin_dirtying()) return NVBX_E_DEVICE;
   static const int decay_grid = getenv("NVBX_DECAY_GRID") ? atoi(getenv("NVBX_DECAY_GRID")) : 4096;      // (env: tools/decay_grid_sweep.sh)
-  const int grid = (int)std::min<int64_t>(m->capacity, decay_grid);
+  // eight slots per workgroup iteration: a room-sized map needs a few hundred workgroups, and launching 4096 costs it ~1.5 us
+  const int64_t hw_seen = std::max<int64_t>(1, __atomic_load_n(&m->h_mirror[1], __ATOMIC_RELAXED));       // (high-water mark as last reported: a hint, the kernel grid-strides)
+  const int grid = (int)std::min<int64_t>(std::min<int64_t>(m->capacity, decay_grid), std::max<int64_t>(512, (hw_seen + 7) / 8));
   EsdfArgs ea = m->make_esdf_args();
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
   NVBX_LAUNCH(m, k_decay<false>, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
