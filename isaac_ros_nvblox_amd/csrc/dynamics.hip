@@ -170,8 +170,10 @@ __device__ inline void cc_union(int32_t* label, int32_t a, int32_t b) {
     b = old;                                                    // somebody re-rooted b meanwhile: unite a with that
   }
 }
-__global__ __launch_bounds__(256) void k_cc_init(const uint8_t* mask, int64_t n, int32_t* label, int32_t* size) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { label[i] = mask[i] ? (int32_t)i : -1; size[i] = 0; }
+// The arrays' resting state is "every pixel its own root, both size arrays zero" -- independent of the mask, so it is established once
+// per image size (k_cc_init) and RESTORED by each call's last kernel (k_cc_filter): three launches per call instead of four.
+__global__ __launch_bounds__(256) void k_cc_init(int64_t n, int32_t* label, int32_t* size_a, int32_t* size_b) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { label[i] = (int32_t)i; size_a[i] = 0; size_b[i] = 0; }
 }
 __global__ __launch_bounds__(256) void k_cc_union(const uint8_t* mask, int32_t rows, int32_t cols, int32_t* label) {
   const int64_t n = (int64_t)rows * cols;
@@ -189,11 +191,11 @@ __global__ __launch_bounds__(256) void k_cc_union(const uint8_t* mask, int32_t r
 }
 // flatten (label = root) and count: the lanes of a wavefront that share a root add their number with ONE atomic (a blob's pixels are
 // neighbours in memory: 64 same-address atomics per wavefront would serialise)
-__global__ __launch_bounds__(256) void k_cc_count(int64_t n, int32_t* label, int32_t* size) {
+__global__ __launch_bounds__(256) void k_cc_count(const uint8_t* mask, int64_t n, int32_t* label, int32_t* size) {
   const int64_t n_pad = (n + 63) & ~(int64_t)63;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += (int64_t)gridDim.x * blockDim.x) {
     int32_t l = -1;
-    if (i < n) { l = label[i]; if (l >= 0) { l = cc_find(label, l); label[i] = l; } }
+    if (i < n && mask[i]) { l = cc_find(label, (int32_t)i); label[i] = l; }
     u64 todo = __ballot(l >= 0);
     while (todo) {
       const int leader = __ffsll((long long)todo) - 1;
@@ -204,26 +206,36 @@ __global__ __launch_bounds__(256) void k_cc_count(int64_t n, int32_t* label, int
     }
   }
 }
-__global__ __launch_bounds__(256) void k_cc_filter(int64_t n, const int32_t* label, const int32_t* size, int32_t min_size, uint8_t* mask) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { const int32_t l = label[i]; if (l >= 0 && size[l] < min_size) mask[i] = 0; }
+// removes the small blobs and restores the resting state: own label (only this thread reads label[i] here), and the size array of the
+// PREVIOUS call, which nobody reads in this one (this call's is still being read by the neighbours' threads: the next call clears it)
+__global__ __launch_bounds__(256) void k_cc_filter(int64_t n, int32_t* label, const int32_t* size, int32_t* size_prev, int32_t min_size, uint8_t* mask) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (mask[i]) { if (size[label[i]] < min_size) mask[i] = 0; label[i] = (int32_t)i; }
+    size_prev[i] = 0;
+  }
 }
 extern "C" int nvbx_remove_small_components(nvbx_mapper* m, uint8_t* mask_dev, int32_t rows, int32_t cols, int32_t min_size) {
   if (!m || !mask_dev || rows <= 0 || cols <= 0) { set_error("nvbx_remove_small_components: invalid argument"); return NVBX_E_INVALID; }
   NVBX_HIP(hipSetDevice(m->device));
   const int64_t n = (int64_t)rows * cols;
-  if (2 * n + 16 > m->cc_scratch_elems) {
+  if (3 * n + 16 > m->cc_scratch_elems) {
     NVBX_HIP(hipStreamSynchronize(m->stream));
     if (m->cc_scratch) NVBX_HIP(hipFree(m->cc_scratch));
-    m->cc_scratch = nullptr; m->cc_scratch_elems = 0;
-    NVBX_HIP(hipMalloc(&m->cc_scratch, (size_t)(2 * n + 16) * 4));
-    m->cc_scratch_elems = 2 * n + 16;
+    m->cc_scratch = nullptr; m->cc_scratch_elems = 0; m->cc_ready_n = 0;
+    NVBX_HIP(hipMalloc(&m->cc_scratch, (size_t)(3 * n + 16) * 4));
+    m->cc_scratch_elems = 3 * n + 16;
   }
-  int32_t* label = m->cc_scratch; int32_t* size = label + n;
+  int32_t* label = m->cc_scratch;
   const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
-  NVBX_LAUNCH(m, k_cc_init, dim3(grid), dim3(256), (const uint8_t*)mask_dev, n, label, size);
+  if (m->cc_ready_n != n) {            // first call / another image size: establish the resting state
+    NVBX_LAUNCH(m, k_cc_init, dim3(grid), dim3(256), n, label, label + n, label + 2 * n);
+    m->cc_ready_n = n; m->cc_parity = 0;
+  }
+  int32_t* size = label + n * (1 + m->cc_parity); int32_t* size_prev = label + n * (2 - m->cc_parity);
+  m->cc_parity ^= 1;
   NVBX_LAUNCH(m, k_cc_union, dim3(grid), dim3(256), (const uint8_t*)mask_dev, rows, cols, label);
-  NVBX_LAUNCH(m, k_cc_count, dim3(grid), dim3(256), n, label, size);
-  NVBX_LAUNCH(m, k_cc_filter, dim3(grid), dim3(256), n, (const int32_t*)label, (const int32_t*)size, min_size, mask_dev);
+  NVBX_LAUNCH(m, k_cc_count, dim3(grid), dim3(256), (const uint8_t*)mask_dev, n, label, size);
+  NVBX_LAUNCH(m, k_cc_filter, dim3(grid), dim3(256), n, label, (const int32_t*)size, size_prev, min_size, mask_dev);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;                  // asynchronous on the mapper's stream, like the other image operations
 }
