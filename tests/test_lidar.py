@@ -110,6 +110,44 @@ def test_lidar_parity_small(oracle_mod, hip_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lidar,tilt", [((256, 48, 0.1, -math.radians(55.0), math.radians(50.0)), (0.0, 0.0)),          # wide vertical FOV: |sin el| > 0.5
+                                        ((256, 48, 0.1, -math.radians(55.0), math.radians(50.0)), (11.0, -17.0)),      # ... on a rolled / pitched sensor
+                                        (SMALL_LIDAR, (23.0, 9.0))])
+def test_lidar_parity_wide_fov_and_tilted_sensor(oracle_mod, hip_lib, lidar, tilt):
+    """The elevation's polynomial covers |sin el| <= 0.5 and falls back to atan2 beyond (csrc/nvbx_lidar_math.h); the integrators add a
+    rotated voxel offset to a per-block origin (nvbx_internal.h sensor_block_origin).  Both on inputs the upright 15-degree sensor of the
+    other tests never produces: beams up to 55 degrees, a sensor frame rotated about all three axes."""
+    from isaac_ros_nvblox_amd import mapper as M
+    kw = dict(voxel_size=0.1, lidar_max_integration_distance_m=25.0, raycast_subsampling_factor=2)
+    pg = M.default_params(**kw); po = H.copy_params(pg, oracle_mod.OrcParams)
+    g = M.Mapper(pg, block_capacity=1 << 16); o = oracle_mod.OracleMap(po)
+    sc = S.LidarScene(n_boxes=12, extent=40.0)
+    roll, pitch = math.radians(tilt[0]), math.radians(tilt[1])
+    Rx = np.array([[1, 0, 0], [0, math.cos(roll), -math.sin(roll)], [0, math.sin(roll), math.cos(roll)]])
+    Ry = np.array([[math.cos(pitch), 0, math.sin(pitch)], [0, 1, 0], [-math.sin(pitch), 0, math.cos(pitch)]])
+    n_steep = 0
+    for i in range(3):
+        T = S.lidar_pose(i * 7).astype(np.float64)
+        T[:3, :3] = T[:3, :3] @ Ry @ Rx
+        T = T.astype(np.float32)
+        img = S.render_lidar(sc, T, lidar, max_range=40.0)
+        n_steep += int((img[:6] > 0).sum() + (img[-6:] > 0).sum())
+        g.integrate_lidar_depth(img, T, lidar); o.integrate_lidar_depth(img, T, lidar)
+        assert H.idx_set(g.last_view()) == H.idx_set(o.last_view())
+    assert n_steep > 100                                                                  # the steepest beams do hit something
+    ig = g.block_indices(M.LAYER_TSDF); io = o.block_indices(oracle_mod.L_TSDF)
+    assert np.array_equal(ig, io) and len(io) > 500
+    bg, found = g.get_blocks(M.LAYER_TSDF, ig)
+    assert found.all()
+    nobs = 0
+    for k, idx in enumerate(io):
+        b = o.get_block(oracle_mod.L_TSDF, idx)
+        assert np.array_equal(bg[k]["distance"], b["distance"]) and np.array_equal(bg[k]["weight"], b["weight"]), idx     # bit for bit
+        nobs += int((b["weight"] > 0).sum())
+    assert nobs > 50000
+
+
+@pytest.mark.gpu
 def test_lidar_full_config_properties(hip_lib):
     """BASELINE.json configs[4] shape: 1024 x 64 beams, 0.10 m voxels, 200 m range (too slow for the scalar oracle at full
     size, so size-independent properties): integrating the same scan twice leaves the block set unchanged and doubles
