@@ -71,9 +71,17 @@ struct LidarSensor {
 #define NVBX_LIDAR_SEG 16
 #endif
   static constexpr int kTileRows = NVBX_LIDAR_TR, kTileCols = NVBX_LIDAR_TC;      // (tuning knobs: tools/lidar_tile_sweep.sh)
-  static constexpr int kSetSize = 1024, kFlushRounds = 6; // early flush at 256 keys: 6 x 64 >= 256 + one step's additions
+#ifndef NVBX_LIDAR_FR
+#define NVBX_LIDAR_FR 6
+#define NVBX_LIDAR_PD 4
+#endif
+#ifndef NVBX_LIDAR_SET
+#define NVBX_LIDAR_SET 1024
+#define NVBX_LIDAR_FLUSH 256
+#endif
+  static constexpr int kSetSize = NVBX_LIDAR_SET, kFlushRounds = NVBX_LIDAR_FR; // early flush at 256 keys: 6 x 64 >= 256 + one step's additions
   static constexpr int kSegments = NVBX_LIDAR_SEG;
-  static constexpr int kProbeDepth = 4;
+  static constexpr int kProbeDepth = NVBX_LIDAR_PD;
   static constexpr int kThreads = 64;
   nvbx_lidar_model l;
   const float2* el_tab; const float2* az_tab;
@@ -127,7 +135,7 @@ struct LidarSensor {
   }
 };
 
-constexpr int LSET_FLUSH = 256;     // early-flush threshold (long rays): keeps the 1024-entry set <= ~30 % full, probes short
+constexpr int LSET_FLUSH = NVBX_LIDAR_FLUSH;     // early-flush threshold (long rays): keeps the 1024-entry set <= ~30 % full, probes short
 
 
 // Claim an entry's stamp word for (frame, camera bit); `cur` = the word as last seen.  True iff THIS call moved the entry to the
