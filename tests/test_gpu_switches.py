@@ -248,3 +248,28 @@ def test_depth_sampling_and_site_rule_switches(oracle_mod, hip_lib, kw):
     n, _ = compare_layer(M, g, o, M.LAYER_ESDF, oracle_mod.L_ESDF,
                          fields_exact=("squared_distance_vox", "parent_direction", "is_inside", "observed", "is_site"))
     assert n > 10
+
+
+def test_plain_instantiation_equals_the_general_kernel(oracle_mod, hip_lib):
+    """k_integrate_tsdf has a compile-time folded instantiation for the default configuration (frame_is_plain, nvbx_internal.h).  An
+    invalid-depth decay factor of exactly 1.0 selects the general kernel without changing any value (weight * 1.0), so the two maps must be
+    bit-identical -- camera (with holes in the depth image, so the decay branch really runs) and LiDAR."""
+    from isaac_ros_nvblox_amd import mapper as M
+    gp = M.Mapper(M.default_params(), block_capacity=1 << 14)
+    gg = M.Mapper(M.default_params(invalid_depth_decay_factor=1.0), block_capacity=1 << 14)
+    for k, (d, rgb, T) in enumerate(H.frames(4, H.SMALL_CAM, color=False, stride=9)):
+        d = d.copy(); d[10 + 5 * k:30 + 5 * k, 20:60] = 0.0
+        gp.integrate_depth(d, T, H.SMALL_CAM); gg.integrate_depth(d, T, H.SMALL_CAM)
+    a, b = tsdf_map(gp, M), tsdf_map(gg, M)
+    assert len(a) > 100 and not maps_differ(a, b)
+    lidar = (256, 16, 0.1, -np.deg2rad(15.0), np.deg2rad(15.0))
+    kw = dict(voxel_size=0.1, lidar_max_integration_distance_m=30.0, raycast_subsampling_factor=2)
+    gp = M.Mapper(M.default_params(**kw), block_capacity=1 << 16)
+    gg = M.Mapper(M.default_params(invalid_depth_decay_factor=1.0, **kw), block_capacity=1 << 16)
+    sc = S.LidarScene(n_boxes=12, extent=40.0)
+    for i in range(2):
+        T = S.lidar_pose(i * 7)
+        img = S.render_lidar(sc, T, lidar, max_range=40.0)
+        gp.integrate_lidar_depth(img, T, lidar); gg.integrate_lidar_depth(img, T, lidar)
+    a, b = tsdf_map(gp, M), tsdf_map(gg, M)
+    assert len(a) > 1000 and not maps_differ(a, b)
