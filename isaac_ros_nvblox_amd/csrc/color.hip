@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, FrameSetC<Pix, 
     if (tid < 6 * NB) (&s_out[0][0])[tid] = 0;
     __syncthreads();
     if (tid < 8 * ncam) {   // frustum: count corners outside each plane, 8 lanes per camera
-      const int c = tid >> 3, q = tid & 7;
+      const int c = NB == 1 ? 0 : (tid >> 3), q = tid & 7;      // (one camera: a constant index -- a per-lane index into the argument block is a vector load from memory)
       const Frame& f = fs.f[c];
       float pc[3];
       apply_rt(f.R_CL, f.t_CL, (float)(bx + (q & 1)) * f.block_size, (float)(by + ((q >> 1) & 1)) * f.block_size,
