@@ -1,7 +1,7 @@
 // nvblox/datasets/image_loader.h -- the image decoding the dataset loaders need: PNG (8 / 16 bit, grey / RGB / RGBA, non-interlaced)
-// through zlib, and binary PGM / PPM.  [U] the core's datasets/image_loader.h uses stb_image; the formats the three supported
-// datasets ship depth in are all 16-bit PNG.  JPEG (Replica / Redwood colour) is NOT decoded: those loaders then run depth-only
-// unless a PNG / PPM of the same stem exists.  Host-only, header-only; link with -lz.
+// through zlib, binary PGM / PPM, and baseline JPEG (jpeg_decoder.h: the colour frames of Replica and Redwood).  [U] the core's
+// datasets/image_loader.h uses stb_image; the formats the three supported datasets ship depth in are all 16-bit PNG.  Progressive
+// JPEGs are refused -- a loader then runs that frame depth-only.  Host-only, header-only; link with -lz.
 #pragma once
 #include <zlib.h>
 #include <cstdint>
@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 #include "nvblox/sensors/image.h"
+#include "nvblox/datasets/jpeg_decoder.h"
 
 namespace nvblox {
 namespace datasets {
@@ -103,7 +104,12 @@ inline bool decodePnm(const std::vector<uint8_t>& file, DecodedImage* img) {
 inline bool decode(const std::string& path, DecodedImage* img) {
   std::vector<uint8_t> file;
   if (!readFile(path, &file)) return false;
-  return decodePng(file, img) || decodePnm(file, img);
+  if (decodePng(file, img) || decodePnm(file, img)) return true;
+  std::vector<uint8_t> rgb;
+  if (!decodeJpeg(file, &img->rows, &img->cols, &rgb)) return false;
+  img->channels = 3; img->bit_depth = 8;
+  img->data.assign(rgb.begin(), rgb.end());
+  return true;
 }
 
 }  // namespace image_io

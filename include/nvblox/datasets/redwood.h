@@ -2,7 +2,7 @@
 // [U] The Redwood indoor RGB-D layout the core's loader reads: <base>/depth/%05d.png (16-bit, millimetres; 1-based numbering),
 // <base>/image/%05d.jpg, <base>/pose_*/*.log trajectory: per frame one metadata line (three integers) followed by a 4x4 row-major
 // camera-to-world matrix; intrinsics = the PrimeSense default fu = fv = 525, cu = 319.5, cv = 239.5 at 640x480.
-// Colour: JPEG is not decoded (image_loader.h) -- image/%05d.png / .ppm is used if present, else depth-only.
+// Colour: image/%05d.jpg (baseline JPEG, datasets/jpeg_decoder.h), or a .png / .ppm of the same stem; else depth-only.
 #pragma once
 #include <dirent.h>
 #include <cmath>

@@ -2,8 +2,8 @@
 // [U] The Replica release the core's loader reads (the NICE-SLAM rendering of Replica): <base>/traj.txt = one row-major 4x4
 // camera-to-world matrix per line; <base>/results/depth%06d.png = 16-bit depth, metres = raw / scale; <base>/results/frame%06d.jpg
 // = colour; <base>/../cam_params.json (or <base>/cam_params.json) = {"camera": {"w","h","fx","fy","cx","cy","scale"}}.
-// Colour: JPEG is not decoded here (image_loader.h) -- frame%06d.png / .ppm of the same stem is used if present, else the
-// fuser runs depth-only.
+// Colour: frame%06d.jpg (baseline JPEG, datasets/jpeg_decoder.h), or a .png / .ppm of the same stem; a frame whose colour does not decode
+// (a progressive JPEG) is integrated depth-only.
 #pragma once
 #include <cstdio>
 #include <fstream>
@@ -28,10 +28,10 @@ inline bool jsonNumber(const std::string& text, const std::string& key, double* 
   if (c == std::string::npos) return false;
   return std::sscanf(text.c_str() + c + 1, " %lf", out) == 1;
 }
-// colour frame of stem `stem` (no extension): PNG, then PPM; false if only a JPEG (or nothing) exists
+// colour frame of stem `stem` (no extension): JPEG (what the datasets ship), PNG, then PPM; false if none exists or decodes
 inline bool loadColorOfStem(const std::string& stem, ColorImage* color, const CudaStream& stream, std::vector<Color>* scratch) {
-  for (const char* ext : {".png", ".ppm"})
-    if (fileExists(stem + ext)) return load8BitColorImage(stem + ext, color, stream, scratch);
+  for (const char* ext : {".jpg", ".jpeg", ".png", ".ppm"})
+    if (fileExists(stem + ext) && load8BitColorImage(stem + ext, color, stream, scratch)) return true;
   return false;
 }
 }  // namespace internal
@@ -81,7 +81,7 @@ class DataLoader : public RgbdDataLoaderInterface {
     if (T_L_C_ptr) *T_L_C_ptr = poses_[(size_t)i];
     if (color_camera_ptr) *color_camera_ptr = camera_;
     if (color_frame_ptr && !internal::loadColorOfStem(base_path_ + "/results/" + internal::numbered("frame%06d", i), color_frame_ptr, *cuda_stream_, &color_scratch_))
-      color_frame_ptr->resize(0, 0);                       // JPEG only / no colour: depth-only frame
+      color_frame_ptr->resize(0, 0);                       // no colour image that decodes (e.g. a progressive JPEG): depth-only frame
     for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) if (!std::isfinite((*T_L_D_ptr)(r, c))) return DataLoadResult::kBadFrame;
     return DataLoadResult::kSuccess;
   }

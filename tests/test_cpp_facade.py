@@ -248,6 +248,15 @@ def write_png(path, arr):
         f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
+def write_color(stem, rgb):
+    """Replica / Redwood colour frames are JPEGs: written with PIL where it is installed (else PNG, which the loaders also accept)."""
+    try:
+        from PIL import Image
+    except ImportError:
+        return write_png(stem + ".png", rgb)
+    Image.fromarray(np.ascontiguousarray(rgb)).save(stem + ".jpg", quality=92)
+
+
 def write_dataset(kind, root, frames, cam):
     """The on-disk layouts the three loaders read (include/nvblox/datasets/*.h); returns the depth images as the loader will see them."""
     os.makedirs(root, exist_ok=True)
@@ -272,7 +281,7 @@ def write_dataset(kind, root, frames, cam):
         for i, (d, rgb, T) in enumerate(frames):
             raw = np.round(d * 6553.5).astype(np.uint16)
             write_png(os.path.join(root, "results", "depth%06d.png" % i), raw)
-            write_png(os.path.join(root, "results", "frame%06d.png" % i), rgb)
+            write_color(os.path.join(root, "results", "frame%06d" % i), rgb)          # frame%06d.jpg, as the dataset ships it
             seen.append((raw.astype(np.float32) * (np.float32(1.0) / np.float32(6553.5))).astype(np.float32))
     else:   # redwood: 1-based numbering, .log trajectory
         os.makedirs(os.path.join(root, "depth")); os.makedirs(os.path.join(root, "image"))
@@ -284,7 +293,7 @@ def write_dataset(kind, root, frames, cam):
         for i, (d, rgb, T) in enumerate(frames):
             mm = np.round(d * 1000.0).astype(np.uint16)
             write_png(os.path.join(root, "depth", "%05d.png" % (i + 1)), mm)
-            write_png(os.path.join(root, "image", "%05d.png" % (i + 1)), rgb)
+            write_color(os.path.join(root, "image", "%05d" % (i + 1)), rgb)
             seen.append((mm.astype(np.float32) * np.float32(1.0 / 1000.0)).astype(np.float32))
     return seen
 
@@ -312,6 +321,42 @@ def test_png_round_trip_through_the_dataset_image_loader(tmp_path):
         assert out.returncode == 0
         r, c, k, b, s = (int(v) for v in out.stdout.split())
         assert (r, c, k, b) == (a.shape[0], a.shape[1], ch, bd) and s == int(a.astype(np.uint64).sum())
+
+
+def test_jpeg_decoder_of_the_dataset_loaders_against_libjpeg(tmp_path):
+    """include/nvblox/datasets/jpeg_decoder.h (baseline JPEG, written from the standard) against PIL's libjpeg on what the datasets hold:
+    4:2:0 / 4:2:2 / 4:4:4 colour at several qualities, optimised Huffman tables, restart intervals, greyscale, odd sizes; progressive
+    files are refused.  Decoders may differ by rounding in the IDCT / colour conversion / chroma upsampling: mean < 0.6, 99 % within 3."""
+    Image = pytest.importorskip("PIL.Image")
+    subprocess.check_call(["make", "-C", CPP, "jpeg_check"], stdout=subprocess.DEVNULL)
+    exe = os.path.join(CPP, "jpeg_check")
+    rng = np.random.default_rng(3)
+
+    def scene(h, w):
+        y, x = np.mgrid[0:h, 0:w]
+        img = np.stack([127 + 100 * np.sin(x / 17.0) * np.cos(y / 23.0), 127 + 90 * np.cos(x / 9.0 + y / 31.0), (x * 3 + y * 2) % 256], -1).astype(np.float64)
+        img[h // 4:h // 2, w // 3:w // 2] = [250, 20, 30]; img[h // 2:, :w // 5] = [10, 200, 240]
+        return np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+
+    cases = [((97, 131), dict(quality=90, subsampling=2)), ((120, 160), dict(quality=75, subsampling=0)), ((64, 200), dict(quality=95, subsampling=1)),
+             ((480, 640), dict(quality=85, subsampling=2)), ((50, 70), dict(quality=60, subsampling=2, optimize=True)),
+             ((81, 93), dict(quality=90, subsampling=2, restart_marker_blocks=3)), ((8, 8), dict(quality=90)), ((1, 17), dict(quality=90))]
+    for (h, w), kw in cases:
+        jpg, ppm = str(tmp_path / "t.jpg"), str(tmp_path / "t.ppm")
+        Image.fromarray(scene(h, w)).save(jpg, **kw)
+        assert subprocess.call([exe, jpg, ppm]) == 0, kw
+        ref = np.asarray(Image.open(jpg).convert("RGB")).astype(int); got = np.asarray(Image.open(ppm)).astype(int)
+        assert ref.shape == got.shape == (h, w, 3)
+        d = np.abs(ref - got)
+        assert d.mean() < 0.6 and np.percentile(d, 99) <= 3, (kw, d.mean(), d.max())
+    Image.fromarray(scene(60, 80)).convert("L").save(str(tmp_path / "g.jpg"), quality=90)
+    assert subprocess.call([exe, str(tmp_path / "g.jpg"), str(tmp_path / "g.ppm")]) == 0
+    ref = np.asarray(Image.open(str(tmp_path / "g.jpg")).convert("RGB")).astype(int); got = np.asarray(Image.open(str(tmp_path / "g.ppm"))).astype(int)
+    assert np.abs(ref - got).max() <= 1
+    Image.fromarray(scene(60, 80)).save(str(tmp_path / "p.jpg"), quality=90, progressive=True)
+    assert subprocess.call([exe, str(tmp_path / "p.jpg"), str(tmp_path / "p.ppm")]) == 2           # refused, not mis-decoded
+    (tmp_path / "trunc.jpg").write_bytes((tmp_path / "t.jpg").read_bytes()[:40])
+    assert subprocess.call([exe, str(tmp_path / "trunc.jpg"), str(tmp_path / "x.ppm")]) == 2
 
 
 @pytest.mark.gpu
