@@ -142,7 +142,13 @@ def kernel_table(prof, counts, ms_per_step, n_steps, bytes_fn, pmc, exclude_from
 
 def roofline_of(kern, ms_per_step, ev_overhead_us, empty_pair_us, note, skip=("k_mesh",)):
     hot = [k for k in kern if not k.startswith(skip) and kern[k]["algorithmic_bytes"] > 0]
-    longest = max(hot, key=lambda k: kern[k]["avg_us"] * kern[k]["launches_per_step"])
+    # the longest kernel of the step by time.  The camera frame has three launches within half a microsecond of each other (view marking,
+    # sphere tracing, colour), less than the event timing resolves run to run: kernels within 7 % of the longest count as tied and the tie
+    # goes to the one that moves the most algorithmic bytes (all of them are listed under `longest_tied`, every kernel under `kernels`)
+    t_of = lambda k: kern[k]["avg_us"] * kern[k]["launches_per_step"]
+    t_max = max(t_of(k) for k in hot)
+    tied = sorted((k for k in hot if t_of(k) >= 0.93 * t_max), key=t_of, reverse=True)
+    longest = max(tied, key=lambda k: kern[k]["algorithmic_bytes"] * kern[k]["launches_per_step"])
     most = max(hot, key=lambda k: kern[k]["algorithmic_bytes"] * kern[k]["launches_per_step"])
     frame_bytes = sum(kern[k]["algorithmic_bytes"] * kern[k]["launches_per_step"] for k in hot)
     k = kern[longest]
@@ -150,6 +156,7 @@ def roofline_of(kern, ms_per_step, ev_overhead_us, empty_pair_us, note, skip=("k
             "frac": round(k["achieved_GBps"] / HBM_PEAK_GBS, 5), "traffic": k["hbm_traffic_bytes"],
             "algorithmic_bytes_per_launch": int(k["algorithmic_bytes"]), "avg_launch_us": round(k["avg_us"], 3),
             "launches_per_step": round(k["launches_per_step"], 2),
+            "longest_tied": {t: round(kern[t]["avg_us"], 3) for t in tied},
             "event_pair_overhead_us": round(ev_overhead_us, 3), "empty_event_pair_us": round(empty_pair_us, 3),
             "step": {"algorithmic_bytes": int(frame_bytes), "achieved": round(frame_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                      "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
