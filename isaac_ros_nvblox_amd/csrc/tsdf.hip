@@ -558,8 +558,7 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   // a held-back EDT rides in this launch (camera: 256-thread workgroups); the LiDAR launch is 64 threads wide, so flush first
   int edt_wg = 0; EsdfArgs ea = m->edt_args;
   if (m->edt_pending) {
-    static const int edt_riders = getenv("NVBX_EDT_RIDERS") ? atoi(getenv("NVBX_EDT_RIDERS")) : 256;     // (a multiple of 8; env: tuning)
-    if (Sensor::kThreads == 256) { edt_wg = edt_riders; m->edt_pending = false; }
+    if (Sensor::kThreads == 256) { edt_wg = 256; m->edt_pending = false; }        // (256 .. 1024 riders measured: no difference, profiles/r02x_kernel_isolation.txt)
     else if (m->flush_edt()) return NVBX_E_DEVICE;
   }
   NVBX_LAUNCH(m, (k_mark_view<Img, Sensor, NB>), dim3(tiles + edt_wg), dim3(Sensor::kThreads), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
