@@ -71,20 +71,25 @@ __device__ inline void edge_decode(int eid, int* li, int* lj, int* axis, int* lx
 // such blocks after its eight hash probes, before touching a voxel.  (The exact per-slot band flag F_BAND would do the same for
 // camera-built maps, but LiDAR integration leaves it stale; the pre-pass is exact for every map and costs ~0.2 ms per 10^5 blocks.)
 __global__ __launch_bounds__(512) void k_mesh_prepass(DMap m, float min_weight, uint8_t* neg_any) {
+  // 16 bytes (two voxels) per lane and load: a 512-thread workgroup covers two blocks per load instruction, PB of them in flight.
+  // No flag test: the TSDF pool of a slot without F_TSDF is all-zero -- weight 0 reads as "unobserved" -- and a flag load in front of
+  // every voxel load made each iteration two dependent round trips.
   constexpr int PB = 8;
   const int32_t hw = m.counters[C_HIGH_WATER];
-  const int tid = threadIdx.x;
-  for (int32_t base = blockIdx.x * PB; base < hw; base += gridDim.x * PB) {
-    float2 tv[PB];
+  const int tid = threadIdx.x, half = tid >> 8, q = tid & 255;
+  const float4* pool = reinterpret_cast<const float4*>(m.tsdf);
+  for (int32_t base = blockIdx.x * (2 * PB); base < hw; base += gridDim.x * (2 * PB)) {
+    float4 tv[PB];
 #pragma unroll
     for (int j = 0; j < PB; j++) {
-      const int32_t slot = base + j;
-      const bool act = slot < hw && (m.slot_flags[slot < hw ? slot : 0] & F_TSDF);
-      tv[j] = act ? m.tsdf[(size_t)slot * 512 + tid] : make_float2(0.0f, 0.0f);
+      const int32_t slot = base + 2 * j + half;
+      tv[j] = slot < hw ? pool[(size_t)slot * 256 + q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 #pragma unroll
-    for (int j = 0; j < PB; j++)
-      if (__ballot(tv[j].y >= min_weight && tv[j].x < 0.0f) != 0ull && (tid & 63) == 0) neg_any[base + j] = 1;
+    for (int j = 0; j < PB; j++) {
+      const bool neg = (tv[j].y >= min_weight && tv[j].x < 0.0f) || (tv[j].w >= min_weight && tv[j].z < 0.0f);
+      if (__ballot(neg) != 0ull && (tid & 63) == 0) neg_any[base + 2 * j + half] = 1;       // (only reached with slot < hw: zeros are never negative)
+    }
   }
 }
 
@@ -341,7 +346,7 @@ extern "C" int nvbx_update_color_mesh(nvbx_mapper* m, int32_t update_full_layer)
   const uint8_t* neg_any = nullptr;
   if (a.full) {            // one byte per slot in the export scratch (capacity x 12 bytes)
     NVBX_HIP(hipMemsetAsync(m->export_idx, 0, (size_t)m->capacity, m->stream));
-    NVBX_LAUNCH(m, k_mesh_prepass, dim3((unsigned)std::min<int64_t>((m->capacity + 7) / 8, 2048)), dim3(512), m->d, a.min_weight, (uint8_t*)m->export_idx);
+    NVBX_LAUNCH(m, k_mesh_prepass, dim3((unsigned)std::min<int64_t>((m->capacity + 15) / 16, 2048)), dim3(512), m->d, a.min_weight, (uint8_t*)m->export_idx);
     neg_any = (const uint8_t*)m->export_idx;
   }
   NVBX_LAUNCH(m, k_mesh, dim3(grid), dim3(512), m->d, a, m->mesh_vert, m->mesh_nrm, (uint32_t*)m->mesh_col,
