@@ -23,123 +23,136 @@ __device__ inline void free_slot(DMap& m, uint32_t slot) {   // one thread
 // A block whose weights all fall below the threshold is deallocated.  If it lies in the ESDF z band and its column already has
 // an ESDF block, that column is flagged for a re-mark (F_ESDF_REMARK) and put on the ESDF work list -- the flag lives on the
 // ESDF slot, which survives, not on the TSDF slot, which may be freed and recycled before the update runs.
-// HBM-streaming form: DB blocks per workgroup iteration (DB independent 8-B loads per thread in flight), the per-block
-// bookkeeping (dirty flags, work lists, deallocation) done by DB lanes in parallel, and work-list entries collected in LDS and
-// appended in batches -- one returning atomic per ~60 blocks instead of two per block on eight counters (146 k same-address
-// atomics serialise at ~12 ns each; a returning atomic in every iteration stalls the whole workgroup ~1 us).
-constexpr int DB = 8, DQ = 64;
-struct DecayQueues { int32_t q[3][DQ]; int n[3]; int32_t base[3]; };     // 0: ESDF-dirty list, 1: mesh-dirty list, 2: deallocated blocks
-__device__ inline void decay_flush(const DMap& m, DecayQueues* dq, const int32_t lists[2], int32_t* cleared_idx, int tid) {   // whole workgroup, between barriers
-  if (tid < 2 && dq->n[tid] > 0) dq->base[tid] = atomicAdd(shc_at(m, lists[tid], my_shard(), 0), dq->n[tid]);
-  if (tid == 2 && dq->n[2] > 0) dq->base[2] = atomicAdd(&m.counters[C_CLEARED], dq->n[2]);
-  __syncthreads();
-  const int l = tid >> 6, k = tid & 63;               // wave 0 writes list 0, wave 1 list 1, wave 2 the cleared-block indices
-  if (l < 2 && k < dq->n[l]) {
-    const int32_t p = dq->base[l] + k;
-    if (p < (int32_t)m.capacity) m.lists[((size_t)lists[l] * NSH + my_shard()) * m.capacity + p] = dq->q[l][k];
+//
+// HBM-streaming form, no barriers and no LDS: ONE WAVEFRONT PER BLOCK.  A lane holds eight voxels of its block (register r = the
+// x = r slab: eight 512-byte loads per wavefront in flight), so "does any voxel survive" is a ballot and the eight band bits of the
+// block come out of the same registers.  The per-block bookkeeping (dirty flags, work lists, deallocation) is taken 64 blocks at a
+// time: lane j fetches the flags (and the exclusion stamp) of the wavefront's j-th next block before the voxel loop and keeps that
+// block's books after it -- the returning flag atomics of 64 blocks are one round trip, and every work list gets ONE
+// wave-aggregated reservation per 64 blocks.  (Steady state on the 146 k-block map: 235 us = 5.1 TB/s; the workgroup-synchronised form
+// before it 249 us; a bare read-modify-write of the same 1.2 GB in this access pattern 206 us -- tools/stream_ceiling.hip)
+__device__ inline void wave_list_append(const DMap& m, int32_t list, bool push, int32_t v, int lane) {      // whole wavefront
+  const u64 mask = __ballot(push);
+  if (!mask) return;
+  const int sh = my_shard();
+  int32_t base = 0;
+  const int leader = __ffsll((long long)mask) - 1;
+  if (lane == leader) base = atomicAdd(shc_at(m, list, sh, 0), (int32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  if (push) {
+    const int32_t p = base + (int32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (p < (int32_t)m.capacity) m.lists[((size_t)list * NSH + sh) * m.capacity + p] = v;
   }
-  if (l == 2 && k < dq->n[2]) {
-    const int32_t p = dq->base[2] + k, s = dq->q[2][k];
-    if (p < (int32_t)m.capacity) { cleared_idx[3 * p] = m.slot_index[3 * s]; cleared_idx[3 * p + 1] = m.slot_index[3 * s + 1]; cleared_idx[3 * p + 2] = m.slot_index[3 * s + 2]; }
-  }
-  __syncthreads();
-  if (tid < 3) dq->n[tid] = 0;
-  __syncthreads();
 }
 // OCC = false: TSDF decay (weight *= factor; a block lives while any weight >= thresh).  OCC = true: occupancy decay (`factor` /
 // `thresh` carry the log-odds steps of the free / occupied regions; every value moves towards 0 and stops there; a block lives
 // while any value != 0) -- [U] OccupancyDecayIntegrator, Mapper::decayOccupancyAllVoxels (nvblox_node.cpp:925-929).
-// (8 waves per SIMD asked for explicitly -- ~100 SGPRs would cost the eighth -- and a grid of several resident rounds: 368 -> 326 us on the
-// 146 k-block map, tools/decay_grid_sweep.sh)
 template <bool OCC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, uint32_t exclude_mask, int32_t mesh_list,
                                                int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc, int32_t* cleared_idx) {
-  __shared__ int s_alive[2][DB];                         // by iteration parity: no barrier between the books of one iteration and the loads of the next
-  __shared__ DecayQueues dq;
   const int32_t hw = m.counters[C_HIGH_WATER];
-  const int tid = threadIdx.x;
-  const int32_t lists[2] = {S_LIST_ESDF_DIRTY, mesh_list};
-  if (tid < 3) dq.n[tid] = 0;
-  uint32_t nflags[DB];                                   // flags of the NEXT iteration's blocks, fetched one iteration ahead
-#pragma unroll
-  for (int j = 0; j < DB; j++) { const int32_t slot = (int32_t)blockIdx.x * DB + j; nflags[j] = slot < hw ? m.slot_flags[slot] : 0u; }
-  int par = 0;
-  for (int32_t base = blockIdx.x * DB; base < hw; base += gridDim.x * DB, par ^= 1) {       // (uniform loop: every thread sees the same `hw`)
-    uint32_t flags[DB]; bool act[DB];
-#pragma unroll
-    for (int j = 0; j < DB; j++) { flags[j] = nflags[j]; act[j] = (flags[j] & F_TSDF) != 0; }
-#pragma unroll
-    for (int j = 0; j < DB; j++) { const int32_t slot = base + (int32_t)gridDim.x * DB + j; nflags[j] = slot < hw ? m.slot_flags[slot] : 0u; }
-    if (exclude_stamp) {
-      uint32_t ent[DB];
-#pragma unroll
-      for (int j = 0; j < DB; j++) ent[j] = act[j] ? m.slot_entry[base + j] : 0u;
-#pragma unroll
-      for (int j = 0; j < DB; j++) if (act[j]) { const uint32_t st = m.table[ent[j]].stamp; if (stamp_frame(st) == exclude_stamp && (st & exclude_mask)) act[j] = false; }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int32_t stride = (int32_t)gridDim.x * 8;                       // wavefronts in the grid: wavefront g takes slots g, g + stride, ...
+  for (int32_t s0 = (int32_t)blockIdx.x * 8 + (tid >> 6); s0 < hw; s0 += 64 * stride) {
+    // ---- lane j: flags (and exclusion) of this round's j-th block
+    const int32_t mine = s0 + lane * stride;
+    const uint32_t fl = mine < hw ? m.slot_flags[mine] : 0u;
+    bool act = (fl & F_TSDF) != 0;
+    if (exclude_stamp && act) {
+      const uint32_t st = m.table[m.slot_entry[mine]].stamp;
+      if (stamp_frame(st) == exclude_stamp && (st & exclude_mask)) act = false;
     }
-    // this iteration's voxels are requested before the barrier: seven wavefronts stream on while lanes of wavefront 0 still keep
-    // the previous iteration's books (returning atomics)
-    float2 tv[DB];
+    const u64 act_mask = __ballot(act);
+    bool my_alive = false; uint32_t my_band = 0u;
+    // ---- the voxels, one block per iteration
+#pragma unroll 1
+    for (int j = 0; j < 64; j++) {
+      if (!((act_mask >> j) & 1ull)) continue;                         // (uniform)
+      const int32_t slot = s0 + j * stride;
+      const uint32_t bflags = (uint32_t)__builtin_amdgcn_readlane((int)fl, j);
+      float2* vp = &m.tsdf[(size_t)slot * 512 + lane];
+      float2 tv[8];
 #pragma unroll
-    for (int j = 0; j < DB; j++) tv[j] = act[j] ? m.tsdf[(size_t)(base + j) * 512 + tid] : make_float2(0.0f, 0.0f);
-    if (tid < DB) s_alive[par][tid] = 0;
-    __syncthreads();
-    if (dq.n[0] > DQ - 2 * DB || dq.n[1] > DQ - DB || dq.n[2] > DQ - DB) decay_flush(m, &dq, lists, cleared_idx, tid);   // uniform: every push of the previous iteration precedes the barrier above
+      for (int r = 0; r < 8; r++) tv[r] = vp[r * 64];
+      bool live = false;
 #pragma unroll
-    for (int j = 0; j < DB; j++) if (act[j]) {
-      bool live;
-      if (OCC) {
-        float v = tv[j].x;
-        if (v > 0.0f) { v = v + thresh; if (v < 0.0f) v = 0.0f; }
-        else if (v < 0.0f) { v = v + factor; if (v > 0.0f) v = 0.0f; }
-        tv[j] = make_float2(v, 0.0f); live = v != 0.0f;
-      } else {
-        tv[j].y = tv[j].y * factor; live = !(tv[j].y < thresh);
-      }
-      if (__ballot(live) != 0ull && (tid & 63) == 0) s_alive[par][j] = 1;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < DB; j++) if (act[j]) {
-      const int32_t slot = base + j;
-      if (s_alive[par][j]) {
-        m.tsdf[(size_t)slot * 512 + tid] = tv[j];
-        if (!OCC) publish_band(m.slot_flags, (uint32_t)slot, tid, in_band(tv[j].x, tv[j].y, trunc));
-      } else {
-        m.tsdf[(size_t)slot * 512 + tid] = make_float2(0.0f, 0.0f);
-        if (!OCC) {                                      // (occupancy mappers carry neither colour nor freespace)
-          m.color[(size_t)slot * 512 + tid] = make_uint2(0u, 0u);
-          if (flags[j] & F_FREESPACE) m.freespace[(size_t)slot * 512 + tid] = make_int4(0, 0, 0, 0);
+      for (int r = 0; r < 8; r++) {
+        if (OCC) {
+          float v = tv[r].x;
+          if (v > 0.0f) { v = v + thresh; if (v < 0.0f) v = 0.0f; }
+          else if (v < 0.0f) { v = v + factor; if (v > 0.0f) v = 0.0f; }
+          tv[r] = make_float2(v, 0.0f); live = live || v != 0.0f;
+        } else {
+          tv[r].y = tv[r].y * factor; live = live || !(tv[r].y < thresh);
         }
       }
+      const bool alive = __ballot(live) != 0ull;                       // (uniform)
+      uint32_t band = 0u;
+      if (alive) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          vp[r * 64] = tv[r];
+          if (!OCC && __ballot(in_band(tv[r].x, tv[r].y, trunc)) != 0ull) band |= 1u << (F_BAND_SHIFT + r);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) vp[r * 64] = make_float2(0.0f, 0.0f);
+        if (!OCC) {                                        // (occupancy mappers carry neither colour nor freespace)
+          uint2* cp = &m.color[(size_t)slot * 512 + lane];
+#pragma unroll
+          for (int r = 0; r < 8; r++) cp[r * 64] = make_uint2(0u, 0u);
+          if (bflags & F_FREESPACE) {
+            int4* fp = &m.freespace[(size_t)slot * 512 + lane];
+#pragma unroll
+            for (int r = 0; r < 8; r++) fp[r * 64] = make_int4(0, 0, 0, 0);
+          }
+        }
+      }
+      if (lane == j) { my_alive = alive; my_band = band; }
     }
-    if (tid < DB && act[tid]) {                         // lane j keeps the books of block j
-      const int32_t slot = base + tid;
-      const uint32_t fl = flags[tid];
+    // ---- the books, lane j for block j
+    const int32_t slot = mine;
+    bool push_esdf = false, push_esdf2 = false, push_mesh = false, push_cleared = false; int32_t esdf2 = 0;
+    if (act) {
       uint32_t old = F_DIRTY_MESH;                       // (occupancy: no mesh, nothing joins the mesh list)
-      if (s_alive[par][tid]) {
-        const uint32_t o = atomicOr(&m.slot_flags[slot], OCC ? F_DIRTY_ESDF : (F_DIRTY_ESDF | F_DIRTY_MESH));
+      if (my_alive) {
+        if (!OCC) { atomicAnd(&m.slot_flags[slot], ~(F_BAND | F_BAND_STALE)); }      // all eight band bits are rewritten: exact again
+        const uint32_t o = atomicOr(&m.slot_flags[slot], OCC ? F_DIRTY_ESDF : (F_DIRTY_ESDF | F_DIRTY_MESH | my_band));
         if (!OCC) old = o;
-        if (!(o & F_DIRTY_ESDF)) dq.q[0][atomicAdd(&dq.n[0], 1)] = slot;
+        push_esdf = !(o & F_DIRTY_ESDF);
       } else {
         if (!OCC) old = atomicOr(&m.slot_flags[slot], F_DIRTY_MESH);
-        dq.q[2][atomicAdd(&dq.n[2], 1)] = slot;          // Mapper::getClearedBlocks (layer_publishing.cpp:716): the viewer deletes it
+        push_cleared = true;                             // Mapper::getClearedBlocks (layer_publishing.cpp:716): the viewer deletes it
         atomicAnd(&m.slot_flags[slot], ~(F_TSDF | F_COLOR | F_MESH | F_FREESPACE | F_BAND | F_BAND_STALE));
         const int32_t bx = m.slot_index[3 * slot], by = m.slot_index[3 * slot + 1], bz = m.slot_index[3 * slot + 2];
         if (bz >= bz_lo && bz <= bz_hi) {
           const uint32_t es = bz_out == INT32_MIN ? (uint32_t)slot : any_slot(m, bx, by, bz_out);   // 3-D ESDF: the block's own slot (the table is rebuilt after this kernel, not during it)
           if (slot_ok(es) && (m.slot_flags[es] & F_ESDF)) {
             const uint32_t eold = atomicOr(&m.slot_flags[es], F_ESDF_REMARK | F_DIRTY_ESDF);
-            if (!(eold & F_DIRTY_ESDF)) dq.q[0][atomicAdd(&dq.n[0], 1)] = (int32_t)es;
+            if (!(eold & F_DIRTY_ESDF)) { push_esdf2 = true; esdf2 = (int32_t)es; }
           }
         }
         if (!(fl & (F_ESDF | F_ESDF_PENDING))) { atomicAnd(&m.slot_flags[slot], OCC ? ~(F_DIRTY_ESDF | F_DIRTY_MESH) : ~F_DIRTY_ESDF); free_slot(m, (uint32_t)slot); }
       }
-      if (!(old & F_DIRTY_MESH)) dq.q[1][atomicAdd(&dq.n[1], 1)] = slot;
+      push_mesh = !(old & F_DIRTY_MESH);
+    }
+    wave_list_append(m, S_LIST_ESDF_DIRTY, push_esdf, slot, lane);
+    wave_list_append(m, S_LIST_ESDF_DIRTY, push_esdf2, esdf2, lane);
+    wave_list_append(m, mesh_list, push_mesh, slot, lane);
+    {
+      const u64 cm = __ballot(push_cleared);
+      if (cm) {
+        int32_t base = 0;
+        const int leader = __ffsll((long long)cm) - 1;
+        if (lane == leader) base = atomicAdd(&m.counters[C_CLEARED], (int32_t)__popcll(cm));
+        base = __shfl(base, leader);
+        if (push_cleared) {
+          const int32_t p = base + (int32_t)__popcll(cm & ((1ull << lane) - 1ull));
+          if (p < (int32_t)m.capacity) { cleared_idx[3 * p] = m.slot_index[3 * slot]; cleared_idx[3 * p + 1] = m.slot_index[3 * slot + 1]; cleared_idx[3 * p + 2] = m.slot_index[3 * slot + 2]; }
+        }
+      }
     }
   }
-  __syncthreads();
-  decay_flush(m, &dq, lists, cleared_idx, tid);
 }
 
 // `srec`: window record of the next ESDF update.  An ESDF block that is dropped takes its sites with it: the distances of
