@@ -162,6 +162,8 @@ def roofline_of(kern, ms_per_step, ev_overhead_us, empty_pair_us, note, skip=("k
                      "frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "most_bytes_kernel": {"kernel": most, "avg_launch_us": round(kern[most]["avg_us"], 3), "achieved": round(kern[most]["achieved_GBps"], 2),
                                   "frac": round(kern[most]["achieved_GBps"] / HBM_PEAK_GBS, 5), "traffic": kern[most]["hbm_traffic_bytes"]},
+            # context for `peak` (the paper figure): what a bare stream over 8-byte voxels reaches on this GPU, measured once
+            "measured_stream_ceiling": {"read_modify_write_GBps": 5800, "read_GBps": 6450, "source": "tools/stream_ceiling.hip (profiles/r02z_stream_ceiling.txt)"},
             "note": note}
 
 
