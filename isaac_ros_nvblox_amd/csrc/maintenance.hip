@@ -283,8 +283,13 @@ __global__ void k_reinsert(DMap m, const uint32_t* tmp, int32_t bz_out) {
     m.table[h].slot = (uint32_t)s; m.table[h].stamp = tmp[s];
     m.slot_entry[s] = h;
     if ((flags & F_ESDF) && z == bz_out) {       // the slicer's image covers the ESDF blocks of the slice plane
-      atomicMin(&m.counters[C_ESDF_AABB + 0], x); atomicMin(&m.counters[C_ESDF_AABB + 1], y);
-      atomicMax(&m.counters[C_ESDF_AABB + 2], x); atomicMax(&m.counters[C_ESDF_AABB + 3], y);
+      // (an atomic only where the block extends the box as last seen: thousands of ESDF blocks on four addresses serialise otherwise;
+      // a stale read costs an unnecessary atomic, never a missing one)
+      int32_t* bb = &m.counters[C_ESDF_AABB];
+      if (x < __hip_atomic_load(&bb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&bb[0], x);
+      if (y < __hip_atomic_load(&bb[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&bb[1], y);
+      if (x > __hip_atomic_load(&bb[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&bb[2], x);
+      if (y > __hip_atomic_load(&bb[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&bb[3], y);
     }
   }
 }
