@@ -148,6 +148,38 @@ def test_lidar_parity_wide_fov_and_tilted_sensor(oracle_mod, hip_lib, lidar, til
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("thr", [(2.0, 0.5), (0.3, 1.5)])
+def test_lidar_parity_noisy_ranges_with_dropouts(oracle_mod, hip_lib, thr):
+    """Range noise and 3 % missing returns: four-beam neighbourhoods that disagree or have holes fall from the bilinear blend to the
+    nearest-beam rule (LidarSensor::sample, tsdf.hip) for a large share of the voxels -- the branch the clean scenes of the other tests
+    rarely take.  Bit for bit against the oracle, with the thresholds in two positions."""
+    from isaac_ros_nvblox_amd import mapper as M
+    kw = dict(voxel_size=0.1, lidar_max_integration_distance_m=30.0, raycast_subsampling_factor=2,
+              lidar_linear_interpolation_max_allowable_difference_vox=thr[0], lidar_nearest_interpolation_max_allowable_dist_to_ray_vox=thr[1])
+    pg = M.default_params(**kw); po = H.copy_params(pg, oracle_mod.OrcParams)
+    g = M.Mapper(pg, block_capacity=1 << 16); o = oracle_mod.OracleMap(po)
+    sc = S.LidarScene(n_boxes=12, extent=40.0)
+    rng = np.random.default_rng(11)
+    for i in range(3):
+        T = S.lidar_pose(i * 7)
+        img = S.render_lidar(sc, T, SMALL_LIDAR, max_range=40.0)
+        img = np.where(img > 0, img + rng.normal(0.0, 0.03, img.shape).astype(np.float32), 0.0).astype(np.float32)
+        img[rng.random(img.shape) < 0.03] = 0.0
+        g.integrate_lidar_depth(img, T, SMALL_LIDAR); o.integrate_lidar_depth(img, T, SMALL_LIDAR)
+        assert H.idx_set(g.last_view()) == H.idx_set(o.last_view())
+    ig = g.block_indices(M.LAYER_TSDF); io = o.block_indices(oracle_mod.L_TSDF)
+    assert np.array_equal(ig, io) and len(io) > 500
+    bg, found = g.get_blocks(M.LAYER_TSDF, ig)
+    assert found.all()
+    nobs = 0
+    for k, idx in enumerate(io):
+        b = o.get_block(oracle_mod.L_TSDF, idx)
+        assert np.array_equal(bg[k]["distance"], b["distance"]) and np.array_equal(bg[k]["weight"], b["weight"]), idx
+        nobs += int((b["weight"] > 0).sum())
+    assert nobs > 20000
+
+
+@pytest.mark.gpu
 def test_lidar_full_config_properties(hip_lib):
     """BASELINE.json configs[4] shape: 1024 x 64 beams, 0.10 m voxels, 200 m range (too slow for the scalar oracle at full
     size, so size-independent properties): integrating the same scan twice leaves the block set unchanged and doubles
