@@ -196,3 +196,30 @@ def test_oracle_and_product_tables_are_the_same_files():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for n in ("mc_table.inc", "mc_table_r1.inc", "mc_table_r2.inc"):
         assert open(os.path.join(root, "oracle", n)).read() == open(os.path.join(root, "isaac_ros_nvblox_amd", "csrc", n)).read()
+
+
+def test_asin_polynomial_of_the_lidar_model_is_the_fitted_one_and_accurate():
+    """csrc/nvbx_lidar_math.h nvbx_asin_small: its coefficients are the ones tools/fit_asin.py produces (the header is not hand-edited),
+    and evaluated the way the kernel does (float32, fused multiply-adds) they reproduce asin on |s| <= 0.5 to 5e-8."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fit_asin.py")], capture_output=True, text=True, check=True).stdout
+    fitted = [float(v) for v in re.search(r"c0\.\.c4 = \[(.*)\]", out).group(1).split(",")]
+    src = open(os.path.join(root, "isaac_ros_nvblox_amd", "csrc", "nvbx_lidar_math.h")).read()
+    body = src[src.index("NVBX_HD float nvbx_asin_small"):src.index("NVBX_HD float nvbx_asin_small") + 700]
+    in_header = [float(v) for v in re.findall(r"([0-9]\.[0-9]+e-[0-9]+)f", body)]
+    assert len(in_header) == 5
+    # header order: c4, c3, c2, c1, c0 (Horner from the highest power)
+    assert np.allclose(np.float32(in_header[::-1]), np.float32(fitted), rtol=0, atol=0)
+    c = np.float32(fitted)
+    x = np.linspace(-0.5, 0.5, 400001).astype(np.float32)
+    z = x * x
+    fma = lambda a, b, cc: (a.astype(np.float64) * b.astype(np.float64) + np.float64(cc)).astype(np.float32)
+    p = np.full_like(x, c[4])
+    for k in (3, 2, 1, 0):
+        p = fma(p, z, c[k])
+    y = fma(p * z, x, x)
+    assert np.abs(y.astype(np.float64) - np.arcsin(x.astype(np.float64))).max() < 5e-8
