@@ -89,7 +89,7 @@ NVBX_HD float nvbx_lidar_range(const float* p) { return NVBX_SQRT((p[0] * p[0] +
  * ONE reciprocal serves both angles: with (n, d) the azimuth's reduced operands (nvbx_atan_ratio's selection), q = 1 / (r d) gives
  * sin(elevation) = (z d) q and the reduced tangent n / d = (n r) q -- four multiplications for the second IEEE division. */
 NVBX_HD int nvbx_lidar_project(const nvbx_lidar_model* l, const float* p, float r, float* u, float* v) {
-  if (r < l->min_valid_range_m || !(r > 0.0f) || !(r < 1.0e18f)) return 0;
+  if (r < l->min_valid_range_m || !(r > 1.0e-9f) || !(r < 1.0e18f)) return 0;      /* (a point within a nanometre of the sensor has no direction; keeps r d inside NVBX_DIV's range) */
   const float ax = fabsf(p[0]), ay = fabsf(p[1]);
   const int hi = !(ax >= ay);                                   /* second octant: azimuth = pi/2 - atan(ax / ay) */
   const float num = hi ? ax : ay, den = hi ? ay : ax;           /* 0 <= num <= den */
@@ -105,7 +105,7 @@ NVBX_HD int nvbx_lidar_project(const nvbx_lidar_model* l, const float* p, float 
     if (fabsf(s) > 0.5f) el = nvbx_atan2f(p[2], NVBX_SQRT(rho2));
   }
   const float vv = NVBX_FMA(l->max_el - el, l->ppr_el, 0.5f);
-  if (vv < 0.0f || vv >= (float)l->rows) return 0;              /* outside the vertical field of view */
+  if (!(vv >= 0.0f && vv < (float)l->rows)) return 0;           /* outside the vertical field of view (written so that a NaN is outside) */
   const float t = (n * r) * q;
   const float z = t * t;
   float c = NVBX_FMA(8.05374449538e-2f, z, -1.38776856032e-1f);        /* nvbx_atan_ratio's polynomial */
@@ -119,7 +119,7 @@ NVBX_HD int nvbx_lidar_project(const nvbx_lidar_model* l, const float* p, float 
   if (p[1] < 0.0f) az = -az;
   float uu = NVBX_FMA(az + NVBX_PI_F, l->ppr_az, 0.5f);
   if (uu >= (float)l->cols) uu = uu - (float)l->cols;           /* azimuth wrap-around */
-  if (uu < 0.0f) return 0;
+  if (!(uu >= 0.0f && uu < (float)l->cols)) return 0;
   *u = uu; *v = vv;
   return 1;
 }
