@@ -302,3 +302,25 @@ def test_lidar_depth_then_camera_colour_parity(oracle_mod, hip_lib):
     g.integrate_color(frames[2][1], frames[2][2], cam); o.integrate_color(frames[2][1], frames[2][2], cam)
     compare_layer(Mm, g, o, Mm.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
     compare_layer(Mm, g, o, Mm.LAYER_COLOR, oracle_mod.L_COLOR, fields_tol=("weight",), lsb_fields=("r", "g", "b"))
+
+
+@pytest.mark.gpu
+def test_depth_image_from_pointcloud_gpu_parity_with_degenerate_points(oracle_mod, hip_lib):
+    """depthImageFromPointcloud (pointcloud_conversions.cu:118-150) on the GPU == the oracle, for a scan plus the points a driver can
+    hand over by accident: NaNs, the origin, points a nanometre / 10^20 m away, points exactly on the sensor's axes.  Distinct pixels per
+    point (last-writer-wins ties are order-dependent), so the two images must be identical."""
+    import torch
+    from isaac_ros_nvblox_amd import mapper as M
+    g = M.Mapper(M.default_params(), block_capacity=1 << 10)
+    sc = S.LidarScene(n_boxes=12, extent=40.0)
+    T = S.lidar_pose(3)
+    img = S.render_lidar(sc, T, SMALL_LIDAR, max_range=60.0)
+    dirs = S.lidar_beam_dirs(SMALL_LIDAR)
+    pts = (dirs * img[..., None]).reshape(-1, 3)[img.reshape(-1) > 0].astype(np.float32)
+    odd = np.float32([[np.nan, 1, 1], [0, 0, 0], [1e-12, 0, 0], [0, 0, 5.0], [0, 0, -5.0], [1e20, 1e20, 0], [3e-39, 0, 2.0], [np.inf, 0, 0], [0.05, 0.0, 0.0]])          # (all of them are outside the model: the image is the scan's)
+    allp = np.concatenate([pts, odd]).astype(np.float32)
+    got = g.depth_image_from_pointcloud(torch.from_numpy(allp).cuda(), SMALL_LIDAR).cpu().numpy()
+    want = oracle_mod.depth_image_from_pointcloud(allp, SMALL_LIDAR)
+    assert got.shape == want.shape == img.shape
+    assert np.array_equal(got, want)
+    assert (got > 0).sum() >= (img > 0).sum() * 0.98 and np.isfinite(got).all()
