@@ -85,3 +85,27 @@ def test_whole_path_parity_on_hard_inputs(oracle_mod, hip_lib, case):
             assert np.abs(a["colors"].astype(int) - mo["colors"].astype(int)).max() <= 1
     assert nonempty > 20
     assert g.counters()["capacity_overflow"] == 0
+
+
+def test_non_finite_and_negative_depth_pixels(oracle_mod, hip_lib):
+    """A depth image with NaN, +-inf, negative and absurdly large pixels (a driver hiccup): the view and the TSDF of the HIP path equal the
+    oracle's (NaN and non-positive pixels are invalid depth; an infinite range is cut at the integration distance), nothing non-finite is
+    written into the map, and the next clean frame integrates normally."""
+    M, g, o = make_pair(oracle_mod)
+    rng = np.random.default_rng(5)
+    fr = H.frames(3, H.SMALL_CAM, color=False, stride=9)
+    for k, (d, _, T) in enumerate(fr):
+        d = d.copy()
+        if k < 2:
+            idx = rng.integers(0, d.size, 400)
+            d.reshape(-1)[idx[:100]] = np.nan; d.reshape(-1)[idx[100:200]] = np.inf; d.reshape(-1)[idx[200:250]] = -np.inf
+            d.reshape(-1)[idx[250:330]] = -1.5; d.reshape(-1)[idx[330:]] = 1.0e30
+        g.integrate_depth(d, T, H.SMALL_CAM); o.integrate_depth(d, T, H.SMALL_CAM)
+        assert H.idx_set(g.last_view()) == H.idx_set(o.last_view())
+    n, _ = compare_layer(M, g, o, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
+    assert n > 100
+    b, _ = g.get_blocks(M.LAYER_TSDF, g.block_indices(M.LAYER_TSDF))
+    assert np.isfinite(b["distance"]).all() and np.isfinite(b["weight"]).all()
+    g.update_esdf(); o.update_esdf()
+    compare_layer(M, g, o, M.LAYER_ESDF, oracle_mod.L_ESDF, fields_exact=ESDF_FIELDS)
+    assert g.counters()["capacity_overflow"] == 0
