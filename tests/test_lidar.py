@@ -165,6 +165,9 @@ def test_lidar_parity_noisy_ranges_with_dropouts(oracle_mod, hip_lib, thr):
         img = S.render_lidar(sc, T, SMALL_LIDAR, max_range=40.0)
         img = np.where(img > 0, img + rng.normal(0.0, 0.03, img.shape).astype(np.float32), 0.0).astype(np.float32)
         img[rng.random(img.shape) < 0.03] = 0.0
+        if i == 1:                                     # a driver hiccup: a few non-finite / negative ranges
+            bad = rng.integers(0, img.size, 60)
+            img.reshape(-1)[bad[:20]] = np.nan; img.reshape(-1)[bad[20:40]] = np.inf; img.reshape(-1)[bad[40:]] = -2.0
         g.integrate_lidar_depth(img, T, SMALL_LIDAR); o.integrate_lidar_depth(img, T, SMALL_LIDAR)
         assert H.idx_set(g.last_view()) == H.idx_set(o.last_view())
     ig = g.block_indices(M.LAYER_TSDF); io = o.block_indices(oracle_mod.L_TSDF)
@@ -176,6 +179,7 @@ def test_lidar_parity_noisy_ranges_with_dropouts(oracle_mod, hip_lib, thr):
         b = o.get_block(oracle_mod.L_TSDF, idx)
         assert np.array_equal(bg[k]["distance"], b["distance"]) and np.array_equal(bg[k]["weight"], b["weight"]), idx
         nobs += int((b["weight"] > 0).sum())
+        assert np.isfinite(b["distance"]).all() and np.isfinite(b["weight"]).all()
     assert nobs > 20000
 
 
