@@ -313,7 +313,8 @@ extern "C" int nvbx_decay_occupancy(nvbx_mapper* m) {
   if (m->begin_dirtying()) return NVBX_E_DEVICE;
   EsdfArgs ea = m->make_esdf_args();
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
-  NVBX_LAUNCH(m, k_decay<true>, dim3((unsigned)std::min<int64_t>(m->capacity, 4096)), dim3(512), m->d,
+  const int64_t hw_seen = std::max<int64_t>(1, __atomic_load_n(&m->h_mirror[1], __ATOMIC_RELAXED));       // (a hint: the kernel grid-strides)
+  NVBX_LAUNCH(m, k_decay<true>, dim3((unsigned)std::min<int64_t>(std::min<int64_t>(m->capacity, 4096), std::max<int64_t>(512, (hw_seen + 7) / 8))), dim3(512), m->d,
               log_odds(m->p.free_region_decay_probability), log_odds(m->p.occupied_region_decay_probability), 0u, 0u, (int32_t)m->mesh_list_live(),
               ea.bz_lo, ea.bz_hi, ea.bz_out, 0.0f, m->cleared_idx);
   return rebuild_table(m);
