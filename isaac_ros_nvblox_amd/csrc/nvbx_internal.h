@@ -418,7 +418,7 @@ __device__ inline bool tsdf_fuse(const Frame& f, float2* v, float ds, float vd) 
   float fused, wnew = fminf(wsum, f.max_weight);
   if (!f.clamp_before_blend) fused = NVBX_DIV(sdf * wm + cur.x * cur.y, wsum);
   else { float wp = wnew - wm; if (wp < 0.0f) wp = 0.0f; fused = NVBX_DIV(sdf * wm + cur.x * wp, wm + wp); }
-  if (fused > 0.0f) fused = fminf(f.trunc, fused); else fused = fmaxf(-f.trunc, fused);
+  fused = __builtin_amdgcn_fmed3f(fused, -f.trunc, f.trunc);     // = (fused > 0 ? min(trunc, fused) : max(-trunc, fused)), one instruction (a NaN comes out as -trunc either way)
   *v = make_float2(fused, wnew);
   return true;
 }
@@ -432,7 +432,7 @@ __device__ inline bool tsdf_fuse_plain(const Frame& f, float2* v, float ds, floa
   const float wsum = 1.0f + cur.y;
   if (!(wsum > 0.0f)) return false;
   float fused = NVBX_DIV(sdf + cur.x * cur.y, wsum);
-  if (fused > 0.0f) fused = fminf(f.trunc, fused); else fused = fmaxf(-f.trunc, fused);
+  fused = __builtin_amdgcn_fmed3f(fused, -f.trunc, f.trunc);     // = (fused > 0 ? min(trunc, fused) : max(-trunc, fused)), one instruction (a NaN comes out as -trunc either way)
   *v = make_float2(fused, fminf(wsum, f.max_weight));
   return true;
 }

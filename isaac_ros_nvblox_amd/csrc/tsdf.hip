@@ -453,6 +453,10 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   }
 }
 
+// A wave-uniform value the inner loop uses as a VALU operand, parked in a vector register: the LiDAR instantiation needs ~100 scalar
+// registers, the 8-waves-per-SIMD budget leaves 72, and every use of a spilled one is a v_readlane in the per-voxel path.
+template <typename T> __device__ inline T in_vgpr(T x) { asm volatile("" : "+v"(x)); return x; }
+
 // Dependent-access chain: {view count, view record} -> {depth gather, voxel} -> store.  The record of the first block
 // is fetched speculatively beside the count, the voxel is fetched before the projection decides whether it is needed,
 // and the flag / dirty-list atomics of lane 0 are issued first and consumed last.
@@ -483,6 +487,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
   float off0[3] = {0.0f, 0.0f, 0.0f};
   if (NB == 1) sensor_voxel_offset(f0, vx, vy, vz, off0);          // (a batch rotates the offset per camera inside the loop)
+  // LiDAR: the image geometry the four-tap gather needs per voxel lives in vector registers (see in_vgpr)
+  Frame fl = f0; Img img0 = fs.img[0];
+  if (Sensor::kLongRays && NB == 1) { fl.cols = in_vgpr(f0.cols); fl.rows = in_vgpr(f0.rows); img0.p = in_vgpr(fs.img[0].p); }
   for (int32_t i0 = blockIdx.x; i0 < n; i0 += 64 * (int32_t)gridDim.x) {
     if (i0 != (int32_t)blockIdx.x) { mine = i0 + lane * (int32_t)gridDim.x; rec = mine < n ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0); }
     if (view_export && tid < 64 && mine < n && mine < view_export_cap) { int32_t* e = view_export + 3 * (1 + (int64_t)mine); e[0] = rec.y; e[1] = rec.z; e[2] = rec.w; }
@@ -505,7 +512,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll 1
       for (int c = 0; c < (NB > 1 ? fs.n : 1); c++) {
         if (NB > 1 && !((cams >> c) & 1u)) continue;       // uniform
-        const Frame& f = fs.f[c];
+        const Frame& f = (Sensor::kLongRays && NB == 1) ? fl : fs.f[c];
+        const Img& img = (Sensor::kLongRays && NB == 1) ? img0 : fs.img[c];
         float pc[3];
         if (NB == 1) {
           pc[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(org[0]), j)) + off0[0];
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
           pc[0] = o[0] + d[0]; pc[1] = o[1] + d[1]; pc[2] = o[2] + d[2];
         }
         float ds = 0.0f, vd = 0.0f;
-        const int got = sensor.sample(f, fs.img[c], pc, &ds, &vd);
+        const int got = sensor.sample(f, img, pc, &ds, &vd);
         if (Plain) {
           if (got > 0 && tsdf_fuse_plain(f, &fin, ds, vd)) touched = true;
         } else if (f.occupancy) {     // occupancy mapper: the pool holds log-odds (nvbx_internal.h occupancy_update)
