@@ -328,3 +328,55 @@ def test_depth_image_from_pointcloud_gpu_parity_with_degenerate_points(oracle_mo
     assert got.shape == want.shape == img.shape
     assert np.array_equal(got, want)
     assert (got > 0).sum() >= (img > 0).sum() * 0.98 and np.isfinite(got).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_azimuth_sector_split_reproduces_the_single_sensor_map_away_from_the_cuts(hip_lib, world):
+    """bench.py --workload lidar --gpus N (BASELINE.json configs[4] "1 and 8 GPUs"): rank r integrates only the beams of azimuth sector r.
+    Every voxel whose four interpolation taps lie inside one sector (two or more columns away from both cuts) must come out of that
+    rank's map exactly as out of the single-sensor map; together the sector maps observe everything the full scan observes except in the
+    columns at the cuts, and the sector views add up to the full view (blocks on a cut are shared)."""
+    from isaac_ros_nvblox_amd import mapper as M
+    lidar = SMALL_LIDAR
+    cols, rows = lidar[0], lidar[1]
+    kw = dict(voxel_size=0.1, lidar_max_integration_distance_m=30.0, raycast_subsampling_factor=1)
+    sc = S.LidarScene(n_boxes=12, extent=40.0)
+    T = S.lidar_pose(5)
+    img = S.render_lidar(sc, T, lidar, max_range=40.0)
+    full = M.Mapper(M.default_params(**kw), block_capacity=1 << 16)
+    full.integrate_lidar_depth(img, T, lidar)
+    fidx = full.block_indices(M.LAYER_TSDF); fb, _ = full.get_blocks(M.LAYER_TSDF, fidx)
+    fmap = {tuple(i): fb[k] for k, i in enumerate(fidx.tolist())}
+    # azimuth column of every voxel centre of the full map (numpy, float64: only used to pick voxels far from the cuts)
+    Tinv = np.linalg.inv(np.asarray(T, np.float64))
+    vs = 0.1
+    g3 = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 3)          # x, y, z ; linear = z + 8y + 64x
+    lin = g3[:, 2] + 8 * g3[:, 1] + 64 * g3[:, 0]
+    covered = 0; checked = 0; views = []
+    sector_maps = []
+    for r in range(world):
+        lo, hi = r * cols // world, (r + 1) * cols // world
+        part = np.where((np.arange(cols) >= lo) & (np.arange(cols) < hi), img, np.float32(0.0)).astype(np.float32)
+        g = M.Mapper(M.default_params(**kw), block_capacity=1 << 16)
+        g.integrate_lidar_depth(part, T, lidar)
+        views.append(H.idx_set(g.last_view()))
+        idx = g.block_indices(M.LAYER_TSDF); b, _ = g.get_blocks(M.LAYER_TSDF, idx)
+        sector_maps.append(({tuple(i): b[k] for k, i in enumerate(idx.tolist())}, lo, hi))
+    assert set().union(*views) == H.idx_set(full.last_view())
+    for bi, blk in fmap.items():
+        centres = (np.asarray(bi, np.float64)[None, :] * 8 + g3 + 0.5) * vs
+        pc = centres @ Tinv[:3, :3].T + Tinv[:3, 3]
+        u = (np.arctan2(pc[:, 1], pc[:, 0]) + np.pi) / (2 * np.pi / cols) + 0.5
+        u = np.where(u >= cols, u - cols, u)
+        w_full = blk["weight"][lin]; d_full = blk["distance"][lin]
+        for smap, lo, hi in sector_maps:
+            inside = (u > lo + 2.0) & (u < hi - 2.0) & (w_full > 0)
+            if not inside.any():
+                continue
+            assert bi in smap
+            sb = smap[bi]
+            assert np.array_equal(sb["weight"][lin][inside], w_full[inside]) and np.array_equal(sb["distance"][lin][inside], d_full[inside]), bi
+            checked += int(inside.sum())
+        covered += int((w_full > 0).sum())
+    assert checked > 0.7 * covered and covered > 50000             # (most of the map is more than two columns from a cut)
