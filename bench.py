@@ -329,6 +329,36 @@ def main_decay(args):
     def barrier():
         gs.synchronize(); gd.synchronize(); torch.cuda.synchronize(dev)
 
+    if args.step_trace:
+        # diagnosis of slow blocks: every step waited for, wall time per step beside the pools' capacities (tools: VERDICT r02 weak #3)
+        for i in range(args.warmup):
+            step(i)
+        barrier(); rec = []
+        calls = {}
+        def wrap(obj, name):                 # every mapper call of the step: waited for and timed on its own
+            fn = getattr(obj, name)
+            def timed_call(*a, **kw):
+                t = time.perf_counter(); r = fn(*a, **kw); barrier()
+                calls.setdefault(cur[0], []).append((("gs." if obj is gs else "gd.") + name, round((time.perf_counter() - t) * 1e3, 3)))
+                return r
+            setattr(obj, name, timed_call)
+        cur = [0]
+        for o_ in (gs, gd):
+            for nm in ("detect_dynamics_into", "remove_small_components_inplace", "split_depth_by_mask_into", "integrate_depth", "integrate_color",
+                       "update_esdf", "decay_tsdf", "decay_occupancy"):
+                wrap(o_, nm)
+        for i in range(args.warmup, args.warmup + args.step_trace):
+            cur[0] = i
+            c0 = (gs.capacity, gd.capacity); t = time.perf_counter(); step(i); barrier()
+            rec.append((i, (time.perf_counter() - t) * 1e3, c0, (gs.capacity, gd.capacity)))
+        w = np.array([r[1] for r in rec])
+        worst = max(rec, key=lambda r: r[1])[0]
+        print(json.dumps({"slowest_step_calls": {"step": worst, "calls_ms": calls.get(worst)}}))
+        print(json.dumps({"step_trace": {"steps": len(rec), "median_ms": round(float(np.median(w)), 4), "mean_ms": round(float(w.mean()), 4),
+                                         "p99_ms": round(float(np.percentile(w, 99)), 4),
+                                         "slowest": [{"step": r[0], "ms": round(r[1], 3), "capacity_before": r[2], "capacity_after": r[3]}
+                                                     for r in sorted(rec, key=lambda r: -r[1])[:12]]}}))
+        return
     tm = Timer(torch, dist, dev, world)
     dt, dts, nxt = tm.run(step, barrier, args.steps, args.warmup)
     ms = dt / args.steps * 1e3
@@ -390,7 +420,7 @@ def main_decay(args):
 # ====================================================================================================== camera / multicam
 def main_camera(args):
     from isaac_ros_nvblox_amd import mapper as M, synthetic as S
-    from isaac_ros_nvblox_amd.dist import MeasurementFusion, PipelinedDirtyBlockExchange, camera_yaw_offset_deg
+    from isaac_ros_nvblox_amd.dist import PipelinedMeasurementFusion, PipelinedDirtyBlockExchange, camera_yaw_offset_deg
     torch, dist, rank, world, local_rank, dev = init_dist(args)
     multicam = args.workload == "multicam"
     ncam = max(1, min(8, args.cameras)) if multicam else 1
@@ -423,7 +453,10 @@ def main_camera(args):
     g = M.Mapper(M.default_params(), device=local_rank, block_capacity=1 << 15, stream=stream.cuda_stream)
     fuse = world > 1 and args.fusion == "measurements"     # ONE fused map on every rank (exact, dist.MeasurementFusion) instead of replicas + index union
     ex = PipelinedDirtyBlockExchange(4096, dev) if (world > 1 and not fuse) else None      # one packed all-gather per frame, joined one frame later
-    mf = MeasurementFusion(1024, dev) if fuse else None      # 1024 records x 4112 B = 4.2 MB per rank and frame (~300 blocks in view are used)
+    # buffers of 1024 records x 4112 B per rank; only max(count) rounded up to 64 records (~320 for ~300 blocks in view, 1.3 MB) goes
+    # to the collective, one frame behind the measurement (dist.PipelinedMeasurementFusion)
+    mf = PipelinedMeasurementFusion(1024, dev) if fuse else None
+    mf_prev = [None]
 
     dargs = [[g.prepare_depth(depth_dev[ci][k], poses[ci][k], cam) for k in range(nu)] for ci in range(len(host_cams))]
     cargs = [[g.prepare_color(rgb_dev[ci][k], poses[ci][k], cam) for k in range(nu)] for ci in range(len(host_cams))]
@@ -442,7 +475,14 @@ def main_camera(args):
         if xg is not None:
             xg.before_depth(g)                   # the depth pass writes this frame's block indices into the exchange buffer itself
         if mf is not None and exchange:
-            mf.integrate_depth(g, depth_dev[0][k], poses[0][k], cam)     # measure (this camera) -> all-gather -> apply all cameras in rank order
+            # frame i: measured now; frame i-1: its payload all-gather runs beside this measurement, then every camera's measurements are
+            # applied in rank order and ITS colour + ESDF run (one fused map, one frame of latency)
+            mf.begin(g, depth_dev[0][k], poses[0][k], cam)
+            done = mf.finish_previous(g)
+            kp, mf_prev[0] = mf_prev[0], k
+            if done:
+                g.integrate_prepared(cargs[0][kp]); g.update_esdf()
+            return
         elif use_batch:
             g.integrate_prepared_batch(bd[n][k])     # n cameras' depth frames: ONE view-marking launch + ONE TSDF-update launch
         else:
@@ -464,6 +504,10 @@ def main_camera(args):
         if ex is not None:
             ex.drain(g)          # the all-gather still in flight is joined and applied inside the timed region
             g.set_view_export(None)
+        if mf is not None and mf_prev[0] is not None:
+            for _ in range(mf.drain(g)):     # the frame still on its way: gathered, applied, coloured, swept -- inside the timed region
+                g.integrate_prepared(cargs[0][mf_prev[0]]); g.update_esdf()
+            mf_prev[0] = None
         g.synchronize()          # launches anything the mapper holds back (the EDT of the last updateEsdf) and waits for its stream
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -609,6 +653,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=48, help="minimum number of frames of the same workload timed on the CPU oracle")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline keeps integrating (cycling the same frames) until this much CPU wall time has passed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-trace", type=int, default=0, help="decay workload: wait for every one of this many steps and report the slowest (diagnosis)")
     ap.add_argument("--cameras", type=int, default=4, help="multicam: cameras per step (1..8)")
     ap.add_argument("--fusion", default="indices", choices=["indices", "measurements"],
                     help="N > 1 GPUs: indices = replicas + all-gather of dirty block indices (north-star wording, default); "

@@ -1,8 +1,10 @@
 // rccl_fusion.cpp -- the multi-GPU measurement exchange driven from C++ through the C-ABI and RCCL directly (no Python, no torch):
 // ONE process, N GPUs (ncclCommInitAll), one nvbx_mapper + one camera per GPU.  Per frame
 //     nvbx_measure_depth (each GPU: view calculation + projection of ITS camera)
-//  -> ncclAllGather of the record counts and of the measurement records over xGMI (grouped, on the mappers' own streams)
-//  -> nvbx_apply_measurements (each GPU: every camera's measurements, in rank order)
+//  -> ncclAllGather of the record COUNTS (4 B per rank), copied to the host
+//  -> ncclAllGather of the first n records of every rank's buffer, n = max(count) rounded up to 64 records: only what is used goes
+//     over xGMI (~1.3 MB per rank for ~300 blocks in view, not the 4.2 MB the buffers are sized for); grouped, on the mappers' streams
+//  -> nvbx_apply_measurements with stride n (each GPU: every camera's measurements, in rank order)
 // after which every GPU holds the same fused map (include/nvblox_hip.h "measurement exchange"; SURVEY.md 8e option B, made exact).
 // The program checks that against ONE mapper on GPU 0 integrating the N cameras as a batch (nvbx_integrate_depth_batch): block sets and
 // voxels must be identical.  nvblox_ros would drive the same three calls from NvbloxNode::processDepthImage (nvblox_node.cpp:1062) with
@@ -11,6 +13,7 @@
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -67,6 +70,7 @@ int main(int argc, char** argv) {
   nvbx_mapper* single = nullptr; CHECK(nvbx_mapper_create(0, nullptr, &p, 1 << 13, &single));
   std::vector<float*> d_batch(n); for (int i = 0; i < n; i++) HIPCHECK(hipMalloc((void**)&d_batch[i], sizeof(float) * ROWS * COLS));
   std::vector<float> depth(ROWS * COLS), T(16 * n);
+  int64_t sent_bytes = 0, used_bytes = 0;          // per rank: bytes handed to the payload collective / bytes of used records (largest rank)
   for (int k = 0; k < n_frames; k++) {
     for (int i = 0; i < n; i++) {
       render(0.3f * k + 0.7853982f * i, depth.data(), &T[16 * i]);
@@ -74,13 +78,20 @@ int main(int argc, char** argv) {
       HIPCHECK(hipSetDevice(0)); HIPCHECK(hipMemcpy(d_batch[i], depth.data(), sizeof(float) * ROWS * COLS, hipMemcpyHostToDevice));
     }
     for (int i = 0; i < n; i++) CHECK(nvbx_measure_depth(rank[i], d_depth[i], ROWS, COLS, &T[16 * i], &cam, buf[i], cnt[i], STRIDE));
+    // phase 1: the counts (every rank learns every count; the host sizes the payload from them)
     NCCLCHECK(ncclGroupStart());
-    for (int i = 0; i < n; i++) {
-      NCCLCHECK(ncclAllGather(cnt[i], all_cnt[i], 1, ncclInt32, comms[i], stream[i]));
-      NCCLCHECK(ncclAllGather(buf[i], all_buf[i], sizeof(nvbx_measurement_block) * STRIDE, ncclChar, comms[i], stream[i]));
-    }
+    for (int i = 0; i < n; i++) NCCLCHECK(ncclAllGather(cnt[i], all_cnt[i], 1, ncclInt32, comms[i], stream[i]));
     NCCLCHECK(ncclGroupEnd());
-    for (int i = 0; i < n; i++) CHECK(nvbx_apply_measurements(rank[i], all_buf[i], all_cnt[i], n, STRIDE, 0, 0));
+    std::vector<int32_t> h_cnt(n);
+    HIPCHECK(hipSetDevice(0)); HIPCHECK(hipMemcpyAsync(h_cnt.data(), all_cnt[0], 4 * n, hipMemcpyDeviceToHost, stream[0])); HIPCHECK(hipStreamSynchronize(stream[0]));
+    int64_t used = 0; for (int i = 0; i < n; i++) used = std::max<int64_t>(used, std::min<int64_t>(h_cnt[i], STRIDE));
+    const int64_t n_rec = std::min<int64_t>(STRIDE, std::max<int64_t>(64, (used + 63) / 64 * 64));
+    sent_bytes += n_rec * (int64_t)sizeof(nvbx_measurement_block); used_bytes += used * (int64_t)sizeof(nvbx_measurement_block);
+    // phase 2: the used prefix of every rank's records
+    NCCLCHECK(ncclGroupStart());
+    for (int i = 0; i < n; i++) NCCLCHECK(ncclAllGather(buf[i], all_buf[i], sizeof(nvbx_measurement_block) * (size_t)n_rec, ncclChar, comms[i], stream[i]));
+    NCCLCHECK(ncclGroupEnd());
+    for (int i = 0; i < n; i++) CHECK(nvbx_apply_measurements(rank[i], all_buf[i], all_cnt[i], n, n_rec, 0, 0));
     CHECK(nvbx_integrate_depth_batch(single, n, d_batch.data(), ROWS, COLS, T.data(), std::vector<nvbx_camera>(n, cam).data()));
   }
   // every rank's map == the single mapper's
@@ -96,7 +107,8 @@ int main(int argc, char** argv) {
     CHECK(nvbx_get_blocks(rank[i], NVBX_LAYER_TSDF, idx.data(), nb, got.data(), nullptr));
     if (std::memcmp(ref.data(), got.data(), sizeof(nvbx_tsdf_voxel) * (size_t)nb * 512)) bad++;
   }
-  std::printf("{\"gpus\": %d, \"frames\": %d, \"tsdf_blocks\": %lld, \"ranks_differing_from_single_mapper\": %d}\n", n, n_frames, (long long)nb, bad);
+  std::printf("{\"gpus\": %d, \"frames\": %d, \"tsdf_blocks\": %lld, \"ranks_differing_from_single_mapper\": %d, \"payload_bytes_sent_per_rank\": %lld, \"payload_bytes_used\": %lld, \"buffer_bytes\": %lld}\n",
+              n, n_frames, (long long)nb, bad, (long long)sent_bytes, (long long)used_bytes, (long long)((int64_t)n_frames * STRIDE * (int64_t)sizeof(nvbx_measurement_block)));
   for (int i = 0; i < n; i++) { nvbx_mapper_destroy(rank[i]); ncclCommDestroy(comms[i]); }
   nvbx_mapper_destroy(single);
   return (bad == 0 && nb > 100) ? 0 : 3;

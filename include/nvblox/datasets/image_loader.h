@@ -44,7 +44,9 @@ inline bool decodePng(const std::vector<uint8_t>& file, DecodedImage* img) {
     const uint8_t* d = &file[pos + 8];
     if (!std::memcmp(type, "IHDR", 4)) {
       if (len < 13) return false;
-      img->cols = (int)be32(d); img->rows = (int)be32(d + 4); img->bit_depth = d[8]; color_type = d[9]; interlace = d[12];
+      const uint32_t wc = be32(d), hr = be32(d + 4);
+      if (wc == 0 || hr == 0 || wc > 32768u || hr > 32768u || (uint64_t)wc * hr > (1ull << 28)) return false;     // (the JPEG path's cap: no multi-GB allocation from a header)
+      img->cols = (int)wc; img->rows = (int)hr; img->bit_depth = d[8]; color_type = d[9]; interlace = d[12];
     } else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), d, d + len);
     else if (!std::memcmp(type, "IEND", 4)) break;
     pos += 12 + (size_t)len;
@@ -89,14 +91,15 @@ inline bool decodePnm(const std::vector<uint8_t>& file, DecodedImage* img) {
     while (pos < file.size() && (file[pos] == ' ' || file[pos] == '\n' || file[pos] == '\r' || file[pos] == '\t')) pos++;
     if (pos < file.size() && file[pos] == '#') { while (pos < file.size() && file[pos] != '\n') pos++; continue; }
     long x = 0; bool any = false;
-    while (pos < file.size() && file[pos] >= '0' && file[pos] <= '9') { x = x * 10 + (file[pos] - '0'); pos++; any = true; }
+    while (pos < file.size() && file[pos] >= '0' && file[pos] <= '9') { x = x * 10 + (file[pos] - '0'); pos++; any = true; if (x > 65535) return false; }
     if (!any) return false;
     v[got++] = x;
   }
   pos++;    // one whitespace after maxval
+  if (got < 3 || v[0] <= 0 || v[1] <= 0 || v[0] > 32768 || v[1] > 32768 || (uint64_t)v[0] * (uint64_t)v[1] > (1ull << 28) || v[2] <= 0) return false;
   img->cols = (int)v[0]; img->rows = (int)v[1]; img->channels = file[1] == '5' ? 1 : 3; img->bit_depth = v[2] > 255 ? 16 : 8;
   const size_t n = (size_t)img->rows * img->cols * img->channels, bps = img->bit_depth / 8;
-  if (pos + n * bps > file.size()) return false;
+  if (pos > file.size() || n * bps > file.size() - pos) return false;
   img->data.resize(n);
   for (size_t i = 0; i < n; i++) img->data[i] = bps == 2 ? (uint16_t)((file[pos + 2 * i] << 8) | file[pos + 2 * i + 1]) : file[pos + i];
   return true;

@@ -184,6 +184,10 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, FrameSetC<Pix, 
     // the band vote ("any voxel with weight > 0 and |distance| < truncation") is the slot's F_BAND flag, kept exact by every
     // kernel that writes TSDF voxels (nvbx_internal.h): no TSDF read here -- unless a LiDAR scan left the block STALE, in which
     // case this workgroup votes from the TSDF once and repairs the bits
+    // Every wavefront loads the chunk's flags on its own, and the STALE repair below REWRITES them (publish_band): all eight must have
+    // their copy before the first of them publishes, or a lagging wavefront would see STALE already cleared and only part of the band bits,
+    // pick a different candidate set and take different barriers (reachable only when LiDAR and colour share a mapper).
+    __syncthreads();
     u64 cand = __ballot(lane_c < chunk && base + lane_c < hw && (lflags & F_TSDF) && (lflags & (F_BAND | F_BAND_STALE)));     // (the same in all eight wavefronts)
   while (cand) {
     const int cj = __ffsll((long long)cand) - 1;

@@ -16,7 +16,7 @@ constexpr uint32_t LAYER_MASK = F_TSDF | F_COLOR | F_ESDF | F_MESH | F_ESDF_PEND
 __device__ inline void free_slot(DMap& m, uint32_t slot) {   // one thread
   const int32_t pos = atomicAdd(&m.counters[C_FREE_TOP], 1);
   m.free_stack[pos] = slot;
-  m.slot_consumed[slot] = STAMP_NEVER; m.slot_stamp[slot] = STAMP_NEVER;
+  m.slot_consumed[slot] = STAMP_NEVER; m.slot_stamp[slot] = STAMP_NEVER; m.slot_cam[slot] = STAMP_NEVER;
   atomicSub(&m.counters[C_LIVE], 1);
 }
 
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const uint32_t fl = mine < hw ? m.slot_flags[mine] : 0u;
     bool act = (fl & F_TSDF) != 0;
     if (exclude_stamp && act) {
-      const uint32_t st = m.table[m.slot_entry[mine]].stamp;
+      const uint32_t st = m.slot_cam[mine];       // (the camera's own stamp, not Entry::stamp: a LiDAR scan since then has re-claimed that)
       if (stamp_frame(st) == exclude_stamp && (st & exclude_mask)) act = false;
     }
     const u64 act_mask = __ballot(act);
@@ -407,75 +407,89 @@ int nvbx_mapper::grow_map(int64_t new_cap) {
   { size_t free_b = 0, total_b = 0; NVBX_HIP(hipMemGetInfo(&free_b, &total_b));
     const size_t need = (size_t)new_cap * 4096 + ((size_t)new_cap - (size_t)old_cap) * (3 * 4096 + (d.freespace ? 8192 : 0) + 512) + (64u << 20);
     if (free_b < need) { set_error("pool growth: not enough free HBM, the block pools stay at their size"); max_capacity = capacity; return NVBX_OK; } }
-  const uint32_t stamp_bytes = (uint32_t)sizeof(uint32_t);
-  uint32_t* saved = nullptr;
-  NVBX_HIP(hipMalloc(&saved, (size_t)old_cap * stamp_bytes));
-  const unsigned rg = (unsigned)std::min<int64_t>((old_cap + 255) / 256, 2048);
-  NVBX_LAUNCH(this, k_save_stamps, dim3(rg), dim3(256), d, saved);          // view stamps live in the table that is about to be replaced
+  // Failure-atomic: EVERY new array is allocated first; if one allocation fails they are all released and the map is untouched
+  // (the pools stay at their size).  Only then are the contents copied and the pointers / capacity swapped in one commit step.
   std::vector<PoolArr> arrs = {
       arr(&d.free_stack, 4, -1), arr(&d.slot_flags, 4, 0), arr(&d.slot_index, 12, 0), arr(&d.slot_entry, 4, 0), arr(&d.slot_stamp, 4, 0xFF),
-      arr(&d.slot_consumed, 4, 0xFF), arr(&d.tsdf, 4096, 0), arr(&d.color, 4096, 0), arr(&d.esdf, 4096, 0), arr(&view_list, 16, -1),
+      arr(&d.slot_consumed, 4, 0xFF), arr(&d.slot_cam, 4, 0xFF), arr(&d.tsdf, 4096, 0), arr(&d.color, 4096, 0), arr(&d.esdf, 4096, 0), arr(&view_list, 16, -1),
       arr(&export_idx, 12, -1), arr(&cleared_idx, 12, -1), arr(&d.site_bits, 8, 0), arr(&d.obs_bits, 8, 0), arr(&d.inside_bits, 8, 0),
       arr(&mesh_rec, sizeof(MeshRecord), -1)};
   if (d.freespace) arrs.push_back(arr(&d.freespace, 512 * 16, 0));
-  for (const PoolArr& a : arrs) {
-    void* np = nullptr;
-    NVBX_HIP(hipMalloc(&np, a.bytes_per_block * (size_t)new_cap));
-    NVBX_HIP(hipMemcpyAsync(np, *a.p, a.bytes_per_block * (size_t)old_cap, hipMemcpyDeviceToDevice, stream));
-    if (a.fill >= 0) NVBX_HIP(hipMemsetAsync((char*)np + a.bytes_per_block * (size_t)old_cap, a.fill, a.bytes_per_block * (size_t)(new_cap - old_cap), stream));
-    NVBX_HIP(hipStreamSynchronize(stream));
-    NVBX_HIP(hipFree(*a.p));
-    *a.p = np;
+  const int64_t new_vcap = std::min<int64_t>(new_cap * 192, 48ll << 20), new_tcap = new_vcap * 2;
+  const bool grow_mesh = new_vcap > mesh_vert_cap;
+  uint64_t tsz = 1; while (tsz < (uint64_t)new_cap * 2) tsz <<= 1;
+  std::vector<void*> fresh;                                    // everything allocated so far (released on failure)
+  auto take = [&](size_t bytes) -> void* {
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    fresh.push_back(q); return q;
+  };
+  bool ok = true;
+  uint32_t* saved = (uint32_t*)take((size_t)old_cap * sizeof(uint32_t)); ok = ok && saved;
+  std::vector<void*> np(arrs.size(), nullptr);
+  for (size_t i = 0; ok && i < arrs.size(); i++) { np[i] = take(arrs[i].bytes_per_block * (size_t)new_cap); ok = ok && np[i]; }
+  int32_t* nl = ok ? (int32_t*)take((size_t)N_LISTS * NSH * (size_t)new_cap * 4) : nullptr; ok = ok && nl;
+  float* nv = nullptr; float* nn = nullptr; uint8_t* nc = nullptr; int32_t* nt = nullptr;
+  if (ok && grow_mesh) {
+    nv = (float*)take(new_vcap * 12); nn = (float*)take(new_vcap * 12); nc = (uint8_t*)take(new_vcap * 4); nt = (int32_t*)take(new_tcap * 12);
+    ok = nv && nn && nc && nt;
   }
-  {   // work lists: [list][shard][capacity] -- every segment moves to its place in the wider layout (entry counts live in d.shc)
-    int32_t* nl = nullptr;
-    NVBX_HIP(hipMalloc(&nl, (size_t)N_LISTS * NSH * (size_t)new_cap * 4));
-    for (int q = 0; q < N_LISTS * NSH; q++)
-      NVBX_HIP(hipMemcpyAsync(nl + (size_t)q * new_cap, d.lists + (size_t)q * old_cap, (size_t)old_cap * 4, hipMemcpyDeviceToDevice, stream));
-    NVBX_HIP(hipStreamSynchronize(stream));
-    NVBX_HIP(hipFree(d.lists)); d.lists = nl;
+  Entry* ntab = ok ? (Entry*)take(tsz * sizeof(Entry)) : nullptr; ok = ok && ntab;
+  if (!ok) {
+    for (void* q : fresh) (void)hipFree(q);
+    set_error("pool growth: device allocation failed, the block pools stay at their size"); max_capacity = capacity;
+    return NVBX_OK;
   }
-  {   // mesh arenas: NSH shard regions each; the used prefix of every region (last mesh update) moves, the records are re-based
-    const int64_t new_vcap = std::min<int64_t>(new_cap * 192, 48ll << 20), new_tcap = new_vcap * 2;
-    if (new_vcap > mesh_vert_cap) {
-      const int64_t ovr = mesh_vert_cap / NSH, otr = mesh_tri_cap / NSH, nvr = new_vcap / NSH, ntr = new_tcap / NSH;
-      float* nv = nullptr; float* nn = nullptr; uint8_t* nc = nullptr; int32_t* nt = nullptr;
-      NVBX_HIP(hipMalloc(&nv, new_vcap * 12)); NVBX_HIP(hipMalloc(&nn, new_vcap * 12)); NVBX_HIP(hipMalloc(&nc, new_vcap * 4)); NVBX_HIP(hipMalloc(&nt, new_tcap * 12));
-      if (mesh_epoch) {
-        const int par = (int)((mesh_epoch + 1) & 1);
-        for (int sh = 0; sh < NSH; sh++) {
-          const int64_t uv = std::min<int64_t>((uint32_t)h_shc[((S_MESH_REC + par) * NSH + sh) * SH_STRIDE + 2], ovr);
-          const int64_t ut = std::min<int64_t>((uint32_t)h_shc[((S_MESH_REC + par) * NSH + sh) * SH_STRIDE + 3], otr);
-          if (uv) {
-            NVBX_HIP(hipMemcpyAsync(nv + sh * nvr * 3, mesh_vert + sh * ovr * 3, (size_t)uv * 12, hipMemcpyDeviceToDevice, stream));
-            NVBX_HIP(hipMemcpyAsync(nn + sh * nvr * 3, mesh_nrm + sh * ovr * 3, (size_t)uv * 12, hipMemcpyDeviceToDevice, stream));
-            NVBX_HIP(hipMemcpyAsync(nc + sh * nvr * 4, mesh_col + sh * ovr * 4, (size_t)uv * 4, hipMemcpyDeviceToDevice, stream));
-          }
-          if (ut) NVBX_HIP(hipMemcpyAsync(nt + sh * ntr * 3, mesh_tri + sh * otr * 3, (size_t)ut * 12, hipMemcpyDeviceToDevice, stream));
+  // from here on only copies, launches and frees: a failure is a device error, not a half-grown map
+  const unsigned rg = (unsigned)std::min<int64_t>((old_cap + 255) / 256, 2048);
+  NVBX_LAUNCH(this, k_save_stamps, dim3(rg), dim3(256), d, saved);          // view stamps live in the table that is about to be replaced
+  for (size_t i = 0; i < arrs.size(); i++) {
+    const PoolArr& a = arrs[i];
+    NVBX_HIP(hipMemcpyAsync(np[i], *a.p, a.bytes_per_block * (size_t)old_cap, hipMemcpyDeviceToDevice, stream));
+    if (a.fill >= 0) NVBX_HIP(hipMemsetAsync((char*)np[i] + a.bytes_per_block * (size_t)old_cap, a.fill, a.bytes_per_block * (size_t)(new_cap - old_cap), stream));
+  }
+  // work lists: [list][shard][capacity] -- every segment moves to its place in the wider layout (entry counts live in d.shc)
+  for (int q = 0; q < N_LISTS * NSH; q++)
+    NVBX_HIP(hipMemcpyAsync(nl + (size_t)q * new_cap, d.lists + (size_t)q * old_cap, (size_t)old_cap * 4, hipMemcpyDeviceToDevice, stream));
+  if (grow_mesh) {   // mesh arenas: NSH shard regions each; the used prefix of every region (last mesh update) moves, the records are re-based
+    const int64_t ovr = mesh_vert_cap / NSH, otr = mesh_tri_cap / NSH, nvr = new_vcap / NSH, ntr = new_tcap / NSH;
+    if (mesh_epoch) {
+      const int par = (int)((mesh_epoch + 1) & 1);
+      for (int sh = 0; sh < NSH; sh++) {
+        const int64_t uv = std::min<int64_t>((uint32_t)h_shc[((S_MESH_REC + par) * NSH + sh) * SH_STRIDE + 2], ovr);
+        const int64_t ut = std::min<int64_t>((uint32_t)h_shc[((S_MESH_REC + par) * NSH + sh) * SH_STRIDE + 3], otr);
+        if (uv) {
+          NVBX_HIP(hipMemcpyAsync(nv + sh * nvr * 3, mesh_vert + sh * ovr * 3, (size_t)uv * 12, hipMemcpyDeviceToDevice, stream));
+          NVBX_HIP(hipMemcpyAsync(nn + sh * nvr * 3, mesh_nrm + sh * ovr * 3, (size_t)uv * 12, hipMemcpyDeviceToDevice, stream));
+          NVBX_HIP(hipMemcpyAsync(nc + sh * nvr * 4, mesh_col + sh * ovr * 4, (size_t)uv * 4, hipMemcpyDeviceToDevice, stream));
         }
-        const int32_t nraw = h_counters[C_MESH_OUT + 4 * par + 0];
-        if (nraw > 0) NVBX_LAUNCH(this, k_remap_mesh_records, dim3(64), dim3(256), mesh_rec, std::min<int32_t>(nraw, (int32_t)old_cap), ovr, nvr, otr, ntr);
+        if (ut) NVBX_HIP(hipMemcpyAsync(nt + sh * ntr * 3, mesh_tri + sh * otr * 3, (size_t)ut * 12, hipMemcpyDeviceToDevice, stream));
       }
-      NVBX_HIP(hipStreamSynchronize(stream));
-      NVBX_HIP(hipFree(mesh_vert)); NVBX_HIP(hipFree(mesh_nrm)); NVBX_HIP(hipFree(mesh_col)); NVBX_HIP(hipFree(mesh_tri));
-      mesh_vert = nv; mesh_nrm = nn; mesh_col = nc; mesh_tri = nt; mesh_vert_cap = new_vcap; mesh_tri_cap = new_tcap;
+      const int32_t nraw = h_counters[C_MESH_OUT + 4 * par + 0];
+      // (the records are re-based in their NEW array: np[] of mesh_rec has its copy already enqueued on the same stream)
+      MeshRecord* new_rec = nullptr;
+      for (size_t i = 0; i < arrs.size(); i++) if (arrs[i].p == reinterpret_cast<void**>(&mesh_rec)) new_rec = (MeshRecord*)np[i];
+      if (nraw > 0) NVBX_LAUNCH(this, k_remap_mesh_records, dim3(64), dim3(256), new_rec, std::min<int32_t>(nraw, (int32_t)old_cap), ovr, nvr, otr, ntr);
     }
   }
-  {   // hash table at twice the size, rebuilt from the live slots on the device
-    uint64_t tsz = 1; while (tsz < (uint64_t)new_cap * 2) tsz <<= 1;
-    Entry* nt = nullptr;
-    NVBX_HIP(hipMalloc(&nt, tsz * sizeof(Entry)));
-    NVBX_HIP(hipFree(d.table)); d.table = nt;
-    d.mask = (uint32_t)(tsz - 1);
-    { uint32_t lg = 0; while ((1ull << lg) < tsz) lg++; d.shift = 32u - lg; }
-    NVBX_HIP(hipMemsetAsync(d.table, 0xFF, tsz * sizeof(Entry), stream));
+  NVBX_HIP(hipMemsetAsync(ntab, 0xFF, tsz * sizeof(Entry), stream));
+  NVBX_HIP(hipStreamSynchronize(stream));
+  // ---- commit: pointers, capacity, hash geometry
+  for (size_t i = 0; i < arrs.size(); i++) { (void)hipFree(*arrs[i].p); *arrs[i].p = np[i]; }
+  (void)hipFree(d.lists); d.lists = nl;
+  if (grow_mesh) {
+    (void)hipFree(mesh_vert); (void)hipFree(mesh_nrm); (void)hipFree(mesh_col); (void)hipFree(mesh_tri);
+    mesh_vert = nv; mesh_nrm = nn; mesh_col = nc; mesh_tri = nt; mesh_vert_cap = new_vcap; mesh_tri_cap = new_tcap;
   }
+  (void)hipFree(d.table); d.table = ntab;
+  d.mask = (uint32_t)(tsz - 1);
+  { uint32_t lg = 0; while ((1ull << lg) < tsz) lg++; d.shift = 32u - lg; }
   d.capacity = (uint32_t)new_cap; capacity = new_cap;
   NVBX_LAUNCH(this, k_grow_free_stack, dim3(256), dim3(256), d, (uint32_t)old_cap, (uint32_t)new_cap);
   NVBX_LAUNCH(this, k_grow_commit, dim3(1), dim3(1), d, (int32_t)(new_cap - old_cap));
   NVBX_LAUNCH(this, k_reinsert, dim3(rg), dim3(256), d, saved, make_esdf_args().bz_out);
   NVBX_HIP(hipStreamSynchronize(stream));
-  NVBX_HIP(hipFree(saved));
+  (void)hipFree(saved);
   if (view_export_cap > 0) view_export_cap = std::min<int64_t>(view_export_cap, capacity);
   growths++;
   return NVBX_OK;

@@ -22,7 +22,7 @@ extern "C" const char* nvbx_last_error(void) { return nvbx::g_err.c_str(); }
 // ------------------------------------------------------------------------------------------------ utility kernels
 __global__ void k_init_map(DMap m) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < m.capacity) { m.free_stack[i] = m.capacity - 1 - i; m.slot_flags[i] = 0; m.slot_stamp[i] = STAMP_NEVER; m.slot_consumed[i] = STAMP_NEVER; }
+  if (i < m.capacity) { m.free_stack[i] = m.capacity - 1 - i; m.slot_flags[i] = 0; m.slot_stamp[i] = STAMP_NEVER; m.slot_consumed[i] = STAMP_NEVER; m.slot_cam[i] = STAMP_NEVER; }
   if (i < (uint32_t)(S_NUM * NSH * SH_STRIDE)) {       // sharded counters: zero, ESDF window records min = +inf / max = -inf
     const int id = (int)i / (NSH * SH_STRIDE), field = (int)i % SH_STRIDE;
     int32_t v = 0;
@@ -190,6 +190,7 @@ static int alloc_all(nvbx_mapper* m) {
   NVBX_HIP(hipMalloc(&d.slot_entry, cap * 4));
   NVBX_HIP(hipMalloc(&d.slot_stamp, cap * 4));
   NVBX_HIP(hipMalloc(&d.slot_consumed, cap * 4));
+  NVBX_HIP(hipMalloc(&d.slot_cam, cap * 4));
   NVBX_HIP(hipMalloc(&d.tsdf, cap * 4096));
   NVBX_HIP(hipMalloc(&d.color, cap * 4096));
   NVBX_HIP(hipMalloc(&d.esdf, cap * 4096));
@@ -372,7 +373,7 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   if (m->ev_side) (void)hipEventDestroy(m->ev_side);
   if (m->side) (void)hipStreamDestroy(m->side);
   DMap& d = m->d;
-  void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.slot_consumed, d.tsdf, d.color, d.esdf,
+  void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.slot_consumed, d.slot_cam, d.tsdf, d.color, d.esdf,
                   m->view_list, d.lists, d.shc, m->export_idx, m->export_count, m->cleared_idx, d.site_bits, d.obs_bits, d.inside_bits,
                   m->synth, m->depth_pre, m->mask_zmin, m->apply_postab, m->esdf3_scratch, m->cc_scratch, d.freespace, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
   for (void* p : ptrs) if (p) (void)hipFree(p);

@@ -117,6 +117,9 @@ struct DMap {
   int32_t* slot_index;      // 3 ints per slot
   uint32_t* slot_entry;     // slot -> hash entry
   uint32_t* slot_stamp;     // ESDF slot: marking pass that last re-marked this column (de-duplication within a pass)
+  uint32_t* slot_cam;       // TSDF slot: (view frame id << 8) | camera mask of the last CAMERA depth launch that had the block in view, written by
+                            //   the TSDF update of that launch.  decayTsdfExcludeLastView<Camera> reads it: the shared Entry::stamp is re-claimed by
+                            //   every later view calculation (a LiDAR scan in between would otherwise take the camera view's place)
   uint32_t* slot_consumed;  // TSDF slot: marking pass that last consumed its ESDF-dirty flag (STAMP_NEVER = none); lets a
                             //   deallocating operation take back marking passes that no distance transform has followed yet
   float2* tsdf;

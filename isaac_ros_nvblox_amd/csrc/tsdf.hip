@@ -152,15 +152,19 @@ __device__ inline bool stamp_claim(uint32_t* p, uint32_t cur, uint32_t frame_id,
 // One block key -> HBM: insert-if-absent, stamp the entry with this frame (and this camera's bit), and report whether THIS call was
 // the first of the frame to do so (the caller then appends {slot, x, y, z} to the view list exactly once).  The common case -- the
 // block exists and a neighbouring tile has stamped it already -- is ONE 16-B load: key, slot and stamp arrive together.
-__device__ inline bool mark_block(const DMap& m, u64 key, uint32_t frame_id, uint32_t cam_bit, int4* rec_out) {
+// `entry_out` (optional): the block's hash entry whenever it exists after the call (-1: table full) -- also when this call was not the
+// first, so that a caller that needs the slot of a block ANOTHER thread of the same launch has just inserted never has to look the key
+// up again with plain loads (hash_find may read a stale EMPTY from L1 / a non-coherent L2 and report "absent").
+__device__ inline bool mark_block(const DMap& m, u64 key, uint32_t frame_id, uint32_t cam_bit, int4* rec_out, int32_t* entry_out = nullptr) {
   int32_t x, y, z; unpack_key(key, &x, &y, &z);
   uint32_t h = table_pos(m, x, y, z);
   uint32_t slot = SLOT_INVALID, cur = STAMP_NEVER;
   bool found = false;
+  if (entry_out) *entry_out = -1;
   for (uint32_t probe = 0; probe <= m.mask; ++probe) {
     const uint4 e = *reinterpret_cast<const uint4*>(&m.table[h]);
     const u64 k = ((u64)e.y << 32) | (u64)e.x;
-    if (k == key) { if (stamp_frame(e.w) == frame_id && (e.w & cam_bit)) return false; slot = e.z; cur = e.w; found = true; break; }
+    if (k == key) { if (entry_out) *entry_out = (int32_t)h; if (stamp_frame(e.w) == frame_id && (e.w & cam_bit)) return false; slot = e.z; cur = e.w; found = true; break; }
     if (k == KEY_EMPTY) break;           // (may be a stale EMPTY: hash_insert's CAS is the truth)
     h = (h + 1) & m.mask;
   }
@@ -169,6 +173,7 @@ __device__ inline bool mark_block(const DMap& m, u64 key, uint32_t frame_id, uin
     const int32_t hi = hash_insert(m, x, y, z, F_TSDF, &is_new);
     if (hi < 0) return false;
     h = (uint32_t)hi;
+    if (entry_out) *entry_out = hi;
   }
   if (!stamp_claim(&m.table[h].stamp, cur, frame_id, cam_bit)) return false;
   while (slot == SLOT_INVALID) slot = ld_slot_acquire(&m.table[h]);     // the inserting lane publishes right after its CAS
@@ -506,6 +511,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       if (NB > 1) cams = __builtin_amdgcn_readfirstlane(m.table[m.slot_entry[slot]].stamp & 0xFFu);
       uint32_t old = 0;
       if (tid == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH | ((Sensor::kLongRays && (Plain || !f0.occupancy)) ? F_BAND_STALE : 0u));
+      if (!Sensor::kLongRays && tid == 64) m.slot_cam[slot] = (f0.frame_id << 8) | cams;       // the camera view decayTsdfExcludeLastView<Camera> spares
       const int32_t bx = __builtin_amdgcn_readlane(rec.y, j), by = __builtin_amdgcn_readlane(rec.z, j), bz = __builtin_amdgcn_readlane(rec.w, j);
       float2 fin = cur_c;            // the voxel as this launch leaves it: the cameras' updates applied in order, exactly as separate calls would
       bool touched = false;
@@ -591,6 +597,7 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
 // the 24-bit view frame id of Entry::stamp: before it would wrap, every stamp is reset (once per 16.7 M depth frames)
 __global__ void k_reset_stamps(DMap m) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= m.mask; i += gridDim.x * blockDim.x) m.table[i].stamp = STAMP_NEVER;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m.capacity; i += gridDim.x * blockDim.x) m.slot_cam[i] = STAMP_NEVER;
   if (blockIdx.x == 0 && threadIdx.x < 4) m.counters[C_VIEW_COUNT + threadIdx.x] = 0;
 }
 static int next_frame_id(nvbx_mapper* m) {
@@ -721,6 +728,7 @@ __global__ __launch_bounds__(512) void k_measure_tsdf(DMap m, Frame f, Img depth
     if (got > 0) o = make_float2(ds, vd); else if (got < 0) o = make_float2(-1.0f, vd);
     MeasRec* r = out + i;
     if (tid == 0) { r->x = rec.y; r->y = rec.z; r->z = rec.w; r->rank = 0; }
+    if (tid == 64 && slot_ok((uint32_t)rec.x)) m.slot_cam[rec.x] = (f.frame_id << 8) | 1u;
     r->v[tid] = o;
   }
 }
@@ -736,10 +744,11 @@ __global__ void k_apply_index(DMap m, const MeasRec* all, const int32_t* counts,
     const int32_t x = rec->x, y = rec->y, z = rec->z;
     if (owner_mod > 1 && (int32_t)(index_hash(x, y, z) % (uint32_t)owner_mod) != owner_rank) continue;
     int4 out;
-    const bool first = mark_block(m, pack_key(x, y, z), frame_id, 1u << r, &out);
+    int32_t h = -1;
+    const bool first = mark_block(m, pack_key(x, y, z), frame_id, 1u << r, &out, &h);
     uint32_t slot;
     if (first) slot = (uint32_t)out.x;
-    else { slot = SLOT_INVALID; const int32_t h = hash_find(m, x, y, z); if (h >= 0) { do { slot = ld_slot_acquire(&m.table[h]); } while (slot == SLOT_INVALID); } }
+    else { slot = SLOT_INVALID; if (h >= 0) { do { slot = ld_slot_acquire(&m.table[h]); } while (slot == SLOT_INVALID); } }   // (the entry mark_block itself reached: no second lookup)
     if (!slot_ok(slot)) continue;                      // pool exhausted
     postab[(size_t)slot * MAX_BATCH + r] = (int32_t)i + 1;
     if (first) { const int32_t p = atomicAdd(cnt, 1); if (p < list_cap) view_list[p] = out; }
@@ -760,9 +769,11 @@ __global__ __launch_bounds__(512) void k_apply_fuse(DMap m, Frame f, const MeasR
     uint32_t old = 0;
     if (tid == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH);
     bool touched = false;
+    uint32_t cams = 0u;
     for (int r = 0; r < world; r++) {
       const int32_t p = postab[(size_t)slot * MAX_BATCH + r];      // uniform
       if (!p) continue;
+      cams |= 1u << r;
       const float2 mv = all[(size_t)r * stride + (p - 1)].v[tid];
       if (mv.y < 0.0f) continue;
       if (f.occupancy) { if (!(mv.x < 0.0f)) { fin = make_float2(occupancy_update(f, fin.x, mv.x, mv.y), 0.0f); touched = true; } }
@@ -770,6 +781,7 @@ __global__ __launch_bounds__(512) void k_apply_fuse(DMap m, Frame f, const MeasR
       else if (tsdf_fuse(f, &fin, mv.x, mv.y)) touched = true;
     }
     if (touched) *vp = fin;
+    if (tid == 64) m.slot_cam[slot] = (f.frame_id << 8) | cams;
     __syncthreads();                                                  // every lane has read the table before it is cleared
     if (tid < MAX_BATCH) postab[(size_t)slot * MAX_BATCH + tid] = 0;
     if (!f.occupancy) {
@@ -789,6 +801,10 @@ extern "C" int nvbx_measure_depth(nvbx_mapper* m, const float* depth_dev, int32_
   if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_measure_depth: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
   if (!nvbx_pose_in_range(T_L_C, m->p.voxel_size * 8.0f, m->p.max_integration_distance_m + 2.0f * m->p.truncation_distance_vox * m->p.voxel_size)) {
     set_error("nvbx_measure_depth: T_L_C is not finite or lies outside the addressable block range"); return NVBX_E_INVALID; }
+  // measure + apply is DEFINED as equal to nvbx_integrate_depth_batch; what the batch cannot express either (depth dilation, per-frame
+  // freespace time stamps) is refused here instead of silently measured without it
+  if (m->p.projective_layer_type == 2 || (m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0)) {
+    set_error("nvbx_measure_depth: mappers with depth preprocessing (dilation) or a freespace layer integrate per frame -- use nvbx_integrate_depth"); return NVBX_E_INVALID; }
   NVBX_HIP(hipSetDevice(m->device));
   if (m->join_side()) return NVBX_E_DEVICE;
   { const int rc = m->maybe_grow(); if (rc) return rc; }

@@ -130,13 +130,18 @@ class PipelinedDirtyBlockExchange:
 class MeasurementFusion:
     """One fused map from one camera per GPU (SURVEY.md 8e option B, made exact -- include/nvblox_hip.h "measurement exchange").
 
-    Per frame: mapper.measure_depth (this rank's view calculation + projection, the sharded part) -> ONE all_gather_into_tensor of the
-    measurement buffers (<= stride x 4112 B per rank; 300 blocks in view = 1.2 MB, 8 us of wire time on one xGMI link) + one of the
-    counts -> mapper.apply_measurements on every rank, in rank order.  Every rank then holds the SAME map, bit-identical to a single
-    mapper integrating the cameras in rank order; `sharded=True` keeps only the blocks this rank owns (Index3DHash mod world).
-    The mapper may be the HIP Mapper (device tensors, RCCL) or any object with the same two methods (CPU tensors, gloo: tests)."""
+    Per frame: mapper.measure_depth (this rank's view calculation + projection, the sharded part) -> all-gather of the record COUNTS
+    (4 B per rank) -> ONE all_gather_into_tensor of the first n records of every rank's buffer, n = max(count) rounded up to 64 records
+    (only what is used goes over the links: ~300 blocks in view = 320 records = 1.3 MB per rank, not the 4.2 MB the buffer is sized
+    for) -> mapper.apply_measurements on every rank, in rank order, with stride n.  Every rank then holds the SAME map, bit-identical
+    to a single mapper integrating the cameras in rank order; `sharded=True` keeps only the blocks this rank owns (Index3DHash mod
+    world).  Sizing the payload needs the counts on the HOST: this unpipelined form waits for them (one small D2H + sync per frame);
+    PipelinedMeasurementFusion below hides that wait and the payload's wire time behind a frame of GPU work.
+    The mapper may be the HIP Mapper (device tensors, RCCL) or any object with the same two methods (CPU tensors, gloo: tests).
+    `sent_records` / `used_records`: records per rank handed to the last payload collective / the largest count among the ranks."""
 
     BLOCK_BYTES = 4112
+    ROUND = 64
 
     def __init__(self, stride_blocks, device, group=None, sharded=False):
         self.group = group
@@ -144,10 +149,12 @@ class MeasurementFusion:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.stride = int(stride_blocks)
         self.sharded = bool(sharded)
+        self.device = device
         self.buf = torch.zeros((self.stride, self.BLOCK_BYTES), dtype=torch.uint8, device=device)
         self.cnt = torch.zeros((1,), dtype=torch.int32, device=device)
-        self.all_buf = torch.zeros((self.world, self.stride, self.BLOCK_BYTES), dtype=torch.uint8, device=device)
+        self.all_flat = torch.zeros((self.world * self.stride * self.BLOCK_BYTES,), dtype=torch.uint8, device=device)
         self.all_cnt = torch.zeros((self.world,), dtype=torch.int32, device=device)
+        self.sent_records = 0; self.used_records = 0; self.sent_bytes_total = 0; self.used_bytes_total = 0
 
     def _order(self, mapper, first, second):
         """event ordering between the mapper's stream and torch's current stream when they differ (see DirtyBlockExchange._streams)"""
@@ -158,20 +165,114 @@ class MeasurementFusion:
             return
         (cur if first == "mapper" else ms).wait_stream(ms if first == "mapper" else cur)
 
+    # -- the three pieces of the exchange (PipelinedMeasurementFusion re-orders them across frames)
+    def gather_counts(self, cnt, all_cnt):
+        if self.world == 1:
+            all_cnt.copy_(cnt)
+        else:
+            dist.all_gather_into_tensor(all_cnt, cnt, group=self.group)
+
+    def sized(self, counts_host):
+        """records per rank the payload collective carries: max(count) rounded up to ROUND, at least ROUND, at most the buffer"""
+        used = max(0, min(self.stride, max(int(c) for c in counts_host)))
+        n = min(self.stride, max(self.ROUND, -(-used // self.ROUND) * self.ROUND))
+        return n, used
+
+    def gather_payload(self, buf, n, async_op=False):
+        """all-gather the first n records of every rank's buffer into all_flat viewed as [world, n, 4112]"""
+        out = self.all_flat[: self.world * n * self.BLOCK_BYTES].view(self.world, n, self.BLOCK_BYTES)
+        self.sent_records = n; self.sent_bytes_total += n * self.BLOCK_BYTES
+        if self.world == 1:
+            out[0].copy_(buf[:n]); return out, None
+        work = dist.all_gather_into_tensor(out.view(-1, self.BLOCK_BYTES), buf[:n], group=self.group, async_op=async_op)
+        return out, (work if async_op else None)
+
+    def apply(self, mapper, gathered, all_cnt):
+        if self.sharded:
+            mapper.apply_measurements(gathered, all_cnt, self.world, self.rank)
+        else:
+            mapper.apply_measurements(gathered, all_cnt)
+
     def integrate_depth(self, mapper, depth, T_L_C, cam):
         """The multi-GPU form of MultiMapper::integrateDepth: collective, every rank calls it with its own camera frame."""
         mapper.measure_depth(depth, T_L_C, cam, self.buf, self.cnt)
-        self._order(mapper, "mapper", "torch")             # the collective reads the buffers only after the mapper's stream has written them
-        if self.world == 1:
-            self.all_buf[0].copy_(self.buf); self.all_cnt.copy_(self.cnt)
-        else:
-            dist.all_gather_into_tensor(self.all_cnt, self.cnt, group=self.group)
-            dist.all_gather_into_tensor(self.all_buf.view(-1, self.BLOCK_BYTES), self.buf, group=self.group)
+        self._order(mapper, "mapper", "torch")             # the collectives read the buffers only after the mapper's stream has written them
+        self.gather_counts(self.cnt, self.all_cnt)
+        n, used = self.sized(self.all_cnt.cpu().tolist())  # (synchronises: the payload is sized on the host)
+        self.used_records = used; self.used_bytes_total += used * self.BLOCK_BYTES
+        gathered, _ = self.gather_payload(self.buf, n)
         self._order(mapper, "torch", "mapper")
-        if self.sharded:
-            mapper.apply_measurements(self.all_buf, self.all_cnt, self.world, self.rank)
-        else:
-            mapper.apply_measurements(self.all_buf, self.all_cnt)
+        self.apply(mapper, gathered, self.all_cnt)
+
+
+class PipelinedMeasurementFusion:
+    """MeasurementFusion software-pipelined by one frame, like PipelinedDirtyBlockExchange: nothing waits for a collective it has just
+    started.  Per step i the caller runs
+
+        begin(mapper, depth_i, T_i, cam)     1. payload all-gather of frame i-1 STARTS (sized from its counts, which reached the host a
+                                                frame ago) -- 2. measure_depth of frame i runs while it is in flight -- 3. the count
+                                                all-gather of frame i + an asynchronous D2H of the counts are enqueued
+        if finish_previous(mapper): ...      4. the payload of frame i-1 is joined and applied (rank order); returns True if a frame was
+                                                applied -- the caller then runs integrateColor / updateEsdf OF FRAME i-1
+        drain(mapper)                        after the last frame: its payload is gathered and applied
+
+    measure_depth does not read voxel values (it allocates the blocks in view and samples the depth image), so measuring frame i
+    before frame i-1 is applied changes nothing: the map after every apply is bit-identical to the unpipelined form and to ONE mapper
+    integrating the cameras in rank order.  Two measurement buffers alternate (the collective in flight reads one while measure_depth
+    writes the other)."""
+
+    def __init__(self, stride_blocks, device, group=None, sharded=False):
+        self.f = MeasurementFusion(stride_blocks, device, group, sharded)
+        self.world = self.f.world
+        cuda = self.f.buf.is_cuda
+        self.bufs = [self.f.buf, torch.zeros_like(self.f.buf)]
+        self.cnts = [self.f.cnt, torch.zeros_like(self.f.cnt)]
+        self.all_cnts = [self.f.all_cnt, torch.zeros_like(self.f.all_cnt)]
+        self.host_cnts = [torch.zeros((self.world,), dtype=torch.int32, pin_memory=cuda) for _ in range(2)]
+        self.events = [torch.cuda.Event() if cuda else None for _ in range(2)]
+        self.frame = 0
+        self.pending = None          # slot of the frame measured but not yet gathered / applied
+        self.inflight = None         # (slot, gathered view, work) of the payload collective started by begin()
+
+    def _start_payload(self, mapper, slot):
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()          # recorded a frame ago: the counts are on the host by now
+        n, used = self.f.sized(self.host_cnts[slot].tolist())
+        self.f.used_records = used; self.f.used_bytes_total += used * self.f.BLOCK_BYTES
+        self.f._order(mapper, "mapper", "torch")
+        gathered, work = self.f.gather_payload(self.bufs[slot], n, async_op=True)
+        self.inflight = (slot, gathered, work)
+
+    def begin(self, mapper, depth, T_L_C, cam):
+        if self.pending is not None:
+            self._start_payload(mapper, self.pending); self.pending = None
+        slot = self.frame & 1
+        mapper.measure_depth(depth, T_L_C, cam, self.bufs[slot], self.cnts[slot])
+        self.f._order(mapper, "mapper", "torch")
+        self.f.gather_counts(self.cnts[slot], self.all_cnts[slot])
+        self.host_cnts[slot].copy_(self.all_cnts[slot], non_blocking=True)
+        if self.events[slot] is not None:
+            self.events[slot].record(torch.cuda.current_stream(self.f.buf.device))
+        self.pending = slot
+        self.frame += 1
+
+    def finish_previous(self, mapper):
+        if self.inflight is None:
+            return False
+        slot, gathered, work = self.inflight; self.inflight = None
+        if work is not None:
+            work.wait()
+        self.f._order(mapper, "torch", "mapper")
+        self.f.apply(mapper, gathered, self.all_cnts[slot])
+        return True
+
+    def drain(self, mapper):
+        """Apply what is still on its way; returns the number of frames applied (0, 1 or 2) -- the caller owes each its colour / ESDF."""
+        n = 1 if self.finish_previous(mapper) else 0
+        if self.pending is not None:
+            self._start_payload(mapper, self.pending); self.pending = None
+            n += 1 if self.finish_previous(mapper) else 0
+        return n
 
 
 def camera_yaw_offset_deg(rank, world):

@@ -126,6 +126,7 @@ typedef struct Block {
   FreespaceVoxel* fs;     /* [512] */
   MeshBlock mesh;
   int32_t stamp_view, stamp_esdf, dirty_esdf, dirty_mesh, remark_esdf;
+  int32_t stamp_cam;                           /* last CAMERA depth frame that had the block in view (a LiDAR scan does not touch it) */
 } Block;
 
 enum { L_TSDF = 1, L_COLOR = 2, L_ESDF = 4, L_MESH = 8, L_FREESPACE = 32 };
@@ -186,7 +187,7 @@ static Block* map_get_or_create(OrcMap* m, Idx3 i) {
     free(old);
   }
   b = (Block*)calloc(1, sizeof(Block));
-  b->idx = i; b->stamp_view = -1; b->stamp_esdf = -1;
+  b->idx = i; b->stamp_view = -1; b->stamp_esdf = -1; b->stamp_cam = -1;
   map_put_raw(m, b);
   if (m->count + 1 > m->order_cap) {
     m->order_cap = m->order_cap ? m->order_cap * 2 : 1024;
@@ -391,6 +392,7 @@ static void view_push(OrcMap* m, Idx3 i) {
   Block* b = map_get_or_create(m, i);
   if (b->stamp_view == m->frame) return;
   b->stamp_view = m->frame;
+  if (m->camera_frame == m->frame) b->stamp_cam = m->frame;     /* (camera entry points set camera_frame = frame before the view calculation) */
   ensure_layer(b, L_TSDF);
   b->dirty_esdf = 1; b->dirty_mesh = 1;
   if (m->n_view + 1 > m->view_cap) { m->view_cap = m->view_cap ? m->view_cap * 2 : 1024; m->view = (Idx3*)realloc(m->view, (size_t)m->view_cap * sizeof(Idx3)); }
@@ -1521,7 +1523,7 @@ int64_t orc_decay_tsdf(OrcMap* m, int exclude_last_view) {
   for (int64_t q = 0; q < m->count; q++) {
     Block* b = m->order[q];
     int drop = 0;
-    if ((b->flags & L_TSDF) && !(exclude_last_view && m->camera_frame > 0 && b->stamp_view == m->camera_frame)) {
+    if ((b->flags & L_TSDF) && !(exclude_last_view && m->camera_frame > 0 && b->stamp_cam == m->camera_frame)) {
       int alive = 0;
       for (int i = 0; i < NVOX; i++) { b->tsdf[i].weight = b->tsdf[i].weight * p->tsdf_decay_factor; if (!(b->tsdf[i].weight < p->tsdf_decayed_weight_threshold)) alive = 1; }
       b->dirty_esdf = 1; b->dirty_mesh = 1;

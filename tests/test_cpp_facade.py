@@ -409,3 +409,6 @@ def test_rccl_fusion_example_runs(hip_lib):
     assert r.returncode == 0, r.stdout[-500:] + r.stderr[-2000:]
     got = json.loads(r.stdout.strip().splitlines()[-1])
     assert got["gpus"] >= 1 and got["ranks_differing_from_single_mapper"] == 0 and got["tsdf_blocks"] > 100
+    # only the used records travel: within one 64-record rounding step of the used bytes per frame, far below the fixed-size buffer
+    assert got["payload_bytes_used"] <= got["payload_bytes_sent_per_rank"] <= got["payload_bytes_used"] + got["frames"] * 64 * 4112
+    assert got["payload_bytes_sent_per_rank"] < 0.6 * got["buffer_bytes"]

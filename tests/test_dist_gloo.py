@@ -119,7 +119,7 @@ def test_pipelined_exchange_applies_every_list_once_one_frame_late_world2():
 
 
 # ---------------------------------------------------------------------------------------------- one fused map: measurement exchange
-def _fusion_worker(rank, world, port, q, sharded):
+def _fusion_worker(rank, world, port, q, sharded, pipelined=False):
     """Every rank integrates ITS camera through dist.MeasurementFusion (gloo all-gather of the measurement records) into a CPU map (the
     oracle as the rank's mapper); the result must be the map ONE mapper gets from the same cameras in rank order -- bit for bit."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -133,19 +133,33 @@ def _fusion_worker(rank, world, port, q, sharded):
     p = oracle.default_params(weighting_mode=4, invalid_depth_decay_factor=0.8, max_weight=3.0)
     mine = oracle.OracleMap(p)
     single = oracle.OracleMap(p)                       # the reference: all cameras, in rank order, through one mapper
-    fusion = MeasurementFusion(1024, torch.device("cpu"), sharded=sharded)
+    from isaac_ros_nvblox_amd.dist import PipelinedMeasurementFusion
+    fusion = PipelinedMeasurementFusion(1024, torch.device("cpu"), sharded=sharded) if pipelined else MeasurementFusion(1024, torch.device("cpu"), sharded=sharded)
+    core = fusion.f if pipelined else fusion
     sc = S.Scene()
-    for k in range(3):
+    ok = True
+    applied = 0
+    for k in range(4 if pipelined else 3):
         frames = []
         for r in range(world):
             T = S.trajectory_pose(k * 11, 200, yaw_offset_deg=45.0 * r)      # overlapping views
             d, _ = S.render(sc, T, cam, color=False)
             d[10:30, 20:60] = 0.0                                             # invalid depth: the decay path is exchanged too
             frames.append((d, T))
-        fusion.integrate_depth(mine, frames[rank][0], frames[rank][1], cam)
+        if pipelined:                                                         # bench.py's step order: begin(i), finish_previous() -> frame i-1 applied
+            fusion.begin(mine, frames[rank][0], frames[rank][1], cam)
+            applied += 1 if fusion.finish_previous(mine) else 0
+            ok = ok and applied == k                                          # one frame late
+        else:
+            fusion.integrate_depth(mine, frames[rank][0], frames[rank][1], cam)
+        # only what is used goes to the collective: the payload is max(count) rounded up to 64 records, never the 1024-record buffer
+        if not pipelined or k > 0:
+            ok = ok and 0 < core.used_records <= core.sent_records <= core.used_records + 63 and core.sent_records % 64 == 0 and core.sent_records < 1024
         for d, T in frames:
             single.integrate_depth(d, T, cam)
-    ok = True
+    if pipelined:
+        ok = ok and fusion.drain(mine) == 1 and fusion.drain(mine) == 0
+    ok = ok and core.sent_bytes_total <= 1.25 * core.used_bytes_total + 64 * 4112
     idx_single = single.block_indices(oracle.L_TSDF)
     idx_mine = mine.block_indices(oracle.L_TSDF)
     n_cmp = 0
@@ -168,11 +182,11 @@ def _fusion_worker(rank, world, port, q, sharded):
     dist.destroy_process_group()
 
 
-def _run_fusion(world, sharded):
+def _run_fusion(world, sharded, pipelined=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_fusion_worker, args=(r, world, port, q, sharded)) for r in range(world)]
+    procs = [ctx.Process(target=_fusion_worker, args=(r, world, port, q, sharded, pipelined)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -191,3 +205,16 @@ def test_measurement_fusion_owner_shards_partition_the_single_mapper_map_world3(
     res = _run_fusion(3, sharded=True)
     assert [r[:2] for r in res] == [(0, True), (1, True), (2, True)]
     assert sum(r[2] for r in res) == res[0][3] and min(r[2] for r in res) > 50          # the shards partition the map
+
+
+def test_pipelined_measurement_fusion_equals_single_mapper_world2():
+    """dist.PipelinedMeasurementFusion: payload of frame i-1 in flight while frame i is measured, applied one frame late, the last one
+    by drain(); same map as ONE mapper, bit for bit; the bytes handed to the collective follow the used records (<= 1.25 x)."""
+    res = _run_fusion(2, sharded=False, pipelined=True)
+    assert [r[:2] for r in res] == [(0, True), (1, True)] and all(r[2] == r[3] > 300 for r in res)
+
+
+def test_pipelined_measurement_fusion_owner_shards_world3():
+    res = _run_fusion(3, sharded=True, pipelined=True)
+    assert [r[:2] for r in res] == [(0, True), (1, True), (2, True)]
+    assert sum(r[2] for r in res) == res[0][3] and min(r[2] for r in res) > 50

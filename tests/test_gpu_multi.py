@@ -113,3 +113,47 @@ def test_measurement_exchange_equals_one_mapper_batch(oracle_mod, hip_lib):
     bi = shard.block_indices(M.LAYER_TSDF)
     b, _ = shard.get_blocks(M.LAYER_TSDF, bi)
     assert len(bi) > 20 and all(int(oracle_mod.lib().orc_index_hash(int(x), int(y), int(z))) % world == 2 for x, y, z in bi.tolist())
+
+
+def test_pipelined_measurement_fusion_on_the_hip_mapper(oracle_mod, hip_lib):
+    """dist.PipelinedMeasurementFusion driving the HIP mapper (world 1: the collectives are local copies, everything else -- the sized
+    payload view with stride = max(count) rounded to 64 records instead of the 1024-record buffer, two alternating measurement buffers,
+    the count's asynchronous D2H + event, apply one frame late, colour + ESDF of the applied frame, drain) is the multi-GPU code path.
+    The fused mapper must equal a plain mapper fed integrateDepth / integrateColor / updateEsdf frame by frame, bit for bit."""
+    import torch
+    from isaac_ros_nvblox_amd import mapper as M
+    from isaac_ros_nvblox_amd.dist import PipelinedMeasurementFusion
+    from test_gpu_parity import compare_layer
+    cam = H.SMALL_CAM
+    pg = M.default_params(invalid_depth_decay_factor=0.8)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        fused = M.Mapper(pg, block_capacity=1 << 13, stream=stream.cuda_stream)
+        plain = M.Mapper(pg, block_capacity=1 << 13)
+        o = oracle_mod.OracleMap(H.copy_params(pg, oracle_mod.OrcParams))
+        mf = PipelinedMeasurementFusion(1024, torch.device("cuda", 0))
+        fr = H.frames(6, cam, stride=9)
+        prev = None
+        for k, (d, rgb, T) in enumerate(fr):
+            mf.begin(fused, d, T, cam)
+            if mf.finish_previous(fused):
+                fused.integrate_color(prev[1], prev[2], cam); fused.update_esdf()
+                assert 0 < mf.f.used_records <= mf.f.sent_records <= mf.f.used_records + 63 and mf.f.sent_records < 1024
+            prev = (d, rgb, T)
+            plain.integrate_depth(d, T, cam); plain.integrate_color(rgb, T, cam); plain.update_esdf()
+            o.integrate_depth(d, T, cam); o.integrate_color(rgb, T, cam); o.update_esdf()
+        assert mf.drain(fused) == 1
+        fused.integrate_color(prev[1], prev[2], cam); fused.update_esdf()
+        assert mf.f.sent_bytes_total <= 1.25 * mf.f.used_bytes_total + 64 * 4112
+    idx = plain.block_indices(M.LAYER_TSDF)
+    assert np.array_equal(fused.block_indices(M.LAYER_TSDF), idx) and len(idx) > 300
+    for layer, fields in ((M.LAYER_TSDF, ("distance", "weight")), (M.LAYER_COLOR, ("r", "g", "b", "weight"))):
+        ia = plain.block_indices(layer)
+        assert np.array_equal(fused.block_indices(layer), ia)
+        a, _ = plain.get_blocks(layer, ia); b, _ = fused.get_blocks(layer, ia)
+        for f in fields:
+            assert np.array_equal(a[f], b[f]), (layer, f)
+    sa, aa = plain.esdf_slice_image(); sb, ab = fused.esdf_slice_image()
+    assert sa.shape == sb.shape and np.array_equal(sa, sb) and np.array_equal(aa, ab)
+    n, _ = compare_layer(M, fused, o, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
+    assert n > 300

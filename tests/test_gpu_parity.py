@@ -470,13 +470,13 @@ def test_esdf_3d_parity(oracle_mod, hip_lib):
     assert g.counters()["capacity_overflow"] == 0
 
 
-def test_dynamic_mapping_parity(oracle_mod, hip_lib):
+@pytest.mark.parametrize("cam", [H.SMALL_CAM, S.REPLICA_LIKE_CAM], ids=["160x120", "640x480"])
+def test_dynamic_mapping_parity(oracle_mod, hip_lib, cam):
     """MappingType::kDynamic (nvblox_dynamics.yaml): the static mapper carries a freespace layer (projective_layer_type 2); depth
     pixels whose points fall into high-confidence freespace are dynamic; the mask is cleaned of small components, splits the
     depth image, and the dynamic part feeds an occupancy mapper.  Freespace voxels (timestamps, durations, flags), dynamic masks,
     cleaned masks and both maps are bit-exact against the oracle."""
     from isaac_ros_nvblox_amd import mapper as M
-    cam = H.SMALL_CAM
     fs = dict(projective_layer_type=2, max_integration_distance_m=5.0, invalid_depth_decay_factor=0.8, max_tsdf_distance_for_occupancy_m=0.15,
               max_unobserved_to_keep_consecutive_occupancy_ms=200, min_duration_since_occupied_for_freespace_ms=250,
               min_consecutive_occupancy_duration_for_reset_ms=600, check_neighborhood=1, initialize_to_high_confidence_freespace=0)

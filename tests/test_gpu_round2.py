@@ -57,6 +57,15 @@ def test_decay_excludes_the_camera_view_not_the_lidar_view(oracle_mod, hip_lib):
     bc, _ = g.get_blocks(M.LAYER_TSDF, only_cam); bl, _ = g.get_blocks(M.LAYER_TSDF, only_lidar)
     assert set(np.unique(bc["weight"]).tolist()) <= {0.0, 1.0}
     assert set(np.unique(bl["weight"]).tolist()) <= {0.0, 0.5}
+    # blocks in BOTH views (the LiDAR scan re-claimed their shared view stamp after the camera frame): still the camera's
+    # view, so not decayed -- weights are sums of the two undecayed measurements, never a halved one
+    both = sorted(cam_view & lidar_view)
+    assert len(both) > 20
+    bb, _ = g.get_blocks(M.LAYER_TSDF, both)
+    wb = set(np.unique(bb["weight"]).tolist())
+    assert wb <= {0.0, 1.0, 2.0} and 2.0 in wb, wb
+    for idx in both[:: max(1, len(both) // 40)]:
+        assert set(np.unique(o.get_block(oracle_mod.L_TSDF, idx)["weight"]).tolist()) <= {0.0, 1.0, 2.0}, idx
 
 
 def test_cleared_blocks_are_reported_for_decay_and_radius_clearing(oracle_mod, hip_lib):

@@ -86,8 +86,9 @@ def test_random_api_sequence_parity(oracle_mod, hip_lib, seed):
     assert n_ops["depth"] >= 5
 
 
-def test_redwood_like_decay_dynamic_sequence(oracle_mod, hip_lib):
-    """configs[2]: 8 x 6 x 2.8 m room, a box translating at 0.5 m/s, decay 0.95 every 6th frame (5 Hz at 30 Hz input),
+@pytest.mark.parametrize("CAM", [H.SMALL_CAM, S.REPLICA_LIKE_CAM], ids=["160x120", "640x480"])
+def test_redwood_like_decay_dynamic_sequence(oracle_mod, hip_lib, CAM):
+    """configs[2] (at the reduced and at BASELINE.json's real image size): 8 x 6 x 2.8 m room, a box translating at 0.5 m/s, decay 0.95 every 6th frame (5 Hz at 30 Hz input),
     invalid_depth_decay_factor 0.8, depth limited to 5 m so that part of every frame is invalid."""
     M, g, o = make_pair(oracle_mod, tsdf_decay_factor=0.95, invalid_depth_decay_factor=0.8, max_integration_distance_m=5.0)
     for i in range(30):
