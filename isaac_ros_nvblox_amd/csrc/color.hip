@@ -10,6 +10,7 @@
 //                     ([U] ProjectiveColorIntegrator::integrateFrame restated).
 // Call site served: nvblox_ros/src/lib/nvblox_node.cpp:1264.
 #include <algorithm>
+#include <cstdlib>
 #include "nvbx_mapper.h"
 #include "nvbx_esdf_mark.h"
 
@@ -17,7 +18,10 @@ using namespace nvbx;
 
 // TSDF reads below skip the layer-flag load: the TSDF pool of a slot that does not carry F_TSDF is all-zero (freed /
 // ESDF-only slots are zeroed, maintenance.hip), and weight 0 reads as "unobserved" exactly like a missing block.
-constexpr int RAY_LANES = 8;    // lanes cooperating on one ray = samples fetched per round trip (4: 13.7, 8: 13.4, 16: 14.5, 32: 21.4 us)
+// RAY_LANES (template parameter RL below) = lanes cooperating on one ray = samples fetched per round trip.  One camera: 8 (4: 13.7, 8: 13.4,
+// 16: 14.5, 32: 21.4 us -- 19 200 rays x 8 lanes = 2 400 wavefronts, about one resident round of the chip).  A BATCH of n cameras has n
+// times the rays: the latency trick that fills an idle chip for one camera turns into n occupancy rounds of mostly speculative samples, so
+// the batch launches with fewer lanes per ray (sphere_trace_lanes() below; tools: NVBX_ST_LANES).
 
 // [U] SphereTracer::cast restated, sample-parallel.  The serial march t <- t + tsdf(t) (nearest voxel) is a chain of
 // dependent HBM round trips (hash entry, then voxel) plus ~150 ALU ops per step, and a ray takes 10-20 steps.  But the
@@ -31,7 +35,7 @@ constexpr int RAY_LANES = 8;    // lanes cooperating on one ray = samples fetche
 template <int NB> struct PoseSet { Frame f[NB]; int32_t n; };
 template <typename Pix, int NB> struct FrameSetC { Frame f[NB]; Pix img[NB]; int32_t n; int32_t chunk; };
 
-template <int NB>
+template <int NB, int RAY_LANES>
 __global__ __launch_bounds__(256) void k_sphere_trace(DMap m, PoseSet<NB> poses, float* synth_all, int32_t srows, int32_t scols, int32_t max_steps,
                                                       float max_len, float eps_m) {
   const int tid = threadIdx.x;
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(256) void k_sphere_trace(DMap m, PoseSet<NB> poses,
   // dealt out in row-major order every XCD marches through EVERY part of the frustum and fetches its own copy of every TSDF block
   // and hash line (PMC: 6.6 MB of HBM traffic for 1.0 MB of blocks).  Instead a workgroup takes an 8 x 4 patch of rays, and the
   // patches are numbered so that the workgroups of one XCD (blockIdx.x & 7) own a contiguous band of patch rows.
-  constexpr int PW = 8, PH = (256 / RAY_LANES) / PW;       // 32 rays per 256-thread workgroup
+  constexpr int PW = 8, PH = (256 / RAY_LANES) / PW;       // 256 / RAY_LANES rays per 256-thread workgroup (32 at 8 lanes per ray)
   const int patches_x = (scols + PW - 1) / PW, patches_y = (srows + PH - 1) / PH;
   const int n_patch = patches_x * patches_y, per_xcd = (n_patch + NSH - 1) / NSH;
   const int cam = NB > 1 ? (int)blockIdx.x / (NSH * per_xcd) : 0;          // batch: NSH * per_xcd workgroups per camera, camera after camera
@@ -296,6 +300,15 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, FrameSetC<Pix, 
   }
 }
 
+// lanes per ray of the sphere-tracing launch for a batch of n cameras (1, 2, 4 or 8)
+static int sphere_trace_lanes(int n) {
+  static const int forced = getenv("NVBX_ST_LANES") ? atoi(getenv("NVBX_ST_LANES")) : 0;       // (sweeps)
+  if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
+  // measured (tools/st_lanes_sweep.sh, profiles/r03d_st_lanes.txt; us per launch at 8 / 4 / 2 / 1 lanes): 8 cameras 30.6 / 23.6 / 21.8 / 26.3,
+  // 4 cameras 20.0 / 16.7 / 18.2 / 24.4, 2 cameras 13.1 / 13.5 / 16.1 / 21.4
+  return n >= 6 ? 2 : (n >= 3 ? 4 : 8);
+}
+
 // n colour frames (n = 1: MultiMapper::integrateColor; n > 1: nvbx_integrate_color_batch) of one image size -> one launch set
 template <typename Pix, int NB>
 static int integrate_colors(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t rows, int32_t cols, const float* T_L_C /* n x 16 */, const nvbx_camera* cameras) {
@@ -324,10 +337,15 @@ static int integrate_colors(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t 
     m->synth_cap = (int64_t)srows * scols * n;
   }
   m->synth_rows = srows; m->synth_cols = scols; m->synth_last = n - 1;
-  // one 256-thread workgroup per 8 x 4 patch of rays, NSH x ceil(patches / NSH) workgroups per camera (XCD-banded numbering, see the kernel)
-  const int st_patches = ((scols + 7) / 8) * ((srows + (256 / RAY_LANES / 8) - 1) / (256 / RAY_LANES / 8));
-  NVBX_LAUNCH(m, (k_sphere_trace<NB>), dim3((unsigned)(NSH * ((st_patches + NSH - 1) / NSH) * n)), dim3(256), m->d, ps, m->synth, srows, scols, m->p.sphere_tracing_max_steps,
-                     m->p.sphere_tracing_max_ray_length_m, m->p.sphere_tracing_surface_eps_vox * m->p.voxel_size);
+  // one 256-thread workgroup per 8 x (32 / lanes) patch of rays, NSH x ceil(patches / NSH) workgroups per camera (XCD-banded numbering, see the kernel)
+  const int rl = sphere_trace_lanes(n);
+  const int ph = 256 / rl / 8;
+  const int st_patches = ((scols + 7) / 8) * ((srows + ph - 1) / ph);
+  const dim3 st_grid((unsigned)(NSH * ((st_patches + NSH - 1) / NSH) * n));
+#define NVBX_ST_LAUNCH(RL) NVBX_LAUNCH(m, (k_sphere_trace<NB, RL>), st_grid, dim3(256), m->d, ps, m->synth, srows, scols, m->p.sphere_tracing_max_steps, \
+                                       m->p.sphere_tracing_max_ray_length_m, m->p.sphere_tracing_surface_eps_vox * m->p.voxel_size)
+  if (rl == 8) NVBX_ST_LAUNCH(8); else if (rl == 4) NVBX_ST_LAUNCH(4); else if (rl == 2) NVBX_ST_LAUNCH(2); else NVBX_ST_LAUNCH(1);
+#undef NVBX_ST_LAUNCH
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);     // one resident batch of 512-thread workgroups
   // ESDF site marking of the blocks dirtied since the last marking pass rides in this launch (256 extra single-wavefront
   // workers): it reads only the TSDF, like the colour pass, and a following updateEsdf then needs the EDT kernel only

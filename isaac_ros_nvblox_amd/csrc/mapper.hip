@@ -216,7 +216,7 @@ static int alloc_all(nvbx_mapper* m) {
   NVBX_HIP(hipHostMalloc(&m->h_shc, S_NUM * NSH * SH_STRIDE * 4));
   NVBX_HIP(hipHostMalloc(&m->h_mirror, 64, hipHostMallocMapped));
   { void* dp = nullptr; NVBX_HIP(hipHostGetDevicePointer(&dp, m->h_mirror, 0)); d.host_mirror = (int32_t*)dp; }
-  m->h_mirror[0] = (int32_t)cap; m->h_mirror[1] = 0;
+  m->h_mirror[0] = (int32_t)cap; m->h_mirror[1] = 0; m->h_mirror[2] = 0;
   return NVBX_OK;
 }
 
@@ -237,7 +237,7 @@ static int reset_map(nvbx_mapper* m) {
   NVBX_HIP(hipGetLastError());
   m->dirty_since_mark = false; m->premark_consumed = false; m->mark_pass = 0; m->edt_pending = false; m->import_pending = false;
   m->unresolved_marks = false; m->pass_at_last_edt = 0;
-  if (m->h_mirror) { m->h_mirror[0] = (int32_t)m->capacity; m->h_mirror[1] = 0; }
+  if (m->h_mirror) { m->h_mirror[0] = (int32_t)m->capacity; m->h_mirror[1] = 0; m->h_mirror[2] = 0; }
   m->frame_id = 0; m->esdf_epoch = 0; m->mesh_epoch = 0; m->last_view_frame = 0; m->last_camera_view_frame = 0; m->synth_rows = m->synth_cols = 0;
   return NVBX_OK;
 }

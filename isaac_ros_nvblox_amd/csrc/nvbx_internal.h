@@ -133,7 +133,8 @@ struct DMap {
   u64* inside_bits;         // per slot: inside mask of the slice plane, as of the last marking pass
   int32_t* shc;             // sharded counters (S_* above)
   int32_t* lists;           // N_LISTS x NSH x capacity slot ids: list l, shard s starts at ((l * NSH + s) * capacity)
-  int32_t* host_mirror;     // pinned host memory, device-mapped: [0] = free slots as of the last TSDF-update launch (pool growth, mapper.hip)
+  int32_t* host_mirror;     // pinned host memory, device-mapped: [0] = free slots as of the last TSDF-update launch (pool growth, mapper.hip),
+                            //   [1] = high-water mark, [2] = blocks in view of that launch (sizes the next TSDF-update grid)
 };
 
 // Per-call camera / pose / parameter bundle (kernel argument, lives in SGPRs).

@@ -472,17 +472,23 @@ template <typename T> __device__ inline T in_vgpr(T x) { asm volatile("" : "+v"(
 // at compile time -- same arithmetic, 12 % fewer issue cycles on the LiDAR launch (tools/variant_ab.sh).
 template <typename Img, typename Sensor, int NB, bool Plain>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_integrate_tsdf(DMap m, FrameSet<Img, NB> fs, Sensor sensor, const int4* view_list, int32_t list_cap,
-                                                        int32_t mesh_list, int32_t* view_export, int32_t view_export_cap) {
+                                                        int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes) {
   const Frame& f0 = fs.f[0];
   const int tid = threadIdx.x, lane = tid & 63;
   // The view records are taken 64 at a time: lane j of every wavefront fetches the record of the j-th block this workgroup will
   // process next (speculatively, beside the count) and transforms that block's origin into the sensor frame; the block loop then
   // reads slot and origin out of lane j (v_readlane: scalar operands from there on).  The record fetch leaves the per-block
   // dependent chain and the 3 x 3 transform is paid once per block and wavefront instead of once per voxel.
+  // Only the first `spec_lanes` lanes fetch speculatively (a host hint: the view count the GPU last reported / the grid, + 1): a camera
+  // frame has ~300 blocks in view and about as many workgroups, so one record per wavefront is wanted -- 64 speculative 16-B records from
+  // each of 8 x 1024 wavefronts were 8 MB of HBM traffic for 3.5 MB of work (PMC, profiles/r02z_pmc.json).  A lane the hint left out
+  // fetches once the count is known (a dependent load, only when the view grew by more than the hint's margin).
   int32_t mine = (int32_t)blockIdx.x + lane * (int32_t)gridDim.x;
-  int4 rec = mine < list_cap ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
+  int4 rec = (lane < spec_lanes && mine < list_cap) ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
   int32_t n = m.counters[C_VIEW_COUNT + (f0.frame_id & 3)];
   if (n > list_cap) n = list_cap;
+  if (lane >= spec_lanes && mine < n) rec = view_list[mine];
+  if (blockIdx.x == 0 && tid == 192) __hip_atomic_store(&m.host_mirror[2], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // next launch's hint
   // nvbx_set_view_export: the frame's block indices also go to a caller-owned packed buffer [1 + cap][3] (row 0 = count) --
   // the message of the multi-GPU exchange, written here instead of by an export launch
   if (view_export && blockIdx.x == 0 && tid == 0) { view_export[0] = min(n, view_export_cap); view_export[1] = 0; view_export[2] = 0; }
@@ -580,13 +586,18 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   m->premark_consumed = false; m->dirty_since_mark = true;
   // grid-stride over the view list: exactly the 1024 workgroups that are resident together (4 per CU)
   static const int grid_cap = getenv("NVBX_INTEG_GRID") ? atoi(getenv("NVBX_INTEG_GRID")) : 1024;    // (env: tools/integ_grid_sweep.sh)
-  const int grid = (int)std::min<int64_t>(m->capacity, grid_cap);
+  // ... or fewer when the view is smaller: sized from the view count of the last launch the GPU has finished (pinned host memory, not
+  // waited for) + 25 % + 64; a hint only -- the kernel grid-strides over whatever the count turns out to be
+  const int64_t n_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[2], __ATOMIC_RELAXED));
+  const int64_t want = ((n_hint + n_hint / 4 + 64 + 7) / 8) * 8;
+  const int grid = (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, grid_cap), want));
+  const int32_t spec_lanes = (int32_t)std::min<int64_t>(64, (n_hint + n_hint / 4 + 64 + grid - 1) / grid);
   bool plain = true;
   for (int c = 0; c < fs.n; c++) plain = plain && frame_is_plain(fs.f[c]);
   if (plain) NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor, NB, true>), dim3(grid), dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
-                         m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap);
+                         m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes);
   else NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor, NB, false>), dim3(grid), dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
-                   m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap);
+                   m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes);
   NVBX_HIP(hipGetLastError());
   m->last_view_frame = m->frame_id;
   if (!Sensor::kLongRays) { m->last_camera_view_frame = m->frame_id; m->last_camera_view_mask = 1u << (fs.n - 1); }   // (a batch: the LAST camera's view, as separate calls would leave it)

@@ -411,4 +411,4 @@ def test_rccl_fusion_example_runs(hip_lib):
     assert got["gpus"] >= 1 and got["ranks_differing_from_single_mapper"] == 0 and got["tsdf_blocks"] > 100
     # only the used records travel: within one 64-record rounding step of the used bytes per frame, far below the fixed-size buffer
     assert got["payload_bytes_used"] <= got["payload_bytes_sent_per_rank"] <= got["payload_bytes_used"] + got["frames"] * 64 * 4112
-    assert got["payload_bytes_sent_per_rank"] < 0.6 * got["buffer_bytes"]
+    assert got["payload_bytes_sent_per_rank"] < 0.75 * got["buffer_bytes"]     # (a 160 x 120 wide-angle view of the whole room: ~600 blocks of the 1024-record buffer)
