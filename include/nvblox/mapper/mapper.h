@@ -225,42 +225,23 @@ class Mapper {
   // Mesh streaming is rationed like the reference's layer streamer (layer_streamer_bandwidth_limit_mbps, nvblox_base.yaml:110):
   // the blocks of every mesh update since the last call join a queue (a newer mesh of a queued block replaces it in place),
   // and each call sends the oldest blocks that fit into bandwidth_limit_mbps x (time since the last call, at most 1 s); at
-  // least one block is sent so that the queue always drains.  bandwidth_limit_mbps < 0: no limit.  The TSDF / colour voxel streams are
-  // rationed nearest-first (below); occupancy / freespace layers are sent whole.
+  // least one block is sent so that the queue always drains.  bandwidth_limit_mbps < 0: no limit.  Every voxel-layer stream (TSDF / colour,
+  // occupancy, freespace) is cut to the exclusion cylinder and rationed nearest-first (selectBlocksToStream below).
   void serializeSelectedLayers(LayerTypeBitMask layers, float bandwidth_limit_mbps = -1.f, const BlockExclusionParams& ex = BlockExclusionParams()) {
     if (layers & LayerType::kColorMesh) serializeColorMesh(bandwidth_limit_mbps);
-    if (layers & LayerType::kOccupancy) serialized_occupancy_ = gatherLayer<OccupancyVoxel>(NVBX_LAYER_OCCUPANCY, occupancy_layer_.getAllBlockIndices());
-    if (layers & LayerType::kFreespace) serialized_freespace_ = gatherLayer<FreespaceVoxel>(NVBX_LAYER_FREESPACE, freespace_layer_.getAllBlockIndices());
+    // every voxel-layer stream goes through the same selection: the exclusion cylinder, then the bandwidth ration (layer_publishing.cpp:702-711
+    // passes layer_streamer_bandwidth_limit_mbps and the exclusion parameters for EVERY layer type in the mask)
+    if (layers & LayerType::kOccupancy)
+      serialized_occupancy_ = gatherLayer<OccupancyVoxel>(NVBX_LAYER_OCCUPANCY, selectBlocksToStream(occupancy_layer_.getAllBlockIndices(), occupancy_layer_.block_size(), ex,
+                                                          bandwidth_limit_mbps, 12.0 + 512.0 * sizeof(OccupancyVoxel), &stream_clock_[0]));
+    if (layers & LayerType::kFreespace)
+      serialized_freespace_ = gatherLayer<FreespaceVoxel>(NVBX_LAYER_FREESPACE, selectBlocksToStream(freespace_layer_.getAllBlockIndices(), freespace_layer_.block_size(), ex,
+                                                          bandwidth_limit_mbps, 12.0 + 512.0 * sizeof(FreespaceVoxel), &stream_clock_[1]));
     if (layers & (LayerType::kTsdf | LayerType::kColor)) {
-      std::vector<Index3D> sel;
-      const float bs = tsdf_layer_.block_size();
-      for (const Index3D& b : tsdf_layer_.getAllBlockIndices()) {
-        const Vector3f c = getCenterPositionFromBlockIndex(bs, b);
-        const float dx = c.x() - ex.exclusion_center_m.x(), dy = c.y() - ex.exclusion_center_m.y(), dz = c.z() - ex.exclusion_center_m.z();
-        if (ex.exclusion_radius_m >= 0.f && dx * dx + dy * dy > ex.exclusion_radius_m * ex.exclusion_radius_m) continue;
-        if (ex.exclusion_height_m >= 0.f && std::fabs(dz) > ex.exclusion_height_m) continue;
-        sel.push_back(b);
-      }
-      // bandwidth rationing of the voxel-layer stream (layer_publishing.cpp:702-711 passes layer_streamer_bandwidth_limit_mbps for every
-      // layer type): [U] nearest blocks first -- the list is ordered by distance to the exclusion centre (the robot) and cut where
-      // bandwidth_limit_mbps x (time since the last voxel-layer serialization, at most 1 s) is used up; at least one block goes out.
-      if (bandwidth_limit_mbps >= 0.f && !sel.empty()) {
-        const auto now = std::chrono::steady_clock::now();
-        double dt = last_voxel_stream_valid_ ? std::chrono::duration<double>(now - last_voxel_stream_).count() : 1.0;
-        if (dt > 1.0) dt = 1.0;
-        last_voxel_stream_ = now; last_voxel_stream_valid_ = true;
-        const double per_block = 12.0 + ((layers & LayerType::kTsdf) ? 512.0 * sizeof(TsdfVoxel) : 0.0) + ((layers & LayerType::kColor) ? 512.0 * sizeof(ColorVoxel) : 0.0);
-        const size_t keep = std::max<size_t>(1, (size_t)((double)bandwidth_limit_mbps * 1e6 / 8.0 * dt / per_block));
-        if (keep < sel.size()) {
-          auto dist2 = [&](const Index3D& b) { const Vector3f c = getCenterPositionFromBlockIndex(bs, b);
-            const float dx = c.x() - ex.exclusion_center_m.x(), dy = c.y() - ex.exclusion_center_m.y(), dz = c.z() - ex.exclusion_center_m.z(); return dx * dx + dy * dy + dz * dz; };
-          std::stable_sort(sel.begin(), sel.end(), [&](const Index3D& a, const Index3D& b) { return dist2(a) < dist2(b); });
-          sel.resize(keep);
-          std::sort(sel.begin(), sel.end());
-        }
-      }
+      const double per_block = 12.0 + ((layers & LayerType::kTsdf) ? 512.0 * sizeof(TsdfVoxel) : 0.0) + ((layers & LayerType::kColor) ? 512.0 * sizeof(ColorVoxel) : 0.0);
+      const std::vector<Index3D> sel = selectBlocksToStream(tsdf_layer_.getAllBlockIndices(), tsdf_layer_.block_size(), ex, bandwidth_limit_mbps, per_block, &stream_clock_[2]);
       if (layers & LayerType::kTsdf) serialized_tsdf_ = gatherLayer<TsdfVoxel>(NVBX_LAYER_TSDF, sel);
-      if (layers & LayerType::kColor) serialized_color_ = gatherLayer<ColorVoxel>(NVBX_LAYER_COLOR, sel);
+      if (layers & LayerType::kColor) serialized_color_ = gatherLayer<ColorVoxel>(NVBX_LAYER_COLOR, sel);      // (the SAME block list, as the publisher requires)
     }
   }
   std::shared_ptr<SerializedColorMeshLayer> serializedColorMeshLayer() const { return serialized_mesh_; }
@@ -282,6 +263,37 @@ class Mapper {
 
  private:
   void rebuildViews() { freespace_layer_ = FreespaceLayer(m_, voxel_size_m_); occupancy_layer_ = OccupancyLayer(m_, voxel_size_m_); tsdf_layer_ = TsdfLayer(m_, voxel_size_m_); color_layer_ = ColorLayer(m_, voxel_size_m_); esdf_layer_ = EsdfLayer(m_, voxel_size_m_); }
+  // Blocks of a voxel layer that go out with this call: inside the exclusion cylinder (radius / height around the centre; negative =
+  // unlimited), then -- bandwidth_limit_mbps >= 0 -- [U] nearest first: ordered by distance to the exclusion centre (the robot) and cut where
+  // bandwidth_limit_mbps x (time since this stream's last serialization, at most 1 s) is used up; at least one block goes out.
+  struct StreamClock { std::chrono::steady_clock::time_point last; bool valid = false; };
+  static std::vector<Index3D> selectBlocksToStream(const std::vector<Index3D>& all, float bs, const BlockExclusionParams& ex, float bandwidth_limit_mbps,
+                                                   double bytes_per_block, StreamClock* clock) {
+    std::vector<Index3D> sel;
+    auto off = [&](const Index3D& b, float* dx, float* dy, float* dz) { const Vector3f c = getCenterPositionFromBlockIndex(bs, b);
+      *dx = c.x() - ex.exclusion_center_m.x(); *dy = c.y() - ex.exclusion_center_m.y(); *dz = c.z() - ex.exclusion_center_m.z(); };
+    for (const Index3D& b : all) {
+      float dx, dy, dz; off(b, &dx, &dy, &dz);
+      if (ex.exclusion_radius_m >= 0.f && dx * dx + dy * dy > ex.exclusion_radius_m * ex.exclusion_radius_m) continue;
+      if (ex.exclusion_height_m >= 0.f && std::fabs(dz) > ex.exclusion_height_m) continue;
+      sel.push_back(b);
+    }
+    if (bandwidth_limit_mbps >= 0.f && !sel.empty()) {
+      const auto now = std::chrono::steady_clock::now();
+      double dt = clock->valid ? std::chrono::duration<double>(now - clock->last).count() : 1.0;
+      if (dt > 1.0) dt = 1.0;
+      clock->last = now; clock->valid = true;
+      const size_t keep = std::max<size_t>(1, (size_t)((double)bandwidth_limit_mbps * 1e6 / 8.0 * dt / bytes_per_block));
+      if (keep < sel.size()) {
+        auto dist2 = [&](const Index3D& b) { float dx, dy, dz; off(b, &dx, &dy, &dz); return dx * dx + dy * dy + dz * dz; };
+        std::stable_sort(sel.begin(), sel.end(), [&](const Index3D& a, const Index3D& b) { return dist2(a) < dist2(b); });
+        sel.resize(keep);
+        std::sort(sel.begin(), sel.end());
+      }
+    }
+    return sel;
+  }
+  StreamClock stream_clock_[3];          // occupancy, freespace, TSDF / colour
   template <typename VoxelType>
   std::shared_ptr<SerializedLayer<VoxelType>> gatherLayer(uint32_t layer, const std::vector<Index3D>& sel) const {
     auto out = std::make_shared<SerializedLayer<VoxelType>>();
@@ -349,7 +361,6 @@ class Mapper {
     return s;
   }
 
-  std::chrono::steady_clock::time_point last_voxel_stream_; bool last_voxel_stream_valid_ = false;
   float voxel_size_m_;
   ProjectiveLayerType projective_layer_type_;
   EsdfMode esdf_mode_ = EsdfMode::k2D;

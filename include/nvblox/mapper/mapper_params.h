@@ -52,12 +52,12 @@ constexpr Param<float>::Description kEsdfIntegratorMaxSiteDistanceVoxParamDesc{"
 constexpr Param<float>::Description kEsdfIntegratorMaxDistanceMParamDesc{"esdf_integrator_max_distance_m", 2.0f, "ESDF cut-off distance [m]."};
 constexpr Param<float>::Description kMeshIntegratorMinWeightParamDesc{"mesh_integrator_min_weight", 0.1f, "Minimum TSDF weight of a meshed corner."};
 constexpr Param<bool>::Description kMeshIntegratorWeldVerticesParamDesc{"mesh_integrator_weld_vertices", true, "Weld vertices per block."};
-constexpr Param<bool>::Description kDecayIntegratorDeallocateDecayedBlocks{"decay_integrator_deallocate_decayed_blocks", true, "Deallocate fully decayed blocks (false is not provided by libnvblox_hip)."};
+constexpr Param<bool>::Description kDecayIntegratorDeallocateDecayedBlocks{"decay_integrator_deallocate_decayed_blocks", true, "Deallocate fully decayed blocks (false: they stay allocated with their decayed voxels)."};
 constexpr Param<float>::Description kTsdfDecayFactorParamDesc{"tsdf_decay_factor", 0.95f, "Weight multiplier per decay step."};
 constexpr Param<float>::Description kTsdfDecayedWeightThresholdDesc{"tsdf_decayed_weight_threshold", 0.001f, "Blocks whose weights are all below this are deallocated."};
-constexpr Param<bool>::Description kTsdfSetFreeDistanceOnDecayedDesc{"tsdf_set_free_distance_on_decayed", false, "(not provided by libnvblox_hip)."};
-constexpr Param<float>::Description kTsdfDecayedFreeDistanceVoxDesc{"tsdf_decayed_free_distance_vox", 4.0f, "(not provided by libnvblox_hip)."};
-constexpr Param<float>::Description kFreeRegionDecayProbabilityParamDesc{"free_region_decay_probability", 0.55f, "Occupancy decay towards free instead of unknown (not provided by libnvblox_hip: decay stops at unknown)."};
+constexpr Param<bool>::Description kTsdfSetFreeDistanceOnDecayedDesc{"tsdf_set_free_distance_on_decayed", false, "An observed voxel whose weight decays below the threshold becomes free (distance = tsdf_decayed_free_distance_vox, weight = the threshold) instead of unknown."};
+constexpr Param<float>::Description kTsdfDecayedFreeDistanceVoxDesc{"tsdf_decayed_free_distance_vox", 4.0f, "Distance (voxels) given to a decayed voxel when tsdf_set_free_distance_on_decayed is set."};
+constexpr Param<float>::Description kFreeRegionDecayProbabilityParamDesc{"free_region_decay_probability", 0.55f, "Occupied voxels decay past unknown into free and stay there; free voxels are not decayed."};
 constexpr Param<float>::Description kOccupiedRegionDecayProbabilityParamDesc{"occupied_region_decay_probability", 0.4f, "Decay probability applied to occupied voxels (log-odds step towards unknown)."};
 constexpr Param<bool>::Description kOccupancyDecayToFreeParamDesc{"occupancy_decay_to_free", false, "Occupancy decay towards free instead of unknown (not provided by libnvblox_hip: decay stops at unknown)."};
 constexpr Param<float>::Description kMaxTsdfDistanceForOccupancyMParamDesc{"max_tsdf_distance_for_occupancy_m", 0.15f, "Freespace integrator (dynamic mapping)."};
@@ -176,16 +176,13 @@ struct MapperParams {
 
   // what libnvblox_hip consumes
   nvbx_mapper_params toCAbi(float voxel_size, ProjectiveLayerType layer_type = ProjectiveLayerType::kTsdf, EsdfMode esdf_mode = EsdfMode::k2D) const {
-    // switches libnvblox_hip does not provide are refused loudly, never ignored (the reference CHECK-fails on
-    // parameter errors in the same way)
-    if (tsdf_decay_integrator_params.tsdf_set_free_distance_on_decayed || occupancy_decay_integrator_params.occupancy_decay_to_free ||
-        !decay_integrator_base_params.decay_integrator_deallocate_decayed_blocks) {
-      std::fprintf(stderr, "[nvblox_hip] tsdf_set_free_distance_on_decayed = true / occupancy_decay_to_free = true / "
-                           "decay_integrator_deallocate_decayed_blocks = false are not provided by libnvblox_hip\n");
-      std::abort();
-    }
     nvbx_mapper_params p;
     nvbx_default_params(&p);      // every field this function does not set keeps the library default (incl. the [U] open-choice switches)
+    // the decay integrators' switches (mapper_initialization.cpp:383-428): every value the node can set is honoured
+    p.decay_deallocate_decayed_blocks = decay_integrator_base_params.decay_integrator_deallocate_decayed_blocks ? 1 : 0;
+    p.tsdf_set_free_distance_on_decayed = tsdf_decay_integrator_params.tsdf_set_free_distance_on_decayed ? 1 : 0;
+    p.tsdf_decayed_free_distance_vox = tsdf_decay_integrator_params.tsdf_decayed_free_distance_vox;
+    p.occupancy_decay_to_free = occupancy_decay_integrator_params.occupancy_decay_to_free ? 1 : 0;
     p.voxel_size = voxel_size;
     p.esdf_mode = esdf_mode == EsdfMode::k3D ? 1 : 0;
     p.projective_layer_type = layer_type == ProjectiveLayerType::kOccupancy ? 1 : (layer_type == ProjectiveLayerType::kTsdfWithFreespace ? 2 : 0);

@@ -134,6 +134,12 @@ typedef struct {
                                               2 = complement-symmetric table (rule 0 for <= 4 inside corners, else rule 1: the classic table's behaviour) */
   int32_t mesh_normal_rule;                /* welded vertex normal: 0 = normal of the first triangle referencing it, 1 = area-weighted mean of the
                                               block's triangles referencing it */
+  /* -- decay integrator switches (mapper_initialization.cpp:383-428; nvblox_base.yaml:103-107).  [U] semantics, DESIGN.md 3 */
+  int32_t decay_deallocate_decayed_blocks; /* decay_integrator_deallocate_decayed_blocks (1): 0 = a fully decayed block stays allocated with its decayed voxels */
+  int32_t tsdf_set_free_distance_on_decayed; /* tsdf_set_free_distance_on_decayed (0): 1 = an observed voxel whose weight falls below the threshold
+                                              becomes FREE instead of fading to unknown: distance = tsdf_decayed_free_distance_vox voxels, weight = the threshold */
+  float tsdf_decayed_free_distance_vox;    /* tsdf_decayed_free_distance_vox (4.0) */
+  int32_t occupancy_decay_to_free;         /* occupancy_decay_to_free (0): 1 = occupied voxels decay past unknown into free and stay there; free voxels are not decayed */
 } nvbx_mapper_params;
 
 /* nvblox::Lidar(num_azimuth_divisions, num_elevation_divisions, min_valid_range_m, vertical_fov_rad) or

@@ -62,6 +62,10 @@ class Params(C.Structure):
         ("esdf_propagation", C.c_int32),
         ("mesh_ambiguity_rule", C.c_int32),
         ("mesh_normal_rule", C.c_int32),
+        ("decay_deallocate_decayed_blocks", C.c_int32),
+        ("tsdf_set_free_distance_on_decayed", C.c_int32),
+        ("tsdf_decayed_free_distance_vox", C.c_float),
+        ("occupancy_decay_to_free", C.c_int32),
     ]
 
 

@@ -49,7 +49,11 @@ __device__ inline void wave_list_append(const DMap& m, int32_t list, bool push, 
 // while any value != 0) -- [U] OccupancyDecayIntegrator, Mapper::decayOccupancyAllVoxels (nvblox_node.cpp:925-929).
 template <bool OCC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, uint32_t exclude_mask, int32_t mesh_list,
-                                               int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc, int32_t* cleared_idx) {
+                                               int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc, int32_t* cleared_idx, int32_t keep_blocks, int32_t to_free, float free_dist) {
+  // [U] decay switches (mapper_initialization.cpp:383-428; oracle orc_decay_tsdf / orc_decay_occupancy, same lines): keep_blocks =
+  // !decay_integrator_deallocate_decayed_blocks (a fully decayed block stays allocated); to_free = tsdf_set_free_distance_on_decayed (an
+  // OBSERVED voxel whose weight falls below the threshold becomes free: distance free_dist, weight = the threshold) resp.
+  // occupancy_decay_to_free (occupied voxels decay past unknown into free and stay there; free voxels are not decayed)
   const int32_t hw = m.counters[C_HIGH_WATER];
   const int tid = threadIdx.x, lane = tid & 63;
   const int32_t stride = (int32_t)gridDim.x * 8;                       // wavefronts in the grid: wavefront g takes slots g, g + stride, ...
@@ -79,14 +83,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       for (int r = 0; r < 8; r++) {
         if (OCC) {
           float v = tv[r].x;
-          if (v > 0.0f) { v = v + thresh; if (v < 0.0f) v = 0.0f; }
-          else if (v < 0.0f) { v = v + factor; if (v > 0.0f) v = 0.0f; }
+          if (v > 0.0f) { v = v + thresh; if (v < 0.0f && !to_free) v = 0.0f; }
+          else if (v < 0.0f && !to_free) { v = v + factor; if (v > 0.0f) v = 0.0f; }
           tv[r] = make_float2(v, 0.0f); live = live || v != 0.0f;
         } else {
-          tv[r].y = tv[r].y * factor; live = live || !(tv[r].y < thresh);
+          const float w0 = tv[r].y;
+          float w = w0 * factor;
+          if (!(w < thresh)) live = true;
+          else if (to_free && w0 > 0.0f) { tv[r].x = free_dist; w = thresh; }
+          tv[r].y = w;
         }
       }
-      const bool alive = __ballot(live) != 0ull;                       // (uniform)
+      const bool alive = keep_blocks || __ballot(live) != 0ull;        // (uniform)
       uint32_t band = 0u;
       if (alive) {
 #pragma unroll
@@ -316,7 +324,7 @@ extern "C" int nvbx_decay_occupancy(nvbx_mapper* m) {
   const int64_t hw_seen = std::max<int64_t>(1, __atomic_load_n(&m->h_mirror[1], __ATOMIC_RELAXED));       // (a hint: the kernel grid-strides)
   NVBX_LAUNCH(m, k_decay<true>, dim3((unsigned)std::min<int64_t>(std::min<int64_t>(m->capacity, 4096), std::max<int64_t>(512, (hw_seen + 7) / 8))), dim3(512), m->d,
               log_odds(m->p.free_region_decay_probability), log_odds(m->p.occupied_region_decay_probability), 0u, 0u, (int32_t)m->mesh_list_live(),
-              ea.bz_lo, ea.bz_hi, ea.bz_out, 0.0f, m->cleared_idx);
+              ea.bz_lo, ea.bz_hi, ea.bz_out, 0.0f, m->cleared_idx, (int32_t)(m->p.decay_deallocate_decayed_blocks ? 0 : 1), (int32_t)(m->p.occupancy_decay_to_free ? 1 : 0), 0.0f);
   return rebuild_table(m);
 }
 
@@ -335,7 +343,8 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
   NVBX_LAUNCH(m, k_decay<false>, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
                      exclude_last_view ? m->last_camera_view_frame : 0u, m->last_camera_view_mask, m->mesh_list_live(), ea.bz_lo, ea.bz_hi, ea.bz_out,
-                     m->p.truncation_distance_vox * m->p.voxel_size, m->cleared_idx);
+                     m->p.truncation_distance_vox * m->p.voxel_size, m->cleared_idx, (int32_t)(m->p.decay_deallocate_decayed_blocks ? 0 : 1),
+                     (int32_t)(m->p.tsdf_set_free_distance_on_decayed ? 1 : 0), m->p.tsdf_decayed_free_distance_vox * m->p.voxel_size);
   return rebuild_table(m);
 }
 

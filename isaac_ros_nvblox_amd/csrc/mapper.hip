@@ -442,6 +442,7 @@ extern "C" void nvbx_default_params(nvbx_mapper_params* p) {
   p->check_neighborhood = 1; p->initialize_to_high_confidence_freespace = 0;
   p->tsdf_weighting_variant = 0; p->tsdf_skip_at_negative_truncation = 0; p->tsdf_weight_clamp_before_blend = 0;
   p->color_occlusion_threshold_vox = -1.0f; p->esdf_propagation = 0; p->mesh_ambiguity_rule = 0; p->mesh_normal_rule = 0;
+  p->decay_deallocate_decayed_blocks = 1; p->tsdf_set_free_distance_on_decayed = 0; p->tsdf_decayed_free_distance_vox = 4.0f; p->occupancy_decay_to_free = 0;
 }
 __global__ void k_selftest_arith(const float* a, const float* b, float* q, float* r, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

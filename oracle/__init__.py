@@ -68,6 +68,10 @@ class OrcParams(C.Structure):
         ("esdf_propagation", C.c_int32),
         ("mesh_ambiguity_rule", C.c_int32),
         ("mesh_normal_rule", C.c_int32),
+        ("decay_deallocate_decayed_blocks", C.c_int32),
+        ("tsdf_set_free_distance_on_decayed", C.c_int32),
+        ("tsdf_decayed_free_distance_vox", C.c_float),
+        ("occupancy_decay_to_free", C.c_int32),
     ]
 
 
@@ -92,7 +96,8 @@ def default_params(**kw):
         min_duration_since_occupied_for_freespace_ms=1000, min_consecutive_occupancy_duration_for_reset_ms=2000,
         check_neighborhood=1, initialize_to_high_confidence_freespace=0,
         tsdf_weighting_variant=0, tsdf_skip_at_negative_truncation=0, tsdf_weight_clamp_before_blend=0,
-        color_occlusion_threshold_vox=-1.0, esdf_propagation=0, mesh_ambiguity_rule=0, mesh_normal_rule=0)
+        color_occlusion_threshold_vox=-1.0, esdf_propagation=0, mesh_ambiguity_rule=0, mesh_normal_rule=0,
+        decay_deallocate_decayed_blocks=1, tsdf_set_free_distance_on_decayed=0, tsdf_decayed_free_distance_vox=4.0, occupancy_decay_to_free=0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p

@@ -104,6 +104,8 @@ typedef struct {
   int32_t tsdf_weighting_variant, tsdf_skip_at_negative_truncation, tsdf_weight_clamp_before_blend;
   float color_occlusion_threshold_vox;
   int32_t esdf_propagation, mesh_ambiguity_rule, mesh_normal_rule;
+  /* decay integrator switches (mapper_initialization.cpp:383-428) -- [U] semantics, same lines in maintenance.hip k_decay */
+  int32_t decay_deallocate_decayed_blocks, tsdf_set_free_distance_on_decayed; float tsdf_decayed_free_distance_vox; int32_t occupancy_decay_to_free;
 } OrcParams;
 
 enum { W_CONSTANT = 0, W_CONSTANT_DROPOFF = 1, W_INVERSE_SQUARE = 2, W_INVERSE_SQUARE_DROPOFF = 3,
@@ -1525,7 +1527,18 @@ int64_t orc_decay_tsdf(OrcMap* m, int exclude_last_view) {
     int drop = 0;
     if ((b->flags & L_TSDF) && !(exclude_last_view && m->camera_frame > 0 && b->stamp_cam == m->camera_frame)) {
       int alive = 0;
-      for (int i = 0; i < NVOX; i++) { b->tsdf[i].weight = b->tsdf[i].weight * p->tsdf_decay_factor; if (!(b->tsdf[i].weight < p->tsdf_decayed_weight_threshold)) alive = 1; }
+      /* [U] switches: tsdf_set_free_distance_on_decayed -- an OBSERVED voxel whose weight falls below the threshold becomes free (distance
+       * = tsdf_decayed_free_distance_vox voxels, weight = the threshold) instead of fading to unknown; decay_integrator_deallocate_decayed_blocks
+       * = false -- a fully decayed block stays allocated with its decayed voxels */
+      const float free_dist = p->tsdf_decayed_free_distance_vox * p->voxel_size;
+      for (int i = 0; i < NVOX; i++) {
+        const float w0 = b->tsdf[i].weight;
+        float w = w0 * p->tsdf_decay_factor;
+        if (!(w < p->tsdf_decayed_weight_threshold)) alive = 1;
+        else if (p->tsdf_set_free_distance_on_decayed && w0 > 0.0f) { b->tsdf[i].distance = free_dist; w = p->tsdf_decayed_weight_threshold; }
+        b->tsdf[i].weight = w;
+      }
+      if (!p->decay_deallocate_decayed_blocks) alive = 1;
       b->dirty_esdf = 1; b->dirty_mesh = 1;
       if (!alive) {
         drop = 1; cleared_push(m, b->idx);
@@ -1561,11 +1574,13 @@ int64_t orc_decay_occupancy(OrcMap* m) {
       int alive = 0;
       for (int i = 0; i < NVOX; i++) {
         float v = b->tsdf[i].distance;
-        if (v > 0.0f) { v = v + lo_occ; if (v < 0.0f) v = 0.0f; }
-        else if (v < 0.0f) { v = v + lo_free; if (v > 0.0f) v = 0.0f; }
+        /* [U] occupancy_decay_to_free: occupied voxels decay past unknown into free and stay there; free voxels are not decayed */
+        if (v > 0.0f) { v = v + lo_occ; if (v < 0.0f && !p->occupancy_decay_to_free) v = 0.0f; }
+        else if (v < 0.0f && !p->occupancy_decay_to_free) { v = v + lo_free; if (v > 0.0f) v = 0.0f; }
         b->tsdf[i].distance = v; b->tsdf[i].weight = 0.0f;
         if (v != 0.0f) alive = 1;
       }
+      if (!p->decay_deallocate_decayed_blocks) alive = 1;
       if (alive) b->dirty_esdf = 1;
       else {
         drop = 1; cleared_push(m, b->idx);

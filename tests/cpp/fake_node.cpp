@@ -294,6 +294,22 @@ int main(int argc, char** argv) {
         dynamic_mapper_->serializedOccupancyLayer()->block_indices.size() != (size_t)dynamic_mapper_->occupancy_layer().numAllocatedBlocks() ||
         !(dynamic_mapper_->occupancy_integrator().max_integration_distance_m() > 0.f)) {
       std::fprintf(stderr, "occupancy mapper: %d blocks, %zu occupied voxels\n", occ_blocks, occupied_voxels); return 1; }
+    // the decay switches a node can set (mapper_initialization.cpp:383-428) are honoured, not refused: occupied voxels decay to FREE and
+    // fully decayed blocks stay allocated
+    MapperParams sw;
+    sw.occupancy_decay_integrator_params.occupancy_decay_to_free = true;
+    sw.occupancy_decay_integrator_params.occupied_region_decay_probability = 0.05f;
+    sw.decay_integrator_base_params.decay_integrator_deallocate_decayed_blocks = false;
+    sw.tsdf_decay_integrator_params.tsdf_set_free_distance_on_decayed = true;
+    occ.setMapperParams(sw);
+    const int before = dynamic_mapper_->occupancy_layer().numAllocatedBlocks();
+    for (int k = 0; k < 4; k++) dynamic_mapper_->decayOccupancyAllVoxels();
+    size_t still_occupied = 0, now_free = 0;
+    callFunctionOnAllVoxels<OccupancyVoxel>(dynamic_mapper_->occupancy_layer(), [&](const Index3D&, const Index3D&, const OccupancyVoxel* v) {
+      if (v->log_odds > 0.f) still_occupied++;
+      if (v->log_odds < 0.f) now_free++; });
+    if (dynamic_mapper_->occupancy_layer().numAllocatedBlocks() != before || still_occupied != 0 || now_free < occupied_voxels) {
+      std::fprintf(stderr, "decay switches: %d -> %d blocks, %zu occupied, %zu free\n", before, dynamic_mapper_->occupancy_layer().numAllocatedBlocks(), still_occupied, now_free); return 1; }
   }
   // mapping_type "human_with_static_tsdf" (specializations/nvblox_segmentation.yaml): the masked overloads of nvblox_node.cpp:1057-1060,1261-1262
   {
@@ -412,6 +428,26 @@ int main(int argc, char** argv) {
     const int dyn_blocks = multi_mapper_->foreground_mapper()->occupancy_layer().numAllocatedBlocks();
     if (dynamic_points < 1500 || dynamic_points > 50 * 40 || free_voxels < 10000 || dyn_blocks < 3) {
       std::fprintf(stderr, "dynamic mapping: %d dynamic points, %zu freespace voxels, %d dynamic blocks\n", dynamic_points, free_voxels, dyn_blocks); return 1; }
+    // the freespace and occupancy streams are cut to the exclusion cylinder and rationed like the TSDF stream (layer_publishing.cpp:702-711
+    // hands the limit and the exclusion parameters to serializeSelectedLayers for every layer type)
+    BlockExclusionParams ex; ex.exclusion_center_m = Vector3f(0.0f, 0.0f, 0.0f); ex.exclusion_height_m = -1.0f; ex.exclusion_radius_m = -1.0f;
+    auto bg = multi_mapper_->background_mapper(); auto fg = multi_mapper_->foreground_mapper();
+    bg->serializeSelectedLayers(LayerType::kFreespace, -1.0f, ex);
+    const size_t fs_all = bg->serializedFreespaceLayer()->block_indices.size();
+    bg->serializeSelectedLayers(LayerType::kFreespace, 2.0f, ex);           // 2 Mbit/s x <= 1 s = 250 kB = 30 blocks of 8204 B
+    const std::vector<Index3D> fs_some = bg->serializedFreespaceLayer()->block_indices;
+    const float bs = bg->tsdf_layer().block_size();
+    float far_kept = 0.f;
+    for (const Index3D& b : fs_some) { const Vector3f c = getCenterPositionFromBlockIndex(bs, b); far_kept = std::max(far_kept, c.x() * c.x() + c.y() * c.y() + c.z() * c.z()); }
+    ex.exclusion_radius_m = 0.5f;                                               // a 0.5 m cylinder around the optical axis' origin
+    fg->serializeSelectedLayers(LayerType::kOccupancy, -1.0f, ex);
+    const size_t occ_in = fg->serializedOccupancyLayer()->block_indices.size();
+    ex.exclusion_radius_m = -1.0f;
+    fg->serializeSelectedLayers(LayerType::kOccupancy, 0.05f, ex);              // below one block's worth: exactly one block goes out
+    if (fs_all < 100 || fs_some.empty() || fs_some.size() > 30 || far_kept > 1.6f * 1.6f || occ_in < 1 || occ_in > (size_t)dyn_blocks ||
+        fg->serializedOccupancyLayer()->block_indices.size() != 1) {
+      std::fprintf(stderr, "rationed freespace / occupancy streams: freespace %zu of %zu (farthest %g), occupancy %zu in the cylinder of %d, %zu under a tiny budget\n",
+                   fs_some.size(), fs_all, far_kept, occ_in, dyn_blocks, fg->serializedOccupancyLayer()->block_indices.size()); return 1; }
   }
   // save_map / load_map services (nvblox_node.cpp:1668, 1703): bool results, a missing file is a recoverable error
   const std::string filename = std::string(argv[1]) + ".map";
