@@ -132,6 +132,7 @@ def lib():
         L.orc_split_depth_by_mask.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_float, vp, vp]
         L.orc_lidar_project.restype = C.c_int; L.orc_lidar_project.argtypes = [vp, vp, f32p, f32p]
         L.orc_atan2f.restype = C.c_float; L.orc_atan2f.argtypes = [C.c_float, C.c_float]
+        L.orc_lidar_sample_points.restype = None; L.orc_lidar_sample_points.argtypes = [C.POINTER(OrcParams), vp, vp, vp, i64, C.c_float, vp, vp]
         L.orc_integrate_color.restype = i64; L.orc_integrate_color.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
         L.orc_num_blocks.restype = i64; L.orc_num_blocks.argtypes = [vp, C.c_uint32]
         L.orc_block_indices.restype = i64; L.orc_block_indices.argtypes = [vp, C.c_uint32, vp, i64]
@@ -372,6 +373,14 @@ def split_depth_by_mask(depth, mask, T_CM_CD, depth_cam, mask_cam, occlusion_thr
     lib().orc_split_depth_by_mask(_p(d), d.shape[0], d.shape[1], _p(mk), mk.shape[0], mk.shape[1], _p(T), _p(dc), _p(mc),
                                   float(occlusion_threshold_m), _p(un), _p(ma))
     return un, ma
+
+
+def lidar_sample_points(params, lidar, range_image, pts, max_dist):
+    """The oracle's LiDAR measurement model at sensor-frame points [N, 3] -> (branch int32 [N], ds float32 [N]); tests only."""
+    l5 = np.asarray(lidar, np.float32); img = np.ascontiguousarray(range_image, np.float32); q = np.ascontiguousarray(pts, np.float32)
+    br = np.zeros(len(q), np.int32); ds = np.zeros(len(q), np.float32)
+    lib().orc_lidar_sample_points(C.byref(params), _p(l5), _p(img), _p(q), C.c_int64(len(q)), C.c_float(max_dist), _p(br), _p(ds))
+    return br, ds
 
 
 def lidar_project(lidar, p):

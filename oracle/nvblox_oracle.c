@@ -815,6 +815,32 @@ int orc_lidar_project(const float* lidar5, const float* p, float* u, float* v) {
   return nvbx_lidar_project(&l, p, nvbx_lidar_range(p), u, v);
 }
 float orc_atan2f(float y, float x) { return nvbx_atan2f(y, x); }
+/* exported for tests/test_independent_checks.py: the measurement model (lidar_sample above = LidarSensor::sample of the product) evaluated
+ * at n sensor-frame points: branch[i] = 0 no measurement, 1 four-tap bilinear, 2 nearest beam; ds[i] = the measured range */
+void orc_lidar_sample_points(const OrcParams* p, const float* lidar5, const float* range, const float* pts, int64_t n, float max_dist, int32_t* branch, float* ds) {
+  LidarTab tab = lidar_tab_make(lidar5);
+  const int rows = tab.l.rows, cols = tab.l.cols;
+  const float max_diff = p->lidar_linear_interpolation_max_allowable_difference_vox * p->voxel_size;
+  for (int64_t i = 0; i < n; i++) {
+    float d = 0.0f, vd = 0.0f;
+    const int got = lidar_sample(p, &tab, range, rows, cols, pts + 3 * i, max_dist, &d, &vd);
+    branch[i] = 0; ds[i] = 0.0f;
+    if (!got) continue;
+    /* which rule produced it: re-derive the bilinear test's outcome the way lidar_sample does (same float operations) */
+    float u = 0.0f, v = 0.0f; nvbx_lidar_project(&tab.l, pts + 3 * i, nvbx_lidar_range(pts + 3 * i), &u, &v);
+    const float uc = u - 0.5f, vc = v - 0.5f; const int x0 = (int)floorf(uc), y0 = (int)floorf(vc);
+    int bil = 0;
+    if (!(x0 < 0 || y0 < 0 || x0 + 1 > cols - 1 || y0 + 1 > rows - 1)) {
+      const float f00 = range[(int64_t)y0 * cols + x0], f10 = range[(int64_t)y0 * cols + x0 + 1], f01 = range[(int64_t)(y0 + 1) * cols + x0], f11 = range[(int64_t)(y0 + 1) * cols + x0 + 1];
+      if (f00 > 0.0f && f10 > 0.0f && f01 > 0.0f && f11 > 0.0f) {
+        const float mx = fmaxf(fmaxf(f00, f10), fmaxf(f01, f11)), mn = fminf(fminf(f00, f10), fminf(f01, f11));
+        bil = (mx - mn <= max_diff);
+      }
+    }
+    branch[i] = bil ? 1 : 2; ds[i] = d;
+  }
+  free(tab.el); free(tab.az);
+}
 
 /* ------------------------------------------------------------------ accessors */
 static int idx_cmp(const void* a, const void* b) {

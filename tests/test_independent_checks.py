@@ -223,3 +223,54 @@ def test_asin_polynomial_of_the_lidar_model_is_the_fitted_one_and_accurate():
         p = fma(p, z, c[k])
     y = fma(p * z, x, x)
     assert np.abs(y.astype(np.float64) - np.arcsin(x.astype(np.float64))).max() < 5e-8
+
+
+# ------------------------------------------------------------------------------------------------ LiDAR measurement model (taps, branches)
+def _voxel_centres_near_rays(rng, lidar, img, n, voxel=0.1):
+    """voxel-centre-like points: most of them where the map has them -- along the beams up to the measured range (+ a truncation band)
+    with a lateral scatter of a few voxels -- and some anywhere in the field of view"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from isaac_ros_nvblox_amd import synthetic as S
+    dirs = S.lidar_beam_dirs(lidar)
+    rows, cols = img.shape
+    k = rng.integers(0, rows, n); j = rng.integers(0, cols, n)
+    rng_m = np.where(img[k, j] > 0, img[k, j], 60.0)
+    t = rng.uniform(0.3, 1.0, n) * (rng_m + 0.4)
+    p = dirs[k, j] * t[:, None] + rng.normal(0.0, 1.0, (n, 3)) * (voxel * np.array([0.3, 1.5, 4.0]))[rng.integers(0, 3, n)][:, None]
+    p = (np.floor(p / voxel) + 0.5) * voxel                      # snapped to a voxel grid, like the integrator's inputs
+    return p
+
+
+def test_lidar_measurement_model_against_independent_numpy_restatement():
+    """The oracle's lidar_sample (the code the HIP kernel is bit-compared with, sensor model from csrc/nvbx_lidar_math.h) against
+    tests/lidar_independent.py (numpy float64, libm): the same rule (none / four-tap bilinear / nearest beam) and the same measured
+    range on >= 10^5 voxel centres whose decisions do not hang on the last bits -- clean and noisy range images, three thresholds."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import lidar_independent as LI
+    from isaac_ros_nvblox_amd import synthetic as S
+    rng = np.random.default_rng(9)
+    total = 0; seen = {0: 0, 1: 0, 2: 0}
+    for lidar, extent, noise, thr in [(S.SPINNING_LIDAR, 150.0, 0.0, (2.0, 0.5)), (S.SPINNING_LIDAR, 150.0, 0.03, (2.0, 0.5)),
+                                      ((256, 32, 0.1, -np.deg2rad(60.0), np.deg2rad(10.0)), 40.0, 0.02, (0.5, 1.5))]:
+        sc = S.LidarScene(n_boxes=30, extent=extent)
+        T = S.lidar_pose(5)
+        img = S.render_lidar(sc, T, lidar, max_range=200.0)
+        if noise:
+            img = np.where(img > 0, img + rng.normal(0.0, noise, img.shape), 0.0).astype(np.float32)
+            img[rng.random(img.shape) < 0.03] = 0.0
+        p = oracle.default_params(voxel_size=0.1, lidar_max_integration_distance_m=200.0,
+                                  lidar_linear_interpolation_max_allowable_difference_vox=thr[0], lidar_nearest_interpolation_max_allowable_dist_to_ray_vox=thr[1])
+        pts = _voxel_centres_near_rays(rng, lidar, img, 250000).astype(np.float32)
+        br, ds = oracle.lidar_sample_points(p, lidar, img, pts, 200.0)
+        ref = LI.sample(lidar, img, pts.astype(np.float64), thr[0] * 0.1, thr[1] * 0.1, 200.0)
+        robust = (ref["margin_px"] > 2e-3) & (ref["margin_m"] > 2e-4)
+        assert robust.mean() > 0.9
+        assert np.array_equal(br[robust], ref["branch"][robust]), np.nonzero(robust & (br != ref["branch"]))[0][:5]
+        got = robust & (br > 0)
+        assert np.abs(ds[got] - ref["ds"][got]).max() < 2e-4 * max(1.0, float(ds[got].max()) / 50.0)      # float32 ranges up to 200 m
+        total += int(robust.sum())
+        for b in (0, 1, 2):
+            seen[b] += int((ref["branch"][robust] == b).sum())
+    assert total >= 500000 and min(seen.values()) > 20000, (total, seen)

@@ -380,3 +380,42 @@ def test_azimuth_sector_split_reproduces_the_single_sensor_map_away_from_the_cut
             checked += int(inside.sum())
         covered += int((w_full > 0).sum())
     assert checked > 0.7 * covered and covered > 50000             # (most of the map is more than two columns from a cut)
+
+
+@pytest.mark.gpu
+def test_lidar_hip_map_against_the_independent_model(hip_lib):
+    """The PRODUCT (not the oracle) against tests/lidar_independent.py -- numpy float64 with libm, no code shared with csrc/: one
+    configs[4] scan into an empty map with constant weighting, then for > 3 x 10^5 voxels of blocks at all ranges the voxel must be
+    updated exactly when the independent model yields a measurement with sdf >= -truncation, and hold clamp(measured - range) within
+    2e-4 m; voxels whose decision hangs on the last bits (pixel-bin edges, thresholds) are left out by the model's own margins."""
+    import lidar_independent as LI
+    from isaac_ros_nvblox_amd import mapper as M
+    vs = 0.1; trunc = 4.0 * vs
+    pg = M.default_params(voxel_size=vs, lidar_max_integration_distance_m=200.0, raycast_subsampling_factor=2, weighting_mode=0)
+    g = M.Mapper(pg, block_capacity=1 << 18)
+    sc = S.LidarScene(); T = S.lidar_pose(7)
+    img = S.render_lidar(sc, T, S.SPINNING_LIDAR, max_range=200.0)
+    g.integrate_lidar_depth(img, T, S.SPINNING_LIDAR)
+    idx = g.block_indices(M.LAYER_TSDF)
+    assert len(idx) > 100000
+    rng = np.random.default_rng(2)
+    sel = idx[np.sort(rng.choice(len(idx), 800, replace=False))]
+    b, found = g.get_blocks(M.LAYER_TSDF, sel)
+    assert found.all()
+    vx, vy, vz = np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij")          # voxel order z + 8y + 64x
+    off = np.stack([vx.ravel(), vy.ravel(), vz.ravel()], 1)
+    centres = ((sel[:, None, :].astype(np.float64) * 8 + off[None, :, :]) + 0.5) * vs            # [blocks, 512, 3], world frame
+    Td = np.asarray(T, np.float64)
+    ps = (centres.reshape(-1, 3) - Td[:3, 3]) @ Td[:3, :3]                                       # sensor frame: R^T (c - t)
+    ref = LI.sample(S.SPINNING_LIDAR, img, ps, 2.0 * vs, 0.5 * vs, 200.0)
+    sdf = ref["ds"] - ref["r"]
+    upd = (ref["branch"] > 0) & (sdf >= -trunc)
+    robust = (ref["margin_px"] > 3e-3) & (ref["margin_m"] > 3e-4) & ((ref["branch"] == 0) | (np.abs(sdf + trunc) > 3e-4))
+    w = b["weight"].reshape(-1); d = b["distance"].reshape(-1)
+    assert robust.sum() > 300000 and robust.mean() > 0.85
+    assert np.array_equal((w > 0)[robust], upd[robust]), int(((w > 0) != upd)[robust].sum())
+    k = robust & upd
+    assert set(np.unique(w[k]).tolist()) == {1.0}
+    assert np.abs(d[k] - np.clip(sdf[k], -trunc, trunc)).max() < 2e-4
+    far = np.hypot(ps[:, 0], ps[:, 1]) > 120.0
+    assert (k & far).sum() > 1000 and (k & (ref["branch"] == 1)).sum() > 20000 and (k & (ref["branch"] == 2)).sum() > 5000
