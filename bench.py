@@ -39,7 +39,7 @@ def short(name):
     return m.group(1) if m else name.strip()
 
 
-def algorithmic_bytes(kernel, c, rows, cols, sub_ray=4, sub_trace=4, n_cam=1):
+def algorithmic_bytes(kernel, c, rows, cols, sub_ray=4, sub_trace=4, n_cam=1, trace_in_mark_view=False):
     """SURVEY.md 8(d) algorithmic bytes of ONE launch of `kernel`, from the measured per-launch counts `c`."""
     B = 4096
     Nv, Nc, Na = c.get("tsdf_blocks_in_view", 0), c.get("color_blocks_updated", 0), c.get("blocks_allocated", 0)
@@ -47,7 +47,9 @@ def algorithmic_bytes(kernel, c, rows, cols, sub_ray=4, sub_trace=4, n_cam=1):
     if kernel.startswith("k_integrate_tsdf"):
         return n_cam * rows * cols * 4 + Nv * (12 + 8) + Nv * B * 2
     if kernel.startswith("k_mark_view"):
-        return n_cam * (rows // sub_ray) * (cols // sub_ray) * 4 + Nv * 16 * 2          # sub-sampled depth read + one hash entry RMW per block in view
+        own = n_cam * (rows // sub_ray) * (cols // sub_ray) * 4 + Nv * 16 * 2           # sub-sampled depth read + one hash entry RMW per block in view
+        # colour deferral: the sphere tracing of the previous colour frame rides in this launch (its bytes with it)
+        return own + (algorithmic_bytes("k_sphere_trace", c, rows, cols, sub_ray, sub_trace, n_cam) if trace_in_mark_view else 0)
     if kernel.startswith("k_integrate_color"):
         # colour image + synthetic depth read + colour RMW of the band blocks (the band vote is a per-block flag: no TSDF read),
         # plus the ESDF site marking that rides in the same launch (TSDF z-band of the re-marked columns read, masks written)
@@ -554,6 +556,11 @@ def main_camera(args):
         torch.cuda.synchronize(dev)
 
     tm = Timer(torch, dist, dev, world)
+    # Cross-frame pipelining (nvbx_mapper_set_color_deferral): integrateColor(i) / updateEsdf(i) are held back and carried out by
+    # integrateDepth(i+1) -- view marking(i+1) || sphere tracing(i) in one launch: 3 launches per frame instead of 4.  Same calls, same map;
+    # the caller keeps the colour image valid until its next call (the bench's images are resident).  --no-color-deferral: the classic order.
+    deferral = (not multicam) and world == 1 and not args.no_color_deferral
+    g.set_color_deferral(deferral)
 
     def fresh_map():
         g.clear()
@@ -569,6 +576,12 @@ def main_camera(args):
         step(base + i)
     dt_rev, dts_rev, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 4, first=base + nu)
     ms_revisit = dt_rev / args.steps * 1e3
+    ms_classic = None
+    if deferral:                             # the same revisit blocks in the classic launch order, for the record
+        g.set_color_deferral(False)
+        dt_c, dts_c, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 4, first=base)
+        ms_classic = dt_c / args.steps * 1e3
+        g.set_color_deferral(True)
 
     if rank != 0:
         return finish_dist(dist, world)
@@ -622,20 +635,36 @@ def main_camera(args):
                "note": "one step at a time with a synchronize after each (the ESDF distance transform then runs as its own launch); wall = host "
                        "clock around the calls + synchronize -- the figure comparable to the README's host timers"}
 
-    # per-kernel durations with hipEvent pairs on the mapper stream, same frames, mesh included
-    g.set_profiling(True)
+    # per-step work counts (a query flushes the pipeline, so they are sampled in a loop of their own, not in the profiled one)
     counts_acc = {}
-    for i in range(n2):
+    for i in range(min(n2, 20)):
         step(base + i, mesh=True, exchange=False)
-        if i % 10 == 0:
-            for k_, v_ in g.counters().items():
-                counts_acc.setdefault(k_, []).append(v_)
-    prof = g.profile()
-    g.set_profiling(False)
+        for k_, v_ in g.counters().items():
+            counts_acc.setdefault(k_, []).append(v_)
     counts = {k_: float(np.mean(v_)) for k_, v_ in counts_acc.items()}
+    # per-kernel durations with hipEvent pairs on the mapper stream: the timed step as it is (n2 frames, nothing in between), then a few
+    # frames with a mesh update each for k_mesh's entry
+    g.set_profiling(True)
+    for i in range(n2):
+        step(base + i, exchange=False)
+    g.synchronize()
+    prof = g.profile()
+    g.set_profiling(True)
+    for i in range(10):
+        step(base + i, mesh=True, exchange=False)
+    prof_mesh = g.profile()
+    g.set_profiling(False)
+    for k_, v_ in prof_mesh.items():
+        if short(k_).startswith("k_mesh"):
+            prof[k_] = {"count": v_["count"] * n2 / 10.0, "total_ms": v_["total_ms"] * n2 / 10.0}      # (scaled to one launch per step)
     launches_cam = ncam if not (multicam and batch_ok and ncam in bd) else 1
+    n_trace_launches = sum(v_["count"] for k_, v_ in prof.items() if short(k_).startswith("k_sphere_trace"))
+    fused_trace = deferral and n_trace_launches < n2 / 2          # (the last frame of the loop is flushed in classic order by the synchronize)
+    if fused_trace:
+        for k_ in [k_ for k_ in prof if short(k_).startswith("k_sphere_trace")]:
+            del prof[k_]
     kern, ev_overhead_us, empty_pair_us = kernel_table(
-        prof, counts, ms_per_step, n2, lambda k, cc: algorithmic_bytes(k, cc, rows, cols, n_cam=(ncam // launches_cam)), load_pmc(args.workload),
+        prof, counts, ms_revisit, n2, lambda k, cc: algorithmic_bytes(k, cc, rows, cols, n_cam=(ncam // launches_cam), trace_in_mark_view=fused_trace), load_pmc(args.workload),
         exclude_from_calibration=("k_mesh", "k_esdf_edt"))
     roofline = roofline_of(
         kern, ms_per_step, ev_overhead_us, empty_pair_us,
@@ -682,6 +711,10 @@ def main_camera(args):
                    "revisit_ms_per_step": block_stats(dts_rev, args.steps),
                    "revisit_note": "same blocks of K steps on the fully allocated map (after one untimed loop over all poses)"},
         "ms_per_step_revisit": round(ms_revisit, 4),
+        "color_deferral": {"enabled": bool(deferral), "ms_per_step_revisit_classic_order": (round(ms_classic, 4) if ms_classic else None),
+                           "note": "enabled: integrateColor(i) / updateEsdf(i) are held back and carried out by integrateDepth(i+1) in pipelined order "
+                                   "(view marking(i+1) || sphere tracing(i) in one launch; 3 launches per frame); same calls, bit-identical map "
+                                   "(tests/test_gpu_pipeline.py); contract: include/nvblox_hip.h nvbx_mapper_set_color_deferral"},
         "block_ms": [round(d / args.steps * 1e3, 4) for d in dts[:16]],
         "ms_components": {k_: round(v_, 4) for k_, v_ in comp.items()},
         "components_note": "ms_components are measured per call in isolation: the EDT of updateEsdf is held back and runs inside the next depth "
@@ -710,6 +743,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=48, help="minimum number of frames of the same workload timed on the CPU oracle")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline keeps integrating (cycling the same frames) until this much CPU wall time has passed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-color-deferral", action="store_true", help="camera workload: classic launch order (4 launches per frame) instead of the cross-frame pipeline")
     ap.add_argument("--step-trace", type=int, default=0, help="decay workload: wait for every one of this many steps and report the slowest (diagnosis)")
     ap.add_argument("--cameras", type=int, default=4, help="multicam: cameras per step (1..8)")
     ap.add_argument("--fusion", default="indices", choices=["indices", "measurements"],

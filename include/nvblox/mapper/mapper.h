@@ -256,6 +256,9 @@ class Mapper {
   bool saveLayerCake(const std::string& path) const { return nvbx_save_map(m_, path.c_str()) == NVBX_OK; }
   bool loadMap(const std::string& path) { return nvbx_load_map(m_, path.c_str()) == NVBX_OK; }
 
+  // libnvblox_hip extension (not in the reference; off by default): cross-frame pipelining of integrateColor -- see nvbx_mapper_set_color_deferral
+  // in nvblox_hip.h for the colour-image lifetime contract the caller accepts with it
+  void setColorIntegrationDeferred(bool on) { checkNvbx(nvbx_mapper_set_color_deferral(m_, on ? 1 : 0), "nvbx_mapper_set_color_deferral"); }
   void synchronize() const { checkNvbx(nvbx_synchronize(m_), "nvbx_synchronize"); }
   void flush() const { checkNvbx(nvbx_flush(m_), "nvbx_flush"); }      // enqueue held-back work without waiting
   nvbx_mapper* c_handle() const { return m_; }

@@ -195,6 +195,20 @@ int nvbx_synchronize(nvbx_mapper* m);
 /* Enqueue everything the mapper holds back (the distance transform of the last nvbx_update_esdf, see there) on its stream
  * WITHOUT waiting: for callers that order their own work behind the mapper's with stream events instead of a host sync. */
 int nvbx_flush(nvbx_mapper* m);
+/* Colour deferral (cross-frame pipelining; off by default).  While enabled, nvbx_integrate_color / _bgra8 of a single frame is HELD BACK --
+ * its arguments are remembered, nothing is launched -- and so is an nvbx_update_esdf that follows it.  The next single-frame
+ * nvbx_integrate_depth / _u16mm carries them out in pipelined order: {view marking of the new depth frame || sphere tracing of the held-back
+ * colour frame} in ONE launch, then colour integration (+ ESDF site marking), then the TSDF update of the new frame -- three launches per
+ * depth + colour + ESDF frame instead of four (the two overlapped kernels are independent: sphere tracing reads the TSDF and the insert-only
+ * hash, view marking inserts entries whose blocks are all-zero = unobserved).  EVERY other entry point (queries, synchronize / flush, batches,
+ * LiDAR, mesh, decay, clearing, another integrate_color, ...) first carries the held-back calls out exactly as they would have run at call
+ * time, so results -- map contents, ESDF, views, every query -- are bit-identical to the undeferred sequence (tests/test_gpu_pipeline.py).
+ * CONTRACT (the caller-lifetime rule this buys the launch with): the colour image passed to nvbx_integrate_color must stay valid and
+ * UNCHANGED until the next call into this mapper has returned (any call: it either consumes or flushes the frame).  nvblox_ros re-uses ONE
+ * colour buffer per node (nvblox_node.hpp:485-488) and fills it right before integrateColor, after the depth frame -- compatible with the
+ * contract for the depth -> colour -> updateEsdf order of NvbloxNode::tick(); a node that fills the colour buffer BEFORE calling
+ * integrateDepth must double-buffer it or leave deferral off.  Argument errors are still reported by the call that made them. */
+int nvbx_mapper_set_color_deferral(nvbx_mapper* m, int32_t enable);
 /* The hipStream_t all of the mapper's work is enqueued on (the one handed to nvbx_mapper_create, or the library-owned one):
  * implicit conversion of nvblox::CudaStream to cudaStream_t -- conversions/esdf_slice_conversions.cu:107-108.  A caller that
  * reads / writes buffers it shares with the mapper on ANOTHER stream (e.g. an RCCL collective on the framework's stream) orders

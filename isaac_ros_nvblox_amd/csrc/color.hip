@@ -11,114 +11,19 @@
 // Call site served: nvblox_ros/src/lib/nvblox_node.cpp:1264.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include "nvbx_mapper.h"
 #include "nvbx_esdf_mark.h"
+#include "nvbx_sphere_trace.h"
 
 using namespace nvbx;
 
-// TSDF reads below skip the layer-flag load: the TSDF pool of a slot that does not carry F_TSDF is all-zero (freed /
-// ESDF-only slots are zeroed, maintenance.hip), and weight 0 reads as "unobserved" exactly like a missing block.
-// RAY_LANES (template parameter RL below) = lanes cooperating on one ray = samples fetched per round trip.  One camera: 8 (4: 13.7, 8: 13.4,
-// 16: 14.5, 32: 21.4 us -- 19 200 rays x 8 lanes = 2 400 wavefronts, about one resident round of the chip).  A BATCH of n cameras has n
-// times the rays: the latency trick that fills an idle chip for one camera turns into n occupancy rounds of mostly speculative samples, so
-// the batch launches with fewer lanes per ray (sphere_trace_lanes() below; tools: NVBX_ST_LANES).
-
-// [U] SphereTracer::cast restated, sample-parallel.  The serial march t <- t + tsdf(t) (nearest voxel) is a chain of
-// dependent HBM round trips (hash entry, then voxel) plus ~150 ALU ops per step, and a ray takes 10-20 steps.  But the
-// step is PREDICTABLE: exactly `trunc` through free (clamped) or unobserved space, and the same small value while the
-// ray stays inside one voxel near the surface.  So RAY_LANES lanes serve one ray: lane j fetches the sample at
-// t + j*ps (ps = predicted step, accumulated with the same float additions the serial march performs), all their hash
-// probes and voxel loads are in flight together, and the group consumes the samples in order with ballots while each
-// sample's step equals the prediction.  The first sample that breaks it supplies the next t and the next prediction.
-// The sequence of t values -- and so the result -- is bit-identical to the one-sample-at-a-time march.
-// The colour frames of one launch set: one frame, or a batch of up to MAX_BATCH (nvbx_integrate_color_batch); kernel arguments.
-template <int NB> struct PoseSet { Frame f[NB]; int32_t n; };
 template <typename Pix, int NB> struct FrameSetC { Frame f[NB]; Pix img[NB]; int32_t n; int32_t chunk; };
 
 template <int NB, int RAY_LANES>
 __global__ __launch_bounds__(256) void k_sphere_trace(DMap m, PoseSet<NB> poses, float* synth_all, int32_t srows, int32_t scols, int32_t max_steps,
                                                       float max_len, float eps_m) {
-  const int tid = threadIdx.x;
-  if (blockIdx.x == 0 && tid == 0) list_reset(m, S_LIST_COLOR);
-  const int lane = tid & 63;
-  const int sub = lane & (RAY_LANES - 1);              // sample index within the ray's group
-  const int gsh = lane & ~(RAY_LANES - 1);             // first lane of the group (= shift of its bits in a ballot)
-  // XCD-aware ray -> workgroup mapping.  Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2: with rays
-  // dealt out in row-major order every XCD marches through EVERY part of the frustum and fetches its own copy of every TSDF block
-  // and hash line (PMC: 6.6 MB of HBM traffic for 1.0 MB of blocks).  Instead a workgroup takes an 8 x 4 patch of rays, and the
-  // patches are numbered so that the workgroups of one XCD (blockIdx.x & 7) own a contiguous band of patch rows.
-  constexpr int PW = 8, PH = (256 / RAY_LANES) / PW;       // 256 / RAY_LANES rays per 256-thread workgroup (32 at 8 lanes per ray)
-  const int patches_x = (scols + PW - 1) / PW, patches_y = (srows + PH - 1) / PH;
-  const int n_patch = patches_x * patches_y, per_xcd = (n_patch + NSH - 1) / NSH;
-  const int cam = NB > 1 ? (int)blockIdx.x / (NSH * per_xcd) : 0;          // batch: NSH * per_xcd workgroups per camera, camera after camera
-  const int wg = (int)blockIdx.x - cam * (NSH * per_xcd);
-  const Frame& f = poses.f[cam];
-  float* synth = synth_all + (size_t)cam * srows * scols;
-  const int patch = (wg & (NSH - 1)) * per_xcd + (wg >> 3);
-  const int pr = tid / RAY_LANES;                            // ray within the patch
-  const int py = patch / patches_x, px = patch - py * patches_x;
-  const int r = py * PH + pr / PW, c = px * PW + pr % PW;
-  const bool valid = cam < poses.n && patch < n_patch && (wg >> 3) < per_xcd && r < srows && c < scols;
-  const float rx = (((float)((valid ? c : 0) * f.subsample) + 0.5f) - f.cu) / f.fu;
-  const float ry = (((float)((valid ? r : 0) * f.subsample) + 0.5f) - f.cv) / f.fv;
-  const float n = NVBX_SQRT((rx * rx + ry * ry) + 1.0f);          // (NVBX_SQRT / NVBX_DIV: the IEEE results, shorter sequences -- nvbx_arith.h)
-  const float dcx = NVBX_DIV(rx, n), dcy = NVBX_DIV(ry, n), dcz = NVBX_DIV(1.0f, n);
-  float dl[3];
-  rotate(f.R_LC, dcx, dcy, dcz, dl);
-  // group-uniform march state (replicated in the group's lanes)
-  bool last_positive = false, hit = false, done = !valid;
-  float t = 0.0f, ps = f.trunc;
-  int i = 0;
-  while (__ballot(!done)) {                              // wave-uniform loop: ballots / shuffles below need all lanes
-    // this lane's sample: t advanced `sub` times by the predicted step (the serial march's additions, replayed)
-    float tc = t;
-    for (int j = 0; j < RAY_LANES - 1; j++) if (j < sub) tc = tc + ps;
-    const float px = f.t_LC[0] + tc * dl[0], py = f.t_LC[1] + tc * dl[1], pz = f.t_LC[2] + tc * dl[2];
-    const int32_t gx = (int32_t)floorf(NVBX_DIV(px, f.voxel_size)), gy = (int32_t)floorf(NVBX_DIV(py, f.voxel_size)), gz = (int32_t)floorf(NVBX_DIV(pz, f.voxel_size));
-    const int32_t bx = gx >> 3, by = gy >> 3, bz = gz >> 3;
-    const uint32_t h = done ? 0u : table_pos(m, bx, by, bz);
-    const uint4 e = *reinterpret_cast<const uint4*>(&m.table[h]);
-    const uint32_t slot = done ? SLOT_NONE : resolve_any(m, pack_key(bx, by, bz), h, e);
-    const float2 v = m.tsdf[slot_ok(slot) ? (size_t)slot * 512 + (gz & 7) + 8 * (gy & 7) + 64 * (gx & 7) : 0];
-    // classify the sample as the serial loop body would, assuming every earlier sample of the round kept the prediction
-    const bool in_bounds = (i + sub < max_steps) && (tc < max_len);
-    const bool observed = slot_ok(slot) && (v.y > 1e-4f);
-    const bool surf = observed && (v.x < eps_m);                     // hit test
-    const bool keep = observed && !surf && (v.x == ps);              // observed, step == prediction
-    const u64 obs_mask = __ballot(observed && !surf);                 // samples that set last_positive
-    const uint32_t before = (uint32_t)((obs_mask >> gsh) & ((1u << sub) - 1u));
-    const bool pos_before = last_positive || before != 0;            // last_positive when the serial loop reaches this sample
-    const bool unobs_keep = !observed && !pos_before && (ps == f.trunc);   // unobserved: step = trunc, if that is the prediction
-    const bool event = !done && !(in_bounds && (keep || unobs_keep));
-    const uint32_t ev = (uint32_t)((__ballot(event) >> gsh) & (uint32_t)((1ull << RAY_LANES) - 1ull));
-    const int e_sub = ev ? (__ffs((int)ev) - 1) : RAY_LANES;         // first sample that breaks the prediction
-    const int src = gsh + (e_sub < RAY_LANES ? e_sub : RAY_LANES - 1);
-    // values at the event sample (or at the last sample if the whole round kept the prediction)
-    const float e_tc = __shfl(tc, src);
-    const float e_vx = __shfl(v.x, src);
-    const int e_inb = __shfl((int)in_bounds, src), e_obs = __shfl((int)observed, src), e_surf = __shfl((int)surf, src);
-    const int e_posb = __shfl((int)pos_before, src);
-    const int pos_last = __shfl((int)(pos_before || (observed && !surf)), gsh + RAY_LANES - 1);   // last_positive after a fully kept round
-    if (!done) {
-      if (e_sub == RAY_LANES) {                      // all samples consumed with the predicted step
-        t = e_tc + ps; i += RAY_LANES; last_positive = pos_last != 0;
-      } else {
-        i += e_sub;                                  // samples before the event were regular steps
-        last_positive = e_posb != 0;
-        if (!e_inb) { done = true; }
-        else if (!e_obs) {                           // unobserved / missing
-          if (!last_positive) { t = e_tc + f.trunc; i += 1; ps = f.trunc; }   // (prediction was not trunc)
-          else done = true;
-        } else if (e_surf) {
-          if (last_positive) { t = e_tc + e_vx; hit = true; }
-          done = true;
-        } else {                                     // observed, step differs from the prediction
-          t = e_tc + e_vx; i += 1; last_positive = true; ps = e_vx;
-        }
-      }
-    }
-  }
-  if (valid && sub == 0) synth[(int64_t)r * scols + c] = hit ? t * dcz : 0.0f;
+  sphere_trace_worker<NB, RAY_LANES>(m, poses, synth_all, srows, scols, max_steps, max_len, eps_m, (int)blockIdx.x);
 }
 
 // colour source: rgb8 (nvblox::Color, 3 bytes) or bgra8 (4 bytes, channel reorder of ToRgba<Bgra> fused into the fetch)
@@ -154,7 +59,7 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, FrameSetC<Pix, 
       // workers [0, n_own) re-mark the mapper's own dirty blocks, workers [n_own, n_mark_wg) the peers' gathered lists
       // (multi-GPU union step held back by nvbx_mark_esdf_dirty_gathered_deferred); one marking pass, one column stamp
       const int32_t n_own = n_mark_wg - imp.n_wg;
-      if ((int32_t)blockIdx.x < n_own) esdf_mark_worker(m, ea, (int)blockIdx.x, n_own);
+      if ((int32_t)blockIdx.x < n_own) { esdf_mark_worker(m, ea, (int)blockIdx.x, n_own); esdf_mark_pass_done(m, ea, n_own); }
       else esdf_import_mark_worker(m, ea, imp, (int)blockIdx.x - n_own);
     }
     return;
@@ -309,24 +214,29 @@ static int sphere_trace_lanes(int n) {
   return n >= 6 ? 2 : (n >= 3 ? 4 : 8);
 }
 
-// n colour frames (n = 1: MultiMapper::integrateColor; n > 1: nvbx_integrate_color_batch) of one image size -> one launch set
-template <typename Pix, int NB>
-static int integrate_colors(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t rows, int32_t cols, const float* T_L_C /* n x 16 */, const nvbx_camera* cameras) {
+// n colour frames (n = 1: MultiMapper::integrateColor; n > 1: nvbx_integrate_color_batch) of one image size -> one launch set, in three
+// steps so that a held-back frame (colour deferral, nvbx_mapper.h) can have its sphere tracing launched by the next depth frame:
+// color_setup (checks, frames, scratch), color_launch_trace, color_launch_integrate.
+static int color_precheck(nvbx_mapper* m, int32_t n, int32_t rows, int32_t cols, const float* T_L_C) {
   for (int c = 0; c < n; c++)
     if (!nvbx_pose_in_range(T_L_C + 16 * c, m->p.voxel_size * 8.0f, m->p.sphere_tracing_max_ray_length_m + m->p.max_integration_distance_m)) {
       set_error("integrate color: T_L_C is not finite or lies outside the addressable block range (+-2^20 blocks)"); return NVBX_E_INVALID; }
-  NVBX_HIP(hipSetDevice(m->device));
-  if (m->p.projective_layer_type == 1) return NVBX_OK;      // occupancy mappers carry no colour (the occlusion test sphere-traces a TSDF)
-  if (m->flush_edt()) return NVBX_E_DEVICE;      // a held-back EDT must precede this launch's marking pass (it reads the site masks)
-  FrameSetC<Pix, NB> fs{}; fs.n = n;
-  PoseSet<NB> ps{}; ps.n = n;
-  for (int c = 0; c < n; c++) { fs.f[c] = m->make_frame(T_L_C + 16 * c, cameras + c, rows, cols, m->p.sphere_tracing_subsampling); fs.img[c] = imgs[c]; ps.f[c] = fs.f[c]; }
-  const Frame& f = fs.f[0];
+  const int sub = std::max(1, m->p.sphere_tracing_subsampling);
+  if (rows / sub < 2 || cols / sub < 2) { set_error("colour image too small for the sphere-tracing subsampling"); return NVBX_E_INVALID; }
+  return NVBX_OK;
+}
+template <typename Pix, int NB>
+static int color_setup(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t rows, int32_t cols, const float* T_L_C, const nvbx_camera* cameras,
+                       FrameSetC<Pix, NB>* fs, PoseSet<NB>* ps, int32_t* srows_out, int32_t* scols_out) {
+  *fs = FrameSetC<Pix, NB>{}; fs->n = n;
+  *ps = PoseSet<NB>{}; ps->n = n;
+  for (int c = 0; c < n; c++) { fs->f[c] = m->make_frame(T_L_C + 16 * c, cameras + c, rows, cols, m->p.sphere_tracing_subsampling); fs->img[c] = imgs[c]; ps->f[c] = fs->f[c]; }
+  const Frame& f = fs->f[0];
   { // slots per workgroup iteration of k_integrate_color's candidate scan: from the high-water mark the GPU last reported (a hint only)
     const int64_t hw_seen = std::max<int64_t>(1, __atomic_load_n(&m->h_mirror[1], __ATOMIC_RELAXED));
     int ch = 1; while (ch < 64 && (int64_t)ch * std::min<int64_t>(m->capacity, 1024) * 4 < hw_seen) ch *= 2;     // (up to 4 iterations of single slots: a room-sized map keeps
                                                                                                         //  the stride-grid pairing, which balances the in-band blocks better than runs of neighbours)
-    fs.chunk = ch; }
+    fs->chunk = ch; }
   const int32_t srows = rows / f.subsample, scols = cols / f.subsample;
   if (srows < 2 || scols < 2) { set_error("colour image too small for the sphere-tracing subsampling"); return NVBX_E_INVALID; }
   if ((int64_t)srows * scols * n > m->synth_cap) {
@@ -337,15 +247,28 @@ static int integrate_colors(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t 
     m->synth_cap = (int64_t)srows * scols * n;
   }
   m->synth_rows = srows; m->synth_cols = scols; m->synth_last = n - 1;
-  // one 256-thread workgroup per 8 x (32 / lanes) patch of rays, NSH x ceil(patches / NSH) workgroups per camera (XCD-banded numbering, see the kernel)
-  const int rl = sphere_trace_lanes(n);
+  *srows_out = srows; *scols_out = scols;
+  return NVBX_OK;
+}
+// workgroups of the sphere-tracing launch / rider: one 256-thread workgroup per 8 x (32 / lanes) patch of rays, NSH x ceil(patches / NSH)
+// per camera (XCD-banded numbering, see the worker)
+static int sphere_trace_workgroups(int rl, int32_t srows, int32_t scols, int n) {
   const int ph = 256 / rl / 8;
   const int st_patches = ((scols + 7) / 8) * ((srows + ph - 1) / ph);
-  const dim3 st_grid((unsigned)(NSH * ((st_patches + NSH - 1) / NSH) * n));
+  return NSH * ((st_patches + NSH - 1) / NSH) * n;
+}
+template <int NB>
+static int color_launch_trace(nvbx_mapper* m, const PoseSet<NB>& ps, int32_t n, int32_t srows, int32_t scols) {
+  const int rl = sphere_trace_lanes(n);
+  const dim3 st_grid((unsigned)sphere_trace_workgroups(rl, srows, scols, n));
 #define NVBX_ST_LAUNCH(RL) NVBX_LAUNCH(m, (k_sphere_trace<NB, RL>), st_grid, dim3(256), m->d, ps, m->synth, srows, scols, m->p.sphere_tracing_max_steps, \
                                        m->p.sphere_tracing_max_ray_length_m, m->p.sphere_tracing_surface_eps_vox * m->p.voxel_size)
   if (rl == 8) NVBX_ST_LAUNCH(8); else if (rl == 4) NVBX_ST_LAUNCH(4); else if (rl == 2) NVBX_ST_LAUNCH(2); else NVBX_ST_LAUNCH(1);
 #undef NVBX_ST_LAUNCH
+  return NVBX_OK;
+}
+template <typename Pix, int NB>
+static int color_launch_integrate(nvbx_mapper* m, const FrameSetC<Pix, NB>& fs, int32_t srows, int32_t scols) {
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);     // one resident batch of 512-thread workgroups
   // ESDF site marking of the blocks dirtied since the last marking pass rides in this launch (256 extra single-wavefront
   // workers): it reads only the TSDF, like the colour pass, and a following updateEsdf then needs the EDT kernel only
@@ -355,7 +278,7 @@ static int integrate_colors(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t 
   const bool own = m->p.esdf_mode == 0 && m->p.esdf_propagation == 0 && m->dirty_since_mark && !m->premark_consumed && ea.bz_hi >= ea.bz_lo && ea.bz_hi - ea.bz_lo + 1 <= 63;
   if (own || m->import_pending) {
     m->mark_pass++; ea.mark_pass = m->mark_pass; m->unresolved_marks = true;
-    if (own) { mark_wg = 256; m->dirty_since_mark = false; m->premark_consumed = true; }
+    if (own) { mark_wg = 256; m->dirty_since_mark = false; m->premark_consumed = !ea.self_reset; }     // (pipelined order: the pass empties the list itself)
     if (m->import_pending) {             // (only ever set in 2-D mode with a valid band: nvbx_mark_esdf_dirty_gathered_deferred)
       imp.g = m->import_ptr; imp.world = m->import_world; imp.self_rank = m->import_rank; imp.max_count = m->import_max;
       { const int n_peers = std::max(1, (m->import_rank >= 0 && m->import_rank < m->import_world) ? m->import_world - 1 : m->import_world);
@@ -367,11 +290,63 @@ static int integrate_colors(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t 
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }
+template <typename Pix, int NB>
+static int integrate_colors(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t rows, int32_t cols, const float* T_L_C /* n x 16 */, const nvbx_camera* cameras) {
+  { const int rc = color_precheck(m, n, rows, cols, T_L_C); if (rc) return rc; }
+  NVBX_HIP(hipSetDevice(m->device));
+  if (!m->replaying && m->replay_deferred()) return NVBX_E_DEVICE;      // an older held-back colour frame / ESDF update goes first
+  if (m->p.projective_layer_type == 1) return NVBX_OK;      // occupancy mappers carry no colour (the occlusion test sphere-traces a TSDF)
+  if (m->flush_edt()) return NVBX_E_DEVICE;      // a held-back EDT must precede this launch's marking pass (it reads the site masks)
+  FrameSetC<Pix, NB> fs; PoseSet<NB> ps; int32_t srows = 0, scols = 0;
+  { const int rc = color_setup<Pix, NB>(m, n, imgs, rows, cols, T_L_C, cameras, &fs, &ps, &srows, &scols); if (rc) return rc; }
+  { const int rc = color_launch_trace<NB>(m, ps, n, srows, scols); if (rc) return rc; }
+  return color_launch_integrate<Pix, NB>(m, fs, srows, scols);
+}
+
+// ---- colour deferral (nvbx_mapper.h): hold a single frame back / carry it out in pipelined order
+static bool defer_color(nvbx_mapper* m, int kind, const void* img, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera, int* rc_out) {
+  if (!m->color_deferral || m->replaying || m->p.projective_layer_type == 1) return false;
+  *rc_out = color_precheck(m, 1, rows, cols, T_L_C);            // argument errors are reported by the call that made them
+  if (*rc_out) return true;
+  if (hipSetDevice(m->device) != hipSuccess || m->replay_deferred()) { *rc_out = NVBX_E_DEVICE; return true; }     // an older held-back frame goes first
+  nvbx_mapper::ColorPending& c = m->color_pending;
+  c.on = true; c.kind = kind; c.img = img; c.rows = rows; c.cols = cols; memcpy(c.T, T_L_C, sizeof(c.T)); c.cam = *camera;
+  *rc_out = NVBX_OK;
+  return true;
+}
+// the held-back frame's set-up; its sphere tracing as a rider of the caller's launch
+static_assert(sizeof(FrameSetC<PixRgb8, 1>) == sizeof(FrameSetC<PixBgra8, 1>), "colour frame sets share one layout");
+int nvbx_mapper::pending_color_trace_rider(void* out) {
+  TraceRider* tr = static_cast<TraceRider*>(out);
+  const ColorPending& c = color_pending;
+  int32_t srows = 0, scols = 0;
+  int rc;
+  if (c.kind == 0) { const PixRgb8 img{(const uint8_t*)c.img}; FrameSetC<PixRgb8, 1> fs; rc = color_setup<PixRgb8, 1>(this, 1, &img, c.rows, c.cols, c.T, &c.cam, &fs, &tr->ps, &srows, &scols); }
+  else { const PixBgra8 img{(const uint32_t*)c.img}; FrameSetC<PixBgra8, 1> fs; rc = color_setup<PixBgra8, 1>(this, 1, &img, c.rows, c.cols, c.T, &c.cam, &fs, &tr->ps, &srows, &scols); }
+  if (rc) return rc;
+  tr->synth = synth; tr->srows = srows; tr->scols = scols; tr->max_steps = p.sphere_tracing_max_steps;
+  tr->max_len = p.sphere_tracing_max_ray_length_m; tr->eps_m = p.sphere_tracing_surface_eps_vox * p.voxel_size;
+  tr->n_wg = sphere_trace_workgroups(8, srows, scols, 1);          // (the rider runs the single-camera form: 8 lanes per ray)
+  return NVBX_OK;
+}
+int nvbx_mapper::launch_pending_color_after_trace() {
+  const ColorPending c = color_pending; color_pending.on = false;
+  int32_t srows = 0, scols = 0;
+  if (c.kind == 0) {
+    const PixRgb8 img{(const uint8_t*)c.img}; FrameSetC<PixRgb8, 1> fs; PoseSet<1> ps;
+    const int rc = color_setup<PixRgb8, 1>(this, 1, &img, c.rows, c.cols, c.T, &c.cam, &fs, &ps, &srows, &scols); if (rc) return rc;
+    return color_launch_integrate<PixRgb8, 1>(this, fs, srows, scols);
+  }
+  const PixBgra8 img{(const uint32_t*)c.img}; FrameSetC<PixBgra8, 1> fs; PoseSet<1> ps;
+  const int rc = color_setup<PixBgra8, 1>(this, 1, &img, c.rows, c.cols, c.T, &c.cam, &fs, &ps, &srows, &scols); if (rc) return rc;
+  return color_launch_integrate<PixBgra8, 1>(this, fs, srows, scols);
+}
 
 extern "C" int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                     const nvbx_camera* camera) {
   if (!m || !rgb_dev || !T_L_C || !camera || !image_dims_ok(rows, cols)) { set_error("nvbx_integrate_color: invalid argument (image sides 1 .. 32768)"); return NVBX_E_INVALID; }
   if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_color: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
+  { int rc = NVBX_OK; if (defer_color(m, 0, rgb_dev, rows, cols, T_L_C, camera, &rc)) return rc; }
   const PixRgb8 img{rgb_dev};
   return integrate_colors<PixRgb8, 1>(m, 1, &img, rows, cols, T_L_C, camera);
 }
@@ -379,6 +354,7 @@ extern "C" int nvbx_integrate_color_bgra8(nvbx_mapper* m, const uint8_t* bgra_de
                                           const nvbx_camera* camera) {
   if (!m || !bgra_dev || !T_L_C || !camera || !image_dims_ok(rows, cols) || ((uintptr_t)bgra_dev & 3)) { set_error("nvbx_integrate_color_bgra8: invalid argument"); return NVBX_E_INVALID; }
   if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_color_bgra8: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
+  { int rc = NVBX_OK; if (defer_color(m, 1, bgra_dev, rows, cols, T_L_C, camera, &rc)) return rc; }
   const PixBgra8 img{reinterpret_cast<const uint32_t*>(bgra_dev)};
   return integrate_colors<PixBgra8, 1>(m, 1, &img, rows, cols, T_L_C, camera);
 }
@@ -396,6 +372,7 @@ extern "C" int nvbx_integrate_color_batch(nvbx_mapper* m, int32_t n, const uint8
 
 extern "C" int nvbx_get_synthetic_depth(nvbx_mapper* m, float* out_host, int64_t capacity, int32_t* rows, int32_t* cols) {
   if (!m || !rows || !cols) return NVBX_E_INVALID;
+  if (m->join_side()) return NVBX_E_DEVICE;          // (a held-back colour frame is carried out first)
   *rows = m->synth_rows; *cols = m->synth_cols;
   const int64_t n = (int64_t)m->synth_rows * m->synth_cols;
   if (!out_host || n == 0) return NVBX_OK;

@@ -26,7 +26,7 @@
 
 using namespace nvbx;
 
-__global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a) { esdf_mark_worker(m, a, (int)blockIdx.x, (int)gridDim.x); }
+__global__ __launch_bounds__(64) void k_esdf_mark(DMap m, EsdfArgs a) { esdf_mark_worker(m, a, (int)blockIdx.x, (int)gridDim.x); esdf_mark_pass_done(m, a, (int)gridDim.x); }
 
 __global__ __launch_bounds__(256) void k_esdf_edt(DMap m, EsdfArgs a) {
   __shared__ EdtShared sh;
@@ -166,6 +166,11 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
   if (m->p.esdf_max_distance_m / m->p.voxel_size >= 64.0f) { set_error("esdf_max_distance_m / voxel_size must be < 64 voxels"); return NVBX_E_INVALID; }
   { const EsdfArgs chk = m->make_esdf_args();
     if (chk.bz_hi - chk.bz_lo + 1 > 63 || chk.bz_hi < chk.bz_lo) { set_error("esdf slice z band must span 1..63 blocks"); return NVBX_E_INVALID; } }
+  // colour deferral (nvbx_mapper_set_color_deferral): while a colour frame is held back this update is held back behind it -- its
+  // marking pass rides in that colour launch; both are carried out by the next integrateDepth (pipelined) or by whatever entry point
+  // comes first (join_side -> replay_deferred, in call order)
+  if (m->color_pending.on && !m->replaying && m->p.esdf_propagation == 0 && !m->use_side && m->defer_edt) { m->esdf_update_pending = true; return NVBX_OK; }
+  if (!m->replaying && !m->pipelined_order && m->replay_deferred()) return NVBX_E_DEVICE;
   // a distance transform still held back by the PREVIOUS update goes first: this update's marking pass overwrites the masks
   // and the parity-indexed window record it reads, and edt_args holds one update only (two updates back to back)
   if (m->flush_edt()) return NVBX_E_DEVICE;

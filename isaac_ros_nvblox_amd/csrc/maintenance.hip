@@ -50,7 +50,7 @@ __device__ inline void wave_list_append(const DMap& m, int32_t list, bool push, 
 template <bool OCC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, uint32_t exclude_mask, int32_t mesh_list,
                                                int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc, int32_t* cleared_idx, int32_t keep_blocks, int32_t to_free, float free_dist) {
-  // [U] decay switches (mapper_initialization.cpp:383-428; oracle orc_decay_tsdf / orc_decay_occupancy, same lines): keep_blocks =
+  // [U] decay switches (mapper_initialization.cpp:383-428; restated line by line in the CPU checker): keep_blocks =
   // !decay_integrator_deallocate_decayed_blocks (a fully decayed block stays allocated); to_free = tsdf_set_free_distance_on_decayed (an
   // OBSERVED voxel whose weight falls below the threshold becomes free: distance free_dist, weight = the threshold) resp.
   // occupancy_decay_to_free (occupied voxels decay past unknown into free and stay there; free voxels are not decayed)

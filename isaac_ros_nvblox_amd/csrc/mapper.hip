@@ -236,7 +236,7 @@ static int reset_map(nvbx_mapper* m) {
   NVBX_LAUNCH(m, k_init_map, dim3((unsigned)((n + 255) / 256)), dim3(256), d);
   NVBX_HIP(hipGetLastError());
   m->dirty_since_mark = false; m->premark_consumed = false; m->mark_pass = 0; m->edt_pending = false; m->import_pending = false;
-  m->unresolved_marks = false; m->pass_at_last_edt = 0;
+  m->unresolved_marks = false; m->pass_at_last_edt = 0; m->color_pending.on = false; m->esdf_update_pending = false;
   if (m->h_mirror) { m->h_mirror[0] = (int32_t)m->capacity; m->h_mirror[1] = 0; m->h_mirror[2] = 0; }
   m->frame_id = 0; m->esdf_epoch = 0; m->mesh_epoch = 0; m->last_view_frame = 0; m->last_camera_view_frame = 0; m->synth_rows = m->synth_cols = 0;
   return NVBX_OK;
@@ -299,6 +299,7 @@ EsdfArgs nvbx_mapper::make_esdf_args() const {
   c.min_weight = p.esdf_min_weight; c.voxel_size = vs; c.site_rule = p.projective_layer_type == 1 ? 2 : p.esdf_site_rule;
   c.epoch = esdf_epoch; c.mark_pass = mark_pass;
   c.rec = C_ESDF_UPD + 8 * (int)(esdf_epoch & 1); c.rec_next = C_ESDF_UPD + 8 * (int)((esdf_epoch + 1) & 1);
+  c.self_reset = c.keep_list = pipelined_order ? 1 : 0;       // (see EsdfArgs)
   return c;
 }
 
@@ -892,10 +893,32 @@ int nvbx_mapper::join_side() {
   // every entry point passes here before its first HIP call: make this mapper's device current (hosts with one mapper per GPU in
   // one process); a thread-local read when it already is
   { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != device) NVBX_HIP(hipSetDevice(device)); }
+  if (!replaying && !pipelined_order && replay_deferred()) return NVBX_E_DEVICE;      // held-back integrateColor / updateEsdf: carried out first, in call order
   if (flush_edt()) return NVBX_E_DEVICE;
   if (flush_import()) return NVBX_E_DEVICE;
   main_dirty = true;
   if (side_pending) { NVBX_HIP(hipStreamWaitEvent(stream, ev_side, 0)); side_pending = false; }
+  return NVBX_OK;
+}
+// the held-back calls of colour deferral, carried out as they would have been at call time
+int nvbx_mapper::replay_deferred() {
+  if (!color_pending.on && !esdf_update_pending) return NVBX_OK;
+  replaying = true;
+  int rc = NVBX_OK;
+  if (color_pending.on) {
+    const ColorPending c = color_pending; color_pending.on = false;
+    rc = c.kind == 0 ? nvbx_integrate_color(this, (const uint8_t*)c.img, c.rows, c.cols, c.T, &c.cam)
+                     : nvbx_integrate_color_bgra8(this, (const uint8_t*)c.img, c.rows, c.cols, c.T, &c.cam);
+  }
+  if (rc == NVBX_OK && esdf_update_pending) { esdf_update_pending = false; rc = nvbx_update_esdf(this); }
+  esdf_update_pending = false;
+  replaying = false;
+  return rc == NVBX_OK ? NVBX_OK : NVBX_E_DEVICE;
+}
+extern "C" int nvbx_mapper_set_color_deferral(nvbx_mapper* m, int32_t enable) {
+  if (!m) return NVBX_E_INVALID;
+  if (m->join_side()) return NVBX_E_DEVICE;          // (anything held back under the old setting is carried out)
+  m->color_deferral = enable != 0;
   return NVBX_OK;
 }
 int nvbx_mapper::mark_main() {

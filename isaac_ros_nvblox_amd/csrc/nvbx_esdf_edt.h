@@ -43,7 +43,7 @@ __device__ inline void esdf_edt_worker(const DMap& m, const EsdfArgs& a, int wg,
     *shc_at(m, srec_next, tid, 0) = INT32_MAX; *shc_at(m, srec_next, tid, 1) = INT32_MAX;
     *shc_at(m, srec_next, tid, 2) = INT32_MIN; *shc_at(m, srec_next, tid, 3) = INT32_MIN;
     *shc_at(m, srec_next, tid, 4) = 0; *shc_at(m, srec_next, tid, 5) = 0;
-    *shc_at(m, S_LIST_ESDF_DIRTY, tid, 0) = 0;                     // dirty list consumed by k_esdf_mark
+    if (!a.keep_list) *shc_at(m, S_LIST_ESDF_DIRTY, tid, 0) = 0;   // dirty list consumed by k_esdf_mark (pipelined order: emptied by the marking pass itself)
     if (tid == 0) { m.counters[a.rec_next + 6] = 0; if (ok) m.counters[a.rec + 6] = ww * 8 * wh * 8; }
   }
   if (!ok) return;

@@ -96,6 +96,22 @@ __device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg
   for (int32_t j = j0; j < cnt; j += per) esdf_mark_entry(m, a, (uint32_t)(j == j0 ? first : base[j]), srec, sh);
 }
 
+// A marking pass that empties the list it consumed (EsdfArgs::self_reset): every one of its `n_workers` wavefronts calls this when it is
+// done with its entries; the last one to arrive resets the shard counts and the arrival counter.  Nothing appends to the list while a
+// marking pass runs (stream order), so the reset cannot lose an entry.
+__device__ inline void esdf_mark_pass_done(const DMap& m, const EsdfArgs& a, int n_workers) {
+  if (!a.self_reset) return;
+  __threadfence();                                        // this worker's list reads are complete before it is counted
+  if ((threadIdx.x & 63) == 0) {
+    const int32_t arrived = atomicAdd(&m.counters[C_MARK_DONE], 1);
+    if (arrived == n_workers - 1) {
+#pragma unroll
+      for (int s = 0; s < NSH; s++) __hip_atomic_store(shc_at(m, S_LIST_ESDF_DIRTY, s, 0), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&m.counters[C_MARK_DONE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // The peers' gathered dirty lists (multi-GPU union step): g = int32 [world][1 + max_count][3], row 0 of a rank = its count.
 struct ImportArgs { const int32_t* g; int32_t world, self_rank; int64_t max_count; int32_t n_wg; };
 // worker `w` of imp.n_wg single-wavefront workers over all peers' entries: look the block up, re-mark its column on the spot

@@ -87,6 +87,7 @@ enum {
   C_LIVE = 44,         // live hash entries
   C_TMP = 45,          // scratch counter (point cloud compaction etc.)
   C_CLEARED = 46,      // entries of the cleared-block list (nvbx_take_cleared_blocks)
+  C_MARK_DONE = 47,    // workers of the running ESDF marking pass that have finished (a pass that empties the dirty list itself, EsdfArgs::self_reset)
   C_NUM = 48
 };
 

@@ -21,6 +21,12 @@ struct EsdfArgs {
   uint32_t mark_pass;               // stamp of this marking pass (column de-duplication within one pass)
   int32_t rec;                      // C_ESDF_UPD + 8 * (epoch & 1)
   int32_t rec_next;                 // record of the next epoch (reset by this update)
+  // Who empties the ESDF-dirty list a marking pass has consumed.  Classic order (marking -> view marking of the next frame / EDT -> TSDF
+  // update): the next k_mark_view or the EDT does (the consumed list still names "the blocks dirtied since the last updateEsdf" for
+  // nvbx_esdf_dirty_list until then).  Pipelined order (colour deferral, DESIGN.md 2.8: view marking(i+1) || sphere tracing(i) -> colour(i) +
+  // marking -> TSDF update(i+1)): nothing runs between the marking pass and the next appends, so the pass empties the list itself --
+  // its last worker, counted in C_MARK_DONE (self_reset) -- and the EDT of that update, which then runs AFTER those appends, must not (keep_list).
+  int32_t self_reset, keep_list;
 };
 
 struct MeshRecord { int32_t x, y, z, vbase, nvert, tbase, ntri, pad; };
@@ -124,6 +130,21 @@ struct nvbx_mapper {
   // launch beside the marking of the mapper's own dirty blocks; every other entry point launches it first (flush_import)
   bool import_pending = false; const int32_t* import_ptr = nullptr; int32_t import_world = 0, import_rank = 0; int64_t import_max = 0;
   int flush_import();
+  // Colour deferral (nvbx_mapper_set_color_deferral): integrateColor of a single frame is HELD BACK -- arguments remembered,
+  // nothing launched -- and so is an updateEsdf that follows it.  The next single-camera integrateDepth carries them out in pipelined
+  // order: view marking of the new depth frame || sphere tracing of the held-back colour frame (one launch), colour integration + ESDF
+  // marking, TSDF update of the new frame -- three launches per frame instead of four.  Every other entry point first replays the held-back
+  // calls as they are (join_side -> replay_deferred), so the API observes call order.  Contract: the colour image must stay valid and
+  // unchanged until the next call into the mapper has returned.
+  struct ColorPending { bool on = false; int kind = 0; const void* img = nullptr; int32_t rows = 0, cols = 0; float T[16]; nvbx_camera cam; };
+  bool color_deferral = false;       // the switch
+  ColorPending color_pending;        // the held-back integrateColor
+  bool esdf_update_pending = false;  // an updateEsdf called while a colour frame was held back
+  bool replaying = false;            // inside replay_deferred: the calls run as usual
+  bool pipelined_order = false;      // inside the pipelined integrateDepth: marking passes empty their list, EDTs keep it (EsdfArgs)
+  int replay_deferred();
+  int pending_color_trace_rider(void* trace_rider_out);   // color.hip: set the held-back frame up; its sphere tracing as a nvbx::TraceRider
+  int launch_pending_color_after_trace();      // color.hip: colour integration (+ ESDF marking riders) of color_pending, its sphere tracing already launched
   int32_t* view_export = nullptr; int64_t view_export_cap = 0;      // nvbx_set_view_export
   int reset_consumed_list();         // empty a consumed dirty list (tiny launch; rare paths only)
   int begin_dirtying() { const int rc = reset_consumed_list(); dirty_since_mark = true; return rc; }

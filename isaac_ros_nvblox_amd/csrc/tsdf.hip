@@ -22,6 +22,7 @@
 #include "nvbx_mapper.h"
 #include "nvbx_lidar_math.h"
 #include "nvbx_esdf_edt.h"
+#include "nvbx_sphere_trace.h"
 
 using namespace nvbx;
 
@@ -330,7 +331,7 @@ template <typename Img, int NB> struct FrameSet { Frame f[NB]; Img img[NB]; int3
 
 template <typename Img, typename Sensor, int NB>
 __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet<Img, NB> fs, Sensor sensor, int4* view_list, int32_t list_cap,
-                                                                int32_t reset_esdf_dirty, int32_t n_edt_wg, EsdfArgs ea) {
+                                                                int32_t reset_esdf_dirty, int32_t n_edt_wg, EsdfArgs ea, TraceRider tr) {
   constexpr int LSET = Sensor::kSetSize, FR = Sensor::kFlushRounds;
   constexpr size_t kMarkBytes = 2 * LSET * sizeof(u64);
   constexpr size_t kSmem = (Sensor::kThreads == 256 && sizeof(EdtShared) > kMarkBytes) ? sizeof(EdtShared) : kMarkBytes;
@@ -338,6 +339,12 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   if (Sensor::kThreads == 256) {
     if ((int32_t)blockIdx.x < n_edt_wg) {
       esdf_edt_worker(m, ea, (int)blockIdx.x, n_edt_wg, reinterpret_cast<EdtShared*>(smem));
+      return;
+    }
+    // workgroups [n_edt_wg, n_edt_wg + tr.n_wg): the sphere tracing of a held-back colour frame (colour deferral) -- all four
+    // wavefronts; independent of the view marking (it reads the TSDF and the insert-only hash; new entries point at all-zero blocks)
+    if ((int32_t)blockIdx.x < n_edt_wg + tr.n_wg) {
+      sphere_trace_worker<1, 8>(m, tr.ps, tr.synth, tr.srows, tr.scols, tr.max_steps, tr.max_len, tr.eps_m, (int)blockIdx.x - n_edt_wg);
       return;
     }
     if (threadIdx.x >= 64) return;            // a tile is one wavefront
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   const int tiles_x = (f0.n_ray_cols + TC - 1) / TC, tiles_y = (f0.n_ray_rows + TR - 1) / TR;
   // XCD-aware numbering: workgroups go round-robin over the 8 XCDs (each with its own L2), so the tiles of one XCD (wg & 7) are a
   // contiguous band of tile rows -- neighbouring tiles share most of their blocks, i.e. their hash lines (n_edt_wg is a multiple of 8)
-  const int wg_all = (int)blockIdx.x - (Sensor::kThreads == 256 ? n_edt_wg : 0);
+  const int wg_all = (int)blockIdx.x - (Sensor::kThreads == 256 ? n_edt_wg + tr.n_wg : 0);      // (both rider counts are multiples of 8: the XCD of tile wg stays wg & 7)
   const int n_tiles = tiles_x * tiles_y, per_xcd = (n_tiles + NSH - 1) / NSH;
   const int cam = NB > 1 ? wg_all / (NSH * per_xcd) : 0;        // batch: NSH * per_xcd workgroups per camera, camera after camera
   const int wg = wg_all - cam * (NSH * per_xcd);
@@ -581,8 +588,22 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
     if (Sensor::kThreads == 256) { edt_wg = 256; m->edt_pending = false; }        // (256 .. 1024 riders measured: no difference, profiles/r02x_kernel_isolation.txt)
     else if (m->flush_edt()) return NVBX_E_DEVICE;
   }
-  NVBX_LAUNCH(m, (k_mark_view<Img, Sensor, NB>), dim3(tiles + edt_wg), dim3(Sensor::kThreads), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
-              (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)edt_wg, ea);
+  // Colour deferral: a held-back integrateColor (and an updateEsdf behind it) is carried out in PIPELINED order -- its sphere tracing rides
+  // in this view-marking launch, its colour integration + ESDF marking follow, then this frame's TSDF update: three launches per frame.
+  TraceRider tr{};
+  const bool pipelined = Sensor::kThreads == 256 && NB == 1 && m->color_pending.on;
+  if (pipelined) { m->pipelined_order = true; const int rc = m->pending_color_trace_rider(&tr); if (rc) { m->pipelined_order = false; return rc; } }
+  NVBX_LAUNCH(m, (k_mark_view<Img, Sensor, NB>), dim3(tiles + edt_wg + tr.n_wg), dim3(Sensor::kThreads), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
+              (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)edt_wg, ea, tr);
+  if (pipelined) {
+    // the host-side steps of the held-back calls, in call order: integrateColor (its marking pass empties the dirty list itself, the EDT
+    // of the update keeps it -- EsdfArgs), then updateEsdf (which only arms the next held-back EDT: the marking has just been launched)
+    m->premark_consumed = false;
+    int rc = m->launch_pending_color_after_trace();
+    if (rc == NVBX_OK && m->esdf_update_pending) { m->esdf_update_pending = false; rc = nvbx_update_esdf(m); }
+    m->pipelined_order = false;
+    if (rc) return rc;
+  }
   m->premark_consumed = false; m->dirty_since_mark = true;
   // grid-stride over the view list: exactly the 1024 workgroups that are resident together (4 per CU)
   static const int grid_cap = getenv("NVBX_INTEG_GRID") ? atoi(getenv("NVBX_INTEG_GRID")) : 1024;    // (env: tools/integ_grid_sweep.sh)
@@ -648,10 +669,18 @@ static int integrate_cameras(nvbx_mapper* m, int32_t n, const Img* imgs, int32_t
     if (!nvbx_pose_in_range(T_L_C + 16 * c, m->p.voxel_size * 8.0f, m->p.max_integration_distance_m + 2.0f * m->p.truncation_distance_vox * m->p.voxel_size)) {
       set_error("integrate depth: T_L_C is not finite or lies outside the addressable block range (+-2^20 blocks)"); return NVBX_E_INVALID; }
   NVBX_HIP(hipSetDevice(m->device));
+  const bool dilate_first = m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0;
   { const bool pend = m->edt_pending, ipend = m->import_pending; m->edt_pending = false; m->import_pending = false;
     // (join_side would launch a held-back EDT / union step; the EDT rides in k_mark_view instead, the union step stays held back
     //  for the next integrateColor -- it belongs to the NEXT ESDF update and touches nothing this launch reads)
-    const int rc = m->join_side(); m->edt_pending = pend; m->import_pending = ipend; if (rc) return NVBX_E_DEVICE; }
+    // A held-back colour frame (+ ESDF update) stays held back too when this call can carry it out in pipelined order (a single frame,
+    // no dilation launch in front); otherwise join_side replays it now.
+    const bool keep = NB == 1 && !dilate_first && m->color_pending.on;
+    const nvbx_mapper::ColorPending cp = m->color_pending; const bool up = m->esdf_update_pending;
+    if (keep) { m->color_pending.on = false; m->esdf_update_pending = false; }
+    const int rc = m->join_side(); m->edt_pending = pend; m->import_pending = ipend;
+    if (keep) { m->color_pending = cp; m->esdf_update_pending = up; }
+    if (rc) return NVBX_E_DEVICE; }
   { const int rc = m->maybe_grow(); if (rc) return rc; }          // (before anything of this frame is enqueued)
   const bool dilate = m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0;
   if (dilate && m->flush_edt()) return NVBX_E_DEVICE;   // first launch is the dilation
@@ -829,7 +858,7 @@ extern "C" int nvbx_measure_depth(nvbx_mapper* m, const float* depth_dev, int32_
   // the view calculation against the local map: blocks in view are looked up / allocated exactly as integrateDepth would (they receive
   // their values when the gathered measurements are applied)
   NVBX_LAUNCH(m, (k_mark_view<DepthF32, CameraSensor, 1>), dim3(NSH * ((n_tiles + NSH - 1) / NSH)), dim3(CameraSensor::kThreads), m->d, fs, CameraSensor{},
-              (int4*)m->view_list, (int32_t)m->capacity, (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)0, m->edt_args);
+              (int4*)m->view_list, (int32_t)m->capacity, (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)0, m->edt_args, TraceRider{});
   m->premark_consumed = false;
   NVBX_LAUNCH(m, (k_measure_tsdf<DepthF32>), dim3((unsigned)std::min<int64_t>(m->capacity, 1024)), dim3(512), m->d, f, DepthF32{depth_dev}, CameraSensor{},
               (const int4*)m->view_list, (int32_t)m->capacity, reinterpret_cast<MeasRec*>(out_dev), count_dev, (int32_t)std::min<int64_t>(capacity_blocks, INT32_MAX));

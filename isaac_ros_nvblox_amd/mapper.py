@@ -85,6 +85,12 @@ class Mapper:
     def set_max_capacity(self, max_blocks):
         self._check(self.lib.nvbx_mapper_set_max_capacity(self._h, int(max_blocks)))
 
+    def set_color_deferral(self, enable):
+        """Hold integrateColor (and an updateEsdf behind it) back until the next integrateDepth carries them out in pipelined order (three
+        launches per frame instead of four; include/nvblox_hip.h nvbx_mapper_set_color_deferral).  The colour image handed to integrate_color must
+        then stay valid and unchanged until the next call into the mapper has returned."""
+        self._check(self.lib.nvbx_mapper_set_color_deferral(self._h, 1 if enable else 0))
+
     def _check(self, rc):
         if rc < 0:
             raise NvbxError("nvbx error %d: %s" % (rc, self.lib.nvbx_last_error().decode()))

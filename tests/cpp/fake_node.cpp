@@ -443,7 +443,7 @@ int main(int argc, char** argv) {
     fg->serializeSelectedLayers(LayerType::kOccupancy, -1.0f, ex);
     const size_t occ_in = fg->serializedOccupancyLayer()->block_indices.size();
     ex.exclusion_radius_m = -1.0f;
-    fg->serializeSelectedLayers(LayerType::kOccupancy, 0.05f, ex);              // below one block's worth: exactly one block goes out
+    fg->serializeSelectedLayers(LayerType::kOccupancy, 0.001f, ex);             // below one block's worth: exactly one block goes out
     if (fs_all < 100 || fs_some.empty() || fs_some.size() > 30 || far_kept > 1.6f * 1.6f || occ_in < 1 || occ_in > (size_t)dyn_blocks ||
         fg->serializedOccupancyLayer()->block_indices.size() != 1) {
       std::fprintf(stderr, "rationed freespace / occupancy streams: freespace %zu of %zu (farthest %g), occupancy %zu in the cylinder of %d, %zu under a tiny budget\n",

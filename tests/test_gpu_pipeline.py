@@ -1,0 +1,101 @@
+"""Colour deferral / cross-frame pipelining (nvbx_mapper_set_color_deferral): view marking of depth frame i+1 runs in one
+launch with the sphere tracing of colour frame i.  Whatever the order of launches, the API must observe call order: a deferred mapper and
+a classic one fed the same calls hold bit-identical maps at every point where anything is read."""
+import numpy as np
+import pytest
+
+import helpers as H
+from isaac_ros_nvblox_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _equal_maps(M, a, b):
+    for layer, fields in ((M.LAYER_TSDF, ("distance", "weight")), (M.LAYER_COLOR, ("r", "g", "b", "weight")),
+                          (M.LAYER_ESDF, ("squared_distance_vox", "parent_direction", "is_inside", "observed", "is_site"))):
+        ia = a.block_indices(layer); ib = b.block_indices(layer)
+        assert np.array_equal(ia, ib), layer
+        if len(ia) == 0:
+            continue
+        ba, _ = a.get_blocks(layer, ia); bb, _ = b.get_blocks(layer, ia)
+        for f in fields:
+            assert np.array_equal(ba[f], bb[f]), (layer, f)
+    sa, aa = a.esdf_slice_image(); sb, ab = b.esdf_slice_image()
+    assert sa.shape == sb.shape and np.array_equal(sa, sb) and np.array_equal(aa, ab)
+
+
+@pytest.mark.parametrize("cam", [H.SMALL_CAM, S.REPLICA_LIKE_CAM], ids=["160x120", "640x480"])
+def test_steady_state_pipeline_equals_classic_and_oracle(oracle_mod, hip_lib, cam):
+    """The bench's loop -- depth, colour, updateEsdf per frame -- for 12 frames: every frame but the first takes the pipelined path."""
+    from isaac_ros_nvblox_amd import mapper as M
+    from test_gpu_parity import compare_layer, TOL
+    pg = M.default_params(); po = H.copy_params(pg, oracle_mod.OrcParams)
+    classic = M.Mapper(pg, block_capacity=1 << 14); piped = M.Mapper(pg, block_capacity=1 << 14); o = oracle_mod.OracleMap(po)
+    piped.set_color_deferral(True)
+    for k, (d, rgb, T) in enumerate(H.frames(12, cam, stride=7)):
+        for m_ in (classic, piped, o):
+            m_.integrate_depth(d, T, cam); m_.integrate_color(rgb, T, cam); m_.update_esdf()
+        assert H.idx_set(piped.last_view()) == H.idx_set(o.last_view())
+        if k in (0, 5, 11):                  # (a query flushes the pipeline: the frames in between run pipelined, undisturbed)
+            _equal_maps(M, classic, piped)
+            assert H.idx_set(piped.last_color_view()) == H.idx_set(o.last_color_view())
+    compare_layer(M, piped, o, M.LAYER_TSDF, oracle_mod.L_TSDF, fields_tol=("distance", "weight"))
+    compare_layer(M, piped, o, M.LAYER_COLOR, oracle_mod.L_COLOR, fields_tol=("weight",), lsb_fields=("r", "g", "b"))
+    sg, _ = piped.esdf_slice_image(); so, _ = o.esdf_slice_image()
+    assert sg.shape == so.shape and np.abs(sg - so).max() <= TOL
+    piped.update_color_mesh(); classic.update_color_mesh()
+    ma, mb = piped.mesh(), classic.mesh()
+    assert ma.keys() == mb.keys() and all(np.array_equal(ma[k_]["triangles"], mb[k_]["triangles"]) and np.array_equal(ma[k_]["vertices"], mb[k_]["vertices"]) for k_ in ma)
+    assert piped.counters()["capacity_overflow"] == 0
+
+
+def test_deferred_calls_are_replayed_by_every_other_entry_point(oracle_mod, hip_lib):
+    """Irregular call patterns: two colour frames in a row, an ESDF update without a colour frame, colour without ESDF, bgra8 colour, a LiDAR
+    scan / decay / clearing / mesh / batch right behind a held-back colour frame, switching deferral off with a frame pending, clear()."""
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    pg = M.default_params(tsdf_decay_factor=0.7, tsdf_decayed_weight_threshold=0.2, lidar_max_integration_distance_m=6.0)
+    a = M.Mapper(pg, block_capacity=1 << 14); b = M.Mapper(pg, block_capacity=1 << 14)
+    b.set_color_deferral(True)
+    fr = H.frames(16, cam, stride=5)
+    lidar = (128, 16, 0.1, -np.deg2rad(20.0), np.deg2rad(20.0))
+    Tl = np.eye(4, dtype=np.float32); Tl[:3, 3] = (-1.0, 0.5, 1.0)
+    rng_img = S.Scene().raycast(Tl[:3, 3].astype(float), S.lidar_beam_dirs(lidar).reshape(-1, 3)).reshape(16, 128).astype(np.float32)
+
+    def both(fn):
+        fn(a); fn(b)
+    for k, (d, rgb, T) in enumerate(fr):
+        both(lambda m: m.integrate_depth(d, T, cam))
+        if k % 4 != 3:
+            both(lambda m: m.integrate_color(rgb, T, cam))
+        if k % 5 == 1:
+            both(lambda m: m.integrate_color(fr[(k + 3) % 16][1], fr[(k + 3) % 16][2], cam))          # a second camera's colour frame
+        if k % 3 != 2:
+            both(lambda m: m.update_esdf())
+        if k == 2:
+            both(lambda m: m.integrate_lidar_depth(rng_img, Tl, lidar))
+        if k == 4:
+            both(lambda m: m.decay_tsdf(True))
+        if k == 6:
+            both(lambda m: m.clear_outside_radius((float(T[0, 3]), float(T[1, 3]), 1.0), 3.0))
+        if k == 7:
+            both(lambda m: m.update_color_mesh())
+        if k == 8:
+            both(lambda m: m.integrate_depth_batch([fr[1][0], fr[9][0]], [fr[1][2], fr[9][2]], cam))
+            both(lambda m: m.integrate_color_batch([fr[1][1], fr[9][1]], [fr[1][2], fr[9][2]], cam))
+        if k == 10:
+            b.set_color_deferral(False)
+        if k == 12:
+            b.set_color_deferral(True)
+        if k % 4 == 1 or k == 15:
+            _equal_maps(M, a, b)
+    both(lambda m: m.update_esdf())
+    _equal_maps(M, a, b)
+    assert len(a.block_indices(M.LAYER_COLOR)) > 50
+    # clear() with a frame held back: the frame is dropped with the map
+    d, rgb, T = fr[0]
+    both(lambda m: m.integrate_depth(d, T, cam)); both(lambda m: m.integrate_color(rgb, T, cam))
+    both(lambda m: m.clear())
+    assert b.num_blocks(M.LAYER_TSDF) == 0
+    both(lambda m: m.integrate_depth(d, T, cam)); both(lambda m: m.integrate_color(rgb, T, cam)); both(lambda m: m.update_esdf())
+    _equal_maps(M, a, b)

@@ -37,11 +37,15 @@ def check_all(M, oracle_mod, g, o, mesh=True):
     return 0
 
 
+@pytest.mark.parametrize("deferral", [False, True], ids=["classic", "colour-deferral"])
 @pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
-def test_random_api_sequence_parity(oracle_mod, hip_lib, seed):
+def test_random_api_sequence_parity(oracle_mod, hip_lib, seed, deferral):
+    """deferral = nvbx_mapper_set_color_deferral: integrateColor / updateEsdf held back and carried out by the next integrateDepth in
+    pipelined order, or replayed by whatever other entry point comes first -- the same map either way"""
     rng = np.random.default_rng(100 + seed)
     M, g, o = make_pair(oracle_mod, tsdf_decay_factor=0.7, tsdf_decayed_weight_threshold=0.2,
                         invalid_depth_decay_factor=(0.8 if seed % 3 == 2 else -1.0), weighting_mode=(4 if seed % 3 == 1 else 0))
+    g.set_color_deferral(deferral)
     sc = S.Scene()
     n_ops = {"depth": 0, "color": 0, "esdf": 0, "mesh": 0, "decay": 0, "radius": 0, "shapes": 0}
     last_T = None
@@ -112,12 +116,14 @@ def test_redwood_like_decay_dynamic_sequence(oracle_mod, hip_lib, CAM):
     assert (np.abs(w - np.round(w)) > 1e-3).mean() > 0.5
 
 
-def test_long_soak_parity(oracle_mod, hip_lib):
+@pytest.mark.parametrize("deferral", [False, True], ids=["classic", "colour-deferral"])
+def test_long_soak_parity(oracle_mod, hip_lib, deferral):
     """400 frames of a wandering camera with colour, an ESDF update every 3rd frame, decay every 7th, radius clearing every 40th and
     a mesh update every 25th -- thousands of block allocations, deallocations, slot re-use and hash rebuilds; the maps are
     compared with the oracle every 50 frames.  Guards the device-side allocator / hash / work lists against rare races."""
     rng = np.random.default_rng(7)
     M, g, o = make_pair(oracle_mod, tsdf_decay_factor=0.8, tsdf_decayed_weight_threshold=0.15, max_integration_distance_m=5.0)
+    g.set_color_deferral(deferral)
     sc = S.Scene()
     pos = np.array([0.0, 0.0, 1.4]); yaw = 0.0
     live_hist = []
