@@ -941,14 +941,14 @@ extern "C" int nvbx_get_profile(nvbx_mapper* m, char* json_out, int64_t capacity
   if (!m || !json_out || capacity < 4) return NVBX_E_INVALID;
   if (m->join_side()) return NVBX_E_DEVICE;
   NVBX_HIP(hipStreamSynchronize(m->stream));
-  struct Acc { const char* name; int64_t n; double ms; };
+  struct Acc { const char* name; int64_t n; double ms; double max_ms; };
   std::vector<Acc> acc;
   for (auto& s : m->spans) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) continue;
     bool hit = false;
-    for (auto& a : acc) if (!strcmp(a.name, s.name)) { a.n++; a.ms += ms; hit = true; break; }
-    if (!hit) acc.push_back({s.name, 1, ms});
+    for (auto& a : acc) if (!strcmp(a.name, s.name)) { a.n++; a.ms += ms; if (ms > a.max_ms) a.max_ms = ms; hit = true; break; }
+    if (!hit) acc.push_back({s.name, 1, ms, ms});
   }
   // what a hipEvent pair adds to the span of ONE launch: pairs with nothing between them, on the same (now idle) stream
   {
@@ -958,14 +958,14 @@ extern "C" int nvbx_get_profile(nvbx_mapper* m, char* json_out, int64_t capacity
     NVBX_HIP(hipStreamSynchronize(m->stream));
     for (int i = 0; i < kPairs; i++) { float ms = 0.0f; if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) { ms_sum += ms; n_ok++; } }
     for (hipEvent_t e : ev) m->event_pool.push_back(e);
-    if (n_ok) acc.push_back({"_empty_event_pair", n_ok, ms_sum});
+    if (n_ok) acc.push_back({"_empty_event_pair", n_ok, ms_sum, 0.0});
   }
   std::string out = "{";
   for (size_t i = 0; i < acc.size(); i++) {
     char buf[256];
     std::string nm = acc[i].name;
     for (char& c : nm) if (c == '(' || c == ')' ) c = ' ';
-    snprintf(buf, sizeof(buf), "%s\"%s\": {\"count\": %lld, \"total_ms\": %.6f}", i ? ", " : "", nm.c_str(), (long long)acc[i].n, acc[i].ms);
+    snprintf(buf, sizeof(buf), "%s\"%s\": {\"count\": %lld, \"total_ms\": %.6f, \"max_ms\": %.6f}", i ? ", " : "", nm.c_str(), (long long)acc[i].n, acc[i].ms, acc[i].max_ms);
     out += buf;
   }
   out += "}";

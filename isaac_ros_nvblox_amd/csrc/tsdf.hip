@@ -670,6 +670,9 @@ static int integrate_cameras(nvbx_mapper* m, int32_t n, const Img* imgs, int32_t
       set_error("integrate depth: T_L_C is not finite or lies outside the addressable block range (+-2^20 blocks)"); return NVBX_E_INVALID; }
   NVBX_HIP(hipSetDevice(m->device));
   const bool dilate_first = m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0;
+  // held-back integrateColor / updateEsdf that this call cannot carry out in pipelined order are replayed NOW, with the whole held-back
+  // state in view (the replayed calls launch / re-arm the held-back EDT themselves) -- before the EDT is hidden from join_side below
+  if (!(NB == 1 && !dilate_first && m->color_pending.on) && m->replay_deferred()) return NVBX_E_DEVICE;
   { const bool pend = m->edt_pending, ipend = m->import_pending; m->edt_pending = false; m->import_pending = false;
     // (join_side would launch a held-back EDT / union step; the EDT rides in k_mark_view instead, the union step stays held back
     //  for the next integrateColor -- it belongs to the NEXT ESDF update and touches nothing this launch reads)

@@ -5,6 +5,7 @@ layer_publishing.cpp:686-689).  Images are torch CUDA tensors (device memory, li
 MemoryType::kDevice images) or numpy arrays (uploaded first).
 """
 import ctypes as C
+import os
 import numpy as np
 
 from . import _lib
@@ -108,6 +109,15 @@ class Mapper:
             pass
 
     # -- helpers
+    def _on_mapper_stream(self, t):
+        """The kernels that read an uploaded image run on the MAPPER's stream, which torch's caching allocator knows nothing about: once the
+        Python reference is dropped (the next call's `_keep = ...`) the block could be handed out again and overwritten by the next upload
+        while kernels queued behind a slow launch (a first launch loads its code object: ~0.5 ms) still read it -- found as garbage view rays
+        in tests/test_gpu_pipeline.py.  record_stream makes the allocator wait for the mapper's stream before it re-uses the block."""
+        if t.is_cuda:
+            t.record_stream(self.torch_stream())
+        return t
+
     def _dev(self, a, dtype):
         torch = self._torch
         if isinstance(a, torch.Tensor):
@@ -116,8 +126,9 @@ class Mapper:
                 t = t.cuda(self.device)
             t = t.contiguous()
             assert t.dtype == dtype, (t.dtype, dtype)
-            return t
-        return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda(self.device)
+            return self._on_mapper_stream(t)
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda(self.device)
+        return self._on_mapper_stream(t)
 
     @staticmethod
     def _T(T):

@@ -10,16 +10,16 @@ from isaac_ros_nvblox_amd import synthetic as S
 pytestmark = pytest.mark.gpu
 
 
-def _equal_maps(M, a, b):
+def _equal_maps(M, a, b, tag=""):
     for layer, fields in ((M.LAYER_TSDF, ("distance", "weight")), (M.LAYER_COLOR, ("r", "g", "b", "weight")),
                           (M.LAYER_ESDF, ("squared_distance_vox", "parent_direction", "is_inside", "observed", "is_site"))):
         ia = a.block_indices(layer); ib = b.block_indices(layer)
-        assert np.array_equal(ia, ib), layer
+        assert np.array_equal(ia, ib), (tag, layer, len(ia), len(ib))
         if len(ia) == 0:
             continue
         ba, _ = a.get_blocks(layer, ia); bb, _ = b.get_blocks(layer, ia)
         for f in fields:
-            assert np.array_equal(ba[f], bb[f]), (layer, f)
+            assert np.array_equal(ba[f], bb[f]), (tag, layer, f)
     sa, aa = a.esdf_slice_image(); sb, ab = b.esdf_slice_image()
     assert sa.shape == sb.shape and np.array_equal(sa, sb) and np.array_equal(aa, ab)
 
@@ -88,7 +88,7 @@ def test_deferred_calls_are_replayed_by_every_other_entry_point(oracle_mod, hip_
         if k == 12:
             b.set_color_deferral(True)
         if k % 4 == 1 or k == 15:
-            _equal_maps(M, a, b)
+            _equal_maps(M, a, b, "frame %d" % k)
     both(lambda m: m.update_esdf())
     _equal_maps(M, a, b)
     assert len(a.block_indices(M.LAYER_COLOR)) > 50
