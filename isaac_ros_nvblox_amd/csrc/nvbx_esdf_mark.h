@@ -103,11 +103,20 @@ __device__ inline void esdf_mark_pass_done(const DMap& m, const EsdfArgs& a, int
   if (!a.self_reset) return;
   __threadfence();                                        // this worker's list reads are complete before it is counted
   if ((threadIdx.x & 63) == 0) {
-    const int32_t arrived = atomicAdd(&m.counters[C_MARK_DONE], 1);
-    if (arrived == n_workers - 1) {
+    // two levels: 256 workers on ONE counter serialise at ~12 ns per atomic (3 us inside a 9 us launch, measured); a worker counts itself in
+    // its shard's copy (worker w -> shard w & 7), the last of a shard counts the shard, the last shard resets
+    const int w = (int)blockIdx.x, sh = w & (NSH - 1);
+    const int32_t in_shard = (n_workers - sh + NSH - 1) / NSH;          // workers w' < n_workers with w' & 7 == sh
+    const int32_t arrived = atomicAdd(shc_at(m, S_MARK_DONE, sh, 0), 1);
+    if (arrived == in_shard - 1) {
+      __hip_atomic_store(shc_at(m, S_MARK_DONE, sh, 0), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int32_t shards_with_workers = n_workers < NSH ? n_workers : NSH;
+      const int32_t done = atomicAdd(&m.counters[C_MARK_DONE], 1);
+      if (done == shards_with_workers - 1) {
 #pragma unroll
-      for (int s = 0; s < NSH; s++) __hip_atomic_store(shc_at(m, S_LIST_ESDF_DIRTY, s, 0), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&m.counters[C_MARK_DONE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int s = 0; s < NSH; s++) __hip_atomic_store(shc_at(m, S_LIST_ESDF_DIRTY, s, 0), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&m.counters[C_MARK_DONE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }

@@ -105,7 +105,8 @@ enum {
                            //   (block coords), 4 columns re-marked, 5 ESDF blocks swept
   S_MESH_REC = 6,          // [6..7] parity-indexed mesh update record: 0 blocks meshed, 2..3 u64 arena cursor of this
                            //   shard's arena region = vertices (low 32) | triangles (high 32)
-  S_NUM = 8
+  S_MARK_DONE = 8,         // field 0: workers of the running self-resetting ESDF marking pass that have finished, per shard (C_MARK_DONE counts the shards)
+  S_NUM = 9
 };
 constexpr int N_LISTS = 4;
 

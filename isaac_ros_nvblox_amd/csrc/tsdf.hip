@@ -336,17 +336,19 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   constexpr size_t kMarkBytes = 2 * LSET * sizeof(u64);
   constexpr size_t kSmem = (Sensor::kThreads == 256 && sizeof(EdtShared) > kMarkBytes) ? sizeof(EdtShared) : kMarkBytes;
   __shared__ __align__(16) unsigned char smem[kSmem];
+  int32_t tile_wg = (int32_t)blockIdx.x;      // this workgroup's number among the tiles
   if (Sensor::kThreads == 256) {
-    if ((int32_t)blockIdx.x < n_edt_wg) {
-      esdf_edt_worker(m, ea, (int)blockIdx.x, n_edt_wg, reinterpret_cast<EdtShared*>(smem));
+    // riders: [EDT workers][sphere-tracing workers of a held-back colour frame (colour deferral)] -- before the tiles, or
+    // (tr.n_tile_wg > 0) after them.  All counts are multiples of 8, so a workgroup's XCD (blockIdx.x & 7) is also its number's & 7.
+    const int32_t rider = tr.n_tile_wg > 0 ? (int32_t)blockIdx.x - tr.n_tile_wg : (int32_t)blockIdx.x;
+    const bool is_rider = tr.n_tile_wg > 0 ? rider >= 0 : rider < n_edt_wg + tr.n_wg;
+    if (is_rider) {
+      if (rider < n_edt_wg) esdf_edt_worker(m, ea, (int)rider, n_edt_wg, reinterpret_cast<EdtShared*>(smem));
+      // (sphere tracing: all four wavefronts; independent of the view marking -- it reads the TSDF and the insert-only hash, and new entries point at all-zero blocks)
+      else sphere_trace_worker<1, 8>(m, tr.ps, tr.synth, tr.srows, tr.scols, tr.max_steps, tr.max_len, tr.eps_m, (int)(rider - n_edt_wg));
       return;
     }
-    // workgroups [n_edt_wg, n_edt_wg + tr.n_wg): the sphere tracing of a held-back colour frame (colour deferral) -- all four
-    // wavefronts; independent of the view marking (it reads the TSDF and the insert-only hash; new entries point at all-zero blocks)
-    if ((int32_t)blockIdx.x < n_edt_wg + tr.n_wg) {
-      sphere_trace_worker<1, 8>(m, tr.ps, tr.synth, tr.srows, tr.scols, tr.max_steps, tr.max_len, tr.eps_m, (int)blockIdx.x - n_edt_wg);
-      return;
-    }
+    if (tr.n_tile_wg == 0) tile_wg -= n_edt_wg + tr.n_wg;
     if (threadIdx.x >= 64) return;            // a tile is one wavefront
   }
   u64* lset = reinterpret_cast<u64*>(smem);
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   const int tiles_x = (f0.n_ray_cols + TC - 1) / TC, tiles_y = (f0.n_ray_rows + TR - 1) / TR;
   // XCD-aware numbering: workgroups go round-robin over the 8 XCDs (each with its own L2), so the tiles of one XCD (wg & 7) are a
   // contiguous band of tile rows -- neighbouring tiles share most of their blocks, i.e. their hash lines (n_edt_wg is a multiple of 8)
-  const int wg_all = (int)blockIdx.x - (Sensor::kThreads == 256 ? n_edt_wg + tr.n_wg : 0);      // (both rider counts are multiples of 8: the XCD of tile wg stays wg & 7)
+  const int wg_all = (int)tile_wg;
   const int n_tiles = tiles_x * tiles_y, per_xcd = (n_tiles + NSH - 1) / NSH;
   const int cam = NB > 1 ? wg_all / (NSH * per_xcd) : 0;        // batch: NSH * per_xcd workgroups per camera, camera after camera
   const int wg = wg_all - cam * (NSH * per_xcd);
@@ -592,7 +594,11 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   // in this view-marking launch, its colour integration + ESDF marking follow, then this frame's TSDF update: three launches per frame.
   TraceRider tr{};
   const bool pipelined = Sensor::kThreads == 256 && NB == 1 && m->color_pending.on;
-  if (pipelined) { m->pipelined_order = true; const int rc = m->pending_color_trace_rider(&tr); if (rc) { m->pipelined_order = false; return rc; } }
+  if (pipelined) {
+    m->pipelined_order = true; const int rc = m->pending_color_trace_rider(&tr); if (rc) { m->pipelined_order = false; return rc; }
+    static const int tiles_first = getenv("NVBX_MARK_TILES_FIRST") ? atoi(getenv("NVBX_MARK_TILES_FIRST")) : 1;       // (A/B: riders first = 0)
+    if (tiles_first) tr.n_tile_wg = tiles;
+  }
   NVBX_LAUNCH(m, (k_mark_view<Img, Sensor, NB>), dim3(tiles + edt_wg + tr.n_wg), dim3(Sensor::kThreads), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
               (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)edt_wg, ea, tr);
   if (pipelined) {

@@ -109,14 +109,19 @@ class Mapper:
             pass
 
     # -- helpers
-    def _on_mapper_stream(self, t):
-        """The kernels that read an uploaded image run on the MAPPER's stream, which torch's caching allocator knows nothing about: once the
-        Python reference is dropped (the next call's `_keep = ...`) the block could be handed out again and overwritten by the next upload
-        while kernels queued behind a slow launch (a first launch loads its code object: ~0.5 ms) still read it -- found as garbage view rays
-        in tests/test_gpu_pipeline.py.  record_stream makes the allocator wait for the mapper's stream before it re-uses the block."""
-        if t.is_cuda:
-            t.record_stream(self.torch_stream())
-        return t
+    def _hold(self, slot, tensors):
+        """Keep the device images of the call that has just been enqueued alive (`slot`: "_keep" depth / range images, "_keep_c" colour) and let go
+        of the previous call's.  The kernels that read them run on the MAPPER's stream, which torch's caching allocator knows nothing about: a
+        block it takes back could be handed out again and overwritten by the next upload (on torch's current stream) while kernels queued behind
+        a slow launch -- a first launch loads its code object, ~0.5 ms -- still read it (found as garbage view rays in tests/test_gpu_pipeline.py).
+        So before the old images are dropped, torch's current stream is made to wait for everything queued on the mapper's stream so far."""
+        old = getattr(self, slot, None)
+        if old:
+            torch = self._torch
+            cur = torch.cuda.current_stream(self.device); ms = self.torch_stream()
+            if ms.cuda_stream != cur.cuda_stream:
+                cur.wait_stream(ms)
+        setattr(self, slot, tensors)
 
     def _dev(self, a, dtype):
         torch = self._torch
@@ -126,9 +131,8 @@ class Mapper:
                 t = t.cuda(self.device)
             t = t.contiguous()
             assert t.dtype == dtype, (t.dtype, dtype)
-            return self._on_mapper_stream(t)
-        t = torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda(self.device)
-        return self._on_mapper_stream(t)
+            return t
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda(self.device)
 
     @staticmethod
     def _T(T):
@@ -180,7 +184,7 @@ class Mapper:
             fn = self.lib.nvbx_integrate_depth
         T = self._T(T_L_C); k = self._cam(cam)
         self._check(fn(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k)))
-        self._keep = [d]   # keep the device image alive until the next call (stream-ordered use)
+        self._hold("_keep", [d])   # keep the device image alive until the next call (stream-ordered use)
 
     @staticmethod
     def _lidar(lidar):
@@ -193,7 +197,7 @@ class Mapper:
         d = self._dev(range_image, self._torch.float32)
         T = self._T(T_L_C); k = self._lidar(lidar)
         self._check(self.lib.nvbx_integrate_lidar_depth(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k)))
-        self._keep = [d]
+        self._hold("_keep", [d])
 
     def prepare_lidar(self, range_image, T_L_C, lidar):
         d = self._dev(range_image, self._torch.float32)
@@ -229,10 +233,10 @@ class Mapper:
         T = self._T(T_L_C); k = self._cam(cam)
         if d.shape[2] == 4:
             self._check(self.lib.nvbx_integrate_color_bgra8(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k)))
-            self._keep_c = [d]
+            self._hold("_keep_c", [d])
             return
         self._check(self.lib.nvbx_integrate_color(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k)))
-        self._keep_c = [d]
+        self._hold("_keep_c", [d])
 
     # -- pre-marshalled calls: the reference hands ready C++ objects to integrateDepth/Color; this keeps Python's per-call
     #    argument marshalling (tensor checks, numpy pose copy, struct construction) out of a measured loop
@@ -271,10 +275,10 @@ class Mapper:
             self._check(rc)
 
     def integrate_depth_batch(self, depths, poses, cams):
-        a = self.prepare_depth_batch(depths, poses, cams); self.integrate_prepared_batch(a); self._keep = [a]
+        a = self.prepare_depth_batch(depths, poses, cams); self.integrate_prepared_batch(a); self._hold("_keep", [a])
 
     def integrate_color_batch(self, rgbs, poses, cams):
-        a = self.prepare_color_batch(rgbs, poses, cams); self.integrate_prepared_batch(a); self._keep_c = [a]
+        a = self.prepare_color_batch(rgbs, poses, cams); self.integrate_prepared_batch(a); self._hold("_keep_c", [a])
 
     def integrate_prepared(self, a):
         rc = a[0](self._h, a[1], a[2], a[3], a[4], a[5])
@@ -539,7 +543,7 @@ class Mapper:
         T = self._T(T_L_C); k = self._cam(cam)
         self._check(self.lib.nvbx_measure_depth(self._h, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k),
                                                 C.c_void_p(out_blocks.data_ptr()), C.c_void_p(out_count.data_ptr()), int(out_blocks.shape[0])))
-        self._keep = [d]
+        self._hold("_keep", [d])
 
     def apply_measurements(self, gathered, counts, owner_mod=0, owner_rank=0):
         """gathered uint8 [world, stride, 4112], counts int32 [world] (device): every camera's measurements applied in rank order."""
