@@ -326,7 +326,9 @@ int nvbx_mapper::pending_color_trace_rider(void* out) {
   if (rc) return rc;
   tr->synth = synth; tr->srows = srows; tr->scols = scols; tr->max_steps = p.sphere_tracing_max_steps;
   tr->max_len = p.sphere_tracing_max_ray_length_m; tr->eps_m = p.sphere_tracing_surface_eps_vox * p.voxel_size;
-  tr->n_wg = sphere_trace_workgroups(8, srows, scols, 1);          // (the rider runs the single-camera form: 8 lanes per ray)
+  static const int fused_lanes = getenv("NVBX_FUSED_TRACE_LANES") ? atoi(getenv("NVBX_FUSED_TRACE_LANES")) : 8;       // (A/B: 4 or 8 lanes per ray)
+  tr->lanes = fused_lanes == 4 ? 4 : 8;
+  tr->n_wg = sphere_trace_workgroups(tr->lanes, srows, scols, 1);
   return NVBX_OK;
 }
 int nvbx_mapper::launch_pending_color_after_trace() {

@@ -101,7 +101,8 @@ __device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg
 // marking pass runs (stream order), so the reset cannot lose an entry.
 __device__ inline void esdf_mark_pass_done(const DMap& m, const EsdfArgs& a, int n_workers) {
   if (!a.self_reset) return;
-  __threadfence();                                        // this worker's list reads are complete before it is counted
+  // (no fence: the worker's loads from the list have RETURNED -- it used their values -- before it gets here, and the reset is ordered behind
+  //  every worker's arrival by the atomics themselves; a __threadfence per worker cost the launch ~3 us)
   if ((threadIdx.x & 63) == 0) {
     // two levels: 256 workers on ONE counter serialise at ~12 ns per atomic (3 us inside a 9 us launch, measured); a worker counts itself in
     // its shard's copy (worker w -> shard w & 7), the last of a shard counts the shard, the last shard resets

@@ -115,6 +115,6 @@ __device__ inline void sphere_trace_worker(const DMap& m, const PoseSet<NB>& pos
 
 // The sphere tracing of a held-back colour frame riding in the next depth frame's k_mark_view launch (kernel argument; n_wg = 0: none).
 // n_tile_wg > 0: the launch's first n_tile_wg workgroups are the view-marking tiles and the riders (EDT, then sphere tracing) follow; 0: riders first.
-struct TraceRider { PoseSet<1> ps; float* synth; int32_t srows, scols, max_steps; float max_len, eps_m; int32_t n_wg; int32_t n_tile_wg; };
+struct TraceRider { PoseSet<1> ps; float* synth; int32_t srows, scols, max_steps; float max_len, eps_m; int32_t n_wg; int32_t n_tile_wg; int32_t lanes; };
 
 }  // namespace nvbx

@@ -345,6 +345,7 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
     if (is_rider) {
       if (rider < n_edt_wg) esdf_edt_worker(m, ea, (int)rider, n_edt_wg, reinterpret_cast<EdtShared*>(smem));
       // (sphere tracing: all four wavefronts; independent of the view marking -- it reads the TSDF and the insert-only hash, and new entries point at all-zero blocks)
+      else if (tr.lanes == 4) sphere_trace_worker<1, 4>(m, tr.ps, tr.synth, tr.srows, tr.scols, tr.max_steps, tr.max_len, tr.eps_m, (int)(rider - n_edt_wg));
       else sphere_trace_worker<1, 8>(m, tr.ps, tr.synth, tr.srows, tr.scols, tr.max_steps, tr.max_len, tr.eps_m, (int)(rider - n_edt_wg));
       return;
     }
