@@ -237,6 +237,10 @@ struct MultiMapperParams {   // multi_mapper.* parameters (mapper_initialization
   int connected_mask_component_size_threshold = 2000;   // pixels (mapper_initialization.cpp:130)
   int remove_small_connected_components = 1;
   float mask_occlusion_threshold_m = 0.25f;     // [U] ImageMasker occlusion test (nvbx_split_depth_by_mask)
+  // ground plane estimation (mapper_initialization.cpp:133-153; off in every shipped configuration)
+  bool experimental_use_ground_plane_estimation = false;
+  struct GroundPlaneEstimatorParams { float ground_points_candidates_min_z_m = -0.1f, ground_points_candidates_max_z_m = 0.15f; } ground_plane_estimator_params;
+  struct RansacPlaneFitterParams { float ransac_distance_threshold_m = 0.15f; int num_ransac_iterations = 1000; } ransac_plane_fitter_params;
 };
 
 }  // namespace nvblox

@@ -4,6 +4,7 @@
 // depth / colour, occupancy foreground mapper) and the dynamic mapping type (freespace layer, dynamic-pixel detection, mask clean-up);
 // every overload the node calls is implemented (the reference aborts on programmer errors).
 #pragma once
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -13,14 +14,34 @@
 
 namespace nvblox {
 
-// MultiMapper::ground_plane_estimator() as the node's debug visualisation reads it (nvblox_node.cpp:1456,1474).  Ground-plane
-// estimation itself (TSDF zero crossings near the floor + a RANSAC plane) is outside the hot path of this library: the
-// accessors exist so that the node compiles and runs unchanged, and report "no estimate" -- the node then publishes nothing
-// (`if (maybe_tsdf_zero_crossings)` / `if (maybe_plane)`).
+// MultiMapper::ground_plane_estimator() as the node's debug visualisation reads it (nvblox_node.cpp:1456,1474).  [U] restated
+// (csrc/ground.hip): with multi_mapper.experimental_use_ground_plane_estimation every updateEsdf() extracts the TSDF's upward zero
+// crossings whose height lies in [ground_points_candidates_min_z_m, ..._max_z_m] (nvbx_tsdf_zero_crossings) and fits a RANSAC plane
+// through them (nvbx_fit_plane_ransac: ransac_distance_threshold_m, num_ransac_iterations).  Without the switch, or before the first
+// update, or with fewer than three candidates, the accessors report "no estimate" and the node publishes nothing.  (The reference also
+// lets the plane steer the ESDF slice height -- slice_height_above_plane_m; here the slice stays at its configured heights.)
 class GroundPlaneEstimator {
  public:
-  std::optional<std::vector<Vector3f>> tsdf_zero_crossings_ground_candidates() const { return std::nullopt; }
-  std::optional<Plane> ground_plane() const { return std::nullopt; }
+  std::optional<std::vector<Vector3f>> tsdf_zero_crossings_ground_candidates() const { return candidates_; }
+  std::optional<Plane> ground_plane() const { return plane_; }
+  void update(nvbx_mapper* m, const MultiMapperParams& p) {
+    candidates_.reset(); plane_.reset();
+    const float lo = p.ground_plane_estimator_params.ground_points_candidates_min_z_m, hi = p.ground_plane_estimator_params.ground_points_candidates_max_z_m;
+    int64_t n = nvbx_tsdf_zero_crossings(m, lo, hi, nullptr, 0);
+    if (n < 0) checkNvbx((int)n, "nvbx_tsdf_zero_crossings");
+    std::vector<float> xyz((size_t)std::max<int64_t>(n, 1) * 3);
+    n = std::min<int64_t>(n, nvbx_tsdf_zero_crossings(m, lo, hi, xyz.data(), n));
+    if (n <= 0) return;
+    std::vector<Vector3f> pts((size_t)n);
+    for (int64_t i = 0; i < n; i++) pts[(size_t)i] = Vector3f(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    candidates_ = std::move(pts);
+    float pl[4];
+    const int64_t inl = nvbx_fit_plane_ransac(xyz.data(), n, p.ransac_plane_fitter_params.ransac_distance_threshold_m, p.ransac_plane_fitter_params.num_ransac_iterations, 1u, pl);
+    if (inl >= 3) plane_ = Plane(Vector3f(pl[0], pl[1], pl[2]), pl[3]);
+  }
+ private:
+  std::optional<std::vector<Vector3f>> candidates_;
+  std::optional<Plane> plane_;
 };
 
 class MultiMapper {
@@ -126,7 +147,10 @@ class MultiMapper {
                                        mask.dataConstPtr(), reinterpret_cast<uint8_t*>(color_background_.dataPtr()), nullptr), "nvbx_split_color_by_mask");
     background_mapper_->integrateColor(color_background_, T_L_C, camera);
   }
-  void updateEsdf() { background_mapper_->updateEsdf(); if (human_ || dynamic_) foreground_mapper_->updateEsdf(); }
+  void updateEsdf() {
+    background_mapper_->updateEsdf(); if (human_ || dynamic_) foreground_mapper_->updateEsdf();
+    if (multi_params_.experimental_use_ground_plane_estimation) ground_plane_estimator_.update(background_mapper_->c_handle(), multi_params_);
+  }
   void updateColorMesh(UpdateFullLayer f = UpdateFullLayer::kNo) { background_mapper_->updateColorMesh(f); }
 
   MappingType mapping_type() const { return mapping_type_; }

@@ -462,6 +462,16 @@ int nvbx_measure_depth(nvbx_mapper* m, const float* depth_dev, int32_t rows, int
 int nvbx_apply_measurements(nvbx_mapper* m, const nvbx_measurement_block* gathered_dev, const int32_t* counts_dev, int32_t world, int64_t stride_blocks,
                             int32_t owner_mod, int32_t owner_rank);
 
+/* ---- ground plane (MultiMapper::ground_plane_estimator(), nvblox_node.cpp:1456,1474; parameters mapper_initialization.cpp:133-153) ------
+ * [U] GroundPlaneEstimator restated.  nvbx_tsdf_zero_crossings: the upward zero crossings of the TSDF -- vertically adjacent observed voxels
+ * with d(z) <= 0 < d(z + 1), interpolated linearly along z -- whose height lies in [min_z_m, max_z_m] (ground_points_candidates_min/max_z_m),
+ * as xyz triples in HOST memory sorted by (x, y, z); returns the count (> capacity: nothing written, come back with room); synchronises.
+ * nvbx_fit_plane_ransac (host only, no mapper): `iterations` (num_ransac_iterations) sampled triples, inliers within distance_threshold_m
+ * (ransac_distance_threshold_m), normal turned upwards; plane_out = {nx, ny, nz, d} with n . p + d = 0; returns the inlier count of the winner
+ * (0 = no plane).  The sampling sequence is fixed by `seed`, so the estimate is a pure function of its inputs. */
+int64_t nvbx_tsdf_zero_crossings(nvbx_mapper* m, float min_z_m, float max_z_m, float* points_xyz_host, int64_t capacity);
+int64_t nvbx_fit_plane_ransac(const float* points_xyz_host, int64_t n, float distance_threshold_m, int32_t iterations, uint32_t seed, float plane_out[4]);
+
 /* ---- instrumentation (timing::Timer analogue for the per-kernel roofline line of bench.py) -----------------------
  * While enabled every kernel launch is bracketed by a hipEvent pair on the mapper stream. nvbx_get_profile returns a
  * JSON object {"kernel": {"count": n, "total_ms": t}}; the entry "_empty_event_pair" is the span of event pairs with nothing between

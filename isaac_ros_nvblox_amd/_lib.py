@@ -113,6 +113,8 @@ SIGNATURES = {
     "nvbx_apply_measurements": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _i32, _i32]),
     "nvbx_mapper_set_max_capacity": (C.c_int, [_vp, _i64]),
     "nvbx_mapper_set_color_deferral": (C.c_int, [_vp, C.c_int32]),
+    "nvbx_tsdf_zero_crossings": (_i64, [_vp, C.c_float, C.c_float, _vp, _i64]),
+    "nvbx_fit_plane_ransac": (_i64, [_vp, _i64, C.c_float, C.c_int32, C.c_uint32, _vp]),
     "nvbx_mapper_capacity": (C.c_int64, [_vp]),
     "nvbx_integrate_depth_batch": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "nvbx_integrate_color_batch": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),

@@ -92,6 +92,20 @@ class Mapper:
         then stay valid and unchanged until the next call into the mapper has returned."""
         self._check(self.lib.nvbx_mapper_set_color_deferral(self._h, 1 if enable else 0))
 
+    # -- ground plane (MultiMapper::ground_plane_estimator())
+    def tsdf_zero_crossings(self, min_z_m, max_z_m):
+        """xyz [N, 3] float32 of the TSDF's upward zero crossings with height in [min_z_m, max_z_m], sorted by (x, y, z)."""
+        n = self._check(self.lib.nvbx_tsdf_zero_crossings(self._h, float(min_z_m), float(max_z_m), None, 0))
+        out = np.zeros((max(n, 1), 3), np.float32)
+        n2 = self._check(self.lib.nvbx_tsdf_zero_crossings(self._h, float(min_z_m), float(max_z_m), _np_ptr(out), out.shape[0]))
+        return out[:min(n, n2)]
+
+    def fit_plane_ransac(self, points, distance_threshold_m, iterations, seed=1):
+        """-> (plane [nx, ny, nz, d] float32, inliers); host only"""
+        p = np.ascontiguousarray(points, np.float32).reshape(-1, 3); plane = np.zeros(4, np.float32)
+        n = self._check(self.lib.nvbx_fit_plane_ransac(_np_ptr(p), len(p), float(distance_threshold_m), int(iterations), int(seed), _np_ptr(plane)))
+        return plane, n
+
     def _check(self, rc):
         if rc < 0:
             raise NvbxError("nvbx error %d: %s" % (rc, self.lib.nvbx_last_error().decode()))

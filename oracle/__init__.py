@@ -132,6 +132,8 @@ def lib():
         L.orc_split_depth_by_mask.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_float, vp, vp]
         L.orc_lidar_project.restype = C.c_int; L.orc_lidar_project.argtypes = [vp, vp, f32p, f32p]
         L.orc_atan2f.restype = C.c_float; L.orc_atan2f.argtypes = [C.c_float, C.c_float]
+        L.orc_tsdf_zero_crossings.restype = i64; L.orc_tsdf_zero_crossings.argtypes = [vp, C.c_float, C.c_float, vp, i64]
+        L.orc_fit_plane_ransac.restype = i64; L.orc_fit_plane_ransac.argtypes = [vp, i64, C.c_float, C.c_int32, C.c_uint32, vp]
         L.orc_lidar_sample_points.restype = None; L.orc_lidar_sample_points.argtypes = [C.POINTER(OrcParams), vp, vp, vp, i64, C.c_float, vp, vp]
         L.orc_integrate_color.restype = i64; L.orc_integrate_color.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
         L.orc_num_blocks.restype = i64; L.orc_num_blocks.argtypes = [vp, C.c_uint32]
@@ -330,6 +332,12 @@ class OracleMap:
         c = np.ascontiguousarray(counts.numpy() if hasattr(counts, "numpy") else counts, np.int32)
         return lib().orc_apply_measurements(self._h, _p(g), _p(c), g.shape[0], g.shape[1], int(owner_mod), int(owner_rank))
 
+    def tsdf_zero_crossings(self, min_z_m, max_z_m):
+        out = np.zeros((1 << 20, 3), np.float32)
+        n = lib().orc_tsdf_zero_crossings(self._h, C.c_float(min_z_m), C.c_float(max_z_m), _p(out), out.shape[0])
+        assert n <= out.shape[0]
+        return out[:n].copy()
+
     def take_cleared_blocks(self):
         out = np.zeros((1 << 16, 3), np.int32)
         n = lib().orc_take_cleared_blocks(self._h, _p(out), out.shape[0])
@@ -373,6 +381,12 @@ def split_depth_by_mask(depth, mask, T_CM_CD, depth_cam, mask_cam, occlusion_thr
     lib().orc_split_depth_by_mask(_p(d), d.shape[0], d.shape[1], _p(mk), mk.shape[0], mk.shape[1], _p(T), _p(dc), _p(mc),
                                   float(occlusion_threshold_m), _p(un), _p(ma))
     return un, ma
+
+
+def fit_plane_ransac(points, distance_threshold_m, iterations, seed=1):
+    p = np.ascontiguousarray(points, np.float32).reshape(-1, 3); plane = np.zeros(4, np.float32)
+    n = lib().orc_fit_plane_ransac(_p(p), C.c_int64(len(p)), C.c_float(distance_threshold_m), C.c_int32(iterations), C.c_uint32(seed), _p(plane))
+    return plane, int(n)
 
 
 def lidar_sample_points(params, lidar, range_image, pts, max_dist):

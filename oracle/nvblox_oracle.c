@@ -1538,6 +1538,65 @@ int orc_mesh_get(const OrcMap* m, int32_t x, int32_t y, int32_t z, float* vert, 
   return 1;
 }
 
+/* ------------------------------------------------------------------ ground plane ([U] GroundPlaneEstimator restated; nvblox_node.cpp:1456,1474)
+ * candidates = upward zero crossings of the TSDF (d(z) <= 0 < d(z + 1), both observed, linear interpolation along z) with height in
+ * [min_z, max_z]; plane = RANSAC over them with a fixed linear congruential sampling sequence */
+static int xyz_cmp(const void* a, const void* b) {
+  const float* p = (const float*)a; const float* q = (const float*)b;
+  for (int i = 0; i < 3; i++) if (p[i] != q[i]) return p[i] < q[i] ? -1 : 1;
+  return 0;
+}
+int64_t orc_tsdf_zero_crossings(OrcMap* m, float min_z, float max_z, float* out_xyz, int64_t cap) {
+  const OrcParams* p = &m->p;
+  const float vs = p->voxel_size, bs = vs * 8.0f;
+  const float min_w = p->esdf_min_weight > 0.0f ? p->esdf_min_weight : 1e-4f;
+  int64_t n = 0;
+  for (int64_t q = 0; q < m->count; q++) {
+    const Block* b = m->order[q];
+    if (!(b->flags & L_TSDF)) continue;
+    Idx3 ui = {b->idx.x, b->idx.y, b->idx.z + 1};
+    const Block* up = map_find(m, ui);
+    for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) for (int z = 0; z < 8; z++) {
+      const TsdfVoxel lo = b->tsdf[z + 8 * y + 64 * x];
+      TsdfVoxel hi = {0.0f, 0.0f};
+      if (z < 7) hi = b->tsdf[z + 1 + 8 * y + 64 * x];
+      else if (up && (up->flags & L_TSDF)) hi = up->tsdf[0 + 8 * y + 64 * x];
+      if (!(lo.weight >= min_w && hi.weight >= min_w && lo.distance <= 0.0f && hi.distance > 0.0f)) continue;
+      const float z_lo = ((float)b->idx.z * bs + (float)z * vs) + vs * 0.5f;
+      const float pz = z_lo + vs * (-lo.distance / (hi.distance - lo.distance));
+      if (!(pz >= min_z && pz <= max_z)) continue;
+      if (n < cap) { out_xyz[3 * n] = ((float)b->idx.x * bs + (float)x * vs) + vs * 0.5f; out_xyz[3 * n + 1] = ((float)b->idx.y * bs + (float)y * vs) + vs * 0.5f; out_xyz[3 * n + 2] = pz; }
+      n++;
+    }
+  }
+  if (n <= cap) qsort(out_xyz, (size_t)n, 3 * sizeof(float), xyz_cmp);
+  return n;
+}
+int64_t orc_fit_plane_ransac(const float* pts, int64_t n, float thresh, int32_t iterations, uint32_t seed, float* plane) {
+  plane[0] = 0.0f; plane[1] = 0.0f; plane[2] = 1.0f; plane[3] = 0.0f;
+  if (n < 3) return 0;
+  uint32_t state = seed;
+  const uint32_t mod = (uint32_t)(n < (1 << 24) ? n : (1 << 24));
+  int64_t best = 0;
+  for (int32_t it = 0; it < iterations; it++) {
+    int64_t id[3];
+    for (int k = 0; k < 3; k++) { state = state * 1664525u + 1013904223u; id[k] = (int64_t)((state >> 8) % mod); }
+    if (id[0] == id[1] || id[0] == id[2] || id[1] == id[2]) continue;
+    const float* a = pts + 3 * id[0]; const float* b = pts + 3 * id[1]; const float* c = pts + 3 * id[2];
+    const float ux = b[0] - a[0], uy = b[1] - a[1], uz = b[2] - a[2], vx = c[0] - a[0], vy = c[1] - a[1], vz = c[2] - a[2];
+    float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+    const float len = sqrtf((nx * nx + ny * ny) + nz * nz);
+    if (!(len > 1e-12f)) continue;
+    nx = nx / len; ny = ny / len; nz = nz / len;
+    if (nz < 0.0f) { nx = -nx; ny = -ny; nz = -nz; }
+    const float d = -((nx * a[0] + ny * a[1]) + nz * a[2]);
+    int64_t inl = 0;
+    for (int64_t k = 0; k < n; k++) { const float* q = pts + 3 * k; if (fabsf(((nx * q[0] + ny * q[1]) + nz * q[2]) + d) <= thresh) inl++; }
+    if (inl > best) { best = inl; plane[0] = nx; plane[1] = ny; plane[2] = nz; plane[3] = d; }
+  }
+  return best;
+}
+
 /* ------------------------------------------------------------------ decay / clearing */
 static void cleared_push(OrcMap* m, Idx3 i) {
   if (m->n_cleared + 1 > m->cleared_cap) { m->cleared_cap = m->cleared_cap ? m->cleared_cap * 2 : 1024; m->cleared = (Idx3*)realloc(m->cleared, (size_t)m->cleared_cap * sizeof(Idx3)); }

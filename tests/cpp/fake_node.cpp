@@ -275,6 +275,32 @@ int main(int argc, char** argv) {
     esdf_slicer_.sliceLayersToCombinedDistanceImage(node.static_mapper_->esdf_layer(), node.static_mapper_->esdf_layer(), 0.09f, 0.09f, 1000.0f, &aabb2, &combined);
     if (combined.rows() != height || combined.cols() != width) { std::fprintf(stderr, "combined slice size differs\n"); return 1; }
   }
+  // ground plane estimation (nvblox_node.cpp:1456,1474; multi_mapper.experimental_use_ground_plane_estimation, mapper_initialization.cpp:133-153):
+  // a camera 1 m above a floor, looking down: candidates on the floor, plane z = 0
+  {
+    MultiMapper gp(0.05f, MappingType::kStaticTsdf, EsdfMode::k2D, MemoryType::kDevice, std::make_shared<CudaStreamOwning>(), 1 << 12);
+    MultiMapperParams mp; mp.experimental_use_ground_plane_estimation = true;
+    mp.ground_plane_estimator_params.ground_points_candidates_min_z_m = -0.2f; mp.ground_plane_estimator_params.ground_points_candidates_max_z_m = 0.2f;
+    mp.ransac_plane_fitter_params.ransac_distance_threshold_m = 0.03f; mp.ransac_plane_fitter_params.num_ransac_iterations = 200;
+    gp.setMultiMapperParams(mp);
+    if (gp.ground_plane_estimator().ground_plane() || gp.ground_plane_estimator().tsdf_zero_crossings_ground_candidates()) { std::fprintf(stderr, "ground plane before any update\n"); return 1; }
+    DepthImage down(120, 160, MemoryType::kDevice);
+    std::vector<float> host_depth(120 * 160, 1.0f);                       // optical axis = -z of the world: depth 1 m everywhere = the plane z = 0
+    down.copyFromAsync(120, 160, host_depth.data(), CudaStreamOwning());
+    Transform T_L_C = Transform::Identity();
+    T_L_C(1, 1) = -1.f; T_L_C(2, 2) = -1.f;                              // camera x = world x, y = -y, z = -z (looking down)
+    T_L_C.setTranslation(Vector3f(0.f, 0.f, 1.0f));
+    gp.integrateDepth(down, T_L_C, Camera(80.f, 80.f, 79.5f, 59.5f, 160, 120));
+    gp.updateEsdf();
+    const auto cand = gp.ground_plane_estimator().tsdf_zero_crossings_ground_candidates();
+    const auto plane = gp.ground_plane_estimator().ground_plane();
+    if (!cand || cand->size() < 500 || !plane || std::fabs(plane->normal().z() - 1.f) > 1e-3f || std::fabs(plane->d()) > 0.02f ||
+        std::fabs(plane->getHeightAtXY(Vector2f(0.2f, -0.1f))) > 0.02f) {
+      std::fprintf(stderr, "ground plane: %zu candidates, normal z %g, d %g\n", cand ? cand->size() : (size_t)0, plane ? plane->normal().z() : 0.f, plane ? plane->d() : 0.f); return 1; }
+    float zmin = 1e9f, zmax = -1e9f;
+    for (const Vector3f& q : *cand) { zmin = std::min(zmin, q.z()); zmax = std::max(zmax, q.z()); }
+    if (zmin < -0.03f || zmax > 0.03f) { std::fprintf(stderr, "ground candidates off the floor: z %g .. %g\n", zmin, zmax); return 1; }
+  }
   // mapping_type "static_occupancy" (nvblox_base.yaml:9): an occupancy MultiMapper fed the same way; decayOccupancyAllVoxels
   {
     MultiMapper occ(0.05f, MappingType::kStaticOccupancy, EsdfMode::k2D, MemoryType::kDevice, std::make_shared<CudaStreamOwning>(), 1 << 12);
