@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64) void k_undo_marks(DMap m, uint32_t pass_floor, 
           atomicAnd(&m.slot_flags[s], ~(F_DIRTY_ESDF | F_DIRTY_MESH));
           const int32_t pos = atomicAdd(&m.counters[C_FREE_TOP], 1);
           m.free_stack[pos] = (uint32_t)s;
-          atomicSub(&m.counters[C_LIVE], 1);
+
         }
       }
     }

@@ -17,7 +17,6 @@ __device__ inline void free_slot(DMap& m, uint32_t slot) {   // one thread
   const int32_t pos = atomicAdd(&m.counters[C_FREE_TOP], 1);
   m.free_stack[pos] = slot;
   m.slot_consumed[slot] = STAMP_NEVER; m.slot_stamp[slot] = STAMP_NEVER; m.slot_cam[slot] = STAMP_NEVER;
-  atomicSub(&m.counters[C_LIVE], 1);
 }
 
 // A block whose weights all fall below the threshold is deallocated.  If it lies in the ESDF z band and its column already has

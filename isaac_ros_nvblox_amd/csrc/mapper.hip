@@ -856,7 +856,7 @@ extern "C" int nvbx_get_counters(nvbx_mapper* m, nvbx_counters* out) {
   if (m->fetch_counters()) return NVBX_E_DEVICE;
   const int32_t* c = m->h_counters;
   memset(out, 0, sizeof(*out));
-  out->blocks_allocated = c[C_LIVE];
+  out->blocks_allocated = (int64_t)m->capacity - (int64_t)c[C_FREE_TOP];       // every slot is free or live
   out->tsdf_blocks_in_view = m->last_view_frame ? c[C_VIEW_COUNT + (m->last_view_frame & 3)] : 0;
   out->color_blocks_updated = m->shc_sum(S_LIST_COLOR, 0);
   const int epar = (int)((m->esdf_epoch + 1) & 1);                    // record of the last finished update (epoch - 1)

@@ -84,7 +84,7 @@ enum {
   C_ESDF_AABB = 32,    // [32..35] AABB of all ESDF blocks: min_x, min_y, max_x, max_y
   C_MESH_OUT = 36,     // [36..43] two parity-indexed records of mesh update e: {+0 list entries}; the contended
                        //   fields are sharded (S_MESH_REC below)
-  C_LIVE = 44,         // live hash entries
+  C_LIVE = 44,         // (unused since round 3: live blocks = capacity - C_FREE_TOP)
   C_TMP = 45,          // scratch counter (point cloud compaction etc.)
   C_CLEARED = 46,      // entries of the cleared-block list (nvbx_take_cleared_blocks)
   C_MARK_DONE = 47,    // workers of the running ESDF marking pass that have finished (a pass that empties the dirty list itself, EsdfArgs::self_reset)
@@ -281,7 +281,8 @@ __device__ inline int32_t hash_insert(const DMap& m, int32_t x, int32_t y, int32
           m.slot_entry[slot] = h;
           atomicOr(&m.slot_flags[slot], layer_flags);
           atomicMax(&m.counters[C_HIGH_WATER], (int32_t)slot + 1);
-          atomicAdd(&m.counters[C_LIVE], 1);
+          // (no live-block counter: every slot is either on the free stack or live, so live = capacity - C_FREE_TOP; a third same-address
+          //  atomic per new block was ~12 us of serialised atomics on a frame that allocates 1000 blocks)
         } else {
           atomicAdd(&m.counters[C_FREE_TOP], 1);
           atomicExch(&m.counters[C_OVERFLOW], 1);
