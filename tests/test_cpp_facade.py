@@ -405,7 +405,9 @@ def test_rccl_fusion_example_runs(hip_lib):
     """examples/rccl_fusion.cpp: measure -> ncclAllGather (RCCL) -> apply, from C++ through the C-ABI; with the GPUs present (one on the
     test box) every rank's map must equal the single mapper's batch."""
     subprocess.check_call(["make", "-C", CPP, "rccl_fusion"], stdout=subprocess.DEVNULL)
-    r = subprocess.run([os.path.join(CPP, "rccl_fusion"), "8", "3"], capture_output=True, text=True, timeout=300)
+    # (single node: keep RCCL's bootstrap on the loopback interface -- on some boxes its interface / InfiniBand probing took two minutes)
+    env = dict(os.environ, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1")
+    r = subprocess.run([os.path.join(CPP, "rccl_fusion"), "8", "3"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-500:] + r.stderr[-2000:]
     got = json.loads(r.stdout.strip().splitlines()[-1])
     assert got["gpus"] >= 1 and got["ranks_differing_from_single_mapper"] == 0 and got["tsdf_blocks"] > 100
