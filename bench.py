@@ -46,7 +46,14 @@ def algorithmic_bytes(kernel, c, rows, cols, sub_ray=4, sub_trace=4, n_cam=1, tr
     Nv, Nc, Na = c.get("tsdf_blocks_in_view", 0), c.get("color_blocks_updated", 0), c.get("blocks_allocated", 0)
     Nu, Ne = c.get("esdf_columns_marked", 0), c.get("esdf_blocks_swept", 0)
     if kernel.startswith("k_integrate_tsdf"):
-        return n_cam * rows * cols * 4 + Nv * (12 + 8) + Nv * B * 2
+        # (LiDAR: the blocks the beam-centric launch has taken are skipped by this one -- it reads their records, not their voxels)
+        Ns = c.get("lidar_blocks_beam_centric", 0)
+        return n_cam * rows * cols * 4 + Nv * (12 + 8) + (Nv - Ns) * B * 2
+    if kernel.startswith("k_lidar_sparse"):
+        # per block in view: record + class byte; per block it updates: its footprint of the range image (<= 64 pixels + quads), the beams'
+        # table entries and ~21 voxels read + written (8-byte voxels moved as 32-byte sectors)
+        Ns = c.get("lidar_blocks_beam_centric", 0)
+        return Nv * 17 + Ns * (64 * 4 + 130 * 4 + 21 * 64)
     if kernel.startswith("k_mark_view"):
         own = n_cam * (rows // sub_ray) * (cols // sub_ray) * 4 + Nv * 16 * 2           # sub-sampled depth read + one hash entry RMW per block in view
         # colour deferral: the sphere tracing of the previous colour frame rides in this launch (its bytes with it)
@@ -280,11 +287,11 @@ def main_lidar(args):
         return finish_dist(dist, world)
     n2 = min(args.steps, 40)
     g.set_profiling(True)
-    nv = []
+    nv = []; nsp = []
     for i in range(n2):
-        g.integrate_prepared(largs[i % nu]); nv.append(g.counters()["tsdf_blocks_in_view"])
+        g.integrate_prepared(largs[i % nu]); cc_ = g.counters(); nv.append(cc_["tsdf_blocks_in_view"]); nsp.append(cc_["lidar_blocks_beam_centric"])
     prof = g.profile(); g.set_profiling(False)
-    c = g.counters(); counts = dict(c); counts["tsdf_blocks_in_view"] = float(np.mean(nv))
+    c = g.counters(); counts = dict(c); counts["tsdf_blocks_in_view"] = float(np.mean(nv)); counts["lidar_blocks_beam_centric"] = float(np.mean(nsp))
     rows, cols = lidar[1], lidar[0]
     kern, evo, emp = kernel_table(prof, counts, ms, n2, lambda k, cc: algorithmic_bytes(k, cc, rows, cols, sub_ray=2), load_pmc("lidar"))
     cpu = None
@@ -300,7 +307,16 @@ def main_lidar(args):
            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "configs[4]: synthetic 1024x64 spinning LiDAR (SURVEY 8d), 0.10 m voxels, 200 m range, ray subsampling 2",
                       "parallelism": "azimuth sectors, one per GPU" if world > 1 else "single GPU"},
-           "per_step_counts": {"tsdf_blocks_in_view": round(counts["tsdf_blocks_in_view"], 1), "blocks_allocated": c["blocks_allocated"], "capacity_overflow": c["capacity_overflow"]},
+           "per_step_counts": {"tsdf_blocks_in_view": round(counts["tsdf_blocks_in_view"], 1), "lidar_blocks_beam_centric": round(counts["lidar_blocks_beam_centric"], 1),
+                               "blocks_allocated": c["blocks_allocated"], "capacity_overflow": c["capacity_overflow"]},
+           # the TSDF update as a whole (beam-centric far-field launch + dense launch): what the one-lane-per-voxel formulation of SURVEY 8d would
+           # move for these blocks (every voxel of every block in view read + written) over the time the two launches take -- an EQUIVALENT rate:
+           # the beam-centric launch touches ~20 voxels of a block, not 512, which is the point of it
+           "tsdf_update": (lambda t_us, by: {"launches": [k_ for k_ in ("k_lidar_sparse", "k_integrate_tsdf") if k_ in kern], "us": round(t_us, 1),
+                                             "dense_formula_bytes": int(by), "equivalent_GBps": round(by / (t_us * 1e-6) / 1e9, 1),
+                                             "equivalent_frac": round(by / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})(
+               sum(kern[k_]["avg_us"] for k_ in ("k_lidar_sparse", "k_integrate_tsdf") if k_ in kern),
+               rows * cols * 4 + counts["tsdf_blocks_in_view"] * (20 + 4096 * 2)),
            "block_ms": [round(d / args.steps * 1e3, 4) for d in dts[:16]], "block_stats_ms_per_step": block_stats(dts, args.steps),
            "kernels": kernels_json(kern),
            "roofline": roofline_of(kern, ms, evo, emp, "longest kernel of the scan; durations = hipEvent spans on the mapper stream minus the calibrated "

@@ -162,6 +162,7 @@ typedef struct {
   int64_t mesh_vertices;        /* V written by the last updateColorMesh */
   int64_t mesh_triangles;       /* T (triangles) written by the last updateColorMesh */
   int64_t capacity_overflow;    /* != 0 if any pool / arena / window overflowed since creation */
+  int64_t lidar_blocks_beam_centric; /* blocks in view of the last LiDAR scan that the beam-centric far-field launch updated (the dense launch took the rest) */
 } nvbx_counters;
 
 /* ---- lifetime --------------------------------------------------------------------------------------------------

@@ -96,7 +96,7 @@ class DeviceView(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "blocks_allocated", "tsdf_blocks_in_view", "color_blocks_updated", "esdf_columns_marked", "esdf_blocks_swept",
-        "esdf_window_voxels", "mesh_blocks_updated", "mesh_vertices", "mesh_triangles", "capacity_overflow")]
+        "esdf_window_voxels", "mesh_blocks_updated", "mesh_vertices", "mesh_triangles", "capacity_overflow", "lidar_blocks_beam_centric")]
 
 
 # every symbol include/nvblox_hip.h declares: name -> (restype, argtypes)

@@ -105,8 +105,9 @@ enum {
                            //   (block coords), 4 columns re-marked, 5 ESDF blocks swept
   S_MESH_REC = 6,          // [6..7] parity-indexed mesh update record: 0 blocks meshed, 2..3 u64 arena cursor of this
                            //   shard's arena region = vertices (low 32) | triangles (high 32)
+  S_LIDAR_SPARSE = 9,      // field 0: blocks of the current LiDAR scan updated by the beam-centric launch (reset by that scan's view marking)
   S_MARK_DONE = 8,         // field 0: workers of the running self-resetting ESDF marking pass that have finished, per shard (C_MARK_DONE counts the shards)
-  S_NUM = 9
+  S_NUM = 10
 };
 constexpr int N_LISTS = 4;
 

@@ -145,6 +145,7 @@ struct nvbx_mapper {
   int replay_deferred();
   int pending_color_trace_rider(void* trace_rider_out);   // color.hip: set the held-back frame up; its sphere tracing as a nvbx::TraceRider
   int launch_pending_color_after_trace();      // color.hip: colour integration (+ ESDF marking riders) of color_pending, its sphere tracing already launched
+  uint8_t* view_class = nullptr; int64_t view_class_cap = 0;        // LiDAR: per view record, 1 = updated by the beam-centric launch (tsdf.hip k_lidar_sparse)
   int32_t* view_export = nullptr; int64_t view_export_cap = 0;      // nvbx_set_view_export
   int reset_consumed_list();         // empty a consumed dirty list (tiny launch; rare paths only)
   int begin_dirtying() { const int rc = reset_consumed_list(); dirty_since_mark = true; return rc; }

@@ -98,7 +98,11 @@ struct LidarSensor {
   // [U] interpolateLidarImage restated: bilinear if the four beams are valid and agree within max_diff_m, else the
   // nearest beam if the voxel centre lies within max_ray_dist_m of that beam's ray.  Depth = range along the beam.
   template <typename Img>
-  __device__ int sample(const Frame& f, const Img& img, const float* pc, float* ds, float* vd) const {
+  __device__ int sample(const Frame& f, const Img& img, const float* pc, float* ds, float* vd) const { int px; return sample_px(f, img, pc, ds, vd, &px); }
+  // the same, also reporting which rule measured: *nearest_px = pixel index (row * cols + col) of the beam the nearest-beam rule used, -1 otherwise
+  template <typename Img>
+  __device__ int sample_px(const Frame& f, const Img& img, const float* pc, float* ds, float* vd, int* nearest_px) const {
+    *nearest_px = -1;
     const float r = nvbx_lidar_range(pc);
     *vd = r;
     if (f.max_dist > 0.0f && r > f.max_dist) return 0;      // (before the projection: it costs two atan2)
@@ -132,6 +136,7 @@ struct LidarSensor {
     // (squared distances compared: one IEEE square root less per voxel on the VALU-bound LiDAR path; the oracle does the same)
     if (__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) > max_ray_dist_m * max_ray_dist_m) return 0;
     *ds = d;
+    *nearest_px = pix(rr, c, f.cols);
     return 1;
   }
 };
@@ -379,6 +384,7 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   const float d = active ? depth(pix(prow, pcol, f.cols)) : 0.0f;
   for (int i = lane; i < LSET; i += 64) lset[i] = KEY_EMPTY;
   if (wg_all == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
+  if (Sensor::kLongRays && wg_all == 0 && lane < NSH) *shc_at(m, S_LIDAR_SPARSE, lane, 0) = 0;
   // an ESDF dirty list already consumed by a marking pass (fused into integrateColor) is emptied before k_integrate_tsdf appends
   if (reset_esdf_dirty && wg_all == 0 && lane < NSH) *shc_at(m, S_LIST_ESDF_DIRTY, lane, 0) = 0;
   __syncthreads();
@@ -482,7 +488,7 @@ template <typename T> __device__ inline T in_vgpr(T x) { asm volatile("" : "+v"(
 // at compile time -- same arithmetic, 12 % fewer issue cycles on the LiDAR launch (tools/variant_ab.sh).
 template <typename Img, typename Sensor, int NB, bool Plain>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_integrate_tsdf(DMap m, FrameSet<Img, NB> fs, Sensor sensor, const int4* view_list, int32_t list_cap,
-                                                        int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes) {
+                                                        int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, const uint8_t* view_class) {
   const Frame& f0 = fs.f[0];
   const int tid = threadIdx.x, lane = tid & 63;
   // The view records are taken 64 at a time: lane j of every wavefront fetches the record of the j-th block this workgroup will
@@ -498,6 +504,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   int32_t n = m.counters[C_VIEW_COUNT + (f0.frame_id & 3)];
   if (n > list_cap) n = list_cap;
   if (lane >= spec_lanes && mine < n) rec = view_list[mine];
+  // (LiDAR: blocks the beam-centric launch k_lidar_sparse has already updated are skipped here -- their record reads as "no slot")
+  if (view_class && mine < n && view_class[mine]) rec.x = (int32_t)SLOT_NONE;
   if (blockIdx.x == 0 && tid == 192) __hip_atomic_store(&m.host_mirror[2], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // next launch's hint
   // nvbx_set_view_export: the frame's block indices also go to a caller-owned packed buffer [1 + cap][3] (row 0 = count) --
   // the message of the multi-GPU exchange, written here instead of by an export launch
@@ -512,7 +520,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   Frame fl = f0; Img img0 = fs.img[0];
   if (Sensor::kLongRays && NB == 1) { fl.cols = in_vgpr(f0.cols); fl.rows = in_vgpr(f0.rows); img0.p = in_vgpr(fs.img[0].p); }
   for (int32_t i0 = blockIdx.x; i0 < n; i0 += 64 * (int32_t)gridDim.x) {
-    if (i0 != (int32_t)blockIdx.x) { mine = i0 + lane * (int32_t)gridDim.x; rec = mine < n ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0); }
+    if (i0 != (int32_t)blockIdx.x) {
+      mine = i0 + lane * (int32_t)gridDim.x; rec = mine < n ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
+      if (view_class && mine < n && view_class[mine]) rec.x = (int32_t)SLOT_NONE;
+    }
     if (view_export && tid < 64 && mine < n && mine < view_export_cap) { int32_t* e = view_export + 3 * (1 + (int64_t)mine); e[0] = rec.y; e[1] = rec.z; e[2] = rec.w; }
     float org[3] = {0.0f, 0.0f, 0.0f};
     if (NB == 1) sensor_block_origin(f0, rec.y, rec.z, rec.w, org);
@@ -574,6 +585,241 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ LiDAR, far field: beam-centric update
+// Measured on a configs[4] scan (an instrumented copy of the CPU checker): 78 % of the voxels of the blocks in view run the nearest-beam rule
+// -- the four beams around them do not agree, as on a ground plane seen at a grazing angle -- and only 6 % pass it: at 0.10 m voxels a beam's
+// acceptance tube is one voxel wide while the beams are 0.6 m x 1.2 m apart at 100 m.  One lane per voxel pays the projection, four taps, the
+// nearest tap and the point-to-ray distance 512 times per block to update ~20 voxels.  This launch turns the question round for the blocks
+// where ONLY the nearest-beam rule can apply: ONE WAVEFRONT PER BLOCK
+//   (1) projects the block's 8 corners: its footprint in the range image (+ 0.75 px: the elevation of a box is not extremal at its corners);
+//       a block whose corner fails to project, that straddles the azimuth seam, or whose footprint exceeds 64 pixels is left to the dense launch;
+//   (2) tests every 2 x 2 beam quad a voxel of the block could interpolate in ("four returns that agree"): one valid quad -> dense launch;
+//   (3) otherwise walks every beam of the footprint that has a return through the block: in block voxel coordinates the beam is a line, along its
+//       major axis it crosses 8 voxel slices, and a voxel centre within (0.5 + 0.01) voxel of the line lies within 0.51 / 0.577 = 0.88 < 1 voxel of
+//       the crossing point inside its slice, i.e. among the 2 x 2 cells around that point -- 32 candidate voxels per beam instead of 512 per block;
+//   (4) evaluates every candidate with the SAME per-voxel code as the dense launch (LidarSensor::sample_px, tsdf_fuse_plain; the voxel centre is
+//       block origin + rotated offset, exactly as there) and updates it iff the rule's nearest beam is the beam that enumerated it (so a voxel
+//       near two tubes is updated once).  A voxel that is not a candidate of its nearest beam fails that beam's distance test: untouched, as in the
+//       dense launch.  Result: bit-identical maps (tests/test_gpu_full_size.py compares all 112 k blocks of two scans with the CPU checker).
+// The class of every record (1 = updated here) goes to view_class[]; the dense launch that follows skips those.  Requires the plain integrator
+// configuration (constant weighting, TSDF) and a nearest-beam acceptance radius <= 0.55 voxel (the 2 x 2 argument); the host falls back otherwise.
+template <typename Img>
+__global__ __launch_bounds__(256) void k_lidar_sparse(DMap m, FrameSet<Img, 1> fs, LidarSensor sensor, const int4* view_list, int32_t list_cap,
+                                                      int32_t mesh_list, uint8_t* view_class) {
+  // per wavefront: the crossing beams {line in block voxel coordinates ob[3], db[3]; pixel; range; direction[3]; major axis} and the
+  // candidate voxels that survive the geometric pre-filter {beam << 9 | voxel}
+  __shared__ float s_beam[4][64][12];
+  __shared__ uint16_t s_item[4][512];
+  const Frame& f = fs.f[0];
+  const Img& img = fs.img[0];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int32_t n_waves = (int32_t)gridDim.x * 4;
+  int32_t n = m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
+  if (n > list_cap) n = list_cap;
+  const float vs = f.voxel_size, bs = f.block_size;
+  const int rows = f.rows, cols = f.cols;
+  // Dependent-access chain per block: {record (fetched one block ahead)} -> {quad taps || footprint taps || beam tables || flag atomic} ->
+  // {voxels of the candidates that pass} -> store.  The candidates' arithmetic needs no image access at all: their beam's range and direction
+  // travel with the beam.
+  // Records are taken EIGHT at a time: lanes 8 j .. 8 j + 7 project the eight corners of block j, so the footprints of eight blocks cost one
+  // pass of the projection code (with one block per pass 56 of the 64 lanes idled through it); the blocks are then walked one after the other.
+  const int grp = lane >> 3;
+  int32_t n_mine = 0;                                        // blocks this wavefront updated (one counter atomic per wavefront, at the end)
+  int32_t base = ((int32_t)blockIdx.x * 4 + wv) * 8;
+  int4 rec_next = base + grp < n ? view_list[base + grp] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
+  for (; base < n; base += n_waves * 8) {
+    const int4 rec_g = rec_next;
+    if (base + n_waves * 8 + grp < n) rec_next = view_list[base + n_waves * 8 + grp]; else rec_next = make_int4((int32_t)SLOT_NONE, 0, 0, 0);
+    // (1) corners of the group's block
+    bool sparse_g = base + grp < n && slot_ok((uint32_t)rec_g.x);
+    float org_g[3];
+    sensor_block_origin(f, rec_g.y, rec_g.z, rec_g.w, org_g);
+    int c0_g = 0, r0_g = 0, w_g = 0, h_g = 0;
+    {
+      float off[3], pc[3], u = 0.0f, v = 0.0f;
+      rotate(f.R_CL, (float)(lane & 1) * bs, (float)((lane >> 1) & 1) * bs, (float)((lane >> 2) & 1) * bs, off);
+      pc[0] = org_g[0] + off[0]; pc[1] = org_g[1] + off[1]; pc[2] = org_g[2] + off[2];
+      const bool okc = nvbx_lidar_project(&sensor.l, pc, nvbx_lidar_range(pc), &u, &v) != 0;
+      const u64 bad = __ballot(!okc);
+      if ((bad >> (8 * grp)) & 0xFFull) sparse_g = false;
+      float umin = u, umax = u, vmin = v, vmax = v;
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        umin = fminf(umin, __shfl_xor(umin, o)); umax = fmaxf(umax, __shfl_xor(umax, o));
+        vmin = fminf(vmin, __shfl_xor(vmin, o)); vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+      }
+      if (sparse_g) {
+        if (umax - umin > (float)cols * 0.5f) sparse_g = false;               // straddles the azimuth seam
+        c0_g = (int)floorf(umin - 0.75f); r0_g = (int)floorf(vmin - 0.75f);
+        w_g = (int)floorf(umax + 0.75f) - c0_g + 1; h_g = (int)floorf(vmax + 0.75f) - r0_g + 1;
+        if (w_g < 1 || h_g < 1 || w_g * h_g > 64) sparse_g = false;           // one lane per footprint pixel
+      }
+    }
+    const u64 sparse_groups = __ballot(sparse_g);
+#pragma unroll 1
+    for (int j = 0; j < 8 && base + j < n; j++) {
+    const int32_t i = base + j;
+    bool sparse = ((sparse_groups >> (8 * j)) & 1ull) != 0;
+    if (!sparse) { if (lane == 0) view_class[i] = 0; continue; }               // (uniform)
+    const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane(rec_g.x, 8 * j);
+    const float org[3] = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(org_g[0]), 8 * j)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(org_g[1]), 8 * j)),
+                          __int_as_float(__builtin_amdgcn_readlane(__float_as_int(org_g[2]), 8 * j))};
+    const int c0 = __builtin_amdgcn_readlane(c0_g, 8 * j), r0 = __builtin_amdgcn_readlane(r0_g, 8 * j), w = __builtin_amdgcn_readlane(w_g, 8 * j), h = __builtin_amdgcn_readlane(h_g, 8 * j);
+    // footprint pixel of this lane: its range and its beam's direction tables are requested together with the quad taps below
+    // (lane -> (column, row) of a w-wide grid without an integer division: exact for lane < 2^10)
+    const int ly = (int)(((float)lane + 0.5f) * (1.0f / (float)w)), lx = lane - ly * w;
+    const int bc = c0 + lx, brr = r0 + ly;
+    const bool in_img = ly < h && bc >= 0 && brr >= 0 && bc < cols && brr < rows;
+    const float bd = in_img ? img(pix(brr, bc, cols)) : 0.0f;
+    const float2 te = sensor.el_tab[in_img ? brr : 0], ta = sensor.az_tab[in_img ? bc : 0];
+    // (2) quads x0 in [c0 - 1, c0 + w - 1], y0 in [r0 - 1, r0 + h - 1]: (w + 1) x (h + 1) <= 130 of them, up to three per lane
+    bool anyq = false;
+    const int nq = (w + 1) * (h + 1);
+    const float iw1 = 1.0f / (float)(w + 1);
+    for (int qi = lane; qi < nq; qi += 64) {
+      const int qy = (int)(((float)qi + 0.5f) * iw1), qx = qi - qy * (w + 1);
+      const int x0 = c0 - 1 + qx, y0 = r0 - 1 + qy;
+      if (!(x0 < 0 || y0 < 0 || x0 + 1 > cols - 1 || y0 + 1 > rows - 1)) {
+        const int32_t i00 = pix(y0, x0, cols);
+        const float f00 = img(i00), f10 = img(i00 + 1), f01 = img(i00 + cols), f11 = img(i00 + cols + 1);
+        if (f00 > 0.0f && f10 > 0.0f && f01 > 0.0f && f11 > 0.0f) {
+          const float mx = fmaxf(fmaxf(f00, f10), fmaxf(f01, f11)), mn = fminf(fminf(f00, f10), fminf(f01, f11));
+          if (mx - mn <= sensor.max_diff_m) anyq = true;
+        }
+      }
+    }
+    if (__ballot(anyq)) sparse = false;
+    if (!sparse) { if (lane == 0) view_class[i] = 0; continue; }               // (uniform)
+    // (3) the beams of the footprint that have a return, one per lane: line in block voxel coordinates q = R_LC (P - org) / vs (sensor origin: P = 0)
+    float ob[3] = {0.0f, 0.0f, 0.0f}, db[3] = {1.0f, 0.0f, 0.0f};
+    const float dir[3] = {te.y * ta.y, te.y * ta.x, te.x};                   // == LidarSensor::beam_dir(brr, bc)
+    bool crossing = false; int axis = 0;
+    if (in_img && bd > 0.0f) {
+      float t3[3];
+      rotate(f.R_LC, org[0], org[1], org[2], t3);
+      const float ivs = 1.0f / vs;
+      ob[0] = -t3[0] * ivs; ob[1] = -t3[1] * ivs; ob[2] = -t3[2] * ivs;    // (enumeration geometry only: a slack of 0.1 voxel, no exactness needed)
+      rotate(f.R_LC, dir[0], dir[1], dir[2], db);
+      int a = 0; if (fabsf(db[1]) > fabsf(db[a])) a = 1; if (fabsf(db[2]) > fabsf(a == 0 ? db[0] : db[1])) a = 2;
+      axis = a;
+      const float oa = a == 0 ? ob[0] : (a == 1 ? ob[1] : ob[2]), da = a == 0 ? db[0] : (a == 1 ? db[1] : db[2]);
+      const float obb = a == 0 ? ob[1] : (a == 1 ? ob[2] : ob[0]), dbb = a == 0 ? db[1] : (a == 1 ? db[2] : db[0]);     // axes (a + 1) % 3, (a + 2) % 3
+      const float occ = a == 0 ? ob[2] : (a == 1 ? ob[0] : ob[1]), dcc = a == 0 ? db[2] : (a == 1 ? db[0] : db[1]);
+      const float ida = 1.0f / da;
+      // the line's crossing points of slice 0 and slice 7 bound those of the slices between: the tube meets the block iff the interval of
+      // crossing points (+- one cell) meets [0, 7] in both perpendicular axes
+      const float t0 = (0.5f - oa) * ida, t7 = (7.5f - oa) * ida;
+      const float b0 = obb + t0 * dbb - 0.5f, b7 = obb + t7 * dbb - 0.5f, cc0 = occ + t0 * dcc - 0.5f, cc7 = occ + t7 * dcc - 0.5f;
+      crossing = fmaxf(b0, b7) >= -1.0f && fminf(b0, b7) <= 8.0f && fmaxf(cc0, cc7) >= -1.0f && fminf(cc0, cc7) <= 8.0f;
+    }
+    const u64 cross = __ballot(crossing);
+    const int nb = (int)__popcll(cross);
+    if (crossing) {
+      const int k = (int)__popcll(cross & ((1ull << lane) - 1ull));
+      float* q = s_beam[wv][k];
+      q[0] = ob[0]; q[1] = ob[1]; q[2] = ob[2]; q[3] = db[0]; q[4] = db[1]; q[5] = db[2];
+      q[6] = __int_as_float(pix(brr, bc, cols)); q[7] = bd; q[8] = dir[0]; q[9] = dir[1]; q[10] = dir[2]; q[11] = __int_as_float(axis);
+    }
+    __threadfence_block();                                  // (the wavefront's own LDS writes, read by its other lanes below: no workgroup barrier -- the four wavefronts run independent loops)
+    __builtin_amdgcn_wave_barrier();
+    // (4a) candidates: item = (beam, slice, cell) -> 32 per beam; a candidate survives the PRE-FILTER if its centre lies within the acceptance radius + 0.02 voxel of the
+    // beam's line in block coordinates (the exact test below is this distance in the sensor frame, to ~1e-4 voxel); survivors are compacted
+    int32_t ns = 0;                                           // survivors (wave-uniform)
+    const float pre = sensor.max_ray_dist_m / vs + 0.02f, pre2 = pre * pre;     // acceptance radius of the exact test, in voxels, + slack
+    for (int it0 = 0; it0 < nb * 32; it0 += 64) {
+      const int item = it0 + lane;
+      const int kb = item >> 5, sl = (item >> 2) & 7, cell = item & 3;
+      bool keep = false; int vox = 0;
+      if (kb < nb) {
+        const float* q = s_beam[wv][kb];
+        const float o0 = q[0], o1 = q[1], o2 = q[2], d0 = q[3], d1 = q[4], d2 = q[5];
+        const int a = __float_as_int(q[11]);
+        const float oa = a == 0 ? o0 : (a == 1 ? o1 : o2), da = a == 0 ? d0 : (a == 1 ? d1 : d2);
+        const float obb = a == 0 ? o1 : (a == 1 ? o2 : o0), dbb = a == 0 ? d1 : (a == 1 ? d2 : d0);
+        const float occ = a == 0 ? o2 : (a == 1 ? o0 : o1), dcc = a == 0 ? d2 : (a == 1 ? d0 : d1);
+        const float t = ((float)sl + 0.5f - oa) / da;
+        const int jb = (int)floorf(obb + t * dbb - 0.5f) + (cell & 1), jc = (int)floorf(occ + t * dcc - 0.5f) + (cell >> 1);
+        if (jb >= 0 && jb <= 7 && jc >= 0 && jc <= 7) {
+          const int vx = a == 0 ? sl : (a == 1 ? jc : jb), vy = a == 0 ? jb : (a == 1 ? sl : jc), vz = a == 0 ? jc : (a == 1 ? jb : sl);
+          const float px = (float)vx + 0.5f - o0, py = (float)vy + 0.5f - o1, pz = (float)vz + 0.5f - o2;
+          const float cx = py * d2 - pz * d1, cy = pz * d0 - px * d2, cz = px * d1 - py * d0;     // |(p - o) x d|^2 = squared distance to the line (|d| = 1)
+          keep = (cx * cx + cy * cy) + cz * cz <= pre2;
+          vox = vz + 8 * vy + 64 * vx;
+        }
+      }
+      const u64 km = __ballot(keep);
+      if (keep) { const int pos = ns + (int)__popcll(km & ((1ull << lane) - 1ull)); if (pos < 512) s_item[wv][pos] = (uint16_t)((kb << 9) | vox); }
+      ns += (int32_t)__popcll(km);
+    }
+    if (ns > 512) sparse = false;                             // more survivors than the list holds (dense beams at close range): the dense launch takes the block
+    if (lane == 0) view_class[i] = sparse ? 1 : 0;
+    if (!sparse) { __builtin_amdgcn_wave_barrier(); continue; }                // (uniform)
+    // the block's books, as the dense launch keeps them (lane 0; the returning atomic is consumed after the update)
+    uint32_t old = 0;
+    if (lane == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH | F_BAND_STALE);
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    // (4b) the survivors, 64 at a time.  In a block of this class the four-tap rule cannot measure (no valid quad in reach), so a candidate goes
+    // straight to the nearest-beam rule -- the same operations, in the same order, as the tail of LidarSensor::sample_px, with the beam's range and
+    // direction taken from the beam instead of from the image and the tables.
+    for (int it0 = 0; it0 < ns; it0 += 64) {
+      if (it0 + lane >= ns) continue;
+      const int code = s_item[wv][it0 + lane];
+      const float* q = s_beam[wv][code >> 9];
+      const int vox = code & 511, vx = vox >> 6, vy = (vox >> 3) & 7, vz = vox & 7;
+      float off[3], pc[3];
+      sensor_voxel_offset(f, vx, vy, vz, off);
+      pc[0] = org[0] + off[0]; pc[1] = org[1] + off[1]; pc[2] = org[2] + off[2];
+      const float r = nvbx_lidar_range(pc);
+      if (f.max_dist > 0.0f && r > f.max_dist) continue;
+      float u, v;
+      if (!nvbx_lidar_project(&sensor.l, pc, r, &u, &v)) continue;
+      const int c = (int)floorf(u), rr = (int)floorf(v);
+      if (c < 0 || rr < 0 || c >= cols || rr >= rows) continue;
+      if (pix(rr, c, cols) != __float_as_int(q[6])) continue;   // the rule's nearest beam is another one: that beam's walk takes the voxel (if it can)
+      const float d = q[7];
+      const float bdx = q[8], bdy = q[9], bdz = q[10];
+      const float dot = __builtin_fmaf(pc[2], bdz, __builtin_fmaf(pc[1], bdy, pc[0] * bdx));
+      const float ex = __builtin_fmaf(-dot, bdx, pc[0]), ey = __builtin_fmaf(-dot, bdy, pc[1]), ez = __builtin_fmaf(-dot, bdz, pc[2]);
+      if (__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)) > sensor.max_ray_dist_m * sensor.max_ray_dist_m) continue;
+      float2* vp = &m.tsdf[(size_t)slot * 512 + vox];
+      float2 fin = *vp;
+      if (tsdf_fuse_plain(f, &fin, d, r)) *vp = fin;
+    }
+    if (lane == 0) {
+      if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)slot);
+      if (!(old & F_DIRTY_MESH)) list_append(m, mesh_list, (int32_t)slot);
+    }
+    n_mine++;
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (lane == 0 && n_mine) atomicAdd(shc_at(m, S_LIDAR_SPARSE, my_shard(), 0), n_mine);
+}
+
+// the beam-centric far-field launch (LiDAR only); view_class = nullptr: everything goes to the dense launch
+template <typename Img, typename Sensor, int NB>
+static int launch_lidar_sparse(nvbx_mapper*, const FrameSet<Img, NB>&, const Sensor&, bool, uint8_t** view_class) { *view_class = nullptr; return NVBX_OK; }
+template <typename Img>
+static int launch_lidar_sparse(nvbx_mapper* m, const FrameSet<Img, 1>& fs, const LidarSensor& sensor, bool plain, uint8_t** view_class) {
+  *view_class = nullptr;
+  static const int enabled = getenv("NVBX_LIDAR_SPARSE") ? atoi(getenv("NVBX_LIDAR_SPARSE")) : 1;       // (A/B: 0 = dense launch only)
+  if (!enabled || !plain || !(m->p.lidar_nearest_interpolation_max_allowable_dist_to_ray_vox <= 0.55f)) return NVBX_OK;
+  if (m->view_class_cap < m->capacity) {
+    NVBX_HIP(hipStreamSynchronize(m->stream));
+    if (m->view_class) NVBX_HIP(hipFree(m->view_class));
+    m->view_class = nullptr; m->view_class_cap = 0;
+    NVBX_HIP(hipMalloc(&m->view_class, (size_t)m->capacity));
+    m->view_class_cap = m->capacity;
+  }
+  static const int sparse_grid = getenv("NVBX_LIDAR_SPARSE_GRID") ? atoi(getenv("NVBX_LIDAR_SPARSE_GRID")) : 4096;    // (6 resident wavefronts per SIMD; 1536 / 3072 / 6144 workgroups: 100.8 / 98.9 / 94.8 us -- short work items balance better)
+  NVBX_LAUNCH(m, (k_lidar_sparse<Img>), dim3(sparse_grid), dim3(256), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, m->mesh_list_live(), m->view_class);
+  *view_class = m->view_class;
+  return NVBX_OK;
+}
+
 template <typename Img, typename Sensor, int NB>
 static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sensor& sensor) {
   const int s = fs.f[0].subsample;
@@ -622,10 +868,12 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   const int32_t spec_lanes = (int32_t)std::min<int64_t>(64, (n_hint + n_hint / 4 + 64 + grid - 1) / grid);
   bool plain = true;
   for (int c = 0; c < fs.n; c++) plain = plain && frame_is_plain(fs.f[c]);
+  uint8_t* view_class = nullptr;
+  { const int rc = launch_lidar_sparse(m, fs, sensor, plain, &view_class); if (rc) return rc; }
   if (plain) NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor, NB, true>), dim3(grid), dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
-                         m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes);
+                         m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (const uint8_t*)view_class);
   else NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor, NB, false>), dim3(grid), dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
-                   m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes);
+                   m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (const uint8_t*)view_class);
   NVBX_HIP(hipGetLastError());
   m->last_view_frame = m->frame_id;
   if (!Sensor::kLongRays) { m->last_camera_view_frame = m->frame_id; m->last_camera_view_mask = 1u << (fs.n - 1); }   // (a batch: the LAST camera's view, as separate calls would leave it)
