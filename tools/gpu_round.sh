@@ -17,10 +17,11 @@ for W in "${WL[@]}"; do
   case $W in lidar) ARGS="--steps 100 --warmup 10"; PARGS="--steps 50 --warmup 5";; decay) ARGS="--steps 120 --warmup 24"; PARGS="--steps 60 --warmup 12";;
              multicam) ARGS="--steps 100 --warmup 20 --cameras 4"; PARGS="--steps 50 --warmup 10 --cameras 4 --profile-run";; multicam8) ARGS="--steps 100 --warmup 20 --cameras 8"; PARGS="--steps 50 --warmup 10 --cameras 8 --profile-run";; *) ARGS=""; PARGS="--steps 100 --warmup 20 --profile-run";; esac
   WL_NAME=$W; [ $W = multicam8 ] && WL_NAME=multicam
+  PMS=100; [ $W = lidar ] && PMS=500     # (LiDAR: few, long launches -- a longer run keeps the first-launch outliers out of the average)
   timeout 900 python bench.py --workload $WL_NAME $ARGS > gpurun_out/$TAG/bench$S.json 2> gpurun_out/$TAG/bench$S.err; echo "bench $W rc=$?"
   cat gpurun_out/$TAG/bench$S.json | cut -c1-600
   # (profiling runs: 100 ms timed instead of 1 s -- the per-launch traces / counter tables of a 1 s run are tens of MB, gpurun merges <= 64 MiB)
-  (cd /tmp && NVBX_BENCH_MIN_MS=100 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/stats$S -o stats -- python $R/bench.py --workload $WL_NAME $PARGS --no-cpu-baseline > $R/gpurun_out/$TAG/prof_bench$S.json 2> $R/gpurun_out/$TAG/prof$S.err); echo "rocprof $W rc=$?"
+  (cd /tmp && NVBX_BENCH_MIN_MS=$PMS timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/stats$S -o stats -- python $R/bench.py --workload $WL_NAME $PARGS --no-cpu-baseline > $R/gpurun_out/$TAG/prof_bench$S.json 2> $R/gpurun_out/$TAG/prof$S.err); echo "rocprof $W rc=$?"
   find gpurun_out/$TAG/stats$S -name "*kernel_trace.csv" -delete
   find gpurun_out/$TAG/stats$S -name "*kernel_stats.csv" -exec head -12 {} \;
   if [ $PMC = 1 ]; then
