@@ -216,7 +216,7 @@ static int alloc_all(nvbx_mapper* m) {
   NVBX_HIP(hipHostMalloc(&m->h_shc, S_NUM * NSH * SH_STRIDE * 4));
   NVBX_HIP(hipHostMalloc(&m->h_mirror, 64, hipHostMallocMapped));
   { void* dp = nullptr; NVBX_HIP(hipHostGetDevicePointer(&dp, m->h_mirror, 0)); d.host_mirror = (int32_t*)dp; }
-  m->h_mirror[0] = (int32_t)cap; m->h_mirror[1] = 0; m->h_mirror[2] = 0;
+  m->h_mirror[0] = (int32_t)cap; m->h_mirror[1] = 0; m->h_mirror[2] = 0; m->h_mirror[3] = 0;
   return NVBX_OK;
 }
 
@@ -236,8 +236,8 @@ static int reset_map(nvbx_mapper* m) {
   NVBX_LAUNCH(m, k_init_map, dim3((unsigned)((n + 255) / 256)), dim3(256), d);
   NVBX_HIP(hipGetLastError());
   m->dirty_since_mark = false; m->premark_consumed = false; m->mark_pass = 0; m->edt_pending = false; m->import_pending = false;
-  m->unresolved_marks = false; m->pass_at_last_edt = 0; m->color_pending.on = false; m->esdf_update_pending = false;
-  if (m->h_mirror) { m->h_mirror[0] = (int32_t)m->capacity; m->h_mirror[1] = 0; m->h_mirror[2] = 0; }
+  m->unresolved_marks = false; m->pass_at_last_edt = 0; m->color_pending.on = false; m->esdf_update_pending = false; m->lidar_integrated = false;
+  if (m->h_mirror) { m->h_mirror[0] = (int32_t)m->capacity; m->h_mirror[1] = 0; m->h_mirror[2] = 0; m->h_mirror[3] = 0; }
   m->frame_id = 0; m->esdf_epoch = 0; m->mesh_epoch = 0; m->last_view_frame = 0; m->last_camera_view_frame = 0; m->synth_rows = m->synth_cols = 0;
   return NVBX_OK;
 }
@@ -376,7 +376,7 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   DMap& d = m->d;
   void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.slot_consumed, d.slot_cam, d.tsdf, d.color, d.esdf,
                   m->view_list, d.lists, d.shc, m->export_idx, m->export_count, m->cleared_idx, d.site_bits, d.obs_bits, d.inside_bits,
-                  m->synth, m->view_class, m->depth_pre, m->mask_zmin, m->apply_postab, m->esdf3_scratch, m->cc_scratch, d.freespace, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
+                  m->synth, m->view_class, m->color_cand, m->depth_pre, m->mask_zmin, m->apply_postab, m->esdf3_scratch, m->cc_scratch, d.freespace, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& s : m->spans) { if (s.a) (void)hipEventDestroy(s.a); if (s.b) (void)hipEventDestroy(s.b); }
   for (hipEvent_t e : m->event_pool) if (e) (void)hipEventDestroy(e);

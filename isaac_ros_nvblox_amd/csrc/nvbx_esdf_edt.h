@@ -14,16 +14,18 @@ constexpr int EDT_ROW_WORDS = 5;                    // zero pad word + 3 data wo
 
 // Four wavefronts per ESDF block.  Dependent-access chain: {window record} -> {hash entries of the (2rb+1)^2
 // neighbourhood, own block included} -> {site masks, own layer flag, own voxel flags} -> LDS phases -> store.
-// LDS carve-up of one EDT workgroup (256 threads): 9776 bytes
+// LDS carve-up of one EDT workgroup (256 or 512 threads): 10800 bytes
 struct EdtShared {
   u64 s_bits[EDT_MAX_NN * EDT_MAX_NN];
   u64 s_rows[EDT_MAX_ROWS * EDT_ROW_WORDS];
-  int32_t s_part[4 * 64];
+  int32_t s_part[8 * 64];          // (one row per wavefront: 4 in a 256-thread workgroup, 8 in a 512-thread one)
   uint32_t s_own[2];               // own slot, own layer flags
   u64 s_masks[2];                  // own observed / inside masks
   int8_t s_dx[EDT_MAX_ROWS * 8];
 };
-// worker `wg` of `nwg` 256-thread workgroups; called by k_esdf_edt and by the EDT workgroups riding in k_mark_view
+// worker `wg` of `nwg` NT-thread workgroups (NT = 256: k_esdf_edt and the EDT workgroups riding in k_mark_view; NT = 512: those riding in the
+// fused colour + TSDF launch, tsdf.hip): NT / 64 wavefronts per ESDF block
+template <int NT = 256>
 __device__ inline void esdf_edt_worker(const DMap& m, const EsdfArgs& a, int wg, int nwg, EdtShared* sh_) {
   u64* s_bits = sh_->s_bits; u64* s_rows = sh_->s_rows; int8_t* s_dx = sh_->s_dx; int32_t* s_part = sh_->s_part; uint32_t* s_own = sh_->s_own; u64* s_masks = sh_->s_masks;
   const int tid = threadIdx.x;
@@ -57,7 +59,7 @@ __device__ inline void esdf_edt_worker(const DMap& m, const EsdfArgs& a, int wg,
     const int32_t bx = wx0 + cx, by = wy0 + cy;
     __syncthreads();                     // previous block's LDS reads are done
     // 1. site masks of the nn x nn surrounding blocks (zero where there is no block: site_bits of non-ESDF slots is 0)
-    for (int q = tid; q < nn * nn; q += 256) {
+    for (int q = tid; q < nn * nn; q += NT) {
       const int qy = q / nn, qx = q - qy * nn;
       const uint32_t s = any_slot(m, bx + qx - a.rb, by + qy - a.rb, a.bz_out);
       s_bits[q] = slot_ok(s) ? m.site_bits[s] : 0ull;
@@ -80,7 +82,7 @@ __device__ inline void esdf_edt_worker(const DMap& m, const EsdfArgs& a, int wg,
     const uint32_t vflags = (((s_masks[0] >> lane) & 1ull) ? ESDF_OBSERVED : 0u) | (((s_masks[1] >> lane) & 1ull) ? ESDF_INSIDE : 0u) |
                             (((s_bits[ctr] >> lane) & 1ull) ? ESDF_SITE : 0u);
     // 2. row bitmap: word w of row r holds neighbourhood voxel columns 64(w-1) .. 64(w-1)+63 (bit = column & 63)
-    for (int q = tid; q < rows * EDT_ROW_WORDS; q += 256) {
+    for (int q = tid; q < rows * EDT_ROW_WORDS; q += NT) {
       const int r = q / EDT_ROW_WORDS, w = q - r * EDT_ROW_WORDS;
       u64 word = 0ull;
       if (w >= 1 && w <= 3) {
@@ -95,7 +97,7 @@ __device__ inline void esdf_edt_worker(const DMap& m, const EsdfArgs& a, int wg,
     }
     __syncthreads();
     // 3. row pass: nearest site along x within ri (ties -> -x), for the block's own 8 columns on every strip row
-    for (int q = tid; q < rows * 8; q += 256) {
+    for (int q = tid; q < rows * 8; q += NT) {
       const int r = q >> 3, X = 8 * a.rb + (q & 7);
       const u64* row = &s_rows[r * EDT_ROW_WORDS];
       const int wi = 1 + (X >> 6), b = X & 63;
@@ -111,10 +113,10 @@ __device__ inline void esdf_edt_worker(const DMap& m, const EsdfArgs& a, int wg,
     }
     __syncthreads();
     // 4. column pass: argmin over dy of (dy^2 + dx^2, dy) -- the oracle scans dy ascending with strict improvement,
-    //    i.e. the smallest dy among equal distances.  Wave w takes |dy| = w, w+4, ... (increasing, stop at dy^2 > best);
-    //    the four partial minima are merged with the same lexicographic rule.
+    //    i.e. the smallest dy among equal distances.  Wave w takes |dy| = w, w + NT/64, ... (increasing, stop at dy^2 > best);
+    //    the partial minima are merged with the same lexicographic rule.
     int32_t best = INT32_MAX, bdx = 0, bdy = 0;
-    for (int ady = wave; ady <= a.ri; ady += 4) {
+    for (int ady = wave; ady <= a.ri; ady += NT / 64) {
       if (ady * ady > best) break;
 #pragma unroll
       for (int sgn = 0; sgn < 2; sgn++) {
@@ -132,7 +134,7 @@ __device__ inline void esdf_edt_worker(const DMap& m, const EsdfArgs& a, int wg,
     if (wave == 0) {
       int32_t p = s_part[lane];
 #pragma unroll
-      for (int w = 1; w < 4; w++) { const int32_t o = s_part[w * 64 + lane]; if (o < p) p = o; }
+      for (int w = 1; w < NT / 64; w++) { const int32_t o = s_part[w * 64 + lane]; if (o < p) p = o; }
       if (p != INT32_MAX && (float)(p >> 14) <= a.max_sq) {
         const int32_t fdx = (p & 127) - 64, fdy = ((p >> 7) & 127) - 64;
         *vp = make_uint2(__float_as_uint((float)(p >> 14)), vflags | ((uint32_t)(uint8_t)(int8_t)fdx) | (((uint32_t)(uint8_t)(int8_t)fdy) << 8));

@@ -99,14 +99,14 @@ __device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg
 // A marking pass that empties the list it consumed (EsdfArgs::self_reset): every one of its `n_workers` wavefronts calls this when it is
 // done with its entries; the last one to arrive resets the shard counts and the arrival counter.  Nothing appends to the list while a
 // marking pass runs (stream order), so the reset cannot lose an entry.
-__device__ inline void esdf_mark_pass_done(const DMap& m, const EsdfArgs& a, int n_workers) {
+__device__ inline void esdf_mark_pass_done(const DMap& m, const EsdfArgs& a, int n_workers, int worker = -1) {
   if (!a.self_reset) return;
   // (no fence: the worker's loads from the list have RETURNED -- it used their values -- before it gets here, and the reset is ordered behind
   //  every worker's arrival by the atomics themselves; a __threadfence per worker cost the launch ~3 us)
   if ((threadIdx.x & 63) == 0) {
     // two levels: 256 workers on ONE counter serialise at ~12 ns per atomic (3 us inside a 9 us launch, measured); a worker counts itself in
     // its shard's copy (worker w -> shard w & 7), the last of a shard counts the shard, the last shard resets
-    const int w = (int)blockIdx.x, sh = w & (NSH - 1);
+    const int w = worker >= 0 ? worker : (int)blockIdx.x, sh = w & (NSH - 1);      // (workers = the launch's first workgroups, unless told otherwise)
     const int32_t in_shard = (n_workers - sh + NSH - 1) / NSH;          // workers w' < n_workers with w' & 7 == sh
     const int32_t arrived = atomicAdd(shc_at(m, S_MARK_DONE, sh, 0), 1);
     if (arrived == in_shard - 1) {

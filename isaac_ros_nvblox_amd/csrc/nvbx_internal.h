@@ -88,7 +88,8 @@ enum {
   C_TMP = 45,          // scratch counter (point cloud compaction etc.)
   C_CLEARED = 46,      // entries of the cleared-block list (nvbx_take_cleared_blocks)
   C_MARK_DONE = 47,    // workers of the running ESDF marking pass that have finished (a pass that empties the dirty list itself, EsdfArgs::self_reset)
-  C_NUM = 48
+  C_CAND_COUNT = 48,   // [48..49] parity-indexed: colour candidate records discovered for the fused colour + TSDF launch (nvbx_color_worker.h)
+  C_NUM = 56
 };
 
 // ---- sharded counters.  A counter that every workgroup of a launch bumps serialises at ~12 ns per atomic in the

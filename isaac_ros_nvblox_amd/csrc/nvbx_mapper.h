@@ -144,7 +144,17 @@ struct nvbx_mapper {
   bool pipelined_order = false;      // inside the pipelined integrateDepth: marking passes empty their list, EDTs keep it (EsdfArgs)
   int replay_deferred();
   int pending_color_trace_rider(void* trace_rider_out);   // color.hip: set the held-back frame up; its sphere tracing as a nvbx::TraceRider
-  int launch_pending_color_after_trace();      // color.hip: colour integration (+ ESDF marking riders) of color_pending, its sphere tracing already launched
+  int launch_pending_color_after_trace();
+// -- fused colour + TSDF launch of the pipelined order (two launches per frame)
+  int4* color_cand = nullptr;        // [2][fuse_cap] candidate records {slot, block index} of the held-back colour frame (parity cand_parity)
+  int64_t fuse_cap = 0;
+  int cand_parity = 0;
+  bool lidar_integrated = false;     // a LiDAR scan has been integrated since the last clear: blocks may be F_BAND_STALE -> no fused launches
+  int ensure_fuse_buffers();         // tsdf.hip
+  // color.hip: the marking pass that rides in the view-marking launch (0 workgroups: none), and the held-back colour frame's set-up for the
+  // fused launch (rgb8 / bgra8 share one layout)
+  void pending_marking_args(int32_t* mark_wg, nvbx::EsdfArgs* ea_out);
+  int pending_color_fused_args(void* fsc_out, int* kind, int32_t* srows, int32_t* scols);
   uint8_t* view_class = nullptr; int64_t view_class_cap = 0;        // LiDAR: per view record, 1 = updated by the beam-centric launch (tsdf.hip k_lidar_sparse)
   int32_t* view_export = nullptr; int64_t view_export_cap = 0;      // nvbx_set_view_export
   int reset_consumed_list();         // empty a consumed dirty list (tiny launch; rare paths only)

@@ -115,6 +115,10 @@ __device__ inline void sphere_trace_worker(const DMap& m, const PoseSet<NB>& pos
 
 // The sphere tracing of a held-back colour frame riding in the next depth frame's k_mark_view launch (kernel argument; n_wg = 0: none).
 // n_tile_wg > 0: the launch's first n_tile_wg workgroups are the view-marking tiles and the riders (EDT, then sphere tracing) follow; 0: riders first.
-struct TraceRider { PoseSet<1> ps; float* synth; int32_t srows, scols, max_steps; float max_len, eps_m; int32_t n_wg; int32_t n_tile_wg; int32_t lanes; };
+// n_scan_wg > 0: behind the sphere-tracing workers, n_scan_wg workgroups discover the colour frame's candidate blocks (color_scan_worker,
+// nvbx_color_worker.h) into cand[], count in counters[cand_cnt_idx]; they also zero counters[cand_reset_idx] (the other parity's count).
+struct TraceRider { PoseSet<1> ps; float* synth; int32_t srows, scols, max_steps; float max_len, eps_m; int32_t n_wg; int32_t n_tile_wg; int32_t lanes;
+                    int32_t n_scan_wg; int4* cand; int32_t cand_cnt_idx, cand_reset_idx;
+                    int32_t n_mark_wg; };      // n_mark_wg > 0: behind those, the ESDF site marking of the held-back update (k_mark_view's EsdfArgs)
 
 }  // namespace nvbx

@@ -23,6 +23,8 @@
 #include "nvbx_lidar_math.h"
 #include "nvbx_esdf_edt.h"
 #include "nvbx_sphere_trace.h"
+#include "nvbx_esdf_mark.h"
+#include "nvbx_color_worker.h"
 
 using namespace nvbx;
 
@@ -346,15 +348,23 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
     // riders: [EDT workers][sphere-tracing workers of a held-back colour frame (colour deferral)] -- before the tiles, or
     // (tr.n_tile_wg > 0) after them.  All counts are multiples of 8, so a workgroup's XCD (blockIdx.x & 7) is also its number's & 7.
     const int32_t rider = tr.n_tile_wg > 0 ? (int32_t)blockIdx.x - tr.n_tile_wg : (int32_t)blockIdx.x;
-    const bool is_rider = tr.n_tile_wg > 0 ? rider >= 0 : rider < n_edt_wg + tr.n_wg;
+    const bool is_rider = tr.n_tile_wg > 0 ? rider >= 0 : rider < n_edt_wg + tr.n_wg + tr.n_scan_wg + tr.n_mark_wg;
     if (is_rider) {
       if (rider < n_edt_wg) esdf_edt_worker(m, ea, (int)rider, n_edt_wg, reinterpret_cast<EdtShared*>(smem));
       // (sphere tracing: all four wavefronts; independent of the view marking -- it reads the TSDF and the insert-only hash, and new entries point at all-zero blocks)
-      else if (tr.lanes == 4) sphere_trace_worker<1, 4>(m, tr.ps, tr.synth, tr.srows, tr.scols, tr.max_steps, tr.max_len, tr.eps_m, (int)(rider - n_edt_wg));
-      else sphere_trace_worker<1, 8>(m, tr.ps, tr.synth, tr.srows, tr.scols, tr.max_steps, tr.max_len, tr.eps_m, (int)(rider - n_edt_wg));
+      else if (rider < n_edt_wg + tr.n_wg) {
+        if (tr.lanes == 4) sphere_trace_worker<1, 4>(m, tr.ps, tr.synth, tr.srows, tr.scols, tr.max_steps, tr.max_len, tr.eps_m, (int)(rider - n_edt_wg));
+        else sphere_trace_worker<1, 8>(m, tr.ps, tr.synth, tr.srows, tr.scols, tr.max_steps, tr.max_len, tr.eps_m, (int)(rider - n_edt_wg));
+      }
+      // (candidate discovery of the held-back colour frame, for the fused colour + TSDF launch that follows: four wavefronts of 64 slots each)
+      else if (rider < n_edt_wg + tr.n_wg + tr.n_scan_wg)
+        color_scan_worker(m, tr.ps.f[0], tr.cand, tr.cand_cnt_idx, tr.cand_reset_idx, (int)(rider - n_edt_wg - tr.n_wg) * 4 + (int)(threadIdx.x >> 6), tr.n_scan_wg * 4);
+      // (ESDF site marking of the held-back update, first wavefront only: it reads the TSDF as the last update left it -- nothing in this launch
+      //  writes voxels -- and allocates ESDF blocks beside the view marking's TSDF blocks; `ea` is its argument then: no EDT rides, n_edt_wg = 0)
+      else if (threadIdx.x < 64) { const int w = (int)(rider - n_edt_wg - tr.n_wg - tr.n_scan_wg); esdf_mark_worker(m, ea, w, tr.n_mark_wg); esdf_mark_pass_done(m, ea, tr.n_mark_wg, w); }
       return;
     }
-    if (tr.n_tile_wg == 0) tile_wg -= n_edt_wg + tr.n_wg;
+    if (tr.n_tile_wg == 0) tile_wg -= n_edt_wg + tr.n_wg + tr.n_scan_wg + tr.n_mark_wg;
     if (threadIdx.x >= 64) return;            // a tile is one wavefront
   }
   u64* lset = reinterpret_cast<u64*>(smem);
@@ -487,8 +497,9 @@ template <typename T> __device__ inline T in_vgpr(T x) { asm volatile("" : "+v"(
 // Plain = every camera of the launch is frame_is_plain() (nvbx_internal.h): the occupancy / weighting-mode / decay switches fold away
 // at compile time -- same arithmetic, 12 % fewer issue cycles on the LiDAR launch (tools/variant_ab.sh).
 template <typename Img, typename Sensor, int NB, bool Plain>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_integrate_tsdf(DMap m, FrameSet<Img, NB> fs, Sensor sensor, const int4* view_list, int32_t list_cap,
-                                                        int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, const uint8_t* view_class) {
+__device__ inline void integrate_tsdf_worker(const DMap& m, const FrameSet<Img, NB>& fs, const Sensor& sensor, const int4* view_list, int32_t list_cap,
+                                             int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, const uint8_t* view_class,
+                                             const int32_t wgi, const int32_t n_wg) {
   const Frame& f0 = fs.f[0];
   const int tid = threadIdx.x, lane = tid & 63;
   // The view records are taken 64 at a time: lane j of every wavefront fetches the record of the j-th block this workgroup will
@@ -499,36 +510,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // frame has ~300 blocks in view and about as many workgroups, so one record per wavefront is wanted -- 64 speculative 16-B records from
   // each of 8 x 1024 wavefronts were 8 MB of HBM traffic for 3.5 MB of work (PMC, profiles/r02z_pmc.json).  A lane the hint left out
   // fetches once the count is known (a dependent load, only when the view grew by more than the hint's margin).
-  int32_t mine = (int32_t)blockIdx.x + lane * (int32_t)gridDim.x;
+  int32_t mine = wgi + lane * n_wg;
   int4 rec = (lane < spec_lanes && mine < list_cap) ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
   int32_t n = m.counters[C_VIEW_COUNT + (f0.frame_id & 3)];
   if (n > list_cap) n = list_cap;
   if (lane >= spec_lanes && mine < n) rec = view_list[mine];
   // (LiDAR: blocks the beam-centric launch k_lidar_sparse has already updated are skipped here -- their record reads as "no slot")
   if (view_class && mine < n && view_class[mine]) rec.x = (int32_t)SLOT_NONE;
-  if (blockIdx.x == 0 && tid == 192) __hip_atomic_store(&m.host_mirror[2], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // next launch's hint
+  if (wgi == 0 && tid == 192) __hip_atomic_store(&m.host_mirror[2], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // next launch's hint
   // nvbx_set_view_export: the frame's block indices also go to a caller-owned packed buffer [1 + cap][3] (row 0 = count) --
   // the message of the multi-GPU exchange, written here instead of by an export launch
-  if (view_export && blockIdx.x == 0 && tid == 0) { view_export[0] = min(n, view_export_cap); view_export[1] = 0; view_export[2] = 0; }
+  if (view_export && wgi == 0 && tid == 0) { view_export[0] = min(n, view_export_cap); view_export[1] = 0; view_export[2] = 0; }
   // pool growth: the free-slot count after this frame's allocations goes to pinned host memory (not waited for)
-  if (blockIdx.x == 0 && tid == 64) __hip_atomic_store(&m.host_mirror[0], m.counters[C_FREE_TOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (blockIdx.x == 0 && tid == 128) __hip_atomic_store(&m.host_mirror[1], m.counters[C_HIGH_WATER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (wgi == 0 && tid == 64) __hip_atomic_store(&m.host_mirror[0], m.counters[C_FREE_TOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (wgi == 0 && tid == 128) __hip_atomic_store(&m.host_mirror[1], m.counters[C_HIGH_WATER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
   float off0[3] = {0.0f, 0.0f, 0.0f};
   if (NB == 1) sensor_voxel_offset(f0, vx, vy, vz, off0);          // (a batch rotates the offset per camera inside the loop)
   // LiDAR: the image geometry the four-tap gather needs per voxel lives in vector registers (see in_vgpr)
   Frame fl = f0; Img img0 = fs.img[0];
   if (Sensor::kLongRays && NB == 1) { fl.cols = in_vgpr(f0.cols); fl.rows = in_vgpr(f0.rows); img0.p = in_vgpr(fs.img[0].p); }
-  for (int32_t i0 = blockIdx.x; i0 < n; i0 += 64 * (int32_t)gridDim.x) {
-    if (i0 != (int32_t)blockIdx.x) {
-      mine = i0 + lane * (int32_t)gridDim.x; rec = mine < n ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
+  for (int32_t i0 = wgi; i0 < n; i0 += 64 * n_wg) {
+    if (i0 != wgi) {
+      mine = i0 + lane * n_wg; rec = mine < n ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
       if (view_class && mine < n && view_class[mine]) rec.x = (int32_t)SLOT_NONE;
     }
     if (view_export && tid < 64 && mine < n && mine < view_export_cap) { int32_t* e = view_export + 3 * (1 + (int64_t)mine); e[0] = rec.y; e[1] = rec.z; e[2] = rec.w; }
     float org[3] = {0.0f, 0.0f, 0.0f};
     if (NB == 1) sensor_block_origin(f0, rec.y, rec.z, rec.w, org);
 #pragma unroll 1
-    for (int32_t j = 0; j < 64 && i0 + j * (int32_t)gridDim.x < n; j++) {               // (uniform)
+    for (int32_t j = 0; j < 64 && i0 + j * n_wg < n; j++) {               // (uniform)
       const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane(rec.x, j);               // pool slot (stable across hash rebuilds)
       if (!slot_ok(slot)) continue;
       float2* vp = &m.tsdf[(size_t)slot * 512 + tid];
@@ -584,7 +595,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
   }
 }
+template <typename Img, typename Sensor, int NB, bool Plain>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_integrate_tsdf(DMap m, FrameSet<Img, NB> fs, Sensor sensor, const int4* view_list, int32_t list_cap,
+                                                        int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, const uint8_t* view_class) {
+  integrate_tsdf_worker<Img, Sensor, NB, Plain>(m, fs, sensor, view_list, list_cap, mesh_list, view_export, view_export_cap, spec_lanes, view_class, (int32_t)blockIdx.x, (int32_t)gridDim.x);
+}
 
+// Pipelined order, fused: TSDF update of frame i + 1, colour integration of frame i (from the candidate records the riders
+// of the view-marking launch discovered) and the distance transform of ESDF update i in ONE launch -- two launches per frame:
+//   k_mark_view            view marking (i+1) || sphere tracing (i) || colour candidates (i) || ESDF site marking (i)
+//   k_integrate_tsdf_color TSDF update (i+1)  || colour integration (i)                      || distance transform (i)
+// What makes the three parts of this launch independent: the colour workers read no block flag (their candidates were fixed before the
+// launch: the TSDF update rewrites F_BAND beside them) and no TSDF voxel; the distance transform reads the site masks of a marking pass that
+// has finished (previous launch) and writes ESDF voxels only; the update appends to an ESDF-dirty list that pass has emptied.  Every part
+// reads exactly the state separate calls would have shown it.
+// Workgroups: [distance transform (512 threads = 8 wavefronts per ESDF block)][TSDF update][colour].
+template <typename Img, typename Pix>
+__global__ __launch_bounds__(512) void k_integrate_tsdf_color(DMap m, FrameSet<Img, 1> fs, CameraSensor sensor, const int4* view_list, int32_t list_cap,
+                                                              int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, int32_t n_tsdf_wg,
+                                                              FrameSetC<Pix, 1> fsc, const float* synth, int32_t srows, int32_t scols, const int4* cand, int32_t cand_cnt_idx,
+                                                              int32_t n_edt_wg, EsdfArgs ea) {
+  __shared__ __align__(16) unsigned char smem[sizeof(EdtShared)];
+  const int32_t b = (int32_t)blockIdx.x;
+  if (b < n_edt_wg) { esdf_edt_worker<512>(m, ea, (int)b, n_edt_wg, reinterpret_cast<EdtShared*>(smem)); return; }
+  if (b < n_edt_wg + n_tsdf_wg) {
+    integrate_tsdf_worker<Img, CameraSensor, 1, true>(m, fs, sensor, view_list, list_cap, mesh_list, view_export, view_export_cap, spec_lanes, nullptr, b - n_edt_wg, n_tsdf_wg);
+    return;
+  }
+  color_integrate_list_worker<Pix>(m, fsc, synth, srows, scols, mesh_list, cand, cand_cnt_idx, b - n_edt_wg - n_tsdf_wg, (int32_t)gridDim.x - n_edt_wg - n_tsdf_wg);
+}
+
+int nvbx_mapper::ensure_fuse_buffers() {
+  if (fuse_cap == capacity && color_cand) return NVBX_OK;
+  NVBX_HIP(hipStreamSynchronize(stream));
+  if (color_cand) NVBX_HIP(hipFree(color_cand));
+  color_cand = nullptr; fuse_cap = 0;
+  NVBX_HIP(hipMalloc(&color_cand, (size_t)capacity * 2 * sizeof(int4)));
+  fuse_cap = capacity;
+  return NVBX_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ LiDAR, far field: beam-centric update
 // Measured on a configs[4] scan (an instrumented copy of the CPU checker): 78 % of the voxels of the blocks in view run the nearest-beam rule
@@ -839,20 +888,43 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   }
   // Colour deferral: a held-back integrateColor (and an updateEsdf behind it) is carried out in PIPELINED order -- its sphere tracing rides
   // in this view-marking launch, its colour integration + ESDF marking follow, then this frame's TSDF update: three launches per frame.
+  // Or TWO (fused, k_integrate_tsdf_color above): the colour frame's candidate blocks are discovered and the ESDF marking pass runs as
+  // riders of this view-marking launch too, and colour integration, the update's distance transform and this frame's TSDF update share
+  // the second launch.
   TraceRider tr{};
+  bool plain = true;
+  for (int c = 0; c < fs.n; c++) plain = plain && frame_is_plain(fs.f[c]);
   const bool pipelined = Sensor::kThreads == 256 && NB == 1 && m->color_pending.on;
+  bool fused = false;
   if (pipelined) {
+    static const int fuse_on = getenv("NVBX_FUSE_COLC") ? atoi(getenv("NVBX_FUSE_COLC")) : 1;      // (A/B: 0 = three launches per frame)
+    // plain TSDF mapper, 2-D ESDF by the exact transform (the marking pass / distance transform that ride are the 2-D ones), no multi-GPU
+    // union step waiting for the colour launch, and no block that may be F_BAND_STALE (the candidate riders read the band flags only)
+    fused = fuse_on && plain && m->p.projective_layer_type == 0 && m->p.esdf_mode == 0 && m->p.esdf_propagation == 0 && !m->import_pending && !m->lidar_integrated;
+    // (a distance transform armed outside the pipeline must precede the marking pass that rides in this launch: its own launch, rare)
+    if (fused && edt_wg) { m->edt_pending = true; edt_wg = 0; if (m->flush_edt()) return NVBX_E_DEVICE; }
     m->pipelined_order = true; const int rc = m->pending_color_trace_rider(&tr); if (rc) { m->pipelined_order = false; return rc; }
     static const int tiles_first = getenv("NVBX_MARK_TILES_FIRST") ? atoi(getenv("NVBX_MARK_TILES_FIRST")) : 1;       // (A/B: riders first = 0)
     if (tiles_first) tr.n_tile_wg = tiles;
+    if (fused) {
+      if (m->ensure_fuse_buffers()) { m->pipelined_order = false; return NVBX_E_DEVICE; }
+      const int64_t hw_seen = std::max<int64_t>(1, __atomic_load_n(&m->h_mirror[1], __ATOMIC_RELAXED));
+      tr.n_scan_wg = (int32_t)std::min<int64_t>(256, 8 * ((hw_seen + hw_seen / 4 + 64 + 2047) / 2048));      // 256 slots per workgroup and pass; a hint only (the riders grid-stride)
+      tr.cand = m->color_cand + (size_t)m->cand_parity * m->fuse_cap;
+      tr.cand_cnt_idx = C_CAND_COUNT + m->cand_parity; tr.cand_reset_idx = C_CAND_COUNT + (1 - m->cand_parity);
+      m->pending_marking_args(&tr.n_mark_wg, &ea);        // (the held-back integrateColor's marking pass, in call order: before its colour integration below)
+    }
   }
-  NVBX_LAUNCH(m, (k_mark_view<Img, Sensor, NB>), dim3(tiles + edt_wg + tr.n_wg), dim3(Sensor::kThreads), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
+  NVBX_LAUNCH(m, (k_mark_view<Img, Sensor, NB>), dim3(tiles + edt_wg + tr.n_wg + tr.n_scan_wg + tr.n_mark_wg), dim3(Sensor::kThreads), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
               (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)edt_wg, ea, tr);
+  FrameSetC<PixRgb8, 1> fsc{}; int f_kind = 0; int32_t f_srows = 0, f_scols = 0;
   if (pipelined) {
     // the host-side steps of the held-back calls, in call order: integrateColor (its marking pass empties the dirty list itself, the EDT
-    // of the update keeps it -- EsdfArgs), then updateEsdf (which only arms the next held-back EDT: the marking has just been launched)
-    m->premark_consumed = false;
-    int rc = m->launch_pending_color_after_trace();
+    // of the update keeps it -- EsdfArgs), then updateEsdf (which only arms the next held-back EDT: the marking pass has been launched)
+    if (!fused) m->premark_consumed = false;
+    int rc = NVBX_OK;
+    if (fused) rc = m->pending_color_fused_args(&fsc, &f_kind, &f_srows, &f_scols);
+    else rc = m->launch_pending_color_after_trace();
     if (rc == NVBX_OK && m->esdf_update_pending) { m->esdf_update_pending = false; rc = nvbx_update_esdf(m); }
     m->pipelined_order = false;
     if (rc) return rc;
@@ -866,10 +938,30 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   const int64_t want = ((n_hint + n_hint / 4 + 64 + 7) / 8) * 8;
   const int grid = (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, grid_cap), want));
   const int32_t spec_lanes = (int32_t)std::min<int64_t>(64, (n_hint + n_hint / 4 + 64 + grid - 1) / grid);
-  bool plain = true;
-  for (int c = 0; c < fs.n; c++) plain = plain && frame_is_plain(fs.f[c]);
   uint8_t* view_class = nullptr;
   { const int rc = launch_lidar_sparse(m, fs, sensor, plain, &view_class); if (rc) return rc; }
+  if (Sensor::kLongRays && m->p.projective_layer_type != 1) m->lidar_integrated = true;      // (blocks may be F_BAND_STALE from here on)
+  if (fused) {
+    if constexpr (NB == 1 && Sensor::kThreads == 256) {
+      // [distance transform the held-back updateEsdf has just armed][TSDF update of this frame][colour integration of the held-back frame]
+      int32_t n_edt = 0; EsdfArgs ea_edt = m->edt_args;
+      if (m->edt_pending) { n_edt = 256; m->edt_pending = false; }
+      const int4* cand = m->color_cand + (size_t)m->cand_parity * m->fuse_cap;
+      const int32_t cand_idx = C_CAND_COUNT + m->cand_parity;
+      m->cand_parity ^= 1;
+      const int64_t c_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[3], __ATOMIC_RELAXED));         // candidates of the last colour frame the GPU has finished
+      const int cgrid = (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, 1024), ((c_hint + c_hint / 4 + 64 + 7) / 8) * 8));
+      const dim3 g((unsigned)(n_edt + grid + cgrid));
+      if (f_kind == 0) {
+        NVBX_LAUNCH(m, (k_integrate_tsdf_color<Img, PixRgb8>), g, dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, m->mesh_list_live(), m->view_export,
+                    (int32_t)m->view_export_cap, spec_lanes, (int32_t)grid, fsc, (const float*)m->synth, f_srows, f_scols, cand, cand_idx, n_edt, ea_edt);
+      } else {
+        FrameSetC<PixBgra8, 1> fc; memcpy(&fc, &fsc, sizeof(fc));       // (one layout, color.hip static_assert)
+        NVBX_LAUNCH(m, (k_integrate_tsdf_color<Img, PixBgra8>), g, dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, m->mesh_list_live(), m->view_export,
+                    (int32_t)m->view_export_cap, spec_lanes, (int32_t)grid, fc, (const float*)m->synth, f_srows, f_scols, cand, cand_idx, n_edt, ea_edt);
+      }
+    }
+  } else
   if (plain) NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor, NB, true>), dim3(grid), dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
                          m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (const uint8_t*)view_class);
   else NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor, NB, false>), dim3(grid), dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity,

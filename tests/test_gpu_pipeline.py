@@ -99,3 +99,50 @@ def test_deferred_calls_are_replayed_by_every_other_entry_point(oracle_mod, hip_
     assert b.num_blocks(M.LAYER_TSDF) == 0
     both(lambda m: m.integrate_depth(d, T, cam)); both(lambda m: m.integrate_color(rgb, T, cam)); both(lambda m: m.update_esdf())
     _equal_maps(M, a, b)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_fused_colour_tsdf_launch_under_irregular_calls(oracle_mod, hip_lib, seed):
+    """Two launches per frame: view marking (i+1) || sphere tracing (i) || colour candidates (i) || ESDF site marking (i), then
+    TSDF update (i+1) || colour integration (i) || distance transform (i).  Random call patterns on a plain camera mapper (no LiDAR: the fused
+    launch stays eligible) -- colour frames or ESDF updates left out, two updates back to back, bgra8 frames, decay / clearing / meshing /
+    queries at random points, a pool that grows in mid-pipeline; a classic mapper fed the same calls must hold the same map bit for bit
+    wherever anything is read."""
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    rng = np.random.default_rng(100 + seed)
+    pg = M.default_params(tsdf_decay_factor=0.8, tsdf_decayed_weight_threshold=0.05)
+    a = M.Mapper(pg, block_capacity=1024); b = M.Mapper(pg, block_capacity=1024)      # (the pool grows in mid-sequence)
+    b.set_color_deferral(True); b.set_profiling(True)
+    fr = H.frames(40, cam, stride=5)
+
+    def both(fn):
+        fn(a); fn(b)
+    for k, (d, rgb, T) in enumerate(fr):
+        both(lambda m: m.integrate_depth(d, T, cam))
+        if rng.random() < 0.85:
+            img = rgb if k % 7 else np.ascontiguousarray(np.concatenate([rgb[..., ::-1], np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=2))     # (every 7th frame: bgra8)
+            both(lambda m: m.integrate_color(img, T, cam))
+        if rng.random() < 0.8:
+            both(lambda m: m.update_esdf())
+        r = rng.random()
+        if r < 0.06:
+            both(lambda m: m.decay_tsdf(True))
+        elif r < 0.12:
+            both(lambda m: m.clear_outside_radius((float(T[0, 3]), float(T[1, 3]), 1.0), 3.5))
+        elif r < 0.18:
+            both(lambda m: m.update_color_mesh())
+        elif r < 0.24:
+            both(lambda m: m.update_esdf())                  # two updates back to back
+        elif r < 0.30:
+            sa, _ = a.esdf_slice_image(); sb, _ = b.esdf_slice_image()      # a query: flushes the pipeline
+            assert np.array_equal(sa, sb), k
+        if k % 9 == 8:
+            _equal_maps(M, a, b, "seed %d frame %d" % (seed, k))
+    both(lambda m: m.update_esdf())
+    _equal_maps(M, a, b, "seed %d end" % seed)
+    prof = b.profile()
+    names = " ".join(prof.keys())
+    assert "k_integrate_tsdf_color<Img, PixRgb8>" in names and "k_integrate_tsdf_color<Img, PixBgra8>" in names, names[:600]      # the fused launch has run, both encodings
+    assert "k_grow_commit" in names, names[:600]                                                                                  # ... and the pool has grown under it
+    assert b.counters()["capacity_overflow"] == 0 and len(a.block_indices(M.LAYER_COLOR)) > 50
