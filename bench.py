@@ -41,15 +41,20 @@ def short(name):
     return m.group(1) if m else name.strip()
 
 
-def algorithmic_bytes(kernel, c, rows, cols, sub_ray=4, sub_trace=4, n_cam=1, trace_in_mark_view=False):
-    """SURVEY.md 8(d) algorithmic bytes of ONE launch of `kernel`, from the measured per-launch counts `c`."""
+def algorithmic_bytes(kernel, c, rows, cols, sub_ray=4, sub_trace=4, n_cam=1, trace_in_mark_view=False, fused=False):
+    """SURVEY.md 8(d) algorithmic bytes of ONE launch of `kernel`, from the measured per-launch counts `c`.
+    trace_in_mark_view: colour deferral, the sphere tracing of the previous colour frame rides in the view-marking launch;
+    fused: ... and so do that frame's candidate discovery and ESDF site marking, while its colour integration and distance transform share
+    the TSDF update's launch (k_integrate_tsdf_color) -- two launches per frame, DESIGN.md 2.8."""
     B = 4096
     Nv, Nc, Na = c.get("tsdf_blocks_in_view", 0), c.get("color_blocks_updated", 0), c.get("blocks_allocated", 0)
     Nu, Ne = c.get("esdf_columns_marked", 0), c.get("esdf_blocks_swept", 0)
+    color_only = n_cam * (rows * cols * 3 + (rows // sub_trace) * (cols // sub_trace) * 4) + Nc * B * 2      # colour image + synthetic depth read + colour RMW of the band blocks
+    marking = Nu * 2 * B + Nu * 24                                                                            # TSDF z-band (k_z = 2 blocks) of the re-marked columns read + three mask words written
+    edt = Ne * (512 * 2 + 121 * (16 + 8))                                                                     # plane RMW + 11x11 neighbour hash entries and site masks per swept block
     if kernel.startswith("k_integrate_tsdf_color"):
-        # the fused launch of the pipelined order: TSDF update of this frame + colour integration and ESDF marking of the held-back frame
-        # (colour candidates arrive as 16-byte records, discovered by riders of the view-marking launch: their flag scan is counted there)
-        return (algorithmic_bytes("k_integrate_tsdf", c, rows, cols, sub_ray, sub_trace, n_cam) + algorithmic_bytes("k_integrate_color", c, rows, cols, sub_ray, sub_trace, n_cam) + Nc * 16)
+        # TSDF update of this frame + colour integration of the held-back frame (candidates arrive as 16-byte records) + the distance transform
+        return algorithmic_bytes("k_integrate_tsdf", c, rows, cols, sub_ray, sub_trace, n_cam) + color_only + Nc * 16 + edt
     if kernel.startswith("k_integrate_tsdf"):
         # (LiDAR: the blocks the beam-centric launch has taken are skipped by this one -- it reads their records, not their voxels)
         Ns = c.get("lidar_blocks_beam_centric", 0)
@@ -61,19 +66,20 @@ def algorithmic_bytes(kernel, c, rows, cols, sub_ray=4, sub_trace=4, n_cam=1, tr
         return Nv * 17 + Ns * (64 * 4 + 130 * 4 + 21 * 64)
     if kernel.startswith("k_mark_view"):
         own = n_cam * (rows // sub_ray) * (cols // sub_ray) * 4 + Nv * 16 * 2           # sub-sampled depth read + one hash entry RMW per block in view
-        # colour deferral: the sphere tracing of the previous colour frame rides in this launch (its bytes with it)
-        # (... and, before a fused colour + TSDF launch, the candidate discovery of that colour frame: flags + Index3D of every allocated slot, one record per candidate)
-        return own + ((algorithmic_bytes("k_sphere_trace", c, rows, cols, sub_ray, sub_trace, n_cam) + Na * 16 + Nc * 16) if trace_in_mark_view else 0)
+        if trace_in_mark_view or fused:
+            own += algorithmic_bytes("k_sphere_trace", c, rows, cols, sub_ray, sub_trace, n_cam)
+        if fused:
+            own += Na * 16 + Nc * 16 + marking          # flags + Index3D of every allocated slot, one record per candidate; the marking pass
+        return own
     if kernel.startswith("k_integrate_color"):
-        # colour image + synthetic depth read + colour RMW of the band blocks (the band vote is a per-block flag: no TSDF read),
-        # plus the ESDF site marking that rides in the same launch (TSDF z-band of the re-marked columns read, masks written)
-        return n_cam * (rows * cols * 3 + (rows // sub_trace) * (cols // sub_trace) * 4) + Nc * B * 2 + Nu * 2 * B + Nu * 24
+        # (the band vote is a per-block flag: no TSDF read) plus the ESDF site marking that rides in the same launch
+        return color_only + marking
     if kernel.startswith("k_sphere_trace"):
         return n_cam * (rows // sub_trace) * (cols // sub_trace) * 4 + Nc * B           # synthetic depth write + TSDF blocks read once
     if kernel.startswith("k_esdf_mark"):
-        return Nu * 2 * B + Nu * 24                                  # TSDF z-band (k_z = 2 blocks) read + three mask words written
+        return marking
     if kernel.startswith("k_esdf_edt"):
-        return Ne * (512 * 2 + 121 * (16 + 8))                       # plane RMW + 11x11 neighbour hash entries and site masks per swept block
+        return edt
     if kernel.startswith("k_mesh"):
         return int(c.get("mesh_blocks_updated", 0) * B * (1.42 + 1.0) + c.get("mesh_vertices", 0) * 28 + c.get("mesh_triangles", 0) * 12)
     if kernel.startswith("k_decay"):
@@ -580,7 +586,8 @@ def main_camera(args):
 
     tm = Timer(torch, dist, dev, world)
     # Cross-frame pipelining (nvbx_mapper_set_color_deferral): integrateColor(i) / updateEsdf(i) are held back and carried out by
-    # integrateDepth(i+1) -- view marking(i+1) || sphere tracing(i) in one launch: 3 launches per frame instead of 4.  Same calls, same map;
+    # integrateDepth(i+1) in two launches per frame instead of four (view marking(i+1) || sphere tracing(i) || colour candidates(i) || ESDF marking(i),
+    # then TSDF update(i+1) || colour integration(i) || distance transform(i)).  Same calls, same map;
     # the caller keeps the colour image valid until its next call (the bench's images are resident).  --no-color-deferral: the classic order.
     deferral = (not multicam) and world == 1 and not args.no_color_deferral
     g.set_color_deferral(deferral)
@@ -707,16 +714,20 @@ def main_camera(args):
     launches_cam = ncam if not (multicam and batch_ok and ncam in bd) else 1
     n_trace_launches = sum(v_["count"] for k_, v_ in prof.items() if short(k_).startswith("k_sphere_trace"))
     fused_trace = deferral and n_trace_launches < n2 / 2          # (the last frame of the loop is flushed in classic order by the synchronize)
+    fused_colc = sum(v_["count"] for k_, v_ in prof.items() if short(k_).startswith("k_integrate_tsdf_color")) > n2 / 2
+    launches_per_frame = 2 if fused_colc else (3 if fused_trace else 4)
     if fused_trace:
         for k_ in [k_ for k_ in prof if short(k_).startswith("k_sphere_trace")]:
             del prof[k_]
     kern, ev_overhead_us, empty_pair_us = kernel_table(
-        prof, counts, ms_revisit, n2, lambda k, cc: algorithmic_bytes(k, cc, rows, cols, n_cam=(ncam // launches_cam), trace_in_mark_view=fused_trace), load_pmc(args.workload),
+        prof, counts, ms_revisit, n2, lambda k, cc: algorithmic_bytes(k, cc, rows, cols, n_cam=(ncam // launches_cam), trace_in_mark_view=fused_trace, fused=fused_colc), load_pmc(args.workload),
         exclude_from_calibration=("k_mesh", "k_esdf_edt"))
     roofline = roofline_of(
         kern, ms_per_step, ev_overhead_us, empty_pair_us,
-        "kernel = the LONGEST non-mesh kernel of the step by time (k_integrate_color also carries the ESDF site marking, k_mark_view the held-back "
-        "EDT of the previous update -- DESIGN.md 2.4); durations = span of a hipEvent pair around each launch on the mapper stream minus "
+        "kernel = the LONGEST non-mesh kernel of the step by time (two launches per frame, DESIGN.md 2.8: k_mark_view = view marking of this frame + "
+        "sphere tracing, colour candidates and ESDF marking of the held-back frame; k_integrate_tsdf_color = TSDF update + that frame's colour "
+        "integration and distance transform; classic order, DESIGN.md 2.4: k_integrate_color also carries the ESDF site marking, k_mark_view the "
+        "held-back EDT of the previous update); durations = span of a hipEvent pair around each launch on the mapper stream minus "
         "`event_pair_overhead_us`, the instrumentation cost per launch calibrated so that the step's launches add up to the un-instrumented "
         "step time; compare rocprofv3's kernel-trace averages in profiles/*_kernel_stats.csv.  640x480 @ 0.05 m moves ~10 MB per camera frame, "
         "so every kernel is bound by its dependent-access chain and launch cost rather than by HBM bytes (DESIGN.md 2)")
@@ -761,9 +772,11 @@ def main_camera(args):
                    "revisit_ms_per_step": block_stats(dts_rev, args.steps),
                    "revisit_note": "same blocks of K steps on the fully allocated map (after one untimed loop over all poses)"},
         "ms_per_step_revisit": round(ms_revisit, 4),
-        "color_deferral": {"enabled": bool(deferral), "ms_per_step_revisit_classic_order": (round(ms_classic, 4) if ms_classic else None),
-                           "note": "enabled: integrateColor(i) / updateEsdf(i) are held back and carried out by integrateDepth(i+1) in pipelined order "
-                                   "(view marking(i+1) || sphere tracing(i) in one launch; 3 launches per frame); same calls, bit-identical map "
+        "color_deferral": {"enabled": bool(deferral), "launches_per_frame": launches_per_frame,
+                           "ms_per_step_revisit_classic_order": (round(ms_classic, 4) if ms_classic else None),
+                           "note": "enabled: integrateColor(i) / updateEsdf(i) are held back and carried out by integrateDepth(i+1) in pipelined order: "
+                                   "launch 1 = view marking(i+1) || sphere tracing(i) || colour candidates(i) || ESDF marking(i), launch 2 = TSDF update(i+1) "
+                                   "|| colour integration(i) || distance transform(i) (NVBX_FUSE_COLC=0: three launches); same calls, bit-identical map "
                                    "(tests/test_gpu_pipeline.py); contract: include/nvblox_hip.h nvbx_mapper_set_color_deferral"},
         "block_ms": [round(d / args.steps * 1e3, 4) for d in dts[:16]],
         "ms_components": {k_: round(v_, 4) for k_, v_ in comp.items()},

@@ -198,9 +198,11 @@ int nvbx_synchronize(nvbx_mapper* m);
 int nvbx_flush(nvbx_mapper* m);
 /* Colour deferral (cross-frame pipelining; off by default).  While enabled, nvbx_integrate_color / _bgra8 of a single frame is HELD BACK --
  * its arguments are remembered, nothing is launched -- and so is an nvbx_update_esdf that follows it.  The next single-frame
- * nvbx_integrate_depth / _u16mm carries them out in pipelined order: {view marking of the new depth frame || sphere tracing of the held-back
- * colour frame} in ONE launch, then colour integration (+ ESDF site marking), then the TSDF update of the new frame -- three launches per
- * depth + colour + ESDF frame instead of four (the two overlapped kernels are independent: sphere tracing reads the TSDF and the insert-only
+ * nvbx_integrate_depth / _u16mm carries them out in pipelined order, two launches per depth + colour + ESDF frame instead of four:
+ * {view marking of the new depth frame || sphere tracing, candidate-block discovery and ESDF site marking of the held-back frame}, then
+ * {TSDF update of the new frame || colour integration and distance transform of the held-back frame} (three launches where the mapper is not
+ * a plain TSDF mapper with the exact 2-D ESDF, or has integrated a LiDAR scan).  The overlapped parts are independent: sphere
+ * tracing reads the TSDF and the insert-only
  * hash, view marking inserts entries whose blocks are all-zero = unobserved).  EVERY other entry point (queries, synchronize / flush, batches,
  * LiDAR, mesh, decay, clearing, another integrate_color, ...) first carries the held-back calls out exactly as they would have run at call
  * time, so results -- map contents, ESDF, views, every query -- are bit-identical to the undeferred sequence (tests/test_gpu_pipeline.py).

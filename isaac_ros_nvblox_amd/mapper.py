@@ -87,7 +87,7 @@ class Mapper:
         self._check(self.lib.nvbx_mapper_set_max_capacity(self._h, int(max_blocks)))
 
     def set_color_deferral(self, enable):
-        """Hold integrateColor (and an updateEsdf behind it) back until the next integrateDepth carries them out in pipelined order (three
+        """Hold integrateColor (and an updateEsdf behind it) back until the next integrateDepth carries them out in pipelined order (two
         launches per frame instead of four; include/nvblox_hip.h nvbx_mapper_set_color_deferral).  The colour image handed to integrate_color must
         then stay valid and unchanged until the next call into the mapper has returned."""
         self._check(self.lib.nvbx_mapper_set_color_deferral(self._h, 1 if enable else 0))
