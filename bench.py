@@ -589,7 +589,7 @@ def main_camera(args):
     # integrateDepth(i+1) in two launches per frame instead of four (view marking(i+1) || sphere tracing(i) || colour candidates(i) || ESDF marking(i),
     # then TSDF update(i+1) || colour integration(i) || distance transform(i)).  Same calls, same map;
     # the caller keeps the colour image valid until its next call (the bench's images are resident).  --no-color-deferral: the classic order.
-    deferral = (not multicam) and world == 1 and not args.no_color_deferral
+    deferral = world == 1 and not args.no_color_deferral and ((not multicam) or (batch_ok and ncam in bd))      # (batches: the depth batch carries the held-back colour batch)
     g.set_color_deferral(deferral)
 
     # EXPLORING (the headline): the map is EMPTIED at the start of every loop over the nu unique poses and the timed blocks of K steps tile the

@@ -73,7 +73,7 @@ static int color_setup(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t rows,
   *fs = FrameSetC<Pix, NB>{}; fs->n = n;
   *ps = PoseSet<NB>{}; ps->n = n;
   for (int c = 0; c < n; c++) { fs->f[c] = m->make_frame(T_L_C + 16 * c, cameras + c, rows, cols, m->p.sphere_tracing_subsampling); fs->img[c] = imgs[c]; ps->f[c] = fs->f[c]; }
-  const Frame& f = fs->f[0];
+  const FrameCore& f = fs->f[0];
   { // slots per workgroup iteration of k_integrate_color's candidate scan: from the high-water mark the GPU last reported (a hint only)
     const int64_t hw_seen = std::max<int64_t>(1, __atomic_load_n(&m->h_mirror[1], __ATOMIC_RELAXED));
     int ch = 1; while (ch < 64 && (int64_t)ch * std::min<int64_t>(m->capacity, 1024) * 4 < hw_seen) ch *= 2;     // (up to 4 iterations of single slots: a room-sized map keeps
@@ -145,33 +145,45 @@ static int integrate_colors(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t 
   return color_launch_integrate<Pix, NB>(m, fs, srows, scols);
 }
 
-// ---- colour deferral (nvbx_mapper.h): hold a single frame back / carry it out in pipelined order
-static bool defer_color(nvbx_mapper* m, int kind, const void* img, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera, int* rc_out) {
+// ---- colour deferral (nvbx_mapper.h): hold a frame (or a batch) back / carry it out in pipelined order
+static bool defer_color(nvbx_mapper* m, int kind, int32_t n, const void* const* imgs, int32_t rows, int32_t cols, const float* T_L_C, const nvbx_camera* cameras, int* rc_out) {
   if (!m->color_deferral || m->replaying || m->p.projective_layer_type == 1) return false;
-  *rc_out = color_precheck(m, 1, rows, cols, T_L_C);            // argument errors are reported by the call that made them
+  *rc_out = color_precheck(m, n, rows, cols, T_L_C);            // argument errors are reported by the call that made them
   if (*rc_out) return true;
   if (hipSetDevice(m->device) != hipSuccess || m->replay_deferred()) { *rc_out = NVBX_E_DEVICE; return true; }     // an older held-back frame goes first
   nvbx_mapper::ColorPending& c = m->color_pending;
-  c.on = true; c.kind = kind; c.img = img; c.rows = rows; c.cols = cols; memcpy(c.T, T_L_C, sizeof(c.T)); c.cam = *camera;
+  c.on = true; c.kind = kind; c.n = n; c.rows = rows; c.cols = cols;
+  for (int i = 0; i < n; i++) { c.imgs[i] = imgs[i]; c.cams[i] = cameras[i]; }
+  memcpy(c.T, T_L_C, sizeof(float) * 16 * (size_t)n);
   *rc_out = NVBX_OK;
   return true;
 }
-// the held-back frame's set-up; its sphere tracing as a rider of the caller's launch
+// the held-back frames' set-up (NB = 1: one frame, NB = MAX_BATCH: a batch)
 static_assert(sizeof(FrameSetC<PixRgb8, 1>) == sizeof(FrameSetC<PixBgra8, 1>), "colour frame sets share one layout");
-int nvbx_mapper::pending_color_trace_rider(void* out) {
-  TraceRider* tr = static_cast<TraceRider*>(out);
-  const ColorPending& c = color_pending;
+template <typename Pix, int NB>
+static int pending_setup(nvbx_mapper* m, const nvbx_mapper::ColorPending& c, FrameSetC<Pix, NB>* fs, PoseSet<NB>* ps, int32_t* srows, int32_t* scols) {
+  Pix imgs[NB];
+  for (int i = 0; i < c.n && i < NB; i++) imgs[i] = Pix{reinterpret_cast<decltype(Pix::p)>(c.imgs[i])};
+  return color_setup<Pix, NB>(m, c.n, imgs, c.rows, c.cols, c.T, c.cams, fs, ps, srows, scols);
+}
+template <int NB>
+static int trace_rider_of(nvbx_mapper* m, TraceRiderT<NB>* tr) {
+  const nvbx_mapper::ColorPending& c = m->color_pending;
   int32_t srows = 0, scols = 0;
   int rc;
-  if (c.kind == 0) { const PixRgb8 img{(const uint8_t*)c.img}; FrameSetC<PixRgb8, 1> fs; rc = color_setup<PixRgb8, 1>(this, 1, &img, c.rows, c.cols, c.T, &c.cam, &fs, &tr->ps, &srows, &scols); }
-  else { const PixBgra8 img{(const uint32_t*)c.img}; FrameSetC<PixBgra8, 1> fs; rc = color_setup<PixBgra8, 1>(this, 1, &img, c.rows, c.cols, c.T, &c.cam, &fs, &tr->ps, &srows, &scols); }
+  if (c.kind == 0) { FrameSetC<PixRgb8, NB> fs; rc = pending_setup<PixRgb8, NB>(m, c, &fs, &tr->ps, &srows, &scols); }
+  else { FrameSetC<PixBgra8, NB> fs; rc = pending_setup<PixBgra8, NB>(m, c, &fs, &tr->ps, &srows, &scols); }
   if (rc) return rc;
-  tr->synth = synth; tr->srows = srows; tr->scols = scols; tr->max_steps = p.sphere_tracing_max_steps;
-  tr->max_len = p.sphere_tracing_max_ray_length_m; tr->eps_m = p.sphere_tracing_surface_eps_vox * p.voxel_size;
-  static const int fused_lanes = getenv("NVBX_FUSED_TRACE_LANES") ? atoi(getenv("NVBX_FUSED_TRACE_LANES")) : 8;       // (A/B: 4 or 8 lanes per ray)
-  tr->lanes = fused_lanes == 4 ? 4 : 8;
-  tr->n_wg = sphere_trace_workgroups(tr->lanes, srows, scols, 1);
+  tr->synth = m->synth; tr->srows = srows; tr->scols = scols; tr->max_steps = m->p.sphere_tracing_max_steps;
+  tr->max_len = m->p.sphere_tracing_max_ray_length_m; tr->eps_m = m->p.sphere_tracing_surface_eps_vox * m->p.voxel_size;
+  static const int fused_lanes = getenv("NVBX_FUSED_TRACE_LANES") ? atoi(getenv("NVBX_FUSED_TRACE_LANES")) : 8;       // (A/B, one frame: 4 or 8 lanes per ray)
+  tr->lanes = NB == 1 ? (fused_lanes == 4 ? 4 : 8) : std::max(2, sphere_trace_lanes(c.n));
+  tr->n_wg = sphere_trace_workgroups(tr->lanes, srows, scols, c.n);
   return NVBX_OK;
+}
+// ... its sphere tracing as a rider of the caller's launch
+int nvbx_mapper::pending_color_trace_rider(void* out) {
+  return color_pending.n == 1 ? trace_rider_of<1>(this, static_cast<TraceRiderT<1>*>(out)) : trace_rider_of<MAX_BATCH>(this, static_cast<TraceRiderT<MAX_BATCH>*>(out));
 }
 // Fused colour + TSDF launch (tsdf.hip): the held-back frame's ESDF marking pass rides in the view-marking launch of the next depth frame
 // (color_launch_integrate's own part, decided before that launch) ...
@@ -186,31 +198,28 @@ void nvbx_mapper::pending_marking_args(int32_t* mark_wg, EsdfArgs* ea_out) {
 int nvbx_mapper::pending_color_fused_args(void* fsc_out, int* kind, int32_t* srows, int32_t* scols) {
   const ColorPending c = color_pending; color_pending.on = false;
   *kind = c.kind;
-  if (c.kind == 0) {
-    const PixRgb8 img{(const uint8_t*)c.img}; PoseSet<1> ps;
-    return color_setup<PixRgb8, 1>(this, 1, &img, c.rows, c.cols, c.T, &c.cam, static_cast<FrameSetC<PixRgb8, 1>*>(fsc_out), &ps, srows, scols);
-  }
-  const PixBgra8 img{(const uint32_t*)c.img}; PoseSet<1> ps;
-  return color_setup<PixBgra8, 1>(this, 1, &img, c.rows, c.cols, c.T, &c.cam, static_cast<FrameSetC<PixBgra8, 1>*>(fsc_out), &ps, srows, scols);
+  if (c.n > 1) { PoseSet<MAX_BATCH> ps; return pending_setup<PixRgb8, MAX_BATCH>(this, c, static_cast<FrameSetC<PixRgb8, MAX_BATCH>*>(fsc_out), &ps, srows, scols); }
+  PoseSet<1> ps;
+  if (c.kind == 0) return pending_setup<PixRgb8, 1>(this, c, static_cast<FrameSetC<PixRgb8, 1>*>(fsc_out), &ps, srows, scols);
+  return pending_setup<PixBgra8, 1>(this, c, static_cast<FrameSetC<PixBgra8, 1>*>(fsc_out), &ps, srows, scols);
+}
+template <typename Pix, int NB>
+static int launch_pending_integrate(nvbx_mapper* m, const nvbx_mapper::ColorPending& c) {
+  FrameSetC<Pix, NB> fs; PoseSet<NB> ps; int32_t srows = 0, scols = 0;
+  const int rc = pending_setup<Pix, NB>(m, c, &fs, &ps, &srows, &scols); if (rc) return rc;
+  return color_launch_integrate<Pix, NB>(m, fs, srows, scols);
 }
 int nvbx_mapper::launch_pending_color_after_trace() {
   const ColorPending c = color_pending; color_pending.on = false;
-  int32_t srows = 0, scols = 0;
-  if (c.kind == 0) {
-    const PixRgb8 img{(const uint8_t*)c.img}; FrameSetC<PixRgb8, 1> fs; PoseSet<1> ps;
-    const int rc = color_setup<PixRgb8, 1>(this, 1, &img, c.rows, c.cols, c.T, &c.cam, &fs, &ps, &srows, &scols); if (rc) return rc;
-    return color_launch_integrate<PixRgb8, 1>(this, fs, srows, scols);
-  }
-  const PixBgra8 img{(const uint32_t*)c.img}; FrameSetC<PixBgra8, 1> fs; PoseSet<1> ps;
-  const int rc = color_setup<PixBgra8, 1>(this, 1, &img, c.rows, c.cols, c.T, &c.cam, &fs, &ps, &srows, &scols); if (rc) return rc;
-  return color_launch_integrate<PixBgra8, 1>(this, fs, srows, scols);
+  if (c.n > 1) return launch_pending_integrate<PixRgb8, MAX_BATCH>(this, c);
+  return c.kind == 0 ? launch_pending_integrate<PixRgb8, 1>(this, c) : launch_pending_integrate<PixBgra8, 1>(this, c);
 }
 
 extern "C" int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16],
                                     const nvbx_camera* camera) {
   if (!m || !rgb_dev || !T_L_C || !camera || !image_dims_ok(rows, cols)) { set_error("nvbx_integrate_color: invalid argument (image sides 1 .. 32768)"); return NVBX_E_INVALID; }
   if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_color: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
-  { int rc = NVBX_OK; if (defer_color(m, 0, rgb_dev, rows, cols, T_L_C, camera, &rc)) return rc; }
+  { int rc = NVBX_OK; const void* im = rgb_dev; if (defer_color(m, 0, 1, &im, rows, cols, T_L_C, camera, &rc)) return rc; }
   const PixRgb8 img{rgb_dev};
   return integrate_colors<PixRgb8, 1>(m, 1, &img, rows, cols, T_L_C, camera);
 }
@@ -218,7 +227,7 @@ extern "C" int nvbx_integrate_color_bgra8(nvbx_mapper* m, const uint8_t* bgra_de
                                           const nvbx_camera* camera) {
   if (!m || !bgra_dev || !T_L_C || !camera || !image_dims_ok(rows, cols) || ((uintptr_t)bgra_dev & 3)) { set_error("nvbx_integrate_color_bgra8: invalid argument"); return NVBX_E_INVALID; }
   if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_color_bgra8: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
-  { int rc = NVBX_OK; if (defer_color(m, 1, bgra_dev, rows, cols, T_L_C, camera, &rc)) return rc; }
+  { int rc = NVBX_OK; const void* im = bgra_dev; if (defer_color(m, 1, 1, &im, rows, cols, T_L_C, camera, &rc)) return rc; }
   const PixBgra8 img{reinterpret_cast<const uint32_t*>(bgra_dev)};
   return integrate_colors<PixBgra8, 1>(m, 1, &img, rows, cols, T_L_C, camera);
 }
@@ -229,6 +238,7 @@ extern "C" int nvbx_integrate_color_batch(nvbx_mapper* m, int32_t n, const uint8
   for (int c = 0; c < n; c++)
     if (!rgb_dev[c] || !nvbx_camera_matches(cameras + c, rows, cols)) { set_error("nvbx_integrate_color_batch: every camera's width/height must equal the images' cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
   if (n == 1) return nvbx_integrate_color(m, rgb_dev[0], rows, cols, T_L_C, cameras);
+  { int rc = NVBX_OK; if (defer_color(m, 0, n, reinterpret_cast<const void* const*>(rgb_dev), rows, cols, T_L_C, cameras, &rc)) return rc; }     // (held back: a depth batch carries it out)
   PixRgb8 imgs[MAX_BATCH];
   for (int c = 0; c < n; c++) imgs[c] = PixRgb8{rgb_dev[c]};
   return integrate_colors<PixRgb8, MAX_BATCH>(m, n, imgs, rows, cols, T_L_C, cameras);

@@ -908,8 +908,9 @@ int nvbx_mapper::replay_deferred() {
   int rc = NVBX_OK;
   if (color_pending.on) {
     const ColorPending c = color_pending; color_pending.on = false;
-    rc = c.kind == 0 ? nvbx_integrate_color(this, (const uint8_t*)c.img, c.rows, c.cols, c.T, &c.cam)
-                     : nvbx_integrate_color_bgra8(this, (const uint8_t*)c.img, c.rows, c.cols, c.T, &c.cam);
+    if (c.n > 1) rc = nvbx_integrate_color_batch(this, c.n, reinterpret_cast<const uint8_t* const*>(c.imgs), c.rows, c.cols, c.T, c.cams);
+    else rc = c.kind == 0 ? nvbx_integrate_color(this, (const uint8_t*)c.imgs[0], c.rows, c.cols, c.T, &c.cams[0])
+                          : nvbx_integrate_color_bgra8(this, (const uint8_t*)c.imgs[0], c.rows, c.cols, c.T, &c.cams[0]);
   }
   if (rc == NVBX_OK && esdf_update_pending) { esdf_update_pending = false; rc = nvbx_update_esdf(this); }
   esdf_update_pending = false;

@@ -2,10 +2,11 @@
 // shared by k_integrate_color (color.hip) and by the fused colour + TSDF launch of the pipelined order (tsdf.hip).
 #pragma once
 #include "nvbx_mapper.h"
+#include "nvbx_sphere_trace.h"
 
 namespace nvbx {
 
-template <typename Pix, int NB> struct FrameSetC { Frame f[NB]; Pix img[NB]; int32_t n; int32_t chunk; };
+template <typename Pix, int NB> struct FrameSetC { FrameCore f[NB]; Pix img[NB]; int32_t n; int32_t chunk; };
 
 // colour source: rgb8 (nvblox::Color, 3 bytes) or bgra8 (4 bytes, channel reorder of ToRgba<Bgra> fused into the fetch)
 struct PixRgb8 {
@@ -34,7 +35,7 @@ __device__ inline void color_integrate_block(const DMap& m, const FrameSetC<Pix,
                                              const int32_t slot, const int32_t bx, const int32_t by, const int32_t bz, const uint32_t in_view) {
   const int tid = threadIdx.x;
   const int vx = tid >> 6, vy = (tid >> 3) & 7, vz = tid & 7;
-  const Frame& f0 = fs.f[0];
+  const FrameCore& f0 = fs.f[0];
   const int ncam = NB > 1 ? fs.n : 1;
   if (tid == 0) {
     const uint32_t old = atomicOr(&m.slot_flags[slot], F_COLOR | F_DIRTY_MESH);
@@ -50,7 +51,7 @@ __device__ inline void color_integrate_block(const DMap& m, const FrameSetC<Pix,
 #pragma unroll 1
   for (int c = 0; c < ncam; c++) {
     if (!((in_view >> c) & 1u)) continue;              // uniform
-    const Frame& f = fs.f[c];
+    const FrameCore& f = fs.f[c];
     const float* synth = synth_all + (size_t)c * srows * scols;
     float pc[3];
     apply_rt(f.R_CL, f.t_CL, lx, ly, lz, pc);
@@ -110,7 +111,7 @@ __device__ inline void color_integrate_worker(const DMap& m, const FrameSetC<Pix
                                               int32_t wg, int32_t n_color_wg) {
   __shared__ int s_out[NB][6];
   const int tid = threadIdx.x;
-  const Frame& f0 = fs.f[0];
+  const FrameCore& f0 = fs.f[0];
   const int ncam = NB > 1 ? fs.n : 1;
   // Candidate discovery.  Every allocated slot has to be looked at (O(map) flags, not O(view)): with one slot per workgroup iteration a
   // 10^5-block map costs ~150 dependent flag loads per workgroup.  So a workgroup takes `chunk` CONSECUTIVE slots per iteration (a
@@ -157,7 +158,7 @@ __device__ inline void color_integrate_worker(const DMap& m, const FrameSetC<Pix
     __syncthreads();
     if (tid < 8 * ncam) {   // frustum: count corners outside each plane, 8 lanes per camera
       const int c = NB == 1 ? 0 : (tid >> 3), q = tid & 7;      // (one camera: a constant index -- a per-lane index into the argument block is a vector load from memory)
-      const Frame& f = fs.f[c];
+      const FrameCore& f = fs.f[c];
       float pc[3];
       apply_rt(f.R_CL, f.t_CL, (float)(bx + (q & 1)) * f.block_size, (float)(by + ((q >> 1) & 1)) * f.block_size,
                (float)(bz + ((q >> 2) & 1)) * f.block_size, pc);
@@ -185,12 +186,15 @@ __device__ inline void color_integrate_worker(const DMap& m, const FrameSetC<Pix
 // ---- pipelined order with a fused colour + TSDF launch: the candidate discovery of colour frame i runs as a rider of the
 // PREVIOUS launch (view marking of depth frame i + 1 -- nothing writes block flags or TSDF voxels there), so that the colour integration
 // itself reads no flag the TSDF update of frame i + 1, running beside it, is changing (F_BAND).
-// Candidate records {slot, block index}: exactly the blocks color_integrate_worker would visit for ONE camera -- TSDF layer, truncation-band
-// flag, inside the frustum (the same expressions).  One wavefront per 64 consecutive slots (lane = slot), wave-aggregated append.
+// Candidate records {slot | camera mask << 24, block index}: exactly the blocks color_integrate_worker would visit -- TSDF layer, truncation-band
+// flag, inside the frustum of at least one camera (the same expressions; the mask names which).  One wavefront per 64 consecutive slots
+// (lane = slot), wave-aggregated append.  Slot ids stay below 2^24 (mapper.hip: max_capacity).
 // Requires: no block flagged F_BAND_STALE (the host does not take this path once a LiDAR scan has been integrated into the mapper).
-__device__ inline void color_scan_worker(const DMap& m, const Frame& f, int4* cand, int32_t cnt_idx, int32_t reset_idx, int w, int n_waves) {
+template <int NB>
+__device__ inline void color_scan_worker(const DMap& m, const PoseSet<NB>& ps, int4* cand, int32_t cnt_idx, int32_t reset_idx, int w, int n_waves) {
   const int lane = threadIdx.x & 63;
   const int32_t cap = (int32_t)m.capacity;
+  const int ncam = NB > 1 ? ps.n : 1;
   if (w == 0 && lane == 0) m.counters[reset_idx] = 0;       // the other parity's count: consumed one launch ago, appended to by the next scan
   int32_t base = w * 64;
   int32_t s = min(base + lane, cap - 1);
@@ -202,37 +206,44 @@ __device__ inline void color_scan_worker(const DMap& m, const Frame& f, int4* ca
       s = min(base + lane, cap - 1);
       flags = m.slot_flags[s]; bx = m.slot_index[3 * s]; by = m.slot_index[3 * s + 1]; bz = m.slot_index[3 * s + 2];
     }
-    bool keep = base + lane < hw && (flags & F_TSDF) && (flags & F_BAND);
-    if (keep) {          // frustum: corners outside each plane (color_integrate_worker's test, one lane per block)
-      int out[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t in_view = 0u;
+    if (base + lane < hw && (flags & F_TSDF) && (flags & F_BAND)) {
+#pragma unroll 1
+      for (int c = 0; c < ncam; c++) {          // frustum: corners outside each plane (color_integrate_worker's test, one lane per block)
+        const FrameCore& f = ps.f[NB == 1 ? 0 : c];
+        int out[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int q = 0; q < 8; q++) {
-        float pc[3];
-        apply_rt(f.R_CL, f.t_CL, (float)(bx + (q & 1)) * f.block_size, (float)(by + ((q >> 1) & 1)) * f.block_size, (float)(bz + ((q >> 2) & 1)) * f.block_size, pc);
-        if (f.fu * pc[0] + f.cu * pc[2] < 0.0f) out[0]++;
-        if (f.fu * pc[0] + (f.cu - (float)f.w) * pc[2] > 0.0f) out[1]++;
-        if (f.fv * pc[1] + f.cv * pc[2] < 0.0f) out[2]++;
-        if (f.fv * pc[1] + (f.cv - (float)f.h) * pc[2] > 0.0f) out[3]++;
-        if (pc[2] < 0.0f) out[4]++;
-        if (f.max_dist > 0.0f && pc[2] > f.max_dist) out[5]++;
+        for (int q = 0; q < 8; q++) {
+          float pc[3];
+          apply_rt(f.R_CL, f.t_CL, (float)(bx + (q & 1)) * f.block_size, (float)(by + ((q >> 1) & 1)) * f.block_size, (float)(bz + ((q >> 2) & 1)) * f.block_size, pc);
+          if (f.fu * pc[0] + f.cu * pc[2] < 0.0f) out[0]++;
+          if (f.fu * pc[0] + (f.cu - (float)f.w) * pc[2] > 0.0f) out[1]++;
+          if (f.fv * pc[1] + f.cv * pc[2] < 0.0f) out[2]++;
+          if (f.fv * pc[1] + (f.cv - (float)f.h) * pc[2] > 0.0f) out[3]++;
+          if (pc[2] < 0.0f) out[4]++;
+          if (f.max_dist > 0.0f && pc[2] > f.max_dist) out[5]++;
+        }
+        bool iv = true;
+#pragma unroll
+        for (int q = 0; q < 6; q++) if (out[q] == 8) iv = false;
+        if (iv) in_view |= 1u << c;
       }
-#pragma unroll
-      for (int q = 0; q < 6; q++) if (out[q] == 8) keep = false;
     }
+    const bool keep = in_view != 0u;
     const u64 km = __ballot(keep);
     if (km) {
       int32_t pos0 = 0;
       if (lane == 0) pos0 = atomicAdd(&m.counters[cnt_idx], (int32_t)__popcll(km));
       pos0 = __shfl(pos0, 0);
       const int32_t pos = pos0 + (int32_t)__popcll(km & ((1ull << lane) - 1ull));
-      if (keep && pos < cap) cand[pos] = make_int4(s, bx, by, bz);
+      if (keep && pos < cap) cand[pos] = make_int4((int32_t)((uint32_t)s | (in_view << 24)), bx, by, bz);
     }
   }
 }
 
-// worker `wg` of `n_wg` 512-thread workgroups over the candidate records (one camera)
-template <typename Pix>
-__device__ inline void color_integrate_list_worker(const DMap& m, const FrameSetC<Pix, 1>& fs, const float* synth, int32_t srows, int32_t scols, int32_t mesh_list,
+// worker `wg` of `n_wg` 512-thread workgroups over the candidate records
+template <typename Pix, int NB>
+__device__ inline void color_integrate_list_worker(const DMap& m, const FrameSetC<Pix, NB>& fs, const float* synth, int32_t srows, int32_t scols, int32_t mesh_list,
                                                    const int4* cand, int32_t cnt_idx, int32_t wg, int32_t n_wg) {
   const int32_t cap = (int32_t)m.capacity;
   int4 rec = cand[min(wg, cap - 1)];                        // (speculative, beside the count)
@@ -241,7 +252,7 @@ __device__ inline void color_integrate_list_worker(const DMap& m, const FrameSet
   if (wg == 0 && threadIdx.x == 0) __hip_atomic_store(&m.host_mirror[3], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // the next fused launch's grid hint
   for (int32_t i = wg; i < n; i += n_wg) {
     if (i != wg) rec = cand[i];
-    color_integrate_block<Pix, 1>(m, fs, synth, srows, scols, mesh_list, rec.x, rec.y, rec.z, rec.w, 1u);
+    color_integrate_block<Pix, NB>(m, fs, synth, srows, scols, mesh_list, (int32_t)((uint32_t)rec.x & 0xFFFFFFu), rec.y, rec.z, rec.w, (uint32_t)rec.x >> 24);
   }
 }
 

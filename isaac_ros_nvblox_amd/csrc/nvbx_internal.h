@@ -142,20 +142,26 @@ struct DMap {
 };
 
 // Per-call camera / pose / parameter bundle (kernel argument, lives in SGPRs).
-struct Frame {
+// The part of a frame the colour path needs (sphere tracing, candidate discovery, colour integration): pose, intrinsics, image size and a few
+// scalars -- 156 bytes.  Kept apart because a BATCH passes eight of these per argument block, and a launch that carries the frames of a depth
+// batch AND of a colour batch (pipelined order) has to fit the 4 KiB kernel-argument limit.
+struct FrameCore {
   float R_CL[9], t_CL[3];   // p_C = R_CL p_L + t_CL
   float R_LC[9], t_LC[3];   // p_L = R_LC p_C + t_LC
   float fu, fv, cu, cv; int32_t w, h;
   int32_t rows, cols;
   float voxel_size, block_size, trunc, max_dist, max_weight;
+  float occlusion_thresh;   // [U] colour occlusion threshold (m)
+  int32_t subsample;        // raycast / sphere-tracing subsampling
+};
+struct Frame : FrameCore {
   int32_t weighting_mode, interp_nearest;
-  // [U] open-choice switches (include/nvblox_hip.h): weighting formula set, sdf == -trunc edge, clamp order, colour occlusion threshold (m)
-  int32_t weighting_variant, skip_at_neg_trunc, clamp_before_blend; float occlusion_thresh;
+  // [U] open-choice switches (include/nvblox_hip.h): weighting formula set, sdf == -trunc edge, clamp order
+  int32_t weighting_variant, skip_at_neg_trunc, clamp_before_blend;
   float invalid_decay;      // invalid_depth_decay_factor (< 0 = off)
   // occupancy mappers (projective_layer_type 1): the projective pool holds {log_odds, 0}; log-odds updates of the three regions
   int32_t occupancy; float lo_free, lo_occupied, lo_unobserved, occ_half_width;
   int32_t ws_type; float ws_min[3], ws_max[3];   // workspace bounds of the view calculator (0 = unbounded)
-  int32_t subsample;        // raycast / sphere-tracing subsampling
   int32_t n_ray_rows, n_ray_cols;
   uint32_t frame_id;        // 24-bit view frame id (Entry::stamp)
   uint32_t cam_bit;         // 1 << index of this camera in its batch (1 for a single frame)
@@ -334,7 +340,7 @@ __device__ inline void sensor_voxel_offset(const Frame& f, int vx, int vy, int v
 __device__ inline float voxel_center(int32_t bi, int32_t vi, float bs, float vs) {
   return ((float)bi * bs + (float)vi * vs) + vs * 0.5f;   // layer_publishing.cpp:527
 }
-__device__ inline bool cam_project(const Frame& f, const float* p, float* u, float* v) {
+__device__ inline bool cam_project(const FrameCore& f, const float* p, float* u, float* v) {
   if (p[2] <= 0.0f) return false;
   *u = f.fu * NVBX_DIV(p[0], p[2]) + f.cu;          // (NVBX_DIV: the IEEE quotient, nvbx_arith.h)
   *v = f.fv * NVBX_DIV(p[1], p[2]) + f.cv;

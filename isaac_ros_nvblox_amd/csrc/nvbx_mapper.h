@@ -136,14 +136,15 @@ struct nvbx_mapper {
   // marking, TSDF update of the new frame -- three launches per frame instead of four.  Every other entry point first replays the held-back
   // calls as they are (join_side -> replay_deferred), so the API observes call order.  Contract: the colour image must stay valid and
   // unchanged until the next call into the mapper has returned.
-  struct ColorPending { bool on = false; int kind = 0; const void* img = nullptr; int32_t rows = 0, cols = 0; float T[16]; nvbx_camera cam; };
+  // (n = 1: integrateColor, kind 0 = rgb8 / 1 = bgra8; n > 1: nvbx_integrate_color_batch, rgb8 -- carried out by a depth BATCH in pipelined order)
+  struct ColorPending { bool on = false; int kind = 0; int32_t n = 1; const void* imgs[nvbx::MAX_BATCH] = {}; int32_t rows = 0, cols = 0; float T[16 * nvbx::MAX_BATCH]; nvbx_camera cams[nvbx::MAX_BATCH]; };
   bool color_deferral = false;       // the switch
   ColorPending color_pending;        // the held-back integrateColor
   bool esdf_update_pending = false;  // an updateEsdf called while a colour frame was held back
   bool replaying = false;            // inside replay_deferred: the calls run as usual
   bool pipelined_order = false;      // inside the pipelined integrateDepth: marking passes empty their list, EDTs keep it (EsdfArgs)
   int replay_deferred();
-  int pending_color_trace_rider(void* trace_rider_out);   // color.hip: set the held-back frame up; its sphere tracing as a nvbx::TraceRider
+  int pending_color_trace_rider(void* trace_rider_out);   // color.hip: set the held-back frame(s) up; the sphere tracing as a nvbx::TraceRiderT<1> (one frame) / <MAX_BATCH> (a batch)
   int launch_pending_color_after_trace();
 // -- fused colour + TSDF launch of the pipelined order (two launches per frame)
   int4* color_cand = nullptr;        // [2][fuse_cap] candidate records {slot, block index} of the held-back colour frame (parity cand_parity)
@@ -152,7 +153,7 @@ struct nvbx_mapper {
   bool lidar_integrated = false;     // a LiDAR scan has been integrated since the last clear: blocks may be F_BAND_STALE -> no fused launches
   int ensure_fuse_buffers();         // tsdf.hip
   // color.hip: the marking pass that rides in the view-marking launch (0 workgroups: none), and the held-back colour frame's set-up for the
-  // fused launch (rgb8 / bgra8 share one layout)
+  // fused launch (FrameSetC<Pix, 1>: rgb8 / bgra8 share one layout; FrameSetC<PixRgb8, MAX_BATCH> for a held-back batch)
   void pending_marking_args(int32_t* mark_wg, nvbx::EsdfArgs* ea_out);
   int pending_color_fused_args(void* fsc_out, int* kind, int32_t* srows, int32_t* scols);
   uint8_t* view_class = nullptr; int64_t view_class_cap = 0;        // LiDAR: per view record, 1 = updated by the beam-centric launch (tsdf.hip k_lidar_sparse)

@@ -23,7 +23,7 @@ namespace nvbx {
 // sample's step equals the prediction.  The first sample that breaks it supplies the next t and the next prediction.
 // The sequence of t values -- and so the result -- is bit-identical to the one-sample-at-a-time march.
 // The colour frames of one launch set: one frame, or a batch of up to MAX_BATCH (nvbx_integrate_color_batch); kernel arguments.
-template <int NB> struct PoseSet { Frame f[NB]; int32_t n; };
+template <int NB> struct PoseSet { FrameCore f[NB]; int32_t n; };
 
 // worker `wgi` (a 256-thread workgroup) of NSH * ceil(patches / NSH) * n workers; every thread of the workgroup calls
 template <int NB, int RAY_LANES>
@@ -43,7 +43,7 @@ __device__ inline void sphere_trace_worker(const DMap& m, const PoseSet<NB>& pos
   const int n_patch = patches_x * patches_y, per_xcd = (n_patch + NSH - 1) / NSH;
   const int cam = NB > 1 ? wgi / (NSH * per_xcd) : 0;          // batch: NSH * per_xcd workgroups per camera, camera after camera
   const int wg = wgi - cam * (NSH * per_xcd);
-  const Frame& f = poses.f[cam];
+  const FrameCore& f = poses.f[cam];
   float* synth = synth_all + (size_t)cam * srows * scols;
   const int patch = (wg & (NSH - 1)) * per_xcd + (wg >> 3);
   const int pr = tid / RAY_LANES;                            // ray within the patch
@@ -117,8 +117,10 @@ __device__ inline void sphere_trace_worker(const DMap& m, const PoseSet<NB>& pos
 // n_tile_wg > 0: the launch's first n_tile_wg workgroups are the view-marking tiles and the riders (EDT, then sphere tracing) follow; 0: riders first.
 // n_scan_wg > 0: behind the sphere-tracing workers, n_scan_wg workgroups discover the colour frame's candidate blocks (color_scan_worker,
 // nvbx_color_worker.h) into cand[], count in counters[cand_cnt_idx]; they also zero counters[cand_reset_idx] (the other parity's count).
-struct TraceRider { PoseSet<1> ps; float* synth; int32_t srows, scols, max_steps; float max_len, eps_m; int32_t n_wg; int32_t n_tile_wg; int32_t lanes;
-                    int32_t n_scan_wg; int4* cand; int32_t cand_cnt_idx, cand_reset_idx;
-                    int32_t n_mark_wg; };      // n_mark_wg > 0: behind those, the ESDF site marking of the held-back update (k_mark_view's EsdfArgs)
+template <int NB>
+struct TraceRiderT { PoseSet<NB> ps; float* synth; int32_t srows, scols, max_steps; float max_len, eps_m; int32_t n_wg; int32_t n_tile_wg; int32_t lanes;
+                     int32_t n_scan_wg; int4* cand; int32_t cand_cnt_idx, cand_reset_idx;
+                     int32_t n_mark_wg; };     // n_mark_wg > 0: behind those, the ESDF site marking of the held-back update (k_mark_view's EsdfArgs)
+using TraceRider = TraceRiderT<1>;
 
 }  // namespace nvbx

@@ -338,7 +338,7 @@ template <typename Img, int NB> struct FrameSet { Frame f[NB]; Img img[NB]; int3
 
 template <typename Img, typename Sensor, int NB>
 __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet<Img, NB> fs, Sensor sensor, int4* view_list, int32_t list_cap,
-                                                                int32_t reset_esdf_dirty, int32_t n_edt_wg, EsdfArgs ea, TraceRider tr) {
+                                                                int32_t reset_esdf_dirty, int32_t n_edt_wg, EsdfArgs ea, TraceRiderT<NB> tr) {
   constexpr int LSET = Sensor::kSetSize, FR = Sensor::kFlushRounds;
   constexpr size_t kMarkBytes = 2 * LSET * sizeof(u64);
   constexpr size_t kSmem = (Sensor::kThreads == 256 && sizeof(EdtShared) > kMarkBytes) ? sizeof(EdtShared) : kMarkBytes;
@@ -353,12 +353,14 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
       if (rider < n_edt_wg) esdf_edt_worker(m, ea, (int)rider, n_edt_wg, reinterpret_cast<EdtShared*>(smem));
       // (sphere tracing: all four wavefronts; independent of the view marking -- it reads the TSDF and the insert-only hash, and new entries point at all-zero blocks)
       else if (rider < n_edt_wg + tr.n_wg) {
-        if (tr.lanes == 4) sphere_trace_worker<1, 4>(m, tr.ps, tr.synth, tr.srows, tr.scols, tr.max_steps, tr.max_len, tr.eps_m, (int)(rider - n_edt_wg));
-        else sphere_trace_worker<1, 8>(m, tr.ps, tr.synth, tr.srows, tr.scols, tr.max_steps, tr.max_len, tr.eps_m, (int)(rider - n_edt_wg));
+        const int tw = (int)(rider - n_edt_wg);
+        if (NB > 1 && tr.lanes == 2) sphere_trace_worker<NB, 2>(m, tr.ps, tr.synth, tr.srows, tr.scols, tr.max_steps, tr.max_len, tr.eps_m, tw);
+        else if (tr.lanes == 4) sphere_trace_worker<NB, 4>(m, tr.ps, tr.synth, tr.srows, tr.scols, tr.max_steps, tr.max_len, tr.eps_m, tw);
+        else sphere_trace_worker<NB, 8>(m, tr.ps, tr.synth, tr.srows, tr.scols, tr.max_steps, tr.max_len, tr.eps_m, tw);
       }
-      // (candidate discovery of the held-back colour frame, for the fused colour + TSDF launch that follows: four wavefronts of 64 slots each)
+      // (candidate discovery of the held-back colour frame(s), for the fused colour + TSDF launch that follows: four wavefronts of 64 slots each)
       else if (rider < n_edt_wg + tr.n_wg + tr.n_scan_wg)
-        color_scan_worker(m, tr.ps.f[0], tr.cand, tr.cand_cnt_idx, tr.cand_reset_idx, (int)(rider - n_edt_wg - tr.n_wg) * 4 + (int)(threadIdx.x >> 6), tr.n_scan_wg * 4);
+        color_scan_worker<NB>(m, tr.ps, tr.cand, tr.cand_cnt_idx, tr.cand_reset_idx, (int)(rider - n_edt_wg - tr.n_wg) * 4 + (int)(threadIdx.x >> 6), tr.n_scan_wg * 4);
       // (ESDF site marking of the held-back update, first wavefront only: it reads the TSDF as the last update left it -- nothing in this launch
       //  writes voxels -- and allocates ESDF blocks beside the view marking's TSDF blocks; `ea` is its argument then: no EDT rides, n_edt_wg = 0)
       else if (threadIdx.x < 64) { const int w = (int)(rider - n_edt_wg - tr.n_wg - tr.n_scan_wg); esdf_mark_worker(m, ea, w, tr.n_mark_wg); esdf_mark_pass_done(m, ea, tr.n_mark_wg, w); }
@@ -610,20 +612,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // has finished (previous launch) and writes ESDF voxels only; the update appends to an ESDF-dirty list that pass has emptied.  Every part
 // reads exactly the state separate calls would have shown it.
 // Workgroups: [distance transform (512 threads = 8 wavefronts per ESDF block)][TSDF update][colour].
-template <typename Img, typename Pix>
-__global__ __launch_bounds__(512) void k_integrate_tsdf_color(DMap m, FrameSet<Img, 1> fs, CameraSensor sensor, const int4* view_list, int32_t list_cap,
+template <typename Img, typename Pix, int NB>
+__global__ __launch_bounds__(512) void k_integrate_tsdf_color(DMap m, FrameSet<Img, NB> fs, CameraSensor sensor, const int4* view_list, int32_t list_cap,
                                                               int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, int32_t n_tsdf_wg,
-                                                              FrameSetC<Pix, 1> fsc, const float* synth, int32_t srows, int32_t scols, const int4* cand, int32_t cand_cnt_idx,
+                                                              FrameSetC<Pix, NB> fsc, const float* synth, int32_t srows, int32_t scols, const int4* cand, int32_t cand_cnt_idx,
                                                               int32_t n_edt_wg, EsdfArgs ea) {
   __shared__ __align__(16) unsigned char smem[sizeof(EdtShared)];
   const int32_t b = (int32_t)blockIdx.x;
   if (b < n_edt_wg) { esdf_edt_worker<512>(m, ea, (int)b, n_edt_wg, reinterpret_cast<EdtShared*>(smem)); return; }
   if (b < n_edt_wg + n_tsdf_wg) {
-    integrate_tsdf_worker<Img, CameraSensor, 1, true>(m, fs, sensor, view_list, list_cap, mesh_list, view_export, view_export_cap, spec_lanes, nullptr, b - n_edt_wg, n_tsdf_wg);
+    integrate_tsdf_worker<Img, CameraSensor, NB, true>(m, fs, sensor, view_list, list_cap, mesh_list, view_export, view_export_cap, spec_lanes, nullptr, b - n_edt_wg, n_tsdf_wg);
     return;
   }
-  color_integrate_list_worker<Pix>(m, fsc, synth, srows, scols, mesh_list, cand, cand_cnt_idx, b - n_edt_wg - n_tsdf_wg, (int32_t)gridDim.x - n_edt_wg - n_tsdf_wg);
+  color_integrate_list_worker<Pix, NB>(m, fsc, synth, srows, scols, mesh_list, cand, cand_cnt_idx, b - n_edt_wg - n_tsdf_wg, (int32_t)gridDim.x - n_edt_wg - n_tsdf_wg);
 }
+// (a depth batch AND a colour batch in one argument block: the 4 KiB kernel-argument limit is why the colour path's frames are FrameCore)
+static_assert(sizeof(DMap) + sizeof(FrameSet<DepthF32, MAX_BATCH>) + sizeof(FrameSetC<PixRgb8, MAX_BATCH>) + sizeof(EsdfArgs) + 160 <= 4096, "k_integrate_tsdf_color<.., MAX_BATCH>: kernel arguments");
+static_assert(sizeof(DMap) + sizeof(FrameSet<DepthF32, MAX_BATCH>) + sizeof(TraceRiderT<MAX_BATCH>) + sizeof(EsdfArgs) + 64 <= 4096, "k_mark_view<.., MAX_BATCH>: kernel arguments");
 
 int nvbx_mapper::ensure_fuse_buffers() {
   if (fuse_cap == capacity && color_cand) return NVBX_OK;
@@ -891,20 +896,24 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   // Or TWO (fused, k_integrate_tsdf_color above): the colour frame's candidate blocks are discovered and the ESDF marking pass runs as
   // riders of this view-marking launch too, and colour integration, the update's distance transform and this frame's TSDF update share
   // the second launch.
-  TraceRider tr{};
+  TraceRiderT<NB> tr{};
   bool plain = true;
   for (int c = 0; c < fs.n; c++) plain = plain && frame_is_plain(fs.f[c]);
-  const bool pipelined = Sensor::kThreads == 256 && NB == 1 && m->color_pending.on;
+  const bool pipelined = Sensor::kThreads == 256 && m->color_pending.on && ((NB == 1) == (m->color_pending.n == 1));     // (one frame carries a frame, a batch a batch)
   bool fused = false;
   if (pipelined) {
     static const int fuse_on = getenv("NVBX_FUSE_COLC") ? atoi(getenv("NVBX_FUSE_COLC")) : 1;      // (A/B: 0 = three launches per frame)
     // plain TSDF mapper, 2-D ESDF by the exact transform (the marking pass / distance transform that ride are the 2-D ones), no multi-GPU
     // union step waiting for the colour launch, and no block that may be F_BAND_STALE (the candidate riders read the band flags only)
-    fused = fuse_on && plain && m->p.projective_layer_type == 0 && m->p.esdf_mode == 0 && m->p.esdf_propagation == 0 && !m->import_pending && !m->lidar_integrated;
+    fused = fuse_on && plain && m->p.projective_layer_type == 0 && m->p.esdf_mode == 0 && m->p.esdf_propagation == 0 && !m->import_pending && !m->lidar_integrated && m->capacity <= (1ll << 24);
     // (a distance transform armed outside the pipeline must precede the marking pass that rides in this launch: its own launch, rare)
     if (fused && edt_wg) { m->edt_pending = true; edt_wg = 0; if (m->flush_edt()) return NVBX_E_DEVICE; }
     m->pipelined_order = true; const int rc = m->pending_color_trace_rider(&tr); if (rc) { m->pipelined_order = false; return rc; }
-    static const int tiles_first = getenv("NVBX_MARK_TILES_FIRST") ? atoi(getenv("NVBX_MARK_TILES_FIRST")) : 1;       // (A/B: riders first = 0)
+    // riders before or after the tiles (A/B: NVBX_MARK_TILES_FIRST = 0 / 1).  One frame: tiles first (15.2 vs 15.8 us).  A batch of 8: riders first
+    // (32.4 vs 42.0 us) -- its 2 688 single-wavefront tile workgroups, each holding its LDS key set, take most of the workgroup slots, and
+    // sphere-tracing workgroups dispatched behind them start when the tiles are done: the launch took the SUM of its parts.
+    static const int tiles_first_env = getenv("NVBX_MARK_TILES_FIRST") ? atoi(getenv("NVBX_MARK_TILES_FIRST")) : -1;
+    const bool tiles_first = tiles_first_env >= 0 ? tiles_first_env != 0 : NB == 1;
     if (tiles_first) tr.n_tile_wg = tiles;
     if (fused) {
       if (m->ensure_fuse_buffers()) { m->pipelined_order = false; return NVBX_E_DEVICE; }
@@ -917,7 +926,7 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   }
   NVBX_LAUNCH(m, (k_mark_view<Img, Sensor, NB>), dim3(tiles + edt_wg + tr.n_wg + tr.n_scan_wg + tr.n_mark_wg), dim3(Sensor::kThreads), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
               (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)edt_wg, ea, tr);
-  FrameSetC<PixRgb8, 1> fsc{}; int f_kind = 0; int32_t f_srows = 0, f_scols = 0;
+  FrameSetC<PixRgb8, NB> fsc{}; int f_kind = 0; int32_t f_srows = 0, f_scols = 0;
   if (pipelined) {
     // the host-side steps of the held-back calls, in call order: integrateColor (its marking pass empties the dirty list itself, the EDT
     // of the update keeps it -- EsdfArgs), then updateEsdf (which only arms the next held-back EDT: the marking pass has been launched)
@@ -942,7 +951,7 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   { const int rc = launch_lidar_sparse(m, fs, sensor, plain, &view_class); if (rc) return rc; }
   if (Sensor::kLongRays && m->p.projective_layer_type != 1) m->lidar_integrated = true;      // (blocks may be F_BAND_STALE from here on)
   if (fused) {
-    if constexpr (NB == 1 && Sensor::kThreads == 256) {
+    if constexpr (Sensor::kThreads == 256) {
       // [distance transform the held-back updateEsdf has just armed][TSDF update of this frame][colour integration of the held-back frame]
       int32_t n_edt = 0; EsdfArgs ea_edt = m->edt_args;
       if (m->edt_pending) { n_edt = 256; m->edt_pending = false; }
@@ -952,12 +961,12 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
       const int64_t c_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[3], __ATOMIC_RELAXED));         // candidates of the last colour frame the GPU has finished
       const int cgrid = (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, 1024), ((c_hint + c_hint / 4 + 64 + 7) / 8) * 8));
       const dim3 g((unsigned)(n_edt + grid + cgrid));
-      if (f_kind == 0) {
-        NVBX_LAUNCH(m, (k_integrate_tsdf_color<Img, PixRgb8>), g, dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, m->mesh_list_live(), m->view_export,
+      if (NB > 1 || f_kind == 0) {
+        NVBX_LAUNCH(m, (k_integrate_tsdf_color<Img, PixRgb8, NB>), g, dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, m->mesh_list_live(), m->view_export,
                     (int32_t)m->view_export_cap, spec_lanes, (int32_t)grid, fsc, (const float*)m->synth, f_srows, f_scols, cand, cand_idx, n_edt, ea_edt);
-      } else {
+      } else if constexpr (NB == 1) {
         FrameSetC<PixBgra8, 1> fc; memcpy(&fc, &fsc, sizeof(fc));       // (one layout, color.hip static_assert)
-        NVBX_LAUNCH(m, (k_integrate_tsdf_color<Img, PixBgra8>), g, dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, m->mesh_list_live(), m->view_export,
+        NVBX_LAUNCH(m, (k_integrate_tsdf_color<Img, PixBgra8, 1>), g, dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, m->mesh_list_live(), m->view_export,
                     (int32_t)m->view_export_cap, spec_lanes, (int32_t)grid, fc, (const float*)m->synth, f_srows, f_scols, cand, cand_idx, n_edt, ea_edt);
       }
     }
@@ -1019,13 +1028,14 @@ static int integrate_cameras(nvbx_mapper* m, int32_t n, const Img* imgs, int32_t
   const bool dilate_first = m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0;
   // held-back integrateColor / updateEsdf that this call cannot carry out in pipelined order are replayed NOW, with the whole held-back
   // state in view (the replayed calls launch / re-arm the held-back EDT themselves) -- before the EDT is hidden from join_side below
-  if (!(NB == 1 && !dilate_first && m->color_pending.on) && m->replay_deferred()) return NVBX_E_DEVICE;
+  const bool carry = !dilate_first && m->color_pending.on && ((NB == 1) == (m->color_pending.n == 1));      // this call can carry the held-back calls out in pipelined order
+  if (!carry && m->replay_deferred()) return NVBX_E_DEVICE;
   { const bool pend = m->edt_pending, ipend = m->import_pending; m->edt_pending = false; m->import_pending = false;
     // (join_side would launch a held-back EDT / union step; the EDT rides in k_mark_view instead, the union step stays held back
     //  for the next integrateColor -- it belongs to the NEXT ESDF update and touches nothing this launch reads)
     // A held-back colour frame (+ ESDF update) stays held back too when this call can carry it out in pipelined order (a single frame,
     // no dilation launch in front); otherwise join_side replays it now.
-    const bool keep = NB == 1 && !dilate_first && m->color_pending.on;
+    const bool keep = carry;
     const nvbx_mapper::ColorPending cp = m->color_pending; const bool up = m->esdf_update_pending;
     if (keep) { m->color_pending.on = false; m->esdf_update_pending = false; }
     const int rc = m->join_side(); m->edt_pending = pend; m->import_pending = ipend;

@@ -143,6 +143,46 @@ def test_fused_colour_tsdf_launch_under_irregular_calls(oracle_mod, hip_lib, see
     _equal_maps(M, a, b, "seed %d end" % seed)
     prof = b.profile()
     names = " ".join(prof.keys())
-    assert "k_integrate_tsdf_color<Img, PixRgb8>" in names and "k_integrate_tsdf_color<Img, PixBgra8>" in names, names[:600]      # the fused launch has run, both encodings
+    assert "k_integrate_tsdf_color<Img, PixRgb8" in names and "k_integrate_tsdf_color<Img, PixBgra8" in names, names[:600]      # the fused launch has run, both encodings
     assert "k_grow_commit" in names, names[:600]                                                                                  # ... and the pool has grown under it
     assert b.counters()["capacity_overflow"] == 0 and len(a.block_indices(M.LAYER_COLOR)) > 50
+
+
+@pytest.mark.parametrize("ncam", [2, 4, 8])
+def test_camera_batches_take_the_pipeline_too(oracle_mod, hip_lib, ncam):
+    """nvbx_integrate_depth_batch / _color_batch with deferral on: the colour BATCH is held back and the next depth batch carries it out in two
+    launches (k_mark_view<.., 8> with the batch's sphere tracing / candidates / ESDF marking riding, then k_integrate_tsdf_color<.., 8>).
+    Same calls on a classic mapper: the same map, views and mesh, bit for bit; irregular steps (a batch without colour, an ESDF update left
+    out, a single frame between batches, decay) are replayed in call order."""
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    pg = M.default_params(tsdf_decay_factor=0.8, tsdf_decayed_weight_threshold=0.05)
+    a = M.Mapper(pg, block_capacity=1 << 14); b = M.Mapper(pg, block_capacity=1 << 14)
+    b.set_color_deferral(True); b.set_profiling(True)
+    fr = H.frames(14 * ncam, cam, stride=2)
+
+    def both(fn):
+        fn(a); fn(b)
+    for k in range(14):
+        grp = fr[k * ncam:(k + 1) * ncam]
+        ds, cs, Ts = [g[0] for g in grp], [g[1] for g in grp], [g[2] for g in grp]
+        both(lambda m: m.integrate_depth_batch(ds, Ts, cam))
+        if k != 5:
+            both(lambda m: m.integrate_color_batch(cs, Ts, cam))
+        if k not in (3, 9):
+            both(lambda m: m.update_esdf())
+        if k == 6:
+            both(lambda m: m.integrate_depth(ds[0], Ts[0], cam)); both(lambda m: m.integrate_color(cs[0], Ts[0], cam))      # a single frame between batches
+        if k == 10:
+            both(lambda m: m.decay_tsdf(True))
+        if k in (2, 7, 13):
+            _equal_maps(M, a, b, "%d cameras step %d" % (ncam, k))
+            assert H.idx_set(a.last_view()) == H.idx_set(b.last_view()) and H.idx_set(a.last_color_view()) == H.idx_set(b.last_color_view())
+    both(lambda m: m.update_esdf())
+    _equal_maps(M, a, b, "%d cameras end" % ncam)
+    both(lambda m: m.update_color_mesh())
+    ma, mb = a.mesh(), b.mesh()
+    assert ma.keys() == mb.keys() and all(np.array_equal(ma[k_]["triangles"], mb[k_]["triangles"]) and np.array_equal(ma[k_]["vertices"], mb[k_]["vertices"]) for k_ in ma)
+    prof = b.profile()
+    fused = sum(v["count"] for k_, v in prof.items() if "k_integrate_tsdf_color" in k_)
+    assert fused >= 7, {k_: v["count"] for k_, v in prof.items()}          # (of 15 depth launches: the ones that followed a colour batch directly)
