@@ -198,7 +198,8 @@ int nvbx_synchronize(nvbx_mapper* m);
 int nvbx_flush(nvbx_mapper* m);
 /* Colour deferral (cross-frame pipelining; off by default).  While enabled, nvbx_integrate_color / _bgra8 of a single frame is HELD BACK --
  * its arguments are remembered, nothing is launched -- and so is an nvbx_update_esdf that follows it.  The next single-frame
- * nvbx_integrate_depth / _u16mm carries them out in pipelined order, two launches per depth + colour + ESDF frame instead of four:
+ * nvbx_integrate_depth / _u16mm (for a held-back nvbx_integrate_color_batch of n > 1 frames: the next nvbx_integrate_depth_batch of n > 1
+ * frames; the image pointers are remembered, not the pointer array) carries them out in pipelined order, two launches per depth + colour + ESDF frame instead of four:
  * {view marking of the new depth frame || sphere tracing, candidate-block discovery and ESDF site marking of the held-back frame}, then
  * {TSDF update of the new frame || colour integration and distance transform of the held-back frame} (three launches where the mapper is not
  * a plain TSDF mapper with the exact 2-D ESDF, or has integrated a LiDAR scan).  The overlapped parts are independent: sphere
