@@ -6,7 +6,9 @@
 // with the reference's timer tags; it prints timing::Timing::Print() like the node does on shutdown
 // (nvblox_node.cpp:178-180) and one JSON line with ms/frame measured around the whole loop (stream synchronised).
 //
-// usage: fuser_loop frames.bin [n_frames_to_integrate] [esdf_every] [mesh_every]
+// usage: fuser_loop frames.bin [n_frames_to_integrate] [esdf_every] [mesh_every] [deferred_colour 0|1]
+// deferred_colour = 1: Mapper::setColorIntegrationDeferred(true) -- the libnvblox_hip extension that carries integrateColor(i) / updateEsdf(i) out
+// inside integrateDepth(i + 1), two launches per frame; the colour images here are resident and unchanged, as its contract asks.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -18,9 +20,10 @@
 using namespace nvblox;
 
 int main(int argc, char** argv) {
-  if (argc < 2) { std::fprintf(stderr, "usage: %s frames.bin [n_frames] [esdf_every] [mesh_every]\n", argv[0]); return 2; }
+  if (argc < 2) { std::fprintf(stderr, "usage: %s frames.bin [n_frames] [esdf_every] [mesh_every] [deferred_colour]\n", argv[0]); return 2; }
   const int number_of_frames_to_integrate = argc > 2 ? std::atoi(argv[2]) : -1;      // fuser_node.cpp:207-209
   const int esdf_every = argc > 3 ? std::atoi(argv[3]) : 1, mesh_every = argc > 4 ? std::atoi(argv[4]) : 0;
+  const bool deferred = argc > 5 && std::atoi(argv[5]) != 0;
   FILE* f = std::fopen(argv[1], "rb");
   if (!f) { std::perror("open"); return 2; }
   int32_t hdr[3]; float k[4];
@@ -39,6 +42,7 @@ int main(int argc, char** argv) {
   p.esdf_integrator_params.esdf_slice_height = 0.09f; p.esdf_integrator_params.esdf_slice_min_height = 0.09f;
   p.esdf_integrator_params.esdf_slice_max_height = 0.65f;
   multi_mapper->setMapperParams(p);
+  if (deferred) multi_mapper->background_mapper()->setColorIntegrationDeferred(true);
   const Camera camera(k[0], k[1], k[2], k[3], cols, rows);
 
   // the data loader's job: frames resident on the device
@@ -70,7 +74,7 @@ int main(int argc, char** argv) {
   cuda_stream->synchronize();
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   std::fprintf(stderr, "%s", timing::Timing::Print().c_str());
-  std::printf("{\"frames\": %d, \"ms_per_frame\": %.5f, \"tsdf_blocks\": %d, \"esdf_every\": %d, \"mesh_every\": %d, \"host\": \"c++ facade\"}\n",
-              total, ms / total, multi_mapper->background_mapper()->tsdf_layer().numAllocatedBlocks(), esdf_every, mesh_every);
+  std::printf("{\"frames\": %d, \"ms_per_frame\": %.5f, \"tsdf_blocks\": %d, \"esdf_every\": %d, \"mesh_every\": %d, \"deferred_colour\": %d, \"host\": \"c++ facade\"}\n",
+              total, ms / total, multi_mapper->background_mapper()->tsdf_layer().numAllocatedBlocks(), esdf_every, mesh_every, deferred ? 1 : 0);
   return 0;
 }

@@ -139,6 +139,13 @@ def test_fuser_loop_cpp_host(hip_lib, tmp_path):
     assert 0.01 < got["ms_per_frame"] < 0.5, got            # README RTX 5090 sum for the same three components: 0.7 ms
     assert "tsdf/integrate" in r.stderr and "esdf/integrate" in r.stderr      # the reference's core timer tags
     print(got)
+    # the same loop with Mapper::setColorIntegrationDeferred(true): two launches per frame, the same map
+    r2 = subprocess.run([os.path.join(CPP, "fuser_loop"), str(path), "400", "1", "0", "1"], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    got2 = json.loads(r2.stdout.strip().splitlines()[-1])
+    assert got2["deferred_colour"] == 1 and got2["tsdf_blocks"] == got["tsdf_blocks"]
+    assert got2["ms_per_frame"] < 1.05 * got["ms_per_frame"], (got, got2)
+    print(got2)
 
 
 @pytest.mark.gpu
