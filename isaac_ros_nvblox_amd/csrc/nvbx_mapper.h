@@ -192,6 +192,13 @@ struct nvbx_mapper {
     if ((m)->profiling) (m)->span_end((s));                                          \
   } while (0)
 #define NVBX_LAUNCH(m, kernel, grid, block, ...) NVBX_LAUNCH_ON(m, (m)->stream, kernel, grid, block, __VA_ARGS__)
+// (... with `smem` bytes of dynamic LDS per workgroup)
+#define NVBX_LAUNCH_SMEM(m, kernel, grid, block, smem, ...)                          \
+  do {                                                                               \
+    if ((m)->profiling) (m)->span_begin(#kernel, (m)->stream);                       \
+    hipLaunchKernelGGL(kernel, grid, block, (smem), (m)->stream, __VA_ARGS__);       \
+    if ((m)->profiling) (m)->span_end((m)->stream);                                  \
+  } while (0)
 
 #define NVBX_HIP(call)                                                 \
   do {                                                                 \

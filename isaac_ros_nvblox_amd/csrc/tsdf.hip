@@ -336,13 +336,18 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
 // cameras through one mapper, one integrateDepth call each: nvblox_node.hpp:298-332).  Kernel argument (SGPRs / scalar loads).
 template <typename Img, int NB> struct FrameSet { Frame f[NB]; Img img[NB]; int32_t n; };
 
+template <typename Sensor> static size_t mark_view_smem(bool edt_rides) {
+  const size_t mark = 2 * (size_t)Sensor::kSetSize * sizeof(u64);
+  return (Sensor::kThreads == 256 && edt_rides && sizeof(EdtShared) > mark) ? sizeof(EdtShared) : mark;
+}
 template <typename Img, typename Sensor, int NB>
 __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet<Img, NB> fs, Sensor sensor, int4* view_list, int32_t list_cap,
                                                                 int32_t reset_esdf_dirty, int32_t n_edt_wg, EsdfArgs ea, TraceRiderT<NB> tr) {
   constexpr int LSET = Sensor::kSetSize, FR = Sensor::kFlushRounds;
-  constexpr size_t kMarkBytes = 2 * LSET * sizeof(u64);
-  constexpr size_t kSmem = (Sensor::kThreads == 256 && sizeof(EdtShared) > kMarkBytes) ? sizeof(EdtShared) : kMarkBytes;
-  __shared__ __align__(16) unsigned char smem[kSmem];
+  // LDS: the tile's key set (2 * LSET u64), or -- when a distance transform rides (camera, classic order) -- at least an EdtShared; sized by
+  // the launch (mark_view_smem below): EVERY workgroup of the launch holds it, the riders too, and it decides how many are resident
+  // (a batch of 8 cameras: 2 688 tile workgroups beside 1 200 sphere-tracing ones)
+  extern __shared__ __align__(16) unsigned char smem[];
   int32_t tile_wg = (int32_t)blockIdx.x;      // this workgroup's number among the tiles
   if (Sensor::kThreads == 256) {
     // riders: [EDT workers][sphere-tracing workers of a held-back colour frame (colour deferral)] -- before the tiles, or
@@ -924,7 +929,7 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
       m->pending_marking_args(&tr.n_mark_wg, &ea);        // (the held-back integrateColor's marking pass, in call order: before its colour integration below)
     }
   }
-  NVBX_LAUNCH(m, (k_mark_view<Img, Sensor, NB>), dim3(tiles + edt_wg + tr.n_wg + tr.n_scan_wg + tr.n_mark_wg), dim3(Sensor::kThreads), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
+  NVBX_LAUNCH_SMEM(m, (k_mark_view<Img, Sensor, NB>), dim3(tiles + edt_wg + tr.n_wg + tr.n_scan_wg + tr.n_mark_wg), dim3(Sensor::kThreads), mark_view_smem<Sensor>(edt_wg > 0), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
               (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)edt_wg, ea, tr);
   FrameSetC<PixRgb8, NB> fsc{}; int f_kind = 0; int32_t f_srows = 0, f_scols = 0;
   if (pipelined) {
@@ -1217,7 +1222,7 @@ extern "C" int nvbx_measure_depth(nvbx_mapper* m, const float* depth_dev, int32_
   const int n_tiles = ((f.n_ray_rows + CameraSensor::kTileRows - 1) / CameraSensor::kTileRows) * ((f.n_ray_cols + CameraSensor::kTileCols - 1) / CameraSensor::kTileCols);
   // the view calculation against the local map: blocks in view are looked up / allocated exactly as integrateDepth would (they receive
   // their values when the gathered measurements are applied)
-  NVBX_LAUNCH(m, (k_mark_view<DepthF32, CameraSensor, 1>), dim3(NSH * ((n_tiles + NSH - 1) / NSH)), dim3(CameraSensor::kThreads), m->d, fs, CameraSensor{},
+  NVBX_LAUNCH_SMEM(m, (k_mark_view<DepthF32, CameraSensor, 1>), dim3(NSH * ((n_tiles + NSH - 1) / NSH)), dim3(CameraSensor::kThreads), mark_view_smem<CameraSensor>(false), m->d, fs, CameraSensor{},
               (int4*)m->view_list, (int32_t)m->capacity, (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)0, m->edt_args, TraceRider{});
   m->premark_consumed = false;
   NVBX_LAUNCH(m, (k_measure_tsdf<DepthF32>), dim3((unsigned)std::min<int64_t>(m->capacity, 1024)), dim3(512), m->d, f, DepthF32{depth_dev}, CameraSensor{},
