@@ -1,13 +1,15 @@
 // color.hip -- MultiMapper::integrateColor on MI355X.
 //
-// Two launches per colour frame:
-//   k_sphere_trace    one wavefront per 8x8 tile of the 1/f-resolution synthetic depth image; each lane sphere-traces
-//                     its ray through the TSDF, caching the last block's slot so consecutive samples of a ray skip the
-//                     hash probe and the last voxel's value so repeated samples of one voxel skip memory ([U] SphereTracer::cast restated).
-//   k_integrate_color one 512-thread workgroup per allocated block slot (grid-stride over the slot range): frustum test
-//                     (8 lanes = 8 corners), truncation-band test (block-wide vote), then the per-voxel projective
-//                     colour blend -- selection and integration fused, no block list round trip
-//                     ([U] ProjectiveColorIntegrator::integrateFrame restated).
+// Classic order, two launches per colour frame (the workers live in headers so that other launches can carry them):
+//   k_sphere_trace    sample-parallel sphere tracing of the 1/f-resolution synthetic depth image, 8 lanes per ray
+//                     (nvbx_sphere_trace.h; [U] SphereTracer::cast restated)
+//   k_integrate_color one 512-thread workgroup per allocated block slot (grid-stride over the slot range): truncation-band flag,
+//                     frustum test (8 lanes = 8 corners), then the per-voxel projective colour blend -- selection and integration
+//                     fused, no block list round trip -- with the ESDF site marking riding in extra workgroups
+//                     (nvbx_color_worker.h; [U] ProjectiveColorIntegrator::integrateFrame restated).
+// Pipelined order (colour deferral): the frame is held back; its sphere tracing, candidate discovery and the marking
+// pass ride in the next depth frame's view-marking launch and its colour integration in that frame's TSDF-update launch (tsdf.hip) --
+// this file keeps the held-back state's set-up (pending_*) and the replay in classic order.
 // Call site served: nvblox_ros/src/lib/nvblox_node.cpp:1264.
 #include <algorithm>
 #include <cstdlib>

@@ -959,7 +959,8 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
     if constexpr (Sensor::kThreads == 256) {
       // [distance transform the held-back updateEsdf has just armed][TSDF update of this frame][colour integration of the held-back frame]
       int32_t n_edt = 0; EsdfArgs ea_edt = m->edt_args;
-      if (m->edt_pending) { n_edt = 256; m->edt_pending = false; }
+      static const int edt_riders = getenv("NVBX_EDT_RIDERS") ? atoi(getenv("NVBX_EDT_RIDERS")) : 256;      // (A/B; a multiple of 8)
+      if (m->edt_pending) { n_edt = edt_riders; m->edt_pending = false; }
       const int4* cand = m->color_cand + (size_t)m->cand_parity * m->fuse_cap;
       const int32_t cand_idx = C_CAND_COUNT + m->cand_parity;
       m->cand_parity ^= 1;
