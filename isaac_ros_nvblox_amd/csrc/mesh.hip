@@ -93,7 +93,10 @@ __global__ __launch_bounds__(512) void k_mesh_prepass(DMap m, float min_weight, 
   }
 }
 
-__global__ __launch_bounds__(512, 4) void k_mesh(DMap m, MeshArgs a, float* o_vert, float* o_nrm, uint32_t* o_col,
+#ifndef NVBX_MESH_WAVES
+#define NVBX_MESH_WAVES 4      // (waves per SIMD the register budget is sized for: tools/mesh_occupancy_sweep.sh)
+#endif
+__global__ __launch_bounds__(512, NVBX_MESH_WAVES) void k_mesh(DMap m, MeshArgs a, float* o_vert, float* o_nrm, uint32_t* o_col,
                                               int32_t* o_tri, MeshRecord* o_rec, const uint8_t* neg_any) {
   __shared__ float s_d[NLAT];
   __shared__ uint8_t s_valid[NLAT];
