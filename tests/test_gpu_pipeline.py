@@ -119,7 +119,8 @@ def test_fused_colour_tsdf_launch_under_irregular_calls(oracle_mod, hip_lib, see
     def both(fn):
         fn(a); fn(b)
     for k, (d, rgb, T) in enumerate(fr):
-        both(lambda m: m.integrate_depth(d, T, cam))
+        dd = d if k % 5 else np.round(d * 1000.0).astype(np.uint16)       # (every 5th depth frame: 16-bit millimetres, converted in the kernels' fetch)
+        both(lambda m: m.integrate_depth(dd, T, cam))
         if rng.random() < 0.85:
             img = rgb if k % 7 else np.ascontiguousarray(np.concatenate([rgb[..., ::-1], np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=2))     # (every 7th frame: bgra8)
             both(lambda m: m.integrate_color(img, T, cam))
