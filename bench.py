@@ -777,7 +777,9 @@ def main_camera(args):
                            "note": "enabled: integrateColor(i) / updateEsdf(i) are held back and carried out by integrateDepth(i+1) in pipelined order: "
                                    "launch 1 = view marking(i+1) || sphere tracing(i) || colour candidates(i) || ESDF marking(i), launch 2 = TSDF update(i+1) "
                                    "|| colour integration(i) || distance transform(i) (NVBX_FUSE_COLC=0: three launches); same calls, bit-identical map "
-                                   "(tests/test_gpu_pipeline.py); contract: include/nvblox_hip.h nvbx_mapper_set_color_deferral"},
+                                   "(tests/test_gpu_pipeline.py); contract: include/nvblox_hip.h nvbx_mapper_set_color_deferral.  N > 1 GPUs run the CLASSIC "
+                                   "order (four launches per frame): the index exchange's gathered lists are double-buffered per frame and the pipelined order "
+                                   "would read them one launch later -- the N = 1 figure to compare an N > 1 line with is ms_per_step_revisit_classic_order"},
         "block_ms": [round(d / args.steps * 1e3, 4) for d in dts[:16]],
         "ms_components": {k_: round(v_, 4) for k_, v_ in comp.items()},
         "components_note": "ms_components are measured per call in isolation: the EDT of updateEsdf is held back and runs inside the next depth "
