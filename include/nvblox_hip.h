@@ -208,7 +208,9 @@ int nvbx_flush(nvbx_mapper* m);
  * LiDAR, mesh, decay, clearing, another integrate_color, ...) first carries the held-back calls out exactly as they would have run at call
  * time, so results -- map contents, ESDF, views, every query -- are bit-identical to the undeferred sequence (tests/test_gpu_pipeline.py).
  * CONTRACT (the caller-lifetime rule this buys the launch with): the colour image passed to nvbx_integrate_color must stay valid and
- * UNCHANGED until the next call into this mapper has returned (any call: it either consumes or flushes the frame).  nvblox_ros re-uses ONE
+ * UNCHANGED until the next call into this mapper has returned that either consumes or flushes the frame -- any call except
+ * nvbx_detect_dynamics, nvbx_remove_small_components, nvbx_split_depth_by_mask and nvbx_set_time_ms, which leave held-back work alone
+ * (the dynamic-mapping frame starts with them; they read TSDF voxels / the freespace layer / images only).  nvblox_ros re-uses ONE
  * colour buffer per node (nvblox_node.hpp:485-488) and fills it right before integrateColor, after the depth frame -- compatible with the
  * contract for the depth -> colour -> updateEsdf order of NvbloxNode::tick(); a node that fills the colour buffer BEFORE calling
  * integrateDepth must double-buffer it or leave deferral off.  Argument errors are still reported by the call that made them. */

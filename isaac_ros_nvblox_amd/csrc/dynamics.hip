@@ -124,7 +124,7 @@ extern "C" int nvbx_detect_dynamics(nvbx_mapper* m, const float* depth_dev, int3
                                     float max_distance_m, uint8_t* mask_dev) {
   if (!m || !depth_dev || !T_L_C || !camera || !mask_dev || rows <= 0 || cols <= 0) { set_error("nvbx_detect_dynamics: invalid argument"); return NVBX_E_INVALID; }
   NVBX_HIP(hipSetDevice(m->device));
-  if (m->join_side()) return NVBX_E_DEVICE;
+  if (m->join_side_keeping_held()) return NVBX_E_DEVICE;      // (reads TSDF voxels and the freespace layer only)
   const int64_t n = (int64_t)rows * cols;
   if (!m->d.freespace) { NVBX_HIP(hipMemsetAsync(mask_dev, 0, (size_t)n, m->stream)); return NVBX_OK; }    // no freespace layer yet: nothing is dynamic
   RtCam g;

@@ -901,6 +901,13 @@ int nvbx_mapper::join_side() {
   if (side_pending) { NVBX_HIP(hipStreamWaitEvent(stream, ev_side, 0)); side_pending = false; }
   return NVBX_OK;
 }
+int nvbx_mapper::join_side_keeping_held() {
+  const bool e = edt_pending, i = import_pending, u = esdf_update_pending, c = color_pending.on;
+  edt_pending = false; import_pending = false; esdf_update_pending = false; color_pending.on = false;
+  const int rc = join_side();
+  edt_pending = e; import_pending = i; esdf_update_pending = u; color_pending.on = c;
+  return rc;
+}
 // the held-back calls of colour deferral, carried out as they would have been at call time
 int nvbx_mapper::replay_deferred() {
   if (!color_pending.on && !esdf_update_pending) return NVBX_OK;

@@ -144,6 +144,10 @@ struct nvbx_mapper {
   bool replaying = false;            // inside replay_deferred: the calls run as usual
   bool pipelined_order = false;      // inside the pipelined integrateDepth: marking passes empty their list, EDTs keep it (EsdfArgs)
   int replay_deferred();
+  // join_side for an entry point that neither reads nor writes what the held-back work touches (colour layer, ESDF layer, site masks, the
+  // ESDF-dirty list): the held-back distance transform, union step, colour frame and ESDF update stay held back (nvbx_detect_dynamics: TSDF +
+  // freespace reads only -- the dynamic-mapping frame starts with it, and flushing there would cost the pipeline every frame)
+  int join_side_keeping_held();
   int pending_color_trace_rider(void* trace_rider_out);   // color.hip: set the held-back frame(s) up; the sphere tracing as a nvbx::TraceRiderT<1> (one frame) / <MAX_BATCH> (a batch)
   int launch_pending_color_after_trace();
 // -- fused colour + TSDF launch of the pipelined order (two launches per frame)

@@ -926,6 +926,7 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
       tr.n_scan_wg = (int32_t)std::min<int64_t>(256, 8 * ((hw_seen + hw_seen / 4 + 64 + 2047) / 2048));      // 256 slots per workgroup and pass; a hint only (the riders grid-stride)
       tr.cand = m->color_cand + (size_t)m->cand_parity * m->fuse_cap;
       tr.cand_cnt_idx = C_CAND_COUNT + m->cand_parity; tr.cand_reset_idx = C_CAND_COUNT + (1 - m->cand_parity);
+      m->cand_parity ^= 1;      // (the next fused launch resets THIS count, whether or not the colour launch below is reached: an error return in between leaves no stale candidates behind)
       m->pending_marking_args(&tr.n_mark_wg, &ea);        // (the held-back integrateColor's marking pass, in call order: before its colour integration below)
     }
   }
@@ -961,9 +962,8 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
       int32_t n_edt = 0; EsdfArgs ea_edt = m->edt_args;
       static const int edt_riders = getenv("NVBX_EDT_RIDERS") ? atoi(getenv("NVBX_EDT_RIDERS")) : 256;      // (A/B; a multiple of 8)
       if (m->edt_pending) { n_edt = edt_riders; m->edt_pending = false; }
-      const int4* cand = m->color_cand + (size_t)m->cand_parity * m->fuse_cap;
-      const int32_t cand_idx = C_CAND_COUNT + m->cand_parity;
-      m->cand_parity ^= 1;
+      const int4* cand = tr.cand;
+      const int32_t cand_idx = tr.cand_cnt_idx;
       const int64_t c_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[3], __ATOMIC_RELAXED));         // candidates of the last colour frame the GPU has finished
       const int cgrid = (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, 1024), ((c_hint + c_hint / 4 + 64 + 7) / 8) * 8));
       const dim3 g((unsigned)(n_edt + grid + cgrid));

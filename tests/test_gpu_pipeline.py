@@ -187,3 +187,69 @@ def test_camera_batches_take_the_pipeline_too(oracle_mod, hip_lib, ncam):
     prof = b.profile()
     fused = sum(v["count"] for k_, v in prof.items() if "k_integrate_tsdf_color" in k_)
     assert fused >= 7, {k_: v["count"] for k_, v in prof.items()}          # (of 15 depth launches: the ones that followed a colour batch directly)
+
+
+def test_dynamic_mapping_frame_keeps_the_pipeline(oracle_mod, hip_lib):
+    """The dynamic-mapping frame (MappingType::kDynamic: detect dynamics -> clean the mask -> split the depth image -> static mapper with a
+    freespace layer + occupancy mapper -> colour -> two ESDF updates, decay every 6th frame) starts with nvbx_detect_dynamics on the static
+    mapper.  That call reads TSDF voxels and the freespace layer only, so it leaves the held-back colour frame / ESDF update / distance
+    transform held back and the next integrateDepth carries them out in pipelined order.  Same calls on classic mappers: identical masks,
+    split depth images, maps (TSDF, colour, ESDF, freespace) and occupancy, bit for bit.  (Stream-ordered host, like bench.py: mappers and
+    torch share one stream, nothing in the loop waits for the GPU.)"""
+    from isaac_ros_nvblox_amd import mapper as M
+    import torch
+    cam = H.SMALL_CAM; rows, cols = cam[5], cam[4]
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    fs = dict(projective_layer_type=2, max_integration_distance_m=5.0, invalid_depth_decay_factor=0.8, tsdf_decay_factor=0.95,
+              min_duration_since_occupied_for_freespace_ms=250)
+    occ = dict(projective_layer_type=1, max_integration_distance_m=5.0)
+    with torch.cuda.stream(stream):
+        mk = lambda prm, cap: M.Mapper(M.default_params(**prm), block_capacity=cap, stream=stream.cuda_stream)
+        gs_a, gd_a, gs_b, gd_b = mk(fs, 1 << 14), mk(occ, 1 << 13), mk(fs, 1 << 14), mk(occ, 1 << 13)
+        gs_b.set_color_deferral(True); gs_b.set_profiling(True)
+        eye = np.eye(4, dtype=np.float32)
+        kept = []
+        t = 0
+        for i in range(20):
+            sc = S.redwood_like_scene(i * 6)                       # a box translating through the room
+            T = S.trajectory_pose(i * 3, 200, radius=1.2, height=1.4)
+            d, rgb = S.render(sc, T, cam, max_range=5.0)
+            d_dev = torch.from_numpy(d).to(dev); rgb_dev = torch.from_numpy(rgb).to(dev)
+            outs = []
+            for gs, gd in ((gs_a, gd_a), (gs_b, gd_b)):
+                mask = torch.empty((rows, cols), dtype=torch.uint8, device=dev); un = torch.empty((rows, cols), dtype=torch.float32, device=dev); ma = torch.empty_like(un)
+                gs.detect_dynamics_into(d_dev, T, cam, 5.0, mask)
+                raw = mask.clone()
+                gs.remove_small_components_inplace(mask, 40)
+                gs.split_depth_by_mask_into(d_dev, mask, eye, cam, cam, 0.25, un, ma)
+                gs.set_time_ms(t)
+                gs.integrate_depth(un, T, cam); gd.integrate_depth(ma, T, cam)
+                gs.integrate_color(rgb_dev, T, cam)
+                gs.update_esdf(); gd.update_esdf()
+                if i % 6 == 5:
+                    gs.decay_tsdf(True); gd.decay_occupancy()
+                outs.append((raw, mask, un, ma))
+            kept.append((outs, d_dev, rgb_dev))       # (device images stay alive: the colour frame is held back until the next integrateDepth)
+            t += 100
+            if i % 5 == 4 or i == 19:
+                for outs_, _, _ in kept:
+                    for x, y in zip(outs_[0], outs_[1]):
+                        assert torch.equal(x, y), i
+                kept = kept[-1:]
+        n_dyn = int(kept[-1][0][0][1].sum().item())
+        _equal_maps(M, gs_a, gs_b, "static mapper")
+        ia, ib = gs_a.block_indices(M.LAYER_FREESPACE), gs_b.block_indices(M.LAYER_FREESPACE)
+        assert np.array_equal(ia, ib) and len(ia) > 50
+        fa, _ = gs_a.get_blocks(M.LAYER_FREESPACE, ia); fb, _ = gs_b.get_blocks(M.LAYER_FREESPACE, ia)
+        for f in ("last_occupied_timestamp_ms", "consecutive_occupancy_duration_ms", "is_high_confidence_freespace", "initialized"):
+            assert np.array_equal(fa[f], fb[f]), f
+        oa, ob = gd_a.block_indices(M.LAYER_OCCUPANCY), gd_b.block_indices(M.LAYER_OCCUPANCY)
+        assert np.array_equal(oa, ob)
+        if len(oa):
+            ba, _ = gd_a.get_blocks(M.LAYER_OCCUPANCY, oa); bb, _ = gd_b.get_blocks(M.LAYER_OCCUPANCY, oa)
+            assert np.array_equal(ba["log_odds"], bb["log_odds"])
+        prof = gs_b.profile()
+        n_trace = sum(v["count"] for k_, v in prof.items() if "k_sphere_trace" in k_)
+        n_mark = sum(v["count"] for k_, v in prof.items() if "k_mark_view" in k_)
+        assert n_mark >= 20 and n_trace <= 8, ({k_: v["count"] for k_, v in prof.items()}, n_dyn)      # most colour frames' sphere tracing rode in a view-marking launch
