@@ -364,7 +364,7 @@ def main_decay(args):
     gs = M.Mapper(M.default_params(**fs), device=local_rank, block_capacity=1 << 15, stream=stream.cuda_stream)
     gd = M.Mapper(M.default_params(**occ), device=local_rank, block_capacity=1 << 13, stream=stream.cuda_stream)
     # cross-frame pipelining on the static mapper: the frame's first call, detect_dynamics, leaves held-back work alone, so the
-    # colour frame / ESDF update of frame i are carried out by integrateDepth(i + 1) (three launches: a freespace mapper is not eligible for two)
+    # colour frame / ESDF update of frame i are carried out by integrateDepth(i + 1) in two launches
     gs.set_color_deferral(not args.no_color_deferral)
     eye = np.eye(4, dtype=np.float32)
     mask = torch.empty((rows, cols), dtype=torch.uint8, device=dev)

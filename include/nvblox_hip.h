@@ -201,8 +201,8 @@ int nvbx_flush(nvbx_mapper* m);
  * nvbx_integrate_depth / _u16mm (for a held-back nvbx_integrate_color_batch of n > 1 frames: the next nvbx_integrate_depth_batch of n > 1
  * frames; the image pointers are remembered, not the pointer array) carries them out in pipelined order, two launches per depth + colour + ESDF frame instead of four:
  * {view marking of the new depth frame || sphere tracing, candidate-block discovery and ESDF site marking of the held-back frame}, then
- * {TSDF update of the new frame || colour integration and distance transform of the held-back frame} (three launches where the mapper is not
- * a plain TSDF mapper with the exact 2-D ESDF, or has integrated a LiDAR scan).  The overlapped parts are independent: sphere
+ * {TSDF update of the new frame || colour integration and distance transform of the held-back frame} (three launches where the mapper does not
+ * run the exact 2-D ESDF, or has integrated a LiDAR scan).  The overlapped parts are independent: sphere
  * tracing reads the TSDF and the insert-only
  * hash, view marking inserts entries whose blocks are all-zero = unobserved).  EVERY other entry point (queries, synchronize / flush, batches,
  * LiDAR, mesh, decay, clearing, another integrate_color, ...) first carries the held-back calls out exactly as they would have run at call

@@ -617,7 +617,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // has finished (previous launch) and writes ESDF voxels only; the update appends to an ESDF-dirty list that pass has emptied.  Every part
 // reads exactly the state separate calls would have shown it.
 // Workgroups: [distance transform (512 threads = 8 wavefronts per ESDF block)][TSDF update][colour].
-template <typename Img, typename Pix, int NB>
+template <typename Img, typename Pix, int NB, bool Plain>
 __global__ __launch_bounds__(512) void k_integrate_tsdf_color(DMap m, FrameSet<Img, NB> fs, CameraSensor sensor, const int4* view_list, int32_t list_cap,
                                                               int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, int32_t n_tsdf_wg,
                                                               FrameSetC<Pix, NB> fsc, const float* synth, int32_t srows, int32_t scols, const int4* cand, int32_t cand_cnt_idx,
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf_color(DMap m, FrameSet<I
   const int32_t b = (int32_t)blockIdx.x;
   if (b < n_edt_wg) { esdf_edt_worker<512>(m, ea, (int)b, n_edt_wg, reinterpret_cast<EdtShared*>(smem)); return; }
   if (b < n_edt_wg + n_tsdf_wg) {
-    integrate_tsdf_worker<Img, CameraSensor, NB, true>(m, fs, sensor, view_list, list_cap, mesh_list, view_export, view_export_cap, spec_lanes, nullptr, b - n_edt_wg, n_tsdf_wg);
+    integrate_tsdf_worker<Img, CameraSensor, NB, Plain>(m, fs, sensor, view_list, list_cap, mesh_list, view_export, view_export_cap, spec_lanes, nullptr, b - n_edt_wg, n_tsdf_wg);
     return;
   }
   color_integrate_list_worker<Pix, NB>(m, fsc, synth, srows, scols, mesh_list, cand, cand_cnt_idx, b - n_edt_wg - n_tsdf_wg, (int32_t)gridDim.x - n_edt_wg - n_tsdf_wg);
@@ -908,9 +908,10 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   bool fused = false;
   if (pipelined) {
     static const int fuse_on = getenv("NVBX_FUSE_COLC") ? atoi(getenv("NVBX_FUSE_COLC")) : 1;      // (A/B: 0 = three launches per frame)
-    // plain TSDF mapper, 2-D ESDF by the exact transform (the marking pass / distance transform that ride are the 2-D ones), no multi-GPU
-    // union step waiting for the colour launch, and no block that may be F_BAND_STALE (the candidate riders read the band flags only)
-    fused = fuse_on && plain && m->p.projective_layer_type == 0 && m->p.esdf_mode == 0 && m->p.esdf_propagation == 0 && !m->import_pending && !m->lidar_integrated && m->capacity <= (1ll << 24);
+    // TSDF mapper (with or without a freespace layer), 2-D ESDF by the exact transform (the marking pass / distance transform that ride are the
+    // 2-D ones), no multi-GPU union step waiting for the colour launch, and no block that may be F_BAND_STALE (the candidate riders read the
+    // band flags only)
+    fused = fuse_on && m->p.projective_layer_type != 1 && m->p.esdf_mode == 0 && m->p.esdf_propagation == 0 && !m->import_pending && !m->lidar_integrated && m->capacity <= (1ll << 24);
     // (a distance transform armed outside the pipeline must precede the marking pass that rides in this launch: its own launch, rare)
     if (fused && edt_wg) { m->edt_pending = true; edt_wg = 0; if (m->flush_edt()) return NVBX_E_DEVICE; }
     m->pipelined_order = true; const int rc = m->pending_color_trace_rider(&tr); if (rc) { m->pipelined_order = false; return rc; }
@@ -967,14 +968,15 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
       const int64_t c_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[3], __ATOMIC_RELAXED));         // candidates of the last colour frame the GPU has finished
       const int cgrid = (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, 1024), ((c_hint + c_hint / 4 + 64 + 7) / 8) * 8));
       const dim3 g((unsigned)(n_edt + grid + cgrid));
+#define NVBX_FUSED_LAUNCH(PIX, PLAIN, FC) NVBX_LAUNCH(m, (k_integrate_tsdf_color<Img, PIX, NB, PLAIN>), g, dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, \
+        m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (int32_t)grid, FC, (const float*)m->synth, f_srows, f_scols, cand, cand_idx, n_edt, ea_edt)
       if (NB > 1 || f_kind == 0) {
-        NVBX_LAUNCH(m, (k_integrate_tsdf_color<Img, PixRgb8, NB>), g, dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, m->mesh_list_live(), m->view_export,
-                    (int32_t)m->view_export_cap, spec_lanes, (int32_t)grid, fsc, (const float*)m->synth, f_srows, f_scols, cand, cand_idx, n_edt, ea_edt);
+        if (plain) NVBX_FUSED_LAUNCH(PixRgb8, true, fsc); else NVBX_FUSED_LAUNCH(PixRgb8, false, fsc);
       } else if constexpr (NB == 1) {
         FrameSetC<PixBgra8, 1> fc; memcpy(&fc, &fsc, sizeof(fc));       // (one layout, color.hip static_assert)
-        NVBX_LAUNCH(m, (k_integrate_tsdf_color<Img, PixBgra8, 1>), g, dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, m->mesh_list_live(), m->view_export,
-                    (int32_t)m->view_export_cap, spec_lanes, (int32_t)grid, fc, (const float*)m->synth, f_srows, f_scols, cand, cand_idx, n_edt, ea_edt);
+        if (plain) NVBX_FUSED_LAUNCH(PixBgra8, true, fc); else NVBX_FUSED_LAUNCH(PixBgra8, false, fc);
       }
+#undef NVBX_FUSED_LAUNCH
     }
   } else
   if (plain) NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor, NB, true>), dim3(grid), dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
