@@ -151,6 +151,17 @@ class Timer:
         return float(np.median(dts)), dts, first
 
 
+def complete_loops(tags, dts, nu, steps):
+    """Exploring bookkeeping: tags[i] = position in the loop over the nu unique poses at which timed block i started (0 = the map had just been
+    emptied), dts[i] = its duration.  -> (blocks per loop, indices of the blocks that started a loop, indices of the first blocks of COMPLETE
+    loops, durations of all blocks of complete loops -- or of every block if no loop was completed)."""
+    per_loop = max(1, nu // steps)
+    starts = [i for i, t in enumerate(tags) if t == 0]
+    whole = [i for i in starts if i + per_loop <= len(dts) and all(tags[i + j] == j * steps for j in range(per_loop))]
+    kept = [dts[i + j] for i in whole for j in range(per_loop)] or list(dts)
+    return per_loop, starts, whole, kept
+
+
 def block_stats(dts, steps):
     """per-step milliseconds of the timed blocks: median (the reported figure), mean, p99, min / max, how many blocks, total timed"""
     v = np.asarray(dts) / steps * 1e3
@@ -612,10 +623,7 @@ def main_camera(args):
         tags.append(loop_pos[0])
         loop_pos[0] += args.steps
     dt, dts, base = tm.run(step, barrier, args.steps, args.warmup, before_block=fresh_map)
-    per_loop = max(1, nu // args.steps)
-    starts = [i for i, t in enumerate(tags) if t == 0]
-    whole = [i for i in starts if i + per_loop <= len(dts) and all(tags[i + j] == j * args.steps for j in range(per_loop))]
-    kept = [dts[i + j] for i in whole for j in range(per_loop)] or list(dts)
+    per_loop, starts, whole, kept = complete_loops(tags, dts, nu, args.steps)
     dt = float(np.sum(kept)) / len(kept)                 # mean block of the complete loops
     dt_first = float(np.median([dts[i] for i in starts]))
     ms_per_step = dt / args.steps * 1e3

@@ -1,0 +1,56 @@
+"""bench.py's pure helpers (no GPU): kernel-name parsing, the SURVEY 8d byte formulas -- in particular that the fused launches of the
+two-launch pipeline account for exactly the work of the classic launches they replace --, block statistics and the exploring bookkeeping."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+COUNTS = {"tsdf_blocks_in_view": 310.0, "color_blocks_updated": 240.0, "blocks_allocated": 1650.0, "esdf_columns_marked": 120.0, "esdf_blocks_swept": 108.0,
+          "mesh_blocks_updated": 300.0, "mesh_vertices": 21000.0, "mesh_triangles": 14000.0}
+R, C = 480, 640
+
+
+def test_kernel_name_parsing():
+    assert bench.short(" k_mark_view<Img, Sensor, NB> ") == "k_mark_view"
+    assert bench.short("void k_integrate_tsdf_color<nvbx::DepthF32, nvbx::PixRgb8, 1, true>(nvbx::DMap, ...)") == "k_integrate_tsdf_color"
+    assert bench.short("k_esdf_edt(nvbx::DMap, nvbx::EsdfArgs)") == "k_esdf_edt"
+
+
+def test_fused_launches_account_for_the_work_they_replace():
+    ab = lambda k, **kw: bench.algorithmic_bytes(k, COUNTS, R, C, **kw)
+    classic = ab("k_mark_view") + ab("k_sphere_trace") + ab("k_integrate_color") + ab("k_integrate_tsdf") + ab("k_esdf_edt")
+    three = ab("k_mark_view", trace_in_mark_view=True) + ab("k_integrate_color") + ab("k_integrate_tsdf") + ab("k_esdf_edt")
+    two = ab("k_mark_view", fused=True) + ab("k_integrate_tsdf_color", fused=True)
+    assert three == classic
+    # two launches: the same work + the candidate discovery (flags / Index3D of every allocated slot, one 16-byte record per candidate written
+    # by the riders and read by the colour workers)
+    extra = COUNTS["blocks_allocated"] * 16 + 2 * COUNTS["color_blocks_updated"] * 16
+    assert two == classic + extra
+    assert ab("k_integrate_tsdf_color") > ab("k_integrate_tsdf") > 0 and ab("k_integrate_color") == ab("k_esdf_mark") + (ab("k_integrate_color") - ab("k_esdf_mark")) > 0
+
+
+def test_lidar_launches_split_the_blocks():
+    c = dict(COUNTS, tsdf_blocks_in_view=112000.0, lidar_blocks_beam_centric=68000.0)
+    dense_only = bench.algorithmic_bytes("k_integrate_tsdf", dict(c, lidar_blocks_beam_centric=0.0), 64, 1024)
+    dense = bench.algorithmic_bytes("k_integrate_tsdf", c, 64, 1024)
+    sparse = bench.algorithmic_bytes("k_lidar_sparse", c, 64, 1024)
+    assert dense_only - dense == 68000 * 4096 * 2          # the blocks the beam-centric launch takes are not credited to the dense one
+    assert 0 < sparse < 68000 * 4096                       # ... and cost it a fraction of a block each
+
+
+def test_block_stats_and_exploring_bookkeeping():
+    st = bench.block_stats([0.002, 0.004, 0.003], 100)
+    assert st["blocks"] == 3 and st["median"] == 0.03 and st["min"] == 0.02 and st["max"] == 0.04 and abs(st["timed_ms_total"] - 9.0) < 1e-9
+    # driver-like: 20 steps per block, 200 unique poses -> 10 blocks per loop; the third loop was cut short and does not count
+    tags = [20 * (i % 10) for i in range(27)]
+    dts = [1.0 + 0.5 * (t == 0) for t in tags]
+    per_loop, starts, whole, kept = bench.complete_loops(tags, dts, 200, 20)
+    assert per_loop == 10 and starts == [0, 10, 20] and whole == [0, 10] and len(kept) == 20 and abs(sum(kept) - 21.0) < 1e-9
+    # one block per loop (K = nu), and K > nu (every block starts from an empty map)
+    assert bench.complete_loops([0, 0, 0], [1.0, 2.0, 3.0], 200, 200) == (1, [0, 1, 2], [0, 1, 2], [1.0, 2.0, 3.0])
+    assert bench.complete_loops([0, 0], [1.0, 2.0], 200, 500)[3] == [1.0, 2.0]
+    # no loop completed: every block counts
+    assert bench.complete_loops([0, 20], [1.0, 2.0], 200, 20)[3] == [1.0, 2.0]
