@@ -377,6 +377,7 @@ def main_decay(args):
     # cross-frame pipelining on the static mapper: the frame's first call, detect_dynamics, leaves held-back work alone, so the
     # colour frame / ESDF update of frame i are carried out by integrateDepth(i + 1) in two launches
     gs.set_color_deferral(not args.no_color_deferral)
+    gd.set_color_deferral(not args.no_color_deferral)       # (an occupancy mapper has no colour: its updateEsdf alone is held back -- marking pass and distance transform ride in its next depth launches)
     eye = np.eye(4, dtype=np.float32)
     mask = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
     un = torch.empty((rows, cols), dtype=torch.float32, device=dev); ma = torch.empty_like(un)

@@ -207,6 +207,8 @@ int nvbx_flush(nvbx_mapper* m);
  * hash, view marking inserts entries whose blocks are all-zero = unobserved).  EVERY other entry point (queries, synchronize / flush, batches,
  * LiDAR, mesh, decay, clearing, another integrate_color, ...) first carries the held-back calls out exactly as they would have run at call
  * time, so results -- map contents, ESDF, views, every query -- are bit-identical to the undeferred sequence (tests/test_gpu_pipeline.py).
+ * With the switch on, an nvbx_update_esdf that follows a depth frame WITHOUT a colour frame in between is held back the same way and carried
+ * out by the next camera depth frame (marking pass in its view-marking launch, distance transform in its TSDF-update launch).
  * CONTRACT (the caller-lifetime rule this buys the launch with): the colour image passed to nvbx_integrate_color must stay valid and
  * UNCHANGED until the next call into this mapper has returned that either consumes or flushes the frame -- any call except
  * nvbx_detect_dynamics, nvbx_remove_small_components, nvbx_split_depth_by_mask and nvbx_set_time_ms, which leave held-back work alone

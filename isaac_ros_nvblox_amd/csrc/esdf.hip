@@ -169,7 +169,10 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
   // colour deferral (nvbx_mapper_set_color_deferral): while a colour frame is held back this update is held back behind it -- its
   // marking pass rides in that colour launch; both are carried out by the next integrateDepth (pipelined) or by whatever entry point
   // comes first (join_side -> replay_deferred, in call order)
-  if (m->color_pending.on && !m->replaying && m->p.esdf_propagation == 0 && !m->use_side && m->defer_edt) { m->esdf_update_pending = true; return NVBX_OK; }
+  // (... or, with the switch on and no colour frame around, behind nothing: the next camera depth frame carries it alone -- depth-only hosts,
+  //  occupancy mappers; nvbx_mapper::esdf_only_carry)
+  if ((m->color_pending.on || (m->color_deferral && !m->pipelined_order && !m->import_pending)) && !m->replaying && m->p.esdf_propagation == 0 && !m->use_side && m->defer_edt) {
+    m->esdf_update_pending = true; return NVBX_OK; }
   if (!m->replaying && !m->pipelined_order && m->replay_deferred()) return NVBX_E_DEVICE;
   // a distance transform still held back by the PREVIOUS update goes first: this update's marking pass overwrites the masks
   // and the parity-indexed window record it reads, and edt_args holds one update only (two updates back to back)

@@ -148,6 +148,10 @@ struct nvbx_mapper {
   // ESDF-dirty list): the held-back distance transform, union step, colour frame and ESDF update stay held back (nvbx_detect_dynamics: TSDF +
   // freespace reads only -- the dynamic-mapping frame starts with it, and flushing there would cost the pipeline every frame)
   int join_side_keeping_held();
+  // a held-back updateEsdf with NO colour frame in front of it (colour deferral on, the caller integrates no colour: depth-only hosts, occupancy
+  // mappers) that the next camera launch can carry in two-launch order: marking pass in the view-marking launch, distance transform in the
+  // TSDF-update launch
+  bool esdf_only_carry() const { return esdf_update_pending && !color_pending.on && p.esdf_mode == 0 && p.esdf_propagation == 0 && !import_pending && !use_side && defer_edt; }
   int pending_color_trace_rider(void* trace_rider_out);   // color.hip: set the held-back frame(s) up; the sphere tracing as a nvbx::TraceRiderT<1> (one frame) / <MAX_BATCH> (a batch)
   int launch_pending_color_after_trace();
 // -- fused colour + TSDF launch of the pipelined order (two launches per frame)

@@ -904,24 +904,30 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   TraceRiderT<NB> tr{};
   bool plain = true;
   for (int c = 0; c < fs.n; c++) plain = plain && frame_is_plain(fs.f[c]);
-  const bool pipelined = Sensor::kThreads == 256 && m->color_pending.on && ((NB == 1) == (m->color_pending.n == 1));     // (one frame carries a frame, a batch a batch)
+  const bool has_color = m->color_pending.on;
+  // (one frame carries a frame, a batch a batch; a held-back updateEsdf WITHOUT a colour frame -- depth-only and occupancy mappers -- is carried by
+  //  any camera launch: integrate_cameras has checked that the two-launch order applies, nvbx_mapper::esdf_only_carry)
+  const bool pipelined = Sensor::kThreads == 256 && (has_color ? ((NB == 1) == (m->color_pending.n == 1)) : m->esdf_update_pending);
   bool fused = false;
   if (pipelined) {
     static const int fuse_on = getenv("NVBX_FUSE_COLC") ? atoi(getenv("NVBX_FUSE_COLC")) : 1;      // (A/B: 0 = three launches per frame)
     // TSDF mapper (with or without a freespace layer), 2-D ESDF by the exact transform (the marking pass / distance transform that ride are the
     // 2-D ones), no multi-GPU union step waiting for the colour launch, and no block that may be F_BAND_STALE (the candidate riders read the
     // band flags only)
-    fused = fuse_on && m->p.projective_layer_type != 1 && m->p.esdf_mode == 0 && m->p.esdf_propagation == 0 && !m->import_pending && !m->lidar_integrated && m->capacity <= (1ll << 24);
+    fused = has_color ? (fuse_on && m->p.projective_layer_type != 1 && m->p.esdf_mode == 0 && m->p.esdf_propagation == 0 && !m->import_pending && !m->lidar_integrated && m->capacity <= (1ll << 24))
+                      : true;      // (no colour: no candidates, no band flags -- esdf_only_carry has checked the rest)
     // (a distance transform armed outside the pipeline must precede the marking pass that rides in this launch: its own launch, rare)
     if (fused && edt_wg) { m->edt_pending = true; edt_wg = 0; if (m->flush_edt()) return NVBX_E_DEVICE; }
-    m->pipelined_order = true; const int rc = m->pending_color_trace_rider(&tr); if (rc) { m->pipelined_order = false; return rc; }
+    m->pipelined_order = true;
+    if (has_color) { const int rc = m->pending_color_trace_rider(&tr); if (rc) { m->pipelined_order = false; return rc; } }
     // riders before or after the tiles (A/B: NVBX_MARK_TILES_FIRST = 0 / 1).  One frame: tiles first (15.2 vs 15.8 us).  A batch of 8: riders first
     // (32.4 vs 42.0 us) -- its 2 688 single-wavefront tile workgroups, each holding its LDS key set, take most of the workgroup slots, and
     // sphere-tracing workgroups dispatched behind them start when the tiles are done: the launch took the SUM of its parts.
     static const int tiles_first_env = getenv("NVBX_MARK_TILES_FIRST") ? atoi(getenv("NVBX_MARK_TILES_FIRST")) : -1;
     const bool tiles_first = tiles_first_env >= 0 ? tiles_first_env != 0 : NB == 1;
     if (tiles_first) tr.n_tile_wg = tiles;
-    if (fused) {
+    if (fused && !has_color) m->pending_marking_args(&tr.n_mark_wg, &ea);
+    if (fused && has_color) {
       if (m->ensure_fuse_buffers()) { m->pipelined_order = false; return NVBX_E_DEVICE; }
       const int64_t hw_seen = std::max<int64_t>(1, __atomic_load_n(&m->h_mirror[1], __ATOMIC_RELAXED));
       tr.n_scan_wg = (int32_t)std::min<int64_t>(256, 8 * ((hw_seen + hw_seen / 4 + 64 + 2047) / 2048));      // 256 slots per workgroup and pass; a hint only (the riders grid-stride)
@@ -939,7 +945,7 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
     // of the update keeps it -- EsdfArgs), then updateEsdf (which only arms the next held-back EDT: the marking pass has been launched)
     if (!fused) m->premark_consumed = false;
     int rc = NVBX_OK;
-    if (fused) rc = m->pending_color_fused_args(&fsc, &f_kind, &f_srows, &f_scols);
+    if (fused) { if (has_color) rc = m->pending_color_fused_args(&fsc, &f_kind, &f_srows, &f_scols); }
     else rc = m->launch_pending_color_after_trace();
     if (rc == NVBX_OK && m->esdf_update_pending) { m->esdf_update_pending = false; rc = nvbx_update_esdf(m); }
     m->pipelined_order = false;
@@ -966,7 +972,7 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
       const int4* cand = tr.cand;
       const int32_t cand_idx = tr.cand_cnt_idx;
       const int64_t c_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[3], __ATOMIC_RELAXED));         // candidates of the last colour frame the GPU has finished
-      const int cgrid = (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, 1024), ((c_hint + c_hint / 4 + 64 + 7) / 8) * 8));
+      const int cgrid = !has_color ? 0 : (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, 1024), ((c_hint + c_hint / 4 + 64 + 7) / 8) * 8));      // (no colour frame: update + distance transform only)
       const dim3 g((unsigned)(n_edt + grid + cgrid));
 #define NVBX_FUSED_LAUNCH(PIX, PLAIN, FC) NVBX_LAUNCH(m, (k_integrate_tsdf_color<Img, PIX, NB, PLAIN>), g, dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, \
         m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (int32_t)grid, FC, (const float*)m->synth, f_srows, f_scols, cand, cand_idx, n_edt, ea_edt)
@@ -1036,7 +1042,7 @@ static int integrate_cameras(nvbx_mapper* m, int32_t n, const Img* imgs, int32_t
   const bool dilate_first = m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0;
   // held-back integrateColor / updateEsdf that this call cannot carry out in pipelined order are replayed NOW, with the whole held-back
   // state in view (the replayed calls launch / re-arm the held-back EDT themselves) -- before the EDT is hidden from join_side below
-  const bool carry = !dilate_first && m->color_pending.on && ((NB == 1) == (m->color_pending.n == 1));      // this call can carry the held-back calls out in pipelined order
+  const bool carry = !dilate_first && (m->color_pending.on ? ((NB == 1) == (m->color_pending.n == 1)) : m->esdf_only_carry());      // this call can carry the held-back calls out in pipelined order
   if (!carry && m->replay_deferred()) return NVBX_E_DEVICE;
   { const bool pend = m->edt_pending, ipend = m->import_pending; m->edt_pending = false; m->import_pending = false;
     // (join_side would launch a held-back EDT / union step; the EDT rides in k_mark_view instead, the union step stays held back

@@ -208,6 +208,7 @@ def test_dynamic_mapping_frame_keeps_the_pipeline(oracle_mod, hip_lib):
         mk = lambda prm, cap: M.Mapper(M.default_params(**prm), block_capacity=cap, stream=stream.cuda_stream)
         gs_a, gd_a, gs_b, gd_b = mk(fs, 1 << 14), mk(occ, 1 << 13), mk(fs, 1 << 14), mk(occ, 1 << 13)
         gs_b.set_color_deferral(True); gs_b.set_profiling(True)
+        gd_b.set_color_deferral(True); gd_b.set_profiling(True)       # (no colour on the occupancy mapper: its updateEsdf alone is held back and carried)
         eye = np.eye(4, dtype=np.float32)
         kept = []
         t = 0
@@ -252,4 +253,6 @@ def test_dynamic_mapping_frame_keeps_the_pipeline(oracle_mod, hip_lib):
         prof = gs_b.profile()
         n_trace = sum(v["count"] for k_, v in prof.items() if "k_sphere_trace" in k_)
         n_mark = sum(v["count"] for k_, v in prof.items() if "k_mark_view" in k_)
+        pd = gd_b.profile()
+        assert sum(v["count"] for k_, v in pd.items() if "k_esdf_mark" in k_) <= 8 and sum(v["count"] for k_, v in pd.items() if "k_integrate_tsdf_color" in k_) >= 10, {k_: v["count"] for k_, v in pd.items()}
         assert n_mark >= 20 and n_trace <= 8, ({k_: v["count"] for k_, v in prof.items()}, n_dyn)      # most colour frames' sphere tracing rode in a view-marking launch
