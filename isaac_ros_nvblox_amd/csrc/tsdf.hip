@@ -901,6 +901,8 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   // Or TWO (fused, k_integrate_tsdf_color above): the colour frame's candidate blocks are discovered and the ESDF marking pass runs as
   // riders of this view-marking launch too, and colour integration, the update's distance transform and this frame's TSDF update share
   // the second launch.
+  // A held-back updateEsdf with NO colour frame in front (depth-only hosts, occupancy mappers) is carried the same way: marking pass here,
+  // distance transform in the second launch, no colour workgroups.
   TraceRiderT<NB> tr{};
   bool plain = true;
   for (int c = 0; c < fs.n; c++) plain = plain && frame_is_plain(fs.f[c]);
