@@ -16,15 +16,22 @@
 #include <cstring>
 #include "nvbx_mapper.h"
 #include "nvbx_esdf_mark.h"
+#include "nvbx_esdf_edt.h"
 #include "nvbx_sphere_trace.h"
 #include "nvbx_color_worker.h"
 
 using namespace nvbx;
 
 
+// (n_mark_wg > 0: behind the n_trace_wg sphere-tracing workgroups, the ESDF site marking of a held-back updateEsdf -- first wavefront only; both
+//  read the TSDF only.  Used when a held-back colour frame AND its updateEsdf are replayed together: nvbx_mapper::replay_pair)
 template <int NB, int RAY_LANES>
 __global__ __launch_bounds__(256) void k_sphere_trace(DMap m, PoseSet<NB> poses, float* synth_all, int32_t srows, int32_t scols, int32_t max_steps,
-                                                      float max_len, float eps_m) {
+                                                      float max_len, float eps_m, int32_t n_trace_wg, int32_t n_mark_wg, EsdfArgs ea) {
+  if ((int32_t)blockIdx.x >= n_trace_wg) {
+    if (threadIdx.x < 64) { const int w = (int)blockIdx.x - n_trace_wg; esdf_mark_worker(m, ea, w, n_mark_wg); esdf_mark_pass_done(m, ea, n_mark_wg, w); }
+    return;
+  }
   sphere_trace_worker<NB, RAY_LANES>(m, poses, synth_all, srows, scols, max_steps, max_len, eps_m, (int)blockIdx.x);
 }
 
@@ -35,7 +42,11 @@ __global__ __launch_bounds__(256) void k_sphere_trace(DMap m, PoseSet<NB> poses,
 // (7 waves/SIMD at 67 VGPRs; forcing the eighth -- amdgpu_waves_per_eu(8, 8), 63 VGPRs -- was measured: 9.5 -> 10.3 us, rejected)
 template <typename Pix, int NB>
 __global__ __launch_bounds__(512) void k_integrate_color(DMap m, FrameSetC<Pix, NB> fs, const float* synth_all, int32_t srows, int32_t scols,
-                                                         int32_t mesh_list, int32_t n_mark_wg, EsdfArgs ea, ImportArgs imp) {
+                                                         int32_t mesh_list, int32_t n_mark_wg, EsdfArgs ea, ImportArgs imp, int32_t n_edt_wg) {
+  // (n_edt_wg > 0, then n_mark_wg = 0: the distance transform of the held-back updateEsdf whose marking pass rode in the sphere-tracing launch
+  //  -- nvbx_mapper::replay_pair; it touches the ESDF layer only; `ea` is its argument)
+  __shared__ __align__(16) unsigned char edt_smem[sizeof(EdtShared)];
+  if ((int32_t)blockIdx.x < n_edt_wg) { esdf_edt_worker<512>(m, ea, (int)blockIdx.x, n_edt_wg, reinterpret_cast<EdtShared*>(edt_smem)); return; }
   if ((int32_t)blockIdx.x < n_mark_wg) {
     if (threadIdx.x < 64) {
       // workers [0, n_own) re-mark the mapper's own dirty blocks, workers [n_own, n_mark_wg) the peers' gathered lists
@@ -46,7 +57,7 @@ __global__ __launch_bounds__(512) void k_integrate_color(DMap m, FrameSetC<Pix, 
     }
     return;
   }
-  color_integrate_worker<Pix, NB>(m, fs, synth_all, srows, scols, mesh_list, (int32_t)blockIdx.x - n_mark_wg, (int32_t)gridDim.x - n_mark_wg);
+  color_integrate_worker<Pix, NB>(m, fs, synth_all, srows, scols, mesh_list, (int32_t)blockIdx.x - n_mark_wg - n_edt_wg, (int32_t)gridDim.x - n_mark_wg - n_edt_wg);
 }
 
 // lanes per ray of the sphere-tracing launch for a batch of n cameras (1, 2, 4 or 8)
@@ -102,17 +113,18 @@ static int sphere_trace_workgroups(int rl, int32_t srows, int32_t scols, int n) 
   return NSH * ((st_patches + NSH - 1) / NSH) * n;
 }
 template <int NB>
-static int color_launch_trace(nvbx_mapper* m, const PoseSet<NB>& ps, int32_t n, int32_t srows, int32_t scols) {
+static int color_launch_trace(nvbx_mapper* m, const PoseSet<NB>& ps, int32_t n, int32_t srows, int32_t scols, int32_t mark_wg = 0, const EsdfArgs& ea = EsdfArgs{}) {
   const int rl = sphere_trace_lanes(n);
-  const dim3 st_grid((unsigned)sphere_trace_workgroups(rl, srows, scols, n));
+  const int32_t n_trace = sphere_trace_workgroups(rl, srows, scols, n);
+  const dim3 st_grid((unsigned)(n_trace + mark_wg));
 #define NVBX_ST_LAUNCH(RL) NVBX_LAUNCH(m, (k_sphere_trace<NB, RL>), st_grid, dim3(256), m->d, ps, m->synth, srows, scols, m->p.sphere_tracing_max_steps, \
-                                       m->p.sphere_tracing_max_ray_length_m, m->p.sphere_tracing_surface_eps_vox * m->p.voxel_size)
+                                       m->p.sphere_tracing_max_ray_length_m, m->p.sphere_tracing_surface_eps_vox * m->p.voxel_size, n_trace, mark_wg, ea)
   if (rl == 8) NVBX_ST_LAUNCH(8); else if (rl == 4) NVBX_ST_LAUNCH(4); else if (rl == 2) NVBX_ST_LAUNCH(2); else NVBX_ST_LAUNCH(1);
 #undef NVBX_ST_LAUNCH
   return NVBX_OK;
 }
 template <typename Pix, int NB>
-static int color_launch_integrate(nvbx_mapper* m, const FrameSetC<Pix, NB>& fs, int32_t srows, int32_t scols) {
+static int color_launch_integrate(nvbx_mapper* m, const FrameSetC<Pix, NB>& fs, int32_t srows, int32_t scols, bool take_edt = false) {
   const int grid = (int)std::min<int64_t>(m->capacity, 1024);     // one resident batch of 512-thread workgroups
   // ESDF site marking of the blocks dirtied since the last marking pass rides in this launch (256 extra single-wavefront
   // workers): it reads only the TSDF, like the colour pass, and a following updateEsdf then needs the EDT kernel only
@@ -130,7 +142,10 @@ static int color_launch_integrate(nvbx_mapper* m, const FrameSetC<Pix, NB>& fs, 
       mark_wg += imp.n_wg; m->import_pending = false;
     }
   }
-  NVBX_LAUNCH(m, (k_integrate_color<Pix, NB>), dim3(grid + mark_wg), dim3(512), m->d, fs, m->synth, srows, scols, m->mesh_list_live(), (int32_t)mark_wg, ea, imp);
+  // (replay_pair: the distance transform the held-back updateEsdf has just armed rides here -- its marking pass rode in the sphere-tracing launch)
+  int32_t n_edt = 0;
+  if (take_edt && mark_wg == 0 && m->edt_pending) { n_edt = 256; ea = m->edt_args; m->edt_pending = false; }
+  NVBX_LAUNCH(m, (k_integrate_color<Pix, NB>), dim3(grid + mark_wg + n_edt), dim3(512), m->d, fs, m->synth, srows, scols, m->mesh_list_live(), (int32_t)mark_wg, ea, imp, n_edt);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }
@@ -210,6 +225,29 @@ static int launch_pending_integrate(nvbx_mapper* m, const nvbx_mapper::ColorPend
   FrameSetC<Pix, NB> fs; PoseSet<NB> ps; int32_t srows = 0, scols = 0;
   const int rc = pending_setup<Pix, NB>(m, c, &fs, &ps, &srows, &scols); if (rc) return rc;
   return color_launch_integrate<Pix, NB>(m, fs, srows, scols);
+}
+// A held-back colour frame AND the updateEsdf behind it, replayed together (a drain: synchronize, a query, any other entry point) in TWO
+// launches instead of three: {sphere tracing || ESDF site marking} (both read the TSDF only), then {colour integration || distance transform}.
+// The same kernels as the classic replay, the same order of dependent steps, the same map.
+template <typename Pix, int NB>
+static int replay_pair_t(nvbx_mapper* m, const nvbx_mapper::ColorPending& c) {
+  { const int rc = color_precheck(m, c.n, c.rows, c.cols, c.T); if (rc) return rc; }
+  if (m->flush_edt()) return NVBX_E_DEVICE;      // an older held-back distance transform precedes the marking pass (it reads the masks)
+  FrameSetC<Pix, NB> fs; PoseSet<NB> ps; int32_t srows = 0, scols = 0;
+  { const int rc = pending_setup<Pix, NB>(m, c, &fs, &ps, &srows, &scols); if (rc) return rc; }
+  int32_t mark_wg = 0; EsdfArgs ea{};
+  m->pending_marking_args(&mark_wg, &ea);        // (classic flags: the distance transform below empties the list)
+  { const int rc = color_launch_trace<NB>(m, ps, c.n, srows, scols, mark_wg, ea); if (rc) return rc; }
+  { const int rc = nvbx_update_esdf(m); if (rc) return rc; }      // arms the distance transform (launches the marking pass itself if it could not ride)
+  return color_launch_integrate<Pix, NB>(m, fs, srows, scols, true);
+}
+bool nvbx_mapper::replay_pair_applies() const {
+  return color_pending.on && esdf_update_pending && p.projective_layer_type != 1 && p.esdf_mode == 0 && p.esdf_propagation == 0 && !use_side && defer_edt && !import_pending;
+}
+int nvbx_mapper::replay_pair() {
+  const ColorPending c = color_pending; color_pending.on = false; esdf_update_pending = false;
+  if (c.n > 1) return replay_pair_t<PixRgb8, MAX_BATCH>(this, c);
+  return c.kind == 0 ? replay_pair_t<PixRgb8, 1>(this, c) : replay_pair_t<PixBgra8, 1>(this, c);
 }
 int nvbx_mapper::launch_pending_color_after_trace() {
   const ColorPending c = color_pending; color_pending.on = false;

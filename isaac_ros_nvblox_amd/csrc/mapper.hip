@@ -913,6 +913,7 @@ int nvbx_mapper::replay_deferred() {
   if (!color_pending.on && !esdf_update_pending) return NVBX_OK;
   replaying = true;
   int rc = NVBX_OK;
+  if (replay_pair_applies()) { rc = replay_pair(); replaying = false; return rc == NVBX_OK ? NVBX_OK : NVBX_E_DEVICE; }
   if (color_pending.on) {
     const ColorPending c = color_pending; color_pending.on = false;
     if (c.n > 1) rc = nvbx_integrate_color_batch(this, c.n, reinterpret_cast<const uint8_t* const*>(c.imgs), c.rows, c.cols, c.T, c.cams);

@@ -154,6 +154,8 @@ struct nvbx_mapper {
   bool esdf_only_carry() const { return esdf_update_pending && !color_pending.on && p.esdf_mode == 0 && p.esdf_propagation == 0 && !import_pending && !use_side && defer_edt; }
   int pending_color_trace_rider(void* trace_rider_out);   // color.hip: set the held-back frame(s) up; the sphere tracing as a nvbx::TraceRiderT<1> (one frame) / <MAX_BATCH> (a batch)
   int launch_pending_color_after_trace();
+  bool replay_pair_applies() const;  // color.hip: a held-back colour frame + updateEsdf can be replayed in two launches (replay_pair)
+  int replay_pair();
 // -- fused colour + TSDF launch of the pipelined order (two launches per frame)
   int4* color_cand = nullptr;        // [2][fuse_cap] candidate records {slot, block index} of the held-back colour frame (parity cand_parity)
   int64_t fuse_cap = 0;
