@@ -242,7 +242,8 @@ static int replay_pair_t(nvbx_mapper* m, const nvbx_mapper::ColorPending& c) {
   return color_launch_integrate<Pix, NB>(m, fs, srows, scols, true);
 }
 bool nvbx_mapper::replay_pair_applies() const {
-  return color_pending.on && esdf_update_pending && p.projective_layer_type != 1 && p.esdf_mode == 0 && p.esdf_propagation == 0 && !use_side && defer_edt && !import_pending;
+  static const int on = getenv("NVBX_REPLAY_PAIR") ? atoi(getenv("NVBX_REPLAY_PAIR")) : 1;      // (A/B: 0 = three classic launches)
+  return on && color_pending.on && esdf_update_pending && p.projective_layer_type != 1 && p.esdf_mode == 0 && p.esdf_propagation == 0 && !use_side && defer_edt && !import_pending;
 }
 int nvbx_mapper::replay_pair() {
   const ColorPending c = color_pending; color_pending.on = false; esdf_update_pending = false;

@@ -171,7 +171,8 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
   // comes first (join_side -> replay_deferred, in call order)
   // (... or, with the switch on and no colour frame around, behind nothing: the next camera depth frame carries it alone -- depth-only hosts,
   //  occupancy mappers; nvbx_mapper::esdf_only_carry)
-  if ((m->color_pending.on || (m->color_deferral && !m->pipelined_order && !m->import_pending)) && !m->replaying && m->p.esdf_propagation == 0 && !m->use_side && m->defer_edt) {
+  static const int esdf_only = getenv("NVBX_ESDF_ONLY_CARRY") ? atoi(getenv("NVBX_ESDF_ONLY_CARRY")) : 1;      // (A/B: 0 = an updateEsdf is held back behind a colour frame only)
+  if ((m->color_pending.on || (esdf_only && m->color_deferral && !m->pipelined_order && !m->import_pending)) && !m->replaying && m->p.esdf_propagation == 0 && !m->use_side && m->defer_edt) {
     m->esdf_update_pending = true; return NVBX_OK; }
   if (!m->replaying && !m->pipelined_order && m->replay_deferred()) return NVBX_E_DEVICE;
   // a distance transform still held back by the PREVIOUS update goes first: this update's marking pass overwrites the masks

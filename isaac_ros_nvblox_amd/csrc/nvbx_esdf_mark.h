@@ -9,12 +9,18 @@ namespace nvbx {
 // Dependent-access chain: {shard counts of the dirty list} -> {dirty slot} -> {flags, Index3D} -> {hash entries of the ESDF block and of the
 // TSDF z-band blocks, one per lane, in flight together} -> {column stamp exchange || TSDF column loads} -> store.
 // One list entry (one wavefront): re-mark the ESDF column of TSDF slot `tslot` (or of the ESDF slot itself if it is flagged REMARK).
-__device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_t tslot, int srec, int sh) {
+__device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_t tslot, int srec, int sh, bool from_dirty_list = false) {
   const int lane = threadIdx.x & 63;
   const int vx = lane & 7, vy = lane >> 3;
   const int nz = a.bz_hi - a.bz_lo + 1;                    // TSDF blocks spanned by the slice z band (<= 62)
   const uint32_t tflags = m.slot_flags[tslot];
   const int32_t bx = m.slot_index[3 * tslot], by = m.slot_index[3 * tslot + 1], bz = m.slot_index[3 * tslot + 2];
+  // An entry of the ESDF-dirty list names a slot that carried F_DIRTY_ESDF when it was appended (the flag is the list's de-duplication); a slot
+  // WITHOUT it has been freed since (decay, clearing) -- and may be handed out again at this very moment: the marking pass of a held-back update
+  // rides in the view-marking launch of the NEXT frame, whose tiles allocate.  The new block's dirtiness belongs to the next
+  // update (its TSDF update sets the flag one launch later), so the stale entry is skipped; found as ESDF columns the sequential order never
+  // creates when the new block was deallocated again before that update (tests/test_gpu_sequences.py, seed 3).
+  if (from_dirty_list && !(tflags & F_DIRTY_ESDF)) return;
   if (lane == 0) { atomicAnd(&m.slot_flags[tslot], ~F_DIRTY_ESDF); m.slot_consumed[tslot] = a.mark_pass; }
   // a dirty TSDF block of the z band dirties its column; an ESDF slot flagged F_ESDF_REMARK (a TSDF block of its band was
   // deallocated by decay) re-marks its own column
@@ -93,7 +99,7 @@ __device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg
   int32_t cnt = *shc_at(m, S_LIST_ESDF_DIRTY, sh_l, 0);
   if (cnt > (int32_t)m.capacity) cnt = (int32_t)m.capacity;
   const int srec = S_ESDF_REC + (int)(a.epoch & 1), sh = my_shard();
-  for (int32_t j = j0; j < cnt; j += per) esdf_mark_entry(m, a, (uint32_t)(j == j0 ? first : base[j]), srec, sh);
+  for (int32_t j = j0; j < cnt; j += per) esdf_mark_entry(m, a, (uint32_t)(j == j0 ? first : base[j]), srec, sh, true);
 }
 
 // A marking pass that empties the list it consumed (EsdfArgs::self_reset): every one of its `n_workers` wavefronts calls this when it is
