@@ -246,6 +246,87 @@ def cpu_sample(step_cpu, seconds, min_steps, unit, what, oracle):
             "sample": "%d %s, oracle/nvblox_oracle.c, OpenMP with %d threads" % (k, what, int(oracle.num_threads()))}
 
 
+def map_parity(M, g, o, oracle):
+    """The HIP map `g` against the checker map `o` (oracle.OracleMap) fed the same calls: block index sets (bit-exact), TSDF distance / weight
+    (north_star: 1e-4), colour (+-1 LSB) and colour weight, every ESDF voxel field (exact), the 2-D slice image (1e-4 m).  Test
+    infrastructure: called outside every timed region (bench.py's `parity` block, tests/test_gpu_round4.py)."""
+    out = {}
+    it, io = g.block_indices(M.LAYER_TSDF), o.block_indices(oracle.L_TSDF)
+    out["blocks"] = int(len(it)); out["blocks_checker"] = int(len(io))
+    out["index_sets_equal"] = bool(np.array_equal(it, io))
+    ok = out["index_sets_equal"]
+    if ok and len(it):
+        bg, _ = g.get_blocks(M.LAYER_TSDF, it)
+        bo = np.stack([o.get_block(oracle.L_TSDF, i) for i in io])
+        out["max_abs_tsdf"] = float(max(np.abs(bg["distance"].astype(np.float64) - bo["distance"]).max(), np.abs(bg["weight"].astype(np.float64) - bo["weight"]).max()))
+    ic, ico = g.block_indices(M.LAYER_COLOR), o.block_indices(oracle.L_COLOR)
+    out["color_blocks"] = int(len(ic)); out["color_index_sets_equal"] = bool(np.array_equal(ic, ico))
+    if out["color_index_sets_equal"] and len(ic):
+        bg, _ = g.get_blocks(M.LAYER_COLOR, ic)
+        bo = np.stack([o.get_block(oracle.L_COLOR, i) for i in ico])
+        out["max_color_lsb"] = int(max(np.abs(bg[f].astype(np.int32) - bo[f].astype(np.int32)).max() for f in ("r", "g", "b")))
+        out["max_abs_color_weight"] = float(np.abs(bg["weight"].astype(np.float64) - bo["weight"]).max())
+    ie, ieo = g.block_indices(M.LAYER_ESDF), o.block_indices(oracle.L_ESDF)
+    out["esdf_blocks"] = int(len(ie)); out["esdf_index_sets_equal"] = bool(np.array_equal(ie, ieo))
+    if out["esdf_index_sets_equal"] and len(ie):
+        bg, _ = g.get_blocks(M.LAYER_ESDF, ie)
+        bo = np.stack([o.get_block(oracle.L_ESDF, i) for i in ieo])
+        out["esdf_voxels_differing"] = int(sum(int((bg[f] != bo[f]).sum()) for f in ("squared_distance_vox", "parent_direction", "is_inside", "observed", "is_site")))
+    sg, ag = g.esdf_slice_image(); so, ao = o.esdf_slice_image()
+    out["slice_shape"] = [int(sg.shape[0]), int(sg.shape[1])]
+    out["slice_shapes_equal"] = bool(sg.shape == so.shape and np.array_equal(ag, ao))
+    if out["slice_shapes_equal"] and sg.size:
+        out["max_abs_slice_m"] = float(np.abs(sg.astype(np.float64) - so).max())
+    out["ok"] = bool(ok and out["color_index_sets_equal"] and out["esdf_index_sets_equal"] and out["slice_shapes_equal"] and
+                     out.get("max_abs_tsdf", 0.0) <= 1e-4 and out.get("max_color_lsb", 0) <= 1 and out.get("max_abs_color_weight", 0.0) <= 1e-4 and
+                     out.get("esdf_voxels_differing", 0) == 0 and out.get("max_abs_slice_m", 0.0) <= 1e-4)
+    return out
+
+
+def exploring_parity(M, g, gpu_step, drain, n_frames, checker_step, steps, oracle, threads=8):
+    """The sequence the headline times, run once more OUTSIDE the timed region and compared with the checker at its end: clear(), every pose
+    of the loop once (depth, colour, updateEsdf per frame through `gpu_step(k)`), a drain (`drain()`: what ends a timed block -- synchronize,
+    which replays whatever the mapper holds back) after every `steps` frames; then the CPU checker is fed the same frames in plain call order."""
+    g.clear()
+    for k in range(n_frames):
+        gpu_step(k)
+        if (k + 1) % steps == 0:
+            drain()
+    drain()
+    oracle.set_num_threads(min(threads, os.cpu_count() or 1))
+    o = oracle.OracleMap(copy_params(oracle, g.params))
+    t = time.perf_counter()
+    for k in range(n_frames):
+        checker_step(o, k)
+    out = map_parity(M, g, o, oracle)
+    out["steps_compared"] = int(n_frames); out["drain_every"] = int(steps); out["checker_s"] = round(time.perf_counter() - t, 2)
+    out["what"] = ("one more exploring loop exactly as timed (map emptied, %d steps of depth + colour + updateEsdf, a drain every %d steps) against "
+                   "oracle/nvblox_oracle.c fed the same frames in plain call order; outside the timed region" % (n_frames, steps))
+    return out
+
+
+def launch_command(n, argv, port=None):
+    """`python bench.py --gpus N ...` without WORLD_SIZE in the environment re-executes itself as N ranks, one per GPU:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ..."""
+    if port is None:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n)), "--master-addr", "127.0.0.1",
+            "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n, argv):
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = launch_command(n, argv)
+    if os.environ.get("NVBX_BENCH_LAUNCH_DRY") == "1":     # (tests: show the command, start nothing)
+        print(" ".join(cmd)); return 0
+    return subprocess.call(cmd, env=env)
+
+
 def init_dist(args):
     import torch
     import torch.distributed as dist
@@ -633,11 +714,16 @@ def main_camera(args):
         step(base + i)
     dt_rev, dts_rev, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 4, first=base + nu)
     ms_revisit = dt_rev / args.steps * 1e3
-    ms_classic = None
+    ms_classic = None; ms_classic_exploring = None
     if deferral and not args.profile_run:    # the same revisit blocks in the classic launch order, for the record
         g.set_color_deferral(False)
         dt_c, dts_c, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 4, first=base)
         ms_classic = dt_c / args.steps * 1e3
+        # ... and the EXPLORING figure in classic order: what a host that only swaps the library gets for the headline sequence
+        loop_pos[0] = 0; n_tags0 = len(tags)
+        dt_ce, dts_ce, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 2, before_block=fresh_map, first=0)
+        _, _, whole_c, kept_c = complete_loops(tags[n_tags0:], dts_ce, nu, args.steps)
+        ms_classic_exploring = float(np.sum(kept_c)) / len(kept_c) / args.steps * 1e3
         g.set_color_deferral(True)
 
     if rank != 0:
@@ -764,6 +850,24 @@ def main_camera(args):
         if multicam:
             cpu["value"] = round(cpu["value"] * ncam, 3); cpu["unit"] = "frames/s"
 
+    # the timed sequence once more, outside the timed region, against the checker (the 200-pose exploring loop with clear(),
+    # deferral and a drain per block had never been compared end to end)
+    parity = None
+    if not args.no_parity:
+        import oracle
+
+        def checker_step(o, k):
+            for ci in range(ncam):
+                d, c_, T = host_cams[ci][k % nu]; o.integrate_depth(d, T, cam)
+            for ci in range(ncam):
+                d, c_, T = host_cams[ci][k % nu]; o.integrate_color(c_, T, cam)
+            o.update_esdf()
+
+        def drain_local():
+            g.synchronize(); torch.cuda.synchronize(dev)
+        parity = exploring_parity(M, g, lambda k: step(k, exchange=False), drain_local, nu, checker_step, args.steps, oracle)
+        parity["mode"] = "color_deferral" if deferral else "classic"
+
     out = {
         "metric": "frames/s, TSDF+Color+ESDF integrate per frame, synthetic Replica-like 640x480 @0.05m",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": len(dts),
@@ -773,8 +877,11 @@ def main_camera(args):
                                "synthetic Replica-like room (SURVEY 8d), 640x480 depth+colour, 0.05 m voxels, "
                                "fuser.yaml params, TSDF+Color+ESDF every frame (mesh timed separately)",
                    "cameras_per_gpu": ncam, "parallelism": ("one camera per GPU, RCCL all-gather of per-voxel measurements, one fused map on every rank" if fuse else "one camera per GPU, RCCL all-gather of dirty block indices") if world > 1 else "single GPU",
-                   "unique_frames": nu},
+                   "unique_frames": nu,
+                   "mode": ("color_deferral: nvbx_mapper_set_color_deferral(1) -- OPT-IN, the nvblox:: facade leaves it off (Mapper::setColorIntegrationDeferred); "
+                            "a host that only swaps the library runs the classic order, quoted as ms_per_step_classic_order") if deferral else "classic launch order (the facade default)"},
         "ms_per_frame": round(ms_per_step / ncam, 4),
+        "ms_per_step_classic_order": (round(ms_classic_exploring, 4) if ms_classic_exploring else (None if deferral else round(ms_per_step, 4))),
         "timing": {"value_is": "exploring: the map is emptied at the start of every loop over the %d unique poses; timed blocks of %d steps tile the loop "
                                "(%d per loop), every pose is integrated once per map (allocation inside the timed region); mean over the %d complete "
                                "loops timed" % (nu, args.steps, per_loop, len(whole)),
@@ -804,6 +911,7 @@ def main_camera(args):
         "kernels": kernels_json(kern),
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "parity": parity,
     }
     if sweep is not None:
         out["camera_sweep_ms_per_step"] = sweep
@@ -820,6 +928,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=48, help="minimum number of frames of the same workload timed on the CPU oracle")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline keeps integrating (cycling the same frames) until this much CPU wall time has passed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="camera / multicam: skip the end-state comparison of the timed sequence with the checker (outside the timed region)")
     ap.add_argument("--profile-run", action="store_true", help="camera / multicam: only the timed step is launched (for rocprofv3 runs: clean per-kernel averages)")
     ap.add_argument("--no-color-deferral", action="store_true", help="camera workload: classic launch order (4 launches per frame) instead of the cross-frame pipeline")
     ap.add_argument("--step-trace", type=int, default=0, help="decay workload: wait for every one of this many steps and report the slowest (diagnosis)")
@@ -831,6 +940,9 @@ def main():
                     help="camera = BASELINE.json configs[1] (the metric's configuration, default); multicam = configs[3] on one GPU; "
                          "decay = configs[2]; lidar = configs[4]")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks (one process per GPU) -- the same command line the driver uses
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.workload == "lidar":
         return main_lidar(args)
     if args.workload == "decay":

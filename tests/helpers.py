@@ -8,12 +8,17 @@ SMALL_CAM = (80.0, 80.0, 79.5, 59.5, 160, 120)      # 160x120, same 90 deg HFOV 
 
 def frames(n, cam=S.REPLICA_LIKE_CAM, start=0, color=True, stride=1, **kw):
     sc = S.Scene()
-    out = []
-    for i in range(n):
+
+    def one(i):
         T = S.trajectory_pose(start + i * stride, 200, **kw)
         d, rgb = S.render(sc, T, cam, color=color)
-        out.append((d, rgb, T))
-    return out
+        return (d, rgb, T)
+    if n >= 16:          # (numpy releases the GIL in the ray casts: long sequences render on a few threads)
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as pool:
+            return list(pool.map(one, range(n)))
+    return [one(i) for i in range(n)]
 
 
 def idx_set(a):

@@ -54,3 +54,20 @@ def test_block_stats_and_exploring_bookkeeping():
     assert bench.complete_loops([0, 0], [1.0, 2.0], 200, 500)[3] == [1.0, 2.0]
     # no loop completed: every block counts
     assert bench.complete_loops([0, 20], [1.0, 2.0], 200, 20)[3] == [1.0, 2.0]
+
+
+def test_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus N` without WORLD_SIZE re-executes itself through torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1
+    (bench.py --gpus 8 as the driver types it for N = 1 died on the WORLD_SIZE assertion)."""
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], port=29517)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    free = bench.launch_command(2, [])              # (no port given: a free one is picked)
+    assert 1024 < int(free[free.index("--master-port") + 1]) < 65536
+    # and the re-exec really happens: a 2-rank launch of `bench.py --help`-like failure is reported through the exit code, not an assertion in rank 0
+    import subprocess
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env["NVBX_BENCH_LAUNCH_DRY"] = "1"
+    p = subprocess.run([sys.executable, bench.__file__, "--gpus", "2", "--steps", "3"], capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode == 0 and "torch.distributed.run" in p.stdout and "--nproc-per-node 2" in p.stdout, (p.stdout, p.stderr[-500:])

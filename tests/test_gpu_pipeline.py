@@ -189,7 +189,8 @@ def test_camera_batches_take_the_pipeline_too(oracle_mod, hip_lib, ncam):
     assert fused >= 7, {k_: v["count"] for k_, v in prof.items()}          # (of 15 depth launches: the ones that followed a colour batch directly)
 
 
-def test_dynamic_mapping_frame_keeps_the_pipeline(oracle_mod, hip_lib):
+@pytest.mark.parametrize("cam", [H.SMALL_CAM, S.REPLICA_LIKE_CAM], ids=["160x120", "640x480"])
+def test_dynamic_mapping_frame_keeps_the_pipeline(oracle_mod, hip_lib, cam):
     """The dynamic-mapping frame (MappingType::kDynamic: detect dynamics -> clean the mask -> split the depth image -> static mapper with a
     freespace layer + occupancy mapper -> colour -> two ESDF updates, decay every 6th frame) starts with nvbx_detect_dynamics on the static
     mapper.  That call reads TSDF voxels and the freespace layer only, so it leaves the held-back colour frame / ESDF update / distance
@@ -198,7 +199,8 @@ def test_dynamic_mapping_frame_keeps_the_pipeline(oracle_mod, hip_lib):
     torch share one stream, nothing in the loop waits for the GPU.)"""
     from isaac_ros_nvblox_amd import mapper as M
     import torch
-    cam = H.SMALL_CAM; rows, cols = cam[5], cam[4]
+    rows, cols = cam[5], cam[4]          # (640x480: the size profiles/*_bench_decay.json times this frame at)
+    min_component = 40 if cols == 160 else 640
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(dev)
     fs = dict(projective_layer_type=2, max_integration_distance_m=5.0, invalid_depth_decay_factor=0.8, tsdf_decay_factor=0.95,
@@ -222,7 +224,7 @@ def test_dynamic_mapping_frame_keeps_the_pipeline(oracle_mod, hip_lib):
                 mask = torch.empty((rows, cols), dtype=torch.uint8, device=dev); un = torch.empty((rows, cols), dtype=torch.float32, device=dev); ma = torch.empty_like(un)
                 gs.detect_dynamics_into(d_dev, T, cam, 5.0, mask)
                 raw = mask.clone()
-                gs.remove_small_components_inplace(mask, 40)
+                gs.remove_small_components_inplace(mask, min_component)
                 gs.split_depth_by_mask_into(d_dev, mask, eye, cam, cam, 0.25, un, ma)
                 gs.set_time_ms(t)
                 gs.integrate_depth(un, T, cam); gd.integrate_depth(ma, T, cam)
