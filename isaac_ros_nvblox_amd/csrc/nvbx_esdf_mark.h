@@ -99,7 +99,9 @@ __device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg
   int32_t cnt = *shc_at(m, S_LIST_ESDF_DIRTY, sh_l, 0);
   if (cnt > (int32_t)m.capacity) cnt = (int32_t)m.capacity;
   const int srec = S_ESDF_REC + (int)(a.epoch & 1), sh = my_shard();
-  for (int32_t j = j0; j < cnt; j += per) esdf_mark_entry(m, a, (uint32_t)(j == j0 ? first : base[j]), srec, sh, true);
+  int n_done = 0;
+  for (int32_t j = j0; j < cnt; j += per) { esdf_mark_entry(m, a, (uint32_t)(j == j0 ? first : base[j]), srec, sh, true); n_done++; if (n_done == 1) NVBX_TV(0, 1, wall_clock64()); }
+  NVBX_TV(0, 6, n_done); NVBX_TV(0, 2, wall_clock64());
 }
 
 // A marking pass that empties the list it consumed (EsdfArgs::self_reset): every one of its `n_workers` wavefronts calls this when it is

@@ -190,6 +190,13 @@ __host__ __device__ inline uint32_t table_pos(const DMap& m, int32_t x, int32_t 
 }
 
 #ifdef __HIPCC__
+// per-workgroup instrumentation (tools/wg_timeline.py, -DNVBX_WG_TIMES; tsdf.hip defines the buffer): nothing in the product build
+#if defined(NVBX_WG_TIMES) && defined(NVBX_WGT_HERE)       // (tsdf.hip only: the buffer pointer is a device global of that translation unit)
+extern __device__ unsigned long long* g_wgt;
+#define NVBX_TV(k, i, v) do { if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0 && g_wgt && blockIdx.x < 8192) g_wgt[((size_t)(k) * 8192 + blockIdx.x) * 8 + (i)] = (unsigned long long)(v); } while (0)
+#else
+#define NVBX_TV(k, i, v) do { } while (0)
+#endif
 __device__ inline int32_t* shc_at(const DMap& m, int id, int shard, int field) { return &m.shc[(id * NSH + shard) * SH_STRIDE + field]; }
 __device__ inline int my_shard() { return (int)(blockIdx.x & (NSH - 1)); }
 

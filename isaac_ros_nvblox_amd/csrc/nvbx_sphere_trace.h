@@ -60,7 +60,9 @@ __device__ inline void sphere_trace_worker(const DMap& m, const PoseSet<NB>& pos
   bool last_positive = false, hit = false, done = !valid;
   float t = 0.0f, ps = f.trunc;
   int i = 0;
+  int n_rounds = 0;
   while (__ballot(!done)) {                              // wave-uniform loop: ballots / shuffles below need all lanes
+    n_rounds++;
     // this lane's sample: t advanced `sub` times by the predicted step (the serial march's additions, replayed)
     float tc = t;
     for (int j = 0; j < RAY_LANES - 1; j++) if (j < sub) tc = tc + ps;
@@ -110,6 +112,7 @@ __device__ inline void sphere_trace_worker(const DMap& m, const PoseSet<NB>& pos
     }
   }
   if (valid && sub == 0) synth[(int64_t)r * scols + c] = hit ? t * dcz : 0.0f;
+  NVBX_TV(0, 6, n_rounds);
 }
 
 

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+#define NVBX_WGT_HERE
 #include "nvbx_mapper.h"
 #include "nvbx_lidar_math.h"
 #include "nvbx_esdf_edt.h"
@@ -27,6 +28,31 @@
 #include "nvbx_color_worker.h"
 
 using namespace nvbx;
+
+// Per-workgroup time stamps of the two camera launches (tools/wg_timeline.py builds a variant of the library with -DNVBX_WG_TIMES; the product
+// build compiles NVBX_T to nothing).  s_memrealtime: a constant 100 MHz clock shared by all CUs; slot i of workgroup blockIdx.x of kernel k.
+#ifdef NVBX_WG_TIMES
+namespace nvbx { __device__ unsigned long long* g_wgt = nullptr; }
+constexpr int WGT_MAX_WG = 8192, WGT_SLOTS = 8;
+#define NVBX_T(k, i) NVBX_TV(k, i, wall_clock64())
+static unsigned long long* g_wgt_host = nullptr;
+extern "C" int nvbx_debug_wg_times(unsigned long long* out_host, int64_t n_words) {
+  const size_t total = (size_t)2 * WGT_MAX_WG * WGT_SLOTS;
+  if (!g_wgt_host) {
+    if (hipMalloc(&g_wgt_host, total * 8) != hipSuccess) return -1;
+    (void)hipMemset(g_wgt_host, 0, total * 8);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wgt), &g_wgt_host, sizeof(g_wgt_host));
+  }
+  if (out_host) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(out_host, g_wgt_host, std::min<size_t>(total, (size_t)n_words) * 8, hipMemcpyDeviceToHost);
+    (void)hipMemset(g_wgt_host, 0, total * 8);
+  }
+  return (int)WGT_MAX_WG;
+}
+#else
+#define NVBX_T(k, i) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------ sensor models
 // Camera(fu, fv, cu, cv, w, h): conversions/image_conversions.cpp:27-32.  Everything it needs is in Frame.
@@ -41,7 +67,14 @@ struct CameraSensor {
   static constexpr int kSetSize = 512, kFlushRounds = 2; // a tile crosses < 100 blocks: 4 KiB set, 128 keys per flush pass
   static constexpr int kSegments = NVBX_CAM_SEG;         // lanes per ray
   static constexpr int kProbeDepth = 2;                  // hash probe positions fetched up front per key in a flush
-  static constexpr int kThreads = 256;                   // 4 waves: the tile uses the first, a riding EDT workgroup all four
+  static constexpr int kThreads = 256;                   // 4 waves: four tiles (one wavefront each) share the workgroup's key set; a riding worker uses all four as it likes
+  // Tiles per workgroup: kGroupRows x kGroupCols NEIGHBOURING tiles share ONE LDS key set.  Every ray starts in the camera's block and
+  // the rays of neighbouring tiles run through the same blocks for their first metres, so with one tile per workgroup the block at the
+  // origin had its stamp claimed by ALL 336 tiles of a 640x480 frame at the same moment -- returning atomics on one address serialise
+  // at ~12 ns each in the memory-side atomic unit (tools/micro/atomic_scope_bench.hip: 336 of them = 4.0 us for the last; whatever the
+  // scope, there are no XCD-local atomics) -- and the tiles' flush took 4.2 of their 10.7 us (tools/wg_timeline.py).  Four tiles per set:
+  // a quarter of the contenders on every hot stamp, and the workgroup's other three wavefronts, idle before, do the work.
+  static constexpr int kGroupRows = 2, kGroupCols = 2;
   // end point (camera frame) of the ray through the centre of pixel (prow, pcol) at depth `de` along the optical axis
   __device__ void ray_end(const Frame& f, int prow, int pcol, float de, float* pc) const {
     const float rx = (((float)pcol + 0.5f) - f.cu) / f.fu;
@@ -86,6 +119,7 @@ struct LidarSensor {
   static constexpr int kSegments = NVBX_LIDAR_SEG;
   static constexpr int kProbeDepth = NVBX_LIDAR_PD;
   static constexpr int kThreads = 64;
+  static constexpr int kGroupRows = 1, kGroupCols = 1;   // one tile (bundle of rays) per workgroup
   nvbx_lidar_model l;
   const float2* el_tab; const float2* az_tab;
   float max_diff_m, max_ray_dist_m;
@@ -246,28 +280,56 @@ __device__ inline void dda_step(int32_t* cur, const int32_t* step, float* tmax, 
 // are issued together, (D) ONE wave-aggregated returning atomicAdd reserves view-list space for all first-stampers,
 // (E) records are stored.  A camera tile flushes ~60 keys in one such pass; a long LiDAR bundle 256+ keys per pass
 // instead of 64 per dependent round.  Whole wave must call.
-template <int LSET, int R, int PD>
+// NW = wavefronts of the workgroup that share the set (camera: 4 tiles per workgroup; LiDAR: 1): wave w compacts the w-th part of the
+// set, the parts' counts meet in LDS (s_part), and key number i of the compacted list goes to thread i of the workgroup.
+template <int LSET, int R, int PD, int NW = 1>
 __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* lkeys, int32_t* cnt, int4* view_list, int32_t list_cap,
-                                 int lane, bool clear) {
+                                 int lane, bool clear, int32_t* s_part = nullptr) {
   __syncthreads();
+  const int wave = NW > 1 ? (int)(threadIdx.x >> 6) : 0;
+  constexpr int PART = LSET / NW;
+  static_assert(PART % 64 == 0, "whole wavefronts per part");
   int32_t nk = 0;
+  if (NW > 1) {              // counts first: where this wave's keys go depends on the parts before it
+    int32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < LSET / 64; i++) {
-    const u64 kk = lset[i * 64 + lane];
-    const u64 mask = __ballot(kk != KEY_EMPTY);
-    if (kk != KEY_EMPTY) lkeys[nk + (int32_t)__popcll(mask & ((1ull << lane) - 1ull))] = kk;
-    nk += (int32_t)__popcll(mask);
-    if (clear) lset[i * 64 + lane] = KEY_EMPTY;
+    for (int i = 0; i < PART / 64; i++) c += (int32_t)__popcll(__ballot(lset[wave * PART + i * 64 + lane] != KEY_EMPTY));
+    if (lane == 0) s_part[wave] = c;
+    __syncthreads();
+    int32_t before = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) { const int32_t cw = s_part[w]; if (w < wave) before += cw; nk += cw; }
+    int32_t pos = before;
+#pragma unroll
+    for (int i = 0; i < PART / 64; i++) {
+      const u64 kk = lset[wave * PART + i * 64 + lane];
+      const u64 mask = __ballot(kk != KEY_EMPTY);
+      if (kk != KEY_EMPTY) lkeys[pos + (int32_t)__popcll(mask & ((1ull << lane) - 1ull))] = kk;
+      pos += (int32_t)__popcll(mask);
+      if (clear) lset[wave * PART + i * 64 + lane] = KEY_EMPTY;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < LSET / 64; i++) {
+      const u64 kk = lset[i * 64 + lane];
+      const u64 mask = __ballot(kk != KEY_EMPTY);
+      if (kk != KEY_EMPTY) lkeys[nk + (int32_t)__popcll(mask & ((1ull << lane) - 1ull))] = kk;
+      nk += (int32_t)__popcll(mask);
+      if (clear) lset[i * 64 + lane] = KEY_EMPTY;
+    }
   }
   __syncthreads();
-  for (int32_t kb = 0; kb < nk; kb += R * 64) {              // one pass per R x 64 keys (wave-uniform)
-    const int rounds = min(R, (nk - kb + 63) >> 6);
+  NVBX_T(0, 3); NVBX_TV(0, 6, nk);
+  // key number kb + r * (NW * 64) + (this thread's number in the workgroup): wave w takes the w-th 64 keys of every round
+  const int tlane = NW > 1 ? (int)threadIdx.x : lane;
+  for (int32_t kb = 0; kb < nk; kb += R * NW * 64) {         // one pass per R x NW x 64 keys (workgroup-uniform)
+    const int rounds = min(R, (nk - kb + NW * 64 - 1) / (NW * 64));
     u64 key[R]; uint32_t h[R]; uint4 e[R][PD]; bool have[R];
     // (A) the first PD probe positions of every key, all in flight
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      have[r] = r < rounds && (kb + r * 64 + lane) < nk;
-      key[r] = have[r] ? lkeys[kb + r * 64 + lane] : KEY_EMPTY;
+      have[r] = r < rounds && (kb + r * NW * 64 + tlane) < nk;
+      key[r] = have[r] ? lkeys[kb + r * NW * 64 + tlane] : KEY_EMPTY;
       int32_t x, y, z; unpack_key(key[r], &x, &y, &z);
       h[r] = have[r] ? table_pos(m, x, y, z) : 0u;
     }
@@ -309,6 +371,7 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
         }
       }
     }
+    NVBX_T(0, 4);
     // (D) one reservation for the whole pass
     int32_t total = 0; int32_t pre[R];
 #pragma unroll
@@ -324,6 +387,7 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
       // (E)
 #pragma unroll
       for (int r = 0; r < R; r++) if (r < rounds && first[r]) { const int32_t pos = base + pre[r]; if (pos < list_cap) view_list[pos] = rec[r]; }
+      NVBX_T(0, 5);
     }
   }
   __syncthreads();
@@ -336,6 +400,12 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
 // cameras through one mapper, one integrateDepth call each: nvblox_node.hpp:298-332).  Kernel argument (SGPRs / scalar loads).
 template <typename Img, int NB> struct FrameSet { Frame f[NB]; Img img[NB]; int32_t n; };
 
+// workgroups of one frame's view marking: its tile groups, padded to a multiple of the XCD count (XCD-banded numbering in the kernel)
+template <typename Sensor> static int mark_view_tile_wgs(const Frame& f) {
+  const int tiles_x = (f.n_ray_cols + Sensor::kTileCols - 1) / Sensor::kTileCols, tiles_y = (f.n_ray_rows + Sensor::kTileRows - 1) / Sensor::kTileRows;
+  const int n_groups = ((tiles_x + Sensor::kGroupCols - 1) / Sensor::kGroupCols) * ((tiles_y + Sensor::kGroupRows - 1) / Sensor::kGroupRows);
+  return NSH * ((n_groups + NSH - 1) / NSH);
+}
 template <typename Sensor> static size_t mark_view_smem(bool edt_rides) {
   const size_t mark = 2 * (size_t)Sensor::kSetSize * sizeof(u64);
   return (Sensor::kThreads == 256 && edt_rides && sizeof(EdtShared) > mark) ? sizeof(EdtShared) : mark;
@@ -349,6 +419,7 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   // (a batch of 8 cameras: 2 688 tile workgroups beside 1 200 sphere-tracing ones)
   extern __shared__ __align__(16) unsigned char smem[];
   int32_t tile_wg = (int32_t)blockIdx.x;      // this workgroup's number among the tiles
+  NVBX_T(0, 0);
   if (Sensor::kThreads == 256) {
     // riders: [EDT workers][sphere-tracing workers of a held-back colour frame (colour deferral)] -- before the tiles, or
     // (tr.n_tile_wg > 0) after them.  All counts are multiples of 8, so a workgroup's XCD (blockIdx.x & 7) is also its number's & 7.
@@ -369,29 +440,35 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
       // (ESDF site marking of the held-back update, first wavefront only: it reads the TSDF as the last update left it -- nothing in this launch
       //  writes voxels -- and allocates ESDF blocks beside the view marking's TSDF blocks; `ea` is its argument then: no EDT rides, n_edt_wg = 0)
       else if (threadIdx.x < 64) { const int w = (int)(rider - n_edt_wg - tr.n_wg - tr.n_scan_wg); esdf_mark_worker(m, ea, w, tr.n_mark_wg); esdf_mark_pass_done(m, ea, tr.n_mark_wg, w); }
+      NVBX_T(0, 7);
       return;
     }
     if (tr.n_tile_wg == 0) tile_wg -= n_edt_wg + tr.n_wg + tr.n_scan_wg + tr.n_mark_wg;
-    if (threadIdx.x >= 64) return;            // a tile is one wavefront
   }
+  __shared__ int32_t s_part[4];
   u64* lset = reinterpret_cast<u64*>(smem);
   u64* lkeys = lset + LSET;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   constexpr int TR = Sensor::kTileRows, TC = Sensor::kTileCols, NSEG = Sensor::kSegments;
+  constexpr int GR = Sensor::kGroupRows, GC = Sensor::kGroupCols, NW = GR * GC;       // tiles (wavefronts) per workgroup
   static_assert(TR * TC * NSEG <= 64, "one wavefront per tile");
+  static_assert(NW * 64 == Sensor::kThreads && NW <= 4, "one wavefront per tile of the group");
+  const int wave = NW > 1 ? (int)(threadIdx.x >> 6) : 0;
   const Frame& f0 = fs.f[0];                    // (image size, subsampling and view frame id are the same for every frame of a batch)
   const int tiles_x = (f0.n_ray_cols + TC - 1) / TC, tiles_y = (f0.n_ray_rows + TR - 1) / TR;
-  // XCD-aware numbering: workgroups go round-robin over the 8 XCDs (each with its own L2), so the tiles of one XCD (wg & 7) are a
-  // contiguous band of tile rows -- neighbouring tiles share most of their blocks, i.e. their hash lines (n_edt_wg is a multiple of 8)
+  const int groups_x = (tiles_x + GC - 1) / GC, groups_y = (tiles_y + GR - 1) / GR;
+  // XCD-aware numbering: workgroups go round-robin over the 8 XCDs (each with its own L2), so the tile groups of one XCD (wg & 7) are a
+  // contiguous band of group rows -- neighbouring tiles share most of their blocks, i.e. their hash lines (n_edt_wg is a multiple of 8)
   const int wg_all = (int)tile_wg;
-  const int n_tiles = tiles_x * tiles_y, per_xcd = (n_tiles + NSH - 1) / NSH;
+  const int n_groups = groups_x * groups_y, per_xcd = (n_groups + NSH - 1) / NSH;
   const int cam = NB > 1 ? wg_all / (NSH * per_xcd) : 0;        // batch: NSH * per_xcd workgroups per camera, camera after camera
   const int wg = wg_all - cam * (NSH * per_xcd);
-  const Frame& f = fs.f[cam];
-  const Img& depth = fs.img[cam];
-  const int tile = (wg & (NSH - 1)) * per_xcd + (wg >> 3);
-  const bool tile_ok = (wg >> 3) < per_xcd && tile < n_tiles && cam < fs.n;
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const Frame& f = fs.f[cam < fs.n ? cam : 0];
+  const Img& depth = fs.img[cam < fs.n ? cam : 0];
+  const int group = (wg & (NSH - 1)) * per_xcd + (wg >> 3);
+  const int gy = group / groups_x, gx = group - gy * groups_x;
+  const int ty = gy * GR + wave / GC, tx = gx * GC + wave % GC;
+  const bool tile_ok = (wg >> 3) < per_xcd && group < n_groups && cam < fs.n && ty < tiles_y && tx < tiles_x;
   const int ray = lane / NSEG, seg = lane % NSEG;
   const int ri = ty * TR + ray / TC, ci = tx * TC + ray % TC;
   bool active = tile_ok && ray < TR * TC && ri < f.n_ray_rows && ci < f.n_ray_cols;
@@ -399,12 +476,13 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   int prow = ri * f.subsample; if (prow >= f.rows) prow = f.rows - 1;
   int pcol = ci * f.subsample; if (pcol >= f.cols) pcol = f.cols - 1;
   const float d = active ? depth(pix(prow, pcol, f.cols)) : 0.0f;
-  for (int i = lane; i < LSET; i += 64) lset[i] = KEY_EMPTY;
-  if (wg_all == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
-  if (Sensor::kLongRays && wg_all == 0 && lane < NSH) *shc_at(m, S_LIDAR_SPARSE, lane, 0) = 0;
+  for (int i = (int)threadIdx.x; i < LSET; i += NW * 64) lset[i] = KEY_EMPTY;
+  if (wg_all == 0 && threadIdx.x == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
+  if (Sensor::kLongRays && wg_all == 0 && threadIdx.x < NSH) *shc_at(m, S_LIDAR_SPARSE, threadIdx.x, 0) = 0;
   // an ESDF dirty list already consumed by a marking pass (fused into integrateColor) is emptied before k_integrate_tsdf appends
-  if (reset_esdf_dirty && wg_all == 0 && lane < NSH) *shc_at(m, S_LIST_ESDF_DIRTY, lane, 0) = 0;
+  if (reset_esdf_dirty && wg_all == 0 && threadIdx.x < NSH) *shc_at(m, S_LIST_ESDF_DIRTY, threadIdx.x, 0) = 0;
   __syncthreads();
+  NVBX_T(0, 1);
 
   int32_t cur[3] = {0, 0, 0}, step[3] = {0, 0, 0}, nsteps = -1;
   float tmax[3] = {0, 0, 0}, tdelta[3] = {0, 0, 0};
@@ -466,7 +544,9 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
         view_append(cnt, view_list, list_cap, first, rec, lane);
       }
     }
-    flush_set<LSET, FR, Sensor::kProbeDepth>(m, f, lset, lkeys, cnt, view_list, list_cap, lane, false);
+    NVBX_T(0, 2);
+    flush_set<LSET, FR, Sensor::kProbeDepth, NW>(m, f, lset, lkeys, cnt, view_list, list_cap, lane, false, s_part);
+    NVBX_T(0, 7);
     return;
   }
   // LiDAR: hundreds of steps per ray and little sharing at long range -- wave-uniform loop, flush whenever the set is
@@ -624,12 +704,15 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf_color(DMap m, FrameSet<I
                                                               int32_t n_edt_wg, EsdfArgs ea) {
   __shared__ __align__(16) unsigned char smem[sizeof(EdtShared)];
   const int32_t b = (int32_t)blockIdx.x;
-  if (b < n_edt_wg) { esdf_edt_worker<512>(m, ea, (int)b, n_edt_wg, reinterpret_cast<EdtShared*>(smem)); return; }
+  NVBX_T(1, 0);
+  if (b < n_edt_wg) { esdf_edt_worker<512>(m, ea, (int)b, n_edt_wg, reinterpret_cast<EdtShared*>(smem)); NVBX_T(1, 1); NVBX_T(1, 7); return; }
   if (b < n_edt_wg + n_tsdf_wg) {
     integrate_tsdf_worker<Img, CameraSensor, NB, Plain>(m, fs, sensor, view_list, list_cap, mesh_list, view_export, view_export_cap, spec_lanes, nullptr, b - n_edt_wg, n_tsdf_wg);
+    NVBX_T(1, 2); NVBX_T(1, 7);
     return;
   }
   color_integrate_list_worker<Pix, NB>(m, fsc, synth, srows, scols, mesh_list, cand, cand_cnt_idx, b - n_edt_wg - n_tsdf_wg, (int32_t)gridDim.x - n_edt_wg - n_tsdf_wg);
+  NVBX_T(1, 3); NVBX_T(1, 7);
 }
 // (a depth batch AND a colour batch in one argument block: the 4 KiB kernel-argument limit is why the colour path's frames are FrameCore)
 static_assert(sizeof(DMap) + sizeof(FrameSet<DepthF32, MAX_BATCH>) + sizeof(FrameSetC<PixRgb8, MAX_BATCH>) + sizeof(EsdfArgs) + 160 <= 4096, "k_integrate_tsdf_color<.., MAX_BATCH>: kernel arguments");
@@ -888,8 +971,7 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
     fs.f[c].cam_bit = 1u << c;
   }
   const Frame& f = fs.f[0];
-  const int n_tiles = ((f.n_ray_rows + Sensor::kTileRows - 1) / Sensor::kTileRows) * ((f.n_ray_cols + Sensor::kTileCols - 1) / Sensor::kTileCols);
-  const int tiles = NSH * ((n_tiles + NSH - 1) / NSH) * fs.n;   // padded: the tiles of one XCD are a contiguous band (k_mark_view); camera after camera
+  const int tiles = mark_view_tile_wgs<Sensor>(f) * fs.n;       // tile workgroups (padded: the groups of one XCD are a contiguous band, k_mark_view); camera after camera
   // a held-back EDT rides in this launch (camera: 256-thread workgroups); the LiDAR launch is 64 threads wide, so flush first
   int edt_wg = 0; EsdfArgs ea = m->edt_args;
   if (m->edt_pending) {
@@ -1230,10 +1312,9 @@ extern "C" int nvbx_measure_depth(nvbx_mapper* m, const float* depth_dev, int32_
   const int s = fs.f[0].subsample;
   fs.f[0].n_ray_rows = (rows + s - 1 + s - 1) / s; fs.f[0].n_ray_cols = (cols + s - 1 + s - 1) / s; fs.f[0].cam_bit = 1u;
   const Frame& f = fs.f[0];
-  const int n_tiles = ((f.n_ray_rows + CameraSensor::kTileRows - 1) / CameraSensor::kTileRows) * ((f.n_ray_cols + CameraSensor::kTileCols - 1) / CameraSensor::kTileCols);
   // the view calculation against the local map: blocks in view are looked up / allocated exactly as integrateDepth would (they receive
   // their values when the gathered measurements are applied)
-  NVBX_LAUNCH_SMEM(m, (k_mark_view<DepthF32, CameraSensor, 1>), dim3(NSH * ((n_tiles + NSH - 1) / NSH)), dim3(CameraSensor::kThreads), mark_view_smem<CameraSensor>(false), m->d, fs, CameraSensor{},
+  NVBX_LAUNCH_SMEM(m, (k_mark_view<DepthF32, CameraSensor, 1>), dim3(mark_view_tile_wgs<CameraSensor>(f)), dim3(CameraSensor::kThreads), mark_view_smem<CameraSensor>(false), m->d, fs, CameraSensor{},
               (int4*)m->view_list, (int32_t)m->capacity, (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)0, m->edt_args, TraceRider{});
   m->premark_consumed = false;
   NVBX_LAUNCH(m, (k_measure_tsdf<DepthF32>), dim3((unsigned)std::min<int64_t>(m->capacity, 1024)), dim3(512), m->d, f, DepthF32{depth_dev}, CameraSensor{},
