@@ -21,6 +21,7 @@ __device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_
   // update (its TSDF update sets the flag one launch later), so the stale entry is skipped; found as ESDF columns the sequential order never
   // creates when the new block was deallocated again before that update (tests/test_gpu_sequences.py, seed 3).
   if (from_dirty_list && !(tflags & F_DIRTY_ESDF)) return;
+  NVBX_TV(0, 3, wall_clock64());
   if (lane == 0) { atomicAnd(&m.slot_flags[tslot], ~F_DIRTY_ESDF); m.slot_consumed[tslot] = a.mark_pass; }
   // a dirty TSDF block of the z band dirties its column; an ESDF slot flagged F_ESDF_REMARK (a TSDF block of its band was
   // deallocated by decay) re-marks its own column
@@ -33,9 +34,23 @@ __device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_
   const uint4 qe = ld_entry(m, qh);
   uint32_t qslot = probing ? resolve_any(m, qkey, qh, qe) : SLOT_NONE;
   uint32_t eslot = __shfl(qslot, 0);
+  NVBX_TV(0, 4, wall_clock64());
+  // Everything that depends on the probes alone is requested TOGETHER, one round trip instead of three in a row: the ESDF slot's flags, the
+  // column stamp exchange (the common case: the entry is a live TSDF block -- then the early return below cannot be taken -- and the column
+  // exists), and the first two TSDF blocks of the band (the shipped configurations span two).
+  const bool early = (tflags & F_TSDF) && slot_ok(eslot);
+  int first = 0;
+  if (early && lane == 0) first = atomicExch(&m.slot_stamp[eslot], a.mark_pass) != a.mark_pass;
+  float4 pre[2][4];
+  const uint32_t ts0 = __shfl(qslot, 1), ts1 = __shfl(qslot, nz > 1 ? 2 : 1);
+  {
+    const float4* c0 = reinterpret_cast<const float4*>(&m.tsdf[(size_t)(slot_ok(ts0) ? ts0 : 0) * 512 + 64 * vx + 8 * vy]);
+    const float4* c1 = reinterpret_cast<const float4*>(&m.tsdf[(size_t)(slot_ok(ts1) ? ts1 : 0) * 512 + 64 * vx + 8 * vy]);
+#pragma unroll
+    for (int w = 0; w < 4; w++) { pre[0][w] = c0[w]; pre[1][w] = c1[w]; }
+  }
   const bool e_exists = slot_ok(eslot) && (m.slot_flags[slot_ok(eslot) ? eslot : 0] & (F_ESDF | F_ESDF_PENDING));
   if (!(tflags & F_TSDF) && !(e_exists && (tflags & F_ESDF_REMARK))) return;          // uniform
-  int first = 0;
   if (lane == 0) {
     if (!slot_ok(eslot)) {                                // new column: insert (device-side allocation)
       bool is_new;
@@ -44,7 +59,7 @@ __device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_
     }
     if (slot_ok(eslot)) {
       if (!e_exists) atomicOr(&m.slot_flags[eslot], F_ESDF_PENDING);   // joins the ESDF layer when the EDT of this update runs
-      first = atomicExch(&m.slot_stamp[eslot], a.mark_pass) != a.mark_pass;
+      if (!early) first = atomicExch(&m.slot_stamp[eslot], a.mark_pass) != a.mark_pass;
     }
   }
   // TSDF columns of the band: this lane's (x, y) column of block bzz is voxels 64*vx + 8*vy + 0..7 = 64 contiguous bytes
@@ -57,7 +72,7 @@ __device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_
     const float4* col = reinterpret_cast<const float4*>(&m.tsdf[(size_t)ts * 512 + 64 * vx + 8 * vy]);
     float dz[8], wz[8];
 #pragma unroll
-    for (int w = 0; w < 4; w++) { const float4 v = col[w]; dz[2 * w] = v.x; wz[2 * w] = v.y; dz[2 * w + 1] = v.z; wz[2 * w + 1] = v.w; }
+    for (int w = 0; w < 4; w++) { const float4 v = q < 2 ? pre[q][w] : col[w]; dz[2 * w] = v.x; wz[2 * w] = v.y; dz[2 * w + 1] = v.z; wz[2 * w + 1] = v.w; }
 #pragma unroll
     for (int z = 0; z < 8; z++) {
       const int32_t kz = bzz * 8 + z;
@@ -74,6 +89,7 @@ __device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_
     }
   }
   eslot = __shfl(eslot, 0); first = __shfl(first, 0);
+  NVBX_TV(0, 5, wall_clock64());
   if (!first || !slot_ok(eslot)) return;                // column already re-marked in this marking pass
   if (lane == 0) {                                         // window record: this workgroup's shard copy
     atomicMin(shc_at(m, srec, sh, 0), bx); atomicMin(shc_at(m, srec, sh, 1), by);
@@ -100,7 +116,7 @@ __device__ inline void esdf_mark_worker(const DMap& m, const EsdfArgs& a, int wg
   if (cnt > (int32_t)m.capacity) cnt = (int32_t)m.capacity;
   const int srec = S_ESDF_REC + (int)(a.epoch & 1), sh = my_shard();
   int n_done = 0;
-  for (int32_t j = j0; j < cnt; j += per) { esdf_mark_entry(m, a, (uint32_t)(j == j0 ? first : base[j]), srec, sh, true); n_done++; if (n_done == 1) NVBX_TV(0, 1, wall_clock64()); }
+  for (int32_t j = j0; j < cnt; j += per) { esdf_mark_entry(m, a, (uint32_t)(j == j0 ? first : base[j]), srec, sh, true); n_done++;  if (n_done == 1) NVBX_TV(0, 1, wall_clock64()); }
   NVBX_TV(0, 6, n_done); NVBX_TV(0, 2, wall_clock64());
 }
 

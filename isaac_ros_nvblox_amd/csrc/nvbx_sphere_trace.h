@@ -112,7 +112,7 @@ __device__ inline void sphere_trace_worker(const DMap& m, const PoseSet<NB>& pos
     }
   }
   if (valid && sub == 0) synth[(int64_t)r * scols + c] = hit ? t * dcz : 0.0f;
-  NVBX_TV(0, 6, n_rounds);
+  NVBX_TV(0, 6, n_rounds); (void)n_rounds;
 }
 
 

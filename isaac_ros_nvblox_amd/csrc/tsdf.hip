@@ -319,7 +319,10 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
     }
   }
   __syncthreads();
-  NVBX_T(0, 3); NVBX_TV(0, 6, nk);
+  NVBX_T(0, 3);
+#ifndef NVBX_WGT_WALK_START
+  NVBX_TV(0, 6, nk);
+#endif
   // key number kb + r * (NW * 64) + (this thread's number in the workgroup): wave w takes the w-th 64 keys of every round
   const int tlane = NW > 1 ? (int)threadIdx.x : lane;
   for (int32_t kb = 0; kb < nk; kb += R * NW * 64) {         // one pass per R x NW x 64 keys (workgroup-uniform)
@@ -439,7 +442,13 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
         color_scan_worker<NB>(m, tr.ps, tr.cand, tr.cand_cnt_idx, tr.cand_reset_idx, (int)(rider - n_edt_wg - tr.n_wg) * 4 + (int)(threadIdx.x >> 6), tr.n_scan_wg * 4);
       // (ESDF site marking of the held-back update, first wavefront only: it reads the TSDF as the last update left it -- nothing in this launch
       //  writes voxels -- and allocates ESDF blocks beside the view marking's TSDF blocks; `ea` is its argument then: no EDT rides, n_edt_wg = 0)
-      else if (threadIdx.x < 64) { const int w = (int)(rider - n_edt_wg - tr.n_wg - tr.n_scan_wg); esdf_mark_worker(m, ea, w, tr.n_mark_wg); esdf_mark_pass_done(m, ea, tr.n_mark_wg, w); }
+      // (all four wavefronts are workers -- a frame dirties ~300 blocks, 4 x 256 workers take at most one entry each: an entry is a chain of
+      //  dependent round trips, and a worker with two of them was the launch's tail; the workgroup then counts itself in as one arrival)
+      else {
+        const int w = (int)(rider - n_edt_wg - tr.n_wg - tr.n_scan_wg);
+        esdf_mark_worker(m, ea, w * 4 + (int)(threadIdx.x >> 6), tr.n_mark_wg * 4);
+        if (ea.self_reset) { __syncthreads(); if (threadIdx.x < 64) esdf_mark_pass_done(m, ea, tr.n_mark_wg, w); }
+      }
       NVBX_T(0, 7);
       return;
     }
@@ -519,6 +528,9 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
     for (int32_t k = 0; k < k0 && k0 <= nsteps; k++) dda_step(cur, step, tmax, tdelta);
   }
   int32_t* cnt = &m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
+#ifdef NVBX_WGT_WALK_START
+  NVBX_TV(0, 6, wall_clock64() + (unsigned long long)(nsteps & 0));        // (experiment: when the ray set-up is done -- the depth pixel has arrived)
+#endif
   if (!Sensor::kLongRays) {
     // camera: a tile's rays cross < 100 blocks in ~20 steps -- walk every ray to its end, then flush once
     for (int32_t k = k0; k <= k1; k++) {                   // (this lane's segment of the ray; the whole ray if it is not shared)
@@ -697,6 +709,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // has finished (previous launch) and writes ESDF voxels only; the update appends to an ESDF-dirty list that pass has emptied.  Every part
 // reads exactly the state separate calls would have shown it.
 // Workgroups: [distance transform (512 threads = 8 wavefronts per ESDF block)][TSDF update][colour].
+// (occupancy: the compiler's own register choice gives 3 of these 8-wavefront workgroups per CU -- 768 resident of the ~1 080 a frame launches, so the
+//  colour workgroups, dispatched last, start late; asking for four per CU with amdgpu_waves_per_eu(8, 8) was measured in round 4: the colour part
+//  starts at once but every part runs slower, the launch 9.2 -> 10.0 us -- left at the compiler's choice)
 template <typename Img, typename Pix, int NB, bool Plain>
 __global__ __launch_bounds__(512) void k_integrate_tsdf_color(DMap m, FrameSet<Img, NB> fs, CameraSensor sensor, const int4* view_list, int32_t list_cap,
                                                               int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, int32_t n_tsdf_wg,

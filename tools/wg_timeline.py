@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=30)
     ap.add_argument("--frames", type=int, default=48)
+    ap.add_argument("--classic", action="store_true", help="classic launch order: the view-marking launch carries the tiles and the held-back distance transform only")
     ap.add_argument("--tiles", type=int, default=88, help="tile workgroups of the view-marking launch (640x480, factor 4: 11 x 8 groups of 2 x 2 tiles)")
     args = ap.parse_args()
     import torch
@@ -40,7 +41,7 @@ def main():
         fr = list(pool.map(one, range(args.frames)))
     stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream)
     g = M.Mapper(M.default_params(), device=0, block_capacity=1 << 14, stream=stream.cuda_stream)
-    g.set_color_deferral(True)
+    g.set_color_deferral(not args.classic)
     da = [g.prepare_depth(torch.from_numpy(d).to(dev), T, cam) for d, _, T in fr]
     ca = [g.prepare_color(torch.from_numpy(c).to(dev), T, cam) for _, c, T in fr]
     for k in range(args.frames):      # build the map once (revisit steady state below)
@@ -59,14 +60,16 @@ def main():
             used = b[:, 0] > 0
             if used.sum() == 0:
                 continue
-            used &= b[:, 0] > b[:, 0].max() - 5000               # the LAST launch only (grids differ from frame to frame: higher workgroups keep older stamps)
+            used &= b[:, 0] > b[:, 0].max() - 1200               # the LAST launch only (grids differ from frame to frame: higher workgroups keep older stamps)
             t0 = b[used, 0].min()
             rel = np.where((b > 0) & used[:, None], (b - t0) / 100.0, np.nan)        # us
-            rel[:, 6] = np.where(used, b[:, 6], np.nan)          # slot 6 carries a count, not a time
+            rel[:, 6] = np.where(used, np.where(b[:, 6] > 10 ** 9, (b[:, 6] - t0) / 100.0, b[:, 6]), np.nan)          # slot 6 carries a count (or, in an experiment build, a time)
             acc[kern].append(rel[: int(np.nonzero(used)[0].max()) + 1])
     hw = g.counters()["blocks_allocated"]
     n_scan = min(256, 8 * ((hw + hw // 4 + 64 + 2047) // 2048))
     roles0 = [("tiles", args.tiles), ("trace", 600), ("scan", n_scan), ("mark", 256)]
+    if args.classic:
+        roles0 = [("edt", 256), ("tiles", args.tiles)]
     out = {}
     def summarize(samples, roles, name):
         n = min(x.shape[0] for x in samples)
@@ -82,7 +85,7 @@ def main():
             dur = np.array([np.nanmedian(x[o:o + cnt, 7] - x[o:o + cnt, 0]) for x in samples]); durmax = np.array([np.nanmax(x[o:o + cnt, 7] - x[o:o + cnt, 0]) for x in samples])
             r = {"n": int(cnt), "first_start": round(float(np.median(st)), 2), "last_start": round(float(np.median(stl)), 2), "end_median": round(float(np.median(en_med)), 2),
                  "end_max": round(float(np.median(en_max)), 2), "dur_median": round(float(np.median(dur)), 2), "dur_max": round(float(np.median(durmax)), 2)}
-            if role == "tiles":
+            if role == "tiles" and not args.classic or role == "tiles":
                 ph = {}
                 for i, nm in ((1, "depth+init"), (2, "walk"), (3, "compact"), (4, "probe+claim"), (5, "append")):
                     v = np.array([np.nanmedian(x[o:o + cnt, i] - x[o:o + cnt, 0]) for x in samples])
