@@ -88,6 +88,10 @@ def algorithmic_bytes(kernel, c, rows, cols, sub_ray=4, sub_trace=4, n_cam=1, tr
         return Nv * (B + 2 * 512 * 16)                               # TSDF read, freespace voxels (16 B) read + written
     if kernel.startswith("k_detect_dynamics") or kernel.startswith("k_split_depth") or kernel.startswith("k_mask_zmin"):
         return rows * cols * (4 + 4 + 1)
+    if kernel.startswith("k_dyn_detect_union"):
+        return rows * cols * (4 + 1 + 4 + 4)          # depth read, mask written, label + nearest-depth images touched
+    if kernel.startswith("k_dyn_filter_split"):
+        return rows * cols * (4 + 1 + 4 + 4 + 8 + 12)     # depth, mask, label, nearest depth read; two depth images written; the next call's three arrays reset
     if kernel.startswith("k_cc_"):
         return rows * cols * 8
     if kernel.startswith("k_save_stamps") or kernel.startswith("k_reinsert"):
@@ -466,9 +470,12 @@ def main_decay(args):
 
     def step(i):
         k = i % nu
-        gs.detect_dynamics_into(depth_dev[k], poses[k], cam, 5.0, mask)
-        gs.remove_small_components_inplace(mask, 2000)             # multi_mapper connected_mask_component_size_threshold (mapper_initialization.cpp:130)
-        gs.split_depth_by_mask_into(depth_dev[k], mask, eye, cam, cam, 0.25, un, ma)
+        if args.separate_front_end:      # (A/B: the front end as three entry points = six launches + a memset)
+            gs.detect_dynamics_into(depth_dev[k], poses[k], cam, 5.0, mask)
+            gs.remove_small_components_inplace(mask, 2000)             # multi_mapper connected_mask_component_size_threshold (mapper_initialization.cpp:130)
+            gs.split_depth_by_mask_into(depth_dev[k], mask, eye, cam, cam, 0.25, un, ma)
+        else:                            # detect dynamics -> remove small components -> split: one call, three launches (what MultiMapper::integrateDepth runs)
+            gs.dynamic_depth_split_into(depth_dev[k], poses[k], cam, 5.0, 2000, 0.25, mask, un, ma)
         gs.set_time_ms(t_ms[0]); t_ms[0] += 33
         gs.integrate_depth(un, poses[k], cam)
         gd.integrate_depth(ma, poses[k], cam)
@@ -497,7 +504,7 @@ def main_decay(args):
             setattr(obj, name, timed_call)
         cur = [0]
         for o_ in (gs, gd):
-            for nm in ("detect_dynamics_into", "remove_small_components_inplace", "split_depth_by_mask_into", "integrate_depth", "integrate_color",
+            for nm in ("detect_dynamics_into", "remove_small_components_inplace", "split_depth_by_mask_into", "dynamic_depth_split_into", "integrate_depth", "integrate_color",
                        "update_esdf", "decay_tsdf", "decay_occupancy"):
                 wrap(o_, nm)
         kern_of = {}
@@ -931,6 +938,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="camera / multicam: skip the end-state comparison of the timed sequence with the checker (outside the timed region)")
     ap.add_argument("--profile-run", action="store_true", help="camera / multicam: only the timed step is launched (for rocprofv3 runs: clean per-kernel averages)")
     ap.add_argument("--no-color-deferral", action="store_true", help="camera workload: classic launch order (4 launches per frame) instead of the cross-frame pipeline")
+    ap.add_argument("--separate-front-end", action="store_true", help="decay workload: detect / remove-small-components / split as three entry points (A/B against nvbx_dynamic_depth_split)")
     ap.add_argument("--step-trace", type=int, default=0, help="decay workload: wait for every one of this many steps and report the slowest (diagnosis)")
     ap.add_argument("--cameras", type=int, default=4, help="multicam: cameras per step (1..8)")
     ap.add_argument("--fusion", default="indices", choices=["indices", "measurements"],

@@ -83,13 +83,11 @@ class MultiMapper {
     dynamic_mask_.resize(rows, cols); depth_background_.resize(rows, cols); depth_foreground_.resize(rows, cols); depth_overlay_.resize(rows, cols);
     float T[16]; T_L_C.toRowMajor(T);
     const float max_d = background_mapper_->tsdf_integrator().max_integration_distance_m();
-    checkNvbx(nvbx_detect_dynamics(m, depth.dataConstPtr(), rows, cols, T, &camera.c_abi(), max_d, dynamic_mask_.dataPtr()), "nvbx_detect_dynamics");
-    if (multi_params_.remove_small_connected_components)
-      checkNvbx(nvbx_remove_small_components(m, dynamic_mask_.dataPtr(), rows, cols, multi_params_.connected_mask_component_size_threshold), "nvbx_remove_small_components");
-    float I[16]; Transform::Identity().toRowMajor(I);
-    checkNvbx(nvbx_split_depth_by_mask(m, depth.dataConstPtr(), rows, cols, dynamic_mask_.dataConstPtr(), rows, cols, I, &camera.c_abi(), &camera.c_abi(),
-                                       multi_params_.mask_occlusion_threshold_m, depth_background_.dataPtr(), depth_foreground_.dataPtr(),
-                                       reinterpret_cast<uint8_t*>(depth_overlay_.dataPtr())), "nvbx_split_depth_by_mask");
+    // (detect -> remove small components -> split, one call: three launches, include/nvblox_hip.h nvbx_dynamic_depth_split)
+    checkNvbx(nvbx_dynamic_depth_split(m, depth.dataConstPtr(), rows, cols, T, &camera.c_abi(), max_d,
+                                       multi_params_.remove_small_connected_components ? multi_params_.connected_mask_component_size_threshold : 0,
+                                       multi_params_.mask_occlusion_threshold_m, dynamic_mask_.dataPtr(), depth_background_.dataPtr(), depth_foreground_.dataPtr(),
+                                       reinterpret_cast<uint8_t*>(depth_overlay_.dataPtr())), "nvbx_dynamic_depth_split");
     if (update_time_ms) background_mapper_->setUpdateTime(*update_time_ms);
     background_mapper_->integrateDepth(depth_background_, T_L_C, camera);
     foreground_mapper_->integrateDepth(depth_foreground_, T_L_C, camera);

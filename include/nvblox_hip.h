@@ -395,6 +395,14 @@ int nvbx_detect_dynamics(nvbx_mapper* m, const float* depth_dev, int32_t rows, i
 /* [U] removeSmallConnectedComponents (multi_mapper connected_mask_component_size_threshold, mapper_initialization.cpp:130): erases the
  * 8-connected components of non-zero pixels smaller than min_size.  In place; asynchronous on the mapper's stream (lock-free union-find). */
 int nvbx_remove_small_components(nvbx_mapper* m, uint8_t* mask_dev, int32_t rows, int32_t cols, int32_t min_size);
+/* The front end of MultiMapper::integrateDepth(depth, T_L_C, camera) in MappingType::kDynamic (nvblox_node.cpp:1062; its outputs are read at
+ * :1098,1108) as ONE call: nvbx_detect_dynamics -> nvbx_remove_small_components(min_component_size; <= 0: not removed) ->
+ * nvbx_split_depth_by_mask with the depth camera as the mask camera (T_CM_CD = identity).  Same results as the three calls, bit for bit
+ * (mask_dev = the cleaned mask; overlay_rgb_dev may be NULL), in three launches and no memset instead of six and one.  Like
+ * nvbx_detect_dynamics it leaves held-back work (colour deferral) alone.  Asynchronous. */
+int nvbx_dynamic_depth_split(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera,
+                             float max_distance_m, int32_t min_component_size, float occlusion_threshold_m,
+                             uint8_t* mask_dev, float* depth_unmasked_dev, float* depth_masked_dev, uint8_t* overlay_rgb_dev);
 
 /* ---- device-side view for the caller's own kernels (GPULayerView / gpu_indexing.cuh: esdf_slice_conversions.cu:18,
  * esdf_and_gradients_conversions.cu:19-23).  Accessors: include/nvblox_hip_device.h. */

@@ -126,6 +126,7 @@ SIGNATURES = {
     "nvbx_set_time_ms": (C.c_int, [_vp, C.c_int64]),
     "nvbx_detect_dynamics": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera), C.c_float, _vp]),
     "nvbx_remove_small_components": (C.c_int, [_vp, _vp, _i32, _i32, _i32]),
+    "nvbx_dynamic_depth_split": (C.c_int, [_vp, _vp, _i32, _i32, _vp, C.POINTER(Camera), C.c_float, _i32, C.c_float, _vp, _vp, _vp, _vp]),
     "nvbx_set_view_export": (C.c_int, [_vp, _vp, _i64]),
     "nvbx_split_depth_by_mask": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp, C.POINTER(Camera), C.POINTER(Camera), C.c_float, _vp, _vp, _vp]),
     "nvbx_split_color_by_mask": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),

@@ -5,6 +5,7 @@
 #include <cmath>
 #include "nvbx_mapper.h"
 #include "nvbx_motion_math.h"
+#include "nvbx_mask_geom.h"
 
 using namespace nvbx;
 
@@ -53,7 +54,6 @@ extern "C" int nvbx_backproject_depth(nvbx_mapper* m, const float* depth_dev, in
   return NVBX_OK;
 }
 
-struct Rt { float R[9], t[3]; };
 __global__ __launch_bounds__(256) void k_transform_points(Rt T, const float* in, int64_t n, float* out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float o[3];
@@ -172,18 +172,6 @@ extern "C" int nvbx_esdf_slice_combined_to_image(nvbx_mapper* m1, nvbx_mapper* m
 }
 
 // ------------------------------------------------------------------------------------------------ mask splitting
-struct MaskGeom { Rt T; float dfu, dfv, dcu, dcv, mfu, mfv, mcu, mcv; int32_t rows, cols, mrows, mcols; };
-// depth pixel i -> index of the mask pixel it lands on (or -1) and its depth in the mask camera
-__device__ inline int32_t mask_pixel(const MaskGeom& g, int32_t r, int32_t c, float d, float* z_cm) {
-  const float rx = (((float)c + 0.5f) - g.dcu) / g.dfu, ry = (((float)r + 0.5f) - g.dcv) / g.dfv;
-  float p[3]; apply_rt(g.T.R, g.T.t, d * rx, d * ry, d, p);
-  *z_cm = p[2];
-  if (p[2] <= 0.0f) return -1;
-  const float u = g.mfu * (p[0] / p[2]) + g.mcu, v = g.mfv * (p[1] / p[2]) + g.mcv;
-  const int32_t mc = (int32_t)floorf(u), mr = (int32_t)floorf(v);
-  if (mc < 0 || mr < 0 || mc >= g.mcols || mr >= g.mrows) return -1;
-  return mr * g.mcols + mc;
-}
 __global__ __launch_bounds__(256) void k_mask_zmin(MaskGeom g, const float* depth, uint32_t* zmin) {
   const int64_t n = (int64_t)g.rows * g.cols;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -226,10 +214,7 @@ extern "C" int nvbx_split_depth_by_mask(nvbx_mapper* m, const float* depth_dev, 
     NVBX_HIP(hipMalloc(&m->mask_zmin, (size_t)mn * 4));
     m->mask_zmin_cap = mn;
   }
-  MaskGeom g;
-  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) g.T.R[3 * i + j] = T_CM_CD[4 * i + j]; g.T.t[i] = T_CM_CD[4 * i + 3]; }
-  g.dfu = dc->fu; g.dfv = dc->fv; g.dcu = dc->cu; g.dcv = dc->cv; g.mfu = mc->fu; g.mfv = mc->fv; g.mcu = mc->cu; g.mcv = mc->cv;
-  g.rows = rows; g.cols = cols; g.mrows = mask_rows; g.mcols = mask_cols;
+  const MaskGeom g = make_mask_geom(T_CM_CD, dc, mc, rows, cols, mask_rows, mask_cols);
   NVBX_HIP(hipMemsetAsync(m->mask_zmin, 0x7F, (size_t)mn * 4, m->stream));        // 0x7F7F7F7F = 3.4e38
   const unsigned grid = (unsigned)std::min<int64_t>(((int64_t)rows * cols + 255) / 256, 2048);
   NVBX_LAUNCH(m, k_mask_zmin, dim3(grid), dim3(256), g, depth_dev, m->mask_zmin);

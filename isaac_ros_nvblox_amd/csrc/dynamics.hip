@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include "nvbx_mapper.h"
+#include "nvbx_mask_geom.h"
 
 using namespace nvbx;
 
@@ -104,21 +105,27 @@ extern "C" int nvbx_set_time_ms(nvbx_mapper* m, int64_t update_time_ms) {
 }
 
 struct RtCam { float R[9], t[3], fu, fv, cu, cv; };
+// [U] DynamicsDetection: the depth pixel (r, c) at depth d is dynamic iff its point lies in a high-confidence-freespace voxel
+__device__ inline uint8_t pixel_is_dynamic(const DMap& m, const RtCam& g, int32_t r, int32_t c, float d, float max_d, float vs) {
+  if (!(d > 0.0f) || (max_d > 0.0f && d > max_d)) return 0;
+  const float rx = (((float)c + 0.5f) - g.cu) / g.fu, ry = (((float)r + 0.5f) - g.cv) / g.fv;
+  float pl[3]; apply_rt(g.R, g.t, d * rx, d * ry, d, pl);
+  const int32_t gx = (int32_t)floorf(pl[0] / vs), gy = (int32_t)floorf(pl[1] / vs), gz = (int32_t)floorf(pl[2] / vs);
+  const uint32_t s = find_slot(m, gx >> 3, gy >> 3, gz >> 3, F_FREESPACE);
+  return (slot_ok(s) && (m.freespace[(size_t)s * 512 + (gz & 7) + 8 * (gy & 7) + 64 * (gx & 7)].w & 1)) ? 1 : 0;
+}
 __global__ __launch_bounds__(256) void k_detect_dynamics(DMap m, RtCam g, const float* depth, int32_t rows, int32_t cols, float max_d, float vs, uint8_t* mask) {
   const int64_t n = (int64_t)rows * cols;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    uint8_t out = 0;
-    const float d = depth[i];
-    if (d > 0.0f && !(max_d > 0.0f && d > max_d)) {
-      const int32_t r = (int32_t)(i / cols), c = (int32_t)(i - (int64_t)r * cols);
-      const float rx = (((float)c + 0.5f) - g.cu) / g.fu, ry = (((float)r + 0.5f) - g.cv) / g.fv;
-      float pl[3]; apply_rt(g.R, g.t, d * rx, d * ry, d, pl);
-      const int32_t gx = (int32_t)floorf(pl[0] / vs), gy = (int32_t)floorf(pl[1] / vs), gz = (int32_t)floorf(pl[2] / vs);
-      const uint32_t s = find_slot(m, gx >> 3, gy >> 3, gz >> 3, F_FREESPACE);
-      if (slot_ok(s) && (m.freespace[(size_t)s * 512 + (gz & 7) + 8 * (gy & 7) + 64 * (gx & 7)].w & 1)) out = 1;
-    }
-    mask[i] = out;
+    const int32_t r = (int32_t)(i / cols), c = (int32_t)(i - (int64_t)r * cols);
+    mask[i] = pixel_is_dynamic(m, g, r, c, depth[i], max_d, vs);
   }
+}
+static RtCam make_rtcam(const float T_L_C[16], const nvbx_camera* camera) {
+  RtCam g;
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) g.R[3 * i + j] = T_L_C[4 * i + j]; g.t[i] = T_L_C[4 * i + 3]; }
+  g.fu = camera->fu; g.fv = camera->fv; g.cu = camera->cu; g.cv = camera->cv;
+  return g;
 }
 extern "C" int nvbx_detect_dynamics(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera,
                                     float max_distance_m, uint8_t* mask_dev) {
@@ -127,9 +134,7 @@ extern "C" int nvbx_detect_dynamics(nvbx_mapper* m, const float* depth_dev, int3
   if (m->join_side_keeping_held()) return NVBX_E_DEVICE;      // (reads TSDF voxels and the freespace layer only)
   const int64_t n = (int64_t)rows * cols;
   if (!m->d.freespace) { NVBX_HIP(hipMemsetAsync(mask_dev, 0, (size_t)n, m->stream)); return NVBX_OK; }    // no freespace layer yet: nothing is dynamic
-  RtCam g;
-  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) g.R[3 * i + j] = T_L_C[4 * i + j]; g.t[i] = T_L_C[4 * i + 3]; }
-  g.fu = camera->fu; g.fv = camera->fv; g.cu = camera->cu; g.cv = camera->cv;
+  const RtCam g = make_rtcam(T_L_C, camera);
   NVBX_LAUNCH(m, k_detect_dynamics, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), m->d, g, depth_dev, rows, cols, max_distance_m,
               m->p.voxel_size, mask_dev);
   NVBX_HIP(hipGetLastError());
@@ -238,4 +243,109 @@ extern "C" int nvbx_remove_small_components(nvbx_mapper* m, uint8_t* mask_dev, i
   NVBX_LAUNCH(m, k_cc_filter, dim3(grid), dim3(256), n, label, (const int32_t*)size, size_prev, min_size, mask_dev);
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;                  // asynchronous on the mapper's stream, like the other image operations
+}
+
+// ------------------------------------------------------------------------------------------------ the front end of a dynamic-mapping frame, fused
+// MultiMapper::integrateDepth(depth, T_L_C, camera) of MappingType::kDynamic (nvblox_node.cpp:1062; the node reads the mask overlay and the
+// dynamic points at :1098,1108) runs, before its two integrator calls, detect dynamics -> remove small components -> split the depth image:
+// as separate entry points six dependent image-sized launches and a memset (k_detect_dynamics, k_cc_union, k_cc_count, k_cc_filter, fill,
+// k_mask_zmin, k_split_depth: ~30 us of an 83 us frame, each moving <= 2.8 MB).  What really orders them is three GLOBAL dependencies -- the
+// union needs the neighbours' mask bits, the sizes need the finished union, the filter needs the finished sizes -- so: THREE launches, no memset.
+//   A  k_dyn_detect_union   a 256-thread workgroup takes a 32 x 8 PATCH of pixels and owns its inner 30 x 7: every thread evaluates one pixel
+//                           (the ring is the neighbours' neighbourhood, re-evaluated: +22 % pixels, no second dependent chain), the mask bits
+//                           meet in LDS, owned pixels write their bit and unite with their W / NW / N / NE neighbours in the global label image
+//                           (the same lock-free union-find); the split's nearest-depth image (atomicMin) depends on the depth image only and is
+//                           filled here as well
+//   B  k_cc_count           as before: flatten + wave-aggregated sizes
+//   C  k_dyn_filter_split   the filter AND the split: the split of pixel i asks for the CLEANED mask at the pixel mi it lands on, i.e.
+//                           mask[mi] && size[label[mi]] >= min -- evaluated on the spot, so it needs no finished filter pass; every thread also
+//                           cleans its own mask bit (a reader that meets the cleaned bit instead of the raw one decides the same) and restores
+//                           the resting state of the arrays the NEXT call uses (labels, sizes and nearest depths exist twice, by call parity:
+//                           nothing this launch reads is reset by it)
+// Results: bit-identical to the three calls (tests/test_gpu_round4.py), which stay for callers that bring their own mask.
+__global__ __launch_bounds__(256) void k_dyn_init(int64_t n, int32_t* label2, int32_t* size2, uint32_t* zmin2) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += (int64_t)gridDim.x * blockDim.x) {
+    label2[i] = (int32_t)(i < n ? i : i - n); size2[i] = 0; zmin2[i] = 0x7F7F7F7Fu;
+  }
+}
+constexpr int DYN_PW = 32, DYN_PH = 8, DYN_OW = DYN_PW - 2, DYN_OH = DYN_PH - 1;       // patch; owned inner region (left + right column and top row are the ring)
+__global__ __launch_bounds__(256) void k_dyn_detect_union(DMap m, RtCam g, MaskGeom mg, const float* depth, int32_t rows, int32_t cols, float max_d, float vs,
+                                                         int32_t has_freespace, int32_t tiles_x, uint8_t* mask, int32_t* label, uint32_t* zmin) {
+  __shared__ uint8_t s_mask[DYN_PH][DYN_PW];
+  const int px = threadIdx.x & (DYN_PW - 1), py = threadIdx.x / DYN_PW;
+  const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
+  const int32_t r = ty * DYN_OH - 1 + py, c = tx * DYN_OW - 1 + px;
+  const bool in_img = r >= 0 && c >= 0 && r < rows && c < cols;
+  const int32_t i = in_img ? r * cols + c : 0;
+  const float d = in_img ? depth[i] : 0.0f;
+  const bool owned = in_img && px >= 1 && px <= DYN_OW && py >= 1;
+  // the split's nearest depth per mask pixel: needs the depth image only (positive floats order like their bit patterns)
+  if (owned && d > 0.0f) { float z; const int32_t mi = mask_pixel(mg, r, c, d, &z); if (mi >= 0) atomicMin(&zmin[mi], __float_as_uint(z)); }
+  const uint8_t mk = (in_img && has_freespace) ? pixel_is_dynamic(m, g, r, c, d, max_d, vs) : (uint8_t)0;
+  s_mask[py][px] = mk;
+  __syncthreads();
+  if (!owned) return;
+  mask[i] = mk;
+  if (!mk) return;
+  if (s_mask[py][px - 1]) cc_union(label, i, i - 1);
+  if (s_mask[py - 1][px]) cc_union(label, i, i - cols);
+  if (s_mask[py - 1][px - 1]) cc_union(label, i, i - cols - 1);
+  if (s_mask[py - 1][px + 1]) cc_union(label, i, i - cols + 1);
+}
+__global__ __launch_bounds__(256) void k_dyn_filter_split(MaskGeom g, const float* depth, uint8_t* mask, const int32_t* label, const int32_t* size, int32_t min_size, float thr,
+                                                         const uint32_t* zmin, float* unmasked, float* masked, uint8_t* overlay,
+                                                         int32_t* label_next, int32_t* size_next, uint32_t* zmin_next) {
+  const int64_t n = (int64_t)g.rows * g.cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float d = depth[i];
+    bool is_masked = false;
+    if (d > 0.0f) {
+      float z; const int32_t mi = mask_pixel(g, (int32_t)(i / g.cols), (int32_t)(i % g.cols), d, &z);
+      if (mi >= 0 && mask[mi] != 0 && (min_size <= 0 || size[label[mi]] >= min_size) && z <= __uint_as_float(zmin[mi]) + thr) is_masked = true;
+    }
+    if (min_size > 0 && mask[i] && size[label[i]] < min_size) mask[i] = 0;          // this pixel's own bit, cleaned
+    unmasked[i] = (d > 0.0f && is_masked) ? NVBX_MASKED_DEPTH_INVALID : d;
+    masked[i] = (d > 0.0f && is_masked) ? d : NVBX_MASKED_DEPTH_INVALID;
+    if (overlay) {
+      float gv = d > 0.0f ? d * (255.0f / 5.0f) : 0.0f; if (gv > 255.0f) gv = 255.0f;
+      const uint8_t q = (uint8_t)gv;
+      overlay[3 * i] = is_masked ? 255 : q; overlay[3 * i + 1] = q; overlay[3 * i + 2] = q;
+    }
+    label_next[i] = (int32_t)i; size_next[i] = 0; zmin_next[i] = 0x7F7F7F7Fu;       // resting state of the other parity (left behind by the call before this one)
+  }
+}
+extern "C" int nvbx_dynamic_depth_split(nvbx_mapper* m, const float* depth_dev, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera,
+                                        float max_distance_m, int32_t min_component_size, float occlusion_threshold_m,
+                                        uint8_t* mask_dev, float* depth_unmasked_dev, float* depth_masked_dev, uint8_t* overlay_rgb_dev) {
+  if (!m || !depth_dev || !T_L_C || !camera || !mask_dev || !depth_unmasked_dev || !depth_masked_dev || !image_dims_ok(rows, cols)) {
+    set_error("nvbx_dynamic_depth_split: invalid argument (image sides 1 .. 32768)"); return NVBX_E_INVALID; }
+  NVBX_HIP(hipSetDevice(m->device));
+  if (m->join_side_keeping_held()) return NVBX_E_DEVICE;      // (reads TSDF voxels and the freespace layer only: held-back work stays held back, as for nvbx_detect_dynamics)
+  const int64_t n = (int64_t)rows * cols;
+  if (6 * n + 16 > m->dyn_scratch_elems) {
+    NVBX_HIP(hipStreamSynchronize(m->stream));
+    if (m->dyn_scratch) NVBX_HIP(hipFree(m->dyn_scratch));
+    m->dyn_scratch = nullptr; m->dyn_scratch_elems = 0; m->dyn_ready_n = 0;
+    NVBX_HIP(hipMalloc(&m->dyn_scratch, (size_t)(6 * n + 16) * 4));
+    m->dyn_scratch_elems = 6 * n + 16;
+  }
+  int32_t* label2 = m->dyn_scratch; int32_t* size2 = label2 + 2 * n; uint32_t* zmin2 = reinterpret_cast<uint32_t*>(size2 + 2 * n);
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+  if (m->dyn_ready_n != n) {            // first call / another image size: resting state of both parities
+    NVBX_LAUNCH(m, k_dyn_init, dim3(grid), dim3(256), n, label2, size2, zmin2);
+    m->dyn_ready_n = n; m->dyn_parity = 0;
+  }
+  const int par = m->dyn_parity; m->dyn_parity ^= 1;
+  int32_t* label = label2 + (size_t)par * n; int32_t* size = size2 + (size_t)par * n; uint32_t* zmin = zmin2 + (size_t)par * n;
+  const RtCam g = make_rtcam(T_L_C, camera);
+  const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const MaskGeom mg = make_mask_geom(I, camera, camera, rows, cols, rows, cols);       // (the mask is the depth camera's own: MultiMapper::integrateDepth, dynamic mode)
+  const int32_t tiles_x = (cols + DYN_OW - 1) / DYN_OW, tiles_y = (rows + DYN_OH - 1) / DYN_OH;
+  NVBX_LAUNCH(m, k_dyn_detect_union, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), m->d, g, mg, depth_dev, rows, cols, max_distance_m, m->p.voxel_size,
+              (int32_t)(m->d.freespace ? 1 : 0), tiles_x, mask_dev, label, zmin);
+  if (min_component_size > 0) NVBX_LAUNCH(m, k_cc_count, dim3(grid), dim3(256), (const uint8_t*)mask_dev, n, label, size);
+  NVBX_LAUNCH(m, k_dyn_filter_split, dim3(grid), dim3(256), mg, depth_dev, mask_dev, (const int32_t*)label, (const int32_t*)size, min_component_size, occlusion_threshold_m,
+              (const uint32_t*)zmin, depth_unmasked_dev, depth_masked_dev, overlay_rgb_dev, label2 + (size_t)(1 - par) * n, size2 + (size_t)(1 - par) * n, zmin2 + (size_t)(1 - par) * n);
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;
 }

@@ -120,6 +120,8 @@ struct nvbx_mapper {
   int32_t* apply_postab = nullptr; int64_t apply_postab_cap = 0;      // nvbx_apply_measurements: per slot, the record position of each rank (+1)
   int32_t* cc_scratch = nullptr; int64_t cc_scratch_elems = 0;      // connected components: label[n], size[2][n]
   int64_t cc_ready_n = 0; int cc_parity = 0;                         // image size the arrays are initialised for; which size array the next call uses
+  int32_t* dyn_scratch = nullptr; int64_t dyn_scratch_elems = 0;    // nvbx_dynamic_depth_split: label[2][n], size[2][n], nearest depth[2][n] (by call parity)
+  int64_t dyn_ready_n = 0; int dyn_parity = 0;
   // EsdfMode::k3D (esdf3d.hip)
   int update_esdf_3d();
   void* esdf3_scratch = nullptr; int64_t esdf3_scratch_bytes = 0; int64_t esdf3_blocks_marked = 0, esdf3_window_voxels = 0;

@@ -340,6 +340,13 @@ class Mapper:
                                                       C.byref(self._cam(depth_cam)), C.byref(self._cam(mask_cam)), float(occlusion_threshold_m),
                                                       C.c_void_p(unmasked_out.data_ptr()), C.c_void_p(masked_out.data_ptr()), None))
 
+    def dynamic_depth_split_into(self, depth_dev, T_L_C, cam, max_distance_m, min_component_size, occlusion_threshold_m, mask_out, unmasked_out, masked_out, overlay_out=None):
+        """The dynamic-mapping frame's front end in one call (three launches): detect_dynamics -> remove_small_components -> split_depth_by_mask."""
+        self._check(self.lib.nvbx_dynamic_depth_split(self._h, C.c_void_p(depth_dev.data_ptr()), depth_dev.shape[0], depth_dev.shape[1], _np_ptr(self._T(T_L_C)),
+                                                      C.byref(self._cam(cam)), float(max_distance_m), int(min_component_size), float(occlusion_threshold_m),
+                                                      C.c_void_p(mask_out.data_ptr()), C.c_void_p(unmasked_out.data_ptr()), C.c_void_p(masked_out.data_ptr()),
+                                                      C.c_void_p(overlay_out.data_ptr()) if overlay_out is not None else None))
+
     def remove_small_components(self, mask, min_size):
         torch = self._torch
         mk = self._dev(mask, torch.uint8).clone()

@@ -151,3 +151,63 @@ def test_bench_gpus_2_starts_itself_and_prints_one_line():
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak" and out["parity"]["ok"], out
+
+
+@pytest.mark.parametrize("cam", [H.SMALL_CAM, S.REPLICA_LIKE_CAM], ids=["160x120", "640x480"])
+def test_dynamic_front_end_in_three_launches_equals_the_three_calls_and_the_checker(oracle_mod, hip_lib, cam):
+    """nvbx_dynamic_depth_split (detect dynamics -> remove small components -> split, three launches, no memset) against the three separate entry
+    points on a second mapper fed the same frames, and against the checker's detect / remove_small_components / split_depth_by_mask: the cleaned
+    mask and both depth images bit for bit, every frame -- from the first (no freespace layer yet) to frames with a moving box in view; also
+    with the component filter off and with the overlay image."""
+    import torch
+    from isaac_ros_nvblox_amd import mapper as M
+    rows, cols = cam[5], cam[4]
+    min_component = 40 if cols == 160 else 640
+    dev = torch.device("cuda", 0)
+    fs = dict(projective_layer_type=2, max_integration_distance_m=5.0, invalid_depth_decay_factor=0.8, min_duration_since_occupied_for_freespace_ms=250)
+    pg = M.default_params(**fs)
+    a = M.Mapper(pg, block_capacity=1 << 14); b = M.Mapper(pg, block_capacity=1 << 14); o = oracle_mod.OracleMap(H.copy_params(pg, oracle_mod.OrcParams))
+    b.set_profiling(True)
+    eye = np.eye(4, dtype=np.float32)
+    n_dynamic = 0
+    static_scene = S.Scene(); moving = S.Scene(box_min=(1.6, -0.3, 0.0), box_max=(2.0, 0.3, 1.3))      # (the scenes of test_dynamic_mapping_parity)
+    for i in range(14):
+        # the static room for 0.8 s at 10 Hz from a slowly turning camera (free voxels become high-confidence freespace), then an object in mid-room
+        sc = static_scene if i < 8 else moving
+        T = S.trajectory_pose(min(i, 8), 200)
+        d, _ = S.render(sc, T, cam, max_range=5.0, color=False)
+        d_dev = torch.from_numpy(d).to(dev)
+        thr = min_component if i != 9 else 0                      # (one frame with the filter off)
+        mk_a = torch.empty((rows, cols), dtype=torch.uint8, device=dev); un_a = torch.empty((rows, cols), dtype=torch.float32, device=dev); ma_a = torch.empty_like(un_a)
+        a.detect_dynamics_into(d_dev, T, cam, 5.0, mk_a)
+        if thr:
+            a.remove_small_components_inplace(mk_a, thr)
+        a.split_depth_by_mask_into(d_dev, mk_a, eye, cam, cam, 0.25, un_a, ma_a)
+        mk_b = torch.empty_like(mk_a); un_b = torch.empty_like(un_a); ma_b = torch.empty_like(un_a)
+        ov = torch.empty((rows, cols, 3), dtype=torch.uint8, device=dev) if i % 4 == 0 else None
+        b.dynamic_depth_split_into(d_dev, T, cam, 5.0, thr, 0.25, mk_b, un_b, ma_b, ov)
+        a.synchronize(); b.synchronize()            # (each mapper owns its stream; the comparisons run on torch's)
+        assert torch.equal(mk_a, mk_b) and torch.equal(un_a, un_b) and torch.equal(ma_a, ma_b), i
+        mo = o.detect_dynamics(d, T, cam, 5.0)
+        if thr:
+            mo = oracle_mod.remove_small_components(mo, thr)
+        uo, mao = oracle_mod.split_depth_by_mask(d, mo, eye, cam, cam, 0.25)
+        assert np.array_equal(mk_b.cpu().numpy(), mo) and np.array_equal(un_b.cpu().numpy(), uo) and np.array_equal(ma_b.cpu().numpy(), mao), i
+        if ov is not None:
+            red = ov.cpu().numpy()[..., 0] == 255
+            assert np.array_equal(red & (d > 0) & (d * 51.0 < 255.0), (ma_b.cpu().numpy() > 0) & (d * 51.0 < 255.0))
+        n_dynamic += int(mk_b.sum().item())
+        for m_, un_, t_ in ((a, un_a, i * 100), (b, un_b, i * 100)):
+            m_.set_time_ms(t_); m_.integrate_depth(un_, T, cam)
+        o.set_time_ms(i * 100); o.integrate_depth(uo, T, cam)
+    assert n_dynamic > (600 if cols == 160 else 9000), n_dynamic          # the object was detected in several frames (and survived the clean-up)
+    prof = b.profile()
+    names = {bench_short(k_) for k_ in prof}
+    assert "k_dyn_detect_union" in names and "k_dyn_filter_split" in names and not ({"k_detect_dynamics", "k_cc_union", "k_cc_filter", "k_mask_zmin", "k_split_depth"} & names), names
+    per_call = sum(v["count"] for k_, v in prof.items() if bench_short(k_) in ("k_dyn_detect_union", "k_cc_count", "k_dyn_filter_split", "k_dyn_init")) / 14.0
+    assert per_call <= 3.1, per_call
+
+
+def bench_short(name):
+    import bench
+    return bench.short(name)
