@@ -107,7 +107,10 @@ def load_pmc(workload):
     except Exception:
         return {}
     if workload in pmc and isinstance(pmc[workload], dict) and not any(k.startswith("FETCH") for k in pmc[workload]):
-        return pmc[workload]
+        out = dict(pmc[workload])
+        if workload == "camera" and "k_mesh" in pmc.get("camera_mesh", {}):       # (k_mesh: from the pass that updates the mesh every frame, --with-mesh)
+            out["k_mesh"] = pmc["camera_mesh"]["k_mesh"]
+        return out
     return pmc if workload == "camera" else {}
 
 
@@ -711,7 +714,8 @@ def main_camera(args):
             loop_pos[0] = 0
         tags.append(loop_pos[0])
         loop_pos[0] += args.steps
-    dt, dts, base = tm.run(step, barrier, args.steps, args.warmup, before_block=fresh_map)
+    timed_step = (lambda i: step(i, mesh=True)) if args.with_mesh else step       # (--with-mesh: profiling passes that need k_mesh in the trace)
+    dt, dts, base = tm.run(timed_step, barrier, args.steps, args.warmup, before_block=fresh_map)
     per_loop, starts, whole, kept = complete_loops(tags, dts, nu, args.steps)
     dt = float(np.sum(kept)) / len(kept)                 # mean block of the complete loops
     dt_first = float(np.median([dts[i] for i in starts]))
@@ -737,7 +741,9 @@ def main_camera(args):
         return finish_dist(dist, world)
 
     # ---- rank 0 extras (outside the timed region): per-component times, per-kernel roofline, CPU baseline
-    def timed(fn, n):
+    def timed(fn, n, warm=8):
+        for i in range(warm):            # (the first calls of a loop differ: e.g. the first mesh update after many frames without one meshes every block dirtied since)
+            fn(i)
         g.synchronize(); torch.cuda.synchronize(dev); t = time.perf_counter()
         for i in range(n):
             fn(i)
@@ -745,6 +751,7 @@ def main_camera(args):
         return (time.perf_counter() - t) / n * 1e3
 
     n2 = min(args.steps, 100)
+    n2c = 100                                # iterations of the per-component loops (whatever --steps is: 20 iterations between two synchronisations measured the synchronisation)
     comp = {}
     sweep = None
     if args.profile_run:
@@ -757,23 +764,28 @@ def main_camera(args):
         print(json.dumps(out))
         return finish_dist(dist, world)
     if not multicam:
-        comp["tsdf"] = timed(lambda i: g.integrate_prepared(dargs[0][(base + i) % nu]), n2)
-        comp["color"] = timed(lambda i: g.integrate_prepared(cargs[0][(base + i) % nu]), n2)
+        comp["tsdf"] = timed(lambda i: g.integrate_prepared(dargs[0][(base + i) % nu]), n2c)
+        comp["color"] = timed(lambda i: g.integrate_prepared(cargs[0][(base + i) % nu]), n2c)
 
         def esdf_only(i):
             g.integrate_prepared(dargs[0][(base + i) % nu]); g.update_esdf()
-        comp["esdf"] = max(0.0, timed(esdf_only, n2) - comp["tsdf"])
+        comp["esdf"] = max(0.0, timed(esdf_only, n2c) - comp["tsdf"])
 
         def mesh_only(i):
             g.integrate_prepared(dargs[0][(base + i) % nu]); g.update_color_mesh()
-        comp["mesh"] = max(0.0, timed(mesh_only, n2) - comp["tsdf"])
+        comp["mesh"] = max(0.0, timed(mesh_only, n2c) - comp["tsdf"])
+        # the whole frame WITH a mesh update (configs[1] names Mesh): depth + colour + updateEsdf + updateColorMesh per frame -- the mesh reads the
+        # colour layer, so it drains the pipeline every frame (five launches) -- and at the reference's cadence, every 8th frame (mesh 5 Hz against
+        # depth 40 Hz, nvblox_base.yaml:13-23)
+        comp["frame_with_mesh_every_frame"] = timed(lambda i: step(base + i, mesh=True, exchange=False), n2c)
+        comp["frame_with_mesh_every_8th"] = timed(lambda i: step(base + i, mesh=(i % 8 == 7), exchange=False), n2c)
     else:
         # 1 / 2 / 4 / 8 cameras through one mapper: sequential calls vs one batched launch set
         sweep = {}
         for n_ in (1, 2, 4, 8):
-            e = {"sequential_ms": round(timed(lambda i: step(base + i, n=n_, batched=False), n2), 4)}
+            e = {"sequential_ms": round(timed(lambda i: step(base + i, n=n_, batched=False), n2c), 4)}
             if batch_ok:
-                e["batched_ms"] = round(timed(lambda i: step(base + i, n=n_, batched=True), n2), 4)
+                e["batched_ms"] = round(timed(lambda i: step(base + i, n=n_, batched=True), n2c), 4)
             sweep[str(n_)] = e
 
     # per-frame latency (SURVEY 8d timing protocol): every frame is waited for, so this is the latency a caller sees, not the
@@ -937,6 +949,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="camera / multicam: skip the end-state comparison of the timed sequence with the checker (outside the timed region)")
     ap.add_argument("--profile-run", action="store_true", help="camera / multicam: only the timed step is launched (for rocprofv3 runs: clean per-kernel averages)")
+    ap.add_argument("--with-mesh", action="store_true", help="camera: the timed step also updates the colour mesh (TSDF+Color+ESDF+Mesh per frame; profiling passes for k_mesh)")
     ap.add_argument("--no-color-deferral", action="store_true", help="camera workload: classic launch order (4 launches per frame) instead of the cross-frame pipeline")
     ap.add_argument("--separate-front-end", action="store_true", help="decay workload: detect / remove-small-components / split as three entry points (A/B against nvbx_dynamic_depth_split)")
     ap.add_argument("--step-trace", type=int, default=0, help="decay workload: wait for every one of this many steps and report the slowest (diagnosis)")
