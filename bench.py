@@ -725,7 +725,7 @@ def main_camera(args):
         step(base + i)
     dt_rev, dts_rev, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 4, first=base + nu)
     ms_revisit = dt_rev / args.steps * 1e3
-    ms_classic = None; ms_classic_exploring = None
+    ms_classic = None; ms_classic_exploring = None; ms_staged = None
     if deferral and not args.profile_run:    # the same revisit blocks in the classic launch order, for the record
         g.set_color_deferral(False)
         dt_c, dts_c, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 4, first=base)
@@ -735,6 +735,11 @@ def main_camera(args):
         dt_ce, dts_ce, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 2, before_block=fresh_map, first=0)
         _, _, whole_c, kept_c = complete_loops(tags[n_tags0:], dts_ce, nu, args.steps)
         ms_classic_exploring = float(np.sum(kept_c)) / len(kept_c) / args.steps * 1e3
+        # ... and with the STAGED copy (nvbx_mapper_set_color_deferral(m, 2), what the nvblox:: facade's setColorIntegrationDeferred(true) switches
+        # on): the held-back frame is copied into mapper-owned memory, no lifetime contract on the caller's image
+        g.set_color_deferral(True, staged=True)
+        dt_s, dts_s, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 4, first=base)
+        ms_staged = dt_s / args.steps * 1e3
         g.set_color_deferral(True)
 
     if rank != 0:
@@ -897,7 +902,8 @@ def main_camera(args):
                                "fuser.yaml params, TSDF+Color+ESDF every frame (mesh timed separately)",
                    "cameras_per_gpu": ncam, "parallelism": ("one camera per GPU, RCCL all-gather of per-voxel measurements, one fused map on every rank" if fuse else "one camera per GPU, RCCL all-gather of dirty block indices") if world > 1 else "single GPU",
                    "unique_frames": nu,
-                   "mode": ("color_deferral: nvbx_mapper_set_color_deferral(1) -- OPT-IN, the nvblox:: facade leaves it off (Mapper::setColorIntegrationDeferred); "
+                   "mode": ("color_deferral, zero-copy: nvbx_mapper_set_color_deferral(m, 1) -- OPT-IN (the nvblox:: facade leaves deferral off; its "
+                            "Mapper::setColorIntegrationDeferred(true) switches on the staged-copy form, color_deferral.ms_per_step_revisit_staged_copy); "
                             "a host that only swaps the library runs the classic order, quoted as ms_per_step_classic_order") if deferral else "classic launch order (the facade default)"},
         "ms_per_frame": round(ms_per_step / ncam, 4),
         "ms_per_step_classic_order": (round(ms_classic_exploring, 4) if ms_classic_exploring else (None if deferral else round(ms_per_step, 4))),
@@ -912,6 +918,7 @@ def main_camera(args):
         "ms_per_step_revisit": round(ms_revisit, 4),
         "color_deferral": {"enabled": bool(deferral), "launches_per_frame": launches_per_frame,
                            "ms_per_step_revisit_classic_order": (round(ms_classic, 4) if ms_classic else None),
+                           "ms_per_step_revisit_staged_copy": (round(ms_staged, 4) if ms_staged else None),
                            "note": "enabled: integrateColor(i) / updateEsdf(i) are held back and carried out by integrateDepth(i+1) in pipelined order: "
                                    "launch 1 = view marking(i+1) || sphere tracing(i) || colour candidates(i) || ESDF marking(i), launch 2 = TSDF update(i+1) "
                                    "|| colour integration(i) || distance transform(i) (NVBX_FUSE_COLC=0: three launches); same calls, bit-identical map "

@@ -258,7 +258,9 @@ class Mapper {
 
   // libnvblox_hip extension (not in the reference; off by default): cross-frame pipelining of integrateColor -- see nvbx_mapper_set_color_deferral
   // in nvblox_hip.h for the colour-image lifetime contract the caller accepts with it
-  void setColorIntegrationDeferred(bool on) { checkNvbx(nvbx_mapper_set_color_deferral(m_, on ? 1 : 0), "nvbx_mapper_set_color_deferral"); }
+  // (staged: the held-back frame is copied into mapper-owned memory, so the caller's ColorImage may be refilled right after integrateColor
+  //  returns -- what a node does with its one colour buffer; `zero_copy` = no copy, the caller keeps the image unchanged until the next call)
+  void setColorIntegrationDeferred(bool on, bool zero_copy = false) { checkNvbx(nvbx_mapper_set_color_deferral(m_, on ? (zero_copy ? 1 : 2) : 0), "nvbx_mapper_set_color_deferral"); }
   void synchronize() const { checkNvbx(nvbx_synchronize(m_), "nvbx_synchronize"); }
   void flush() const { checkNvbx(nvbx_flush(m_), "nvbx_flush"); }      // enqueue held-back work without waiting
   nvbx_mapper* c_handle() const { return m_; }

@@ -215,7 +215,11 @@ int nvbx_flush(nvbx_mapper* m);
  * (the dynamic-mapping frame starts with them; they read TSDF voxels / the freespace layer / images only).  nvblox_ros re-uses ONE
  * colour buffer per node (nvblox_node.hpp:485-488) and fills it right before integrateColor, after the depth frame -- compatible with the
  * contract for the depth -> colour -> updateEsdf order of NvbloxNode::tick(); a node that fills the colour buffer BEFORE calling
- * integrateDepth must double-buffer it or leave deferral off.  Argument errors are still reported by the call that made them. */
+ * integrateDepth must double-buffer it or leave deferral off.  Argument errors are still reported by the call that made them.
+ * enable = 2: the same pipeline WITHOUT the contract -- a frame that is held back is first copied into staging memory the mapper owns (one
+ * asynchronous device-to-device copy on the mapper's stream per frame, ~0.9 MB at 640x480), so the caller may overwrite or free its image as
+ * soon as nvbx_integrate_color has returned, exactly as with deferral off.  This is what the nvblox:: facade switches on
+ * (Mapper::setColorIntegrationDeferred): a ROS callback that recycles its colour buffer stays correct.  enable = 1: no copy, the contract above. */
 int nvbx_mapper_set_color_deferral(nvbx_mapper* m, int32_t enable);
 /* The hipStream_t all of the mapper's work is enqueued on (the one handed to nvbx_mapper_create, or the library-owned one):
  * implicit conversion of nvblox::CudaStream to cudaStream_t -- conversions/esdf_slice_conversions.cu:107-108.  A caller that

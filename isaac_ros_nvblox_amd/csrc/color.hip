@@ -169,8 +169,21 @@ static bool defer_color(nvbx_mapper* m, int kind, int32_t n, const void* const* 
   if (*rc_out) return true;
   if (hipSetDevice(m->device) != hipSuccess || m->replay_deferred()) { *rc_out = NVBX_E_DEVICE; return true; }     // an older held-back frame goes first
   nvbx_mapper::ColorPending& c = m->color_pending;
+  if (m->color_staging) {            // the frame travels in the mapper's own memory from here on (a host that recycles its colour buffer)
+    const size_t bytes = (size_t)rows * (size_t)cols * (kind == 0 ? 3u : 4u);
+    if (bytes > m->color_stage_bytes) {
+      if (hipStreamSynchronize(m->stream) != hipSuccess) { *rc_out = NVBX_E_DEVICE; return true; }
+      for (int i = 0; i < MAX_BATCH; i++) { if (m->color_stage[i]) (void)hipFree(m->color_stage[i]); m->color_stage[i] = nullptr; }
+      m->color_stage_bytes = 0;
+      for (int i = 0; i < MAX_BATCH; i++) if (hipMalloc(&m->color_stage[i], bytes) != hipSuccess) { set_error("colour staging buffers"); *rc_out = NVBX_E_DEVICE; return true; }
+      m->color_stage_bytes = bytes;
+    }
+    for (int i = 0; i < n; i++) {
+      if (hipMemcpyAsync(m->color_stage[i], imgs[i], bytes, hipMemcpyDeviceToDevice, m->stream) != hipSuccess) { set_error("colour staging copy"); *rc_out = NVBX_E_DEVICE; return true; }
+    }
+  }
   c.on = true; c.kind = kind; c.n = n; c.rows = rows; c.cols = cols;
-  for (int i = 0; i < n; i++) { c.imgs[i] = imgs[i]; c.cams[i] = cameras[i]; }
+  for (int i = 0; i < n; i++) { c.imgs[i] = m->color_staging ? m->color_stage[i] : imgs[i]; c.cams[i] = cameras[i]; }
   memcpy(c.T, T_L_C, sizeof(float) * 16 * (size_t)n);
   *rc_out = NVBX_OK;
   return true;

@@ -378,6 +378,7 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
                   m->view_list, d.lists, d.shc, m->export_idx, m->export_count, m->cleared_idx, d.site_bits, d.obs_bits, d.inside_bits,
                   m->synth, m->view_class, m->color_cand, m->depth_pre, m->mask_zmin, m->apply_postab, m->esdf3_scratch, m->cc_scratch, m->dyn_scratch, d.freespace, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (void* p : m->color_stage) if (p) (void)hipFree(p);
   for (auto& s : m->spans) { if (s.a) (void)hipEventDestroy(s.a); if (s.b) (void)hipEventDestroy(s.b); }
   for (hipEvent_t e : m->event_pool) if (e) (void)hipEventDestroy(e);
   if (m->h_counters) (void)hipHostFree(m->h_counters);
@@ -928,7 +929,8 @@ int nvbx_mapper::replay_deferred() {
 extern "C" int nvbx_mapper_set_color_deferral(nvbx_mapper* m, int32_t enable) {
   if (!m) return NVBX_E_INVALID;
   if (m->join_side()) return NVBX_E_DEVICE;          // (anything held back under the old setting is carried out)
-  m->color_deferral = enable != 0;
+  if (enable < 0 || enable > 2) { set_error("nvbx_mapper_set_color_deferral: 0 = off, 1 = on (the caller keeps the image valid), 2 = on with a staged copy"); return NVBX_E_INVALID; }
+  m->color_deferral = enable != 0; m->color_staging = enable == 2;
   return NVBX_OK;
 }
 int nvbx_mapper::mark_main() {

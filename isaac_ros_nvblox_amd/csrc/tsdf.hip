@@ -265,13 +265,17 @@ __device__ inline bool lset_insert(u64* lset, const int32_t* cur, u64 key, bool*
   return false;
 }
 // Amanatides-Woo: advance to the next block along the ray (select without dynamic register indexing)
+// (select-only: as three exec-masked branches a step cost ~300 cycles of a lone wavefront -- a LiDAR lane replays up to 234 of them before it
+//  reaches its segment of a 200 m ray, 35 of the slowest bundle's 78 us, tools/wg_timeline_lidar.py; the same comparisons and the same one
+//  addition on the chosen axis' tmax, so the traversal is bit-identical)
 __device__ inline void dda_step(int32_t* cur, const int32_t* step, float* tmax, const float* tdelta) {
-  int a = 0;
-  if (tmax[1] < tmax[a]) a = 1;
-  if (tmax[2] < tmax[a]) a = 2;
-  if (a == 0) { cur[0] += step[0]; tmax[0] = tmax[0] + tdelta[0]; }
-  else if (a == 1) { cur[1] += step[1]; tmax[1] = tmax[1] + tdelta[1]; }
-  else { cur[2] += step[2]; tmax[2] = tmax[2] + tdelta[2]; }
+  const bool s1 = tmax[1] < tmax[0];
+  const float m01 = s1 ? tmax[1] : tmax[0];
+  const bool s2 = tmax[2] < m01;
+  const bool a0 = !s1 && !s2, a1 = s1 && !s2;
+  const float t0 = tmax[0] + tdelta[0], t1 = tmax[1] + tdelta[1], t2 = tmax[2] + tdelta[2];
+  tmax[0] = a0 ? t0 : tmax[0]; tmax[1] = a1 ? t1 : tmax[1]; tmax[2] = s2 ? t2 : tmax[2];
+  cur[0] += a0 ? step[0] : 0; cur[1] += a1 ? step[1] : 0; cur[2] += s2 ? step[2] : 0;
 }
 // Flush: compact the set (ballot + popcount), then every key goes to HBM with the dependent round trips taken
 // PHASE-WISE over up to R keys per lane at once: (A) the first PD probe positions of every key are loaded together
@@ -564,6 +568,10 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   // LiDAR: hundreds of steps per ray and little sharing at long range -- wave-uniform loop, flush whenever the set is
   // half full
   int32_t nset = 0;                                   // keys in the LDS set (wave-uniform)
+#ifdef NVBX_WG_TIMES
+  unsigned long long t_flush = 0, n_flush = 0, n_keys = 0;     // (tools/wg_timeline.py --lidar: time inside the flushes, their number, keys sent to HBM)
+  NVBX_T(0, 1);
+#endif
   for (int32_t j = 0; __ballot(k0 + j <= k1) != 0ull; j++) {
     bool spill = false, added = false;
     u64 key = KEY_EMPTY;
@@ -579,8 +587,20 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
       view_append(cnt, view_list, list_cap, first, rec, lane);
     }
     const bool last = __ballot(k0 + j + 1 <= k1) == 0ull;
-    if (last || nset > LSET_FLUSH) { flush_set<LSET, FR, Sensor::kProbeDepth>(m, f, lset, lkeys, cnt, view_list, list_cap, lane, !last); nset = 0; }
+#ifdef NVBX_WG_TIMES
+    const unsigned long long tf0 = (last || nset > LSET_FLUSH) ? wall_clock64() : 0ull;
+#endif
+    if (last || nset > LSET_FLUSH) {
+      flush_set<LSET, FR, Sensor::kProbeDepth>(m, f, lset, lkeys, cnt, view_list, list_cap, lane, !last);
+#ifdef NVBX_WG_TIMES
+      t_flush += wall_clock64() - tf0; n_flush++; n_keys += (unsigned long long)nset;
+#endif
+      nset = 0;
+    }
   }
+#ifdef NVBX_WG_TIMES
+  NVBX_TV(0, 2, t_flush); NVBX_TV(0, 3, n_flush); NVBX_TV(0, 4, n_keys); NVBX_T(0, 7);
+#endif
 }
 
 // A wave-uniform value the inner loop uses as a VALU operand, parked in a vector register: the LiDAR instantiation needs ~100 scalar

@@ -86,11 +86,12 @@ class Mapper:
     def set_max_capacity(self, max_blocks):
         self._check(self.lib.nvbx_mapper_set_max_capacity(self._h, int(max_blocks)))
 
-    def set_color_deferral(self, enable):
+    def set_color_deferral(self, enable, staged=False):
         """Hold integrateColor (and an updateEsdf behind it) back until the next integrateDepth carries them out in pipelined order (two
-        launches per frame instead of four; include/nvblox_hip.h nvbx_mapper_set_color_deferral).  The colour image handed to integrate_color must
-        then stay valid and unchanged until the next call into the mapper has returned."""
-        self._check(self.lib.nvbx_mapper_set_color_deferral(self._h, 1 if enable else 0))
+        launches per frame instead of four; include/nvblox_hip.h nvbx_mapper_set_color_deferral).  staged=False: the colour image handed to
+        integrate_color must then stay valid and unchanged until the next call into the mapper has returned; staged=True: the mapper copies a
+        held-back frame into its own memory first (what the nvblox:: facade switches on), no such contract."""
+        self._check(self.lib.nvbx_mapper_set_color_deferral(self._h, (2 if staged else 1) if enable else 0))
 
     # -- ground plane (MultiMapper::ground_plane_estimator())
     def tsdf_zero_crossings(self, min_z_m, max_z_m):

@@ -211,3 +211,39 @@ def test_dynamic_front_end_in_three_launches_equals_the_three_calls_and_the_chec
 def bench_short(name):
     import bench
     return bench.short(name)
+
+
+def test_staged_colour_deferral_survives_a_recycled_colour_buffer(oracle_mod, hip_lib):
+    """nvbx_mapper_set_color_deferral(m, 2) -- what nvblox::Mapper::setColorIntegrationDeferred(true) switches on: the held-back frame is copied into
+    mapper-owned memory, so a host that refills or scribbles over its ONE colour buffer right after integrateColor returns (a ROS callback,
+    nvblox_node.hpp:485-488) still gets the classic result, bit for bit, in two launches per frame.  (Zero-copy deferral, mode 1, would read the
+    scribbled buffer: its contract forbids exactly this.)"""
+    import torch
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        pg = M.default_params()
+        classic = M.Mapper(pg, block_capacity=1 << 13, stream=stream.cuda_stream); staged = M.Mapper(pg, block_capacity=1 << 13, stream=stream.cuda_stream)
+        zero_copy = M.Mapper(pg, block_capacity=1 << 13, stream=stream.cuda_stream)
+        staged.set_color_deferral(True, staged=True); staged.set_profiling(True)
+        zero_copy.set_color_deferral(True)
+        buf = torch.empty((cam[5], cam[4], 3), dtype=torch.uint8, device=dev)          # the host's one colour buffer
+        noise = torch.randint(0, 255, buf.shape, dtype=torch.uint8, device=dev)
+        for k, (d, rgb, T) in enumerate(H.frames(10, cam, stride=7)):
+            d_dev = torch.from_numpy(d).to(dev)
+            for m_ in (classic, staged, zero_copy):
+                m_.integrate_depth(d_dev, T, cam)
+                buf.copy_(torch.from_numpy(rgb).to(dev))
+                m_.integrate_color(buf, T, cam)
+                buf.copy_(noise)                               # recycled before the next call into the mapper
+                m_.update_esdf()
+        for m_ in (classic, staged, zero_copy):
+            m_.synchronize()
+    bit_equal(M, classic, staged, "staged deferral")
+    ic = classic.block_indices(M.LAYER_COLOR)
+    bc, _ = classic.get_blocks(M.LAYER_COLOR, ic); bz, _ = zero_copy.get_blocks(M.LAYER_COLOR, ic)
+    assert not np.array_equal(bc["r"], bz["r"])              # (the test does scribble where it matters: the zero-copy mapper integrated the noise)
+    prof = staged.profile()
+    assert sum(v["count"] for k_, v in prof.items() if "k_integrate_tsdf_color" in k_) >= 8, {k_: v["count"] for k_, v in prof.items()}
