@@ -695,7 +695,10 @@ def main_camera(args):
     # integrateDepth(i+1) in two launches per frame instead of four (view marking(i+1) || sphere tracing(i) || colour candidates(i) || ESDF marking(i),
     # then TSDF update(i+1) || colour integration(i) || distance transform(i)).  Same calls, same map;
     # the caller keeps the colour image valid until its next call (the bench's images are resident).  --no-color-deferral: the classic order.
-    deferral = world == 1 and not args.no_color_deferral and ((not multicam) or (batch_ok and ncam in bd))      # (batches: the depth batch carries the held-back colour batch)
+    # (batches: the depth batch carries the held-back colour batch; N > 1 ranks with the index exchange take the pipeline too -- the union step
+    #  of the peers' lists rides in the fused TSDF-update launch, dist.PipelinedDirtyBlockExchange rotates three buffer sets; the measurement
+    #  exchange (--fusion measurements) applies whole frames one step late and keeps the classic order)
+    deferral = (world == 1 or not fuse) and not args.no_color_deferral and ((not multicam) or (batch_ok and ncam in bd))
     g.set_color_deferral(deferral)
 
     # EXPLORING (the headline): the map is EMPTIED at the start of every loop over the nu unique poses and the timed blocks of K steps tile the
@@ -922,9 +925,9 @@ def main_camera(args):
                            "note": "enabled: integrateColor(i) / updateEsdf(i) are held back and carried out by integrateDepth(i+1) in pipelined order: "
                                    "launch 1 = view marking(i+1) || sphere tracing(i) || colour candidates(i) || ESDF marking(i), launch 2 = TSDF update(i+1) "
                                    "|| colour integration(i) || distance transform(i) (NVBX_FUSE_COLC=0: three launches); same calls, bit-identical map "
-                                   "(tests/test_gpu_pipeline.py); contract: include/nvblox_hip.h nvbx_mapper_set_color_deferral.  N > 1 GPUs run the CLASSIC "
-                                   "order (four launches per frame): the index exchange's gathered lists are double-buffered per frame and the pipelined order "
-                                   "would read them one launch later -- the N = 1 figure to compare an N > 1 line with is ms_per_step_revisit_classic_order"},
+                                   "(tests/test_gpu_pipeline.py); contract: include/nvblox_hip.h nvbx_mapper_set_color_deferral.  N > 1 GPUs with the index "
+                                   "exchange run the same two launches: the union step of the peers' gathered lists rides in launch 2 (three rotating buffer "
+                                   "sets, DESIGN.md 6.1); --fusion measurements keeps the classic order"},
         "block_ms": [round(d / args.steps * 1e3, 4) for d in dts[:16]],
         "ms_components": {k_: round(v_, 4) for k_, v_ in comp.items()},
         "components_note": "ms_components are measured per call in isolation: the EDT of updateEsdf is held back and runs inside the next depth "

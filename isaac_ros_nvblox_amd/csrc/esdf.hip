@@ -178,7 +178,9 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
   // a distance transform still held back by the PREVIOUS update goes first: this update's marking pass overwrites the masks
   // and the parity-indexed window record it reads, and edt_args holds one update only (two updates back to back)
   if (m->flush_edt()) return NVBX_E_DEVICE;
-  if (m->flush_import()) return NVBX_E_DEVICE;     // a held-back union step belongs to this update
+  // a held-back union step belongs to this update -- except in pipelined order with the fused launch, where it rides in the TSDF-update launch
+  // that follows and dirties the peers' blocks for the NEXT marking pass (tsdf.hip)
+  if (!m->pipelined_order && m->flush_import()) return NVBX_E_DEVICE;
   if (m->dirty_since_mark) m->mark_pass++;
   const EsdfArgs a = m->make_esdf_args();
   hipStream_t s = m->stream;

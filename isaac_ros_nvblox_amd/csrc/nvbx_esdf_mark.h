@@ -166,4 +166,23 @@ __device__ inline void esdf_import_mark_worker(const DMap& m, const EsdfArgs& a,
   }
 }
 
+// The union step WITHOUT the marking, for the two-launch pipeline: thread `t` of `nt` over all peers' entries -- every peer block
+// that exists locally as a TSDF block becomes ESDF-dirty (flag + dirty list, de-duplicated by the flag like every other append), to be re-marked
+// by the NEXT marking pass.  Rides in the TSDF-update launch: nothing there inserts into the hash, and the update's own appends go through the
+// same flag, so a block both updated locally and named by a peer is listed once.
+__device__ inline void esdf_import_dirty_worker(const DMap& m, const ImportArgs& imp, int64_t t, int64_t nt) {
+  for (int32_t r = 0; r < imp.world; r++) {
+    if (r == imp.self_rank) continue;
+    const int32_t* base = imp.g + (size_t)r * (size_t)(imp.max_count + 1) * 3;
+    int64_t n = base[0]; if (n > imp.max_count) n = imp.max_count;
+    const int32_t* idx = base + 3;
+    for (int64_t i = t; i < n; i += nt) {
+      const uint32_t s = find_slot(m, idx[3 * i], idx[3 * i + 1], idx[3 * i + 2], F_TSDF);
+      if (!slot_ok(s)) continue;
+      const uint32_t old = atomicOr(&m.slot_flags[s], F_DIRTY_ESDF);
+      if (!(old & F_DIRTY_ESDF)) list_append(m, S_LIST_ESDF_DIRTY, (int32_t)s);
+    }
+  }
+}
+
 }  // namespace nvbx

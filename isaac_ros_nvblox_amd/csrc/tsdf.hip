@@ -736,7 +736,7 @@ template <typename Img, typename Pix, int NB, bool Plain>
 __global__ __launch_bounds__(512) void k_integrate_tsdf_color(DMap m, FrameSet<Img, NB> fs, CameraSensor sensor, const int4* view_list, int32_t list_cap,
                                                               int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, int32_t n_tsdf_wg,
                                                               FrameSetC<Pix, NB> fsc, const float* synth, int32_t srows, int32_t scols, const int4* cand, int32_t cand_cnt_idx,
-                                                              int32_t n_edt_wg, EsdfArgs ea) {
+                                                              int32_t n_edt_wg, EsdfArgs ea, ImportArgs imp) {
   __shared__ __align__(16) unsigned char smem[sizeof(EdtShared)];
   const int32_t b = (int32_t)blockIdx.x;
   NVBX_T(1, 0);
@@ -746,11 +746,14 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf_color(DMap m, FrameSet<I
     NVBX_T(1, 2); NVBX_T(1, 7);
     return;
   }
-  color_integrate_list_worker<Pix, NB>(m, fsc, synth, srows, scols, mesh_list, cand, cand_cnt_idx, b - n_edt_wg - n_tsdf_wg, (int32_t)gridDim.x - n_edt_wg - n_tsdf_wg);
+  // (multi-GPU, imp.n_wg > 0: the LAST workgroups resolve the peers' gathered block lists into ESDF-dirty flags, nvbx_esdf_mark.h)
+  const int32_t n_color_wg = (int32_t)gridDim.x - n_edt_wg - n_tsdf_wg - imp.n_wg;
+  if (b >= n_edt_wg + n_tsdf_wg + n_color_wg) { esdf_import_dirty_worker(m, imp, (int64_t)(b - n_edt_wg - n_tsdf_wg - n_color_wg) * 512 + threadIdx.x, (int64_t)imp.n_wg * 512); return; }
+  color_integrate_list_worker<Pix, NB>(m, fsc, synth, srows, scols, mesh_list, cand, cand_cnt_idx, b - n_edt_wg - n_tsdf_wg, n_color_wg);
   NVBX_T(1, 3); NVBX_T(1, 7);
 }
 // (a depth batch AND a colour batch in one argument block: the 4 KiB kernel-argument limit is why the colour path's frames are FrameCore)
-static_assert(sizeof(DMap) + sizeof(FrameSet<DepthF32, MAX_BATCH>) + sizeof(FrameSetC<PixRgb8, MAX_BATCH>) + sizeof(EsdfArgs) + 160 <= 4096, "k_integrate_tsdf_color<.., MAX_BATCH>: kernel arguments");
+static_assert(sizeof(DMap) + sizeof(FrameSet<DepthF32, MAX_BATCH>) + sizeof(FrameSetC<PixRgb8, MAX_BATCH>) + sizeof(EsdfArgs) + sizeof(ImportArgs) + 160 <= 4096, "k_integrate_tsdf_color<.., MAX_BATCH>: kernel arguments");
 static_assert(sizeof(DMap) + sizeof(FrameSet<DepthF32, MAX_BATCH>) + sizeof(TraceRiderT<MAX_BATCH>) + sizeof(EsdfArgs) + 64 <= 4096, "k_mark_view<.., MAX_BATCH>: kernel arguments");
 
 int nvbx_mapper::ensure_fuse_buffers() {
@@ -1033,7 +1036,7 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
     // TSDF mapper (with or without a freespace layer), 2-D ESDF by the exact transform (the marking pass / distance transform that ride are the
     // 2-D ones), no multi-GPU union step waiting for the colour launch, and no block that may be F_BAND_STALE (the candidate riders read the
     // band flags only)
-    fused = has_color ? (fuse_on && m->p.projective_layer_type != 1 && m->p.esdf_mode == 0 && m->p.esdf_propagation == 0 && !m->import_pending && !m->lidar_integrated && m->capacity <= (1ll << 24))
+    fused = has_color ? (fuse_on && m->p.projective_layer_type != 1 && m->p.esdf_mode == 0 && m->p.esdf_propagation == 0 && !m->lidar_integrated && m->capacity <= (1ll << 24))
                       : true;      // (no colour: no candidates, no band flags -- esdf_only_carry has checked the rest)
     // (a distance transform armed outside the pipeline must precede the marking pass that rides in this launch: its own launch, rare)
     if (fused && edt_wg) { m->edt_pending = true; edt_wg = 0; if (m->flush_edt()) return NVBX_E_DEVICE; }
@@ -1092,9 +1095,17 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
       const int32_t cand_idx = tr.cand_cnt_idx;
       const int64_t c_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[3], __ATOMIC_RELAXED));         // candidates of the last colour frame the GPU has finished
       const int cgrid = !has_color ? 0 : (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, 1024), ((c_hint + c_hint / 4 + 64 + 7) / 8) * 8));      // (no colour frame: update + distance transform only)
-      const dim3 g((unsigned)(n_edt + grid + cgrid));
+      // a held-back union step of the multi-GPU exchange (nvbx_mark_esdf_dirty_gathered_deferred) rides here in eight workgroups: the peers'
+      // blocks become ESDF-dirty for the NEXT marking pass (its own marking launch, or a ride in the colour launch, would be a third launch;
+      // beside this frame's view marking it would meet blocks that launch is just allocating -- DESIGN.md 6.1)
+      ImportArgs imp{};
+      if (m->import_pending) {
+        imp.g = m->import_ptr; imp.world = m->import_world; imp.self_rank = m->import_rank; imp.max_count = m->import_max; imp.n_wg = 8;
+        m->import_pending = false;
+      }
+      const dim3 g((unsigned)(n_edt + grid + cgrid + imp.n_wg));
 #define NVBX_FUSED_LAUNCH(PIX, PLAIN, FC) NVBX_LAUNCH(m, (k_integrate_tsdf_color<Img, PIX, NB, PLAIN>), g, dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, \
-        m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (int32_t)grid, FC, (const float*)m->synth, f_srows, f_scols, cand, cand_idx, n_edt, ea_edt)
+        m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (int32_t)grid, FC, (const float*)m->synth, f_srows, f_scols, cand, cand_idx, n_edt, ea_edt, imp)
       if (NB > 1 || f_kind == 0) {
         if (plain) NVBX_FUSED_LAUNCH(PixRgb8, true, fsc); else NVBX_FUSED_LAUNCH(PixRgb8, false, fsc);
       } else if constexpr (NB == 1) {

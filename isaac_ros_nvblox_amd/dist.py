@@ -90,11 +90,16 @@ class PipelinedDirtyBlockExchange:
     just before frame i+1's ESDF update, so the collective has a whole frame of GPU work (colour(i), ESDF(i), depth(i+1),
     colour(i+1)) to hide its latency behind instead of one colour pass.  Every list is still applied exactly once, one ESDF
     update later than in the unpipelined form -- for the peers' lists that is immaterial (each GPU sweeps its OWN TSDF over
-    the union; a peer's update of a block changes nothing in the local layer).  Two buffer sets alternate, so the buffers of
-    the collective in flight are never written.  drain() joins the last one (call it before reading results / timing)."""
+    the union; a peer's update of a block changes nothing in the local layer).  THREE buffer sets rotate: the set whose
+    collective is in flight is never written, and neither is the set a mapper with colour deferral still reads -- there the
+    union step of frame i's lists rides in a launch of integrateDepth(i + 2) (the fused TSDF-update launch),
+    i.e. while frame i + 1's collective is in flight and frame i + 2's message is being written.  drain() joins the last one
+    (call it before reading results / timing)."""
+
+    N_SLOTS = 3
 
     def __init__(self, max_blocks, device, group=None):
-        self.slots = [DirtyBlockExchange(max_blocks, device, group), DirtyBlockExchange(max_blocks, device, group)]
+        self.slots = [DirtyBlockExchange(max_blocks, device, group) for _ in range(self.N_SLOTS)]
         self.world = self.slots[0].world
         self.frame = 0
         self.pending = None          # (slot, work) of the frame whose lists have not been applied yet
@@ -102,12 +107,12 @@ class PipelinedDirtyBlockExchange:
 
     def before_depth(self, mapper):
         """Optional, before integrateDepth of the current frame: the depth pass itself writes the message (no export launch)."""
-        mapper.set_view_export(self.slots[self.frame & 1].buf)
+        mapper.set_view_export(self.slots[self.frame % self.N_SLOTS].buf)
         self.registered = True
 
     def start(self, mapper):
         """After integrateDepth of the current frame."""
-        slot = self.slots[self.frame & 1]
+        slot = self.slots[self.frame % self.N_SLOTS]
         self.started = (slot, slot.start(mapper, export=not getattr(self, "registered", False)))
         self.registered = False
         self.frame += 1

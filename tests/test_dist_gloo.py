@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -65,16 +66,13 @@ def test_single_process_exchange_is_identity():
 
 
 class _StubMapper:
-    """Stands in for Mapper in the pipelined exchange: exports a per-frame list that encodes (rank, frame), records what is applied."""
-    def __init__(self, rank):
-        self.rank = rank; self.frame = 0; self.applied = []
+    """Stands in for Mapper in the pipelined exchange: exports a per-frame list that encodes (rank, frame), records what is applied.
+    late_read: like a mapper with colour deferral on, a deferred union step is only REMEMBERED (the gathered buffer by reference) and read while the
+    NEXT frame's depth pass runs -- here: when that frame's message is exported -- so the buffer set must still hold the lists then."""
+    def __init__(self, rank, late_read=False):
+        self.rank = rank; self.frame = 0; self.applied = []; self.late_read = late_read; self.held = None
 
-    def esdf_dirty_list(self, idx_out, count_out):
-        n = 3 + self.rank + (self.frame % 2)
-        idx_out[:n] = torch.tensor([[self.rank, self.frame, k] for k in range(n)], dtype=torch.int32)
-        count_out[0] = n
-
-    def mark_esdf_dirty_gathered(self, gathered, world, self_rank, max_count, deferred=False):
+    def _read(self, gathered, world, self_rank):
         got = []
         for r in range(world):
             if r == self_rank:
@@ -82,13 +80,28 @@ class _StubMapper:
             c = int(gathered[r, 0, 0]); got += [tuple(v) for v in gathered[r, 1:1 + c].tolist()]
         self.applied.append(got)
 
+    def esdf_dirty_list(self, idx_out, count_out):
+        if self.held is not None:            # the held-back union step rides in this frame's depth launches
+            self._read(*self.held); self.held = None
+        n = 3 + self.rank + (self.frame % 2)
+        idx_out[:n] = torch.tensor([[self.rank, self.frame, k] for k in range(n)], dtype=torch.int32)
+        count_out[0] = n
 
-def _pipelined_worker(rank, world, port, q):
+    def mark_esdf_dirty_gathered(self, gathered, world, self_rank, max_count, deferred=False):
+        if self.late_read and deferred:
+            self.held = (gathered, world, self_rank)
+        else:
+            if self.held is not None:
+                self._read(*self.held); self.held = None
+            self._read(gathered, world, self_rank)
+
+
+def _pipelined_worker(rank, world, port, q, late_read=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from isaac_ros_nvblox_amd.dist import PipelinedDirtyBlockExchange
     ex = PipelinedDirtyBlockExchange(16, torch.device("cpu"))
-    m = _StubMapper(rank)
+    m = _StubMapper(rank, late_read)
     n_frames = 5
     for f in range(n_frames):           # bench.py's step: depth, start, finish_previous (deferred), colour, updateEsdf
         m.frame = f
@@ -104,11 +117,12 @@ def _pipelined_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_pipelined_exchange_applies_every_list_once_one_frame_late_world2():
+@pytest.mark.parametrize("late_read", [False, True], ids=["classic_order", "deferred_mapper_reads_one_depth_pass_later"])
+def test_pipelined_exchange_applies_every_list_once_one_frame_late_world2(late_read):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, q, late_read)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

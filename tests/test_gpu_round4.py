@@ -151,6 +151,7 @@ def test_bench_gpus_2_starts_itself_and_prints_one_line():
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak" and out["parity"]["ok"], out
+    assert out["color_deferral"]["enabled"] and out["color_deferral"]["launches_per_frame"] == 2, out["color_deferral"]      # N > 1 ranks take the two-launch pipeline
 
 
 @pytest.mark.parametrize("cam", [H.SMALL_CAM, S.REPLICA_LIKE_CAM], ids=["160x120", "640x480"])
@@ -247,3 +248,46 @@ def test_staged_colour_deferral_survives_a_recycled_colour_buffer(oracle_mod, hi
     assert not np.array_equal(bc["r"], bz["r"])              # (the test does scribble where it matters: the zero-copy mapper integrated the noise)
     prof = staged.profile()
     assert sum(v["count"] for k_, v in prof.items() if "k_integrate_tsdf_color" in k_) >= 8, {k_: v["count"] for k_, v in prof.items()}
+
+
+def test_union_step_of_the_index_exchange_rides_in_the_fused_launch(oracle_mod, hip_lib):
+    """One camera per GPU with colour deferral on (bench.py --gpus N): the union step of the peers' gathered block lists
+    (nvbx_mark_esdf_dirty_gathered_deferred) is held back and rides in the NEXT depth frame's fused TSDF-update launch -- two launches per frame
+    for N > 1 as well.  One GPU, a stand-in peer (a second mapper looking the other way, its per-frame block list exported by its own depth pass):
+    the map of the rank with the exchange == a mapper without any exchange, bit for bit (re-marking a column from an unchanged TSDF changes no
+    voxel), the fused launch ran every frame, no marking launch of its own was needed, and the last update's sweep window reaches the peer's blocks."""
+    import torch
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    dev = torch.device("cuda", 0)
+    pg = M.default_params()
+    plain = M.Mapper(pg, block_capacity=1 << 13); rank0 = M.Mapper(pg, block_capacity=1 << 13); peer = M.Mapper(pg, block_capacity=1 << 13)
+    own = H.frames(24, cam, stride=8); other = H.frames(24, cam, stride=8, yaw_offset_deg=180.0)
+    for d, rgb, T in own + other:                 # both ranks know the whole room already (the peers' blocks exist locally)
+        for m_ in (plain, rank0):
+            m_.integrate_depth(d, T, cam)
+    for m_ in (plain, rank0):
+        m_.update_esdf(); m_.synchronize()
+    rank0.set_color_deferral(True); rank0.set_profiling(True)
+    bufs = [torch.zeros((2, 4097, 3), dtype=torch.int32, device=dev) for _ in range(3)]       # three rotating gathered sets, as dist.PipelinedDirtyBlockExchange
+    for k in range(12):
+        d, rgb, T = own[2 * k]; dp, _, Tp = other[2 * k]
+        g = bufs[k % 3]
+        peer.set_view_export(g[1]); peer.integrate_depth(dp, Tp, cam); peer.synchronize()     # the peer's message (row 0 = count)
+        for m_ in (plain, rank0):
+            m_.integrate_depth(d, T, cam)
+        rank0.mark_esdf_dirty_gathered(g, 2, 0, 4096, deferred=True)
+        for m_ in (plain, rank0):
+            m_.integrate_color(rgb, T, cam); m_.update_esdf()
+        assert int(g[1, 0, 0].item()) > 50
+    prof = rank0.profile()
+    fused = sum(v["count"] for k_, v in prof.items() if "k_integrate_tsdf_color" in k_)
+    own_launches = sum(v["count"] for k_, v in prof.items() if "k_import_mark_gathered" in k_)       # (only the drain by profile() launches the last step's list on its own)
+    assert fused >= 11 and own_launches <= 1, {k_: v["count"] for k_, v in prof.items()}
+    # the last update (replayed by the drain above) re-marked the peer's blocks of the step before, dirtied by the last fused launch: they lie
+    # behind this camera, so more columns were marked and the sweep window is larger than without the exchange
+    c0, c1 = plain.counters(), rank0.counters()
+    assert c1["esdf_columns_marked"] > c0["esdf_columns_marked"] and c1["esdf_window_voxels"] > c0["esdf_window_voxels"], (c0, c1)
+    bit_equal(M, plain, rank0, "index exchange in the pipeline")
+    sa, _ = plain.esdf_slice_image(); sb, _ = rank0.esdf_slice_image()
+    assert np.array_equal(sa, sb)
