@@ -76,9 +76,18 @@ class Mapper {
   Mapper(const Mapper&) = delete;
   Mapper& operator=(const Mapper&) = delete;
 
+  // [U] the ground plane the 2-D ESDF slice follows (slice_height_above_plane_m / slice_height_thickness_m, mapper_initialization.cpp:257-260):
+  // set by MultiMapper from its estimator before updateEsdf when multi_mapper.experimental_use_ground_plane_estimation is on; nullopt = the fixed heights
+  void setEsdfGroundPlane(const std::optional<Plane>& plane) {
+    nvbx_mapper_params p = params_.toCAbi(voxel_size_m_, projective_layer_type_, esdf_mode_);
+    ground_plane_ = plane;
+    applyGroundPlane(&p);
+    checkNvbx(nvbx_mapper_set_params(m_, &p), "nvbx_mapper_set_params");
+  }
   void setMapperParams(const MapperParams& params) {
     params_ = params;
-    const nvbx_mapper_params p = params_.toCAbi(voxel_size_m_, projective_layer_type_, esdf_mode_);
+    nvbx_mapper_params p = params_.toCAbi(voxel_size_m_, projective_layer_type_, esdf_mode_);
+    applyGroundPlane(&p);
     checkNvbx(nvbx_mapper_set_params(m_, &p), "nvbx_mapper_set_params");
   }
   const MapperParams& params() const { return params_; }
@@ -267,6 +276,11 @@ class Mapper {
   const std::shared_ptr<CudaStream>& cuda_stream() const { return cuda_stream_; }
 
  private:
+  void applyGroundPlane(nvbx_mapper_params* p) const {
+    p->esdf_use_ground_plane = ground_plane_ ? 1 : 0;
+    if (ground_plane_) { p->esdf_ground_plane[0] = ground_plane_->normal().x(); p->esdf_ground_plane[1] = ground_plane_->normal().y(); p->esdf_ground_plane[2] = ground_plane_->normal().z(); p->esdf_ground_plane[3] = ground_plane_->d(); }
+  }
+  std::optional<Plane> ground_plane_;
   void rebuildViews() { freespace_layer_ = FreespaceLayer(m_, voxel_size_m_); occupancy_layer_ = OccupancyLayer(m_, voxel_size_m_); tsdf_layer_ = TsdfLayer(m_, voxel_size_m_); color_layer_ = ColorLayer(m_, voxel_size_m_); esdf_layer_ = EsdfLayer(m_, voxel_size_m_); }
   // Blocks of a voxel layer that go out with this call: inside the exclusion cylinder (radius / height around the centre; negative =
   // unlimited), then -- bandwidth_limit_mbps >= 0 -- [U] nearest first: ordered by distance to the exclusion centre (the robot) and cut where

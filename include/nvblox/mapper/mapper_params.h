@@ -57,9 +57,9 @@ constexpr Param<float>::Description kTsdfDecayFactorParamDesc{"tsdf_decay_factor
 constexpr Param<float>::Description kTsdfDecayedWeightThresholdDesc{"tsdf_decayed_weight_threshold", 0.001f, "Blocks whose weights are all below this are deallocated."};
 constexpr Param<bool>::Description kTsdfSetFreeDistanceOnDecayedDesc{"tsdf_set_free_distance_on_decayed", false, "An observed voxel whose weight decays below the threshold becomes free (distance = tsdf_decayed_free_distance_vox, weight = the threshold) instead of unknown."};
 constexpr Param<float>::Description kTsdfDecayedFreeDistanceVoxDesc{"tsdf_decayed_free_distance_vox", 4.0f, "Distance (voxels) given to a decayed voxel when tsdf_set_free_distance_on_decayed is set."};
-constexpr Param<float>::Description kFreeRegionDecayProbabilityParamDesc{"free_region_decay_probability", 0.55f, "Occupied voxels decay past unknown into free and stay there; free voxels are not decayed."};
+constexpr Param<float>::Description kFreeRegionDecayProbabilityParamDesc{"free_region_decay_probability", 0.55f, "Decay probability applied to free voxels (log-odds step towards unknown)."};
 constexpr Param<float>::Description kOccupiedRegionDecayProbabilityParamDesc{"occupied_region_decay_probability", 0.4f, "Decay probability applied to occupied voxels (log-odds step towards unknown)."};
-constexpr Param<bool>::Description kOccupancyDecayToFreeParamDesc{"occupancy_decay_to_free", false, "Occupancy decay towards free instead of unknown (not provided by libnvblox_hip: decay stops at unknown)."};
+constexpr Param<bool>::Description kOccupancyDecayToFreeParamDesc{"occupancy_decay_to_free", false, "Occupied voxels decay past unknown into free and stay there; free voxels are not decayed."};
 constexpr Param<float>::Description kMaxTsdfDistanceForOccupancyMParamDesc{"max_tsdf_distance_for_occupancy_m", 0.15f, "Freespace integrator (dynamic mapping)."};
 constexpr Param<int>::Description kMaxUnobservedToKeepConsecutiveOccupancyMsParamDesc{"max_unobserved_to_keep_consecutive_occupancy_ms", 200, "Freespace integrator (dynamic mapping)."};
 constexpr Param<int>::Description kMinDurationSinceOccupiedForFreespaceMsParamDesc{"min_duration_since_occupied_for_freespace_ms", 1000, "Freespace integrator (dynamic mapping)."};
@@ -209,6 +209,8 @@ struct MapperParams {
     p.esdf_slice_height = esdf_integrator_params.esdf_slice_height;
     p.esdf_slice_min_height = esdf_integrator_params.esdf_slice_min_height;
     p.esdf_slice_max_height = esdf_integrator_params.esdf_slice_max_height;
+    p.slice_height_above_plane_m = esdf_integrator_params.slice_height_above_plane_m;      // (mapper_initialization.cpp:257-260; used once a ground plane is set: Mapper::setEsdfGroundPlane)
+    p.slice_height_thickness_m = esdf_integrator_params.slice_height_thickness_m;
     p.mesh_min_weight = mesh_integrator_params.mesh_integrator_min_weight;
     p.mesh_weld_vertices = mesh_integrator_params.mesh_integrator_weld_vertices ? 1 : 0;
     p.sphere_tracing_subsampling = 4; p.sphere_tracing_max_steps = 100;

@@ -18,8 +18,8 @@ namespace nvblox {
 // (csrc/ground.hip): with multi_mapper.experimental_use_ground_plane_estimation every updateEsdf() extracts the TSDF's upward zero
 // crossings whose height lies in [ground_points_candidates_min_z_m, ..._max_z_m] (nvbx_tsdf_zero_crossings) and fits a RANSAC plane
 // through them (nvbx_fit_plane_ransac: ransac_distance_threshold_m, num_ransac_iterations).  Without the switch, or before the first
-// update, or with fewer than three candidates, the accessors report "no estimate" and the node publishes nothing.  (The reference also
-// lets the plane steer the ESDF slice height -- slice_height_above_plane_m; here the slice stays at its configured heights.)
+// update, or with fewer than three candidates, the accessors report "no estimate" and the node publishes nothing.  The plane also steers the
+// 2-D ESDF slice (slice_height_above_plane_m / slice_height_thickness_m): MultiMapper::updateEsdf hands it to the mappers, Mapper::setEsdfGroundPlane.
 class GroundPlaneEstimator {
  public:
   std::optional<std::vector<Vector3f>> tsdf_zero_crossings_ground_candidates() const { return candidates_; }
@@ -146,8 +146,14 @@ class MultiMapper {
     background_mapper_->integrateColor(color_background_, T_L_C, camera);
   }
   void updateEsdf() {
+    // [U] ground-plane mode (multi_mapper.experimental_use_ground_plane_estimation, mapper_initialization.cpp:133-153): the plane is estimated from
+    // the TSDF first and the 2-D slice of this update follows it (slice_height_above_plane_m / slice_height_thickness_m); no estimate = fixed heights
+    if (multi_params_.experimental_use_ground_plane_estimation) {
+      ground_plane_estimator_.update(background_mapper_->c_handle(), multi_params_);
+      background_mapper_->setEsdfGroundPlane(ground_plane_estimator_.ground_plane());
+      if (human_ || dynamic_) foreground_mapper_->setEsdfGroundPlane(ground_plane_estimator_.ground_plane());
+    }
     background_mapper_->updateEsdf(); if (human_ || dynamic_) foreground_mapper_->updateEsdf();
-    if (multi_params_.experimental_use_ground_plane_estimation) ground_plane_estimator_.update(background_mapper_->c_handle(), multi_params_);
   }
   void updateColorMesh(UpdateFullLayer f = UpdateFullLayer::kNo) { background_mapper_->updateColorMesh(f); }
 

@@ -140,6 +140,15 @@ typedef struct {
                                               becomes FREE instead of fading to unknown: distance = tsdf_decayed_free_distance_vox voxels, weight = the threshold */
   float tsdf_decayed_free_distance_vox;    /* tsdf_decayed_free_distance_vox (4.0) */
   int32_t occupancy_decay_to_free;         /* occupancy_decay_to_free (0): 1 = occupied voxels decay past unknown into free and stay there; free voxels are not decayed */
+  /* -- ground-plane-relative 2-D slice (mapper_initialization.cpp:136,257-260; [U] semantics).  With esdf_use_ground_plane the z
+   *    band a column (x, y) of the slice looks at is [h + slice_height_above_plane_m, h + slice_height_above_plane_m + slice_height_thickness_m],
+   *    h = the height of esdf_ground_plane {nx, ny, nz, d: n . p + d = 0, nz > 0} at the column's centre, instead of the fixed
+   *    [esdf_slice_min_height, esdf_slice_max_height]; the output plane stays esdf_slice_height.  nvblox::MultiMapper sets plane and switch from its
+   *    ground-plane estimator before every updateEsdf when multi_mapper.experimental_use_ground_plane_estimation is on. */
+  float slice_height_above_plane_m;        /* slice_height_above_plane_m (0) */
+  float slice_height_thickness_m;          /* slice_height_thickness_m (0) */
+  int32_t esdf_use_ground_plane;           /* (0) */
+  float esdf_ground_plane[4];
 } nvbx_mapper_params;
 
 /* nvblox::Lidar(num_azimuth_divisions, num_elevation_divisions, min_valid_range_m, vertical_fov_rad) or

@@ -66,6 +66,10 @@ class Params(C.Structure):
         ("tsdf_set_free_distance_on_decayed", C.c_int32),
         ("tsdf_decayed_free_distance_vox", C.c_float),
         ("occupancy_decay_to_free", C.c_int32),
+        ("slice_height_above_plane_m", C.c_float),
+        ("slice_height_thickness_m", C.c_float),
+        ("esdf_use_ground_plane", C.c_int32),
+        ("esdf_ground_plane", C.c_float * 4),
     ]
 
 

@@ -320,6 +320,7 @@ extern "C" int nvbx_decay_occupancy(nvbx_mapper* m) {
   if (m->begin_dirtying()) return NVBX_E_DEVICE;
   EsdfArgs ea = m->make_esdf_args();
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
+  else if (ea.plane_on) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; }      // ground-plane mode: the band's blocks vary with (x, y) -- a deallocated block of ANY height has its column re-marked
   const int64_t hw_seen = std::max<int64_t>(1, __atomic_load_n(&m->h_mirror[1], __ATOMIC_RELAXED));       // (a hint: the kernel grid-strides)
   NVBX_LAUNCH(m, k_decay<true>, dim3((unsigned)std::min<int64_t>(std::min<int64_t>(m->capacity, 4096), std::max<int64_t>(512, (hw_seen + 7) / 8))), dim3(512), m->d,
               log_odds(m->p.free_region_decay_probability), log_odds(m->p.occupied_region_decay_probability), 0u, 0u, (int32_t)m->mesh_list_live(),
@@ -340,6 +341,7 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   const int grid = (int)std::min<int64_t>(std::min<int64_t>(m->capacity, decay_grid), std::max<int64_t>(512, (hw_seen + 7) / 8));
   EsdfArgs ea = m->make_esdf_args();
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
+  else if (ea.plane_on) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; }      // ground-plane mode: the band's blocks vary with (x, y) -- a deallocated block of ANY height has its column re-marked
   NVBX_LAUNCH(m, k_decay<false>, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
                      exclude_last_view ? m->last_camera_view_frame : 0u, m->last_camera_view_mask, m->mesh_list_live(), ea.bz_lo, ea.bz_hi, ea.bz_out,
                      m->p.truncation_distance_vox * m->p.voxel_size, m->cleared_idx, (int32_t)(m->p.decay_deallocate_decayed_blocks ? 0 : 1),

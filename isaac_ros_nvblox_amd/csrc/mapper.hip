@@ -300,6 +300,10 @@ EsdfArgs nvbx_mapper::make_esdf_args() const {
   c.epoch = esdf_epoch; c.mark_pass = mark_pass;
   c.rec = C_ESDF_UPD + 8 * (int)(esdf_epoch & 1); c.rec_next = C_ESDF_UPD + 8 * (int)((esdf_epoch + 1) & 1);
   c.self_reset = c.keep_list = pipelined_order ? 1 : 0;       // (see EsdfArgs)
+  // ground-plane-relative band: only with a usable plane (pointing up) and a positive thickness; else the fixed heights
+  c.plane_on = (p.esdf_use_ground_plane && p.esdf_ground_plane[2] > 1e-3f && p.slice_height_thickness_m > 0.0f) ? 1 : 0;
+  for (int i = 0; i < 4; i++) c.pl[i] = p.esdf_ground_plane[i];
+  c.above = p.slice_height_above_plane_m; c.thick = p.slice_height_thickness_m;
   return c;
 }
 

@@ -12,9 +12,22 @@ namespace nvbx {
 __device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_t tslot, int srec, int sh, bool from_dirty_list = false) {
   const int lane = threadIdx.x & 63;
   const int vx = lane & 7, vy = lane >> 3;
-  const int nz = a.bz_hi - a.bz_lo + 1;                    // TSDF blocks spanned by the slice z band (<= 62)
   const uint32_t tflags = m.slot_flags[tslot];
   const int32_t bx = m.slot_index[3 * tslot], by = m.slot_index[3 * tslot + 1], bz = m.slot_index[3 * tslot + 2];
+  // the z band: fixed heights, or -- [U] ground-plane mode -- relative to the plane: per COLUMN kz_lo .. kz_hi from the plane's height at the
+  // column's centre; the blocks the column's wavefront may have to read span the heights at the block's four corners (a plane is extremal there)
+  int32_t kz_lo = a.kz_min, kz_hi = a.kz_max, bz_lo = a.bz_lo, bz_hi = a.bz_hi;
+  if (a.plane_on) {
+    const float bs = a.voxel_size * 8.0f;
+    const float hl = esdf_plane_height(a.pl, voxel_center(bx, vx, bs, a.voxel_size), voxel_center(by, vy, bs, a.voxel_size));
+    kz_lo = (int32_t)floorf((hl + a.above) / a.voxel_size); kz_hi = (int32_t)floorf(((hl + a.above) + a.thick) / a.voxel_size);
+    const float x0 = (float)bx * bs, x1 = (float)(bx + 1) * bs, y0 = (float)by * bs, y1 = (float)(by + 1) * bs;
+    const float h00 = esdf_plane_height(a.pl, x0, y0), h10 = esdf_plane_height(a.pl, x1, y0), h01 = esdf_plane_height(a.pl, x0, y1), h11 = esdf_plane_height(a.pl, x1, y1);
+    const float hmin = fminf(fminf(h00, h10), fminf(h01, h11)), hmax = fmaxf(fmaxf(h00, h10), fmaxf(h01, h11));
+    bz_lo = floor_div8((int32_t)floorf((hmin + a.above) / a.voxel_size)); bz_hi = floor_div8((int32_t)floorf(((hmax + a.above) + a.thick) / a.voxel_size));
+    if (bz_hi - bz_lo > 61) bz_hi = bz_lo + 61;            // (a wavefront probes the ESDF block + at most 62 band blocks)
+  }
+  const int nz = bz_hi - bz_lo + 1;                        // TSDF blocks spanned by the slice z band (<= 62)
   // An entry of the ESDF-dirty list names a slot that carried F_DIRTY_ESDF when it was appended (the flag is the list's de-duplication); a slot
   // WITHOUT it has been freed since (decay, clearing) -- and may be handed out again at this very moment: the marking pass of a held-back update
   // rides in the view-marking launch of the NEXT frame, whose tiles allocate.  The new block's dirtiness belongs to the next
@@ -25,9 +38,9 @@ __device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_
   if (lane == 0) { atomicAnd(&m.slot_flags[tslot], ~F_DIRTY_ESDF); m.slot_consumed[tslot] = a.mark_pass; }
   // a dirty TSDF block of the z band dirties its column; an ESDF slot flagged F_ESDF_REMARK (a TSDF block of its band was
   // deallocated by decay) re-marks its own column
-  if (!(tflags & F_ESDF_REMARK) && (bz < a.bz_lo || bz > a.bz_hi)) return;
+  if (!(tflags & F_ESDF_REMARK) && (bz < bz_lo || bz > bz_hi)) return;
   // lane 0: the ESDF block (x, y, z_slice); lanes 1..nz: the TSDF blocks of the band -- one probe each, together
-  const int32_t qz = lane == 0 ? a.bz_out : a.bz_lo + lane - 1;
+  const int32_t qz = lane == 0 ? a.bz_out : bz_lo + lane - 1;
   const bool probing = lane <= nz;
   const u64 qkey = pack_key(bx, by, qz);
   const uint32_t qh = probing ? table_pos(m, bx, by, qz) : 0u;
@@ -68,7 +81,7 @@ __device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_
   for (int32_t q = 0; q < nz; ++q) {
     const uint32_t ts = __shfl(qslot, q + 1);
     if (!slot_ok(ts)) continue;                           // uniform
-    const int32_t bzz = a.bz_lo + q;
+    const int32_t bzz = bz_lo + q;
     const float4* col = reinterpret_cast<const float4*>(&m.tsdf[(size_t)ts * 512 + 64 * vx + 8 * vy]);
     float dz[8], wz[8];
 #pragma unroll
@@ -76,7 +89,7 @@ __device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_
 #pragma unroll
     for (int z = 0; z < 8; z++) {
       const int32_t kz = bzz * 8 + z;
-      if (kz < a.kz_min || kz > a.kz_max) continue;
+      if (kz < kz_lo || kz > kz_hi) continue;
       if (a.site_rule == 2) {          // occupancy layer {log_odds, -}: [U] OccupancySiteFunctor -- known iff log-odds != 0, site = inside = occupied (p > 0.5)
         if (dz[z] != 0.0f) observed = 1;
         if (dz[z] > 0.0f) { inside = 1; site = 1; }

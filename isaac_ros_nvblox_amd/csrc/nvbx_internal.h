@@ -462,6 +462,13 @@ __host__ __device__ inline bool frame_is_plain(const Frame& f) {
   return !f.occupancy && f.weighting_mode == 0 && !f.clamp_before_blend && !(f.invalid_decay >= 0.0f);
 }
 
+// [U] height of the ground plane n . p + d = 0 (nz > 0) at (x, y), fixed evaluation order (the oracle's esdf_plane_height, same lines)
+__host__ __device__ inline float esdf_plane_height(const float* pl, float x, float y) {
+  float t = pl[0] * x;
+  t = t + pl[1] * y;
+  t = t + pl[3];
+  return -(t / pl[2]);
+}
 // ESDF packed voxel: {f32 squared_distance_vox, u32 meta}; meta = dx | dy<<8 | dz<<16 (int8 each) | observed<<24 | inside<<25 | site<<26
 __device__ __host__ inline uint32_t esdf_meta(int dx, int dy, int dz, int observed, int inside, int site) {
   return ((uint32_t)(uint8_t)(int8_t)dx) | (((uint32_t)(uint8_t)(int8_t)dy) << 8) | (((uint32_t)(uint8_t)(int8_t)dz) << 16) |

@@ -27,6 +27,9 @@ struct EsdfArgs {
   // marking -> TSDF update(i+1)): nothing runs between the marking pass and the next appends, so the pass empties the list itself --
   // its last worker, counted in C_MARK_DONE (self_reset) -- and the EDT of that update, which then runs AFTER those appends, must not (keep_list).
   int32_t self_reset, keep_list;
+  // [U] ground-plane-relative slice (nvbx_mapper_params::esdf_use_ground_plane): the z band of column (x, y) is [h + above, h + above + thick],
+  // h = height of the plane {n, d} at the column's centre (esdf_plane_height); 0 = the fixed band kz_min .. kz_max above
+  int32_t plane_on; float pl[4], above, thick;
 };
 
 struct MeshRecord { int32_t x, y, z, vbase, nvert, tbase, ntri, pad; };

@@ -106,6 +106,8 @@ typedef struct {
   int32_t esdf_propagation, mesh_ambiguity_rule, mesh_normal_rule;
   /* decay integrator switches (mapper_initialization.cpp:383-428) -- [U] semantics, same lines in maintenance.hip k_decay */
   int32_t decay_deallocate_decayed_blocks, tsdf_set_free_distance_on_decayed; float tsdf_decayed_free_distance_vox; int32_t occupancy_decay_to_free;
+  /* ground-plane-relative 2-D slice (mapper_initialization.cpp:136,257-260) -- [U] semantics, same lines in csrc/nvbx_esdf_mark.h */
+  float slice_height_above_plane_m, slice_height_thickness_m; int32_t esdf_use_ground_plane; float esdf_ground_plane[4];
 } OrcParams;
 
 enum { W_CONSTANT = 0, W_CONSTANT_DROPOFF = 1, W_INVERSE_SQUARE = 2, W_INVERSE_SQUARE_DROPOFF = 3,
@@ -1057,7 +1059,14 @@ int orc_get_synthetic_depth(const OrcMap* m, float* out, int* rows, int* cols) {
 }
 
 /* ------------------------------------------------------------------ ESDF (2-D slice) */
-typedef struct { int32_t kz_min, kz_max, kz_out, ri; float max_sq, site_dist_m; } EsdfCfg;
+typedef struct { int32_t kz_min, kz_max, kz_out, ri; float max_sq, site_dist_m; int plane_on; } EsdfCfg;
+/* [U] height of the ground plane n . p + d = 0 at (x, y) (nvbx_internal.h esdf_plane_height, same lines) */
+static float esdf_plane_height(const float* pl, float x, float y) {
+  float t = pl[0] * x;
+  t = t + pl[1] * y;
+  t = t + pl[3];
+  return -(t / pl[2]);
+}
 static EsdfCfg esdf_cfg(const OrcParams* p) {
   EsdfCfg c;
   const float vs = p->voxel_size;
@@ -1068,7 +1077,30 @@ static EsdfCfg esdf_cfg(const OrcParams* p) {
   c.max_sq = r * r;
   c.ri = (int32_t)floorf(r);
   c.site_dist_m = p->esdf_max_site_distance_vox * vs;
+  c.plane_on = (p->esdf_use_ground_plane && p->esdf_ground_plane[2] > 1e-3f && p->slice_height_thickness_m > 0.0f) ? 1 : 0;
   return c;
+}
+/* [U] ground-plane mode: the z band of column (vx, vy) of block column (bx, by), and the block range the band can reach anywhere in that block
+ * column (plane heights at its four corners) -- csrc/nvbx_esdf_mark.h esdf_mark_entry, same expressions */
+static void esdf_column_band(const OrcParams* p, const EsdfCfg* c, int32_t bx, int32_t by, int vx, int vy, int32_t* kz_lo, int32_t* kz_hi) {
+  *kz_lo = c->kz_min; *kz_hi = c->kz_max;
+  if (!c->plane_on) return;
+  const float vs = p->voxel_size, bs = vs * 8.0f;
+  const float hl = esdf_plane_height(p->esdf_ground_plane, voxel_center(bx, vx, bs, vs), voxel_center(by, vy, bs, vs));
+  *kz_lo = (int32_t)floorf((hl + p->slice_height_above_plane_m) / vs);
+  *kz_hi = (int32_t)floorf(((hl + p->slice_height_above_plane_m) + p->slice_height_thickness_m) / vs);
+}
+static void esdf_block_band(const OrcParams* p, const EsdfCfg* c, int32_t bx, int32_t by, int32_t* bz_lo, int32_t* bz_hi) {
+  *bz_lo = floor_div8(c->kz_min); *bz_hi = floor_div8(c->kz_max);
+  if (!c->plane_on) return;
+  const float vs = p->voxel_size, bs = vs * 8.0f;
+  const float x0 = (float)bx * bs, x1 = (float)(bx + 1) * bs, y0 = (float)by * bs, y1 = (float)(by + 1) * bs;
+  const float h00 = esdf_plane_height(p->esdf_ground_plane, x0, y0), h10 = esdf_plane_height(p->esdf_ground_plane, x1, y0);
+  const float h01 = esdf_plane_height(p->esdf_ground_plane, x0, y1), h11 = esdf_plane_height(p->esdf_ground_plane, x1, y1);
+  const float hmin = fminf(fminf(h00, h10), fminf(h01, h11)), hmax = fmaxf(fmaxf(h00, h10), fmaxf(h01, h11));
+  *bz_lo = floor_div8((int32_t)floorf((hmin + p->slice_height_above_plane_m) / vs));
+  *bz_hi = floor_div8((int32_t)floorf(((hmax + p->slice_height_above_plane_m) + p->slice_height_thickness_m) / vs));
+  if (*bz_hi - *bz_lo > 61) *bz_hi = *bz_lo + 61;
 }
 
 /* Exact 2-D Euclidean distance transform of the slice with cut-off: row pass (nearest site along x, ties -> -x),
@@ -1253,7 +1285,6 @@ int64_t orc_update_esdf(OrcMap* m) {
   const OrcParams* p = &m->p;
   const EsdfCfg c = esdf_cfg(p);
   const int32_t bz_out = floor_div8(c.kz_out), vz_out = mod8(c.kz_out);
-  const int32_t bz_lo = floor_div8(c.kz_min), bz_hi = floor_div8(c.kz_max);
   /* 1. allocate + mark sites for dirty TSDF columns intersecting the z band; columns whose TSDF block was
    *    deallocated (decay) are re-marked if their ESDF block exists */
   int64_t n_dirty = 0;
@@ -1261,7 +1292,9 @@ int64_t orc_update_esdf(OrcMap* m) {
   for (int64_t q = 0; q < count0; q++) {
     Block* tb = m->order[q];
     int want = 0;
-    if ((tb->flags & L_TSDF) && tb->dirty_esdf) { tb->dirty_esdf = 0; if (tb->idx.z >= bz_lo && tb->idx.z <= bz_hi) want = 1; }
+    int32_t bz_lo_e, bz_hi_e;                      /* the band's blocks in this block column (fixed, or by the ground plane) */
+    esdf_block_band(p, &c, tb->idx.x, tb->idx.y, &bz_lo_e, &bz_hi_e);
+    if ((tb->flags & L_TSDF) && tb->dirty_esdf) { tb->dirty_esdf = 0; if (tb->idx.z >= bz_lo_e && tb->idx.z <= bz_hi_e) want = 1; }
     if (tb->remark_esdf) { tb->remark_esdf = 0; want = 2; }
     if (!want) continue;
     Idx3 ei = {tb->idx.x, tb->idx.y, bz_out};
@@ -1274,7 +1307,10 @@ int64_t orc_update_esdf(OrcMap* m) {
     n_dirty++;
     for (int x = 0; x < 8; x++) for (int y = 0; y < 8; y++) {
       int observed = 0, inside = 0, site = 0;
-      for (int32_t kz = c.kz_min; kz <= c.kz_max; kz++) {
+      int32_t kz_lo, kz_hi;
+      esdf_column_band(p, &c, ei.x, ei.y, x, y, &kz_lo, &kz_hi);
+      if (c.plane_on) { if (kz_lo < bz_lo_e * 8) kz_lo = bz_lo_e * 8; if (kz_hi > bz_hi_e * 8 + 7) kz_hi = bz_hi_e * 8 + 7; }      /* (the 62-block cap of the wavefront's probes) */
+      for (int32_t kz = kz_lo; kz <= kz_hi; kz++) {
         Idx3 ti = {ei.x, ei.y, floor_div8(kz)};
         Block* b = map_find(m, ti);
         if (!b || !(b->flags & L_TSDF)) continue;
@@ -1629,7 +1665,7 @@ int64_t orc_decay_tsdf(OrcMap* m, int exclude_last_view) {
         drop = 1; cleared_push(m, b->idx);
         const EsdfCfg ec = esdf_cfg(p);
         if (p->esdf_mode == 1) { if (b->flags & L_ESDF) b->remark_esdf = 1; }      /* 3-D: the block's own ESDF block */
-        else if (b->idx.z >= floor_div8(ec.kz_min) && b->idx.z <= floor_div8(ec.kz_max)) {
+        else if (ec.plane_on || (b->idx.z >= floor_div8(ec.kz_min) && b->idx.z <= floor_div8(ec.kz_max))) {      /* (ground-plane mode: a block of any height) */
           Idx3 ei = {b->idx.x, b->idx.y, floor_div8(ec.kz_out)};
           Block* eb = map_find(m, ei);
           if (eb && (eb->flags & L_ESDF)) eb->remark_esdf = 1;
@@ -1671,7 +1707,7 @@ int64_t orc_decay_occupancy(OrcMap* m) {
         drop = 1; cleared_push(m, b->idx);
         const EsdfCfg ec = esdf_cfg(p);
         if (p->esdf_mode == 1) { if (b->flags & L_ESDF) b->remark_esdf = 1; }      /* 3-D: the block's own ESDF block */
-        else if (b->idx.z >= floor_div8(ec.kz_min) && b->idx.z <= floor_div8(ec.kz_max)) {
+        else if (ec.plane_on || (b->idx.z >= floor_div8(ec.kz_min) && b->idx.z <= floor_div8(ec.kz_max))) {      /* (ground-plane mode: a block of any height) */
           Idx3 ei = {b->idx.x, b->idx.y, floor_div8(ec.kz_out)};
           Block* eb = map_find(m, ei);
           if (eb && (eb->flags & L_ESDF)) eb->remark_esdf = 1;

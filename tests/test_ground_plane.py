@@ -80,3 +80,49 @@ def test_ground_plane_parity(oracle_mod, hip_lib):
     # decay to nothing: no candidates, no plane
     g2 = M.Mapper(M.default_params(projective_layer_type=1), block_capacity=1 << 12)
     assert len(g2.tsdf_zero_crossings(-1.0, 1.0)) == 0
+
+
+def _plane_params(M, plane, above, thick, **kw):
+    p = M.default_params(esdf_use_ground_plane=1, slice_height_above_plane_m=above, slice_height_thickness_m=thick, **kw)
+    for i in range(4):
+        p.esdf_ground_plane[i] = float(plane[i])
+    return p
+
+
+@pytest.mark.gpu
+def test_esdf_slice_follows_the_ground_plane(oracle_mod, hip_lib):
+    """[U] ground-plane-relative 2-D slice (mapper_initialization.cpp:136,257-260: slice_height_above_plane_m / slice_height_thickness_m with
+    multi_mapper.experimental_use_ground_plane_estimation): (1) over the horizontal plane z = 0 the band [above, above + thickness] IS the fixed band
+    [esdf_slice_min_height, esdf_slice_max_height] of the same heights -- identical ESDF layer; (2) over a tilted plane every column looks at its own
+    band: HIP == checker on every ESDF voxel over incremental updates with a decay in between, and the layer differs from the fixed-height one."""
+    from isaac_ros_nvblox_amd import mapper as M
+    from test_gpu_parity import compare_layer
+    cam = H.SMALL_CAM
+    fr = H.frames(10, cam, stride=9, color=False)
+    fields = ("squared_distance_vox", "parent_direction", "is_inside", "observed", "is_site")
+    fixed = M.Mapper(M.default_params(esdf_slice_min_height=0.09, esdf_slice_max_height=0.65), block_capacity=1 << 13)
+    flat = M.Mapper(_plane_params(M, (0.0, 0.0, 1.0, 0.0), 0.09, 0.56), block_capacity=1 << 13)
+    tilt = (0.06, -0.04, 1.0, -0.12)
+    n = float(np.linalg.norm(tilt[:3])); tilt = tuple(v / n for v in tilt)
+    pt = _plane_params(M, tilt, 0.05, 0.5, tsdf_decay_factor=0.6, tsdf_decayed_weight_threshold=0.3)
+    gt = M.Mapper(pt, block_capacity=1 << 13); ot = oracle_mod.OracleMap(H.copy_params(pt, oracle_mod.OrcParams))
+    for k, (d, _, T) in enumerate(fr):
+        for m_ in (fixed, flat, gt, ot):
+            m_.integrate_depth(d, T, cam)
+        if k % 3 == 2:
+            for m_ in (fixed, flat, gt, ot):
+                m_.update_esdf()
+        if k == 6:
+            gt.decay_tsdf(True); ot.decay_tsdf(True)          # deallocations in plane mode: the columns of freed blocks are re-marked
+    for m_ in (fixed, flat, gt, ot):
+        m_.update_esdf()
+    i0, i1 = fixed.block_indices(M.LAYER_ESDF), flat.block_indices(M.LAYER_ESDF)
+    assert np.array_equal(i0, i1) and len(i0) > 30
+    b0, _ = fixed.get_blocks(M.LAYER_ESDF, i0); b1, _ = flat.get_blocks(M.LAYER_ESDF, i0)
+    for f in fields:
+        assert np.array_equal(b0[f], b1[f]), f
+    nblk, _ = compare_layer(M, gt, ot, M.LAYER_ESDF, oracle_mod.L_ESDF, fields_exact=fields)
+    assert nblk > 30
+    sg, _ = gt.esdf_slice_image(); so, _ = ot.esdf_slice_image(); sf, _ = fixed.esdf_slice_image()
+    assert sg.shape == so.shape and np.array_equal(sg, so)
+    assert sg.shape != sf.shape or not np.array_equal(sg, sf)               # the tilted band sees other voxels than the fixed one
