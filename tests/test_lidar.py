@@ -270,6 +270,49 @@ def test_motion_compensation_oracle_against_exact_motion(oracle_mod):
     assert np.allclose(clamp[0], pts[0], atol=1e-6) and np.allclose(clamp[1], oracle_mod.motion_compensate_pointcloud(pts[1:2], np.array([100.0], np.float32), T0, T1, 100.0)[0])
 
 
+def _random_motions(rng, n):
+    from scipy.spatial.transform import Rotation
+    out = []
+    for _ in range(n):
+        T0 = np.eye(4); T0[:3, :3] = Rotation.random(random_state=int(rng.integers(1 << 30))).as_matrix(); T0[:3, 3] = rng.uniform(-20, 20, 3)
+        d = np.eye(4); d[:3, :3] = Rotation.from_rotvec(rng.normal(size=3) * np.deg2rad(rng.uniform(0.0, 12.0)) / np.sqrt(3.0)).as_matrix(); d[:3, 3] = rng.uniform(-0.6, 0.6, 3)
+        out.append((T0.astype(np.float32), (T0 @ d).astype(np.float32)))
+    return out
+
+
+def test_motion_compensation_against_an_independent_float64_model(oracle_mod):
+    """The per-point arithmetic of the motion compensation is SHARED by the kernel and the checker (csrc/nvbx_motion_math.h: that is what makes them
+    bit-identical) -- so a slip in it would be invisible to every HIP-vs-checker comparison.  tests/motion_independent.py
+    restates the model in float64 on numpy + scipy.Rotation; the checker must agree with it to float32 accuracy on random poses anywhere in
+    the map, relative rotations up to 12 degrees, points out to 150 m, times inside and outside the scan."""
+    import motion_independent as MI
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for T0, T1 in _random_motions(rng, 12):
+        pts = (rng.normal(size=(20000, 3)) * rng.uniform(1.0, 50.0)).astype(np.float32)
+        t_ms = rng.uniform(-10.0, 110.0, len(pts)).astype(np.float32)
+        got = oracle_mod.motion_compensate_pointcloud(pts, t_ms, T0, T1, 100.0)
+        want = MI.compensate(pts, t_ms, T0, T1, 100.0)
+        err = np.linalg.norm(got - want, axis=1) / np.maximum(1.0, np.linalg.norm(pts.astype(np.float64), axis=1))
+        worst = max(worst, float(err.max()))
+    assert worst < 5e-6, worst            # a few float32 ulps of the point's magnitude
+
+
+@pytest.mark.gpu
+def test_motion_compensation_gpu_against_the_independent_model(hip_lib):
+    import motion_independent as MI
+    from isaac_ros_nvblox_amd import mapper as M
+    g = M.Mapper(M.default_params(), block_capacity=256)
+    rng = np.random.default_rng(12)
+    for T0, T1 in _random_motions(rng, 6):
+        pts = (rng.normal(size=(50000, 3)) * rng.uniform(1.0, 50.0)).astype(np.float32)
+        t_ms = rng.uniform(-10.0, 110.0, len(pts)).astype(np.float32)
+        got = g.motion_compensate_pointcloud(pts, t_ms, T0, T1, 100.0).cpu().numpy()
+        want = MI.compensate(pts, t_ms, T0, T1, 100.0)
+        err = np.linalg.norm(got - want, axis=1) / np.maximum(1.0, np.linalg.norm(pts.astype(np.float64), axis=1))
+        assert err.max() < 5e-6, err.max()
+
+
 @pytest.mark.gpu
 def test_motion_compensation_gpu_parity(oracle_mod, hip_lib):
     from isaac_ros_nvblox_amd import mapper as M
