@@ -147,6 +147,9 @@ static int color_launch_integrate(nvbx_mapper* m, const FrameSetC<Pix, NB>& fs, 
   if (take_edt && mark_wg == 0 && m->edt_pending) { n_edt = 256; ea = m->edt_args; m->edt_pending = false; }
   NVBX_LAUNCH(m, (k_integrate_color<Pix, NB>), dim3(grid + mark_wg + n_edt), dim3(512), m->d, fs, m->synth, srows, scols, m->mesh_list_live(), (int32_t)mark_wg, ea, imp, n_edt);
   NVBX_HIP(hipGetLastError());
+  // this launch looks at every allocated slot and votes + repairs the band bits of each block a LiDAR scan left F_BAND_STALE: from here on (stream
+  // order) no block is stale, and the next camera frames may take the fused launches again (the switch was sticky until clear())
+  m->lidar_integrated = false;
   return NVBX_OK;
 }
 template <typename Pix, int NB>

@@ -173,7 +173,11 @@ extern "C" int nvbx_update_esdf(nvbx_mapper* m) {
   //  occupancy mappers; nvbx_mapper::esdf_only_carry)
   static const int esdf_only = getenv("NVBX_ESDF_ONLY_CARRY") ? atoi(getenv("NVBX_ESDF_ONLY_CARRY")) : 1;      // (A/B: 0 = an updateEsdf is held back behind a colour frame only)
   if ((m->color_pending.on || (esdf_only && m->color_deferral && !m->pipelined_order && !m->import_pending)) && !m->replaying && m->p.esdf_propagation == 0 && !m->use_side && m->defer_edt) {
-    m->esdf_update_pending = true; return NVBX_OK; }
+    // (an update already held back is carried out first: two updates in a row stay two updates -- epochs and the "last update" counters as in
+    //  the undeferred sequence)
+    if (m->esdf_update_pending && m->replay_deferred()) return NVBX_E_DEVICE;
+    if (m->color_pending.on || (esdf_only && m->color_deferral && !m->import_pending)) { m->esdf_update_pending = true; return NVBX_OK; }
+  }
   if (!m->replaying && !m->pipelined_order && m->replay_deferred()) return NVBX_E_DEVICE;
   // a distance transform still held back by the PREVIOUS update goes first: this update's marking pass overwrites the masks
   // and the parity-indexed window record it reads, and edt_args holds one update only (two updates back to back)

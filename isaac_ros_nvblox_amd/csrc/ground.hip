@@ -6,6 +6,7 @@
 // (the node's debug visualisation; off in every shipped configuration): one streaming launch over the TSDF blocks, the sampling on the host.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 #include "nvbx_mapper.h"
 
@@ -51,30 +52,45 @@ __global__ void k_zero_tmp3(DMap m) { m.counters[C_TMP] = 0; }
 extern "C" int64_t nvbx_tsdf_zero_crossings(nvbx_mapper* m, float min_z_m, float max_z_m, float* points_xyz_host, int64_t capacity) {
   if (!m || capacity < 0 || (capacity > 0 && !points_xyz_host) || !(max_z_m >= min_z_m)) { set_error("nvbx_tsdf_zero_crossings: invalid argument"); return NVBX_E_INVALID; }
   if (m->p.projective_layer_type == 1) return 0;                          // an occupancy mapper has no TSDF
-  if (m->join_side()) return NVBX_E_DEVICE;
-  const int64_t cap = std::min<int64_t>(m->capacity * 64, (int64_t)1 << 24);       // at most one crossing per column and block in practice
-  if (m->staging_bytes < cap * 16) {
-    NVBX_HIP(hipStreamSynchronize(m->stream));
-    if (m->staging) NVBX_HIP(hipFree(m->staging));
-    m->staging = nullptr; m->staging_bytes = 0;
-    NVBX_HIP(hipMalloc(&m->staging, (size_t)cap * 16));
-    m->staging_bytes = cap * 16;
+  // The usual caller asks twice -- for the count, then with room for it (GroundPlaneEstimator::update, the Python mirror): the sorted result of
+  // the first call is kept and serves the second, as long as no other entry point has come between (join_side drops it) and the band is the same.
+  if (!(m->zc_valid && m->zc_min == min_z_m && m->zc_max == max_z_m)) {
+    if (m->join_side()) return NVBX_E_DEVICE;
+    m->zc_valid = false; m->zc_points.clear();
+    int64_t cap = std::min<int64_t>(m->capacity * 64, (int64_t)1 << 24);       // one crossing per column and block in practice; a column can hold up to four
+    for (int attempt = 0; attempt < 2; attempt++) {
+      if (m->staging_bytes < cap * 16) {
+        NVBX_HIP(hipStreamSynchronize(m->stream));
+        if (m->staging) NVBX_HIP(hipFree(m->staging));
+        m->staging = nullptr; m->staging_bytes = 0;
+        NVBX_HIP(hipMalloc(&m->staging, (size_t)cap * 16));
+        m->staging_bytes = cap * 16;
+      }
+      NVBX_LAUNCH(m, k_zero_tmp3, dim3(1), dim3(1), m->d);
+      NVBX_LAUNCH(m, k_tsdf_zero_crossings, dim3((unsigned)std::min<int64_t>(m->capacity, 4096)), dim3(64), m->d, m->p.voxel_size, min_z_m, max_z_m,
+                  m->p.esdf_min_weight > 0.0f ? m->p.esdf_min_weight : 1e-4f, (float4*)m->staging, (int32_t)cap);
+      if (m->fetch_counters()) return NVBX_E_DEVICE;
+      const int64_t found = m->h_counters[C_TMP];
+      if (found <= cap) break;
+      // more crossings than the buffer holds: never a silent, order-dependent truncation -- once more with room for all of them
+      if (attempt == 1 || found > ((int64_t)1 << 27)) { set_error("nvbx_tsdf_zero_crossings: more zero crossings than the staging buffer can hold"); return NVBX_E_CAPACITY; }
+      cap = found;
+    }
+    const int64_t n = m->h_counters[C_TMP];
+    std::vector<float> tmp((size_t)n * 4);
+    if (n) NVBX_HIP(hipMemcpy(tmp.data(), m->staging, (size_t)n * 16, hipMemcpyDeviceToHost));
+    std::vector<int64_t> order((size_t)n);
+    for (int64_t i = 0; i < n; i++) order[(size_t)i] = i;
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {      // deterministic order: x, then y, then z
+      const float* p = &tmp[(size_t)a * 4]; const float* q = &tmp[(size_t)b * 4];
+      if (p[0] != q[0]) return p[0] < q[0]; if (p[1] != q[1]) return p[1] < q[1]; return p[2] < q[2]; });
+    m->zc_points.resize((size_t)n * 3);
+    for (int64_t i = 0; i < n; i++) { const float* p = &tmp[(size_t)order[(size_t)i] * 4]; m->zc_points[3 * i] = p[0]; m->zc_points[3 * i + 1] = p[1]; m->zc_points[3 * i + 2] = p[2]; }
+    m->zc_valid = true; m->zc_min = min_z_m; m->zc_max = max_z_m;
   }
-  NVBX_LAUNCH(m, k_zero_tmp3, dim3(1), dim3(1), m->d);
-  NVBX_LAUNCH(m, k_tsdf_zero_crossings, dim3((unsigned)std::min<int64_t>(m->capacity, 4096)), dim3(64), m->d, m->p.voxel_size, min_z_m, max_z_m,
-              m->p.esdf_min_weight > 0.0f ? m->p.esdf_min_weight : 1e-4f, (float4*)m->staging, (int32_t)cap);
-  if (m->fetch_counters()) return NVBX_E_DEVICE;
-  const int64_t n = std::min<int64_t>(m->h_counters[C_TMP], cap);
-  if (n == 0) return 0;
-  std::vector<float> tmp((size_t)n * 4);
-  NVBX_HIP(hipMemcpy(tmp.data(), m->staging, (size_t)n * 16, hipMemcpyDeviceToHost));
-  std::vector<int64_t> order((size_t)n);
-  for (int64_t i = 0; i < n; i++) order[(size_t)i] = i;
-  std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {      // deterministic order: x, then y, then z
-    const float* p = &tmp[(size_t)a * 4]; const float* q = &tmp[(size_t)b * 4];
-    if (p[0] != q[0]) return p[0] < q[0]; if (p[1] != q[1]) return p[1] < q[1]; return p[2] < q[2]; });
+  const int64_t n = (int64_t)m->zc_points.size() / 3;
   if (n > capacity) return n;                                             // too small: the caller comes back with room for n
-  for (int64_t i = 0; i < n; i++) { const float* p = &tmp[(size_t)order[(size_t)i] * 4]; points_xyz_host[3 * i] = p[0]; points_xyz_host[3 * i + 1] = p[1]; points_xyz_host[3 * i + 2] = p[2]; }
+  if (n) memcpy(points_xyz_host, m->zc_points.data(), (size_t)n * 12);
   return n;
 }
 

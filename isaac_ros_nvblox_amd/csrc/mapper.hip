@@ -896,6 +896,7 @@ int nvbx_mapper::reset_consumed_list() {
   return NVBX_OK;
 }
 int nvbx_mapper::join_side() {
+  zc_valid = false;                  // (whatever follows may change the TSDF: the kept zero-crossing list is dropped)
   // every entry point passes here before its first HIP call: make this mapper's device current (hosts with one mapper per GPU in
   // one process); a thread-local read when it already is
   { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != device) NVBX_HIP(hipSetDevice(device)); }

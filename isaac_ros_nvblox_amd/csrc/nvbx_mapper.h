@@ -116,6 +116,9 @@ struct nvbx_mapper {
   // mark_pass when the last distance transform was enqueued (passes above it are the unresolved ones).
   bool unresolved_marks = false; uint32_t pass_at_last_edt = 0;
   int undo_marks();
+  // nvbx_tsdf_zero_crossings: the sorted result of the last call, valid until any other entry point runs (join_side) -- serves the
+  // "count, then data" pair of calls with one launch, one download and one sort
+  bool zc_valid = false; float zc_min = 0.0f, zc_max = 0.0f; std::vector<float> zc_points;
   // dynamic mapping (dynamics.hip)
   int64_t time_ms = 0;               // update_time_ms of the next integrateDepth
   int ensure_freespace_pool();

@@ -291,3 +291,36 @@ def test_union_step_of_the_index_exchange_rides_in_the_fused_launch(oracle_mod, 
     bit_equal(M, plain, rank0, "index exchange in the pipeline")
     sa, _ = plain.esdf_slice_image(); sb, _ = rank0.esdf_slice_image()
     assert np.array_equal(sa, sb)
+
+
+def test_advice_r03_two_updates_in_a_row_and_lidar_then_colour(oracle_mod, hip_lib):
+    """(a) Two updateEsdf calls held back with nothing between them stay two updates: the "last update" counters equal the undeferred mapper's.
+    (b) One LiDAR scan no longer keeps a camera + LiDAR mapper out of the fused launches for good: the next colour launch repairs every block the
+    scan left stale, and the frames after it run in two launches again -- with the classic mapper's map, bit for bit."""
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    pg = M.default_params(lidar_max_integration_distance_m=6.0)
+    a = M.Mapper(pg, block_capacity=1 << 13); b = M.Mapper(pg, block_capacity=1 << 13)
+    b.set_color_deferral(True); b.set_profiling(True)
+    fr = H.frames(14, cam, stride=6)
+    lidar = (128, 16, 0.1, -np.deg2rad(20.0), np.deg2rad(20.0))
+    Tl = np.eye(4, dtype=np.float32); Tl[:3, 3] = (-1.0, 0.5, 1.0)
+    rng_img = S.Scene().raycast(Tl[:3, 3].astype(float), S.lidar_beam_dirs(lidar).reshape(-1, 3)).reshape(16, 128).astype(np.float32)
+    for k, (d, rgb, T) in enumerate(fr):
+        for m_ in (a, b):
+            m_.integrate_depth(d, T, cam); m_.integrate_color(rgb, T, cam); m_.update_esdf()
+            if k == 3:
+                m_.update_esdf()                          # a second update right behind the first
+        if k == 3:
+            ca, cb = a.counters(), b.counters()
+            for f in ("esdf_columns_marked", "esdf_blocks_swept", "esdf_window_voxels"):
+                assert ca[f] == cb[f], (f, ca[f], cb[f])
+        if k == 5:
+            for m_ in (a, b):
+                m_.integrate_lidar_depth(rng_img, Tl, lidar)
+            n_fused_before = sum(v["count"] for k_, v in b.profile().items() if "k_integrate_tsdf_color" in k_)
+            b.set_profiling(True)
+    prof = b.profile()
+    fused_after = sum(v["count"] for k_, v in prof.items() if "k_integrate_tsdf_color" in k_)
+    assert n_fused_before >= 3 and fused_after >= 5, (n_fused_before, {k_: v["count"] for k_, v in prof.items()})      # frames 8..13 fused again
+    bit_equal(M, a, b, "camera + LiDAR mapper")
