@@ -54,14 +54,10 @@ __device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_
   const bool early = (tflags & F_TSDF) && slot_ok(eslot);
   int first = 0;
   if (early && lane == 0) first = atomicExch(&m.slot_stamp[eslot], a.mark_pass) != a.mark_pass;
-  float4 pre[2][4];
   const uint32_t ts0 = __shfl(qslot, 1), ts1 = __shfl(qslot, nz > 1 ? 2 : 1);
-  {
-    const float4* c0 = reinterpret_cast<const float4*>(&m.tsdf[(size_t)(slot_ok(ts0) ? ts0 : 0) * 512 + 64 * vx + 8 * vy]);
-    const float4* c1 = reinterpret_cast<const float4*>(&m.tsdf[(size_t)(slot_ok(ts1) ? ts1 : 0) * 512 + 64 * vx + 8 * vy]);
-#pragma unroll
-    for (int w = 0; w < 4; w++) { pre[0][w] = c0[w]; pre[1][w] = c1[w]; }
-  }
+  const float4* c0 = reinterpret_cast<const float4*>(&m.tsdf[(size_t)(slot_ok(ts0) ? ts0 : 0) * 512 + 64 * vx + 8 * vy]);
+  const float4* c1 = reinterpret_cast<const float4*>(&m.tsdf[(size_t)(slot_ok(ts1) ? ts1 : 0) * 512 + 64 * vx + 8 * vy]);
+  const float4 p00 = c0[0], p01 = c0[1], p02 = c0[2], p03 = c0[3], p10 = c1[0], p11 = c1[1], p12 = c1[2], p13 = c1[3];      // (named registers: an indexed array of them went to scratch memory)
   const bool e_exists = slot_ok(eslot) && (m.slot_flags[slot_ok(eslot) ? eslot : 0] & (F_ESDF | F_ESDF_PENDING));
   if (!(tflags & F_TSDF) && !(e_exists && (tflags & F_ESDF_REMARK))) return;          // uniform
   if (lane == 0) {
@@ -78,14 +74,9 @@ __device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_
   // TSDF columns of the band: this lane's (x, y) column of block bzz is voxels 64*vx + 8*vy + 0..7 = 64 contiguous bytes
   // (weight 0 -- also what a slot without a TSDF block reads -- contributes nothing)
   int observed = 0, inside = 0, site = 0;
-  for (int32_t q = 0; q < nz; ++q) {
-    const uint32_t ts = __shfl(qslot, q + 1);
-    if (!slot_ok(ts)) continue;                           // uniform
-    const int32_t bzz = bz_lo + q;
-    const float4* col = reinterpret_cast<const float4*>(&m.tsdf[(size_t)ts * 512 + 64 * vx + 8 * vy]);
-    float dz[8], wz[8];
-#pragma unroll
-    for (int w = 0; w < 4; w++) { const float4 v = q < 2 ? pre[q][w] : col[w]; dz[2 * w] = v.x; wz[2 * w] = v.y; dz[2 * w + 1] = v.z; wz[2 * w + 1] = v.w; }
+  // one band block's column: 8 voxels {distance, weight} of this lane's (x, y), block z index bzz
+  auto column = [&](int32_t bzz, const float4& v0, const float4& v1, const float4& v2, const float4& v3) {
+    const float dz[8] = {v0.x, v0.z, v1.x, v1.z, v2.x, v2.z, v3.x, v3.z}, wz[8] = {v0.y, v0.w, v1.y, v1.w, v2.y, v2.w, v3.y, v3.w};
 #pragma unroll
     for (int z = 0; z < 8; z++) {
       const int32_t kz = bzz * 8 + z;
@@ -100,6 +91,14 @@ __device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_
         if ((a.site_rule == 1 || in) && fabsf(dz[z]) <= a.site_dist_m) site = 1;
       }
     }
+  };
+  if (slot_ok(ts0)) column(bz_lo, p00, p01, p02, p03);                          // (uniform)
+  if (nz > 1 && slot_ok(ts1)) column(bz_lo + 1, p10, p11, p12, p13);
+  for (int32_t q = 2; q < nz; ++q) {                                            // (a band of more than two blocks: loaded here)
+    const uint32_t ts = __shfl(qslot, q + 1);
+    if (!slot_ok(ts)) continue;                           // uniform
+    const float4* col = reinterpret_cast<const float4*>(&m.tsdf[(size_t)ts * 512 + 64 * vx + 8 * vy]);
+    column(bz_lo + q, col[0], col[1], col[2], col[3]);
   }
   eslot = __shfl(eslot, 0); first = __shfl(first, 0);
   NVBX_TV(0, 5, wall_clock64());

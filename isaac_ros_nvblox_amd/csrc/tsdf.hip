@@ -239,8 +239,9 @@ __device__ inline void view_append(int32_t* cnt, int4* view_list, int32_t list_c
 
 // [U] workspace bounds of the view calculator (workspace_bounds_type, mapper_initialization.cpp:337-358): a block is kept
 // iff its cube overlaps the bounds (height bounds: z only)
-__device__ inline bool block_in_workspace(const Frame& f, const int32_t* cur) {
+__device__ inline bool block_in_workspace(const Frame& f, int32_t bx, int32_t by, int32_t bz) {
   if (f.ws_type == 0) return true;
+  const int32_t cur[3] = {bx, by, bz};
   bool ok = true;
 #pragma unroll
   for (int a = 0; a < 3; a++) {
@@ -252,9 +253,9 @@ __device__ inline bool block_in_workspace(const Frame& f, const int32_t* cur) {
 }
 // insert `key` into the tile's LDS set; false = probe window exhausted (caller sends the key to HBM itself)
 template <int LSET>
-__device__ inline bool lset_insert(u64* lset, const int32_t* cur, u64 key, bool* added) {
+__device__ inline bool lset_insert(u64* lset, int32_t bx, int32_t by, int32_t bz, u64 key, bool* added) {
   static_assert((LSET & (LSET - 1)) == 0, "power of two");
-  const uint32_t lh = ((index_hash(cur[0], cur[1], cur[2]) * 2654435761u) >> 16) & (LSET - 1);
+  const uint32_t lh = ((index_hash(bx, by, bz) * 2654435761u) >> 16) & (LSET - 1);
   *added = false;
 #pragma unroll 1
   for (int p = 0; p < 16; p++) {
@@ -265,17 +266,57 @@ __device__ inline bool lset_insert(u64* lset, const int32_t* cur, u64 key, bool*
   return false;
 }
 // Amanatides-Woo: advance to the next block along the ray (select without dynamic register indexing)
-// (select-only: as three exec-masked branches a step cost ~300 cycles of a lone wavefront -- a LiDAR lane replays up to 234 of them before it
-//  reaches its segment of a 200 m ray, 35 of the slowest bundle's 78 us, tools/wg_timeline_lidar.py; the same comparisons and the same one
-//  addition on the chosen axis' tmax, so the traversal is bit-identical)
-__device__ inline void dda_step(int32_t* cur, const int32_t* step, float* tmax, const float* tdelta) {
-  const bool s1 = tmax[1] < tmax[0];
-  const float m01 = s1 ? tmax[1] : tmax[0];
-  const bool s2 = tmax[2] < m01;
+// Amanatides-Woo through the block grid with the crossing parameters in CLOSED FORM: crossing number k of axis a lies at
+//   T_a(k) = fmaf(k, tdelta_a, tmax0_a)            (one rounding; the checker evaluates the same fmaf: oracle/nvblox_oracle.c raycast_blocks)
+// instead of tmax_a accumulated by k additions.  Same traversal up to the last bit of a near-tie -- and a state that depends on the crossing
+// COUNTS (n_x, n_y, n_z) alone, so a lane can enter the traversal at any step in O(1) (dda_jump) instead of replaying every step before it:
+// a LiDAR lane used to replay up to 234 steps of a 200 m ray before its own 16 (35 of the slowest bundle's 78 us, tools/wg_timeline_lidar.py).
+// A step: the axis with the smallest next crossing (ties: x before y before z), select-only.
+struct Dda { int32_t cur[3], step[3], n[3]; float t0[3], dt[3], tm[3]; };
+__device__ inline float dda_T(const Dda& d, int a, int32_t k) { return __builtin_fmaf((float)k, d.dt[a], d.t0[a]); }
+__device__ inline void dda_step(Dda& d) {
+  const bool s1 = d.tm[1] < d.tm[0];
+  const float m01 = s1 ? d.tm[1] : d.tm[0];
+  const bool s2 = d.tm[2] < m01;
   const bool a0 = !s1 && !s2, a1 = s1 && !s2;
-  const float t0 = tmax[0] + tdelta[0], t1 = tmax[1] + tdelta[1], t2 = tmax[2] + tdelta[2];
-  tmax[0] = a0 ? t0 : tmax[0]; tmax[1] = a1 ? t1 : tmax[1]; tmax[2] = s2 ? t2 : tmax[2];
-  cur[0] += a0 ? step[0] : 0; cur[1] += a1 ? step[1] : 0; cur[2] += s2 ? step[2] : 0;
+  d.n[0] += a0 ? 1 : 0; d.n[1] += a1 ? 1 : 0; d.n[2] += s2 ? 1 : 0;
+  d.cur[0] += a0 ? d.step[0] : 0; d.cur[1] += a1 ? d.step[1] : 0; d.cur[2] += s2 ? d.step[2] : 0;
+  d.tm[0] = dda_T(d, 0, d.n[0]); d.tm[1] = dda_T(d, 1, d.n[1]); d.tm[2] = dda_T(d, 2, d.n[2]);
+}
+// undo the last step taken: of the crossings taken, the one with the LARGEST parameter (ties: z before y before x -- the reverse of dda_step's order)
+__device__ inline void dda_unstep(Dda& d) {
+  const float l0 = d.n[0] > 0 ? dda_T(d, 0, d.n[0] - 1) : -1.0f, l1 = d.n[1] > 0 ? dda_T(d, 1, d.n[1] - 1) : -1.0f, l2 = d.n[2] > 0 ? dda_T(d, 2, d.n[2] - 1) : -1.0f;
+  const bool s2 = d.n[2] > 0 && l2 >= l1 && l2 >= l0;
+  const bool a1 = !s2 && d.n[1] > 0 && l1 >= l0;
+  const bool a0 = !s2 && !a1 && d.n[0] > 0;
+  d.n[0] -= a0 ? 1 : 0; d.n[1] -= a1 ? 1 : 0; d.n[2] -= s2 ? 1 : 0;
+  d.cur[0] -= a0 ? d.step[0] : 0; d.cur[1] -= a1 ? d.step[1] : 0; d.cur[2] -= s2 ? d.step[2] : 0;
+  d.tm[0] = dda_T(d, 0, d.n[0]); d.tm[1] = dda_T(d, 1, d.n[1]); d.tm[2] = dda_T(d, 2, d.n[2]);
+}
+// Enter the traversal after exactly K steps (from the initial state).  (1) a parameter tau at which about K crossings have happened (the crossing
+// density is linear in the parameter); (2) the EXACT state "every crossing with T < tau taken" -- counted per axis with the same fmaf the
+// traversal compares, so it is a state the step-by-step traversal passes through whatever the estimate was; (3) a few steps forwards or
+// backwards until the count is K.  `inv[a]` = 1 / tdelta_a (0 for an axis the ray does not move along).
+__device__ inline void dda_jump(Dda& d, int32_t K, const float* inv) {
+  const float s1 = (inv[0] + inv[1]) + inv[2];
+  float s0 = 0.0f;
+#pragma unroll
+  for (int a = 0; a < 3; a++) s0 = s0 + (inv[a] > 0.0f ? 1.0f - d.t0[a] * inv[a] : 0.0f);
+  const float tau = s1 > 0.0f ? ((float)K - s0) / s1 : 0.0f;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    int32_t k = 0;
+    if (inv[a] > 0.0f) {
+      const float e = ceilf((tau - d.t0[a]) * inv[a]);
+      k = e > 0.0f ? (e < 1.0e6f ? (int32_t)e : 1000000) : 0;
+      while (k > 0 && dda_T(d, a, k - 1) >= tau) k--;
+      while (k < 1000000 && dda_T(d, a, k) < tau) k++;
+    }
+    d.n[a] = k; d.cur[a] += k * d.step[a]; d.tm[a] = dda_T(d, a, k);
+  }
+  int32_t have = (d.n[0] + d.n[1]) + d.n[2];
+  while (have < K) { dda_step(d); have++; }
+  while (have > K) { dda_unstep(d); have--; }
 }
 // Flush: compact the set (ballot + popcount), then every key goes to HBM with the dependent round trips taken
 // PHASE-WISE over up to R keys per lane at once: (A) the first PD probe positions of every key are loaded together
@@ -325,7 +366,7 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
   __syncthreads();
   NVBX_T(0, 3);
 #ifndef NVBX_WGT_WALK_START
-  NVBX_TV(0, 6, nk);
+  if (NW > 1) NVBX_TV(0, 6, nk);
 #endif
   // key number kb + r * (NW * 64) + (this thread's number in the workgroup): wave w takes the w-th 64 keys of every round
   const int tlane = NW > 1 ? (int)threadIdx.x : lane;
@@ -497,8 +538,9 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   __syncthreads();
   NVBX_T(0, 1);
 
-  int32_t cur[3] = {0, 0, 0}, step[3] = {0, 0, 0}, nsteps = -1;
-  float tmax[3] = {0, 0, 0}, tdelta[3] = {0, 0, 0};
+  Dda dd{};                                     // traversal state of this lane's ray (cur = block, n = crossings taken per axis)
+  int32_t nsteps = -1;
+  float inv_dt[3] = {0.0f, 0.0f, 0.0f};          // 1 / tdelta per axis (= |ray| in blocks), for dda_jump
   if (active) {
     if (!(d > 0.0f)) active = false;
     else {
@@ -511,25 +553,26 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         const float s = f.t_LC[a] / f.block_size, t = pl[a] / f.block_size;
-        cur[a] = (int32_t)floorf(s);
+        dd.cur[a] = (int32_t)floorf(s);
         const int32_t end = (int32_t)floorf(t);
-        const int32_t dd = end - cur[a]; nsteps += dd < 0 ? -dd : dd;
+        const int32_t db = end - dd.cur[a]; nsteps += db < 0 ? -db : db;
         const float ray = t - s;
-        step[a] = ray > 0.0f ? 1 : (ray < 0.0f ? -1 : 0);
-        const float corrected = step[a] > 0 ? 1.0f : 0.0f;
-        const float dist_to_boundary = corrected - (s - (float)cur[a]);
-        if (fabsf(ray) < 1e-9f) { tmax[a] = 2.0f; tdelta[a] = 2.0f; }
-        else { tmax[a] = dist_to_boundary / ray; tdelta[a] = (float)step[a] / ray; }
+        dd.step[a] = ray > 0.0f ? 1 : (ray < 0.0f ? -1 : 0);
+        const float corrected = dd.step[a] > 0 ? 1.0f : 0.0f;
+        const float dist_to_boundary = corrected - (s - (float)dd.cur[a]);
+        if (fabsf(ray) < 1e-9f) { dd.t0[a] = 2.0f; dd.dt[a] = 2.0f; }
+        else { dd.t0[a] = dist_to_boundary / ray; dd.dt[a] = (float)dd.step[a] / ray; inv_dt[a] = fabsf(ray); }
+        dd.tm[a] = dd.t0[a];
       }
     }
   }
-  // this lane's share of the ray: steps [k0, k1]; the traversal state is advanced to k0 without touching the set
+  // this lane's share of the ray: steps [k0, k1]; the traversal is ENTERED at step k0 (dda_jump: no replay of the steps before it)
   int32_t k0 = 0, k1 = nsteps;
   if (NSEG > 1 && nsteps >= 0) {
     const int32_t q = (nsteps + NSEG) / NSEG;                  // ceil((nsteps + 1) / NSEG)
     k0 = seg * q; k1 = min(nsteps, k0 + q - 1);
     if (k0 > nsteps) k1 = -1;                                   // short ray: nothing left for this segment
-    for (int32_t k = 0; k < k0 && k0 <= nsteps; k++) dda_step(cur, step, tmax, tdelta);
+    else if (k0 > 0) dda_jump(dd, k0, inv_dt);
   }
   int32_t* cnt = &m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
 #ifdef NVBX_WGT_WALK_START
@@ -538,13 +581,13 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   if (!Sensor::kLongRays) {
     // camera: a tile's rays cross < 100 blocks in ~20 steps -- walk every ray to its end, then flush once
     for (int32_t k = k0; k <= k1; k++) {                   // (this lane's segment of the ray; the whole ray if it is not shared)
-      const u64 key = pack_key(cur[0], cur[1], cur[2]);
-      const bool inside = block_in_workspace(f, cur);
-      const uint32_t lh = ((index_hash(cur[0], cur[1], cur[2]) * 2654435761u) >> 16) & (LSET - 1);
+      const u64 key = pack_key(dd.cur[0], dd.cur[1], dd.cur[2]);
+      const bool inside = block_in_workspace(f, dd.cur[0], dd.cur[1], dd.cur[2]);
+      const uint32_t lh = ((index_hash(dd.cur[0], dd.cur[1], dd.cur[2]) * 2654435761u) >> 16) & (LSET - 1);
       // first probe issued, the traversal step runs in the shadow of the LDS round trip, then the result is looked at
       u64 old = KEY_EMPTY;
       if (inside) old = atomicCAS(&lset[lh], KEY_EMPTY, key);
-      dda_step(cur, step, tmax, tdelta);
+      dda_step(dd);
       bool spill = false;
       if (inside && old != KEY_EMPTY && old != key) {          // occupied by another block: continue along the probe window
         spill = true;
@@ -569,16 +612,15 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   // half full
   int32_t nset = 0;                                   // keys in the LDS set (wave-uniform)
 #ifdef NVBX_WG_TIMES
-  unsigned long long t_flush = 0, n_flush = 0, n_keys = 0;     // (tools/wg_timeline.py --lidar: time inside the flushes, their number, keys sent to HBM)
-  NVBX_T(0, 1);
+  unsigned long long t_flush = 0, n_flush = 0, n_keys = 0;     // (tools/wg_timeline_lidar.py: time inside the flushes, their number, keys sent to HBM)
 #endif
   for (int32_t j = 0; __ballot(k0 + j <= k1) != 0ull; j++) {
     bool spill = false, added = false;
     u64 key = KEY_EMPTY;
     if (k0 + j <= k1) {
-      key = pack_key(cur[0], cur[1], cur[2]);
-      spill = block_in_workspace(f, cur) && !lset_insert<LSET>(lset, cur, key, &added);
-      dda_step(cur, step, tmax, tdelta);
+      key = pack_key(dd.cur[0], dd.cur[1], dd.cur[2]);
+      spill = block_in_workspace(f, dd.cur[0], dd.cur[1], dd.cur[2]) && !lset_insert<LSET>(lset, dd.cur[0], dd.cur[1], dd.cur[2], key, &added);
+      dda_step(dd);
     }
     nset += (int32_t)__popcll(__ballot(added));
     if (__ballot(spill)) {
@@ -589,6 +631,7 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
     const bool last = __ballot(k0 + j + 1 <= k1) == 0ull;
 #ifdef NVBX_WG_TIMES
     const unsigned long long tf0 = (last || nset > LSET_FLUSH) ? wall_clock64() : 0ull;
+    if (last || nset > LSET_FLUSH) NVBX_TV(0, 1, tf0);          // (slot 1: start of the LAST flush; slots 3, 4, 5: its phases, flush_set)
 #endif
     if (last || nset > LSET_FLUSH) {
       flush_set<LSET, FR, Sensor::kProbeDepth>(m, f, lset, lkeys, cnt, view_list, list_cap, lane, !last);
@@ -599,7 +642,7 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
     }
   }
 #ifdef NVBX_WG_TIMES
-  NVBX_TV(0, 2, t_flush); NVBX_TV(0, 3, n_flush); NVBX_TV(0, 4, n_keys); NVBX_T(0, 7);
+  NVBX_TV(0, 2, t_flush); NVBX_TV(0, 6, (n_flush << 32) | n_keys); NVBX_T(0, 7);
 #endif
 }
 

@@ -407,10 +407,13 @@ static void view_push(OrcMap* m, Idx3 i) {
   m->view[m->n_view++] = i;
 }
 
+/* [U] Amanatides-Woo through the block grid.  The crossing parameters are evaluated in CLOSED FORM -- crossing number k of axis a at
+ * T_a(k) = fmaf(k, tdelta_a, tmax0_a), one rounding -- instead of accumulated by k additions: the traversal then depends on the crossing counts
+ * alone, which lets the kernel enter a ray at any step without replaying the steps before it (csrc/tsdf.hip dda_step / dda_jump, same fmaf). */
 static void raycast_blocks(OrcMap* m, const float* o, const float* e, float bs) {
   float s[3], t[3];
-  int32_t cur[3], end[3], step[3];
-  float tmax[3], tdelta[3];
+  int32_t cur[3], end[3], step[3], ncross[3] = {0, 0, 0};
+  float tmax[3], tdelta[3], tmax0[3];
   int32_t nsteps = 0;
   for (int a = 0; a < 3; a++) {
     s[a] = o[a] / bs; t[a] = e[a] / bs;
@@ -422,6 +425,7 @@ static void raycast_blocks(OrcMap* m, const float* o, const float* e, float bs) 
     float dist_to_boundary = corrected - (s[a] - (float)cur[a]);
     if (fabsf(ray) < 1e-9f) { tmax[a] = 2.0f; tdelta[a] = 2.0f; }
     else { tmax[a] = dist_to_boundary / ray; tdelta[a] = (float)step[a] / ray; }
+    tmax0[a] = tmax[a];
   }
   for (int32_t k = 0; k <= nsteps; k++) {
     Idx3 i = {cur[0], cur[1], cur[2]};
@@ -430,7 +434,8 @@ static void raycast_blocks(OrcMap* m, const float* o, const float* e, float bs) 
     if (tmax[1] < tmax[a]) a = 1;
     if (tmax[2] < tmax[a]) a = 2;
     cur[a] += step[a];
-    tmax[a] = tmax[a] + tdelta[a];
+    ncross[a]++;
+    tmax[a] = fmaf((float)ncross[a], tdelta[a], tmax0[a]);
   }
 }
 

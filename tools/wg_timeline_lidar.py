@@ -28,15 +28,17 @@ for s in range(6):
     b = buf[0].astype(np.int64); used = b[:, 0] > 0
     t0 = b[used, 0].min()
     st = (b[used, 0] - t0) / 100.0; en = (b[used, 7] - t0) / 100.0
+    nfl = b[:, 6] >> 32; nkeys = b[:, 6] & 0xFFFFFFFF
     res.append({"workgroups": int(used.sum()), "launch_end_us": round(float(en.max()), 1), "start_median_us": round(float(np.median(st)), 1), "start_max_us": round(float(st.max()), 1),
                 "dur_median_us": round(float(np.median(en - st)), 1), "dur_max_us": round(float((en - st).max()), 1),
-                "setup_median_us": round(float(np.median((b[used, 1] - b[used, 0]) / 100.0)), 2),
                 "flush_time_median_us": round(float(np.median(b[used, 2] / 100.0)), 1), "flush_time_sum_over_dur": round(float((b[used, 2] / 100.0).sum() / (en - st).sum()), 3),
-                "flushes_median": float(np.median(b[used, 3])), "keys_median": float(np.median(b[used, 4])), "keys_total": int(b[used, 4].sum())})
+                "flushes_median": float(np.median(nfl[used])), "keys_median": float(np.median(nkeys[used])), "keys_total": int(nkeys[used].sum())})
 idx = np.nonzero(used)[0]; dur = en - st
 order = np.argsort(-dur)[:12]
-slow = [{"wg": int(idx[j]), "start": round(float(st[j]), 1), "dur": round(float(dur[j]), 1), "setup": round(float((b[idx[j], 1] - b[idx[j], 0]) / 100.0), 1), "flush_time": round(float(b[idx[j], 2] / 100.0), 1),
-         "flushes": int(b[idx[j], 3]), "keys": int(b[idx[j], 4])} for j in order]
+slow = [{"wg": int(idx[j]), "start": round(float(st[j]), 1), "dur": round(float(dur[j]), 1), "flush_time": round(float(b[idx[j], 2] / 100.0), 1),
+         "flushes": int(nfl[idx[j]]), "keys": int(nkeys[idx[j]]),
+         "last_flush_phases_us": {"compact": round(float((b[idx[j], 3] - b[idx[j], 1]) / 100.0), 2), "probe+claim": round(float((b[idx[j], 4] - b[idx[j], 3]) / 100.0), 2),
+                                  "append": round(float((b[idx[j], 5] - b[idx[j], 4]) / 100.0), 2), "end": round(float((b[idx[j], 7] - b[idx[j], 5]) / 100.0), 2)}} for j in order]
 hist = np.histogram(dur, bins=[0, 5, 10, 20, 30, 40, 60, 80, 200])[0].tolist()
 late = [{"wg": int(idx[j]), "start": round(float(st[j]), 1), "dur": round(float(dur[j]), 1)} for j in np.argsort(-en)[:8]]
 print(json.dumps({"duration_histogram_us[0,5,10,20,30,40,60,80,200]": hist, "slowest": slow, "last_to_end": late}))
