@@ -14,7 +14,7 @@ if [ $TEST = 1 ]; then
 fi
 for W in "${WL[@]}"; do
   S=""; [ $W != camera ] && S="_$W"
-  case $W in lidar) ARGS="--steps 100 --warmup 10"; PARGS="--steps 50 --warmup 5";; decay) ARGS="--steps 120 --warmup 24"; PARGS="--steps 60 --warmup 12";;
+  case $W in lidar) ARGS="--steps 100 --warmup 10"; PARGS="--steps 50 --warmup 5 --profile-run";; decay) ARGS="--steps 120 --warmup 24"; PARGS="--steps 60 --warmup 12";;
              camera_mesh) ARGS="--steps 100 --warmup 20 --with-mesh"; PARGS="--steps 100 --warmup 20 --profile-run --with-mesh";;
              multicam) ARGS="--steps 100 --warmup 20 --cameras 4"; PARGS="--steps 50 --warmup 10 --cameras 4 --profile-run";; multicam8) ARGS="--steps 100 --warmup 20 --cameras 8"; PARGS="--steps 50 --warmup 10 --cameras 8 --profile-run";; *) ARGS=""; PARGS="--steps 100 --warmup 20 --profile-run";; esac
   WL_NAME=$W; [ $W = multicam8 ] && WL_NAME=multicam; [ $W = camera_mesh ] && WL_NAME=camera
