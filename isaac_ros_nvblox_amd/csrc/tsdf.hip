@@ -387,25 +387,82 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
       for (int q = 0; q < PD; q++) e[r][q] = *reinterpret_cast<const uint4*>(&m.table[(h[r] + q) & m.mask]);
     }
     // (B) resolve + (C) stamp exchanges in flight
-    bool fast[R], first[R], claim[R]; uint32_t old[R], seen[R], slot[R], hpos[R]; int4 rec[R];
+    bool fast[R], first[R], claim[R], ins[R]; uint32_t old[R], seen[R], slot[R], hpos[R]; int4 rec[R];
     const uint32_t want = (f.frame_id << 8) | f.cam_bit;
+    bool any_ins = false;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      fast[r] = false; first[r] = false; claim[r] = false; old[r] = 0u; seen[r] = 0u; hpos[r] = 0u; slot[r] = SLOT_INVALID; rec[r] = make_int4(0, 0, 0, 0);
+      fast[r] = false; first[r] = false; claim[r] = false; ins[r] = false; old[r] = 0u; seen[r] = 0u; hpos[r] = 0u; slot[r] = SLOT_INVALID; rec[r] = make_int4(0, 0, 0, 0);
       if (r < rounds && have[r]) {
-        uint32_t hh = h[r], st = 0; bool open = true;        // open: no EMPTY entry seen yet on the probe chain
+        uint32_t hh = h[r], st = 0; bool open = true, hit = false;        // open: no EMPTY entry seen yet on the probe chain
+        int qe = -1;                                                      // first EMPTY position of the chain, if the key is not in front of it
 #pragma unroll
         for (int q = 0; q < PD; q++) {
           const u64 kq = ((u64)e[r][q].y << 32) | (u64)e[r][q].x;
-          if (open && !fast[r] && kq == key[r]) { slot[r] = e[r][q].z; st = e[r][q].w; hh = (h[r] + q) & m.mask; fast[r] = true; }
-          if (kq == KEY_EMPTY) open = false;
+          if (open && !fast[r] && kq == key[r]) { slot[r] = e[r][q].z; st = e[r][q].w; hh = (h[r] + q) & m.mask; fast[r] = true; hit = true; }
+          if (open && kq == KEY_EMPTY) { open = false; if (!hit) qe = q; }
         }
         if (slot[r] == SLOT_INVALID) fast[r] = false;              // being inserted right now: general path waits for the slot
         if (fast[r]) {
           hpos[r] = hh; seen[r] = st;
           if (stamp_frame(st) != f.frame_id) { claim[r] = true; old[r] = atomicCAS(&m.table[hh].stamp, st, want); }   // the returning atomics of a pass: in flight together
           else if (!(st & f.cam_bit)) atomicOr(&m.table[hh].stamp, f.cam_bit);     // stamped by another camera of this batch: add our bit (not waited for)
+#ifndef NVBX_NO_BATCH_INSERT             // (A/B: tools/build_variant.sh nobatch "-DNVBX_NO_BATCH_INSERT")
+        } else if (qe >= 0) { ins[r] = true; any_ins = true; hpos[r] = (h[r] + qe) & m.mask;        // a NEW block (as far as this pass can see)
+#endif
         }
+      }
+    }
+    // (B') new blocks, batch-wise: the pass's key inserts in flight together, then ONE pop of the free stack for all the wavefront's winners
+    // (hash_insert pops one slot per block: two returning atomics on ONE address each -- free-stack top and high-water mark --, ~12 ns apiece
+    // chip-wide, i.e. 2.7 ms of a first LiDAR scan's 112 k new blocks before anything else; and a chain of ~8 dependent round trips per key, R
+    // keys one after the other).  A lane that loses its insert (another wavefront's key landed in the entry first) takes the general path.
+    bool won[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) won[r] = false;
+    if (__ballot(any_ins)) {
+      u64 oldk[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) if (ins[r]) oldk[r] = atomicCAS(&m.table[hpos[r]].key, KEY_EMPTY, key[r]);
+      int32_t wtotal = 0, wpre[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        won[r] = ins[r] && oldk[r] == KEY_EMPTY;
+        const u64 mask = __ballot(won[r]);
+        wpre[r] = wtotal + (int32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        wtotal += (int32_t)__popcll(mask);
+      }
+      if (wtotal) {
+        int32_t top = 0;
+        if (lane == 0) {
+          top = atomicSub(&m.counters[C_FREE_TOP], wtotal);
+          if (top < wtotal) { atomicAdd(&m.counters[C_FREE_TOP], wtotal - (top > 0 ? top : 0)); atomicExch(&m.counters[C_OVERFLOW], 1); }     // pool exhausted: give back what was not there
+        }
+        top = __shfl(top, 0);
+        uint32_t ost[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) if (won[r]) {
+          const int32_t idx = top - 1 - wpre[r];
+          slot[r] = idx >= 0 ? m.free_stack[idx] : SLOT_NONE;
+          ost[r] = atomicCAS(&m.table[hpos[r]].stamp, STAMP_NEVER, want);          // (a fresh entry's stamp; somebody may have met the key and claimed it already)
+        }
+        int32_t hwm = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) if (won[r]) {
+          int32_t x, y, z; unpack_key(key[r], &x, &y, &z);
+          if (slot_ok(slot[r])) {
+            m.slot_index[3 * slot[r]] = x; m.slot_index[3 * slot[r] + 1] = y; m.slot_index[3 * slot[r] + 2] = z;
+            m.slot_entry[slot[r]] = hpos[r];
+            atomicOr(&m.slot_flags[slot[r]], F_TSDF);
+            hwm = max(hwm, (int32_t)slot[r] + 1);
+          }
+          __hip_atomic_store(&m.table[hpos[r]].slot, slot[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // published: every winner of the pass BEFORE this wavefront waits for anybody else's
+          first[r] = ost[r] == STAMP_NEVER || stamp_claim(&m.table[hpos[r]].stamp, ost[r], f.frame_id, f.cam_bit);
+          rec[r] = make_int4((int32_t)slot[r], x, y, z);
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) hwm = max(hwm, __shfl_xor(hwm, o));
+        if (lane == 0 && hwm) atomicMax(&m.counters[C_HIGH_WATER], hwm);
       }
     }
 #pragma unroll
@@ -414,8 +471,8 @@ __device__ inline void flush_set(const DMap& m, const Frame& f, u64* lset, u64* 
         if (fast[r]) {
           first[r] = claim[r] && (old[r] == seen[r] || stamp_claim(&m.table[hpos[r]].stamp, old[r], f.frame_id, f.cam_bit));   // (a lost CAS: another tile claimed it, add our bit)
           if (first[r]) { int32_t x, y, z; unpack_key(key[r], &x, &y, &z); rec[r] = make_int4((int32_t)slot[r], x, y, z); }
-        } else {
-          first[r] = mark_block(m, key[r], f.frame_id, f.cam_bit, &rec[r]);     // longer probe chain, new block, or slot not published yet
+        } else if (!won[r]) {
+          first[r] = mark_block(m, key[r], f.frame_id, f.cam_bit, &rec[r]);     // longer probe chain, a lost insert, or slot not published yet
         }
       }
     }
@@ -1121,8 +1178,10 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   static const int grid_cap = getenv("NVBX_INTEG_GRID") ? atoi(getenv("NVBX_INTEG_GRID")) : 1024;    // (env: tools/integ_grid_sweep.sh)
   // ... or fewer when the view is smaller: sized from the view count of the last launch the GPU has finished (pinned host memory, not
   // waited for) + 25 % + 64; a hint only -- the kernel grid-strides over whatever the count turns out to be
+  // (no launch finished yet -- a new or just cleared map: the full grid; sized for 64 blocks, the first scans of a LiDAR map, enqueued faster
+  //  than the first finishes, took 1.7 ms each for their 112 k blocks: the whole of round 4's first "exploring" LiDAR figure)
   const int64_t n_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[2], __ATOMIC_RELAXED));
-  const int64_t want = ((n_hint + n_hint / 4 + 64 + 7) / 8) * 8;
+  const int64_t want = n_hint == 0 ? (int64_t)grid_cap : ((n_hint + n_hint / 4 + 64 + 7) / 8) * 8;
   const int grid = (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, grid_cap), want));
   const int32_t spec_lanes = (int32_t)std::min<int64_t>(64, (n_hint + n_hint / 4 + 64 + grid - 1) / grid);
   uint8_t* view_class = nullptr;
