@@ -474,18 +474,23 @@ def main_decay(args):
               min_duration_since_occupied_for_freespace_ms=250)                     # nvblox_dynamics.yaml:11-18
     occ = dict(projective_layer_type=1, max_integration_distance_m=5.0)
     gs = M.Mapper(M.default_params(**fs), device=local_rank, block_capacity=1 << 15, stream=stream.cuda_stream)
-    gd = M.Mapper(M.default_params(**occ), device=local_rank, block_capacity=1 << 13, stream=stream.cuda_stream)
+    # both mappers on ONE stream, as nvblox::MultiMapper hands them out.  --own-stream (A/B, measured and not kept -- EXPERIMENTS.md): the dynamic
+    # (occupancy) mapper on a stream of its own, the split image ordered with nvbx_mapper_wait_for: its launches are independent of the static
+    # mapper's once the depth image is split, but an event record + wait per frame on the static mapper's stream costs more than the overlap saves
+    stream_d = torch.cuda.Stream(dev) if args.own_stream else stream
+    gd = M.Mapper(M.default_params(**occ), device=local_rank, block_capacity=1 << 13, stream=stream_d.cuda_stream)
     # cross-frame pipelining on the static mapper: the frame's first call, detect_dynamics, leaves held-back work alone, so the
     # colour frame / ESDF update of frame i are carried out by integrateDepth(i + 1) in two launches
     gs.set_color_deferral(not args.no_color_deferral)
     gd.set_color_deferral(not args.no_color_deferral)       # (an occupancy mapper has no colour: its updateEsdf alone is held back -- marking pass and distance transform ride in its next depth launches)
     eye = np.eye(4, dtype=np.float32)
     mask = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
-    un = torch.empty((rows, cols), dtype=torch.float32, device=dev); ma = torch.empty_like(un)
+    un = torch.empty((rows, cols), dtype=torch.float32, device=dev); ma2 = [torch.empty_like(un), torch.empty_like(un)]; ma = ma2[0]
     t_ms = [0]
 
     def step(i):
         k = i % nu
+        ma = ma2[i & 1]                  # (two buffers: the split of frame i + 1 must not overwrite what the dynamic mapper reads in frame i)
         if args.separate_front_end:      # (A/B: the front end as three entry points = six launches + a memset)
             gs.detect_dynamics_into(depth_dev[k], poses[k], cam, 5.0, mask)
             gs.remove_small_components_inplace(mask, 2000)             # multi_mapper connected_mask_component_size_threshold (mapper_initialization.cpp:130)
@@ -493,6 +498,8 @@ def main_decay(args):
         else:                            # detect dynamics -> remove small components -> split: one call, three launches (what MultiMapper::integrateDepth runs)
             gs.dynamic_depth_split_into(depth_dev[k], poses[k], cam, 5.0, 2000, 0.25, mask, un, ma)
         gs.set_time_ms(t_ms[0]); t_ms[0] += 33
+        gs.wait_for(gd)                  # (the dynamic mapper's frame i - 1 is over before the static mapper's stream goes on: frame i + 1's split rewrites that buffer)
+        gd.wait_for(gs)                  # (`ma` is written)
         gs.integrate_depth(un, poses[k], cam)
         gd.integrate_depth(ma, poses[k], cam)
         gs.integrate_color(rgb_dev[k], poses[k], cam)
@@ -592,7 +599,10 @@ def main_decay(args):
            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "configs[2]: synthetic Redwood-like room 8x6x2.8 m with a box moving at 0.5 m/s (SURVEY 8d), 640x480 depth+colour "
                                   "limited to 5 m, 0.05 m voxels, MappingType::kDynamic (freespace layer, dynamics detection, occupancy mapper), "
-                                  "invalid_depth_decay 0.8, tsdf_decay 0.95 + occupancy decay every 6th frame", "unique_frames": nu},
+                                  "invalid_depth_decay 0.8, tsdf_decay 0.95 + occupancy decay every 6th frame", "unique_frames": nu,
+                      "mode": ("colour deferral on both mappers (opt-in, DESIGN.md 2.8); " if not args.no_color_deferral else "classic launch order; ") +
+                              ("the dynamic (occupancy) mapper on a stream of its own, ordered with nvbx_mapper_wait_for (A/B)" if args.own_stream else
+                               "both mappers on one stream (as nvblox::MultiMapper hands them out)")},
            "readme_rtx5090_ms": README_RTX5090_MS,
            "per_step_counts": {k_: round(v_, 1) for k_, v_ in counts.items()},
            "block_ms": [round(d / args.steps * 1e3, 4) for d in dts[:16]], "block_stats_ms_per_step": block_stats(dts, args.steps),
@@ -971,6 +981,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU baseline keeps integrating (cycling the same frames) until this much CPU wall time has passed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="camera / multicam: skip the end-state comparison of the timed sequence with the checker (outside the timed region)")
+    ap.add_argument("--own-stream", action="store_true", help="decay: the dynamic mapper of the dynamic-mapping frame on a stream of its own (A/B; slower: EXPERIMENTS.md)")
     ap.add_argument("--profile-run", action="store_true", help="camera / multicam: only the timed step is launched (for rocprofv3 runs: clean per-kernel averages)")
     ap.add_argument("--with-mesh", action="store_true", help="camera: the timed step also updates the colour mesh (TSDF+Color+ESDF+Mesh per frame; profiling passes for k_mesh)")
     ap.add_argument("--no-color-deferral", action="store_true", help="camera workload: classic launch order (4 launches per frame) instead of the cross-frame pipeline")

@@ -235,6 +235,13 @@ int nvbx_mapper_set_color_deferral(nvbx_mapper* m, int32_t enable);
  * reads / writes buffers it shares with the mapper on ANOTHER stream (e.g. an RCCL collective on the framework's stream) orders
  * the two with events on this handle. */
 int nvbx_get_stream(nvbx_mapper* m, void** hip_stream_out);
+/* Stream order between two mappers on DIFFERENT streams of one device (no reference counterpart: nvblox::MultiMapper hands both of its mappers one
+ * CudaStream, nvblox_node.cpp:187-190; a host that creates its mappers on streams of their own -- stream = NULL at nvbx_mapper_create -- and passes
+ * device images from one to the other, e.g. the split depth image of nvbx_dynamic_depth_split, orders them with this instead of a host
+ * synchronisation): work enqueued on `waiter`'s stream after this call starts only when
+ * everything ENQUEUED on `producer`'s stream before it has finished (held-back calls of `producer` are not enqueued yet and are not waited for).
+ * Asynchronous; a no-op when both run on one stream. */
+int nvbx_mapper_wait_for(nvbx_mapper* waiter, nvbx_mapper* producer);
 const char* nvbx_last_error(void);
 /* Arithmetic self-test (no reference counterpart; test infrastructure of the boundary): evaluates the library's own division and
  * square-root sequences (csrc/nvbx_arith.h: the compiler's IEEE sequences without their range-scaling steps) on device arrays --

@@ -124,6 +124,7 @@ SIGNATURES = {
     "nvbx_integrate_color_batch": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "nvbx_take_cleared_blocks": (C.c_int64, [_vp, _vp, _i64]),
     "nvbx_get_stream": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "nvbx_mapper_wait_for": (C.c_int, [_vp, _vp]),
     "nvbx_selftest_arith": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64]),
     "nvbx_decay_occupancy": (C.c_int, [_vp]),
     "nvbx_motion_compensate_pointcloud": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, C.c_float, _vp]),

@@ -374,6 +374,7 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   (void)hipSetDevice(m->device);
   if (m->side) (void)hipStreamSynchronize(m->side);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
+  if (m->ev_order) (void)hipEventDestroy(m->ev_order);
   if (m->ev_main) (void)hipEventDestroy(m->ev_main);
   if (m->ev_side) (void)hipEventDestroy(m->ev_side);
   if (m->side) (void)hipStreamDestroy(m->side);
@@ -466,6 +467,18 @@ extern "C" int nvbx_selftest_arith(const float* a_dev, const float* b_dev, float
 extern "C" int nvbx_get_stream(nvbx_mapper* m, void** hip_stream_out) {
   if (!m || !hip_stream_out) return NVBX_E_INVALID;
   *hip_stream_out = (void*)m->stream;
+  return NVBX_OK;
+}
+// Two mappers on two streams (a MultiMapper whose foreground mapper runs beside the background mapper): `waiter`'s stream takes up work enqueued
+// after this call only when everything enqueued on `producer`'s stream so far has finished.
+extern "C" int nvbx_mapper_wait_for(nvbx_mapper* waiter, nvbx_mapper* producer) {
+  if (!waiter || !producer) return NVBX_E_INVALID;
+  if (waiter == producer || waiter->stream == producer->stream) return NVBX_OK;
+  if (waiter->device != producer->device) { set_error("nvbx_mapper_wait_for: mappers on different devices"); return NVBX_E_INVALID; }
+  NVBX_HIP(hipSetDevice(producer->device));
+  if (!producer->ev_order) NVBX_HIP(hipEventCreateWithFlags(&producer->ev_order, hipEventDisableTiming));
+  NVBX_HIP(hipEventRecord(producer->ev_order, producer->stream));
+  NVBX_HIP(hipStreamWaitEvent(waiter->stream, producer->ev_order, 0));
   return NVBX_OK;
 }
 extern "C" int nvbx_flush(nvbx_mapper* m) {

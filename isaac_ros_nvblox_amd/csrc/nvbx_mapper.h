@@ -67,6 +67,7 @@ struct nvbx_mapper {
   // Every other entry point joins the side stream first, so the caller still sees single-stream ordering.
   hipStream_t side = nullptr;
   hipEvent_t ev_main = nullptr, ev_side = nullptr;
+  hipEvent_t ev_order = nullptr;     // nvbx_mapper_wait_for: this mapper's stream as the producer
   bool use_side = false;        // NVBX_SIDE_STREAM=0 disables
   bool side_pending = false;    // ESDF work enqueued on `side` that `stream` has not waited for yet
   bool main_dirty = true;       // non-colour work enqueued on `stream` since ev_main was recorded

@@ -166,6 +166,10 @@ class Mapper:
     def synchronize(self):
         self._check(self.lib.nvbx_synchronize(self._h))
 
+    def wait_for(self, producer):
+        """This mapper's stream waits for everything enqueued so far on `producer`'s stream (two mappers on two streams; nvbx_mapper_wait_for)."""
+        self._check(self.lib.nvbx_mapper_wait_for(self._h, producer._h))
+
     def stream_handle(self):
         """The raw hipStream_t of the mapper (int)."""
         h = C.c_void_p()

@@ -324,3 +324,73 @@ def test_advice_r03_two_updates_in_a_row_and_lidar_then_colour(oracle_mod, hip_l
     fused_after = sum(v["count"] for k_, v in prof.items() if "k_integrate_tsdf_color" in k_)
     assert n_fused_before >= 3 and fused_after >= 5, (n_fused_before, {k_: v["count"] for k_, v in prof.items()})      # frames 8..13 fused again
     bit_equal(M, a, b, "camera + LiDAR mapper")
+
+
+def test_dynamic_mapper_on_its_own_stream_equals_one_stream(oracle_mod, hip_lib):
+    """nvbx_mapper_wait_for: the dynamic (occupancy) mapper of a dynamic-mapping frame on a stream of its own, ordered against the static mapper's stream
+    with nvbx_mapper_wait_for at the two hand-overs of the split depth image (written on the static mapper's stream, read on the other; two buffers
+    in turn).  The same 24 frames -- fused front end, both mappers with colour deferral, decay every 6th frame, nothing in the loop
+    waits for the GPU -- as with both mappers on one stream: masks, split images, both maps, freespace and both ESDFs bit for bit."""
+    import torch
+    from isaac_ros_nvblox_amd import mapper as M
+    from test_gpu_pipeline import _equal_maps
+    cam = S.REPLICA_LIKE_CAM
+    rows, cols = cam[5], cam[4]
+    dev = torch.device("cuda", 0)
+    s0 = torch.cuda.Stream(dev); s1 = torch.cuda.Stream(dev); s2 = torch.cuda.Stream(dev)
+    fs = dict(projective_layer_type=2, max_integration_distance_m=5.0, invalid_depth_decay_factor=0.8, tsdf_decay_factor=0.95,
+              min_duration_since_occupied_for_freespace_ms=250)
+    occ = dict(projective_layer_type=1, max_integration_distance_m=5.0)
+    frames = []
+    static_scene = S.Scene(); moving = S.Scene(box_min=(1.6, -0.3, 0.0), box_max=(2.0, 0.3, 1.3))      # (the static room for 0.8 s, then an object in mid-room)
+    for i in range(24):
+        sc = static_scene if i < 8 else moving
+        T = S.trajectory_pose(min(i, 8) + max(0, i - 8) // 4, 200)
+        d, rgb = S.render(sc, T, cam, max_range=5.0)
+        frames.append((torch.from_numpy(d).to(dev), torch.from_numpy(rgb).to(dev), T))
+    torch.cuda.synchronize(dev)
+
+    def run(stream_s, stream_d):
+        with torch.cuda.stream(stream_s):
+            gs = M.Mapper(M.default_params(**fs), block_capacity=1 << 14, stream=stream_s.cuda_stream)
+            gd = M.Mapper(M.default_params(**occ), block_capacity=1 << 13, stream=stream_d.cuda_stream)
+            gs.set_color_deferral(True); gd.set_color_deferral(True)
+            mask = torch.empty((rows, cols), dtype=torch.uint8, device=dev); un = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+            ma2 = [torch.empty_like(un), torch.empty_like(un)]
+            kept = []; n_dyn = 0
+            for i, (d_dev, rgb_dev, T) in enumerate(frames):
+                ma = ma2[i & 1]              # two buffers, as bench.py: frame i + 1's split must not overwrite what the dynamic mapper reads in frame i
+                gs.dynamic_depth_split_into(d_dev, T, cam, 5.0, 640, 0.25, mask, un, ma)
+                gs.wait_for(gd)              # (the dynamic mapper's frame i - 1 is over before this stream goes on to frame i + 1's split)
+                gd.wait_for(gs)              # (`ma` is written)
+                gs.set_time_ms(i * 100)
+                gs.integrate_depth(un, T, cam); gd.integrate_depth(ma, T, cam)
+                gs.integrate_color(rgb_dev, T, cam)
+                gs.update_esdf(); gd.update_esdf()
+                if i % 6 == 5:
+                    gs.decay_tsdf(True); gd.decay_occupancy()
+                if i % 4 == 3:
+                    kept.append((mask.clone(), ma.clone()))          # (on the static mapper's stream, behind the split that wrote them)
+            gs.synchronize(); gd.synchronize(); torch.cuda.synchronize(dev)
+            n_dyn = sum(int(m_.sum().item()) for m_, _ in kept)
+        return gs, gd, kept, n_dyn
+
+    gs_a, gd_a, kept_a, n_a = run(s0, s0)
+    gs_b, gd_b, kept_b, n_b = run(s1, s2)
+    assert n_a == n_b and n_a > 9000, (n_a, n_b)
+    for (ma_, da_), (mb_, db_) in zip(kept_a, kept_b):
+        assert torch.equal(ma_, mb_) and torch.equal(da_, db_)
+    _equal_maps(M, gs_a, gs_b, "static mapper")
+    ia, ib = gs_a.block_indices(M.LAYER_FREESPACE), gs_b.block_indices(M.LAYER_FREESPACE)
+    assert np.array_equal(ia, ib) and len(ia) > 50
+    fa, _ = gs_a.get_blocks(M.LAYER_FREESPACE, ia); fb, _ = gs_b.get_blocks(M.LAYER_FREESPACE, ia)
+    for f in ("last_occupied_timestamp_ms", "consecutive_occupancy_duration_ms", "is_high_confidence_freespace", "initialized"):
+        assert np.array_equal(fa[f], fb[f]), f
+    oa, ob = gd_a.block_indices(M.LAYER_OCCUPANCY), gd_b.block_indices(M.LAYER_OCCUPANCY)
+    assert np.array_equal(oa, ob) and len(oa) > 0
+    ba, _ = gd_a.get_blocks(M.LAYER_OCCUPANCY, oa); bb, _ = gd_b.get_blocks(M.LAYER_OCCUPANCY, oa)
+    assert np.array_equal(ba["log_odds"], bb["log_odds"])
+    ea, eb = gd_a.block_indices(M.LAYER_ESDF), gd_b.block_indices(M.LAYER_ESDF)
+    assert np.array_equal(ea, eb)
+    sa, aa = gd_a.esdf_slice_image(); sb, ab = gd_b.esdf_slice_image()
+    assert sa.shape == sb.shape and np.array_equal(sa, sb) and np.array_equal(aa, ab)
