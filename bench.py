@@ -88,6 +88,8 @@ def algorithmic_bytes(kernel, c, rows, cols, sub_ray=4, sub_trace=4, n_cam=1, tr
         return Nv * (B + 2 * 512 * 16)                               # TSDF read, freespace voxels (16 B) read + written
     if kernel.startswith("k_detect_dynamics") or kernel.startswith("k_split_depth") or kernel.startswith("k_mask_zmin"):
         return rows * cols * (4 + 4 + 1)
+    if kernel.startswith("k_stage_color"):
+        return n_cam * rows * cols * 3 * 2               # the held-back colour image(s) copied into the mapper's staging memory: read + written
     if kernel.startswith("k_dyn_detect_union"):
         return rows * cols * (4 + 1 + 4 + 4)          # depth read, mask written, label + nearest-depth images touched
     if kernel.startswith("k_dyn_filter_split"):
@@ -481,8 +483,8 @@ def main_decay(args):
     gd = M.Mapper(M.default_params(**occ), device=local_rank, block_capacity=1 << 13, stream=stream_d.cuda_stream)
     # cross-frame pipelining on the static mapper: the frame's first call, detect_dynamics, leaves held-back work alone, so the
     # colour frame / ESDF update of frame i are carried out by integrateDepth(i + 1) in two launches
-    gs.set_color_deferral(not args.no_color_deferral)
-    gd.set_color_deferral(not args.no_color_deferral)       # (an occupancy mapper has no colour: its updateEsdf alone is held back -- marking pass and distance transform ride in its next depth launches)
+    gs.set_color_deferral(not args.no_color_deferral, staged=True)           # (staged: the default form of a new mapper)
+    gd.set_color_deferral(not args.no_color_deferral, staged=True)       # (an occupancy mapper has no colour: its updateEsdf alone is held back -- marking pass and distance transform ride in its next depth launches)
     eye = np.eye(4, dtype=np.float32)
     mask = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
     un = torch.empty((rows, cols), dtype=torch.float32, device=dev); ma2 = [torch.empty_like(un), torch.empty_like(un)]; ma = ma2[0]
@@ -600,7 +602,7 @@ def main_decay(args):
            "config": {"workload": "configs[2]: synthetic Redwood-like room 8x6x2.8 m with a box moving at 0.5 m/s (SURVEY 8d), 640x480 depth+colour "
                                   "limited to 5 m, 0.05 m voxels, MappingType::kDynamic (freespace layer, dynamics detection, occupancy mapper), "
                                   "invalid_depth_decay 0.8, tsdf_decay 0.95 + occupancy decay every 6th frame", "unique_frames": nu,
-                      "mode": ("colour deferral on both mappers (opt-in, DESIGN.md 2.8); " if not args.no_color_deferral else "classic launch order; ") +
+                      "mode": ("colour deferral, staged form, on both mappers (a new mapper's default, DESIGN.md 2.8); " if not args.no_color_deferral else "classic launch order; ") +
                               ("the dynamic (occupancy) mapper on a stream of its own, ordered with nvbx_mapper_wait_for (A/B)" if args.own_stream else
                                "both mappers on one stream (as nvblox::MultiMapper hands them out)")},
            "readme_rtx5090_ms": README_RTX5090_MS,
@@ -722,7 +724,10 @@ def main_camera(args):
     #  of the peers' lists rides in the fused TSDF-update launch, dist.PipelinedDirtyBlockExchange rotates three buffer sets; the measurement
     #  exchange (--fusion measurements) applies whole frames one step late and keeps the classic order)
     deferral = (world == 1 or not fuse) and not args.no_color_deferral and ((not multicam) or (batch_ok and ncam in bd))
-    g.set_color_deferral(deferral)
+    # the form: STAGED (the default of a new mapper -- what a host gets that only swaps the library; one copy launch per colour frame) or, with
+    # --zero-copy-deferral, the opt-in form without the copy (the caller keeps the colour image unchanged until its next call: the bench's are resident)
+    staged = deferral and not args.zero_copy_deferral
+    g.set_color_deferral(deferral, staged=staged)
 
     # EXPLORING (the headline): the map is EMPTIED at the start of every loop over the nu unique poses and the timed blocks of K steps tile the
     # loop (K = 200 = nu: one block per loop; the driver's K = 20: ten blocks per loop, the map emptied before every tenth), so every pose is
@@ -751,7 +756,7 @@ def main_camera(args):
         step(base + i)
     dt_rev, dts_rev, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 4, first=base + nu)
     ms_revisit = dt_rev / args.steps * 1e3
-    ms_classic = None; ms_classic_exploring = None; ms_staged = None
+    ms_classic = None; ms_classic_exploring = None; ms_other_form = None
     if deferral and not args.profile_run:    # the same revisit blocks in the classic launch order, for the record
         g.set_color_deferral(False)
         dt_c, dts_c, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 4, first=base)
@@ -761,12 +766,11 @@ def main_camera(args):
         dt_ce, dts_ce, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 2, before_block=fresh_map, first=0)
         _, _, whole_c, kept_c = complete_loops(tags[n_tags0:], dts_ce, nu, args.steps)
         ms_classic_exploring = float(np.sum(kept_c)) / len(kept_c) / args.steps * 1e3
-        # ... and with the STAGED copy (nvbx_mapper_set_color_deferral(m, 2), what the nvblox:: facade's setColorIntegrationDeferred(true) switches
-        # on): the held-back frame is copied into mapper-owned memory, no lifetime contract on the caller's image
-        g.set_color_deferral(True, staged=True)
+        # ... and in the OTHER form of the deferral (zero-copy when the line is the staged default, staged when it was asked to be zero-copy)
+        g.set_color_deferral(True, staged=not staged)
         dt_s, dts_s, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 4, first=base)
-        ms_staged = dt_s / args.steps * 1e3
-        g.set_color_deferral(True)
+        ms_other_form = dt_s / args.steps * 1e3
+        g.set_color_deferral(True, staged=staged)
 
     if rank != 0:
         return finish_dist(dist, world)
@@ -928,9 +932,12 @@ def main_camera(args):
                                "fuser.yaml params, TSDF+Color+ESDF every frame (mesh timed separately)",
                    "cameras_per_gpu": ncam, "parallelism": ("one camera per GPU, RCCL all-gather of per-voxel measurements, one fused map on every rank" if fuse else "one camera per GPU, RCCL all-gather of dirty block indices") if world > 1 else "single GPU",
                    "unique_frames": nu,
-                   "mode": ("color_deferral, zero-copy: nvbx_mapper_set_color_deferral(m, 1) -- OPT-IN (the nvblox:: facade leaves deferral off; its "
-                            "Mapper::setColorIntegrationDeferred(true) switches on the staged-copy form, color_deferral.ms_per_step_revisit_staged_copy); "
-                            "a host that only swaps the library runs the classic order, quoted as ms_per_step_classic_order") if deferral else "classic launch order (the facade default)"},
+                   "mode": (("color_deferral, staged: nvbx_mapper_set_color_deferral(m, 2) -- the DEFAULT of a new mapper (C-ABI and nvblox:: facade): what a host gets "
+                             "that only swaps the library; the opt-in zero-copy form is quoted as color_deferral.ms_per_step_revisit_zero_copy, the classic "
+                             "order of four launches as ms_per_step_classic_order") if staged else
+                            ("color_deferral, zero-copy: nvbx_mapper_set_color_deferral(m, 1) -- OPT-IN (--zero-copy-deferral; the caller keeps its colour image "
+                             "unchanged until its next call); the default of a new mapper is the staged form, color_deferral.ms_per_step_revisit_staged_copy")) if deferral
+                           else "classic launch order (--no-color-deferral / NVBX_COLOR_DEFERRAL=0; a new mapper defaults to staged colour deferral)"},
         "ms_per_frame": round(ms_per_step / ncam, 4),
         "ms_per_step_classic_order": (round(ms_classic_exploring, 4) if ms_classic_exploring else (None if deferral else round(ms_per_step, 4))),
         "timing": {"value_is": "exploring: the map is emptied at the start of every loop over the %d unique poses; timed blocks of %d steps tile the loop "
@@ -942,9 +949,9 @@ def main_camera(args):
                    "revisit_ms_per_step": block_stats(dts_rev, args.steps),
                    "revisit_note": "same blocks of K steps on the fully allocated map (after one untimed loop over all poses)"},
         "ms_per_step_revisit": round(ms_revisit, 4),
-        "color_deferral": {"enabled": bool(deferral), "launches_per_frame": launches_per_frame,
+        "color_deferral": {"enabled": bool(deferral), "form": ("staged" if staged else "zero_copy") if deferral else None, "launches_per_frame": launches_per_frame,
                            "ms_per_step_revisit_classic_order": (round(ms_classic, 4) if ms_classic else None),
-                           "ms_per_step_revisit_staged_copy": (round(ms_staged, 4) if ms_staged else None),
+                           ("ms_per_step_revisit_zero_copy" if staged else "ms_per_step_revisit_staged_copy"): (round(ms_other_form, 4) if ms_other_form else None),
                            "note": "enabled: integrateColor(i) / updateEsdf(i) are held back and carried out by integrateDepth(i+1) in pipelined order: "
                                    "launch 1 = view marking(i+1) || sphere tracing(i) || colour candidates(i) || ESDF marking(i), launch 2 = TSDF update(i+1) "
                                    "|| colour integration(i) || distance transform(i) (NVBX_FUSE_COLC=0: three launches); same calls, bit-identical map "
@@ -984,6 +991,7 @@ def main():
     ap.add_argument("--own-stream", action="store_true", help="decay: the dynamic mapper of the dynamic-mapping frame on a stream of its own (A/B; slower: EXPERIMENTS.md)")
     ap.add_argument("--profile-run", action="store_true", help="camera / multicam: only the timed step is launched (for rocprofv3 runs: clean per-kernel averages)")
     ap.add_argument("--with-mesh", action="store_true", help="camera: the timed step also updates the colour mesh (TSDF+Color+ESDF+Mesh per frame; profiling passes for k_mesh)")
+    ap.add_argument("--zero-copy-deferral", action="store_true", help="camera workload: colour deferral WITHOUT the staging copy (opt-in form: the caller keeps the colour image unchanged); default: staged, as a new mapper")
     ap.add_argument("--no-color-deferral", action="store_true", help="camera workload: classic launch order (4 launches per frame) instead of the cross-frame pipeline")
     ap.add_argument("--separate-front-end", action="store_true", help="decay workload: detect / remove-small-components / split as three entry points (A/B against nvbx_dynamic_depth_split)")
     ap.add_argument("--step-trace", type=int, default=0, help="decay workload: wait for every one of this many steps and report the slowest (diagnosis)")

@@ -265,10 +265,10 @@ class Mapper {
   bool saveLayerCake(const std::string& path) const { return nvbx_save_map(m_, path.c_str()) == NVBX_OK; }
   bool loadMap(const std::string& path) { return nvbx_load_map(m_, path.c_str()) == NVBX_OK; }
 
-  // libnvblox_hip extension (not in the reference; off by default): cross-frame pipelining of integrateColor -- see nvbx_mapper_set_color_deferral
-  // in nvblox_hip.h for the colour-image lifetime contract the caller accepts with it
-  // (staged: the held-back frame is copied into mapper-owned memory, so the caller's ColorImage may be refilled right after integrateColor
-  //  returns -- what a node does with its one colour buffer; `zero_copy` = no copy, the caller keeps the image unchanged until the next call)
+  // libnvblox_hip extension (not in the reference): cross-frame pipelining of integrateColor -- nvbx_mapper_set_color_deferral in nvblox_hip.h.
+  // ON by default in its staged form (the held-back frame is copied into mapper-owned memory, so the caller's ColorImage may be refilled right after
+  // integrateColor returns -- what a node does with its one colour buffer; nothing observable through this API differs from `false` but the time);
+  // `zero_copy` = no copy, the caller keeps the image unchanged until the next call into the mapper (opt-in); false = the classic launch order
   void setColorIntegrationDeferred(bool on, bool zero_copy = false) { checkNvbx(nvbx_mapper_set_color_deferral(m_, on ? (zero_copy ? 1 : 2) : 0), "nvbx_mapper_set_color_deferral"); }
   void synchronize() const { checkNvbx(nvbx_synchronize(m_), "nvbx_synchronize"); }
   void flush() const { checkNvbx(nvbx_flush(m_), "nvbx_flush"); }      // enqueue held-back work without waiting

@@ -205,30 +205,28 @@ int nvbx_synchronize(nvbx_mapper* m);
 /* Enqueue everything the mapper holds back (the distance transform of the last nvbx_update_esdf, see there) on its stream
  * WITHOUT waiting: for callers that order their own work behind the mapper's with stream events instead of a host sync. */
 int nvbx_flush(nvbx_mapper* m);
-/* Colour deferral (cross-frame pipelining; off by default).  While enabled, nvbx_integrate_color / _bgra8 of a single frame is HELD BACK --
- * its arguments are remembered, nothing is launched -- and so is an nvbx_update_esdf that follows it.  The next single-frame
- * nvbx_integrate_depth / _u16mm (for a held-back nvbx_integrate_color_batch of n > 1 frames: the next nvbx_integrate_depth_batch of n > 1
- * frames; the image pointers are remembered, not the pointer array) carries them out in pipelined order, two launches per depth + colour + ESDF frame instead of four:
- * {view marking of the new depth frame || sphere tracing, candidate-block discovery and ESDF site marking of the held-back frame}, then
- * {TSDF update of the new frame || colour integration and distance transform of the held-back frame} (three launches where the mapper does not
- * run the exact 2-D ESDF, or has integrated a LiDAR scan).  The overlapped parts are independent: sphere
- * tracing reads the TSDF and the insert-only
- * hash, view marking inserts entries whose blocks are all-zero = unobserved).  EVERY other entry point (queries, synchronize / flush, batches,
- * LiDAR, mesh, decay, clearing, another integrate_color, ...) first carries the held-back calls out exactly as they would have run at call
- * time, so results -- map contents, ESDF, views, every query -- are bit-identical to the undeferred sequence (tests/test_gpu_pipeline.py).
- * With the switch on, an nvbx_update_esdf that follows a depth frame WITHOUT a colour frame in between is held back the same way and carried
- * out by the next camera depth frame (marking pass in its view-marking launch, distance transform in its TSDF-update launch).
- * CONTRACT (the caller-lifetime rule this buys the launch with): the colour image passed to nvbx_integrate_color must stay valid and
- * UNCHANGED until the next call into this mapper has returned that either consumes or flushes the frame -- any call except
- * nvbx_detect_dynamics, nvbx_remove_small_components, nvbx_split_depth_by_mask and nvbx_set_time_ms, which leave held-back work alone
- * (the dynamic-mapping frame starts with them; they read TSDF voxels / the freespace layer / images only).  nvblox_ros re-uses ONE
- * colour buffer per node (nvblox_node.hpp:485-488) and fills it right before integrateColor, after the depth frame -- compatible with the
- * contract for the depth -> colour -> updateEsdf order of NvbloxNode::tick(); a node that fills the colour buffer BEFORE calling
- * integrateDepth must double-buffer it or leave deferral off.  Argument errors are still reported by the call that made them.
- * enable = 2: the same pipeline WITHOUT the contract -- a frame that is held back is first copied into staging memory the mapper owns (one
- * asynchronous device-to-device copy on the mapper's stream per frame, ~0.9 MB at 640x480), so the caller may overwrite or free its image as
- * soon as nvbx_integrate_color has returned, exactly as with deferral off.  This is what the nvblox:: facade switches on
- * (Mapper::setColorIntegrationDeferred): a ROS callback that recycles its colour buffer stays correct.  enable = 1: no copy, the contract above. */
+/* Colour deferral (cross-frame pipelining).  enable = 2, the DEFAULT of a new mapper since round 4: nvbx_integrate_color / _bgra8 of a single frame
+ * is HELD BACK -- the image is copied into staging memory the mapper owns (one launch on the mapper's stream, ~0.9 MB at 640x480), the other arguments
+ * are remembered -- and so is an nvbx_update_esdf that follows it.  The next single-frame nvbx_integrate_depth / _u16mm (for a held-back
+ * nvbx_integrate_color_batch of n > 1 frames: the next nvbx_integrate_depth_batch of n > 1 frames) carries them out in pipelined order, two launches per
+ * depth + colour + ESDF frame instead of four: {view marking of the new depth frame || sphere tracing, candidate-block discovery and ESDF site marking of
+ * the held-back frame}, then {TSDF update of the new frame || colour integration and distance transform of the held-back frame} (three launches where the
+ * mapper does not run the exact 2-D ESDF, or has integrated a LiDAR scan).  The overlapped parts are independent (DESIGN.md 2.8, table of invariants).
+ * EVERY other entry point (queries, synchronize / flush, batches, LiDAR, mesh, decay, clearing, another integrate_color, ...) first carries the held-back
+ * calls out exactly as they would have run at call time, so results -- map contents, ESDF, views, every query -- are bit-identical to the undeferred
+ * sequence (tests/test_gpu_pipeline.py; the whole GPU suite runs with this default), and the caller may overwrite or free its colour image as soon as
+ * nvbx_integrate_color has returned: nothing a host can observe through this header differs from enable = 0, except the time.  (What CAN tell the
+ * difference: a kernel of the caller's own that reads the colour layer or the ESDF through include/nvblox_hip_device.h without calling nvbx_flush first.)
+ * An nvbx_update_esdf that follows a depth frame WITHOUT a colour frame in between is held back the same way and carried out by the next camera depth
+ * frame.  Argument errors are still reported by the call that made them.
+ * enable = 1 (opt-in, zero-copy): no staging copy -- and a CONTRACT instead: the colour image passed to nvbx_integrate_color must stay valid and UNCHANGED
+ * until the next call into this mapper has returned that either consumes or flushes the frame -- any call except nvbx_detect_dynamics,
+ * nvbx_remove_small_components, nvbx_split_depth_by_mask, nvbx_dynamic_depth_split and nvbx_set_time_ms, which leave held-back work alone (the
+ * dynamic-mapping frame starts with them).  nvblox_ros re-uses ONE colour buffer per node (nvblox_node.hpp:485-488) and fills it right before
+ * integrateColor, after the depth frame -- compatible with the contract for the depth -> colour -> updateEsdf order of NvbloxNode::tick(); a node that
+ * fills the colour buffer BEFORE calling integrateDepth must not use it.
+ * enable = 0: the classic order, every call launches its own kernels (four launches per frame).  NVBX_COLOR_DEFERRAL=0|1|2 in the environment sets the
+ * default of mappers created afterwards. */
 int nvbx_mapper_set_color_deferral(nvbx_mapper* m, int32_t enable);
 /* The hipStream_t all of the mapper's work is enqueued on (the one handed to nvbx_mapper_create, or the library-owned one):
  * implicit conversion of nvblox::CudaStream to cudaStream_t -- conversions/esdf_slice_conversions.cu:107-108.  A caller that

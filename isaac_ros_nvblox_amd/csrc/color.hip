@@ -166,6 +166,19 @@ static int integrate_colors(nvbx_mapper* m, int32_t n, const Pix* imgs, int32_t 
 }
 
 // ---- colour deferral (nvbx_mapper.h): hold a frame (or a batch) back / carry it out in pipelined order
+// the staged form's copy of the held-back images (one launch for a whole batch; the runtime's own device-to-device copy is a launch per image, ~4 us each)
+struct StagePtrs { const unsigned char* src[MAX_BATCH]; unsigned char* dst[MAX_BATCH]; };
+__global__ __launch_bounds__(256) void k_stage_color(StagePtrs p, int64_t bytes, int32_t wg_per_image) {
+  const int img = (int)blockIdx.x / wg_per_image, wg = (int)blockIdx.x - img * wg_per_image;
+  const unsigned char* s = p.src[img]; unsigned char* d = p.dst[img];
+  if ((((uintptr_t)s | (uintptr_t)d) & 15u) == 0) {
+    const int64_t n16 = bytes >> 4;
+    for (int64_t i = (int64_t)wg * 256 + threadIdx.x; i < n16; i += (int64_t)wg_per_image * 256) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+    if (wg == 0 && (int64_t)threadIdx.x < (bytes & 15)) d[(n16 << 4) + threadIdx.x] = s[(n16 << 4) + threadIdx.x];
+  } else {
+    for (int64_t i = (int64_t)wg * 256 + threadIdx.x; i < bytes; i += (int64_t)wg_per_image * 256) d[i] = s[i];
+  }
+}
 static bool defer_color(nvbx_mapper* m, int kind, int32_t n, const void* const* imgs, int32_t rows, int32_t cols, const float* T_L_C, const nvbx_camera* cameras, int* rc_out) {
   if (!m->color_deferral || m->replaying || m->p.projective_layer_type == 1) return false;
   *rc_out = color_precheck(m, n, rows, cols, T_L_C);            // argument errors are reported by the call that made them
@@ -181,9 +194,11 @@ static bool defer_color(nvbx_mapper* m, int kind, int32_t n, const void* const* 
       for (int i = 0; i < MAX_BATCH; i++) if (hipMalloc(&m->color_stage[i], bytes) != hipSuccess) { set_error("colour staging buffers"); *rc_out = NVBX_E_DEVICE; return true; }
       m->color_stage_bytes = bytes;
     }
-    for (int i = 0; i < n; i++) {
-      if (hipMemcpyAsync(m->color_stage[i], imgs[i], bytes, hipMemcpyDeviceToDevice, m->stream) != hipSuccess) { set_error("colour staging copy"); *rc_out = NVBX_E_DEVICE; return true; }
-    }
+    StagePtrs sp{};
+    for (int i = 0; i < n; i++) { sp.src[i] = (const unsigned char*)imgs[i]; sp.dst[i] = (unsigned char*)m->color_stage[i]; }
+    const int32_t wgi = (int32_t)std::min<int64_t>(256, std::max<int64_t>(1, (int64_t)(bytes >> 4) / 256 + 1));      // 640x480 rgb8: 226 workgroups, one 16-B access per thread
+    NVBX_LAUNCH(m, k_stage_color, dim3((unsigned)(wgi * n)), dim3(256), sp, (int64_t)bytes, wgi);
+    if (hipGetLastError() != hipSuccess) { set_error("colour staging copy"); *rc_out = NVBX_E_DEVICE; return true; }
   }
   c.on = true; c.kind = kind; c.n = n; c.rows = rows; c.cols = cols;
   for (int i = 0; i < n; i++) { c.imgs[i] = m->color_staging ? m->color_stage[i] : imgs[i]; c.cams[i] = cameras[i]; }

@@ -356,6 +356,8 @@ extern "C" int nvbx_mapper_create(int device, void* hip_stream, const nvbx_mappe
   // cross-stream hand-off costs ~10 us each way on this runtime, which eats most of the overlap)
   { const char* e = getenv("NVBX_SIDE_STREAM"); m->use_side = (e && e[0] == '1'); }
   { const char* e = getenv("NVBX_DEFER_EDT"); m->defer_edt = !(e && e[0] == '0'); }
+  // colour deferral of a new mapper (nvbx_mapper_set_color_deferral overrides): NVBX_COLOR_DEFERRAL = 0 / 1 / 2 in the environment
+  { const char* e = getenv("NVBX_COLOR_DEFERRAL"); if (e && e[0] >= '0' && e[0] <= '2' && !e[1]) { m->color_deferral = e[0] != '0'; m->color_staging = e[0] == '2'; } }
   if (m->use_side) {
     if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming) != hipSuccess ||

@@ -147,12 +147,12 @@ struct nvbx_mapper {
   // unchanged until the next call into the mapper has returned.
   // (n = 1: integrateColor, kind 0 = rgb8 / 1 = bgra8; n > 1: nvbx_integrate_color_batch, rgb8 -- carried out by a depth BATCH in pipelined order)
   struct ColorPending { bool on = false; int kind = 0; int32_t n = 1; const void* imgs[nvbx::MAX_BATCH] = {}; int32_t rows = 0, cols = 0; float T[16 * nvbx::MAX_BATCH]; nvbx_camera cams[nvbx::MAX_BATCH]; };
-  bool color_deferral = false;       // the switch
+  bool color_deferral = true;        // the switch (default: on, staged -- nvbx_mapper_create; NVBX_COLOR_DEFERRAL=0 in the environment: off)
   // nvbx_mapper_set_color_deferral(m, 2): a held-back frame is COPIED into mapper-owned staging memory when it is held back (one asynchronous
   // device-to-device copy on the mapper's stream per frame) -- the caller may recycle or overwrite its image as soon as integrateColor has
   // returned, as without deferral.  One buffer per camera of a batch suffices: the copy of the next frame is stream-ordered behind the launches
   // that read the previous one.
-  bool color_staging = false;
+  bool color_staging = true;
   void* color_stage[nvbx::MAX_BATCH] = {}; size_t color_stage_bytes = 0;
   ColorPending color_pending;        // the held-back integrateColor
   bool esdf_update_pending = false;  // an updateEsdf called while a colour frame was held back

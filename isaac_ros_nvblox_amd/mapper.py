@@ -88,9 +88,10 @@ class Mapper:
 
     def set_color_deferral(self, enable, staged=False):
         """Hold integrateColor (and an updateEsdf behind it) back until the next integrateDepth carries them out in pipelined order (two
-        launches per frame instead of four; include/nvblox_hip.h nvbx_mapper_set_color_deferral).  staged=False: the colour image handed to
-        integrate_color must then stay valid and unchanged until the next call into the mapper has returned; staged=True: the mapper copies a
-        held-back frame into its own memory first (what the nvblox:: facade switches on), no such contract."""
+        launches per frame instead of four; include/nvblox_hip.h nvbx_mapper_set_color_deferral).  A NEW mapper does so in the staged form
+        (enable=True, staged=True: the mapper copies a held-back frame into its own memory first, nothing observable changes but the time).
+        staged=False (opt-in, zero-copy): the colour image handed to integrate_color must then stay valid and unchanged until the next call into
+        the mapper has returned.  enable=False: the classic order, every call launches its own kernels."""
         self._check(self.lib.nvbx_mapper_set_color_deferral(self._h, (2 if staged else 1) if enable else 0))
 
     # -- ground plane (MultiMapper::ground_plane_estimator())

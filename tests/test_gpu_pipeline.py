@@ -31,6 +31,7 @@ def test_steady_state_pipeline_equals_classic_and_oracle(oracle_mod, hip_lib, ca
     from test_gpu_parity import compare_layer, TOL
     pg = M.default_params(); po = H.copy_params(pg, oracle_mod.OrcParams)
     classic = M.Mapper(pg, block_capacity=1 << 14); piped = M.Mapper(pg, block_capacity=1 << 14); o = oracle_mod.OracleMap(po)
+    classic.set_color_deferral(False)          # (a new mapper defers in the staged form: the reference order is asked for)
     piped.set_color_deferral(True)
     for k, (d, rgb, T) in enumerate(H.frames(12, cam, stride=7)):
         for m_ in (classic, piped, o):
@@ -56,6 +57,7 @@ def test_deferred_calls_are_replayed_by_every_other_entry_point(oracle_mod, hip_
     cam = H.SMALL_CAM
     pg = M.default_params(tsdf_decay_factor=0.7, tsdf_decayed_weight_threshold=0.2, lidar_max_integration_distance_m=6.0)
     a = M.Mapper(pg, block_capacity=1 << 14); b = M.Mapper(pg, block_capacity=1 << 14)
+    a.set_color_deferral(False)
     b.set_color_deferral(True)
     fr = H.frames(16, cam, stride=5)
     lidar = (128, 16, 0.1, -np.deg2rad(20.0), np.deg2rad(20.0))
@@ -113,6 +115,7 @@ def test_fused_colour_tsdf_launch_under_irregular_calls(oracle_mod, hip_lib, see
     rng = np.random.default_rng(100 + seed)
     pg = M.default_params(tsdf_decay_factor=0.8, tsdf_decayed_weight_threshold=0.05)
     a = M.Mapper(pg, block_capacity=1024); b = M.Mapper(pg, block_capacity=1024)      # (the pool grows in mid-sequence)
+    a.set_color_deferral(False)
     b.set_color_deferral(True); b.set_profiling(True)
     fr = H.frames(40, cam, stride=5)
 
@@ -159,6 +162,7 @@ def test_camera_batches_take_the_pipeline_too(oracle_mod, hip_lib, ncam):
     cam = H.SMALL_CAM
     pg = M.default_params(tsdf_decay_factor=0.8, tsdf_decayed_weight_threshold=0.05)
     a = M.Mapper(pg, block_capacity=1 << 14); b = M.Mapper(pg, block_capacity=1 << 14)
+    a.set_color_deferral(False)
     b.set_color_deferral(True); b.set_profiling(True)
     fr = H.frames(14 * ncam, cam, stride=2)
 
@@ -209,6 +213,7 @@ def test_dynamic_mapping_frame_keeps_the_pipeline(oracle_mod, hip_lib, cam):
     with torch.cuda.stream(stream):
         mk = lambda prm, cap: M.Mapper(M.default_params(**prm), block_capacity=cap, stream=stream.cuda_stream)
         gs_a, gd_a, gs_b, gd_b = mk(fs, 1 << 14), mk(occ, 1 << 13), mk(fs, 1 << 14), mk(occ, 1 << 13)
+        gs_a.set_color_deferral(False); gd_a.set_color_deferral(False)
         gs_b.set_color_deferral(True); gs_b.set_profiling(True)
         gd_b.set_color_deferral(True); gd_b.set_profiling(True)       # (no colour on the occupancy mapper: its updateEsdf alone is held back and carried)
         eye = np.eye(4, dtype=np.float32)

@@ -55,7 +55,7 @@ def test_camera_batch_at_640x480_against_the_checker(oracle_mod, hip_lib, n_cams
     cam = S.REPLICA_LIKE_CAM
     pg = M.default_params(); po = H.copy_params(pg, oracle_mod.OrcParams)
     classic = M.Mapper(pg, block_capacity=1 << 14); piped = M.Mapper(pg, block_capacity=1 << 14); o = oracle_mod.OracleMap(po)
-    piped.set_color_deferral(True); piped.set_profiling(True)
+    classic.set_color_deferral(False); piped.set_color_deferral(True); piped.set_profiling(True)
     oracle_mod.set_num_threads(min(8, os.cpu_count() or 1))
     for k in range(4):
         fr = rig_frames(n_cams, k, cam)
@@ -228,6 +228,7 @@ def test_staged_colour_deferral_survives_a_recycled_colour_buffer(oracle_mod, hi
         pg = M.default_params()
         classic = M.Mapper(pg, block_capacity=1 << 13, stream=stream.cuda_stream); staged = M.Mapper(pg, block_capacity=1 << 13, stream=stream.cuda_stream)
         zero_copy = M.Mapper(pg, block_capacity=1 << 13, stream=stream.cuda_stream)
+        classic.set_color_deferral(False)
         staged.set_color_deferral(True, staged=True); staged.set_profiling(True)
         zero_copy.set_color_deferral(True)
         buf = torch.empty((cam[5], cam[4], 3), dtype=torch.uint8, device=dev)          # the host's one colour buffer
@@ -268,7 +269,7 @@ def test_union_step_of_the_index_exchange_rides_in_the_fused_launch(oracle_mod, 
             m_.integrate_depth(d, T, cam)
     for m_ in (plain, rank0):
         m_.update_esdf(); m_.synchronize()
-    rank0.set_color_deferral(True); rank0.set_profiling(True)
+    plain.set_color_deferral(False); rank0.set_color_deferral(True); rank0.set_profiling(True)
     bufs = [torch.zeros((2, 4097, 3), dtype=torch.int32, device=dev) for _ in range(3)]       # three rotating gathered sets, as dist.PipelinedDirtyBlockExchange
     for k in range(12):
         d, rgb, T = own[2 * k]; dp, _, Tp = other[2 * k]
@@ -301,7 +302,7 @@ def test_advice_r03_two_updates_in_a_row_and_lidar_then_colour(oracle_mod, hip_l
     cam = H.SMALL_CAM
     pg = M.default_params(lidar_max_integration_distance_m=6.0)
     a = M.Mapper(pg, block_capacity=1 << 13); b = M.Mapper(pg, block_capacity=1 << 13)
-    b.set_color_deferral(True); b.set_profiling(True)
+    a.set_color_deferral(False); b.set_color_deferral(True); b.set_profiling(True)
     fr = H.frames(14, cam, stride=6)
     lidar = (128, 16, 0.1, -np.deg2rad(20.0), np.deg2rad(20.0))
     Tl = np.eye(4, dtype=np.float32); Tl[:3, 3] = (-1.0, 0.5, 1.0)
