@@ -16,8 +16,10 @@ for W in "${WL[@]}"; do
   S=""; [ $W != camera ] && S="_$W"
   case $W in lidar) ARGS="--steps 100 --warmup 10"; PARGS="--steps 50 --warmup 5 --profile-run";; decay) ARGS="--steps 120 --warmup 24"; PARGS="--steps 60 --warmup 12";;
              camera_mesh) ARGS="--steps 100 --warmup 20 --with-mesh"; PARGS="--steps 100 --warmup 20 --profile-run --with-mesh";;
+             camera_zc) ARGS="--zero-copy-deferral"; PARGS="--steps 100 --warmup 20 --profile-run --zero-copy-deferral";;
+             camera_k20) ARGS="--steps 20 --warmup 5"; PARGS="--steps 20 --warmup 5 --profile-run";;
              multicam) ARGS="--steps 100 --warmup 20 --cameras 4"; PARGS="--steps 50 --warmup 10 --cameras 4 --profile-run";; multicam8) ARGS="--steps 100 --warmup 20 --cameras 8"; PARGS="--steps 50 --warmup 10 --cameras 8 --profile-run";; *) ARGS=""; PARGS="--steps 100 --warmup 20 --profile-run";; esac
-  WL_NAME=$W; [ $W = multicam8 ] && WL_NAME=multicam; [ $W = camera_mesh ] && WL_NAME=camera
+  WL_NAME=$W; [ $W = multicam8 ] && WL_NAME=multicam; [ $W = camera_mesh ] && WL_NAME=camera; [ $W = camera_zc ] && WL_NAME=camera; [ $W = camera_k20 ] && WL_NAME=camera
   PMS=100; [ $W = lidar ] && PMS=500     # (LiDAR: few, long launches -- a longer run keeps the first-launch outliers out of the average)
   timeout 900 python bench.py --workload $WL_NAME $ARGS > gpurun_out/$TAG/bench$S.json 2> gpurun_out/$TAG/bench$S.err; echo "bench $W rc=$?"
   cat gpurun_out/$TAG/bench$S.json | cut -c1-600
