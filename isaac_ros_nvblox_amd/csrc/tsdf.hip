@@ -111,6 +111,9 @@ struct LidarSensor {
 #define NVBX_LIDAR_FR 6
 #define NVBX_LIDAR_PD 4
 #endif
+#ifndef NVBX_LIDAR_SPARSE_STRIDED
+#define NVBX_LIDAR_SPARSE_STRIDED 1       // (0: eight consecutive records per pass -- 126.5 instead of 116.4 us, EXPERIMENTS.md)
+#endif
 #ifndef NVBX_LIDAR_SET
 #define NVBX_LIDAR_SET 1024
 #define NVBX_LIDAR_FLUSH 256
@@ -906,13 +909,17 @@ __global__ __launch_bounds__(256) void k_lidar_sparse(DMap m, FrameSet<Img, 1> f
   // pass of the projection code (with one block per pass 56 of the 64 lanes idled through it); the blocks are then walked one after the other.
   const int grp = lane >> 3;
   int32_t n_mine = 0;                                        // blocks this wavefront updated (one counter atomic per wavefront, at the end)
-  int32_t base = ((int32_t)blockIdx.x * 4 + wv) * 8;
-  int4 rec_next = base + grp < n ? view_list[base + grp] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
-  for (; base < n; base += n_waves * 8) {
+  // pass p of G = ceil(n / 8) takes records 8 p .. 8 p + 7 -- or, NVBX_LIDAR_SPARSE_STRIDED, records p, G + p, 2 G + p, ...: eight far-apart
+  // places of the list (a pass's cost is the sum of its blocks' footprints; neighbours in the list have footprints of one size)
+  const int32_t G = (n + 7) >> 3;
+  auto ridx = [&](int32_t p, int g) -> int32_t { return NVBX_LIDAR_SPARSE_STRIDED ? g * G + p : p * 8 + g; };
+  int32_t pass = (int32_t)blockIdx.x * 4 + wv;
+  int4 rec_next = (pass < G && ridx(pass, grp) < n) ? view_list[ridx(pass, grp)] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
+  for (; pass < G; pass += n_waves) {
     const int4 rec_g = rec_next;
-    if (base + n_waves * 8 + grp < n) rec_next = view_list[base + n_waves * 8 + grp]; else rec_next = make_int4((int32_t)SLOT_NONE, 0, 0, 0);
+    if (pass + n_waves < G && ridx(pass + n_waves, grp) < n) rec_next = view_list[ridx(pass + n_waves, grp)]; else rec_next = make_int4((int32_t)SLOT_NONE, 0, 0, 0);
     // (1) corners of the group's block
-    bool sparse_g = base + grp < n && slot_ok((uint32_t)rec_g.x);
+    bool sparse_g = ridx(pass, grp) < n && slot_ok((uint32_t)rec_g.x);
     float org_g[3];
     sensor_block_origin(f, rec_g.y, rec_g.z, rec_g.w, org_g);
     int c0_g = 0, r0_g = 0, w_g = 0, h_g = 0;
@@ -938,8 +945,9 @@ __global__ __launch_bounds__(256) void k_lidar_sparse(DMap m, FrameSet<Img, 1> f
     }
     const u64 sparse_groups = __ballot(sparse_g);
 #pragma unroll 1
-    for (int j = 0; j < 8 && base + j < n; j++) {
-    const int32_t i = base + j;
+    for (int j = 0; j < 8; j++) {
+    const int32_t i = ridx(pass, j);
+    if (i >= n) continue;                                                       // (uniform)
     bool sparse = ((sparse_groups >> (8 * j)) & 1ull) != 0;
     if (!sparse) { if (lane == 0) view_class[i] = 0; continue; }               // (uniform)
     const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane(rec_g.x, 8 * j);
