@@ -592,7 +592,7 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   const float d = active ? depth(pix(prow, pcol, f.cols)) : 0.0f;
   for (int i = (int)threadIdx.x; i < LSET; i += NW * 64) lset[i] = KEY_EMPTY;
   if (wg_all == 0 && threadIdx.x == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
-  if (Sensor::kLongRays && wg_all == 0 && threadIdx.x < NSH) *shc_at(m, S_LIDAR_SPARSE, threadIdx.x, 0) = 0;
+  if (Sensor::kLongRays && wg_all == 0 && threadIdx.x < NSH) { *shc_at(m, S_LIDAR_SPARSE, threadIdx.x, 0) = 0; *shc_at(m, S_LIDAR_SPARSE, threadIdx.x, 1) = 0; }     // (field 1: the dense launch's work list, filled by the beam-centric one)
   // an ESDF dirty list already consumed by a marking pass (fused into integrateColor) is emptied before k_integrate_tsdf appends
   if (reset_esdf_dirty && wg_all == 0 && threadIdx.x < NSH) *shc_at(m, S_LIST_ESDF_DIRTY, threadIdx.x, 0) = 0;
   __syncthreads();
@@ -721,7 +721,7 @@ template <typename T> __device__ inline T in_vgpr(T x) { asm volatile("" : "+v"(
 template <typename Img, typename Sensor, int NB, bool Plain>
 __device__ inline void integrate_tsdf_worker(const DMap& m, const FrameSet<Img, NB>& fs, const Sensor& sensor, const int4* view_list, int32_t list_cap,
                                              int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, const uint8_t* view_class,
-                                             const int32_t wgi, const int32_t n_wg) {
+                                             const int32_t wgi, const int32_t n_wg, const int32_t* dense_list = nullptr) {
   const Frame& f0 = fs.f[0];
   const int tid = threadIdx.x, lane = tid & 63;
   // The view records are taken 64 at a time: lane j of every wavefront fetches the record of the j-th block this workgroup will
@@ -733,13 +733,34 @@ __device__ inline void integrate_tsdf_worker(const DMap& m, const FrameSet<Img, 
   // each of 8 x 1024 wavefronts were 8 MB of HBM traffic for 3.5 MB of work (PMC, profiles/r02z_pmc.json).  A lane the hint left out
   // fetches once the count is known (a dependent load, only when the view grew by more than the hint's margin).
   int32_t mine = wgi + lane * n_wg;
-  int4 rec = (lane < spec_lanes && mine < list_cap) ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
+  int4 rec = (!dense_list && lane < spec_lanes && mine < list_cap) ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
   int32_t n = m.counters[C_VIEW_COUNT + (f0.frame_id & 3)];
   if (n > list_cap) n = list_cap;
-  if (lane >= spec_lanes && mine < n) rec = view_list[mine];
-  // (LiDAR: blocks the beam-centric launch k_lidar_sparse has already updated are skipped here -- their record reads as "no slot")
-  if (view_class && mine < n && view_class[mine]) rec.x = (int32_t)SLOT_NONE;
-  if (wgi == 0 && tid == 192) __hip_atomic_store(&m.host_mirror[2], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // next launch's hint
+  if (wgi == 0 && tid == 192) __hip_atomic_store(&m.host_mirror[2], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // next launch's hint (the VIEW count)
+  // LiDAR behind the beam-centric launch: that launch has left the records it did NOT take as a work list (indices into the view list, one
+  // region per shard) -- this launch deals THOSE out, so every workgroup gets the same number of blocks.  Dealing out the whole view list and
+  // skipping the taken records (60 %) left a workgroup with Binomial(110, 0.4) blocks: 44 +- 5, the slowest of 1024 with ~60.
+  int32_t dpre[NSH + 1];
+  auto dense_at = [&](int32_t k) -> int32_t {          // (selects only: a dynamically indexed dpre[] would live in scratch memory)
+    int sh = 0; int32_t base = 0;
+#pragma unroll
+    for (int q = 1; q < NSH; q++) if (k >= dpre[q]) { sh = q; base = dpre[q]; }
+    return dense_list[(size_t)sh * list_cap + (k - base)];
+  };
+  if (dense_list) {
+    int32_t c[NSH];
+#pragma unroll
+    for (int q = 0; q < NSH; q++) c[q] = *shc_at(m, S_LIDAR_SPARSE, q, 1);
+    dpre[0] = 0;
+#pragma unroll
+    for (int q = 0; q < NSH; q++) dpre[q + 1] = dpre[q] + min(c[q], list_cap);
+    n = dpre[NSH];
+    if (mine < n) rec = view_list[dense_at(mine)];
+  } else {
+    if (lane >= spec_lanes && mine < n) rec = view_list[mine];
+    // (LiDAR without the work list: blocks the beam-centric launch k_lidar_sparse has already updated are skipped -- their record reads as "no slot")
+    if (view_class && mine < n && view_class[mine]) rec.x = (int32_t)SLOT_NONE;
+  }
   // nvbx_set_view_export: the frame's block indices also go to a caller-owned packed buffer [1 + cap][3] (row 0 = count) --
   // the message of the multi-GPU exchange, written here instead of by an export launch
   if (view_export && wgi == 0 && tid == 0) { view_export[0] = min(n, view_export_cap); view_export[1] = 0; view_export[2] = 0; }
@@ -754,8 +775,12 @@ __device__ inline void integrate_tsdf_worker(const DMap& m, const FrameSet<Img, 
   if (Sensor::kLongRays && NB == 1) { fl.cols = in_vgpr(f0.cols); fl.rows = in_vgpr(f0.rows); img0.p = in_vgpr(fs.img[0].p); }
   for (int32_t i0 = wgi; i0 < n; i0 += 64 * n_wg) {
     if (i0 != wgi) {
-      mine = i0 + lane * n_wg; rec = mine < n ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
-      if (view_class && mine < n && view_class[mine]) rec.x = (int32_t)SLOT_NONE;
+      mine = i0 + lane * n_wg;
+      if (dense_list) rec = mine < n ? view_list[dense_at(mine)] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
+      else {
+        rec = mine < n ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
+        if (view_class && mine < n && view_class[mine]) rec.x = (int32_t)SLOT_NONE;
+      }
     }
     if (view_export && tid < 64 && mine < n && mine < view_export_cap) { int32_t* e = view_export + 3 * (1 + (int64_t)mine); e[0] = rec.y; e[1] = rec.z; e[2] = rec.w; }
     float org[3] = {0.0f, 0.0f, 0.0f};
@@ -819,8 +844,9 @@ __device__ inline void integrate_tsdf_worker(const DMap& m, const FrameSet<Img, 
 }
 template <typename Img, typename Sensor, int NB, bool Plain>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_integrate_tsdf(DMap m, FrameSet<Img, NB> fs, Sensor sensor, const int4* view_list, int32_t list_cap,
-                                                        int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, const uint8_t* view_class) {
-  integrate_tsdf_worker<Img, Sensor, NB, Plain>(m, fs, sensor, view_list, list_cap, mesh_list, view_export, view_export_cap, spec_lanes, view_class, (int32_t)blockIdx.x, (int32_t)gridDim.x);
+                                                        int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, const uint8_t* view_class,
+                                                        const int32_t* dense_list) {
+  integrate_tsdf_worker<Img, Sensor, NB, Plain>(m, fs, sensor, view_list, list_cap, mesh_list, view_export, view_export_cap, spec_lanes, view_class, (int32_t)blockIdx.x, (int32_t)gridDim.x, dense_list);
 }
 
 // Pipelined order, fused: TSDF update of frame i + 1, colour integration of frame i (from the candidate records the riders
@@ -892,7 +918,7 @@ int nvbx_mapper::ensure_fuse_buffers() {
 #endif
 template <typename Img>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NVBX_SPARSE_WAVES, NVBX_SPARSE_WAVES))) void k_lidar_sparse(DMap m, FrameSet<Img, 1> fs, LidarSensor sensor, const int4* view_list, int32_t list_cap,
-                                                      int32_t mesh_list, uint8_t* view_class) {
+                                                      int32_t mesh_list, uint8_t* view_class, int32_t* dense_list) {
   // per wavefront: the crossing beams {line in block voxel coordinates ob[3], db[3]; pixel; range; direction[3]; major axis} and the
   // candidate voxels that survive the geometric pre-filter {beam << 9 | voxel}
   __shared__ float s_beam[4][64][12];
@@ -947,13 +973,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NVBX_SPARSE
       }
     }
     const u64 sparse_groups = __ballot(sparse_g);
+    uint32_t dmask = 0;                                                         // records of this pass left to the dense launch (uniform)
 #pragma unroll 1
     for (int j = 0; j < 8; j++) {
     const int32_t i = ridx(pass, j);
     if (i >= n) continue;                                                       // (uniform)
     bool sparse = ((sparse_groups >> (8 * j)) & 1ull) != 0;
-    if (!sparse) { if (lane == 0) view_class[i] = 0; continue; }               // (uniform)
     const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane(rec_g.x, 8 * j);
+    if (!sparse) { if (lane == 0) view_class[i] = 0; if (slot_ok(slot)) dmask |= 1u << j; continue; }               // (uniform)
     const float org[3] = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(org_g[0]), 8 * j)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(org_g[1]), 8 * j)),
                           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(org_g[2]), 8 * j))};
     const int c0 = __builtin_amdgcn_readlane(c0_g, 8 * j), r0 = __builtin_amdgcn_readlane(r0_g, 8 * j), w = __builtin_amdgcn_readlane(w_g, 8 * j), h = __builtin_amdgcn_readlane(h_g, 8 * j);
@@ -981,7 +1008,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NVBX_SPARSE
       }
     }
     if (__ballot(anyq)) sparse = false;
-    if (!sparse) { if (lane == 0) view_class[i] = 0; continue; }               // (uniform)
+    if (!sparse) { if (lane == 0) view_class[i] = 0; dmask |= 1u << j; continue; }               // (uniform)
     // (3) the beams of the footprint that have a return, one per lane: line in block voxel coordinates q = R_LC (P - org) / vs (sensor origin: P = 0)
     float ob[3] = {0.0f, 0.0f, 0.0f}, db[3] = {1.0f, 0.0f, 0.0f};
     const float dir[3] = {te.y * ta.y, te.y * ta.x, te.x};                   // == LidarSensor::beam_dir(brr, bc)
@@ -1045,7 +1072,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NVBX_SPARSE
     }
     if (ns > 512) sparse = false;                             // more survivors than the list holds (dense beams at close range): the dense launch takes the block
     if (lane == 0) view_class[i] = sparse ? 1 : 0;
-    if (!sparse) { __builtin_amdgcn_wave_barrier(); continue; }                // (uniform)
+    if (!sparse) { dmask |= 1u << j; __builtin_amdgcn_wave_barrier(); continue; }                // (uniform)
     // the block's books, as the dense launch keeps them (lane 0; the returning atomic is consumed after the update)
     uint32_t old = 0;
     if (lane == 0) old = atomicOr(&m.slot_flags[slot], F_TSDF | F_DIRTY_ESDF | F_DIRTY_MESH | F_BAND_STALE);
@@ -1086,27 +1113,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NVBX_SPARSE
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
     }
+    // the dense launch's work list: the view-list indices of the records left to it, one reservation per pass in this workgroup's shard
+    if (dense_list && dmask) {
+      const int sh = my_shard();
+      int32_t base0 = 0;
+      if (lane == 0) base0 = atomicAdd(shc_at(m, S_LIDAR_SPARSE, sh, 1), (int32_t)__popc(dmask));
+      base0 = __shfl(base0, 0);
+      if (lane < 8 && ((dmask >> lane) & 1u)) {
+        const int32_t pos = base0 + (int32_t)__popc(dmask & ((1u << lane) - 1u));
+        if (pos < list_cap) dense_list[(size_t)sh * list_cap + pos] = ridx(pass, lane);
+      }
+    }
   }
   if (lane == 0 && n_mine) atomicAdd(shc_at(m, S_LIDAR_SPARSE, my_shard(), 0), n_mine);
 }
 
 // the beam-centric far-field launch (LiDAR only); view_class = nullptr: everything goes to the dense launch
 template <typename Img, typename Sensor, int NB>
-static int launch_lidar_sparse(nvbx_mapper*, const FrameSet<Img, NB>&, const Sensor&, bool, uint8_t** view_class) { *view_class = nullptr; return NVBX_OK; }
+static int launch_lidar_sparse(nvbx_mapper*, const FrameSet<Img, NB>&, const Sensor&, bool, uint8_t** view_class, int32_t** dense_list) { *view_class = nullptr; *dense_list = nullptr; return NVBX_OK; }
 template <typename Img>
-static int launch_lidar_sparse(nvbx_mapper* m, const FrameSet<Img, 1>& fs, const LidarSensor& sensor, bool plain, uint8_t** view_class) {
-  *view_class = nullptr;
+static int launch_lidar_sparse(nvbx_mapper* m, const FrameSet<Img, 1>& fs, const LidarSensor& sensor, bool plain, uint8_t** view_class, int32_t** dense_list) {
+  *view_class = nullptr; *dense_list = nullptr;
   static const int enabled = getenv("NVBX_LIDAR_SPARSE") ? atoi(getenv("NVBX_LIDAR_SPARSE")) : 1;       // (A/B: 0 = dense launch only)
   if (!enabled || !plain || !(m->p.lidar_nearest_interpolation_max_allowable_dist_to_ray_vox <= 0.55f)) return NVBX_OK;
   if (m->view_class_cap < m->capacity) {
     NVBX_HIP(hipStreamSynchronize(m->stream));
     if (m->view_class) NVBX_HIP(hipFree(m->view_class));
     m->view_class = nullptr; m->view_class_cap = 0;
-    NVBX_HIP(hipMalloc(&m->view_class, (size_t)m->capacity));
+    // [capacity class bytes][NSH x capacity view-list indices: the dense launch's work list, one region per shard]
+    NVBX_HIP(hipMalloc(&m->view_class, (((size_t)m->capacity + 15) & ~(size_t)15) + (size_t)NSH * (size_t)m->capacity * 4));
     m->view_class_cap = m->capacity;
   }
   static const int sparse_grid = getenv("NVBX_LIDAR_SPARSE_GRID") ? atoi(getenv("NVBX_LIDAR_SPARSE_GRID")) : 4096;    // (6 resident wavefronts per SIMD; 1536 / 3072 / 6144 workgroups: 100.8 / 98.9 / 94.8 us -- short work items balance better)
-  NVBX_LAUNCH(m, (k_lidar_sparse<Img>), dim3(sparse_grid), dim3(256), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, m->mesh_list_live(), m->view_class);
+  // (with an exchange buffer registered -- nvbx_set_view_export -- the dense launch walks the whole view list, as it writes every record's index there)
+  static const int use_list = getenv("NVBX_LIDAR_DENSE_LIST") ? atoi(getenv("NVBX_LIDAR_DENSE_LIST")) : 1;       // (A/B: 0 = the dense launch skips the taken records of the whole list)
+  int32_t* dense = (use_list && !m->view_export) ? reinterpret_cast<int32_t*>(m->view_class + (((size_t)m->capacity + 15) & ~(size_t)15)) : nullptr;
+  NVBX_LAUNCH(m, (k_lidar_sparse<Img>), dim3(sparse_grid), dim3(256), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, m->mesh_list_live(), m->view_class, dense);
+  *dense_list = dense;
   *view_class = m->view_class;
   return NVBX_OK;
 }
@@ -1195,8 +1238,8 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   const int64_t want = n_hint == 0 ? (int64_t)grid_cap : ((n_hint + n_hint / 4 + 64 + 7) / 8) * 8;
   const int grid = (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, grid_cap), want));
   const int32_t spec_lanes = (int32_t)std::min<int64_t>(64, (n_hint + n_hint / 4 + 64 + grid - 1) / grid);
-  uint8_t* view_class = nullptr;
-  { const int rc = launch_lidar_sparse(m, fs, sensor, plain, &view_class); if (rc) return rc; }
+  uint8_t* view_class = nullptr; int32_t* dense_list = nullptr;
+  { const int rc = launch_lidar_sparse(m, fs, sensor, plain, &view_class, &dense_list); if (rc) return rc; }
   if (Sensor::kLongRays && m->p.projective_layer_type != 1) m->lidar_integrated = true;      // (blocks may be F_BAND_STALE from here on)
   if (fused) {
     if constexpr (Sensor::kThreads == 256) {
@@ -1229,9 +1272,9 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
     }
   } else
   if (plain) NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor, NB, true>), dim3(grid), dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
-                         m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (const uint8_t*)view_class);
+                         m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (const uint8_t*)view_class, (const int32_t*)dense_list);
   else NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor, NB, false>), dim3(grid), dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
-                   m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (const uint8_t*)view_class);
+                   m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (const uint8_t*)view_class, (const int32_t*)dense_list);
   NVBX_HIP(hipGetLastError());
   m->last_view_frame = m->frame_id;
   if (!Sensor::kLongRays) { m->last_camera_view_frame = m->frame_id; m->last_camera_view_mask = 1u << (fs.n - 1); }   // (a batch: the LAST camera's view, as separate calls would leave it)
