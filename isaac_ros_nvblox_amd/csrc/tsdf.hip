@@ -103,8 +103,8 @@ struct LidarSensor {
   // ray subsampling 2, us per scan): 4x4 rays x 4 segments 155 | 2x4x8 113 | 2x2x16 82 | 1x4x16 74 | 1x2x32 75 | 1x1x64 111.
 #ifndef NVBX_LIDAR_TR
 #define NVBX_LIDAR_TR 1
-#define NVBX_LIDAR_TC 4
-#define NVBX_LIDAR_SEG 16
+#define NVBX_LIDAR_TC 2
+#define NVBX_LIDAR_SEG 32
 #endif
   static constexpr int kTileRows = NVBX_LIDAR_TR, kTileCols = NVBX_LIDAR_TC;      // (tuning knobs: tools/lidar_tile_sweep.sh)
 #ifndef NVBX_LIDAR_FR
