@@ -1250,7 +1250,8 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
       const int4* cand = tr.cand;
       const int32_t cand_idx = tr.cand_cnt_idx;
       const int64_t c_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[3], __ATOMIC_RELAXED));         // candidates of the last colour frame the GPU has finished
-      const int cgrid = !has_color ? 0 : (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, 1024), ((c_hint + c_hint / 4 + 64 + 7) / 8) * 8));      // (no colour frame: update + distance transform only)
+      // (no colour frame: update + distance transform only; no colour launch finished yet -- a new or just cleared map: as many as the TSDF part)
+      const int cgrid = !has_color ? 0 : (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, 1024), c_hint == 0 ? (int64_t)grid : ((c_hint + c_hint / 4 + 64 + 7) / 8) * 8));
       // a held-back union step of the multi-GPU exchange (nvbx_mark_esdf_dirty_gathered_deferred) rides here in eight workgroups: the peers'
       // blocks become ESDF-dirty for the NEXT marking pass (its own marking launch, or a ride in the colour launch, would be a third launch;
       // beside this frame's view marking it would meet blocks that launch is just allocating -- DESIGN.md 6.1)
