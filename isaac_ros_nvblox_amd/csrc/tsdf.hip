@@ -1144,7 +1144,7 @@ static int launch_lidar_sparse(nvbx_mapper* m, const FrameSet<Img, 1>& fs, const
     NVBX_HIP(hipMalloc(&m->view_class, (((size_t)m->capacity + 15) & ~(size_t)15) + (size_t)NSH * (size_t)m->capacity * 4));
     m->view_class_cap = m->capacity;
   }
-  static const int sparse_grid = getenv("NVBX_LIDAR_SPARSE_GRID") ? atoi(getenv("NVBX_LIDAR_SPARSE_GRID")) : 4096;    // (6 resident wavefronts per SIMD; 1536 / 3072 / 6144 workgroups: 100.8 / 98.9 / 94.8 us -- short work items balance better)
+  static const int sparse_grid = getenv("NVBX_LIDAR_SPARSE_GRID") ? atoi(getenv("NVBX_LIDAR_SPARSE_GRID")) : 2048;    // (six resident wavefronts per SIMD = 1536 workgroups; 1536 / 2048 / 2560 / 3072 / 3584 / 4096 / 8192 workgroups: 111.1 / 109.5 / 110.5 / 111.0 / 114.8 / 115.3 / 114.3 us with strided passes and the work list)
   // (with an exchange buffer registered -- nvbx_set_view_export -- the dense launch walks the whole view list, as it writes every record's index there)
   static const int use_list = getenv("NVBX_LIDAR_DENSE_LIST") ? atoi(getenv("NVBX_LIDAR_DENSE_LIST")) : 1;       // (A/B: 0 = the dense launch skips the taken records of the whole list)
   int32_t* dense = (use_list && !m->view_export) ? reinterpret_cast<int32_t*>(m->view_class + (((size_t)m->capacity + 15) & ~(size_t)15)) : nullptr;
