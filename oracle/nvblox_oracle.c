@@ -47,6 +47,9 @@
  *   csrc/nvbx_lidar_math.h   LiDAR projection (asin / atan2 polynomials)          tests/lidar_independent.py: float64 numpy + libm, 5e5 points (tests/test_independent_checks.py, tests/test_lidar.py)
  *   csrc/nvbx_motion_math.h  pose interpolation of the motion compensation      tests/motion_independent.py: float64 numpy + scipy.Rotation, 2.4e5 points against this file, 3e5 against the kernel (tests/test_lidar.py)
  *   mc_table*.inc            marching-cubes tables (tools/gen_mc_table.py)        brute-force sign topology of all 256 cases, crack census over the 4096 two-cube configurations (tests/test_independent_checks.py)
+ * A DEFINITION shared with the product rather than source: the view calculation's crossing parameters in closed form (raycast_blocks below <->
+ * csrc/tsdf.hip dda_step) -- checked against float64 segment / grid-plane geometry without any stepping, tests/view_independent.py
+ * (tests/test_independent_checks.py::test_view_calculation_against_float64_geometry).
  * (csrc/nvbx_arith.h is NOT used here: this file keeps `/` and sqrtf; the kernel's shortened sequences are compared with numpy's IEEE results, tests/test_gpu_arith.py.) */
 #include "../isaac_ros_nvblox_amd/csrc/nvbx_lidar_math.h"
 #include "../isaac_ros_nvblox_amd/csrc/nvbx_motion_math.h"

@@ -274,3 +274,27 @@ def test_lidar_measurement_model_against_independent_numpy_restatement():
         for b in (0, 1, 2):
             seen[b] += int((ref["branch"][robust] == b).sum())
     assert total >= 500000 and min(seen.values()) > 20000, (total, seen)
+
+
+def test_view_calculation_against_float64_geometry(oracle_mod):
+    """The blocks in view of a camera frame (oracle: float32 Amanatides-Woo with closed-form crossing parameters -- what the HIP view marking
+    reproduces bit for bit, tests/test_gpu_parity.py) against tests/view_independent.py: float64 segment / grid-plane geometry, no stepping.
+    Two-sided with a margin for rays that graze a block: crossed over more than 1e-3 of a block => in view; in view => within 1e-3 of a ray."""
+    import helpers as H
+    import view_independent as V
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    for k, (d, _, T) in enumerate(H.frames(3, cam, stride=23, color=False)):
+        # (the last setting: 1 cm voxels = 8 cm blocks, i.e. rays of up to ~90 steps -- the regime of a 200 m LiDAR ray at 0.8 m blocks)
+        for sub, maxd, vs in ((4, 7.0, 0.05), (1, 3.0, 0.05), (8, 7.0, 0.01)):
+            p = H.copy_params(M.default_params(raycast_subsampling_factor=sub, max_integration_distance_m=maxd, voxel_size=vs), oracle_mod.OrcParams)
+            o = oracle_mod.OracleMap(p)
+            o.integrate_depth(d, T, cam)
+            view = {tuple(int(v) for v in r) for r in np.asarray(o.last_view())}
+            org, ends = V.camera_rays(d, T, cam, p.voxel_size, p.truncation_distance_vox, p.max_integration_distance_m, sub)
+            bs = p.voxel_size * 8.0
+            must = V.blocks_crossed(org, ends, bs, 1e-3)
+            assert len(must) > 100 and must <= view, (k, sub, len(must), len(view), sorted(must - view)[:5])
+            extra = sorted(view - V.blocks_crossed(org, ends, bs, 0.0))
+            assert len(extra) <= len(view) // 50, (len(extra), len(view))          # (grazed blocks only: a few per frame)
+            assert all(V.near_some_ray(extra, org, ends, bs, 1e-3)), (k, sub, extra[:5])
