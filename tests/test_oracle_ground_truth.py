@@ -280,3 +280,38 @@ def test_esdf_3d_oracle_equals_bruteforce(oracle_mod):
         best = np.minimum(best, ((sub[:, None, :] - pts[None, s0:s0 + 4000, :]) ** 2).sum(-1).min(1))
     want = np.where(best <= 100.0, best, 100.0).astype(np.float32)
     assert np.array_equal(sq[sub[:, 0], sub[:, 1], sub[:, 2]], want)
+
+
+def test_colour_close_to_the_analytic_checker_pattern(mapped, oracle_mod):
+    """The synthetic scene is painted with a checker of 12.5 cm cells per channel (r / g / b = 64 or 192 by the parity of the cell along x / y / z,
+    isaac_ros_nvblox_amd/synthetic.py render): after ten
+    colour frames a coloured voxel next to the surface must carry the colour of the checker cell the SURFACE POINT under it lies in -- wherever
+    that point is well inside its cell (away from cell borders the bilinear colour tap and the view-to-view blend cannot mix the two greys).
+    Independent of the colour integrator's arithmetic: the expectation is the scene's own colour function at the analytic closest surface point."""
+    o, _ = mapped
+    vs = 0.05
+    sc = S.Scene()
+    n = 0; bad = 0; n_dark = 0
+    for idx in o.block_indices(oracle_mod.L_COLOR):
+        c = o.get_block(oracle_mod.L_COLOR, idx).reshape(8, 8, 8)
+        t = o.get_block(oracle_mod.L_TSDF, idx).reshape(8, 8, 8)
+        gx, gy, gz = np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij")
+        p = (np.stack([gx, gy, gz], -1) + idx * 8 + 0.5) * vs
+        sel = (c["weight"] > 0.0) & (t["weight"] >= 1.0) & (np.abs(t["distance"]) < 0.6 * vs)
+        if not sel.any():
+            continue
+        ps = p[sel]
+        # the closest surface point by the analytic SDF's gradient (central differences in float64), then the checker cell it lies in
+        eps = 1e-4
+        g = np.stack([(scene_sdf(ps + np.eye(3)[a] * eps) - scene_sdf(ps - np.eye(3)[a] * eps)) / (2 * eps) for a in range(3)], -1)
+        q = ps - g * scene_sdf(ps)[:, None]
+        cell = 8.0 * q + 0.37
+        inside = np.abs(cell - np.round(cell)).min(axis=-1) > 0.3          # > 0.3 cells = 3.75 cm from every cell border (a voxel is 5 cm, a pixel ~2 cm)
+        smooth = np.abs(np.linalg.norm(g, axis=-1) - 1.0) < 1e-3            # (not on an edge / corner of the scene, where the closest point jumps)
+        want = np.where((np.floor(cell).astype(np.int64) & 1) == 1, 192, 64)
+        got = np.stack([c["r"][sel], c["g"][sel], c["b"][sel]], -1).astype(np.int64)
+        k = inside & smooth
+        n += int(k.sum()); n_dark += int((want[k] == 64).sum())
+        bad += int((np.abs(got[k] - want[k]).max(axis=-1) > 40).sum())
+    assert n > 1500 and 0.3 * 3 * n < n_dark < 0.7 * 3 * n, (n, n_dark)        # (the checker is per channel and axis: both greys are well represented)
+    assert bad <= 0.03 * n, (bad, n)                  # (voxels seen only at grazing angles keep a tap from the neighbouring cell)
