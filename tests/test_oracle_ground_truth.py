@@ -315,3 +315,25 @@ def test_colour_close_to_the_analytic_checker_pattern(mapped, oracle_mod):
         bad += int((np.abs(got[k] - want[k]).max(axis=-1) > 40).sum())
     assert n > 1500 and 0.3 * 3 * n < n_dark < 0.7 * 3 * n, (n, n_dark)        # (the checker is per channel and axis: both greys are well represented)
     assert bad <= 0.03 * n, (bad, n)                  # (voxels seen only at grazing angles keep a tap from the neighbouring cell)
+
+
+def test_synthetic_depth_of_the_sphere_tracer_close_to_the_analytic_depth(oracle_mod):
+    """integrateColor's occlusion test sphere-traces the TSDF at a quarter of the resolution: where a ray hits, its depth must be the analytic
+    depth of the scene along that pixel's ray (the renderer's own ray casting, float64) to within a voxel or so -- the TSDF is projective and
+    the tracer stops within 0.1 voxel of the zero crossing of a nearest-voxel field.  Independent of the tracer's stepping."""
+    cam = H.SMALL_CAM
+    o = oracle_mod.OracleMap(oracle_mod.default_params())
+    fr = H.frames(6, cam, color=True, stride=9)
+    for d, rgb, T in fr:
+        o.integrate_depth(d, T, cam)
+    d, rgb, T = fr[-1]
+    o.integrate_color(rgb, T, cam)
+    synth = np.asarray(o.synthetic_depth())
+    sub = 4
+    assert synth.shape == (cam[5] // sub, cam[4] // sub)
+    # the tracer's ray of synthetic pixel (r, c) goes through the centre of full-resolution pixel (r * sub, c * sub)
+    true = d[::sub, ::sub][: synth.shape[0], : synth.shape[1]].astype(np.float64)
+    hit = synth > 0.0
+    assert hit.mean() > 0.6
+    err = np.abs(synth[hit] - true[hit])
+    assert np.median(err) < 0.5 * 0.05 and np.percentile(err, 95) < 2.0 * 0.05, (np.median(err), np.percentile(err, 95))
