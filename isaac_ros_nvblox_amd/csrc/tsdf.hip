@@ -914,7 +914,7 @@ int nvbx_mapper::ensure_fuse_buffers() {
 // The class of every record (1 = updated here) goes to view_class[]; the dense launch that follows skips those.  Requires the plain integrator
 // configuration (constant weighting, TSDF) and a nearest-beam acceptance radius <= 0.55 voxel (the 2 x 2 argument); the host falls back otherwise.
 #ifndef NVBX_SPARSE_WAVES
-#define NVBX_SPARSE_WAVES 6      // (81 VGPRs were one register away from six wavefronts per SIMD: 5 / 6 / 8 asked for = 116.6 / 110.0 / 114.4 us)
+#define NVBX_SPARSE_WAVES 6      // (81 VGPRs were one register away from six wavefronts per SIMD: 5 / 6 / 7 / 8 asked for = 116.6 / 110.0 / 111.1 / 114.4 us)
 #endif
 template <typename Img>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NVBX_SPARSE_WAVES, NVBX_SPARSE_WAVES))) void k_lidar_sparse(DMap m, FrameSet<Img, 1> fs, LidarSensor sensor, const int4* view_list, int32_t list_cap,
