@@ -89,7 +89,7 @@ def algorithmic_bytes(kernel, c, rows, cols, sub_ray=4, sub_trace=4, n_cam=1, tr
     if kernel.startswith("k_detect_dynamics") or kernel.startswith("k_split_depth") or kernel.startswith("k_mask_zmin"):
         return rows * cols * (4 + 4 + 1)
     if kernel.startswith("k_stage_color"):
-        return n_cam * rows * cols * 3 * 2               # the held-back colour image(s) copied into the mapper's staging memory: read + written
+        return 0                 # OVERHEAD, not algorithm (SURVEY 8d has no such term): overhead_bytes() below; absent when the images live in library frames
     if kernel.startswith("k_dyn_detect_union"):
         return rows * cols * (4 + 1 + 4 + 4)          # depth read, mask written, label + nearest-depth images touched
     if kernel.startswith("k_dyn_filter_split"):
@@ -99,6 +99,20 @@ def algorithmic_bytes(kernel, c, rows, cols, sub_ray=4, sub_trace=4, n_cam=1, tr
     if kernel.startswith("k_save_stamps") or kernel.startswith("k_reinsert"):
         return Na * 32
     return 0
+
+
+def overhead_bytes(kernel, rows, cols, n_cam=1):
+    """Bytes a launch moves that SURVEY 8d's formulas do not contain: the staged form's copy of raw-pointer colour images (read + written)."""
+    return n_cam * rows * cols * 3 * 2 if kernel.startswith("k_stage_color") else 0
+
+
+def pmc_source():
+    """Where `traffic` comes from: the committed table of the last PMC passes (never measured inside this run: counters need rocprofv3)."""
+    try:
+        meta = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get("_meta", {})
+    except Exception:
+        meta = {}
+    return "profiles/pmc_latest.json@%s (%s)" % (meta.get("commit", "unknown"), meta.get("tag", "?"))
 
 
 def load_pmc(workload):
@@ -614,6 +628,137 @@ def main_decay(args):
     print(json.dumps(out))
 
 
+
+# ====================================================================================================== node cadence (the node's shape, not the fuser's)
+def main_node(args):
+    """One simulated second of NvbloxNode::tick() at the rates of nvblox_base.yaml:13-23: 40 depth frames, 5 colour frames, 10 updateEsdf each followed at
+    once by the distance-slice query (processEsdf -> sliceAndPublishEsdf, nvblox_node.cpp:774-889: the slice is downloaded, so every ESDF tick drains the
+    pipeline and waits), 5 updateColorMesh, 5 decayTsdfExcludeLastView, 1 clearOutsideRadius(7 m) -- in tick() order (depth, colour, ESDF, mesh, decay,
+    clearing: nvblox_node.cpp:582-678) on the ticks where their periods coincide.  A block of `steps` = 40 depth slots is one simulated second; five seconds
+    walk the 200-pose loop once.  Reported: GPU + host milliseconds per simulated second, launches per depth slot, drains per second, and per README tag the
+    time a timing::Timer around the call reads as called (under deferral held-back work is not in it) and ATTRIBUTED (classic order, each call waited for)."""
+    from isaac_ros_nvblox_amd import mapper as M, synthetic as S
+    torch, dist, rank, world, local_rank, dev = init_dist(args)
+    assert world == 1, "the node-cadence line is single-GPU"
+    cam = S.REPLICA_LIKE_CAM; rows, cols = cam[5], cam[4]
+    scene = S.Scene(); nu = 200
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(i):
+        T = S.trajectory_pose(i, 200); d, rgb = S.render(scene, T, cam); return (d, rgb, T)
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as pool:
+        host = list(pool.map(one, range(nu)))
+    stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream)
+    g = M.Mapper(M.default_params(), device=local_rank, block_capacity=1 << 14, stream=stream.cuda_stream)
+    depth_dev = [torch.from_numpy(d).to(dev) for d, _, _ in host]
+    rgb_frames = [M.ColorFrame(rows, cols, 3, local_rank).write(torch.from_numpy(c).to(dev), stream.cuda_stream) for _, c, _ in host]
+    dargs = [g.prepare_depth(depth_dev[k], host[k][2], cam) for k in range(nu)]
+    cargs = [g.prepare_color(rgb_frames[k], host[k][2], cam) for k in range(nu)]
+    torch.cuda.synchronize(dev)
+    SLOTS = 40; RADIUS = 7.0
+    tags = ("tsdf/integrate", "color/integrate", "esdf/integrate", "esdf/slice", "mesh/integrate", "decay", "clear_outside_radius")
+    acc = {t: [0.0, 0] for t in tags}
+    timing_on = [False]; wait_each = [False]
+
+    def call(tag, fn):
+        if not timing_on[0]:
+            return fn()
+        t = time.perf_counter(); r = fn()
+        if wait_each[0]:
+            g.synchronize()
+        a = acc[tag]; a[0] += (time.perf_counter() - t) * 1e3; a[1] += 1
+        return r
+
+    def slot(i):
+        k = i % nu; s = i % SLOTS
+        call("tsdf/integrate", lambda: g.integrate_prepared(dargs[k]))
+        if s % 8 == 0:
+            call("color/integrate", lambda: g.integrate_prepared(cargs[k]))
+        if s % 4 == 0:
+            call("esdf/integrate", g.update_esdf)
+            call("esdf/slice", g.esdf_slice_image)            # -> host, as the node publishes it: drains and waits
+        if s % 8 == 0:
+            call("mesh/integrate", g.update_color_mesh)
+            call("decay", lambda: g.decay_tsdf(True))
+        if s == 0:
+            T = host[k][2]
+            call("clear_outside_radius", lambda: g.clear_outside_radius((float(T[0, 3]), float(T[1, 3]), float(T[2, 3])), RADIUS))
+
+    def barrier():
+        g.synchronize(); torch.cuda.synchronize(dev)
+
+    def fresh():
+        if fresh.pos == 0:
+            g.clear()
+        fresh.pos = (fresh.pos + SLOTS) % nu
+    fresh.pos = 0
+    tm = Timer(torch, dist, dev, world)
+    dt, dts, base = tm.run(slot, barrier, SLOTS, SLOTS, before_block=fresh)
+    ms_second = float(np.mean(dts)) * 1e3
+    # per-tag host timers: as called (deferral as shipped), then attributed (classic order, every call waited for)
+    def tag_pass(classic):
+        for t in tags:
+            acc[t] = [0.0, 0]
+        g.set_color_deferral(not classic, staged=True); wait_each[0] = classic
+        g.clear(); barrier(); timing_on[0] = True
+        for i in range(nu):
+            slot(i)
+        barrier(); timing_on[0] = False; wait_each[0] = False
+        return {t: {"ms_per_call": round(a[0] / max(1, a[1]), 4), "calls_per_second": a[1] / (nu / SLOTS), "ms_per_second": round(a[0] / (nu / SLOTS), 4)} for t, a in acc.items()}
+    as_called = tag_pass(False)
+    attributed = tag_pass(True)
+    g.set_color_deferral(True, staged=True)
+    # launches per slot / drains per second from the library's own spans
+    g.clear(); barrier(); g.set_profiling(True)
+    for i in range(nu):
+        slot(i)
+    prof = g.profile(); g.set_profiling(False); prof.pop("_empty_event_pair", None)
+    launches = sum(v["count"] for v in prof.values())
+    drains = sum(v["count"] for k_, v in prof.items() if short(k_).startswith("k_sphere_trace"))      # (a replay outside the pipeline launches the tracing on its own)
+    kern = {short(k_): {"launches_per_second": round(v["count"] / (nu / SLOTS), 2), "ms_per_second": round(v["total_ms"] / (nu / SLOTS), 4)} for k_, v in prof.items()}
+    parity = None
+    if not args.no_parity:
+        import oracle
+        oracle.set_num_threads(min(8, os.cpu_count() or 1))
+        o = oracle.OracleMap(copy_params(oracle, g.params))
+        g.clear()
+        slices_equal = True
+        for i in range(nu):
+            k = i % nu; s = i % SLOTS; d, c_, T = host[k]
+            slot(i)
+            o.integrate_depth(d, T, cam)
+            if s % 8 == 0:
+                o.integrate_color(c_, T, cam)
+            if s % 4 == 0:
+                o.update_esdf()
+                if s % 20 == 0:
+                    sg, _ = g.esdf_slice_image(); so, _ = o.esdf_slice_image()
+                    slices_equal = slices_equal and sg.shape == so.shape and float(np.abs(sg - so).max()) <= 1e-4
+            if s % 8 == 0:
+                o.update_mesh(); o.decay_tsdf(True)
+            if s == 0:
+                o.clear_outside_radius((float(T[0, 3]), float(T[1, 3]), float(T[2, 3])), RADIUS)
+        g.update_esdf(); o.update_esdf()
+        parity = map_parity(M, g, o, oracle)
+        parity["slices_along_the_way_equal"] = bool(slices_equal); parity["ok"] = bool(parity["ok"] and slices_equal)
+        parity["what"] = "the five simulated seconds once more, every call mirrored on oracle/nvblox_oracle.c; outside the timed region"
+    out = {"metric": "depth frames/s at the node's call cadence (nvblox_base.yaml:13-23), synthetic Replica-like 640x480 @0.05m", "value": round(SLOTS / (ms_second * 1e-3), 2),
+           "unit": "frames/s", "n_gpus": 1, "steps": SLOTS, "warmup": SLOTS, "repeats": len(dts), "ms_per_step": round(ms_second / SLOTS, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "node cadence: per simulated second 40 integrateDepth, 5 integrateColor, 10 updateEsdf + distance-slice download, 5 updateColorMesh, "
+                                  "5 decayTsdfExcludeLastView, 1 clearOutsideRadius(7 m), in NvbloxNode::tick() order; 200-pose loop = 5 s, map emptied per loop",
+                      "mode": "a new mapper's default (colour deferral, images in library frames)"},
+           "ms_per_simulated_second": round(ms_second, 4), "gpu_utilisation_at_real_time": round(ms_second / 1000.0, 6),
+           "launches_per_depth_slot": round(launches / nu, 3), "drains_per_second": round(drains / (nu / SLOTS), 2),
+           "tags_as_called": as_called, "tags_attributed": attributed,
+           "tags_note": "as_called: host timer around each call under the default deferral -- color/integrate and esdf/integrate read the ENQUEUE time only, their "
+                        "kernels run inside the next tsdf/integrate or the next query (esdf/slice pays for the drain); attributed: classic launch order with a wait "
+                        "after every call -- what the README's per-tag timers mean (README.md:69-97)",
+           "kernels": kern, "readme_rtx5090_ms": README_RTX5090_MS, "parity": parity, "block_ms": [round(d * 1e3, 4) for d in dts[:16]]}
+    print(json.dumps(out))
+    finish_dist(dist, world)
+
+
 # ====================================================================================================== camera / multicam
 def main_camera(args):
     from isaac_ros_nvblox_amd import mapper as M, synthetic as S
@@ -659,14 +804,25 @@ def main_camera(args):
     mf = PipelinedMeasurementFusion(1024, dev) if fuse else None
     mf_prev = [None]
 
+    # Where the resident colour images live (the depth images and the raw colour tensors are torch allocations):
+    #   "frames" (default): in library-owned device frames (nvbx_frame_acquire, include/nvblox_hip.h) -- what the device memory of an
+    #     nvblox::Image<Color> IS in the facade, i.e. where the node's colour conversion writes (nvblox_node.cpp:1237-1263).  A mapper that holds
+    #     integrateColor back retains such a frame instead of copying it: no k_stage_color launch.
+    #   "staged" (--staged-deferral): raw device pointers, the mapper copies each held-back image into a frame of its own (round 4's default line)
+    #   "zero_copy" (--zero-copy-deferral): raw device pointers under the caller's contract (nvbx_mapper_set_color_deferral(m, 1))
+    cform = "zero_copy" if args.zero_copy_deferral else ("staged" if args.staged_deferral else "frames")
+    rgb_frames = [[M.ColorFrame(rows, cols, 3, local_rank).write(t, stream.cuda_stream) for t in fr] for fr in rgb_dev]
     dargs = [[g.prepare_depth(depth_dev[ci][k], poses[ci][k], cam) for k in range(nu)] for ci in range(len(host_cams))]
-    cargs = [[g.prepare_color(rgb_dev[ci][k], poses[ci][k], cam) for k in range(nu)] for ci in range(len(host_cams))]
+    cargs_raw = [[g.prepare_color(rgb_dev[ci][k], poses[ci][k], cam) for k in range(nu)] for ci in range(len(host_cams))]
+    cargs_frames = [[g.prepare_color(rgb_frames[ci][k], poses[ci][k], cam) for k in range(nu)] for ci in range(len(host_cams))]
     batch_ok = hasattr(g, "integrate_depth_batch")
-    bd = {}; bc = {}
+    bd = {}; bc_raw = {}; bc_frames = {}
     if multicam and batch_ok:
         for n_ in (1, 2, 4, 8):
             bd[n_] = [g.prepare_depth_batch([depth_dev[ci][k] for ci in range(n_)], [poses[ci][k] for ci in range(n_)], cam) for k in range(nu)]
-            bc[n_] = [g.prepare_color_batch([rgb_dev[ci][k] for ci in range(n_)], [poses[ci][k] for ci in range(n_)], cam) for k in range(nu)]
+            bc_raw[n_] = [g.prepare_color_batch([rgb_dev[ci][k] for ci in range(n_)], [poses[ci][k] for ci in range(n_)], cam) for k in range(nu)]
+            bc_frames[n_] = [g.prepare_color_batch([rgb_frames[ci][k] for ci in range(n_)], [poses[ci][k] for ci in range(n_)], cam) for k in range(nu)]
+    csel = [cargs_frames if cform == "frames" else cargs_raw, bc_frames if cform == "frames" else bc_raw]      # (switched for the other forms' figures below)
 
     def step(i, mesh=False, exchange=True, n=None, batched=None):
         n = ncam if n is None else n
@@ -682,7 +838,7 @@ def main_camera(args):
             done = mf.finish_previous(g)
             kp, mf_prev[0] = mf_prev[0], k
             if done:
-                g.integrate_prepared(cargs[0][kp]); g.update_esdf()
+                g.integrate_prepared(csel[0][0][kp]); g.update_esdf()
             return
         elif use_batch:
             g.integrate_prepared_batch(bd[n][k])     # n cameras' depth frames: ONE view-marking launch + ONE TSDF-update launch
@@ -693,10 +849,10 @@ def main_camera(args):
             xg.start(g)                          # dirty block indices: export + async RCCL all-gather (needs only the depth pass)
             xg.finish_previous(g, deferred=True) # join the PREVIOUS frame's all-gather; its union step rides in the colour launch below
         if use_batch:
-            g.integrate_prepared_batch(bc[n][k])
+            g.integrate_prepared_batch(csel[1][n][k])
         else:
             for ci in range(n):
-                g.integrate_prepared(cargs[ci][k])   # MultiMapper::integrateColor (+ marking of own and peers' dirty blocks)
+                g.integrate_prepared(csel[0][ci][k])   # MultiMapper::integrateColor (+ marking of own and peers' dirty blocks)
         g.update_esdf()                          # MultiMapper::updateEsdf
         if mesh:
             g.update_color_mesh()
@@ -707,7 +863,7 @@ def main_camera(args):
             g.set_view_export(None)
         if mf is not None and mf_prev[0] is not None:
             for _ in range(mf.drain(g)):     # the frame still on its way: gathered, applied, coloured, swept -- inside the timed region
-                g.integrate_prepared(cargs[0][mf_prev[0]]); g.update_esdf()
+                g.integrate_prepared(csel[0][0][mf_prev[0]]); g.update_esdf()
             mf_prev[0] = None
         g.synchronize()          # launches anything the mapper holds back (the EDT of the last updateEsdf) and waits for its stream
         torch.cuda.synchronize(dev)
@@ -726,7 +882,7 @@ def main_camera(args):
     deferral = (world == 1 or not fuse) and not args.no_color_deferral and ((not multicam) or (batch_ok and ncam in bd))
     # the form: STAGED (the default of a new mapper -- what a host gets that only swaps the library; one copy launch per colour frame) or, with
     # --zero-copy-deferral, the opt-in form without the copy (the caller keeps the colour image unchanged until its next call: the bench's are resident)
-    staged = deferral and not args.zero_copy_deferral
+    staged = deferral and not args.zero_copy_deferral          # (frames / staged: the mapper's default setting, nvbx_mapper_set_color_deferral(m, 2))
     g.set_color_deferral(deferral, staged=staged)
 
     # EXPLORING (the headline): the map is EMPTIED at the start of every loop over the nu unique poses and the timed blocks of K steps tile the
@@ -756,7 +912,7 @@ def main_camera(args):
         step(base + i)
     dt_rev, dts_rev, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 4, first=base + nu)
     ms_revisit = dt_rev / args.steps * 1e3
-    ms_classic = None; ms_classic_exploring = None; ms_other_form = None
+    ms_classic = None; ms_classic_exploring = None; ms_forms = {}
     if deferral and not args.profile_run:    # the same revisit blocks in the classic launch order, for the record
         g.set_color_deferral(False)
         dt_c, dts_c, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 4, first=base)
@@ -766,10 +922,17 @@ def main_camera(args):
         dt_ce, dts_ce, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 2, before_block=fresh_map, first=0)
         _, _, whole_c, kept_c = complete_loops(tags[n_tags0:], dts_ce, nu, args.steps)
         ms_classic_exploring = float(np.sum(kept_c)) / len(kept_c) / args.steps * 1e3
-        # ... and in the OTHER form of the deferral (zero-copy when the line is the staged default, staged when it was asked to be zero-copy)
-        g.set_color_deferral(True, staged=not staged)
-        dt_s, dts_s, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 4, first=base)
-        ms_other_form = dt_s / args.steps * 1e3
+        # ... and in the OTHER forms of the deferral (revisit blocks): images in library frames / raw pointers staged / raw pointers zero-copy
+        ms_forms = {}
+        keep_sel = list(csel)
+        for form_ in ("frames", "staged", "zero_copy"):
+            if form_ == cform:
+                continue
+            csel[0], csel[1] = (cargs_frames, bc_frames) if form_ == "frames" else (cargs_raw, bc_raw)
+            g.set_color_deferral(True, staged=form_ != "zero_copy")
+            dt_s, dts_s, base = tm.run(step, barrier, args.steps, 0, min_ms=MIN_TIMED_MS / 4, first=base)
+            ms_forms[form_] = dt_s / args.steps * 1e3
+        csel[0], csel[1] = keep_sel
         g.set_color_deferral(True, staged=staged)
 
     if rank != 0:
@@ -800,7 +963,7 @@ def main_camera(args):
         return finish_dist(dist, world)
     if not multicam:
         comp["tsdf"] = timed(lambda i: g.integrate_prepared(dargs[0][(base + i) % nu]), n2c)
-        comp["color"] = timed(lambda i: g.integrate_prepared(cargs[0][(base + i) % nu]), n2c)
+        comp["color"] = timed(lambda i: g.integrate_prepared(csel[0][0][(base + i) % nu]), n2c)
 
         def esdf_only(i):
             g.integrate_prepared(dargs[0][(base + i) % nu]); g.update_esdf()
@@ -884,6 +1047,10 @@ def main_camera(args):
         "step time; compare rocprofv3's kernel-trace averages in profiles/*_kernel_stats.csv.  640x480 @ 0.05 m moves ~10 MB per camera frame, "
         "so every kernel is bound by its dependent-access chain and launch cost rather than by HBM bytes (DESIGN.md 2)")
 
+    # bytes the step moves that are NOT in SURVEY 8d's formulas (the staged form's copy of raw-pointer colour images): reported, never counted as algorithmic
+    roofline["step"]["overhead_bytes"] = int(sum(overhead_bytes(k_, rows, cols, n_cam=(ncam // launches_cam)) * v_["launches_per_step"] for k_, v_ in kern.items()))
+    roofline["traffic_source"] = pmc_source()
+
     cpu = None
     if not args.no_cpu_baseline:
         import oracle
@@ -932,9 +1099,12 @@ def main_camera(args):
                                "fuser.yaml params, TSDF+Color+ESDF every frame (mesh timed separately)",
                    "cameras_per_gpu": ncam, "parallelism": ("one camera per GPU, RCCL all-gather of per-voxel measurements, one fused map on every rank" if fuse else "one camera per GPU, RCCL all-gather of dirty block indices") if world > 1 else "single GPU",
                    "unique_frames": nu,
-                   "mode": (("color_deferral, staged: nvbx_mapper_set_color_deferral(m, 2) -- the DEFAULT of a new mapper (C-ABI and nvblox:: facade): what a host gets "
-                             "that only swaps the library; the opt-in zero-copy form is quoted as color_deferral.ms_per_step_revisit_zero_copy, the classic "
-                             "order of four launches as ms_per_step_classic_order") if staged else
+                   "mode": (("color_deferral, images in library-owned frames: a new mapper's default setting (nvbx_mapper_set_color_deferral(m, 2)) fed colour images that "
+                             "live in frames of nvbx_frame_acquire -- the device memory of an nvblox::Image<Color> in the facade, where the node's conversion writes; the "
+                             "mapper retains the frame of a held-back image instead of copying it (csrc/frames.hip).  Raw device pointers under the same setting are copied "
+                             "first (color_deferral.ms_per_step_revisit_staged_copy, --staged-deferral); classic order of four launches: ms_per_step_classic_order") if cform == "frames" else
+                            ("color_deferral, staged: nvbx_mapper_set_color_deferral(m, 2), the default of a new mapper, fed RAW device pointers (--staged-deferral): "
+                             "each held-back image is copied into a frame of the mapper's own first (k_stage_color)") if staged else
                             ("color_deferral, zero-copy: nvbx_mapper_set_color_deferral(m, 1) -- OPT-IN (--zero-copy-deferral; the caller keeps its colour image "
                              "unchanged until its next call); the default of a new mapper is the staged form, color_deferral.ms_per_step_revisit_staged_copy")) if deferral
                            else "classic launch order (--no-color-deferral / NVBX_COLOR_DEFERRAL=0; a new mapper defaults to staged colour deferral)"},
@@ -949,9 +1119,12 @@ def main_camera(args):
                    "revisit_ms_per_step": block_stats(dts_rev, args.steps),
                    "revisit_note": "same blocks of K steps on the fully allocated map (after one untimed loop over all poses)"},
         "ms_per_step_revisit": round(ms_revisit, 4),
-        "color_deferral": {"enabled": bool(deferral), "form": ("staged" if staged else "zero_copy") if deferral else None, "launches_per_frame": launches_per_frame,
+        "color_deferral": {"enabled": bool(deferral), "form": cform if deferral else None, "launches_per_frame": launches_per_frame,
                            "ms_per_step_revisit_classic_order": (round(ms_classic, 4) if ms_classic else None),
-                           ("ms_per_step_revisit_zero_copy" if staged else "ms_per_step_revisit_staged_copy"): (round(ms_other_form, 4) if ms_other_form else None),
+                           "ms_per_step_revisit_frames": (round(ms_forms["frames"], 4) if "frames" in ms_forms else None),
+                           "ms_per_step_revisit_staged_copy": (round(ms_forms["staged"], 4) if "staged" in ms_forms else None),
+                           "ms_per_step_revisit_zero_copy": (round(ms_forms["zero_copy"], 4) if "zero_copy" in ms_forms else None),
+                           "frame_pool": dict(zip(("held", "free", "bytes", "created", "waits", "syncs"), M.frame_pool_stats())),
                            "note": "enabled: integrateColor(i) / updateEsdf(i) are held back and carried out by integrateDepth(i+1) in pipelined order: "
                                    "launch 1 = view marking(i+1) || sphere tracing(i) || colour candidates(i) || ESDF marking(i), launch 2 = TSDF update(i+1) "
                                    "|| colour integration(i) || distance transform(i) (NVBX_FUSE_COLC=0: three launches); same calls, bit-identical map "
@@ -991,6 +1164,7 @@ def main():
     ap.add_argument("--own-stream", action="store_true", help="decay: the dynamic mapper of the dynamic-mapping frame on a stream of its own (A/B; slower: EXPERIMENTS.md)")
     ap.add_argument("--profile-run", action="store_true", help="camera / multicam: only the timed step is launched (for rocprofv3 runs: clean per-kernel averages)")
     ap.add_argument("--with-mesh", action="store_true", help="camera: the timed step also updates the colour mesh (TSDF+Color+ESDF+Mesh per frame; profiling passes for k_mesh)")
+    ap.add_argument("--staged-deferral", action="store_true", help="camera workload: colour images as RAW device pointers under the default (staged) deferral: one k_stage_color copy per held-back frame (round 4's default line); default now: the images live in library-owned frames (nvbx_frame_acquire), no copy")
     ap.add_argument("--zero-copy-deferral", action="store_true", help="camera workload: colour deferral WITHOUT the staging copy (opt-in form: the caller keeps the colour image unchanged); default: staged, as a new mapper")
     ap.add_argument("--no-color-deferral", action="store_true", help="camera workload: classic launch order (4 launches per frame) instead of the cross-frame pipeline")
     ap.add_argument("--separate-front-end", action="store_true", help="decay workload: detect / remove-small-components / split as three entry points (A/B against nvbx_dynamic_depth_split)")
@@ -999,7 +1173,7 @@ def main():
     ap.add_argument("--fusion", default="indices", choices=["indices", "measurements"],
                     help="N > 1 GPUs: indices = replicas + all-gather of dirty block indices (north-star wording, default); "
                          "measurements = all-gather of per-voxel measurements, ONE fused map on every rank (SURVEY 8e option B, exact)")
-    ap.add_argument("--workload", default="camera", choices=["camera", "multicam", "decay", "lidar"],
+    ap.add_argument("--workload", default="camera", choices=["camera", "multicam", "decay", "lidar", "node"],
                     help="camera = BASELINE.json configs[1] (the metric's configuration, default); multicam = configs[3] on one GPU; "
                          "decay = configs[2]; lidar = configs[4]")
     args = ap.parse_args()
@@ -1008,6 +1182,9 @@ def main():
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.workload == "lidar":
         return main_lidar(args)
+    if args.workload == "node":
+        args.steps = 40
+        return main_node(args)
     if args.workload == "decay":
         return main_decay(args)
     return main_camera(args)

@@ -11,6 +11,7 @@
 #include <optional>
 #include <vector>
 #include "nvblox/mapper/mapper.h"
+#include "nvblox/mapper/block_index_exchange.h"
 
 namespace nvblox {
 
@@ -74,8 +75,22 @@ class MultiMapper {
   std::shared_ptr<Mapper> background_mapper() const { return background_mapper_; }
   std::shared_ptr<Mapper> foreground_mapper() const { return foreground_mapper_; }
 
+  // libnvblox_hip extension (multi-GPU, one camera / one MultiMapper per GPU; block_index_exchange.h): with an exchange set, every camera
+  // integrateDepth writes and starts this rank's block-index message, the next integrateColor (or updateEsdf, for hosts without colour) hands the
+  // previous frame's gathered lists to the background mapper -- the union step before the ESDF sweep.  The node's calls do not change.
+  void setBlockIndexExchange(std::shared_ptr<BlockIndexExchange> exchange) {
+    if (block_index_exchange_) block_index_exchange_->drain(background_mapper_->c_handle());
+    block_index_exchange_ = std::move(exchange);
+  }
+  const std::shared_ptr<BlockIndexExchange>& block_index_exchange() const { return block_index_exchange_; }
+
   void integrateDepth(const DepthImage& depth, const Transform& T_L_C, const Camera& camera, std::optional<Time> update_time_ms = std::nullopt) {
-    if (!dynamic_) { background_mapper_->integrateDepth(depth, T_L_C, camera); return; }
+    if (!dynamic_) {
+      if (block_index_exchange_) block_index_exchange_->beforeDepth(background_mapper_->c_handle());
+      background_mapper_->integrateDepth(depth, T_L_C, camera);
+      if (block_index_exchange_) block_index_exchange_->start(background_mapper_->c_handle());
+      return;
+    }
     // MappingType::kDynamic (nvblox_dynamics.yaml): pixels whose points lie in high-confidence freespace are dynamic; the mask is
     // cleaned of small components, splits the depth image; static part -> TSDF + freespace update, dynamic part -> occupancy mapper
     nvbx_mapper* m = background_mapper_->c_handle();
@@ -136,7 +151,10 @@ class MultiMapper {
     background_mapper_->integrateLidarPointcloud(deskewed_, T_L_C, lidar);
   }
   const DepthImage& getLastDepthFrameFromPointcloud() const { return background_mapper_->getLastDepthFrameFromPointcloud(); }
-  void integrateColor(const ColorImage& color, const Transform& T_L_C, const Camera& camera) { background_mapper_->integrateColor(color, T_L_C, camera); }
+  void integrateColor(const ColorImage& color, const Transform& T_L_C, const Camera& camera) {
+    if (block_index_exchange_ && !block_index_exchange_->finishedThisFrame()) block_index_exchange_->finishPrevious(background_mapper_->c_handle(), true);
+    background_mapper_->integrateColor(color, T_L_C, camera);
+  }
   // nvblox_node.cpp:1261-1262: the masked pixels are removed from the colour image before the background mapper integrates it
   void integrateColor(const ColorImage& color, const MonoImage& mask, const Transform& T_L_C, const Camera& camera) {
     if (!human_) unsupported("masked colour integration outside the human mapping types");
@@ -153,6 +171,7 @@ class MultiMapper {
       background_mapper_->setEsdfGroundPlane(ground_plane_estimator_.ground_plane());
       if (human_ || dynamic_) foreground_mapper_->setEsdfGroundPlane(ground_plane_estimator_.ground_plane());
     }
+    if (block_index_exchange_ && !block_index_exchange_->finishedThisFrame()) block_index_exchange_->finishPrevious(background_mapper_->c_handle(), false);      // (a host without colour)
     background_mapper_->updateEsdf(); if (human_ || dynamic_) foreground_mapper_->updateEsdf();
   }
   void updateColorMesh(UpdateFullLayer f = UpdateFullLayer::kNo) { background_mapper_->updateColorMesh(f); }
@@ -175,6 +194,7 @@ class MultiMapper {
   MappingType mapping_type_; EsdfMode esdf_mode_;
   std::shared_ptr<CudaStream> cuda_stream_;
   std::shared_ptr<Mapper> background_mapper_, foreground_mapper_;
+  std::shared_ptr<BlockIndexExchange> block_index_exchange_;
   MultiMapperParams multi_params_;
 };
 

@@ -4,11 +4,23 @@
 // (.copyFromAsync(rows, cols, ptr, stream)).
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <cstdlib>
+#include <utility>
+#include "nvblox_hip.h"
 #include "nvblox/core/cuda_stream.h"
 #include "nvblox/core/types.h"
 
 namespace nvblox {
 
+// Device images (MemoryType::kDevice, the default) live in library-owned, reference-counted frames (nvbx_frame_acquire, include/nvblox_hip.h).
+// Why: a mapper with colour deferral on (the default) HOLDS an integrateColor back until the next integrateDepth.  The reference's node refills its one
+// colour image right before every integrateColor (nvblox_node.cpp:1237-1263; the converter writes through the non-const dataPtr(),
+// conversions/image_conversions_thrust.cu:75-80).  Here the mapper RETAINS the frame of a held-back image instead of copying it, and every WRITE access
+// of the image -- non-const dataPtr(), copyFromAsync, resize -- first makes sure nobody else holds the frame: if a mapper does, the image lets go of it
+// and continues in another frame of the pool (rotation; the mapper's frame stays untouched until its launches are done, then returns to the pool).
+// What differs from a plain buffer: after integrateColor, the memory behind a NON-CONST dataPtr() is a different frame whose contents are unspecified
+// (every writer in the reference overwrites the whole image); NVBX_IMAGE_ROTATE_PRESERVE=1 in the environment copies the old contents over first
+// (a blocking device-to-device copy -- for hosts that patch images in place).  Const access (dataConstPtr) never rotates.
 template <typename T>
 class Image {
  public:
@@ -27,7 +39,7 @@ class Image {
   int height() const { return rows_; } int width() const { return cols_; }
   int numel() const { return rows_ * cols_; }
   MemoryType memory_type() const { return memory_type_; }
-  T* dataPtr() { return data_; }
+  T* dataPtr() { makeExclusive(NVBX_STREAM_UNKNOWN); return data_; }
   const T* dataConstPtr() const { return data_; }
   // (re)allocate without preserving contents; keeps the allocation when it is large enough
   void resize(int rows, int cols) {
@@ -36,22 +48,39 @@ class Image {
       release();
       if (memory_type_ == MemoryType::kHost) (void)hipHostMalloc((void**)&data_, need * sizeof(T));
       else if (memory_type_ == MemoryType::kUnified) (void)hipMallocManaged((void**)&data_, need * sizeof(T));
-      else (void)hipMalloc((void**)&data_, need * sizeof(T));
-      cap_ = need;
+      else { int dev = 0; (void)hipGetDevice(&dev); void* p = nullptr; if (nvbx_frame_acquire(dev, need * sizeof(T), NVBX_STREAM_UNKNOWN, &p) == 0) data_ = static_cast<T*>(p); }
+      cap_ = data_ ? need : 0;
     }
     rows_ = rows; cols_ = cols;
   }
   void copyFromAsync(int rows, int cols, const T* src, const CudaStream& stream) {
     resize(rows, cols);
+    makeExclusive(static_cast<void*>(static_cast<hipStream_t>(stream)));      // (the whole image is overwritten: nothing to preserve)
     (void)hipMemcpyAsync(data_, src, (size_t)rows * cols * sizeof(T), hipMemcpyDefault, stream);
   }
   void copyToAsync(T* dst, const CudaStream& stream) const {
     (void)hipMemcpyAsync(dst, data_, (size_t)numel() * sizeof(T), hipMemcpyDefault, stream);
   }
+  // libnvblox_hip extension: the frame is shared with a mapper that holds the image back (the next write access rotates)
+  bool sharedWithMapper() const { return memory_type_ == MemoryType::kDevice && data_ && nvbx_frame_refcount(data_) > 1; }
  private:
+  // before a write: if a mapper has retained the frame (a held-back integrateColor), or has let go of it but its launches may still be reading it and
+  // were not enqueued on the writer's own stream, continue in another one
+  void makeExclusive(void* writer_stream) {
+    if (memory_type_ != MemoryType::kDevice || !data_ || nvbx_frame_writable(data_, writer_stream) != 0) return;
+    int dev = 0; (void)hipGetDevice(&dev);
+    void* p = nullptr;
+    if (nvbx_frame_acquire(dev, cap_ * sizeof(T), writer_stream, &p) != 0) return;       // (no memory: stay -- the mapper's staged copy is not in play, so say so loudly)
+    static const bool preserve = [] { const char* e = getenv("NVBX_IMAGE_ROTATE_PRESERVE"); return e && e[0] == '1'; }();
+    if (preserve && writer_stream == NVBX_STREAM_UNKNOWN) (void)hipMemcpy(p, data_, cap_ * sizeof(T), hipMemcpyDeviceToDevice);
+    (void)nvbx_frame_release(data_);
+    data_ = static_cast<T*>(p);
+  }
   void release() {
     if (!data_) return;
-    if (memory_type_ == MemoryType::kHost) (void)hipHostFree(data_); else (void)hipFree(data_);
+    if (memory_type_ == MemoryType::kHost) (void)hipHostFree(data_);
+    else if (memory_type_ == MemoryType::kUnified) (void)hipFree(data_);
+    else (void)nvbx_frame_release(data_);
     data_ = nullptr; cap_ = 0;
   }
   T* data_ = nullptr;

@@ -23,6 +23,7 @@
 #ifndef NVBLOX_HIP_H_
 #define NVBLOX_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -228,6 +229,40 @@ int nvbx_flush(nvbx_mapper* m);
  * enable = 0: the classic order, every call launches its own kernels (four launches per frame).  NVBX_COLOR_DEFERRAL=0|1|2 in the environment sets the
  * default of mappers created afterwards. */
 int nvbx_mapper_set_color_deferral(nvbx_mapper* m, int32_t enable);
+/* ---- Library-owned device frames: OWNERSHIP TRANSFER of input images (csrc/frames.hip).
+ * Replaces the node-owned, re-used device image buffers of the reference (nvblox_node.hpp:484-488: color_image_, filled by the conversion on the
+ * mapper's stream right before integrateColor, nvblox_node.cpp:1237-1263, conversions/image_conversions_thrust.cu:68-84) for a library that may hold a
+ * colour frame back (nvbx_mapper_set_color_deferral above): an image that lives in a frame of nvbx_frame_acquire is RETAINED by the mapper instead of
+ * copied (no k_stage_color launch, in either deferral form), and let go of when the launches that read it are enqueued.  A writer asks for "a frame
+ * nobody else holds" before it writes: nvblox::Image<T> does so in its non-const dataPtr() / copyFromAsync / resize (include/nvblox/sensors/image.h) and
+ * rotates to another frame while the mapper still holds the last one.
+ *   nvbx_frame_acquire(device, bytes, writer_stream, &ptr): a device buffer of >= bytes, reference count 1 (the caller's).  Never hands out memory
+ *     that launches of a mapper may still read: a frame a mapper has let go of is given to a writer only when those launches are known to have
+ *     finished, or when `writer_stream` is the very stream they were enqueued on (stream order does the rest); otherwise another frame is taken, the
+ *     pool grows (NVBX_FRAME_POOL_MAX frames per size, default 8) or -- pool full -- the call waits for the oldest.  writer_stream: the stream the
+ *     caller will write the frame on, or NVBX_STREAM_UNKNOWN (host writes, any stream).
+ *   nvbx_frame_retain / nvbx_frame_release: reference counting; at 0 the frame returns to the pool (a caller that lets go of a frame ITS OWN work still
+ *     uses orders that itself, as with hipFree).  nvbx_frame_refcount: > 1 = somebody else (a mapper) holds it too; -1 = not a frame.
+ *     nvbx_frame_writable: the question a writer asks before it overwrites a frame it holds (below).
+ *   nvbx_frame_pool_trim(device | -1): hipFree every frame nobody holds; returns how many.  nvbx_frame_pool_stats: {held, free, bytes, created, waits, syncs}.
+ *   nvbx_frame_upload: hipMemcpyAsync into a frame on `hip_stream` (NVBX_STREAM_UNKNOWN: a blocking hipMemcpy) -- for hosts without a HIP binding of
+ *     their own (the ctypes mirror).
+ *   nvbx_color_image_acquire(m, rows, cols, 3 | 4, &ptr) = nvbx_frame_acquire(device of m, rows * cols * bytes_per_pixel, stream of m, &ptr): for the
+ *     converter that runs on the mapper's stream.  nvbx_integrate_color_owned(m, frame, 3 | 4, ...) = nvbx_integrate_color / _bgra8 + the caller's
+ *     reference passes to the mapper (released for the caller; on NVBX_E_INVALID the caller keeps it). */
+#define NVBX_STREAM_UNKNOWN ((void*)(intptr_t)-1)
+int nvbx_frame_acquire(int device, size_t bytes, void* writer_stream, void** dev_ptr_out);
+int nvbx_frame_retain(void* dev_ptr);
+int nvbx_frame_release(void* dev_ptr);
+int32_t nvbx_frame_refcount(const void* dev_ptr);
+/* 1 = the caller is the only holder AND no launch of a mapper can still be reading the frame (finished, or enqueued on `writer_stream` itself): write in
+ * place; 0 = take another frame (nvbx_frame_acquire) and let go of this one; -1 = not a live frame. */
+int32_t nvbx_frame_writable(const void* dev_ptr, void* writer_stream);
+int nvbx_frame_pool_trim(int device);
+int nvbx_frame_pool_stats(int64_t out[6]);
+int nvbx_frame_upload(void* dev_ptr, const void* src, size_t bytes, void* hip_stream);
+int nvbx_color_image_acquire(nvbx_mapper* m, int32_t rows, int32_t cols, int32_t bytes_per_pixel, void** dev_ptr_out);
+int nvbx_integrate_color_owned(nvbx_mapper* m, void* frame, int32_t bytes_per_pixel, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera);
 /* The hipStream_t all of the mapper's work is enqueued on (the one handed to nvbx_mapper_create, or the library-owned one):
  * implicit conversion of nvblox::CudaStream to cudaStream_t -- conversions/esdf_slice_conversions.cu:107-108.  A caller that
  * reads / writes buffers it shares with the mapper on ANOTHER stream (e.g. an RCCL collective on the framework's stream) orders

@@ -178,9 +178,21 @@ SIGNATURES = {
     "nvbx_mark_esdf_dirty": (C.c_int, [_vp, _vp, _vp, _i64]),
     "nvbx_mark_esdf_dirty_gathered": (C.c_int, [_vp, _vp, _i32, _i32, _i64]),
     "nvbx_mark_esdf_dirty_gathered_deferred": (C.c_int, [_vp, _vp, _i32, _i32, _i64]),
+    "nvbx_frame_acquire": (C.c_int, [C.c_int, C.c_size_t, _vp, C.POINTER(_vp)]),
+    "nvbx_frame_retain": (C.c_int, [_vp]),
+    "nvbx_frame_release": (C.c_int, [_vp]),
+    "nvbx_frame_refcount": (_i32, [_vp]),
+    "nvbx_frame_writable": (_i32, [_vp, _vp]),
+    "nvbx_frame_pool_trim": (C.c_int, [C.c_int]),
+    "nvbx_frame_pool_stats": (C.c_int, [C.POINTER(_i64)]),
+    "nvbx_frame_upload": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "nvbx_color_image_acquire": (C.c_int, [_vp, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "nvbx_integrate_color_owned": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, C.POINTER(Camera)]),
     "nvbx_set_profiling": (C.c_int, [_vp, _i32]),
     "nvbx_get_profile": (C.c_int, [_vp, C.c_char_p, _i64]),
 }
+
+STREAM_UNKNOWN = C.c_void_p(-1)      # NVBX_STREAM_UNKNOWN
 
 _lib = None
 

@@ -184,24 +184,34 @@ static bool defer_color(nvbx_mapper* m, int kind, int32_t n, const void* const* 
   *rc_out = color_precheck(m, n, rows, cols, T_L_C);            // argument errors are reported by the call that made them
   if (*rc_out) return true;
   if (hipSetDevice(m->device) != hipSuccess || m->replay_deferred()) { *rc_out = NVBX_E_DEVICE; return true; }     // an older held-back frame goes first
+  m->release_consumed_frames();
   nvbx_mapper::ColorPending& c = m->color_pending;
-  if (m->color_staging) {            // the frame travels in the mapper's own memory from here on (a host that recycles its colour buffer)
-    const size_t bytes = (size_t)rows * (size_t)cols * (kind == 0 ? 3u : 4u);
-    if (bytes > m->color_stage_bytes) {
-      if (hipStreamSynchronize(m->stream) != hipSuccess) { *rc_out = NVBX_E_DEVICE; return true; }
-      for (int i = 0; i < MAX_BATCH; i++) { if (m->color_stage[i]) (void)hipFree(m->color_stage[i]); m->color_stage[i] = nullptr; }
-      m->color_stage_bytes = 0;
-      for (int i = 0; i < MAX_BATCH; i++) if (hipMalloc(&m->color_stage[i], bytes) != hipSuccess) { set_error("colour staging buffers"); *rc_out = NVBX_E_DEVICE; return true; }
-      m->color_stage_bytes = bytes;
-    }
-    StagePtrs sp{};
-    for (int i = 0; i < n; i++) { sp.src[i] = (const unsigned char*)imgs[i]; sp.dst[i] = (unsigned char*)m->color_stage[i]; }
+  const size_t bytes = (size_t)rows * (size_t)cols * (kind == 0 ? 3u : 4u);
+  // Where each held-back image lives until it is carried out:
+  //   a frame of nvbx_frame_acquire (nvblox::Image<T> device memory, nvbx_color_image_acquire): RETAINED -- no copy, in either mode (frames.hip);
+  //   a raw device pointer, staged form (the default): copied into a frame of the mapper's own, one launch for the whole call (the caller may
+  //     recycle or overwrite its image as soon as integrateColor has returned -- ADVICE r03);
+  //   a raw device pointer, zero-copy form (opt-in): used where it lies, under the caller's contract (nvblox_hip.h).
+  void* frames[MAX_BATCH] = {}; const void* use[MAX_BATCH] = {};
+  StagePtrs sp{}; int n_copy = 0;
+  auto undo = [&]() { for (int i = 0; i < n; i++) if (frames[i]) (void)nvbx_frame_release(frames[i]); };
+  for (int i = 0; i < n; i++) {
+    bool too_small = false;
+    if (frame_retain_if_frame(imgs[i], bytes, &too_small)) { frames[i] = const_cast<void*>(imgs[i]); use[i] = imgs[i]; continue; }
+    if (too_small) { undo(); set_error("integrate color: the frame of nvbx_frame_acquire is smaller than rows x cols pixels"); *rc_out = NVBX_E_INVALID; return true; }
+    if (!m->color_staging) { use[i] = imgs[i]; continue; }
+    void* f = nullptr;
+    if (nvbx_frame_acquire(m->device, bytes, m->stream, &f) != NVBX_OK) { undo(); *rc_out = NVBX_E_DEVICE; return true; }
+    frames[i] = f; use[i] = f;
+    sp.src[n_copy] = (const unsigned char*)imgs[i]; sp.dst[n_copy] = (unsigned char*)f; n_copy++;
+  }
+  if (n_copy) {
     const int32_t wgi = (int32_t)std::min<int64_t>(256, std::max<int64_t>(1, (int64_t)(bytes >> 4) / 256 + 1));      // 640x480 rgb8: 226 workgroups, one 16-B access per thread
-    NVBX_LAUNCH(m, k_stage_color, dim3((unsigned)(wgi * n)), dim3(256), sp, (int64_t)bytes, wgi);
-    if (hipGetLastError() != hipSuccess) { set_error("colour staging copy"); *rc_out = NVBX_E_DEVICE; return true; }
+    NVBX_LAUNCH(m, k_stage_color, dim3((unsigned)(wgi * n_copy)), dim3(256), sp, (int64_t)bytes, wgi);
+    if (hipGetLastError() != hipSuccess) { undo(); set_error("colour staging copy"); *rc_out = NVBX_E_DEVICE; return true; }
   }
   c.on = true; c.kind = kind; c.n = n; c.rows = rows; c.cols = cols;
-  for (int i = 0; i < n; i++) { c.imgs[i] = m->color_staging ? m->color_stage[i] : imgs[i]; c.cams[i] = cameras[i]; }
+  for (int i = 0; i < MAX_BATCH; i++) { c.imgs[i] = i < n ? use[i] : nullptr; c.frames[i] = i < n ? frames[i] : nullptr; if (i < n) c.cams[i] = cameras[i]; }
   memcpy(c.T, T_L_C, sizeof(float) * 16 * (size_t)n);
   *rc_out = NVBX_OK;
   return true;
@@ -244,7 +254,7 @@ void nvbx_mapper::pending_marking_args(int32_t* mark_wg, EsdfArgs* ea_out) {
 }
 // ... and its colour integration shares a launch with that frame's TSDF update: frames and scratch as for the separate launch
 int nvbx_mapper::pending_color_fused_args(void* fsc_out, int* kind, int32_t* srows, int32_t* scols) {
-  const ColorPending c = color_pending; color_pending.on = false;
+  const ColorPending c = take_pending();      // (its frames are let go of by the caller, once the launch that reads them is enqueued: release_consumed_frames)
   *kind = c.kind;
   if (c.n > 1) { PoseSet<MAX_BATCH> ps; return pending_setup<PixRgb8, MAX_BATCH>(this, c, static_cast<FrameSetC<PixRgb8, MAX_BATCH>*>(fsc_out), &ps, srows, scols); }
   PoseSet<1> ps;
@@ -277,14 +287,16 @@ bool nvbx_mapper::replay_pair_applies() const {
   return on && color_pending.on && esdf_update_pending && p.projective_layer_type != 1 && p.esdf_mode == 0 && p.esdf_propagation == 0 && !use_side && defer_edt && !import_pending;
 }
 int nvbx_mapper::replay_pair() {
-  const ColorPending c = color_pending; color_pending.on = false; esdf_update_pending = false;
-  if (c.n > 1) return replay_pair_t<PixRgb8, MAX_BATCH>(this, c);
-  return c.kind == 0 ? replay_pair_t<PixRgb8, 1>(this, c) : replay_pair_t<PixBgra8, 1>(this, c);
+  const ColorPending c = take_pending(); esdf_update_pending = false;
+  const int rc = c.n > 1 ? replay_pair_t<PixRgb8, MAX_BATCH>(this, c) : (c.kind == 0 ? replay_pair_t<PixRgb8, 1>(this, c) : replay_pair_t<PixBgra8, 1>(this, c));
+  release_consumed_frames();
+  return rc;
 }
 int nvbx_mapper::launch_pending_color_after_trace() {
-  const ColorPending c = color_pending; color_pending.on = false;
-  if (c.n > 1) return launch_pending_integrate<PixRgb8, MAX_BATCH>(this, c);
-  return c.kind == 0 ? launch_pending_integrate<PixRgb8, 1>(this, c) : launch_pending_integrate<PixBgra8, 1>(this, c);
+  const ColorPending c = take_pending();
+  const int rc = c.n > 1 ? launch_pending_integrate<PixRgb8, MAX_BATCH>(this, c) : (c.kind == 0 ? launch_pending_integrate<PixRgb8, 1>(this, c) : launch_pending_integrate<PixBgra8, 1>(this, c));
+  release_consumed_frames();
+  return rc;
 }
 
 extern "C" int nvbx_integrate_color(nvbx_mapper* m, const uint8_t* rgb_dev, int32_t rows, int32_t cols, const float T_L_C[16],
@@ -302,6 +314,21 @@ extern "C" int nvbx_integrate_color_bgra8(nvbx_mapper* m, const uint8_t* bgra_de
   { int rc = NVBX_OK; const void* im = bgra_dev; if (defer_color(m, 1, 1, &im, rows, cols, T_L_C, camera, &rc)) return rc; }
   const PixBgra8 img{reinterpret_cast<const uint32_t*>(bgra_dev)};
   return integrate_colors<PixBgra8, 1>(m, 1, &img, rows, cols, T_L_C, camera);
+}
+// integrateColor of an image in a frame of nvbx_frame_acquire / nvbx_color_image_acquire whose ownership passes to the mapper with the call
+extern "C" int nvbx_integrate_color_owned(nvbx_mapper* m, void* frame, int32_t bytes_per_pixel, int32_t rows, int32_t cols, const float T_L_C[16], const nvbx_camera* camera) {
+  if (!m || (bytes_per_pixel != 3 && bytes_per_pixel != 4) || !image_dims_ok(rows, cols)) { set_error("nvbx_integrate_color_owned: invalid argument (3 = rgb8, 4 = bgra8)"); return NVBX_E_INVALID; }
+  bool too_small = false;
+  if (!frame_retain_if_frame(frame, (size_t)rows * (size_t)cols * (size_t)bytes_per_pixel, &too_small)) {       // (a reference of this call's own, for the way through)
+    set_error(too_small ? "nvbx_integrate_color_owned: the frame is smaller than rows x cols pixels" : "nvbx_integrate_color_owned: not a live frame of nvbx_frame_acquire"); return NVBX_E_INVALID; }
+  const int rc = bytes_per_pixel == 4 ? nvbx_integrate_color_bgra8(m, (const uint8_t*)frame, rows, cols, T_L_C, camera) : nvbx_integrate_color(m, (const uint8_t*)frame, rows, cols, T_L_C, camera);
+  if (rc == NVBX_E_INVALID) { (void)nvbx_frame_release(frame); return rc; }              // (argument errors: the caller keeps the frame)
+  // a frame that was NOT held back (deferral off, an occupancy mapper) has just been read by launches enqueued on the mapper's stream: it is let go of
+  // behind them, with a fence, like a held-back one
+  if (rc == NVBX_OK && !(m->color_pending.on && m->color_pending.frames[0] == frame)) { m->consumed_frames.push_back(frame); m->release_consumed_frames(); }
+  else (void)nvbx_frame_release(frame);
+  (void)nvbx_frame_release(frame);          // the caller's reference: ownership has passed
+  return rc;
 }
 // Up to NVBX_MAX_BATCH colour frames (rgb8, same image size) in ONE launch set: see include/nvblox_hip.h
 extern "C" int nvbx_integrate_color_batch(nvbx_mapper* m, int32_t n, const uint8_t* const* rgb_dev, int32_t rows, int32_t cols, const float* T_L_C,

@@ -216,7 +216,7 @@ static int alloc_all(nvbx_mapper* m) {
   NVBX_HIP(hipHostMalloc(&m->h_shc, S_NUM * NSH * SH_STRIDE * 4));
   NVBX_HIP(hipHostMalloc(&m->h_mirror, 64, hipHostMallocMapped));
   { void* dp = nullptr; NVBX_HIP(hipHostGetDevicePointer(&dp, m->h_mirror, 0)); d.host_mirror = (int32_t*)dp; }
-  m->h_mirror[0] = (int32_t)cap; m->h_mirror[1] = 0; m->h_mirror[2] = 0; m->h_mirror[3] = 0;
+  m->h_mirror[0] = (int32_t)cap; m->h_mirror[1] = 0; m->h_mirror[2] = 0; m->h_mirror[3] = 0; m->h_mirror[4] = 0;      // ([4]: fence progress of held-back colour frames, frames.hip -- never reset)
   return NVBX_OK;
 }
 
@@ -236,7 +236,7 @@ static int reset_map(nvbx_mapper* m) {
   NVBX_LAUNCH(m, k_init_map, dim3((unsigned)((n + 255) / 256)), dim3(256), d);
   NVBX_HIP(hipGetLastError());
   m->dirty_since_mark = false; m->premark_consumed = false; m->mark_pass = 0; m->edt_pending = false; m->import_pending = false;
-  m->unresolved_marks = false; m->pass_at_last_edt = 0; m->color_pending.on = false; m->esdf_update_pending = false; m->lidar_integrated = false;
+  m->unresolved_marks = false; m->pass_at_last_edt = 0; (void)m->take_pending(); m->release_consumed_frames(); m->esdf_update_pending = false; m->lidar_integrated = false;
   if (m->h_mirror) { m->h_mirror[0] = (int32_t)m->capacity; m->h_mirror[1] = 0; m->h_mirror[2] = 0; m->h_mirror[3] = 0; }
   m->frame_id = 0; m->esdf_epoch = 0; m->mesh_epoch = 0; m->last_view_frame = 0; m->last_camera_view_frame = 0; m->synth_rows = m->synth_cols = 0;
   return NVBX_OK;
@@ -385,7 +385,8 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
                   m->view_list, d.lists, d.shc, m->export_idx, m->export_count, m->cleared_idx, d.site_bits, d.obs_bits, d.inside_bits,
                   m->synth, m->view_class, m->color_cand, m->depth_pre, m->mask_zmin, m->apply_postab, m->esdf3_scratch, m->cc_scratch, m->dyn_scratch, d.freespace, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  for (void* p : m->color_stage) if (p) (void)hipFree(p);
+  // (both streams are idle: whatever read a held-back colour frame has finished)
+  (void)m->take_pending(); m->release_consumed_frames(); nvbx::frames_forget_owner(m);
   for (auto& s : m->spans) { if (s.a) (void)hipEventDestroy(s.a); if (s.b) (void)hipEventDestroy(s.b); }
   for (hipEvent_t e : m->event_pool) if (e) (void)hipEventDestroy(e);
   if (m->h_counters) (void)hipHostFree(m->h_counters);
@@ -936,7 +937,7 @@ int nvbx_mapper::replay_deferred() {
   int rc = NVBX_OK;
   if (replay_pair_applies()) { rc = replay_pair(); replaying = false; return rc == NVBX_OK ? NVBX_OK : NVBX_E_DEVICE; }
   if (color_pending.on) {
-    const ColorPending c = color_pending; color_pending.on = false;
+    const ColorPending c = take_pending();
     if (c.n > 1) rc = nvbx_integrate_color_batch(this, c.n, reinterpret_cast<const uint8_t* const*>(c.imgs), c.rows, c.cols, c.T, c.cams);
     else rc = c.kind == 0 ? nvbx_integrate_color(this, (const uint8_t*)c.imgs[0], c.rows, c.cols, c.T, &c.cams[0])
                           : nvbx_integrate_color_bgra8(this, (const uint8_t*)c.imgs[0], c.rows, c.cols, c.T, &c.cams[0]);
@@ -944,6 +945,7 @@ int nvbx_mapper::replay_deferred() {
   if (rc == NVBX_OK && esdf_update_pending) { esdf_update_pending = false; rc = nvbx_update_esdf(this); }
   esdf_update_pending = false;
   replaying = false;
+  release_consumed_frames();
   return rc == NVBX_OK ? NVBX_OK : NVBX_E_DEVICE;
 }
 extern "C" int nvbx_mapper_set_color_deferral(nvbx_mapper* m, int32_t enable) {

@@ -35,6 +35,10 @@ struct EsdfArgs {
 struct MeshRecord { int32_t x, y, z, vbase, nvert, tbase, ntri, pad; };
 
 float log_odds(float p);
+// frames.hip: library-owned, reference-counted device frames (ownership transfer of input images)
+bool frame_retain_if_frame(const void* p, size_t need_bytes, bool* too_small);
+void frame_release_fenced(void* p, const volatile int32_t* progress, int32_t seq, const volatile int32_t* reports_enqueued, hipStream_t reader, const void* owner);
+void frames_forget_owner(const void* owner);
 void set_error(const char* what, hipError_t e);
 void set_error(const char* what);
 
@@ -146,15 +150,30 @@ struct nvbx_mapper {
   // calls as they are (join_side -> replay_deferred), so the API observes call order.  Contract: the colour image must stay valid and
   // unchanged until the next call into the mapper has returned.
   // (n = 1: integrateColor, kind 0 = rgb8 / 1 = bgra8; n > 1: nvbx_integrate_color_batch, rgb8 -- carried out by a depth BATCH in pipelined order)
-  struct ColorPending { bool on = false; int kind = 0; int32_t n = 1; const void* imgs[nvbx::MAX_BATCH] = {}; int32_t rows = 0, cols = 0; float T[16 * nvbx::MAX_BATCH]; nvbx_camera cams[nvbx::MAX_BATCH]; };
+  // (frames[i] != nullptr: imgs[i] lives in a library-owned frame this mapper has RETAINED -- the caller's own frame of nvbx_frame_acquire, or the
+  //  frame the staged form copied a raw pointer's image into; let go of, with a fence, once the launches that read it are enqueued: frames.hip)
+  struct ColorPending { bool on = false; int kind = 0; int32_t n = 1; const void* imgs[nvbx::MAX_BATCH] = {}; void* frames[nvbx::MAX_BATCH] = {}; int32_t rows = 0, cols = 0; float T[16 * nvbx::MAX_BATCH]; nvbx_camera cams[nvbx::MAX_BATCH]; };
   bool color_deferral = true;        // the switch (default: on, staged -- nvbx_mapper_create; NVBX_COLOR_DEFERRAL=0 in the environment: off)
   // nvbx_mapper_set_color_deferral(m, 2): a held-back frame is COPIED into mapper-owned staging memory when it is held back (one asynchronous
   // device-to-device copy on the mapper's stream per frame) -- the caller may recycle or overwrite its image as soon as integrateColor has
   // returned, as without deferral.  One buffer per camera of a batch suffices: the copy of the next frame is stream-ordered behind the launches
   // that read the previous one.
   bool color_staging = true;
-  void* color_stage[nvbx::MAX_BATCH] = {}; size_t color_stage_bytes = 0;
   ColorPending color_pending;        // the held-back integrateColor
+  // frames of held-back colour images (frames.hip).  take_pending: the held-back call is being carried out -- its frames move to `consumed_frames`;
+  // release_consumed_frames (after the launches that read them are enqueued, or abandoned): refs dropped with the fence {h_mirror[4] >= seq}.
+  // h_mirror[4] is written by the next view-marking launch as its first action (TraceRiderT::fence_report = color_reads_enqueued at that time).
+  std::vector<void*> consumed_frames;
+  int32_t color_reads_enqueued = 0;      // fence sequence: bumped once per release_consumed_frames
+  int32_t fence_reports_enqueued = 0;    // the largest fence_report any ENQUEUED launch carries
+  ColorPending take_pending() { ColorPending c = color_pending; color_pending.on = false; for (int i = 0; i < nvbx::MAX_BATCH; i++) { if (c.frames[i]) consumed_frames.push_back(c.frames[i]); color_pending.frames[i] = nullptr; } return c; }
+  void release_consumed_frames() {
+    if (consumed_frames.empty()) return;
+    const int32_t seq = ++color_reads_enqueued;
+    for (void* f : consumed_frames) nvbx::frame_release_fenced(f, h_mirror + 4, seq, &fence_reports_enqueued, stream, this);
+    consumed_frames.clear();
+  }
+  int32_t next_fence_report() { __atomic_store_n(&fence_reports_enqueued, color_reads_enqueued, __ATOMIC_RELEASE); return color_reads_enqueued; }
   bool esdf_update_pending = false;  // an updateEsdf called while a colour frame was held back
   bool replaying = false;            // inside replay_deferred: the calls run as usual
   bool pipelined_order = false;      // inside the pipelined integrateDepth: marking passes empty their list, EDTs keep it (EsdfArgs)

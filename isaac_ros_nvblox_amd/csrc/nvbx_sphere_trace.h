@@ -123,6 +123,7 @@ __device__ inline void sphere_trace_worker(const DMap& m, const PoseSet<NB>& pos
 template <int NB>
 struct TraceRiderT { PoseSet<NB> ps; float* synth; int32_t srows, scols, max_steps; float max_len, eps_m; int32_t n_wg; int32_t n_tile_wg; int32_t lanes;
                      int32_t n_scan_wg; int4* cand; int32_t cand_cnt_idx, cand_reset_idx;
+                     int32_t fence_report;     // written to host_mirror[4] as the launch's first action: colour-reading launches enqueued before it (frames.hip)
                      int32_t n_mark_wg; };     // n_mark_wg > 0: behind those, the ESDF site marking of the held-back update (k_mark_view's EsdfArgs)
 using TraceRider = TraceRiderT<1>;
 

@@ -528,6 +528,9 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   extern __shared__ __align__(16) unsigned char smem[];
   int32_t tile_wg = (int32_t)blockIdx.x;      // this workgroup's number among the tiles
   NVBX_T(0, 0);
+  // this launch has STARTED, so every launch enqueued before it on the stream has finished -- among them the tr.fence_report colour-reading launches
+  // whose images' frames wait for exactly this news (frames.hip)
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&m.host_mirror[4], tr.fence_report, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (Sensor::kThreads == 256) {
     // riders: [EDT workers][sphere-tracing workers of a held-back colour frame (colour deferral)] -- before the tiles, or
     // (tr.n_tile_wg > 0) after them.  All counts are multiples of 8, so a workgroup's XCD (blockIdx.x & 7) is also its number's & 7.
@@ -1156,6 +1159,8 @@ static int launch_lidar_sparse(nvbx_mapper* m, const FrameSet<Img, 1>& fs, const
 
 template <typename Img, typename Sensor, int NB>
 static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sensor& sensor) {
+  // (frames of a held-back colour image this call carries out: let go of on every way out, behind the launches that read them)
+  struct ReleaseFrames { nvbx_mapper* m; ~ReleaseFrames() { m->release_consumed_frames(); } } release_frames{m};
   const int s = fs.f[0].subsample;
   for (int c = 0; c < fs.n; c++) {
     fs.f[c].n_ray_rows = (fs.f[c].rows + s - 1 + s - 1) / s;   // indices i with i*s < rows + s - 1
@@ -1213,6 +1218,7 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
       m->pending_marking_args(&tr.n_mark_wg, &ea);        // (the held-back integrateColor's marking pass, in call order: before its colour integration below)
     }
   }
+  tr.fence_report = m->next_fence_report();
   NVBX_LAUNCH_SMEM(m, (k_mark_view<Img, Sensor, NB>), dim3(tiles + edt_wg + tr.n_wg + tr.n_scan_wg + tr.n_mark_wg), dim3(Sensor::kThreads), mark_view_smem<Sensor>(edt_wg > 0), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
               (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)edt_wg, ea, tr);
   FrameSetC<PixRgb8, NB> fsc{}; int f_kind = 0; int32_t f_srows = 0, f_scols = 0;
@@ -1517,8 +1523,9 @@ extern "C" int nvbx_measure_depth(nvbx_mapper* m, const float* depth_dev, int32_
   const Frame& f = fs.f[0];
   // the view calculation against the local map: blocks in view are looked up / allocated exactly as integrateDepth would (they receive
   // their values when the gathered measurements are applied)
+  TraceRider no_riders{}; no_riders.fence_report = m->next_fence_report();
   NVBX_LAUNCH_SMEM(m, (k_mark_view<DepthF32, CameraSensor, 1>), dim3(mark_view_tile_wgs<CameraSensor>(f)), dim3(CameraSensor::kThreads), mark_view_smem<CameraSensor>(false), m->d, fs, CameraSensor{},
-              (int4*)m->view_list, (int32_t)m->capacity, (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)0, m->edt_args, TraceRider{});
+              (int4*)m->view_list, (int32_t)m->capacity, (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)0, m->edt_args, no_riders);
   m->premark_consumed = false;
   NVBX_LAUNCH(m, (k_measure_tsdf<DepthF32>), dim3((unsigned)std::min<int64_t>(m->capacity, 1024)), dim3(512), m->d, f, DepthF32{depth_dev}, CameraSensor{},
               (const int4*)m->view_list, (int32_t)m->capacity, reinterpret_cast<MeasRec*>(out_dev), count_dev, (int32_t)std::min<int64_t>(capacity_blocks, INT32_MAX));

@@ -56,8 +56,71 @@ class NvbxError(RuntimeError):
     pass
 
 
+def frame_pool_stats():
+    """(held, free, bytes, created, waits, syncs) of the library's frame pool (nvbx_frame_pool_stats)."""
+    out = (C.c_int64 * 6)()
+    _lib.load().nvbx_frame_pool_stats(out)
+    return tuple(int(v) for v in out)
+
+
 def _np_ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class ColorFrame:
+    """A colour image in a library-owned, reference-counted device frame (nvbx_frame_acquire, include/nvblox_hip.h): what nvblox::Image<Color>
+    device memory is in the C++ facade.  A mapper that holds integrate_color back RETAINS the frame instead of copying the image; `write` first makes
+    sure nobody else holds the frame and continues in another one if a mapper does (rotation) -- the node's one re-used colour buffer
+    (nvblox_node.hpp:484-488) without the staging copy."""
+
+    def __init__(self, rows, cols, channels=3, device=0):
+        self.lib = _lib.load()
+        self.rows, self.cols, self.channels, self.device = int(rows), int(cols), int(channels), int(device)
+        self.nbytes = self.rows * self.cols * self.channels
+        self._p = C.c_void_p()
+        self._acquire(_lib.STREAM_UNKNOWN)
+
+    def _acquire(self, stream):
+        p = C.c_void_p()
+        if self.lib.nvbx_frame_acquire(self.device, self.nbytes, stream, C.byref(p)) != 0:
+            raise NvbxError("nvbx_frame_acquire: %s" % self.lib.nvbx_last_error().decode())
+        self._p = p
+
+    @property
+    def ptr(self):
+        return self._p.value
+
+    def shared(self):
+        return self.lib.nvbx_frame_refcount(self._p) > 1
+
+    def write(self, src, stream=None):
+        """Overwrite the image from a torch CUDA tensor / numpy array of rows x cols x channels uint8: asynchronously on `stream` (a raw hipStream_t),
+        or with a blocking copy (stream=None: a writer the library knows nothing about).  Continues in another frame first when a mapper still holds
+        this one, or its launches may still be reading it."""
+        s = C.c_void_p(stream) if stream else _lib.STREAM_UNKNOWN
+        if self.lib.nvbx_frame_writable(self._p, s) == 0:      # a mapper holds it, or its launches may still be reading it (and not on this stream)
+            old = self._p
+            self._acquire(s)
+            self.lib.nvbx_frame_release(old)
+        if hasattr(src, "data_ptr"):
+            assert src.is_contiguous() and src.numel() * src.element_size() == self.nbytes
+            sp = C.c_void_p(src.data_ptr())
+        else:
+            a = np.ascontiguousarray(src, np.uint8); assert a.nbytes == self.nbytes
+            self._host_keep = a; sp = _np_ptr(a)
+        if self.lib.nvbx_frame_upload(self._p, sp, self.nbytes, s) != 0:
+            raise NvbxError("nvbx_frame_upload: %s" % self.lib.nvbx_last_error().decode())
+        return self
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p.value:
+            self.lib.nvbx_frame_release(self._p); self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Mapper:
@@ -86,12 +149,13 @@ class Mapper:
     def set_max_capacity(self, max_blocks):
         self._check(self.lib.nvbx_mapper_set_max_capacity(self._h, int(max_blocks)))
 
-    def set_color_deferral(self, enable, staged=False):
+    def set_color_deferral(self, enable, staged=True):
         """Hold integrateColor (and an updateEsdf behind it) back until the next integrateDepth carries them out in pipelined order (two
         launches per frame instead of four; include/nvblox_hip.h nvbx_mapper_set_color_deferral).  A NEW mapper does so in the staged form
         (enable=True, staged=True: the mapper copies a held-back frame into its own memory first, nothing observable changes but the time).
         staged=False (opt-in, zero-copy): the colour image handed to integrate_color must then stay valid and unchanged until the next call into
-        the mapper has returned.  enable=False: the classic order, every call launches its own kernels."""
+        the mapper has returned.  enable=False: the classic order, every call launches its own kernels.
+        (staged=True is the default here as in C and C++ -- ADVICE r04.)  An image in a ColorFrame is never copied, in either form."""
         self._check(self.lib.nvbx_mapper_set_color_deferral(self._h, (2 if staged else 1) if enable else 0))
 
     # -- ground plane (MultiMapper::ground_plane_estimator())
@@ -248,6 +312,11 @@ class Mapper:
 
     def integrate_color(self, rgb, T_L_C, cam):
         """rgb8 [rows, cols, 3] or bgra8 [rows, cols, 4] (the two encodings image_conversions.cpp:170-176 accepts)."""
+        if isinstance(rgb, ColorFrame):
+            T = self._T(T_L_C); k = self._cam(cam)
+            fn = self.lib.nvbx_integrate_color_bgra8 if rgb.channels == 4 else self.lib.nvbx_integrate_color
+            self._check(fn(self._h, C.c_void_p(rgb.ptr), rgb.rows, rgb.cols, _np_ptr(T), C.byref(k)))
+            return
         d = self._dev(rgb, self._torch.uint8)
         assert d.dim() == 3 and d.shape[2] in (3, 4)
         T = self._T(T_L_C); k = self._cam(cam)
@@ -267,6 +336,10 @@ class Mapper:
         return (self.lib.nvbx_integrate_depth, C.c_void_p(d.data_ptr()), d.shape[0], d.shape[1], _np_ptr(T), C.byref(k), (d, T, k))
 
     def prepare_color(self, rgb, T_L_C, cam):
+        if isinstance(rgb, ColorFrame):
+            assert rgb.channels == 3
+            T = self._T(T_L_C); k = self._cam(cam)
+            return (self.lib.nvbx_integrate_color, C.c_void_p(rgb.ptr), rgb.rows, rgb.cols, _np_ptr(T), C.byref(k), (rgb, T, k))
         d = self._dev(rgb, self._torch.uint8)
         assert d.dim() == 3 and d.shape[2] == 3
         T = self._T(T_L_C); k = self._cam(cam)
@@ -275,13 +348,14 @@ class Mapper:
     # -- camera batches (nvbx_integrate_depth_batch / _color_batch): n frames of one image size in ONE launch set
     def _batch(self, fn, imgs, dtype, poses, cams):
         n = len(imgs)
-        d = [self._dev(i, dtype) for i in imgs]
-        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in d])
+        d = [i if isinstance(i, ColorFrame) else self._dev(i, dtype) for i in imgs]
+        ptrs = (C.c_void_p * n)(*[t.ptr if isinstance(t, ColorFrame) else t.data_ptr() for t in d])
         T = np.ascontiguousarray(np.stack([self._T(p) for p in poses]).reshape(n, 16))
         if not isinstance(cams, (list, tuple)) or not isinstance(cams[0], (list, tuple, Camera)):
             cams = [cams] * n
         ks = (Camera * n)(*[self._cam(k) for k in cams])
-        return (fn, n, ptrs, d[0].shape[0], d[0].shape[1], _np_ptr(T), ks, (d, T))
+        r_, c_ = (d[0].rows, d[0].cols) if isinstance(d[0], ColorFrame) else (d[0].shape[0], d[0].shape[1])
+        return (fn, n, ptrs, r_, c_, _np_ptr(T), ks, (d, T))
 
     def prepare_depth_batch(self, depths, poses, cams):
         return self._batch(self.lib.nvbx_integrate_depth_batch, depths, self._torch.float32, poses, cams)

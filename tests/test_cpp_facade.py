@@ -105,6 +105,27 @@ def test_facade_matches_ctypes_path(hip_lib, tmp_path):
 
 
 @pytest.mark.gpu
+def test_recycled_color_image_is_retained_not_copied(hip_lib, tmp_path):
+    """tests/cpp/image_frames.cpp: the node's one re-used nvblox::ColorImage, written through the non-const dataPtr() before integrateColor and scribbled
+    over right after it (same stream / second stream / blocking host copy) -- default (deferred) mapper == classic mapper bit for bit, no k_stage_color."""
+    subprocess.check_call(["make", "-C", CPP, "image_frames"], stdout=subprocess.DEVNULL)
+    cam = H.SMALL_CAM
+    fr = H.frames(5, cam, color=True, stride=9)
+    path = tmp_path / "frames.bin"
+    with open(path, "wb") as f:
+        f.write(np.array([len(fr), cam[5], cam[4]], np.int32).tobytes())
+        f.write(np.array(cam[:4], np.float32).tobytes())
+        for d, rgb, T in fr:
+            f.write(np.asarray(T, np.float32).reshape(4, 4).tobytes())
+            f.write(np.ascontiguousarray(d, np.float32).tobytes())
+            f.write(np.ascontiguousarray(rgb, np.uint8).tobytes())
+    r = subprocess.run([os.path.join(CPP, "image_frames"), str(path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["failures"] == 0 and got["pool_syncs"] == 0, got
+
+
+@pytest.mark.gpu
 def test_facade_lidar_pointcloud(hip_lib):
     """MultiMapper::integrateDepth(Pointcloud, T, Lidar, ...) through the facade (nvblox_node.cpp:1382-1384,1397)."""
     exe = build_fake_node()
@@ -421,3 +442,78 @@ def test_rccl_fusion_example_runs(hip_lib):
     # only the used records travel: within one 64-record rounding step of the used bytes per frame, far below the fixed-size buffer
     assert got["payload_bytes_used"] <= got["payload_bytes_sent_per_rank"] <= got["payload_bytes_used"] + got["frames"] * 64 * 4112
     assert got["payload_bytes_sent_per_rank"] < 0.75 * got["buffer_bytes"]     # (a 160 x 120 wide-angle view of the whole room: ~600 blocks of the 1024-record buffer)
+
+
+def test_rccl_index_exchange_example_compiles():
+    subprocess.check_call(["make", "-C", CPP, "rccl_index_exchange"], stdout=subprocess.DEVNULL)
+    out = subprocess.run(["ldd", os.path.join(CPP, "rccl_index_exchange")], capture_output=True, text=True).stdout
+    assert "librccl" in out and "libnvblox_hip.so" in out
+
+
+@pytest.mark.gpu
+def test_rccl_index_exchange_cpp_host_equals_the_python_path(hip_lib, tmp_path):
+    """examples/rccl_index_exchange.cpp: the north-star collective (all-gather of updated block indices before the ESDF sweep) with a C++ host over
+    nvblox::MultiMapper::setBlockIndexExchange -- no Python, no torch.  Two ranks; on a box with fewer GPUs than ranks the transport is a stand-in
+    (device copies), protocol and launches are the same.  Rank 0's map must equal a mapper without any exchange, and every rank's checksums must
+    equal the same protocol driven through the ctypes mirror (dist.PipelinedDirtyBlockExchange's calls, three rotating buffer sets)."""
+    import torch
+    from isaac_ros_nvblox_amd import mapper as M
+    subprocess.check_call(["make", "-C", CPP, "rccl_index_exchange"], stdout=subprocess.DEVNULL)
+    cam = H.SMALL_CAM
+    n, ranks, warm = 9, 2, 5
+    fr = [H.frames(n, cam, color=True, stride=11), H.frames(n, cam, color=True, stride=11, yaw_offset_deg=180.0)]
+    path = tmp_path / "frames.bin"
+    with open(path, "wb") as f:
+        f.write(np.array([ranks, n, cam[5], cam[4]], np.int32).tobytes())
+        f.write(np.array(cam[:4], np.float32).tobytes())
+        for r in range(ranks):
+            for d, rgb, T in fr[r]:
+                f.write(np.asarray(T, np.float32).reshape(4, 4).tobytes())
+                f.write(np.ascontiguousarray(d, np.float32).tobytes())
+                f.write(np.ascontiguousarray(rgb, np.uint8).tobytes())
+    env = dict(os.environ, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1")
+    r_ = subprocess.run([os.path.join(CPP, "rccl_index_exchange"), "2", str(n), str(path)], capture_output=True, text=True, timeout=900, env=env)
+    assert r_.returncode == 0, r_.stdout[-800:] + r_.stderr[-2000:]
+    got = json.loads(r_.stdout.strip().splitlines()[-1])
+    assert got["ranks"] == 2 and got["rank0_equals_mapper_without_exchange"] is True and got["frames_per_s"] > 0
+    assert got["esdf_columns_marked_last_update"][1] >= got["esdf_columns_marked_last_update"][0]
+
+    # the same protocol through the ctypes mirror
+    dev = torch.device("cuda", 0)
+    ms = [M.Mapper(M.default_params(), block_capacity=1 << 14) for _ in range(ranks)]
+    for m_ in ms:
+        for q in range(ranks):
+            for d, rgb, T in fr[q]:
+                m_.integrate_depth(d, T, cam)
+        m_.update_esdf(); m_.synchronize()
+    bufs = [[torch.zeros((4097, 3), dtype=torch.int32, device=dev) for _ in range(3)] for _ in range(ranks)]
+    alls = [[torch.zeros((ranks, 4097, 3), dtype=torch.int32, device=dev) for _ in range(3)] for _ in range(ranks)]
+    pending = [None] * ranks
+    for i in range(warm + n):
+        u, slot = i % n, i % 3
+        for r in range(ranks):
+            ms[r].set_view_export(bufs[r][slot]); ms[r].integrate_depth(fr[r][u][0], fr[r][u][2], cam)
+        for r in range(ranks):
+            ms[r].synchronize()
+        for r in range(ranks):
+            for q in range(ranks):
+                alls[r][slot][q].copy_(bufs[q][slot])
+        torch.cuda.synchronize(dev)
+        for r in range(ranks):
+            if pending[r] is not None:
+                ms[r].mark_esdf_dirty_gathered(alls[r][pending[r]], ranks, r, 4096, deferred=True)
+            pending[r] = slot
+            ms[r].integrate_color(fr[r][u][1], fr[r][u][2], cam); ms[r].update_esdf()
+    for r in range(ranks):
+        ms[r].mark_esdf_dirty_gathered(alls[r][pending[r]], ranks, r, 4096)
+        ms[r].set_view_export(None); ms[r].update_esdf(); ms[r].synchronize()
+    for r in range(ranks):
+        c = got["per_rank"][r]
+        idx = ms[r].block_indices(M.LAYER_TSDF); blocks, _ = ms[r].get_blocks(M.LAYER_TSDF, idx)
+        w = blocks["weight"].astype(np.float64); d_ = blocks["distance"].astype(np.float64)
+        img, _ = ms[r].esdf_slice_image(1000.0)
+        known = img < 999.0
+        assert c["tsdf_blocks"] == len(idx) and c["color_blocks"] == ms[r].num_blocks(M.LAYER_COLOR) and c["esdf_blocks"] == ms[r].num_blocks(M.LAYER_ESDF), (r, c)
+        assert abs(c["tsdf_sum"] - float((d_ * w)[w > 0].sum())) <= 1e-6 * max(1.0, abs(c["tsdf_sum"]))
+        assert tuple(c["slice_shape"]) == img.shape and c["slice_known"] == int(known.sum())
+        assert abs(c["slice_sum"] - float(img[known].astype(np.float64).sum())) <= 1e-6 * max(1.0, abs(c["slice_sum"]))

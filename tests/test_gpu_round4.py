@@ -230,7 +230,7 @@ def test_staged_colour_deferral_survives_a_recycled_colour_buffer(oracle_mod, hi
         zero_copy = M.Mapper(pg, block_capacity=1 << 13, stream=stream.cuda_stream)
         classic.set_color_deferral(False)
         staged.set_color_deferral(True, staged=True); staged.set_profiling(True)
-        zero_copy.set_color_deferral(True)
+        zero_copy.set_color_deferral(True, staged=False)
         buf = torch.empty((cam[5], cam[4], 3), dtype=torch.uint8, device=dev)          # the host's one colour buffer
         noise = torch.randint(0, 255, buf.shape, dtype=torch.uint8, device=dev)
         for k, (d, rgb, T) in enumerate(H.frames(10, cam, stride=7)):
