@@ -2,7 +2,7 @@
 # After tools/gpu_round.sh TAG ... came back (gpurun merges gpurun_out/): copy the summaries the judge reads into profiles/.
 # Usage: tools/collect_round.sh TAG
 TAG=$1
-for W in camera camera_zc camera_k20 camera_mesh lidar decay multicam multicam8; do
+for W in camera camera_zc camera_k20 camera_mesh lidar decay multicam multicam8 node; do
   S=""; [ $W != camera ] && S="_$W"
   [ -d gpurun_out/$TAG/stats$S ] || continue
   if [ -d gpurun_out/$TAG/pmc_fetch$S ]; then

@@ -15,6 +15,7 @@ fi
 for W in "${WL[@]}"; do
   S=""; [ $W != camera ] && S="_$W"
   case $W in lidar) ARGS="--steps 100 --warmup 10"; PARGS="--steps 50 --warmup 5 --profile-run";; decay) ARGS="--steps 120 --warmup 24"; PARGS="--steps 60 --warmup 12";;
+             node) ARGS=""; PARGS="--no-parity";;
              camera_mesh) ARGS="--steps 100 --warmup 20 --with-mesh"; PARGS="--steps 100 --warmup 20 --profile-run --with-mesh";;
              camera_zc) ARGS="--zero-copy-deferral"; PARGS="--steps 100 --warmup 20 --profile-run --zero-copy-deferral";;
              camera_k20) ARGS="--steps 20 --warmup 5"; PARGS="--steps 20 --warmup 5 --profile-run";;
