@@ -214,7 +214,11 @@ int main(int argc, char** argv) {
     per_rank += b;
   }
   per_rank += "]";
-  std::printf("{\"ranks\": %d, \"gpus\": %d, \"transport\": \"%s\", \"frames_per_rank\": %d, \"image\": [%d, %d], \"frames_per_s\": %.1f, \"ms_per_frame_per_rank\": %.4f, "
+  // the parameters the mappers ran with (the facade's defaults), for a caller that drives the same protocol through another binding
+  nvbx_mapper_params pp{}; nvbx_mapper_get_params(mm[0]->background_mapper()->c_handle(), &pp);
+  std::string params_hex; { const unsigned char* b = reinterpret_cast<const unsigned char*>(&pp); char h[3]; for (size_t i = 0; i < sizeof(pp); i++) { std::snprintf(h, sizeof(h), "%02x", b[i]); params_hex += h; } }
+  std::printf("{\"params_hex\": \"%s\", ", params_hex.c_str());
+  std::printf("\"ranks\": %d, \"gpus\": %d, \"transport\": \"%s\", \"frames_per_rank\": %d, \"image\": [%d, %d], \"frames_per_s\": %.1f, \"ms_per_frame_per_rank\": %.4f, "
               "\"rank0_equals_mapper_without_exchange\": %s, \"esdf_columns_marked_last_update\": [%lld, %lld], \"per_rank\": %s}\n",
               ranks, std::min(ranks, ndev), rccl ? "rccl" : (ranks > 1 ? "stand-in (device copies, one stream)" : "none"), n_frames, rows, cols, ranks * n_frames / dt, dt / n_frames * 1e3,
               equal ? "true" : "false", (long long)c0.esdf_columns_marked, (long long)c1.esdf_columns_marked, per_rank.c_str());

@@ -201,6 +201,10 @@ struct nvbx_mapper {
   void pending_marking_args(int32_t* mark_wg, nvbx::EsdfArgs* ea_out);
   int pending_color_fused_args(void* fsc_out, int* kind, int32_t* srows, int32_t* scols);
   uint8_t* view_class = nullptr; int64_t view_class_cap = 0;        // LiDAR: per view record, 1 = updated by the beam-centric launch (tsdf.hip k_lidar_sparse)
+  // LiDAR view calculation over a dense grid (tsdf.hip k_mark_view_grid): one byte per block of the box around the sensor (cell-major, 64 B per
+  // 4 x 4 x 4 cell) + one byte per cell; all-zero between scans (k_scan_view_grid puts back what the scan set).  `view_grid_dirty`: a scan's
+  // launches were not all enqueued (an error return in between) -- the next scan clears the arrays first.
+  uint8_t* view_grid_fine = nullptr; int64_t view_grid_cells_cap = 0; bool view_grid_dirty = false;
   int32_t* view_export = nullptr; int64_t view_export_cap = 0;      // nvbx_set_view_export
   int reset_consumed_list();         // empty a consumed dirty list (tiny launch; rare paths only)
   int begin_dirtying() { const int rc = reset_consumed_list(); dirty_since_mark = true; return rc; }

@@ -321,6 +321,38 @@ __device__ inline void dda_jump(Dda& d, int32_t K, const float* inv) {
   while (have < K) { dda_step(d); have++; }
   while (have > K) { dda_unstep(d); have--; }
 }
+// The ray of depth pixel (prow, pcol) with measured depth `d` through the block grid: traversal state at the sensor's block, number of block
+// steps to the block of the end point min(d + truncation, max integration distance) (-1: no ray -- inactive lane or invalid depth), 1 / tdelta.
+template <typename Sensor>
+__device__ inline int32_t view_ray_setup(const Frame& f, const Sensor& sensor, bool& active, float d, int prow, int pcol, Dda& dd, float* inv_dt) {
+  int32_t nsteps = -1;
+  if (active) {
+    if (!(d > 0.0f)) active = false;
+    else {
+      float de = d + f.trunc;
+      if (f.max_dist > 0.0f && de > f.max_dist) de = f.max_dist;
+      float pc[3], pl[3];
+      sensor.ray_end(f, prow, pcol, de, pc);
+      apply_rt(f.R_LC, f.t_LC, pc[0], pc[1], pc[2], pl);
+      nsteps = 0;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const float s = f.t_LC[a] / f.block_size, t = pl[a] / f.block_size;
+        dd.cur[a] = (int32_t)floorf(s);
+        const int32_t end = (int32_t)floorf(t);
+        const int32_t db = end - dd.cur[a]; nsteps += db < 0 ? -db : db;
+        const float ray = t - s;
+        dd.step[a] = ray > 0.0f ? 1 : (ray < 0.0f ? -1 : 0);
+        const float corrected = dd.step[a] > 0 ? 1.0f : 0.0f;
+        const float dist_to_boundary = corrected - (s - (float)dd.cur[a]);
+        if (fabsf(ray) < 1e-9f) { dd.t0[a] = 2.0f; dd.dt[a] = 2.0f; }
+        else { dd.t0[a] = dist_to_boundary / ray; dd.dt[a] = (float)dd.step[a] / ray; inv_dt[a] = fabsf(ray); }
+        dd.tm[a] = dd.t0[a];
+      }
+    }
+  }
+  return nsteps;
+}
 // Flush: compact the set (ballot + popcount), then every key goes to HBM with the dependent round trips taken
 // PHASE-WISE over up to R keys per lane at once: (A) the first PD probe positions of every key are loaded together
 // (2 cover ~98 % of lookups at a room-sized map's load factor, 4 are used for the larger LiDAR maps), (B) resolved -- a key further down its probe chain, a new block, or a
@@ -602,33 +634,8 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
   NVBX_T(0, 1);
 
   Dda dd{};                                     // traversal state of this lane's ray (cur = block, n = crossings taken per axis)
-  int32_t nsteps = -1;
   float inv_dt[3] = {0.0f, 0.0f, 0.0f};          // 1 / tdelta per axis (= |ray| in blocks), for dda_jump
-  if (active) {
-    if (!(d > 0.0f)) active = false;
-    else {
-      float de = d + f.trunc;
-      if (f.max_dist > 0.0f && de > f.max_dist) de = f.max_dist;
-      float pc[3], pl[3];
-      sensor.ray_end(f, prow, pcol, de, pc);
-      apply_rt(f.R_LC, f.t_LC, pc[0], pc[1], pc[2], pl);
-      nsteps = 0;
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        const float s = f.t_LC[a] / f.block_size, t = pl[a] / f.block_size;
-        dd.cur[a] = (int32_t)floorf(s);
-        const int32_t end = (int32_t)floorf(t);
-        const int32_t db = end - dd.cur[a]; nsteps += db < 0 ? -db : db;
-        const float ray = t - s;
-        dd.step[a] = ray > 0.0f ? 1 : (ray < 0.0f ? -1 : 0);
-        const float corrected = dd.step[a] > 0 ? 1.0f : 0.0f;
-        const float dist_to_boundary = corrected - (s - (float)dd.cur[a]);
-        if (fabsf(ray) < 1e-9f) { dd.t0[a] = 2.0f; dd.dt[a] = 2.0f; }
-        else { dd.t0[a] = dist_to_boundary / ray; dd.dt[a] = (float)dd.step[a] / ray; inv_dt[a] = fabsf(ray); }
-        dd.tm[a] = dd.t0[a];
-      }
-    }
-  }
+  const int32_t nsteps = view_ray_setup(f, sensor, active, d, prow, pcol, dd, inv_dt);
   // this lane's share of the ray: steps [k0, k1]; the traversal is ENTERED at step k0 (dda_jump: no replay of the steps before it)
   int32_t k0 = 0, k1 = nsteps;
   if (NSEG > 1 && nsteps >= 0) {
@@ -707,6 +714,298 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
 #ifdef NVBX_WG_TIMES
   NVBX_TV(0, 2, t_flush); NVBX_TV(0, 6, (n_flush << 32) | n_keys); NVBX_T(0, 7);
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------ LiDAR view calculation over a dense "seen in this scan" grid
+// A 200 m scan walks its 16 k (sub-sampled) rays through ~10^6 blocks to find the ~112 k distinct ones.  k_mark_view<Lidar> above decides "first
+// ray through this block?" with one compare-and-swap per key on the hash entry's stamp; a first version of this path decided it with one returning
+// atomicOr per key on a bit of a dense grid.  Both take ~58 us, and the per-bundle time stamps (tools/wg_timeline_lidar_grid.py) say why: a bundle
+// with ONE far key waits 30-40 us for its atomic like a bundle with 500 -- ~10^5 returning atomics on scattered addresses are served at ~3 G/s by the
+// memory side, whoever issues them.  So the marking launch issues NO atomic at all:
+//   k_mark_view_grid : the walk (same code as k_mark_view: view_ray_setup, dda_jump, dda_step); a visited block is a plain STORE of 1 to its byte of a
+//                      dense grid around the sensor (idempotent: any number of rays may visit) + a store of 1 to the byte of its 4 x 4 x 4 cell in
+//                      a coarse map.  The grid is cell-major -- the 64 bytes of a cell are one 64-B line.  Within VG_NEAR blocks of the sensor,
+//                      where every ray passes the same few lines, a byte is stored only if it reads 0.
+//   k_scan_view_grid : reads the coarse map (0.8 MB for a 200 m box at 0.8 m blocks), the lines of the touched cells, and appends {tag, x, y, z} per
+//                      set byte to the view list -- one reservation per wavefront -- and puts every byte it found back to 0: the grid is all-zero
+//                      again when the scan's launches are done.
+//   k_resolve_view   : one lane per tagged record: hash lookup or insert (the wavefront's new blocks pop their slots together), entry stamp, slot
+//                      written into the record.
+// Blocks outside the box (none, if the box was sized from the sensor's range: a ray then ends inside by construction) take mark_block directly.
+// Same block set as k_mark_view<Lidar>; only the de-duplication differs.
+struct ViewGrid {
+  uint8_t* fine;           // byte cell * 64 + (lx & 3) + 4 (ly & 3) + 16 (lz & 3), cell = ((lz >> 2) * ncy + (ly >> 2)) * ncx + (lx >> 2), l = block - o
+  uint8_t* coarse;         // byte per cell (padded to a multiple of 4)
+  int32_t ox, oy, oz;      // block index of the box's minimum corner
+  int32_t ncx, ncy, ncz;   // cells per axis (<= 256: local block coordinates are 10 bits)
+  int32_t cx, cy, cz;      // the sensor's block
+  uint32_t tag;            // slot field of a record waiting for k_resolve_view: 0x80000000 | view frame id (never a slot: capacity <= 2^24)
+};
+#ifndef NVBX_VG_NEAR
+#define NVBX_VG_NEAR 0              // (0: every visit stores.  24 / 48: 19.3 / 19.9 us for the launch instead of 16.6 -- the stores were never what waited)
+#define NVBX_VG_CHUNK 16
+#endif
+constexpr int VG_NEAR = NVBX_VG_NEAR, VG_CHUNK = NVBX_VG_CHUNK;
+constexpr uint32_t VG_NONE = 0xFFFFFFFFu;
+
+template <typename Img>
+__global__ __launch_bounds__(64) void k_mark_view_grid(DMap m, FrameSet<Img, 1> fs, LidarSensor sensor, int4* view_list, int32_t list_cap,
+                                                       int32_t reset_esdf_dirty, int32_t fence_report, ViewGrid vg) {
+  constexpr int TR = LidarSensor::kTileRows, TC = LidarSensor::kTileCols, NSEG = LidarSensor::kSegments, C = VG_CHUNK;
+  static_assert(TR * TC * NSEG <= 64, "one wavefront per bundle of rays");
+  const int lane = (int)threadIdx.x;
+  const Frame& f = fs.f[0];
+  const Img& depth = fs.img[0];
+  NVBX_T(0, 0);
+  if (blockIdx.x == 0 && lane == 0) __hip_atomic_store(&m.host_mirror[4], fence_report, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);    // (k_mark_view: frames.hip's fence)
+  // XCD-aware numbering, as k_mark_view: the bundles of one XCD are a contiguous band of ray rows
+  const int tiles_x = (f.n_ray_cols + TC - 1) / TC, tiles_y = (f.n_ray_rows + TR - 1) / TR;
+  const int n_tiles = tiles_x * tiles_y, per_xcd = (n_tiles + NSH - 1) / NSH;
+  const int wg = (int)blockIdx.x;
+  const int tile = (wg & (NSH - 1)) * per_xcd + (wg >> 3);
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int ray = lane / NSEG, seg = lane % NSEG;
+  const int ri = ty * TR + ray / TC, ci = tx * TC + ray % TC;
+  bool active = (wg >> 3) < per_xcd && tile < n_tiles && ray < TR * TC && ri < f.n_ray_rows && ci < f.n_ray_cols;
+  int prow = ri * f.subsample; if (prow >= f.rows) prow = f.rows - 1;
+  int pcol = ci * f.subsample; if (pcol >= f.cols) pcol = f.cols - 1;
+  const float d = active ? depth(pix(prow, pcol, f.cols)) : 0.0f;
+  if (wg == 0 && lane == 0) m.counters[C_VIEW_COUNT + ((f.frame_id + 1) & 3)] = 0;   // next frame's counter
+  if (wg == 0 && lane < NSH) { *shc_at(m, S_LIDAR_SPARSE, lane, 0) = 0; *shc_at(m, S_LIDAR_SPARSE, lane, 1) = 0; }
+  if (reset_esdf_dirty && wg == 0 && lane < NSH) *shc_at(m, S_LIST_ESDF_DIRTY, lane, 0) = 0;
+  Dda dd{};
+  float inv_dt[3] = {0.0f, 0.0f, 0.0f};
+  const int32_t nsteps = view_ray_setup(f, sensor, active, d, prow, pcol, dd, inv_dt);
+  NVBX_TV(0, 1, wall_clock64() + (unsigned long long)(nsteps & 0));       // (the depth pixel has arrived, the ray is set up)
+  int32_t k0 = 0, k1 = nsteps;
+  if (NSEG > 1 && nsteps >= 0) {
+    const int32_t q = (nsteps + NSEG) / NSEG;
+    k0 = seg * q; k1 = min(nsteps, k0 + q - 1);
+    if (k0 > nsteps) k1 = -1;
+    else if (k0 > 0) dda_jump(dd, k0, inv_dt);
+  }
+  NVBX_TV(0, 2, wall_clock64() + (unsigned long long)(dd.cur[0] & 0));    // (this lane stands at the start of its segment)
+  int32_t* cnt = &m.counters[C_VIEW_COUNT + (f.frame_id & 3)];
+  const uint32_t NX = 4u * (uint32_t)vg.ncx, NY = 4u * (uint32_t)vg.ncy, NZ = 4u * (uint32_t)vg.ncz;
+  for (int32_t base = k0; __ballot(base <= k1) != 0ull; base += C) {
+    uint32_t code[VG_NEAR > 0 ? C : 1], w[VG_NEAR > 0 ? C : 1];
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      if (VG_NEAR > 0) code[i] = VG_NONE;
+      bool spill = false; u64 key = KEY_EMPTY;
+      if (base + i <= k1) {
+        const int32_t bx = dd.cur[0], by = dd.cur[1], bz = dd.cur[2];
+        if (block_in_workspace(f, bx, by, bz)) {
+          const uint32_t lx = (uint32_t)(bx - vg.ox), ly = (uint32_t)(by - vg.oy), lz = (uint32_t)(bz - vg.oz);
+          if (lx < NX && ly < NY && lz < NZ) {
+            const uint32_t cell = ((lz >> 2) * (uint32_t)vg.ncy + (ly >> 2)) * (uint32_t)vg.ncx + (lx >> 2);
+            const uint32_t at = cell * 64u + ((lx & 3u) | ((ly & 3u) << 2) | ((lz & 3u) << 4));
+            const uint32_t nx = (uint32_t)(bx - vg.cx + VG_NEAR), ny = (uint32_t)(by - vg.cy + VG_NEAR), nz = (uint32_t)(bz - vg.cz + VG_NEAR);
+            if (VG_NEAR > 0 && nx < 2u * VG_NEAR && ny < 2u * VG_NEAR && nz < 2u * VG_NEAR) code[VG_NEAR > 0 ? i : 0] = at;      // (looked at first, below)
+            else { vg.fine[at] = 1; vg.coarse[cell] = 1; }
+          } else { spill = true; key = pack_key(bx, by, bz); }
+        }
+        dda_step(dd);
+      }
+      if (__ballot(spill)) {                     // outside the box (a box sized from the sensor's range holds every ray): the hash decides
+        int4 rec = make_int4(0, 0, 0, 0);
+        const bool first = spill && mark_block(m, key, f.frame_id, f.cam_bit, &rec);
+        view_append(cnt, view_list, list_cap, first, rec, lane);
+      }
+    }
+    if (base == k0) NVBX_TV(0, 3, wall_clock64());
+    if (VG_NEAR > 0) {
+      // near the sensor: the chunk's bytes are loaded together and stored only where they read 0 (a stale 0 costs a store, nothing else)
+#pragma unroll
+      for (int i = 0; i < C; i++) { w[i] = 1u; if (code[i] != VG_NONE) w[i] = (uint32_t)vg.fine[code[i]]; }
+#pragma unroll
+      for (int i = 0; i < C; i++) if (code[i] != VG_NONE && !w[i]) { vg.fine[code[i]] = 1; vg.coarse[code[i] >> 6] = 1; }
+      if (base == k0) NVBX_TV(0, 4, wall_clock64() + (unsigned long long)(w[0] & 0u));
+    }
+  }
+  NVBX_T(0, 7);
+}
+
+// Up to K keys per lane -> pool slots, the dependent round trips taken together: the first PD probe positions of every key, then the inserts of
+// the blocks that are new (compare-and-swap on the entries; the wavefront's winners pop their slots with ONE atomicSub on the free-stack top and
+// one atomicMax on the high-water mark -- flush_set's B'), then whatever is left (a longer probe chain, a lost insert) by hash_insert.  The caller
+// OWNS these keys for the launch (nobody else looks them up or stamps them), so the entry stamp is a plain store.  Whole wavefront must call.
+template <int K, int PD>
+__device__ inline void resolve_keys(const DMap& m, const u64 (&key)[K], const bool (&valid)[K], uint32_t want, uint32_t (&slot)[K], int lane) {
+  uint32_t h[K]; uint4 e[K][PD];
+#pragma unroll
+  for (int k = 0; k < K; k++) { int32_t x, y, z; unpack_key(key[k], &x, &y, &z); h[k] = valid[k] ? table_pos(m, x, y, z) : 0u; }
+#pragma unroll
+  for (int k = 0; k < K; k++) if (valid[k]) {
+#pragma unroll
+    for (int q = 0; q < PD; q++) e[k][q] = ld_entry(m, (h[k] + q) & m.mask);
+  }
+  bool done[K], ins[K], won[K]; uint32_t hpos[K];
+  bool any_ins = false;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    done[k] = false; ins[k] = false; won[k] = false; hpos[k] = 0u; slot[k] = SLOT_NONE;
+    if (valid[k]) {
+      bool open = true; int qe = -1;
+#pragma unroll
+      for (int q = 0; q < PD; q++) {
+        const u64 kq = ((u64)e[k][q].y << 32) | (u64)e[k][q].x;
+        if (open && !done[k] && kq == key[k]) { slot[k] = e[k][q].z; hpos[k] = (h[k] + q) & m.mask; done[k] = true; }
+        if (open && kq == KEY_EMPTY) { open = false; if (!done[k]) qe = q; }
+      }
+      if (done[k] && slot[k] == SLOT_INVALID) done[k] = false;            // (being inserted by somebody else right now: hash_insert below waits)
+      else if (!done[k] && qe >= 0) { ins[k] = true; any_ins = true; hpos[k] = (h[k] + qe) & m.mask; }
+    }
+  }
+  if (__ballot(any_ins)) {
+    u64 oldk[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) if (ins[k]) oldk[k] = atomicCAS(&m.table[hpos[k]].key, KEY_EMPTY, key[k]);
+    int32_t wtotal = 0, wpre[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      won[k] = ins[k] && oldk[k] == KEY_EMPTY;
+      const u64 mask = __ballot(won[k]);
+      wpre[k] = wtotal + (int32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      wtotal += (int32_t)__popcll(mask);
+    }
+    if (wtotal) {
+      int32_t top = 0;
+      if (lane == 0) {
+        top = atomicSub(&m.counters[C_FREE_TOP], wtotal);
+        if (top < wtotal) { atomicAdd(&m.counters[C_FREE_TOP], wtotal - (top > 0 ? top : 0)); atomicExch(&m.counters[C_OVERFLOW], 1); }     // pool exhausted: give back what was not there
+      }
+      top = __shfl(top, 0);
+      int32_t hwm = 0;
+#pragma unroll
+      for (int k = 0; k < K; k++) if (won[k]) {
+        const int32_t idx = top - 1 - wpre[k];
+        slot[k] = idx >= 0 ? m.free_stack[idx] : SLOT_NONE;
+        if (slot_ok(slot[k])) {
+          int32_t x, y, z; unpack_key(key[k], &x, &y, &z);
+          m.slot_index[3 * slot[k]] = x; m.slot_index[3 * slot[k] + 1] = y; m.slot_index[3 * slot[k] + 2] = z;
+          m.slot_entry[slot[k]] = hpos[k];
+          atomicOr(&m.slot_flags[slot[k]], F_TSDF);
+          hwm = max(hwm, (int32_t)slot[k] + 1);
+        }
+        __hip_atomic_store(&m.table[hpos[k]].slot, slot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        done[k] = true;
+      }
+#pragma unroll
+      for (int o = 32; o; o >>= 1) hwm = max(hwm, __shfl_xor(hwm, o));
+      if (lane == 0 && hwm) atomicMax(&m.counters[C_HIGH_WATER], hwm);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) if (valid[k]) {
+    if (!done[k]) {
+      int32_t x, y, z; unpack_key(key[k], &x, &y, &z);
+      bool is_new;
+      const int32_t hi = hash_insert(m, x, y, z, F_TSDF, &is_new);
+      if (hi < 0) { slot[k] = SLOT_NONE; continue; }
+      hpos[k] = (uint32_t)hi;
+      uint32_t s = SLOT_INVALID;
+      while (s == SLOT_INVALID) s = ld_slot_acquire(&m.table[hi]);
+      slot[k] = s;
+    }
+    m.table[hpos[k]].stamp = want;
+  }
+}
+
+// The launches behind k_mark_view_grid.  k_scan_view_grid: a wavefront takes four 64-B lines of the coarse map (256 cells; the four lines from
+// four far-apart places: the cells around the sensor are all touched and lie in a few hundred neighbouring lines -- taken as consecutive lines they
+// gave a few wavefronts 60 cells each and the launch 28 us), lists the touched cells in LDS, reads their lines (four lanes x 16 bytes per cell,
+// sixteen cells per round) once to count and once more -- from the L2 -- to write {tag, x, y, z} per set byte behind ONE reservation; whatever it
+// found set goes back to 0.
+__device__ inline int32_t vg_nonzero_bytes(uint32_t b) { return (int32_t)((b & 0xFFu) != 0u) + (int32_t)((b & 0xFF00u) != 0u) + (int32_t)((b & 0xFF0000u) != 0u) + (int32_t)((b >> 24) != 0u); }
+constexpr int VG_SCAN_WAVES = 8;          // wavefronts per scanning workgroup: ONE reservation per workgroup (3 000 per-wavefront reservations on the
+                                          // view counter were most of a 15 us launch: returning atomics on one address are served one after the other)
+__global__ __launch_bounds__(64 * VG_SCAN_WAVES) void k_scan_view_grid(DMap m, uint32_t frame_id, int4* view_list, int32_t list_cap, ViewGrid vg) {
+  __shared__ uint32_t s_cells[VG_SCAN_WAVES][256];
+  __shared__ int32_t s_total[VG_SCAN_WAVES], s_base;
+  int32_t* cnt = &m.counters[C_VIEW_COUNT + (frame_id & 3)];
+  const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+  const int32_t n_cells = vg.ncx * vg.ncy * vg.ncz, n_words = (n_cells + 3) >> 2, n_lines = (n_words + 15) >> 4;
+  const int32_t n_waves = (int32_t)gridDim.x * VG_SCAN_WAVES, me = (int32_t)blockIdx.x * VG_SCAN_WAVES + wave;       // (4 n_waves >= n_lines: one pass)
+  uint32_t* cw = reinterpret_cast<uint32_t*>(vg.coarse);
+  uint4* fq = reinterpret_cast<uint4*>(vg.fine);
+  uint32_t* cells = s_cells[wave];
+  const int32_t line = me + (lane >> 4) * n_waves;
+  const int32_t i = line * 16 + (lane & 15);
+  const uint32_t v = (line < n_lines && i < n_words) ? cw[i] : 0u;
+  if (v) cw[i] = 0u;
+  int32_t n = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const bool t = ((v >> (8 * k)) & 0xFFu) != 0u;
+    const u64 mask = __ballot(t);
+    if (t) cells[n + (int32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)(4 * i + k);
+    n += (int32_t)__popcll(mask);
+  }
+  const int sub = lane >> 2, part = lane & 3;             // sixteen cells per round, four lanes (16 bytes each) per cell
+  int32_t mine = 0;
+  for (int32_t it = 0; it < n; it += 16) {
+    uint4 b = make_uint4(0u, 0u, 0u, 0u);
+    if (it + sub < n) b = fq[(size_t)cells[it + sub] * 4 + part];
+    mine += vg_nonzero_bytes(b.x) + vg_nonzero_bytes(b.y) + vg_nonzero_bytes(b.z) + vg_nonzero_bytes(b.w);
+  }
+  int32_t total = mine;
+#pragma unroll
+  for (int o = 32; o; o >>= 1) total += __shfl_xor(total, o);
+  if (lane == 0) s_total[wave] = total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t all = 0;
+#pragma unroll
+    for (int w = 0; w < VG_SCAN_WAVES; w++) all += s_total[w];
+    s_base = all ? atomicAdd(cnt, all) : 0;
+  }
+  __syncthreads();
+  if (!total) return;
+  int32_t pos = s_base;
+#pragma unroll
+  for (int w = 0; w < VG_SCAN_WAVES; w++) if (w < wave) pos += s_total[w];
+  for (int32_t it = 0; it < n; it += 16) {
+    const bool have = it + sub < n;
+    const uint32_t cell = have ? cells[it + sub] : 0u;
+    uint4 b = make_uint4(0u, 0u, 0u, 0u);
+    if (have) b = fq[(size_t)cell * 4 + part];
+    if (b.x | b.y | b.z | b.w) fq[(size_t)cell * 4 + part] = make_uint4(0u, 0u, 0u, 0u);
+    const int32_t cxi = (int32_t)(cell % (uint32_t)vg.ncx), cyi = (int32_t)((cell / (uint32_t)vg.ncx) % (uint32_t)vg.ncy), czi = (int32_t)(cell / ((uint32_t)vg.ncx * (uint32_t)vg.ncy));
+    const uint32_t bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (__ballot(bw[q] != 0u) == 0ull) continue;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const bool t = ((bw[q] >> (8 * k)) & 0xFFu) != 0u;
+        const u64 mask = __ballot(t);
+        if (t) {
+          const int32_t at = pos + (int32_t)__popcll(mask & ((1ull << lane) - 1ull));
+          const int j = part * 16 + q * 4 + k;               // byte of the cell: lx & 3 | (ly & 3) << 2 | (lz & 3) << 4
+          if (at < list_cap) view_list[at] = make_int4((int32_t)vg.tag, vg.ox + 4 * cxi + (j & 3), vg.oy + 4 * cyi + ((j >> 2) & 3), vg.oz + 4 * czi + (j >> 4));
+        }
+        pos += (int32_t)__popcll(mask);
+      }
+    }
+  }
+}
+// k_resolve_view: the records the scan left tagged, one per lane -- the slot replaces the tag (records of blocks outside the box carry their slot already)
+__global__ __launch_bounds__(256) void k_resolve_view(DMap m, uint32_t frame_id, int4* view_list, int32_t list_cap, uint32_t tag) {
+  const int32_t n = min(m.counters[C_VIEW_COUNT + (frame_id & 3)], list_cap);
+  const uint32_t want = (frame_id << 8) | 1u;
+  const int lane = (int)(threadIdx.x & 63);
+  for (int32_t i0 = (int32_t)blockIdx.x * 256 + (int32_t)(threadIdx.x & ~63u); i0 < n; i0 += (int32_t)gridDim.x * 256) {
+    const int32_t i = i0 + lane;
+    int4 rec = make_int4(0, 0, 0, 0);
+    if (i < n) rec = view_list[i];
+    u64 key[1]; bool valid[1]; uint32_t slot[1];
+    valid[0] = i < n && (uint32_t)rec.x == tag;
+    key[0] = pack_key(rec.y, rec.z, rec.w);
+    if (__ballot(valid[0]) == 0ull) continue;
+    resolve_keys<1, 2>(m, key, valid, want, slot, lane);
+    if (valid[0]) view_list[i].x = (int32_t)slot[0];
+  }
 }
 
 // A wave-uniform value the inner loop uses as a VALU operand, parked in a vector register: the LiDAR instantiation needs ~100 scalar
@@ -1157,6 +1456,58 @@ static int launch_lidar_sparse(nvbx_mapper* m, const FrameSet<Img, 1>& fs, const
   return NVBX_OK;
 }
 
+// LiDAR view calculation over the dense grid (k_mark_view_grid, k_scan_view_grid, k_resolve_view) instead of k_mark_view; *used = false: the caller
+// launches k_mark_view (cameras; a scan without a range limit or with a box beyond the grid's addressing / memory cap; NVBX_LIDAR_VIEW_GRID=0)
+template <typename Img, typename Sensor, int NB>
+static int launch_view_grid(nvbx_mapper*, const FrameSet<Img, NB>&, const Sensor&, int, int32_t, bool* used) { *used = false; return NVBX_OK; }
+template <typename Img>
+static int launch_view_grid(nvbx_mapper* m, const FrameSet<Img, 1>& fs, const LidarSensor& sensor, int tiles, int32_t fence_report, bool* used) {
+  *used = false;
+  static const int enabled = getenv("NVBX_LIDAR_VIEW_GRID") ? atoi(getenv("NVBX_LIDAR_VIEW_GRID")) : 1;       // (A/B: 0 = k_mark_view<Lidar>)
+  const Frame& f = fs.f[0];
+  if (!enabled || !(f.max_dist > 0.0f) || m->capacity > (1ll << 24)) return NVBX_OK;
+  // the box: every ray ends within max_dist of the sensor; along z the beams' elevation range bounds it (|world z of a unit beam| <=
+  // hypot(R20, R21) cos(el) + |R22 sin(el)|, elevation table rows on the host: ensure_lidar_tables)
+  const double reach = (double)f.max_dist / (double)f.block_size;
+  double wz = 0.0;
+  const double hxy = std::hypot((double)f.R_LC[6], (double)f.R_LC[7]);
+  for (int k = 0; k < sensor.l.rows; k++) wz = std::max(wz, hxy * std::fabs((double)m->lidar_host[2 * (size_t)k + 1]) + std::fabs((double)f.R_LC[8] * (double)m->lidar_host[2 * (size_t)k]));
+  const int64_t H = (int64_t)std::ceil(reach) + 2, Hz = std::min<int64_t>(H, (int64_t)std::ceil(reach * std::min(1.0, wz)) + 2);
+  const int64_t ncx = (2 * H + 1 + 3) / 4, ncz = (2 * Hz + 1 + 3) / 4;
+  const int64_t cells = ncx * ncx * ncz;
+  static const int64_t cap_mb = getenv("NVBX_VIEW_GRID_MAX_MB") ? atoll(getenv("NVBX_VIEW_GRID_MAX_MB")) : 128;
+  if (ncx > 256 || ncz > 256 || cells * 64 > (cap_mb << 20)) return NVBX_OK;
+  const size_t coarse_bytes = ((size_t)cells + 3) & ~(size_t)3;
+  if (m->view_grid_cells_cap < cells) {
+    NVBX_HIP(hipStreamSynchronize(m->stream));
+    if (m->view_grid_fine) NVBX_HIP(hipFree(m->view_grid_fine));
+    m->view_grid_fine = nullptr; m->view_grid_cells_cap = 0;
+    NVBX_HIP(hipMalloc(&m->view_grid_fine, (size_t)cells * 64 + coarse_bytes));      // [fine: 64 B per cell][coarse: 1 B per cell]
+    m->view_grid_cells_cap = cells; m->view_grid_dirty = true;
+  }
+  if (m->view_grid_dirty) NVBX_HIP(hipMemsetAsync(m->view_grid_fine, 0, (size_t)m->view_grid_cells_cap * 64 + (((size_t)m->view_grid_cells_cap + 3) & ~(size_t)3), m->stream));
+  m->view_grid_dirty = true;                 // until all three launches are enqueued
+  ViewGrid vg{};
+  vg.fine = m->view_grid_fine; vg.coarse = m->view_grid_fine + (size_t)m->view_grid_cells_cap * 64;
+  vg.cx = (int32_t)std::floor(f.t_LC[0] / f.block_size); vg.cy = (int32_t)std::floor(f.t_LC[1] / f.block_size); vg.cz = (int32_t)std::floor(f.t_LC[2] / f.block_size);
+  vg.ox = vg.cx - (int32_t)H; vg.oy = vg.cy - (int32_t)H; vg.oz = vg.cz - (int32_t)Hz;
+  vg.ncx = (int32_t)ncx; vg.ncy = (int32_t)ncx; vg.ncz = (int32_t)ncz;
+  vg.tag = 0x80000000u | f.frame_id;
+  NVBX_LAUNCH(m, (k_mark_view_grid<Img>), dim3(tiles), dim3(64), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity, (int32_t)(m->premark_consumed ? 1 : 0), fence_report, vg);
+  // the resolving launch: one tagged record per lane -- as many as the last finished scan had in view (+ 25 %; a hint only, it grid-strides)
+  // the scan: a wavefront per four lines (256 cells) of the coarse map, VG_SCAN_WAVES wavefronts per workgroup, everything in one pass
+  const int64_t coarse_lines = ((cells + 3) / 4 + 15) / 16;
+  const int64_t scan_wg = (coarse_lines + 4 * VG_SCAN_WAVES - 1) / (4 * VG_SCAN_WAVES);
+  NVBX_LAUNCH(m, k_scan_view_grid, dim3((unsigned)scan_wg), dim3(64 * VG_SCAN_WAVES), m->d, f.frame_id, (int4*)m->view_list, (int32_t)m->capacity, vg);
+  const int64_t n_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[2], __ATOMIC_RELAXED));
+  const int64_t rec_wg = n_hint == 0 ? 512 : std::max<int64_t>(8, std::min<int64_t>(2048, (n_hint + n_hint / 4 + 255) / 256));
+  NVBX_LAUNCH(m, k_resolve_view, dim3((unsigned)rec_wg), dim3(256), m->d, f.frame_id, (int4*)m->view_list, (int32_t)m->capacity, vg.tag);
+  NVBX_HIP(hipGetLastError());
+  m->view_grid_dirty = false;
+  *used = true;
+  return NVBX_OK;
+}
+
 template <typename Img, typename Sensor, int NB>
 static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sensor& sensor) {
   // (frames of a held-back colour image this call carries out: let go of on every way out, behind the launches that read them)
@@ -1219,6 +1570,9 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
     }
   }
   tr.fence_report = m->next_fence_report();
+  bool grid_view = false;
+  { const int rc = launch_view_grid(m, fs, sensor, tiles, tr.fence_report, &grid_view); if (rc) return rc; }
+  if (!grid_view)
   NVBX_LAUNCH_SMEM(m, (k_mark_view<Img, Sensor, NB>), dim3(tiles + edt_wg + tr.n_wg + tr.n_scan_wg + tr.n_mark_wg), dim3(Sensor::kThreads), mark_view_smem<Sensor>(edt_wg > 0), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
               (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)edt_wg, ea, tr);
   FrameSetC<PixRgb8, NB> fsc{}; int f_kind = 0; int32_t f_srows = 0, f_scols = 0;

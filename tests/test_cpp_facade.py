@@ -480,7 +480,8 @@ def test_rccl_index_exchange_cpp_host_equals_the_python_path(hip_lib, tmp_path):
 
     # the same protocol through the ctypes mirror
     dev = torch.device("cuda", 0)
-    ms = [M.Mapper(M.default_params(), block_capacity=1 << 14) for _ in range(ranks)]
+    pg = M.Params.from_buffer_copy(bytes.fromhex(got["params_hex"]))          # (the facade's defaults, as the C++ mappers ran: include/nvblox/mapper/mapper_params.h)
+    ms = [M.Mapper(pg, block_capacity=1 << 14) for _ in range(ranks)]
     for m_ in ms:
         for q in range(ranks):
             for d, rgb, T in fr[q]:

@@ -139,7 +139,7 @@ def test_frame_api_contract(oracle_mod, hip_lib):
 
 
 def test_pool_backpressure_when_the_host_runs_far_ahead(oracle_mod, hip_lib, monkeypatch):
-    """A host that is several frames ahead of the GPU (here: the mapper's stream is kept busy by ~30 ms of matrix products first) with a writer on a
+    """A host that is several frames ahead of the GPU (here: the mapper's stream is kept busy by a ~0.2 s spin kernel first) with a writer on a
     stream the mapper knows nothing about: the pool grows to its cap (2 here), then nvbx_frame_acquire WAITS for the oldest fence -- it polls the
     progress word, the queue is not drained -- and the map still equals the classic one."""
     import torch
@@ -154,16 +154,19 @@ def test_pool_backpressure_when_the_host_runs_far_ahead(oracle_mod, hip_lib, mon
     classic.set_color_deferral(False)
     fr = H.frames(6, cam, stride=11)
     d_dev = [torch.from_numpy(d).to(dev) for d, _, _ in fr]; c_dev = [torch.from_numpy(c).to(dev) for _, c, _ in fr]
-    big = torch.randn((8192, 8192), device=dev)
     torch.cuda.synchronize(dev)
     for k in range(6):
         classic.integrate_depth(d_dev[k], fr[k][2], cam); classic.integrate_color(c_dev[k], fr[k][2], cam); classic.update_esdf()
     classic.synchronize()
+    # (two frames first, then an empty map again: the lazily allocated buffers of the pipelined frame exist -- a hipMalloc in the middle of the
+    #  loop below would wait for the busy stream and the host would never get ahead)
+    for k in range(2):
+        owned.integrate_depth(d_dev[k], fr[k][2], cam); owned.integrate_color(c_dev[k], fr[k][2], cam); owned.update_esdf()
+    owned.integrate_depth(d_dev[2], fr[2][2], cam); owned.clear(); owned.synchronize()
     stats0 = M.frame_pool_stats()
     img = M.ColorFrame(cam[5], cam[4], 3, 0)
     with torch.cuda.stream(ms):
-        for _ in range(5):
-            big = big @ big * 1e-4                       # the mapper's stream is busy: every launch below queues up behind this
+        torch.cuda._sleep(int(4e8))                      # the mapper's stream is busy (a spin kernel, ~0.2 s): every launch below queues up behind this
     for k in range(6):
         T = fr[k][2]
         owned.integrate_depth(d_dev[k], T, cam)

@@ -8,7 +8,7 @@ B=build/variant_$NAME; mkdir -p $B isaac_ros_nvblox_amd/variants
 C=isaac_ros_nvblox_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-result $EXTRA"
 PIDS=()
-for f in mapper tsdf esdf color mesh maintenance convert esdf3d dynamics ground; do
+for f in mapper tsdf esdf color mesh maintenance convert esdf3d dynamics ground frames; do
   rm -f $B/$f.o
   ( /opt/rocm/bin/hipcc $FLAGS -c $C/$f.hip -o $B/$f.o ) &
   PIDS+=($!)
