@@ -64,6 +64,15 @@ def algorithmic_bytes(kernel, c, rows, cols, sub_ray=4, sub_trace=4, n_cam=1, tr
         # table entries and ~21 voxels read + written (8-byte voxels moved as 32-byte sectors)
         Ns = c.get("lidar_blocks_beam_centric", 0)
         return Nv * 17 + Ns * (64 * 4 + 130 * 4 + 21 * 64)
+    if kernel.startswith("k_mark_view_grid"):
+        # LiDAR view calculation over the dense grid: sub-sampled range image read; per block in view one byte of the grid and one
+        # byte of the coarse cell map stored (visits beyond the first store the same bytes again: not counted)
+        return (rows // sub_ray) * (cols // sub_ray) * 4 + Nv * 2
+    if kernel.startswith("k_scan_view_grid"):
+        # the coarse cell map read (and its touched bytes cleared), the set bytes read and cleared, one 16-byte record per block written
+        return c.get("view_grid_cells", 0) + Nv * (1 + 1 + 16)
+    if kernel.startswith("k_resolve_view"):
+        return Nv * (16 + 16 + 4 + 4)                  # record read, hash entry read, entry stamp + the record's slot written
     if kernel.startswith("k_mark_view"):
         own = n_cam * (rows // sub_ray) * (cols // sub_ray) * 4 + Nv * 16 * 2           # sub-sampled depth read + one hash entry RMW per block in view
         if trace_in_mark_view or fused:
@@ -430,7 +439,38 @@ def main_lidar(args):
     prof = g.profile(); g.set_profiling(False)
     c = g.counters(); counts = dict(c); counts["tsdf_blocks_in_view"] = float(np.mean(nv)); counts["lidar_blocks_beam_centric"] = float(np.mean(nsp))
     rows, cols = lidar[1], lidar[0]
+    # cells of the view grid's coarse map (tsdf.hip launch_view_grid: box = range / block size + 2 blocks each way, z from the elevation range of a level sensor)
+    reach = 200.0 / (8 * p.voxel_size); Hh = int(np.ceil(reach)) + 2; Hz = min(Hh, int(np.ceil(reach * np.sin(max(abs(lidar[3]), abs(lidar[4]))))) + 2)
+    counts["view_grid_cells"] = ((2 * Hh + 1 + 3) // 4) ** 2 * ((2 * Hz + 1 + 3) // 4)
     kern, evo, emp = kernel_table(prof, counts, ms, n2, lambda k, cc: algorithmic_bytes(k, cc, rows, cols, sub_ray=2), load_pmc("lidar"))
+    # the timed loop once more against the checker (outside the timed region): the nu scans from an empty map; view sets per scan, block index
+    # set at the end, and every voxel of a seeded sample of the blocks
+    parity = None
+    if not args.no_parity and world == 1:
+        import oracle
+        oracle.set_num_threads(min(8, os.cpu_count() or 1))
+        o = oracle.OracleMap(copy_params(oracle, g.params))
+        g.clear(); views_equal = True; t_par = time.perf_counter()
+        for i in range(nu):
+            g.integrate_prepared(largs[i]); o.integrate_lidar_depth(host[i][0], host[i][1], lidar)
+            vg_ = np.asarray(g.last_view()).reshape(-1, 3); vo_ = np.asarray(o.last_view()).reshape(-1, 3)
+            views_equal = views_equal and len(vg_) == len(vo_) and set(map(tuple, vg_.tolist())) == set(map(tuple, vo_.tolist()))
+        ig, io = g.block_indices(M.LAYER_TSDF), o.block_indices(oracle.L_TSDF)
+        same = bool(np.array_equal(ig, io)); worst = 0.0; n_cmp = 0
+        if same and len(io):
+            sel = io[np.random.default_rng(5).choice(len(io), size=min(4096, len(io)), replace=False)]
+            bg, found = g.get_blocks(M.LAYER_TSDF, sel)
+            for k_, idx in enumerate(sel):
+                b = o.get_block(oracle.L_TSDF, idx)
+                worst = max(worst, float(np.abs(bg[k_]["distance"].astype(np.float64) - b["distance"]).max()), float(np.abs(bg[k_]["weight"].astype(np.float64) - b["weight"]).max()))
+            n_cmp = len(sel); same = same and bool(found.all())
+        parity = {"scans": nu, "views_equal_every_scan": bool(views_equal), "blocks": int(len(ig)), "blocks_checker": int(len(io)), "index_sets_equal": same,
+                  "blocks_compared_voxelwise": int(n_cmp), "max_abs_tsdf": worst, "ok": bool(views_equal and same and worst <= 1e-4), "checker_s": round(time.perf_counter() - t_par, 2),
+                  "what": "the %d-scan loop from an empty map once more, every scan mirrored on oracle/nvblox_oracle.c: blocks in view per scan (sets), the "
+                          "block index set at the end, every voxel of a seeded sample of blocks; outside the timed region (all blocks of two scans: "
+                          "tests/test_gpu_full_size.py)" % nu}
+        for i in range(nu):      # (the map as the profiling passes left it)
+            g.integrate_prepared(largs[i % nu])
     cpu = None
     if not args.no_cpu_baseline:
         import oracle
@@ -461,7 +501,11 @@ def main_lidar(args):
            "kernels": kernels_json(kern),
            "roofline": roofline_of(kern, ms, evo, emp, "longest kernel of the scan; durations = hipEvent spans on the mapper stream minus the calibrated "
                                    "instrumentation cost; compare profiles/*_lidar_kernel_stats.csv", skip=()),
-           "cpu_baseline": cpu}
+           "cpu_baseline": cpu, "parity": parity}
+    out["roofline"]["traffic_source"] = pmc_source()
+    # the scan as a whole by what its launches move (their own algorithmic bytes, not SURVEY 8d's one-lane-per-voxel formula)
+    sb = sum(v_["algorithmic_bytes"] * v_["launches_per_step"] for v_ in kern.values())
+    out["roofline"]["step"] = {"algorithmic_bytes": int(sb), "achieved": round(sb / (ms * 1e-3) / 1e9, 2), "frac": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
     print(json.dumps(out))
     finish_dist(dist, world)
 
@@ -1070,6 +1114,19 @@ def main_camera(args):
                          "steps of the same 640x480 sequence (%d camera%s per step), TSDF+Color+ESDF" % (ncam, "" if ncam == 1 else "s"), oracle)
         if multicam:
             cpu["value"] = round(cpu["value"] * ncam, 3); cpu["unit"] = "frames/s"
+        else:
+            # BASELINE.json configs[0]: "TSDF+ESDF only, CPU reference path, single process" -- the same frames without colour, one thread and eight
+            def c0(threads):
+                oracle.set_num_threads(min(threads, os.cpu_count() or 1))
+                o0 = oracle.OracleMap(copy_params(oracle, g.params))
+
+                def s0(k):
+                    d, c_, T = host_cams[0][k % nu]; o0.integrate_depth(d, T, cam); o0.update_esdf()
+                s0(0); s0(1)
+                r = cpu_sample(lambda k: s0(2 + k), max(2.0, args.cpu_seconds / 4), 8, "frames/s", "frames of the same 640x480 sequence, TSDF+ESDF only (configs[0])", oracle)
+                return {k_: r[k_] for k_ in ("value", "unit", "cores", "ms_per_step", "sample")}
+            cpu["configs0_tsdf_esdf_only"] = {"one_thread": c0(1), "eight_threads": c0(8)}
+            oracle.set_num_threads(min(8, os.cpu_count() or 1))
 
     # the timed sequence once more, outside the timed region, against the checker (the 200-pose exploring loop with clear(),
     # deferral and a drain per block had never been compared end to end)

@@ -371,7 +371,9 @@ int nvbx_clear_tsdf_inside_shapes(nvbx_mapper* m, const nvbx_bounding_shape* sha
 int nvbx_esdf_slice_size(nvbx_mapper* m, int32_t* rows, int32_t* cols, float aabb_min_max[6]);
 int nvbx_esdf_slice_to_image(nvbx_mapper* m, float unknown_value, float* image_dev, int64_t capacity_elems,
                              int32_t* rows, int32_t* cols, float aabb_min_max[6]);
-/* EsdfSliceConverter::distanceMapSliceMsgFromSliceImage's D2H (esdf_slice_conversions.cu:81-109) in one call. */
+/* EsdfSliceConverter::distanceMapSliceMsgFromSliceImage's D2H (esdf_slice_conversions.cu:81-109) in one call -- and ONE wait for the device: the
+ * slicing launch reads the layer's AABB itself and writes size + image into pinned host memory (no size query first; round 5).  NVBX_E_CAPACITY
+ * (image_host null or capacity_elems too small): *rows / *cols / aabb report what is needed, nothing is copied. */
 int nvbx_esdf_slice_to_host(nvbx_mapper* m, float unknown_value, float* image_host, int64_t capacity_elems,
                             int32_t* rows, int32_t* cols, float aabb_min_max[6]);
 /* EsdfSlicer::sliceLayersToCombinedDistanceImage(layer_1, layer_2, height_1, height_2, unknown, &aabb, &image) --

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(64) void k_esdf_slice(DMap m, int32_t bz_out, int32
 extern "C" int nvbx_esdf_slice_size(nvbx_mapper* m, int32_t* rows, int32_t* cols, float aabb[6]) {
   if (!m || !rows || !cols) return NVBX_E_INVALID;
   if (m->fetch_counters()) return NVBX_E_DEVICE;
+  m->slice_size_seq = m->enqueue_seq;          // (nvbx_esdf_slice_to_image right behind this call needs no second fetch)
   const int32_t* c = m->h_counters + C_ESDF_AABB;
   if (c[0] > c[2]) { *rows = 0; *cols = 0; return NVBX_OK; }
   const EsdfArgs a = m->make_esdf_args();
@@ -255,7 +256,18 @@ extern "C" int nvbx_esdf_slice_size(nvbx_mapper* m, int32_t* rows, int32_t* cols
 extern "C" int nvbx_esdf_slice_to_image(nvbx_mapper* m, float unknown_value, float* image_dev, int64_t capacity_elems, int32_t* rows,
                                         int32_t* cols, float aabb[6]) {
   if (!m || !rows || !cols) return NVBX_E_INVALID;
-  int rc = nvbx_esdf_slice_size(m, rows, cols, aabb); if (rc) return rc;
+  // (called right behind nvbx_esdf_slice_size -- the facade's EsdfSlicer sizes its image first -- nothing has been enqueued since: the counters
+  //  on the host are still the device's, no second round trip)
+  int rc = NVBX_OK;
+  if (m->slice_size_seq != 0 && m->slice_size_seq == m->enqueue_seq && !m->color_pending.on && !m->esdf_update_pending && !m->edt_pending && !m->import_pending) {
+    const int32_t* c0 = m->h_counters + C_ESDF_AABB;
+    if (c0[0] > c0[2]) { *rows = 0; *cols = 0; } else { *cols = (c0[2] - c0[0] + 1) * 8; *rows = (c0[3] - c0[1] + 1) * 8; }
+    if (aabb && *rows) {
+      const EsdfArgs a0 = m->make_esdf_args(); const float bs = m->p.voxel_size * 8.0f;
+      aabb[0] = (float)c0[0] * bs; aabb[1] = (float)c0[1] * bs; aabb[2] = (float)a0.bz_out * bs;
+      aabb[3] = (float)(c0[2] + 1) * bs; aabb[4] = (float)(c0[3] + 1) * bs; aabb[5] = (float)(a0.bz_out + 1) * bs;
+    }
+  } else { rc = nvbx_esdf_slice_size(m, rows, cols, aabb); if (rc) return rc; }
   if (*rows == 0) return NVBX_OK;
   if (!image_dev || (int64_t)*rows * *cols > capacity_elems) { set_error("slice image capacity too small"); return NVBX_E_CAPACITY; }
   const EsdfArgs a = m->make_esdf_args();
@@ -277,17 +289,76 @@ static int ensure_staging(nvbx_mapper* m, int64_t bytes) {
   return NVBX_OK;
 }
 
+// The slice for a HOST caller in ONE wait (processEsdf slices right after updateEsdf and publishes from the host, nvblox_node.cpp:774-889: ten
+// times a second the node drains its pipeline here).  Size, then image, then download used to be three round trips to the device -- the layer's AABB
+// had to reach the host before the slicing launch could be sized.  k_esdf_slice_rows reads the AABB itself (device counters), writes
+// {min_x, min_y, max_x, max_y, status} + the image straight into pinned host memory, in whole 256-B row segments (one wavefront per strip of 8
+// blocks: lane = pixel of a 64-pixel row segment), and the host waits once.  status: 1 = image written, 0 = no ESDF block, -1 = `cap` too small.
+__global__ __launch_bounds__(64) void k_esdf_slice_rows(DMap m, int32_t bz_out, int32_t vz_out, float voxel_size, float unknown, float* img, int64_t cap, int32_t* header) {
+  const int32_t bx0 = m.counters[C_ESDF_AABB], by0 = m.counters[C_ESDF_AABB + 1], bx1 = m.counters[C_ESDF_AABB + 2], by1 = m.counters[C_ESDF_AABB + 3];
+  const int lane = (int)threadIdx.x;
+  const bool empty = bx0 > bx1;
+  const int32_t nbx = empty ? 0 : bx1 - bx0 + 1, nby = empty ? 0 : by1 - by0 + 1;
+  const bool fits = (int64_t)nbx * nby * 64 <= cap;
+  if (blockIdx.x == 0 && lane < 5) header[lane] = lane == 0 ? bx0 : lane == 1 ? by0 : lane == 2 ? bx1 : lane == 3 ? by1 : (empty ? 0 : (fits ? 1 : -1));
+  if (empty || !fits) return;
+  const int32_t strips_x = (nbx + 7) / 8, cols = nbx * 8;
+  for (int32_t s = (int32_t)blockIdx.x; s < strips_x * nby; s += (int32_t)gridDim.x) {
+    const int32_t cy = s / strips_x, cx0 = (s - cy * strips_x) * 8;
+    // lanes 0..7 look the strip's blocks up; lane l then reads pixel (l & 7) of block (l >> 3), row r
+    uint32_t es = SLOT_NONE;
+    if (lane < 8 && cx0 + lane < nbx) es = find_slot(m, bx0 + cx0 + lane, by0 + cy, bz_out, F_ESDF);
+    const uint32_t mine = __shfl(es, lane >> 3);
+    const bool in_img = cx0 + (lane >> 3) < nbx;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      float v = unknown;
+      if (slot_ok(mine)) {
+        const uint2 e = m.esdf[(size_t)mine * 512 + vz_out * 64 + r * 8 + (lane & 7)];
+        if (e.y & ESDF_OBSERVED) { v = sqrtf(__uint_as_float(e.x)) * voxel_size; if (e.y & ESDF_INSIDE) v = -v; }
+      }
+      if (in_img) img[(int64_t)(cy * 8 + r) * cols + cx0 * 8 + lane] = v;
+    }
+  }
+}
+static int ensure_slice_pinned(nvbx_mapper* m, int64_t elems) {
+  if (elems <= m->slice_pinned_elems) return NVBX_OK;
+  NVBX_HIP(hipStreamSynchronize(m->stream));
+  if (m->slice_pinned) NVBX_HIP(hipHostFree(m->slice_pinned));
+  m->slice_pinned = nullptr; m->slice_pinned_elems = 0; m->slice_pinned_dev = nullptr;
+  NVBX_HIP(hipHostMalloc((void**)&m->slice_pinned, (size_t)(elems + 16) * 4, hipHostMallocMapped));
+  { void* dp = nullptr; NVBX_HIP(hipHostGetDevicePointer(&dp, m->slice_pinned, 0)); m->slice_pinned_dev = (float*)dp; }
+  m->slice_pinned_elems = elems;
+  return NVBX_OK;
+}
+
 extern "C" int nvbx_esdf_slice_to_host(nvbx_mapper* m, float unknown_value, float* image_host, int64_t capacity_elems, int32_t* rows,
                                        int32_t* cols, float aabb[6]) {
   if (!m || !rows || !cols) return NVBX_E_INVALID;
-  int rc = nvbx_esdf_slice_size(m, rows, cols, aabb); if (rc) return rc;
-  const int64_t n = (int64_t)*rows * *cols;
-  if (n == 0) return NVBX_OK;
-  if (!image_host || n > capacity_elems) { set_error("slice image capacity too small"); return NVBX_E_CAPACITY; }
-  rc = ensure_staging(m, n * 4); if (rc) return rc;
-  rc = nvbx_esdf_slice_to_image(m, unknown_value, (float*)m->staging, n, rows, cols, aabb); if (rc) return rc;
-  NVBX_HIP(hipMemcpyAsync(image_host, m->staging, n * 4, hipMemcpyDeviceToHost, m->stream));
+  *rows = 0; *cols = 0;
+  if (m->join_side()) return NVBX_E_DEVICE;
+  // (the pinned image is at least as large as the caller's, and never smaller than 256 x 256: a caller that passes no buffer learns the size)
+  int rc = ensure_slice_pinned(m, std::max<int64_t>(image_host ? capacity_elems : 0, 65536)); if (rc) return rc;
+  const EsdfArgs a = m->make_esdf_args();
+  int32_t* header = reinterpret_cast<int32_t*>(m->slice_pinned_dev);          // [0..15] header, image behind it
+  volatile int32_t* h = reinterpret_cast<volatile int32_t*>(m->slice_pinned);
+  NVBX_LAUNCH(m, k_esdf_slice_rows, dim3(1024), dim3(64), m->d, a.bz_out, a.vz_out, m->p.voxel_size, unknown_value, m->slice_pinned_dev + 16, m->slice_pinned_elems, header);
+  NVBX_HIP(hipGetLastError());
   NVBX_HIP(hipStreamSynchronize(m->stream));
+  if (h[4] == 0) return NVBX_OK;
+  const float bs = m->p.voxel_size * 8.0f;
+  *cols = (h[2] - h[0] + 1) * 8; *rows = (h[3] - h[1] + 1) * 8;
+  if (aabb) {
+    aabb[0] = (float)h[0] * bs; aabb[1] = (float)h[1] * bs; aabb[2] = (float)a.bz_out * bs;
+    aabb[3] = (float)(h[2] + 1) * bs; aabb[4] = (float)(h[3] + 1) * bs; aabb[5] = (float)(a.bz_out + 1) * bs;
+  }
+  const int64_t n = (int64_t)*rows * *cols;
+  if (!image_host || n > capacity_elems) { set_error("slice image capacity too small"); return NVBX_E_CAPACITY; }
+  if (h[4] < 0) {          // larger than the pinned image (the layer grew past it between two calls): once more with room
+    rc = ensure_slice_pinned(m, n + n / 2); if (rc) return rc;
+    return nvbx_esdf_slice_to_host(m, unknown_value, image_host, capacity_elems, rows, cols, aabb);
+  }
+  memcpy(image_host, m->slice_pinned + 16, (size_t)n * 4);
   return NVBX_OK;
 }
 

@@ -392,6 +392,7 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   if (m->h_counters) (void)hipHostFree(m->h_counters);
   if (m->h_shc) (void)hipHostFree(m->h_shc);
   if (m->h_mirror) (void)hipHostFree(m->h_mirror);
+  if (m->slice_pinned) (void)hipHostFree(m->slice_pinned);
   if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
   delete m;
   return NVBX_OK;
@@ -912,6 +913,7 @@ int nvbx_mapper::reset_consumed_list() {
   return NVBX_OK;
 }
 int nvbx_mapper::join_side() {
+  enqueue_seq++;                     // (an entry point runs: host copies of device counters are stale from here on, esdf.hip nvbx_esdf_slice_to_image)
   zc_valid = false;                  // (whatever follows may change the TSDF: the kept zero-crossing list is dropped)
   // every entry point passes here before its first HIP call: make this mapper's device current (hosts with one mapper per GPU in
   // one process); a thread-local read when it already is

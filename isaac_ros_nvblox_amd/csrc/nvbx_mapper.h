@@ -108,6 +108,10 @@ struct nvbx_mapper {
   int64_t mesh_vert_cap = 0, mesh_tri_cap = 0;
   // staging
   void* staging = nullptr; int64_t staging_bytes = 0;
+  // nvbx_esdf_slice_to_host: pinned, device-mapped [16-int header][image] that k_esdf_slice_rows writes directly (one wait per host slice)
+  float* slice_pinned = nullptr; float* slice_pinned_dev = nullptr; int64_t slice_pinned_elems = 0;
+  // every kernel launch bumps enqueue_seq (NVBX_LAUNCH*); nvbx_esdf_slice_size remembers it: a slice_to_image right behind it re-uses the counters
+  uint64_t enqueue_seq = 1, slice_size_seq = 0;
   int32_t* h_counters = nullptr;     // pinned
   uint32_t frame_id = 0;
   uint32_t esdf_epoch = 0;
@@ -236,6 +240,7 @@ struct nvbx_mapper {
 #define NVBX_LAUNCH_ON(m, s, kernel, grid, block, ...)                               \
   do {                                                                               \
     if ((m)->profiling) (m)->span_begin(#kernel, (s));                               \
+    (m)->enqueue_seq++;                                                              \
     hipLaunchKernelGGL(kernel, grid, block, 0, (s), __VA_ARGS__);                    \
     if ((m)->profiling) (m)->span_end((s));                                          \
   } while (0)
@@ -244,6 +249,7 @@ struct nvbx_mapper {
 #define NVBX_LAUNCH_SMEM(m, kernel, grid, block, smem, ...)                          \
   do {                                                                               \
     if ((m)->profiling) (m)->span_begin(#kernel, (m)->stream);                       \
+    (m)->enqueue_seq++;                                                              \
     hipLaunchKernelGGL(kernel, grid, block, (smem), (m)->stream, __VA_ARGS__);       \
     if ((m)->profiling) (m)->span_end((m)->stream);                                  \
   } while (0)

@@ -522,13 +522,19 @@ class Mapper:
         return out
 
     def esdf_slice_image(self, unknown_value=1000.0):
+        """EsdfSlicer::sliceLayerToDistanceImage for a host caller: ONE wait for the device (nvbx_esdf_slice_to_host sizes the image on the device);
+        the buffer it is written into is kept and grows when the layer outgrows it."""
         r, c = C.c_int32(), C.c_int32()
         aabb = np.zeros(6, np.float32)
-        self._check(self.lib.nvbx_esdf_slice_size(self._h, C.byref(r), C.byref(c), _np_ptr(aabb)))
-        img = np.zeros((r.value, c.value), np.float32)
-        if img.size:
-            self._check(self.lib.nvbx_esdf_slice_to_host(self._h, unknown_value, _np_ptr(img), img.size, C.byref(r), C.byref(c), _np_ptr(aabb)))
-        return img, aabb
+        buf = getattr(self, "_slice_buf", None)
+        if buf is None:
+            buf = self._slice_buf = np.empty(256 * 256, np.float32)
+        rc = self.lib.nvbx_esdf_slice_to_host(self._h, unknown_value, _np_ptr(buf), buf.size, C.byref(r), C.byref(c), _np_ptr(aabb))
+        if rc == -3:          # NVBX_E_CAPACITY: rows / cols are reported
+            buf = self._slice_buf = np.empty(int(r.value * c.value * 1.5), np.float32)
+            rc = self.lib.nvbx_esdf_slice_to_host(self._h, unknown_value, _np_ptr(buf), buf.size, C.byref(r), C.byref(c), _np_ptr(aabb))
+        self._check(rc)
+        return buf[:r.value * c.value].reshape(r.value, c.value).copy(), aabb
 
     def esdf_slice_image_device(self, unknown_value=1000.0):
         torch = self._torch
