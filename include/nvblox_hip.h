@@ -511,9 +511,17 @@ int nvbx_mark_esdf_dirty(nvbx_mapper* m, const int32_t* indices_dev, const int32
  * each rank = (count, -, -), rows 1.. = block indices (the packed layout isaac_ros_nvblox_amd/dist.py all-gathers);
  * rank `self_rank`'s own list is skipped. */
 int nvbx_mark_esdf_dirty_gathered(nvbx_mapper* m, const int32_t* gathered_dev, int32_t world, int32_t self_rank, int64_t max_count);
-/* The same union step, held back: it is performed by extra workgroups of the next nvbx_integrate_color launch (beside the marking
- * of the mapper's own dirty blocks) -- no launch of its own -- or first thing by any other entry point that comes before.  The
- * gathered buffer must stay valid and unchanged until then.  For the pipelined exchange of bench.py / dist.py. */
+/* The same union step, held back -- no launch of its own.  WHEN it runs, and how long `gathered_dev` must stay valid and unchanged:
+ *   classic launch order: extra workgroups of the next nvbx_integrate_color launch perform it beside the marking of the mapper's own
+ *     dirty blocks; the peers' blocks reach the ESDF with the NEXT nvbx_update_esdf (one update after the frame that produced them).
+ *   pipelined order (colour deferral, the default): it rides in the fused TSDF-update launch of the next nvbx_integrate_depth, where it only
+ *     sets the blocks ESDF-dirty for the marking pass AFTER that -- the peers' blocks reach the ESDF TWO updates after the frame that produced
+ *     them, and the buffer is read one nvbx_integrate_depth later than in classic order.
+ *   any other entry point that comes first performs it at once (its own launch).
+ * A caller that refills gathered buffers in rotation therefore needs THREE sets (filling / in flight in the collective / being read here):
+ * nvblox::BlockIndexExchange (include/nvblox/mapper/block_index_exchange.h) and dist.PipelinedDirtyBlockExchange do exactly that; two sets race
+ * with the rider.  Under option (A) of SURVEY.md 8e (replicas + index union) the extra update of delay changes no voxel: a peer's block only
+ * re-marks a column from the local, unchanged TSDF. */
 int nvbx_mark_esdf_dirty_gathered_deferred(nvbx_mapper* m, const int32_t* gathered_dev, int32_t world, int32_t self_rank, int64_t max_count);
 
 /* ---- multi-GPU, one fused map (SURVEY.md 8e option B, made exact): measurement exchange ---------------------------------------------

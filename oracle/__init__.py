@@ -129,6 +129,7 @@ def lib():
         L.orc_destroy.argtypes = [vp]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_traversal_accumulate.argtypes = [C.c_int]; L.orc_set_traversal_accumulate.restype = None
         L.orc_index_hash.restype = C.c_uint32; L.orc_index_hash.argtypes = [i32, i32, i32]
         L.orc_integrate_depth.restype = i64; L.orc_integrate_depth.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
         L.orc_integrate_lidar_depth.restype = i64; L.orc_integrate_lidar_depth.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
@@ -346,6 +347,11 @@ class OracleMap:
         out = np.zeros((1 << 16, 3), np.int32)
         n = lib().orc_take_cleared_blocks(self._h, _p(out), out.shape[0])
         return out[:n].copy()
+
+
+def set_traversal_accumulate(on):
+    """1: the view calculation walks with the textbook accumulated crossing parameters instead of the closed form (a cross-check, process-wide)."""
+    lib().orc_set_traversal_accumulate(int(bool(on)))
 
 
 def set_num_threads(n):

@@ -413,6 +413,11 @@ static void view_push(OrcMap* m, Idx3 i) {
 /* [U] Amanatides-Woo through the block grid.  The crossing parameters are evaluated in CLOSED FORM -- crossing number k of axis a at
  * T_a(k) = fmaf(k, tdelta_a, tmax0_a), one rounding -- instead of accumulated by k additions: the traversal then depends on the crossing counts
  * alone, which lets the kernel enter a ray at any step without replaying the steps before it (csrc/tsdf.hip dda_step / dda_jump, same fmaf). */
+/* 0 (default) = crossing parameters in closed form, T_a(k) = fmaf(k, tdelta_a, tmax0_a) -- the definition shared with the product;
+ * 1 = the textbook Amanatides-Woo accumulation tmax_a += tdelta_a.  Test infrastructure only (tests/test_independent_checks.py counts the blocks
+ * on which the two disagree: near-ties at ulp level, nothing else). */
+static int g_traversal_accumulate = 0;
+void orc_set_traversal_accumulate(int on) { g_traversal_accumulate = on ? 1 : 0; }
 static void raycast_blocks(OrcMap* m, const float* o, const float* e, float bs) {
   float s[3], t[3];
   int32_t cur[3], end[3], step[3], ncross[3] = {0, 0, 0};
@@ -438,7 +443,7 @@ static void raycast_blocks(OrcMap* m, const float* o, const float* e, float bs) 
     if (tmax[2] < tmax[a]) a = 2;
     cur[a] += step[a];
     ncross[a]++;
-    tmax[a] = fmaf((float)ncross[a], tdelta[a], tmax0[a]);
+    tmax[a] = g_traversal_accumulate ? tmax[a] + tdelta[a] : fmaf((float)ncross[a], tdelta[a], tmax0[a]);
   }
 }
 

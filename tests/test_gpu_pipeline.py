@@ -24,15 +24,17 @@ def _equal_maps(M, a, b, tag=""):
     assert sa.shape == sb.shape and np.array_equal(sa, sb) and np.array_equal(aa, ab)
 
 
+@pytest.mark.parametrize("staged", [True, False], ids=["staged", "zero_copy"])
 @pytest.mark.parametrize("cam", [H.SMALL_CAM, S.REPLICA_LIKE_CAM], ids=["160x120", "640x480"])
-def test_steady_state_pipeline_equals_classic_and_oracle(oracle_mod, hip_lib, cam):
-    """The bench's loop -- depth, colour, updateEsdf per frame -- for 12 frames: every frame but the first takes the pipelined path."""
+def test_steady_state_pipeline_equals_classic_and_oracle(oracle_mod, hip_lib, cam, staged):
+    """The bench's loop -- depth, colour, updateEsdf per frame -- for 12 frames: every frame but the first takes the pipelined path.  Both forms of
+    the deferral: staged (the shipped default: a raw-pointer image is copied first) and zero-copy (opt-in) -- ADVICE r04."""
     from isaac_ros_nvblox_amd import mapper as M
     from test_gpu_parity import compare_layer, TOL
     pg = M.default_params(); po = H.copy_params(pg, oracle_mod.OrcParams)
     classic = M.Mapper(pg, block_capacity=1 << 14); piped = M.Mapper(pg, block_capacity=1 << 14); o = oracle_mod.OracleMap(po)
     classic.set_color_deferral(False)          # (a new mapper defers in the staged form: the reference order is asked for)
-    piped.set_color_deferral(True)
+    piped.set_color_deferral(True, staged=staged)
     for k, (d, rgb, T) in enumerate(H.frames(12, cam, stride=7)):
         for m_ in (classic, piped, o):
             m_.integrate_depth(d, T, cam); m_.integrate_color(rgb, T, cam); m_.update_esdf()

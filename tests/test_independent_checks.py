@@ -298,3 +298,43 @@ def test_view_calculation_against_float64_geometry(oracle_mod):
             extra = sorted(view - V.blocks_crossed(org, ends, bs, 0.0))
             assert len(extra) <= len(view) // 50, (len(extra), len(view))          # (grazed blocks only: a few per frame)
             assert all(V.near_some_ray(extra, org, ends, bs, 1e-3)), (k, sub, extra[:5])
+
+
+def test_closed_form_traversal_against_textbook_accumulation(oracle_mod):
+    """The closed-form crossing parameters T_a(k) = fmaf(k, tdelta_a, tmax0_a) are this repository's own definition (kernel and checker changed in the
+    same commit).  The checker keeps the textbook Amanatides-Woo accumulation tmax_a += tdelta_a behind a switch (oracle.set_traversal_accumulate):
+    the two may differ only where two crossings tie within rounding.  Counted here on camera frames (rays of ~20 steps), on a fine grid (rays of ~90
+    steps) and on a 200 m LiDAR scan (rays of up to ~450 steps, where the accumulated rounding error is largest): the symmetric difference of the
+    two block sets stays below 1 % (camera) / 2 % (LiDAR) of the view, and every block only one of them names lies within 1e-3 of a block of some
+    ray (float64 geometry, tests/view_independent.py)."""
+    import helpers as H
+    import view_independent as V
+    from isaac_ros_nvblox_amd import mapper as M, synthetic as S
+    cam = H.SMALL_CAM
+    try:
+        for k, (d, _, T) in enumerate(H.frames(2, cam, stride=31, color=False)):
+            for sub, maxd, vs in ((4, 7.0, 0.05), (8, 7.0, 0.01)):
+                p = H.copy_params(M.default_params(raycast_subsampling_factor=sub, max_integration_distance_m=maxd, voxel_size=vs), oracle_mod.OrcParams)
+                views = []
+                for acc in (0, 1):
+                    oracle_mod.set_traversal_accumulate(acc)
+                    o = oracle_mod.OracleMap(p); o.integrate_depth(d, T, cam)
+                    views.append({tuple(int(v) for v in r) for r in np.asarray(o.last_view())})
+                diff = views[0] ^ views[1]
+                assert len(views[0]) > 100 and len(diff) <= max(2, len(views[0]) // 100), (k, sub, len(views[0]), len(diff))
+                if diff:
+                    org, ends = V.camera_rays(d, T, cam, p.voxel_size, p.truncation_distance_vox, p.max_integration_distance_m, sub)
+                    assert all(V.near_some_ray(sorted(diff), org, ends, p.voxel_size * 8.0, 1e-3)), sorted(diff)[:5]
+        # LiDAR, 200 m
+        p = H.copy_params(M.default_params(voxel_size=0.1, lidar_max_integration_distance_m=200.0, raycast_subsampling_factor=2), oracle_mod.OrcParams)
+        T = S.lidar_pose(0); img = S.render_lidar(S.LidarScene(), T, S.SPINNING_LIDAR, max_range=200.0)
+        views = []
+        for acc in (0, 1):
+            oracle_mod.set_traversal_accumulate(acc)
+            o = oracle_mod.OracleMap(p); o.integrate_lidar_depth(img, T, S.SPINNING_LIDAR)
+            views.append({tuple(int(v) for v in r) for r in np.asarray(o.last_view())})
+        diff = views[0] ^ views[1]
+        assert len(views[0]) > 100000 and len(diff) <= len(views[0]) // 50, (len(views[0]), len(diff))
+        print("closed form vs accumulation, 200 m LiDAR scan: %d of %d blocks differ" % (len(diff), len(views[0])))
+    finally:
+        oracle_mod.set_traversal_accumulate(0)
