@@ -530,6 +530,11 @@ def main_decay(args):
     rgb_dev = [torch.from_numpy(c).to(dev) for _, c, _ in host]
     poses = [T for _, _, T in host]
     stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream)
+    # colour images in library-owned frames (the device memory of an nvblox::Image<Color> in the facade, csrc/frames.hip): a held-back frame is retained,
+    # not copied; --staged-deferral: raw device pointers, one k_stage_color copy per held-back frame (round 4's line)
+    use_frames = not args.staged_deferral and not args.no_color_deferral
+    if use_frames:
+        rgb_dev = [M.ColorFrame(rows, cols, 3, local_rank).write(t_, stream.cuda_stream) for t_ in rgb_dev]
     fs = dict(projective_layer_type=2, max_integration_distance_m=5.0, invalid_depth_decay_factor=0.8, tsdf_decay_factor=0.95,
               min_duration_since_occupied_for_freespace_ms=250)                     # nvblox_dynamics.yaml:11-18
     occ = dict(projective_layer_type=1, max_integration_distance_m=5.0)
@@ -653,6 +658,40 @@ def main_decay(args):
                 os_.decay_tsdf(True); od.decay_occupancy()
         cstep(0); cstep(1)
         cpu = cpu_sample(lambda k: cstep(2 + k), args.cpu_seconds, 6, "frames/s", "frames of the same 640x480 dynamic sequence (all of the step)", oracle)
+    # the timed sequence once more against the checker, outside the timed region: both maps emptied, the nu frames (decay on every 6th) mirrored on two
+    # checker maps; static mapper: TSDF / colour / ESDF / slice, dynamic mapper: occupancy block set + log-odds, ESDF block set
+    parity = None
+    if not args.no_parity:
+        import oracle
+        oracle.set_num_threads(min(8, os.cpu_count() or 1))
+        ps_, pd_ = oracle.OracleMap(copy_params(oracle, gs.params)), oracle.OracleMap(copy_params(oracle, gd.params))
+        gs.clear(); gd.clear(); barrier(); t_ms[0] = 0; tq = 0; t_par = time.perf_counter()
+        occ_same = True; occ_worst = 0.0; occ_max = 0
+        n_par = 2 * nu          # (two loops: the freespace layer needs the first to gain confidence, the second then meets dynamic pixels -- the occupancy mapper has blocks)
+        for i in range(n_par):
+            step(i)
+            d, rgb, T = host[i % nu]
+            mk = oracle.remove_small_components(ps_.detect_dynamics(d, T, cam, 5.0), 2000)
+            u_, m_ = oracle.split_depth_by_mask(d, mk, eye, cam, cam, 0.25)
+            ps_.set_time_ms(tq); tq += 33
+            ps_.integrate_depth(u_, T, cam); pd_.integrate_depth(m_, T, cam); ps_.integrate_color(rgb, T, cam)
+            ps_.update_esdf(); pd_.update_esdf()
+            if i % 6 == 5:
+                ps_.decay_tsdf(True); pd_.decay_occupancy()
+            if i % 8 == 4:          # the dynamic (occupancy) mapper along the way: its layer comes and goes with the moving box
+                io_, ig_ = pd_.block_indices(oracle.L_TSDF), gd.block_indices(M.LAYER_OCCUPANCY)
+                same_ = bool(np.array_equal(ig_, io_)); occ_same = occ_same and same_; occ_max = max(occ_max, int(len(ig_)))
+                if same_ and len(io_):
+                    bg, _ = gd.get_blocks(M.LAYER_OCCUPANCY, ig_)
+                    occ_worst = max(occ_worst, float(max(np.abs(bg[k_]["log_odds"].astype(np.float64) - pd_.get_block(oracle.L_TSDF, idx)["distance"]).max() for k_, idx in enumerate(io_))))
+        barrier()
+        parity = map_parity(M, gs, ps_, oracle)
+        parity["dynamic_mapper"] = {"occupancy_blocks_max_along_the_way": occ_max, "index_sets_equal_every_8th_frame": occ_same, "max_abs_log_odds": occ_worst,
+                                    "esdf_index_sets_equal": bool(np.array_equal(gd.block_indices(M.LAYER_ESDF), pd_.block_indices(oracle.L_ESDF)))}
+        parity["ok"] = bool(parity["ok"] and occ_same and occ_worst <= 1e-4 and parity["dynamic_mapper"]["esdf_index_sets_equal"])
+        parity["steps_compared"] = n_par; parity["checker_s"] = round(time.perf_counter() - t_par, 2)
+        parity["what"] = ("the %d-frame sequence twice from two empty maps (front end, both mappers, colour, both ESDF updates, decay on every 6th frame), every call "
+                          "mirrored on oracle/nvblox_oracle.c; outside the timed region" % nu)
     c = gs.counters()
     out = {"metric": "frames/s, dynamic mapping frame (dynamics + TSDF/freespace + occupancy + Color + ESDF, decay every 6th), synthetic Redwood-like 640x480 @0.05m",
            "value": round(args.steps / dt, 2), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "repeats": len(dts),
@@ -660,7 +699,8 @@ def main_decay(args):
            "config": {"workload": "configs[2]: synthetic Redwood-like room 8x6x2.8 m with a box moving at 0.5 m/s (SURVEY 8d), 640x480 depth+colour "
                                   "limited to 5 m, 0.05 m voxels, MappingType::kDynamic (freespace layer, dynamics detection, occupancy mapper), "
                                   "invalid_depth_decay 0.8, tsdf_decay 0.95 + occupancy decay every 6th frame", "unique_frames": nu,
-                      "mode": ("colour deferral, staged form, on both mappers (a new mapper's default, DESIGN.md 2.8); " if not args.no_color_deferral else "classic launch order; ") +
+                      "mode": (("colour deferral on both mappers (a new mapper's default, DESIGN.md 2.8), colour images in library-owned frames (retained, not copied); " if use_frames else
+                                "colour deferral, staged form (raw device pointers: one k_stage_color copy per held-back frame), on both mappers; ") if not args.no_color_deferral else "classic launch order; ") +
                               ("the dynamic (occupancy) mapper on a stream of its own, ordered with nvbx_mapper_wait_for (A/B)" if args.own_stream else
                                "both mappers on one stream (as nvblox::MultiMapper hands them out)")},
            "readme_rtx5090_ms": README_RTX5090_MS,
@@ -668,7 +708,8 @@ def main_decay(args):
            "block_ms": [round(d / args.steps * 1e3, 4) for d in dts[:16]], "block_stats_ms_per_step": block_stats(dts, args.steps),
            "kernels": kernels_json(kern),
            "roofline": roofline_of(kern, ms, evo, emp, "longest kernel of the dynamic-mapping step (launches of the static and the dynamic mapper together)"),
-           "cpu_baseline": cpu, "capacity_overflow": c["capacity_overflow"]}
+           "cpu_baseline": cpu, "parity": parity, "capacity_overflow": c["capacity_overflow"]}
+    out["roofline"]["traffic_source"] = pmc_source()
     print(json.dumps(out))
 
 

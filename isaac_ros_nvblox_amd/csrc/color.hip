@@ -222,6 +222,9 @@ template <typename Pix, int NB>
 static int pending_setup(nvbx_mapper* m, const nvbx_mapper::ColorPending& c, FrameSetC<Pix, NB>* fs, PoseSet<NB>* ps, int32_t* srows, int32_t* scols) {
   Pix imgs[NB];
   for (int i = 0; i < c.n && i < NB; i++) imgs[i] = Pix{reinterpret_cast<decltype(Pix::p)>(c.imgs[i])};
+#ifdef NVBX_CHECK_INVARIANTS
+  for (int i = 0; i < c.n && i < NB; i++) if (c.frames[i] && nvbx_frame_refcount(c.frames[i]) < 1) m->inv_i8++;      // I8: a held-back image's frame is held until its readers are enqueued
+#endif
   return color_setup<Pix, NB>(m, c.n, imgs, c.rows, c.cols, c.T, c.cams, fs, ps, srows, scols);
 }
 template <int NB>

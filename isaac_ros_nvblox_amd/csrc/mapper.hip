@@ -36,6 +36,9 @@ __global__ void k_init_map(DMap m) {
     if (a >= 0 && a < 4) v = a < 2 ? INT32_MAX : INT32_MIN;
     const int w3 = (int)i - C_ESDF3_WIN;
     if (w3 >= 0 && w3 < 6) v = w3 < 3 ? INT32_MAX : INT32_MIN;
+#ifdef NVBX_CHECK_INVARIANTS
+    if (i >= C_INV_I1 && i <= C_INV_I3) v = m.counters[i];      // (violations survive clear(): a mapper answers for all its launches when it is closed)
+#endif
     m.counters[i] = v;
   }
 }
@@ -185,6 +188,7 @@ static int alloc_all(nvbx_mapper* m) {
   NVBX_HIP(hipMalloc(&d.table, tsz * sizeof(Entry)));
   NVBX_HIP(hipMalloc(&d.free_stack, cap * 4));
   NVBX_HIP(hipMalloc(&d.counters, C_NUM * 4));
+  NVBX_HIP(hipMemset(d.counters, 0, C_NUM * 4));      // (k_init_map of the -DNVBX_CHECK_INVARIANTS variant keeps some of them across clear())
   NVBX_HIP(hipMalloc(&d.slot_flags, cap * 4));
   NVBX_HIP(hipMalloc(&d.slot_index, cap * 12));
   NVBX_HIP(hipMalloc(&d.slot_entry, cap * 4));
@@ -417,6 +421,27 @@ extern "C" int nvbx_mapper_set_params(nvbx_mapper* m, const nvbx_mapper_params* 
   }
   return NVBX_OK;
 }
+#ifdef NVBX_CHECK_INVARIANTS
+// Variant-only (tools/build_variant.sh inv "-DNVBX_CHECK_INVARIANTS"; not part of include/nvblox_hip.h): the violation counters of DESIGN.md 2.8's
+// invariants as the kernels counted them -- out[0] = I1 (a TSDF-reading rider of launch 1 beside a running TSDF writer), out[1] = I3 (a colour worker
+// handed a record whose slot does not name the block), out[2] = I4 (the marking pass took an entry of a slot without a layer), out[3] = writers
+// still counted as running (must be 0 between launches), out[4] = I8 (host side: a colour-reading launch enqueued on a frame nobody holds).
+// selftest != 0: first makes one reader meet a (pretended) writer, so a caller can see that the counters count.
+__global__ void k_inv_selftest(DMap m) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&m.counters[C_INV_WRITERS], 1);
+  __syncthreads();
+  NVBX_INV_TSDF_READER(m);
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicSub(&m.counters[C_INV_WRITERS], 1);
+}
+extern "C" int nvbx_debug_invariants(nvbx_mapper* m, int64_t out[5], int32_t selftest) {
+  if (!m || !out) return NVBX_E_INVALID;
+  if (selftest) { NVBX_LAUNCH(m, k_inv_selftest, dim3(1), dim3(64), m->d); NVBX_HIP(hipGetLastError()); }
+  if (m->fetch_counters()) return NVBX_E_DEVICE;
+  out[0] = m->h_counters[C_INV_I1]; out[1] = m->h_counters[C_INV_I3]; out[2] = m->h_counters[C_INV_I4]; out[3] = m->h_counters[C_INV_WRITERS]; out[4] = m->inv_i8;
+  return NVBX_OK;
+}
+#endif
 extern "C" int nvbx_mapper_get_params(const nvbx_mapper* m, nvbx_mapper_params* out) {
   if (!m || !out) return NVBX_E_INVALID;
   *out = m->p; return NVBX_OK;

@@ -195,6 +195,7 @@ __device__ inline void color_scan_worker(const DMap& m, const PoseSet<NB>& ps, i
   const int lane = threadIdx.x & 63;
   const int32_t cap = (int32_t)m.capacity;
   const int ncam = NB > 1 ? ps.n : 1;
+  NVBX_INV_TSDF_READER(m);
   if (w == 0 && lane == 0) m.counters[reset_idx] = 0;       // the other parity's count: consumed one launch ago, appended to by the next scan
   int32_t base = w * 64;
   int32_t s = min(base + lane, cap - 1);
@@ -252,6 +253,7 @@ __device__ inline void color_integrate_list_worker(const DMap& m, const FrameSet
   if (wg == 0 && threadIdx.x == 0) __hip_atomic_store(&m.host_mirror[3], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // the next fused launch's grid hint
   for (int32_t i = wg; i < n; i += n_wg) {
     if (i != wg) rec = cand[i];
+    NVBX_INV_COUNT(m, C_INV_I3, threadIdx.x == 0 && (m.slot_index[3 * ((uint32_t)rec.x & 0xFFFFFFu)] != rec.y || m.slot_index[3 * ((uint32_t)rec.x & 0xFFFFFFu) + 1] != rec.z || m.slot_index[3 * ((uint32_t)rec.x & 0xFFFFFFu) + 2] != rec.w));
     color_integrate_block<Pix, NB>(m, fs, synth, srows, scols, mesh_list, (int32_t)((uint32_t)rec.x & 0xFFFFFFu), rec.y, rec.z, rec.w, (uint32_t)rec.x >> 24);
   }
 }

@@ -34,6 +34,8 @@ __device__ inline void esdf_mark_entry(const DMap& m, const EsdfArgs& a, uint32_
   // update (its TSDF update sets the flag one launch later), so the stale entry is skipped; found as ESDF columns the sequential order never
   // creates when the new block was deallocated again before that update (tests/test_gpu_sequences.py, seed 3).
   if (from_dirty_list && !(tflags & F_DIRTY_ESDF)) return;
+  NVBX_INV_TSDF_READER(m);
+  NVBX_INV_COUNT(m, C_INV_I4, lane == 0 && from_dirty_list && !(tflags & (F_TSDF | F_ESDF)));
   NVBX_TV(0, 3, wall_clock64());
   if (lane == 0) { atomicAnd(&m.slot_flags[tslot], ~F_DIRTY_ESDF); m.slot_consumed[tslot] = a.mark_pass; }
   // a dirty TSDF block of the z band dirties its column; an ESDF slot flagged F_ESDF_REMARK (a TSDF block of its band was

@@ -89,6 +89,11 @@ enum {
   C_CLEARED = 46,      // entries of the cleared-block list (nvbx_take_cleared_blocks)
   C_MARK_DONE = 47,    // workers of the running ESDF marking pass that have finished (a pass that empties the dirty list itself, EsdfArgs::self_reset)
   C_CAND_COUNT = 48,   // [48..49] parity-indexed: colour candidate records discovered for the fused colour + TSDF launch (nvbx_color_worker.h)
+  // -DNVBX_CHECK_INVARIANTS variant of the library only (tools/build_variant.sh inv "-DNVBX_CHECK_INVARIANTS"; DESIGN.md 2.8's table made executable):
+  C_INV_WRITERS = 50,  // workers that write TSDF voxels / band flags and are running right now
+  C_INV_I1 = 51,       // violations of I1: a TSDF-reading rider of launch 1 (sphere tracing, colour candidates, ESDF marking) met a running TSDF writer
+  C_INV_I4 = 52,       // violations of I4: the marking pass took a dirty-list entry whose slot carries no projective layer (freed and not re-issued: the flag test must have stopped it)
+  C_INV_I3 = 53,       // violations of I3: a colour worker of launch 2 was handed a candidate record whose slot does not name that block
   C_NUM = 56
 };
 
@@ -196,6 +201,20 @@ extern __device__ unsigned long long* g_wgt;
 #define NVBX_TV(k, i, v) do { if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 0 && g_wgt && blockIdx.x < 8192) g_wgt[((size_t)(k) * 8192 + blockIdx.x) * 8 + (i)] = (unsigned long long)(v); } while (0)
 #else
 #define NVBX_TV(k, i, v) do { } while (0)
+#endif
+// ---- executable invariants (the -DNVBX_CHECK_INVARIANTS variant; the product build compiles every macro to nothing)
+#ifdef NVBX_CHECK_INVARIANTS
+// a worker that writes TSDF voxels or band flags: bracketed by these (one lane per workgroup counts)
+#define NVBX_INV_WRITER_BEGIN(m) do { __syncthreads(); if (threadIdx.x == 0) atomicAdd(&(m).counters[C_INV_WRITERS], 1); } while (0)
+#define NVBX_INV_WRITER_END(m) do { __syncthreads(); if (threadIdx.x == 0) atomicSub(&(m).counters[C_INV_WRITERS], 1); } while (0)
+// a rider that READS the TSDF as the last update left it: no writer may be running (checked where the rider starts and where it ends)
+#define NVBX_INV_TSDF_READER(m) do { if ((threadIdx.x & 63) == 0 && __hip_atomic_load(&(m).counters[C_INV_WRITERS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) atomicAdd(&(m).counters[C_INV_I1], 1); } while (0)
+#define NVBX_INV_COUNT(m, idx, cond) do { if (cond) atomicAdd(&(m).counters[idx], 1); } while (0)
+#else
+#define NVBX_INV_WRITER_BEGIN(m) do { } while (0)
+#define NVBX_INV_WRITER_END(m) do { } while (0)
+#define NVBX_INV_TSDF_READER(m) do { } while (0)
+#define NVBX_INV_COUNT(m, idx, cond) do { } while (0)
 #endif
 __device__ inline int32_t* shc_at(const DMap& m, int id, int shard, int field) { return &m.shc[(id * NSH + shard) * SH_STRIDE + field]; }
 __device__ inline int my_shard() { return (int)(blockIdx.x & (NSH - 1)); }

@@ -178,6 +178,7 @@ struct nvbx_mapper {
     consumed_frames.clear();
   }
   int32_t next_fence_report() { __atomic_store_n(&fence_reports_enqueued, color_reads_enqueued, __ATOMIC_RELEASE); return color_reads_enqueued; }
+  int64_t inv_i8 = 0;                // (-DNVBX_CHECK_INVARIANTS) colour-reading launches enqueued on a library frame that nobody holds
   bool esdf_update_pending = false;  // an updateEsdf called while a colour frame was held back
   bool replaying = false;            // inside replay_deferred: the calls run as usual
   bool pipelined_order = false;      // inside the pipelined integrateDepth: marking passes empty their list, EDTs keep it (EsdfArgs)

@@ -30,6 +30,7 @@ template <int NB, int RAY_LANES>
 __device__ inline void sphere_trace_worker(const DMap& m, const PoseSet<NB>& poses, float* synth_all, int32_t srows, int32_t scols, int32_t max_steps,
                                            float max_len, float eps_m, int wgi) {
   const int tid = threadIdx.x;
+  NVBX_INV_TSDF_READER(m);
   if (wgi == 0 && tid == 0) list_reset(m, S_LIST_COLOR);
   const int lane = tid & 63;
   const int sub = lane & (RAY_LANES - 1);              // sample index within the ray's group

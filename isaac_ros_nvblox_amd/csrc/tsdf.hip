@@ -589,6 +589,7 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
         esdf_mark_worker(m, ea, w * 4 + (int)(threadIdx.x >> 6), tr.n_mark_wg * 4);
         if (ea.self_reset) { __syncthreads(); if (threadIdx.x < 64) esdf_mark_pass_done(m, ea, tr.n_mark_wg, w); }
       }
+      if (rider >= n_edt_wg) NVBX_INV_TSDF_READER(m);       // (sphere tracing, candidates, marking: still no TSDF writer beside them when they end)
       NVBX_T(0, 7);
       return;
     }
@@ -1148,7 +1149,9 @@ template <typename Img, typename Sensor, int NB, bool Plain>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_integrate_tsdf(DMap m, FrameSet<Img, NB> fs, Sensor sensor, const int4* view_list, int32_t list_cap,
                                                         int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, const uint8_t* view_class,
                                                         const int32_t* dense_list) {
+  NVBX_INV_WRITER_BEGIN(m);
   integrate_tsdf_worker<Img, Sensor, NB, Plain>(m, fs, sensor, view_list, list_cap, mesh_list, view_export, view_export_cap, spec_lanes, view_class, (int32_t)blockIdx.x, (int32_t)gridDim.x, dense_list);
+  NVBX_INV_WRITER_END(m);
 }
 
 // Pipelined order, fused: TSDF update of frame i + 1, colour integration of frame i (from the candidate records the riders
@@ -1173,7 +1176,9 @@ __global__ __launch_bounds__(512) void k_integrate_tsdf_color(DMap m, FrameSet<I
   NVBX_T(1, 0);
   if (b < n_edt_wg) { esdf_edt_worker<512>(m, ea, (int)b, n_edt_wg, reinterpret_cast<EdtShared*>(smem)); NVBX_T(1, 1); NVBX_T(1, 7); return; }
   if (b < n_edt_wg + n_tsdf_wg) {
+    NVBX_INV_WRITER_BEGIN(m);
     integrate_tsdf_worker<Img, CameraSensor, NB, Plain>(m, fs, sensor, view_list, list_cap, mesh_list, view_export, view_export_cap, spec_lanes, nullptr, b - n_edt_wg, n_tsdf_wg);
+    NVBX_INV_WRITER_END(m);
     NVBX_T(1, 2); NVBX_T(1, 7);
     return;
   }

@@ -56,6 +56,10 @@ class NvbxError(RuntimeError):
     pass
 
 
+# NVBX_CHECK_ON_CLOSE=1 with the -DNVBX_CHECK_INVARIANTS variant of the library: what the mappers closed so far reported (tests/test_gpu_invariants.py)
+INVARIANT_REPORT = {"mappers_checked": 0, "violations": []}
+
+
 def frame_pool_stats():
     """(held, free, bytes, created, waits, syncs) of the library's frame pool (nvbx_frame_pool_stats)."""
     out = (C.c_int64 * 6)()
@@ -177,8 +181,28 @@ class Mapper:
             raise NvbxError("nvbx error %d: %s" % (rc, self.lib.nvbx_last_error().decode()))
         return rc
 
+    def invariant_violations(self, selftest=False):
+        """-DNVBX_CHECK_INVARIANTS variant of the library only (NVBX_LIB=...; tools/build_variant.sh inv): (I1, I3, I4, writers still running, I8) as
+        the kernels and the host counted them; None with the product library, which compiles the checks to nothing."""
+        try:
+            fn = self.lib.nvbx_debug_invariants
+        except AttributeError:
+            return None
+        fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        out = (C.c_int64 * 5)()
+        self._check(fn(self._h, out, int(bool(selftest))))
+        return tuple(int(v) for v in out)
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
+            if os.environ.get("NVBX_CHECK_ON_CLOSE") == "1":        # (tests/test_gpu_invariants.py: every mapper of a test run answers for its launches)
+                v = self.invariant_violations()
+                if v is not None:
+                    INVARIANT_REPORT["mappers_checked"] += 1
+                    if any(v):          # (recorded as well as raised: most mappers are closed by __del__, which swallows exceptions)
+                        INVARIANT_REPORT["violations"].append(v)
+                        self.lib.nvbx_mapper_destroy(self._h); self._h = C.c_void_p()
+                        raise NvbxError("invariant violations (I1, I3, I4, writers running, I8) = %r" % (v,))
             self.lib.nvbx_mapper_destroy(self._h)
             self._h = C.c_void_p()
 
