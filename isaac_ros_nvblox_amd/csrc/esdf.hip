@@ -344,7 +344,7 @@ extern "C" int nvbx_esdf_slice_to_host(nvbx_mapper* m, float unknown_value, floa
   volatile int32_t* h = reinterpret_cast<volatile int32_t*>(m->slice_pinned);
   NVBX_LAUNCH(m, k_esdf_slice_rows, dim3(1024), dim3(64), m->d, a.bz_out, a.vz_out, m->p.voxel_size, unknown_value, m->slice_pinned_dev + 16, m->slice_pinned_elems, header);
   NVBX_HIP(hipGetLastError());
-  NVBX_HIP(hipStreamSynchronize(m->stream));
+  if (m->wait_stream()) return NVBX_E_DEVICE;
   if (h[4] == 0) return NVBX_OK;
   const float bs = m->p.voxel_size * 8.0f;
   *cols = (h[2] - h[0] + 1) * 8; *rows = (h[3] - h[1] + 1) * 8;

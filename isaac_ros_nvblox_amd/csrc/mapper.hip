@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include "nvbx_mapper.h"
@@ -220,7 +221,7 @@ static int alloc_all(nvbx_mapper* m) {
   NVBX_HIP(hipHostMalloc(&m->h_shc, S_NUM * NSH * SH_STRIDE * 4));
   NVBX_HIP(hipHostMalloc(&m->h_mirror, 64, hipHostMallocMapped));
   { void* dp = nullptr; NVBX_HIP(hipHostGetDevicePointer(&dp, m->h_mirror, 0)); d.host_mirror = (int32_t*)dp; }
-  m->h_mirror[0] = (int32_t)cap; m->h_mirror[1] = 0; m->h_mirror[2] = 0; m->h_mirror[3] = 0; m->h_mirror[4] = 0;      // ([4]: fence progress of held-back colour frames, frames.hip -- never reset)
+  m->h_mirror[0] = (int32_t)cap; m->h_mirror[1] = 0; m->h_mirror[2] = 0; m->h_mirror[3] = 0; m->h_mirror[4] = 0; m->h_mirror[8] = 0;      // ([4]: fence progress of held-back colour frames, frames.hip -- never reset)
   return NVBX_OK;
 }
 
@@ -246,12 +247,17 @@ static int reset_map(nvbx_mapper* m) {
   return NVBX_OK;
 }
 
+// (a polled stream write -- hipStreamWriteValue32 of a sequence number into pinned memory, the host spinning on it -- was measured in round 5 and not
+//  kept: the write is itself ~15 us late, a frame waited for took 0.066 instead of 0.052 ms; EXPERIMENTS.md)
+int nvbx_mapper::wait_stream() {
+  NVBX_HIP(hipStreamSynchronize(stream));
+  return NVBX_OK;
+}
 int nvbx_mapper::fetch_counters() {
   if (join_side()) return NVBX_E_DEVICE;
   NVBX_HIP(hipMemcpyAsync(h_counters, d.counters, C_NUM * 4, hipMemcpyDeviceToHost, stream));
   NVBX_HIP(hipMemcpyAsync(h_shc, d.shc, S_NUM * NSH * SH_STRIDE * 4, hipMemcpyDeviceToHost, stream));
-  NVBX_HIP(hipStreamSynchronize(stream));
-  return NVBX_OK;
+  return wait_stream();
 }
 
 // log-odds of a probability, evaluated on the host in float (the oracle does the same with the same libm)
@@ -449,8 +455,7 @@ extern "C" int nvbx_mapper_get_params(const nvbx_mapper* m, nvbx_mapper_params* 
 extern "C" int nvbx_synchronize(nvbx_mapper* m) {
   if (!m) return NVBX_E_INVALID;
   if (m->join_side()) return NVBX_E_DEVICE;
-  NVBX_HIP(hipStreamSynchronize(m->stream));
-  return NVBX_OK;
+  return m->wait_stream();
 }
 extern "C" void nvbx_default_params(nvbx_mapper_params* p) {
   if (!p) return;

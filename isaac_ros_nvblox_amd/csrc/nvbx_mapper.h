@@ -227,6 +227,8 @@ struct nvbx_mapper {
   nvbx::Frame make_frame(const float T_L_C[16], const nvbx_camera* cam, int32_t rows, int32_t cols, int32_t subsample) const;
   nvbx::EsdfArgs make_esdf_args() const;
   int fetch_counters();              // D2H of all counters + stream sync
+  // wait until the mapper's stream has done everything enqueued so far (queries: the slice for a host, counters, nvbx_synchronize)
+  int wait_stream();
   // optional per-kernel timing (hipEvent pairs on the mapper stream), used by bench.py for the roofline line
   bool profiling = false;
   struct Span { const char* name; hipEvent_t a, b; };

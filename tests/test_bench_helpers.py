@@ -87,3 +87,18 @@ def test_round4_kernels_have_algorithmic_bytes():
         assert rows * cols * 4 < b < rows * cols * 64, (k, b)
     two = sum(bench.algorithmic_bytes(k, c, rows, cols, trace_in_mark_view=True, fused=True) for k in ("k_mark_view", "k_integrate_tsdf_color"))
     assert two > 5e6 and bench.overhead_bytes("k_stage_color", rows, cols) < 0.4 * two
+
+
+def test_round5_lidar_view_launches_have_algorithmic_bytes():
+    """The three launches of the LiDAR view calculation over the dense grid: the marking launch reads the sub-sampled range image and
+    stores two bytes per block in view, the scan reads the coarse cell map and 16-byte records go out, the resolving launch touches one record and one
+    hash entry per block -- and `k_mark_view_grid` must not fall into `k_mark_view`'s formula (a prefix of its name)."""
+    c = dict(COUNTS, tsdf_blocks_in_view=112000.0, view_grid_cells=127 * 127 * 50)
+    ab = lambda k: bench.algorithmic_bytes(k, c, 64, 1024, sub_ray=2)
+    assert ab("k_mark_view_grid") == 32 * 512 * 4 + 112000 * 2
+    assert ab("k_scan_view_grid") == 127 * 127 * 50 + 112000 * 18
+    assert ab("k_resolve_view") == 112000 * 40
+    assert ab("k_mark_view") != ab("k_mark_view_grid")
+    assert bench.short("void k_mark_view_grid<nvbx::DepthF32>(nvbx::DMap, ...)") == "k_mark_view_grid"
+    # the staged copy is overhead, never algorithm
+    assert bench.algorithmic_bytes("k_stage_color", COUNTS, R, C) == 0 and bench.overhead_bytes("k_stage_color", R, C) == R * C * 3 * 2
