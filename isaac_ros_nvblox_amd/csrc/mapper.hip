@@ -189,7 +189,9 @@ static int alloc_all(nvbx_mapper* m) {
   NVBX_HIP(hipMalloc(&d.table, tsz * sizeof(Entry)));
   NVBX_HIP(hipMalloc(&d.free_stack, cap * 4));
   NVBX_HIP(hipMalloc(&d.counters, C_NUM * 4));
-  NVBX_HIP(hipMemset(d.counters, 0, C_NUM * 4));      // (k_init_map of the -DNVBX_CHECK_INVARIANTS variant keeps some of them across clear())
+  // (k_init_map of the -DNVBX_CHECK_INVARIANTS variant keeps some of them across clear().  ON THE MAPPER'S STREAM: a memset on the null stream is
+  //  not ordered with a non-blocking stream and landed after k_init_map once in a while -- a map with no free slot, tests/cpp rccl_fusion)
+  NVBX_HIP(hipMemsetAsync(d.counters, 0, C_NUM * 4, m->stream));
   NVBX_HIP(hipMalloc(&d.slot_flags, cap * 4));
   NVBX_HIP(hipMalloc(&d.slot_index, cap * 12));
   NVBX_HIP(hipMalloc(&d.slot_entry, cap * 4));

@@ -831,7 +831,7 @@ __global__ __launch_bounds__(64) void k_mark_view_grid(DMap m, FrameSet<Img, 1> 
 // the blocks that are new (compare-and-swap on the entries; the wavefront's winners pop their slots with ONE atomicSub on the free-stack top and
 // one atomicMax on the high-water mark -- flush_set's B'), then whatever is left (a longer probe chain, a lost insert) by hash_insert.  The caller
 // OWNS these keys for the launch (nobody else looks them up or stamps them), so the entry stamp is a plain store.  Whole wavefront must call.
-template <int K, int PD>
+template <int K, int PD, bool STAMP = true>
 __device__ inline void resolve_keys(const DMap& m, const u64 (&key)[K], const bool (&valid)[K], uint32_t want, uint32_t (&slot)[K], int lane) {
   uint32_t h[K]; uint4 e[K][PD];
 #pragma unroll
@@ -909,7 +909,7 @@ __device__ inline void resolve_keys(const DMap& m, const u64 (&key)[K], const bo
       while (s == SLOT_INVALID) s = ld_slot_acquire(&m.table[hi]);
       slot[k] = s;
     }
-    m.table[hpos[k]].stamp = want;
+    if (STAMP) m.table[hpos[k]].stamp = want;
   }
 }
 
@@ -1004,7 +1004,9 @@ __global__ __launch_bounds__(256) void k_resolve_view(DMap m, uint32_t frame_id,
     valid[0] = i < n && (uint32_t)rec.x == tag;
     key[0] = pack_key(rec.y, rec.z, rec.w);
     if (__ballot(valid[0]) == 0ull) continue;
-    resolve_keys<1, 2>(m, key, valid, want, slot, lane);
+    // (no entry stamp: Entry::stamp de-duplicates the tiles of a CAMERA frame and carries a batch's camera masks; a scan's view is its view list --
+    //  nothing reads the stamp of a LiDAR frame, and 112 k scattered 4-byte stores are 112 k lines written back)
+    resolve_keys<1, 2, false>(m, key, valid, want, slot, lane);
     if (valid[0]) view_list[i].x = (int32_t)slot[0];
   }
 }
