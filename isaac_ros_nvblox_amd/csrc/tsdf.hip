@@ -1479,7 +1479,10 @@ static int launch_view_grid(nvbx_mapper* m, const FrameSet<Img, 1>& fs, const Li
   double wz = 0.0;
   const double hxy = std::hypot((double)f.R_LC[6], (double)f.R_LC[7]);
   for (int k = 0; k < sensor.l.rows; k++) wz = std::max(wz, hxy * std::fabs((double)m->lidar_host[2 * (size_t)k + 1]) + std::fabs((double)f.R_LC[8] * (double)m->lidar_host[2 * (size_t)k]));
-  const int64_t H = (int64_t)std::ceil(reach) + 2, Hz = std::min<int64_t>(H, (int64_t)std::ceil(reach * std::min(1.0, wz)) + 2);
+  int64_t H = (int64_t)std::ceil(reach) + 2, Hz = std::min<int64_t>(H, (int64_t)std::ceil(reach * std::min(1.0, wz)) + 2);
+  // (tests: a box SMALLER than the sensor's range -- the blocks beyond it take the hash path, block by block; tests/test_gpu_round5.py)
+  static const int64_t reach_cap = getenv("NVBX_VIEW_GRID_REACH") ? atoll(getenv("NVBX_VIEW_GRID_REACH")) : 0;
+  if (reach_cap > 0) { H = std::min(H, reach_cap); Hz = std::min(Hz, reach_cap); }
   const int64_t ncx = (2 * H + 1 + 3) / 4, ncz = (2 * Hz + 1 + 3) / 4;
   const int64_t cells = ncx * ncx * ncz;
   static const int64_t cap_mb = getenv("NVBX_VIEW_GRID_MAX_MB") ? atoll(getenv("NVBX_VIEW_GRID_MAX_MB")) : 128;
