@@ -115,13 +115,14 @@ def overhead_bytes(kernel, rows, cols, n_cam=1):
     return n_cam * rows * cols * 3 * 2 if kernel.startswith("k_stage_color") else 0
 
 
-def pmc_source():
+def pmc_source(workload=None):
     """Where `traffic` comes from: the committed table of the last PMC passes (never measured inside this run: counters need rocprofv3)."""
     try:
-        meta = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get("_meta", {})
+        meta = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get("_meta") or {}
     except Exception:
         meta = {}
-    return "profiles/pmc_latest.json@%s (%s)" % (meta.get("commit", "unknown"), meta.get("tag", "?"))
+    w = (meta.get("by_workload") or {}).get(workload) or meta
+    return "profiles/pmc_latest.json[%s]@%s (%s)" % (workload or "camera", w.get("commit_when_summarised", w.get("commit", "unknown")), w.get("tag", "?"))
 
 
 def load_pmc(workload):
@@ -502,7 +503,7 @@ def main_lidar(args):
            "roofline": roofline_of(kern, ms, evo, emp, "longest kernel of the scan; durations = hipEvent spans on the mapper stream minus the calibrated "
                                    "instrumentation cost; compare profiles/*_lidar_kernel_stats.csv", skip=()),
            "cpu_baseline": cpu, "parity": parity}
-    out["roofline"]["traffic_source"] = pmc_source()
+    out["roofline"]["traffic_source"] = pmc_source("lidar")
     # What bounds the scan is VALU ISSUE, not HBM: wavefront instructions per launch from the committed SQ-counter pass (profiles/r05_lidar_sq_pmc.json,
     # tools/gpu_pmc.sh) over this run's launch durations, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 614 G/s
     try:
@@ -721,7 +722,7 @@ def main_decay(args):
            "kernels": kernels_json(kern),
            "roofline": roofline_of(kern, ms, evo, emp, "longest kernel of the dynamic-mapping step (launches of the static and the dynamic mapper together)"),
            "cpu_baseline": cpu, "parity": parity, "capacity_overflow": c["capacity_overflow"]}
-    out["roofline"]["traffic_source"] = pmc_source()
+    out["roofline"]["traffic_source"] = pmc_source("decay")
     print(json.dumps(out))
 
 
@@ -1131,8 +1132,10 @@ def main_camera(args):
     if fused_trace:
         for k_ in [k_ for k_ in prof if short(k_).startswith("k_sphere_trace")]:
             del prof[k_]
+    # the PMC table of THIS shape of the workload (the 4- and 8-camera lines carried one table): multicam = 4 cameras, multicam8 = 8; none for other counts
+    pmc_key = ("multicam8" if ncam == 8 else "multicam" if ncam == 4 else "none") if multicam else ("camera_mesh" if args.with_mesh else "camera")
     kern, ev_overhead_us, empty_pair_us = kernel_table(
-        prof, counts, ms_revisit, n2, lambda k, cc: algorithmic_bytes(k, cc, rows, cols, n_cam=(ncam // launches_cam), trace_in_mark_view=fused_trace, fused=fused_colc), load_pmc(args.workload),
+        prof, counts, ms_revisit, n2, lambda k, cc: algorithmic_bytes(k, cc, rows, cols, n_cam=(ncam // launches_cam), trace_in_mark_view=fused_trace, fused=fused_colc), load_pmc(pmc_key),
         exclude_from_calibration=("k_mesh", "k_esdf_edt"))
     roofline = roofline_of(
         kern, ms_per_step, ev_overhead_us, empty_pair_us,
@@ -1146,7 +1149,7 @@ def main_camera(args):
 
     # bytes the step moves that are NOT in SURVEY 8d's formulas (the staged form's copy of raw-pointer colour images): reported, never counted as algorithmic
     roofline["step"]["overhead_bytes"] = int(sum(overhead_bytes(k_, rows, cols, n_cam=(ncam // launches_cam)) * v_["launches_per_step"] for k_, v_ in kern.items()))
-    roofline["traffic_source"] = pmc_source()
+    roofline["traffic_source"] = pmc_source(pmc_key)
 
     cpu = None
     if not args.no_cpu_baseline:

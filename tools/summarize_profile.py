@@ -66,6 +66,16 @@ def main():
         if any(k.startswith("k_") or k.startswith("__amd") for k in latest):      # round-1 layout (flat = camera)
             latest = {"camera": {k: v for k, v in latest.items() if k.startswith("k_")}}
         latest[workload] = out
+        # where each workload's table comes from: bench.py prints it as roofline.traffic_source (the counters are never measured inside a bench run)
+        import subprocess
+        try:
+            commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
+        except Exception:
+            commit = "unknown"
+        meta = latest.get("_meta") or {}
+        meta.setdefault("by_workload", {})[workload] = {"tag": tag, "commit_when_summarised": commit}
+        meta["tag"] = tag; meta["commit"] = commit
+        latest["_meta"] = meta
         json.dump(latest, open(latest_path, "w"), indent=1)
         print(json.dumps(out, indent=1))
 
