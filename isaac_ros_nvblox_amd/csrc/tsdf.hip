@@ -725,8 +725,8 @@ __global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet
 // memory side, whoever issues them.  So the marking launch issues NO atomic at all:
 //   k_mark_view_grid : the walk (same code as k_mark_view: view_ray_setup, dda_jump, dda_step); a visited block is a plain STORE of 1 to its byte of a
 //                      dense grid around the sensor (idempotent: any number of rays may visit) + a store of 1 to the byte of its 4 x 4 x 4 cell in
-//                      a coarse map.  The grid is cell-major -- the 64 bytes of a cell are one 64-B line.  Within VG_NEAR blocks of the sensor,
-//                      where every ray passes the same few lines, a byte is stored only if it reads 0.
+//                      a coarse map.  The grid is cell-major -- the 64 bytes of a cell are one 64-B line.  (Every visit stores: ~700 k redundant byte
+//                      stores around the sensor cost less than looking first -- VG_NEAR > 0 builds the look-before-store variant, measured slower.)
 //   k_scan_view_grid : reads the coarse map (0.8 MB for a 200 m box at 0.8 m blocks), the lines of the touched cells, and appends {tag, x, y, z} per
 //                      set byte to the view list -- one reservation per wavefront -- and puts every byte it found back to 0: the grid is all-zero
 //                      again when the scan's launches are done.
