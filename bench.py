@@ -814,6 +814,30 @@ def main_node(args):
     launches = sum(v["count"] for v in prof.values())
     drains = sum(v["count"] for k_, v in prof.items() if short(k_).startswith("k_sphere_trace"))      # (a replay outside the pipeline launches the tracing on its own)
     kern = {short(k_): {"launches_per_second": round(v["count"] / (nu / SLOTS), 2), "ms_per_second": round(v["total_ms"] / (nu / SLOTS), 4)} for k_, v in prof.items()}
+    # roofline of the longest kernel, per depth slot, with the counts of the loop's last state (the same formulas and PMC tables as the camera line)
+    cnt_ = {k_: float(v_) for k_, v_ in g.counters().items()}
+    ktab, evo_, emp_ = kernel_table(dict(prof), cnt_, ms_second / SLOTS, nu, lambda k_, cc: algorithmic_bytes(k_, cc, rows, cols), load_pmc("node"), exclude_from_calibration=())
+    roofline = roofline_of(ktab, ms_second / SLOTS, evo_, emp_, "longest kernel per depth slot of the node-cadence second (launch counts per slot are fractional: colour, ESDF, mesh and decay "
+                           "ticks are rarer than depth); durations = hipEvent spans minus the calibrated instrumentation cost", skip=())
+    roofline["traffic_source"] = pmc_source("node")
+    cpu = None
+    if not args.no_cpu_baseline:
+        import oracle
+        oracle.set_num_threads(min(8, os.cpu_count() or 1))
+        oc = oracle.OracleMap(copy_params(oracle, g.params))
+
+        def cslot(i):
+            k = i % nu; s_ = i % SLOTS; d, c_, T = host[k]
+            oc.integrate_depth(d, T, cam)
+            if s_ % 8 == 0:
+                oc.integrate_color(c_, T, cam)
+            if s_ % 4 == 0:
+                oc.update_esdf(); oc.esdf_slice_image()
+            if s_ % 8 == 0:
+                oc.update_mesh(); oc.decay_tsdf(True)
+            if s_ == 0:
+                oc.clear_outside_radius((float(T[0, 3]), float(T[1, 3]), float(T[2, 3])), RADIUS)
+        cpu = cpu_sample(cslot, args.cpu_seconds, SLOTS, "frames/s", "depth slots of the same node-cadence sequence (all of the tick's calls)", oracle)
     parity = None
     if not args.no_parity:
         import oracle
@@ -852,7 +876,7 @@ def main_node(args):
            "tags_note": "as_called: host timer around each call under the default deferral -- color/integrate and esdf/integrate read the ENQUEUE time only, their "
                         "kernels run inside the next tsdf/integrate or the next query (esdf/slice pays for the drain); attributed: classic launch order with a wait "
                         "after every call -- what the README's per-tag timers mean (README.md:69-97)",
-           "kernels": kern, "readme_rtx5090_ms": README_RTX5090_MS, "parity": parity, "block_ms": [round(d * 1e3, 4) for d in dts[:16]]}
+           "kernels": kern, "roofline": roofline, "cpu_baseline": cpu, "readme_rtx5090_ms": README_RTX5090_MS, "parity": parity, "block_ms": [round(d * 1e3, 4) for d in dts[:16]]}
     print(json.dumps(out))
     finish_dist(dist, world)
 
