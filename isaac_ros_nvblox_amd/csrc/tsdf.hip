@@ -550,8 +550,19 @@ template <typename Sensor> static size_t mark_view_smem(bool edt_rides) {
   const size_t mark = 2 * (size_t)Sensor::kSetSize * sizeof(u64);
   return (Sensor::kThreads == 256 && edt_rides && sizeof(EdtShared) > mark) ? sizeof(EdtShared) : mark;
 }
+// Occupancy of the two fused launches, by batch size (the attribute's arguments depend on the template parameter).  One camera frame launches ~960
+// workgroups -- fewer than are resident at the compiler's own register choice (87 VGPRs = 5 waves per SIMD = 1 280 workgroups of four wavefronts), and
+// squeezing it costs time (8 waves per SIMD asked for: 11.2 -> 13.1 us).  A batch of eight launches 2 256: the tiles, dispatched behind the riders,
+// started when the first 1 280 workgroups were done (11-15 us into a 31 us launch, tools/wg_timeline_batch.py) -- there 8 waves per SIMD (64 VGPRs,
+// 26 spilled to scratch) are worth it: 31.6 -> 26.9 us; the fused TSDF / colour launch likewise (three 8-wavefront workgroups per CU -> four): 30.5 -> 28.6 us.
+#ifndef NVBX_MARK_VIEW_ATTR
+#define NVBX_MARK_VIEW_ATTR __attribute__((amdgpu_waves_per_eu(NB > 1 ? 8 : 1, NB > 1 ? 8 : 8)))
+#endif
+#ifndef NVBX_FUSED_ATTR
+#define NVBX_FUSED_ATTR __attribute__((amdgpu_waves_per_eu(NB > 1 ? 8 : 1, NB > 1 ? 8 : 8)))
+#endif
 template <typename Img, typename Sensor, int NB>
-__global__ __launch_bounds__(Sensor::kThreads) void k_mark_view(DMap m, FrameSet<Img, NB> fs, Sensor sensor, int4* view_list, int32_t list_cap,
+__global__ __launch_bounds__(Sensor::kThreads) NVBX_MARK_VIEW_ATTR void k_mark_view(DMap m, FrameSet<Img, NB> fs, Sensor sensor, int4* view_list, int32_t list_cap,
                                                                 int32_t reset_esdf_dirty, int32_t n_edt_wg, EsdfArgs ea, TraceRiderT<NB> tr) {
   constexpr int LSET = Sensor::kSetSize, FR = Sensor::kFlushRounds;
   // LDS: the tile's key set (2 * LSET u64), or -- when a distance transform rides (camera, classic order) -- at least an EdtShared; sized by
@@ -1169,7 +1180,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 //  colour workgroups, dispatched last, start late; asking for four per CU with amdgpu_waves_per_eu(8, 8) was measured in round 4: the colour part
 //  starts at once but every part runs slower, the launch 9.2 -> 10.0 us -- left at the compiler's choice)
 template <typename Img, typename Pix, int NB, bool Plain>
-__global__ __launch_bounds__(512) void k_integrate_tsdf_color(DMap m, FrameSet<Img, NB> fs, CameraSensor sensor, const int4* view_list, int32_t list_cap,
+__global__ __launch_bounds__(512) NVBX_FUSED_ATTR void k_integrate_tsdf_color(DMap m, FrameSet<Img, NB> fs, CameraSensor sensor, const int4* view_list, int32_t list_cap,
                                                               int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, int32_t n_tsdf_wg,
                                                               FrameSetC<Pix, NB> fsc, const float* synth, int32_t srows, int32_t scols, const int4* cand, int32_t cand_cnt_idx,
                                                               int32_t n_edt_wg, EsdfArgs ea, ImportArgs imp) {
