@@ -760,8 +760,11 @@ struct ViewGrid {
 constexpr int VG_NEAR = NVBX_VG_NEAR, VG_CHUNK = NVBX_VG_CHUNK;
 constexpr uint32_t VG_NONE = 0xFFFFFFFFu;
 
+#ifndef NVBX_VIEW_GRID_ATTR
+#define NVBX_VIEW_GRID_ATTR
+#endif
 template <typename Img>
-__global__ __launch_bounds__(64) void k_mark_view_grid(DMap m, FrameSet<Img, 1> fs, LidarSensor sensor, int4* view_list, int32_t list_cap,
+__global__ __launch_bounds__(64) NVBX_VIEW_GRID_ATTR void k_mark_view_grid(DMap m, FrameSet<Img, 1> fs, LidarSensor sensor, int4* view_list, int32_t list_cap,
                                                        int32_t reset_esdf_dirty, int32_t fence_report, ViewGrid vg) {
   constexpr int TR = LidarSensor::kTileRows, TC = LidarSensor::kTileCols, NSEG = LidarSensor::kSegments, C = VG_CHUNK;
   static_assert(TR * TC * NSEG <= 64, "one wavefront per bundle of rays");
