@@ -1613,7 +1613,10 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   }
   m->premark_consumed = false; m->dirty_since_mark = true;
   // grid-stride over the view list: exactly the 1024 workgroups that are resident together (4 per CU)
-  static const int grid_cap = getenv("NVBX_INTEG_GRID") ? atoi(getenv("NVBX_INTEG_GRID")) : 1024;    // (env: tools/integ_grid_sweep.sh)
+  // (a camera BATCH: 512 -- its fused launch is residency-bound, 1 024 eight-wavefront workgroups resident, and 1 024 TSDF workgroups in front kept the colour
+  //  part waiting: 4 / 8 cameras 0.0382 / 0.0560 -> 0.0365 / 0.0547 ms per step, tools/fused_grid_sweep.sh)
+  static const int grid_cap_env = getenv("NVBX_INTEG_GRID") ? atoi(getenv("NVBX_INTEG_GRID")) : 0;    // (env: tools/integ_grid_sweep.sh, tools/fused_grid_sweep.sh)
+  const int grid_cap = grid_cap_env > 0 ? grid_cap_env : (NB > 1 ? 512 : 1024);
   // ... or fewer when the view is smaller: sized from the view count of the last launch the GPU has finished (pinned host memory, not
   // waited for) + 25 % + 64; a hint only -- the kernel grid-strides over whatever the count turns out to be
   // (no launch finished yet -- a new or just cleared map: the full grid; sized for 64 blocks, the first scans of a LiDAR map, enqueued faster
@@ -1635,7 +1638,8 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
       const int32_t cand_idx = tr.cand_cnt_idx;
       const int64_t c_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[3], __ATOMIC_RELAXED));         // candidates of the last colour frame the GPU has finished
       // (no colour frame: update + distance transform only; no colour launch finished yet -- a new or just cleared map: as many as the TSDF part)
-      const int cgrid = !has_color ? 0 : (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, 1024), c_hint == 0 ? (int64_t)grid : ((c_hint + c_hint / 4 + 64 + 7) / 8) * 8));
+      static const int color_cap = getenv("NVBX_COLOR_GRID") ? atoi(getenv("NVBX_COLOR_GRID")) : 1024;      // (A/B: workgroups of the colour part, tools/fused_grid_sweep.sh)
+      const int cgrid = !has_color ? 0 : (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, color_cap), c_hint == 0 ? (int64_t)grid : ((c_hint + c_hint / 4 + 64 + 7) / 8) * 8));
       // a held-back union step of the multi-GPU exchange (nvbx_mark_esdf_dirty_gathered_deferred) rides here in eight workgroups: the peers'
       // blocks become ESDF-dirty for the NEXT marking pass (its own marking launch, or a ride in the colour launch, would be a third launch;
       // beside this frame's view marking it would meet blocks that launch is just allocating -- DESIGN.md 6.1)
