@@ -142,7 +142,10 @@ int main(int argc, char** argv) {
     BlockIndexExchange::AllGather ag;
     if (rccl) { ncclComm_t c = comms[(size_t)r]; ag = [c](const int32_t* send, int32_t* recv, size_t n, hipStream_t st) { return ncclAllGather(send, recv, n, ncclInt32, c, st) == ncclSuccess ? 0 : 1; }; }
     else ag = [&group, r](const int32_t* send, int32_t* recv, size_t n, hipStream_t st) { group[(size_t)r] = Pending{send, recv, n, st}; return 0; };     // carried out at group_end
-    ex[(size_t)r] = std::make_shared<BlockIndexExchange>(ranks, r, 4096, ag);
+    // NVBX_EXCHANGE_COMM_STREAM=1: the collective on a stream of its own per rank (events order it with the mapper's stream both ways) instead of on the mapper's stream
+    hipStream_t cs = nullptr;
+    if (const char* e = std::getenv("NVBX_EXCHANGE_COMM_STREAM")) if (e[0] == '1') HIPCHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    ex[(size_t)r] = std::make_shared<BlockIndexExchange>(ranks, r, 4096, ag, cs);
   }
   auto group_begin = [&]() { if (rccl) ncclGroupStart(); };
   auto group_end = [&]() {

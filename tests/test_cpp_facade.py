@@ -475,6 +475,11 @@ def test_rccl_index_exchange_cpp_host_equals_the_python_path(hip_lib, tmp_path):
     r_ = subprocess.run([os.path.join(CPP, "rccl_index_exchange"), "2", str(n), str(path)], capture_output=True, text=True, timeout=900, env=env)
     assert r_.returncode == 0, r_.stdout[-800:] + r_.stderr[-2000:]
     got = json.loads(r_.stdout.strip().splitlines()[-1])
+    # the same with the collective on a stream of its own per rank (BlockIndexExchange's comm_stream: events order the two streams): same maps
+    r2_ = subprocess.run([os.path.join(CPP, "rccl_index_exchange"), "2", str(n), str(path)], capture_output=True, text=True, timeout=900, env=dict(env, NVBX_EXCHANGE_COMM_STREAM="1"))
+    assert r2_.returncode == 0, r2_.stdout[-800:] + r2_.stderr[-2000:]
+    got2 = json.loads(r2_.stdout.strip().splitlines()[-1])
+    assert got2["per_rank"] == got["per_rank"] and got2["rank0_equals_mapper_without_exchange"] is True
     assert got["ranks"] == 2 and got["rank0_equals_mapper_without_exchange"] is True and got["frames_per_s"] > 0
     assert got["esdf_columns_marked_last_update"][1] >= got["esdf_columns_marked_last_update"][0]
 
