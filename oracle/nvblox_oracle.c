@@ -49,7 +49,10 @@
  *   mc_table*.inc            marching-cubes tables (tools/gen_mc_table.py)        brute-force sign topology of all 256 cases, crack census over the 4096 two-cube configurations (tests/test_independent_checks.py)
  * A DEFINITION shared with the product rather than source: the view calculation's crossing parameters in closed form (raycast_blocks below <->
  * csrc/tsdf.hip dda_step) -- checked against float64 segment / grid-plane geometry without any stepping, tests/view_independent.py
- * (tests/test_independent_checks.py::test_view_calculation_against_float64_geometry).
+ * (tests/test_independent_checks.py::test_view_calculation_against_float64_geometry), and against the textbook accumulated traversal kept below behind
+ * orc_set_traversal_accumulate (::test_closed_form_traversal_against_textbook_accumulation: 0 of 111 735 blocks differ on a 200 m scan).
+ * The TSDF update rule of this file (tsdf_integrate_block: all six weighting modes, both formula sets, blend, clamps) has a float64 numpy model of its
+ * own, tests/tsdf_independent.py (::test_tsdf_update_rule_against_an_independent_float64_model, > 1.5 M voxels within 2e-5).
  * (csrc/nvbx_arith.h is NOT used here: this file keeps `/` and sqrtf; the kernel's shortened sequences are compared with numpy's IEEE results, tests/test_gpu_arith.py.) */
 #include "../isaac_ros_nvblox_amd/csrc/nvbx_lidar_math.h"
 #include "../isaac_ros_nvblox_amd/csrc/nvbx_motion_math.h"

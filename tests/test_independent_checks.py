@@ -338,3 +338,41 @@ def test_closed_form_traversal_against_textbook_accumulation(oracle_mod):
         print("closed form vs accumulation, 200 m LiDAR scan: %d of %d blocks differ" % (len(diff), len(views[0])))
     finally:
         oracle_mod.set_traversal_accumulate(0)
+
+
+def test_tsdf_update_rule_against_an_independent_float64_model(oracle_mod):
+    """The checker's projective TSDF update (what the HIP integrator is compared with bit for bit) against tests/tsdf_independent.py -- numpy float64, whole
+    arrays, no shared code: all six WeightingFunctionType values in both formula sets, two frames from two poses (so the blend with a previous weight and
+    the weight clamp are exercised), every voxel of every block the checker allocated whose decisions do not hang on the last bits."""
+    import helpers as H
+    import tsdf_independent as TI
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    fr = H.frames(2, cam, stride=9, color=False)
+    total = 0
+    for mode in range(6):
+        for variant in (0, 1):
+            pg = M.default_params(weighting_mode=mode, tsdf_weighting_variant=variant, max_weight=1.7)
+            p = H.copy_params(pg, oracle_mod.OrcParams)
+            o = oracle_mod.OracleMap(p)
+            model = {}
+            for d, _, T in fr:
+                o.integrate_depth(d, T, cam)
+                for idx in o.block_indices(oracle_mod.L_TSDF):
+                    key = tuple(int(v) for v in idx)
+                    pd_, pw_ = model.get(key, (np.zeros(512), np.zeros(512)))
+                    nd, nw, upd, rob = TI.update_block(pd_, pw_, key, d, T, cam, p)
+                    model[key] = (nd, nw)
+                    model.setdefault(("robust", key), np.ones(512, bool))
+                    model[("robust", key)] &= rob
+            n_cmp = 0; n_upd = 0
+            for idx in o.block_indices(oracle_mod.L_TSDF):
+                key = tuple(int(v) for v in idx)
+                b = o.get_block(oracle_mod.L_TSDF, idx)
+                ed, ew = model[key]; rob = model[("robust", key)]
+                n_cmp += int(rob.sum()); n_upd += int((ew[rob] > 0).sum())
+                assert np.abs(b["distance"][rob] - ed[rob]).max(initial=0.0) <= 2e-5, (mode, variant, key)
+                assert np.abs(b["weight"][rob] - ew[rob]).max(initial=0.0) <= 2e-5 * max(1.0, float(ew.max())), (mode, variant, key)
+            assert n_cmp > 100000 and n_upd > 20000, (mode, variant, n_cmp, n_upd)
+            total += n_cmp
+    assert total > 1500000
