@@ -13,6 +13,7 @@
 import itertools
 
 import numpy as np
+import pytest
 
 import oracle
 
@@ -376,3 +377,66 @@ def test_tsdf_update_rule_against_an_independent_float64_model(oracle_mod):
             assert n_cmp > 100000 and n_upd > 20000, (mode, variant, n_cmp, n_upd)
             total += n_cmp
     assert total > 1500000
+
+
+@pytest.mark.parametrize("site_rule", [0, 1])
+def test_esdf_column_marking_against_a_numpy_model(oracle_mod, site_rule):
+    """The 2-D ESDF's marking rule -- per (x, y) column over the z band [esdf_slice_min_height, esdf_slice_max_height]: observed = any voxel with
+    weight >= esdf_min_weight; inside = any observed voxel with distance <= 0; site = any observed voxel with |distance| <= max_site_distance (and, rule 0,
+    distance <= 0) -- restated with whole-array numpy on a dense copy of the checker's TSDF layer, against the observed / inside / site flags of the
+    checker's ESDF slice plane: after a first update, and after further frames + a second (incremental) update.  No code shared with either side."""
+    import helpers as H
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    pg = M.default_params(esdf_site_rule=site_rule)
+    p = H.copy_params(pg, oracle_mod.OrcParams)
+    o = oracle_mod.OracleMap(p)
+    vs = float(p.voxel_size)
+    kz_min, kz_max, kz_out = int(np.floor(np.float32(p.esdf_slice_min_height) / np.float32(vs))), int(np.floor(np.float32(p.esdf_slice_max_height) / np.float32(vs))), int(np.floor(np.float32(p.esdf_slice_height) / np.float32(vs)))
+    s_max = float(p.esdf_max_site_distance_vox) * vs
+    fr = H.frames(6, cam, stride=9, color=False)
+
+    def check(tag):
+        ti = o.block_indices(oracle_mod.L_TSDF)
+        lo = ti.min(0); hi = ti.max(0)
+        nz = kz_max - kz_min + 1
+        W, Hh = (hi[0] - lo[0] + 1) * 8, (hi[1] - lo[1] + 1) * 8
+        d = np.zeros((W, Hh, nz), np.float32); w = np.zeros((W, Hh, nz), np.float32)
+        for i in ti:
+            b = o.get_block(oracle_mod.L_TSDF, i).reshape(8, 8, 8)          # [x][y][z]
+            for vz in range(8):
+                kz = int(i[2]) * 8 + vz
+                if kz_min <= kz <= kz_max:
+                    xs, ys = (i[0] - lo[0]) * 8, (i[1] - lo[1]) * 8
+                    d[xs:xs + 8, ys:ys + 8, kz - kz_min] = b["distance"][:, :, vz]; w[xs:xs + 8, ys:ys + 8, kz - kz_min] = b["weight"][:, :, vz]
+        obs_v = w >= np.float32(p.esdf_min_weight)
+        in_v = obs_v & (d <= 0)
+        site_v = obs_v & (np.abs(d) <= np.float32(s_max)) & ((d <= 0) if site_rule == 0 else True)
+        obs, ins, site = obs_v.any(2), in_v.any(2), site_v.any(2)
+        n = 0; n_site = 0
+        bz_out, vz_out = kz_out // 8, kz_out % 8
+        for i in o.block_indices(oracle_mod.L_ESDF):
+            assert int(i[2]) == bz_out
+            b = o.get_block(oracle_mod.L_ESDF, i).reshape(8, 8, 8)[:, :, vz_out]       # [x][y]
+            xs, ys = (i[0] - lo[0]) * 8, (i[1] - lo[1]) * 8
+            if xs < 0 or ys < 0 or xs + 8 > W or ys + 8 > Hh:
+                assert not b["observed"].any(); continue
+            assert np.array_equal(b["observed"].astype(bool), obs[xs:xs + 8, ys:ys + 8]), (tag, i)
+            assert np.array_equal(b["is_inside"].astype(bool), ins[xs:xs + 8, ys:ys + 8]), (tag, i)
+            assert np.array_equal(b["is_site"].astype(bool), site[xs:xs + 8, ys:ys + 8]), (tag, i)
+            n += 64; n_site += int(b["is_site"].sum())
+        # every column the model marks observed lies in an ESDF block
+        have = np.zeros((W, Hh), bool)
+        for i in o.block_indices(oracle_mod.L_ESDF):
+            xs, ys = (i[0] - lo[0]) * 8, (i[1] - lo[1]) * 8
+            if 0 <= xs < W and 0 <= ys < Hh:
+                have[xs:xs + 8, ys:ys + 8] = True
+        assert not (obs & ~have).any(), tag
+        assert n > 3000 and n_site > 100, (tag, n, n_site)
+
+    for d_, _, T in fr[:3]:
+        o.integrate_depth(d_, T, cam)
+    o.update_esdf(); check("first update")
+    for d_, _, T in fr[3:]:
+        o.integrate_depth(d_, T, cam)
+    o.update_esdf(); check("incremental update")
