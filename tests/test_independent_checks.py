@@ -440,3 +440,74 @@ def test_esdf_column_marking_against_a_numpy_model(oracle_mod, site_rule):
     for d_, _, T in fr[3:]:
         o.integrate_depth(d_, T, cam)
     o.update_esdf(); check("incremental update")
+
+
+def test_colour_voxel_rule_against_a_numpy_model(oracle_mod):
+    """The colour integrator's per-voxel rule -- projection, occlusion test against the synthetic depth (bilinear with validity at 1/4 resolution,
+    |synthetic - voxel depth| <= truncation distance), bilinear colour, weight-1 blend rounded to u8, weight clamp -- restated with numpy float64 against the
+    checker's colour layer over two colour frames (first: from nothing; second: blended), on the blocks the checker selected (last_color_view) and, as a
+    negative, on every other allocated block (must stay uncoloured by that frame).  The synthetic depth is taken from the checker (its sphere tracing has an
+    analytic check of its own, tests/test_oracle_ground_truth.py); nothing else is shared."""
+    import helpers as H
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM; fu, fv, cu, cv, w, h = cam
+    pg = M.default_params(max_weight=1.6)
+    p = H.copy_params(pg, oracle_mod.OrcParams)
+    o = oracle_mod.OracleMap(p)
+    vs = float(p.voxel_size); bs = 8 * vs; trunc = float(p.truncation_distance_vox) * vs; f = int(p.sphere_tracing_subsampling)
+    fr = H.frames(3, cam, stride=7, color=True)
+    for d, _, T in fr:
+        o.integrate_depth(d, T, cam)
+    lin = np.arange(512); vx, vy, vz = lin // 64, (lin // 8) % 8, lin % 8
+    model = {}
+    n_cmp = 0; n_col = 0; worst = 0
+    for d, rgb, T in fr[:2]:
+        o.integrate_color(rgb, T, cam)
+        synth = o.synthetic_depth().astype(np.float64); srows, scols = synth.shape
+        Tm = np.asarray(T, np.float64); R = Tm[:3, :3]; t = Tm[:3, 3]
+        img = rgb.astype(np.float64); rows, cols = img.shape[:2]
+        for idx in o.last_color_view():
+            key = tuple(int(v) for v in idx)
+            c0, w0, rob_acc = model.get(key, (np.zeros((512, 3)), np.zeros(512), np.ones(512, bool)))
+            pl = np.stack([idx[0] * bs + vx * vs + vs / 2, idx[1] * bs + vy * vs + vs / 2, idx[2] * bs + vz * vs + vs / 2], 1)
+            pc = (pl - t) @ R; z = pc[:, 2]; zs = np.where(z > 0, z, 1.0)
+            u = fu * pc[:, 0] / zs + cu; v = fv * pc[:, 1] / zs + cv
+            ok = (z > 0) & (u >= 0) & (v >= 0) & (u <= w) & (v <= h) & (z <= float(p.max_integration_distance_m))
+            # synthetic depth, bilinear with validity at (u / f, v / f)
+            us, vs_ = u / f - 0.5, v / f - 0.5
+            x0 = np.floor(us).astype(np.int64); y0 = np.floor(vs_).astype(np.int64)
+            inb = (x0 >= 0) & (y0 >= 0) & (x0 + 1 <= scols - 1) & (y0 + 1 <= srows - 1)
+            xs = np.clip(x0, 0, scols - 2); ys = np.clip(y0, 0, srows - 2)
+            s00, s10, s01, s11 = synth[ys, xs], synth[ys, xs + 1], synth[ys + 1, xs], synth[ys + 1, xs + 1]
+            sval = (s00 > 0) & (s10 > 0) & (s01 > 0) & (s11 > 0)
+            ax, ay = us - np.floor(us), vs_ - np.floor(vs_)
+            sd = (1 - ay) * ((1 - ax) * s00 + ax * s10) + ay * ((1 - ax) * s01 + ax * s11)
+            occl_ok = np.abs(sd - z) <= trunc
+            # colour, bilinear at (u, v)
+            uc, vc = u - 0.5, v - 0.5
+            cx0 = np.floor(uc).astype(np.int64); cy0 = np.floor(vc).astype(np.int64)
+            cin = (cx0 >= 0) & (cy0 >= 0) & (cx0 + 1 <= cols - 1) & (cy0 + 1 <= rows - 1)
+            cxs = np.clip(cx0, 0, cols - 2); cys = np.clip(cy0, 0, rows - 2)
+            bx, by = (uc - np.floor(uc))[:, None], (vc - np.floor(vc))[:, None]
+            col = (1 - by) * ((1 - bx) * img[cys, cxs] + bx * img[cys, cxs + 1]) + by * ((1 - bx) * img[cys + 1, cxs] + bx * img[cys + 1, cxs + 1])
+            upd = ok & inb & sval & occl_ok & cin
+            blended = np.floor((c0 * (w0 / (w0 + 1))[:, None] + col * (1 / (w0 + 1))[:, None]) + 0.5).clip(0, 255)
+            c1 = np.where(upd[:, None], blended, c0); w1 = np.where(upd, np.minimum(w0 + 1, float(p.max_weight)), w0)
+            spread = np.maximum.reduce([s00, s10, s01, s11]) - np.minimum.reduce([s00, s10, s01, s11])
+            rob = ((np.minimum.reduce([np.abs(u), np.abs(v), np.abs(u - w), np.abs(v - h)]) > 0.02) & (np.abs(z - float(p.max_integration_distance_m)) > 1e-3) &
+                   (np.minimum(np.abs(us - np.round(us)), np.abs(vs_ - np.round(vs_))) > 0.01) & (np.minimum(np.abs(uc - np.round(uc)), np.abs(vc - np.round(vc))) > 0.01) &
+                   (np.abs(np.abs(sd - z) - trunc) > 2e-3) & ((spread < 0.3) | ~sval) & (z > 0.05))
+            model[key] = (c1, w1, rob_acc & rob)
+    for idx in o.block_indices(oracle_mod.L_COLOR):
+        key = tuple(int(v) for v in idx)
+        b = o.get_block(oracle_mod.L_COLOR, idx)
+        if key not in model:
+            assert not (b["weight"] > 0).any(); continue
+        c1, w1, rob = model[key]
+        got = np.stack([b["r"], b["g"], b["b"]], 1).astype(np.int64)
+        assert np.array_equal(b["weight"][rob].astype(np.float64), w1[rob]), key
+        diff = np.abs(got[rob] - c1[rob]).max(initial=0)
+        worst = max(worst, int(diff))
+        n_cmp += int(rob.sum()); n_col += int((w1[rob] > 0).sum())
+    assert worst <= 1, worst                      # (a blend that lands on x.5 in one arithmetic and just off it in the other: one grey level)
+    assert n_cmp > 100000 and n_col > 15000, (n_cmp, n_col)
