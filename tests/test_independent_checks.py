@@ -511,3 +511,52 @@ def test_colour_voxel_rule_against_a_numpy_model(oracle_mod):
         n_cmp += int(rob.sum()); n_col += int((w1[rob] > 0).sum())
     assert worst <= 1, worst                      # (a blend that lands on x.5 in one arithmetic and just off it in the other: one grey level)
     assert n_cmp > 100000 and n_col > 15000, (n_cmp, n_col)
+
+
+@pytest.mark.parametrize("exclude,kw", [(False, {}), (True, {}), (False, dict(tsdf_set_free_distance_on_decayed=1, tsdf_decayed_free_distance_vox=3.0)),
+                                        (False, dict(decay_deallocate_decayed_blocks=0))], ids=["all", "exclude_last_view", "free_on_decay", "keep_blocks"])
+def test_tsdf_decay_rule_against_a_numpy_model(oracle_mod, exclude, kw):
+    """decayTsdf / decayTsdfExcludeLastView restated with numpy float32 on a copy of the checker's TSDF layer: weight <- weight * factor; a block none of whose
+    weights reaches the threshold is deallocated (unless decay_integrator_deallocate_decayed_blocks is off); with tsdf_set_free_distance_on_decayed an
+    OBSERVED voxel that falls below the threshold becomes free instead (distance = tsdf_decayed_free_distance_vox voxels, weight = the threshold); the last
+    camera view's blocks are spared on request.  Four calls in a row, block sets and every voxel compared exactly after each."""
+    import helpers as H
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    pg = M.default_params(tsdf_decay_factor=0.45, tsdf_decayed_weight_threshold=0.3, **kw)
+    p = H.copy_params(pg, oracle_mod.OrcParams)
+    o = oracle_mod.OracleMap(p)
+    for d, _, T in H.frames(3, cam, stride=13, color=False):
+        o.integrate_depth(d, T, cam)
+    spared = {tuple(int(v) for v in r) for r in np.asarray(o.last_view())} if exclude else set()
+    model = {tuple(int(v) for v in i): (o.get_block(oracle_mod.L_TSDF, i)["distance"].astype(np.float32).copy(), o.get_block(oracle_mod.L_TSDF, i)["weight"].astype(np.float32).copy())
+             for i in o.block_indices(oracle_mod.L_TSDF)}
+    f = np.float32(p.tsdf_decay_factor); thr = np.float32(p.tsdf_decayed_weight_threshold); free_d = np.float32(p.tsdf_decayed_free_distance_vox) * np.float32(p.voxel_size)
+    n_dropped = 0; n_freed_vox = 0
+    for call in range(4):
+        o.decay_tsdf(exclude)
+        for key in list(model):
+            if key in spared:
+                continue
+            d, w0 = model[key]
+            w = (w0 * f).astype(np.float32)
+            below = w < thr
+            alive = bool((~below).any()) or not int(p.decay_deallocate_decayed_blocks)
+            if int(p.tsdf_set_free_distance_on_decayed):
+                to_free = below & (w0 > 0)
+                d = np.where(to_free, free_d, d).astype(np.float32); w = np.where(to_free, thr, w).astype(np.float32); n_freed_vox += int(to_free.sum())
+            if alive:
+                model[key] = (d, w)
+            else:
+                del model[key]; n_dropped += 1
+        got = {tuple(int(v) for v in i) for i in o.block_indices(oracle_mod.L_TSDF)}
+        assert got == set(model), (call, len(got), len(model))
+        for key, (d, w) in model.items():
+            b = o.get_block(oracle_mod.L_TSDF, np.array(key, np.int32))
+            assert np.array_equal(b["weight"], w) and np.array_equal(b["distance"], d), (call, key)
+    if kw.get("decay_deallocate_decayed_blocks", 1) and not kw.get("tsdf_set_free_distance_on_decayed"):
+        assert n_dropped > 20, n_dropped                  # (weights <= 3 after three frames: 3 * 0.45^3 < 0.3 -- whole blocks go)
+    if kw.get("tsdf_set_free_distance_on_decayed"):
+        assert n_freed_vox > 1000
+    if exclude:
+        assert len(spared) > 50 and spared <= set(model)
