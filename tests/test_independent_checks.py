@@ -560,3 +560,79 @@ def test_tsdf_decay_rule_against_a_numpy_model(oracle_mod, exclude, kw):
         assert n_freed_vox > 1000
     if exclude:
         assert len(spared) > 50 and spared <= set(model)
+
+
+def test_occupancy_update_and_invalid_depth_decay_against_the_independent_model(oracle_mod):
+    """Two more [U] per-voxel rules against tests/tsdf_independent.py (numpy float64, no shared code): the occupancy mapper's log-odds update by region along
+    the ray (free / occupied / unobserved, clamp +-10) over three frames, and the TSDF integrator's invalid-depth decay (weight *= factor where the voxel
+    projects onto an invalid depth tap) on depth images with holes."""
+    import helpers as H
+    import tsdf_independent as TI
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    fr = H.frames(3, cam, stride=9, color=False)
+    # occupancy
+    p = H.copy_params(M.default_params(projective_layer_type=1), oracle_mod.OrcParams)
+    o = oracle_mod.OracleMap(p); model = {}; rob_acc = {}
+    for d, _, T in fr:
+        o.integrate_depth(d, T, cam)
+        for idx in np.asarray(o.last_view()):
+            key = tuple(int(v) for v in idx)
+            new, rob = TI.update_block_occupancy(model.get(key, np.zeros(512)), key, d, T, cam, p)
+            model[key] = new; rob_acc[key] = rob_acc.get(key, np.ones(512, bool)) & rob
+    n = 0; n_occ = 0
+    for idx in o.block_indices(oracle_mod.L_TSDF):
+        key = tuple(int(v) for v in idx); b = o.get_block(oracle_mod.L_TSDF, idx)
+        rob = rob_acc[key]
+        assert np.abs(b["distance"][rob] - model[key][rob]).max(initial=0.0) <= 2e-5, key
+        n += int(rob.sum()); n_occ += int((model[key][rob] > 0).sum())
+    assert n > 100000 and n_occ > 500, (n, n_occ)
+    # invalid-depth decay
+    rng = np.random.default_rng(4)
+    p = H.copy_params(M.default_params(invalid_depth_decay_factor=0.8), oracle_mod.OrcParams)
+    o = oracle_mod.OracleMap(p); model = {}; rob_acc = {}
+    n_dec = 0
+    for k, (d, _, T) in enumerate(fr):
+        d = d.copy()
+        if k > 0:
+            for _ in range(12):
+                r0, c0 = rng.integers(0, d.shape[0] - 12), rng.integers(0, d.shape[1] - 16)
+                d[r0:r0 + 12, c0:c0 + 16] = 0.0                                      # holes: the voxels behind them lose confidence
+        o.integrate_depth(d, T, cam)
+        for idx in o.block_indices(oracle_mod.L_TSDF):
+            key = tuple(int(v) for v in idx)
+            pd_, pw_ = model.get(key, (np.zeros(512), np.zeros(512)))
+            nd, nw, rob = TI.update_block_invalid_decay(pd_, pw_, key, d, T, cam, p)
+            n_dec += int(((nw < pw_) & rob).sum())
+            model[key] = (nd, nw); rob_acc[key] = rob_acc.get(key, np.ones(512, bool)) & rob
+    n = 0
+    for idx in o.block_indices(oracle_mod.L_TSDF):
+        key = tuple(int(v) for v in idx); b = o.get_block(oracle_mod.L_TSDF, idx); rob = rob_acc[key]
+        assert np.abs(b["distance"][rob] - model[key][0][rob]).max(initial=0.0) <= 2e-5, key
+        assert np.abs(b["weight"][rob] - model[key][1][rob]).max(initial=0.0) <= 2e-5, key
+        n += int(rob.sum())
+    assert n > 100000 and n_dec > 2000, (n, n_dec)
+
+
+def test_radius_clearing_against_a_numpy_model(oracle_mod):
+    """clearOutsideRadius: a block goes iff the centre of its cube lies farther than the radius from the centre point -- numpy float32 on the block index list;
+    the cleared-block list names exactly the projective blocks that went."""
+    import helpers as H
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    p = H.copy_params(M.default_params(), oracle_mod.OrcParams)
+    o = oracle_mod.OracleMap(p)
+    for d, _, T in H.frames(4, cam, stride=11, color=False):
+        o.integrate_depth(d, T, cam)
+    o.update_esdf()
+    before = o.block_indices(oracle_mod.L_TSDF)
+    c = np.array([0.3, -0.2, 1.1], np.float32); r = np.float32(1.9); bs = np.float32(8) * np.float32(p.voxel_size)
+    ctr = (before.astype(np.float32) * bs + bs * np.float32(0.5)) - c
+    d2 = (ctr[:, 0] * ctr[:, 0] + ctr[:, 1] * ctr[:, 1]) + ctr[:, 2] * ctr[:, 2]
+    keep = ~(d2 > r * r)
+    o.take_cleared_blocks()
+    o.clear_outside_radius(tuple(float(v) for v in c), float(r))
+    after = {tuple(int(v) for v in i) for i in o.block_indices(oracle_mod.L_TSDF)}
+    assert after == {tuple(int(v) for v in i) for i in before[keep]} and 20 < keep.sum() < len(before) - 20
+    gone = {tuple(int(v) for v in i) for i in np.asarray(o.take_cleared_blocks()).reshape(-1, 3)}
+    assert gone == {tuple(int(v) for v in i) for i in before[~keep]}

@@ -67,3 +67,50 @@ def update_block(prev_d, prev_w, block_index, depth, T_L_C, cam, p, margin=2e-4)
               (np.minimum(np.abs(uc - np.round(uc)), np.abs(vc - np.round(vc))) > margin * 50) & (np.abs(z - max_dist) > margin) &
               (np.abs(sdf + trunc) > margin) & (spread < 0.5))
     return out_d, out_w, upd, robust
+
+
+def project_and_sample(block_index, depth, T_L_C, cam, vs, max_dist):
+    """shared geometry of the update rules below: voxel depth z, measured depth ds, masks (in view & range, four valid taps, some tap invalid), robustness inputs"""
+    fu, fv, cu, cv, w, h = cam
+    bs = 8.0 * vs
+    rows, cols = depth.shape
+    lin = np.arange(512); vx, vy, vz = lin // 64, (lin // 8) % 8, lin % 8
+    pl = np.stack([block_index[0] * bs + vx * vs + vs / 2, block_index[1] * bs + vy * vs + vs / 2, block_index[2] * bs + vz * vs + vs / 2], 1)
+    T = np.asarray(T_L_C, np.float64); pc = (pl - T[:3, 3]) @ T[:3, :3]
+    z = pc[:, 2]; zs = np.where(z > 0, z, 1.0)
+    u = fu * pc[:, 0] / zs + cu; v = fv * pc[:, 1] / zs + cv
+    seen = (z > 0) & (u >= 0) & (v >= 0) & (u <= w) & (v <= h) & (~(max_dist > 0) | (z <= max_dist))
+    uc, vc = u - 0.5, v - 0.5
+    x0 = np.floor(uc).astype(np.int64); y0 = np.floor(vc).astype(np.int64)
+    in_taps = (x0 >= 0) & (y0 >= 0) & (x0 + 1 <= cols - 1) & (y0 + 1 <= rows - 1)
+    xs = np.clip(x0, 0, cols - 2); ys = np.clip(y0, 0, rows - 2)
+    d = depth.astype(np.float64)
+    f00, f10, f01, f11 = d[ys, xs], d[ys, xs + 1], d[ys + 1, xs], d[ys + 1, xs + 1]
+    valid = (f00 > 0) & (f10 > 0) & (f01 > 0) & (f11 > 0)
+    ax, ay = uc - np.floor(uc), vc - np.floor(vc)
+    ds = (1 - ay) * ((1 - ax) * f00 + ax * f10) + ay * ((1 - ax) * f01 + ax * f11)
+    spread = np.maximum.reduce([f00, f10, f01, f11]) - np.minimum.reduce([f00, f10, f01, f11])
+    near_edge = ((np.abs(z) < 1e-3) | (np.minimum.reduce([np.abs(u), np.abs(v), np.abs(u - w), np.abs(v - h)]) < 0.01) |
+                 (np.minimum(np.abs(uc - np.round(uc)), np.abs(vc - np.round(vc))) < 0.01) | (np.abs(z - max_dist) < 2e-4))
+    return z, ds, seen & in_taps & valid, seen & in_taps & ~valid, spread, near_edge
+
+
+def update_block_occupancy(prev_lo, block_index, depth, T_L_C, cam, p):
+    """ProjectiveOccupancyIntegrator as restated: a voxel in front of the measured surface by more than the half width adds logit(free), within +- the half
+    width logit(occupied), behind it logit(unobserved); clamp +-10.  -> (log-odds [512], robust mask)"""
+    lo = lambda q: np.log(np.float32(q) / (np.float32(1.0) - np.float32(q)))
+    hw = float(p.occupied_region_half_width_m)
+    z, ds, got, _, spread, near_edge = project_and_sample(block_index, depth, T_L_C, cam, float(p.voxel_size), float(p.max_integration_distance_m))
+    upd = np.where(z < ds - hw, lo(p.free_region_occupancy_probability), np.where(z <= ds + hw, lo(p.occupied_region_occupancy_probability), lo(p.unobserved_region_occupancy_probability)))
+    out = np.where(got, np.clip(prev_lo + upd, -10.0, 10.0), prev_lo)
+    robust = ~near_edge & (np.abs(z - (ds - hw)) > 2e-4) & (np.abs(z - (ds + hw)) > 2e-4) & (spread < 0.5)
+    return out, robust
+
+
+def update_block_invalid_decay(prev_d, prev_w, block_index, depth, T_L_C, cam, p):
+    """[U] invalid-depth decay: a voxel that projects into the image onto an invalid (<= 0) depth tap has its weight multiplied by the factor (and is not
+    integrated); everything else as update_block"""
+    nd, nw, upd, rob = update_block(prev_d, prev_w, block_index, depth, T_L_C, cam, p)
+    z, ds, got, bad, spread, near_edge = project_and_sample(block_index, depth, T_L_C, cam, float(p.voxel_size), float(p.max_integration_distance_m))
+    nw = np.where(bad, prev_w * float(p.invalid_depth_decay_factor), nw); nd = np.where(bad, prev_d, nd)
+    return nd, nw, rob & ~near_edge
