@@ -690,3 +690,75 @@ def test_mesh_rules_against_a_table_free_numpy_model(oracle_mod):
         nv += len(v); nt += len(t); n_col += int((cols != 127).any(1).sum())
     assert nv > 5000 and nt > 5000 and n_col > 1000, (nv, nt, n_col)
     assert n_flip <= 0.002 * nt, (n_flip, nt)          # (a saddle cube's mean gradient can disagree with one of its sheets; measured: 0 of 18 217)
+
+
+def test_freespace_state_machine_against_a_numpy_model(oracle_mod):
+    """The freespace layer's per-voxel state machine (first touch; occupied with / without the 6-neighbourhood; consecutive-occupancy duration with its
+    forgiveness gap; reset; promotion to high-confidence freespace) as whole-array numpy over a dense copy of the TSDF layer: eight frames at irregular
+    times from a moving camera with an object dropped into some of them, every voxel of every freespace block equal after every frame; then the dynamic
+    mask of a frame against the numpy lookup of each pixel's 3-D point."""
+    import helpers as H
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    kw = dict(projective_layer_type=2, min_duration_since_occupied_for_freespace_ms=250, max_unobserved_to_keep_consecutive_occupancy_ms=150,
+              min_consecutive_occupancy_duration_for_reset_ms=300, check_neighborhood=1)
+    p = H.copy_params(M.default_params(**kw), oracle_mod.OrcParams)
+    o = oracle_mod.OracleMap(p)
+    fr = H.frames(8, cam, stride=3, color=False)
+    times = [0, 90, 210, 260, 400, 520, 640, 760]
+    NB_ = 40; G = NB_ * 8                                                        # dense window of 40^3 blocks around the origin
+    off = np.array([NB_ // 2] * 3) * 8
+    init = np.zeros((G, G, G), bool); last = np.zeros((G, G, G), np.int64); dur = np.zeros((G, G, G), np.int64); hc = np.zeros((G, G, G), bool)
+    thr = np.float32(p.max_tsdf_distance_for_occupancy_m)
+    n_checked = n_occ = n_hc = n_reset = 0
+    for k, ((d_, _, T), now) in enumerate(zip(fr, times)):
+        d_ = d_.copy()
+        if k >= 4:
+            d_[40:90, 60:110] = np.minimum(d_[40:90, 60:110], 0.9)             # something standing in what was free space
+        o.set_time_ms(now); o.integrate_depth(d_, T, cam)
+        dist = np.zeros((G, G, G), np.float32); wgt = np.zeros((G, G, G), np.float32)
+        ti = o.block_indices(oracle_mod.L_TSDF)
+        assert ti.min() > -NB_ // 2 and ti.max() < NB_ // 2 - 1
+        for i in ti:
+            b = o.get_block(oracle_mod.L_TSDF, i).reshape(8, 8, 8); s = tuple(slice(int(a) * 8 + int(c), int(a) * 8 + int(c) + 8) for a, c in zip(i, off))
+            dist[s] = b["distance"]; wgt[s] = b["weight"]
+        view = np.zeros((G, G, G), bool)
+        for i in np.asarray(o.last_view()).reshape(-1, 3):
+            view[tuple(slice(int(a) * 8 + int(c), int(a) * 8 + int(c) + 8) for a, c in zip(i, off))] = True
+        occ_self = (wgt > 0) & (dist < thr)
+        occ = occ_self.copy()
+        for ax in range(3):
+            occ |= np.roll(occ_self, 1, ax) | np.roll(occ_self, -1, ax)         # (the window's rim is empty: nothing wraps)
+        first = view & ~init
+        init |= first; last[first] = now; dur[first] = 0; hc[first] = bool(p.initialize_to_high_confidence_freespace)
+        obs = view & (wgt > 0)
+        is_occ = obs & occ
+        gap = now - last
+        dur = np.where(is_occ, np.where(gap <= int(p.max_unobserved_to_keep_consecutive_occupancy_ms), dur + gap, 0), dur)
+        last = np.where(is_occ, now, last)
+        reset = is_occ & (dur >= int(p.min_consecutive_occupancy_duration_for_reset_ms))
+        n_reset += int((reset & hc).sum())
+        hc = np.where(reset, False, hc)
+        hc = np.where(obs & ~is_occ & (now - last >= int(p.min_duration_since_occupied_for_freespace_ms)), True, hc)
+        for i in o.block_indices(oracle_mod.L_FREESPACE):
+            f = o.get_block(oracle_mod.L_FREESPACE, i).reshape(8, 8, 8); s = tuple(slice(int(a) * 8 + int(c), int(a) * 8 + int(c) + 8) for a, c in zip(i, off))
+            assert init[s].all(), (k, tuple(i))
+            assert np.array_equal(f["is_high_confidence_freespace"].astype(bool), hc[s]), (k, tuple(i))
+            assert np.array_equal(f["last_occupied_timestamp_ms"], last[s]) and np.array_equal(f["consecutive_occupancy_duration_ms"], dur[s]), (k, tuple(i))
+            n_checked += 512
+        assert init.sum() == 512 * len(o.block_indices(oracle_mod.L_FREESPACE))
+        n_occ += int(is_occ.sum()); n_hc = int(hc.sum())
+    assert n_checked > 10 ** 6 and n_occ > 10 ** 4 and n_hc > 10 ** 4 and n_reset > 100, (n_checked, n_occ, n_hc, n_reset)
+    # dynamic mask of one more frame with an object in known free space
+    d_, _, T = fr[-1]; d_ = d_.copy(); d_[30:70, 40:100] = np.minimum(d_[30:70, 40:100], 0.8)
+    mask = o.detect_dynamics(d_, T, cam, float(p.max_integration_distance_m))
+    fu, fv, cu, cv, w_, h_ = cam
+    rr, cc = np.mgrid[0:d_.shape[0], 0:d_.shape[1]]
+    dd = d_.astype(np.float64)
+    pc = np.stack([dd * ((cc + 0.5) - cu) / fu, dd * ((rr + 0.5) - cv) / fv, dd], -1)
+    T64 = np.asarray(T, np.float64); pl = pc @ T64[:3, :3].T + T64[:3, 3]
+    g = pl / float(p.voxel_size)
+    gi = np.floor(g).astype(np.int64) + off
+    robust = (np.abs(g - np.round(g)) > 1e-3).all(-1) & (d_ > 0) & (d_ <= float(p.max_integration_distance_m) - 1e-4)
+    exp = hc[gi[..., 0], gi[..., 1], gi[..., 2]] & (d_ > 0)
+    assert np.array_equal(mask.astype(bool)[robust], exp[robust]) and exp[robust].sum() > 500, int(exp[robust].sum())
