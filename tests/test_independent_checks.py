@@ -762,3 +762,36 @@ def test_freespace_state_machine_against_a_numpy_model(oracle_mod):
     robust = (np.abs(g - np.round(g)) > 1e-3).all(-1) & (d_ > 0) & (d_ <= float(p.max_integration_distance_m) - 1e-4)
     exp = hc[gi[..., 0], gi[..., 1], gi[..., 2]] & (d_ > 0)
     assert np.array_equal(mask.astype(bool)[robust], exp[robust]) and exp[robust].sum() > 500, int(exp[robust].sum())
+
+
+def test_shape_clearing_against_a_numpy_model(oracle_mod):
+    """clearTsdfInsideShapes: a voxel is reset (distance 0, weight 0) iff its centre lies inside one of the spheres / boxes; every other voxel is untouched --
+    numpy float32 over the dense layer."""
+    import helpers as H
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    p = H.copy_params(M.default_params(), oracle_mod.OrcParams)
+    o = oracle_mod.OracleMap(p)
+    for d, _, T in H.frames(3, cam, stride=11, color=False):
+        o.integrate_depth(d, T, cam)
+    ti = o.block_indices(oracle_mod.L_TSDF)
+    before = {tuple(int(v) for v in i): o.get_block(oracle_mod.L_TSDF, i).copy() for i in ti}
+    shapes = np.array([[0, 1.5, 1.0, 0.6, 0.8, 0, 0], [1, -3.1, -2.6, -0.1, -1.0, 0.0, 1.0], [0, 9.0, 9.0, 9.0, 0.2, 0, 0]], np.float32)
+    n_reported = o.clear_tsdf_inside_shapes([("sphere", tuple(s[1:4]), s[4]) if s[0] == 0 else ("aabb", tuple(s[1:4]), tuple(s[4:7])) for s in shapes])
+    vs = np.float32(p.voxel_size); bs = np.float32(8) * vs
+    lin = np.arange(512); v3 = np.stack([lin // 64, (lin // 8) % 8, lin % 8], 1).astype(np.float32)
+    n = 0
+    for key, b0 in before.items():
+        c = (np.asarray(key, np.float32) * bs)[None, :] + v3 * vs + vs * np.float32(0.5)
+        inside = np.zeros(512, bool)
+        for s in shapes:
+            if s[0] == 0:
+                dd = c - s[1:4]
+                inside |= ((dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]) <= s[4] * s[4]
+            else:
+                inside |= (c >= s[1:4]).all(1) & (c <= s[4:7]).all(1)
+        b1 = o.get_block(oracle_mod.L_TSDF, np.asarray(key, np.int32))
+        assert (b1["distance"][inside] == 0).all() and (b1["weight"][inside] == 0).all(), key
+        assert np.array_equal(b1["distance"][~inside], b0["distance"][~inside]) and np.array_equal(b1["weight"][~inside], b0["weight"][~inside]), key
+        n += int(inside.sum())
+    assert n == n_reported and n > 5000, (n, n_reported)
