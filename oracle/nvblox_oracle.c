@@ -53,6 +53,10 @@
  * orc_set_traversal_accumulate (::test_closed_form_traversal_against_textbook_accumulation: 0 of 111 735 blocks differ on a 200 m scan).
  * The TSDF update rule of this file (tsdf_integrate_block: all six weighting modes, both formula sets, blend, clamps) has a float64 numpy model of its
  * own, tests/tsdf_independent.py (::test_tsdf_update_rule_against_an_independent_float64_model, > 1.5 M voxels within 2e-5).
+ * Further rules of this file with a numpy model of their own (tests/test_independent_checks.py; none shares code with this file or the product): occupancy
+ * log-odds update and invalid-depth decay (tests/tsdf_independent.py), 2-D ESDF column marking, the colour voxel rule, TSDF decay with its three switches,
+ * radius and shape clearing, the freespace state machine + dynamic mask, and the mesh integrator's table-free rules (tests/mesh_independent.py: meshed
+ * cubes, welded vertices at the zero crossing in edge order, triangle containment / orientation, vertex colour, normal rule 0).
  * (csrc/nvbx_arith.h is NOT used here: this file keeps `/` and sqrtf; the kernel's shortened sequences are compared with numpy's IEEE results, tests/test_gpu_arith.py.) */
 #include "../isaac_ros_nvblox_amd/csrc/nvbx_lidar_math.h"
 #include "../isaac_ros_nvblox_amd/csrc/nvbx_motion_math.h"
