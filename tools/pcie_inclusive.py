@@ -39,6 +39,11 @@ torch.cuda.set_stream(stream)
 g = M.Mapper(M.default_params(), device=0, block_capacity=1 << 14, stream=stream.cuda_stream)
 dbuf = [torch.empty((rows, cols), dtype=torch.float32, device=dev) for _ in range(3)]
 dargs = [[g.prepare_depth(dbuf[j], poses[k], cam) for k in range(NU)] for j in range(3)]
+# the same with the depth image as uint16 millimetres (the encoding a depth camera delivers; nvbx_integrate_depth_u16mm converts in the kernels): half the bytes
+depth16_h = [torch.from_numpy(np.round(np.clip(np.asarray(d, np.float64) * 1000.0, 0, 65535)).astype(np.uint16).view(np.int16)).pin_memory() for d, _, _ in host]
+dbuf16 = [torch.empty((rows, cols), dtype=torch.int16, device=dev) for _ in range(3)]
+Tn = [M.Mapper._T(T) for T in poses]; kc = M.Mapper._cam(cam)
+import ctypes as C
 frame = M.ColorFrame(rows, cols, 3, 0)
 # resident copies for the comparison loop
 depth_d = [t.to(dev) for t in depth_h]
@@ -85,6 +90,27 @@ def step_copy_stream(i):
     g.integrate_color(frame, poses[k], cam); g.update_esdf()
 
 
+def upload16(i):
+    k = i % NU; j = i % 3
+    copy_stream.wait_event(free[j])
+    with torch.cuda.stream(copy_stream):
+        dbuf16[j].copy_(depth16_h[k], non_blocking=True)
+    ready[j].record(copy_stream)
+
+
+def step_copy_stream_u16(i):
+    k = i % NU; j = i % 3
+    if state["primed"] < i:
+        upload16(i); state["primed"] = i
+    stream.wait_event(ready[j])
+    g._check(g.lib.nvbx_integrate_depth_u16mm(g._h, C.c_void_p(dbuf16[j].data_ptr()), rows, cols, Tn[k].ctypes.data_as(C.c_void_p), C.byref(kc)))
+    free[j].record(stream)
+    upload16(i + 1); state["primed"] = i + 1
+    frame.write(rgb_h[k], copy_stream.cuda_stream); cready.record(copy_stream)
+    stream.wait_event(cready)
+    g.integrate_color(frame, poses[k], cam); g.update_esdf()
+
+
 def timed(step):
     for j in range(3):
         free[j].record(stream)
@@ -107,7 +133,7 @@ def timed(step):
 import gc
 gc.collect(); gc.freeze(); gc.disable()
 res = {}
-for name, fn in (("resident", step_resident), ("same_stream", step_same_stream), ("copy_stream", step_copy_stream), ("resident_again", step_resident)):
+for name, fn in (("resident", step_resident), ("same_stream", step_same_stream), ("copy_stream", step_copy_stream), ("copy_stream_depth_u16mm", step_copy_stream_u16), ("resident_again", step_resident)):
     v = timed(fn)
     res[name] = {"ms_per_frame_median": round(float(np.median(v)), 4), "blocks": [round(x, 4) for x in v]}
 # the bare uploads, for scale
@@ -117,6 +143,6 @@ for i in range(400):
 torch.cuda.synchronize(dev); up = (time.perf_counter() - t0) / 400
 h2d = rows * cols * 4 + rows * cols * 3
 res["upload_only"] = {"ms_per_frame": round(up * 1e3, 4), "GBps": round(h2d / up / 1e9, 2)}
-res["h2d_bytes_per_frame"] = h2d
+res["h2d_bytes_per_frame"] = h2d; res["h2d_bytes_per_frame_depth_u16mm"] = rows * cols * 2 + rows * cols * 3
 res["workload"] = "configs[1] camera step, %d distinct 640x480 frames on the allocated map, blocks of %d frames" % (NU, STEPS)
 print(json.dumps(res, indent=1))
