@@ -57,7 +57,13 @@ class BlockIndexExchange {
   int32_t* message(int slot) const { return buf_[slot]; }
 
   void beforeDepth(nvbx_mapper* m) { checkRc(nvbx_set_view_export(m, buf_[frame_ % kSlots], max_blocks_), "nvbx_set_view_export"); }
+  // A host whose depth rate exceeds its colour / ESDF rate (the reference node: 40 Hz depth, 5 Hz colour, 10 Hz ESDF, nvblox_base.yaml:13-23) calls
+  // start() several times per finishPrevious().  No frame's lists may be dropped and no buffer set refilled before it was applied, so start() itself
+  // advances the rotation when the previous frame's collective is still waiting for its finishPrevious (round 6): the lists gathered one
+  // frame earlier are handed over (in the form the host last used), the previous frame's become pending.  Buffer set s is refilled by the collective
+  // of frame i + 3, which is enqueued behind integrateDepth(i + 3); the union step of set s rides at the latest in integrateDepth(i + 2)'s launches.
   void start(nvbx_mapper* m) {
+    if (started_ >= 0) advance(m, last_deferred_);
     const int s = (int)(frame_ % kSlots);
     hipStream_t ms = mapperStream(m);
     hipStream_t cs = comm_stream_ ? comm_stream_ : ms;
@@ -65,24 +71,36 @@ class BlockIndexExchange {
     const size_t n = (size_t)(max_blocks_ + 1) * 3;
     if (all_gather_(buf_[s], all_[s], n, cs) != 0) { std::fprintf(stderr, "[nvblox_hip] BlockIndexExchange: all-gather failed\n"); std::abort(); }
     if (comm_stream_) (void)hipEventRecord(done_[s], comm_stream_);
-    started_ = s; frame_++; finished_this_frame_ = false;
+    started_ = s; slot_frame_[s] = frame_; frame_++; finished_this_frame_ = false;
   }
   // between integrateDepth and updateEsdf of the current frame: hand over the PREVIOUS frame's lists; the current frame's stay in flight
   void finishPrevious(nvbx_mapper* m, bool deferred) {
-    if (pending_ >= 0) apply(m, pending_, deferred);
-    pending_ = started_; started_ = -1; finished_this_frame_ = true;
+    last_deferred_ = deferred;
+    advance(m, deferred);
+    finished_this_frame_ = true;
   }
   bool finishedThisFrame() const { return finished_this_frame_; }
   void drain(nvbx_mapper* m) {
-    if (started_ >= 0) { if (pending_ >= 0) apply(m, pending_, false); pending_ = started_; started_ = -1; }
+    if (started_ >= 0) advance(m, false);
     if (pending_ >= 0) { apply(m, pending_, false); pending_ = -1; }
     checkRc(nvbx_set_view_export(m, nullptr, 0), "nvbx_set_view_export");
   }
+  // (tests) how many frames' gathered lists have been handed to the mapper, and the frame number of the last one: after drain() every started frame
+  // has been applied exactly once, in order
+  int64_t frames_applied() const { return frames_applied_; }
+  int64_t last_applied_frame() const { return last_applied_frame_; }
+  bool applied_in_order() const { return applied_in_order_; }
 
  private:
   static void checkRc(int rc, const char* what) { if (rc < 0) { std::fprintf(stderr, "[nvblox_hip] %s failed (%d): %s\n", what, rc, nvbx_last_error()); std::abort(); } }
   static hipStream_t mapperStream(nvbx_mapper* m) { void* s = nullptr; checkRc(nvbx_get_stream(m, &s), "nvbx_get_stream"); return (hipStream_t)s; }
+  void advance(nvbx_mapper* m, bool deferred) {
+    if (pending_ >= 0) apply(m, pending_, deferred);
+    pending_ = started_; started_ = -1;
+  }
   void apply(nvbx_mapper* m, int slot, bool deferred) {
+    if (slot_frame_[slot] != last_applied_frame_ + 1) applied_in_order_ = false;       // (a dropped frame, or a set refilled before it was applied)
+    last_applied_frame_ = slot_frame_[slot]; frames_applied_++;
     if (comm_stream_) (void)hipStreamWaitEvent(mapperStream(m), done_[slot], 0);       // the union step reads the gathered lists after they have landed
     if (world_ < 2) return;
     if (deferred) checkRc(nvbx_mark_esdf_dirty_gathered_deferred(m, all_[slot], world_, rank_, max_blocks_), "nvbx_mark_esdf_dirty_gathered_deferred");
@@ -94,8 +112,9 @@ class BlockIndexExchange {
   int32_t* buf_[kSlots] = {}; int32_t* all_[kSlots] = {};
   hipEvent_t ready_[kSlots] = {}, done_[kSlots] = {};
   int64_t frame_ = 0;
+  int64_t slot_frame_[kSlots] = {-1, -1, -1}, frames_applied_ = 0, last_applied_frame_ = -1;
   int pending_ = -1, started_ = -1;
-  bool finished_this_frame_ = true;
+  bool finished_this_frame_ = true, last_deferred_ = true, applied_in_order_ = true;
 };
 
 }  // namespace nvblox

@@ -76,7 +76,7 @@ class MultiMapper {
   std::shared_ptr<Mapper> foreground_mapper() const { return foreground_mapper_; }
 
   // libnvblox_hip extension (multi-GPU, one camera / one MultiMapper per GPU; block_index_exchange.h): with an exchange set, every camera
-  // integrateDepth writes and starts this rank's block-index message, the next integrateColor (or updateEsdf, for hosts without colour) hands the
+  // integrateDepth (plain, mask-split and dynamic) writes and starts this rank's block-index message, the next integrateColor (or updateEsdf, for hosts without colour) hands the
   // previous frame's gathered lists to the background mapper -- the union step before the ESDF sweep.  The node's calls do not change.
   void setBlockIndexExchange(std::shared_ptr<BlockIndexExchange> exchange) {
     if (block_index_exchange_) block_index_exchange_->drain(background_mapper_->c_handle());
@@ -104,7 +104,9 @@ class MultiMapper {
                                        multi_params_.mask_occlusion_threshold_m, dynamic_mask_.dataPtr(), depth_background_.dataPtr(), depth_foreground_.dataPtr(),
                                        reinterpret_cast<uint8_t*>(depth_overlay_.dataPtr())), "nvbx_dynamic_depth_split");
     if (update_time_ms) background_mapper_->setUpdateTime(*update_time_ms);
+    if (block_index_exchange_) block_index_exchange_->beforeDepth(m);        // (the static part's blocks are what the peers' ESDF sweeps need)
     background_mapper_->integrateDepth(depth_background_, T_L_C, camera);
+    if (block_index_exchange_) block_index_exchange_->start(m);
     foreground_mapper_->integrateDepth(depth_foreground_, T_L_C, camera);
     last_dynamic_T_L_C_ = T_L_C; last_dynamic_camera_ = camera;
   }
@@ -128,7 +130,9 @@ class MultiMapper {
     checkNvbx(nvbx_split_depth_by_mask(background_mapper_->c_handle(), depth.dataConstPtr(), depth.rows(), depth.cols(), mask.dataConstPtr(), mask.rows(), mask.cols(),
                                        T, &depth_camera.c_abi(), &mask_camera.c_abi(), multi_params_.mask_occlusion_threshold_m, depth_background_.dataPtr(),
                                        depth_foreground_.dataPtr(), reinterpret_cast<uint8_t*>(depth_overlay_.dataPtr())), "nvbx_split_depth_by_mask");
+    if (block_index_exchange_) block_index_exchange_->beforeDepth(background_mapper_->c_handle());
     background_mapper_->integrateDepth(depth_background_, T_L_CD, depth_camera);
+    if (block_index_exchange_) block_index_exchange_->start(background_mapper_->c_handle());
     foreground_mapper_->integrateDepth(depth_foreground_, T_L_CD, depth_camera);
   }
   const DepthImage& getLastDepthFrameForeground() const { return depth_foreground_; }      // nvblox_node.cpp:1126
@@ -158,6 +162,7 @@ class MultiMapper {
   // nvblox_node.cpp:1261-1262: the masked pixels are removed from the colour image before the background mapper integrates it
   void integrateColor(const ColorImage& color, const MonoImage& mask, const Transform& T_L_C, const Camera& camera) {
     if (!human_) unsupported("masked colour integration outside the human mapping types");
+    if (block_index_exchange_ && !block_index_exchange_->finishedThisFrame()) block_index_exchange_->finishPrevious(background_mapper_->c_handle(), true);
     color_background_.resize(color.rows(), color.cols());
     checkNvbx(nvbx_split_color_by_mask(background_mapper_->c_handle(), reinterpret_cast<const uint8_t*>(color.dataConstPtr()), color.rows(), color.cols(),
                                        mask.dataConstPtr(), reinterpret_cast<uint8_t*>(color_background_.dataPtr()), nullptr), "nvbx_split_color_by_mask");

@@ -21,6 +21,12 @@ namespace nvblox {
 // What differs from a plain buffer: after integrateColor, the memory behind a NON-CONST dataPtr() is a different frame whose contents are unspecified
 // (every writer in the reference overwrites the whole image); NVBX_IMAGE_ROTATE_PRESERVE=1 in the environment copies the old contents over first
 // (a blocking device-to-device copy -- for hosts that patch images in place).  Const access (dataConstPtr) never rotates.
+// Lifetime (round 6): an image that is destroyed, resized or rotated lets go of its frame with nvbx_frame_release -- the frame is handed to another
+// image only after everything enqueued so far on the streams the library knows (every live mapper's stream -- the node's cuda_stream_ -- and the
+// legacy default stream) has finished: a temporary DepthImage passed to integrateDepth may die right after the call, as with the reference's buffers
+// (whose cudaFree waits for the device).  Work on a non-blocking stream of the host's own that no mapper runs on is the
+// host's to finish first, as it is with any allocator that does not synchronise.  The frame stays on the device it was acquired on: a rotation or a
+// regrowth happens there, whatever the calling thread's current device is.
 template <typename T>
 class Image {
  public:
@@ -32,7 +38,7 @@ class Image {
   Image& operator=(const Image&) = delete;
   Image(Image&& o) noexcept { *this = std::move(o); }
   Image& operator=(Image&& o) noexcept {
-    if (this != &o) { release(); data_ = o.data_; rows_ = o.rows_; cols_ = o.cols_; cap_ = o.cap_; memory_type_ = o.memory_type_; o.data_ = nullptr; o.rows_ = o.cols_ = 0; o.cap_ = 0; }
+    if (this != &o) { release(); data_ = o.data_; rows_ = o.rows_; cols_ = o.cols_; cap_ = o.cap_; memory_type_ = o.memory_type_; device_ = o.device_; o.data_ = nullptr; o.rows_ = o.cols_ = 0; o.cap_ = 0; }
     return *this;
   }
   int rows() const { return rows_; } int cols() const { return cols_; }
@@ -48,7 +54,10 @@ class Image {
       release();
       if (memory_type_ == MemoryType::kHost) (void)hipHostMalloc((void**)&data_, need * sizeof(T));
       else if (memory_type_ == MemoryType::kUnified) (void)hipMallocManaged((void**)&data_, need * sizeof(T));
-      else { int dev = 0; (void)hipGetDevice(&dev); void* p = nullptr; if (nvbx_frame_acquire(dev, need * sizeof(T), NVBX_STREAM_UNKNOWN, &p) == 0) data_ = static_cast<T*>(p); }
+      else {
+        int dev = device_; if (dev < 0) (void)hipGetDevice(&dev);      // (an image that had a frame regrows on that frame's device)
+        void* p = nullptr; if (nvbx_frame_acquire(dev, need * sizeof(T), NVBX_STREAM_UNKNOWN, &p) == 0) { data_ = static_cast<T*>(p); device_ = dev; }
+      }
       cap_ = data_ ? need : 0;
     }
     rows_ = rows; cols_ = cols;
@@ -68,7 +77,7 @@ class Image {
   // were not enqueued on the writer's own stream, continue in another one
   void makeExclusive(void* writer_stream) {
     if (memory_type_ != MemoryType::kDevice || !data_ || nvbx_frame_writable(data_, writer_stream) != 0) return;
-    int dev = 0; (void)hipGetDevice(&dev);
+    int dev = nvbx_frame_device(data_); if (dev < 0) (void)hipGetDevice(&dev);      // (the frame's own device, not the calling thread's current one)
     void* p = nullptr;
     if (nvbx_frame_acquire(dev, cap_ * sizeof(T), writer_stream, &p) != 0) return;       // (no memory: stay -- the mapper's staged copy is not in play, so say so loudly)
     static const bool preserve = [] { const char* e = getenv("NVBX_IMAGE_ROTATE_PRESERVE"); return e && e[0] == '1'; }();
@@ -86,6 +95,7 @@ class Image {
   T* data_ = nullptr;
   int rows_ = 0, cols_ = 0;
   size_t cap_ = 0;
+  int device_ = -1;          // the device of the image's frame (kDevice), remembered across release() so that a regrowth stays there
   MemoryType memory_type_;
 };
 

@@ -241,8 +241,14 @@ int nvbx_mapper_set_color_deferral(nvbx_mapper* m, int32_t enable);
  *     finished, or when `writer_stream` is the very stream they were enqueued on (stream order does the rest); otherwise another frame is taken, the
  *     pool grows (NVBX_FRAME_POOL_MAX frames per size, default 8) or -- pool full -- the call waits for the oldest.  writer_stream: the stream the
  *     caller will write the frame on, or NVBX_STREAM_UNKNOWN (host writes, any stream).
- *   nvbx_frame_retain / nvbx_frame_release: reference counting; at 0 the frame returns to the pool (a caller that lets go of a frame ITS OWN work still
- *     uses orders that itself, as with hipFree).  nvbx_frame_refcount: > 1 = somebody else (a mapper) holds it too; -1 = not a frame.
+ *   nvbx_frame_retain / nvbx_frame_release: reference counting; at 0 the frame returns to the pool -- and is handed out again only after the work that
+ *     may still use it: the release that brings the count to 0 records an event on every stream the library knows on the frame's device (the streams
+ *     of live mappers and the legacy default stream), and nvbx_frame_acquire skips the frame until those events are reached (hipFree, which the
+ *     reference's image buffers end in, waits for the device instead).  Only work on a non-blocking stream that no live mapper runs on is the
+ *     caller's to order (or to name: nvbx_frame_release_on).  nvbx_frame_release_on(ptr, stream): the same for a caller that knows
+ *     the ONE stream its work on the frame was enqueued on (one event; NVBX_STREAM_UNKNOWN = nvbx_frame_release).  A holder that lets go while others
+ *     still hold the frame records nothing: its writes precede the others' reads by its own ordering, as with any shared buffer.
+ *     nvbx_frame_refcount: > 1 = somebody else (a mapper) holds it too; -1 = not a frame.  nvbx_frame_device: the device the frame lives on (-1 = not a frame).
  *     nvbx_frame_writable: the question a writer asks before it overwrites a frame it holds (below).
  *   nvbx_frame_pool_trim(device | -1): hipFree every frame nobody holds; returns how many.  nvbx_frame_pool_stats: {held, free, bytes, created, waits, syncs}.
  *   nvbx_frame_upload: hipMemcpyAsync into a frame on `hip_stream` (NVBX_STREAM_UNKNOWN: a blocking hipMemcpy) -- for hosts without a HIP binding of
@@ -254,8 +260,10 @@ int nvbx_mapper_set_color_deferral(nvbx_mapper* m, int32_t enable);
 int nvbx_frame_acquire(int device, size_t bytes, void* writer_stream, void** dev_ptr_out);
 int nvbx_frame_retain(void* dev_ptr);
 int nvbx_frame_release(void* dev_ptr);
+int nvbx_frame_release_on(void* dev_ptr, void* last_stream);
+int32_t nvbx_frame_device(const void* dev_ptr);
 int32_t nvbx_frame_refcount(const void* dev_ptr);
-/* 1 = the caller is the only holder AND no launch of a mapper can still be reading the frame (finished, or enqueued on `writer_stream` itself): write in
+/* 1 = the caller is the only holder AND no launch of a mapper (nor work recorded at an earlier release) can still be using the frame (finished, or enqueued on `writer_stream` itself): write in
  * place; 0 = take another frame (nvbx_frame_acquire) and let go of this one; -1 = not a live frame. */
 int32_t nvbx_frame_writable(const void* dev_ptr, void* writer_stream);
 int nvbx_frame_pool_trim(int device);

@@ -181,6 +181,8 @@ SIGNATURES = {
     "nvbx_frame_acquire": (C.c_int, [C.c_int, C.c_size_t, _vp, C.POINTER(_vp)]),
     "nvbx_frame_retain": (C.c_int, [_vp]),
     "nvbx_frame_release": (C.c_int, [_vp]),
+    "nvbx_frame_release_on": (C.c_int, [_vp, _vp]),
+    "nvbx_frame_device": (_i32, [_vp]),
     "nvbx_frame_refcount": (_i32, [_vp]),
     "nvbx_frame_writable": (_i32, [_vp, _vp]),
     "nvbx_frame_pool_trim": (C.c_int, [C.c_int]),

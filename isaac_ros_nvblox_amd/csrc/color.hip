@@ -326,11 +326,12 @@ extern "C" int nvbx_integrate_color_owned(nvbx_mapper* m, void* frame, int32_t b
     set_error(too_small ? "nvbx_integrate_color_owned: the frame is smaller than rows x cols pixels" : "nvbx_integrate_color_owned: not a live frame of nvbx_frame_acquire"); return NVBX_E_INVALID; }
   const int rc = bytes_per_pixel == 4 ? nvbx_integrate_color_bgra8(m, (const uint8_t*)frame, rows, cols, T_L_C, camera) : nvbx_integrate_color(m, (const uint8_t*)frame, rows, cols, T_L_C, camera);
   if (rc == NVBX_E_INVALID) { (void)nvbx_frame_release(frame); return rc; }              // (argument errors: the caller keeps the frame)
+  (void)nvbx_frame_release(frame);          // the caller's reference: ownership has passed (never the last one here -- this call still holds its own)
   // a frame that was NOT held back (deferral off, an occupancy mapper) has just been read by launches enqueued on the mapper's stream: it is let go of
-  // behind them, with a fence, like a held-back one
-  if (rc == NVBX_OK && !(m->color_pending.on && m->color_pending.frames[0] == frame)) { m->consumed_frames.push_back(frame); m->release_consumed_frames(); }
-  else (void)nvbx_frame_release(frame);
-  (void)nvbx_frame_release(frame);          // the caller's reference: ownership has passed
+  // behind them, with a fence, like a held-back one -- and so is the frame of a call that failed on the device (NVBX_E_DEVICE): reader launches may
+  // already be enqueued
+  if (rc == NVBX_OK && m->color_pending.on && m->color_pending.frames[0] == frame) (void)nvbx_frame_release(frame);     // (held back: the mapper keeps the reference defer_color took)
+  else { m->consumed_frames.push_back(frame); m->release_consumed_frames(); }
   return rc;
 }
 // Up to NVBX_MAX_BATCH colour frames (rgb8, same image size) in ONE launch set: see include/nvblox_hip.h

@@ -259,7 +259,11 @@ extern "C" int nvbx_esdf_slice_to_image(nvbx_mapper* m, float unknown_value, flo
   // (called right behind nvbx_esdf_slice_size -- the facade's EsdfSlicer sizes its image first -- nothing has been enqueued since: the counters
   //  on the host are still the device's, no second round trip)
   int rc = NVBX_OK;
-  if (m->slice_size_seq != 0 && m->slice_size_seq == m->enqueue_seq && !m->color_pending.on && !m->esdf_update_pending && !m->edt_pending && !m->import_pending) {
+  if (m->slice_size_seq != 0 && m->slice_size_seq == m->enqueue_seq && !m->color_pending.on && !m->esdf_update_pending && !m->edt_pending && !m->import_pending && !m->side_pending) {
+    // (the parts of join_side() that still apply: this mapper's device is the current one -- the call may come from another thread, or behind a call
+    //  into a mapper on another GPU -- and the launch below counts as work on the main stream; nothing is held back and the side stream is joined)
+    { int cur = -1; if (hipGetDevice(&cur) != hipSuccess || cur != m->device) NVBX_HIP(hipSetDevice(m->device)); }
+    m->main_dirty = true;
     const int32_t* c0 = m->h_counters + C_ESDF_AABB;
     if (c0[0] > c0[2]) { *rows = 0; *cols = 0; } else { *cols = (c0[2] - c0[0] + 1) * 8; *rows = (c0[3] - c0[1] + 1) * 8; }
     if (aabb && *rows) {

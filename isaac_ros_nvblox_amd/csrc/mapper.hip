@@ -364,6 +364,7 @@ extern "C" int nvbx_mapper_create(int device, void* hip_stream, const nvbx_mappe
   { const char* e = getenv("NVBX_MAX_BLOCKS"); if (e && atoll(e) > 0) m->max_capacity = std::max<int64_t>(block_capacity, std::min<int64_t>(atoll(e), 1ll << 24)); }
   if (hip_stream) { m->stream = (hipStream_t)hip_stream; m->own_stream = false; }
   else { hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking); if (e != hipSuccess) { set_error("hipStreamCreate", e); delete m; return NVBX_E_DEVICE; } m->own_stream = true; }
+  nvbx::frames_register_stream(device, m->stream); m->stream_registered = true;      // (frames let go of without a fence wait for this stream too, frames.hip)
   // ESDF on a side stream beside colour integration: off by default, NVBX_SIDE_STREAM=1 enables (the
   // cross-stream hand-off costs ~10 us each way on this runtime, which eats most of the overlap)
   { const char* e = getenv("NVBX_SIDE_STREAM"); m->use_side = (e && e[0] == '1'); }
@@ -398,7 +399,8 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
                   m->synth, m->view_class, m->view_grid_fine, m->color_cand, m->depth_pre, m->mask_zmin, m->apply_postab, m->esdf3_scratch, m->cc_scratch, m->dyn_scratch, d.freespace, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   // (both streams are idle: whatever read a held-back colour frame has finished)
-  (void)m->take_pending(); m->release_consumed_frames(); nvbx::frames_forget_owner(m);
+  (void)m->take_pending(); m->release_consumed_frames();
+  if (m->stream_registered) nvbx::frames_forget_owner(m, m->device, m->stream);
   for (auto& s : m->spans) { if (s.a) (void)hipEventDestroy(s.a); if (s.b) (void)hipEventDestroy(s.b); }
   for (hipEvent_t e : m->event_pool) if (e) (void)hipEventDestroy(e);
   if (m->h_counters) (void)hipHostFree(m->h_counters);

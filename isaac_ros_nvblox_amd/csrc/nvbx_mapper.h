@@ -38,7 +38,8 @@ float log_odds(float p);
 // frames.hip: library-owned, reference-counted device frames (ownership transfer of input images)
 bool frame_retain_if_frame(const void* p, size_t need_bytes, bool* too_small);
 void frame_release_fenced(void* p, const volatile int32_t* progress, int32_t seq, const volatile int32_t* reports_enqueued, hipStream_t reader, const void* owner);
-void frames_forget_owner(const void* owner);
+void frames_register_stream(int device, hipStream_t stream);
+void frames_forget_owner(const void* owner, int device, hipStream_t stream);
 void set_error(const char* what, hipError_t e);
 void set_error(const char* what);
 
@@ -65,7 +66,7 @@ static inline bool nvbx_index_in_range(int32_t x, int32_t y, int32_t z) {
 struct nvbx_mapper {
   int device = 0;
   hipStream_t stream = nullptr;
-  bool own_stream = false;
+  bool own_stream = false, stream_registered = false;
   // Side stream: the ESDF update (k_esdf_mark + k_esdf_edt) is independent of colour integration, so it
   // runs on its own stream behind an event recorded after the last non-colour operation and overlaps integrateColor.
   // Every other entry point joins the side stream first, so the caller still sees single-stream ordering.

@@ -523,3 +523,46 @@ def test_rccl_index_exchange_cpp_host_equals_the_python_path(hip_lib, tmp_path):
         assert abs(c["tsdf_sum"] - float((d_ * w)[w > 0].sum())) <= 1e-6 * max(1.0, abs(c["tsdf_sum"]))
         assert tuple(c["slice_shape"]) == img.shape and c["slice_known"] == int(known.sum())
         assert abs(c["slice_sum"] - float(img[known].astype(np.float64).sum())) <= 1e-6 * max(1.0, abs(c["slice_sum"]))
+
+
+def _write_frames_bin(path, fr, cam):
+    with open(path, "wb") as f:
+        f.write(np.array([len(fr), cam[5], cam[4]], np.int32).tobytes())
+        f.write(np.array(cam[:4], np.float32).tobytes())
+        for d, rgb, T in fr:
+            f.write(np.asarray(T, np.float32).reshape(4, 4).tobytes())
+            f.write(np.ascontiguousarray(d, np.float32).tobytes())
+            f.write(np.ascontiguousarray(rgb, np.uint8).tobytes())
+
+
+def test_round6_checks_compile():
+    subprocess.check_call(["make", "-C", CPP, "round6_checks"], stdout=subprocess.DEVNULL)
+
+
+@pytest.mark.gpu
+def test_temporary_images_may_die_with_their_readers_in_flight(hip_lib, tmp_path):
+    """tests/cpp/round6_checks.cpp lifetime: a temporary DepthImage / ColorImage handed to integrateDepth / integrateColor and destroyed
+    right after the call while the mapper's stream is still busy -- the frame returns to the library's pool but is not handed to the next image
+    (which a blocking host copy overwrites) before the launches that read it have finished; map == a mapper fed long-lived images, bit for bit."""
+    subprocess.check_call(["make", "-C", CPP, "round6_checks"], stdout=subprocess.DEVNULL)
+    cam = H.SMALL_CAM
+    path = tmp_path / "frames.bin"
+    _write_frames_bin(path, H.frames(6, cam, color=True, stride=9), cam)
+    r = subprocess.run([os.path.join(CPP, "round6_checks"), "lifetime", str(path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["equal"] is True and got["handed_out_while_busy"] == 0 and got["busy_frames"] > 0 and got["reused_when_idle"] is True, got
+
+
+@pytest.mark.gpu
+def test_block_index_exchange_under_the_node_call_cadence(hip_lib, tmp_path):
+    """tests/cpp/round6_checks.cpp cadence: 40 integrateDepth, 5 integrateColor, 10 updateEsdf per simulated second (nvblox_base.yaml:13-23)
+    through MultiMapper::setBlockIndexExchange, static and dynamic mapping types -- every frame's gathered lists reach the mapper exactly once and in
+    order (no start() overwrites an unfinished one, no buffer set is refilled before it was applied); the map equals a mapper without exchange."""
+    subprocess.check_call(["make", "-C", CPP, "round6_checks"], stdout=subprocess.DEVNULL)
+    cam = H.SMALL_CAM
+    path = tmp_path / "frames.bin"
+    _write_frames_bin(path, H.frames(8, cam, color=True, stride=7), cam)
+    r = subprocess.run([os.path.join(CPP, "round6_checks"), "cadence", str(path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert json.loads(r.stdout.strip().splitlines()[-1])["failures"] == 0, r.stdout[-2000:]

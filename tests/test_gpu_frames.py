@@ -178,3 +178,47 @@ def test_pool_backpressure_when_the_host_runs_far_ahead(oracle_mod, hip_lib, mon
     held, free, nbytes, created, waits, syncs = M.frame_pool_stats()
     assert held == 1 and free <= 2 and created - stats0[3] <= 3 and waits > stats0[4], (held, free, created - stats0[3], waits - stats0[4], syncs - stats0[5])
     img.close(); classic.close(); owned.close()
+
+
+def test_a_frame_let_go_of_without_a_fence_waits_for_the_streams_the_library_knows(oracle_mod, hip_lib):
+    """nvbx_frame_release used to put the frame back into the pool at once (hipFree, which the reference's buffers end in, waits for the
+    device).  Now the release that brings the count to 0 records an event on every stream the library knows -- here a live mapper's stream, kept busy
+    by a spin kernel -- and nvbx_frame_acquire skips the frame until the events are reached; a writer on that very stream may have it (stream order).
+    nvbx_frame_release_on names the one stream instead.  nvbx_frame_device answers where a frame lives."""
+    import torch
+    from isaac_ros_nvblox_amd import mapper as M, _lib
+    lib = hip_lib
+    dev = torch.device("cuda", 0)
+    ms = torch.cuda.Stream(dev)
+    g = M.Mapper(M.default_params(), block_capacity=1 << 12, stream=ms.cuda_stream)
+    g.synchronize(); torch.cuda.synchronize(dev)
+    lib.nvbx_frame_pool_trim(-1)
+    nbytes = 777 * 1024                                  # (a size class of this test's own)
+    def acquire(stream=_lib.STREAM_UNKNOWN):
+        q = C.c_void_p(); assert lib.nvbx_frame_acquire(0, nbytes, stream, C.byref(q)) == 0 and q.value; return q
+    msh = C.c_void_p(ms.cuda_stream)
+    for release_on in (False, True):
+        p = acquire()
+        assert lib.nvbx_frame_device(p) == 0 and lib.nvbx_frame_device(C.c_void_p(p.value + 64)) == -1
+        with torch.cuda.stream(ms):
+            torch.cuda._sleep(int(3e8))                  # the mapper's stream is busy for ~0.15 s
+        assert (lib.nvbx_frame_release_on(p, msh) if release_on else lib.nvbx_frame_release(p)) == 0
+        assert lib.nvbx_frame_refcount(p) == 0
+        assert not ms.query()                            # (still busy: the checks below mean something)
+        q = acquire()                                    # a writer on an unknown stream: OTHER memory
+        assert q.value != p.value, "a frame whose stream is still busy was handed out"
+        if release_on:                                   # a writer on the very stream the release named: stream order does it
+            r = acquire(msh)
+            assert r.value == p.value
+            assert lib.nvbx_frame_release_on(r, msh) == 0
+        assert not ms.query()
+        ms.synchronize()
+        assert lib.nvbx_frame_release(q) == 0
+        torch.cuda.synchronize(dev)                      # (q's own events, just recorded on idle streams, have been reached too)
+        got = {acquire().value for _ in range(2)}        # idle: both frames are cool again
+        assert got == {p.value, q.value}, (got, p.value, q.value)
+        for v in got:
+            assert lib.nvbx_frame_release(C.c_void_p(v)) == 0
+        torch.cuda.synchronize(dev)
+        lib.nvbx_frame_pool_trim(-1)
+    g.close()
