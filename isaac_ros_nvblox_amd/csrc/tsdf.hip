@@ -63,18 +63,23 @@ struct CameraSensor {
 #define NVBX_CAM_TC 8
 #define NVBX_CAM_SEG 1
 #endif
+#ifndef NVBX_CAM_GR
+#define NVBX_CAM_GR 2
+#define NVBX_CAM_GC 2
+#endif
   static constexpr int kTileRows = NVBX_CAM_TR, kTileCols = NVBX_CAM_TC;     // rays per wavefront: one tile of the ray grid (tools/lidar_tile_sweep.sh cam)
   static constexpr int kSetSize = 512, kFlushRounds = 2; // a tile crosses < 100 blocks: 4 KiB set, 128 keys per flush pass
   static constexpr int kSegments = NVBX_CAM_SEG;         // lanes per ray
   static constexpr int kProbeDepth = 2;                  // hash probe positions fetched up front per key in a flush
-  static constexpr int kThreads = 256;                   // 4 waves: four tiles (one wavefront each) share the workgroup's key set; a riding worker uses all four as it likes
+  static constexpr bool kRiders = true;                  // workers of other passes may ride in the view-marking launch (256 threads each: a riding worker uses four wavefronts as it likes)
+  static constexpr int kThreads = 64 * NVBX_CAM_GR * NVBX_CAM_GC;      // one wavefront per tile: the tiles of a group share the workgroup's key set
   // Tiles per workgroup: kGroupRows x kGroupCols NEIGHBOURING tiles share ONE LDS key set.  Every ray starts in the camera's block and
   // the rays of neighbouring tiles run through the same blocks for their first metres, so with one tile per workgroup the block at the
   // origin had its stamp claimed by ALL 336 tiles of a 640x480 frame at the same moment -- returning atomics on one address serialise
   // at ~12 ns each in the memory-side atomic unit (tools/micro/atomic_scope_bench.hip: 336 of them = 4.0 us for the last; whatever the
   // scope, there are no XCD-local atomics) -- and the tiles' flush took 4.2 of their 10.7 us (tools/wg_timeline.py).  Four tiles per set:
   // a quarter of the contenders on every hot stamp, and the workgroup's other three wavefronts, idle before, do the work.
-  static constexpr int kGroupRows = 2, kGroupCols = 2;
+  static constexpr int kGroupRows = NVBX_CAM_GR, kGroupCols = NVBX_CAM_GC;
   // end point (camera frame) of the ray through the centre of pixel (prow, pcol) at depth `de` along the optical axis
   __device__ void ray_end(const Frame& f, int prow, int pcol, float de, float* pc) const {
     const float rx = (((float)pcol + 0.5f) - f.cu) / f.fu;
@@ -121,6 +126,7 @@ struct LidarSensor {
   static constexpr int kSetSize = NVBX_LIDAR_SET, kFlushRounds = NVBX_LIDAR_FR; // early flush at 256 keys: 6 x 64 >= 256 + one step's additions
   static constexpr int kSegments = NVBX_LIDAR_SEG;
   static constexpr int kProbeDepth = NVBX_LIDAR_PD;
+  static constexpr bool kRiders = false;
   static constexpr int kThreads = 64;
   static constexpr int kGroupRows = 1, kGroupCols = 1;   // one tile (bundle of rays) per workgroup
   nvbx_lidar_model l;
@@ -548,7 +554,7 @@ template <typename Sensor> static int mark_view_tile_wgs(const Frame& f) {
 }
 template <typename Sensor> static size_t mark_view_smem(bool edt_rides) {
   const size_t mark = 2 * (size_t)Sensor::kSetSize * sizeof(u64);
-  return (Sensor::kThreads == 256 && edt_rides && sizeof(EdtShared) > mark) ? sizeof(EdtShared) : mark;
+  return (Sensor::kRiders && edt_rides && sizeof(EdtShared) > mark) ? sizeof(EdtShared) : mark;
 }
 // Occupancy of the two fused launches, by batch size (the attribute's arguments depend on the template parameter).  One camera frame launches ~960
 // workgroups -- fewer than are resident at the compiler's own register choice (87 VGPRs = 5 waves per SIMD = 1 280 workgroups of four wavefronts), and
@@ -574,12 +580,13 @@ __global__ __launch_bounds__(Sensor::kThreads) NVBX_MARK_VIEW_ATTR void k_mark_v
   // this launch has STARTED, so every launch enqueued before it on the stream has finished -- among them the tr.fence_report colour-reading launches
   // whose images' frames wait for exactly this news (frames.hip)
   if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&m.host_mirror[4], tr.fence_report, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (Sensor::kThreads == 256) {
+  if (Sensor::kRiders) {
     // riders: [EDT workers][sphere-tracing workers of a held-back colour frame (colour deferral)] -- before the tiles, or
     // (tr.n_tile_wg > 0) after them.  All counts are multiples of 8, so a workgroup's XCD (blockIdx.x & 7) is also its number's & 7.
     const int32_t rider = tr.n_tile_wg > 0 ? (int32_t)blockIdx.x - tr.n_tile_wg : (int32_t)blockIdx.x;
     const bool is_rider = tr.n_tile_wg > 0 ? rider >= 0 : rider < n_edt_wg + tr.n_wg + tr.n_scan_wg + tr.n_mark_wg;
     if (is_rider) {
+      if (Sensor::kThreads > 256 && threadIdx.x >= 256) return;      // (a rider is a 256-thread worker: the wavefronts a wider tile group needs go home at once -- they are not waited for by the others' barriers)
       if (rider < n_edt_wg) esdf_edt_worker(m, ea, (int)rider, n_edt_wg, reinterpret_cast<EdtShared*>(smem));
       // (sphere tracing: all four wavefronts; independent of the view marking -- it reads the TSDF and the insert-only hash, and new entries point at all-zero blocks)
       else if (rider < n_edt_wg + tr.n_wg) {
@@ -606,14 +613,14 @@ __global__ __launch_bounds__(Sensor::kThreads) NVBX_MARK_VIEW_ATTR void k_mark_v
     }
     if (tr.n_tile_wg == 0) tile_wg -= n_edt_wg + tr.n_wg + tr.n_scan_wg + tr.n_mark_wg;
   }
-  __shared__ int32_t s_part[4];
+  __shared__ int32_t s_part[8];
   u64* lset = reinterpret_cast<u64*>(smem);
   u64* lkeys = lset + LSET;
   const int lane = threadIdx.x & 63;
   constexpr int TR = Sensor::kTileRows, TC = Sensor::kTileCols, NSEG = Sensor::kSegments;
   constexpr int GR = Sensor::kGroupRows, GC = Sensor::kGroupCols, NW = GR * GC;       // tiles (wavefronts) per workgroup
   static_assert(TR * TC * NSEG <= 64, "one wavefront per tile");
-  static_assert(NW * 64 == Sensor::kThreads && NW <= 4, "one wavefront per tile of the group");
+  static_assert(NW * 64 == Sensor::kThreads && NW <= 8, "one wavefront per tile of the group");
   const int wave = NW > 1 ? (int)(threadIdx.x >> 6) : 0;
   const Frame& f0 = fs.f[0];                    // (image size, subsampling and view frame id are the same for every frame of a batch)
   const int tiles_x = (f0.n_ray_cols + TC - 1) / TC, tiles_y = (f0.n_ray_rows + TR - 1) / TR;
@@ -1547,7 +1554,7 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   // a held-back EDT rides in this launch (camera: 256-thread workgroups); the LiDAR launch is 64 threads wide, so flush first
   int edt_wg = 0; EsdfArgs ea = m->edt_args;
   if (m->edt_pending) {
-    if (Sensor::kThreads == 256) { edt_wg = 256; m->edt_pending = false; }        // (256 .. 1024 riders measured: no difference, profiles/r02x_kernel_isolation.txt)
+    if (Sensor::kRiders) { edt_wg = 256; m->edt_pending = false; }        // (256 .. 1024 riders measured: no difference, profiles/r02x_kernel_isolation.txt)
     else if (m->flush_edt()) return NVBX_E_DEVICE;
   }
   // Colour deferral: a held-back integrateColor (and an updateEsdf behind it) is carried out in PIPELINED order -- its sphere tracing rides
@@ -1563,7 +1570,7 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   const bool has_color = m->color_pending.on;
   // (one frame carries a frame, a batch a batch; a held-back updateEsdf WITHOUT a colour frame -- depth-only and occupancy mappers -- is carried by
   //  any camera launch: integrate_cameras has checked that the two-launch order applies, nvbx_mapper::esdf_only_carry)
-  const bool pipelined = Sensor::kThreads == 256 && (has_color ? ((NB == 1) == (m->color_pending.n == 1)) : m->esdf_update_pending);
+  const bool pipelined = Sensor::kRiders && (has_color ? ((NB == 1) == (m->color_pending.n == 1)) : m->esdf_update_pending);
   bool fused = false;
   if (pipelined) {
     static const int fuse_on = getenv("NVBX_FUSE_COLC") ? atoi(getenv("NVBX_FUSE_COLC")) : 1;      // (A/B: 0 = three launches per frame)
@@ -1629,7 +1636,7 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   { const int rc = launch_lidar_sparse(m, fs, sensor, plain, &view_class, &dense_list); if (rc) return rc; }
   if (Sensor::kLongRays && m->p.projective_layer_type != 1) m->lidar_integrated = true;      // (blocks may be F_BAND_STALE from here on)
   if (fused) {
-    if constexpr (Sensor::kThreads == 256) {
+    if constexpr (Sensor::kRiders) {
       // [distance transform the held-back updateEsdf has just armed][TSDF update of this frame][colour integration of the held-back frame]
       int32_t n_edt = 0; EsdfArgs ea_edt = m->edt_args;
       static const int edt_riders = getenv("NVBX_EDT_RIDERS") ? atoi(getenv("NVBX_EDT_RIDERS")) : 256;      // (A/B; a multiple of 8)
