@@ -52,6 +52,14 @@ def algorithmic_bytes(kernel, c, rows, cols, sub_ray=4, sub_trace=4, n_cam=1, tr
     color_only = n_cam * (rows * cols * 3 + (rows // sub_trace) * (cols // sub_trace) * 4) + Nc * B * 2      # colour image + synthetic depth read + colour RMW of the band blocks
     marking = Nu * 2 * B + Nu * 24                                                                            # TSDF z-band (k_z = 2 blocks) of the re-marked columns read + three mask words written
     edt = Ne * (512 * 2 + 121 * (16 + 8))                                                                     # plane RMW + 11x11 neighbour hash entries and site masks per swept block
+    if kernel.startswith("k_integrate_tsdf_color_pair") or kernel.startswith("k_mark_view_pair"):
+        # two mappers' launches in one grid (nvbx_integrate_depth_pair): the first mapper's bytes (counts `c`) + the second's (counts under "b_...": the
+        # foreground occupancy mapper -- its half of the depth image, its few blocks, the marking pass / distance transform of its held-back update)
+        base = "k_integrate_tsdf_color" if kernel.startswith("k_integrate") else "k_mark_view"
+        cb = {k_[2:]: v_ for k_, v_ in c.items() if k_.startswith("b_")}
+        cb["color_blocks_updated"] = 0
+        return (algorithmic_bytes(base, c, rows, cols, sub_ray, sub_trace, n_cam, trace_in_mark_view, fused) +
+                algorithmic_bytes(base, cb, rows, cols, sub_ray, sub_trace, n_cam, False, False) - (n_cam * (rows * cols * 3 + (rows // sub_trace) * (cols // sub_trace) * 4) if base == "k_integrate_tsdf_color" else 0))
     if kernel.startswith("k_integrate_tsdf_color"):
         # TSDF update of this frame + colour integration of the held-back frame (candidates arrive as 16-byte records) + the distance transform
         return algorithmic_bytes("k_integrate_tsdf", c, rows, cols, sub_ray, sub_trace, n_cam) + color_only + Nc * 16 + edt
@@ -561,6 +569,7 @@ def main_decay(args):
     # colour frame / ESDF update of frame i are carried out by integrateDepth(i + 1) in two launches
     gs.set_color_deferral(not args.no_color_deferral, staged=True)           # (staged: the default form of a new mapper)
     gd.set_color_deferral(not args.no_color_deferral, staged=True)       # (an occupancy mapper has no colour: its updateEsdf alone is held back -- marking pass and distance transform ride in its next depth launches)
+    pair = not args.no_depth_pair and not args.own_stream
     eye = np.eye(4, dtype=np.float32)
     mask = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
     un = torch.empty((rows, cols), dtype=torch.float32, device=dev); ma2 = [torch.empty_like(un), torch.empty_like(un)]; ma = ma2[0]
@@ -578,8 +587,11 @@ def main_decay(args):
         gs.set_time_ms(t_ms[0]); t_ms[0] += 33
         gs.wait_for(gd)                  # (the dynamic mapper's frame i - 1 is over before the static mapper's stream goes on: frame i + 1's split rewrites that buffer)
         gd.wait_for(gs)                  # (`ma` is written)
-        gs.integrate_depth(un, poses[k], cam)
-        gd.integrate_depth(ma, poses[k], cam)
+        if pair:                         # both mappers' depth frames in two launches (nvbx_integrate_depth_pair: what MultiMapper::integrateDepth calls)
+            gs.integrate_depth_pair(un, gd, ma, poses[k], cam)
+        else:
+            gs.integrate_depth(un, poses[k], cam)
+            gd.integrate_depth(ma, poses[k], cam)
         gs.integrate_color(rgb_dev[k], poses[k], cam)
         gs.update_esdf(); gd.update_esdf()
         if i % 6 == 5:
@@ -640,6 +652,9 @@ def main_decay(args):
         if i % 6 == 0:
             for k_, v_ in gs.counters().items():
                 acc.setdefault(k_, []).append(v_)
+            for k_, v_ in gd.counters().items():      # (the dynamic mapper's share of the pair launches' bytes)
+                if k_ in ("tsdf_blocks_in_view", "esdf_columns_marked", "esdf_blocks_swept", "blocks_allocated"):
+                    acc.setdefault("b_" + k_, []).append(v_)
     prof = gs.profile(); prof_d = gd.profile()
     gs.set_profiling(False); gd.set_profiling(False)
     for k_, v_ in prof_d.items():          # the dynamic (occupancy) mapper's launches join the static mapper's under the same kernel names
@@ -715,7 +730,10 @@ def main_decay(args):
                       "mode": (("colour deferral on both mappers (a new mapper's default, DESIGN.md 2.8), colour images in library-owned frames (retained, not copied); " if use_frames else
                                 "colour deferral, staged form (raw device pointers: one k_stage_color copy per held-back frame), on both mappers; ") if not args.no_color_deferral else "classic launch order; ") +
                               ("the dynamic (occupancy) mapper on a stream of its own, ordered with nvbx_mapper_wait_for (A/B)" if args.own_stream else
-                               "both mappers on one stream (as nvblox::MultiMapper hands them out)")},
+                               "both mappers on one stream (as nvblox::MultiMapper hands them out)") +
+                              ("; the two mappers' depth frames through nvbx_integrate_depth_pair (two launches for both, what MultiMapper::integrateDepth calls)" if pair else
+                               "; the two mappers' depth frames as two nvbx_integrate_depth calls (four launches; --no-depth-pair)")},
+           "depth_pair": pair,
            "readme_rtx5090_ms": README_RTX5090_MS,
            "per_step_counts": {k_: round(v_, 1) for k_, v_ in counts.items()},
            "block_ms": [round(d / args.steps * 1e3, 4) for d in dts[:16]], "block_stats_ms_per_step": block_stats(dts, args.steps),
@@ -1306,6 +1324,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="camera / multicam: skip the end-state comparison of the timed sequence with the checker (outside the timed region)")
     ap.add_argument("--own-stream", action="store_true", help="decay: the dynamic mapper of the dynamic-mapping frame on a stream of its own (A/B; slower: EXPERIMENTS.md)")
+    ap.add_argument("--no-depth-pair", action="store_true", help="decay workload: the static and the dynamic mapper's depth frames as two calls (four launches) instead of nvbx_integrate_depth_pair (A/B)")
     ap.add_argument("--profile-run", action="store_true", help="camera / multicam: only the timed step is launched (for rocprofv3 runs: clean per-kernel averages)")
     ap.add_argument("--with-mesh", action="store_true", help="camera: the timed step also updates the colour mesh (TSDF+Color+ESDF+Mesh per frame; profiling passes for k_mesh)")
     ap.add_argument("--staged-deferral", action="store_true", help="camera workload: colour images as RAW device pointers under the default (staged) deferral: one k_stage_color copy per held-back frame (round 4's default line); default now: the images live in library-owned frames (nvbx_frame_acquire), no copy")

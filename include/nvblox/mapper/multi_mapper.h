@@ -105,9 +105,8 @@ class MultiMapper {
                                        reinterpret_cast<uint8_t*>(depth_overlay_.dataPtr())), "nvbx_dynamic_depth_split");
     if (update_time_ms) background_mapper_->setUpdateTime(*update_time_ms);
     if (block_index_exchange_) block_index_exchange_->beforeDepth(m);        // (the static part's blocks are what the peers' ESDF sweeps need)
-    background_mapper_->integrateDepth(depth_background_, T_L_C, camera);
+    integrateDepthPair(depth_background_, depth_foreground_, T_L_C, camera);
     if (block_index_exchange_) block_index_exchange_->start(m);
-    foreground_mapper_->integrateDepth(depth_foreground_, T_L_C, camera);
     last_dynamic_T_L_C_ = T_L_C; last_dynamic_camera_ = camera;
   }
   // nvblox_node.cpp:1098,1108 (dynamic mapping): the dynamic part of the last depth frame as points of the layer frame / as an overlay
@@ -131,9 +130,8 @@ class MultiMapper {
                                        T, &depth_camera.c_abi(), &mask_camera.c_abi(), multi_params_.mask_occlusion_threshold_m, depth_background_.dataPtr(),
                                        depth_foreground_.dataPtr(), reinterpret_cast<uint8_t*>(depth_overlay_.dataPtr())), "nvbx_split_depth_by_mask");
     if (block_index_exchange_) block_index_exchange_->beforeDepth(background_mapper_->c_handle());
-    background_mapper_->integrateDepth(depth_background_, T_L_CD, depth_camera);
+    integrateDepthPair(depth_background_, depth_foreground_, T_L_CD, depth_camera);
     if (block_index_exchange_) block_index_exchange_->start(background_mapper_->c_handle());
-    foreground_mapper_->integrateDepth(depth_foreground_, T_L_CD, depth_camera);
   }
   const DepthImage& getLastDepthFrameForeground() const { return depth_foreground_; }      // nvblox_node.cpp:1126
   const DepthImage& getLastDepthFrameBackground() const { return depth_background_; }
@@ -185,6 +183,14 @@ class MultiMapper {
   EsdfMode esdf_mode() const { return esdf_mode_; }
 
  private:
+  // background_mapper_->integrateDepth(bg) followed by foreground_mapper_->integrateDepth(fg): the same maps in two launches instead of four
+  // (nvbx_integrate_depth_pair: the two mappers share a stream, their view-marking launches share a grid and so do their TSDF-update launches)
+  void integrateDepthPair(const DepthImage& bg, const DepthImage& fg, const Transform& T_L_C, const Camera& camera) {
+    timing::Timer t("tsdf/integrate");
+    float T[16]; T_L_C.toRowMajor(T);
+    checkNvbx(nvbx_integrate_depth_pair(background_mapper_->c_handle(), bg.dataConstPtr(), foreground_mapper_->c_handle(), fg.dataConstPtr(), bg.rows(), bg.cols(), T, &camera.c_abi()),
+              "nvbx_integrate_depth_pair");
+  }
   [[noreturn]] static void unsupported(const char* what) {
     std::fprintf(stderr, "[nvblox_hip] %s is outside the MI355X hot path of this library (static TSDF + colour + 2-D ESDF + mesh)\n", what);
     std::abort();

@@ -341,6 +341,15 @@ int nvbx_integrate_depth_batch(nvbx_mapper* m, int32_t n, const float* const* de
                                const nvbx_camera* cameras);
 int nvbx_integrate_color_batch(nvbx_mapper* m, int32_t n, const uint8_t* const* rgb_dev, int32_t rows, int32_t cols, const float* T_L_C,
                                const nvbx_camera* cameras);
+/* ---- a PAIR of mappers, one depth frame each: MultiMapper::integrateDepth of the dynamic and the human mapping types (nvblox_node.cpp:1057-1062:
+ * the depth image is split by a mask; the unmasked part goes to the background mapper, the masked part to the foreground occupancy mapper, one
+ * integrateDepth each).  DEFINED as equal to nvbx_integrate_depth(ma, depth_a, ...) followed by nvbx_integrate_depth(mb, depth_b, ...) -- both maps, the
+ * held-back calls each of them carries, "last view" queries: bit for bit -- but the two view-marking launches share one grid and so do the two
+ * TSDF-update launches (k_mark_view_pair, k_integrate_tsdf_color_pair): two launches instead of four; the maps share nothing, so nothing else changes.
+ * Needs both mappers on one device and one stream (what nvblox::MultiMapper hands out); whatever the pair cannot express -- different streams, depth
+ * dilation, a held-back colour BATCH, the ESDF side stream -- falls back to the two calls.  NVBX_DEPTH_PAIR=0 in the environment: always the two calls. */
+int nvbx_integrate_depth_pair(nvbx_mapper* ma, const float* depth_a_dev, nvbx_mapper* mb, const float* depth_b_dev, int32_t rows, int32_t cols,
+                              const float T_L_C[16], const nvbx_camera* camera);
 /* MultiMapper::updateEsdf() (EsdfMode::k2D) -- nvblox_node.cpp:781.
  * Scheduling note: the site-marking half runs at once (or already ran inside the preceding nvbx_integrate_color launch);
  * the distance-transform half may be HELD BACK until the next entry point of this mapper: nvbx_integrate_depth[_u16mm]

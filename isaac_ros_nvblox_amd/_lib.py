@@ -121,6 +121,7 @@ SIGNATURES = {
     "nvbx_fit_plane_ransac": (_i64, [_vp, _i64, C.c_float, C.c_int32, C.c_uint32, _vp]),
     "nvbx_mapper_capacity": (C.c_int64, [_vp]),
     "nvbx_integrate_depth_batch": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "nvbx_integrate_depth_pair": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "nvbx_integrate_color_batch": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _vp, _vp]),
     "nvbx_take_cleared_blocks": (C.c_int64, [_vp, _vp, _i64]),
     "nvbx_get_stream": (C.c_int, [_vp, C.POINTER(_vp)]),

@@ -567,23 +567,22 @@ template <typename Sensor> static size_t mark_view_smem(bool edt_rides) {
 #ifndef NVBX_FUSED_ATTR
 #define NVBX_FUSED_ATTR __attribute__((amdgpu_waves_per_eu(NB > 1 ? 8 : 1, NB > 1 ? 8 : 8)))
 #endif
+// The launch's body as a function of the workgroup's NUMBER (`wg_index`, not blockIdx.x): k_mark_view passes blockIdx.x; k_mark_view_pair (round 6) runs the
+// bodies of TWO mappers' view-marking launches in one grid -- the second mapper's workgroups are numbered from its own 0 (every part's count is a multiple
+// of 8, so blockIdx.x & 7 -- the shard of the sharded counters, my_shard() -- is also wg_index & 7).
 template <typename Img, typename Sensor, int NB>
-__global__ __launch_bounds__(Sensor::kThreads) NVBX_MARK_VIEW_ATTR void k_mark_view(DMap m, FrameSet<Img, NB> fs, Sensor sensor, int4* view_list, int32_t list_cap,
-                                                                int32_t reset_esdf_dirty, int32_t n_edt_wg, EsdfArgs ea, TraceRiderT<NB> tr) {
+__device__ __forceinline__ void mark_view_body(const DMap& m, const FrameSet<Img, NB>& fs, const Sensor& sensor, int4* view_list, int32_t list_cap,
+                                               int32_t reset_esdf_dirty, int32_t n_edt_wg, const EsdfArgs& ea, const TraceRiderT<NB>& tr, const int32_t wg_index, unsigned char* smem) {
   constexpr int LSET = Sensor::kSetSize, FR = Sensor::kFlushRounds;
-  // LDS: the tile's key set (2 * LSET u64), or -- when a distance transform rides (camera, classic order) -- at least an EdtShared; sized by
-  // the launch (mark_view_smem below): EVERY workgroup of the launch holds it, the riders too, and it decides how many are resident
-  // (a batch of 8 cameras: 2 688 tile workgroups beside 1 200 sphere-tracing ones)
-  extern __shared__ __align__(16) unsigned char smem[];
-  int32_t tile_wg = (int32_t)blockIdx.x;      // this workgroup's number among the tiles
+  int32_t tile_wg = wg_index;      // this workgroup's number among the tiles
   NVBX_T(0, 0);
   // this launch has STARTED, so every launch enqueued before it on the stream has finished -- among them the tr.fence_report colour-reading launches
   // whose images' frames wait for exactly this news (frames.hip)
-  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&m.host_mirror[4], tr.fence_report, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (wg_index == 0 && threadIdx.x == 0) __hip_atomic_store(&m.host_mirror[4], tr.fence_report, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (Sensor::kRiders) {
     // riders: [EDT workers][sphere-tracing workers of a held-back colour frame (colour deferral)] -- before the tiles, or
     // (tr.n_tile_wg > 0) after them.  All counts are multiples of 8, so a workgroup's XCD (blockIdx.x & 7) is also its number's & 7.
-    const int32_t rider = tr.n_tile_wg > 0 ? (int32_t)blockIdx.x - tr.n_tile_wg : (int32_t)blockIdx.x;
+    const int32_t rider = tr.n_tile_wg > 0 ? wg_index - tr.n_tile_wg : wg_index;
     const bool is_rider = tr.n_tile_wg > 0 ? rider >= 0 : rider < n_edt_wg + tr.n_wg + tr.n_scan_wg + tr.n_mark_wg;
     if (is_rider) {
       if (Sensor::kThreads > 256 && threadIdx.x >= 256) return;      // (a rider is a 256-thread worker: the wavefronts a wider tile group needs go home at once -- they are not waited for by the others' barriers)
@@ -734,6 +733,35 @@ __global__ __launch_bounds__(Sensor::kThreads) NVBX_MARK_VIEW_ATTR void k_mark_v
   NVBX_TV(0, 2, t_flush); NVBX_TV(0, 6, (n_flush << 32) | n_keys); NVBX_T(0, 7);
 #endif
 }
+
+template <typename Img, typename Sensor, int NB>
+__global__ __launch_bounds__(Sensor::kThreads) NVBX_MARK_VIEW_ATTR void k_mark_view(DMap m, FrameSet<Img, NB> fs, Sensor sensor, int4* view_list, int32_t list_cap,
+                                                                int32_t reset_esdf_dirty, int32_t n_edt_wg, EsdfArgs ea, TraceRiderT<NB> tr) {
+  // LDS: the tile's key set (2 * LSET u64), or -- when a distance transform rides (camera, classic order) -- at least an EdtShared; sized by
+  // the launch (mark_view_smem below): EVERY workgroup of the launch holds it, the riders too, and it decides how many are resident
+  // (a batch of 8 cameras: 2 688 tile workgroups beside 1 200 sphere-tracing ones)
+  extern __shared__ __align__(16) unsigned char smem[];
+  mark_view_body<Img, Sensor, NB>(m, fs, sensor, view_list, list_cap, reset_esdf_dirty, n_edt_wg, ea, tr, (int32_t)blockIdx.x, smem);
+}
+// Two mappers' view-marking launches in ONE grid (nvbx_integrate_depth_pair: the background and the foreground mapper of a MultiMapper's dynamic / human
+// mapping types take the same depth frame, split by a mask, one after the other -- four dependent launches of 6-8 us each for two small jobs).  Workgroups
+// [0, a.n_wg) run mapper a's body, the rest mapper b's, each numbered from its own 0; nothing is shared between the two maps.
+template <typename Img> struct MarkViewArgs { DMap m; FrameSet<Img, 1> fs; int4* view_list; int32_t list_cap, reset_esdf_dirty, n_edt_wg; EsdfArgs ea; TraceRiderT<1> tr; int32_t n_tiles, n_wg; };
+template <typename Img>
+__global__ __launch_bounds__(CameraSensor::kThreads) void k_mark_view_pair(MarkViewArgs<Img> a, MarkViewArgs<Img> b) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  // dispatch order [a's tiles][b's tiles][a's riders][b's riders]: the tiles are each map's longest chain (~9 us) and start first; behind mapper a's ~900
+  // workgroups, mapper b's tiles started late and the launch took 11.6 us against the 9.5 of mapper a's alone.  Every segment is a multiple of 8 long.
+  const int32_t g = (int32_t)blockIdx.x, at = a.n_tiles, bt = b.n_tiles, ar = a.n_wg - a.n_tiles;
+  bool is_a; int32_t wg;
+  if (g < at) { is_a = true; wg = g; }
+  else if (g < at + bt) { is_a = false; wg = g - at; }
+  else if (g < at + bt + ar) { is_a = true; wg = at + (g - at - bt); }
+  else { is_a = false; wg = bt + (g - at - bt - ar); }
+  if (is_a) mark_view_body<Img, CameraSensor, 1>(a.m, a.fs, CameraSensor{}, a.view_list, a.list_cap, a.reset_esdf_dirty, a.n_edt_wg, a.ea, a.tr, wg, smem);
+  else mark_view_body<Img, CameraSensor, 1>(b.m, b.fs, CameraSensor{}, b.view_list, b.list_cap, b.reset_esdf_dirty, b.n_edt_wg, b.ea, b.tr, wg, smem);
+}
+static_assert(2 * sizeof(MarkViewArgs<DepthF32>) <= 4096, "k_mark_view_pair: kernel arguments");
 
 // ------------------------------------------------------------------------------------------------ LiDAR view calculation over a dense "seen in this scan" grid
 // A 200 m scan walks its 16 k (sub-sampled) rays through ~10^6 blocks to find the ~112 k distinct ones.  k_mark_view<Lidar> above decides "first
@@ -1190,12 +1218,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 //  colour workgroups, dispatched last, start late; asking for four per CU with amdgpu_waves_per_eu(8, 8) was measured in round 4: the colour part
 //  starts at once but every part runs slower, the launch 9.2 -> 10.0 us -- left at the compiler's choice)
 template <typename Img, typename Pix, int NB, bool Plain>
-__global__ __launch_bounds__(512) NVBX_FUSED_ATTR void k_integrate_tsdf_color(DMap m, FrameSet<Img, NB> fs, CameraSensor sensor, const int4* view_list, int32_t list_cap,
-                                                              int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, int32_t n_tsdf_wg,
-                                                              FrameSetC<Pix, NB> fsc, const float* synth, int32_t srows, int32_t scols, const int4* cand, int32_t cand_cnt_idx,
-                                                              int32_t n_edt_wg, EsdfArgs ea, ImportArgs imp) {
-  __shared__ __align__(16) unsigned char smem[sizeof(EdtShared)];
-  const int32_t b = (int32_t)blockIdx.x;
+__device__ __forceinline__ void integrate_tsdf_color_body(const DMap& m, const FrameSet<Img, NB>& fs, const CameraSensor& sensor, const int4* view_list, int32_t list_cap,
+                                                          int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, int32_t n_tsdf_wg,
+                                                          const FrameSetC<Pix, NB>& fsc, const float* synth, int32_t srows, int32_t scols, const int4* cand, int32_t cand_cnt_idx,
+                                                          int32_t n_edt_wg, const EsdfArgs& ea, const ImportArgs& imp, const int32_t b, const int32_t n_wg_total, unsigned char* smem) {
   NVBX_T(1, 0);
   if (b < n_edt_wg) { esdf_edt_worker<512>(m, ea, (int)b, n_edt_wg, reinterpret_cast<EdtShared*>(smem)); NVBX_T(1, 1); NVBX_T(1, 7); return; }
   if (b < n_edt_wg + n_tsdf_wg) {
@@ -1206,11 +1232,40 @@ __global__ __launch_bounds__(512) NVBX_FUSED_ATTR void k_integrate_tsdf_color(DM
     return;
   }
   // (multi-GPU, imp.n_wg > 0: the LAST workgroups resolve the peers' gathered block lists into ESDF-dirty flags, nvbx_esdf_mark.h)
-  const int32_t n_color_wg = (int32_t)gridDim.x - n_edt_wg - n_tsdf_wg - imp.n_wg;
+  const int32_t n_color_wg = n_wg_total - n_edt_wg - n_tsdf_wg - imp.n_wg;
   if (b >= n_edt_wg + n_tsdf_wg + n_color_wg) { esdf_import_dirty_worker(m, imp, (int64_t)(b - n_edt_wg - n_tsdf_wg - n_color_wg) * 512 + threadIdx.x, (int64_t)imp.n_wg * 512); return; }
   color_integrate_list_worker<Pix, NB>(m, fsc, synth, srows, scols, mesh_list, cand, cand_cnt_idx, b - n_edt_wg - n_tsdf_wg, n_color_wg);
   NVBX_T(1, 3); NVBX_T(1, 7);
 }
+template <typename Img, typename Pix, int NB, bool Plain>
+__global__ __launch_bounds__(512) NVBX_FUSED_ATTR void k_integrate_tsdf_color(DMap m, FrameSet<Img, NB> fs, CameraSensor sensor, const int4* view_list, int32_t list_cap,
+                                                              int32_t mesh_list, int32_t* view_export, int32_t view_export_cap, int32_t spec_lanes, int32_t n_tsdf_wg,
+                                                              FrameSetC<Pix, NB> fsc, const float* synth, int32_t srows, int32_t scols, const int4* cand, int32_t cand_cnt_idx,
+                                                              int32_t n_edt_wg, EsdfArgs ea, ImportArgs imp) {
+  __shared__ __align__(16) unsigned char smem[sizeof(EdtShared)];
+  integrate_tsdf_color_body<Img, Pix, NB, Plain>(m, fs, sensor, view_list, list_cap, mesh_list, view_export, view_export_cap, spec_lanes, n_tsdf_wg, fsc, synth, srows, scols, cand, cand_cnt_idx,
+                                                 n_edt_wg, ea, imp, (int32_t)blockIdx.x, (int32_t)gridDim.x, smem);
+}
+// ... and two mappers' fused TSDF-update launches in one grid (nvbx_integrate_depth_pair, see k_mark_view_pair): mapper a's [distance transform][TSDF
+// update][colour][union step] workgroups, then mapper b's, each numbered from its own 0.  The general (not "plain") arithmetic path for both.
+template <typename Img, typename Pix> struct FusedArgs {
+  DMap m; FrameSet<Img, 1> fs; const int4* view_list; int32_t list_cap, mesh_list; int32_t* view_export; int32_t view_export_cap, spec_lanes, n_tsdf_wg;
+  FrameSetC<Pix, 1> fsc; const float* synth; int32_t srows, scols; const int4* cand; int32_t cand_cnt_idx, n_edt_wg; EsdfArgs ea; ImportArgs imp; int32_t n_wg; };
+template <typename Img, typename Pix>
+__global__ __launch_bounds__(512) void k_integrate_tsdf_color_pair(FusedArgs<Img, Pix> a, FusedArgs<Img, Pix> b) {
+  __shared__ __align__(16) unsigned char smem[sizeof(EdtShared)];
+  // dispatch order: mapper a's workgroups, then mapper b's (dealing the parts out alternately -- transforms, updates, colour -- measured slower: 9.5 -> 10.4 us;
+  // about 770 of these 8-wavefront workgroups are resident at a time, so what matters is how MANY there are: the second mapper brings few, see the host side)
+  const int32_t g = (int32_t)blockIdx.x;
+  const bool is_a = g < a.n_wg; const int32_t wg = is_a ? g : g - a.n_wg;
+  if (is_a)
+    integrate_tsdf_color_body<Img, Pix, 1, false>(a.m, a.fs, CameraSensor{}, a.view_list, a.list_cap, a.mesh_list, a.view_export, a.view_export_cap, a.spec_lanes, a.n_tsdf_wg, a.fsc, a.synth, a.srows,
+                                                  a.scols, a.cand, a.cand_cnt_idx, a.n_edt_wg, a.ea, a.imp, wg, a.n_wg, smem);
+  else
+    integrate_tsdf_color_body<Img, Pix, 1, false>(b.m, b.fs, CameraSensor{}, b.view_list, b.list_cap, b.mesh_list, b.view_export, b.view_export_cap, b.spec_lanes, b.n_tsdf_wg, b.fsc, b.synth, b.srows,
+                                                  b.scols, b.cand, b.cand_cnt_idx, b.n_edt_wg, b.ea, b.imp, wg, b.n_wg, smem);
+}
+static_assert(2 * sizeof(FusedArgs<DepthF32, PixRgb8>) <= 4096, "k_integrate_tsdf_color_pair: kernel arguments");
 // (a depth batch AND a colour batch in one argument block: the 4 KiB kernel-argument limit is why the colour path's frames are FrameCore)
 static_assert(sizeof(DMap) + sizeof(FrameSet<DepthF32, MAX_BATCH>) + sizeof(FrameSetC<PixRgb8, MAX_BATCH>) + sizeof(EsdfArgs) + sizeof(ImportArgs) + 160 <= 4096, "k_integrate_tsdf_color<.., MAX_BATCH>: kernel arguments");
 static_assert(sizeof(DMap) + sizeof(FrameSet<DepthF32, MAX_BATCH>) + sizeof(TraceRiderT<MAX_BATCH>) + sizeof(EsdfArgs) + 64 <= 4096, "k_mark_view<.., MAX_BATCH>: kernel arguments");
@@ -1539,10 +1594,22 @@ static int launch_view_grid(nvbx_mapper* m, const FrameSet<Img, 1>& fs, const Li
   return NVBX_OK;
 }
 
+// ---- One depth frame's two launches, in STEPS (round 6): integrate_depth_impl runs them in order for one mapper; nvbx_integrate_depth_pair interleaves the
+// steps of TWO mappers around two shared launches (k_mark_view_pair, k_integrate_tsdf_color_pair).  The steps are the former body of integrate_depth_impl, cut
+// where it launches; what each step does to the mapper's host state, and in which order, is unchanged.
+static bool fused_colour_applies(const nvbx_mapper* m) {
+  return m->p.projective_layer_type != 1 && m->p.esdf_mode == 0 && m->p.esdf_propagation == 0 && !m->lidar_integrated && m->capacity <= (1ll << 24);
+}
+template <int NB> struct DepthSteps {
+  int tiles = 0, edt_wg = 0; EsdfArgs ea{}; TraceRiderT<NB> tr{};                 // launch 1
+  bool plain = true, has_color = false, pipelined = false, fused = false;
+  FrameSetC<PixRgb8, NB> fsc{}; int f_kind = 0; int32_t f_srows = 0, f_scols = 0;      // launch 2 (fused form)
+  int grid = 8; int32_t spec_lanes = 1;
+  int32_t n_edt = 0; EsdfArgs ea_edt{}; const int4* cand = nullptr; int32_t cand_idx = 0; int cgrid = 0; ImportArgs imp{};
+};
+// step 1: everything in front of the view-marking launch (ray grid, riders of the held-back calls, the fence report)
 template <typename Img, typename Sensor, int NB>
-static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sensor& sensor) {
-  // (frames of a held-back colour image this call carries out: let go of on every way out, behind the launches that read them)
-  struct ReleaseFrames { nvbx_mapper* m; ~ReleaseFrames() { m->release_consumed_frames(); } } release_frames{m};
+static int depth_step_before_mark_view(nvbx_mapper* m, FrameSet<Img, NB>& fs, DepthSteps<NB>& st) {
   const int s = fs.f[0].subsample;
   for (int c = 0; c < fs.n; c++) {
     fs.f[c].n_ray_rows = (fs.f[c].rows + s - 1 + s - 1) / s;   // indices i with i*s < rows + s - 1
@@ -1550,11 +1617,11 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
     fs.f[c].cam_bit = 1u << c;
   }
   const Frame& f = fs.f[0];
-  const int tiles = mark_view_tile_wgs<Sensor>(f) * fs.n;       // tile workgroups (padded: the groups of one XCD are a contiguous band, k_mark_view); camera after camera
+  st.tiles = mark_view_tile_wgs<Sensor>(f) * fs.n;       // tile workgroups (padded: the groups of one XCD are a contiguous band, k_mark_view); camera after camera
   // a held-back EDT rides in this launch (camera: 256-thread workgroups); the LiDAR launch is 64 threads wide, so flush first
-  int edt_wg = 0; EsdfArgs ea = m->edt_args;
+  st.edt_wg = 0; st.ea = m->edt_args;
   if (m->edt_pending) {
-    if (Sensor::kRiders) { edt_wg = 256; m->edt_pending = false; }        // (256 .. 1024 riders measured: no difference, profiles/r02x_kernel_isolation.txt)
+    if (Sensor::kRiders) { st.edt_wg = 256; m->edt_pending = false; }        // (256 .. 1024 riders measured: no difference, profiles/r02x_kernel_isolation.txt)
     else if (m->flush_edt()) return NVBX_E_DEVICE;
   }
   // Colour deferral: a held-back integrateColor (and an updateEsdf behind it) is carried out in PIPELINED order -- its sphere tracing rides
@@ -1564,55 +1631,54 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   // the second launch.
   // A held-back updateEsdf with NO colour frame in front (depth-only hosts, occupancy mappers) is carried the same way: marking pass here,
   // distance transform in the second launch, no colour workgroups.
-  TraceRiderT<NB> tr{};
-  bool plain = true;
-  for (int c = 0; c < fs.n; c++) plain = plain && frame_is_plain(fs.f[c]);
-  const bool has_color = m->color_pending.on;
+  st.tr = TraceRiderT<NB>{};
+  st.plain = true;
+  for (int c = 0; c < fs.n; c++) st.plain = st.plain && frame_is_plain(fs.f[c]);
+  st.has_color = m->color_pending.on;
   // (one frame carries a frame, a batch a batch; a held-back updateEsdf WITHOUT a colour frame -- depth-only and occupancy mappers -- is carried by
   //  any camera launch: integrate_cameras has checked that the two-launch order applies, nvbx_mapper::esdf_only_carry)
-  const bool pipelined = Sensor::kRiders && (has_color ? ((NB == 1) == (m->color_pending.n == 1)) : m->esdf_update_pending);
-  bool fused = false;
-  if (pipelined) {
+  st.pipelined = Sensor::kRiders && (st.has_color ? ((NB == 1) == (m->color_pending.n == 1)) : m->esdf_update_pending);
+  st.fused = false;
+  if (st.pipelined) {
     static const int fuse_on = getenv("NVBX_FUSE_COLC") ? atoi(getenv("NVBX_FUSE_COLC")) : 1;      // (A/B: 0 = three launches per frame)
     // TSDF mapper (with or without a freespace layer), 2-D ESDF by the exact transform (the marking pass / distance transform that ride are the
     // 2-D ones), no multi-GPU union step waiting for the colour launch, and no block that may be F_BAND_STALE (the candidate riders read the
     // band flags only)
-    fused = has_color ? (fuse_on && m->p.projective_layer_type != 1 && m->p.esdf_mode == 0 && m->p.esdf_propagation == 0 && !m->lidar_integrated && m->capacity <= (1ll << 24))
-                      : true;      // (no colour: no candidates, no band flags -- esdf_only_carry has checked the rest)
+    st.fused = st.has_color ? (fuse_on && fused_colour_applies(m))
+                            : true;      // (no colour: no candidates, no band flags -- esdf_only_carry has checked the rest)
     // (a distance transform armed outside the pipeline must precede the marking pass that rides in this launch: its own launch, rare)
-    if (fused && edt_wg) { m->edt_pending = true; edt_wg = 0; if (m->flush_edt()) return NVBX_E_DEVICE; }
+    if (st.fused && st.edt_wg) { m->edt_pending = true; st.edt_wg = 0; if (m->flush_edt()) return NVBX_E_DEVICE; }
     m->pipelined_order = true;
-    if (has_color) { const int rc = m->pending_color_trace_rider(&tr); if (rc) { m->pipelined_order = false; return rc; } }
+    if (st.has_color) { const int rc = m->pending_color_trace_rider(&st.tr); if (rc) { m->pipelined_order = false; return rc; } }
     // riders before or after the tiles (A/B: NVBX_MARK_TILES_FIRST = 0 / 1).  One frame: tiles first (15.2 vs 15.8 us).  A batch of 8: riders first
     // (32.4 vs 42.0 us) -- its 2 688 single-wavefront tile workgroups, each holding its LDS key set, take most of the workgroup slots, and
     // sphere-tracing workgroups dispatched behind them start when the tiles are done: the launch took the SUM of its parts.
     static const int tiles_first_env = getenv("NVBX_MARK_TILES_FIRST") ? atoi(getenv("NVBX_MARK_TILES_FIRST")) : -1;
     const bool tiles_first = tiles_first_env >= 0 ? tiles_first_env != 0 : NB == 1;
-    if (tiles_first) tr.n_tile_wg = tiles;
-    if (fused && !has_color) m->pending_marking_args(&tr.n_mark_wg, &ea);
-    if (fused && has_color) {
+    if (tiles_first) st.tr.n_tile_wg = st.tiles;
+    if (st.fused && !st.has_color) m->pending_marking_args(&st.tr.n_mark_wg, &st.ea);
+    if (st.fused && st.has_color) {
       if (m->ensure_fuse_buffers()) { m->pipelined_order = false; return NVBX_E_DEVICE; }
       const int64_t hw_seen = std::max<int64_t>(1, __atomic_load_n(&m->h_mirror[1], __ATOMIC_RELAXED));
-      tr.n_scan_wg = (int32_t)std::min<int64_t>(256, 8 * ((hw_seen + hw_seen / 4 + 64 + 2047) / 2048));      // 256 slots per workgroup and pass; a hint only (the riders grid-stride)
-      tr.cand = m->color_cand + (size_t)m->cand_parity * m->fuse_cap;
-      tr.cand_cnt_idx = C_CAND_COUNT + m->cand_parity; tr.cand_reset_idx = C_CAND_COUNT + (1 - m->cand_parity);
+      st.tr.n_scan_wg = (int32_t)std::min<int64_t>(256, 8 * ((hw_seen + hw_seen / 4 + 64 + 2047) / 2048));      // 256 slots per workgroup and pass; a hint only (the riders grid-stride)
+      st.tr.cand = m->color_cand + (size_t)m->cand_parity * m->fuse_cap;
+      st.tr.cand_cnt_idx = C_CAND_COUNT + m->cand_parity; st.tr.cand_reset_idx = C_CAND_COUNT + (1 - m->cand_parity);
       m->cand_parity ^= 1;      // (the next fused launch resets THIS count, whether or not the colour launch below is reached: an error return in between leaves no stale candidates behind)
-      m->pending_marking_args(&tr.n_mark_wg, &ea);        // (the held-back integrateColor's marking pass, in call order: before its colour integration below)
+      m->pending_marking_args(&st.tr.n_mark_wg, &st.ea);        // (the held-back integrateColor's marking pass, in call order: before its colour integration below)
     }
   }
-  tr.fence_report = m->next_fence_report();
-  bool grid_view = false;
-  { const int rc = launch_view_grid(m, fs, sensor, tiles, tr.fence_report, &grid_view); if (rc) return rc; }
-  if (!grid_view)
-  NVBX_LAUNCH_SMEM(m, (k_mark_view<Img, Sensor, NB>), dim3(tiles + edt_wg + tr.n_wg + tr.n_scan_wg + tr.n_mark_wg), dim3(Sensor::kThreads), mark_view_smem<Sensor>(edt_wg > 0), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
-              (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)edt_wg, ea, tr);
-  FrameSetC<PixRgb8, NB> fsc{}; int f_kind = 0; int32_t f_srows = 0, f_scols = 0;
-  if (pipelined) {
+  st.tr.fence_report = m->next_fence_report();
+  return NVBX_OK;
+}
+// step 2: between the two launches -- the host-side steps of the held-back calls, then the sizes of the TSDF-update part
+template <typename Sensor, int NB>
+static int depth_step_between(nvbx_mapper* m, DepthSteps<NB>& st) {
+  if (st.pipelined) {
     // the host-side steps of the held-back calls, in call order: integrateColor (its marking pass empties the dirty list itself, the EDT
     // of the update keeps it -- EsdfArgs), then updateEsdf (which only arms the next held-back EDT: the marking pass has been launched)
-    if (!fused) m->premark_consumed = false;
+    if (!st.fused) m->premark_consumed = false;
     int rc = NVBX_OK;
-    if (fused) { if (has_color) rc = m->pending_color_fused_args(&fsc, &f_kind, &f_srows, &f_scols); }
+    if (st.fused) { if (st.has_color) rc = m->pending_color_fused_args(&st.fsc, &st.f_kind, &st.f_srows, &st.f_scols); }
     else rc = m->launch_pending_color_after_trace();
     if (rc == NVBX_OK && m->esdf_update_pending) { m->esdf_update_pending = false; rc = nvbx_update_esdf(m); }
     m->pipelined_order = false;
@@ -1630,38 +1696,69 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
   //  than the first finishes, took 1.7 ms each for their 112 k blocks: the whole of round 4's first "exploring" LiDAR figure)
   const int64_t n_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[2], __ATOMIC_RELAXED));
   const int64_t want = n_hint == 0 ? (int64_t)grid_cap : ((n_hint + n_hint / 4 + 64 + 7) / 8) * 8;
-  const int grid = (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, grid_cap), want));
-  const int32_t spec_lanes = (int32_t)std::min<int64_t>(64, (n_hint + n_hint / 4 + 64 + grid - 1) / grid);
+  st.grid = (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, grid_cap), want));
+  st.spec_lanes = (int32_t)std::min<int64_t>(64, (n_hint + n_hint / 4 + 64 + st.grid - 1) / st.grid);
+  return NVBX_OK;
+}
+// step 3 (fused form): the riders of the TSDF-update launch
+// [distance transform the held-back updateEsdf has just armed][TSDF update of this frame][colour integration of the held-back frame]
+template <int NB>
+static void depth_step_fused_riders(nvbx_mapper* m, DepthSteps<NB>& st) {
+  st.n_edt = 0; st.ea_edt = m->edt_args;
+  static const int edt_riders = getenv("NVBX_EDT_RIDERS") ? atoi(getenv("NVBX_EDT_RIDERS")) : 256;      // (A/B; a multiple of 8)
+  if (m->edt_pending) { st.n_edt = edt_riders; m->edt_pending = false; }
+  st.cand = st.tr.cand;
+  st.cand_idx = st.tr.cand_cnt_idx;
+  const int64_t c_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[3], __ATOMIC_RELAXED));         // candidates of the last colour frame the GPU has finished
+  // (no colour frame: update + distance transform only; no colour launch finished yet -- a new or just cleared map: as many as the TSDF part)
+  static const int color_cap = getenv("NVBX_COLOR_GRID") ? atoi(getenv("NVBX_COLOR_GRID")) : 1024;      // (A/B: workgroups of the colour part, tools/fused_grid_sweep.sh)
+  st.cgrid = !st.has_color ? 0 : (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, color_cap), c_hint == 0 ? (int64_t)st.grid : ((c_hint + c_hint / 4 + 64 + 7) / 8) * 8));
+  // a held-back union step of the multi-GPU exchange (nvbx_mark_esdf_dirty_gathered_deferred) rides here in eight workgroups: the peers'
+  // blocks become ESDF-dirty for the NEXT marking pass (its own marking launch, or a ride in the colour launch, would be a third launch;
+  // beside this frame's view marking it would meet blocks that launch is just allocating -- DESIGN.md 6.1)
+  st.imp = ImportArgs{};
+  if (m->import_pending) {
+    st.imp.g = m->import_ptr; st.imp.world = m->import_world; st.imp.self_rank = m->import_rank; st.imp.max_count = m->import_max; st.imp.n_wg = 8;
+    m->import_pending = false;
+  }
+}
+// step 4: behind the TSDF-update launch
+template <typename Sensor>
+static int depth_step_after(nvbx_mapper* m, int n_frames) {
+  NVBX_HIP(hipGetLastError());
+  m->last_view_frame = m->frame_id;
+  if (!Sensor::kLongRays) { m->last_camera_view_frame = m->frame_id; m->last_camera_view_mask = 1u << (n_frames - 1); }   // (a batch: the LAST camera's view, as separate calls would leave it)
+  m->last_view_batch = n_frames;
+  if (m->p.projective_layer_type == 2 && m->update_freespace()) return NVBX_E_DEVICE;     // TSDF with freespace (dynamic mapping)
+  return m->mark_main();
+}
+
+template <typename Img, typename Sensor, int NB>
+static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sensor& sensor) {
+  // (frames of a held-back colour image this call carries out: let go of on every way out, behind the launches that read them)
+  struct ReleaseFrames { nvbx_mapper* m; ~ReleaseFrames() { m->release_consumed_frames(); } } release_frames{m};
+  DepthSteps<NB> st;
+  { const int rc = depth_step_before_mark_view<Img, Sensor, NB>(m, fs, st); if (rc) return rc; }
+  bool grid_view = false;
+  { const int rc = launch_view_grid(m, fs, sensor, st.tiles, st.tr.fence_report, &grid_view); if (rc) return rc; }
+  if (!grid_view)
+  NVBX_LAUNCH_SMEM(m, (k_mark_view<Img, Sensor, NB>), dim3(st.tiles + st.edt_wg + st.tr.n_wg + st.tr.n_scan_wg + st.tr.n_mark_wg), dim3(Sensor::kThreads), mark_view_smem<Sensor>(st.edt_wg > 0), m->d, fs, sensor, (int4*)m->view_list, (int32_t)m->capacity,
+              (int32_t)(m->premark_consumed ? 1 : 0), (int32_t)st.edt_wg, st.ea, st.tr);
+  { const int rc = depth_step_between<Sensor, NB>(m, st); if (rc) return rc; }
+  const int grid = st.grid; const int32_t spec_lanes = st.spec_lanes; const bool plain = st.plain;
   uint8_t* view_class = nullptr; int32_t* dense_list = nullptr;
   { const int rc = launch_lidar_sparse(m, fs, sensor, plain, &view_class, &dense_list); if (rc) return rc; }
   if (Sensor::kLongRays && m->p.projective_layer_type != 1) m->lidar_integrated = true;      // (blocks may be F_BAND_STALE from here on)
-  if (fused) {
+  if (st.fused) {
     if constexpr (Sensor::kRiders) {
-      // [distance transform the held-back updateEsdf has just armed][TSDF update of this frame][colour integration of the held-back frame]
-      int32_t n_edt = 0; EsdfArgs ea_edt = m->edt_args;
-      static const int edt_riders = getenv("NVBX_EDT_RIDERS") ? atoi(getenv("NVBX_EDT_RIDERS")) : 256;      // (A/B; a multiple of 8)
-      if (m->edt_pending) { n_edt = edt_riders; m->edt_pending = false; }
-      const int4* cand = tr.cand;
-      const int32_t cand_idx = tr.cand_cnt_idx;
-      const int64_t c_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[3], __ATOMIC_RELAXED));         // candidates of the last colour frame the GPU has finished
-      // (no colour frame: update + distance transform only; no colour launch finished yet -- a new or just cleared map: as many as the TSDF part)
-      static const int color_cap = getenv("NVBX_COLOR_GRID") ? atoi(getenv("NVBX_COLOR_GRID")) : 1024;      // (A/B: workgroups of the colour part, tools/fused_grid_sweep.sh)
-      const int cgrid = !has_color ? 0 : (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, color_cap), c_hint == 0 ? (int64_t)grid : ((c_hint + c_hint / 4 + 64 + 7) / 8) * 8));
-      // a held-back union step of the multi-GPU exchange (nvbx_mark_esdf_dirty_gathered_deferred) rides here in eight workgroups: the peers'
-      // blocks become ESDF-dirty for the NEXT marking pass (its own marking launch, or a ride in the colour launch, would be a third launch;
-      // beside this frame's view marking it would meet blocks that launch is just allocating -- DESIGN.md 6.1)
-      ImportArgs imp{};
-      if (m->import_pending) {
-        imp.g = m->import_ptr; imp.world = m->import_world; imp.self_rank = m->import_rank; imp.max_count = m->import_max; imp.n_wg = 8;
-        m->import_pending = false;
-      }
-      const dim3 g((unsigned)(n_edt + grid + cgrid + imp.n_wg));
+      depth_step_fused_riders<NB>(m, st);
+      const dim3 g((unsigned)(st.n_edt + grid + st.cgrid + st.imp.n_wg));
 #define NVBX_FUSED_LAUNCH(PIX, PLAIN, FC) NVBX_LAUNCH(m, (k_integrate_tsdf_color<Img, PIX, NB, PLAIN>), g, dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity, \
-        m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (int32_t)grid, FC, (const float*)m->synth, f_srows, f_scols, cand, cand_idx, n_edt, ea_edt, imp)
-      if (NB > 1 || f_kind == 0) {
-        if (plain) NVBX_FUSED_LAUNCH(PixRgb8, true, fsc); else NVBX_FUSED_LAUNCH(PixRgb8, false, fsc);
+        m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (int32_t)grid, FC, (const float*)m->synth, st.f_srows, st.f_scols, st.cand, st.cand_idx, st.n_edt, st.ea_edt, st.imp)
+      if (NB > 1 || st.f_kind == 0) {
+        if (plain) NVBX_FUSED_LAUNCH(PixRgb8, true, st.fsc); else NVBX_FUSED_LAUNCH(PixRgb8, false, st.fsc);
       } else if constexpr (NB == 1) {
-        FrameSetC<PixBgra8, 1> fc; memcpy(&fc, &fsc, sizeof(fc));       // (one layout, color.hip static_assert)
+        FrameSetC<PixBgra8, 1> fc; memcpy(&fc, &st.fsc, sizeof(fc));       // (one layout, color.hip static_assert)
         if (plain) NVBX_FUSED_LAUNCH(PixBgra8, true, fc); else NVBX_FUSED_LAUNCH(PixBgra8, false, fc);
       }
 #undef NVBX_FUSED_LAUNCH
@@ -1671,12 +1768,55 @@ static int integrate_depth_impl(nvbx_mapper* m, FrameSet<Img, NB> fs, const Sens
                          m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (const uint8_t*)view_class, (const int32_t*)dense_list);
   else NVBX_LAUNCH(m, (k_integrate_tsdf<Img, Sensor, NB, false>), dim3(grid), dim3(512), m->d, fs, sensor, (const int4*)m->view_list, (int32_t)m->capacity,
                    m->mesh_list_live(), m->view_export, (int32_t)m->view_export_cap, spec_lanes, (const uint8_t*)view_class, (const int32_t*)dense_list);
-  NVBX_HIP(hipGetLastError());
-  m->last_view_frame = m->frame_id;
-  if (!Sensor::kLongRays) { m->last_camera_view_frame = m->frame_id; m->last_camera_view_mask = 1u << (fs.n - 1); }   // (a batch: the LAST camera's view, as separate calls would leave it)
-  m->last_view_batch = fs.n;
-  if (m->p.projective_layer_type == 2 && m->update_freespace()) return NVBX_E_DEVICE;     // TSDF with freespace (dynamic mapping)
-  return m->mark_main();
+  return depth_step_after<Sensor>(m, fs.n);
+}
+
+// Two mappers, one depth frame each (same image size, same stream), in TWO launches instead of four: defined as equal to integrate_depth_impl(ma) followed by
+// integrate_depth_impl(mb) -- the maps share nothing, so running each launch's two halves side by side changes no result (tests/test_gpu_round6.py).  Both
+// frames are camera frames that have passed integrate_cameras' own preparation (pair_prepare below).
+template <typename Img>
+static int integrate_depth_pair_impl(nvbx_mapper* ma, FrameSet<Img, 1> fa, nvbx_mapper* mb, FrameSet<Img, 1> fb) {
+  struct ReleaseFrames { nvbx_mapper* m; ~ReleaseFrames() { m->release_consumed_frames(); } } release_a{ma}, release_b{mb};
+  DepthSteps<1> sa, sb;
+  { const int rc = depth_step_before_mark_view<Img, CameraSensor, 1>(ma, fa, sa); if (rc) return rc; }
+  { const int rc = depth_step_before_mark_view<Img, CameraSensor, 1>(mb, fb, sb); if (rc) { ma->pipelined_order = false; return rc; } }
+  // (a distance transform armed in classic order would ride with the LDS of an EdtShared: launched on its own first -- rare, a mapper that has just left the classic order)
+  if (sa.edt_wg) { ma->edt_pending = true; sa.edt_wg = 0; if (ma->flush_edt()) return NVBX_E_DEVICE; }
+  if (sb.edt_wg) { mb->edt_pending = true; sb.edt_wg = 0; if (mb->flush_edt()) return NVBX_E_DEVICE; }
+  // (tiles-first layout inside each mapper's numbering, whether or not it has riders: the pair kernel deals the tiles of both out first)
+  sa.tr.n_tile_wg = sa.tiles; sb.tr.n_tile_wg = sb.tiles;
+  MarkViewArgs<Img> A{ma->d, fa, (int4*)ma->view_list, (int32_t)ma->capacity, (int32_t)(ma->premark_consumed ? 1 : 0), 0, sa.ea, sa.tr, sa.tiles, sa.tiles + sa.tr.n_wg + sa.tr.n_scan_wg + sa.tr.n_mark_wg};
+  MarkViewArgs<Img> B{mb->d, fb, (int4*)mb->view_list, (int32_t)mb->capacity, (int32_t)(mb->premark_consumed ? 1 : 0), 0, sb.ea, sb.tr, sb.tiles, sb.tiles + sb.tr.n_wg + sb.tr.n_scan_wg + sb.tr.n_mark_wg};
+  mb->enqueue_seq++;
+  NVBX_LAUNCH_SMEM(ma, (k_mark_view_pair<Img>), dim3((unsigned)(A.n_wg + B.n_wg)), dim3(CameraSensor::kThreads), mark_view_smem<CameraSensor>(false), A, B);
+  { const int rc = depth_step_between<CameraSensor, 1>(ma, sa); if (rc) { mb->pipelined_order = false; return rc; } }
+  { const int rc = depth_step_between<CameraSensor, 1>(mb, sb); if (rc) return rc; }
+  // the TSDF-update launch in its fused form for both (a mapper with nothing held back: no riders -- the same worker as k_integrate_tsdf)
+  if (sa.fused) depth_step_fused_riders<1>(ma, sa);      // (else: zero riders, DepthSteps' defaults)
+  if (sb.fused) depth_step_fused_riders<1>(mb, sb);
+  // (the second mapper of a pair is the foreground mapper: a few blocks.  Its distance transform gets 64 workers instead of 256 -- they grid-stride, and the
+  //  launch is residency-bound: every idle 8-wavefront workgroup holds a slot for ~1.5 us)
+  static const int pair_b_edt = getenv("NVBX_PAIR_B_EDT_RIDERS") ? atoi(getenv("NVBX_PAIR_B_EDT_RIDERS")) : 64;
+  if (sb.n_edt > pair_b_edt && pair_b_edt >= 8) sb.n_edt = pair_b_edt & ~7;
+  const int kind = sa.has_color ? sa.f_kind : (sb.has_color ? sb.f_kind : 0);
+  auto fused_args = [&](nvbx_mapper* m, const FrameSet<Img, 1>& f, const DepthSteps<1>& st, auto* out) {
+    using FA = std::remove_pointer_t<decltype(out)>;
+    FA x{}; x.m = m->d; x.fs = f; x.view_list = (const int4*)m->view_list; x.list_cap = (int32_t)m->capacity; x.mesh_list = m->mesh_list_live(); x.view_export = m->view_export;
+    x.view_export_cap = (int32_t)m->view_export_cap; x.spec_lanes = st.spec_lanes; x.n_tsdf_wg = (int32_t)st.grid; memcpy(&x.fsc, &st.fsc, sizeof(x.fsc));
+    x.synth = (const float*)m->synth; x.srows = st.f_srows; x.scols = st.f_scols; x.cand = st.cand; x.cand_cnt_idx = st.cand_idx; x.n_edt_wg = st.n_edt; x.ea = st.ea_edt; x.imp = st.imp;
+    x.n_wg = st.n_edt + st.grid + st.cgrid + st.imp.n_wg;
+    *out = x;
+  };
+  mb->enqueue_seq++;
+  if (kind == 0) {
+    FusedArgs<Img, PixRgb8> FA_, FB_; fused_args(ma, fa, sa, &FA_); fused_args(mb, fb, sb, &FB_);
+    NVBX_LAUNCH(ma, (k_integrate_tsdf_color_pair<Img, PixRgb8>), dim3((unsigned)(FA_.n_wg + FB_.n_wg)), dim3(512), FA_, FB_);
+  } else {
+    FusedArgs<Img, PixBgra8> FA_, FB_; fused_args(ma, fa, sa, &FA_); fused_args(mb, fb, sb, &FB_);
+    NVBX_LAUNCH(ma, (k_integrate_tsdf_color_pair<Img, PixBgra8>), dim3((unsigned)(FA_.n_wg + FB_.n_wg)), dim3(512), FA_, FB_);
+  }
+  { const int rc = depth_step_after<CameraSensor>(ma, 1); if (rc) return rc; }
+  return depth_step_after<CameraSensor>(mb, 1);
 }
 // the 24-bit view frame id of Entry::stamp: before it would wrap, every stamp is reset (once per 16.7 M depth frames)
 __global__ void k_reset_stamps(DMap m) {
@@ -1714,9 +1854,9 @@ __global__ void k_dilate_invalid(Img in, int32_t rows, int32_t cols, int32_t n, 
   }
 }
 
-// n camera frames (n = 1: MultiMapper::integrateDepth; n > 1: nvbx_integrate_depth_batch) of one image size -> one launch set
-template <typename Img, int NB>
-static int integrate_cameras(nvbx_mapper* m, int32_t n, const Img* imgs, int32_t rows, int32_t cols, const float* T_L_C /* n x 16 */, const nvbx_camera* cameras) {
+// what a camera integrateDepth does before it enqueues anything of its own frame: argument check, the held-back calls it cannot carry, pool growth
+template <int NB>
+static int cameras_prepare(nvbx_mapper* m, int32_t n, const float* T_L_C /* n x 16 */) {
   for (int c = 0; c < n; c++)
     if (!nvbx_pose_in_range(T_L_C + 16 * c, m->p.voxel_size * 8.0f, m->p.max_integration_distance_m + 2.0f * m->p.truncation_distance_vox * m->p.voxel_size)) {
       set_error("integrate depth: T_L_C is not finite or lies outside the addressable block range (+-2^20 blocks)"); return NVBX_E_INVALID; }
@@ -1738,6 +1878,12 @@ static int integrate_cameras(nvbx_mapper* m, int32_t n, const Img* imgs, int32_t
     if (keep) { m->color_pending = cp; m->esdf_update_pending = up; }
     if (rc) return NVBX_E_DEVICE; }
   { const int rc = m->maybe_grow(); if (rc) return rc; }          // (before anything of this frame is enqueued)
+  return NVBX_OK;
+}
+// n camera frames (n = 1: MultiMapper::integrateDepth; n > 1: nvbx_integrate_depth_batch) of one image size -> one launch set
+template <typename Img, int NB>
+static int integrate_cameras(nvbx_mapper* m, int32_t n, const Img* imgs, int32_t rows, int32_t cols, const float* T_L_C /* n x 16 */, const nvbx_camera* cameras) {
+  { const int rc = cameras_prepare<NB>(m, n, T_L_C); if (rc) return rc; }
   const bool dilate = m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0;
   if (dilate && m->flush_edt()) return NVBX_E_DEVICE;   // first launch is the dilation
   { const int rc = next_frame_id(m); if (rc) return rc; }
@@ -1788,6 +1934,36 @@ extern "C" int nvbx_integrate_depth_batch(nvbx_mapper* m, int32_t n, const float
   DepthF32 imgs[MAX_BATCH];
   for (int c = 0; c < n; c++) imgs[c] = DepthF32{depth_dev[c]};
   return integrate_cameras<DepthF32, MAX_BATCH>(m, n, imgs, rows, cols, T_L_C, cameras);
+}
+
+// One depth frame each for TWO mappers on one stream -- MultiMapper::integrateDepth of the dynamic and the human mapping types: the background mapper takes the
+// unmasked part of the depth image, the foreground (occupancy) mapper the masked part, nvblox_node.cpp:1057-1062 -- in two launches instead of four.
+// See include/nvblox_hip.h; whatever the pair cannot express falls back to the two calls it is defined by.
+static bool pair_can_fuse(const nvbx_mapper* m) {
+  static const int fuse_on = getenv("NVBX_FUSE_COLC") ? atoi(getenv("NVBX_FUSE_COLC")) : 1;
+  if (m->use_side || m->capacity > (1ll << 24)) return false;
+  if (m->p.do_depth_preprocessing && m->p.depth_preprocessing_num_dilations > 0) return false;          // (a dilation launch in front)
+  if (m->color_pending.on && (m->color_pending.n != 1 || !fuse_on || !fused_colour_applies(m))) return false;      // (its colour frame would be carried in three launches)
+  return true;
+}
+extern "C" int nvbx_integrate_depth_pair(nvbx_mapper* ma, const float* depth_a_dev, nvbx_mapper* mb, const float* depth_b_dev, int32_t rows, int32_t cols,
+                                         const float T_L_C[16], const nvbx_camera* camera) {
+  if (!ma || !mb || ma == mb || !depth_a_dev || !depth_b_dev || !T_L_C || !camera || !image_dims_ok(rows, cols)) { set_error("nvbx_integrate_depth_pair: invalid argument (two different mappers, image sides 1 .. 32768)"); return NVBX_E_INVALID; }
+  if (!nvbx_camera_matches(camera, rows, cols)) { set_error("nvbx_integrate_depth_pair: camera width/height must equal the image's cols/rows, focal lengths > 0"); return NVBX_E_INVALID; }
+  static const int pair_on = getenv("NVBX_DEPTH_PAIR") ? atoi(getenv("NVBX_DEPTH_PAIR")) : 1;       // (A/B: 0 = always the two separate calls)
+  if (!pair_on || ma->device != mb->device || ma->stream != mb->stream || !pair_can_fuse(ma) || !pair_can_fuse(mb)) {
+    const int rc = nvbx_integrate_depth(ma, depth_a_dev, rows, cols, T_L_C, camera); if (rc) return rc;
+    return nvbx_integrate_depth(mb, depth_b_dev, rows, cols, T_L_C, camera);
+  }
+  // each mapper's own preparation, in call order (held-back calls it cannot carry are replayed, pools grow), then the frame ids
+  { const int rc = cameras_prepare<1>(ma, 1, T_L_C); if (rc) return rc; }
+  { const int rc = cameras_prepare<1>(mb, 1, T_L_C); if (rc) return rc; }
+  { const int rc = next_frame_id(ma); if (rc) return rc; }
+  { const int rc = next_frame_id(mb); if (rc) return rc; }
+  FrameSet<DepthF32, 1> fa{}, fb{}; fa.n = 1; fb.n = 1;
+  fa.f[0] = ma->make_frame(T_L_C, camera, rows, cols, ma->p.raycast_subsampling_factor); fa.img[0] = DepthF32{depth_a_dev};
+  fb.f[0] = mb->make_frame(T_L_C, camera, rows, cols, mb->p.raycast_subsampling_factor); fb.img[0] = DepthF32{depth_b_dev};
+  return integrate_depth_pair_impl<DepthF32>(ma, fa, mb, fb);
 }
 
 // ------------------------------------------------------------------------------------------------ multi-GPU: measurement exchange

@@ -398,6 +398,16 @@ class Mapper:
     def integrate_color_batch(self, rgbs, poses, cams):
         a = self.prepare_color_batch(rgbs, poses, cams); self.integrate_prepared_batch(a); self._hold("_keep_c", [a])
 
+    def integrate_depth_pair(self, depth_a, other, depth_b, T_L_C, cam):
+        """nvbx_integrate_depth_pair: self.integrate_depth(depth_a) followed by other.integrate_depth(depth_b) -- the background / foreground mappers of a
+        MultiMapper's dynamic and human mapping types, fed the two halves of one mask-split depth frame -- in two launches instead of four (both mappers on
+        one stream; anything else falls back to the two calls).  Same maps, bit for bit."""
+        da = self._dev(depth_a, self._torch.float32); db = self._dev(depth_b, self._torch.float32)
+        assert da.shape == db.shape
+        self._check(self.lib.nvbx_integrate_depth_pair(self._h, C.c_void_p(da.data_ptr()), other._h, C.c_void_p(db.data_ptr()), da.shape[0], da.shape[1],
+                                                       _np_ptr(self._T(T_L_C)), C.byref(self._cam(cam))))
+        self._hold("_keep", [da, db]); other._hold("_keep", [db])
+
     def integrate_prepared(self, a):
         rc = a[0](self._h, a[1], a[2], a[3], a[4], a[5])
         if rc < 0:

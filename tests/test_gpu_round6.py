@@ -1,0 +1,146 @@
+"""Round 6: nvbx_integrate_depth_pair -- the background and the foreground mapper of a MultiMapper's dynamic / human mapping types take the two halves of
+one mask-split depth frame (nvblox_node.cpp:1057-1062) in TWO launches instead of four (k_mark_view_pair, k_integrate_tsdf_color_pair).  Defined as
+equal to the two nvbx_integrate_depth calls in order: every layer of both maps bit for bit, whatever each mapper holds back at the time (colour frame +
+ESDF update, ESDF update alone, nothing), across decay, clearing, queries and drains; and equal to the checker."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as H
+from isaac_ros_nvblox_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _layers(M, m, layers):
+    out = {}
+    for name, lay in layers:
+        idx = m.block_indices(lay)
+        blk, _ = m.get_blocks(lay, idx)
+        out[name] = (idx, blk)
+    return out
+
+
+def _same(M, a, b, layers, tag):
+    la, lb = _layers(M, a, layers), _layers(M, b, layers)
+    for name in la:
+        ia, ba = la[name]; ib, bb = lb[name]
+        assert np.array_equal(ia, ib), (tag, name, len(ia), len(ib))
+        assert ba.tobytes() == bb.tobytes(), (tag, name)
+
+
+def _short(name):
+    import bench
+    return bench.short(name)
+
+
+@pytest.mark.parametrize("cam", [H.SMALL_CAM, S.REPLICA_LIKE_CAM], ids=["160x120", "640x480"])
+def test_depth_pair_equals_the_two_calls_and_the_checker(oracle_mod, hip_lib, cam):
+    """The dynamic-mapping frame as bench.py --workload decay drives it: front end, static mapper (TSDF + freespace, colour, ESDF), dynamic mapper
+    (occupancy, ESDF), decay on every sixth frame, a slice query now and then -- once with nvbx_integrate_depth_pair, once with the two calls, once on
+    the checker.  The held-back state of each mapper differs from frame to frame (colour on two frames of three, an ESDF update skipped now and then)."""
+    import torch
+    from isaac_ros_nvblox_amd import mapper as M
+    rows, cols = cam[5], cam[4]
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    fs = dict(projective_layer_type=2, max_integration_distance_m=5.0, invalid_depth_decay_factor=0.8, tsdf_decay_factor=0.95, min_duration_since_occupied_for_freespace_ms=250)
+    oc = dict(projective_layer_type=1, max_integration_distance_m=5.0, free_region_decay_probability=0.55, occupied_region_decay_probability=0.4)
+    ps, pd = M.default_params(**fs), M.default_params(**oc)
+    with torch.cuda.stream(stream):
+        sa = M.Mapper(ps, block_capacity=1 << 14, stream=stream.cuda_stream); da = M.Mapper(pd, block_capacity=1 << 12, stream=stream.cuda_stream)      # the pair
+        sb = M.Mapper(ps, block_capacity=1 << 14, stream=stream.cuda_stream); db = M.Mapper(pd, block_capacity=1 << 12, stream=stream.cuda_stream)      # the two calls
+        os_ = oracle_mod.OracleMap(H.copy_params(ps, oracle_mod.OrcParams)); od = oracle_mod.OracleMap(H.copy_params(pd, oracle_mod.OrcParams))
+        sa.set_profiling(True); da.set_profiling(True)
+        eye = np.eye(4, dtype=np.float32)
+        static_scene = S.Scene(); moving = S.Scene(box_min=(1.6, -0.3, 0.0), box_max=(2.0, 0.3, 1.3))
+        min_component = 40 if cols == 160 else 640
+        rng = np.random.default_rng(6)
+        n_frames = 20
+        for i in range(n_frames):
+            sc = static_scene if i < 8 else moving
+            T = S.trajectory_pose(min(i, 10), 200)
+            d, rgb = S.render(sc, T, cam, max_range=5.0)
+            d_dev = torch.from_numpy(d).to(dev); rgb_dev = torch.from_numpy(rgb).to(dev)
+            t_ms = i * 100
+            halves = []
+            for st_ in (sa, sb):
+                st_.set_time_ms(t_ms)
+                mk = torch.empty((rows, cols), dtype=torch.uint8, device=dev); un = torch.empty((rows, cols), dtype=torch.float32, device=dev); ma = torch.empty_like(un)
+                st_.dynamic_depth_split_into(d_dev, T, cam, 5.0, min_component, 0.25, mk, un, ma)
+                halves.append((un, ma))
+            sa.integrate_depth_pair(halves[0][0], da, halves[0][1], T, cam)
+            sb.integrate_depth(halves[1][0], T, cam); db.integrate_depth(halves[1][1], T, cam)
+            mo = os_.detect_dynamics(d, T, cam, 5.0); mo = oracle_mod.remove_small_components(mo, min_component)
+            uo, mao = oracle_mod.split_depth_by_mask(d, mo, eye, cam, cam, 0.25)
+            os_.set_time_ms(t_ms); os_.integrate_depth(uo, T, cam); od.integrate_depth(mao, T, cam)
+            if i % 3 != 2:
+                for st_ in (sa, sb):
+                    st_.integrate_color(rgb_dev, T, cam)
+                os_.integrate_color(rgb, T, cam)
+            if rng.random() < 0.8:
+                for m_ in (sa, sb, da, db):
+                    m_.update_esdf()
+                os_.update_esdf(); od.update_esdf()
+            if i % 6 == 5:
+                sa.decay_tsdf(True); da.decay_occupancy(); sb.decay_tsdf(True); db.decay_occupancy()
+                os_.decay_tsdf(True); od.decay_occupancy()
+            if i % 7 == 3:                                           # a query: drains what is held back
+                img_a, _ = sa.esdf_slice_image(); img_b, _ = sb.esdf_slice_image()
+                assert img_a.shape == img_b.shape and np.array_equal(img_a, img_b), i
+        for m_ in (sa, sb, da, db):
+            m_.synchronize()
+        static_layers = [("tsdf", M.LAYER_TSDF), ("color", M.LAYER_COLOR), ("esdf", M.LAYER_ESDF), ("freespace", M.LAYER_FREESPACE)]
+        dyn_layers = [("occupancy", M.LAYER_OCCUPANCY), ("esdf", M.LAYER_ESDF)]
+        _same(M, sa, sb, static_layers, "static mapper, pair vs two calls")
+        _same(M, da, db, dyn_layers, "dynamic mapper, pair vs two calls")
+        # ... and the checker: block sets equal, TSDF / occupancy values within the contract (observed: 0)
+        for g, o, lay_g, lay_o in ((sa, os_, M.LAYER_TSDF, oracle_mod.L_TSDF), (da, od, M.LAYER_OCCUPANCY, oracle_mod.L_TSDF)):
+            ig = g.block_indices(lay_g); io = o.block_indices(lay_o)
+            assert np.array_equal(ig, io) and (len(io) > 0 or g is da)
+            bg, _ = g.get_blocks(lay_g, ig)
+            field = "log_odds" if g is da else "distance"
+            for k, idx in enumerate(io):
+                bo = o.get_block(lay_o, idx)
+                assert np.abs(bg[k][field] - bo["distance"]).max() <= 1e-4
+        assert len(da.block_indices(M.LAYER_OCCUPANCY)) > 0           # the moving box reached the foreground mapper
+        # the pair really shared launches: pair kernels in the first mapper's profile, no view-marking launch of its own on most frames
+        names = {}
+        for k_, v in sa.profile().items():
+            names[_short(k_)] = names.get(_short(k_), 0) + v["count"]
+        assert names.get("k_mark_view_pair", 0) >= n_frames - 1 and names.get("k_integrate_tsdf_color_pair", 0) >= n_frames - 1, names
+        assert names.get("k_mark_view", 0) <= 1, names
+        dn = {_short(k_) for k_ in da.profile()}
+        assert "k_mark_view" not in dn and "k_integrate_tsdf" not in dn, dn
+        for m_ in (sa, sb, da, db):
+            m_.close()
+
+
+def test_depth_pair_falls_back_to_the_two_calls(oracle_mod, hip_lib):
+    """Different streams (or the same mapper twice: an argument error) -- the pair is the two calls, nothing else."""
+    import torch
+    from isaac_ros_nvblox_amd import mapper as M, _lib
+    cam = H.SMALL_CAM
+    pg = M.default_params()
+    a = M.Mapper(pg, block_capacity=1 << 12); b = M.Mapper(pg, block_capacity=1 << 12)          # each on a stream of its own
+    ra = M.Mapper(pg, block_capacity=1 << 12); rb = M.Mapper(pg, block_capacity=1 << 12)
+    a.set_profiling(True)
+    fr = H.frames(3, cam, color=True, stride=9)
+    for d, rgb, T in fr:
+        d2 = d.copy(); d2[:, : cam[4] // 2] = 0.0
+        a.integrate_depth_pair(d, b, d2, T, cam)
+        ra.integrate_depth(d, T, cam); rb.integrate_depth(d2, T, cam)
+        for m_ in (a, ra):
+            m_.integrate_color(rgb, T, cam); m_.update_esdf()
+        b.update_esdf(); rb.update_esdf()
+    for m_ in (a, b, ra, rb):
+        m_.synchronize()
+    lay = [("tsdf", M.LAYER_TSDF), ("color", M.LAYER_COLOR), ("esdf", M.LAYER_ESDF)]
+    _same(M, a, ra, lay, "fallback a"); _same(M, b, rb, lay, "fallback b")
+    assert not ({"k_mark_view_pair", "k_integrate_tsdf_color_pair"} & {_short(k_) for k_ in a.profile()}), list(a.profile())
+    d_dev = torch.from_numpy(fr[0][0]).cuda(); Tm = np.ascontiguousarray(np.asarray(fr[0][2], np.float32).reshape(4, 4))
+    k = M.Camera(*[float(v) for v in cam[:4]], int(cam[4]), int(cam[5]))
+    assert hip_lib.nvbx_integrate_depth_pair(a._h, C.c_void_p(d_dev.data_ptr()), a._h, C.c_void_p(d_dev.data_ptr()), cam[5], cam[4], Tm.ctypes.data_as(C.c_void_p), C.byref(k)) < 0
+    for m_ in (a, b, ra, rb):
+        m_.close()
