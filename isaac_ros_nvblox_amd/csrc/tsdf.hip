@@ -1694,10 +1694,14 @@ static int depth_step_between(nvbx_mapper* m, DepthSteps<NB>& st) {
   // waited for) + 25 % + 64; a hint only -- the kernel grid-strides over whatever the count turns out to be
   // (no launch finished yet -- a new or just cleared map: the full grid; sized for 64 blocks, the first scans of a LiDAR map, enqueued faster
   //  than the first finishes, took 1.7 ms each for their 112 k blocks: the whole of round 4's first "exploring" LiDAR figure)
+  // (the margin over the last count, NVBX_GRID_MARGIN="percent,blocks": A/B only -- tools/env_ab.sh; 25 % + 64 is what a view that grows while exploring needs)
+  static const int mg_pct = getenv("NVBX_GRID_MARGIN") ? atoi(getenv("NVBX_GRID_MARGIN")) : 25;
+  static const int mg_abs = (getenv("NVBX_GRID_MARGIN") && strchr(getenv("NVBX_GRID_MARGIN"), ',')) ? atoi(strchr(getenv("NVBX_GRID_MARGIN"), ',') + 1) : 64;
   const int64_t n_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[2], __ATOMIC_RELAXED));
-  const int64_t want = n_hint == 0 ? (int64_t)grid_cap : ((n_hint + n_hint / 4 + 64 + 7) / 8) * 8;
+  const int64_t n_want = n_hint + n_hint * mg_pct / 100 + mg_abs;
+  const int64_t want = n_hint == 0 ? (int64_t)grid_cap : ((n_want + 7) / 8) * 8;
   st.grid = (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, grid_cap), want));
-  st.spec_lanes = (int32_t)std::min<int64_t>(64, (n_hint + n_hint / 4 + 64 + st.grid - 1) / st.grid);
+  st.spec_lanes = (int32_t)std::min<int64_t>(64, (n_want + st.grid - 1) / st.grid);
   return NVBX_OK;
 }
 // step 3 (fused form): the riders of the TSDF-update launch
@@ -1712,7 +1716,9 @@ static void depth_step_fused_riders(nvbx_mapper* m, DepthSteps<NB>& st) {
   const int64_t c_hint = std::max<int64_t>(0, __atomic_load_n(&m->h_mirror[3], __ATOMIC_RELAXED));         // candidates of the last colour frame the GPU has finished
   // (no colour frame: update + distance transform only; no colour launch finished yet -- a new or just cleared map: as many as the TSDF part)
   static const int color_cap = getenv("NVBX_COLOR_GRID") ? atoi(getenv("NVBX_COLOR_GRID")) : 1024;      // (A/B: workgroups of the colour part, tools/fused_grid_sweep.sh)
-  st.cgrid = !st.has_color ? 0 : (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, color_cap), c_hint == 0 ? (int64_t)st.grid : ((c_hint + c_hint / 4 + 64 + 7) / 8) * 8));
+  static const int mg_pct = getenv("NVBX_GRID_MARGIN") ? atoi(getenv("NVBX_GRID_MARGIN")) : 25;       // (depth_step_between)
+  static const int mg_abs = (getenv("NVBX_GRID_MARGIN") && strchr(getenv("NVBX_GRID_MARGIN"), ',')) ? atoi(strchr(getenv("NVBX_GRID_MARGIN"), ',') + 1) : 64;
+  st.cgrid = !st.has_color ? 0 : (int)std::max<int64_t>(8, std::min<int64_t>(std::min<int64_t>(m->capacity, color_cap), c_hint == 0 ? (int64_t)st.grid : ((c_hint + c_hint * mg_pct / 100 + mg_abs + 7) / 8) * 8));
   // a held-back union step of the multi-GPU exchange (nvbx_mark_esdf_dirty_gathered_deferred) rides here in eight workgroups: the peers'
   // blocks become ESDF-dirty for the NEXT marking pass (its own marking launch, or a ride in the colour launch, would be a third launch;
   // beside this frame's view marking it would meet blocks that launch is just allocating -- DESIGN.md 6.1)
