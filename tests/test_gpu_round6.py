@@ -144,3 +144,67 @@ def test_depth_pair_falls_back_to_the_two_calls(oracle_mod, hip_lib):
     assert hip_lib.nvbx_integrate_depth_pair(a._h, C.c_void_p(d_dev.data_ptr()), a._h, C.c_void_p(d_dev.data_ptr()), cam[5], cam[4], Tm.ctypes.data_as(C.c_void_p), C.byref(k)) < 0
     for m_ in (a, b, ra, rb):
         m_.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_depth_pair_in_randomised_call_sequences(oracle_mod, hip_lib, seed):
+    """Random call patterns around the pair: colour frames or not, ESDF updates on either mapper or not, decay, radius clearing, slice queries, mesh updates,
+    a change of the deferral mode, a frame integrated by the two calls in between -- the pair mappers against two mappers driven by the separate calls,
+    layers compared at random check points and at the end (bit for bit)."""
+    import torch
+    from isaac_ros_nvblox_amd import mapper as M
+    cam = H.SMALL_CAM
+    rows, cols = cam[5], cam[4]
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    rng = np.random.default_rng(100 + seed)
+    ps = M.default_params(tsdf_decay_factor=0.8, tsdf_decayed_weight_threshold=0.3)
+    pd = M.default_params(projective_layer_type=1, free_region_decay_probability=0.6, occupied_region_decay_probability=0.35)
+    lay_s = [("tsdf", M.LAYER_TSDF), ("color", M.LAYER_COLOR), ("esdf", M.LAYER_ESDF)]
+    lay_d = [("occupancy", M.LAYER_OCCUPANCY), ("esdf", M.LAYER_ESDF)]
+    with torch.cuda.stream(stream):
+        sa = M.Mapper(ps, block_capacity=1 << 13, stream=stream.cuda_stream); da = M.Mapper(pd, block_capacity=1 << 12, stream=stream.cuda_stream)
+        sb = M.Mapper(ps, block_capacity=1 << 13, stream=stream.cuda_stream); db = M.Mapper(pd, block_capacity=1 << 12, stream=stream.cuda_stream)
+        fr = H.frames(10, cam, color=True, stride=7)
+        n_pair = 0
+        for step in range(36):
+            d, rgb, T = fr[int(rng.integers(len(fr)))]
+            # the two halves: a vertical split at a random column (foreground = the right part), now and then an empty foreground
+            cut = int(rng.integers(cols // 4, cols)) if rng.random() < 0.85 else cols
+            bg = d.copy(); bg[:, cut:] = 0.0
+            fg = d.copy(); fg[:, :cut] = 0.0
+            if rng.random() < 0.85:
+                sa.integrate_depth_pair(bg, da, fg, T, cam); n_pair += 1
+            else:                                                  # (the pair mappers take a frame by the two calls now and then)
+                sa.integrate_depth(bg, T, cam); da.integrate_depth(fg, T, cam)
+            sb.integrate_depth(bg, T, cam); db.integrate_depth(fg, T, cam)
+            if rng.random() < 0.7:
+                sa.integrate_color(rgb, T, cam); sb.integrate_color(rgb, T, cam)
+            if rng.random() < 0.7:
+                sa.update_esdf(); sb.update_esdf()
+            if rng.random() < 0.6:
+                da.update_esdf(); db.update_esdf()
+            r = rng.random()
+            if r < 0.12:
+                sa.decay_tsdf(True); sb.decay_tsdf(True)
+            elif r < 0.22:
+                da.decay_occupancy(); db.decay_occupancy()
+            elif r < 0.30:
+                c = (float(T[0, 3]), float(T[1, 3]), 1.0)
+                sa.clear_outside_radius(c, 2.5); sb.clear_outside_radius(c, 2.5)
+            elif r < 0.40:
+                ia, _ = sa.esdf_slice_image(); ib, _ = sb.esdf_slice_image()
+                assert ia.shape == ib.shape and np.array_equal(ia, ib), (seed, step)
+            elif r < 0.48:
+                sa.update_color_mesh(); sb.update_color_mesh()
+            elif r < 0.54:
+                on = bool(rng.integers(2))
+                sa.set_color_deferral(on, staged=True); sb.set_color_deferral(on, staged=True)
+            if rng.random() < 0.15:
+                _same(M, sa, sb, lay_s, ("static", seed, step)); _same(M, da, db, lay_d, ("dynamic", seed, step))
+        for m_ in (sa, sb, da, db):
+            m_.synchronize()
+        _same(M, sa, sb, lay_s, ("static, end", seed)); _same(M, da, db, lay_d, ("dynamic, end", seed))
+        assert n_pair > 20 and sa.counters()["capacity_overflow"] == 0
+        for m_ in (sa, sb, da, db):
+            m_.close()

@@ -11,4 +11,4 @@ def pytest_sessionfinish(session, exitstatus):
     print("\nINVARIANT_REPORT", M.INVARIANT_REPORT)
 PY
 NVBX_LIB=$PWD/isaac_ros_nvblox_amd/variants/libnvblox_hip_inv.so NVBX_CHECK_ON_CLOSE=1 PYTHONPATH=/tmp:$PYTHONPATH \
-  python -m pytest -p inv_report_plugin tests/test_gpu_pipeline.py tests/test_gpu_sequences.py tests/test_gpu_batch.py tests/test_gpu_frames.py tests/test_gpu_multi.py tests/test_gpu_parity.py -m gpu -q "$@" 2>&1 | tail -8
+  python -m pytest -p inv_report_plugin tests/test_gpu_pipeline.py tests/test_gpu_sequences.py tests/test_gpu_batch.py tests/test_gpu_frames.py tests/test_gpu_multi.py tests/test_gpu_parity.py tests/test_gpu_round6.py -m gpu -q "$@" 2>&1 | tail -8
