@@ -665,7 +665,10 @@ def main_decay(args):
         else:
             prof[k_] = v_
     counts = {k_: float(np.mean(v_)) for k_, v_ in acc.items()}
-    kern, evo, emp = kernel_table(prof, counts, ms, n2, lambda k, cc: algorithmic_bytes(k, cc, rows, cols), load_pmc("decay"))
+    # (the pair launches carry the static mapper's riders -- sphere tracing, candidates, marking of the held-back frame -- and its colour integration + transform:
+    #  the formulas of the two-launch frame for the first mapper, the plain ones for the second; the classic kernels of a drain keep their own)
+    pipelined_bytes = pair and not args.no_color_deferral
+    kern, evo, emp = kernel_table(prof, counts, ms, n2, lambda k, cc: algorithmic_bytes(k, cc, rows, cols, fused=(pipelined_bytes and k.endswith("_pair"))), load_pmc("decay"))
     cpu = None
     if not args.no_cpu_baseline:
         import oracle

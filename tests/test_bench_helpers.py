@@ -102,3 +102,17 @@ def test_round5_lidar_view_launches_have_algorithmic_bytes():
     assert bench.short("void k_mark_view_grid<nvbx::DepthF32>(nvbx::DMap, ...)") == "k_mark_view_grid"
     # the staged copy is overhead, never algorithm
     assert bench.algorithmic_bytes("k_stage_color", COUNTS, R, C) == 0 and bench.overhead_bytes("k_stage_color", R, C) == R * C * 3 * 2
+
+
+def test_pair_launch_byte_formulas():
+    """nvbx_integrate_depth_pair (round 6): a pair launch moves the first mapper's bytes (two-launch frame formulas) + the second mapper's plain ones."""
+    import bench
+    c = {"tsdf_blocks_in_view": 400, "color_blocks_updated": 300, "blocks_allocated": 2000, "esdf_columns_marked": 200, "esdf_blocks_swept": 250,
+         "b_tsdf_blocks_in_view": 10, "b_esdf_columns_marked": 3, "b_esdf_blocks_swept": 20, "b_blocks_allocated": 15}
+    cb = {k[2:]: v for k, v in c.items() if k.startswith("b_")}; cb["color_blocks_updated"] = 0
+    rows, cols = 480, 640
+    assert bench.algorithmic_bytes("k_mark_view_pair", c, rows, cols, fused=True) == \
+        bench.algorithmic_bytes("k_mark_view", c, rows, cols, fused=True) + bench.algorithmic_bytes("k_mark_view", cb, rows, cols)
+    second = bench.algorithmic_bytes("k_integrate_tsdf_color", cb, rows, cols) - (rows * cols * 3 + (rows // 4) * (cols // 4) * 4)      # (no colour image on an occupancy mapper)
+    assert bench.algorithmic_bytes("k_integrate_tsdf_color_pair", c, rows, cols, fused=True) == bench.algorithmic_bytes("k_integrate_tsdf_color", c, rows, cols) + second
+    assert bench.short("void k_integrate_tsdf_color_pair<nvbx::DepthF32, nvbx::PixRgb8>(FusedArgs<...>)") == "k_integrate_tsdf_color_pair"
