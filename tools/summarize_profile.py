@@ -4,8 +4,10 @@
 usage: summarize_profile.py TAG STATS_DIR [PMC_FETCH_DIR PMC_WRITE_DIR] [--workload W]
   - copies *_kernel_stats.csv to profiles/TAG_kernel_stats.csv (W != camera: profiles/TAG_W_kernel_stats.csv)
   - per kernel: mean FETCH_SIZE / WRITE_SIZE per launch -> HBM bytes per launch, with the gfx950 correction of
-    /opt/skills/guides/MI355X_MICROARCH.md (HBM section): units are KiB, FETCH_SIZE counts 64 B per 128-B request on wide
-    coalesced reads (x2).  Written to profiles/TAG[_W]_pmc.json and merged into profiles/pmc_latest.json under the workload's
+    /opt/skills/guides/MI355X_MICROARCH.md (HBM section): units are KiB, FETCH_SIZE counts 64 B per 128-B request (x2) -- which the guide
+    calibrates for wide coalesced reads and tools/pmc_calibrate.sh confirms for THIS library's patterns (8-byte voxels per lane, 64 contiguous
+    bytes per lane, scattered 16-byte hash entries and 8-byte voxels: TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ, i.e. a scattered access costs a
+    whole 128-B line); WRITE_SIZE is exact (64-B requests).  Written to profiles/TAG[_W]_pmc.json and merged into profiles/pmc_latest.json under the workload's
     key (read by bench.py `traffic`).
 """
 import csv
@@ -56,7 +58,7 @@ def main():
             fk, wk = fetch.get(k, 0.0), write.get(k, 0.0)
             out[k] = {"FETCH_SIZE_KiB": round(fk, 3), "WRITE_SIZE_KiB": round(wk, 3),
                       "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024),
-                      "note": "2x FETCH_SIZE gfx950 correction (calibrated for 16-B/lane streams; our 8-B/lane accesses are uncalibrated)"}
+                      "note": "2x FETCH_SIZE gfx950 correction, 1x WRITE_SIZE: calibrated on known byte counts in this library's access patterns (profiles/r06_pmc_calibration.json: every read request is 128 B, counted at 64)"}
         json.dump(out, open(os.path.join(ROOT, "profiles", "%s%s_pmc.json" % (tag, suffix)), "w"), indent=1)
         latest_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         try:
