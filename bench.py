@@ -262,6 +262,10 @@ def roofline_of(kern, ms_per_step, ev_overhead_us, empty_pair_us, note, skip=("k
                                   "frac": round(kern[most]["achieved_GBps"] / HBM_PEAK_GBS, 5), "traffic": kern[most]["hbm_traffic_bytes"]},
             # context for `peak` (the paper figure): what a bare stream over 8-byte voxels reaches on this GPU, measured once
             "measured_stream_ceiling": {"read_modify_write_GBps": 5800, "read_GBps": 6450, "source": "tools/stream_ceiling.hip (profiles/r02z_stream_ceiling.txt)"},
+            # the 640x480 working set (10-40 MB) sits in the 256 MiB last-level cache / the 32 MiB of L2, so the same bytes against the L2 fabric's
+            # rate too (MI355X_MICROARCH.md: 34.5 TB/s) -- both fractions are small because the launches are dependent-access chains, not streams
+            "l2_fabric": {"peak_GBps": 34500, "frac": round(k["achieved_GBps"] / 34500.0, 5), "step_frac": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / 34500.0, 5)},
+            "counters": "profiles/r06_request_counters.json (L2 requests, L1 accesses, VALU / LDS / VMEM wave-instructions per launch); what FETCH_SIZE / WRITE_SIZE mean for these access patterns: profiles/r06_pmc_calibration.json",
             "note": note}
 
 
