@@ -15,8 +15,11 @@
 // frames.bin as for image_frames: int32 {n, rows, cols}, float {fu fv cu cv}, then per frame T[16] f32, depth f32, rgb u8.
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <string>
 #include <vector>
 #include "nvblox/nvblox.h"
@@ -153,6 +156,54 @@ static int cadence(const std::vector<Fr>& fr, int rows, int cols, const Camera& 
   return failures ? 1 : 0;
 }
 
+//   threads <frames.bin>    ADVICE r05 (low): a back-pressure wait inside nvbx_frame_acquire on one thread while another thread destroys the mapper whose
+//                           fence it waits for.  Thread B creates a mapper, hands it a colour frame (held back -> retained -> let go of with a fence when the
+//                           next depth frame carries it out) and destroys the mapper at once, over and over; thread A acquires and releases frames of the same
+//                           size from a pool of two, so it keeps running into B's fences.  Nothing to compare: it must neither crash nor hang, and the pool
+//                           must come out consistent (every frame free at the end).
+static int threads(const std::vector<Fr>& fr, int rows, int cols, const Camera& camera) {
+  setenv("NVBX_FRAME_POOL_MAX", "2", 1);
+  (void)nvbx_frame_pool_trim(-1);
+  const size_t bytes = (size_t)rows * cols * 3;
+  std::atomic<bool> stop{false}; std::atomic<long> acquired{0}; std::atomic<int> errors{0};
+  std::thread a([&] {
+    (void)hipSetDevice(0);
+    while (!stop.load()) {
+      void* p = nullptr;
+      if (nvbx_frame_acquire(0, bytes, NVBX_STREAM_UNKNOWN, &p) != 0 || !p) { errors++; continue; }
+      acquired++;
+      if (nvbx_frame_release(p) != 0) errors++;
+    }
+  });
+  nvbx_mapper_params pp; nvbx_default_params(&pp);
+  const nvbx_camera cam = camera.c_abi();
+  int mappers = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<void*> dev_depth;
+  for (const auto& x : fr) { void* d = nullptr; (void)hipMalloc(&d, x.d.size() * 4); (void)hipMemcpy(d, x.d.data(), x.d.size() * 4, hipMemcpyHostToDevice); dev_depth.push_back(d); }
+  while (std::chrono::steady_clock::now() - t0 < std::chrono::seconds(4)) {
+    nvbx_mapper* m = nullptr;
+    if (nvbx_mapper_create(0, nullptr, &pp, 1 << 11, &m) != 0) { errors++; break; }
+    for (int i = 0; i < 3 && !errors; i++) {
+      const Fr& x = fr[(size_t)(mappers + i) % fr.size()];
+      if (nvbx_integrate_depth(m, (const float*)dev_depth[(size_t)(mappers + i) % fr.size()], rows, cols, x.T, &cam) != 0) errors++;
+      void* q = nullptr; void* st = nullptr; (void)nvbx_get_stream(m, &st);
+      if (nvbx_color_image_acquire(m, rows, cols, 3, &q) != 0) { errors++; break; }
+      if (nvbx_frame_upload(q, x.c.data(), bytes, st) != 0) errors++;
+      if (nvbx_integrate_color_owned(m, q, 3, rows, cols, x.T, &cam) != 0) errors++;       // held back: the mapper retains the frame
+    }
+    (void)nvbx_mapper_destroy(m);          // fences of this mapper die here, possibly under thread A's wait
+    mappers++;
+  }
+  stop = true; a.join();
+  for (void* d : dev_depth) (void)hipFree(d);
+  (void)hipDeviceSynchronize();
+  int64_t st[6]; nvbx_frame_pool_stats(st);
+  std::printf("{\"check\": \"threads\", \"mappers\": %d, \"acquired\": %ld, \"errors\": %d, \"held_at_end\": %lld, \"pool_waits\": %lld, \"pool_syncs\": %lld}\n", mappers, acquired.load(), errors.load(),
+              (long long)st[0], (long long)st[4], (long long)st[5]);
+  return (errors.load() == 0 && st[0] == 0 && mappers > 3 && acquired.load() > 100) ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) return 2;
   FILE* f = std::fopen(argv[2], "rb"); if (!f) return 2;
@@ -169,5 +220,6 @@ int main(int argc, char** argv) {
   const std::string what = argv[1];
   if (what == "lifetime") return lifetime(fr, rows, cols, camera);
   if (what == "cadence") return cadence(fr, rows, cols, camera);
+  if (what == "threads") return threads(fr, rows, cols, camera);
   return 2;
 }

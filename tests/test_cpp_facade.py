@@ -566,3 +566,17 @@ def test_block_index_exchange_under_the_node_call_cadence(hip_lib, tmp_path):
     r = subprocess.run([os.path.join(CPP, "round6_checks"), "cadence", str(path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert json.loads(r.stdout.strip().splitlines()[-1])["failures"] == 0, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_frame_pool_survives_a_mapper_destroyed_under_a_waiting_thread(hip_lib, tmp_path):
+    """tests/cpp/round6_checks.cpp threads: one thread acquires / releases frames from a pool of two and keeps running into the fences of
+    mappers that a second thread creates, feeds a held-back colour frame and destroys at once.  No crash, no hang, no error, every frame free at the end."""
+    subprocess.check_call(["make", "-C", CPP, "round6_checks"], stdout=subprocess.DEVNULL)
+    cam = H.SMALL_CAM
+    path = tmp_path / "frames.bin"
+    _write_frames_bin(path, H.frames(4, cam, color=True, stride=9), cam)
+    r = subprocess.run([os.path.join(CPP, "round6_checks"), "threads", str(path)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["errors"] == 0 and got["held_at_end"] == 0 and got["mappers"] > 3, got
