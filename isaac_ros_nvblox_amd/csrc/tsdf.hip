@@ -744,14 +744,15 @@ __global__ __launch_bounds__(Sensor::kThreads) NVBX_MARK_VIEW_ATTR void k_mark_v
   mark_view_body<Img, Sensor, NB>(m, fs, sensor, view_list, list_cap, reset_esdf_dirty, n_edt_wg, ea, tr, (int32_t)blockIdx.x, smem);
 }
 // Two mappers' view-marking launches in ONE grid (nvbx_integrate_depth_pair: the background and the foreground mapper of a MultiMapper's dynamic / human
-// mapping types take the same depth frame, split by a mask, one after the other -- four dependent launches of 6-8 us each for two small jobs).  Workgroups
-// [0, a.n_wg) run mapper a's body, the rest mapper b's, each numbered from its own 0; nothing is shared between the two maps.
+// mapping types take the same depth frame, split by a mask, one after the other -- four dependent launches of 6-8 us each for two small jobs).  A workgroup
+// runs mapper a's body or mapper b's, numbered from that mapper's own 0 (n_tiles tiles, then its riders; n_wg in all); nothing is shared between the two maps.
 template <typename Img> struct MarkViewArgs { DMap m; FrameSet<Img, 1> fs; int4* view_list; int32_t list_cap, reset_esdf_dirty, n_edt_wg; EsdfArgs ea; TraceRiderT<1> tr; int32_t n_tiles, n_wg; };
 template <typename Img>
 __global__ __launch_bounds__(CameraSensor::kThreads) void k_mark_view_pair(MarkViewArgs<Img> a, MarkViewArgs<Img> b) {
   extern __shared__ __align__(16) unsigned char smem[];
-  // dispatch order [a's tiles][b's tiles][a's riders][b's riders]: the tiles are each map's longest chain (~9 us) and start first; behind mapper a's ~900
-  // workgroups, mapper b's tiles started late and the launch took 11.6 us against the 9.5 of mapper a's alone.  Every segment is a multiple of 8 long.
+  // dispatch order [a's tiles][b's tiles][a's riders][b's riders]: the tiles are each map's longest chain (~9 us) and start first (measured against
+  // [all of a][all of b]: 11.4 against 11.6 us -- within the noise; kept because it is the order a single mapper's launch has).  Every segment is a
+  // multiple of 8 long.
   const int32_t g = (int32_t)blockIdx.x, at = a.n_tiles, bt = b.n_tiles, ar = a.n_wg - a.n_tiles;
   bool is_a; int32_t wg;
   if (g < at) { is_a = true; wg = g; }
