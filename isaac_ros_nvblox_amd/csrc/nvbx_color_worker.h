@@ -247,10 +247,12 @@ template <typename Pix, int NB>
 __device__ inline void color_integrate_list_worker(const DMap& m, const FrameSetC<Pix, NB>& fs, const float* synth, int32_t srows, int32_t scols, int32_t mesh_list,
                                                    const int4* cand, int32_t cnt_idx, int32_t wg, int32_t n_wg) {
   const int32_t cap = (int32_t)m.capacity;
+  const int32_t wg0 = wg;
+  wg = xcd_chunked(wg, n_wg);                               // runs of consecutive candidates (neighbouring blocks: one patch of the colour image) stay on one XCD's L2
   int4 rec = cand[min(wg, cap - 1)];                        // (speculative, beside the count)
   int32_t n = m.counters[cnt_idx];
   if (n > cap) n = cap;
-  if (wg == 0 && threadIdx.x == 0) __hip_atomic_store(&m.host_mirror[3], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // the next fused launch's grid hint
+  if (wg0 == 0 && threadIdx.x == 0) __hip_atomic_store(&m.host_mirror[3], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // the next fused launch's grid hint
   for (int32_t i = wg; i < n; i += n_wg) {
     if (i != wg) rec = cand[i];
     NVBX_INV_COUNT(m, C_INV_I3, threadIdx.x == 0 && (m.slot_index[3 * ((uint32_t)rec.x & 0xFFFFFFu)] != rec.y || m.slot_index[3 * ((uint32_t)rec.x & 0xFFFFFFu) + 1] != rec.z || m.slot_index[3 * ((uint32_t)rec.x & 0xFFFFFFu) + 2] != rec.w));

@@ -1087,7 +1087,10 @@ __device__ inline void integrate_tsdf_worker(const DMap& m, const FrameSet<Img, 
   // frame has ~300 blocks in view and about as many workgroups, so one record per wavefront is wanted -- 64 speculative 16-B records from
   // each of 8 x 1024 wavefronts were 8 MB of HBM traffic for 3.5 MB of work (PMC, profiles/r02z_pmc.json).  A lane the hint left out
   // fetches once the count is known (a dependent load, only when the view grew by more than the hint's margin).
-  int32_t mine = wgi + lane * n_wg;
+  // which records this workgroup takes: runs of consecutive records (neighbouring blocks: the same patch of the depth image) stay on one XCD's L2
+  // (xcd_chunked, nvbx_internal.h); the LiDAR work list is dealt out per shard already
+  const int32_t wgr = dense_list ? wgi : xcd_chunked(wgi, n_wg);
+  int32_t mine = wgr + lane * n_wg;
   int4 rec = (!dense_list && lane < spec_lanes && mine < list_cap) ? view_list[mine] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
   int32_t n = m.counters[C_VIEW_COUNT + (f0.frame_id & 3)];
   if (n > list_cap) n = list_cap;
@@ -1128,8 +1131,8 @@ __device__ inline void integrate_tsdf_worker(const DMap& m, const FrameSet<Img, 
   // LiDAR: the image geometry the four-tap gather needs per voxel lives in vector registers (see in_vgpr)
   Frame fl = f0; Img img0 = fs.img[0];
   if (Sensor::kLongRays && NB == 1) { fl.cols = in_vgpr(f0.cols); fl.rows = in_vgpr(f0.rows); img0.p = in_vgpr(fs.img[0].p); }
-  for (int32_t i0 = wgi; i0 < n; i0 += 64 * n_wg) {
-    if (i0 != wgi) {
+  for (int32_t i0 = wgr; i0 < n; i0 += 64 * n_wg) {
+    if (i0 != wgr) {
       mine = i0 + lane * n_wg;
       if (dense_list) rec = mine < n ? view_list[dense_at(mine)] : make_int4((int32_t)SLOT_NONE, 0, 0, 0);
       else {

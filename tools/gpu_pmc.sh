@@ -2,7 +2,7 @@
 # PMC pass for latency analysis: wave lifetime and wait split per kernel.  Usage: tools/gpu_pmc.sh TAG "COUNTERS..."
 TAG=${1:-pmcX}; shift
 R=$PWD; mkdir -p gpurun_out/$TAG; export TMPDIR=/tmp
-(cd /tmp && timeout 600 rocprofv3 --pmc $@ --output-format csv -d $R/gpurun_out/$TAG -o pmc -- python $R/bench.py ${BENCH_ARGS:---steps 30 --warmup 10 --no-cpu-baseline} > /dev/null 2> $R/gpurun_out/$TAG/err.txt); echo "rc=$?"
+(cd /tmp && timeout ${PMC_TIMEOUT:-600} rocprofv3 --pmc $@ --output-format csv -d $R/gpurun_out/$TAG -o pmc -- python $R/bench.py ${BENCH_ARGS:---steps 30 --warmup 10 --no-cpu-baseline} > /dev/null 2> $R/gpurun_out/$TAG/err.txt); echo "rc=$?"
 python - <<PY
 import csv, glob, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
