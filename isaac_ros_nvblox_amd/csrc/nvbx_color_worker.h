@@ -121,6 +121,7 @@ __device__ inline void color_integrate_worker(const DMap& m, const FrameSetC<Pix
   const int chunk = fs.chunk;
   const int lane_c = tid & 63;
   const int32_t cap = (int32_t)m.capacity;
+  wg = xcd_chunked(wg, n_color_wg);       // runs of consecutive slots -- allocated together: neighbours, one patch of the colour image -- stay on one XCD's L2 (nvbx_internal.h)
   int32_t base = wg * chunk;
   int32_t ls = min(base + lane_c, cap - 1);
   uint32_t lflags = lane_c < chunk ? m.slot_flags[ls] : 0u;
