@@ -109,3 +109,34 @@ int main(void) { printf("%zu\n", sizeof(nvbx_device_view)); return 0; }'''
         open(c, "w").write(src)
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         assert int(subprocess.check_output([exe]).decode()) == C.sizeof(_lib.DeviceView)
+
+
+def test_xcd_affine_record_numbering_is_a_bijection_with_runs_on_one_xcd(tmp_path):
+    """csrc/nvbx_numbering.h xcd_chunked (round 6): the function the TSDF-update / colour workers call to pick their record, compiled from the shipped
+    header with gcc.  For every grid size: every record taken exactly once; inside the permuted part, the C consecutive records of a run are taken by
+    workers with one `w & 7` (= one XCD, workgroups being dispatched round-robin) and the eight runs of a period by eight different ones; the tail that
+    does not fill a period keeps its numbers; run length 0 = identity."""
+    import ctypes
+    src = tmp_path / "num.c"
+    src.write_text('#include "nvbx_numbering.h"\nint32_t map_c(int32_t w, int32_t n, int32_t c) { return xcd_chunked_c(w, n, c); }\n'
+                   'int32_t map_default(int32_t w, int32_t n) { return xcd_chunked(w, n); }\nint32_t run_default(void) { return NVBX_XCD_CHUNK; }\n')
+    so = tmp_path / "num.so"
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-Wall", "-Werror", "-I", os.path.join(ROOT, "isaac_ros_nvblox_amd", "csrc"), str(src), "-o", str(so)])
+    lib = ctypes.CDLL(str(so))
+    run = lib.run_default()
+    assert run in (8, 16, 32)
+    for n in [0, 1, 7, 8, 63, 64, 65, 127, 128, 129, 255, 256, 300, 449, 450, 512, 1000, 1024, 2304]:
+        for c in [0, 4, 8, 16, 32]:
+            taken = [lib.map_c(w, n, c) for w in range(n)]
+            assert sorted(taken) == list(range(n)), (n, c)
+            if c == 0:
+                assert taken == list(range(n))
+                continue
+            period = 8 * c; full = (n // period) * period
+            assert taken[full:] == list(range(full, n)), (n, c)
+            owner = {rec: w & 7 for w, rec in enumerate(taken)}
+            for r0 in range(0, full, c):
+                assert len({owner[r] for r in range(r0, r0 + c)}) == 1, (n, c, r0)
+            for p0 in range(0, full, period):
+                assert {owner[p0 + k * c] for k in range(8)} == set(range(8)), (n, c, p0)
+        assert [lib.map_default(w, n) for w in range(n)] == [lib.map_c(w, n, run) for w in range(n)]
