@@ -917,7 +917,9 @@ def main_camera(args):
 
     cam = S.REPLICA_LIKE_CAM
     rows, cols = cam[5], cam[4]
-    scene = S.Scene()
+    # --scene hall: NOT the metric's configuration -- the same camera, trajectory and parameters in a 14 x 12 x 3 m hall, where the 8 m integration range
+    # is used: 3-4 x the blocks in view of SURVEY 8d's 6 x 5 x 3 m room (whose ~300 are the low end of SURVEY 8a's own estimate for a real room)
+    scene = S.Scene() if args.scene == "room" else S.Scene(room_min=(-7.0, -6.0, 0.0), room_max=(7.0, 6.0, 3.0))
     # distinct rendered frames, whatever --steps is: the whole 200-pose loop of SURVEY 8d for the metric's configuration (a block of K
     # steps integrates K CONSECUTIVE poses of it), 24 per camera for the 8-camera sweep
     nu = max(2, args.unique_frames)
@@ -1190,6 +1192,8 @@ def main_camera(args):
             del prof[k_]
     # the PMC table of THIS shape of the workload (the 4- and 8-camera lines carried one table): multicam = 4 cameras, multicam8 = 8; none for other counts
     pmc_key = ("multicam8" if ncam == 8 else "multicam" if ncam == 4 else "none") if multicam else ("camera_mesh" if args.with_mesh else "camera")
+    if args.scene != "room":
+        pmc_key = "none"          # (the committed PMC tables are the room's: no `traffic` for another scene)
     kern, ev_overhead_us, empty_pair_us = kernel_table(
         prof, counts, ms_revisit, n2, lambda k, cc: algorithmic_bytes(k, cc, rows, cols, n_cam=(ncam // launches_cam), trace_in_mark_view=fused_trace, fused=fused_colc), load_pmc(pmc_key),
         exclude_from_calibration=("k_mesh", "k_esdf_edt"))
@@ -1205,7 +1209,7 @@ def main_camera(args):
 
     # bytes the step moves that are NOT in SURVEY 8d's formulas (the staged form's copy of raw-pointer colour images): reported, never counted as algorithmic
     roofline["step"]["overhead_bytes"] = int(sum(overhead_bytes(k_, rows, cols, n_cam=(ncam // launches_cam)) * v_["launches_per_step"] for k_, v_ in kern.items()))
-    roofline["traffic_source"] = pmc_source(pmc_key)
+    roofline["traffic_source"] = pmc_source(pmc_key) if pmc_key != "none" else None
 
     cpu = None
     if not args.no_cpu_baseline:
@@ -1264,8 +1268,9 @@ def main_camera(args):
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("configs[3] on one GPU: %d cameras (45 deg yaw offsets) through one mapper, %s; " % (ncam, "one batched launch set per step" if (batch_ok and ncam in bd) else "sequential calls") if multicam else "configs[1]: ") +
-                               "synthetic Replica-like room (SURVEY 8d), 640x480 depth+colour, 0.05 m voxels, "
-                               "fuser.yaml params, TSDF+Color+ESDF every frame (mesh timed separately)",
+                               ("synthetic Replica-like room (SURVEY 8d)" if args.scene == "room" else "NOT the metric's scene -- a 14 x 12 x 3 m hall (--scene hall: 3-4 x the blocks in view), same camera and trajectory") +
+                               ", 640x480 depth+colour, 0.05 m voxels, fuser.yaml params, TSDF+Color+ESDF every frame (mesh timed separately)",
+                   "scene": args.scene,
                    "cameras_per_gpu": ncam, "parallelism": ("one camera per GPU, RCCL all-gather of per-voxel measurements, one fused map on every rank" if fuse else "one camera per GPU, RCCL all-gather of dirty block indices") if world > 1 else "single GPU",
                    "unique_frames": nu,
                    "mode": (("color_deferral, images in library-owned frames: a new mapper's default setting (nvbx_mapper_set_color_deferral(m, 2)) fed colour images that "
@@ -1340,6 +1345,7 @@ def main():
     ap.add_argument("--separate-front-end", action="store_true", help="decay workload: detect / remove-small-components / split as three entry points (A/B against nvbx_dynamic_depth_split)")
     ap.add_argument("--step-trace", type=int, default=0, help="decay workload: wait for every one of this many steps and report the slowest (diagnosis)")
     ap.add_argument("--cameras", type=int, default=4, help="multicam: cameras per step (1..8)")
+    ap.add_argument("--scene", default="room", choices=["room", "hall"], help="camera / multicam: room = SURVEY 8d's 6 x 5 x 3 m room (the metric's configuration); hall = 14 x 12 x 3 m, 3-4 x the blocks in view (a scaling check, not the metric)")
     ap.add_argument("--fusion", default="indices", choices=["indices", "measurements"],
                     help="N > 1 GPUs: indices = replicas + all-gather of dirty block indices (north-star wording, default); "
                          "measurements = all-gather of per-voxel measurements, ONE fused map on every rank (SURVEY 8e option B, exact)")
