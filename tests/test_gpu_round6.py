@@ -208,3 +208,36 @@ def test_depth_pair_in_randomised_call_sequences(oracle_mod, hip_lib, seed):
         assert n_pair > 20 and sa.counters()["capacity_overflow"] == 0
         for m_ in (sa, sb, da, db):
             m_.close()
+
+
+def test_a_view_of_two_thousand_blocks_takes_the_pipeline_like_the_room(oracle_mod, hip_lib):
+    """bench.py --scene hall: the metric's camera and trajectory in a 14 x 12 x 3 m hall -- ~2 400 blocks in view and ~1 200 colour candidates per frame, more
+    than the fused launch has workgroups for (its TSDF and colour parts grid-stride, the records taken in runs per XCD with an unpermuted tail), pools that grow twice
+    on the way (4 096 -> 16 384 blocks) with work held back.  Eight frames of depth + colour + updateEsdf on a default mapper (two launches per frame) and on one in
+    classic order: the same map bit for bit, and the checker's."""
+    from isaac_ros_nvblox_amd import mapper as M
+    from test_gpu_parity import compare_layer, TOL
+    from test_gpu_sequences import check_all
+    cam = S.REPLICA_LIKE_CAM
+    hall = S.Scene(room_min=(-7.0, -6.0, 0.0), room_max=(7.0, 6.0, 3.0))
+    pg = M.default_params(); po = H.copy_params(pg, oracle_mod.OrcParams)
+    piped = M.Mapper(pg, block_capacity=1 << 12); classic = M.Mapper(pg, block_capacity=1 << 12); o = oracle_mod.OracleMap(po)
+    classic.set_color_deferral(False)
+    n_view = []
+    for i in range(8):
+        T = S.trajectory_pose(i * 9, 200)
+        d, rgb = S.render(hall, T, cam)
+        for m_ in (classic, piped, o):
+            m_.integrate_depth(d, T, cam); m_.integrate_color(rgb, T, cam); m_.update_esdf()
+        n_view.append(len(np.asarray(o.last_view()).reshape(-1, 3)))
+        assert H.idx_set(piped.last_view()) == H.idx_set(o.last_view())
+    assert min(n_view) > 1500, n_view
+    for layer, fields in ((M.LAYER_TSDF, ("distance", "weight")), (M.LAYER_COLOR, ("r", "g", "b", "weight"))):
+        ia = classic.block_indices(layer); ib = piped.block_indices(layer)
+        assert np.array_equal(ia, ib)
+        ba, _ = classic.get_blocks(layer, ia); bb, _ = piped.get_blocks(layer, ia)
+        for f in fields:
+            assert np.array_equal(ba[f], bb[f]), (layer, f)
+    piped.update_color_mesh(full=True); o.update_mesh(full=True)
+    n_tri = check_all(M, oracle_mod, piped, o)
+    assert n_tri > 50000 and piped.counters()["capacity_overflow"] == 0 and piped.capacity >= 1 << 13
