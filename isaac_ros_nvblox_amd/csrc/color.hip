@@ -248,11 +248,22 @@ int nvbx_mapper::pending_color_trace_rider(void* out) {
 }
 // Fused colour + TSDF launch (tsdf.hip): the held-back frame's ESDF marking pass rides in the view-marking launch of the next depth frame
 // (color_launch_integrate's own part, decided before that launch) ...
-void nvbx_mapper::pending_marking_args(int32_t* mark_wg, EsdfArgs* ea_out) {
+void nvbx_mapper::pending_marking_args(int32_t* mark_wg, EsdfArgs* ea_out, bool single_frame) {
   *mark_wg = 0;
   EsdfArgs ea = make_esdf_args();
   const bool own = dirty_since_mark && !premark_consumed && ea.bz_hi >= ea.bz_lo && ea.bz_hi - ea.bz_lo + 1 <= 63;     // (2-D exact transform: checked by the caller)
-  if (own) { mark_pass++; ea.mark_pass = mark_pass; unresolved_marks = true; *mark_wg = 256; dirty_since_mark = false; premark_consumed = !ea.self_reset; }
+  if (own) {
+    mark_pass++; ea.mark_pass = mark_pass; unresolved_marks = true; dirty_since_mark = false; premark_consumed = !ea.self_reset;
+    // one wavefront per dirty TSDF block, four per riding workgroup: 256 workgroups cover the ~300 blocks a room-sized view dirties per frame in one round; a
+    // larger view (the dirty list is what the last TSDF updates had in view: the count the GPU last mirrored) gets as many as give every entry a wavefront of
+    // its own, up to 1 024 -- with 256, the 2 400 entries of a 14 x 12 m hall were 2-3 dependent entries per wavefront and the marking riders the
+    // longest part of the view-marking launch (18.6 us against the tiles' 16.1; tools/wg_timeline.py --scene hall: k_mark_view 17.7 -> 16.6 us, tools/mark_riders_ab.sh).
+    // A BATCH keeps 256: its view-marking launch is residency-bound and more riders in front keep the tiles waiting (8 cameras: 27.0 -> 27.9 us).
+    // NVBX_MARK_RIDERS=n: fixed (A/B).
+    static const int fixed = getenv("NVBX_MARK_RIDERS") ? atoi(getenv("NVBX_MARK_RIDERS")) : 0;
+    const int64_t n_hint = std::max<int64_t>(0, __atomic_load_n(&h_mirror[2], __ATOMIC_RELAXED));
+    *mark_wg = fixed > 0 ? (fixed + 7) / 8 * 8 : (!single_frame ? 256 : (int32_t)std::min<int64_t>(1024, std::max<int64_t>(256, ((n_hint + n_hint / 4 + 3) / 4 + 7) / 8 * 8)));
+  }
   *ea_out = ea;
 }
 // ... and its colour integration shares a launch with that frame's TSDF update: frames and scratch as for the separate launch
@@ -280,7 +291,7 @@ static int replay_pair_t(nvbx_mapper* m, const nvbx_mapper::ColorPending& c) {
   FrameSetC<Pix, NB> fs; PoseSet<NB> ps; int32_t srows = 0, scols = 0;
   { const int rc = pending_setup<Pix, NB>(m, c, &fs, &ps, &srows, &scols); if (rc) return rc; }
   int32_t mark_wg = 0; EsdfArgs ea{};
-  m->pending_marking_args(&mark_wg, &ea);        // (classic flags: the distance transform below empties the list)
+  m->pending_marking_args(&mark_wg, &ea, NB == 1);        // (classic flags: the distance transform below empties the list)
   { const int rc = color_launch_trace<NB>(m, ps, c.n, srows, scols, mark_wg, ea); if (rc) return rc; }
   { const int rc = nvbx_update_esdf(m); if (rc) return rc; }      // arms the distance transform (launches the marking pass itself if it could not ride)
   return color_launch_integrate<Pix, NB>(m, fs, srows, scols, true);

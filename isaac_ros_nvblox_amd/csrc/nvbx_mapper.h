@@ -204,7 +204,7 @@ struct nvbx_mapper {
   int ensure_fuse_buffers();         // tsdf.hip
   // color.hip: the marking pass that rides in the view-marking launch (0 workgroups: none), and the held-back colour frame's set-up for the
   // fused launch (FrameSetC<Pix, 1>: rgb8 / bgra8 share one layout; FrameSetC<PixRgb8, MAX_BATCH> for a held-back batch)
-  void pending_marking_args(int32_t* mark_wg, nvbx::EsdfArgs* ea_out);
+  void pending_marking_args(int32_t* mark_wg, nvbx::EsdfArgs* ea_out, bool single_frame);
   int pending_color_fused_args(void* fsc_out, int* kind, int32_t* srows, int32_t* scols);
   uint8_t* view_class = nullptr; int64_t view_class_cap = 0;        // LiDAR: per view record, 1 = updated by the beam-centric launch (tsdf.hip k_lidar_sparse)
   // LiDAR view calculation over a dense grid (tsdf.hip k_mark_view_grid): one byte per block of the box around the sensor (cell-major, 64 B per

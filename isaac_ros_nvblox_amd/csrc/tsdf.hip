@@ -1660,7 +1660,7 @@ static int depth_step_before_mark_view(nvbx_mapper* m, FrameSet<Img, NB>& fs, De
     static const int tiles_first_env = getenv("NVBX_MARK_TILES_FIRST") ? atoi(getenv("NVBX_MARK_TILES_FIRST")) : -1;
     const bool tiles_first = tiles_first_env >= 0 ? tiles_first_env != 0 : NB == 1;
     if (tiles_first) st.tr.n_tile_wg = st.tiles;
-    if (st.fused && !st.has_color) m->pending_marking_args(&st.tr.n_mark_wg, &st.ea);
+    if (st.fused && !st.has_color) m->pending_marking_args(&st.tr.n_mark_wg, &st.ea, NB == 1);
     if (st.fused && st.has_color) {
       if (m->ensure_fuse_buffers()) { m->pipelined_order = false; return NVBX_E_DEVICE; }
       const int64_t hw_seen = std::max<int64_t>(1, __atomic_load_n(&m->h_mirror[1], __ATOMIC_RELAXED));
@@ -1668,7 +1668,7 @@ static int depth_step_before_mark_view(nvbx_mapper* m, FrameSet<Img, NB>& fs, De
       st.tr.cand = m->color_cand + (size_t)m->cand_parity * m->fuse_cap;
       st.tr.cand_cnt_idx = C_CAND_COUNT + m->cand_parity; st.tr.cand_reset_idx = C_CAND_COUNT + (1 - m->cand_parity);
       m->cand_parity ^= 1;      // (the next fused launch resets THIS count, whether or not the colour launch below is reached: an error return in between leaves no stale candidates behind)
-      m->pending_marking_args(&st.tr.n_mark_wg, &st.ea);        // (the held-back integrateColor's marking pass, in call order: before its colour integration below)
+      m->pending_marking_args(&st.tr.n_mark_wg, &st.ea, NB == 1);        // (the held-back integrateColor's marking pass, in call order: before its colour integration below)
     }
   }
   st.tr.fence_report = m->next_fence_report();

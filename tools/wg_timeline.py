@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--samples", type=int, default=30)
     ap.add_argument("--frames", type=int, default=48)
     ap.add_argument("--classic", action="store_true", help="classic launch order: the view-marking launch carries the tiles and the held-back distance transform only")
+    ap.add_argument("--scene", default="room", choices=["room", "hall"], help="hall: bench.py --scene hall (14 x 12 x 3 m, ~2 400 blocks in view)")
     ap.add_argument("--tiles", type=int, default=88, help="tile workgroups of the view-marking launch (640x480, factor 4: 11 x 8 groups of 2 x 2 tiles)")
     args = ap.parse_args()
     import torch
@@ -31,7 +32,7 @@ def main():
     assert max_wg > 0
     cam = S.REPLICA_LIKE_CAM
     dev = torch.device("cuda", 0)
-    sc = S.Scene()
+    sc = S.Scene() if args.scene == "room" else S.Scene(room_min=(-7.0, -6.0, 0.0), room_max=(7.0, 6.0, 3.0))
     from concurrent.futures import ThreadPoolExecutor
     def one(i):
         T = S.trajectory_pose(i * (200 // args.frames), 200)
@@ -40,7 +41,7 @@ def main():
     with ThreadPoolExecutor(16) as pool:
         fr = list(pool.map(one, range(args.frames)))
     stream = torch.cuda.Stream(dev); torch.cuda.set_stream(stream)
-    g = M.Mapper(M.default_params(), device=0, block_capacity=1 << 14, stream=stream.cuda_stream)
+    g = M.Mapper(M.default_params(), device=0, block_capacity=(1 << 14) if args.scene == "room" else (1 << 15), stream=stream.cuda_stream)
     g.set_color_deferral(not args.classic)
     da = [g.prepare_depth(torch.from_numpy(d).to(dev), T, cam) for d, _, T in fr]
     ca = [g.prepare_color(torch.from_numpy(c).to(dev), T, cam) for _, c, T in fr]
