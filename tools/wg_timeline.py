@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--samples", type=int, default=30)
     ap.add_argument("--frames", type=int, default=48)
     ap.add_argument("--classic", action="store_true", help="classic launch order: the view-marking launch carries the tiles and the held-back distance transform only")
+    ap.add_argument("--window-us", type=float, default=12.0, help="a workgroup belongs to the last launch if it started within this many us of the launch's last start (the hall's launches run 17-25 us: 22)")
     ap.add_argument("--scene", default="room", choices=["room", "hall"], help="hall: bench.py --scene hall (14 x 12 x 3 m, ~2 400 blocks in view)")
     ap.add_argument("--tiles", type=int, default=88, help="tile workgroups of the view-marking launch (640x480, factor 4: 11 x 8 groups of 2 x 2 tiles)")
     args = ap.parse_args()
@@ -61,7 +62,7 @@ def main():
             used = b[:, 0] > 0
             if used.sum() == 0:
                 continue
-            used &= b[:, 0] > b[:, 0].max() - 1200               # the LAST launch only (grids differ from frame to frame: higher workgroups keep older stamps)
+            used &= b[:, 0] > b[:, 0].max() - int(args.window_us * 100)               # the LAST launch only (grids differ from frame to frame: higher workgroups keep older stamps)
             t0 = b[used, 0].min()
             rel = np.where((b > 0) & used[:, None], (b - t0) / 100.0, np.nan)        # us
             rel[:, 6] = np.where(used, np.where(b[:, 6] > 10 ** 9, (b[:, 6] - t0) / 100.0, b[:, 6]), np.nan)          # slot 6 carries a count (or, in an experiment build, a time)
