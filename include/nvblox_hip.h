@@ -192,7 +192,7 @@ int nvbx_mapper_destroy(nvbx_mapper* m);
  * on the device; the call synchronises once) up to max_block_capacity (default 2^22, NVBX_MAX_BLOCKS in the environment; at most 2^24).
  * max_block_capacity <= the current capacity: fixed pools -- an allocation beyond them is dropped and reported through
  * nvbx_counters::capacity_overflow, never fatal.  Device pointers handed out by nvbx_get_device_view are valid until the next call
- * that can allocate.  nvbx_mapper_capacity = the current capacity. */
+ * that can allocate, or that decays the map (the hash table of the surviving blocks is built in a second buffer: nvblox_hip_device.h).  nvbx_mapper_capacity = the current capacity. */
 int nvbx_mapper_set_max_capacity(nvbx_mapper* m, int64_t max_block_capacity);
 int64_t nvbx_mapper_capacity(nvbx_mapper* m);
 /* the offline fuser's parameter values (nvblox_examples_bringup/config/nvblox/fuser.yaml:24-42; decay / workspace values from

@@ -7,9 +7,9 @@
  *
  * Contract: fill an nvbx_device_view with nvbx_get_device_view() (include/nvblox_hip.h) and pass it BY VALUE to a kernel
  * launched on the mapper's stream (or ordered behind it with an event).  The view's pointers are valid until the next
- * call that can allocate blocks (the pools and the table grow on demand, nvbx_mapper_set_max_capacity in nvblox_hip.h;
- * with fixed pools -- max_block_capacity <= capacity -- for the mapper's lifetime): fetch the view again after an integrate /
- * upload call, it costs nothing.  What a kernel reads through it is whatever the mapper calls enqueued before the kernel have
+ * call that can allocate blocks (the pools and the table grow on demand, nvbx_mapper_set_max_capacity in nvblox_hip.h) or
+ * that decays the map (nvbx_decay_tsdf / nvbx_decay_occupancy build the table of the surviving blocks in a second buffer
+ * and the two change places): fetch the view again after an integrate / upload / decay call, it costs nothing.  What a kernel reads through it is whatever the mapper calls enqueued before the kernel have
  * produced.  Read-only: writing through the view breaks the library's invariants.
  * Layouts: TSDF / colour voxel v = z + 8y + 64x in the block (the reference's order); ESDF voxel
  * v = x + 8y + 64z, packed {f32 squared_distance_vox, u32 meta}. */

@@ -1,8 +1,11 @@
 // maintenance.hip -- Mapper::decayTsdf / clearOutsideRadius on MI355X (device-side deallocation + hash rebuild).
 //
 // Deallocation never leaves tombstones: freed slots go back on the free stack (their 4 KiB blocks are zeroed by the
-// freeing workgroup, so a popped slot is always clean) and the hash table is rebuilt on the device from the live slots
-// (memset + one insert per live slot).  Call sites served: nvblox_ros/src/lib/nvblox_node.cpp:931-936 (decayTsdf...),
+// freeing workgroup, so a popped slot is always clean) and the hash table is rebuilt on the device from the live slots --
+// radius clearing: stamps saved, memset, one insert per live slot, the ESDF layer's AABB recomputed (three launches);
+// decay (round 6): k_decay itself enters every slot it leaves live into a second, all-empty table and the two change
+// places behind the launch (tombstones instead were measured: the workload frees and re-allocates the same blocks, the
+// probe chains grow -- EXPERIMENTS.md).  Call sites served: nvblox_ros/src/lib/nvblox_node.cpp:931-936 (decayTsdf...),
 // :1566-1583 (clearOutsideRadius); parameters nvblox_base.yaml:103-107.
 #include <algorithm>
 #include <cstring>
@@ -48,7 +51,7 @@ __device__ inline void wave_list_append(const DMap& m, int32_t list, bool push, 
 // while any value != 0) -- [U] OccupancyDecayIntegrator, Mapper::decayOccupancyAllVoxels (nvblox_node.cpp:925-929).
 template <bool OCC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, uint32_t exclude_mask, int32_t mesh_list,
-                                               int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc, int32_t* cleared_idx, int32_t keep_blocks, int32_t to_free, float free_dist) {
+                                               int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc, int32_t* cleared_idx, int32_t keep_blocks, int32_t to_free, float free_dist, Entry* next_table) {
   // [U] decay switches (mapper_initialization.cpp:383-428; restated line by line in the CPU checker): keep_blocks =
   // !decay_integrator_deallocate_decayed_blocks (a fully decayed block stays allocated); to_free = tsdf_set_free_distance_on_decayed (an
   // OBSERVED voxel whose weight falls below the threshold becomes free: distance free_dist, weight = the threshold) resp.
@@ -157,6 +160,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
           const int32_t p = base + (int32_t)__popcll(cm & ((1ull << lane) - 1ull));
           if (p < (int32_t)m.capacity) { cleared_idx[3 * p] = m.slot_index[3 * slot]; cleared_idx[3 * p + 1] = m.slot_index[3 * slot + 1]; cleared_idx[3 * p + 2] = m.slot_index[3 * slot + 2]; }
         }
+      }
+    }
+    // ---- the table of the map as this launch leaves it (round 6): the lane that keeps a slot's books also enters the slot -- if it is still live -- into the
+    // SPARE table (all-empty, same size), with the view stamp of its old entry; the host swaps the two tables behind the launch.  The rebuild that
+    // used to follow every decay call (k_save_stamps, a 2 MB memset, k_reinsert: three launches, ~19 us for a room-sized map) is this and ONE memset of the table
+    // that has become the spare.  Lookups of this launch (any_slot above) read the OLD table, which nobody writes here.  What is live afterwards: a slot this
+    // lane has just freed of its projective layers stays only if it carries the ESDF layer; every other slot as its flags said (no other lane changes layer bits).
+    if (next_table && mine < hw) {
+      const uint32_t layers_after = (act && !my_alive) ? (fl & (F_ESDF | F_ESDF_PENDING)) : (fl & LAYER_MASK);
+      if (layers_after) {
+        const int32_t x = m.slot_index[3 * slot], y = m.slot_index[3 * slot + 1], z = m.slot_index[3 * slot + 2];
+        const uint32_t stamp = m.table[m.slot_entry[slot]].stamp;
+        const u64 key = pack_key(x, y, z);
+        uint32_t h = table_pos(m, x, y, z);
+        for (;;) {
+          const u64 k = atomicCAS(&next_table[h].key, KEY_EMPTY, key);
+          if (k == KEY_EMPTY) break;
+          h = (h + 1) & m.mask;
+        }
+        next_table[h].slot = (uint32_t)slot; next_table[h].stamp = stamp;
+        m.slot_entry[slot] = h;
       }
     }
   }
@@ -301,6 +325,28 @@ __global__ void k_reinsert(DMap m, const uint32_t* tmp, int32_t bz_out) {
   }
 }
 
+#ifndef NVBX_DECAY_INLINE_REBUILD
+#define NVBX_DECAY_INLINE_REBUILD 1       // (A/B: 0 = the three-launch rebuild behind every decay call, as up to round 5)
+#endif
+// the spare table k_decay builds the next table in: all-empty, as large as the live one (allocated at the first decay, again after a growth)
+static int ensure_spare_table(nvbx_mapper* m) {
+  if (m->table_spare && m->table_spare_mask == m->d.mask) return NVBX_OK;
+  NVBX_HIP(hipStreamSynchronize(m->stream));
+  if (m->table_spare) NVBX_HIP(hipFree(m->table_spare));
+  m->table_spare = nullptr; m->table_spare_mask = 0;
+  NVBX_HIP(hipMalloc(&m->table_spare, ((size_t)m->d.mask + 1) * sizeof(Entry)));
+  m->table_spare_mask = m->d.mask;
+  NVBX_HIP(hipMemsetAsync(m->table_spare, 0xFF, ((size_t)m->d.mask + 1) * sizeof(Entry), m->stream));
+  return NVBX_OK;
+}
+// behind a k_decay launch that filled the spare table: the tables change places, the old one is emptied for the next call
+static int swap_tables(nvbx_mapper* m) {
+  Entry* old = m->d.table;
+  m->d.table = static_cast<Entry*>(m->table_spare); m->table_spare = old;
+  NVBX_HIP(hipMemsetAsync(old, 0xFF, ((size_t)m->d.mask + 1) * sizeof(Entry), m->stream));
+  NVBX_HIP(hipGetLastError());
+  return NVBX_OK;
+}
 static int rebuild_table(nvbx_mapper* m) {
   uint32_t* tmp = (uint32_t*)m->export_idx;   // capacity * 12 bytes scratch >= capacity * 4
   const unsigned rg = (unsigned)std::min<int64_t>((m->capacity + 255) / 256, 2048);       // one thread per slot up to 512 k slots
@@ -322,10 +368,13 @@ extern "C" int nvbx_decay_occupancy(nvbx_mapper* m) {
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
   else if (ea.plane_on) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; }      // ground-plane mode: the band's blocks vary with (x, y) -- a deallocated block of ANY height has its column re-marked
   const int64_t hw_seen = std::max<int64_t>(1, __atomic_load_n(&m->h_mirror[1], __ATOMIC_RELAXED));       // (a hint: the kernel grid-strides)
+  const bool inline_rebuild = NVBX_DECAY_INLINE_REBUILD != 0;
+  if (inline_rebuild && ensure_spare_table(m)) return NVBX_E_DEVICE;
   NVBX_LAUNCH(m, k_decay<true>, dim3((unsigned)std::min<int64_t>(std::min<int64_t>(m->capacity, 4096), std::max<int64_t>(512, (hw_seen + 7) / 8))), dim3(512), m->d,
               log_odds(m->p.free_region_decay_probability), log_odds(m->p.occupied_region_decay_probability), 0u, 0u, (int32_t)m->mesh_list_live(),
-              ea.bz_lo, ea.bz_hi, ea.bz_out, 0.0f, m->cleared_idx, (int32_t)(m->p.decay_deallocate_decayed_blocks ? 0 : 1), (int32_t)(m->p.occupancy_decay_to_free ? 1 : 0), 0.0f);
-  return rebuild_table(m);
+              ea.bz_lo, ea.bz_hi, ea.bz_out, 0.0f, m->cleared_idx, (int32_t)(m->p.decay_deallocate_decayed_blocks ? 0 : 1), (int32_t)(m->p.occupancy_decay_to_free ? 1 : 0), 0.0f,
+              inline_rebuild ? static_cast<Entry*>(m->table_spare) : nullptr);
+  return inline_rebuild ? swap_tables(m) : rebuild_table(m);
 }
 
 extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
@@ -342,11 +391,14 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   EsdfArgs ea = m->make_esdf_args();
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
   else if (ea.plane_on) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; }      // ground-plane mode: the band's blocks vary with (x, y) -- a deallocated block of ANY height has its column re-marked
+  const bool inline_rebuild = NVBX_DECAY_INLINE_REBUILD != 0;
+  if (inline_rebuild && ensure_spare_table(m)) return NVBX_E_DEVICE;
   NVBX_LAUNCH(m, k_decay<false>, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
                      exclude_last_view ? m->last_camera_view_frame : 0u, m->last_camera_view_mask, m->mesh_list_live(), ea.bz_lo, ea.bz_hi, ea.bz_out,
                      m->p.truncation_distance_vox * m->p.voxel_size, m->cleared_idx, (int32_t)(m->p.decay_deallocate_decayed_blocks ? 0 : 1),
-                     (int32_t)(m->p.tsdf_set_free_distance_on_decayed ? 1 : 0), m->p.tsdf_decayed_free_distance_vox * m->p.voxel_size);
-  return rebuild_table(m);
+                     (int32_t)(m->p.tsdf_set_free_distance_on_decayed ? 1 : 0), m->p.tsdf_decayed_free_distance_vox * m->p.voxel_size,
+                     inline_rebuild ? static_cast<Entry*>(m->table_spare) : nullptr);
+  return inline_rebuild ? swap_tables(m) : rebuild_table(m);
 }
 
 extern "C" int nvbx_clear_outside_radius(nvbx_mapper* m, const float center[3], float radius) {
