@@ -3,8 +3,8 @@
 // Deallocation never leaves tombstones: freed slots go back on the free stack (their 4 KiB blocks are zeroed by the
 // freeing workgroup, so a popped slot is always clean) and the hash table is rebuilt on the device from the live slots --
 // radius clearing: stamps saved, memset, one insert per live slot, the ESDF layer's AABB recomputed (three launches);
-// decay (round 6): k_decay itself enters every slot it leaves live into a second, all-empty table and the two change
-// places behind the launch (tombstones instead were measured: the workload frees and re-allocates the same blocks, the
+// decay (round 6): k_decay itself enters every slot it leaves live into an all-empty table that becomes the live one behind
+// the launch, and empties the table of the call before for the call after (three tables rotate: no launch follows a decay) (tombstones instead were measured: the workload frees and re-allocates the same blocks, the
 // probe chains grow -- EXPERIMENTS.md).  Call sites served: nvblox_ros/src/lib/nvblox_node.cpp:931-936 (decayTsdf...),
 // :1566-1583 (clearOutsideRadius); parameters nvblox_base.yaml:103-107.
 #include <algorithm>
@@ -51,14 +51,24 @@ __device__ inline void wave_list_append(const DMap& m, int32_t list, bool push, 
 // while any value != 0) -- [U] OccupancyDecayIntegrator, Mapper::decayOccupancyAllVoxels (nvblox_node.cpp:925-929).
 template <bool OCC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_decay(DMap m, float factor, float thresh, uint32_t exclude_stamp, uint32_t exclude_mask, int32_t mesh_list,
-                                               int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc, int32_t* cleared_idx, int32_t keep_blocks, int32_t to_free, float free_dist, Entry* next_table) {
+                                               int32_t bz_lo, int32_t bz_hi, int32_t bz_out, float trunc, int32_t* cleared_idx, int32_t keep_blocks, int32_t to_free, float free_dist, Entry* next_table,
+                                               Entry* clear_table, int32_t n_clear_wg) {
   // [U] decay switches (mapper_initialization.cpp:383-428; restated line by line in the CPU checker): keep_blocks =
   // !decay_integrator_deallocate_decayed_blocks (a fully decayed block stays allocated); to_free = tsdf_set_free_distance_on_decayed (an
   // OBSERVED voxel whose weight falls below the threshold becomes free: distance free_dist, weight = the threshold) resp.
   // occupancy_decay_to_free (occupied voxels decay past unknown into free and stay there; free voxels are not decayed)
-  const int32_t hw = m.counters[C_HIGH_WATER];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int32_t stride = (int32_t)gridDim.x * 8;                       // wavefronts in the grid: wavefront g takes slots g, g + stride, ...
+  // the last n_clear_wg workgroups empty the table that was live BEFORE the previous decay call (three tables rotate: live, next, and the one being emptied
+  // here for the call after this one): no memset launch behind a decay call
+  const int32_t n_decay_wg = (int32_t)gridDim.x - n_clear_wg;
+  if ((int32_t)blockIdx.x >= n_decay_wg) {
+    uint4* t = reinterpret_cast<uint4*>(clear_table);
+    const uint4 ff = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    for (uint32_t i = ((uint32_t)blockIdx.x - (uint32_t)n_decay_wg) * 512u + (uint32_t)tid; i <= m.mask; i += (uint32_t)n_clear_wg * 512u) t[i] = ff;
+    return;
+  }
+  const int32_t hw = m.counters[C_HIGH_WATER];
+  const int32_t stride = n_decay_wg * 8;                               // wavefronts of the decay part: wavefront g takes slots g, g + stride, ...
   for (int32_t s0 = (int32_t)blockIdx.x * 8 + (tid >> 6); s0 < hw; s0 += 64 * stride) {
     // ---- lane j: flags (and exclusion) of this round's j-th block
     const int32_t mine = s0 + lane * stride;
@@ -164,8 +174,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     // ---- the table of the map as this launch leaves it (round 6): the lane that keeps a slot's books also enters the slot -- if it is still live -- into the
     // SPARE table (all-empty, same size), with the view stamp of its old entry; the host swaps the two tables behind the launch.  The rebuild that
-    // used to follow every decay call (k_save_stamps, a 2 MB memset, k_reinsert: three launches, ~19 us for a room-sized map) is this and ONE memset of the table
-    // that has become the spare.  Lookups of this launch (any_slot above) read the OLD table, which nobody writes here.  What is live afterwards: a slot this
+    // used to follow every decay call (k_save_stamps, a 2 MB memset, k_reinsert: three launches, ~19 us for a room-sized map) is this -- and the riders at the top of
+    // the kernel, which empty the table for the call after this one.  Lookups of this launch (any_slot above) read the OLD table, which nobody writes here.  What is live afterwards: a slot this
     // lane has just freed of its projective layers stays only if it carries the ESDF layer; every other slot as its flags said (no other lane changes layer bits).
     if (next_table && mine < hw) {
       const uint32_t layers_after = (act && !my_alive) ? (fl & (F_ESDF | F_ESDF_PENDING)) : (fl & LAYER_MASK);
@@ -328,22 +338,30 @@ __global__ void k_reinsert(DMap m, const uint32_t* tmp, int32_t bz_out) {
 #ifndef NVBX_DECAY_INLINE_REBUILD
 #define NVBX_DECAY_INLINE_REBUILD 1       // (A/B: 0 = the three-launch rebuild behind every decay call, as up to round 5)
 #endif
-// the spare table k_decay builds the next table in: all-empty, as large as the live one (allocated at the first decay, again after a growth)
-static int ensure_spare_table(nvbx_mapper* m) {
-  if (m->table_spare && m->table_spare_mask == m->d.mask) return NVBX_OK;
-  NVBX_HIP(hipStreamSynchronize(m->stream));
-  if (m->table_spare) NVBX_HIP(hipFree(m->table_spare));
-  m->table_spare = nullptr; m->table_spare_mask = 0;
-  NVBX_HIP(hipMalloc(&m->table_spare, ((size_t)m->d.mask + 1) * sizeof(Entry)));
-  m->table_spare_mask = m->d.mask;
-  NVBX_HIP(hipMemsetAsync(m->table_spare, 0xFF, ((size_t)m->d.mask + 1) * sizeof(Entry), m->stream));
+// Three hash tables of one size rotate through a mapper that decays: LIVE (DMap::table), NEXT (all-empty: k_decay enters the surviving slots) and DIRTY (the table
+// that was live before the previous call: emptied by riders of this call's k_decay, the next call's NEXT).  Allocated at the first two decay calls, again after a
+// growth.  *clear_out = nullptr: nothing to empty in this launch (first call).
+static int prepare_tables(nvbx_mapper* m, Entry** next_out, Entry** clear_out) {
+  const size_t bytes = ((size_t)m->d.mask + 1) * sizeof(Entry);
+  if (m->table_mask_extra != m->d.mask) {               // first decay, or the table has grown
+    NVBX_HIP(hipStreamSynchronize(m->stream));
+    if (m->table_spare) NVBX_HIP(hipFree(m->table_spare));
+    if (m->table_dirty) NVBX_HIP(hipFree(m->table_dirty));
+    m->table_spare = nullptr; m->table_dirty = nullptr; m->table_mask_extra = m->d.mask;
+  }
+  if (!m->table_spare) {
+    NVBX_HIP(hipMalloc(&m->table_spare, bytes));
+    NVBX_HIP(hipMemsetAsync(m->table_spare, 0xFF, bytes, m->stream));
+  }
+  *next_out = static_cast<Entry*>(m->table_spare); *clear_out = static_cast<Entry*>(m->table_dirty);
   return NVBX_OK;
 }
-// behind a k_decay launch that filled the spare table: the tables change places, the old one is emptied for the next call
-static int swap_tables(nvbx_mapper* m) {
-  Entry* old = m->d.table;
-  m->d.table = static_cast<Entry*>(m->table_spare); m->table_spare = old;
-  NVBX_HIP(hipMemsetAsync(old, 0xFF, ((size_t)m->d.mask + 1) * sizeof(Entry), m->stream));
+// behind the k_decay launch: NEXT becomes live, the table emptied by the launch's riders becomes the next call's NEXT, the old live table waits to be emptied
+static int rotate_tables(nvbx_mapper* m) {
+  Entry* old_live = m->d.table;
+  m->d.table = static_cast<Entry*>(m->table_spare);
+  m->table_spare = m->table_dirty;          // (emptied by this launch; nullptr after the first call: prepare_tables allocates a second one)
+  m->table_dirty = old_live;
   NVBX_HIP(hipGetLastError());
   return NVBX_OK;
 }
@@ -369,12 +387,14 @@ extern "C" int nvbx_decay_occupancy(nvbx_mapper* m) {
   else if (ea.plane_on) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; }      // ground-plane mode: the band's blocks vary with (x, y) -- a deallocated block of ANY height has its column re-marked
   const int64_t hw_seen = std::max<int64_t>(1, __atomic_load_n(&m->h_mirror[1], __ATOMIC_RELAXED));       // (a hint: the kernel grid-strides)
   const bool inline_rebuild = NVBX_DECAY_INLINE_REBUILD != 0;
-  if (inline_rebuild && ensure_spare_table(m)) return NVBX_E_DEVICE;
-  NVBX_LAUNCH(m, k_decay<true>, dim3((unsigned)std::min<int64_t>(std::min<int64_t>(m->capacity, 4096), std::max<int64_t>(512, (hw_seen + 7) / 8))), dim3(512), m->d,
+  Entry* next_table = nullptr; Entry* clear_table = nullptr;
+  if (inline_rebuild && prepare_tables(m, &next_table, &clear_table)) return NVBX_E_DEVICE;
+  const int32_t n_clear_wg = clear_table ? 64 : 0;
+  NVBX_LAUNCH(m, k_decay<true>, dim3((unsigned)std::min<int64_t>(std::min<int64_t>(m->capacity, 4096), std::max<int64_t>(512, (hw_seen + 7) / 8)) + (unsigned)n_clear_wg), dim3(512), m->d,
               log_odds(m->p.free_region_decay_probability), log_odds(m->p.occupied_region_decay_probability), 0u, 0u, (int32_t)m->mesh_list_live(),
               ea.bz_lo, ea.bz_hi, ea.bz_out, 0.0f, m->cleared_idx, (int32_t)(m->p.decay_deallocate_decayed_blocks ? 0 : 1), (int32_t)(m->p.occupancy_decay_to_free ? 1 : 0), 0.0f,
-              inline_rebuild ? static_cast<Entry*>(m->table_spare) : nullptr);
-  return inline_rebuild ? swap_tables(m) : rebuild_table(m);
+              next_table, clear_table, n_clear_wg);
+  return inline_rebuild ? rotate_tables(m) : rebuild_table(m);
 }
 
 extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
@@ -392,13 +412,15 @@ extern "C" int nvbx_decay_tsdf(nvbx_mapper* m, int32_t exclude_last_view) {
   if (m->p.esdf_mode == 1) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; ea.bz_out = INT32_MIN; }      // 3-D ESDF: every block is its own column
   else if (ea.plane_on) { ea.bz_lo = INT32_MIN + 1; ea.bz_hi = INT32_MAX; }      // ground-plane mode: the band's blocks vary with (x, y) -- a deallocated block of ANY height has its column re-marked
   const bool inline_rebuild = NVBX_DECAY_INLINE_REBUILD != 0;
-  if (inline_rebuild && ensure_spare_table(m)) return NVBX_E_DEVICE;
-  NVBX_LAUNCH(m, k_decay<false>, dim3(grid), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
+  Entry* next_table = nullptr; Entry* clear_table = nullptr;
+  if (inline_rebuild && prepare_tables(m, &next_table, &clear_table)) return NVBX_E_DEVICE;
+  const int32_t n_clear_wg = clear_table ? 64 : 0;
+  NVBX_LAUNCH(m, k_decay<false>, dim3((unsigned)(grid + n_clear_wg)), dim3(512), m->d, m->p.tsdf_decay_factor, m->p.tsdf_decayed_weight_threshold,
                      exclude_last_view ? m->last_camera_view_frame : 0u, m->last_camera_view_mask, m->mesh_list_live(), ea.bz_lo, ea.bz_hi, ea.bz_out,
                      m->p.truncation_distance_vox * m->p.voxel_size, m->cleared_idx, (int32_t)(m->p.decay_deallocate_decayed_blocks ? 0 : 1),
                      (int32_t)(m->p.tsdf_set_free_distance_on_decayed ? 1 : 0), m->p.tsdf_decayed_free_distance_vox * m->p.voxel_size,
-                     inline_rebuild ? static_cast<Entry*>(m->table_spare) : nullptr);
-  return inline_rebuild ? swap_tables(m) : rebuild_table(m);
+                     next_table, clear_table, n_clear_wg);
+  return inline_rebuild ? rotate_tables(m) : rebuild_table(m);
 }
 
 extern "C" int nvbx_clear_outside_radius(nvbx_mapper* m, const float center[3], float radius) {

@@ -396,7 +396,7 @@ extern "C" int nvbx_mapper_destroy(nvbx_mapper* m) {
   DMap& d = m->d;
   void* ptrs[] = {d.table, d.free_stack, d.counters, d.slot_flags, d.slot_index, d.slot_entry, d.slot_stamp, d.slot_consumed, d.slot_cam, d.tsdf, d.color, d.esdf,
                   m->view_list, d.lists, d.shc, m->export_idx, m->export_count, m->cleared_idx, d.site_bits, d.obs_bits, d.inside_bits,
-                  m->table_spare, m->synth, m->view_class, m->view_grid_fine, m->color_cand, m->depth_pre, m->mask_zmin, m->apply_postab, m->esdf3_scratch, m->cc_scratch, m->dyn_scratch, d.freespace, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
+                  m->table_spare, m->table_dirty, m->synth, m->view_class, m->view_grid_fine, m->color_cand, m->depth_pre, m->mask_zmin, m->apply_postab, m->esdf3_scratch, m->cc_scratch, m->dyn_scratch, d.freespace, m->lidar_tab, m->mesh_vert, m->mesh_nrm, m->mesh_col, m->mesh_tri, m->mesh_rec, m->staging};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   // (both streams are idle: whatever read a held-back colour frame has finished)
   (void)m->take_pending(); m->release_consumed_frames();

@@ -206,7 +206,7 @@ struct nvbx_mapper {
   // fused launch (FrameSetC<Pix, 1>: rgb8 / bgra8 share one layout; FrameSetC<PixRgb8, MAX_BATCH> for a held-back batch)
   void pending_marking_args(int32_t* mark_wg, nvbx::EsdfArgs* ea_out, bool single_frame);
   int pending_color_fused_args(void* fsc_out, int* kind, int32_t* srows, int32_t* scols);
-  void* table_spare = nullptr; uint32_t table_spare_mask = 0;       // the all-empty second hash table k_decay builds the next table in (maintenance.hip, round 6)
+  void* table_spare = nullptr; void* table_dirty = nullptr; uint32_t table_mask_extra = 0xFFFFFFFFu;       // decay's rotating hash tables: the all-empty one k_decay builds the next table in, and the one it empties for the call after (maintenance.hip, round 6)
   uint8_t* view_class = nullptr; int64_t view_class_cap = 0;        // LiDAR: per view record, 1 = updated by the beam-centric launch (tsdf.hip k_lidar_sparse)
   // LiDAR view calculation over a dense grid (tsdf.hip k_mark_view_grid): one byte per block of the box around the sensor (cell-major, 64 B per
   // 4 x 4 x 4 cell) + one byte per cell; all-zero between scans (k_scan_view_grid puts back what the scan set).  `view_grid_dirty`: a scan's
